@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Transcribes the reference's own table tests for the predicate hot path into tests/golden/*.json.
+
+The reference is Go and cannot be executed in this image (no Go toolchain, k8s.io modules not vendored), so
+these fixtures are a hand transcription of the *data* in the reference's tests — pod spec, node, enabled plugin
+set, phase, expected result — each entry citing the `file:line` it was read from (paths relative to
+/root/reference). Run `python tests/golden/make_golden.py` to regenerate the JSON files next to this script.
+
+Every pod / node is written in Kubernetes JSON field names (what `json.Marshal(&v1.Pod{...})` would emit for the
+fields the path reads), which is also the snapshot format the oracle and the host library parse.
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PM = "pkg/plugin/predicates/predicate_manager_test.go"
+RT = "pkg/common/resource_test.go"
+
+
+def affinity(terms):
+    return {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": terms}}}
+
+
+def expr(key, op, values=None):
+    r = {"key": key, "operator": op}
+    if values is not None:
+        r["values"] = values
+    return r
+
+
+def pod(spec=None, **meta):
+    p = {"metadata": meta or {}}
+    if spec is not None:
+        p["spec"] = spec
+    return p
+
+
+def node(name="", labels=None, alloc=None, pods=None, unschedulable=False, taints=None):
+    n = {"metadata": {"name": name}}
+    if labels is not None:
+        n["metadata"]["labels"] = labels
+    if alloc is not None:
+        n["status"] = {"allocatable": alloc}
+    spec = {}
+    if unschedulable:
+        spec["unschedulable"] = True
+    if taints:
+        spec["taints"] = taints
+    if spec:
+        n["spec"] = spec
+    if pods:
+        n["pods"] = pods
+    return n
+
+
+def resource_pod(milli_cpu=0, memory=0, **meta):
+    """newResourcePod (predicate_manager_test.go:1032-1060): one container, only the non-zero requests."""
+    req = {}
+    if milli_cpu > 0:
+        req["cpu"] = f"{milli_cpu}m"
+    if memory > 0:
+        req["memory"] = str(memory)
+    return pod({"containers": [{"resources": {"requests": req}}]}, **meta)
+
+
+def make_resources(milli_cpu, memory, pods):
+    """makeResources (predicate_manager_test.go:1062-1071) with the zero extended/storage/hugepage entries."""
+    return {"cpu": f"{milli_cpu}m", "memory": str(memory), "pods": str(pods), "example.com/aaa": "0",
+            "ephemeral-storage": "0", "hugepages-2Mi": "0"}
+
+
+MATCH_NAME_NODE1 = expr("metadata.name", "In", ["node_1"])
+
+# ---------------------------------------------------------------------------------------------------------
+# TestPodFitsSelector — predicate_manager_test.go:338-1030; plugins NodePorts + NodeAffinity (:339); allocate
+# phase (:1024); node = {name: nodeName, labels} with no allocatable (:1017-1022).
+# ---------------------------------------------------------------------------------------------------------
+SELECTOR = [
+    (351, "no selector", pod(), None, "", True),
+    (356, "missing labels", pod({"nodeSelector": {"foo": "bar"}}), None, "", False),
+    (367, "same labels", pod({"nodeSelector": {"foo": "bar"}}), {"foo": "bar"}, "", True),
+    (381, "node labels are superset", pod({"nodeSelector": {"foo": "bar"}}), {"foo": "bar", "baz": "blah"}, "", True),
+    (396, "node labels are subset", pod({"nodeSelector": {"foo": "bar", "baz": "blah"}}), {"foo": "bar"}, "", False),
+    (411, "matchExpressions In matches", pod({"affinity": affinity([{"matchExpressions": [expr("foo", "In", ["bar", "value2"])]}])}),
+     {"foo": "bar"}, "", True),
+    (439, "matchExpressions Gt matches", pod({"affinity": affinity([{"matchExpressions": [expr("kernel-version", "Gt", ["0204"])]}])}),
+     {"kernel-version": "0206"}, "", True),
+    (468, "matchExpressions NotIn matches", pod({"affinity": affinity([{"matchExpressions": [expr("mem-type", "NotIn", ["DDR", "DDR2"])]}])}),
+     {"mem-type": "DDR3"}, "", True),
+    (496, "matchExpressions Exists matches", pod({"affinity": affinity([{"matchExpressions": [expr("GPU", "Exists")]}])}),
+     {"GPU": "NVIDIA-GRID-K1"}, "", True),
+    (523, "affinity that doesn't match node's labels", pod({"affinity": affinity([{"matchExpressions": [expr("foo", "In", ["value1", "value2"])]}])}),
+     {"foo": "bar"}, "", False),
+    (551, "nil []NodeSelectorTerm", pod({"affinity": affinity(None)}), {"foo": "bar"}, "", False),
+    (569, "empty []NodeSelectorTerm", pod({"affinity": affinity([])}), {"foo": "bar"}, "", False),
+    (587, "empty MatchExpressions", pod({"affinity": affinity([{"matchExpressions": []}])}), {"foo": "bar"}, "", False),
+    (609, "no Affinity", pod(), {"foo": "bar"}, "", True),
+    (617, "Affinity but nil NodeSelector",
+     pod({"affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": None}}}), {"foo": "bar"}, "", True),
+    (633, "multiple matchExpressions ANDed, match",
+     pod({"affinity": affinity([{"matchExpressions": [expr("GPU", "Exists"), expr("GPU", "NotIn", ["AMD", "INTER"])]}])}),
+     {"GPU": "NVIDIA-GRID-K1"}, "", True),
+    (664, "multiple matchExpressions ANDed, no match",
+     pod({"affinity": affinity([{"matchExpressions": [expr("GPU", "Exists"), expr("GPU", "In", ["AMD", "INTER"])]}])}),
+     {"GPU": "NVIDIA-GRID-K1"}, "", False),
+    (695, "multiple NodeSelectorTerms ORed",
+     pod({"affinity": affinity([{"matchExpressions": [expr("foo", "In", ["bar", "value2"])]},
+                                {"matchExpressions": [expr("diffkey", "In", ["wrong", "value2"])]}])}),
+     {"foo": "bar"}, "", True),
+    (732, "Affinity and nodeSelector both satisfied",
+     pod({"nodeSelector": {"foo": "bar"}, "affinity": affinity([{"matchExpressions": [expr("foo", "Exists")]}])}),
+     {"foo": "bar"}, "", True),
+    (763, "Affinity matches but nodeSelector does not",
+     pod({"nodeSelector": {"foo": "bar"}, "affinity": affinity([{"matchExpressions": [expr("foo", "Exists")]}])}),
+     {"foo": "barrrrrr"}, "", False),
+    (794, "invalid value in Affinity term",
+     pod({"affinity": affinity([{"matchExpressions": [expr("foo", "NotIn", ["invalid value: ___@#$%^"])]}])}),
+     {"foo": "bar"}, "", False),
+    (822, "matchFields In matches", pod({"affinity": affinity([{"matchFields": [MATCH_NAME_NODE1]}])}), None, "node_1", True),
+    (848, "matchFields In does not match", pod({"affinity": affinity([{"matchFields": [MATCH_NAME_NODE1]}])}), None, "node_2", False),
+    (874, "two terms: matchFields miss, matchExpressions hit",
+     pod({"affinity": affinity([{"matchFields": [MATCH_NAME_NODE1]}, {"matchExpressions": [expr("foo", "In", ["bar"])]}])}),
+     {"foo": "bar"}, "node_2", True),
+    (910, "one term: matchFields miss AND matchExpressions hit",
+     pod({"affinity": affinity([{"matchFields": [MATCH_NAME_NODE1], "matchExpressions": [expr("foo", "In", ["bar"])]}])}),
+     {"foo": "bar"}, "node_2", False),
+    (944, "one term: both match",
+     pod({"affinity": affinity([{"matchFields": [MATCH_NAME_NODE1], "matchExpressions": [expr("foo", "In", ["bar"])]}])}),
+     {"foo": "bar"}, "node_1", True),
+    (978, "two terms: both miss",
+     pod({"affinity": affinity([{"matchFields": [MATCH_NAME_NODE1]}, {"matchExpressions": [expr("foo", "In", ["not-match-to-bar"])]}])}),
+     {"foo": "bar"}, "node_2", False),
+]
+
+
+def predicate_cases():
+    cases = []
+    for line, name, p, labels, node_name, fits in SELECTOR:
+        cases.append({"test": "TestPodFitsSelector", "name": name, "source": f"{PM}:{line}",
+                      "plugins": ["NodePorts", "NodeAffinity"], "allocate": True,
+                      "pod": p, "node": node(node_name, labels), "fits": fits})
+
+    # TestPodFitsHost — :141-197, plugin NodeName (:142), allocate (:191)
+    for line, name, p, n, fits in [
+        (151, "no host specified", pod(), node(""), True),
+        (157, "host matches", pod({"nodeName": "foo"}), node("foo"), True),
+        (171, "host doesn't match", pod({"nodeName": "bar"}), node("foo"), False),
+    ]:
+        cases.append({"test": "TestPodFitsHost", "name": name, "source": f"{PM}:{line}", "plugins": ["NodeName"],
+                      "allocate": True, "pod": p, "node": n, "fits": fits})
+
+    # TestRunGeneralPredicates — :1095-1168, plugins NodeResourcesFit, NodeName, NodePorts, NodeVolumeLimits (:1096).
+    # The fourth case (:1147-1157, host-port conflict) exercises NodePorts, which is outside this path.
+    alloc = make_resources(10, 20, 32)
+    for line, name, p, existing, fits in [
+        (1108, "no resources/port/host requested always fits", pod(), [resource_pod(9, 19)], True),
+        (1120, "not enough cpu and memory resource", resource_pod(8, 10), [resource_pod(5, 19)], False),
+        (1132, "host not match", pod({"nodeName": "machine2"}), [], False),
+    ]:
+        cases.append({"test": "TestRunGeneralPredicates", "name": name, "source": f"{PM}:{line}",
+                      "plugins": ["NodeResourcesFit", "NodeName", "NodePorts"], "allocate": True,
+                      "pod": p, "node": node("machine1", alloc=alloc, pods=existing), "fits": fits})
+
+    # TestReserveAlloc — :2115-2154, reservation phase (allocate=false), pod{nodeName: foo} on node foo that
+    # already lists the pod (NewNodeInfo(pod) :2126).
+    ra_pod = pod({"nodeName": "foo"}, uid="reserve-alloc")
+    cases.append({"test": "TestReserveAlloc", "name": "no predicates configured", "source": f"{PM}:2129",
+                  "plugins": [], "allocate": False, "pod": ra_pod, "node": node("foo", pods=[ra_pod]), "fits": True})
+    cases.append({"test": "TestReserveAlloc", "name": "node is schedulable", "source": f"{PM}:2136",
+                  "plugins": ["NodeUnschedulable"], "allocate": False, "pod": ra_pod, "node": node("foo", pods=[ra_pod]),
+                  "fits": True})
+    cases.append({"test": "TestReserveAlloc", "name": "node cordoned + unschedulable taint", "source": f"{PM}:2142",
+                  "plugins": ["NodeUnschedulable"], "allocate": False, "pod": ra_pod,
+                  "node": node("foo", pods=[ra_pod], unschedulable=True,
+                               taints=[{"key": "node.kubernetes.io/unschedulable", "effect": "NoSchedule"}]),
+                  "fits": False})
+
+    # TestReserveNodeSelector — :2156-2199, reservation phase, plugins NodeName, NodePorts, PodTopologySpread,
+    # NodeAffinity (:2171); node "node" holds the pod (:2168).
+    for line, name, labels, selector, err in [
+        (2181, "Match labels", {"foo": "bar"}, {"foo": "bar"}, False),
+        (2182, "Missing labels", {"foo": "bar"}, {"foo2": "bar2"}, True),
+        (2183, "empty node labels", {}, {"foo2": "bar2"}, True),
+        (2184, "empty node selectors", {"foo": "bar"}, {}, False),
+    ]:
+        p = pod({"nodeSelector": selector}, uid="reserve-selector")
+        cases.append({"test": "TestReserveNodeSelector", "name": name, "source": f"{PM}:{line}",
+                      "plugins": ["NodeName", "NodePorts", "PodTopologySpread", "NodeAffinity"], "allocate": False,
+                      "pod": p, "node": node("node", labels, pods=[pod({}, uid="reserve-selector")]), "fits": not err})
+    return cases
+
+
+def preemption_cases():
+    """TestPreemptionPredicates :71-117 and TestPreemptionPredicatesEmpty :58-69; plugin NodeResourcesFit."""
+    victims = [resource_pod(100, 1000000, name="pod0", uid="pod0"), resource_pod(100, 1000000, name="pod1", uid="pod1"),
+               resource_pod(300, 3000000, name="pod2", uid="pod2"), resource_pod(500, 5000000, name="pod3", uid="pod3")]
+    n0 = node("node0", alloc=make_resources(1000, 100000000, 10), pods=victims)
+    return [
+        {"test": "TestPreemptionPredicatesEmpty", "source": f"{PM}:58", "plugins": ["NodeResourcesFit"],
+         "pod": pod(), "node": node(""), "victims": [], "start_index": 0, "index": -1},
+        {"test": "TestPreemptionPredicates", "name": "smallpod", "source": f"{PM}:107", "plugins": ["NodeResourcesFit"],
+         "pod": resource_pod(500, 5000000, name="smallpod", uid="smallpod"), "node": n0, "victims": [0, 1, 2, 3],
+         "start_index": 1, "index": 2},
+        {"test": "TestPreemptionPredicates", "name": "largepod", "source": f"{PM}:115", "plugins": ["NodeResourcesFit"],
+         "pod": resource_pod(1500, 15000000, name="largepod", uid="largepod"), "node": n0, "victims": [0, 1, 2, 3],
+         "start_index": 1, "index": -1},
+    ]
+
+
+def container(name, requests, restart=None):
+    c = {"name": name, "resources": {"requests": requests}}
+    if restart:
+        c["restartPolicy"] = restart
+    return c
+
+
+def request_cases():
+    """Request-vector known answers from pkg/common/resource_test.go. The expected maps drop YuniKorn's own
+    "pods": 1 entry (resource.go:58), i.e. they are what the test asserts for upstream PodRequests too
+    (resource_test.go:201-202 etc.)."""
+    gpu = "nvidia.com/gpu"
+    c1 = container("container-01", {"memory": "500M", "cpu": "1", gpu: "1"})
+    c2 = container("container-02", {"memory": "1024M", "cpu": "2", gpu: "4"})
+    overhead = {"memory": "500M", "cpu": "1", gpu: "1"}
+    ic1 = container("initcontainer-01", {"memory": "4096M", "cpu": "0.5", gpu: "1"})
+    ic2 = container("initcontainer-02", {"memory": "10000M", "cpu": "5.12", gpu: "4"})
+    c1b = container("container-01", {"memory": "2000M", "cpu": "4.096", gpu: "2"})
+    c2b = container("container-02", {"memory": "5000M", "cpu": "1.024", gpu: "2"})
+    c1c = container("container-01", {"memory": "2000M", "cpu": "4.096"})
+    c2c = container("container-02", {"memory": "5000M", "cpu": "1.024"})
+    small = {"memory": "10M", "cpu": "1"}
+    M = 1000 * 1000
+    return [
+        {"name": "two containers", "source": f"{RT}:197-200", "pod": pod({"containers": [c1, c2]}),
+         "expect": {"cpu": 3000, "memory": 1524 * M, gpu: 5}},
+        {"name": "two containers + overhead", "source": f"{RT}:214-217",
+         "pod": pod({"containers": [c1, c2], "overhead": overhead}), "expect": {"cpu": 4000, "memory": 2024 * M, gpu: 6}},
+        {"name": "init containers vs containers", "source": f"{RT}:266-269",
+         "pod": pod({"containers": [c1b, c2b], "initContainers": [ic1, ic2]}),
+         "expect": {"cpu": 5120, "memory": 10000 * M, gpu: 4}},
+        {"name": "init container without cpu/gpu", "source": f"{RT}:287-290",
+         "pod": pod({"containers": [c1c, c2c],
+                     "initContainers": [ic1, container("initcontainer-02", {"memory": "10000M"})]}),
+         "expect": {"cpu": 5120, "memory": 10000 * M, gpu: 1}},
+        {"name": "single sidecar", "source": f"{RT}:314-316",
+         "pod": pod({"containers": [c1c, c2c], "initContainers": [container("container-04", small, "Always")]}),
+         "expect": {"cpu": 6120, "memory": 7010 * M}},
+        {"name": "two sidecars + init container", "source": f"{RT}:357-359",
+         "pod": pod({"containers": [c1c, c2c],
+                     "initContainers": [container("container-05", small, "Always"), container("container-06", small, "Always"),
+                                        container("container-07", {"memory": "4096M", "cpu": "10"})]}),
+         "expect": {"cpu": 12000, "memory": 7020 * M}},
+        {"name": "sidecar then init container (memory only)", "source": f"{RT}:424",
+         "pod": pod({"containers": [container("container-main", {"memory": "512M"})],
+                     "initContainers": [container("container-ic1", {"memory": "1024M"}, "Always"),
+                                        container("container-ic2", {"memory": "256M"})]}),
+         "expect": {"memory": 1536 * M}},
+        {"name": "init container then sidecar", "source": f"{RT}:468-469",
+         "pod": pod({"containers": [container("container-main", {"memory": "512M", "cpu": "1"})],
+                     "initContainers": [container("container-ic1", {"memory": "1024M", "cpu": "1", gpu: "1"}),
+                                        container("container-ic2", {"memory": "1024M", "cpu": "1"}, "Always")]}),
+         "expect": {"cpu": 2000, "memory": 1536 * M, gpu: 1}},
+        {"name": "sidecar, init, sidecar + two containers", "source": f"{RT}:539-541",
+         "pod": pod({"containers": [container("container-main1", {"memory": "512M", "cpu": "1"}),
+                                    container("container-main2", {"memory": "512M", "cpu": "1"})],
+                     "initContainers": [container("container-ic1", {"memory": "1024M", "cpu": "1"}, "Always"),
+                                        container("container-ic2", {"memory": "4096M", "cpu": "1", gpu: "1"}),
+                                        container("container-ic3", {"memory": "512", "cpu": "100m"}, "Always")]}),
+         "expect": {"cpu": 3100, "memory": 5120 * M, gpu: 1}},
+        {"name": "pod-level requests override cpu/memory only", "source": f"{RT}:614-620",
+         "pod": pod({"containers": [c1, c2], "resources": {"requests": {"memory": "128M", "cpu": "5", "invalid": "1"}}}),
+         "expect": {"cpu": 5000, "memory": 128 * M, gpu: 5}},
+    ]
+
+
+QUANTITIES = [
+    # (text, Value(), MilliValue()) — resource.Quantity semantics used by resource.go:273-285
+    ("1", 1, 1000), ("2", 2, 2000), ("0.5", 1, 500), ("5.12", 6, 5120), ("500M", 500000000, 500000000000),
+    ("1024M", 1024000000, 1024000000000), ("4096M", 4096000000, 4096000000000), ("100m", 1, 100), ("10m", 1, 10),
+    ("1Gi", 1073741824, 1073741824000), ("256Gi", 274877906944, 274877906944000), ("128Mi", 134217728, 134217728000),
+    ("1Ki", 1024, 1024000), ("1k", 1000, 1000000), ("1e3", 1000, 1000000), ("1E3", 1000, 1000000), ("1E", 10**18, 9223372036854775807),
+    ("1.5Gi", 1610612736, 1610612736000), ("0", 0, 0), ("32", 32, 32000), ("110", 110, 110000), ("1u", 1, 1), ("1n", 1, 1),
+    ("1500u", 1, 2), ("0.0001", 1, 1), ("12e-1", 2, 1200),
+]
+
+
+def main():
+    with open(os.path.join(HERE, "predicate_cases.json"), "w") as f:
+        json.dump(predicate_cases(), f, indent=1)
+    with open(os.path.join(HERE, "preemption_cases.json"), "w") as f:
+        json.dump(preemption_cases(), f, indent=1)
+    req = request_cases()
+    with open(os.path.join(HERE, "request_cases.json"), "w") as f:
+        json.dump(req, f, indent=1)
+    with open(os.path.join(HERE, "quantity_cases.json"), "w") as f:
+        json.dump([{"text": t, "value": v, "milli": m} for t, v, m in QUANTITIES], f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
