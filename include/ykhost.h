@@ -1,0 +1,98 @@
+/*
+ * ykhost.h — C API of libykhost.so: the host-side mirror of the reference's predicate interface.
+ *
+ * In the real system this layer is Go: a `gpuPredicateManager` in pkg/plugin/predicates that keeps an encoded
+ * mirror of pkg/cache/external.SchedulerCache and talks to libykpred.so through cgo. Go is not
+ * available in this image, so the same layer is written in C++ above the SAME C ABI (include/ykpred.h) and
+ * exposed here so that tests and bench.py can drive it with Kubernetes-JSON objects. Names follow the reference:
+ *
+ *   ykhost_predicates            PredicateManager.Predicates(pod, node, allocate) (string, error)
+ *                                /root/reference/pkg/plugin/predicates/predicate_manager.go:134-139
+ *   ykhost_preemption_predicates PredicateManager.PreemptionPredicates(pod, node, victims, startIndex) int   (:141-179)
+ *   ykhost_set_plugins           newPredicateManagerInternal(handle, resPre, allocPre, resFilt, allocFilt) (:378-424)
+ *   ykhost_update_node / ykhost_remove_node / ykhost_update_pod / ykhost_remove_pod / ykhost_assume_pod /
+ *   ykhost_forget_pod            SchedulerCache.UpdateNode / RemoveNode / UpdatePod / RemovePod / AssumePod / ForgetPod
+ *                                /root/reference/pkg/cache/external/scheduler_cache.go:148-239,303-484
+ *   ykhost_evaluate              the batched form of the core's loop over (ask, node) → Predicates()
+ *
+ * All functions return 0 on success, negative on error (text via ykhost_last_error).
+ */
+#ifndef YKHOST_H_
+#define YKHOST_H_
+#include <stdint.h>
+
+#include "ykpred.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ykhost ykhost_t;
+
+ykhost_t* ykhost_create(int32_t device, char* err, int32_t errlen); /* NULL on failure (no GPU ⇒ failure) */
+void ykhost_destroy(ykhost_t* h);
+const char* ykhost_last_error(const ykhost_t* h);
+
+/* plugin lists of the four phases; defaults = NewPredicateManager (predicate_manager.go:321-373) */
+int32_t ykhost_set_plugins(ykhost_t* h, uint32_t reservation_prefilters, uint32_t allocation_prefilters,
+                           uint32_t reservation_filters, uint32_t allocation_filters);
+
+/* --- cluster state (SchedulerCache mirror). JSON uses Kubernetes field names; see INTEGRATION.md. */
+int32_t ykhost_load_snapshot(ykhost_t* h, const char* json); /* {"nodes":[{..., "pods":[...]}], "pods":[pending asks]} — replaces all state */
+int32_t ykhost_update_node(ykhost_t* h, const char* node_json);
+int32_t ykhost_remove_node(ykhost_t* h, const char* node_name);
+int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json); /* spec.nodeName set ⇒ assigned to that node, else a pending ask */
+int32_t ykhost_remove_pod(ykhost_t* h, const char* uid);
+int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name);
+int32_t ykhost_forget_pod(ykhost_t* h, const char* uid);
+
+/* synthetic KWOK-style cluster, replaces all state */
+typedef struct ykhost_kwok {
+  uint64_t seed;
+  int32_t num_nodes;
+  int32_t num_pods;
+  int32_t num_templates;   /* distinct pod templates ("deployments"); 0 = every pod draws its own */
+  int32_t node_affinity;   /* 0 = pods carry no nodeSelector/affinity (configs 1-2), 1 = config-3 mix */
+  int32_t tolerations;     /* 0 = no tolerations and no node taints (config 1), 1 = KWOK taints + tolerations */
+  int32_t unique_requests; /* 1 = adversarial: every pod a distinct cpu request (no signature sharing) */
+  int32_t gang_size;       /* >0: pods are gang placeholders, `gang_size` identical members per task group */
+  int32_t node_index_offset; /* node-sharded clusters: this shard holds global nodes [offset, offset+num_nodes); node draws
+                                are seeded per global index range, pod draws depend on `seed` only (identical on all shards) */
+  int32_t reserved[4];
+} ykhost_kwok_t;
+int32_t ykhost_generate_kwok(ykhost_t* h, const ykhost_kwok_t* cfg);
+
+int32_t ykhost_num_nodes(const ykhost_t* h);
+int32_t ykhost_num_pods(const ykhost_t* h); /* pending asks */
+int32_t ykhost_pod_index(const ykhost_t* h, const char* uid);       /* index among pending asks, -1 = unknown */
+int32_t ykhost_node_index(const ykhost_t* h, const char* node_name); /* -1 = unknown */
+
+/* Serialises pending pods `pods[0..np)` (NULL = all) and nodes `nodes[0..nn)` (NULL = all, with their assigned pods)
+ * as a snapshot document. Returns the required length (incl. NUL); writes at most `len` bytes. */
+int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len);
+
+/* encode + upload whatever changed since the last sync (called implicitly by the functions below) */
+int32_t ykhost_sync(ykhost_t* h);
+ykpred_engine_t* ykhost_engine(ykhost_t* h); /* the underlying engine, for layout / readback / timing calls */
+
+/* batched evaluation of every pending ask against every node: phase selects the plugin lists */
+int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options /* YKPRED_OUT_* | YKPRED_EVAL_* */);
+
+/* PredicateManager.Predicates for pending pod #pod on node #node. Returns 1 = fits ("", nil), 0 = error returned.
+ * plugin receives the failing plugin name ("" when a PreFilter plugin rejected the pod), msg the status message. */
+int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t allocate, char* plugin, int32_t plugin_len, char* msg,
+                          int32_t msg_len);
+/* victims: UIDs of pods assigned to the node (NULL / unknown UID = nil victim). Returns the index or -1. */
+int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t num_victims,
+                                     int32_t start_index);
+
+/* request vector of pending pod #pod as JSON {"cpu": milli, "memory": bytes, ...} */
+int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len);
+
+/* encoder statistics: out[0]=R, [1]=KT, [2]=W, [3]=#taints, [4]=#requirements, [5]=#templates, [6]=#specs, [7]=last encode µs */
+int32_t ykhost_stats(const ykhost_t* h, int64_t* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YKHOST_H_ */

@@ -1,0 +1,234 @@
+/*
+ * ykpred.h — C ABI of libykpred.so, the MI355X (gfx950) batched predicate engine.
+ *
+ * This is the drop-in boundary for the yunikorn-k8shim predicate hot path. A Go
+ * `gpuPredicateManager` implementing the reference's
+ *     type PredicateManager interface { EventsToRegister; Predicates; PreemptionPredicates }
+ *     (/root/reference/pkg/plugin/predicates/predicate_manager.go:47-55)
+ * binds these entry points through cgo (binding sketch: INTEGRATION.md) and is installed at the one
+ * construction site /root/reference/pkg/cache/context.go:130; pkg/shim and the scheduler-interface
+ * callback (/root/reference/pkg/cache/scheduler_callback.go:203-216) stay untouched.
+ *
+ * Conventions
+ *   - plain C types, caller-owned flat arrays (structure-of-arrays), copied during the call: the library
+ *     never retains a caller pointer (cgo rule: no Go pointers kept after return);
+ *   - every function returns YKPRED_OK (0) or a negative YKPRED_E_* code; ykpred_last_error() gives text;
+ *   - no CPU fallback exists in this library: if the HIP device is missing, create() fails;
+ *   - evals may run concurrently with queries only if the caller serialises them against uploads — the same
+ *     contract the reference gets from Context.lock / SchedulerCache.lock (context.go:697,709).
+ *
+ * What replaces what
+ *   ykpred_set_nodes / ykpred_update_node   the per-call reads of framework.NodeInfo{Allocatable, Requested,
+ *                                           Pods, Node().Spec/Labels} (scheduler_cache.go:84-145, a14 in SURVEY §8a)
+ *   ykpred_set_specs / ykpred_set_pods      the pod side of every Predicates(pod, ...) call: the request vector of
+ *                                           pkg/common/resource.go:56-109 and the toleration / node-selector ASTs,
+ *                                           pre-encoded once per pod update instead of once per (pod,node) pair
+ *   ykpred_eval                             the P×N loop of Predicates() calls: runPreFilterPlugins +
+ *                                           runFilterPlugins (predicate_manager.go:221-283) for every pending
+ *                                           ask against every node of one snapshot
+ *   ykpred_query                            one Predicates() result: fit + first failing plugin (:206-219)
+ *   ykpred_preemption                       PreemptionPredicates (:141-179)
+ */
+#ifndef YKPRED_H_
+#define YKPRED_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YKPRED_ABI_VERSION 1
+
+/* status codes */
+#define YKPRED_OK 0
+#define YKPRED_E_INVALID (-1)   /* bad argument / inconsistent sizes */
+#define YKPRED_E_DEVICE (-2)    /* HIP runtime error (message in ykpred_last_error) */
+#define YKPRED_E_NOMEM (-3)     /* device or host allocation failed */
+#define YKPRED_E_STATE (-4)     /* call sequence error (e.g. eval before nodes/specs/pods were uploaded) */
+#define YKPRED_E_UNSUPPORTED (-5)
+
+/* Plugin bits. Bit order = Filter order of predicate_manager.go:339-352. */
+#define YKPRED_PLUGIN_NODE_UNSCHEDULABLE (1u << 0)
+#define YKPRED_PLUGIN_NODE_NAME (1u << 1)
+#define YKPRED_PLUGIN_TAINT_TOLERATION (1u << 2)
+#define YKPRED_PLUGIN_NODE_AFFINITY (1u << 3)
+#define YKPRED_PLUGIN_NODE_PORTS (1u << 4) /* reserved: not evaluated by the engine */
+#define YKPRED_PLUGIN_NODE_RESOURCES_FIT (1u << 5)
+#define YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD (1u << 6)
+#define YKPRED_PLUGIN_ALL 0x7fu
+
+/* "failing plugin" codes returned by ykpred_query (0 = "" — a PreFilter plugin rejected the pod, :236-238) */
+#define YKPRED_CODE_NONE 0
+#define YKPRED_CODE_NODE_UNSCHEDULABLE 1
+#define YKPRED_CODE_NODE_NAME 2
+#define YKPRED_CODE_TAINT_TOLERATION 3
+#define YKPRED_CODE_NODE_AFFINITY 4
+#define YKPRED_CODE_NODE_PORTS 5
+#define YKPRED_CODE_NODE_RESOURCES_FIT 6
+#define YKPRED_CODE_POD_TOPOLOGY_SPREAD 7
+
+/* reason bits returned by ykpred_query next to the plugin code (the host composes the status message) */
+#define YKPRED_REASON_TOO_MANY_PODS (1u << 0)
+#define YKPRED_REASON_PREFILTER_NODE_NOT_ELIGIBLE (1u << 1)
+#define YKPRED_REASON_PREFILTER_REJECTED (1u << 2)
+#define YKPRED_REASON_MISSING_TOPOLOGY_LABEL (1u << 3)
+#define YKPRED_REASON_RESOURCE_SHIFT 8 /* bit (8+r) set: insufficient resource dimension r */
+
+/* node flags */
+#define YKPRED_NODE_UNSCHEDULABLE (1u << 0)
+
+/* spec flags */
+#define YKPRED_SPEC_TOLERATES_UNSCHEDULABLE (1u << 0) /* tolerates node.kubernetes.io/unschedulable:NoSchedule */
+#define YKPRED_SPEC_AFFINITY_SKIP (1u << 1)           /* NodeAffinity.PreFilter returns Skip (no selector, no required affinity) */
+#define YKPRED_SPEC_PREFILTER_REJECT (1u << 2)        /* NodeAffinity.PreFilter: conflicting metadata.name terms */
+#define YKPRED_SPEC_PREFILTER_NAMES (1u << 3)         /* NodeAffinity.PreFilter returned a NodeNames set (pre_terms) */
+
+/* special values for pods.node_name_index */
+#define YKPRED_NO_NODE_NAME (-1)      /* pod.Spec.NodeName == "" */
+#define YKPRED_UNKNOWN_NODE_NAME (-2) /* names a node that is not in the table: matches no node */
+
+typedef struct ykpred_engine ykpred_engine_t;
+
+typedef struct ykpred_config {
+  int32_t abi_version;      /* YKPRED_ABI_VERSION */
+  int32_t device;           /* HIP device ordinal */
+  int32_t num_resources;    /* R >= 3: 0 = cpu (milli), 1 = memory, 2 = ephemeral-storage, 3.. = scalar resources */
+  int32_t taint_words;      /* KT >= 1: 64-bit words of the taint dictionary */
+  int32_t label_words;      /* W  >= 1: 64-bit words of the node-selector requirement dictionary */
+  int32_t topology_keys;    /* KD >= 0: topology keys used by hard spread constraints */
+  int32_t selector_classes; /* KS >= 0: distinct (namespace, labelSelector) classes of spread constraints */
+  int32_t reserved[9];
+} ykpred_config_t;
+
+/* Node table, structure-of-arrays. Arrays documented [A][count] are A consecutive runs of `count` values. */
+typedef struct ykpred_nodes {
+  int32_t count;
+  const int64_t* allocatable;    /* [R][count]   NodeInfo.Allocatable */
+  const int64_t* requested;      /* [R][count]   NodeInfo.Requested (assumed pods included) */
+  const int32_t* allowed_pods;   /* [count]      Allocatable.AllowedPodNumber */
+  const int32_t* pod_count;      /* [count]      len(NodeInfo.Pods) */
+  const uint32_t* flags;         /* [count]      YKPRED_NODE_* */
+  const uint64_t* taint_bits;    /* [KT][count]  bit t: node carries dictionary taint t (NoSchedule/NoExecute only) */
+  const uint64_t* label_bits;    /* [W][count]   bit q: node satisfies dictionary requirement q */
+  const int32_t* domain_id;      /* [KD][count]  id of the node's value for topology key k, -1 = label missing */
+  const int32_t* selector_count; /* [KS][count]  # pods on the node matching selector class s */
+} ykpred_nodes_t;
+
+/* One hard (DoNotSchedule) topology spread constraint of a pod spec. */
+typedef struct ykpred_spread {
+  int32_t topology_key;   /* index into domain_id[KD] */
+  int32_t selector_class; /* index into selector_count[KS]; -1 = selector counts nothing (nil / empty selector) */
+  int32_t max_skew;
+  int32_t min_domains;    /* nil => 1 */
+  int32_t self_match;     /* 1 if the incoming pod's own labels match the selector */
+  uint32_t flags;         /* bit0: nodeAffinityPolicy == Honor, bit1: nodeTaintsPolicy == Honor */
+} ykpred_spread_t;
+#define YKPRED_SPREAD_HONOR_AFFINITY (1u << 0)
+#define YKPRED_SPREAD_HONOR_TAINTS (1u << 1)
+
+/* Pod specs (one per distinct pod template / task group; pods reference them by index). */
+typedef struct ykpred_specs {
+  int32_t count;
+  const int64_t* requests;       /* [count][R]  upstream PodRequests: cpu milli, others Value() */
+  const uint64_t* tolerated;     /* [count][KT] bit t: some toleration tolerates dictionary taint t */
+  const uint32_t* flags;         /* [count]     YKPRED_SPEC_* */
+  const int32_t* aff_term_off;   /* [count+1]   Filter DNF: spec s owns aff_terms rows [off[s], off[s+1]) */
+  const uint64_t* aff_terms;     /* [n][W]      a term matches a node iff (label_bits & term) == term;
+                                                no rows = matches no node; one all-zero row = matches every node */
+  const int32_t* pre_term_off;   /* [count+1]   PreFilter NodeNames set as DNF (only if YKPRED_SPEC_PREFILTER_NAMES) */
+  const uint64_t* pre_terms;     /* [m][W] */
+  const int32_t* spread_off;     /* [count+1]   may be NULL when no spec has hard spread constraints */
+  const ykpred_spread_t* spread; /* [k] */
+} ykpred_specs_t;
+
+typedef struct ykpred_pods {
+  int32_t count;
+  const int32_t* spec_index;      /* [count] */
+  const int32_t* node_name_index; /* [count] node index named by pod.Spec.NodeName, or YKPRED_NO_/UNKNOWN_NODE_NAME */
+} ykpred_pods_t;
+
+#define YKPRED_OUT_BITMAP (1u << 0)    /* P x N feasibility bitmap */
+#define YKPRED_OUT_COUNTS (1u << 1)    /* per-pod number of feasible nodes */
+#define YKPRED_OUT_DECISIONS (1u << 2) /* per-pod best feasible node under the bin-pack order (-1 = none) */
+#define YKPRED_OUT_DECISION_KEYS (1u << 3) /* per-pod order key of that node (int64; INT64_MAX = none): lets shards of a
+                                              node-sharded cluster pick the global best with one MIN all-reduce */
+#define YKPRED_EVAL_PROFILE (1u << 8)  /* bracket every kernel with HIP events (see ykpred_last_timing) */
+#define YKPRED_EVAL_DIRECT (1u << 9)   /* use the per-pair reference kernel instead of the plane/class path */
+
+typedef struct ykpred_eval_args {
+  uint32_t prefilter_plugins; /* enabled PreFilter plugins (YKPRED_PLUGIN_* bits) */
+  uint32_t filter_plugins;    /* enabled Filter plugins */
+  uint32_t options;           /* YKPRED_OUT_* | YKPRED_EVAL_* */
+  uint32_t reserved;
+  void* bitmap;               /* optional caller-owned DEVICE buffer of layout.bitmap_bytes; NULL = engine-owned */
+  void* stream;               /* hipStream_t to launch on; NULL = the engine's own stream */
+  void* counts;               /* optional caller-owned DEVICE int32[P]; NULL = engine-owned */
+  void* decisions;            /* optional caller-owned DEVICE int32[P]; NULL = engine-owned */
+  void* decision_keys;        /* optional caller-owned DEVICE int64[P]; NULL = engine-owned */
+} ykpred_eval_args_t;
+
+typedef struct ykpred_layout {
+  int32_t num_nodes;  /* N */
+  int32_t num_pods;   /* P */
+  int32_t num_specs;
+  int32_t num_classes;
+  int32_t row_words;   /* ceil(N/64): meaningful 64-bit words per bitmap row */
+  int32_t row_stride;  /* words between consecutive rows (>= row_words, multiple of 8; padding words are 0) */
+  int32_t num_chunks;
+  int32_t plane_rows;  /* total signature planes evaluated per eval */
+  uint64_t bitmap_bytes;
+  void* bitmap;        /* device pointer of the last evaluated bitmap: bit (n & 63) of word [p*row_stride + (n >> 6)] */
+  void* counts;        /* device int32[P] */
+  void* decisions;     /* device int32[P] */
+  void* decision_keys; /* device int64[P] */
+} ykpred_layout_t;
+
+#define YKPRED_MAX_TIMED_KERNELS 16
+typedef struct ykpred_timing {
+  int32_t num_kernels;
+  float total_ms;                         /* first launch to last completion, device time */
+  float kernel_ms[YKPRED_MAX_TIMED_KERNELS];
+  const char* kernel_name[YKPRED_MAX_TIMED_KERNELS];
+} ykpred_timing_t;
+
+/* lifecycle */
+int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out);
+void ykpred_destroy(ykpred_engine_t* e);
+const char* ykpred_last_error(const ykpred_engine_t* e); /* e may be NULL: error of the last failed create() */
+int32_t ykpred_abi_version(void);
+
+/* state upload (externally serialised against evals) */
+int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* nodes);
+int32_t ykpred_update_node(ykpred_engine_t* e, int32_t index, const ykpred_nodes_t* one_node); /* count must be 1 */
+int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* specs);
+int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* pods);
+
+/* evaluation of every pending pod against every node of the uploaded snapshot */
+int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* args);
+int32_t ykpred_synchronize(ykpred_engine_t* e);
+int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* out);
+int32_t ykpred_last_timing(const ykpred_engine_t* e, ykpred_timing_t* out);
+
+/* readback (device -> caller host buffers); each implies a synchronize */
+int32_t ykpred_read_bitmap(ykpred_engine_t* e, int32_t first_pod, int32_t num_pods, uint64_t* out /* [num_pods][row_words] */);
+int32_t ykpred_read_counts(ykpred_engine_t* e, int32_t* out /* [P] */);
+int32_t ykpred_read_decisions(ykpred_engine_t* e, int32_t* out /* [P] */);
+int32_t ykpred_read_scores(ykpred_engine_t* e, double* out /* [N] bin-pack score per node */);
+int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out); /* order-independent hash of (pod,word,value) */
+
+/* one Predicates() answer per (pod,node) pair, evaluated on the device straight from the tables */
+int32_t ykpred_query(ykpred_engine_t* e, int32_t num_pairs, const int32_t* pod_index, const int32_t* node_index,
+                     uint32_t prefilter_plugins, uint32_t filter_plugins, uint8_t* fit /* [num_pairs] */,
+                     uint8_t* plugin_code /* [num_pairs], may be NULL */, uint32_t* reason /* [num_pairs], may be NULL */);
+
+/* PreemptionPredicates (predicate_manager.go:141-179): victims are described by their request vectors, in order. */
+int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod_index, int32_t node_index, int32_t num_victims,
+                          const int64_t* victim_requests /* [num_victims][R]; a nil victim is an all-zero row with present=0 */,
+                          const uint8_t* victim_present /* [num_victims] */, int32_t start_index,
+                          uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t* out_index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YKPRED_H_ */

@@ -1,0 +1,53 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI libraries build, load, and export every entry point that
+include/*.h declares; and the product fails loudly (no CPU fallback) when no HIP device is present."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(yk(?:pred|host)_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_libraries_build_and_export_every_declared_symbol():
+    pred_path, host_path = pkg.build_all()
+    pred = ctypes.CDLL(pred_path, mode=ctypes.RTLD_GLOBAL)
+    host = ctypes.CDLL(host_path)
+    names = declared_functions("ykpred.h")
+    assert len(names) >= 18
+    for fn in names:
+        assert hasattr(pred, fn), f"libykpred.so does not export {fn}"
+    hnames = [n for n in declared_functions("ykhost.h") if n.startswith("ykhost_")]
+    assert len(hnames) >= 20
+    for fn in hnames:
+        assert hasattr(host, fn), f"libykhost.so does not export {fn}"
+    pred.ykpred_abi_version.restype = ctypes.c_int32
+    assert pred.ykpred_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.GpuPredicateManager()
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under the package may include, link or load it."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "yunikorn-k8shim_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"ykoracle|oracle/|import _oracle|orc_", text):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

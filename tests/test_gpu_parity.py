@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP engine (through the C ABI: libykhost → libykpred) against the CPU oracle.
+
+Bar: BIT-EXACT. Every fit bit, every failing-plugin code, every feasible count, every decision and every float64
+bin-pack score must equal the oracle's on the same snapshot (the oracle is fed the JSON that the host library
+serialises from its own object model, or the same Python-built snapshot).
+"""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _gen
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = orc.PLUGIN_NAMES
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def pm():
+    m = pkg.GpuPredicateManager()
+    yield m
+    m.close()
+
+
+def unpack(bitmap, n_nodes):
+    """[P][row_words] uint64 → [P][N] 0/1 (bit n%64 of word n//64 = node n)."""
+    bits = np.unpackbits(bitmap.view(np.uint8), axis=1, bitorder="little")
+    return bits[:, :n_nodes]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the reference's own table tests, replayed through PredicateManager.Predicates on the GPU
+# ------------------------------------------------------------------------------------------------------------
+PRED = load("predicate_cases.json")
+
+
+@pytest.mark.parametrize("case", PRED, ids=[f"{c['test']}:{c['name']}" for c in PRED])
+def test_reference_table_tests(case):
+    ep = case["plugins"]
+    m = pkg.GpuPredicateManager.internal(ep, ep, ep, ep)  # predicate_manager_test.go:341
+    try:
+        m.load_snapshot({"nodes": [case["node"]], "pods": [case["pod"]]})
+        plugin, err = m.predicates(0, 0, case["allocate"])
+        assert (err is None) == case["fits"], f"{case['source']}: plugin={plugin!r} err={err}"
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("case", load("preemption_cases.json"), ids=lambda c: c["source"])
+def test_reference_preemption_tests(case):
+    ep = case["plugins"]
+    m = pkg.GpuPredicateManager.internal(ep, ep, ep, ep)
+    try:
+        m.load_snapshot({"nodes": [case["node"]], "pods": [case["pod"]]})
+        uids = [case["node"]["pods"][i]["metadata"]["uid"] for i in case["victims"]]
+        assert m.preemption_predicates(0, 0, uids, case["start_index"]) == case["index"], case["source"]
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("case", load("request_cases.json"), ids=lambda c: c["name"])
+def test_reference_request_vectors(pm, case):
+    pm.load_snapshot({"nodes": [], "pods": [case["pod"]]})
+    got = {k: v for k, v in pm.pod_request(0).items() if v != 0 or k in case["expect"]}
+    assert got == case["expect"], case["source"]
+
+
+def test_default_manager_phases_and_messages(pm):
+    node = {"metadata": {"name": "n0"}, "spec": {"taints": [{"key": "k", "value": "v", "effect": "NoSchedule"}]},
+            "status": {"allocatable": {"cpu": "1", "memory": "1Gi", "pods": "10"}}}
+    pod = {"metadata": {"name": "p", "uid": "p"}, "spec": {"containers": [{"resources": {"requests": {"cpu": "2"}}}],
+                                                           "tolerations": [{"key": "k", "operator": "Exists"}]}}
+    pm.load_snapshot({"nodes": [node], "pods": [pod]})
+    plugin, err = pm.predicates(0, 0, True)
+    assert plugin == "NodeResourcesFit" and "Insufficient cpu" in err.message
+    assert pm.predicates(0, 0, False) == ("", None)  # reservation phase skips NodeResourcesFit (predicate_manager.go:326,363)
+    pod["spec"].pop("tolerations")
+    pm.load_snapshot({"nodes": [node], "pods": [pod]})
+    plugin, err = pm.predicates("p", "n0", True)
+    assert plugin == "TaintToleration" and "taint" in err.message  # e2e `.*taint.*`, test/e2e/predicates/predicates_test.go:439
+
+
+# ------------------------------------------------------------------------------------------------------------
+# randomized edge-case clusters: full grid, both phases, bits + failing plugin
+# ------------------------------------------------------------------------------------------------------------
+def check_against_oracle(pm, snapshot, allocate, pre=None, filt=None, check_plugins=True):
+    o = orc.Oracle(snapshot)
+    if pre is None:
+        pre, filt = (orc.ALL, orc.ALL) if allocate else (orc.RESERVE_PRE, orc.RESERVE_FILT)
+    want, want_plugin = o.eval_grid(pre_mask=pre, filt_mask=filt, threads=8, want_plugin=True)
+    pm.evaluate(allocate=allocate)
+    lay = pm.layout()
+    assert lay.num_nodes == o.num_nodes and lay.num_pods == o.num_pods
+    got = unpack(pm.read_bitmap(), lay.num_nodes)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} differing bits, first (pod,node)={bad[0].tolist()} want={want[tuple(bad[0])]}"
+    # feasible counts
+    assert np.array_equal(pm.read_counts(), want.sum(axis=1).astype(np.int32))
+    if check_plugins:
+        P, N = want.shape
+        pods, nodes = np.divmod(np.arange(P * N, dtype=np.int64), N)
+        fit, code, _ = pm.query(pods.astype(np.int32), nodes.astype(np.int32), pre_mask=pre, filt_mask=filt)
+        assert np.array_equal(fit.reshape(P, N), want)
+        codes = code.reshape(P, N)
+        mism = np.argwhere((codes != want_plugin) & (want == 0))
+        assert mism.size == 0, (f"failing plugin differs at (pod,node)={mism[0].tolist()}: "
+                                f"gpu={NAMES[codes[tuple(mism[0])]]} oracle={NAMES[want_plugin[tuple(mism[0])]]}")
+    return o, want
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("allocate", [True, False])
+def test_random_clusters_full_grid(pm, seed, allocate):
+    snap = _gen.random_snapshot(1000 + seed, n_nodes=70 + 13 * seed, n_pods=60)
+    pm.load_snapshot(snap)
+    check_against_oracle(pm, snap, allocate)
+
+
+@pytest.mark.parametrize("plugins", [["NodeResourcesFit"], ["TaintToleration", "NodeUnschedulable"], ["NodeAffinity"], ["NodeName"], []])
+def test_random_clusters_plugin_subsets(plugins):
+    snap = _gen.random_snapshot(77, n_nodes=130, n_pods=80)
+    m = pkg.GpuPredicateManager.internal(plugins, plugins, plugins, plugins)
+    try:
+        m.load_snapshot(snap)
+        mask = orc.mask_of(plugins)
+        check_against_oracle(m, snap, True, pre=mask, filt=mask)
+    finally:
+        m.close()
+
+
+def test_empty_and_ragged_inputs(pm):
+    node = _gen.random_snapshot(5, 1, 0)["nodes"][0]
+    pod = _gen.random_snapshot(5, 1, 1)["pods"][0]
+    for snap in ({"nodes": [], "pods": []}, {"nodes": [node], "pods": []}, {"nodes": [], "pods": [pod]}):
+        pm.load_snapshot(snap)
+        pm.evaluate()
+        lay = pm.layout()
+        assert lay.num_nodes == len(snap["nodes"]) and lay.num_pods == len(snap["pods"])
+    # 64 / 65 / 127 / 128 nodes: word boundaries of the bitmap rows
+    for n in (63, 64, 65, 127, 128, 129):
+        snap = _gen.random_snapshot(300 + n, n_nodes=n, n_pods=20)
+        pm.load_snapshot(snap)
+        check_against_oracle(pm, snap, True, check_plugins=False)
+
+
+def test_direct_kernel_matches_plane_path(pm):
+    snap = _gen.random_snapshot(4242, n_nodes=333, n_pods=200)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    a = pm.read_bitmap().copy()
+    ca = pm.checksum()
+    pm.evaluate(direct=True)
+    b = pm.read_bitmap()
+    assert np.array_equal(a, b)
+    assert pm.checksum() == ca
+
+
+# ------------------------------------------------------------------------------------------------------------
+# KWOK-style clusters from the product's generator; oracle fed the serialised snapshot
+# ------------------------------------------------------------------------------------------------------------
+def test_kwok_config1_shape_fit_only():
+    """configs[0]: 100 nodes × 1k pods, NodeResourcesFit only."""
+    ep = ["NodeResourcesFit"]
+    m = pkg.GpuPredicateManager.internal(ep, ep, ep, ep)
+    try:
+        m.generate_kwok(seed=0x59554E49 + 1, num_nodes=100, num_pods=1000, node_affinity=0, tolerations=0)
+        snap = m.dump_snapshot()
+        mask = orc.mask_of(ep)
+        check_against_oracle(m, snap, True, pre=mask, filt=mask)
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("affinity,templates", [(0, 0), (1, 0), (1, 50)])
+def test_kwok_midsize_full_grid(pm, affinity, templates):
+    """configs[1]/[2] plugin mixes at a size the oracle finishes in seconds (1.5k nodes × 3k pods = 4.5M pairs)."""
+    pm.generate_kwok(seed=0x59554E49 + 2 + affinity, num_nodes=1500, num_pods=3000, num_templates=templates, node_affinity=affinity)
+    snap = pm.dump_snapshot()
+    o, want = check_against_oracle(pm, snap, True, check_plugins=False)
+    # decisions + scores
+    scores = pm.read_scores()
+    assert np.array_equal(scores.view(np.uint64), o.binpack_scores().view(np.uint64)), "float64 bin-pack score differs bitwise"
+    dec = pm.read_decisions()
+    order = np.lexsort((np.arange(len(scores)), scores))
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    masked = np.where(want.astype(bool), rank[None, :], np.iinfo(np.int64).max)
+    best = np.where(want.any(axis=1), order[np.clip(masked.min(axis=1), 0, len(order) - 1)], -1)
+    assert np.array_equal(dec, best.astype(np.int32))
+    for p in (0, 17, 2999):
+        assert o.decide(p) == (int(want[p].sum()), int(dec[p]))
+    # reservation phase on the same cluster
+    check_against_oracle(pm, snap, False, check_plugins=False)
+
+
+def test_kwok_gang_placeholders_share_rows(pm):
+    """configs[3] shape: gang placeholder asks — all members of a task group are one pod class (placeholder.go:113-157)."""
+    pm.generate_kwok(seed=99, num_nodes=700, num_pods=4000, gang_size=100, node_affinity=1)
+    pm.evaluate()
+    lay = pm.layout()
+    assert lay.num_classes <= 40 + 8  # 40 groups (+ the few pods pinned by nodeName)
+    bm = pm.read_bitmap()
+    snap = pm.dump_snapshot(pods=np.arange(0, 4000, 37))
+    o = orc.Oracle(snap)
+    want = o.eval_grid(threads=8)
+    assert np.array_equal(unpack(bm[0:4000:37], lay.num_nodes), want)
+
+
+def test_incremental_assume_forget(pm):
+    """AssumePod / ForgetPod patch one node row; the next evaluation sees it (context.go:828-898)."""
+    snap = _gen.random_snapshot(2024, n_nodes=90, n_pods=40, scalars=False)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    target = next(n["metadata"]["name"] for n in snap["nodes"] if n["metadata"]["name"])
+    uid = snap["pods"][3]["metadata"]["uid"]
+    pm.assume_pod(uid, target)
+    moved = dict(snap["pods"][3])
+    moved["spec"] = dict(moved["spec"], nodeName=target)
+    snap2 = {"nodes": json.loads(json.dumps(snap["nodes"])), "pods": [p for p in snap["pods"] if p["metadata"]["uid"] != uid]}
+    next(n for n in snap2["nodes"] if n["metadata"]["name"] == target).setdefault("pods", []).append(moved)
+    check_against_oracle(pm, snap2, True)
+    pm.forget_pod(uid)
+    snap3 = {"nodes": snap["nodes"], "pods": [p for p in snap["pods"] if p["metadata"]["uid"] != uid] + [snap["pods"][3]]}
+    check_against_oracle(pm, snap3, True)
+
+
+def test_unsupported_pods_are_rejected_loudly(pm):
+    pod = {"metadata": {"name": "p", "uid": "p"}, "spec": {"containers": [{"ports": [{"hostPort": 80}]}]}}
+    pm.load_snapshot({"nodes": [{"metadata": {"name": "n"}}], "pods": [pod]})
+    with pytest.raises(RuntimeError, match="NodePorts"):
+        pm.evaluate()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: properties + oracle on a sample (the oracle cannot finish 5e10 pairs)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_nodes,n_pods,affinity", [(10_000, 100_000, 0), (50_000, 1_000_000, 1)])
+def test_full_size_configs(pm, n_nodes, n_pods, affinity):
+    """configs[1] (10k × 100k, Fit + TaintToleration) and configs[2] (50k × 1M, + NodeAffinity)."""
+    pm.generate_kwok(seed=0x59554E49 + 10 + affinity, num_nodes=n_nodes, num_pods=n_pods, num_templates=2000, node_affinity=affinity)
+    pm.evaluate()
+    lay = pm.layout()
+    assert (lay.num_nodes, lay.num_pods) == (n_nodes, n_pods)
+    sum_plane = pm.checksum()
+    rng = np.random.default_rng(7)
+    pods = np.sort(rng.choice(n_pods, 96, replace=False)).astype(np.int32)
+    nodes = np.sort(rng.choice(n_nodes, 1200, replace=False)).astype(np.int32)
+    rows = np.stack([pm.read_bitmap(int(p), 1)[0] for p in pods])
+    counts = pm.read_counts()
+    # (1) sampled pods × sampled nodes against the oracle, per pair
+    o = orc.Oracle(pm.dump_snapshot(pods=pods, nodes=nodes))
+    want = o.eval_grid(threads=8)
+    got = unpack(rows, n_nodes)[:, nodes]
+    assert np.array_equal(got, want)
+    # (2) popcount of every sampled row == the reported feasible count; padding bits are zero
+    assert np.array_equal(unpack(rows, lay.row_words * 64).sum(axis=1), counts[pods])
+    assert unpack(rows, lay.row_words * 64)[:, n_nodes:].sum() == 0
+    # (3) the device per-pair kernel (k_query) agrees on 200k random pairs
+    qp = rng.integers(0, n_pods, 200_000).astype(np.int32)
+    qn = rng.integers(0, n_nodes, 200_000).astype(np.int32)
+    fit, _, _ = pm.query(qp, qn)
+    sample_rows = {int(p): None for p in np.unique(qp[:2000])}
+    for p in sample_rows:
+        sample_rows[p] = pm.read_bitmap(p, 1)[0]
+    for i in range(2000):
+        w = sample_rows[int(qp[i])][qn[i] >> 6]
+        assert ((int(w) >> int(qn[i] & 63)) & 1) == fit[i]
+    # (4) checksum of checksums: the independent per-pair formulation (k_direct) reproduces the whole bitmap
+    pm.evaluate(direct=True, counts=False, decisions=False)
+    assert pm.checksum() == sum_plane

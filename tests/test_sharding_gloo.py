@@ -1,0 +1,67 @@
+"""N>1 path on CPU: two gloo ranks run the decision exchange of the node-sharded engine on synthetic per-shard
+outputs; the result must equal what one process computes over the concatenated node axis."""
+import importlib
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sharding = importlib.import_module("yunikorn-k8shim_amd.sharding")
+INT64_MAX = np.iinfo(np.int64).max
+
+
+def make_shard(rank, P, n_local, seed=5):
+    """Synthetic outputs of one shard: feasibility [P][n_local], per-node order keys (with ties across shards)."""
+    rng = np.random.default_rng(seed + rank)
+    feas = rng.random((P, n_local)) < 0.05
+    feas[::7] = False  # some pods infeasible on every shard
+    node_key = rng.integers(0, 40, n_local).astype(np.int64)  # few distinct keys ⇒ cross-shard ties
+    counts = feas.sum(axis=1).astype(np.int32)
+    order = np.lexsort((np.arange(n_local), node_key))
+    rank_of = np.empty(n_local, dtype=np.int64)
+    rank_of[order] = np.arange(n_local)
+    masked = np.where(feas, rank_of[None, :], n_local)
+    best_pos = masked.min(axis=1)
+    has = best_pos < n_local
+    best = np.where(has, order[np.clip(best_pos, 0, n_local - 1)], -1).astype(np.int32)
+    keys = np.where(has, node_key[np.clip(best, 0, n_local - 1)], INT64_MAX).astype(np.int64)
+    return feas, node_key, counts, best, keys
+
+
+def worker(rank, world, port, P, n_local, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, counts, best, keys = make_shard(rank, P, n_local)
+    c, d = sharding.exchange_decisions(torch.from_numpy(counts.copy()), torch.from_numpy(best.copy()), torch.from_numpy(keys.copy()),
+                                       rank * n_local, dist)
+    if rank == 0:
+        torch.save({"counts": c, "decisions": d}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_decisions_world2(tmp_path):
+    world, P, n_local = 2, 500, 96
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(worker, args=(world, 29531, P, n_local, out), nprocs=world, join=True)
+    got = torch.load(out)
+    shards = [make_shard(r, P, n_local) for r in range(world)]
+    feas = np.concatenate([s[0] for s in shards], axis=1)
+    key = np.concatenate([s[1] for s in shards])
+    order = np.lexsort((np.arange(len(key)), key))
+    rank_of = np.empty(len(key), dtype=np.int64)
+    rank_of[order] = np.arange(len(key))
+    masked = np.where(feas, rank_of[None, :], len(key))
+    pos = masked.min(axis=1)
+    want = np.where(pos < len(key), order[np.clip(pos, 0, len(key) - 1)], -1)
+    assert np.array_equal(got["counts"].numpy(), feas.sum(axis=1))
+    assert np.array_equal(got["decisions"].numpy(), want)
+
+
+def test_gathered_row_layout():
+    G, P, stride, words = 3, 4, 8, 5
+    g = torch.arange(G * P * stride).reshape(G, P, stride)
+    row = sharding.gathered_row(g, 2, G, words)
+    assert row.tolist() == [int(g[s, 2, w]) for s in range(G) for w in range(words)]

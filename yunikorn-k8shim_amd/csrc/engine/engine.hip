@@ -1,0 +1,790 @@
+// engine.hip — C-ABI implementation of libykpred.so (include/ykpred.h) for MI355X / gfx950.
+//
+// Host side of the engine: owns the device tables (structure-of-arrays), groups pod specs into per-plugin
+// signatures and pods into classes (pure bookkeeping on the upload path, O(1) per pod), and launches the
+// kernels of kernels.hip.h. There is no CPU evaluation path in this file: every verdict comes from a kernel.
+#include "../../../include/ykpred.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.hip.h"
+
+using ykk::i64;
+using ykk::u64;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+struct Family {
+  int D = 0;  // number of signatures
+  DevBuf canon, ranked;
+};
+
+}  // namespace
+
+struct ykpred_engine {
+  ykpred_config_t cfg{};
+  int R = 3, KT = 1, W = 1;
+  hipStream_t own_stream = nullptr;
+  std::string err;
+
+  // --- node table
+  int N = 0;
+  int row_words = 0, row_stride = 0;
+  DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels;
+  DevBuf d_score, d_key, d_rank, d_perm;
+  bool nodes_set = false;
+
+  // --- specs (host copies kept for class building)
+  int S = 0;
+  std::vector<i64> h_req;
+  std::vector<u64> h_tol;
+  std::vector<uint32_t> h_sflags;
+  std::vector<int32_t> h_aff_off, h_pre_off;
+  std::vector<u64> h_aff_terms, h_pre_terms;
+  DevBuf d_sreq, d_stol, d_sflags, d_aff_off, d_aff_terms, d_pre_off, d_pre_terms;  // per-spec tables (k_query / k_direct)
+  // per-family signature tables
+  std::vector<int32_t> spec_sig_res, spec_sig_tol, spec_sig_aff;
+  Family fam_res, fam_tol, fam_aff;
+  DevBuf d_sig_req;                                                            // [Dres][R]
+  DevBuf d_sig_tol, d_sig_tolflags;                                            // [Dtol][KT], [Dtol]
+  DevBuf d_sig_aff_flags, d_sig_aff_off, d_sig_aff_terms, d_sig_pre_off, d_sig_pre_terms;
+  bool specs_set = false;
+
+  // --- pods / classes
+  int P = 0, C = 0, NC = 0;
+  std::vector<int32_t> h_pod_spec, h_pod_pin;
+  DevBuf d_pod_spec, d_pod_pin, d_pod_class;
+  DevBuf d_class_sig, d_class_pin, d_chunk_class, d_chunk_begin, d_chunk_len, d_chunk_first, d_members;
+  DevBuf d_class_count, d_class_best;
+  bool pods_set = false, classes_dirty = true;
+
+  // --- outputs
+  DevBuf d_bitmap, d_counts, d_decisions, d_keys, d_scratch;
+  void* last_bitmap = nullptr;
+  void *last_counts = nullptr, *last_decisions = nullptr, *last_keys = nullptr;
+
+  // --- timing
+  hipEvent_t ev[YKPRED_MAX_TIMED_KERNELS + 1]{};
+  bool ev_ready = false;
+  int timed = 0;
+  const char* timed_name[YKPRED_MAX_TIMED_KERNELS]{};
+  bool timing_valid = false;
+};
+
+namespace {
+
+int fail(ykpred_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+#define HIPCHK(call)                                                                                        \
+  do {                                                                                                      \
+    hipError_t _s = (call);                                                                                 \
+    if (_s != hipSuccess)                                                                                   \
+      return fail(e, _s == hipErrorOutOfMemory ? YKPRED_E_NOMEM : YKPRED_E_DEVICE,                          \
+                  std::string(#call) + ": " + hipGetErrorString(_s));                                       \
+  } while (0)
+
+template <class T>
+int upload(ykpred_engine* e, DevBuf& b, const T* src, size_t n, hipStream_t st) {
+  HIPCHK(b.ensure(n * sizeof(T)));
+  if (n) HIPCHK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+  return YKPRED_OK;
+}
+#define TRY(x)                     \
+  do {                             \
+    int _r = (x);                  \
+    if (_r != YKPRED_OK) return _r; \
+  } while (0)
+
+ykk::NodeTable node_table(const ykpred_engine* e) {
+  ykk::NodeTable t;
+  t.n = e->N;
+  t.R = e->R;
+  t.KT = e->KT;
+  t.W = e->W;
+  t.alloc = e->d_alloc.as<i64>();
+  t.req = e->d_req.as<i64>();
+  t.allowed = e->d_allowed.as<int>();
+  t.count = e->d_count.as<int>();
+  t.flags = e->d_nflags.as<unsigned>();
+  t.taints = e->d_taints.as<u64>();
+  t.labels = e->d_labels.as<u64>();
+  return t;
+}
+ykk::SpecTable spec_table(const ykpred_engine* e) {
+  ykk::SpecTable s;
+  s.R = e->R;
+  s.KT = e->KT;
+  s.W = e->W;
+  s.req = e->d_sreq.as<i64>();
+  s.tol = e->d_stol.as<u64>();
+  s.flags = e->d_sflags.as<unsigned>();
+  s.aff.flags = e->d_sflags.as<unsigned>();
+  s.aff.term_off = e->d_aff_off.as<int>();
+  s.aff.terms = e->d_aff_terms.as<u64>();
+  s.aff.pre_off = e->d_pre_off.as<int>();
+  s.aff.pre_terms = e->d_pre_terms.as<u64>();
+  return s;
+}
+
+// Groups pods into classes (same signatures + same pinned node) and classes into chunks of <= kChunkMembers pods.
+int build_classes(ykpred_engine* e, hipStream_t st) {
+  const int P = e->P;
+  struct Key {
+    int32_t a, b, c, pin;
+    bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c && pin == o.pin; }
+  };
+  struct KeyHash {
+    size_t operator()(const Key& k) const {
+      uint64_t h = (uint64_t)(uint32_t)k.a * 0x9e3779b97f4a7c15ull;
+      h ^= ((uint64_t)(uint32_t)k.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+      h ^= ((uint64_t)(uint32_t)k.c + 0x1ce4e5b9ull) * 0x94d049bb133111ebull;
+      h ^= ((uint64_t)(uint32_t)k.pin + 0x133111ebull) * 0xd6e8feb86659fd93ull;
+      return (size_t)(h ^ (h >> 29));
+    }
+  };
+  std::unordered_map<Key, int32_t, KeyHash> ids;
+  ids.reserve(1024);
+  std::vector<int32_t> pod_class((size_t)P);
+  std::vector<int32_t> class_sig, class_pin, class_size;
+  for (int p = 0; p < P; ++p) {
+    int s = e->h_pod_spec[(size_t)p];
+    Key k{e->spec_sig_res[(size_t)s], e->spec_sig_tol[(size_t)s], e->spec_sig_aff[(size_t)s], e->h_pod_pin[(size_t)p]};
+    auto it = ids.find(k);
+    int32_t c;
+    if (it == ids.end()) {
+      c = (int32_t)class_pin.size();
+      ids.emplace(k, c);
+      class_sig.insert(class_sig.end(), {k.a, k.b, k.c, -1});
+      class_pin.push_back(k.pin);
+      class_size.push_back(0);
+    } else {
+      c = it->second;
+    }
+    pod_class[(size_t)p] = c;
+    class_size[(size_t)c]++;
+  }
+  const int C = (int)class_pin.size();
+  std::vector<int32_t> class_off((size_t)C + 1, 0);
+  for (int c = 0; c < C; ++c) class_off[(size_t)c + 1] = class_off[(size_t)c] + class_size[(size_t)c];
+  std::vector<int32_t> members((size_t)P), cursor(class_off.begin(), class_off.end() - 1);
+  for (int p = 0; p < P; ++p) members[(size_t)cursor[(size_t)pod_class[(size_t)p]]++] = p;
+  std::vector<int32_t> ch_class, ch_begin, ch_len, ch_first;
+  for (int c = 0; c < C; ++c) {
+    for (int b = class_off[(size_t)c]; b < class_off[(size_t)c + 1]; b += ykk::kChunkMembers) {
+      ch_class.push_back(c);
+      ch_begin.push_back(b);
+      ch_len.push_back(std::min(ykk::kChunkMembers, class_off[(size_t)c + 1] - b));
+      ch_first.push_back(b == class_off[(size_t)c] ? 1 : 0);
+    }
+  }
+  e->C = C;
+  e->NC = (int)ch_class.size();
+  TRY(upload(e, e->d_pod_class, pod_class.data(), pod_class.size(), st));
+  TRY(upload(e, e->d_class_sig, class_sig.data(), class_sig.size(), st));
+  TRY(upload(e, e->d_class_pin, class_pin.data(), class_pin.size(), st));
+  TRY(upload(e, e->d_members, members.data(), members.size(), st));
+  TRY(upload(e, e->d_chunk_class, ch_class.data(), ch_class.size(), st));
+  TRY(upload(e, e->d_chunk_begin, ch_begin.data(), ch_begin.size(), st));
+  TRY(upload(e, e->d_chunk_len, ch_len.data(), ch_len.size(), st));
+  TRY(upload(e, e->d_chunk_first, ch_first.data(), ch_first.size(), st));
+  HIPCHK(e->d_class_count.ensure((size_t)std::max(C, 1) * sizeof(int)));
+  HIPCHK(e->d_class_best.ensure((size_t)std::max(C, 1) * sizeof(int)));
+  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  e->classes_dirty = false;
+  return YKPRED_OK;
+}
+
+int ensure_planes(ykpred_engine* e) {
+  size_t row = (size_t)e->row_stride * sizeof(u64);
+  for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff}) {
+    size_t need = row * (size_t)std::max(f->D, 1);
+    if (f->canon.cap < need) {
+      HIPCHK(f->canon.ensure(need));
+      HIPCHK(hipMemset(f->canon.p, 0, need));
+    }
+    if (f->ranked.cap < need) {
+      HIPCHK(f->ranked.ensure(need));
+      HIPCHK(hipMemset(f->ranked.p, 0, need));
+    }
+  }
+  return YKPRED_OK;
+}
+
+struct Timer {
+  ykpred_engine* e;
+  hipStream_t st;
+  bool on;
+  void start() {
+    e->timed = 0;
+    e->timing_valid = false;
+    if (on) (void)hipEventRecord(e->ev[0], st);
+  }
+  void mark(const char* name) {
+    if (!on || e->timed >= YKPRED_MAX_TIMED_KERNELS) return;
+    e->timed_name[e->timed] = name;
+    (void)hipEventRecord(e->ev[e->timed + 1], st);
+    e->timed++;
+  }
+  void done() { e->timing_valid = on; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int32_t ykpred_abi_version(void) { return YKPRED_ABI_VERSION; }
+
+const char* ykpred_last_error(const ykpred_engine_t* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return YKPRED_E_INVALID;
+  }
+  if (cfg->abi_version != YKPRED_ABI_VERSION) {
+    g_create_error = "ABI version mismatch";
+    return YKPRED_E_INVALID;
+  }
+  if (cfg->num_resources < 3 || cfg->num_resources > ykk::kMaxR || cfg->taint_words < 1 || cfg->taint_words > ykk::kMaxKT ||
+      cfg->label_words < 1 || cfg->label_words > ykk::kMaxW) {
+    g_create_error = "config out of range: need 3<=R<=8, 1<=KT<=4, 1<=W<=8";
+    return YKPRED_E_UNSUPPORTED;
+  }
+  if (cfg->topology_keys != 0 || cfg->selector_classes != 0) {
+    g_create_error = "PodTopologySpread tables are not supported by this build of the engine";
+    return YKPRED_E_UNSUPPORTED;
+  }
+  int ndev = 0;
+  hipError_t s = hipGetDeviceCount(&ndev);
+  if (s != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("no HIP device: ") + hipGetErrorString(s) + " (libykpred has no CPU fallback)";
+    return YKPRED_E_DEVICE;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) {
+    g_create_error = "device ordinal out of range";
+    return YKPRED_E_INVALID;
+  }
+  s = hipSetDevice(cfg->device);
+  if (s != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(s);
+    return YKPRED_E_DEVICE;
+  }
+  auto* e = new ykpred_engine();
+  e->cfg = *cfg;
+  e->R = cfg->num_resources;
+  e->KT = cfg->taint_words;
+  e->W = cfg->label_words;
+  s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+  if (s != hipSuccess) {
+    g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(s);
+    delete e;
+    return YKPRED_E_DEVICE;
+  }
+  for (auto& ev : e->ev) (void)hipEventCreate(&ev);
+  e->ev_ready = true;
+  *out = e;
+  return YKPRED_OK;
+}
+
+void ykpred_destroy(ykpred_engine_t* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_score, &e->d_key,
+                    &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
+                    &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
+                    &e->d_class_sig, &e->d_class_pin, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
+                    &e->d_members, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
+                    &e->fam_res.canon, &e->fam_res.ranked, &e->fam_tol.canon, &e->fam_tol.ranked, &e->fam_aff.canon, &e->fam_aff.ranked})
+    b->release();
+  if (e->ev_ready)
+    for (auto& ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
+  if (!e || !n || n->count < 0) return fail(e, YKPRED_E_INVALID, "set_nodes: bad argument");
+  if (n->count > 0 && (!n->allocatable || !n->requested || !n->allowed_pods || !n->pod_count || !n->flags || !n->taint_bits ||
+                       !n->label_bits))
+    return fail(e, YKPRED_E_INVALID, "set_nodes: null column");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  const size_t N = (size_t)n->count;
+  TRY(upload(e, e->d_alloc, n->allocatable, N * (size_t)e->R, st));
+  TRY(upload(e, e->d_req, n->requested, N * (size_t)e->R, st));
+  TRY(upload(e, e->d_allowed, n->allowed_pods, N, st));
+  TRY(upload(e, e->d_count, n->pod_count, N, st));
+  TRY(upload(e, e->d_nflags, n->flags, N, st));
+  TRY(upload(e, e->d_taints, n->taint_bits, N * (size_t)e->KT, st));
+  TRY(upload(e, e->d_labels, n->label_bits, N * (size_t)e->W, st));
+  HIPCHK(e->d_score.ensure(N * sizeof(double)));
+  HIPCHK(e->d_key.ensure(N * sizeof(u64)));
+  HIPCHK(e->d_rank.ensure(N * sizeof(int)));
+  HIPCHK(e->d_perm.ensure(N * sizeof(int)));
+  HIPCHK(hipStreamSynchronize(st));
+  if (e->N != n->count) {
+    // plane rows change length: drop them so ensure_planes() re-zeroes the padding
+    for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff}) {
+      f->canon.release();
+      f->ranked.release();
+    }
+  }
+  e->N = n->count;
+  e->row_words = (e->N + 63) / 64;
+  e->row_stride = std::max(8, (e->row_words + 7) / 8 * 8);
+  e->nodes_set = true;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t* n) {
+  if (!e || !n || n->count != 1) return fail(e, YKPRED_E_INVALID, "update_node: count must be 1");
+  if (!e->nodes_set || idx < 0 || idx >= e->N) return fail(e, YKPRED_E_INVALID, "update_node: index out of range");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  const size_t N = (size_t)e->N;
+  for (int r = 0; r < e->R; ++r) {
+    HIPCHK(hipMemcpyAsync(e->d_alloc.as<i64>() + (size_t)r * N + idx, n->allocatable + r, sizeof(i64), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_req.as<i64>() + (size_t)r * N + idx, n->requested + r, sizeof(i64), hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipMemcpyAsync(e->d_allowed.as<int>() + idx, n->allowed_pods, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_count.as<int>() + idx, n->pod_count, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_nflags.as<unsigned>() + idx, n->flags, sizeof(unsigned), hipMemcpyHostToDevice, st));
+  for (int k = 0; k < e->KT; ++k)
+    HIPCHK(hipMemcpyAsync(e->d_taints.as<u64>() + (size_t)k * N + idx, n->taint_bits + k, sizeof(u64), hipMemcpyHostToDevice, st));
+  for (int w = 0; w < e->W; ++w)
+    HIPCHK(hipMemcpyAsync(e->d_labels.as<u64>() + (size_t)w * N + idx, n->label_bits + w, sizeof(u64), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
+  if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
+  if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
+    return fail(e, YKPRED_E_INVALID, "set_specs: null column");
+  if (s->spread_off && s->count > 0 && s->spread_off[s->count] != 0)
+    return fail(e, YKPRED_E_UNSUPPORTED, "set_specs: hard topology spread constraints are not supported by this build");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  const int S = s->count, R = e->R, KT = e->KT, W = e->W;
+  const int T = S ? s->aff_term_off[S] : 0, M = S ? s->pre_term_off[S] : 0;
+  if (T < 0 || M < 0 || (T > 0 && !s->aff_terms) || (M > 0 && !s->pre_terms)) return fail(e, YKPRED_E_INVALID, "set_specs: bad term tables");
+  e->S = S;
+  e->h_req.assign(s->requests, s->requests + (size_t)S * R);
+  e->h_tol.assign(s->tolerated, s->tolerated + (size_t)S * KT);
+  e->h_sflags.assign(s->flags, s->flags + S);
+  e->h_aff_off.assign(s->aff_term_off, s->aff_term_off + S + (S ? 1 : 0));
+  e->h_pre_off.assign(s->pre_term_off, s->pre_term_off + S + (S ? 1 : 0));
+  if (!S) {
+    e->h_aff_off.assign(1, 0);
+    e->h_pre_off.assign(1, 0);
+  }
+  e->h_aff_terms.assign(s->aff_terms, s->aff_terms + (size_t)T * W);
+  e->h_pre_terms.assign(s->pre_terms, s->pre_terms + (size_t)M * W);
+  TRY(upload(e, e->d_sreq, e->h_req.data(), e->h_req.size(), st));
+  TRY(upload(e, e->d_stol, e->h_tol.data(), e->h_tol.size(), st));
+  TRY(upload(e, e->d_sflags, e->h_sflags.data(), e->h_sflags.size(), st));
+  TRY(upload(e, e->d_aff_off, e->h_aff_off.data(), e->h_aff_off.size(), st));
+  TRY(upload(e, e->d_pre_off, e->h_pre_off.data(), e->h_pre_off.size(), st));
+  TRY(upload(e, e->d_aff_terms, e->h_aff_terms.data(), e->h_aff_terms.size(), st));
+  TRY(upload(e, e->d_pre_terms, e->h_pre_terms.data(), e->h_pre_terms.size(), st));
+
+  // ---- per-plugin signatures: identical byte strings share one plane
+  e->spec_sig_res.assign((size_t)S, 0);
+  e->spec_sig_tol.assign((size_t)S, 0);
+  e->spec_sig_aff.assign((size_t)S, 0);
+  std::unordered_map<std::string, int32_t> m_res, m_tol, m_aff;
+  std::vector<i64> sig_req;
+  std::vector<u64> sig_tol, sig_aff_terms, sig_pre_terms;
+  std::vector<uint32_t> sig_tolflags, sig_aff_flags;
+  std::vector<int32_t> sig_aff_off{0}, sig_pre_off{0};
+  const uint32_t aff_flag_mask = YKPRED_SPEC_AFFINITY_SKIP | YKPRED_SPEC_PREFILTER_REJECT | YKPRED_SPEC_PREFILTER_NAMES;
+  for (int i = 0; i < S; ++i) {
+    std::string k((const char*)(s->requests + (size_t)i * R), (size_t)R * sizeof(i64));
+    auto it = m_res.find(k);
+    if (it == m_res.end()) {
+      it = m_res.emplace(std::move(k), (int32_t)m_res.size()).first;
+      sig_req.insert(sig_req.end(), s->requests + (size_t)i * R, s->requests + (size_t)(i + 1) * R);
+    }
+    e->spec_sig_res[(size_t)i] = it->second;
+
+    uint32_t tf = s->flags[i] & YKPRED_SPEC_TOLERATES_UNSCHEDULABLE;
+    std::string kt((const char*)(s->tolerated + (size_t)i * KT), (size_t)KT * sizeof(u64));
+    kt.append((const char*)&tf, sizeof(tf));
+    auto jt = m_tol.find(kt);
+    if (jt == m_tol.end()) {
+      jt = m_tol.emplace(std::move(kt), (int32_t)m_tol.size()).first;
+      sig_tol.insert(sig_tol.end(), s->tolerated + (size_t)i * KT, s->tolerated + (size_t)(i + 1) * KT);
+      sig_tolflags.push_back(tf);
+    }
+    e->spec_sig_tol[(size_t)i] = jt->second;
+
+    uint32_t af = s->flags[i] & aff_flag_mask;
+    int t0 = s->aff_term_off[i], t1 = s->aff_term_off[i + 1], p0 = s->pre_term_off[i], p1 = s->pre_term_off[i + 1];
+    if (t1 < t0 || p1 < p0) return fail(e, YKPRED_E_INVALID, "set_specs: offsets not monotone");
+    std::string ka((const char*)&af, sizeof(af));
+    int32_t nt = t1 - t0;
+    ka.append((const char*)&nt, sizeof(nt));
+    if (nt) ka.append((const char*)(s->aff_terms + (size_t)t0 * W), (size_t)nt * W * sizeof(u64));
+    if (p1 > p0) ka.append((const char*)(s->pre_terms + (size_t)p0 * W), (size_t)(p1 - p0) * W * sizeof(u64));
+    auto kt2 = m_aff.find(ka);
+    if (kt2 == m_aff.end()) {
+      kt2 = m_aff.emplace(std::move(ka), (int32_t)m_aff.size()).first;
+      sig_aff_flags.push_back(af);
+      if (nt) sig_aff_terms.insert(sig_aff_terms.end(), s->aff_terms + (size_t)t0 * W, s->aff_terms + (size_t)t1 * W);
+      if (p1 > p0) sig_pre_terms.insert(sig_pre_terms.end(), s->pre_terms + (size_t)p0 * W, s->pre_terms + (size_t)p1 * W);
+      sig_aff_off.push_back((int32_t)(sig_aff_terms.size() / (size_t)W));
+      sig_pre_off.push_back((int32_t)(sig_pre_terms.size() / (size_t)W));
+    }
+    e->spec_sig_aff[(size_t)i] = kt2->second;
+  }
+  e->fam_res.D = (int)m_res.size();
+  e->fam_tol.D = (int)m_tol.size();
+  e->fam_aff.D = (int)m_aff.size();
+  TRY(upload(e, e->d_sig_req, sig_req.data(), sig_req.size(), st));
+  TRY(upload(e, e->d_sig_tol, sig_tol.data(), sig_tol.size(), st));
+  TRY(upload(e, e->d_sig_tolflags, sig_tolflags.data(), sig_tolflags.size(), st));
+  TRY(upload(e, e->d_sig_aff_flags, sig_aff_flags.data(), sig_aff_flags.size(), st));
+  TRY(upload(e, e->d_sig_aff_off, sig_aff_off.data(), sig_aff_off.size(), st));
+  TRY(upload(e, e->d_sig_pre_off, sig_pre_off.data(), sig_pre_off.size(), st));
+  TRY(upload(e, e->d_sig_aff_terms, sig_aff_terms.data(), sig_aff_terms.size(), st));
+  TRY(upload(e, e->d_sig_pre_terms, sig_pre_terms.data(), sig_pre_terms.size(), st));
+  HIPCHK(hipStreamSynchronize(st));
+  e->specs_set = true;
+  e->classes_dirty = true;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* p) {
+  if (!e || !p || p->count < 0) return fail(e, YKPRED_E_INVALID, "set_pods: bad argument");
+  if (p->count > 0 && (!p->spec_index || !p->node_name_index)) return fail(e, YKPRED_E_INVALID, "set_pods: null column");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->P = p->count;
+  e->h_pod_spec.assign(p->spec_index, p->spec_index + p->count);
+  e->h_pod_pin.assign(p->node_name_index, p->node_name_index + p->count);
+  TRY(upload(e, e->d_pod_spec, e->h_pod_spec.data(), e->h_pod_spec.size(), e->own_stream));
+  TRY(upload(e, e->d_pod_pin, e->h_pod_pin.data(), e->h_pod_pin.size(), e->own_stream));
+  HIPCHK(hipStreamSynchronize(e->own_stream));
+  e->pods_set = true;
+  e->classes_dirty = true;
+  return YKPRED_OK;
+}
+
+static int validate_state(ykpred_engine* e) {
+  if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "nodes, specs and pods must be uploaded first");
+  for (int p = 0; p < e->P; ++p) {
+    int s = e->h_pod_spec[(size_t)p], pin = e->h_pod_pin[(size_t)p];
+    if (s < 0 || s >= e->S) return fail(e, YKPRED_E_INVALID, "pod references a spec that was not uploaded");
+    if (pin < YKPRED_UNKNOWN_NODE_NAME || pin >= e->N) return fail(e, YKPRED_E_INVALID, "pod node_name_index out of range");
+  }
+  return YKPRED_OK;
+}
+
+int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
+  if (!e || !a) return fail(e, YKPRED_E_INVALID, "eval: bad argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
+  if (e->classes_dirty) {
+    TRY(validate_state(e));
+    TRY(build_classes(e, e->own_stream));
+  }
+  const unsigned pre = a->prefilter_plugins, filt = a->filter_plugins;
+  if ((pre | filt) & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) {
+    // no spec may carry hard constraints (rejected in set_specs) ⇒ PodTopologySpread.PreFilter returns Skip for every pod
+  }
+  const int N = e->N, P = e->P;
+  const size_t bitmap_bytes = (size_t)std::max(P, 1) * (size_t)e->row_stride * sizeof(u64);
+  u64* bitmap = (u64*)a->bitmap;
+  if (!bitmap) {
+    HIPCHK(e->d_bitmap.ensure(bitmap_bytes));
+    bitmap = e->d_bitmap.as<u64>();
+  }
+  e->last_bitmap = bitmap;
+  HIPCHK(e->d_counts.ensure((size_t)std::max(P, 1) * sizeof(int)));
+  HIPCHK(e->d_decisions.ensure((size_t)std::max(P, 1) * sizeof(int)));
+  HIPCHK(e->d_keys.ensure((size_t)std::max(P, 1) * sizeof(i64)));
+  e->last_counts = a->counts ? a->counts : e->d_counts.p;
+  e->last_decisions = a->decisions ? a->decisions : e->d_decisions.p;
+  e->last_keys = a->decision_keys ? a->decision_keys : e->d_keys.p;
+  TRY(ensure_planes(e));
+  Timer tm{e, st, (a->options & YKPRED_EVAL_PROFILE) != 0};
+  tm.start();
+  if (N == 0 || P == 0) {
+    tm.done();
+    return YKPRED_OK;
+  }
+  ykk::NodeTable nt = node_table(e);
+  const bool want_keys = a->options & YKPRED_OUT_DECISION_KEYS;
+  const bool want_dec = (a->options & YKPRED_OUT_DECISIONS) || want_keys;
+  const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
+  const int nblk_nodes = (N + ykk::kBlock - 1) / ykk::kBlock;
+
+  if (a->options & YKPRED_EVAL_DIRECT) {
+    ykk::SpecTable stbl = spec_table(e);
+    dim3 grid((unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock), (unsigned)((P + ykk::kWave - 1) / ykk::kWave));
+    hipLaunchKernelGGL(ykk::k_direct, grid, dim3(ykk::kBlock), 0, st, nt, stbl, P, e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre,
+                       filt, bitmap, e->row_words, e->row_stride);
+    tm.mark("k_direct");
+    HIPCHK(hipGetLastError());
+    tm.done();
+    return YKPRED_OK;
+  }
+
+  // 1. bin-pack order (needed for the rank-ordered planes of the decision stage)
+  if (want_dec) {
+    hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, nt, e->d_score.as<double>(), e->d_key.as<u64>());
+    tm.mark("k_score");
+    hipLaunchKernelGGL(ykk::k_rank, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, N, e->d_key.as<u64>(), e->d_rank.as<int>(),
+                       e->d_perm.as<int>());
+    tm.mark("k_rank");
+  }
+  // 2. signature planes
+  const unsigned zdim = want_dec ? 2u : 1u;
+  const unsigned wgroups = (unsigned)((e->row_words + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock);
+  const bool res_on = filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT;
+  const bool tol_on = true;  // also carries "node exists" for the padding bits
+  const bool aff_on = (filt | pre) & YKPRED_PLUGIN_NODE_AFFINITY;
+  auto sig_chunks = [](int D) { return (unsigned)((D + ykk::kSigsPerBlock - 1) / ykk::kSigsPerBlock); };
+  if (res_on) {
+    ykk::PlaneOut o{e->fam_res.canon.as<u64>(), e->fam_res.ranked.as<u64>(), e->row_stride, e->fam_res.D};
+    hipLaunchKernelGGL(ykk::k_plane_res, dim3(wgroups, sig_chunks(e->fam_res.D), zdim), dim3(ykk::kBlock), 0, st, nt, e->d_perm.as<int>(),
+                       e->d_sig_req.as<i64>(), o, (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1, e->row_words);
+    tm.mark("k_plane_res");
+  }
+  if (tol_on) {
+    ykk::PlaneOut o{e->fam_tol.canon.as<u64>(), e->fam_tol.ranked.as<u64>(), e->row_stride, e->fam_tol.D};
+    hipLaunchKernelGGL(ykk::k_plane_tol, dim3(wgroups, sig_chunks(e->fam_tol.D), zdim), dim3(ykk::kBlock), 0, st, nt, e->d_perm.as<int>(),
+                       e->d_sig_tol.as<u64>(), e->d_sig_tolflags.as<unsigned>(), o, filt, e->row_words);
+    tm.mark("k_plane_tol");
+  }
+  if (aff_on) {
+    ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
+                    e->d_sig_pre_terms.as<u64>()};
+    ykk::PlaneOut o{e->fam_aff.canon.as<u64>(), e->fam_aff.ranked.as<u64>(), e->row_stride, e->fam_aff.D};
+    hipLaunchKernelGGL(ykk::k_plane_aff, dim3(wgroups, sig_chunks(e->fam_aff.D), zdim), dim3(ykk::kBlock), 0, st, nt, e->d_perm.as<int>(), as,
+                       o, pre, filt, e->row_words);
+    tm.mark("k_plane_aff");
+  }
+  // 3. combine → bitmap (+ class feasible counts)
+  ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>()};
+  // the class table stores plane rows for all three families; disabled families are masked out here
+  ykk::Planes pc{res_on ? e->fam_res.canon.as<u64>() : nullptr, e->fam_tol.canon.as<u64>(), aff_on ? e->fam_aff.canon.as<u64>() : nullptr,
+                 nullptr, e->row_stride};
+  ykk::Planes pr{res_on ? e->fam_res.ranked.as<u64>() : nullptr, e->fam_tol.ranked.as<u64>(), aff_on ? e->fam_aff.ranked.as<u64>() : nullptr,
+                 nullptr, e->row_stride};
+  const int pin_on = (filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0;
+  HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
+  {
+    const int seg = ykk::kBlock * ykk::kCombineUnroll;
+    dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
+    hipLaunchKernelGGL(ykk::k_combine, grid, dim3(ykk::kBlock), 0, st, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                       e->d_class_count.as<int>());
+    tm.mark("k_combine");
+  }
+  // 4. decisions
+  if (want_dec) {
+    hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct,
+                       pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
+    tm.mark("k_decide");
+  }
+  if (want_dec || want_cnt) {
+    hipLaunchKernelGGL(ykk::k_scatter, dim3((unsigned)((P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, P,
+                       e->d_pod_class.as<int>(), e->d_class_count.as<int>(), e->d_class_best.as<int>(), e->d_key.as<u64>(),
+                       want_cnt ? (int*)e->last_counts : nullptr, want_dec ? (int*)e->last_decisions : nullptr,
+                       want_keys ? (i64*)e->last_keys : nullptr);
+    tm.mark("k_scatter");
+  }
+  HIPCHK(hipGetLastError());
+  tm.done();
+  return YKPRED_OK;
+}
+
+int32_t ykpred_synchronize(ykpred_engine_t* e) {
+  if (!e) return YKPRED_E_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  return YKPRED_OK;
+}
+
+int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
+  if (!e || !o) return YKPRED_E_INVALID;
+  o->num_nodes = e->N;
+  o->num_pods = e->P;
+  o->num_specs = e->S;
+  o->num_classes = e->C;
+  o->row_words = e->row_words;
+  o->row_stride = e->row_stride;
+  o->num_chunks = e->NC;
+  o->plane_rows = e->fam_res.D + e->fam_tol.D + e->fam_aff.D;
+  o->bitmap_bytes = (uint64_t)e->P * (uint64_t)e->row_stride * sizeof(u64);
+  o->bitmap = e->last_bitmap;
+  o->counts = e->last_counts ? e->last_counts : e->d_counts.p;
+  o->decisions = e->last_decisions ? e->last_decisions : e->d_decisions.p;
+  o->decision_keys = e->last_keys ? e->last_keys : e->d_keys.p;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_last_timing(const ykpred_engine_t* ce, ykpred_timing_t* o) {
+  ykpred_engine_t* e = const_cast<ykpred_engine_t*>(ce);
+  if (!e || !o) return YKPRED_E_INVALID;
+  if (!e->timing_valid) return fail(e, YKPRED_E_STATE, "last eval was not run with YKPRED_EVAL_PROFILE");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->timed > 0) HIPCHK(hipEventSynchronize(e->ev[e->timed]));
+  o->num_kernels = e->timed;
+  o->total_ms = 0.f;
+  for (int i = 0; i < e->timed; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+    o->kernel_ms[i] = ms;
+    o->kernel_name[i] = e->timed_name[i];
+  }
+  if (e->timed > 0) HIPCHK(hipEventElapsedTime(&o->total_ms, e->ev[0], e->ev[e->timed]));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_read_bitmap(ykpred_engine_t* e, int32_t first, int32_t num, uint64_t* out) {
+  if (!e || !out || first < 0 || num < 0 || first + num > e->P) return fail(e, YKPRED_E_INVALID, "read_bitmap: range");
+  if (!e->last_bitmap) return fail(e, YKPRED_E_STATE, "read_bitmap: no eval yet");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  if (num == 0) return YKPRED_OK;
+  const u64* src = (const u64*)e->last_bitmap + (size_t)first * e->row_stride;
+  HIPCHK(hipMemcpy2D(out, (size_t)e->row_words * sizeof(u64), src, (size_t)e->row_stride * sizeof(u64), (size_t)e->row_words * sizeof(u64),
+                     (size_t)num, hipMemcpyDeviceToHost));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_read_counts(ykpred_engine_t* e, int32_t* out) {
+  if (!e || !out) return YKPRED_E_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  if (e->P) HIPCHK(hipMemcpy(out, e->last_counts ? e->last_counts : e->d_counts.p, (size_t)e->P * sizeof(int), hipMemcpyDeviceToHost));
+  return YKPRED_OK;
+}
+int32_t ykpred_read_decisions(ykpred_engine_t* e, int32_t* out) {
+  if (!e || !out) return YKPRED_E_INVALID;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  if (e->P) HIPCHK(hipMemcpy(out, e->last_decisions ? e->last_decisions : e->d_decisions.p, (size_t)e->P * sizeof(int), hipMemcpyDeviceToHost));
+  return YKPRED_OK;
+}
+int32_t ykpred_read_scores(ykpred_engine_t* e, double* out) {
+  if (!e || !out) return YKPRED_E_INVALID;
+  if (!e->nodes_set) return fail(e, YKPRED_E_STATE, "read_scores: no nodes");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->N) {
+    ykk::NodeTable nt = node_table(e);
+    hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)((e->N + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, e->own_stream, nt,
+                       e->d_score.as<double>(), e->d_key.as<u64>());
+    HIPCHK(hipStreamSynchronize(e->own_stream));
+    HIPCHK(hipMemcpy(out, e->d_score.p, (size_t)e->N * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return YKPRED_OK;
+}
+
+int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
+  if (!e || !out) return YKPRED_E_INVALID;
+  if (!e->last_bitmap) return fail(e, YKPRED_E_STATE, "checksum: no eval yet");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(e->d_scratch.ensure(sizeof(u64)));
+  HIPCHK(hipMemset(e->d_scratch.p, 0, sizeof(u64)));
+  if (e->P && e->row_words)
+    hipLaunchKernelGGL(ykk::k_checksum, dim3(2048), dim3(ykk::kBlock), 0, e->own_stream, (const u64*)e->last_bitmap, e->P, e->row_words,
+                       e->row_stride, e->d_scratch.as<u64>());
+  HIPCHK(hipStreamSynchronize(e->own_stream));
+  HIPCHK(hipMemcpy(out, e->d_scratch.p, sizeof(u64), hipMemcpyDeviceToHost));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const int32_t* nodes, uint32_t pre, uint32_t filt, uint8_t* fit,
+                     uint8_t* code, uint32_t* reason) {
+  if (!e || n < 0 || (n > 0 && (!pods || !nodes || !fit))) return fail(e, YKPRED_E_INVALID, "query: bad argument");
+  if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query: tables not uploaded");
+  for (int i = 0; i < n; ++i)
+    if (pods[i] < 0 || pods[i] >= e->P || nodes[i] < 0 || nodes[i] >= e->N) return fail(e, YKPRED_E_INVALID, "query: index out of range");
+  if (n == 0) return YKPRED_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  // scratch layout: pods | nodes | reason | fit | code
+  size_t need = (size_t)n * (3 * sizeof(int32_t) + 2);
+  HIPCHK(e->d_scratch.ensure(need + 64));
+  int32_t* d_p = e->d_scratch.as<int32_t>();
+  int32_t* d_n = d_p + n;
+  uint32_t* d_r = (uint32_t*)(d_n + n);
+  uint8_t* d_f = (uint8_t*)(d_r + n);
+  uint8_t* d_c = d_f + n;
+  HIPCHK(hipMemcpyAsync(d_p, pods, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_n, nodes, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ykk::k_query, dim3((unsigned)((n + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, node_table(e),
+                     spec_table(e), n, d_p, d_n, e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre, filt, d_f, d_c, d_r);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(fit, d_f, (size_t)n, hipMemcpyDeviceToHost, st));
+  if (code) HIPCHK(hipMemcpyAsync(code, d_c, (size_t)n, hipMemcpyDeviceToHost, st));
+  if (reason) HIPCHK(hipMemcpyAsync(reason, d_r, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
+                          int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
+  if (!e || !out || nv < 0 || start < 0 || (nv > 0 && (!vreq || !vpresent))) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");
+  if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "preemption: tables not uploaded");
+  if (pod < 0 || pod >= e->P || node < 0 || node >= e->N) return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  size_t vbytes = (size_t)nv * (size_t)e->R * sizeof(i64);
+  HIPCHK(e->d_scratch.ensure(vbytes + (size_t)nv + 64));
+  i64* d_v = e->d_scratch.as<i64>();
+  uint8_t* d_pr = (uint8_t*)e->d_scratch.p + vbytes;
+  int* d_out = (int*)((uint8_t*)e->d_scratch.p + ((vbytes + (size_t)nv + 7) / 8 * 8));
+  if (nv) {
+    HIPCHK(hipMemcpyAsync(d_v, vreq, vbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_pr, vpresent, (size_t)nv, hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(ykk::k_preempt, dim3(1), dim3(64), 0, st, node_table(e), spec_table(e), e->h_pod_spec[(size_t)pod],
+                     e->h_pod_pin[(size_t)pod], node, nv, d_v, d_pr, start, pre, filt, d_out);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, d_out, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,599 @@
+// kernels.hip.h — hand-written HIP kernels of the ykpred engine, gfx950 (MI355X / CDNA4) only.
+//
+// The hot path replaces the reference's per-(pod,node) Predicates() loop
+// (/root/reference/pkg/plugin/predicates/predicate_manager.go:206-283) with three device stages:
+//
+//   1. SIGNATURE PLANES (k_plane_*): pods are grouped by what each plugin can see of them. Every distinct
+//      request vector, toleration mask and node-selector DNF ("signature") is evaluated ONCE against all N
+//      nodes: lane = node, one wave = 64 nodes, `__ballot` packs the 64 verdicts into one u64 word of the
+//      signature's N-bit plane. Node columns are read coalesced from the structure-of-arrays tables and held
+//      in registers while the wave walks the signatures (signature data is wave-uniform → scalar loads).
+//   2. COMBINE (k_combine): a pod class = tuple of signatures (+ pinned node). Its bitmap row is the AND of
+//      its planes; the block holds that row in registers and streams it to the bitmap row of every member
+//      pod — sequential 6 KB row writes, no per-pair arithmetic left. `__popcll` of the row gives the class's
+//      feasible-node count. This kernel writes the P×N/8-byte bitmap and is HBM-write bound.
+//   3. DECIDE (k_decide): planes are also produced in bin-pack rank order, so the best feasible node of a
+//      class is the first set bit of the AND of its rank-ordered planes (early exit).
+//
+// k_direct is the per-pair formulation (lane = node, wave walks pods) kept as the on-device cross-check and
+// as the ablation baseline; k_query answers single Predicates() calls including the first failing plugin.
+//
+// No MFMA anywhere: the path is integer compare / bitmask / popcount, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ykk {
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+// compile-time ceilings of the register-resident node columns (checked in ykpred_create)
+constexpr int kMaxR = 8;   // resource dimensions
+constexpr int kMaxKT = 4;  // taint dictionary words (256 taints)
+constexpr int kMaxW = 8;   // requirement dictionary words (512 requirements)
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kSigsPerBlock = 64;   // signatures walked by one plane block (one ballot word per lane)
+constexpr int kChunkMembers = 64;   // member pods per combine chunk (member ids live in the lanes of a wave)
+constexpr int kCombineUnroll = 4;   // row words per thread held in registers by k_combine
+
+// plugin bits (mirror include/ykpred.h)
+constexpr unsigned kPlugUnsched = 1u << 0, kPlugNodeName = 1u << 1, kPlugTaint = 1u << 2, kPlugAffinity = 1u << 3,
+                   kPlugFit = 1u << 5, kPlugSpread = 1u << 6;
+constexpr unsigned kSpecToleratesUnsched = 1u << 0, kSpecAffSkip = 1u << 1, kSpecPreReject = 1u << 2, kSpecPreNames = 1u << 3;
+constexpr unsigned kNodeUnschedulable = 1u << 0;
+
+struct NodeTable {
+  int n;               // nodes
+  int R, KT, W;        // dims
+  const i64* alloc;    // [R][n]
+  const i64* req;      // [R][n]
+  const int* allowed;  // [n]
+  const int* count;    // [n]
+  const unsigned* flags;  // [n]
+  const u64* taints;   // [KT][n]
+  const u64* labels;   // [W][n]
+};
+
+// ---------------------------------------------------------------------------------------------------
+// bin-pack score + rank
+// ---------------------------------------------------------------------------------------------------
+// score(n) = 1 - (Σ_{r∈{cpu,mem}, total_r>0} (1 - avail_r/total_r)) / #r   in float64, the exact operation
+// order written in DESIGN.md §"bin-pack score contract" (no multiplies ⇒ nothing for FMA contraction to fuse).
+__device__ __forceinline__ double node_score(const NodeTable& t, int n) {
+  double sum = 0.0, wsum = 0.0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    i64 total = t.alloc[(size_t)r * t.n + n];
+    i64 used = t.req[(size_t)r * t.n + n];
+    if (total <= 0) continue;
+    double avail = (double)(total - used);
+    double share = 1.0 - avail / (double)total;
+    sum = sum + share;
+    wsum = wsum + 1.0;
+  }
+  if (wsum == 0.0) return 1.0;
+  return 1.0 - sum / wsum;
+}
+__device__ __forceinline__ u64 sortable_key(double s) {
+  u64 b = (u64)__double_as_longlong(s);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ __launch_bounds__(kBlock) void k_score(NodeTable t, double* __restrict__ score, u64* __restrict__ key) {
+  int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= t.n) return;
+  double s = node_score(t, n);
+  score[n] = s;
+  key[n] = sortable_key(s);
+}
+// rank[n] = #{m : (key_m, m) < (key_n, n)}; perm[rank[n]] = n. O(N²) compares through an LDS tile of keys:
+// 50k nodes = 2.5e9 compares ≈ 0.2 ms on 256 CUs — cheaper than a multi-pass sort at this N.
+__global__ __launch_bounds__(kBlock) void k_rank(int n_nodes, const u64* __restrict__ key, int* __restrict__ rank,
+                                                 int* __restrict__ perm) {
+  __shared__ u64 tile[kBlock];
+  int n = blockIdx.x * kBlock + threadIdx.x;
+  u64 mine = n < n_nodes ? key[n] : ~0ull;
+  int r = 0;
+  for (int base = 0; base < n_nodes; base += kBlock) {
+    int m = base + threadIdx.x;
+    tile[threadIdx.x] = m < n_nodes ? key[m] : ~0ull;
+    __syncthreads();
+    int lim = min(kBlock, n_nodes - base);
+    for (int j = 0; j < lim; ++j) {
+      u64 k = tile[j];
+      r += (k < mine) || (k == mine && (base + j) < n);
+    }
+    __syncthreads();
+  }
+  if (n < n_nodes) {
+    rank[n] = r;
+    perm[r] = n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// signature planes
+// ---------------------------------------------------------------------------------------------------
+struct PlaneOut {
+  u64* canon;   // [D][stride]
+  u64* ranked;  // [D][stride] (node axis permuted by bin-pack rank), may be null
+  int stride;   // words per plane row
+  int D;        // signatures
+};
+
+// blockIdx.x: group of 4 node words; blockIdx.y: chunk of kSigsPerBlock signatures; blockIdx.z: 0 canonical, 1 ranked.
+// Returns the node handled by this lane (-1 = past the end) and the word index.
+__device__ __forceinline__ int plane_node(int n_nodes, const int* __restrict__ perm, int* word) {
+  int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  int w = blockIdx.x * kWavesPerBlock + wave;
+  *word = w;
+  int pos = w * kWave + lane;
+  if (pos >= n_nodes) return -1;
+  return blockIdx.z ? perm[pos] : pos;
+}
+__device__ __forceinline__ void plane_store(const PlaneOut& o, int word, int d0, u64 keep) {
+  int lane = threadIdx.x % kWave;
+  int d = d0 + lane;
+  if (word < o.stride && d < o.D) {
+    u64* base = blockIdx.z ? o.ranked : o.canon;
+    base[(size_t)d * o.stride + word] = keep;
+  }
+}
+
+// NodeResourcesFit.Filter: fail ⇔ count+1 > allowed ∨ ∃r: req_r > 0 ∧ req_r > alloc_r − requested_r.
+// One signature = one distinct request vector. `fit_error`: Filter enabled without its PreFilter (no cycle state).
+__global__ __launch_bounds__(kBlock) void k_plane_res(NodeTable t, const int* __restrict__ perm, const i64* __restrict__ sig_req /*[D][R]*/,
+                                                      PlaneOut o, int fit_error, int n_words) {
+  int word;
+  int n = plane_node(t.n, perm, &word);
+  if (word >= n_words) return;
+  i64 fr[kMaxR];
+  bool slots_ok = false;
+#pragma unroll
+  for (int r = 0; r < kMaxR; ++r) fr[r] = 0;
+  if (n >= 0) {
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r)
+      if (r < t.R) fr[r] = t.alloc[(size_t)r * t.n + n] - t.req[(size_t)r * t.n + n];
+    slots_ok = (i64)t.count[n] + 1 <= (i64)t.allowed[n];
+  }
+  int d0 = blockIdx.y * kSigsPerBlock;
+  int dend = min(d0 + kSigsPerBlock, o.D);
+  u64 keep = 0;
+  for (int d = d0; d < dend; ++d) {
+    const i64* v = sig_req + (size_t)d * t.R;
+    bool ok = n >= 0 && slots_ok && !fit_error;
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r)
+      if (r < t.R) {
+        i64 q = v[r];
+        ok = ok && !(q > 0 && q > fr[r]);
+      }
+    u64 b = __ballot(ok);
+    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
+  }
+  plane_store(o, word, d0, keep);
+}
+
+// TaintToleration.Filter + NodeUnschedulable.Filter (A.4, A.7). Signature = (tolerated mask, tolerates-unschedulable).
+__global__ __launch_bounds__(kBlock) void k_plane_tol(NodeTable t, const int* __restrict__ perm, const u64* __restrict__ sig_tol /*[D][KT]*/,
+                                                      const unsigned* __restrict__ sig_flags /*[D]*/, PlaneOut o, unsigned filt_mask,
+                                                      int n_words) {
+  int word;
+  int n = plane_node(t.n, perm, &word);
+  if (word >= n_words) return;
+  u64 tn[kMaxKT];
+  bool unsched = false;
+#pragma unroll
+  for (int k = 0; k < kMaxKT; ++k) tn[k] = 0;
+  if (n >= 0) {
+#pragma unroll
+    for (int k = 0; k < kMaxKT; ++k)
+      if (k < t.KT) tn[k] = t.taints[(size_t)k * t.n + n];
+    unsched = t.flags[n] & kNodeUnschedulable;
+  }
+  const bool taint_en = filt_mask & kPlugTaint, unsched_en = filt_mask & kPlugUnsched;
+  int d0 = blockIdx.y * kSigsPerBlock;
+  int dend = min(d0 + kSigsPerBlock, o.D);
+  u64 keep = 0;
+  for (int d = d0; d < dend; ++d) {
+    const u64* tol = sig_tol + (size_t)d * t.KT;
+    bool ok = n >= 0;
+    if (taint_en) {
+#pragma unroll
+      for (int k = 0; k < kMaxKT; ++k)
+        if (k < t.KT) ok = ok && (tn[k] & ~tol[k]) == 0;
+    }
+    if (unsched_en) ok = ok && (!unsched || (sig_flags[d] & kSpecToleratesUnsched));
+    u64 b = __ballot(ok);
+    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
+  }
+  plane_store(o, word, d0, keep);
+}
+
+// NodeAffinity PreFilter + Filter (A.5). Signature = (flags, Filter DNF, PreFilter node-name DNF).
+struct AffSigs {
+  const unsigned* flags;  // [D]
+  const int* term_off;    // [D+1]
+  const u64* terms;       // [T][W]
+  const int* pre_off;     // [D+1]
+  const u64* pre_terms;   // [M][W]
+};
+__device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0, int t1, const u64 (&lb)[kMaxW], int W) {
+  bool any = false;
+  for (int t = t0; t < t1; ++t) {
+    const u64* m = terms + (size_t)t * W;
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < kMaxW; ++w)
+      if (w < W) all = all && (lb[w] & m[w]) == m[w];
+    any = any || all;
+  }
+  return any;
+}
+__device__ __forceinline__ bool affinity_ok(const AffSigs& s, int d, const u64 (&lb)[kMaxW], int W, unsigned pre_mask, unsigned filt_mask,
+                                            unsigned* reason_code) {
+  unsigned f = s.flags[d];
+  bool pre_en = pre_mask & kPlugAffinity, filt_en = filt_mask & kPlugAffinity;
+  bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
+  if (pre_en && !skip) {
+    if (f & kSpecPreReject) {
+      if (reason_code) *reason_code = 2;  // PreFilter rejected the pod (:236-238)
+      return false;
+    }
+    if ((f & kSpecPreNames) && !dnf_match(s.pre_terms, s.pre_off[d], s.pre_off[d + 1], lb, W)) {
+      if (reason_code) *reason_code = 1;  // "node not eligible" (:248-250)
+      return false;
+    }
+  }
+  if (filt_en && !skip && !dnf_match(s.terms, s.term_off[d], s.term_off[d + 1], lb, W)) {
+    if (reason_code) *reason_code = 0;
+    return false;
+  }
+  return true;
+}
+__global__ __launch_bounds__(kBlock) void k_plane_aff(NodeTable t, const int* __restrict__ perm, AffSigs s, PlaneOut o, unsigned pre_mask,
+                                                      unsigned filt_mask, int n_words) {
+  int word;
+  int n = plane_node(t.n, perm, &word);
+  if (word >= n_words) return;
+  u64 lb[kMaxW];
+#pragma unroll
+  for (int w = 0; w < kMaxW; ++w) lb[w] = 0;
+  if (n >= 0) {
+#pragma unroll
+    for (int w = 0; w < kMaxW; ++w)
+      if (w < t.W) lb[w] = t.labels[(size_t)w * t.n + n];
+  }
+  int d0 = blockIdx.y * kSigsPerBlock;
+  int dend = min(d0 + kSigsPerBlock, o.D);
+  u64 keep = 0;
+  for (int d = d0; d < dend; ++d) {
+    bool ok = n >= 0 && affinity_ok(s, d, lb, t.W, pre_mask, filt_mask, nullptr);
+    u64 b = __ballot(ok);
+    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
+  }
+  plane_store(o, word, d0, keep);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// combine: class row = AND of its planes; stream it into every member pod's bitmap row
+// ---------------------------------------------------------------------------------------------------
+struct ClassTable {
+  const int* sig;       // [C][4]: res, tol, aff, spread plane row (-1 = family not evaluated ⇒ all ones)
+  const int* pin;       // [C]: pinned node (NodeName), -1 none, -2 unknown name
+  const int* chunk_class;  // [NC]
+  const int* chunk_begin;  // [NC] offset into members
+  const int* chunk_len;    // [NC] 1..kChunkMembers
+  const int* chunk_first;  // [NC] 1 = first chunk of its class (owns the popcount)
+  const int* members;      // [P] pod ids grouped by class
+};
+struct Planes {
+  const u64* res;
+  const u64* tol;
+  const u64* aff;
+  const u64* spread;
+  int stride;
+};
+
+__device__ __forceinline__ u64 class_word(const Planes& pl, int sr, int st, int sa, int ss, int w) {
+  u64 v = ~0ull;
+  // a null family pointer = plugin family disabled for this eval (wave-uniform branches)
+  if (pl.res && sr >= 0) v &= pl.res[(size_t)sr * pl.stride + w];
+  if (pl.tol && st >= 0) v &= pl.tol[(size_t)st * pl.stride + w];
+  if (pl.aff && sa >= 0) v &= pl.aff[(size_t)sa * pl.stride + w];
+  if (pl.spread && ss >= 0) v &= pl.spread[(size_t)ss * pl.stride + w];
+  return v;
+}
+
+// grid.x = chunks, grid.y = row super-segments of kBlock*kCombineUnroll words. Each thread owns
+// kCombineUnroll words of the class row (word = seg_base + u*kBlock + tid ⇒ every wave store is 512 B contiguous).
+__global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
+                                                    int pin_enabled, int* __restrict__ class_count) {
+  const int chunk = blockIdx.x;
+  const int cls = ct.chunk_class[chunk];
+  const int begin = ct.chunk_begin[chunk];
+  const int len = ct.chunk_len[chunk];
+  const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
+  const int pin = pin_enabled ? ct.pin[cls] : -1;
+  const int lane = threadIdx.x % kWave;
+  const int seg_base = blockIdx.y * (kBlock * kCombineUnroll);
+
+  u64 v[kCombineUnroll];
+  int pc = 0;
+#pragma unroll
+  for (int u = 0; u < kCombineUnroll; ++u) {
+    int w = seg_base + u * kBlock + threadIdx.x;
+    u64 x = 0;
+    if (w < row_words) {
+      x = class_word(pl, sr, st, sa, ss, w);
+      if (pin == -2)
+        x = 0;
+      else if (pin >= 0)
+        x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+    }
+    v[u] = x;
+    pc += __popcll(x);
+  }
+  if (ct.chunk_first[chunk]) {
+    // feasible-node count of the class: wave reduce, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
+    if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+  }
+  // member ids: lane i of every wave holds member i (one coalesced 256 B load), broadcast by v_readlane
+  int mine = lane < len ? ct.members[begin + lane] : 0;
+  for (int i = 0; i < len; ++i) {
+    int p = __builtin_amdgcn_readlane(mine, i);
+    u64* row = bitmap + (size_t)p * row_stride;
+#pragma unroll
+    for (int u = 0; u < kCombineUnroll; ++u) {
+      int w = seg_base + u * kBlock + threadIdx.x;
+      if (w < row_stride) row[w] = v[u];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decide: best feasible node of a class = first set bit in bin-pack rank order
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked, int n_classes, int row_words, const int* __restrict__ perm,
+                                                   const int* __restrict__ rank, int pin_enabled, int* __restrict__ class_best) {
+  int cls = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (cls >= n_classes) return;
+  const int lane = threadIdx.x % kWave;
+  const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
+  const int pin = pin_enabled ? ct.pin[cls] : -1;
+  int best = -1;
+  if (pin == -2) {
+    best = -1;
+  } else if (pin >= 0) {
+    int pos = rank[pin];
+    u64 x = class_word(ranked, sr, st, sa, ss, pos >> 6);
+    best = ((x >> (pos & 63)) & 1ull) ? pin : -1;
+  } else {
+    for (int base = 0; base < row_words; base += kWave) {
+      int w = base + lane;
+      u64 x = w < row_words ? class_word(ranked, sr, st, sa, ss, w) : 0ull;
+      u64 any = __ballot(x != 0);
+      if (any) {
+        int first_lane = __ffsll((long long)any) - 1;
+        u64 xw = __shfl(x, first_lane, kWave);
+        int pos = (base + first_lane) * kWave + (__ffsll((long long)xw) - 1);
+        best = perm[pos];
+        break;
+      }
+    }
+  }
+  if (lane == 0) class_best[cls] = best;
+}
+
+// decision key = order-preserving signed image of the node's sortable score key (smaller = earlier in bin-pack order)
+__global__ __launch_bounds__(kBlock) void k_scatter(int n_pods, const int* __restrict__ pod_class, const int* __restrict__ class_count,
+                                                    const int* __restrict__ class_best, const u64* __restrict__ node_key,
+                                                    int* __restrict__ counts, int* __restrict__ decisions, i64* __restrict__ keys) {
+  int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pods) return;
+  int c = pod_class[p];
+  if (counts) counts[p] = class_count[c];
+  int b = (decisions || keys) ? class_best[c] : -1;
+  if (decisions) decisions[p] = b;
+  if (keys) keys[p] = b >= 0 ? (i64)(node_key[b] ^ 0x8000000000000000ull) : 0x7fffffffffffffffll;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-pair evaluation straight from the tables (k_direct: whole grid; k_query: listed pairs)
+// ---------------------------------------------------------------------------------------------------
+struct SpecTable {
+  int R, KT, W;
+  const i64* req;        // [S][R]
+  const u64* tol;        // [S][KT]
+  const unsigned* flags; // [S]
+  AffSigs aff;           // indexed by spec
+};
+
+struct NodeRegs {
+  i64 fr[kMaxR];
+  u64 tn[kMaxKT];
+  u64 lb[kMaxW];
+  bool slots_ok, unsched;
+};
+__device__ __forceinline__ void load_node(const NodeTable& t, int n, NodeRegs* r) {
+#pragma unroll
+  for (int i = 0; i < kMaxR; ++i) r->fr[i] = (i < t.R && n >= 0) ? t.alloc[(size_t)i * t.n + n] - t.req[(size_t)i * t.n + n] : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxKT; ++i) r->tn[i] = (i < t.KT && n >= 0) ? t.taints[(size_t)i * t.n + n] : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxW; ++i) r->lb[i] = (i < t.W && n >= 0) ? t.labels[(size_t)i * t.n + n] : 0;
+  r->slots_ok = n >= 0 && (i64)t.count[n] + 1 <= (i64)t.allowed[n];
+  r->unsched = n >= 0 && (t.flags[n] & kNodeUnschedulable);
+}
+
+// One Predicates() call: PreFilter pass, then the ordered Filter list with early exit
+// (predicate_manager.go:206-283). Returns fit; *code / *reason describe the first failure.
+__device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin, int node, const NodeRegs& nr, unsigned pre_mask,
+                                          unsigned filt_mask, int* code, unsigned* reason) {
+  unsigned f = s.flags[spec];
+  *code = 0;
+  *reason = 0;
+  // --- PreFilter plugins, MultiPoint order: NodeAffinity, NodeResourcesFit (never rejects), PodTopologySpread
+  if ((pre_mask & kPlugAffinity) && !(f & kSpecAffSkip)) {
+    if (f & kSpecPreReject) {
+      *code = 0;
+      *reason = 1u << 2;
+      return false;
+    }
+    if ((f & kSpecPreNames) && !dnf_match(s.aff.pre_terms, s.aff.pre_off[spec], s.aff.pre_off[spec + 1], nr.lb, s.W)) {
+      *code = 4;
+      *reason = 1u << 1;
+      return false;
+    }
+  }
+  // --- Filter plugins
+  if ((filt_mask & kPlugUnsched) && nr.unsched && !(f & kSpecToleratesUnsched)) {
+    *code = 1;
+    return false;
+  }
+  if ((filt_mask & kPlugNodeName) && pin != -1 && pin != node) {
+    *code = 2;
+    return false;
+  }
+  if (filt_mask & kPlugTaint) {
+    const u64* tol = s.tol + (size_t)spec * s.KT;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < kMaxKT; ++k)
+      if (k < s.KT) ok = ok && (nr.tn[k] & ~tol[k]) == 0;
+    if (!ok) {
+      *code = 3;
+      return false;
+    }
+  }
+  if (filt_mask & kPlugAffinity) {
+    bool skip = (pre_mask & kPlugAffinity) && (f & kSpecAffSkip);
+    if (!skip && !dnf_match(s.aff.terms, s.aff.term_off[spec], s.aff.term_off[spec + 1], nr.lb, s.W)) {
+      *code = 4;
+      return false;
+    }
+  }
+  if (filt_mask & kPlugFit) {
+    unsigned why = 0;
+    if (!(pre_mask & kPlugFit)) {
+      *code = 6;  // Filter without PreFilter state: Error status (:269-277)
+      return false;
+    }
+    if (!nr.slots_ok) why |= 1u;
+    const i64* q = s.req + (size_t)spec * s.R;
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r)
+      if (r < s.R && q[r] > 0 && q[r] > nr.fr[r]) why |= 1u << (8 + r);
+    if (why) {
+      *code = 6;
+      *reason = why;
+      return false;
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(kBlock) void k_query(NodeTable t, SpecTable s, int n_pairs, const int* __restrict__ pods,
+                                                  const int* __restrict__ nodes, const int* __restrict__ pod_spec,
+                                                  const int* __restrict__ pod_pin, unsigned pre_mask, unsigned filt_mask,
+                                                  unsigned char* __restrict__ fit, unsigned char* __restrict__ code_out,
+                                                  unsigned* __restrict__ reason_out) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_pairs) return;
+  int p = pods[i], n = nodes[i];
+  NodeRegs nr;
+  load_node(t, n, &nr);
+  int code;
+  unsigned reason;
+  bool ok = eval_pair(s, pod_spec[p], pod_pin[p], n, nr, pre_mask, filt_mask, &code, &reason);
+  fit[i] = ok ? 1 : 0;
+  if (code_out) code_out[i] = (unsigned char)code;
+  if (reason_out) reason_out[i] = reason;
+}
+
+// Per-pair grid: blockIdx.x = group of 4 node words, blockIdx.y = chunk of 64 pods. lane = node, the wave walks the
+// 64 pods of its chunk (pod data wave-uniform), ballot → lane (i) keeps pod i's word → 64 row stores.
+__global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int n_pods, const int* __restrict__ pod_spec,
+                                                   const int* __restrict__ pod_pin, unsigned pre_mask, unsigned filt_mask,
+                                                   u64* __restrict__ bitmap, int row_words, int row_stride) {
+  int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  int w = blockIdx.x * kWavesPerBlock + wave;
+  if (w >= row_stride) return;
+  int n = w * kWave + lane;
+  if (n >= t.n) n = -1;
+  NodeRegs nr;
+  load_node(t, n, &nr);
+  int p0 = blockIdx.y * kWave;
+  int pend = min(p0 + kWave, n_pods);
+  u64 keep = 0;
+  for (int p = p0; p < pend; ++p) {
+    int code;
+    unsigned reason;
+    bool ok = n >= 0 && eval_pair(s, pod_spec[p], pod_pin[p], n, nr, pre_mask, filt_mask, &code, &reason);
+    u64 b = __ballot(ok);
+    if (p - p0 == lane) keep = b;
+  }
+  int p = p0 + lane;
+  if (p < n_pods) bitmap[(size_t)p * row_stride + w] = (w < row_words) ? keep : 0ull;
+}
+
+// PreemptionPredicates (predicate_manager.go:141-179): single (pod,node); victims removed in order.
+__global__ void k_preempt(NodeTable t, SpecTable s, int spec, int pin, int node, int n_victims, const i64* __restrict__ vreq,
+                          const unsigned char* __restrict__ vpresent, int start, unsigned pre_mask, unsigned filt_mask,
+                          int* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  NodeRegs nr;
+  load_node(t, node, &nr);
+  int code;
+  unsigned reason;
+  // PreFilter check first (:146-155): evaluate with filters disabled to see only PreFilter failures
+  if (!eval_pair(s, spec, pin, node, nr, pre_mask, 0u, &code, &reason)) {
+    *out = -1;
+    return;
+  }
+  i64 pods_on_node = t.count[node];
+  i64 allowed = t.allowed[node];
+  int result = -1;
+  for (int i = 0; i < n_victims; ++i) {
+    if (vpresent[i]) {  // removePodFromNodeNoFail (:181-192)
+      for (int r = 0; r < s.R && r < kMaxR; ++r) nr.fr[r] += vreq[(size_t)i * s.R + r];
+      pods_on_node -= 1;
+    }
+    if (i < start) continue;  // :161-163
+    nr.slots_ok = pods_on_node + 1 <= allowed;
+    // PreFilter outcomes were accepted above; eval_pair re-checks them (idempotent) and runs the filters (:168)
+    if (eval_pair(s, spec, pin, node, nr, pre_mask, filt_mask, &code, &reason)) {
+      result = i;
+      break;
+    }
+  }
+  *out = result;
+}
+
+// order-independent checksum of the bitmap: Σ mix64(word ⊕ position-salt) over the meaningful words
+__device__ __forceinline__ u64 mix64(u64 z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_checksum(const u64* __restrict__ bitmap, int n_pods, int row_words, int row_stride,
+                                                     u64* __restrict__ out) {
+  size_t total = (size_t)n_pods * row_words;
+  u64 acc = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    size_t p = i / row_words, w = i % row_words;
+    u64 x = bitmap[p * row_stride + w];
+    acc += mix64(x ^ ((i + 1) * 0x9e3779b97f4a7c15ull));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+  if (threadIdx.x % kWave == 0) atomicAdd(out, acc);
+}
+
+}  // namespace ykk

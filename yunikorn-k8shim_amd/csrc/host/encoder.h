@@ -1,0 +1,383 @@
+// encoder.h — object model → the structure-of-arrays tables of include/ykpred.h.
+//
+// This is the work the Go side does ONCE per pod / node update instead of once per (pod,node) pair:
+//   * request vectors (pkg/common/resource.go:56-109 → int64 per resource dimension),
+//   * a taint dictionary: every distinct NoSchedule/NoExecute (key,value,effect) on any node gets a bit; a node
+//     is the OR of its taints' bits, a pod spec the set of dictionary taints its tolerations tolerate
+//     (v1.Toleration.ToleratesTaint) — TaintToleration.Filter becomes (taints & ~tolerated) == 0,
+//   * a requirement dictionary: every distinct node-selector requirement that some pod uses (label
+//     expressions, nodeSelector pairs, matchFields, PreFilter node names) gets a bit, evaluated once per node
+//     with the full apimachinery semantics (validation, In/NotIn/Exists/DoesNotExist/Gt/Lt); a selector
+//     term becomes a mask and NodeAffinity.Filter becomes "some term's mask ⊆ node bits".
+// Pods carrying features the engine does not evaluate (host ports, inter-pod affinity, volumes, hard
+// topology-spread constraints in this build) are REJECTED with an error — never silently passed, and there
+// is no CPU evaluation fallback in this library.
+#pragma once
+#include <algorithm>
+#include <limits>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/ykpred.h"
+#include "objects.h"
+
+namespace ykh {
+
+// ---- apimachinery validation (labels.NewRequirement); pin: predicate_manager_test.go:793-820 -------------
+inline bool is_alnum(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9'); }
+inline bool is_name_part(const std::string& s) {
+  if (s.empty() || s.size() > 63) return false;
+  if (!is_alnum(s.front()) || !is_alnum(s.back())) return false;
+  for (char c : s)
+    if (!is_alnum(c) && c != '-' && c != '_' && c != '.') return false;
+  return true;
+}
+inline bool is_dns1123_subdomain(const std::string& s) {
+  if (s.empty() || s.size() > 253) return false;
+  auto ok = [](char c) { return (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9'); };
+  size_t start = 0;
+  for (;;) {
+    size_t dot = s.find('.', start);
+    size_t end = dot == std::string::npos ? s.size() : dot;
+    if (end == start) return false;
+    if (!ok(s[start]) || !ok(s[end - 1])) return false;
+    for (size_t i = start; i < end; ++i)
+      if (!ok(s[i]) && s[i] != '-') return false;
+    if (dot == std::string::npos) return true;
+    start = dot + 1;
+  }
+}
+inline bool is_qualified_name(const std::string& k) {
+  size_t slash = k.find('/');
+  if (slash == std::string::npos) return is_name_part(k);
+  if (k.find('/', slash + 1) != std::string::npos) return false;
+  return is_dns1123_subdomain(k.substr(0, slash)) && is_name_part(k.substr(slash + 1));
+}
+inline bool is_valid_label_value(const std::string& v) { return v.empty() || is_name_part(v); }
+inline bool parse_int64(const std::string& s, int64_t* out) {  // strconv.ParseInt(s, 10, 64)
+  size_t p = 0;
+  bool neg = false;
+  if (p < s.size() && (s[p] == '+' || s[p] == '-')) neg = s[p++] == '-';
+  if (p >= s.size()) return false;
+  unsigned __int128 v = 0;
+  const unsigned __int128 lim = (unsigned __int128)1 << 63;
+  for (; p < s.size(); ++p) {
+    if (s[p] < '0' || s[p] > '9') return false;
+    v = v * 10 + (unsigned)(s[p] - '0');
+    if (v > lim) return false;
+  }
+  if (!neg && v >= lim) return false;
+  *out = neg ? (int64_t)(-(__int128)v) : (int64_t)v;
+  return true;
+}
+inline bool valid_label_requirement(const Requirement& r) {
+  if (!is_qualified_name(r.key)) return false;
+  if (r.op == "In" || r.op == "NotIn") {
+    if (r.values.empty()) return false;
+  } else if (r.op == "Exists" || r.op == "DoesNotExist") {
+    if (!r.values.empty()) return false;
+  } else if (r.op == "Gt" || r.op == "Lt") {
+    int64_t tmp;
+    if (r.values.size() != 1 || !parse_int64(r.values[0], &tmp)) return false;
+  } else {
+    return false;
+  }
+  for (auto& v : r.values)
+    if (!is_valid_label_value(v)) return false;
+  return true;
+}
+inline bool label_requirement_matches(const Requirement& r, const StrMap& labels) {  // labels.Requirement.Matches
+  auto it = labels.find(r.key);
+  bool has = it != labels.end();
+  auto in = [&](const std::string& v) { return std::find(r.values.begin(), r.values.end(), v) != r.values.end(); };
+  if (r.op == "In") return has && in(it->second);
+  if (r.op == "NotIn") return !has || !in(it->second);
+  if (r.op == "Exists") return has;
+  if (r.op == "DoesNotExist") return !has;
+  if (r.op == "Gt" || r.op == "Lt") {
+    int64_t lv, rv;
+    if (!has || !parse_int64(it->second, &lv) || r.values.size() != 1 || !parse_int64(r.values[0], &rv)) return false;
+    return r.op == "Gt" ? lv > rv : lv < rv;
+  }
+  return false;
+}
+inline bool toleration_tolerates(const Toleration& t, const Taint& taint) {  // v1.Toleration.ToleratesTaint
+  if (!t.effect.empty() && t.effect != taint.effect) return false;
+  if (!t.key.empty() && t.key != taint.key) return false;
+  if (t.op.empty() || t.op == "Equal") return t.value == taint.value;
+  return t.op == "Exists";
+}
+
+// ---- dictionary entries -------------------------------------------------------------------------------
+struct DictReq {
+  enum Kind { kLabel, kEquals, kField, kNameIn } kind;
+  Requirement req;  // kLabel: validated requirement; kEquals: key + values[0]; kField: key/op/values[0]; kNameIn: values[0]
+  bool eval(const Node& n) const {
+    switch (kind) {
+      case kLabel: return label_requirement_matches(req, n.labels);
+      case kEquals: {
+        auto it = n.labels.find(req.key);
+        return it != n.labels.end() && it->second == req.values[0];
+      }
+      case kField: {
+        // nodeSelectorTerm.match consults matchFields only when the node has a name (extractNodeFields)
+        if (n.name.empty()) return true;
+        std::string fv = req.key == "metadata.name" ? n.name : std::string();
+        bool eq = fv == req.values[0];
+        return req.op == "In" ? eq : !eq;
+      }
+      case kNameIn: return n.name == req.values[0];
+    }
+    return false;
+  }
+};
+
+struct EncodedSpec {
+  std::vector<int64_t> req;          // [R]
+  std::vector<uint64_t> tol;         // [KT]
+  uint32_t flags = 0;
+  std::vector<std::vector<uint64_t>> terms, pre_terms;  // each [W]
+};
+
+class Encoder {
+ public:
+  std::string error;
+  int R = 3, KT = 1, W = 1;
+  std::vector<std::string> scalar_names;  // resource dimension 3+i
+  std::vector<Taint> taint_dict;
+  std::vector<DictReq> req_dict;
+
+  // Builds every dictionary from the current objects. Returns false (error set) on unsupported input.
+  bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates) {
+    error.clear();
+    scalar_names.clear();
+    taint_dict.clear();
+    req_dict.clear();
+    scalar_ix_.clear();
+    taint_ix_.clear();
+    req_ix_.clear();
+    for (const PodTemplate* t : templates) {
+      if (t->pod_affinity) return fail("inter-pod affinity is outside the engine's plugin set (InterPodAffinity)");
+      for (auto& c : t->containers)
+        if (c.host_ports) return fail("host ports are outside the engine's plugin set (NodePorts)");
+      for (auto& c : t->spread)
+        if (c.when_unsatisfiable == "DoNotSchedule") return fail("hard topologySpreadConstraints are not supported by this build (PodTopologySpread)");
+      for (auto& kv : t->requests)
+        if (is_scalar_resource_name(kv.first)) scalar(kv.first);
+    }
+    for (const NodeInfo* ni : nodes) {
+      for (auto& kv : ni->allocatable.scalar) scalar(kv.first);
+      for (auto& kv : ni->requested.scalar) scalar(kv.first);
+      for (auto& t : ni->node.taints)
+        if (t.effect == "NoSchedule" || t.effect == "NoExecute") taint(t);
+    }
+    R = 3 + (int)scalar_names.size();
+    KT = std::max(1, ((int)taint_dict.size() + 63) / 64);
+    // requirement dictionary: walk every template's selector AST
+    for (const PodTemplate* t : templates) collect_requirements(*t);
+    W = std::max(1, ((int)req_dict.size() + 63) / 64);
+    if (R > 8) return fail("more than 5 scalar resource names in use (engine limit R<=8)");
+    if (KT > 4) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
+    if (W > 8) return fail("more than 512 distinct node-selector requirements (engine limit)");
+    return true;
+  }
+
+  // ---- node rows -----------------------------------------------------------------------------------
+  void encode_node(const NodeInfo& ni, int64_t* alloc, int64_t* requested, int32_t* allowed, int32_t* count, uint32_t* flags,
+                   uint64_t* taints, uint64_t* labels) const {
+    std::fill(alloc, alloc + R, 0);
+    std::fill(requested, requested + R, 0);
+    alloc[0] = ni.allocatable.milli_cpu;
+    alloc[1] = ni.allocatable.memory;
+    alloc[2] = ni.allocatable.ephemeral;
+    requested[0] = ni.requested.milli_cpu;
+    requested[1] = ni.requested.memory;
+    requested[2] = ni.requested.ephemeral;
+    for (size_t i = 0; i < scalar_names.size(); ++i) {
+      auto a = ni.allocatable.scalar.find(scalar_names[i]);
+      auto u = ni.requested.scalar.find(scalar_names[i]);
+      alloc[3 + i] = a == ni.allocatable.scalar.end() ? 0 : a->second;
+      requested[3 + i] = u == ni.requested.scalar.end() ? 0 : u->second;
+    }
+    *allowed = clamp32(ni.allocatable.allowed_pods);
+    *count = (int32_t)ni.pods.size();
+    *flags = ni.node.unschedulable ? YKPRED_NODE_UNSCHEDULABLE : 0u;
+    std::fill(taints, taints + KT, 0);
+    for (auto& t : ni.node.taints) {
+      if (t.effect != "NoSchedule" && t.effect != "NoExecute") continue;  // PreferNoSchedule is ignored by the Filter
+      auto it = taint_ix_.find(taint_key(t));
+      if (it != taint_ix_.end()) taints[it->second >> 6] |= 1ull << (it->second & 63);
+    }
+    std::fill(labels, labels + W, 0);
+    for (size_t q = 0; q < req_dict.size(); ++q)
+      if (req_dict[q].eval(ni.node)) labels[q >> 6] |= 1ull << (q & 63);
+  }
+
+  // ---- spec rows -----------------------------------------------------------------------------------
+  EncodedSpec encode_spec(const PodTemplate& t) const {
+    EncodedSpec s;
+    s.req.assign((size_t)R, 0);
+    for (auto& kv : t.requests) {
+      if (kv.first == "cpu")
+        s.req[0] = kv.second;
+      else if (kv.first == "memory")
+        s.req[1] = kv.second;
+      else if (kv.first == "ephemeral-storage")
+        s.req[2] = kv.second;
+      else {
+        auto it = scalar_ix_.find(kv.first);
+        if (it != scalar_ix_.end()) s.req[3 + (size_t)it->second] = kv.second;
+      }
+    }
+    s.tol.assign((size_t)KT, 0);
+    for (size_t i = 0; i < taint_dict.size(); ++i)
+      for (auto& tol : t.tolerations)
+        if (toleration_tolerates(tol, taint_dict[i])) {
+          s.tol[i >> 6] |= 1ull << (i & 63);
+          break;
+        }
+    Taint unsched{"node.kubernetes.io/unschedulable", "", "NoSchedule"};
+    for (auto& tol : t.tolerations)
+      if (toleration_tolerates(tol, unsched)) s.flags |= YKPRED_SPEC_TOLERATES_UNSCHEDULABLE;
+
+    // NodeAffinity.PreFilter: Skip when there is neither a nodeSelector nor required affinity
+    if (!t.has_required && !t.has_node_selector) s.flags |= YKPRED_SPEC_AFFINITY_SKIP;
+    // Filter DNF: nodeSelector pairs are ANDed into every term
+    std::vector<uint64_t> base((size_t)W, 0);
+    for (auto& kv : t.node_selector) set_bit(base, find_req(DictReq::kEquals, kv.first, "", {kv.second}));
+    if (!t.has_required) {
+      s.terms.push_back(base);
+    } else {
+      for (auto& term : t.terms) {
+        if (term.exprs.empty() && term.fields.empty()) continue;  // empty term selects no objects
+        bool valid = true;
+        std::vector<uint64_t> m = base;
+        for (auto& e : term.exprs) {
+          if (!valid_label_requirement(e)) {
+            valid = false;
+            break;
+          }
+          set_bit(m, find_req(DictReq::kLabel, e.key, e.op, canonical_values(e)));
+        }
+        for (auto& f : term.fields) {
+          if (!valid) break;
+          if ((f.op != "In" && f.op != "NotIn") || f.values.size() != 1) {
+            valid = false;
+            break;
+          }
+          set_bit(m, find_req(DictReq::kField, f.key, f.op, f.values));
+        }
+        if (valid) s.terms.push_back(std::move(m));
+      }
+    }
+    // PreFilter NodeNames: union over terms of the intersection of their metadata.name In sets,
+    // only when EVERY term carries such a requirement.
+    if (t.has_required && !t.terms.empty()) {
+      std::set<std::string> names;
+      bool all_terms = true;
+      for (auto& term : t.terms) {
+        bool term_set = false;
+        std::set<std::string> tn;
+        for (auto& f : term.fields) {
+          if (f.key != "metadata.name" || f.op != "In") continue;
+          std::set<std::string> v(f.values.begin(), f.values.end());
+          if (!term_set) {
+            tn = v;
+            term_set = true;
+          } else {
+            std::set<std::string> inter;
+            for (auto& x : tn)
+              if (v.count(x)) inter.insert(x);
+            tn.swap(inter);
+          }
+        }
+        if (!term_set) {
+          all_terms = false;
+          break;
+        }
+        names.insert(tn.begin(), tn.end());
+      }
+      if (all_terms) {
+        if (names.empty()) {
+          s.flags |= YKPRED_SPEC_PREFILTER_REJECT;
+        } else {
+          s.flags |= YKPRED_SPEC_PREFILTER_NAMES;
+          for (auto& nm : names) {
+            std::vector<uint64_t> m((size_t)W, 0);
+            set_bit(m, find_req(DictReq::kNameIn, "", "", {nm}));
+            s.pre_terms.push_back(std::move(m));
+          }
+        }
+      }
+    }
+    return s;
+  }
+
+ private:
+  std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_;
+
+  bool fail(const std::string& m) {
+    error = m;
+    return false;
+  }
+  static int32_t clamp32(int64_t v) {
+    if (v > std::numeric_limits<int32_t>::max()) return std::numeric_limits<int32_t>::max();
+    if (v < std::numeric_limits<int32_t>::min()) return std::numeric_limits<int32_t>::min();
+    return (int32_t)v;
+  }
+  void scalar(const std::string& n) {
+    if (scalar_ix_.emplace(n, (int)scalar_names.size()).second) scalar_names.push_back(n);
+  }
+  static std::string taint_key(const Taint& t) { return t.key + '\x1f' + t.value + '\x1f' + t.effect; }
+  void taint(const Taint& t) {
+    if (taint_ix_.emplace(taint_key(t), (int)taint_dict.size()).second) taint_dict.push_back(t);
+  }
+  static std::vector<std::string> canonical_values(const Requirement& r) {
+    std::vector<std::string> v = r.values;
+    if (r.op == "In" || r.op == "NotIn") {
+      std::sort(v.begin(), v.end());
+      v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    return v;
+  }
+  static std::string req_key(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) {
+    std::string s = std::to_string((int)k) + '\x1f' + key + '\x1f' + op;
+    for (auto& v : values) s += '\x1f' + v;
+    return s;
+  }
+  void add_req(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) {
+    std::string rk = req_key(k, key, op, values);
+    if (req_ix_.count(rk)) return;
+    req_ix_.emplace(std::move(rk), (int)req_dict.size());
+    DictReq d;
+    d.kind = k;
+    d.req.key = key;
+    d.req.op = op;
+    d.req.values = values;
+    req_dict.push_back(std::move(d));
+  }
+  int find_req(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) const {
+    auto it = req_ix_.find(req_key(k, key, op, values));
+    return it == req_ix_.end() ? -1 : it->second;
+  }
+  static void set_bit(std::vector<uint64_t>& m, int q) {
+    if (q >= 0 && (size_t)(q >> 6) < m.size()) m[(size_t)(q >> 6)] |= 1ull << (q & 63);
+  }
+  void collect_requirements(const PodTemplate& t) {
+    for (auto& kv : t.node_selector) add_req(DictReq::kEquals, kv.first, "", {kv.second});
+    if (!t.has_required) return;
+    for (auto& term : t.terms) {
+      for (auto& e : term.exprs)
+        if (valid_label_requirement(e)) add_req(DictReq::kLabel, e.key, e.op, canonical_values(e));
+      for (auto& f : term.fields) {
+        if ((f.op == "In" || f.op == "NotIn") && f.values.size() == 1) add_req(DictReq::kField, f.key, f.op, f.values);
+        if (f.key == "metadata.name" && f.op == "In")
+          for (auto& v : f.values) add_req(DictReq::kNameIn, "", "", {v});
+      }
+    }
+  }
+};
+
+}  // namespace ykh

@@ -1,0 +1,867 @@
+// host.cpp — libykhost.so: SchedulerCache mirror + encoder + GpuPredicateManager above the C ABI of libykpred.so.
+//
+// Stand-in for the Go layer of the drop-in (see include/ykhost.h). It never evaluates a
+// predicate itself: every fit / no-fit verdict and every failing-plugin code comes back from the engine
+// (ykpred_eval / ykpred_query / ykpred_preemption). The only string work done here for a verdict is composing
+// the human-readable status message AFTER the device has named the failing plugin.
+#include "../../../include/ykhost.h"
+
+#include <chrono>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "encoder.h"
+#include "objects.h"
+
+namespace ykh {
+
+// Default plugin lists of NewPredicateManager (predicate_manager.go:321-373), restricted to the engine's plugins.
+constexpr uint32_t kAllPlugins = YKPRED_PLUGIN_ALL;
+constexpr uint32_t kReservationPre = YKPRED_PLUGIN_NODE_AFFINITY | YKPRED_PLUGIN_NODE_PORTS | YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
+constexpr uint32_t kReservationFilt = YKPRED_PLUGIN_NODE_UNSCHEDULABLE | YKPRED_PLUGIN_NODE_NAME | YKPRED_PLUGIN_TAINT_TOLERATION |
+                                      YKPRED_PLUGIN_NODE_AFFINITY | YKPRED_PLUGIN_NODE_PORTS | YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
+
+static const char* kPluginNames[] = {"", "NodeUnschedulable", "NodeName", "TaintToleration", "NodeAffinity", "NodePorts",
+                                     "NodeResourcesFit", "PodTopologySpread"};
+
+struct Rng {  // splitmix64
+  uint64_t s;
+  uint64_t next() {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  }
+  uint32_t below(uint32_t n) { return n ? (uint32_t)(next() % n) : 0; }
+  bool chance(uint32_t num, uint32_t den) { return below(den) < num; }
+};
+
+}  // namespace ykh
+
+using namespace ykh;
+
+struct ykhost {
+  ykpred_engine_t* eng = nullptr;
+  int device = 0;
+  std::string err;
+  uint32_t res_pre = kReservationPre, alloc_pre = kAllPlugins, res_filt = kReservationFilt, alloc_filt = kAllPlugins;
+
+  // ---- SchedulerCache mirror
+  TemplatePool pool;
+  std::deque<NodeInfo> node_store;
+  std::vector<NodeInfo*> nodes;  // index = engine node index
+  std::unordered_map<std::string, int> node_ix;
+  std::deque<Pod> pod_store;
+  std::vector<Pod*> pending;  // index = engine pod index
+  std::unordered_map<std::string, Pod*> by_uid;
+  bool uid_index = true;  // false for generated clusters until first needed
+
+  // ---- encoder state
+  Encoder enc;
+  bool dirty_all = true, dirty_pods = false;
+  std::vector<int> dirty_nodes;
+  std::vector<PodTemplate*> spec_templates;  // spec id → template
+  int64_t last_encode_us = 0;
+  int cfgR = 0, cfgKT = 0, cfgW = 0;
+
+  void clear_state() {
+    pool.clear();
+    node_store.clear();
+    nodes.clear();
+    node_ix.clear();
+    pod_store.clear();
+    pending.clear();
+    by_uid.clear();
+    uid_index = true;
+    dirty_all = true;
+    dirty_nodes.clear();
+    spec_templates.clear();
+  }
+};
+
+namespace {
+
+int fail(ykhost* h, const std::string& m, int code = -1) {
+  h->err = m;
+  return code;
+}
+void copy_out(const std::string& s, char* out, int64_t len) {
+  if (!out || len <= 0) return;
+  size_t n = std::min((size_t)(len - 1), s.size());
+  memcpy(out, s.data(), n);
+  out[n] = 0;
+}
+
+void ensure_uid_index(ykhost* h) {
+  if (h->uid_index) return;
+  h->by_uid.clear();
+  h->by_uid.reserve(h->pod_store.size());
+  for (Pod& p : h->pod_store)
+    if (p.tpl) h->by_uid[p.uid] = &p;
+  h->uid_index = true;
+}
+
+Pod* add_pod_object(ykhost* h, const mj::Value& v, size_t* anon) {
+  Pod p;
+  if (const mj::Value* md = v.get_nn("metadata")) {
+    p.uid = md->str_or("uid", "");
+    p.name = md->str_or("name", "");
+    p.terminating = md->get_nn("deletionTimestamp") != nullptr;
+  }
+  if (const mj::Value* spec = v.get_nn("spec")) p.node_name = spec->str_or("nodeName", "");
+  if (p.uid.empty()) p.uid = "anon-" + std::to_string((*anon)++);
+  p.tpl = h->pool.intern(read_template(v));
+  h->pod_store.push_back(std::move(p));
+  return &h->pod_store.back();
+}
+
+// ---- encode + upload -------------------------------------------------------------------------------
+int recreate_engine(ykhost* h) {
+  if (h->eng && h->cfgR == h->enc.R && h->cfgKT == h->enc.KT && h->cfgW == h->enc.W) return 0;
+  if (h->eng) ykpred_destroy(h->eng);
+  h->eng = nullptr;
+  ykpred_config_t c{};
+  c.abi_version = YKPRED_ABI_VERSION;
+  c.device = h->device;
+  c.num_resources = h->enc.R;
+  c.taint_words = h->enc.KT;
+  c.label_words = h->enc.W;
+  int r = ykpred_create(&c, &h->eng);
+  if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
+  h->cfgR = c.num_resources;
+  h->cfgKT = c.taint_words;
+  h->cfgW = c.label_words;
+  return 0;
+}
+
+int full_sync(ykhost* h) {
+  auto t0 = std::chrono::steady_clock::now();
+  // templates of pending asks, in first-use order → spec ids
+  h->spec_templates.clear();
+  for (PodTemplate* t : h->pool.all()) t->spec_id = -1;
+  for (Pod* p : h->pending) {
+    PodTemplate* t = const_cast<PodTemplate*>(p->tpl);
+    if (t->spec_id < 0) {
+      t->spec_id = (int32_t)h->spec_templates.size();
+      h->spec_templates.push_back(t);
+    }
+  }
+  if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
+  int rc = recreate_engine(h);
+  if (rc) return rc;
+  const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W;
+  const size_t N = h->nodes.size();
+  std::vector<int64_t> alloc(N * R), req(N * R), a1(R), r1(R);
+  std::vector<int32_t> allowed(N), count(N);
+  std::vector<uint32_t> flags(N);
+  std::vector<uint64_t> taints(N * KT), labels(N * W), t1(KT), l1(W);
+  for (size_t n = 0; n < N; ++n) {
+    h->nodes[n]->index = (int32_t)n;
+    h->enc.encode_node(*h->nodes[n], a1.data(), r1.data(), &allowed[n], &count[n], &flags[n], t1.data(), l1.data());
+    for (int r = 0; r < R; ++r) {
+      alloc[(size_t)r * N + n] = a1[(size_t)r];
+      req[(size_t)r * N + n] = r1[(size_t)r];
+    }
+    for (int k = 0; k < KT; ++k) taints[(size_t)k * N + n] = t1[(size_t)k];
+    for (int w = 0; w < W; ++w) labels[(size_t)w * N + n] = l1[(size_t)w];
+  }
+  ykpred_nodes_t nt{};
+  nt.count = (int32_t)N;
+  nt.allocatable = alloc.data();
+  nt.requested = req.data();
+  nt.allowed_pods = allowed.data();
+  nt.pod_count = count.data();
+  nt.flags = flags.data();
+  nt.taint_bits = taints.data();
+  nt.label_bits = labels.data();
+  rc = ykpred_set_nodes(h->eng, &nt);
+  if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
+
+  const size_t S = h->spec_templates.size();
+  std::vector<int64_t> sreq(S * R);
+  std::vector<uint64_t> stol(S * KT), aff_terms, pre_terms;
+  std::vector<uint32_t> sflags(S);
+  std::vector<int32_t> aff_off{0}, pre_off{0};
+  for (size_t s = 0; s < S; ++s) {
+    EncodedSpec es = h->enc.encode_spec(*h->spec_templates[s]);
+    std::copy(es.req.begin(), es.req.end(), sreq.begin() + (long)(s * R));
+    std::copy(es.tol.begin(), es.tol.end(), stol.begin() + (long)(s * KT));
+    sflags[s] = es.flags;
+    for (auto& t : es.terms) aff_terms.insert(aff_terms.end(), t.begin(), t.end());
+    for (auto& t : es.pre_terms) pre_terms.insert(pre_terms.end(), t.begin(), t.end());
+    aff_off.push_back((int32_t)(aff_terms.size() / (size_t)W));
+    pre_off.push_back((int32_t)(pre_terms.size() / (size_t)W));
+  }
+  uint64_t dummy = 0;
+  ykpred_specs_t sp{};
+  sp.count = (int32_t)S;
+  sp.requests = sreq.data();
+  sp.tolerated = stol.data();
+  sp.flags = sflags.data();
+  sp.aff_term_off = aff_off.data();
+  sp.aff_terms = aff_terms.empty() ? &dummy : aff_terms.data();
+  sp.pre_term_off = pre_off.data();
+  sp.pre_terms = pre_terms.empty() ? &dummy : pre_terms.data();
+  rc = ykpred_set_specs(h->eng, &sp);
+  if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
+  h->dirty_all = false;
+  h->dirty_nodes.clear();
+  h->dirty_pods = true;
+  h->last_encode_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
+int pods_sync(ykhost* h) {
+  const size_t P = h->pending.size();
+  std::vector<int32_t> spec(P), pin(P);
+  for (size_t p = 0; p < P; ++p) {
+    const Pod* pod = h->pending[p];
+    spec[p] = pod->tpl->spec_id;
+    if (pod->node_name.empty()) {
+      pin[p] = YKPRED_NO_NODE_NAME;
+    } else {
+      auto it = h->node_ix.find(pod->node_name);
+      pin[p] = it == h->node_ix.end() ? YKPRED_UNKNOWN_NODE_NAME : it->second;
+    }
+  }
+  ykpred_pods_t pp{};
+  pp.count = (int32_t)P;
+  pp.spec_index = spec.data();
+  pp.node_name_index = pin.data();
+  int rc = ykpred_set_pods(h->eng, &pp);
+  if (rc) return fail(h, std::string("ykpred_set_pods: ") + ykpred_last_error(h->eng), rc);
+  h->dirty_pods = false;
+  return 0;
+}
+
+int node_row_sync(ykhost* h, int n) {
+  const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W;
+  std::vector<int64_t> a((size_t)R), r((size_t)R);
+  std::vector<uint64_t> t((size_t)KT), l((size_t)W);
+  int32_t allowed, count;
+  uint32_t flags;
+  h->enc.encode_node(*h->nodes[(size_t)n], a.data(), r.data(), &allowed, &count, &flags, t.data(), l.data());
+  ykpred_nodes_t nt{};
+  nt.count = 1;
+  nt.allocatable = a.data();
+  nt.requested = r.data();
+  nt.allowed_pods = &allowed;
+  nt.pod_count = &count;
+  nt.flags = &flags;
+  nt.taint_bits = t.data();
+  nt.label_bits = l.data();
+  int rc = ykpred_update_node(h->eng, n, &nt);
+  if (rc) return fail(h, std::string("ykpred_update_node: ") + ykpred_last_error(h->eng), rc);
+  return 0;
+}
+
+int sync(ykhost* h) {
+  if (h->dirty_all) {
+    int rc = full_sync(h);
+    if (rc) return rc;
+  }
+  for (int n : h->dirty_nodes) {
+    int rc = node_row_sync(h, n);
+    if (rc) return rc;
+  }
+  h->dirty_nodes.clear();
+  if (h->dirty_pods) return pods_sync(h);
+  return 0;
+}
+
+// A node-level change that cannot introduce new dictionary entries (pod assumed / forgotten / removed).
+void touch_node(ykhost* h, int n) {
+  if (!h->dirty_all) h->dirty_nodes.push_back(n);
+}
+
+// ---- status message for a device verdict -------------------------------------------------------------
+std::string compose_message(ykhost* h, const Pod& pod, const NodeInfo& ni, int code, uint32_t reason) {
+  switch (code) {
+    case YKPRED_CODE_NONE: return "node(s) didn't match Pod's node affinity/selector";  // PreFilter rejected (conflicting terms)
+    case YKPRED_CODE_NODE_UNSCHEDULABLE: return "node(s) were unschedulable";
+    case YKPRED_CODE_NODE_NAME: return "node(s) didn't match the requested node name";
+    case YKPRED_CODE_TAINT_TOLERATION: {
+      for (auto& t : ni.node.taints) {
+        if (t.effect != "NoSchedule" && t.effect != "NoExecute") continue;
+        bool ok = false;
+        for (auto& tol : pod.tpl->tolerations) ok = ok || toleration_tolerates(tol, t);
+        if (!ok) return "node(s) had untolerated taint {" + t.key + ": " + t.value + "}";
+      }
+      return "node(s) had untolerated taint";
+    }
+    case YKPRED_CODE_NODE_AFFINITY:
+      if (reason & YKPRED_REASON_PREFILTER_NODE_NOT_ELIGIBLE) return "node not eligible";
+      return "node(s) didn't match Pod's node affinity/selector";
+    case YKPRED_CODE_NODE_RESOURCES_FIT: {
+      std::string m;
+      auto add = [&](const std::string& s) {
+        if (!m.empty()) m += ", ";
+        m += s;
+      };
+      if (reason & YKPRED_REASON_TOO_MANY_PODS) add("Too many pods");
+      static const char* base[] = {"cpu", "memory", "ephemeral-storage"};
+      for (int r = 0; r < h->enc.R; ++r)
+        if (reason & (1u << (YKPRED_REASON_RESOURCE_SHIFT + r))) add(std::string("Insufficient ") + (r < 3 ? base[r] : h->enc.scalar_names[(size_t)r - 3].c_str()));
+      if (m.empty()) m = "running \"NodeResourcesFit\" filter plugin: reading \"PreFilterNodeResourcesFit\" from cycleState: not found";
+      return m;
+    }
+    case YKPRED_CODE_POD_TOPOLOGY_SPREAD: return "node(s) didn't match pod topology spread constraints";
+    default: return "unschedulable";
+  }
+}
+
+// ---- KWOK-style generator --------------------------------------------------------------
+const char* kCpuPalette[] = {"0", "10m", "100m", "250m", "500m", "1", "2", "4", "8"};
+const char* kMemPalette[] = {"0", "1M", "128Mi", "500M", "1Gi", "4Gi", "16Gi"};
+const char* kKernel[] = {"0204", "0206", "0510", "0601"};
+const char* kKernelThreshold[] = {"0100", "0205", "0300", "0600"};
+
+std::string fmt(const char* f, int v) {
+  char b[64];
+  snprintf(b, sizeof b, f, v);
+  return b;
+}
+
+PodTemplate draw_template(Rng& g, const ykhost_kwok_t& c, int n_nodes) {
+  PodTemplate t;
+  t.ns = "default";
+  t.labels["app"] = fmt("app-%d", (int)g.below(8));
+  Container ct;
+  ct.name = "main";
+  const char* cpu = kCpuPalette[g.below(9)];
+  const char* mem = kMemPalette[g.below(7)];
+  if (strcmp(cpu, "0") != 0) ct.requests["cpu"] = cpu;
+  if (strcmp(mem, "0") != 0) ct.requests["memory"] = mem;
+  t.containers.push_back(ct);
+  if (c.tolerations) {
+    if (g.chance(90, 100)) t.tolerations.push_back({"kwok.x-k8s.io/node", "Exists", "", "NoSchedule"});
+    if (g.chance(10, 100)) t.tolerations.push_back({"dedicated", "Equal", fmt("team-%d", (int)g.below(8)), "NoSchedule"});
+    if (g.chance(2, 100)) t.tolerations.push_back({"", "Exists", "", ""});
+    if (g.chance(3, 100)) t.tolerations.push_back({"node.example.com/maintenance", "Exists", "", "NoExecute"});
+  }
+  if (c.node_affinity) {
+    auto zone = [&](int i) { return fmt("zone-%02d", i % 16); };
+    auto label_expr = [&]() {
+      Requirement r;
+      switch (g.below(6)) {
+        case 0: {  // zone In / NotIn a run of 1-3 zones
+          r.key = "topology.kubernetes.io/zone";
+          r.op = g.chance(1, 2) ? "In" : "NotIn";
+          int z = (int)g.below(16), len = 1 + (int)g.below(3);
+          for (int i = 0; i < len; ++i) r.values.push_back(zone(z + i));
+          break;
+        }
+        case 1:
+          r.key = "node.kubernetes.io/instance-type";
+          r.op = g.chance(1, 2) ? "In" : "NotIn";
+          r.values.push_back(fmt("type-%d", (int)g.below(8)));
+          break;
+        case 2:
+          r.key = "kernel-version";
+          r.op = g.chance(1, 2) ? "Gt" : "Lt";
+          r.values.push_back(kKernelThreshold[g.below(4)]);
+          break;
+        case 3:
+          r.key = "gpu";
+          r.op = g.chance(1, 2) ? "Exists" : "DoesNotExist";
+          break;
+        case 4:
+          r.key = "topology.kubernetes.io/zone";
+          r.op = "Exists";
+          break;
+        default:
+          r.key = "type";
+          r.op = "In";
+          r.values.push_back(g.chance(9, 10) ? "kwok" : "real");
+          break;
+      }
+      return r;
+    };
+    uint32_t d = g.below(100);
+    if (d < 60) {
+      // none
+    } else if (d < 80) {
+      t.has_node_selector = true;
+      switch (g.below(3)) {
+        case 0: t.node_selector["topology.kubernetes.io/zone"] = zone((int)g.below(16)); break;
+        case 1: t.node_selector["node.kubernetes.io/instance-type"] = fmt("type-%d", (int)g.below(8)); break;
+        default: t.node_selector["type"] = "kwok"; break;
+      }
+    } else if (d < 95) {
+      t.has_required = true;
+      SelectorTerm term;
+      int ne = 1 + (int)g.below(2);
+      for (int i = 0; i < ne; ++i) term.exprs.push_back(label_expr());
+      t.terms.push_back(term);
+    } else {
+      t.has_required = true;
+      int nt = 2 + (int)g.below(3);
+      for (int i = 0; i < nt; ++i) {
+        SelectorTerm term;
+        if (g.chance(1, 3)) {
+          Requirement f;
+          f.key = "metadata.name";
+          f.op = g.chance(3, 4) ? "In" : "NotIn";
+          f.values.push_back(fmt("kwok-node-%06d", (int)g.below((uint32_t)std::min(n_nodes, 32))));
+          term.fields.push_back(f);
+          if (g.chance(1, 2)) term.exprs.push_back(label_expr());
+        } else {
+          term.exprs.push_back(label_expr());
+        }
+        t.terms.push_back(term);
+      }
+    }
+  }
+  return t;
+}
+
+int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
+  h->clear_state();
+  h->uid_index = false;
+  Rng g{(c.seed ^ 0x4e4f444553ull) + (uint64_t)c.node_index_offset * 0x9e3779b97f4a7c15ull};  // node stream
+  const int N = c.num_nodes, P = c.num_pods;
+  // ---- nodes
+  for (int n = 0; n < N; ++n) {
+    Node nd;
+    nd.name = fmt("kwok-node-%06d", c.node_index_offset + n);
+    bool big = g.chance(80, 100);
+    int64_t cpu_milli = big ? 32000 : 16000;
+    int64_t mem = big ? (256ll << 30) : 16000000000ll;
+    nd.allocatable["cpu"] = big ? "32" : "16";
+    nd.allocatable["memory"] = big ? "256Gi" : "16G";
+    nd.allocatable["pods"] = "110";
+    nd.labels["kubernetes.io/hostname"] = nd.name;
+    nd.labels["topology.kubernetes.io/zone"] = fmt("zone-%02d", (int)g.below(16));
+    nd.labels["node.kubernetes.io/instance-type"] = fmt("type-%d", (int)g.below(8));
+    nd.labels["type"] = "kwok";
+    nd.labels["kernel-version"] = kKernel[g.below(4)];
+    if (c.tolerations) {
+      nd.taints.push_back({"kwok.x-k8s.io/node", "fake", "NoSchedule"});
+      if (g.chance(10, 100)) nd.taints.push_back({"dedicated", fmt("team-%d", (int)g.below(8)), "NoSchedule"});
+      if (g.chance(2, 100)) nd.taints.push_back({"node.example.com/maintenance", "true", "NoExecute"});
+      if (g.chance(5, 100)) nd.taints.push_back({"prefer", "soft", "PreferNoSchedule"});
+    }
+    nd.unschedulable = g.chance(1, 100);
+    h->node_store.emplace_back();
+    NodeInfo& ni = h->node_store.back();
+    ni.set_node(nd);
+    ni.index = n;
+    h->nodes.push_back(&ni);
+    h->node_ix[nd.name] = n;
+    // ---- pods already on the node: 1 pod carrying the node's Requested, the rest best-effort
+    int k = (int)g.below(111);
+    uint32_t special = g.below(1000);
+    int64_t used_cpu = (int64_t)((double)cpu_milli * (double)g.below(951) / 1000.0);
+    int64_t used_mem = (int64_t)((double)mem * (double)g.below(951) / 1000.0);
+    if (special < 5) {  // exactly full: no pod slot left, cpu free hits a palette value exactly
+      k = 110;
+      used_cpu = cpu_milli - 1000;
+    } else if (special < 10) {  // over-committed: negative free
+      used_cpu = cpu_milli + cpu_milli / 10;
+      used_mem = mem + mem / 10;
+      if (k == 0) k = 1;
+    }
+    if (k > 0) {
+      PodTemplate a;
+      a.ns = "default";
+      a.labels["app"] = fmt("app-%d", (int)g.below(8));
+      Container ct;
+      ct.name = "main";
+      if (used_cpu > 0) ct.requests["cpu"] = std::to_string(used_cpu) + "m";
+      if (used_mem > 0) ct.requests["memory"] = std::to_string(used_mem);
+      a.containers.push_back(ct);
+      const PodTemplate* at = h->pool.intern(std::move(a));
+      Pod p;
+      p.uid = p.name = fmt("n%d-p0", n);
+      p.node_name = nd.name;
+      p.tpl = at;
+      h->pod_store.push_back(std::move(p));
+      ni.add_pod(&h->pod_store.back());
+      PodTemplate b;
+      b.ns = "default";
+      b.labels["app"] = fmt("app-%d", (int)g.below(8));
+      Container cb;
+      cb.name = "main";
+      b.containers.push_back(cb);
+      const PodTemplate* bt = h->pool.intern(std::move(b));
+      for (int i = 1; i < k; ++i) {
+        Pod q;
+        q.uid = q.name = "n" + std::to_string(n) + "-p" + std::to_string(i);
+        q.node_name = nd.name;
+        q.tpl = bt;
+        h->pod_store.push_back(std::move(q));
+        ni.add_pod(&h->pod_store.back());
+      }
+    }
+  }
+  // ---- pending asks (own stream: identical on every shard of a node-sharded cluster)
+  g = Rng{c.seed ^ 0x504f4453ull};
+  std::vector<const PodTemplate*> tpls;
+  int T = c.num_templates;
+  if (c.gang_size > 0) T = (P + c.gang_size - 1) / c.gang_size;
+  for (int i = 0; i < T; ++i) tpls.push_back(h->pool.intern(draw_template(g, c, N)));
+  for (int p = 0; p < P; ++p) {
+    Pod pod;
+    pod.uid = pod.name = fmt("pod-%07d", p);
+    if (c.unique_requests) {
+      PodTemplate t = draw_template(g, c, N);
+      t.containers[0].requests["cpu"] = std::to_string(p + 1) + "m";
+      pod.tpl = h->pool.intern(std::move(t));
+    } else if (T > 0) {
+      pod.tpl = c.gang_size > 0 ? tpls[(size_t)(p / c.gang_size)] : tpls[(size_t)(p % T)];
+    } else {
+      pod.tpl = h->pool.intern(draw_template(g, c, N));
+    }
+    uint32_t pin = g.below(10000);
+    if (N > 0 && pin < 10)
+      pod.node_name = fmt("kwok-node-%06d", (int)g.below((uint32_t)N));  // a GLOBAL name of shard 0's range
+    else if (pin == 10)
+      pod.node_name = "no-such-node";
+    h->pod_store.push_back(std::move(pod));
+    h->pending.push_back(&h->pod_store.back());
+  }
+  h->dirty_all = true;
+  return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+ykhost_t* ykhost_create(int32_t device, char* err, int32_t errlen) {
+  auto* h = new ykhost();
+  h->device = device;
+  // create the engine eagerly with the minimal shape so that a missing GPU fails here, loudly
+  h->enc.R = 3;
+  h->enc.KT = 1;
+  h->enc.W = 1;
+  if (recreate_engine(h) != 0) {
+    copy_out(h->err, err, errlen);
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+void ykhost_destroy(ykhost_t* h) {
+  if (!h) return;
+  if (h->eng) ykpred_destroy(h->eng);
+  delete h;
+}
+const char* ykhost_last_error(const ykhost_t* h) { return h ? h->err.c_str() : ""; }
+
+int32_t ykhost_set_plugins(ykhost_t* h, uint32_t rp, uint32_t ap, uint32_t rf, uint32_t af) {
+  h->res_pre = rp;
+  h->alloc_pre = ap;
+  h->res_filt = rf;
+  h->alloc_filt = af;
+  return 0;
+}
+
+int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
+  try {
+    mj::ValuePtr root = mj::parse(json);
+    h->clear_state();
+    size_t anon = 0;
+    if (const mj::Value* nodes = root->get_nn("nodes"))
+      for (auto& nv : nodes->arr) {
+        h->node_store.emplace_back();
+        NodeInfo& ni = h->node_store.back();
+        ni.set_node(read_node(*nv));
+        ni.index = (int32_t)h->nodes.size();
+        h->node_ix[ni.node.name] = ni.index;
+        h->nodes.push_back(&ni);
+        if (const mj::Value* pods = nv->get_nn("pods"))
+          for (auto& pv : pods->arr) {
+            int64_t reps = pv->int_or("replicas", 1);
+            for (int64_t r = 0; r < reps; ++r) {
+              Pod* p = add_pod_object(h, *pv, &anon);
+              if (reps > 1) p->uid += "#" + std::to_string(r);
+              p->node_name = ni.node.name;
+              ni.add_pod(p);
+              h->by_uid[p->uid] = p;
+            }
+          }
+      }
+    if (const mj::Value* pods = root->get_nn("pods"))
+      for (auto& pv : pods->arr) {
+        Pod* p = add_pod_object(h, *pv, &anon);
+        h->pending.push_back(p);
+        h->by_uid[p->uid] = p;
+      }
+    h->dirty_all = true;
+    return 0;
+  } catch (const std::exception& e) {
+    return fail(h, e.what());
+  }
+}
+
+// SchedulerCache.UpdateNode (scheduler_cache.go:148-187): add or replace the node object, keep its pods.
+int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
+  try {
+    mj::ValuePtr v = mj::parse(node_json);
+    Node n = read_node(*v);
+    auto it = h->node_ix.find(n.name);
+    if (it == h->node_ix.end()) {
+      h->node_store.emplace_back();
+      NodeInfo& ni = h->node_store.back();
+      ni.set_node(n);
+      ni.index = (int32_t)h->nodes.size();
+      h->node_ix[n.name] = ni.index;
+      h->nodes.push_back(&ni);
+    } else {
+      h->nodes[(size_t)it->second]->set_node(n);
+    }
+    h->dirty_all = true;  // labels / taints / scalars may extend the dictionaries
+    return 0;
+  } catch (const std::exception& e) {
+    return fail(h, e.what());
+  }
+}
+
+// SchedulerCache.RemoveNode (:189-239): pods that were on the node become unassigned (orphans are dropped here).
+int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
+  auto it = h->node_ix.find(name);
+  if (it == h->node_ix.end()) return fail(h, "node not found");
+  int idx = it->second;
+  h->nodes.erase(h->nodes.begin() + idx);
+  h->node_ix.clear();
+  for (size_t i = 0; i < h->nodes.size(); ++i) {
+    h->nodes[i]->index = (int32_t)i;
+    h->node_ix[h->nodes[i]->node.name] = (int)i;
+  }
+  h->dirty_all = true;
+  return 0;
+}
+
+// SchedulerCache.UpdatePod (:303-388): drop the old version, then account the pod on its node if assigned.
+int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json) {
+  try {
+    mj::ValuePtr v = mj::parse(pod_json);
+    ensure_uid_index(h);
+    std::string uid;
+    if (const mj::Value* md = v->get_nn("metadata")) uid = md->str_or("uid", "");
+    if (!uid.empty() && h->by_uid.count(uid)) ykhost_remove_pod(h, uid.c_str());
+    size_t anon = h->pod_store.size();
+    Pod* p = add_pod_object(h, *v, &anon);
+    h->by_uid[p->uid] = p;
+    std::string phase;
+    if (const mj::Value* st = v->get_nn("status")) phase = st->str_or("phase", "");
+    bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated
+    if (!p->node_name.empty() && !terminated) {
+      auto it = h->node_ix.find(p->node_name);
+      if (it != h->node_ix.end()) {
+        h->nodes[(size_t)it->second]->add_pod(p);
+        touch_node(h, it->second);
+      }
+    } else if (p->node_name.empty() && !terminated) {
+      h->pending.push_back(p);
+      if (p->tpl->spec_id < 0)
+        h->dirty_all = true;  // new template: dictionaries may grow
+      else
+        h->dirty_pods = true;
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    return fail(h, e.what());
+  }
+}
+
+int32_t ykhost_remove_pod(ykhost_t* h, const char* uid) {
+  ensure_uid_index(h);
+  auto it = h->by_uid.find(uid);
+  if (it == h->by_uid.end()) return fail(h, "pod not found");
+  Pod* p = it->second;
+  for (size_t i = 0; i < h->pending.size(); ++i)
+    if (h->pending[i] == p) {
+      h->pending.erase(h->pending.begin() + (long)i);
+      h->dirty_pods = true;
+      break;
+    }
+  if (!p->node_name.empty()) {
+    auto nt = h->node_ix.find(p->node_name);
+    if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
+  }
+  h->by_uid.erase(it);
+  return 0;
+}
+
+// Context.AssumePod → SchedulerCache.AssumePod (context.go:828-885, scheduler_cache.go:443-461): the ask is bound
+// to the node in the cache; the node's Requested / pod count grow and later predicate calls see it.
+int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name) {
+  ensure_uid_index(h);
+  auto it = h->by_uid.find(uid);
+  auto nt = h->node_ix.find(node_name);
+  if (it == h->by_uid.end()) return fail(h, "pod not found");
+  if (nt == h->node_ix.end()) return fail(h, "node not found");
+  Pod* p = it->second;
+  for (size_t i = 0; i < h->pending.size(); ++i)
+    if (h->pending[i] == p) {
+      h->pending.erase(h->pending.begin() + (long)i);
+      h->dirty_pods = true;
+      break;
+    }
+  p->node_name = node_name;
+  h->nodes[(size_t)nt->second]->add_pod(p);
+  touch_node(h, nt->second);
+  return 0;
+}
+
+// SchedulerCache.ForgetPod (:463-484): undo an assumption; the pod is a pending ask again.
+int32_t ykhost_forget_pod(ykhost_t* h, const char* uid) {
+  ensure_uid_index(h);
+  auto it = h->by_uid.find(uid);
+  if (it == h->by_uid.end()) return fail(h, "pod not found");
+  Pod* p = it->second;
+  if (p->node_name.empty()) return 0;
+  auto nt = h->node_ix.find(p->node_name);
+  if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
+  p->node_name.clear();
+  h->pending.push_back(p);
+  if (p->tpl->spec_id < 0)
+    h->dirty_all = true;
+  else
+    h->dirty_pods = true;
+  return 0;
+}
+
+int32_t ykhost_generate_kwok(ykhost_t* h, const ykhost_kwok_t* cfg) {
+  if (!cfg || cfg->num_nodes < 0 || cfg->num_pods < 0) return fail(h, "bad kwok config");
+  return generate_kwok(h, *cfg);
+}
+
+int32_t ykhost_num_nodes(const ykhost_t* h) { return (int32_t)h->nodes.size(); }
+int32_t ykhost_num_pods(const ykhost_t* h) { return (int32_t)h->pending.size(); }
+int32_t ykhost_pod_index(const ykhost_t* h, const char* uid) {
+  for (size_t i = 0; i < h->pending.size(); ++i)
+    if (h->pending[i]->uid == uid) return (int32_t)i;
+  return -1;
+}
+int32_t ykhost_node_index(const ykhost_t* h, const char* name) {
+  auto it = h->node_ix.find(name);
+  return it == h->node_ix.end() ? -1 : it->second;
+}
+
+int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len) {
+  std::string o = "{\"nodes\":[";
+  int count_n = nodes ? nn : (int)h->nodes.size();
+  for (int i = 0; i < count_n; ++i) {
+    int idx = nodes ? nodes[i] : i;
+    if (idx < 0 || idx >= (int)h->nodes.size()) return fail(h, "dump: node index out of range");
+    if (i) o.push_back(',');
+    node_json(*h->nodes[(size_t)idx], o);
+  }
+  o += "],\"pods\":[";
+  int count_p = pods ? np : (int)h->pending.size();
+  for (int i = 0; i < count_p; ++i) {
+    int idx = pods ? pods[i] : i;
+    if (idx < 0 || idx >= (int)h->pending.size()) return fail(h, "dump: pod index out of range");
+    if (i) o.push_back(',');
+    pod_json(*h->pending[(size_t)idx], o);
+  }
+  o += "]}";
+  if (out && len > 0) copy_out(o, out, len);
+  return (int64_t)o.size() + 1;
+}
+
+int32_t ykhost_sync(ykhost_t* h) { return sync(h); }
+ykpred_engine_t* ykhost_engine(ykhost_t* h) { return h->eng; }
+
+int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
+  int rc = sync(h);
+  if (rc) return rc;
+  ykpred_eval_args_t a{};
+  a.prefilter_plugins = allocate ? h->alloc_pre : h->res_pre;
+  a.filter_plugins = allocate ? h->alloc_filt : h->res_filt;
+  a.options = options;
+  rc = ykpred_eval(h->eng, &a);
+  if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
+  return 0;
+}
+
+int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t allocate, char* plugin, int32_t plugin_len, char* msg,
+                          int32_t msg_len) {
+  if (pod < 0 || pod >= (int)h->pending.size() || node < 0 || node >= (int)h->nodes.size()) return fail(h, "index out of range", -1);
+  int rc = sync(h);
+  if (rc) return rc;
+  uint8_t fit = 0, code = 0;
+  uint32_t reason = 0;
+  rc = ykpred_query(h->eng, 1, &pod, &node, allocate ? h->alloc_pre : h->res_pre, allocate ? h->alloc_filt : h->res_filt, &fit, &code, &reason);
+  if (rc) return fail(h, std::string("ykpred_query: ") + ykpred_last_error(h->eng), rc);
+  if (fit) {
+    copy_out("", plugin, plugin_len);
+    copy_out("", msg, msg_len);
+    return 1;
+  }
+  copy_out(code < 8 ? kPluginNames[code] : "", plugin, plugin_len);
+  copy_out(compose_message(h, *h->pending[(size_t)pod], *h->nodes[(size_t)node], code, reason), msg, msg_len);
+  return 0;
+}
+
+int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t nv, int32_t start) {
+  if (pod < 0 || pod >= (int)h->pending.size() || node < 0 || node >= (int)h->nodes.size()) return fail(h, "index out of range", -2);
+  int rc = sync(h);
+  if (rc) return -2;
+  ensure_uid_index(h);
+  const int R = h->enc.R;
+  const NodeInfo& ni = *h->nodes[(size_t)node];
+  std::vector<int64_t> vreq((size_t)std::max(nv, 1) * (size_t)R, 0);
+  std::vector<uint8_t> present((size_t)std::max(nv, 1), 0);
+  std::vector<const Pod*> gone;
+  for (int i = 0; i < nv; ++i) {
+    if (!victim_uids || !victim_uids[i]) continue;  // nil victim (:182-184)
+    const Pod* v = nullptr;
+    for (const Pod* q : ni.pods)
+      if (q->uid == victim_uids[i]) v = q;
+    // RemovePod fails (and is ignored) when the pod is not on the node or was already removed (:185-191)
+    if (!v || std::find(gone.begin(), gone.end(), v) != gone.end()) continue;
+    gone.push_back(v);
+    present[(size_t)i] = 1;
+    Resource r = to_resource(v->tpl->requests);
+    vreq[(size_t)i * R + 0] = r.milli_cpu;
+    vreq[(size_t)i * R + 1] = r.memory;
+    vreq[(size_t)i * R + 2] = r.ephemeral;
+    for (size_t s = 0; s < h->enc.scalar_names.size(); ++s) {
+      auto it = r.scalar.find(h->enc.scalar_names[s]);
+      if (it != r.scalar.end()) vreq[(size_t)i * R + 3 + s] = it->second;
+    }
+  }
+  int32_t out = -1;
+  rc = ykpred_preemption(h->eng, pod, node, nv, vreq.data(), present.data(), start, h->alloc_pre, h->alloc_filt, &out);
+  if (rc) {
+    fail(h, std::string("ykpred_preemption: ") + ykpred_last_error(h->eng), rc);
+    return -2;
+  }
+  return out;
+}
+
+int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len) {
+  if (pod < 0 || pod >= (int)h->pending.size()) return fail(h, "index out of range");
+  std::string js = "{";
+  bool first = true;
+  for (auto& kv : h->pending[(size_t)pod]->tpl->requests) {
+    if (!first) js += ",";
+    first = false;
+    js += "\"" + kv.first + "\":" + std::to_string(kv.second);
+  }
+  js += "}";
+  copy_out(js, out, len);
+  return 0;
+}
+
+int32_t ykhost_stats(const ykhost_t* h, int64_t* o) {
+  o[0] = h->enc.R;
+  o[1] = h->enc.KT;
+  o[2] = h->enc.W;
+  o[3] = (int64_t)h->enc.taint_dict.size();
+  o[4] = (int64_t)h->enc.req_dict.size();
+  o[5] = (int64_t)h->pool.all().size();
+  o[6] = (int64_t)h->spec_templates.size();
+  o[7] = h->last_encode_us;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,555 @@
+// objects.h — the slice of v1.Pod / v1.Node / framework.NodeInfo that the predicate path reads, as held by
+// the host library (the C++ stand-in for the Go shim side; Go is not available in this image).
+//
+// Mirrors what /root/reference/pkg/cache/external/scheduler_cache.go keeps per node (NodeInfo: Allocatable,
+// Requested, Pods, Node()) and per pod (*v1.Pod). Pods share an interned, immutable PodTemplate: everything
+// of the pod except its identity (uid/name) and spec.nodeName, so a million replicas of a few thousand
+// Deployments / gang task groups cost one template each (placeholder.go:113-157 builds exactly such clones).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "minijson.h"
+#include "quantity.h"
+
+namespace ykh {
+
+using StrMap = std::map<std::string, std::string>;
+using ResMap = std::map<std::string, int64_t>;
+
+struct Taint {
+  std::string key, value, effect;
+};
+struct Toleration {
+  std::string key, op, value, effect;
+};
+struct Requirement {
+  std::string key, op;
+  std::vector<std::string> values;
+};
+struct SelectorTerm {
+  std::vector<Requirement> exprs, fields;
+};
+struct LabelSelector {
+  bool present = false;
+  StrMap match_labels;
+  std::vector<Requirement> match_exprs;
+};
+struct SpreadConstraint {
+  int32_t max_skew = 1;
+  std::string topology_key, when_unsatisfiable = "DoNotSchedule";
+  LabelSelector selector;
+  bool has_min_domains = false;
+  int32_t min_domains = 1;
+  std::string node_affinity_policy = "Honor", node_taints_policy = "Ignore";
+  std::vector<std::string> match_label_keys;
+};
+struct Container {
+  std::string name;
+  StrMap requests;
+  bool sidecar = false;
+  bool host_ports = false;
+};
+
+// Everything of a pod except uid / name / nodeName.
+struct PodTemplate {
+  std::string ns;
+  StrMap labels;
+  bool has_node_selector = false;
+  StrMap node_selector;
+  bool has_required = false;
+  std::vector<SelectorTerm> terms;
+  std::vector<Toleration> tolerations;
+  std::vector<Container> containers, init_containers;
+  bool has_overhead = false;
+  StrMap overhead;
+  StrMap pod_level_requests;
+  std::vector<SpreadConstraint> spread;
+  bool pod_affinity = false;  // inter-pod (anti)affinity present: outside this path
+  std::string canonical;      // interning key (canonical JSON of the fields above)
+  // derived once at interning time
+  ResMap requests;            // upstream PodRequests (resource.go:56-109 minus the "pods" entry)
+  int32_t spec_id = -1;       // engine spec index (assigned by the encoder)
+};
+
+struct Pod {
+  std::string uid, name;
+  std::string node_name;  // spec.nodeName ("" = pending ask)
+  bool terminating = false;
+  const PodTemplate* tpl = nullptr;
+};
+
+struct Node {
+  std::string name;
+  StrMap labels;
+  std::vector<Taint> taints;
+  bool unschedulable = false;
+  StrMap allocatable;
+};
+
+struct Resource {  // framework.Resource
+  int64_t milli_cpu = 0, memory = 0, ephemeral = 0, allowed_pods = 0;
+  std::map<std::string, int64_t> scalar;
+};
+
+inline bool has_prefix(const std::string& s, const char* p) { return s.rfind(p, 0) == 0; }
+// schedutil.IsScalarResourceName
+inline bool is_scalar_resource_name(const std::string& n) {
+  bool has_slash = n.find('/') != std::string::npos;
+  bool k8s = n.find("kubernetes.io/") != std::string::npos;
+  bool extended = has_slash && !k8s && !has_prefix(n, "requests.");
+  return extended || k8s || has_prefix(n, "hugepages-") || has_prefix(n, "attachable-volumes-");
+}
+inline ResMap get_resource(const StrMap& rl) {  // resource.go:273-285
+  ResMap out;
+  for (auto& kv : rl) out[kv.first] = kv.first == "cpu" ? quantity_milli(kv.second) : quantity_value(kv.second);
+  return out;
+}
+inline Resource to_resource(const ResMap& m) {
+  Resource r;
+  for (auto& kv : m) {
+    if (kv.first == "cpu")
+      r.milli_cpu += kv.second;
+    else if (kv.first == "memory")
+      r.memory += kv.second;
+    else if (kv.first == "ephemeral-storage")
+      r.ephemeral += kv.second;
+    else if (kv.first == "pods")
+      r.allowed_pods += kv.second;
+    else if (is_scalar_resource_name(kv.first))
+      r.scalar[kv.first] += kv.second;
+  }
+  return r;
+}
+
+// Request vector of a template: containers summed, init containers / native sidecars folded in, pod-level
+// override for cpu/memory/hugepages, overhead added (resource.go:56-109,164-182,287-301).
+inline ResMap compute_requests(const PodTemplate& t) {
+  auto add = [](ResMap& l, const ResMap& r) {
+    for (auto& kv : r) l[kv.first] += kv.second;
+  };
+  auto upmax = [](ResMap& l, const ResMap& r) {
+    for (auto& kv : r) {
+      auto it = l.find(kv.first);
+      if (it == l.end())
+        l[kv.first] = kv.second;
+      else if (kv.second > it->second)
+        it->second = kv.second;
+    }
+  };
+  ResMap total;
+  for (auto& c : t.containers) add(total, get_resource(c.requests));
+  if (!t.init_containers.empty()) {
+    ResMap init_max, sidecars;
+    for (auto& c : t.init_containers) {
+      ResMap ic = get_resource(c.requests);
+      ResMap cur = ic;
+      add(cur, sidecars);
+      if (c.sidecar) add(sidecars, ic);
+      upmax(init_max, cur);
+    }
+    add(total, sidecars);
+    upmax(total, init_max);
+  }
+  for (auto& kv : get_resource(t.pod_level_requests))
+    if (kv.first == "cpu" || kv.first == "memory" || has_prefix(kv.first, "hugepages-")) total[kv.first] = kv.second;
+  if (t.has_overhead) add(total, get_resource(t.overhead));
+  return total;
+}
+
+// framework.NodeInfo
+struct NodeInfo {
+  Node node;
+  std::vector<const Pod*> pods;
+  Resource requested, allocatable;
+  int32_t index = -1;  // engine node index
+
+  void set_node(const Node& n) {
+    node = n;
+    allocatable = to_resource(get_resource(n.allocatable));
+  }
+  void account(const Pod* p, int sign) {
+    Resource r = to_resource(p->tpl->requests);
+    requested.milli_cpu += sign * r.milli_cpu;
+    requested.memory += sign * r.memory;
+    requested.ephemeral += sign * r.ephemeral;
+    for (auto& kv : r.scalar) requested.scalar[kv.first] += sign * kv.second;
+  }
+  void add_pod(const Pod* p) {
+    pods.push_back(p);
+    account(p, +1);
+  }
+  bool remove_pod(const std::string& uid) {
+    for (size_t i = 0; i < pods.size(); ++i)
+      if (pods[i]->uid == uid) {
+        account(pods[i], -1);
+        pods.erase(pods.begin() + (long)i);
+        return true;
+      }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// JSON → objects (Kubernetes field names)
+// ---------------------------------------------------------------------------------------------------
+inline StrMap read_strmap(const mj::Value* v) {
+  StrMap out;
+  if (v && v->is_obj())
+    for (auto& kv : v->obj)
+      if (kv.second->is_str() || kv.second->is_num()) out[kv.first] = kv.second->s;
+  return out;
+}
+inline std::vector<Requirement> read_requirements(const mj::Value* v) {
+  std::vector<Requirement> out;
+  if (v && v->is_arr())
+    for (auto& e : v->arr) {
+      Requirement r;
+      r.key = e->str_or("key", "");
+      r.op = e->str_or("operator", "");
+      if (const mj::Value* vals = e->get_nn("values"))
+        for (auto& x : vals->arr) r.values.push_back(x->s);
+      out.push_back(std::move(r));
+    }
+  return out;
+}
+inline std::vector<Container> read_containers(const mj::Value* v, bool init) {
+  std::vector<Container> out;
+  if (v && v->is_arr())
+    for (auto& e : v->arr) {
+      Container c;
+      c.name = e->str_or("name", "");
+      if (const mj::Value* res = e->get_nn("resources")) c.requests = read_strmap(res->get_nn("requests"));
+      if (init) c.sidecar = e->str_or("restartPolicy", "") == "Always";
+      if (const mj::Value* ports = e->get_nn("ports"))
+        for (auto& pt : ports->arr)
+          if (pt->int_or("hostPort", 0) != 0) c.host_ports = true;
+      out.push_back(std::move(c));
+    }
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// objects → JSON (used for interning keys and for ykhost_dump_snapshot)
+// ---------------------------------------------------------------------------------------------------
+inline void js_str(std::string& o, const std::string& s) {
+  o.push_back('"');
+  for (unsigned char c : s) {
+    if (c == '"' || c == '\\') {
+      o.push_back('\\');
+      o.push_back((char)c);
+    } else if (c < 0x20) {
+      char buf[8];
+      snprintf(buf, sizeof buf, "\\u%04x", c);
+      o += buf;
+    } else {
+      o.push_back((char)c);
+    }
+  }
+  o.push_back('"');
+}
+inline void js_map(std::string& o, const StrMap& m) {
+  o.push_back('{');
+  bool first = true;
+  for (auto& kv : m) {
+    if (!first) o.push_back(',');
+    first = false;
+    js_str(o, kv.first);
+    o.push_back(':');
+    js_str(o, kv.second);
+  }
+  o.push_back('}');
+}
+inline void js_reqs(std::string& o, const std::vector<Requirement>& rs) {
+  o.push_back('[');
+  for (size_t i = 0; i < rs.size(); ++i) {
+    if (i) o.push_back(',');
+    o += "{\"key\":";
+    js_str(o, rs[i].key);
+    o += ",\"operator\":";
+    js_str(o, rs[i].op);
+    if (!rs[i].values.empty()) {
+      o += ",\"values\":[";
+      for (size_t j = 0; j < rs[i].values.size(); ++j) {
+        if (j) o.push_back(',');
+        js_str(o, rs[i].values[j]);
+      }
+      o.push_back(']');
+    }
+    o.push_back('}');
+  }
+  o.push_back(']');
+}
+inline void js_containers(std::string& o, const std::vector<Container>& cs) {
+  o.push_back('[');
+  for (size_t i = 0; i < cs.size(); ++i) {
+    if (i) o.push_back(',');
+    o += "{\"name\":";
+    js_str(o, cs[i].name);
+    o += ",\"resources\":{\"requests\":";
+    js_map(o, cs[i].requests);
+    o += "}";
+    if (cs[i].sidecar) o += ",\"restartPolicy\":\"Always\"";
+    if (cs[i].host_ports) o += ",\"ports\":[{\"hostPort\":1}]";
+    o.push_back('}');
+  }
+  o.push_back(']');
+}
+
+// "metadata" (namespace + labels only) and "spec" members of a pod, without identity and nodeName.
+inline void template_json(const PodTemplate& t, std::string& meta, std::string& spec) {
+  meta.clear();
+  spec.clear();
+  meta += "\"namespace\":";
+  js_str(meta, t.ns);
+  meta += ",\"labels\":";
+  js_map(meta, t.labels);
+  spec += "\"containers\":";
+  js_containers(spec, t.containers);
+  if (!t.init_containers.empty()) {
+    spec += ",\"initContainers\":";
+    js_containers(spec, t.init_containers);
+  }
+  if (t.has_node_selector) {
+    spec += ",\"nodeSelector\":";
+    js_map(spec, t.node_selector);
+  }
+  if (t.has_required || t.pod_affinity) {
+    spec += ",\"affinity\":{";
+    if (t.has_required) {
+      spec += "\"nodeAffinity\":{\"requiredDuringSchedulingIgnoredDuringExecution\":{\"nodeSelectorTerms\":[";
+      for (size_t i = 0; i < t.terms.size(); ++i) {
+        if (i) spec.push_back(',');
+        spec += "{\"matchExpressions\":";
+        js_reqs(spec, t.terms[i].exprs);
+        spec += ",\"matchFields\":";
+        js_reqs(spec, t.terms[i].fields);
+        spec.push_back('}');
+      }
+      spec += "]}}";
+    }
+    if (t.pod_affinity) spec += std::string(t.has_required ? "," : "") + "\"podAffinity\":{}";
+    spec += "}";
+  }
+  if (!t.tolerations.empty()) {
+    spec += ",\"tolerations\":[";
+    for (size_t i = 0; i < t.tolerations.size(); ++i) {
+      const Toleration& x = t.tolerations[i];
+      if (i) spec.push_back(',');
+      spec += "{\"key\":";
+      js_str(spec, x.key);
+      spec += ",\"operator\":";
+      js_str(spec, x.op);
+      spec += ",\"value\":";
+      js_str(spec, x.value);
+      spec += ",\"effect\":";
+      js_str(spec, x.effect);
+      spec.push_back('}');
+    }
+    spec.push_back(']');
+  }
+  if (t.has_overhead) {
+    spec += ",\"overhead\":";
+    js_map(spec, t.overhead);
+  }
+  if (!t.pod_level_requests.empty()) {
+    spec += ",\"resources\":{\"requests\":";
+    js_map(spec, t.pod_level_requests);
+    spec += "}";
+  }
+  if (!t.spread.empty()) {
+    spec += ",\"topologySpreadConstraints\":[";
+    for (size_t i = 0; i < t.spread.size(); ++i) {
+      const SpreadConstraint& c = t.spread[i];
+      if (i) spec.push_back(',');
+      spec += "{\"maxSkew\":" + std::to_string(c.max_skew) + ",\"topologyKey\":";
+      js_str(spec, c.topology_key);
+      spec += ",\"whenUnsatisfiable\":";
+      js_str(spec, c.when_unsatisfiable);
+      if (c.selector.present) {
+        spec += ",\"labelSelector\":{\"matchLabels\":";
+        js_map(spec, c.selector.match_labels);
+        spec += ",\"matchExpressions\":";
+        js_reqs(spec, c.selector.match_exprs);
+        spec += "}";
+      }
+      if (c.has_min_domains) spec += ",\"minDomains\":" + std::to_string(c.min_domains);
+      spec += ",\"nodeAffinityPolicy\":";
+      js_str(spec, c.node_affinity_policy);
+      spec += ",\"nodeTaintsPolicy\":";
+      js_str(spec, c.node_taints_policy);
+      if (!c.match_label_keys.empty()) {
+        spec += ",\"matchLabelKeys\":[";
+        for (size_t j = 0; j < c.match_label_keys.size(); ++j) {
+          if (j) spec.push_back(',');
+          js_str(spec, c.match_label_keys[j]);
+        }
+        spec.push_back(']');
+      }
+      spec.push_back('}');
+    }
+    spec.push_back(']');
+  }
+}
+
+inline void pod_json(const Pod& p, std::string& o, int replicas = 1) {
+  std::string meta, spec;
+  template_json(*p.tpl, meta, spec);
+  o += "{\"metadata\":{\"name\":";
+  js_str(o, p.name);
+  o += ",\"uid\":";
+  js_str(o, p.uid);
+  o += ",";
+  o += meta;
+  if (p.terminating) o += ",\"deletionTimestamp\":\"2026-01-01T00:00:00Z\"";
+  o += "},\"spec\":{";
+  if (!p.node_name.empty()) {
+    o += "\"nodeName\":";
+    js_str(o, p.node_name);
+    o += ",";
+  }
+  o += spec;
+  o += "}";
+  if (replicas > 1) o += ",\"replicas\":" + std::to_string(replicas);
+  o += "}";
+}
+
+inline void node_json(const NodeInfo& ni, std::string& o) {
+  const Node& n = ni.node;
+  o += "{\"metadata\":{\"name\":";
+  js_str(o, n.name);
+  o += ",\"labels\":";
+  js_map(o, n.labels);
+  o += "},\"spec\":{\"unschedulable\":";
+  o += n.unschedulable ? "true" : "false";
+  o += ",\"taints\":[";
+  for (size_t i = 0; i < n.taints.size(); ++i) {
+    if (i) o.push_back(',');
+    o += "{\"key\":";
+    js_str(o, n.taints[i].key);
+    o += ",\"value\":";
+    js_str(o, n.taints[i].value);
+    o += ",\"effect\":";
+    js_str(o, n.taints[i].effect);
+    o.push_back('}');
+  }
+  o += "]},\"status\":{\"allocatable\":";
+  js_map(o, n.allocatable);
+  o += "},\"pods\":[";
+  for (size_t i = 0; i < ni.pods.size(); ++i) {
+    if (i) o.push_back(',');
+    pod_json(*ni.pods[i], o);
+  }
+  o += "]}";
+}
+
+// ---------------------------------------------------------------------------------------------------
+// template interning
+// ---------------------------------------------------------------------------------------------------
+class TemplatePool {
+ public:
+  const PodTemplate* intern(PodTemplate&& t) {
+    std::string meta, spec;
+    template_json(t, meta, spec);
+    std::string key = meta + "|" + spec;
+    auto it = by_key_.find(key);
+    if (it != by_key_.end()) return it->second.get();
+    t.canonical = key;
+    t.requests = compute_requests(t);
+    auto up = std::make_unique<PodTemplate>(std::move(t));
+    const PodTemplate* raw = up.get();
+    by_key_.emplace(std::move(key), std::move(up));
+    order_.push_back(const_cast<PodTemplate*>(raw));
+    return raw;
+  }
+  const std::vector<PodTemplate*>& all() const { return order_; }
+  void clear() {
+    by_key_.clear();
+    order_.clear();
+  }
+
+ private:
+  std::unordered_map<std::string, std::unique_ptr<PodTemplate>> by_key_;
+  std::vector<PodTemplate*> order_;
+};
+
+inline PodTemplate read_template(const mj::Value& v) {
+  PodTemplate t;
+  if (const mj::Value* md = v.get_nn("metadata")) {
+    t.ns = md->str_or("namespace", "");
+    t.labels = read_strmap(md->get_nn("labels"));
+  }
+  const mj::Value* spec = v.get_nn("spec");
+  if (!spec) return t;
+  if (const mj::Value* ns = spec->get_nn("nodeSelector")) {
+    t.has_node_selector = true;
+    t.node_selector = read_strmap(ns);
+  }
+  if (const mj::Value* aff = spec->get_nn("affinity")) {
+    if (const mj::Value* na = aff->get_nn("nodeAffinity"))
+      if (const mj::Value* req = na->get_nn("requiredDuringSchedulingIgnoredDuringExecution")) {
+        t.has_required = true;
+        if (const mj::Value* terms = req->get_nn("nodeSelectorTerms"))
+          for (auto& x : terms->arr) {
+            SelectorTerm term;
+            term.exprs = read_requirements(x->get_nn("matchExpressions"));
+            term.fields = read_requirements(x->get_nn("matchFields"));
+            t.terms.push_back(std::move(term));
+          }
+      }
+    if (aff->get_nn("podAffinity") || aff->get_nn("podAntiAffinity")) t.pod_affinity = true;
+  }
+  if (const mj::Value* tols = spec->get_nn("tolerations"))
+    for (auto& x : tols->arr)
+      t.tolerations.push_back({x->str_or("key", ""), x->str_or("operator", ""), x->str_or("value", ""), x->str_or("effect", "")});
+  t.containers = read_containers(spec->get_nn("containers"), false);
+  t.init_containers = read_containers(spec->get_nn("initContainers"), true);
+  if (const mj::Value* oh = spec->get_nn("overhead")) {
+    t.has_overhead = true;
+    t.overhead = read_strmap(oh);
+  }
+  if (const mj::Value* res = spec->get_nn("resources")) t.pod_level_requests = read_strmap(res->get_nn("requests"));
+  if (const mj::Value* tsc = spec->get_nn("topologySpreadConstraints"))
+    for (auto& c : tsc->arr) {
+      SpreadConstraint sc;
+      sc.max_skew = (int32_t)c->int_or("maxSkew", 1);
+      sc.topology_key = c->str_or("topologyKey", "");
+      sc.when_unsatisfiable = c->str_or("whenUnsatisfiable", "DoNotSchedule");
+      if (const mj::Value* ls = c->get_nn("labelSelector")) {
+        sc.selector.present = true;
+        sc.selector.match_labels = read_strmap(ls->get_nn("matchLabels"));
+        sc.selector.match_exprs = read_requirements(ls->get_nn("matchExpressions"));
+      }
+      if (c->get_nn("minDomains")) {
+        sc.has_min_domains = true;
+        sc.min_domains = (int32_t)c->int_or("minDomains", 1);
+      }
+      sc.node_affinity_policy = c->str_or("nodeAffinityPolicy", "Honor");
+      sc.node_taints_policy = c->str_or("nodeTaintsPolicy", "Ignore");
+      if (const mj::Value* mk = c->get_nn("matchLabelKeys"))
+        for (auto& x : mk->arr) sc.match_label_keys.push_back(x->s);
+      t.spread.push_back(std::move(sc));
+    }
+  return t;
+}
+
+inline Node read_node(const mj::Value& v) {
+  Node n;
+  if (const mj::Value* md = v.get_nn("metadata")) {
+    n.name = md->str_or("name", "");
+    n.labels = read_strmap(md->get_nn("labels"));
+  }
+  if (const mj::Value* spec = v.get_nn("spec")) {
+    n.unschedulable = spec->bool_or("unschedulable", false);
+    if (const mj::Value* ts = spec->get_nn("taints"))
+      for (auto& t : ts->arr) n.taints.push_back({t->str_or("key", ""), t->str_or("value", ""), t->str_or("effect", "")});
+  }
+  if (const mj::Value* st = v.get_nn("status")) n.allocatable = read_strmap(st->get_nn("allocatable"));
+  return n;
+}
+
+}  // namespace ykh

@@ -1,0 +1,272 @@
+"""Python face of the host library: the reference's PredicateManager interface over the MI355X engine.
+
+Method names and result conventions follow /root/reference/pkg/plugin/predicates/predicate_manager.go:47-55 so the
+parity tests read like predicate_manager_test.go:
+
+    pm = GpuPredicateManager()                       # NewPredicateManager(handle)
+    pm = GpuPredicateManager.internal(ep, ep, ep, ep)  # newPredicateManagerInternal(handle, resPre, allocPre, resFilt, allocFilt)
+    plugin, err = pm.predicates(pod, node, allocate)   # ("", None) when the pod fits
+    index = pm.preemption_predicates(pod, node, victims, start_index)
+
+There is no CPU evaluation path: constructing a manager without a visible GPU raises.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _ffi
+
+PLUGIN_BITS = {
+    "NodeUnschedulable": 1 << 0,
+    "NodeName": 1 << 1,
+    "TaintToleration": 1 << 2,
+    "NodeAffinity": 1 << 3,
+    "NodePorts": 1 << 4,
+    "NodeResourcesFit": 1 << 5,
+    "PodTopologySpread": 1 << 6,
+}
+ALL_PLUGINS = 0x7F
+OUT_BITMAP, OUT_COUNTS, OUT_DECISIONS, OUT_DECISION_KEYS = 1, 2, 4, 8
+EVAL_PROFILE, EVAL_DIRECT = 1 << 8, 1 << 9
+
+
+def plugin_mask(names):
+    """enabledPlugins(...) of predicate_manager_test.go:2201-2207; names outside the engine's set are ignored like absent plugins."""
+    if isinstance(names, int):
+        return names
+    m = 0
+    for n in names:
+        if n == "*":
+            return ALL_PLUGINS
+        m |= PLUGIN_BITS.get(n, 0)
+    return m
+
+
+class PredicateError(Exception):
+    """The error value returned by Predicates(): carries the failing plugin like Context.IsPodFitNode's joined error."""
+
+    def __init__(self, plugin, message):
+        super().__init__(f"failed plugin: '{plugin}'\n{message}")
+        self.plugin = plugin
+        self.message = message
+
+
+class GpuPredicateManager:
+    def __init__(self, device=0):
+        self._L = _ffi.load_ykhost()
+        self._P = _ffi.load_ykpred()
+        err = C.create_string_buffer(512)
+        self._h = self._L.ykhost_create(device, err, 512)
+        if not self._h:
+            raise RuntimeError("ykhost_create failed (the engine has no CPU fallback): " + err.value.decode())
+        # NewPredicateManager's phase lists (predicate_manager.go:321-373), restricted to the engine's plugins
+        reserve_pre = PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"]
+        reserve_filt = reserve_pre | PLUGIN_BITS["NodeUnschedulable"] | PLUGIN_BITS["NodeName"] | PLUGIN_BITS["TaintToleration"]
+        self._masks = (reserve_pre, ALL_PLUGINS, reserve_filt, ALL_PLUGINS)
+
+    @classmethod
+    def internal(cls, reservation_prefilters, allocation_prefilters, reservation_filters, allocation_filters, device=0):
+        pm = cls(device)
+        pm._masks = (plugin_mask(reservation_prefilters), plugin_mask(allocation_prefilters),
+                     plugin_mask(reservation_filters), plugin_mask(allocation_filters))
+        pm._L.ykhost_set_plugins(pm._h, *pm._masks)
+        return pm
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ykhost_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RuntimeError(self._L.ykhost_last_error(self._h).decode())
+        return rc
+
+    # ---- cluster state (SchedulerCache mirror) ------------------------------------------------------------
+    def load_snapshot(self, snapshot):
+        text = snapshot if isinstance(snapshot, (str, bytes)) else json.dumps(snapshot)
+        self._check(self._L.ykhost_load_snapshot(self._h, text.encode() if isinstance(text, str) else text))
+
+    def update_node(self, node):
+        self._check(self._L.ykhost_update_node(self._h, json.dumps(node).encode()))
+
+    def remove_node(self, name):
+        self._check(self._L.ykhost_remove_node(self._h, name.encode()))
+
+    def update_pod(self, pod):
+        self._check(self._L.ykhost_update_pod(self._h, json.dumps(pod).encode()))
+
+    def remove_pod(self, uid):
+        self._check(self._L.ykhost_remove_pod(self._h, uid.encode()))
+
+    def assume_pod(self, uid, node_name):
+        self._check(self._L.ykhost_assume_pod(self._h, uid.encode(), node_name.encode()))
+
+    def forget_pod(self, uid):
+        self._check(self._L.ykhost_forget_pod(self._h, uid.encode()))
+
+    def generate_kwok(self, seed, num_nodes, num_pods, num_templates=0, node_affinity=1, tolerations=1, unique_requests=0,
+                      gang_size=0, node_index_offset=0):
+        cfg = _ffi.YkhostKwok(seed=seed, num_nodes=num_nodes, num_pods=num_pods, num_templates=num_templates,
+                              node_affinity=node_affinity, tolerations=tolerations, unique_requests=unique_requests,
+                              gang_size=gang_size, node_index_offset=node_index_offset)
+        self._check(self._L.ykhost_generate_kwok(self._h, C.byref(cfg)))
+
+    @property
+    def num_nodes(self):
+        return self._L.ykhost_num_nodes(self._h)
+
+    @property
+    def num_pods(self):
+        return self._L.ykhost_num_pods(self._h)
+
+    def pod_index(self, uid):
+        return self._L.ykhost_pod_index(self._h, uid.encode())
+
+    def node_index(self, name):
+        return self._L.ykhost_node_index(self._h, name.encode())
+
+    def dump_snapshot(self, pods=None, nodes=None):
+        """Snapshot JSON (text) of the selected pending pods / nodes — what the oracle is fed in parity tests."""
+        pa = None if pods is None else np.ascontiguousarray(pods, dtype=np.int32)
+        na = None if nodes is None else np.ascontiguousarray(nodes, dtype=np.int32)
+        args = (pa.ctypes.data if pa is not None else None, 0 if pa is None else len(pa),
+                na.ctypes.data if na is not None else None, 0 if na is None else len(na))
+        need = self._L.ykhost_dump_snapshot(self._h, *args, None, 0)
+        self._check(need)
+        buf = C.create_string_buffer(need)
+        self._check(self._L.ykhost_dump_snapshot(self._h, *args, buf, need))
+        return buf.value.decode()
+
+    def sync(self):
+        self._check(self._L.ykhost_sync(self._h))
+
+    def stats(self):
+        out = np.zeros(8, dtype=np.int64)
+        self._L.ykhost_stats(self._h, out.ctypes.data)
+        keys = ["R", "KT", "W", "taints", "requirements", "templates", "specs", "encode_us"]
+        return dict(zip(keys, out.tolist()))
+
+    # ---- the PredicateManager interface ---------------------------------------------------------------------
+    def _resolve(self, pod, node):
+        p = pod if isinstance(pod, int) else self.pod_index(pod)
+        n = node if isinstance(node, int) else self.node_index(node)
+        if p < 0 or n < 0:
+            raise KeyError("unknown pod or node")
+        return p, n
+
+    def predicates(self, pod, node, allocate):
+        """Predicates(pod, node, allocate) → (plugin, err): ("", None) on fit, else (failing plugin, PredicateError)."""
+        p, n = self._resolve(pod, node)
+        plugin = C.create_string_buffer(64)
+        msg = C.create_string_buffer(512)
+        rc = self._check(self._L.ykhost_predicates(self._h, p, n, 1 if allocate else 0, plugin, 64, msg, 512))
+        if rc == 1:
+            return "", None
+        return plugin.value.decode(), PredicateError(plugin.value.decode(), msg.value.decode())
+
+    def preemption_predicates(self, pod, node, victims, start_index):
+        """PreemptionPredicates(pod, node, victims, startIndex) → index or -1. victims: UIDs (None = nil pod)."""
+        p, n = self._resolve(pod, node)
+        arr = (C.c_char_p * max(len(victims), 1))()
+        for i, v in enumerate(victims):
+            arr[i] = None if v is None else v.encode()
+        r = self._L.ykhost_preemption_predicates(self._h, p, n, arr, len(victims), start_index)
+        if r < -1:
+            raise RuntimeError(self._L.ykhost_last_error(self._h).decode())
+        return r
+
+    def pod_request(self, pod):
+        buf = C.create_string_buffer(4096)
+        self._check(self._L.ykhost_pod_request_json(self._h, pod, buf, 4096))
+        return json.loads(buf.value.decode())
+
+    # ---- batched evaluation ---------------------------------------------------------------------------------
+    def evaluate(self, allocate=True, bitmap=True, counts=True, decisions=True, profile=False, direct=False):
+        opts = (OUT_BITMAP if bitmap else 0) | (OUT_COUNTS if counts else 0) | (OUT_DECISIONS if decisions else 0)
+        opts |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0)
+        self._check(self._L.ykhost_evaluate(self._h, 1 if allocate else 0, opts))
+
+    def evaluate_into(self, bitmap=None, counts=None, decisions=None, keys=None, stream=None, allocate=True, profile=False,
+                      direct=False):
+        """ykpred_eval with caller-owned DEVICE outputs (objects exposing data_ptr(), e.g. torch tensors) on the
+        caller's HIP stream — how a multi-GPU driver keeps the results where its collectives can reach them."""
+        self.sync()
+        a = _ffi.YkpredEvalArgs()
+        a.prefilter_plugins = self._masks[1] if allocate else self._masks[0]
+        a.filter_plugins = self._masks[3] if allocate else self._masks[2]
+        a.options = OUT_BITMAP | OUT_COUNTS | OUT_DECISIONS | (OUT_DECISION_KEYS if keys is not None else 0)
+        a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0)
+        a.bitmap = None if bitmap is None else bitmap.data_ptr()
+        a.counts = None if counts is None else counts.data_ptr()
+        a.decisions = None if decisions is None else decisions.data_ptr()
+        a.decision_keys = None if keys is None else keys.data_ptr()
+        a.stream = stream
+        self._pcheck(self._P.ykpred_eval(self.engine, C.byref(a)))
+
+    @property
+    def engine(self):
+        return self._L.ykhost_engine(self._h)
+
+    def _pcheck(self, rc):
+        if rc != 0:
+            raise RuntimeError("ykpred: " + self._P.ykpred_last_error(self.engine).decode())
+
+    def layout(self):
+        lay = _ffi.YkpredLayout()
+        self._pcheck(self._P.ykpred_get_layout(self.engine, C.byref(lay)))
+        return lay
+
+    def synchronize(self):
+        self._pcheck(self._P.ykpred_synchronize(self.engine))
+
+    def read_bitmap(self, first=0, count=None):
+        lay = self.layout()
+        count = lay.num_pods - first if count is None else count
+        out = np.zeros((count, lay.row_words), dtype=np.uint64)
+        self._pcheck(self._P.ykpred_read_bitmap(self.engine, first, count, out.ctypes.data))
+        return out
+
+    def read_counts(self):
+        out = np.zeros(self.layout().num_pods, dtype=np.int32)
+        self._pcheck(self._P.ykpred_read_counts(self.engine, out.ctypes.data))
+        return out
+
+    def read_decisions(self):
+        out = np.zeros(self.layout().num_pods, dtype=np.int32)
+        self._pcheck(self._P.ykpred_read_decisions(self.engine, out.ctypes.data))
+        return out
+
+    def read_scores(self):
+        out = np.zeros(self.layout().num_nodes, dtype=np.float64)
+        self._pcheck(self._P.ykpred_read_scores(self.engine, out.ctypes.data))
+        return out
+
+    def checksum(self):
+        v = C.c_uint64(0)
+        self._pcheck(self._P.ykpred_bitmap_checksum(self.engine, C.byref(v)))
+        return v.value
+
+    def query(self, pods, nodes, allocate=True, pre_mask=None, filt_mask=None):
+        """Batch of Predicates() answers evaluated on the device: returns (fit, plugin_code, reason) arrays."""
+        pa = np.ascontiguousarray(pods, dtype=np.int32)
+        na = np.ascontiguousarray(nodes, dtype=np.int32)
+        fit = np.zeros(len(pa), dtype=np.uint8)
+        code = np.zeros(len(pa), dtype=np.uint8)
+        reason = np.zeros(len(pa), dtype=np.uint32)
+        self.sync()
+        pre = ALL_PLUGINS if pre_mask is None else pre_mask
+        filt = ALL_PLUGINS if filt_mask is None else filt_mask
+        self._pcheck(self._P.ykpred_query(self.engine, len(pa), pa.ctypes.data, na.ctypes.data, pre, filt, fit.ctypes.data,
+                                          code.ctypes.data, reason.ctypes.data))
+        return fit, code, reason
+
+    def timing(self):
+        t = _ffi.YkpredTiming()
+        self._pcheck(self._P.ykpred_last_timing(self.engine, C.byref(t)))
+        return {"total_ms": t.total_ms,
+                "kernels": [(t.kernel_name[i].decode(), t.kernel_ms[i]) for i in range(t.num_kernels)]}
