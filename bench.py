@@ -55,9 +55,9 @@ def cpu_baseline(pm, budget_s, seed):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as orc
     rng = np.random.default_rng(seed)
-    n_nodes = min(pm.num_nodes, 2048)
+    n_nodes = min(pm.num_nodes, 4096)
     nodes = np.sort(rng.choice(pm.num_nodes, n_nodes, replace=False)).astype(np.int32)
-    pods = np.sort(rng.choice(pm.num_pods, min(pm.num_pods, 256), replace=False)).astype(np.int32)
+    pods = np.sort(rng.choice(pm.num_pods, min(pm.num_pods, 16384), replace=False)).astype(np.int32)
     o = orc.Oracle(pm.dump_snapshot(pods=pods, nodes=nodes))
     t0 = time.perf_counter()
     o.eval_grid(pods=np.arange(8, dtype=np.int32), threads=1)

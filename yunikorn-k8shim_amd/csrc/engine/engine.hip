@@ -570,8 +570,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) {
     hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, nt, e->d_score.as<double>(), e->d_key.as<u64>());
     tm.mark("k_score");
-    hipLaunchKernelGGL(ykk::k_rank, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, N, e->d_key.as<u64>(), e->d_rank.as<int>(),
-                       e->d_perm.as<int>());
+    HIPCHK(hipMemsetAsync(e->d_rank.p, 0, (size_t)N * sizeof(int), st));
+    hipLaunchKernelGGL(ykk::k_rank_count, dim3((unsigned)nblk_nodes, (unsigned)((N + ykk::kRankTile - 1) / ykk::kRankTile)),
+                       dim3(ykk::kBlock), 0, st, N, e->d_key.as<u64>(), e->d_rank.as<int>());
+    hipLaunchKernelGGL(ykk::k_rank_perm, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, N, e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.mark("k_rank");
   }
   // 2. signature planes
