@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--direct", action="store_true", help="time the per-pair kernel instead of the plane/class path")
     ap.add_argument("--gather-bitmap", action="store_true", help="N>1: also all-gather the shard bitmaps (reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--variant", type=int, default=0, help="k_combine store flavour (0 dwordx4, 1 dwordx2, 2/3 = non-temporal)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps run with per-kernel HIP events for `roofline`")
     return ap.parse_args()
 
@@ -102,7 +103,7 @@ def main():
 
     def step(profile=False):
         pm.evaluate_into(counts=counts, decisions=decisions, keys=keys if world > 1 else None, stream=stream.cuda_stream,
-                         profile=profile, direct=a.direct)
+                         profile=profile, direct=a.direct, variant=a.variant)
         if world > 1:
             shard.exchange_decisions(counts, decisions, keys, rank * a.nodes, dist)
 

@@ -90,14 +90,20 @@ struct ykpred_engine {
   DevBuf d_class_sig, d_class_pin, d_chunk_class, d_chunk_begin, d_chunk_len, d_chunk_first, d_members;
   DevBuf d_class_count, d_class_best;
   bool pods_set = false, classes_dirty = true;
+  int chunk_members = ykk::kChunkMembers;  // tunable: cfg.reserved[0] (1..64)
+  bool chunk_sorted = true;                // tunable: cfg.reserved[1] == 1 disables the pod-order dispatch
 
   // --- outputs
   DevBuf d_bitmap, d_counts, d_decisions, d_keys, d_scratch;
   void* last_bitmap = nullptr;
   void *last_counts = nullptr, *last_decisions = nullptr, *last_keys = nullptr;
 
-  // --- timing
-  hipEvent_t ev[YKPRED_MAX_TIMED_KERNELS + 1]{};
+  // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
+  // --- timing: one (start, stop) event pair per kernel, recorded on the stream the kernel is launched on
+  hipEvent_t ev[2 * YKPRED_MAX_TIMED_KERNELS + 2]{};
   bool ev_ready = false;
   int timed = 0;
   const char* timed_name[YKPRED_MAX_TIMED_KERNELS]{};
@@ -203,14 +209,25 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   for (int c = 0; c < C; ++c) class_off[(size_t)c + 1] = class_off[(size_t)c] + class_size[(size_t)c];
   std::vector<int32_t> members((size_t)P), cursor(class_off.begin(), class_off.end() - 1);
   for (int p = 0; p < P; ++p) members[(size_t)cursor[(size_t)pod_class[(size_t)p]]++] = p;
+  // Chunks of <= chunk_members pods of one class. Members of a class are in ascending pod order, and the chunks are
+  // dispatched in ascending order of their first pod: the ~2k blocks resident at any moment then write bitmap rows
+  // of one narrow, advancing window instead of rows scattered over the whole bitmap (DRAM page locality).
+  const int cm = e->chunk_members;
+  struct Chunk {
+    int32_t cls, begin, len, first, first_pod;
+  };
+  std::vector<Chunk> chunks;
+  for (int c = 0; c < C; ++c)
+    for (int b = class_off[(size_t)c]; b < class_off[(size_t)c + 1]; b += cm)
+      chunks.push_back({c, b, std::min(cm, class_off[(size_t)c + 1] - b), b == class_off[(size_t)c] ? 1 : 0, members[(size_t)b]});
+  if (e->chunk_sorted)
+    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return x.first_pod < y.first_pod; });
   std::vector<int32_t> ch_class, ch_begin, ch_len, ch_first;
-  for (int c = 0; c < C; ++c) {
-    for (int b = class_off[(size_t)c]; b < class_off[(size_t)c + 1]; b += ykk::kChunkMembers) {
-      ch_class.push_back(c);
-      ch_begin.push_back(b);
-      ch_len.push_back(std::min(ykk::kChunkMembers, class_off[(size_t)c + 1] - b));
-      ch_first.push_back(b == class_off[(size_t)c] ? 1 : 0);
-    }
+  for (const Chunk& k : chunks) {
+    ch_class.push_back(k.cls);
+    ch_begin.push_back(k.begin);
+    ch_len.push_back(k.len);
+    ch_first.push_back(k.first);
   }
   e->C = C;
   e->NC = (int)ch_class.size();
@@ -229,17 +246,19 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   return YKPRED_OK;
 }
 
-int ensure_planes(ykpred_engine* e) {
+// (Re)allocated plane buffers are zeroed ON THE LAUNCH STREAM: the engine's stream is non-blocking, so a
+// null-stream hipMemset would not be ordered against the kernels that follow.
+int ensure_planes(ykpred_engine* e, hipStream_t st) {
   size_t row = (size_t)e->row_stride * sizeof(u64);
   for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff}) {
     size_t need = row * (size_t)std::max(f->D, 1);
     if (f->canon.cap < need) {
       HIPCHK(f->canon.ensure(need));
-      HIPCHK(hipMemset(f->canon.p, 0, need));
+      HIPCHK(hipMemsetAsync(f->canon.p, 0, need, st));
     }
     if (f->ranked.cap < need) {
       HIPCHK(f->ranked.ensure(need));
-      HIPCHK(hipMemset(f->ranked.p, 0, need));
+      HIPCHK(hipMemsetAsync(f->ranked.p, 0, need, st));
     }
   }
   return YKPRED_OK;
@@ -247,20 +266,26 @@ int ensure_planes(ykpred_engine* e) {
 
 struct Timer {
   ykpred_engine* e;
-  hipStream_t st;
   bool on;
-  void start() {
+  void start(hipStream_t st) {
     e->timed = 0;
     e->timing_valid = false;
-    if (on) (void)hipEventRecord(e->ev[0], st);
+    if (on) (void)hipEventRecord(e->ev[2 * YKPRED_MAX_TIMED_KERNELS], st);
   }
-  void mark(const char* name) {
+  // bracket one kernel: begin() before the launch, end() after it, both on the launch stream
+  void begin(hipStream_t st) {
+    if (on && e->timed < YKPRED_MAX_TIMED_KERNELS) (void)hipEventRecord(e->ev[2 * e->timed], st);
+  }
+  void end(hipStream_t st, const char* name) {
     if (!on || e->timed >= YKPRED_MAX_TIMED_KERNELS) return;
+    (void)hipEventRecord(e->ev[2 * e->timed + 1], st);
     e->timed_name[e->timed] = name;
-    (void)hipEventRecord(e->ev[e->timed + 1], st);
     e->timed++;
   }
-  void done() { e->timing_valid = on; }
+  void done(hipStream_t st) {
+    if (on) (void)hipEventRecord(e->ev[2 * YKPRED_MAX_TIMED_KERNELS + 1], st);
+    e->timing_valid = on;
+  }
 };
 
 }  // namespace
@@ -309,12 +334,22 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->R = cfg->num_resources;
   e->KT = cfg->taint_words;
   e->W = cfg->label_words;
+  if (cfg->reserved[0] >= 1 && cfg->reserved[0] <= ykk::kChunkMembers) e->chunk_members = cfg->reserved[0];
+  e->chunk_sorted = cfg->reserved[1] != 1;
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(s);
     delete e;
     return YKPRED_E_DEVICE;
   }
+  {
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
+      (void)hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking);
+  }
+  (void)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   e->ev_ready = true;
   *out = e;
@@ -335,6 +370,9 @@ void ykpred_destroy(ykpred_engine_t* e) {
     b->release();
   if (e->ev_ready)
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -542,11 +580,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_counts = a->counts ? a->counts : e->d_counts.p;
   e->last_decisions = a->decisions ? a->decisions : e->d_decisions.p;
   e->last_keys = a->decision_keys ? a->decision_keys : e->d_keys.p;
-  TRY(ensure_planes(e));
-  Timer tm{e, st, (a->options & YKPRED_EVAL_PROFILE) != 0};
-  tm.start();
+  TRY(ensure_planes(e, st));
+  Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
+  tm.start(st);
   if (N == 0 || P == 0) {
-    tm.done();
+    tm.done(st);
     return YKPRED_OK;
   }
   ykk::NodeTable nt = node_table(e);
@@ -558,83 +596,113 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (a->options & YKPRED_EVAL_DIRECT) {
     ykk::SpecTable stbl = spec_table(e);
     dim3 grid((unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock), (unsigned)((P + ykk::kWave - 1) / ykk::kWave));
+    tm.begin(st);
     hipLaunchKernelGGL(ykk::k_direct, grid, dim3(ykk::kBlock), 0, st, nt, stbl, P, e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre,
                        filt, bitmap, e->row_words, e->row_stride);
-    tm.mark("k_direct");
+    tm.end(st, "k_direct");
     HIPCHK(hipGetLastError());
-    tm.done();
+    tm.done(st);
     return YKPRED_OK;
   }
 
-  // 1. bin-pack order (needed for the rank-ordered planes of the decision stage)
-  if (want_dec) {
-    hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, nt, e->d_score.as<double>(), e->d_key.as<u64>());
-    tm.mark("k_score");
-    HIPCHK(hipMemsetAsync(e->d_rank.p, 0, (size_t)N * sizeof(int), st));
-    hipLaunchKernelGGL(ykk::k_rank_count, dim3((unsigned)nblk_nodes, (unsigned)((N + ykk::kRankTile - 1) / ykk::kRankTile)),
-                       dim3(ykk::kBlock), 0, st, N, e->d_key.as<u64>(), e->d_rank.as<int>());
-    hipLaunchKernelGGL(ykk::k_rank_perm, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, st, N, e->d_rank.as<int>(), e->d_perm.as<int>());
-    tm.mark("k_rank");
-  }
-  // 2. signature planes
-  const unsigned zdim = want_dec ? 2u : 1u;
   const unsigned wgroups = (unsigned)((e->row_words + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock);
   const bool res_on = filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT;
-  const bool tol_on = true;  // also carries "node exists" for the padding bits
   const bool aff_on = (filt | pre) & YKPRED_PLUGIN_NODE_AFFINITY;
+  const int fit_error = (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1;
   auto sig_chunks = [](int D) { return (unsigned)((D + ykk::kSigsPerBlock - 1) / ykk::kSigsPerBlock); };
-  if (res_on) {
-    ykk::PlaneOut o{e->fam_res.canon.as<u64>(), e->fam_res.ranked.as<u64>(), e->row_stride, e->fam_res.D};
-    hipLaunchKernelGGL(ykk::k_plane_res, dim3(wgroups, sig_chunks(e->fam_res.D), zdim), dim3(ykk::kBlock), 0, st, nt, e->d_perm.as<int>(),
-                       e->d_sig_req.as<i64>(), o, (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1, e->row_words);
-    tm.mark("k_plane_res");
-  }
-  if (tol_on) {
-    ykk::PlaneOut o{e->fam_tol.canon.as<u64>(), e->fam_tol.ranked.as<u64>(), e->row_stride, e->fam_tol.D};
-    hipLaunchKernelGGL(ykk::k_plane_tol, dim3(wgroups, sig_chunks(e->fam_tol.D), zdim), dim3(ykk::kBlock), 0, st, nt, e->d_perm.as<int>(),
-                       e->d_sig_tol.as<u64>(), e->d_sig_tolflags.as<unsigned>(), o, filt, e->row_words);
-    tm.mark("k_plane_tol");
-  }
-  if (aff_on) {
-    ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
-                    e->d_sig_pre_terms.as<u64>()};
-    ykk::PlaneOut o{e->fam_aff.canon.as<u64>(), e->fam_aff.ranked.as<u64>(), e->row_stride, e->fam_aff.D};
-    hipLaunchKernelGGL(ykk::k_plane_aff, dim3(wgroups, sig_chunks(e->fam_aff.D), zdim), dim3(ykk::kBlock), 0, st, nt, e->d_perm.as<int>(), as,
-                       o, pre, filt, e->row_words);
-    tm.mark("k_plane_aff");
-  }
-  // 3. combine → bitmap (+ class feasible counts)
+  const unsigned aff_chunks = (unsigned)((e->fam_aff.D + ykk::kAffSigsPerBlock - 1) / ykk::kAffSigsPerBlock);
+  ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
+                  e->d_sig_pre_terms.as<u64>()};
+  ykk::PlaneOut o_res{e->fam_res.canon.as<u64>(), e->fam_res.ranked.as<u64>(), e->row_stride, e->fam_res.D};
+  ykk::PlaneOut o_tol{e->fam_tol.canon.as<u64>(), e->fam_tol.ranked.as<u64>(), e->row_stride, e->fam_tol.D};
+  ykk::PlaneOut o_aff{e->fam_aff.canon.as<u64>(), e->fam_aff.ranked.as<u64>(), e->row_stride, e->fam_aff.D};
+  // signature planes of one node order (perm == nullptr: canonical). The tol family always runs: it also carries
+  // "node exists" for the padding bits of the last word.
+  auto launch_planes = [&](hipStream_t s, const int* perm, const char* const* names) {
+    if (res_on) {
+      tm.begin(s);
+      hipLaunchKernelGGL(ykk::k_plane_res, dim3(wgroups, sig_chunks(e->fam_res.D)), dim3(ykk::kBlock), 0, s, nt, perm, e->d_sig_req.as<i64>(),
+                         o_res, fit_error, e->row_words);
+      tm.end(s, names[0]);
+    }
+    tm.begin(s);
+    hipLaunchKernelGGL(ykk::k_plane_tol, dim3(wgroups, sig_chunks(e->fam_tol.D)), dim3(ykk::kBlock), 0, s, nt, perm, e->d_sig_tol.as<u64>(),
+                       e->d_sig_tolflags.as<unsigned>(), o_tol, filt, e->row_words);
+    tm.end(s, names[1]);
+    if (aff_on) {
+      tm.begin(s);
+      hipLaunchKernelGGL(ykk::k_plane_aff, dim3(wgroups, aff_chunks), dim3(ykk::kBlock), 0, s, nt, perm, as, o_aff, pre, filt,
+                         e->row_words);
+      tm.end(s, names[2]);
+    }
+  };
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>()};
-  // the class table stores plane rows for all three families; disabled families are masked out here
   ykk::Planes pc{res_on ? e->fam_res.canon.as<u64>() : nullptr, e->fam_tol.canon.as<u64>(), aff_on ? e->fam_aff.canon.as<u64>() : nullptr,
                  nullptr, e->row_stride};
   ykk::Planes pr{res_on ? e->fam_res.ranked.as<u64>() : nullptr, e->fam_tol.ranked.as<u64>(), aff_on ? e->fam_aff.ranked.as<u64>() : nullptr,
                  nullptr, e->row_stride};
   const int pin_on = (filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0;
+
+  // ---- bitmap branch on the caller's stream: canonical planes first (they are short and on the critical path) ...
+  static const char* const cnames[3] = {"k_plane_res", "k_plane_tol", "k_plane_aff"};
+  launch_planes(st, nullptr, cnames);
+  // ---- decision branch on the (high-priority) aux stream, forked once the canonical planes are queued:
+  // score → rank → rank-ordered planes → first feasible node per class. It is compute/LDS bound and overlaps the
+  // HBM-write-bound k_combine below.
+  if (want_dec) {
+    hipStream_t sb = e->aux_stream;
+    HIPCHK(hipEventRecord(e->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(sb, e->ev_fork, 0));
+    tm.begin(sb);
+    hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, nt, e->d_score.as<double>(), e->d_key.as<u64>());
+    tm.end(sb, "k_score");
+    HIPCHK(hipMemsetAsync(e->d_rank.p, 0, (size_t)N * sizeof(int), sb));
+    tm.begin(sb);
+    hipLaunchKernelGGL(ykk::k_rank_count, dim3((unsigned)nblk_nodes, (unsigned)((N + ykk::kRankTile - 1) / ykk::kRankTile)),
+                       dim3(ykk::kBlock), 0, sb, N, e->d_key.as<u64>(), e->d_rank.as<int>());
+    hipLaunchKernelGGL(ykk::k_rank_perm, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_rank.as<int>(), e->d_perm.as<int>());
+    tm.end(sb, "k_rank");
+    static const char* const rnames[3] = {"k_plane_res(ranked)", "k_plane_tol(ranked)", "k_plane_aff(ranked)"};
+    launch_planes(sb, e->d_perm.as<int>(), rnames);
+    tm.begin(sb);
+    hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
+                       pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
+    tm.end(sb, "k_decide");
+    HIPCHK(hipEventRecord(e->ev_join, sb));
+  }
+  // ---- ... then combine
   HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   {
-    const int seg = ykk::kBlock * ykk::kCombineUnroll;
+    // store flavour: bits 16-17 of options select an experimental variant (0 = default)
+    const unsigned variant = (a->options >> 16) & 3u;
+    const int wpl = (variant & 1u) ? 1 : 2;
+    const int seg = ykk::kBlock * ykk::kCombineUnroll * wpl;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
-    hipLaunchKernelGGL(ykk::k_combine, grid, dim3(ykk::kBlock), 0, st, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                       e->d_class_count.as<int>());
-    tm.mark("k_combine");
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), 0, st, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                         e->d_class_count.as<int>());
+    };
+    tm.begin(st);
+    switch (variant) {
+      case 0: launch(ykk::k_combine<2, false>); break;
+      case 1: launch(ykk::k_combine<1, false>); break;
+      case 2: launch(ykk::k_combine<2, true>); break;
+      default: launch(ykk::k_combine<1, true>); break;
+    }
+    tm.end(st, "k_combine");
   }
-  // 4. decisions
-  if (want_dec) {
-    hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct,
-                       pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
-    tm.mark("k_decide");
-  }
+  if (want_dec) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
   if (want_dec || want_cnt) {
+    tm.begin(st);
     hipLaunchKernelGGL(ykk::k_scatter, dim3((unsigned)((P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, P,
                        e->d_pod_class.as<int>(), e->d_class_count.as<int>(), e->d_class_best.as<int>(), e->d_key.as<u64>(),
                        want_cnt ? (int*)e->last_counts : nullptr, want_dec ? (int*)e->last_decisions : nullptr,
                        want_keys ? (i64*)e->last_keys : nullptr);
-    tm.mark("k_scatter");
+    tm.end(st, "k_scatter");
   }
   HIPCHK(hipGetLastError());
-  tm.done();
+  tm.done(st);
   return YKPRED_OK;
 }
 
@@ -668,16 +736,16 @@ int32_t ykpred_last_timing(const ykpred_engine_t* ce, ykpred_timing_t* o) {
   if (!e || !o) return YKPRED_E_INVALID;
   if (!e->timing_valid) return fail(e, YKPRED_E_STATE, "last eval was not run with YKPRED_EVAL_PROFILE");
   HIPCHK(hipSetDevice(e->cfg.device));
-  if (e->timed > 0) HIPCHK(hipEventSynchronize(e->ev[e->timed]));
+  HIPCHK(hipDeviceSynchronize());
   o->num_kernels = e->timed;
   o->total_ms = 0.f;
   for (int i = 0; i < e->timed; ++i) {
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[2 * i], e->ev[2 * i + 1]));
     o->kernel_ms[i] = ms;
     o->kernel_name[i] = e->timed_name[i];
   }
-  if (e->timed > 0) HIPCHK(hipEventElapsedTime(&o->total_ms, e->ev[0], e->ev[e->timed]));
+  HIPCHK(hipEventElapsedTime(&o->total_ms, e->ev[2 * YKPRED_MAX_TIMED_KERNELS], e->ev[2 * YKPRED_MAX_TIMED_KERNELS + 1]));
   return YKPRED_OK;
 }
 
@@ -727,7 +795,7 @@ int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(e->d_scratch.ensure(sizeof(u64)));
-  HIPCHK(hipMemset(e->d_scratch.p, 0, sizeof(u64)));
+  HIPCHK(hipMemsetAsync(e->d_scratch.p, 0, sizeof(u64), e->own_stream));
   if (e->P && e->row_words)
     hipLaunchKernelGGL(ykk::k_checksum, dim3(2048), dim3(ykk::kBlock), 0, e->own_stream, (const u64*)e->last_bitmap, e->P, e->row_words,
                        e->row_stride, e->d_scratch.as<u64>());

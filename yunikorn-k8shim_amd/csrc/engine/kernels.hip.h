@@ -127,21 +127,22 @@ struct PlaneOut {
   int D;        // signatures
 };
 
-// blockIdx.x: group of 4 node words; blockIdx.y: chunk of kSigsPerBlock signatures; blockIdx.z: 0 canonical, 1 ranked.
-// Returns the node handled by this lane (-1 = past the end) and the word index.
+// blockIdx.x: group of 4 node words; blockIdx.y: chunk of kSigsPerBlock signatures. `perm` != null selects the
+// rank-ordered plane (position i holds node perm[i]); the canonical and the ranked planes are separate launches so
+// that the ranked ones can run on the decision stream. Returns the node of this lane (-1 = past the end).
 __device__ __forceinline__ int plane_node(int n_nodes, const int* __restrict__ perm, int* word) {
   int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   int w = blockIdx.x * kWavesPerBlock + wave;
   *word = w;
   int pos = w * kWave + lane;
   if (pos >= n_nodes) return -1;
-  return blockIdx.z ? perm[pos] : pos;
+  return perm ? perm[pos] : pos;
 }
-__device__ __forceinline__ void plane_store(const PlaneOut& o, int word, int d0, u64 keep) {
+__device__ __forceinline__ void plane_store(const PlaneOut& o, bool ranked, int word, int d0, u64 keep) {
   int lane = threadIdx.x % kWave;
   int d = d0 + lane;
   if (word < o.stride && d < o.D) {
-    u64* base = blockIdx.z ? o.ranked : o.canon;
+    u64* base = ranked ? o.ranked : o.canon;
     base[(size_t)d * o.stride + word] = keep;
   }
 }
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void k_plane_res(NodeTable t, const int* __
     u64 b = __ballot(ok);
     if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
   }
-  plane_store(o, word, d0, keep);
+  plane_store(o, perm != nullptr, word, d0, keep);
 }
 
 // TaintToleration.Filter + NodeUnschedulable.Filter (A.4, A.7). Signature = (tolerated mask, tolerates-unschedulable).
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_plane_tol(NodeTable t, const int* __
     u64 b = __ballot(ok);
     if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
   }
-  plane_store(o, word, d0, keep);
+  plane_store(o, perm != nullptr, word, d0, keep);
 }
 
 // NodeAffinity PreFilter + Filter (A.5). Signature = (flags, Filter DNF, PreFilter node-name DNF).
@@ -237,29 +238,47 @@ __device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0,
   }
   return any;
 }
-__device__ __forceinline__ bool affinity_ok(const AffSigs& s, int d, const u64 (&lb)[kMaxW], int W, unsigned pre_mask, unsigned filt_mask,
-                                            unsigned* reason_code) {
-  unsigned f = s.flags[d];
-  bool pre_en = pre_mask & kPlugAffinity, filt_en = filt_mask & kPlugAffinity;
-  bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
-  if (pre_en && !skip) {
-    if (f & kSpecPreReject) {
-      if (reason_code) *reason_code = 2;  // PreFilter rejected the pod (:236-238)
-      return false;
-    }
-    if ((f & kSpecPreNames) && !dnf_match(s.pre_terms, s.pre_off[d], s.pre_off[d + 1], lb, W)) {
-      if (reason_code) *reason_code = 1;  // "node not eligible" (:248-250)
-      return false;
-    }
+// The block's kSigsPerBlock signatures own CONTIGUOUS rows of the two term tables (CSR), so their offsets, flags and —
+// when they fit — all their term masks are staged into LDS with coalesced loads first; the 64-signature walk then
+// reads wave-uniform LDS words instead of chasing three dependent global loads per signature.
+constexpr int kAffLdsWords = 1024;   // 8 KiB per table
+constexpr int kAffSigsPerBlock = 16;  // fewer signatures per block than the other families: the DNF walk is latency-bound,
+                                      // more (shorter) blocks keep more waves in flight
+__device__ __forceinline__ bool dnf_match_any(const u64* terms, int t0, int t1, const u64 (&lb)[kMaxW], int W) {
+  bool any = false;
+  for (int t = t0; t < t1; ++t) {
+    const u64* m = terms + (size_t)t * W;
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < kMaxW; ++w)
+      if (w < W) all = all && (lb[w] & m[w]) == m[w];
+    any = any || all;
   }
-  if (filt_en && !skip && !dnf_match(s.terms, s.term_off[d], s.term_off[d + 1], lb, W)) {
-    if (reason_code) *reason_code = 0;
-    return false;
-  }
-  return true;
+  return any;
 }
 __global__ __launch_bounds__(kBlock) void k_plane_aff(NodeTable t, const int* __restrict__ perm, AffSigs s, PlaneOut o, unsigned pre_mask,
                                                       unsigned filt_mask, int n_words) {
+  __shared__ u64 s_terms[kAffLdsWords];
+  __shared__ u64 s_pre[kAffLdsWords];
+  __shared__ int s_off[kAffSigsPerBlock + 1], s_poff[kAffSigsPerBlock + 1];
+  __shared__ unsigned s_flags[kAffSigsPerBlock];
+  const int d0 = blockIdx.y * kAffSigsPerBlock;
+  const int nd = min(kAffSigsPerBlock, o.D - d0);
+  if ((int)threadIdx.x <= nd) {
+    s_off[threadIdx.x] = s.term_off[d0 + threadIdx.x];
+    s_poff[threadIdx.x] = s.pre_off[d0 + threadIdx.x];
+    if ((int)threadIdx.x < nd) s_flags[threadIdx.x] = s.flags[d0 + threadIdx.x];
+  }
+  __syncthreads();
+  const int tb = s_off[0], pb = s_poff[0];
+  const int tw = (s_off[nd] - tb) * t.W, pw = (s_poff[nd] - pb) * t.W;
+  const bool t_lds = tw <= kAffLdsWords, p_lds = pw <= kAffLdsWords;
+  if (t_lds)
+    for (int i = threadIdx.x; i < tw; i += kBlock) s_terms[i] = s.terms[(size_t)tb * t.W + i];
+  if (p_lds)
+    for (int i = threadIdx.x; i < pw; i += kBlock) s_pre[i] = s.pre_terms[(size_t)pb * t.W + i];
+  __syncthreads();
+
   int word;
   int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
@@ -271,15 +290,29 @@ __global__ __launch_bounds__(kBlock) void k_plane_aff(NodeTable t, const int* __
     for (int w = 0; w < kMaxW; ++w)
       if (w < t.W) lb[w] = t.labels[(size_t)w * t.n + n];
   }
-  int d0 = blockIdx.y * kSigsPerBlock;
-  int dend = min(d0 + kSigsPerBlock, o.D);
+  const bool pre_en = pre_mask & kPlugAffinity, filt_en = filt_mask & kPlugAffinity;
   u64 keep = 0;
-  for (int d = d0; d < dend; ++d) {
-    bool ok = n >= 0 && affinity_ok(s, d, lb, t.W, pre_mask, filt_mask, nullptr);
+  for (int i = 0; i < nd; ++i) {
+    const unsigned f = s_flags[i];
+    const bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
+    bool ok = n >= 0;
+    if (pre_en && !skip) {
+      if (f & kSpecPreReject) ok = false;  // PreFilter rejected the pod (:236-238)
+      if (f & kSpecPreNames) {             // "node not eligible" (:248-250)
+        bool m = p_lds ? dnf_match_any(s_pre, s_poff[i] - pb, s_poff[i + 1] - pb, lb, t.W)
+                       : dnf_match_any(s.pre_terms, s_poff[i], s_poff[i + 1], lb, t.W);
+        ok = ok && m;
+      }
+    }
+    if (filt_en && !skip) {
+      bool m = t_lds ? dnf_match_any(s_terms, s_off[i] - tb, s_off[i + 1] - tb, lb, t.W)
+                     : dnf_match_any(s.terms, s_off[i], s_off[i + 1], lb, t.W);
+      ok = ok && m;
+    }
     u64 b = __ballot(ok);
-    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
+    if (i == (int)(threadIdx.x % kWave)) keep = b;
   }
-  plane_store(o, word, d0, keep);
+  plane_store(o, perm != nullptr, word, d0, keep);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -312,8 +345,11 @@ __device__ __forceinline__ u64 class_word(const Planes& pl, int sr, int st, int 
   return v;
 }
 
-// grid.x = chunks, grid.y = row super-segments of kBlock*kCombineUnroll words. Each thread owns
-// kCombineUnroll words of the class row (word = seg_base + u*kBlock + tid ⇒ every wave store is 512 B contiguous).
+// grid.x = chunks, grid.y = row super-segments of kBlock*kCombineUnroll*WPL words. Each thread owns kCombineUnroll
+// groups of WPL adjacent words of the class row (group g of thread t covers words seg_base + (u*kBlock + t)*WPL ...),
+// so one wave store instruction writes 64*WPL*8 contiguous bytes (512 B at WPL=1, 1 KiB = dwordx4 per lane at WPL=2).
+// NT selects non-temporal stores: the bitmap is written once and never re-read by this kernel.
+template <int WPL, bool NT>
 __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                     int pin_enabled, int* __restrict__ class_count) {
   const int chunk = blockIdx.x;
@@ -323,23 +359,26 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const int pin = pin_enabled ? ct.pin[cls] : -1;
   const int lane = threadIdx.x % kWave;
-  const int seg_base = blockIdx.y * (kBlock * kCombineUnroll);
+  const int seg_base = blockIdx.y * (kBlock * kCombineUnroll * WPL);
 
-  u64 v[kCombineUnroll];
+  u64 v[kCombineUnroll][WPL];
   int pc = 0;
 #pragma unroll
   for (int u = 0; u < kCombineUnroll; ++u) {
-    int w = seg_base + u * kBlock + threadIdx.x;
-    u64 x = 0;
-    if (w < row_words) {
-      x = class_word(pl, sr, st, sa, ss, w);
-      if (pin == -2)
-        x = 0;
-      else if (pin >= 0)
-        x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) {
+      int w = seg_base + (u * kBlock + threadIdx.x) * WPL + j;
+      u64 x = 0;
+      if (w < row_words) {
+        x = class_word(pl, sr, st, sa, ss, w);
+        if (pin == -2)
+          x = 0;
+        else if (pin >= 0)
+          x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+      }
+      v[u][j] = x;
+      pc += __popcll(x);
     }
-    v[u] = x;
-    pc += __popcll(x);
   }
   if (ct.chunk_first[chunk]) {
     // feasible-node count of the class: wave reduce, one atomic per wave
@@ -354,8 +393,22 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
     u64* row = bitmap + (size_t)p * row_stride;
 #pragma unroll
     for (int u = 0; u < kCombineUnroll; ++u) {
-      int w = seg_base + u * kBlock + threadIdx.x;
-      if (w < row_stride) row[w] = v[u];
+      int w = seg_base + (u * kBlock + threadIdx.x) * WPL;
+      if (w < row_stride) {  // row_stride is a multiple of 8 ⇒ a WPL=2 group never straddles the end
+        if (WPL == 2) {
+          typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+          u64x2 val = {v[u][0], v[u][WPL - 1]};
+          if (NT)
+            __builtin_nontemporal_store(val, (u64x2*)(row + w));
+          else
+            *(u64x2*)(row + w) = val;
+        } else {
+          if (NT)
+            __builtin_nontemporal_store(v[u][0], row + w);
+          else
+            row[w] = v[u][0];
+        }
+      }
     }
   }
 }

@@ -7,6 +7,7 @@
 #include "../../../include/ykhost.h"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -129,6 +130,9 @@ int recreate_engine(ykhost* h) {
   c.num_resources = h->enc.R;
   c.taint_words = h->enc.KT;
   c.label_words = h->enc.W;
+  // engine tunables for experiments: YKPRED_CHUNK_MEMBERS=1..64, YKPRED_CHUNK_UNSORTED=1
+  if (const char* v = getenv("YKPRED_CHUNK_MEMBERS")) c.reserved[0] = atoi(v);
+  if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;

@@ -192,7 +192,7 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_evaluate(self._h, 1 if allocate else 0, opts))
 
     def evaluate_into(self, bitmap=None, counts=None, decisions=None, keys=None, stream=None, allocate=True, profile=False,
-                      direct=False):
+                      direct=False, variant=0):
         """ykpred_eval with caller-owned DEVICE outputs (objects exposing data_ptr(), e.g. torch tensors) on the
         caller's HIP stream — how a multi-GPU driver keeps the results where its collectives can reach them."""
         self.sync()
@@ -200,7 +200,7 @@ class GpuPredicateManager:
         a.prefilter_plugins = self._masks[1] if allocate else self._masks[0]
         a.filter_plugins = self._masks[3] if allocate else self._masks[2]
         a.options = OUT_BITMAP | OUT_COUNTS | OUT_DECISIONS | (OUT_DECISION_KEYS if keys is not None else 0)
-        a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0)
+        a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0) | ((variant & 3) << 16)
         a.bitmap = None if bitmap is None else bitmap.data_ptr()
         a.counts = None if counts is None else counts.data_ptr()
         a.decisions = None if decisions is None else decisions.data_ptr()
