@@ -58,7 +58,8 @@ typedef struct ykhost_kwok {
   int32_t gang_size;       /* >0: pods are gang placeholders, `gang_size` identical members per task group */
   int32_t node_index_offset; /* node-sharded clusters: this shard holds global nodes [offset, offset+num_nodes); node draws
                                 are seeded per global index range, pod draws depend on `seed` only (identical on all shards) */
-  int32_t reserved[4];
+  int32_t spread;            /* 1 = 10 % of the templates carry one DoNotSchedule zone-spread constraint (configs[4]) */
+  int32_t reserved[3];
 } ykhost_kwok_t;
 int32_t ykhost_generate_kwok(ykhost_t* h, const ykhost_kwok_t* cfg);
 

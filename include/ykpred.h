@@ -113,6 +113,7 @@ typedef struct ykpred_nodes {
   const uint64_t* label_bits;    /* [W][count]   bit q: node satisfies dictionary requirement q */
   const int32_t* domain_id;      /* [KD][count]  id of the node's value for topology key k, -1 = label missing */
   const int32_t* selector_count; /* [KS][count]  # pods on the node matching selector class s */
+  const int32_t* domain_sizes;   /* [KD]         number of distinct values (domain ids 0..size-1) of topology key k */
 } ykpred_nodes_t;
 
 /* One hard (DoNotSchedule) topology spread constraint of a pod spec. */
@@ -155,6 +156,9 @@ typedef struct ykpred_pods {
                                               node-sharded cluster pick the global best with one MIN all-reduce */
 #define YKPRED_EVAL_PROFILE (1u << 8)  /* bracket every kernel with HIP events (see ykpred_last_timing) */
 #define YKPRED_EVAL_DIRECT (1u << 9)   /* use the per-pair reference kernel instead of the plane/class path */
+#define YKPRED_EVAL_SPREAD_COUNT_ONLY (1u << 10)   /* node-sharded clusters: only build this shard's PodTopologySpread
+                                                      histograms (layout.spread_counts / spread_present) and return */
+#define YKPRED_EVAL_SPREAD_COUNTS_READY (1u << 11) /* the histograms already hold the cluster-wide (all-reduced) values */
 
 typedef struct ykpred_eval_args {
   uint32_t prefilter_plugins; /* enabled PreFilter plugins (YKPRED_PLUGIN_* bits) */
@@ -182,6 +186,9 @@ typedef struct ykpred_layout {
   void* counts;        /* device int32[P] */
   void* decisions;     /* device int32[P] */
   void* decision_keys; /* device int64[P] */
+  void* spread_counts;  /* device int32[spread_cells]: matching pods per (spread constraint, topology domain) — SUM across shards */
+  void* spread_present; /* device int32[spread_cells]: 1 = an eligible node carries the domain — MAX across shards */
+  int64_t spread_cells;
 } ykpred_layout_t;
 
 #define YKPRED_MAX_TIMED_KERNELS 16

@@ -43,8 +43,11 @@ def rand_node(rng, i, scalars=True):
             req["memory"] = rng.choice(MEM)
         if scalars and rng.random() < 0.2:
             req["example.com/gpu"] = rng.choice(["1", "2"])
-        entry = {"metadata": {"name": f"n{i}-p{j}", "uid": f"n{i}-p{j}", "namespace": "default", "labels": {"app": rng.choice(TEAMS)}},
-                 "spec": {"containers": [{"name": "c", "resources": {"requests": req}}]}}
+        meta = {"name": f"n{i}-p{j}", "uid": f"n{i}-p{j}", "namespace": rng.choice(["default", "default", "default", "other"]),
+                "labels": {"app": rng.choice(TEAMS)}}
+        if rng.random() < 0.05:
+            meta["deletionTimestamp"] = "2026-01-01T00:00:00Z"  # terminating pods are not counted by PodTopologySpread
+        entry = {"metadata": meta, "spec": {"containers": [{"name": "c", "resources": {"requests": req}}]}}
         if rng.random() < 0.2:
             entry["replicas"] = rng.choice([2, 3])
         pods.append(entry)
@@ -77,7 +80,39 @@ def rand_field(rng, n_nodes):
     return {"key": key, "operator": op, "values": vals}
 
 
-def rand_pod(rng, i, n_nodes, scalars=True):
+def rand_spread(rng):
+    """0-2 topologySpreadConstraints with distinct topology keys (API validation forbids duplicate key+whenUnsatisfiable)."""
+    out = []
+    keys = ["zone", "kubernetes.io/hostname", "example.com/tier"]
+    rng.shuffle(keys)
+    for key in keys[:rng.choice([1, 1, 2])]:
+        c = {"maxSkew": rng.choice([1, 1, 2, 3]), "topologyKey": key,
+             "whenUnsatisfiable": rng.choice(["DoNotSchedule", "DoNotSchedule", "DoNotSchedule", "ScheduleAnyway"])}
+        k = rng.random()
+        if k < 0.1:
+            pass  # nil selector: matches nothing
+        elif k < 0.2:
+            c["labelSelector"] = {}
+        elif k < 0.75:
+            c["labelSelector"] = {"matchLabels": {"app": rng.choice(TEAMS)}}
+        else:
+            c["labelSelector"] = {"matchExpressions": [{"key": "app", "operator": rng.choice(["In", "NotIn", "Exists"]),
+                                                        **({"values": rng.sample(TEAMS, 2)} if rng.random() < 0.7 else {})}]}
+            if c["labelSelector"]["matchExpressions"][0]["operator"] == "Exists":
+                c["labelSelector"]["matchExpressions"][0].pop("values", None)
+            elif "values" not in c["labelSelector"]["matchExpressions"][0]:
+                c["labelSelector"]["matchExpressions"][0]["values"] = [rng.choice(TEAMS)]
+        if rng.random() < 0.25:
+            c["minDomains"] = rng.choice([1, 2, 5, 50])
+        if rng.random() < 0.3:
+            c["nodeAffinityPolicy"] = rng.choice(["Honor", "Ignore"])
+        if rng.random() < 0.3:
+            c["nodeTaintsPolicy"] = rng.choice(["Honor", "Ignore"])
+        out.append(c)
+    return out
+
+
+def rand_pod(rng, i, n_nodes, scalars=True, spread=False):
     spec = {}
     req = {}
     if rng.random() < 0.8:
@@ -143,13 +178,15 @@ def rand_pod(rng, i, n_nodes, scalars=True):
         spec["affinity"] = {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": None}}
     if rng.random() < 0.1:
         spec["nodeName"] = rng.choice([f"node-{rng.randrange(max(n_nodes, 1))}", "ghost"])
+    if spread and rng.random() < 0.5:
+        spec["topologySpreadConstraints"] = rand_spread(rng)
     return {"metadata": {"name": f"pod-{i}", "uid": f"pod-{i}", "namespace": "default", "labels": {"app": rng.choice(TEAMS)}}, "spec": spec}
 
 
-def random_snapshot(seed, n_nodes, n_pods, scalars=True):
+def random_snapshot(seed, n_nodes, n_pods, scalars=True, spread=False):
     rng = random.Random(seed)
     nodes = [rand_node(rng, i, scalars) for i in range(n_nodes)]
-    pods = [rand_pod(rng, i, n_nodes, scalars) for i in range(n_pods)]
+    pods = [rand_pod(rng, i, n_nodes, scalars, spread) for i in range(n_pods)]
     # a few exact duplicates so that classes have several members
     for i in range(min(n_pods // 4, 16)):
         src = pods[rng.randrange(len(pods))]

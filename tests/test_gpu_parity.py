@@ -138,6 +138,38 @@ def test_random_clusters_plugin_subsets(plugins):
         m.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("allocate", [True, False])
+def test_random_clusters_with_topology_spread(pm, seed, allocate):
+    """PodTopologySpread (hard constraints, inclusion policies, minDomains, nil/empty selectors, terminating pods,
+    other namespaces) — PARITY UNPINNED in the reference; GPU ≡ oracle bit for bit, incl. the failing plugin."""
+    snap = _gen.random_snapshot(5000 + seed, n_nodes=60 + 17 * seed, n_pods=70, spread=True)
+    pm.load_snapshot(snap)
+    check_against_oracle(pm, snap, allocate)
+
+
+def test_topology_spread_filter_without_prefilter():
+    snap = _gen.random_snapshot(5100, n_nodes=80, n_pods=40, spread=True)
+    m = pkg.GpuPredicateManager.internal([], [], ["PodTopologySpread"], ["PodTopologySpread"])
+    try:
+        m.load_snapshot(snap)
+        check_against_oracle(m, snap, True, pre=0, filt=orc.PLUGIN_BITS["PodTopologySpread"])
+    finally:
+        m.close()
+
+
+def test_kwok_with_spread_constraints(pm):
+    """configs[4] plugin mix at oracle-feasible size: 10 % of the asks carry one DoNotSchedule zone constraint."""
+    pm.generate_kwok(seed=4242, num_nodes=1200, num_pods=2500, num_templates=300, node_affinity=1, spread=1)
+    snap = pm.dump_snapshot()
+    assert '"topologySpreadConstraints"' in snap
+    check_against_oracle(pm, snap, True, check_plugins=False)
+    # incremental: binding an ask changes the selector counts of its node and therefore the histograms
+    uid = json.loads(snap)["pods"][5]["metadata"]["uid"]
+    pm.assume_pod(uid, "kwok-node-000007")
+    check_against_oracle(pm, pm.dump_snapshot(), True, check_plugins=False)
+
+
 def test_empty_and_ragged_inputs(pm):
     node = _gen.random_snapshot(5, 1, 0)["nodes"][0]
     pod = _gen.random_snapshot(5, 1, 1)["pods"][0]

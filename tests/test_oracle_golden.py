@@ -76,3 +76,74 @@ def test_first_failing_plugin_order():
     assert plugin == "TaintToleration" and "taint" in msg  # e2e regex `.*taint.*`, test/e2e/predicates/predicates_test.go:439
     nm &= ~orc.PLUGIN_BITS["TaintToleration"]
     assert o.predicates(0, 0, nm, nm)[1] == "NodeResourcesFit"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PodTopologySpread: PARITY UNPINNED in the reference (only instantiated with constraint-free pods,
+# predicate_manager_test.go:120,2171). These cases restate the upstream documentation's own worked example and the
+# rules of SURVEY.md A.6, so that the oracle's behaviour is at least written down and stable.
+# ---------------------------------------------------------------------------------------------------------------
+def _node(name, zone, pods_with_app=0, extra=None):
+    labels = {"kubernetes.io/hostname": name}
+    if zone is not None:
+        labels["zone"] = zone
+    if extra:
+        labels.update(extra)
+    pods = [{"metadata": {"name": f"{name}-{i}", "uid": f"{name}-{i}", "namespace": "default", "labels": {"foo": "bar"}}}
+            for i in range(pods_with_app)]
+    return {"metadata": {"name": name, "labels": labels}, "pods": pods}
+
+
+def _spread_pod(max_skew=1, selector=None, labels=None, **kw):
+    c = {"maxSkew": max_skew, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule"}
+    if selector is not None:
+        c["labelSelector"] = selector
+    c.update(kw)
+    return {"metadata": {"name": "mypod", "uid": "mypod", "namespace": "default", "labels": labels or {"foo": "bar"}},
+            "spec": {"topologySpreadConstraints": [c]}}
+
+
+SPREAD = orc.PLUGIN_BITS["PodTopologySpread"]
+
+
+def test_spread_documentation_example():
+    """kubernetes.io docs "Pod Topology Spread Constraints", example one constraint: zoneA holds 2 matching pods
+    (node1, node2: 1 each), zoneB holds 1 (node3: 1, node4: 0); maxSkew=1 ⇒ the incoming pod may only land in zoneB."""
+    nodes = [_node("node1", "zoneA", 1), _node("node2", "zoneA", 1), _node("node3", "zoneB", 1), _node("node4", "zoneB", 0)]
+    o = orc.Oracle({"nodes": nodes, "pods": [_spread_pod(selector={"matchLabels": {"foo": "bar"}})]})
+    assert [o.predicates(0, n, SPREAD, SPREAD)[0] for n in range(4)] == [False, False, True, True]
+    o = orc.Oracle({"nodes": nodes, "pods": [_spread_pod(max_skew=2, selector={"matchLabels": {"foo": "bar"}})]})
+    assert all(o.predicates(0, n, SPREAD, SPREAD)[0] for n in range(4))
+
+
+def test_spread_rules():
+    nodes = [_node("n1", "zoneA", 2), _node("n2", "zoneB", 0), _node("n3", None, 0)]
+    sel = {"matchLabels": {"foo": "bar"}}
+    # missing topology label on the candidate node ⇒ unresolvable failure; the node is not counted either
+    o = orc.Oracle({"nodes": nodes, "pods": [_spread_pod(selector=sel)]})
+    got = [o.predicates(0, n, SPREAD, SPREAD) for n in range(3)]
+    assert [g[0] for g in got] == [False, True, False] and "missing required label" in got[2][2]
+    # minDomains larger than the number of domains ⇒ global minimum treated as 0: zoneA (2+1-0 > 1) fails, zoneB (0+1-0) fits
+    o = orc.Oracle({"nodes": nodes[:2], "pods": [_spread_pod(selector=sel, minDomains=5)]})
+    assert [o.predicates(0, n, SPREAD, SPREAD)[0] for n in range(2)] == [False, True]
+    # the pod does not match its own selector ⇒ selfMatch = 0: skew in zoneA = 2 - 0 = 2 > 1 still fails
+    o = orc.Oracle({"nodes": nodes[:2], "pods": [_spread_pod(selector=sel, labels={"foo": "other"})]})
+    assert [o.predicates(0, n, SPREAD, SPREAD)[0] for n in range(2)] == [False, True]
+    # ScheduleAnyway constraints are not hard ⇒ PreFilter Skip ⇒ everything fits
+    o = orc.Oracle({"nodes": nodes, "pods": [_spread_pod(selector=sel, whenUnsatisfiable="ScheduleAnyway")]})
+    assert all(o.predicates(0, n, SPREAD, SPREAD)[0] for n in range(3))
+    # nil / empty selectors count nothing; an empty selector still self-matches
+    o = orc.Oracle({"nodes": nodes[:2], "pods": [_spread_pod(selector={}), _spread_pod()]})
+    assert all(o.predicates(p, n, SPREAD, SPREAD)[0] for p in range(2) for n in range(2))
+    # nodeAffinityPolicy=Honor (default): nodes outside the pod's nodeSelector are not counted, Ignore counts them
+    pod = _spread_pod(selector=sel)
+    pod["spec"]["nodeSelector"] = {"zone": "zoneB"}
+    o = orc.Oracle({"nodes": nodes[:2], "pods": [pod]})
+    assert o.predicates(0, 1, SPREAD, SPREAD)[0]  # only zoneB is a domain: min = 0, skew = 1
+    pod2 = _spread_pod(selector=sel, nodeAffinityPolicy="Ignore", max_skew=1)
+    pod2["spec"]["nodeSelector"] = {"zone": "zoneA"}
+    o = orc.Oracle({"nodes": nodes[:2], "pods": [pod2]})
+    assert not o.predicates(0, 0, SPREAD, SPREAD)[0]  # zoneA=2, zoneB=0 both counted: 2+1-0 > 1
+    # Filter enabled without its PreFilter: Error status ⇒ does not fit
+    o = orc.Oracle({"nodes": nodes[:2], "pods": [_spread_pod(selector=sel)]})
+    assert not o.predicates(0, 1, 0, SPREAD)[0]

@@ -16,7 +16,7 @@ class YkpredConfig(C.Structure):
 class YkpredNodes(C.Structure):
     _fields_ = [("count", C.c_int32), ("allocatable", C.c_void_p), ("requested", C.c_void_p), ("allowed_pods", C.c_void_p),
                 ("pod_count", C.c_void_p), ("flags", C.c_void_p), ("taint_bits", C.c_void_p), ("label_bits", C.c_void_p),
-                ("domain_id", C.c_void_p), ("selector_count", C.c_void_p)]
+                ("domain_id", C.c_void_p), ("selector_count", C.c_void_p), ("domain_sizes", C.c_void_p)]
 
 
 class YkpredSpecs(C.Structure):
@@ -39,7 +39,8 @@ class YkpredLayout(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("num_pods", C.c_int32), ("num_specs", C.c_int32), ("num_classes", C.c_int32),
                 ("row_words", C.c_int32), ("row_stride", C.c_int32), ("num_chunks", C.c_int32), ("plane_rows", C.c_int32),
                 ("bitmap_bytes", C.c_uint64), ("bitmap", C.c_void_p), ("counts", C.c_void_p), ("decisions", C.c_void_p),
-                ("decision_keys", C.c_void_p)]
+                ("decision_keys", C.c_void_p), ("spread_counts", C.c_void_p), ("spread_present", C.c_void_p),
+                ("spread_cells", C.c_int64)]
 
 
 MAX_TIMED = 16
@@ -53,7 +54,7 @@ class YkpredTiming(C.Structure):
 class YkhostKwok(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("num_nodes", C.c_int32), ("num_pods", C.c_int32), ("num_templates", C.c_int32),
                 ("node_affinity", C.c_int32), ("tolerations", C.c_int32), ("unique_requests", C.c_int32),
-                ("gang_size", C.c_int32), ("node_index_offset", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("gang_size", C.c_int32), ("node_index_offset", C.c_int32), ("spread", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 _pred = None

@@ -63,7 +63,9 @@ struct ykpred_engine {
   // --- node table
   int N = 0;
   int row_words = 0, row_stride = 0;
-  DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels;
+  DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels, d_domain, d_selcount;
+  int KD = 0, KS = 0;
+  std::vector<int32_t> h_domain_sizes;
   DevBuf d_score, d_key, d_rank, d_perm;
   bool nodes_set = false;
 
@@ -77,7 +79,15 @@ struct ykpred_engine {
   DevBuf d_sreq, d_stol, d_sflags, d_aff_off, d_aff_terms, d_pre_off, d_pre_terms;  // per-spec tables (k_query / k_direct)
   // per-family signature tables
   std::vector<int32_t> spec_sig_res, spec_sig_tol, spec_sig_aff;
-  Family fam_res, fam_tol, fam_aff;
+  Family fam_res, fam_tol, fam_aff, fam_spread;
+  // PodTopologySpread signatures (host copies; device tables are rebuilt when nodes or specs change)
+  std::vector<int32_t> spec_sig_spread;                 // [S] -1 = no hard constraints
+  std::vector<std::vector<ykpred_spread_t>> spread_sig; // constraints of each signature
+  std::vector<int32_t> spread_sig_aff, spread_sig_tol;  // eligibility signatures
+  DevBuf d_spec_spread, d_sp_coff, d_sp_c, d_sp_aff, d_sp_tol, d_sp_cnt, d_sp_present, d_sp_min;
+  int spread_constraints = 0;
+  int64_t spread_cells = 0;
+  bool spread_dirty = true;
   DevBuf d_sig_req;                                                            // [Dres][R]
   DevBuf d_sig_tol, d_sig_tolflags;                                            // [Dtol][KT], [Dtol]
   DevBuf d_sig_aff_flags, d_sig_aff_off, d_sig_aff_terms, d_sig_pre_off, d_sig_pre_terms;
@@ -149,7 +159,23 @@ ykk::NodeTable node_table(const ykpred_engine* e) {
   t.flags = e->d_nflags.as<unsigned>();
   t.taints = e->d_taints.as<u64>();
   t.labels = e->d_labels.as<u64>();
+  t.KD = e->KD;
+  t.KS = e->KS;
+  t.domain = e->d_domain.as<int>();
+  t.selcount = e->d_selcount.as<int>();
   return t;
+}
+ykk::SpreadSigs spread_sigs(const ykpred_engine* e) {
+  ykk::SpreadSigs sp;
+  sp.D = e->fam_spread.D;
+  sp.c_off = e->d_sp_coff.as<int>();
+  sp.c = e->d_sp_c.as<ykk::SpreadC>();
+  sp.aff_sig = e->d_sp_aff.as<int>();
+  sp.tol_sig = e->d_sp_tol.as<int>();
+  sp.cnt = e->d_sp_cnt.as<int>();
+  sp.present = e->d_sp_present.as<int>();
+  sp.minv = e->d_sp_min.as<int>();
+  return sp;
 }
 ykk::SpecTable spec_table(const ykpred_engine* e) {
   ykk::SpecTable s;
@@ -164,6 +190,8 @@ ykk::SpecTable spec_table(const ykpred_engine* e) {
   s.aff.terms = e->d_aff_terms.as<u64>();
   s.aff.pre_off = e->d_pre_off.as<int>();
   s.aff.pre_terms = e->d_pre_terms.as<u64>();
+  s.spread_sig = e->d_spec_spread.as<int>();
+  s.spread = spread_sigs(e);
   return s;
 }
 
@@ -171,8 +199,8 @@ ykk::SpecTable spec_table(const ykpred_engine* e) {
 int build_classes(ykpred_engine* e, hipStream_t st) {
   const int P = e->P;
   struct Key {
-    int32_t a, b, c, pin;
-    bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c && pin == o.pin; }
+    int32_t a, b, c, d, pin;
+    bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c && d == o.d && pin == o.pin; }
   };
   struct KeyHash {
     size_t operator()(const Key& k) const {
@@ -180,6 +208,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       h ^= ((uint64_t)(uint32_t)k.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
       h ^= ((uint64_t)(uint32_t)k.c + 0x1ce4e5b9ull) * 0x94d049bb133111ebull;
       h ^= ((uint64_t)(uint32_t)k.pin + 0x133111ebull) * 0xd6e8feb86659fd93ull;
+      h ^= ((uint64_t)(uint32_t)k.d + 0x6659fd93ull) * 0xff51afd7ed558ccdull;
       return (size_t)(h ^ (h >> 29));
     }
   };
@@ -189,13 +218,14 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   std::vector<int32_t> class_sig, class_pin, class_size;
   for (int p = 0; p < P; ++p) {
     int s = e->h_pod_spec[(size_t)p];
-    Key k{e->spec_sig_res[(size_t)s], e->spec_sig_tol[(size_t)s], e->spec_sig_aff[(size_t)s], e->h_pod_pin[(size_t)p]};
+    Key k{e->spec_sig_res[(size_t)s], e->spec_sig_tol[(size_t)s], e->spec_sig_aff[(size_t)s], e->spec_sig_spread[(size_t)s],
+          e->h_pod_pin[(size_t)p]};
     auto it = ids.find(k);
     int32_t c;
     if (it == ids.end()) {
       c = (int32_t)class_pin.size();
       ids.emplace(k, c);
-      class_sig.insert(class_sig.end(), {k.a, k.b, k.c, -1});
+      class_sig.insert(class_sig.end(), {k.a, k.b, k.c, k.d});
       class_pin.push_back(k.pin);
       class_size.push_back(0);
     } else {
@@ -250,7 +280,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
 // null-stream hipMemset would not be ordered against the kernels that follow.
 int ensure_planes(ykpred_engine* e, hipStream_t st) {
   size_t row = (size_t)e->row_stride * sizeof(u64);
-  for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff}) {
+  for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff, &e->fam_spread}) {
     size_t need = row * (size_t)std::max(f->D, 1);
     if (f->canon.cap < need) {
       HIPCHK(f->canon.ensure(need));
@@ -261,6 +291,47 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
       HIPCHK(hipMemsetAsync(f->ranked.p, 0, need, st));
     }
   }
+  return YKPRED_OK;
+}
+
+// Device tables of the PodTopologySpread signatures: constraint rows with their histogram cell ranges (which depend on
+// the per-key domain counts of the current node table).
+int build_spread_tables(ykpred_engine* e, hipStream_t st) {
+  std::vector<int32_t> coff{0}, aff, tol;
+  std::vector<ykk::SpreadC> rows;
+  int64_t cells = 0;
+  for (size_t d = 0; d < e->spread_sig.size(); ++d) {
+    for (const ykpred_spread_t& c : e->spread_sig[d]) {
+      if (c.topology_key < 0 || c.topology_key >= e->KD || c.selector_class >= e->KS)
+        return fail(e, YKPRED_E_INVALID, "spread constraint references a topology key / selector class outside the node table");
+      ykk::SpreadC r;
+      r.kd = c.topology_key;
+      r.ks = c.selector_class;
+      r.max_skew = c.max_skew;
+      r.min_domains = c.min_domains;
+      r.self_match = c.self_match;
+      r.flags = c.flags;
+      r.dom_size = (size_t)c.topology_key < e->h_domain_sizes.size() ? e->h_domain_sizes[(size_t)c.topology_key] : 0;
+      r.cnt_off = (int)cells;
+      cells += r.dom_size;
+      if (cells > 0x7fffffff) return fail(e, YKPRED_E_UNSUPPORTED, "spread histograms exceed 2^31 cells");
+      rows.push_back(r);
+    }
+    coff.push_back((int32_t)rows.size());
+    aff.push_back(e->spread_sig_aff[d]);
+    tol.push_back(e->spread_sig_tol[d]);
+  }
+  e->spread_constraints = (int)rows.size();
+  e->spread_cells = cells;
+  TRY(upload(e, e->d_sp_coff, coff.data(), coff.size(), st));
+  TRY(upload(e, e->d_sp_c, rows.data(), rows.size(), st));
+  TRY(upload(e, e->d_sp_aff, aff.data(), aff.size(), st));
+  TRY(upload(e, e->d_sp_tol, tol.data(), tol.size(), st));
+  HIPCHK(e->d_sp_cnt.ensure((size_t)std::max<int64_t>(cells, 1) * sizeof(int)));
+  HIPCHK(e->d_sp_present.ensure((size_t)std::max<int64_t>(cells, 1) * sizeof(int)));
+  HIPCHK(e->d_sp_min.ensure((size_t)std::max(e->spread_constraints, 1) * sizeof(int)));
+  HIPCHK(hipStreamSynchronize(st));
+  e->spread_dirty = false;
   return YKPRED_OK;
 }
 
@@ -288,6 +359,32 @@ struct Timer {
   }
 };
 
+// PodTopologySpread PreFilter for every spread signature: histogram over nodes, then the per-constraint minimum.
+// count_only / counts_ready split the two halves for node-sharded clusters (all-reduce of the histograms in between).
+int run_spread_prefilter(ykpred_engine* e, hipStream_t st, Timer* tm, bool do_count, bool do_min) {
+  if (e->spread_dirty) TRY(build_spread_tables(e, st));
+  if (e->fam_spread.D == 0 || e->N == 0) return YKPRED_OK;
+  ykk::NodeTable nt = node_table(e);
+  ykk::SpreadSigs sp = spread_sigs(e);
+  if (do_count) {
+    HIPCHK(hipMemsetAsync(e->d_sp_cnt.p, 0, (size_t)e->spread_cells * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(e->d_sp_present.p, 0, (size_t)e->spread_cells * sizeof(int), st));
+    ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
+                    e->d_sig_pre_terms.as<u64>()};
+    if (tm) tm->begin(st);
+    hipLaunchKernelGGL(ykk::k_spread_count, dim3((unsigned)((e->N + ykk::kBlock - 1) / ykk::kBlock), (unsigned)e->fam_spread.D),
+                       dim3(ykk::kBlock), 0, st, nt, sp, as, e->d_sig_tol.as<u64>());
+    if (tm) tm->end(st, "k_spread_count");
+  }
+  if (do_min) {
+    if (tm) tm->begin(st);
+    hipLaunchKernelGGL(ykk::k_spread_min, dim3((unsigned)e->spread_constraints), dim3(ykk::kWave), 0, st, sp, e->spread_constraints);
+    if (tm) tm->end(st, "k_spread_min");
+  }
+  HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -310,8 +407,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
     g_create_error = "config out of range: need 3<=R<=8, 1<=KT<=4, 1<=W<=8";
     return YKPRED_E_UNSUPPORTED;
   }
-  if (cfg->topology_keys != 0 || cfg->selector_classes != 0) {
-    g_create_error = "PodTopologySpread tables are not supported by this build of the engine";
+  if (cfg->topology_keys < 0 || cfg->topology_keys > ykk::kMaxKD || cfg->selector_classes < 0 || cfg->selector_classes > 4096) {
+    g_create_error = "config out of range: need 0<=KD<=4 topology keys, 0<=KS<=4096 selector classes";
     return YKPRED_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -334,6 +431,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->R = cfg->num_resources;
   e->KT = cfg->taint_words;
   e->W = cfg->label_words;
+  e->KD = cfg->topology_keys;
+  e->KS = cfg->selector_classes;
   if (cfg->reserved[0] >= 1 && cfg->reserved[0] <= ykk::kChunkMembers) e->chunk_members = cfg->reserved[0];
   e->chunk_sorted = cfg->reserved[1] != 1;
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -360,7 +459,9 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
-  for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_score, &e->d_key,
+  for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount,
+                    &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
+                    &e->fam_spread.canon, &e->fam_spread.ranked, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
@@ -382,6 +483,8 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   if (n->count > 0 && (!n->allocatable || !n->requested || !n->allowed_pods || !n->pod_count || !n->flags || !n->taint_bits ||
                        !n->label_bits))
     return fail(e, YKPRED_E_INVALID, "set_nodes: null column");
+  if ((e->KD > 0 && (!n->domain_sizes || (n->count > 0 && !n->domain_id))) || (e->KS > 0 && n->count > 0 && !n->selector_count))
+    return fail(e, YKPRED_E_INVALID, "set_nodes: topology / selector columns missing (config has KD/KS > 0)");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   const size_t N = (size_t)n->count;
@@ -392,6 +495,10 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   TRY(upload(e, e->d_nflags, n->flags, N, st));
   TRY(upload(e, e->d_taints, n->taint_bits, N * (size_t)e->KT, st));
   TRY(upload(e, e->d_labels, n->label_bits, N * (size_t)e->W, st));
+  TRY(upload(e, e->d_domain, n->domain_id, N * (size_t)e->KD, st));
+  TRY(upload(e, e->d_selcount, n->selector_count, N * (size_t)e->KS, st));
+  e->h_domain_sizes.assign(n->domain_sizes, n->domain_sizes + e->KD);
+  e->spread_dirty = true;
   HIPCHK(e->d_score.ensure(N * sizeof(double)));
   HIPCHK(e->d_key.ensure(N * sizeof(u64)));
   HIPCHK(e->d_rank.ensure(N * sizeof(int)));
@@ -399,7 +506,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   HIPCHK(hipStreamSynchronize(st));
   if (e->N != n->count) {
     // plane rows change length: drop them so ensure_planes() re-zeroes the padding
-    for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff}) {
+    for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff, &e->fam_spread}) {
       f->canon.release();
       f->ranked.release();
     }
@@ -428,6 +535,12 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
     HIPCHK(hipMemcpyAsync(e->d_taints.as<u64>() + (size_t)k * N + idx, n->taint_bits + k, sizeof(u64), hipMemcpyHostToDevice, st));
   for (int w = 0; w < e->W; ++w)
     HIPCHK(hipMemcpyAsync(e->d_labels.as<u64>() + (size_t)w * N + idx, n->label_bits + w, sizeof(u64), hipMemcpyHostToDevice, st));
+  for (int k = 0; k < e->KD; ++k) {
+    if (n->domain_id[k] >= e->h_domain_sizes[(size_t)k]) return fail(e, YKPRED_E_INVALID, "update_node: new topology domain — re-upload the node table");
+    HIPCHK(hipMemcpyAsync(e->d_domain.as<int>() + (size_t)k * N + idx, n->domain_id + k, sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  for (int k = 0; k < e->KS; ++k)
+    HIPCHK(hipMemcpyAsync(e->d_selcount.as<int>() + (size_t)k * N + idx, n->selector_count + k, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   return YKPRED_OK;
 }
@@ -436,8 +549,8 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
   if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
     return fail(e, YKPRED_E_INVALID, "set_specs: null column");
-  if (s->spread_off && s->count > 0 && s->spread_off[s->count] != 0)
-    return fail(e, YKPRED_E_UNSUPPORTED, "set_specs: hard topology spread constraints are not supported by this build");
+  if (s->spread_off && s->count > 0 && s->spread_off[s->count] != 0 && !s->spread)
+    return fail(e, YKPRED_E_INVALID, "set_specs: spread_off without spread rows");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   const int S = s->count, R = e->R, KT = e->KT, W = e->W;
@@ -512,6 +625,37 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     }
     e->spec_sig_aff[(size_t)i] = kt2->second;
   }
+  // ---- PodTopologySpread signatures: constraints + the eligibility inputs they honour
+  e->spec_sig_spread.assign((size_t)S, -1);
+  e->spread_sig.clear();
+  e->spread_sig_aff.clear();
+  e->spread_sig_tol.clear();
+  std::unordered_map<std::string, int32_t> m_spread;
+  for (int i = 0; i < S && s->spread_off; ++i) {
+    int c0 = s->spread_off[i], c1 = s->spread_off[i + 1];
+    if (c1 < c0) return fail(e, YKPRED_E_INVALID, "set_specs: spread offsets not monotone");
+    if (c1 == c0) continue;
+    bool honor_aff = false, honor_tol = false;
+    for (int c = c0; c < c1; ++c) {
+      honor_aff |= (s->spread[c].flags & YKPRED_SPREAD_HONOR_AFFINITY) != 0;
+      honor_tol |= (s->spread[c].flags & YKPRED_SPREAD_HONOR_TAINTS) != 0;
+    }
+    int32_t ea = honor_aff ? e->spec_sig_aff[(size_t)i] : 0, et = honor_tol ? e->spec_sig_tol[(size_t)i] : 0;
+    std::string k((const char*)(s->spread + c0), (size_t)(c1 - c0) * sizeof(ykpred_spread_t));
+    k.append((const char*)&ea, sizeof(ea));
+    k.append((const char*)&et, sizeof(et));
+    auto it = m_spread.find(k);
+    if (it == m_spread.end()) {
+      it = m_spread.emplace(std::move(k), (int32_t)m_spread.size()).first;
+      e->spread_sig.emplace_back(s->spread + c0, s->spread + c1);
+      e->spread_sig_aff.push_back(ea);
+      e->spread_sig_tol.push_back(et);
+    }
+    e->spec_sig_spread[(size_t)i] = it->second;
+  }
+  e->fam_spread.D = (int)m_spread.size();
+  e->spread_dirty = true;
+  TRY(upload(e, e->d_spec_spread, e->spec_sig_spread.data(), e->spec_sig_spread.size(), st));
   e->fam_res.D = (int)m_res.size();
   e->fam_tol.D = (int)m_tol.size();
   e->fam_aff.D = (int)m_aff.size();
@@ -563,9 +707,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     TRY(build_classes(e, e->own_stream));
   }
   const unsigned pre = a->prefilter_plugins, filt = a->filter_plugins;
-  if ((pre | filt) & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) {
-    // no spec may carry hard constraints (rejected in set_specs) ⇒ PodTopologySpread.PreFilter returns Skip for every pod
-  }
+  const bool spread_filt = filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD, spread_pre = pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
+  const bool spread_err = spread_filt && !spread_pre;  // Filter without PreFilter state: every pair fails with an Error status
+  if (e->spread_dirty) TRY(build_spread_tables(e, e->own_stream));
+  const bool spread_on = spread_filt && spread_pre && e->fam_spread.D > 0;
   const int N = e->N, P = e->P;
   const size_t bitmap_bytes = (size_t)std::max(P, 1) * (size_t)e->row_stride * sizeof(u64);
   u64* bitmap = (u64*)a->bitmap;
@@ -593,6 +738,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
   const int nblk_nodes = (N + ykk::kBlock - 1) / ykk::kBlock;
 
+  if (spread_on || (a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY)) {
+    const bool ready = a->options & YKPRED_EVAL_SPREAD_COUNTS_READY, only = a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY;
+    TRY(run_spread_prefilter(e, st, &tm, !ready, !only));
+    if (only) {
+      tm.done(st);
+      return YKPRED_OK;
+    }
+  }
   if (a->options & YKPRED_EVAL_DIRECT) {
     ykk::SpecTable stbl = spec_table(e);
     dim3 grid((unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock), (unsigned)((P + ykk::kWave - 1) / ykk::kWave));
@@ -616,6 +769,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   ykk::PlaneOut o_res{e->fam_res.canon.as<u64>(), e->fam_res.ranked.as<u64>(), e->row_stride, e->fam_res.D};
   ykk::PlaneOut o_tol{e->fam_tol.canon.as<u64>(), e->fam_tol.ranked.as<u64>(), e->row_stride, e->fam_tol.D};
   ykk::PlaneOut o_aff{e->fam_aff.canon.as<u64>(), e->fam_aff.ranked.as<u64>(), e->row_stride, e->fam_aff.D};
+  ykk::PlaneOut o_spread{e->fam_spread.canon.as<u64>(), e->fam_spread.ranked.as<u64>(), e->row_stride, e->fam_spread.D};
   // signature planes of one node order (perm == nullptr: canonical). The tol family always runs: it also carries
   // "node exists" for the padding bits of the last word.
   auto launch_planes = [&](hipStream_t s, const int* perm, const char* const* names) {
@@ -635,17 +789,23 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          e->row_words);
       tm.end(s, names[2]);
     }
+    if (spread_on) {
+      tm.begin(s);
+      hipLaunchKernelGGL(ykk::k_plane_spread, dim3(wgroups, sig_chunks(e->fam_spread.D)), dim3(ykk::kBlock), 0, s, nt, perm, spread_sigs(e),
+                         o_spread, e->row_words);
+      tm.end(s, names[3]);
+    }
   };
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>()};
   ykk::Planes pc{res_on ? e->fam_res.canon.as<u64>() : nullptr, e->fam_tol.canon.as<u64>(), aff_on ? e->fam_aff.canon.as<u64>() : nullptr,
-                 nullptr, e->row_stride};
+                 spread_on ? e->fam_spread.canon.as<u64>() : nullptr, e->row_stride};
   ykk::Planes pr{res_on ? e->fam_res.ranked.as<u64>() : nullptr, e->fam_tol.ranked.as<u64>(), aff_on ? e->fam_aff.ranked.as<u64>() : nullptr,
-                 nullptr, e->row_stride};
-  const int pin_on = (filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0;
+                 spread_on ? e->fam_spread.ranked.as<u64>() : nullptr, e->row_stride};
+  const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
 
   // ---- bitmap branch on the caller's stream: canonical planes first (they are short and on the critical path) ...
-  static const char* const cnames[3] = {"k_plane_res", "k_plane_tol", "k_plane_aff"};
+  static const char* const cnames[4] = {"k_plane_res", "k_plane_tol", "k_plane_aff", "k_plane_spread"};
   launch_planes(st, nullptr, cnames);
   // ---- decision branch on the (high-priority) aux stream, forked once the canonical planes are queued:
   // score → rank → rank-ordered planes → first feasible node per class. It is compute/LDS bound and overlaps the
@@ -663,7 +823,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                        dim3(ykk::kBlock), 0, sb, N, e->d_key.as<u64>(), e->d_rank.as<int>());
     hipLaunchKernelGGL(ykk::k_rank_perm, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.end(sb, "k_rank");
-    static const char* const rnames[3] = {"k_plane_res(ranked)", "k_plane_tol(ranked)", "k_plane_aff(ranked)"};
+    static const char* const rnames[4] = {"k_plane_res(ranked)", "k_plane_tol(ranked)", "k_plane_aff(ranked)", "k_plane_spread(ranked)"};
     launch_planes(sb, e->d_perm.as<int>(), rnames);
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
@@ -722,12 +882,15 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->row_words = e->row_words;
   o->row_stride = e->row_stride;
   o->num_chunks = e->NC;
-  o->plane_rows = e->fam_res.D + e->fam_tol.D + e->fam_aff.D;
+  o->plane_rows = e->fam_res.D + e->fam_tol.D + e->fam_aff.D + e->fam_spread.D;
   o->bitmap_bytes = (uint64_t)e->P * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
   o->counts = e->last_counts ? e->last_counts : e->d_counts.p;
   o->decisions = e->last_decisions ? e->last_decisions : e->d_decisions.p;
   o->decision_keys = e->last_keys ? e->last_keys : e->d_keys.p;
+  o->spread_counts = e->d_sp_cnt.p;
+  o->spread_present = e->d_sp_present.p;
+  o->spread_cells = e->spread_cells;
   return YKPRED_OK;
 }
 
@@ -821,6 +984,8 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
   uint32_t* d_r = (uint32_t*)(d_n + n);
   uint8_t* d_f = (uint8_t*)(d_r + n);
   uint8_t* d_c = d_f + n;
+  if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   HIPCHK(hipMemcpyAsync(d_p, pods, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_n, nodes, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(ykk::k_query, dim3((unsigned)((n + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, node_table(e),
@@ -840,6 +1005,8 @@ int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t
   if (pod < 0 || pod >= e->P || node < 0 || node >= e->N) return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
+  if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   size_t vbytes = (size_t)nv * (size_t)e->R * sizeof(i64);
   HIPCHK(e->d_scratch.ensure(vbytes + (size_t)nv + 64));
   i64* d_v = e->d_scratch.as<i64>();

@@ -32,6 +32,7 @@ typedef long long i64;
 constexpr int kMaxR = 8;   // resource dimensions
 constexpr int kMaxKT = 4;  // taint dictionary words (256 taints)
 constexpr int kMaxW = 8;   // requirement dictionary words (512 requirements)
+constexpr int kMaxKD = 4;  // topology keys used by hard spread constraints
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
@@ -41,6 +42,7 @@ constexpr int kChunkMembers = 64;   // member pods per combine chunk (member ids
 constexpr int kCombineUnroll = 4;   // row words per thread held in registers by k_combine
 
 // plugin bits (mirror include/ykpred.h)
+constexpr unsigned kSpreadHonorAffinity = 1u << 0, kSpreadHonorTaints = 1u << 1;
 constexpr unsigned kPlugUnsched = 1u << 0, kPlugNodeName = 1u << 1, kPlugTaint = 1u << 2, kPlugAffinity = 1u << 3,
                    kPlugFit = 1u << 5, kPlugSpread = 1u << 6;
 constexpr unsigned kSpecToleratesUnsched = 1u << 0, kSpecAffSkip = 1u << 1, kSpecPreReject = 1u << 2, kSpecPreNames = 1u << 3;
@@ -56,6 +58,9 @@ struct NodeTable {
   const unsigned* flags;  // [n]
   const u64* taints;   // [KT][n]
   const u64* labels;   // [W][n]
+  int KD, KS;          // PodTopologySpread: topology keys, selector classes
+  const int* domain;   // [KD][n] id of the node's value for topology key k, -1 = label missing
+  const int* selcount; // [KS][n] pods on the node matching selector class s
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -316,6 +321,117 @@ __global__ __launch_bounds__(kBlock) void k_plane_aff(NodeTable t, const int* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// PodTopologySpread. PreFilter = a histogram over nodes per hard constraint, Filter = a skew test.
+// The reference recomputes the histogram for EVERY (pod,node) call (predicate_manager.go:221-254 lists all nodes per
+// pair); here it is built once per distinct (constraints, eligibility) signature.
+// ---------------------------------------------------------------------------------------------------
+struct SpreadC {  // one hard constraint of one spread signature
+  int kd, ks, max_skew, min_domains, self_match;
+  unsigned flags;
+  int cnt_off, dom_size;  // cells [cnt_off, cnt_off + dom_size) of cnt/present belong to this constraint
+};
+struct SpreadSigs {
+  int D;                // signatures
+  const int* c_off;     // [D+1] → rows of c
+  const SpreadC* c;     // [G]
+  const int* aff_sig;   // [D] row of the AffSigs tables whose Filter DNF decides nodeAffinityPolicy=Honor eligibility
+  const int* tol_sig;   // [D] row of the toleration table for nodeTaintsPolicy=Honor
+  int* cnt;             // [cells] matching pods per (constraint, domain) over eligible nodes   (TpPairToMatchNum)
+  int* present;         // [cells] 1 = some eligible node carries the domain                       (TpKeyToDomainsNum)
+  int* minv;            // [G] global minimum after the minDomains rule                           (criticalPaths / minMatchNum)
+};
+
+// thread = node; blockIdx.y = signature. Eligible nodes add their selector counts to their domain's cell.
+__global__ __launch_bounds__(kBlock) void k_spread_count(NodeTable t, SpreadSigs sp, AffSigs aff, const u64* __restrict__ sig_tol) {
+  const int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= t.n) return;
+  const int d = blockIdx.y;
+  const int c0 = sp.c_off[d], c1 = sp.c_off[d + 1];
+  // nodeLabelsMatchSpreadConstraints: all topology keys of the signature must be present on the node
+  for (int g = c0; g < c1; ++g)
+    if (t.domain[(size_t)sp.c[g].kd * t.n + n] < 0) return;
+  bool need_aff = false, need_tol = false;
+  for (int g = c0; g < c1; ++g) {
+    need_aff |= (sp.c[g].flags & kSpreadHonorAffinity) != 0;
+    need_tol |= (sp.c[g].flags & kSpreadHonorTaints) != 0;
+  }
+  bool aff_ok = true, tol_ok = true;
+  if (need_aff) {
+    u64 lb[kMaxW];
+#pragma unroll
+    for (int w = 0; w < kMaxW; ++w) lb[w] = w < t.W ? t.labels[(size_t)w * t.n + n] : 0;
+    const int a = sp.aff_sig[d];
+    aff_ok = dnf_match(aff.terms, aff.term_off[a], aff.term_off[a + 1], lb, t.W);
+  }
+  if (need_tol) {
+    const u64* tol = sig_tol + (size_t)sp.tol_sig[d] * t.KT;
+    for (int k = 0; k < t.KT; ++k) tol_ok = tol_ok && (t.taints[(size_t)k * t.n + n] & ~tol[k]) == 0;
+  }
+  for (int g = c0; g < c1; ++g) {
+    const SpreadC c = sp.c[g];
+    if ((c.flags & kSpreadHonorAffinity) && !aff_ok) continue;  // matchNodeInclusionPolicies
+    if ((c.flags & kSpreadHonorTaints) && !tol_ok) continue;
+    const int dom = t.domain[(size_t)c.kd * t.n + n];
+    if (dom >= c.dom_size) continue;
+    sp.present[c.cnt_off + dom] = 1;
+    const int v = c.ks >= 0 ? t.selcount[(size_t)c.ks * t.n + n] : 0;
+    if (v) atomicAdd(&sp.cnt[c.cnt_off + dom], v);
+  }
+}
+// one wave per constraint: minimum over present domains, 0 when fewer domains than minDomains
+__global__ __launch_bounds__(kWave) void k_spread_min(SpreadSigs sp, int n_constraints) {
+  const int g = blockIdx.x;
+  if (g >= n_constraints) return;
+  const SpreadC c = sp.c[g];
+  int mn = 0x7fffffff, nd = 0;
+  for (int i = threadIdx.x; i < c.dom_size; i += kWave)
+    if (sp.present[c.cnt_off + i]) {
+      mn = min(mn, sp.cnt[c.cnt_off + i]);
+      ++nd;
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, __shfl_down(mn, off, kWave));
+    nd += __shfl_down(nd, off, kWave);
+  }
+  if (threadIdx.x == 0) sp.minv[g] = nd < c.min_domains ? 0 : mn;
+}
+// Filter: fail ⇔ some constraint's topology label is missing, or matchNum + selfMatch − min > maxSkew
+__device__ __forceinline__ bool spread_ok(const SpreadSigs& sp, int d, const int (&dom)[kMaxKD], unsigned* missing) {
+  for (int g = sp.c_off[d]; g < sp.c_off[d + 1]; ++g) {
+    const SpreadC c = sp.c[g];
+    int dm = -1;
+#pragma unroll
+    for (int k = 0; k < kMaxKD; ++k)
+      if (k == c.kd) dm = dom[k];
+    if (dm < 0) {
+      if (missing) *missing = 1;
+      return false;
+    }
+    i64 match = (dm < c.dom_size && sp.present[c.cnt_off + dm]) ? sp.cnt[c.cnt_off + dm] : 0;
+    if (match + c.self_match - (i64)sp.minv[g] > (i64)c.max_skew) return false;
+  }
+  return true;
+}
+__global__ __launch_bounds__(kBlock) void k_plane_spread(NodeTable t, const int* __restrict__ perm, SpreadSigs sp, PlaneOut o, int n_words) {
+  int word;
+  int n = plane_node(t.n, perm, &word);
+  if (word >= n_words) return;
+  int dom[kMaxKD];
+#pragma unroll
+  for (int k = 0; k < kMaxKD; ++k) dom[k] = (n >= 0 && k < t.KD) ? t.domain[(size_t)k * t.n + n] : -1;
+  int d0 = blockIdx.y * kSigsPerBlock;
+  int dend = min(d0 + kSigsPerBlock, o.D);
+  u64 keep = 0;
+  for (int d = d0; d < dend; ++d) {
+    bool ok = n >= 0 && spread_ok(sp, d, dom, nullptr);
+    u64 b = __ballot(ok);
+    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
+  }
+  plane_store(o, perm != nullptr, word, d0, keep);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // combine: class row = AND of its planes; stream it into every member pod's bitmap row
 // ---------------------------------------------------------------------------------------------------
 struct ClassTable {
@@ -352,6 +468,9 @@ __device__ __forceinline__ u64 class_word(const Planes& pl, int sr, int st, int 
 template <int WPL, bool NT>
 __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                     int pin_enabled, int* __restrict__ class_count) {
+  // pin_enabled bit 0: NodeName filter on; bit 1: PodTopologySpread.Filter has no PreFilter state ⇒ every pair fails
+  const bool all_fail = pin_enabled & 2;
+  pin_enabled &= 1;
   const int chunk = blockIdx.x;
   const int cls = ct.chunk_class[chunk];
   const int begin = ct.chunk_begin[chunk];
@@ -371,7 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
       u64 x = 0;
       if (w < row_words) {
         x = class_word(pl, sr, st, sa, ss, w);
-        if (pin == -2)
+        if (pin == -2 || all_fail)
           x = 0;
         else if (pin >= 0)
           x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
@@ -422,9 +541,10 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
   if (cls >= n_classes) return;
   const int lane = threadIdx.x % kWave;
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
-  const int pin = pin_enabled ? ct.pin[cls] : -1;
+  const bool all_fail = pin_enabled & 2;
+  const int pin = (pin_enabled & 1) ? ct.pin[cls] : -1;
   int best = -1;
-  if (pin == -2) {
+  if (pin == -2 || all_fail) {
     best = -1;
   } else if (pin >= 0) {
     int pos = rank[pin];
@@ -469,12 +589,15 @@ struct SpecTable {
   const u64* tol;        // [S][KT]
   const unsigned* flags; // [S]
   AffSigs aff;           // indexed by spec
+  const int* spread_sig; // [S] spread signature of the spec, -1 = no hard constraints (PreFilter Skip)
+  SpreadSigs spread;
 };
 
 struct NodeRegs {
   i64 fr[kMaxR];
   u64 tn[kMaxKT];
   u64 lb[kMaxW];
+  int dom[kMaxKD];
   bool slots_ok, unsched;
 };
 __device__ __forceinline__ void load_node(const NodeTable& t, int n, NodeRegs* r) {
@@ -484,6 +607,8 @@ __device__ __forceinline__ void load_node(const NodeTable& t, int n, NodeRegs* r
   for (int i = 0; i < kMaxKT; ++i) r->tn[i] = (i < t.KT && n >= 0) ? t.taints[(size_t)i * t.n + n] : 0;
 #pragma unroll
   for (int i = 0; i < kMaxW; ++i) r->lb[i] = (i < t.W && n >= 0) ? t.labels[(size_t)i * t.n + n] : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxKD; ++i) r->dom[i] = (i < t.KD && n >= 0) ? t.domain[(size_t)i * t.n + n] : -1;
   r->slots_ok = n >= 0 && (i64)t.count[n] + 1 <= (i64)t.allowed[n];
   r->unsched = n >= 0 && (t.flags[n] & kNodeUnschedulable);
 }
@@ -550,6 +675,21 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
       *code = 6;
       *reason = why;
       return false;
+    }
+  }
+  if (filt_mask & kPlugSpread) {
+    if (!(pre_mask & kPlugSpread)) {
+      *code = 7;  // Filter without PreFilter state: Error status
+      return false;
+    }
+    const int d = s.spread_sig ? s.spread_sig[spec] : -1;
+    if (d >= 0) {
+      unsigned missing = 0;
+      if (!spread_ok(s.spread, d, nr.dom, &missing)) {
+        *code = 7;
+        *reason = missing ? (1u << 3) : 0u;
+        return false;
+      }
     }
   }
   return true;

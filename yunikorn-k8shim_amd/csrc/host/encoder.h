@@ -110,6 +110,42 @@ inline bool toleration_tolerates(const Toleration& t, const Taint& taint) {  // 
   return t.op == "Exists";
 }
 
+// metav1.LabelSelectorAsSelector(...).Matches(labels). `*invalid` is set when the selector cannot be built
+// (PodTopologySpread.PreFilter would return an Error status for such a pod).
+inline bool selector_matches(const LabelSelector& s, const StrMap& labels, bool* invalid) {
+  if (!s.present) return false;  // nil selector = labels.Nothing()
+  for (auto& kv : s.match_labels) {
+    if (!is_qualified_name(kv.first) || !is_valid_label_value(kv.second)) {
+      *invalid = true;
+      return false;
+    }
+    auto it = labels.find(kv.first);
+    if (it == labels.end() || it->second != kv.second) return false;
+  }
+  for (auto& r : s.match_exprs) {
+    if ((r.op != "In" && r.op != "NotIn" && r.op != "Exists" && r.op != "DoesNotExist") || !valid_label_requirement(r)) {
+      *invalid = true;
+      return false;
+    }
+    if (!label_requirement_matches(r, labels)) return false;
+  }
+  return true;
+}
+inline bool selector_counts_nothing(const LabelSelector& s) {  // nil (Nothing) or empty (Everything ⇒ countPodsMatchSelector returns 0)
+  return !s.present || (s.match_labels.empty() && s.match_exprs.empty());
+}
+inline std::string selector_key(const std::string& ns, const LabelSelector& s) {
+  std::string k = ns + '\x1f';
+  for (auto& kv : s.match_labels) k += kv.first + '=' + kv.second + '\x1e';
+  k += '\x1f';
+  for (auto& r : s.match_exprs) {
+    k += r.key + '\x1d' + r.op;
+    for (auto& v : r.values) k += '\x1d' + v;
+    k += '\x1e';
+  }
+  return k;
+}
+
 // ---- dictionary entries -------------------------------------------------------------------------------
 struct DictReq {
   enum Kind { kLabel, kEquals, kField, kNameIn } kind;
@@ -139,6 +175,11 @@ struct EncodedSpec {
   std::vector<uint64_t> tol;         // [KT]
   uint32_t flags = 0;
   std::vector<std::vector<uint64_t>> terms, pre_terms;  // each [W]
+  std::vector<ykpred_spread_t> spread;                  // hard (DoNotSchedule) topology spread constraints
+};
+struct SelectorClass {
+  std::string ns;
+  LabelSelector selector;
 };
 
 class Encoder {
@@ -148,6 +189,10 @@ class Encoder {
   std::vector<std::string> scalar_names;  // resource dimension 3+i
   std::vector<Taint> taint_dict;
   std::vector<DictReq> req_dict;
+  int KD = 0, KS = 0;
+  std::vector<std::string> topo_keys;                                 // topology key k
+  std::vector<std::unordered_map<std::string, int>> domain_ids;       // value → id, per key (ids follow sorted values)
+  std::vector<SelectorClass> sel_classes;                             // selector class s
 
   // Builds every dictionary from the current objects. Returns false (error set) on unsupported input.
   bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates) {
@@ -158,14 +203,45 @@ class Encoder {
     scalar_ix_.clear();
     taint_ix_.clear();
     req_ix_.clear();
+    topo_keys.clear();
+    topo_ix_.clear();
+    domain_ids.clear();
+    sel_classes.clear();
+    sel_ix_.clear();
+    sel_memo_.clear();
     for (const PodTemplate* t : templates) {
       if (t->pod_affinity) return fail("inter-pod affinity is outside the engine's plugin set (InterPodAffinity)");
       for (auto& c : t->containers)
         if (c.host_ports) return fail("host ports are outside the engine's plugin set (NodePorts)");
-      for (auto& c : t->spread)
-        if (c.when_unsatisfiable == "DoNotSchedule") return fail("hard topologySpreadConstraints are not supported by this build (PodTopologySpread)");
+      std::set<std::string> keys_seen;
+      for (auto& c : t->spread) {
+        if (c.when_unsatisfiable != "DoNotSchedule") continue;  // ScheduleAnyway constraints only score
+        if (!c.match_label_keys.empty()) return fail("topologySpreadConstraints.matchLabelKeys is not supported by the engine");
+        if (!keys_seen.insert(c.topology_key).second) return fail("duplicate topologyKey among DoNotSchedule constraints (rejected by API validation)");
+        bool invalid = false;
+        selector_matches(c.selector, t->labels, &invalid);
+        if (invalid) return fail("invalid labelSelector in topologySpreadConstraints (PodTopologySpread.PreFilter would error)");
+        if (topo_ix_.emplace(c.topology_key, (int)topo_keys.size()).second) topo_keys.push_back(c.topology_key);
+        if (!selector_counts_nothing(c.selector)) {
+          std::string k = selector_key(t->ns, c.selector);
+          if (sel_ix_.emplace(k, (int)sel_classes.size()).second) sel_classes.push_back({t->ns, c.selector});
+        }
+      }
       for (auto& kv : t->requests)
         if (is_scalar_resource_name(kv.first)) scalar(kv.first);
+    }
+    KD = (int)topo_keys.size();
+    KS = (int)sel_classes.size();
+    if (KD > 4) return fail("more than 4 distinct topology keys in DoNotSchedule constraints (engine limit)");
+    domain_ids.assign((size_t)KD, {});
+    for (int k = 0; k < KD; ++k) {
+      std::set<std::string> values;
+      for (const NodeInfo* ni : nodes) {
+        auto it = ni->node.labels.find(topo_keys[(size_t)k]);
+        if (it != ni->node.labels.end()) values.insert(it->second);
+      }
+      int id = 0;
+      for (auto& v : values) domain_ids[(size_t)k][v] = id++;
     }
     for (const NodeInfo* ni : nodes) {
       for (auto& kv : ni->allocatable.scalar) scalar(kv.first);
@@ -182,6 +258,52 @@ class Encoder {
     if (KT > 4) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
     if (W > 8) return fail("more than 512 distinct node-selector requirements (engine limit)");
     return true;
+  }
+
+  std::vector<int32_t> domain_sizes() const {
+    std::vector<int32_t> out;
+    for (auto& m : domain_ids) out.push_back((int32_t)m.size());
+    return out;
+  }
+  // PodTopologySpread inputs of one node: domain id per topology key (-1 = label missing) and
+  // countPodsMatchSelector per selector class. Returns false when a label value is not in the dictionary yet
+  // (the caller must rebuild the dictionaries).
+  bool encode_node_spread(const NodeInfo& ni, int32_t* domain, int32_t* selcount) {
+    bool known = true;
+    for (int k = 0; k < KD; ++k) {
+      auto it = ni.node.labels.find(topo_keys[(size_t)k]);
+      if (it == ni.node.labels.end()) {
+        domain[k] = -1;
+      } else {
+        auto d = domain_ids[(size_t)k].find(it->second);
+        if (d == domain_ids[(size_t)k].end()) {
+          known = false;
+          domain[k] = -1;
+        } else {
+          domain[k] = d->second;
+        }
+      }
+    }
+    for (int s = 0; s < KS; ++s) {
+      const SelectorClass& sc = sel_classes[(size_t)s];
+      int32_t c = 0;
+      for (const Pod* p : ni.pods) {
+        if (p->terminating || p->tpl->ns != sc.ns) continue;  // countPodsMatchSelector: same namespace, not terminating
+        auto key = std::make_pair(p->tpl, s);
+        auto m = sel_memo_.find(key);
+        bool match;
+        if (m == sel_memo_.end()) {
+          bool invalid = false;
+          match = selector_matches(sc.selector, p->tpl->labels, &invalid);
+          sel_memo_.emplace(key, match);
+        } else {
+          match = m->second;
+        }
+        c += match ? 1 : 0;
+      }
+      selcount[s] = c;
+    }
+    return known;
   }
 
   // ---- node rows -----------------------------------------------------------------------------------
@@ -312,11 +434,31 @@ class Encoder {
         }
       }
     }
+    for (auto& c : t.spread) {
+      if (c.when_unsatisfiable != "DoNotSchedule") continue;
+      ykpred_spread_t r{};
+      r.topology_key = topo_ix_.at(c.topology_key);
+      r.selector_class = -1;
+      if (!selector_counts_nothing(c.selector)) r.selector_class = sel_ix_.at(selector_key(t.ns, c.selector));
+      r.max_skew = c.max_skew;
+      r.min_domains = c.has_min_domains ? c.min_domains : 1;
+      bool invalid = false;
+      r.self_match = selector_matches(c.selector, t.labels, &invalid) ? 1 : 0;
+      r.flags = (c.node_affinity_policy == "Honor" ? YKPRED_SPREAD_HONOR_AFFINITY : 0u) |
+                (c.node_taints_policy == "Honor" ? YKPRED_SPREAD_HONOR_TAINTS : 0u);
+      s.spread.push_back(r);
+    }
     return s;
   }
 
  private:
-  std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_;
+  struct MemoHash {
+    size_t operator()(const std::pair<const PodTemplate*, int>& k) const {
+      return std::hash<const void*>()(k.first) * 31u + (size_t)k.second;
+    }
+  };
+  std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_, topo_ix_, sel_ix_;
+  std::unordered_map<std::pair<const PodTemplate*, int>, bool, MemoHash> sel_memo_;
 
   bool fail(const std::string& m) {
     error = m;

@@ -66,7 +66,7 @@ struct ykhost {
   std::vector<int> dirty_nodes;
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
-  int cfgR = 0, cfgKT = 0, cfgW = 0;
+  int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1;
 
   void clear_state() {
     pool.clear();
@@ -121,7 +121,8 @@ Pod* add_pod_object(ykhost* h, const mj::Value& v, size_t* anon) {
 
 // ---- encode + upload -------------------------------------------------------------------------------
 int recreate_engine(ykhost* h) {
-  if (h->eng && h->cfgR == h->enc.R && h->cfgKT == h->enc.KT && h->cfgW == h->enc.W) return 0;
+  if (h->eng && h->cfgR == h->enc.R && h->cfgKT == h->enc.KT && h->cfgW == h->enc.W && h->cfgKD == h->enc.KD && h->cfgKS == h->enc.KS)
+    return 0;
   if (h->eng) ykpred_destroy(h->eng);
   h->eng = nullptr;
   ykpred_config_t c{};
@@ -130,6 +131,8 @@ int recreate_engine(ykhost* h) {
   c.num_resources = h->enc.R;
   c.taint_words = h->enc.KT;
   c.label_words = h->enc.W;
+  c.topology_keys = h->enc.KD;
+  c.selector_classes = h->enc.KS;
   // engine tunables for experiments: YKPRED_CHUNK_MEMBERS=1..64, YKPRED_CHUNK_UNSORTED=1
   if (const char* v = getenv("YKPRED_CHUNK_MEMBERS")) c.reserved[0] = atoi(v);
   if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
@@ -138,6 +141,8 @@ int recreate_engine(ykhost* h) {
   h->cfgR = c.num_resources;
   h->cfgKT = c.taint_words;
   h->cfgW = c.label_words;
+  h->cfgKD = c.topology_keys;
+  h->cfgKS = c.selector_classes;
   return 0;
 }
 
@@ -156,15 +161,18 @@ int full_sync(ykhost* h) {
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
   int rc = recreate_engine(h);
   if (rc) return rc;
-  const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W;
+  const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS;
   const size_t N = h->nodes.size();
   std::vector<int64_t> alloc(N * R), req(N * R), a1(R), r1(R);
-  std::vector<int32_t> allowed(N), count(N);
+  std::vector<int32_t> allowed(N), count(N), domain(N * KD + 1), selcount(N * KS + 1), d1(KD + 1), s1(KS + 1);
   std::vector<uint32_t> flags(N);
   std::vector<uint64_t> taints(N * KT), labels(N * W), t1(KT), l1(W);
   for (size_t n = 0; n < N; ++n) {
     h->nodes[n]->index = (int32_t)n;
     h->enc.encode_node(*h->nodes[n], a1.data(), r1.data(), &allowed[n], &count[n], &flags[n], t1.data(), l1.data());
+    h->enc.encode_node_spread(*h->nodes[n], d1.data(), s1.data());
+    for (int k = 0; k < KD; ++k) domain[(size_t)k * N + n] = d1[(size_t)k];
+    for (int k = 0; k < KS; ++k) selcount[(size_t)k * N + n] = s1[(size_t)k];
     for (int r = 0; r < R; ++r) {
       alloc[(size_t)r * N + n] = a1[(size_t)r];
       req[(size_t)r * N + n] = r1[(size_t)r];
@@ -181,6 +189,11 @@ int full_sync(ykhost* h) {
   nt.flags = flags.data();
   nt.taint_bits = taints.data();
   nt.label_bits = labels.data();
+  std::vector<int32_t> dsizes = h->enc.domain_sizes();
+  dsizes.push_back(0);
+  nt.domain_id = domain.data();
+  nt.selector_count = selcount.data();
+  nt.domain_sizes = dsizes.data();
   rc = ykpred_set_nodes(h->eng, &nt);
   if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
 
@@ -188,9 +201,12 @@ int full_sync(ykhost* h) {
   std::vector<int64_t> sreq(S * R);
   std::vector<uint64_t> stol(S * KT), aff_terms, pre_terms;
   std::vector<uint32_t> sflags(S);
-  std::vector<int32_t> aff_off{0}, pre_off{0};
+  std::vector<int32_t> aff_off{0}, pre_off{0}, spread_off{0};
+  std::vector<ykpred_spread_t> spread;
   for (size_t s = 0; s < S; ++s) {
     EncodedSpec es = h->enc.encode_spec(*h->spec_templates[s]);
+    spread.insert(spread.end(), es.spread.begin(), es.spread.end());
+    spread_off.push_back((int32_t)spread.size());
     std::copy(es.req.begin(), es.req.end(), sreq.begin() + (long)(s * R));
     std::copy(es.tol.begin(), es.tol.end(), stol.begin() + (long)(s * KT));
     sflags[s] = es.flags;
@@ -209,6 +225,9 @@ int full_sync(ykhost* h) {
   sp.aff_terms = aff_terms.empty() ? &dummy : aff_terms.data();
   sp.pre_term_off = pre_off.data();
   sp.pre_terms = pre_terms.empty() ? &dummy : pre_terms.data();
+  ykpred_spread_t no_spread{};
+  sp.spread_off = spread_off.data();
+  sp.spread = spread.empty() ? &no_spread : spread.data();
   rc = ykpred_set_specs(h->eng, &sp);
   if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
   h->dirty_all = false;
@@ -248,8 +267,15 @@ int node_row_sync(ykhost* h, int n) {
   int32_t allowed, count;
   uint32_t flags;
   h->enc.encode_node(*h->nodes[(size_t)n], a.data(), r.data(), &allowed, &count, &flags, t.data(), l.data());
+  std::vector<int32_t> dom((size_t)h->enc.KD + 1), sel((size_t)h->enc.KS + 1);
+  if (!h->enc.encode_node_spread(*h->nodes[(size_t)n], dom.data(), sel.data())) {
+    h->dirty_all = true;  // a topology value outside the dictionary: rebuild everything
+    return full_sync(h);
+  }
   ykpred_nodes_t nt{};
   nt.count = 1;
+  nt.domain_id = dom.data();
+  nt.selector_count = sel.data();
   nt.allocatable = a.data();
   nt.requested = r.data();
   nt.allowed_pods = &allowed;
@@ -312,7 +338,9 @@ std::string compose_message(ykhost* h, const Pod& pod, const NodeInfo& ni, int c
       if (m.empty()) m = "running \"NodeResourcesFit\" filter plugin: reading \"PreFilterNodeResourcesFit\" from cycleState: not found";
       return m;
     }
-    case YKPRED_CODE_POD_TOPOLOGY_SPREAD: return "node(s) didn't match pod topology spread constraints";
+    case YKPRED_CODE_POD_TOPOLOGY_SPREAD:
+      if (reason & YKPRED_REASON_MISSING_TOPOLOGY_LABEL) return "node(s) didn't match pod topology spread constraints (missing required label)";
+      return "node(s) didn't match pod topology spread constraints";
     default: return "unschedulable";
   }
 }
@@ -345,6 +373,20 @@ PodTemplate draw_template(Rng& g, const ykhost_kwok_t& c, int n_nodes) {
     if (g.chance(10, 100)) t.tolerations.push_back({"dedicated", "Equal", fmt("team-%d", (int)g.below(8)), "NoSchedule"});
     if (g.chance(2, 100)) t.tolerations.push_back({"", "Exists", "", ""});
     if (g.chance(3, 100)) t.tolerations.push_back({"node.example.com/maintenance", "Exists", "", "NoExecute"});
+  }
+  if (c.spread && g.chance(10, 100)) {  // configs[4]: 10 % of asks carry one hard zone-spread constraint, maxSkew 1-3
+    SpreadConstraint sc;
+    sc.max_skew = 1 + (int32_t)g.below(3);
+    sc.topology_key = "topology.kubernetes.io/zone";
+    sc.when_unsatisfiable = "DoNotSchedule";
+    sc.selector.present = true;
+    sc.selector.match_labels["app"] = t.labels["app"];
+    if (g.chance(1, 4)) sc.node_taints_policy = "Honor";
+    if (g.chance(1, 8)) {
+      sc.has_min_domains = true;
+      sc.min_domains = 2 + (int32_t)g.below(20);
+    }
+    t.spread.push_back(sc);
   }
   if (c.node_affinity) {
     auto zone = [&](int i) { return fmt("zone-%02d", i % 16); };

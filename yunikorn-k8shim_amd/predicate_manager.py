@@ -110,10 +110,10 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_forget_pod(self._h, uid.encode()))
 
     def generate_kwok(self, seed, num_nodes, num_pods, num_templates=0, node_affinity=1, tolerations=1, unique_requests=0,
-                      gang_size=0, node_index_offset=0):
+                      gang_size=0, node_index_offset=0, spread=0):
         cfg = _ffi.YkhostKwok(seed=seed, num_nodes=num_nodes, num_pods=num_pods, num_templates=num_templates,
                               node_affinity=node_affinity, tolerations=tolerations, unique_requests=unique_requests,
-                              gang_size=gang_size, node_index_offset=node_index_offset)
+                              gang_size=gang_size, node_index_offset=node_index_offset, spread=spread)
         self._check(self._L.ykhost_generate_kwok(self._h, C.byref(cfg)))
 
     @property
