@@ -58,6 +58,38 @@ __global__ __launch_bounds__(256) void fill_rows_persistent_scatter(u64* p, int 
     for (int w = threadIdx.x * 2; w < stride_words; w += 512) *(u64x2*)(base + w) = val;
   }
 }
+// (i) channel-aligned gather-expand: G blocks walk 4 KiB tiles of the output in linear order (tile t → block t % G);
+// every 16-B group is gathered from K source tables: src_k[cls_k(row)][col]. Emulates "bitmap row = AND of K plane rows".
+template <int K, int U>
+__global__ __launch_bounds__(256) void expand_tiles(u64* __restrict__ out, const u64* __restrict__ tab, const int* __restrict__ cls,
+                                                    int tab_rows, long n_rows) {
+  const long total_tiles = n_rows * 6272 / 4096;
+  for (long t0 = blockIdx.x; t0 < total_tiles; t0 += (long)gridDim.x * U) {
+    u64x2 v[U];
+    long offs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long t = t0 + (long)u * gridDim.x;
+      offs[u] = -1;
+      if (t < total_tiles) {
+        long off = t * 4096 + threadIdx.x * 16;
+        long row = off / 6272;
+        int col = (int)(off - row * 6272) / 8;  // word
+        u64x2 acc = {~0ull, ~0ull};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          int c = cls[row * K + k];
+          acc &= *(const u64x2*)(tab + (size_t)c * 784 + col);
+        }
+        v[u] = acc;
+        offs[u] = off;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (offs[u] >= 0) *(u64x2*)((char*)out + offs[u]) = v[u];
+  }
+}
 // (f) one block per row (no inner row loop): 1M blocks
 __global__ __launch_bounds__(256) void fill_row_per_block(u64* p, int stride_words, u64 v) {
   u64x2 val = {v, v};
@@ -87,6 +119,22 @@ int main() {
     { char nm[64]; snprintf(nm, 64, "rows persistent, %d blocks", g); run(nm, [&] { fill_rows_persistent<<<g, 256>>>(d, stride, rows, 7); }); }
   for (int g : {256, 512, 1024})
     { char nm[64]; snprintf(nm, 64, "rows persistent scatter(2000), %d blocks", g); run(nm, [&] { fill_rows_persistent_scatter<<<g, 256>>>(d, stride, rows, 2000, 7); }); }
+  {
+    // class table: 2061 rows (12.9 MB) for K=1; plane table: 375 rows (2.3 MB) for K=3
+    std::vector<int> h1(rows), h3(rows * 3);
+    for (long r = 0; r < rows; ++r) { h1[r] = (int)((r * 2654435761ul) % 2061); h3[3*r] = (int)((r * 2654435761ul) % 63); h3[3*r+1] = 63 + (int)((r * 40503ul) % 18); h3[3*r+2] = 81 + (int)((r * 2246822519ul) % 294); }
+    u64* tab; int *c1, *c3;
+    CK(hipMalloc(&tab, (size_t)2061 * 784 * 8)); CK(hipMemset(tab, 0xff, (size_t)2061 * 784 * 8));
+    CK(hipMalloc(&c1, rows * 4)); CK(hipMalloc(&c3, rows * 12));
+    CK(hipMemcpy(c1, h1.data(), rows * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(c3, h3.data(), rows * 12, hipMemcpyHostToDevice));
+    for (int g : {128, 256, 512})
+    { char nm[80];
+      snprintf(nm, 80, "expand tiles K=1 (class rows 12.9MB) U=2, %d blocks", g); run(nm, [&] { expand_tiles<1, 2><<<g, 256>>>(d, tab, c1, 2061, rows); });
+      snprintf(nm, 80, "expand tiles K=1 (class rows 12.9MB) U=4, %d blocks", g); run(nm, [&] { expand_tiles<1, 4><<<g, 256>>>(d, tab, c1, 2061, rows); });
+      snprintf(nm, 80, "expand tiles K=3 (planes 2.3MB) U=2, %d blocks", g); run(nm, [&] { expand_tiles<3, 2><<<g, 256>>>(d, tab, c3, 375, rows); });
+      snprintf(nm, 80, "expand tiles K=3 (planes 2.3MB) U=4, %d blocks", g); run(nm, [&] { expand_tiles<3, 4><<<g, 256>>>(d, tab, c3, 375, rows); });
+    }
+  }
   for (int bs : {1024})
     for (int g : {256 * 1024 / bs * 2, 256 * 1024 / bs * 8})
       { char nm[80]; snprintf(nm, 80, "linear U=4, block %d, %d blocks", bs, g); run(nm, [&] { fill_linear_u<4><<<g, bs>>>((u64x2*)d, bytes / 16, 7); }); }

@@ -160,7 +160,8 @@ def test_topology_spread_filter_without_prefilter():
 
 def test_kwok_with_spread_constraints(pm):
     """configs[4] plugin mix at oracle-feasible size: 10 % of the asks carry one DoNotSchedule zone constraint."""
-    pm.generate_kwok(seed=4242, num_nodes=1200, num_pods=2500, num_templates=300, node_affinity=1, spread=1)
+    # (small on purpose: the oracle re-runs the PreFilter histogram over all nodes for every pair, like the reference)
+    pm.generate_kwok(seed=4242, num_nodes=300, num_pods=900, num_templates=200, node_affinity=1, spread=1)
     snap = pm.dump_snapshot()
     assert '"topologySpreadConstraints"' in snap
     check_against_oracle(pm, snap, True, check_plugins=False)

@@ -66,7 +66,7 @@ struct ykpred_engine {
   DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels, d_domain, d_selcount;
   int KD = 0, KS = 0;
   std::vector<int32_t> h_domain_sizes;
-  DevBuf d_score, d_key, d_rank, d_perm;
+  DevBuf d_score, d_key, d_rank, d_perm, d_rankbuf;
   bool nodes_set = false;
 
   // --- specs (host copies kept for class building)
@@ -461,7 +461,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   (void)hipDeviceSynchronize();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount,
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
-                    &e->fam_spread.canon, &e->fam_spread.ranked, &e->d_score, &e->d_key,
+                    &e->fam_spread.canon, &e->fam_spread.ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
@@ -503,6 +503,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   HIPCHK(e->d_key.ensure(N * sizeof(u64)));
   HIPCHK(e->d_rank.ensure(N * sizeof(int)));
   HIPCHK(e->d_perm.ensure(N * sizeof(int)));
+  HIPCHK(e->d_rankbuf.ensure((3 * (size_t)ykk::kRankBuckets + 1 + N) * sizeof(int)));
   HIPCHK(hipStreamSynchronize(st));
   if (e->N != n->count) {
     // plane rows change length: drop them so ensure_planes() re-zeroes the padding
@@ -817,11 +818,18 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, nt, e->d_score.as<double>(), e->d_key.as<u64>());
     tm.end(sb, "k_score");
-    HIPCHK(hipMemsetAsync(e->d_rank.p, 0, (size_t)N * sizeof(int), sb));
+    // bucketed exact sort by (score, node index): histogram → scan → bucket fill → rank within bucket
+    int* hist = e->d_rankbuf.as<int>();
+    int* bucket_off = hist + ykk::kRankBuckets;
+    int* cursor = bucket_off + ykk::kRankBuckets + 1;
+    int* members = cursor + ykk::kRankBuckets;
+    HIPCHK(hipMemsetAsync(hist, 0, ykk::kRankBuckets * sizeof(int), sb));
     tm.begin(sb);
-    hipLaunchKernelGGL(ykk::k_rank_count, dim3((unsigned)nblk_nodes, (unsigned)((N + ykk::kRankTile - 1) / ykk::kRankTile)),
-                       dim3(ykk::kBlock), 0, sb, N, e->d_key.as<u64>(), e->d_rank.as<int>());
-    hipLaunchKernelGGL(ykk::k_rank_perm, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_rank.as<int>(), e->d_perm.as<int>());
+    hipLaunchKernelGGL(ykk::k_rank_hist, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), hist);
+    hipLaunchKernelGGL(ykk::k_rank_scan, dim3(1), dim3(ykk::kRankBuckets), 0, sb, hist, bucket_off, cursor);
+    hipLaunchKernelGGL(ykk::k_rank_fill, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), cursor, members);
+    hipLaunchKernelGGL(ykk::k_rank_final, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), e->d_key.as<u64>(),
+                       bucket_off, members, e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.end(sb, "k_rank");
     static const char* const rnames[4] = {"k_plane_res(ranked)", "k_plane_tol(ranked)", "k_plane_aff(ranked)", "k_plane_spread(ranked)"};
     launch_planes(sb, e->d_perm.as<int>(), rnames);
