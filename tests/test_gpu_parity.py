@@ -311,3 +311,21 @@ def test_full_size_configs(pm, n_nodes, n_pods, affinity):
     # (4) checksum of checksums: the independent per-pair formulation (k_direct) reproduces the whole bitmap
     pm.evaluate(direct=True, counts=False, decisions=False)
     assert pm.checksum() == sum_plane
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """The N>1 path of bench.py (node shards + decision exchange) end to end: 2 ranks share this box's GPU, gloo
+    carries the all-reduces (RCCL needs one GPU per rank; the driver's multi-GPU runs use nccl)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--nodes", "4000", "--pods", "50000", "--cpu-seconds", "0", "--profile-steps", "1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["nodes_per_gpu"] == 4000 and d["config"]["pods"] == 50000

@@ -48,8 +48,8 @@ struct DevBuf {
 };
 
 struct Family {
-  int D = 0;  // number of signatures
-  DevBuf canon, ranked;
+  int D = 0;     // number of signatures
+  int base = 0;  // first row of this family in the shared plane buffers
 };
 
 }  // namespace
@@ -66,7 +66,7 @@ struct ykpred_engine {
   DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels, d_domain, d_selcount;
   int KD = 0, KS = 0;
   std::vector<int32_t> h_domain_sizes;
-  DevBuf d_score, d_key, d_rank, d_perm, d_rankbuf;
+  DevBuf d_score, d_key, d_rank, d_perm, d_rankbuf, d_member_key;
   bool nodes_set = false;
 
   // --- specs (host copies kept for class building)
@@ -80,6 +80,8 @@ struct ykpred_engine {
   // per-family signature tables
   std::vector<int32_t> spec_sig_res, spec_sig_tol, spec_sig_aff;
   Family fam_res, fam_tol, fam_aff, fam_spread;
+  DevBuf planes_canon, planes_ranked;  // [total rows][row_stride] u64; families are row ranges
+  int plane_rows_alloc = 0;
   // PodTopologySpread signatures (host copies; device tables are rebuilt when nodes or specs change)
   std::vector<int32_t> spec_sig_spread;                 // [S] -1 = no hard constraints
   std::vector<std::vector<ykpred_spread_t>> spread_sig; // constraints of each signature
@@ -102,6 +104,9 @@ struct ykpred_engine {
   bool pods_set = false, classes_dirty = true;
   int chunk_members = ykk::kChunkMembers;  // tunable: cfg.reserved[0] (1..64)
   bool chunk_sorted = true;                // tunable: cfg.reserved[1] == 1 disables the pod-order dispatch
+  int combine_lds_bytes = 40000;           // tunable: cfg.reserved[2] — LDS reserved per k_combine block = occupancy cap of
+                                           // 4 blocks (16 waves) per CU: measured 1.11 ms vs 1.19 ms at 8 blocks/CU — the
+                                           // write path prefers fewer, longer streams (cf. scripts/fill_probe.hip)
 
   // --- outputs
   DevBuf d_bitmap, d_counts, d_decisions, d_keys, d_scratch;
@@ -110,7 +115,7 @@ struct ykpred_engine {
 
   // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr;
 
   // --- timing: one (start, stop) event pair per kernel, recorded on the stream the kernel is launched on
   hipEvent_t ev[2 * YKPRED_MAX_TIMED_KERNELS + 2]{};
@@ -276,21 +281,23 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   return YKPRED_OK;
 }
 
-// (Re)allocated plane buffers are zeroed ON THE LAUNCH STREAM: the engine's stream is non-blocking, so a
-// null-stream hipMemset would not be ordered against the kernels that follow.
+// Plane buffers: one allocation per node order, families are consecutive row ranges. (Re)allocated buffers are zeroed
+// ON THE LAUNCH STREAM: the engine's streams are non-blocking, so a null-stream hipMemset would not be ordered
+// against the kernels that follow. The zero fill matters for the padding words [row_words, row_stride).
 int ensure_planes(ykpred_engine* e, hipStream_t st) {
-  size_t row = (size_t)e->row_stride * sizeof(u64);
+  int rows = 0;
   for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff, &e->fam_spread}) {
-    size_t need = row * (size_t)std::max(f->D, 1);
-    if (f->canon.cap < need) {
-      HIPCHK(f->canon.ensure(need));
-      HIPCHK(hipMemsetAsync(f->canon.p, 0, need, st));
-    }
-    if (f->ranked.cap < need) {
-      HIPCHK(f->ranked.ensure(need));
-      HIPCHK(hipMemsetAsync(f->ranked.p, 0, need, st));
+    f->base = rows;
+    rows += std::max(f->D, 1);
+  }
+  size_t need = (size_t)rows * (size_t)e->row_stride * sizeof(u64);
+  for (DevBuf* b : {&e->planes_canon, &e->planes_ranked}) {
+    if (b->cap < need || e->plane_rows_alloc != rows) {
+      HIPCHK(b->ensure(need));
+      HIPCHK(hipMemsetAsync(b->p, 0, need, st));
     }
   }
+  e->plane_rows_alloc = rows;
   return YKPRED_OK;
 }
 
@@ -435,6 +442,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->KS = cfg->selector_classes;
   if (cfg->reserved[0] >= 1 && cfg->reserved[0] <= ykk::kChunkMembers) e->chunk_members = cfg->reserved[0];
   e->chunk_sorted = cfg->reserved[1] != 1;
+  if (cfg->reserved[2] > 0 && cfg->reserved[2] <= 160 * 1024) e->combine_lds_bytes = cfg->reserved[2];
+  if (cfg->reserved[2] < 0) e->combine_lds_bytes = 0;
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(s);
@@ -449,6 +458,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   }
   (void)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&e->ev_planes, hipEventDisableTiming);
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   e->ev_ready = true;
   *out = e;
@@ -461,18 +471,19 @@ void ykpred_destroy(ykpred_engine_t* e) {
   (void)hipDeviceSynchronize();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount,
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
-                    &e->fam_spread.canon, &e->fam_spread.ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
+                    &e->planes_canon, &e->planes_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_members, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
-                    &e->fam_res.canon, &e->fam_res.ranked, &e->fam_tol.canon, &e->fam_tol.ranked, &e->fam_aff.canon, &e->fam_aff.ranked})
+                    &e->d_member_key})
     b->release();
   if (e->ev_ready)
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -504,13 +515,12 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   HIPCHK(e->d_rank.ensure(N * sizeof(int)));
   HIPCHK(e->d_perm.ensure(N * sizeof(int)));
   HIPCHK(e->d_rankbuf.ensure((3 * (size_t)ykk::kRankBuckets + 1 + N) * sizeof(int)));
+  HIPCHK(e->d_member_key.ensure(N * sizeof(u64)));
   HIPCHK(hipStreamSynchronize(st));
   if (e->N != n->count) {
     // plane rows change length: drop them so ensure_planes() re-zeroes the padding
-    for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff, &e->fam_spread}) {
-      f->canon.release();
-      f->ranked.release();
-    }
+    e->planes_canon.release();
+    e->planes_ranked.release();
   }
   e->N = n->count;
   e->row_words = (e->N + 63) / 64;
@@ -767,52 +777,23 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const unsigned aff_chunks = (unsigned)((e->fam_aff.D + ykk::kAffSigsPerBlock - 1) / ykk::kAffSigsPerBlock);
   ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
                   e->d_sig_pre_terms.as<u64>()};
-  ykk::PlaneOut o_res{e->fam_res.canon.as<u64>(), e->fam_res.ranked.as<u64>(), e->row_stride, e->fam_res.D};
-  ykk::PlaneOut o_tol{e->fam_tol.canon.as<u64>(), e->fam_tol.ranked.as<u64>(), e->row_stride, e->fam_tol.D};
-  ykk::PlaneOut o_aff{e->fam_aff.canon.as<u64>(), e->fam_aff.ranked.as<u64>(), e->row_stride, e->fam_aff.D};
-  ykk::PlaneOut o_spread{e->fam_spread.canon.as<u64>(), e->fam_spread.ranked.as<u64>(), e->row_stride, e->fam_spread.D};
-  // signature planes of one node order (perm == nullptr: canonical). The tol family always runs: it also carries
-  // "node exists" for the padding bits of the last word.
-  auto launch_planes = [&](hipStream_t s, const int* perm, const char* const* names) {
-    if (res_on) {
-      tm.begin(s);
-      hipLaunchKernelGGL(ykk::k_plane_res, dim3(wgroups, sig_chunks(e->fam_res.D)), dim3(ykk::kBlock), 0, s, nt, perm, e->d_sig_req.as<i64>(),
-                         o_res, fit_error, e->row_words);
-      tm.end(s, names[0]);
-    }
-    tm.begin(s);
-    hipLaunchKernelGGL(ykk::k_plane_tol, dim3(wgroups, sig_chunks(e->fam_tol.D)), dim3(ykk::kBlock), 0, s, nt, perm, e->d_sig_tol.as<u64>(),
-                       e->d_sig_tolflags.as<unsigned>(), o_tol, filt, e->row_words);
-    tm.end(s, names[1]);
-    if (aff_on) {
-      tm.begin(s);
-      hipLaunchKernelGGL(ykk::k_plane_aff, dim3(wgroups, aff_chunks), dim3(ykk::kBlock), 0, s, nt, perm, as, o_aff, pre, filt,
-                         e->row_words);
-      tm.end(s, names[2]);
-    }
-    if (spread_on) {
-      tm.begin(s);
-      hipLaunchKernelGGL(ykk::k_plane_spread, dim3(wgroups, sig_chunks(e->fam_spread.D)), dim3(ykk::kBlock), 0, s, nt, perm, spread_sigs(e),
-                         o_spread, e->row_words);
-      tm.end(s, names[3]);
-    }
-  };
+  auto canon_of = [&](const Family& f) { return e->planes_canon.as<u64>() + (size_t)f.base * e->row_stride; };
+  auto ranked_of = [&](const Family& f) { return e->planes_ranked.as<u64>() + (size_t)f.base * e->row_stride; };
+  ykk::PlaneOut o_res{canon_of(e->fam_res), ranked_of(e->fam_res), e->row_stride, e->fam_res.D};
+  ykk::PlaneOut o_tol{canon_of(e->fam_tol), ranked_of(e->fam_tol), e->row_stride, e->fam_tol.D};
+  ykk::PlaneOut o_aff{canon_of(e->fam_aff), ranked_of(e->fam_aff), e->row_stride, e->fam_aff.D};
+  ykk::PlaneOut o_spread{canon_of(e->fam_spread), ranked_of(e->fam_spread), e->row_stride, e->fam_spread.D};
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>()};
-  ykk::Planes pc{res_on ? e->fam_res.canon.as<u64>() : nullptr, e->fam_tol.canon.as<u64>(), aff_on ? e->fam_aff.canon.as<u64>() : nullptr,
-                 spread_on ? e->fam_spread.canon.as<u64>() : nullptr, e->row_stride};
-  ykk::Planes pr{res_on ? e->fam_res.ranked.as<u64>() : nullptr, e->fam_tol.ranked.as<u64>(), aff_on ? e->fam_aff.ranked.as<u64>() : nullptr,
-                 spread_on ? e->fam_spread.ranked.as<u64>() : nullptr, e->row_stride};
+  ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
+                 e->row_stride};
+  ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
+                 e->row_stride};
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
+  hipStream_t sb = e->aux_stream;
 
-  // ---- bitmap branch on the caller's stream: canonical planes first (they are short and on the critical path) ...
-  static const char* const cnames[4] = {"k_plane_res", "k_plane_tol", "k_plane_aff", "k_plane_spread"};
-  launch_planes(st, nullptr, cnames);
-  // ---- decision branch on the (high-priority) aux stream, forked once the canonical planes are queued:
-  // score → rank → rank-ordered planes → first feasible node per class. It is compute/LDS bound and overlaps the
-  // HBM-write-bound k_combine below.
+  // ---- stream B (decision branch), part 1: bin-pack order. Independent of the planes, runs beside them.
   if (want_dec) {
-    hipStream_t sb = e->aux_stream;
     HIPCHK(hipEventRecord(e->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_fork, 0));
     tm.begin(sb);
@@ -827,19 +808,54 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_rank_hist, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), hist);
     hipLaunchKernelGGL(ykk::k_rank_scan, dim3(1), dim3(ykk::kRankBuckets), 0, sb, hist, bucket_off, cursor);
-    hipLaunchKernelGGL(ykk::k_rank_fill, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), cursor, members);
+    hipLaunchKernelGGL(ykk::k_rank_fill, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), e->d_key.as<u64>(),
+                       cursor, members, e->d_member_key.as<u64>());
     hipLaunchKernelGGL(ykk::k_rank_final, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), e->d_key.as<u64>(),
-                       bucket_off, members, e->d_rank.as<int>(), e->d_perm.as<int>());
+                       bucket_off, members, e->d_member_key.as<u64>(), e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.end(sb, "k_rank");
-    static const char* const rnames[4] = {"k_plane_res(ranked)", "k_plane_tol(ranked)", "k_plane_aff(ranked)", "k_plane_spread(ranked)"};
-    launch_planes(sb, e->d_perm.as<int>(), rnames);
+  }
+  // ---- stream A: signature planes in canonical node order, all families in one launch (grid.z = family). The tol
+  // family always runs: it also carries "node exists" for the padding bits of the last word.
+  {
+    ykk::PlaneArgs pa{};
+    pa.perm = nullptr;
+    pa.res = o_res;
+    pa.tol = o_tol;
+    pa.aff = o_aff;
+    pa.spread = o_spread;
+    if (!res_on) pa.res.D = 0;
+    if (!aff_on) pa.aff.D = 0;
+    if (!spread_on) pa.spread.D = 0;
+    pa.sig_req = e->d_sig_req.as<i64>();
+    pa.sig_tol = e->d_sig_tol.as<u64>();
+    pa.sig_tolflags = e->d_sig_tolflags.as<unsigned>();
+    pa.affs = as;
+    pa.spreads = spread_sigs(e);
+    pa.pre_mask = pre;
+    pa.filt_mask = filt;
+    pa.fit_error = fit_error;
+    pa.n_words = e->row_words;
+    unsigned ychunks = std::max(std::max(sig_chunks(pa.res.D), sig_chunks(pa.tol.D)), std::max(aff_chunks, sig_chunks(pa.spread.D)));
+    tm.begin(st);
+    hipLaunchKernelGGL(ykk::k_planes, dim3(wgroups, std::max(ychunks, 1u), spread_on ? 4u : 3u), dim3(ykk::kBlock), 0, st, nt, pa);
+    tm.end(st, "k_planes");
+  }
+  // ---- stream B, part 2 (after the canonical planes): rank-ordered planes by bit permutation, then the first
+  // feasible node of every class. Overlaps the start of k_combine.
+  if (want_dec) {
+    HIPCHK(hipEventRecord(e->ev_planes, st));
+    HIPCHK(hipStreamWaitEvent(sb, e->ev_planes, 0));
+    tm.begin(sb);
+    hipLaunchKernelGGL(ykk::k_permute_planes, dim3(wgroups, sig_chunks(e->plane_rows_alloc)), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
+                       e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, e->plane_rows_alloc, e->row_words);
+    tm.end(sb, "k_permute_planes");
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
                        pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
     tm.end(sb, "k_decide");
     HIPCHK(hipEventRecord(e->ev_join, sb));
   }
-  // ---- ... then combine
+  // ---- stream A: combine → bitmap
   HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   {
     // store flavour: bits 16-17 of options select an experimental variant (0 = default)
@@ -848,8 +864,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const int seg = ykk::kBlock * ykk::kCombineUnroll * wpl;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
     auto launch = [&](auto kern) {
-      hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), 0, st, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                         e->d_class_count.as<int>());
+      // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
+      hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pc, bitmap, e->row_words, e->row_stride,
+                         pin_on, e->d_class_count.as<int>());
     };
     tm.begin(st);
     switch (variant) {

@@ -37,7 +37,8 @@ constexpr int kMaxKD = 4;  // topology keys used by hard spread constraints
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kSigsPerBlock = 64;   // signatures walked by one plane block (one ballot word per lane)
+constexpr int kSigsPerBlock = 16;   // signatures walked by one plane block (lane i keeps the ballot word of signature i):
+                                    // the walk is latency-bound, so short walks in many blocks beat long ones
 constexpr int kChunkMembers = 64;   // member pods per combine chunk (member ids live in the lanes of a wave)
 constexpr int kCombineUnroll = 4;   // row words per thread held in registers by k_combine
 
@@ -128,23 +129,28 @@ __global__ __launch_bounds__(kRankBuckets) void k_rank_scan(const int* __restric
   cursor[t] = excl;
   if (t == kRankBuckets - 1) bucket_off[kRankBuckets] = tmp[t];
 }
-__global__ __launch_bounds__(kBlock) void k_rank_fill(int n_nodes, const double* __restrict__ score, int* __restrict__ cursor,
-                                                      int* __restrict__ members) {
+__global__ __launch_bounds__(kBlock) void k_rank_fill(int n_nodes, const double* __restrict__ score, const u64* __restrict__ key,
+                                                      int* __restrict__ cursor, int* __restrict__ members, u64* __restrict__ member_key) {
   int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n < n_nodes) members[atomicAdd(&cursor[rank_bucket(score[n])], 1)] = n;
+  if (n >= n_nodes) return;
+  int pos = atomicAdd(&cursor[rank_bucket(score[n])], 1);
+  members[pos] = n;
+  member_key[pos] = key[n];  // keys travel with the ids: the final pass streams them instead of chasing key[members[i]]
 }
 __global__ __launch_bounds__(kBlock) void k_rank_final(int n_nodes, const double* __restrict__ score, const u64* __restrict__ key,
                                                        const int* __restrict__ bucket_off, const int* __restrict__ members,
-                                                       int* __restrict__ rank, int* __restrict__ perm) {
+                                                       const u64* __restrict__ member_key, int* __restrict__ rank,
+                                                       int* __restrict__ perm) {
   int n = blockIdx.x * kBlock + threadIdx.x;
   if (n >= n_nodes) return;
   const int b = rank_bucket(score[n]);
   const int lo = bucket_off[b], hi = bucket_off[b + 1];
   const u64 mine = key[n];
   int r = lo;
+#pragma unroll 4
   for (int i = lo; i < hi; ++i) {
     int m = members[i];
-    u64 k = key[m];
+    u64 k = member_key[i];
     r += (k < mine) || (k == mine && m < n);
   }
   rank[n] = r;
@@ -184,8 +190,8 @@ __device__ __forceinline__ void plane_store(const PlaneOut& o, bool ranked, int 
 
 // NodeResourcesFit.Filter: fail ⇔ count+1 > allowed ∨ ∃r: req_r > 0 ∧ req_r > alloc_r − requested_r.
 // One signature = one distinct request vector. `fit_error`: Filter enabled without its PreFilter (no cycle state).
-__global__ __launch_bounds__(kBlock) void k_plane_res(NodeTable t, const int* __restrict__ perm, const i64* __restrict__ sig_req /*[D][R]*/,
-                                                      PlaneOut o, int fit_error, int n_words) {
+__device__ __forceinline__ void plane_res(const NodeTable& t, const int* __restrict__ perm, const i64* __restrict__ sig_req /*[D][R]*/,
+                                          const PlaneOut& o, int fit_error, int n_words) {
   int word;
   int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
@@ -218,9 +224,9 @@ __global__ __launch_bounds__(kBlock) void k_plane_res(NodeTable t, const int* __
 }
 
 // TaintToleration.Filter + NodeUnschedulable.Filter (A.4, A.7). Signature = (tolerated mask, tolerates-unschedulable).
-__global__ __launch_bounds__(kBlock) void k_plane_tol(NodeTable t, const int* __restrict__ perm, const u64* __restrict__ sig_tol /*[D][KT]*/,
-                                                      const unsigned* __restrict__ sig_flags /*[D]*/, PlaneOut o, unsigned filt_mask,
-                                                      int n_words) {
+__device__ __forceinline__ void plane_tol(const NodeTable& t, const int* __restrict__ perm, const u64* __restrict__ sig_tol /*[D][KT]*/,
+                                          const unsigned* __restrict__ sig_flags /*[D]*/, const PlaneOut& o, unsigned filt_mask,
+                                          int n_words) {
   int word;
   int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
@@ -291,8 +297,8 @@ __device__ __forceinline__ bool dnf_match_any(const u64* terms, int t0, int t1, 
   }
   return any;
 }
-__global__ __launch_bounds__(kBlock) void k_plane_aff(NodeTable t, const int* __restrict__ perm, AffSigs s, PlaneOut o, unsigned pre_mask,
-                                                      unsigned filt_mask, int n_words) {
+__device__ __forceinline__ void plane_aff(const NodeTable& t, const int* __restrict__ perm, const AffSigs& s, const PlaneOut& o,
+                                          unsigned pre_mask, unsigned filt_mask, int n_words) {
   __shared__ u64 s_terms[kAffLdsWords];
   __shared__ u64 s_pre[kAffLdsWords];
   __shared__ int s_off[kAffSigsPerBlock + 1], s_poff[kAffSigsPerBlock + 1];
@@ -348,6 +354,27 @@ __global__ __launch_bounds__(kBlock) void k_plane_aff(NodeTable t, const int* __
     if (i == (int)(threadIdx.x % kWave)) keep = b;
   }
   plane_store(o, perm != nullptr, word, d0, nd, keep);
+}
+
+// Rank-ordered planes by bit permutation: ranked[d] bit i = canonical[d] bit perm[i]. One launch covers every family
+// (their planes are rows of one buffer), replacing a second evaluation of all predicates in permuted node order.
+__global__ __launch_bounds__(kBlock) void k_permute_planes(int n_nodes, const int* __restrict__ perm, const u64* __restrict__ canon,
+                                                           u64* __restrict__ ranked, int stride, int n_rows, int n_words) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int w = blockIdx.x * kWavesPerBlock + wave;
+  if (w >= n_words) return;
+  const int pos = w * kWave + lane;
+  const int src = pos < n_nodes ? perm[pos] : -1;
+  const int sw = src >> 6, sb = src & 63;
+  const int d0 = blockIdx.y * kSigsPerBlock;
+  const int dend = min(d0 + kSigsPerBlock, n_rows);
+  u64 keep = 0;
+  for (int d = d0; d < dend; ++d) {
+    bool bit = src >= 0 && ((canon[(size_t)d * stride + sw] >> sb) & 1ull);
+    u64 b = __ballot(bit);
+    if (d - d0 == lane) keep = b;
+  }
+  if (lane < dend - d0) ranked[(size_t)(d0 + lane) * stride + w] = keep;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -443,7 +470,8 @@ __device__ __forceinline__ bool spread_ok(const SpreadSigs& sp, int d, const int
   }
   return true;
 }
-__global__ __launch_bounds__(kBlock) void k_plane_spread(NodeTable t, const int* __restrict__ perm, SpreadSigs sp, PlaneOut o, int n_words) {
+__device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __restrict__ perm, const SpreadSigs& sp, const PlaneOut& o,
+                                             int n_words) {
   int word;
   int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
@@ -459,6 +487,36 @@ __global__ __launch_bounds__(kBlock) void k_plane_spread(NodeTable t, const int*
     if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
   }
   plane_store(o, perm != nullptr, word, d0, dend - d0, keep);
+}
+
+// One launch for all plugin families: blockIdx.z selects the family, so their (latency-bound, cache-cold) signature
+// walks overlap instead of queueing behind each other. A family that is disabled for this eval has D = 0.
+struct PlaneArgs {
+  const int* perm;
+  PlaneOut res, tol, aff, spread;
+  const i64* sig_req;
+  const u64* sig_tol;
+  const unsigned* sig_tolflags;
+  AffSigs affs;
+  SpreadSigs spreads;
+  unsigned pre_mask, filt_mask;
+  int fit_error, n_words;
+};
+__global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
+  switch (blockIdx.z) {
+    case 0:
+      if ((int)blockIdx.y * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
+      break;
+    case 1:
+      if ((int)blockIdx.y * kSigsPerBlock < a.tol.D) plane_tol(t, a.perm, a.sig_tol, a.sig_tolflags, a.tol, a.filt_mask, a.n_words);
+      break;
+    case 2:
+      if ((int)blockIdx.y * kAffSigsPerBlock < a.aff.D) plane_aff(t, a.perm, a.affs, a.aff, a.pre_mask, a.filt_mask, a.n_words);
+      break;
+    default:
+      if ((int)blockIdx.y * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words);
+      break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -136,6 +136,7 @@ int recreate_engine(ykhost* h) {
   // engine tunables for experiments: YKPRED_CHUNK_MEMBERS=1..64, YKPRED_CHUNK_UNSORTED=1
   if (const char* v = getenv("YKPRED_CHUNK_MEMBERS")) c.reserved[0] = atoi(v);
   if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
+  if (const char* v = getenv("YKPRED_COMBINE_LDS")) c.reserved[2] = atoi(v);
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;
