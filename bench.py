@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--templates", type=int, default=2000, help="distinct pod templates (0 = every pod draws its own)")
     ap.add_argument("--unique-requests", action="store_true", help="adversarial: a distinct cpu request per pod")
     ap.add_argument("--no-affinity", action="store_true", help="configs[1] plugin mix (no nodeSelector/affinity on pods)")
+    ap.add_argument("--spread", action="store_true", help="configs[4] plugin mix: 10 %% of the templates carry a hard zone-spread constraint")
+    ap.add_argument("--gang", type=int, default=0, help="configs[3] shape: asks are gang placeholders, this many identical members per group")
     ap.add_argument("--direct", action="store_true", help="time the per-pair kernel instead of the plane/class path")
     ap.add_argument("--gather-bitmap", action="store_true", help="N>1: also all-gather the shard bitmaps (reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -98,7 +100,7 @@ def main():
     t_gen = time.perf_counter()
     pm.generate_kwok(seed=SEED + 2, num_nodes=a.nodes, num_pods=a.pods, num_templates=a.templates,
                      node_affinity=0 if a.no_affinity else 1, unique_requests=1 if a.unique_requests else 0,
-                     node_index_offset=rank * a.nodes)
+                     node_index_offset=rank * a.nodes, spread=1 if a.spread else 0, gang_size=a.gang)
     pm.sync()
     t_gen = time.perf_counter() - t_gen
     P, N = pm.num_pods, pm.num_nodes
@@ -174,10 +176,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": ("configs[2]: 50k nodes x 1M pods, NodeResourcesFit + TaintToleration + NodeAffinity"
-                                    if (N, P, a.no_affinity) == (50_000, 1_000_000, False) else
+                                    if (N, P, a.no_affinity, a.spread, a.gang) == (50_000, 1_000_000, False, False, 0) else
                                     f"{N} nodes/GPU x {P} pods, affinity={'off' if a.no_affinity else 'on'}"),
                        "nodes_per_gpu": N, "pods": P, "templates": a.templates, "pod_classes": lay.num_classes,
-                       "signature_planes": lay.plane_rows, "unique_requests": bool(a.unique_requests),
+                       "signature_planes": lay.plane_rows, "unique_requests": bool(a.unique_requests), "spread": bool(a.spread), "gang_size": a.gang,
                        "path": "direct" if a.direct else "planes+combine",
                        "parallelism": "single GPU" if world == 1 else f"node-axis shards x{world}, all-reduce of per-pod decisions"},
             "decisions_per_sec": float(P) * a.steps / elapsed,

@@ -329,3 +329,37 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["nodes_per_gpu"] == 4000 and d["config"]["pods"] == 50000
+
+
+def test_topology_spread_sharded_histograms():
+    """Node-sharded PodTopologySpread: two engines hold half of the nodes each; the partial histograms are summed
+    (what sharding.exchange_spread_histograms does over RCCL) and both halves of the bitmap must equal the oracle's
+    verdicts on the whole cluster."""
+    import torch
+    full = pkg.GpuPredicateManager()
+    a, b = pkg.GpuPredicateManager(), pkg.GpuPredicateManager()
+    try:
+        full.generate_kwok(seed=777, num_nodes=256, num_pods=400, num_templates=80, node_affinity=1, spread=1)
+        snap = json.loads(full.dump_snapshot())
+        half = 128
+        a.load_snapshot({"nodes": snap["nodes"][:half], "pods": snap["pods"]})
+        b.load_snapshot({"nodes": snap["nodes"][half:], "pods": snap["pods"]})
+        for m in (a, b):
+            m.evaluate_into(spread_count_only=True)
+            m.synchronize()
+        (ca, pa), (cb, pb) = a.spread_tensors(), b.spread_tensors()
+        assert ca.numel() == cb.numel() and ca.numel() > 1, "shards must share the topology-domain dictionaries"
+        total, present = ca + cb, torch.maximum(pa, pb)
+        for c, p in ((ca, pa), (cb, pb)):
+            c.copy_(total)
+            p.copy_(present)
+        torch.cuda.synchronize()
+        for m in (a, b):
+            m.evaluate_into(spread_counts_ready=True)
+        want = orc.Oracle(snap).eval_grid(threads=8)
+        got = np.concatenate([unpack(a.read_bitmap(), half), unpack(b.read_bitmap(), len(snap["nodes"]) - half)], axis=1)
+        assert np.array_equal(got, want)
+        assert np.array_equal(a.read_counts() + b.read_counts(), want.sum(axis=1))
+    finally:
+        for m in (full, a, b):
+            m.close()

@@ -65,3 +65,30 @@ def test_gathered_row_layout():
     g = torch.arange(G * P * stride).reshape(G, P, stride)
     row = sharding.gathered_row(g, 2, G, words)
     assert row.tolist() == [int(g[s, 2, w]) for s in range(G) for w in range(words)]
+
+
+def _spread_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11 + rank)
+    counts = torch.from_numpy(rng.integers(0, 5, 64).astype(np.int32))
+    present = torch.from_numpy((rng.random(64) < 0.5).astype(np.int32))
+    sharding.exchange_spread_histograms(counts, present, dist)
+    if rank == 0:
+        torch.save({"counts": counts, "present": present}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_spread_histograms_world2(tmp_path):
+    out = str(tmp_path / "s.pt")
+    mp.spawn(_spread_worker, args=(2, 29533, out), nprocs=2, join=True)
+    got = torch.load(out)
+    c = [np.random.default_rng(11 + r).integers(0, 5, 64) for r in range(2)]
+    pr = []
+    for r in range(2):
+        g = np.random.default_rng(11 + r)
+        g.integers(0, 5, 64)
+        pr.append((g.random(64) < 0.5).astype(np.int32))
+    assert np.array_equal(got["counts"].numpy(), c[0] + c[1])
+    assert np.array_equal(got["present"].numpy(), np.maximum(pr[0], pr[1]))

@@ -29,6 +29,7 @@ PLUGIN_BITS = {
 ALL_PLUGINS = 0x7F
 OUT_BITMAP, OUT_COUNTS, OUT_DECISIONS, OUT_DECISION_KEYS = 1, 2, 4, 8
 EVAL_PROFILE, EVAL_DIRECT = 1 << 8, 1 << 9
+EVAL_SPREAD_COUNT_ONLY, EVAL_SPREAD_COUNTS_READY = 1 << 10, 1 << 11
 
 
 def plugin_mask(names):
@@ -192,7 +193,7 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_evaluate(self._h, 1 if allocate else 0, opts))
 
     def evaluate_into(self, bitmap=None, counts=None, decisions=None, keys=None, stream=None, allocate=True, profile=False,
-                      direct=False, variant=0):
+                      direct=False, variant=0, spread_count_only=False, spread_counts_ready=False):
         """ykpred_eval with caller-owned DEVICE outputs (objects exposing data_ptr(), e.g. torch tensors) on the
         caller's HIP stream — how a multi-GPU driver keeps the results where its collectives can reach them."""
         self.sync()
@@ -201,12 +202,27 @@ class GpuPredicateManager:
         a.filter_plugins = self._masks[3] if allocate else self._masks[2]
         a.options = OUT_BITMAP | OUT_COUNTS | OUT_DECISIONS | (OUT_DECISION_KEYS if keys is not None else 0)
         a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0) | ((variant & 3) << 16)
+        a.options |= (EVAL_SPREAD_COUNT_ONLY if spread_count_only else 0) | (EVAL_SPREAD_COUNTS_READY if spread_counts_ready else 0)
         a.bitmap = None if bitmap is None else bitmap.data_ptr()
         a.counts = None if counts is None else counts.data_ptr()
         a.decisions = None if decisions is None else decisions.data_ptr()
         a.decision_keys = None if keys is None else keys.data_ptr()
         a.stream = stream
         self._pcheck(self._P.ykpred_eval(self.engine, C.byref(a)))
+
+    def spread_tensors(self):
+        """(counts, present) int32 torch tensors VIEWING the engine's PodTopologySpread histograms on the device
+        (zero-copy via __cuda_array_interface__) — what a node-sharded driver all-reduces between the two halves."""
+        import torch
+        lay = self.layout()
+
+        class _View:
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 3}
+
+        n = max(int(lay.spread_cells), 1)
+        return (torch.as_tensor(_View(lay.spread_counts, n), device="cuda"),
+                torch.as_tensor(_View(lay.spread_present, n), device="cuda"))
 
     @property
     def engine(self):

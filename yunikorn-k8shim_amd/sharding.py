@@ -32,6 +32,17 @@ def exchange_decisions(counts, decisions, keys, node_offset, dist):
     return counts, decisions
 
 
+def exchange_spread_histograms(counts, present, dist):
+    """PodTopologySpread on a node-sharded cluster: every shard builds partial per-(constraint, domain) histograms
+    over ITS nodes (ykpred_eval with YKPRED_EVAL_SPREAD_COUNT_ONLY); the cluster-wide PreFilter state is their SUM
+    (matching pods) and MAX (domain present on some eligible node). Afterwards each shard evaluates with
+    YKPRED_EVAL_SPREAD_COUNTS_READY. Requires identical topology-domain dictionaries on all shards (the host side
+    builds them from the whole cluster). In place; KBs of traffic."""
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    dist.all_reduce(present, op=dist.ReduceOp.MAX)
+    return counts, present
+
+
 def gathered_row(gathered, pod, num_shards, row_words):
     """Row of `pod` in the canonical node order from the shard-major gathered layout [G][P][row_stride]."""
     return torch.cat([gathered[g, pod, :row_words] for g in range(num_shards)])
