@@ -379,7 +379,7 @@ int run_spread_prefilter(ykpred_engine* e, hipStream_t st, Timer* tm, bool do_co
     ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
                     e->d_sig_pre_terms.as<u64>()};
     if (tm) tm->begin(st);
-    hipLaunchKernelGGL(ykk::k_spread_count, dim3((unsigned)((e->N + ykk::kBlock - 1) / ykk::kBlock), (unsigned)e->fam_spread.D),
+    hipLaunchKernelGGL(ykk::k_spread_count, dim3((unsigned)e->fam_spread.D, (unsigned)((e->N + ykk::kBlock - 1) / ykk::kBlock)),
                        dim3(ykk::kBlock), 0, st, nt, sp, as, e->d_sig_tol.as<u64>());
     if (tm) tm->end(st, "k_spread_count");
   }
@@ -759,7 +759,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   if (a->options & YKPRED_EVAL_DIRECT) {
     ykk::SpecTable stbl = spec_table(e);
-    dim3 grid((unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock), (unsigned)((P + ykk::kWave - 1) / ykk::kWave));
+    dim3 grid((unsigned)((P + ykk::kWave - 1) / ykk::kWave), (unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
     tm.begin(st);
     hipLaunchKernelGGL(ykk::k_direct, grid, dim3(ykk::kBlock), 0, st, nt, stbl, P, e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre,
                        filt, bitmap, e->row_words, e->row_stride);
@@ -837,7 +837,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     pa.n_words = e->row_words;
     unsigned ychunks = std::max(std::max(sig_chunks(pa.res.D), sig_chunks(pa.tol.D)), std::max(aff_chunks, sig_chunks(pa.spread.D)));
     tm.begin(st);
-    hipLaunchKernelGGL(ykk::k_planes, dim3(wgroups, std::max(ychunks, 1u), spread_on ? 4u : 3u), dim3(ykk::kBlock), 0, st, nt, pa);
+    hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(ychunks, 1u), wgroups, spread_on ? 4u : 3u), dim3(ykk::kBlock), 0, st, nt, pa);
     tm.end(st, "k_planes");
   }
   // ---- stream B, part 2 (after the canonical planes): rank-ordered planes by bit permutation, then the first
@@ -846,7 +846,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     HIPCHK(hipEventRecord(e->ev_planes, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_planes, 0));
     tm.begin(sb);
-    hipLaunchKernelGGL(ykk::k_permute_planes, dim3(wgroups, sig_chunks(e->plane_rows_alloc)), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
+    hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(e->plane_rows_alloc), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
                        e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, e->plane_rows_alloc, e->row_words);
     tm.end(sb, "k_permute_planes");
     tm.begin(sb);

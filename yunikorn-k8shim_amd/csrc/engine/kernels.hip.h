@@ -167,12 +167,13 @@ struct PlaneOut {
   int D;        // signatures
 };
 
-// blockIdx.x: group of 4 node words; blockIdx.y: chunk of kSigsPerBlock signatures. `perm` != null selects the
+// blockIdx.x: chunk of kSigsPerBlock signatures (the unbounded axis: up to 2^31 blocks); blockIdx.y: group of 4 node
+// words (≤ 65 535 groups = 16.7 M nodes). `perm` != null selects the
 // rank-ordered plane (position i holds node perm[i]); the canonical and the ranked planes are separate launches so
 // that the ranked ones can run on the decision stream. Returns the node of this lane (-1 = past the end).
 __device__ __forceinline__ int plane_node(int n_nodes, const int* __restrict__ perm, int* word) {
   int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  int w = blockIdx.x * kWavesPerBlock + wave;
+  int w = blockIdx.y * kWavesPerBlock + wave;
   *word = w;
   int pos = w * kWave + lane;
   if (pos >= n_nodes) return -1;
@@ -205,7 +206,7 @@ __device__ __forceinline__ void plane_res(const NodeTable& t, const int* __restr
       if (r < t.R) fr[r] = t.alloc[(size_t)r * t.n + n] - t.req[(size_t)r * t.n + n];
     slots_ok = (i64)t.count[n] + 1 <= (i64)t.allowed[n];
   }
-  int d0 = blockIdx.y * kSigsPerBlock;
+  int d0 = blockIdx.x * kSigsPerBlock;
   int dend = min(d0 + kSigsPerBlock, o.D);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
@@ -241,7 +242,7 @@ __device__ __forceinline__ void plane_tol(const NodeTable& t, const int* __restr
     unsched = t.flags[n] & kNodeUnschedulable;
   }
   const bool taint_en = filt_mask & kPlugTaint, unsched_en = filt_mask & kPlugUnsched;
-  int d0 = blockIdx.y * kSigsPerBlock;
+  int d0 = blockIdx.x * kSigsPerBlock;
   int dend = min(d0 + kSigsPerBlock, o.D);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
@@ -303,7 +304,7 @@ __device__ __forceinline__ void plane_aff(const NodeTable& t, const int* __restr
   __shared__ u64 s_pre[kAffLdsWords];
   __shared__ int s_off[kAffSigsPerBlock + 1], s_poff[kAffSigsPerBlock + 1];
   __shared__ unsigned s_flags[kAffSigsPerBlock];
-  const int d0 = blockIdx.y * kAffSigsPerBlock;
+  const int d0 = blockIdx.x * kAffSigsPerBlock;
   const int nd = min(kAffSigsPerBlock, o.D - d0);
   if ((int)threadIdx.x <= nd) {
     s_off[threadIdx.x] = s.term_off[d0 + threadIdx.x];
@@ -361,12 +362,12 @@ __device__ __forceinline__ void plane_aff(const NodeTable& t, const int* __restr
 __global__ __launch_bounds__(kBlock) void k_permute_planes(int n_nodes, const int* __restrict__ perm, const u64* __restrict__ canon,
                                                            u64* __restrict__ ranked, int stride, int n_rows, int n_words) {
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int w = blockIdx.x * kWavesPerBlock + wave;
+  const int w = blockIdx.y * kWavesPerBlock + wave;
   if (w >= n_words) return;
   const int pos = w * kWave + lane;
   const int src = pos < n_nodes ? perm[pos] : -1;
   const int sw = src >> 6, sb = src & 63;
-  const int d0 = blockIdx.y * kSigsPerBlock;
+  const int d0 = blockIdx.x * kSigsPerBlock;
   const int dend = min(d0 + kSigsPerBlock, n_rows);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
@@ -398,11 +399,12 @@ struct SpreadSigs {
   int* minv;            // [G] global minimum after the minDomains rule                           (criticalPaths / minMatchNum)
 };
 
-// thread = node; blockIdx.y = signature. Eligible nodes add their selector counts to their domain's cell.
+// thread = node; blockIdx.x = signature, blockIdx.y = block of 256 nodes. Eligible nodes add their selector counts to
+// their domain's cell.
 __global__ __launch_bounds__(kBlock) void k_spread_count(NodeTable t, SpreadSigs sp, AffSigs aff, const u64* __restrict__ sig_tol) {
-  const int n = blockIdx.x * kBlock + threadIdx.x;
+  const int n = blockIdx.y * kBlock + threadIdx.x;
   if (n >= t.n) return;
-  const int d = blockIdx.y;
+  const int d = blockIdx.x;
   const int c0 = sp.c_off[d], c1 = sp.c_off[d + 1];
   // nodeLabelsMatchSpreadConstraints: all topology keys of the signature must be present on the node
   for (int g = c0; g < c1; ++g)
@@ -478,7 +480,7 @@ __device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __re
   int dom[kMaxKD];
 #pragma unroll
   for (int k = 0; k < kMaxKD; ++k) dom[k] = (n >= 0 && k < t.KD) ? t.domain[(size_t)k * t.n + n] : -1;
-  int d0 = blockIdx.y * kSigsPerBlock;
+  int d0 = blockIdx.x * kSigsPerBlock;
   int dend = min(d0 + kSigsPerBlock, o.D);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
@@ -505,16 +507,16 @@ struct PlaneArgs {
 __global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
   switch (blockIdx.z) {
     case 0:
-      if ((int)blockIdx.y * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
+      if ((int)blockIdx.x * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
       break;
     case 1:
-      if ((int)blockIdx.y * kSigsPerBlock < a.tol.D) plane_tol(t, a.perm, a.sig_tol, a.sig_tolflags, a.tol, a.filt_mask, a.n_words);
+      if ((int)blockIdx.x * kSigsPerBlock < a.tol.D) plane_tol(t, a.perm, a.sig_tol, a.sig_tolflags, a.tol, a.filt_mask, a.n_words);
       break;
     case 2:
-      if ((int)blockIdx.y * kAffSigsPerBlock < a.aff.D) plane_aff(t, a.perm, a.affs, a.aff, a.pre_mask, a.filt_mask, a.n_words);
+      if ((int)blockIdx.x * kAffSigsPerBlock < a.aff.D) plane_aff(t, a.perm, a.affs, a.aff, a.pre_mask, a.filt_mask, a.n_words);
       break;
     default:
-      if ((int)blockIdx.y * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words);
+      if ((int)blockIdx.x * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words);
       break;
   }
 }
@@ -801,19 +803,19 @@ __global__ __launch_bounds__(kBlock) void k_query(NodeTable t, SpecTable s, int 
   if (reason_out) reason_out[i] = reason;
 }
 
-// Per-pair grid: blockIdx.x = group of 4 node words, blockIdx.y = chunk of 64 pods. lane = node, the wave walks the
+// Per-pair grid: blockIdx.x = chunk of 64 pods (the unbounded axis), blockIdx.y = group of 4 node words. lane = node, the wave walks the
 // 64 pods of its chunk (pod data wave-uniform), ballot → lane (i) keeps pod i's word → 64 row stores.
 __global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int n_pods, const int* __restrict__ pod_spec,
                                                    const int* __restrict__ pod_pin, unsigned pre_mask, unsigned filt_mask,
                                                    u64* __restrict__ bitmap, int row_words, int row_stride) {
   int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  int w = blockIdx.x * kWavesPerBlock + wave;
+  int w = blockIdx.y * kWavesPerBlock + wave;
   if (w >= row_stride) return;
   int n = w * kWave + lane;
   if (n >= t.n) n = -1;
   NodeRegs nr;
   load_node(t, n, &nr);
-  int p0 = blockIdx.y * kWave;
+  int p0 = blockIdx.x * kWave;
   int pend = min(p0 + kWave, n_pods);
   u64 keep = 0;
   for (int p = p0; p < pend; ++p) {
