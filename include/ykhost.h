@@ -43,7 +43,7 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json);
 int32_t ykhost_remove_node(ykhost_t* h, const char* node_name);
 int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json); /* spec.nodeName set ⇒ assigned to that node, else a pending ask */
 int32_t ykhost_remove_pod(ykhost_t* h, const char* uid);
-int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name);
+int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name); /* the ask keeps its index (row); it is skipped by dump */
 int32_t ykhost_forget_pod(ykhost_t* h, const char* uid);
 
 /* synthetic KWOK-style cluster, replaces all state */
@@ -78,6 +78,11 @@ ykpred_engine_t* ykhost_engine(ykhost_t* h); /* the underlying engine, for layou
 
 /* batched evaluation of every pending ask against every node: phase selects the plugin lists */
 int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options /* YKPRED_OUT_* | YKPRED_EVAL_* */);
+
+/* Like ykhost_evaluate, but when only node rows changed since the last evaluation of this phase (AssumePod / ForgetPod /
+ * pods added to or removed from nodes) it patches just those node columns (ykpred_eval_nodes). *columns_patched receives
+ * the number of columns re-evaluated, or -1 when a full evaluation was required. */
+int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched);
 
 /* PredicateManager.Predicates for pending pod #pod on node #node. Returns 1 = fits ("", nil), 0 = error returned.
  * plugin receives the failing plugin name ("" when a PreFilter plugin rejected the pod), msg the status message. */

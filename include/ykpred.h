@@ -213,6 +213,13 @@ int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* pods);
 
 /* evaluation of every pending pod against every node of the uploaded snapshot */
 int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* args);
+/* Incremental form for the sequential scheduling loop (AssumePod / ForgetPod / UpdateNode between two asks,
+ * /root/reference/pkg/cache/context.go:828-898): after ykpred_update_node on `num_nodes` nodes, re-evaluates ONLY those
+ * node columns of the bitmap produced by the last ykpred_eval (same plugin lists, same output buffers) and patches the
+ * feasible counts; decisions are recomputed when YKPRED_OUT_DECISIONS is set. YKPRED_E_STATE if there is no matching
+ * previous evaluation, YKPRED_E_UNSUPPORTED when a PodTopologySpread signature is active (its histograms couple all
+ * nodes — run ykpred_eval). */
+int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* args, int32_t num_nodes, const int32_t* node_index);
 int32_t ykpred_synchronize(ykpred_engine_t* e);
 int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* out);
 int32_t ykpred_last_timing(const ykpred_engine_t* e, ykpred_timing_t* out);

@@ -249,22 +249,90 @@ def test_kwok_gang_placeholders_share_rows(pm):
     assert np.array_equal(unpack(bm[0:4000:37], lay.num_nodes), want)
 
 
+def _compare_live_rows(pm, snap_now, decisions=False):
+    """Rows of the asks that are still pending (assumed asks keep their row but are skipped) against the oracle."""
+    o = orc.Oracle(snap_now)
+    want = o.eval_grid(threads=8)
+    idx = [pm.pod_index(p["metadata"]["uid"]) for p in snap_now["pods"]]
+    lay = pm.layout()
+    got = unpack(pm.read_bitmap(), lay.num_nodes)[idx]
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} differing bits, first (live pod,node)={bad[0].tolist()}"
+    assert np.array_equal(pm.read_counts()[idx], want.sum(axis=1))
+    if decisions:
+        dec = pm.read_decisions()[idx]
+        for k in range(0, len(idx), 7):
+            assert o.decide(k) == (int(want[k].sum()), int(dec[k]))
+
+
+def _move(snap, uid, target):
+    """The snapshot after AssumePod(uid → target): the ask leaves the pending list and joins the node's pods."""
+    pod = next(p for p in snap["pods"] if p["metadata"]["uid"] == uid)
+    moved = dict(pod, spec=dict(pod["spec"], nodeName=target))
+    nodes = json.loads(json.dumps(snap["nodes"]))
+    next(n for n in nodes if n["metadata"]["name"] == target).setdefault("pods", []).append(moved)
+    return {"nodes": nodes, "pods": [p for p in snap["pods"] if p["metadata"]["uid"] != uid]}
+
+
 def test_incremental_assume_forget(pm):
-    """AssumePod / ForgetPod patch one node row; the next evaluation sees it (context.go:828-898)."""
-    snap = _gen.random_snapshot(2024, n_nodes=90, n_pods=40, scalars=False)
+    """AssumePod / ForgetPod patch one node row and ONE bitmap column (ykpred_eval_nodes) instead of a full pass; asks
+    keep their rows (context.go:828-898: the core binds asks one by one between predicate calls)."""
+    import random
+    rng = random.Random(3)
+    snap = _gen.random_snapshot(2024, n_nodes=150, n_pods=60, scalars=False)
     pm.load_snapshot(snap)
     pm.evaluate()
-    target = next(n["metadata"]["name"] for n in snap["nodes"] if n["metadata"]["name"])
-    uid = snap["pods"][3]["metadata"]["uid"]
-    pm.assume_pod(uid, target)
-    moved = dict(snap["pods"][3])
-    moved["spec"] = dict(moved["spec"], nodeName=target)
-    snap2 = {"nodes": json.loads(json.dumps(snap["nodes"])), "pods": [p for p in snap["pods"] if p["metadata"]["uid"] != uid]}
-    next(n for n in snap2["nodes"] if n["metadata"]["name"] == target).setdefault("pods", []).append(moved)
-    check_against_oracle(pm, snap2, True)
-    pm.forget_pod(uid)
-    snap3 = {"nodes": snap["nodes"], "pods": [p for p in snap["pods"] if p["metadata"]["uid"] != uid] + [snap["pods"][3]]}
-    check_against_oracle(pm, snap3, True)
+    names = [n["metadata"]["name"] for n in snap["nodes"] if n["metadata"]["name"]]
+    cur = snap
+    bound = []
+    for step in range(12):
+        if bound and rng.random() < 0.3:
+            uid, target = bound.pop(rng.randrange(len(bound)))
+            pm.forget_pod(uid)
+            pod = next(p for p in snap["pods"] if p["metadata"]["uid"] == uid)
+            nodes = json.loads(json.dumps(cur["nodes"]))
+            tn = next(n for n in nodes if n["metadata"]["name"] == target)
+            tn["pods"] = [q for q in tn["pods"] if q["metadata"]["uid"] != uid]
+            cur = {"nodes": nodes, "pods": cur["pods"] + [pod]}
+        else:
+            uid = rng.choice(cur["pods"])["metadata"]["uid"]
+            target = rng.choice(names)
+            pm.assume_pod(uid, target)
+            bound.append((uid, target))
+            cur = _move(cur, uid, target)
+        patched = pm.evaluate_dirty(decisions=(step % 3 == 0))
+        assert patched == 1, "exactly one node column changed"
+        _compare_live_rows(pm, cur, decisions=(step % 3 == 0))
+    # several nodes touched between two evaluations, some sharing a bitmap word
+    for k in range(5):
+        uid = cur["pods"][k]["metadata"]["uid"]
+        target = names[k * 2]
+        pm.assume_pod(uid, target)
+        cur = _move(cur, uid, target)
+    assert pm.evaluate_dirty() == 5
+    _compare_live_rows(pm, cur)
+    # a full evaluation afterwards agrees with the patched state
+    before = pm.read_bitmap().copy()
+    pm.evaluate()
+    assert np.array_equal(before, pm.read_bitmap())
+
+
+def test_incremental_at_full_size(pm):
+    """configs[2] size: one AssumePod → one column patch; checked against the per-pair kernel on that column and against
+    a full re-evaluation (checksum)."""
+    pm.generate_kwok(seed=0x59554E49 + 21, num_nodes=50_000, num_pods=1_000_000, num_templates=2000, node_affinity=1)
+    pm.evaluate()
+    node = "kwok-node-012345"
+    n_idx = pm.node_index(node)
+    for uid in ("pod-0000017", "pod-0000018", "pod-0000019"):
+        pm.assume_pod(uid, node)
+    assert pm.evaluate_dirty() == 1
+    patched_sum = pm.checksum()
+    col = pm.read_bitmap(0, 4096)[:, n_idx >> 6]
+    fit, _, _ = pm.query(np.arange(4096, dtype=np.int32), np.full(4096, n_idx, dtype=np.int32))
+    assert np.array_equal((col >> np.uint64(n_idx & 63)) & np.uint64(1), fit.astype(np.uint64))
+    pm.evaluate()
+    assert pm.checksum() == patched_sum
 
 
 def test_unsupported_pods_are_rejected_loudly(pm):

@@ -79,6 +79,7 @@ def load_ykpred():
     L.ykpred_set_specs.argtypes = [C.c_void_p, C.POINTER(YkpredSpecs)]
     L.ykpred_set_pods.argtypes = [C.c_void_p, C.POINTER(YkpredPods)]
     L.ykpred_eval.argtypes = [C.c_void_p, C.POINTER(YkpredEvalArgs)]
+    L.ykpred_eval_nodes.argtypes = [C.c_void_p, C.POINTER(YkpredEvalArgs), C.c_int32, C.c_void_p]
     L.ykpred_synchronize.argtypes = [C.c_void_p]
     L.ykpred_get_layout.argtypes = [C.c_void_p, C.POINTER(YkpredLayout)]
     L.ykpred_last_timing.argtypes = [C.c_void_p, C.POINTER(YkpredTiming)]
@@ -124,6 +125,7 @@ def load_ykhost():
     L.ykhost_engine.restype = C.c_void_p
     L.ykhost_engine.argtypes = [C.c_void_p]
     L.ykhost_evaluate.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
+    L.ykhost_evaluate_dirty.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]
     L.ykhost_predicates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_preemption_predicates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
     L.ykhost_pod_request_json.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]

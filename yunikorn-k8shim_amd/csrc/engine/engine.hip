@@ -99,7 +99,9 @@ struct ykpred_engine {
   int P = 0, C = 0, NC = 0;
   std::vector<int32_t> h_pod_spec, h_pod_pin;
   DevBuf d_pod_spec, d_pod_pin, d_pod_class;
-  DevBuf d_class_sig, d_class_pin, d_chunk_class, d_chunk_begin, d_chunk_len, d_chunk_first, d_members;
+  DevBuf d_class_sig, d_class_pin, d_class_first, d_class_word, d_chunk_class, d_chunk_begin, d_chunk_len, d_chunk_first, d_members;
+  unsigned last_pre = 0, last_filt = 0;  // plugin lists of the last full evaluation (ykpred_eval_nodes must match them)
+  bool last_eval_valid = false;
   DevBuf d_class_count, d_class_best;
   bool pods_set = false, classes_dirty = true;
   int chunk_members = ykk::kChunkMembers;  // tunable: cfg.reserved[0] (1..64)
@@ -269,6 +271,11 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   TRY(upload(e, e->d_pod_class, pod_class.data(), pod_class.size(), st));
   TRY(upload(e, e->d_class_sig, class_sig.data(), class_sig.size(), st));
   TRY(upload(e, e->d_class_pin, class_pin.data(), class_pin.size(), st));
+  {
+    std::vector<int32_t> class_first((size_t)C);
+    for (int c = 0; c < C; ++c) class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
+    TRY(upload(e, e->d_class_first, class_first.data(), class_first.size(), st));
+  }
   TRY(upload(e, e->d_members, members.data(), members.size(), st));
   TRY(upload(e, e->d_chunk_class, ch_class.data(), ch_class.size(), st));
   TRY(upload(e, e->d_chunk_begin, ch_begin.data(), ch_begin.size(), st));
@@ -278,6 +285,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   HIPCHK(e->d_class_best.ensure((size_t)std::max(C, 1) * sizeof(int)));
   HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
   e->classes_dirty = false;
+  e->last_eval_valid = false;
   return YKPRED_OK;
 }
 
@@ -475,7 +483,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
-                    &e->d_class_sig, &e->d_class_pin, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
+                    &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_members, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
                     &e->d_member_key})
     b->release();
@@ -855,9 +863,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     tm.end(sb, "k_decide");
     HIPCHK(hipEventRecord(e->ev_join, sb));
   }
-  // ---- stream A: combine → bitmap
-  HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
-  {
+  // ---- stream A: combine → bitmap (skipped by ykpred_eval_nodes' decision refresh: bitmap and class counts were
+  // patched incrementally)
+  const bool skip_combine = a->options & (1u << 12);
+  if (!skip_combine) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
+  if (!skip_combine) {
     // store flavour: bits 16-17 of options select an experimental variant (0 = default)
     const unsigned variant = (a->options >> 16) & 3u;
     const int wpl = (variant & 1u) ? 1 : 2;
@@ -888,6 +898,71 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   HIPCHK(hipGetLastError());
   tm.done(st);
+  e->last_pre = pre;
+  e->last_filt = filt;
+  e->last_eval_valid = true;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_t num_nodes, const int32_t* node_index) {
+  if (!e || !a || num_nodes < 0 || (num_nodes > 0 && !node_index)) return fail(e, YKPRED_E_INVALID, "eval_nodes: bad argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
+  const unsigned pre = a->prefilter_plugins, filt = a->filter_plugins;
+  u64* bitmap = a->bitmap ? (u64*)a->bitmap : e->d_bitmap.as<u64>();
+  if (e->classes_dirty || !e->last_eval_valid || pre != e->last_pre || filt != e->last_filt || (void*)bitmap != e->last_bitmap)
+    return fail(e, YKPRED_E_STATE, "eval_nodes: no matching previous ykpred_eval (tables, plugin lists or bitmap changed)");
+  if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) && e->fam_spread.D > 0)
+    return fail(e, YKPRED_E_UNSUPPORTED, "eval_nodes: PodTopologySpread histograms couple all nodes — run ykpred_eval");
+  for (int i = 0; i < num_nodes; ++i)
+    if (node_index[i] < 0 || node_index[i] >= e->N) return fail(e, YKPRED_E_INVALID, "eval_nodes: node index out of range");
+  Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
+  tm.start(st);
+  const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
+  const bool want_keys = a->options & YKPRED_OUT_DECISION_KEYS;
+  const bool want_dec = (a->options & YKPRED_OUT_DECISIONS) || want_keys;
+  if (num_nodes > 0 && e->P > 0) {
+    // unique nodes, grouped by bitmap word, at most kMaxColGroups words / 64 nodes per launch
+    std::vector<int32_t> nodes(node_index, node_index + num_nodes);
+    std::sort(nodes.begin(), nodes.end());
+    nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+    HIPCHK(e->d_class_word.ensure((size_t)std::max(e->C, 1) * ykk::kMaxColGroups * sizeof(u64)));
+    ykk::NodeTable nt = node_table(e);
+    ykk::SpecTable stbl = spec_table(e);
+    size_t i = 0;
+    while (i < nodes.size()) {
+      ykk::ColumnGroups cg{};
+      int filled = 0;
+      while (i < nodes.size() && cg.n_groups < ykk::kMaxColGroups && filled < 64) {
+        int w = nodes[i] >> 6;
+        cg.word[cg.n_groups] = w;
+        cg.first[cg.n_groups] = filled;
+        while (i < nodes.size() && (nodes[i] >> 6) == w && filled < 64) cg.nodes[filled++] = nodes[i++];
+        cg.n_groups++;
+        if (i < nodes.size() && (nodes[i] >> 6) == w) break;  // word split across launches: its second half goes next
+      }
+      cg.first[cg.n_groups] = filled;
+      tm.begin(st);
+      hipLaunchKernelGGL(ykk::k_column_class, dim3((unsigned)((e->C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, nt, stbl, cg,
+                         e->C, e->d_class_first.as<int>(), e->d_class_pin.as<int>(), e->d_pod_spec.as<int>(), pre, filt, bitmap, e->row_stride,
+                         e->d_class_word.as<u64>(), e->d_class_count.as<int>());
+      tm.end(st, "k_column_class");
+      tm.begin(st);
+      hipLaunchKernelGGL(ykk::k_column_patch, dim3((unsigned)((e->P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, cg, e->P,
+                         e->d_pod_class.as<int>(), e->d_class_word.as<u64>(), e->d_class_count.as<int>(), bitmap, e->row_stride,
+                         want_cnt ? (int*)(a->counts ? a->counts : e->last_counts) : nullptr);
+      tm.end(st, "k_column_patch");
+    }
+  }
+  HIPCHK(hipGetLastError());
+  tm.done(st);
+  if (want_dec) {
+    // the bin-pack order moved with the node's Requested: rerun the (cheap) plane + decision kernels, not the bitmap
+    ykpred_eval_args_t b = *a;
+    b.options = (a->options & ~(uint32_t)YKPRED_OUT_BITMAP) | (1u << 12);  // internal: skip k_combine
+    int rc = ykpred_eval(e, &b);
+    if (rc != YKPRED_OK) return rc;
+  }
   return YKPRED_OK;
 }
 

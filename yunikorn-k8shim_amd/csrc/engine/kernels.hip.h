@@ -829,6 +829,59 @@ __global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int
   if (p < n_pods) bitmap[(size_t)p * row_stride + w] = (w < row_words) ? keep : 0ull;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// incremental column patch: only the bitmap columns of the listed (updated) nodes are re-evaluated
+// ---------------------------------------------------------------------------------------------------
+struct ColumnGroups {     // updated nodes grouped by bitmap word (host-built, <= kMaxColGroups per launch)
+  int n_groups;
+  int word[64];           // bitmap word index of the group
+  int first[65];          // nodes of group g = nodes[first[g] .. first[g+1])
+  int nodes[64];          // node indices
+};
+constexpr int kMaxColGroups = 64;
+// thread = class: every member row of a class is identical, so the old word is read from the first member's row, the
+// touched bits are re-evaluated per pair straight from the tables (same routine as k_query / k_direct), and the class's
+// feasible count moves by the popcount difference.
+__global__ __launch_bounds__(kBlock) void k_column_class(NodeTable t, SpecTable s, ColumnGroups cg, int n_classes,
+                                                         const int* __restrict__ class_first, const int* __restrict__ class_pin,
+                                                         const int* __restrict__ pod_spec, unsigned pre_mask, unsigned filt_mask,
+                                                         const u64* __restrict__ bitmap, int row_stride, u64* __restrict__ class_word,
+                                                         int* __restrict__ class_count) {
+  int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= n_classes) return;
+  const int p0 = class_first[c];
+  const int spec = pod_spec[p0];
+  const int pin = (filt_mask & kPlugNodeName) ? class_pin[c] : -1;
+  int delta = 0;
+  for (int g = 0; g < cg.n_groups; ++g) {
+    const u64 old = bitmap[(size_t)p0 * row_stride + cg.word[g]];
+    u64 neu = old;
+    for (int i = cg.first[g]; i < cg.first[g + 1]; ++i) {
+      const int n = cg.nodes[i];
+      NodeRegs nr;
+      load_node(t, n, &nr);
+      int code;
+      unsigned reason;
+      bool ok = eval_pair(s, spec, pin, n, nr, pre_mask, filt_mask, &code, &reason);
+      const u64 m = 1ull << (n & 63);
+      neu = ok ? (neu | m) : (neu & ~m);
+    }
+    class_word[(size_t)c * kMaxColGroups + g] = neu;
+    delta += __popcll(neu) - __popcll(old);
+  }
+  if (delta) class_count[c] += delta;
+}
+// thread = pod: store the class's new words into the pod's row, refresh its count
+__global__ __launch_bounds__(kBlock) void k_column_patch(ColumnGroups cg, int n_pods, const int* __restrict__ pod_class,
+                                                         const u64* __restrict__ class_word, const int* __restrict__ class_count,
+                                                         u64* __restrict__ bitmap, int row_stride, int* __restrict__ counts) {
+  int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pods) return;
+  const int c = pod_class[p];
+  for (int g = 0; g < cg.n_groups; ++g) bitmap[(size_t)p * row_stride + cg.word[g]] = class_word[(size_t)c * kMaxColGroups + g];
+  if (counts) counts[p] = class_count[c];
+}
+
 // PreemptionPredicates (predicate_manager.go:141-179): single (pod,node); victims removed in order.
 __global__ void k_preempt(NodeTable t, SpecTable s, int spec, int pin, int node, int n_victims, const i64* __restrict__ vreq,
                           const unsigned char* __restrict__ vpresent, int start, unsigned pre_mask, unsigned filt_mask,

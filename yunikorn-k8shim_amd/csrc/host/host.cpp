@@ -63,7 +63,10 @@ struct ykhost {
   // ---- encoder state
   Encoder enc;
   bool dirty_all = true, dirty_pods = false;
-  std::vector<int> dirty_nodes;
+  std::vector<int> dirty_nodes;       // node rows to re-upload
+  std::vector<int> eval_dirty_nodes;  // node columns changed since the last evaluation
+  int last_eval_phase = -1;           // 1 allocate / 0 reserve / -1 none: the phase of the bitmap on the device
+  uint32_t last_eval_options = 0;
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
   int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1;
@@ -79,6 +82,8 @@ struct ykhost {
     uid_index = true;
     dirty_all = true;
     dirty_nodes.clear();
+    eval_dirty_nodes.clear();
+    last_eval_phase = -1;
     spec_templates.clear();
   }
 };
@@ -244,7 +249,7 @@ int pods_sync(ykhost* h) {
   for (size_t p = 0; p < P; ++p) {
     const Pod* pod = h->pending[p];
     spec[p] = pod->tpl->spec_id;
-    if (pod->node_name.empty()) {
+    if (pod->node_name.empty() || pod->assumed) {  // an assumed ask keeps its (now meaningless) row; spec.nodeName was set by the bind
       pin[p] = YKPRED_NO_NODE_NAME;
     } else {
       auto it = h->node_ix.find(pod->node_name);
@@ -305,7 +310,10 @@ int sync(ykhost* h) {
 
 // A node-level change that cannot introduce new dictionary entries (pod assumed / forgotten / removed).
 void touch_node(ykhost* h, int n) {
-  if (!h->dirty_all) h->dirty_nodes.push_back(n);
+  if (!h->dirty_all) {
+    h->dirty_nodes.push_back(n);
+    h->eval_dirty_nodes.push_back(n);
+  }
 }
 
 // ---- status message for a device verdict -------------------------------------------------------------
@@ -745,12 +753,10 @@ int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name) {
   if (it == h->by_uid.end()) return fail(h, "pod not found");
   if (nt == h->node_ix.end()) return fail(h, "node not found");
   Pod* p = it->second;
-  for (size_t i = 0; i < h->pending.size(); ++i)
-    if (h->pending[i] == p) {
-      h->pending.erase(h->pending.begin() + (long)i);
-      h->dirty_pods = true;
-      break;
-    }
+  if (p->assumed || !p->node_name.empty()) return fail(h, "pod is already assigned");
+  // The ask keeps its row in the ask table (marked assumed) so that pod indices — bitmap rows — stay stable during a
+  // scheduling cycle; only the node's row and bitmap column change.
+  p->assumed = true;
   p->node_name = node_name;
   h->nodes[(size_t)nt->second]->add_pod(p);
   touch_node(h, nt->second);
@@ -763,15 +769,11 @@ int32_t ykhost_forget_pod(ykhost_t* h, const char* uid) {
   auto it = h->by_uid.find(uid);
   if (it == h->by_uid.end()) return fail(h, "pod not found");
   Pod* p = it->second;
-  if (p->node_name.empty()) return 0;
+  if (!p->assumed) return fail(h, "pod is not assumed");
   auto nt = h->node_ix.find(p->node_name);
   if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
   p->node_name.clear();
-  h->pending.push_back(p);
-  if (p->tpl->spec_id < 0)
-    h->dirty_all = true;
-  else
-    h->dirty_pods = true;
+  p->assumed = false;
   return 0;
 }
 
@@ -806,7 +808,8 @@ int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const
   for (int i = 0; i < count_p; ++i) {
     int idx = pods ? pods[i] : i;
     if (idx < 0 || idx >= (int)h->pending.size()) return fail(h, "dump: pod index out of range");
-    if (i) o.push_back(',');
+    if (h->pending[(size_t)idx]->assumed) continue;  // bound asks are listed under their node
+    if (o.back() != '[') o.push_back(',');
     pod_json(*h->pending[(size_t)idx], o);
   }
   o += "]}";
@@ -826,6 +829,30 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
   a.options = options;
   rc = ykpred_eval(h->eng, &a);
   if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
+  h->eval_dirty_nodes.clear();
+  h->last_eval_phase = allocate ? 1 : 0;
+  h->last_eval_options = options;
+  return 0;
+}
+
+int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched) {
+  if (columns_patched) *columns_patched = -1;
+  const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0) && h->enc.KD == 0;
+  if (!incremental) return ykhost_evaluate(h, allocate, options);
+  int rc = sync(h);  // uploads the touched node rows
+  if (rc) return rc;
+  ykpred_eval_args_t a{};
+  a.prefilter_plugins = allocate ? h->alloc_pre : h->res_pre;
+  a.filter_plugins = allocate ? h->alloc_filt : h->res_filt;
+  a.options = options;
+  rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.data());
+  if (rc == YKPRED_E_STATE || rc == YKPRED_E_UNSUPPORTED) return ykhost_evaluate(h, allocate, options);
+  if (rc) return fail(h, std::string("ykpred_eval_nodes: ") + ykpred_last_error(h->eng), rc);
+  if (columns_patched) {
+    std::sort(h->eval_dirty_nodes.begin(), h->eval_dirty_nodes.end());
+    *columns_patched = (int32_t)(std::unique(h->eval_dirty_nodes.begin(), h->eval_dirty_nodes.end()) - h->eval_dirty_nodes.begin());
+  }
+  h->eval_dirty_nodes.clear();
   return 0;
 }
 

@@ -80,6 +80,7 @@ struct Pod {
   std::string uid, name;
   std::string node_name;  // spec.nodeName ("" = pending ask)
   bool terminating = false;
+  bool assumed = false;  // a pending ask that was bound to node_name by AssumePod: it keeps its row in the ask table
   const PodTemplate* tpl = nullptr;
 };
 

@@ -192,6 +192,14 @@ class GpuPredicateManager:
         opts |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0)
         self._check(self._L.ykhost_evaluate(self._h, 1 if allocate else 0, opts))
 
+    def evaluate_dirty(self, allocate=True, counts=True, decisions=False, profile=False):
+        """Patches only the node columns touched since the last evaluation (AssumePod / ForgetPod ...). Returns the
+        number of columns re-evaluated, or -1 when a full evaluation had to be run instead."""
+        opts = OUT_BITMAP | (OUT_COUNTS if counts else 0) | (OUT_DECISIONS if decisions else 0) | (EVAL_PROFILE if profile else 0)
+        n = C.c_int32(-1)
+        self._check(self._L.ykhost_evaluate_dirty(self._h, 1 if allocate else 0, opts, C.byref(n)))
+        return n.value
+
     def evaluate_into(self, bitmap=None, counts=None, decisions=None, keys=None, stream=None, allocate=True, profile=False,
                       direct=False, variant=0, spread_count_only=False, spread_counts_ready=False):
         """ykpred_eval with caller-owned DEVICE outputs (objects exposing data_ptr(), e.g. torch tensors) on the
