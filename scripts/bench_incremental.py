@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Latency of the incremental path at configs[2] size (50k nodes x 1M asks): AssumePod → node-row patch → column patch
+(ykpred_eval_nodes), with and without a decision refresh, next to a full ykpred_eval. Prints one JSON line."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+pm = pkg.GpuPredicateManager()
+pm.generate_kwok(seed=0x59554E49 + 2, num_nodes=50_000, num_pods=1_000_000, num_templates=2000, node_affinity=1)
+pm.evaluate()
+pm.synchronize()
+
+
+def timed(decisions, n=40, offset=0):
+    wall, dev = [], []
+    for i in range(n):
+        uid = f"pod-{offset + i:07d}"
+        node = f"kwok-node-{(7919 * (offset + i)) % 50_000:06d}"
+        t0 = time.perf_counter()
+        try:
+            pm.assume_pod(uid, node)
+        except RuntimeError:
+            continue  # the ask was generated with a nodeName pin
+        k = pm.evaluate_dirty(counts=True, decisions=decisions, profile=True)
+        pm.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        assert k == 1
+        dev.append(sum(ms for _, ms in pm.timing()["kernels"]))
+    return float(np.median(wall)), float(np.median(dev))
+
+
+w0, d0 = timed(False, offset=0)
+w1, d1 = timed(True, offset=1000)
+t0 = time.perf_counter()
+for _ in range(5):
+    pm.evaluate()
+pm.synchronize()
+full = (time.perf_counter() - t0) / 5 * 1e3
+print(json.dumps({"workload": "configs[2]: 50k nodes x 1M asks", "assume+column_patch_ms_wall": round(w0, 4),
+                  "column_patch_kernels_ms": round(d0, 4), "assume+column_patch+decisions_ms_wall": round(w1, 4),
+                  "decision_refresh_kernels_ms": round(d1, 4), "full_eval_ms_wall": round(full, 4)}))
