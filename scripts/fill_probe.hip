@@ -90,6 +90,23 @@ __global__ __launch_bounds__(256) void expand_tiles(u64* __restrict__ out, const
       if (offs[u] >= 0) *(u64x2*)((char*)out + offs[u]) = v[u];
   }
 }
+// (j) rows with a padded stride: write `used_words` of every `stride_words` row (row starts 4 KiB aligned when stride = 1024 words)
+__global__ __launch_bounds__(256) void fill_rows_padded(u64* p, int stride_words, int used_words, int rows_per_block, long n_rows, u64 v) {
+  u64x2 val = {v, v};
+  for (int r = 0; r < rows_per_block; ++r) {
+    long row = (long)blockIdx.x * rows_per_block + r;
+    if (row >= n_rows) return;
+    u64* base = p + (size_t)row * stride_words;
+    for (int w = threadIdx.x * 2; w < used_words; w += 512) *(u64x2*)(base + w) = val;
+  }
+}
+__global__ __launch_bounds__(256) void fill_rows_padded_persistent(u64* p, int stride_words, int used_words, long n_rows, u64 v) {
+  u64x2 val = {v, v};
+  for (long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+    u64* base = p + (size_t)row * stride_words;
+    for (int w = threadIdx.x * 2; w < used_words; w += 512) *(u64x2*)(base + w) = val;
+  }
+}
 // (f) one block per row (no inner row loop): 1M blocks
 __global__ __launch_bounds__(256) void fill_row_per_block(u64* p, int stride_words, u64 v) {
   u64x2 val = {v, v};
@@ -134,6 +151,18 @@ int main() {
       snprintf(nm, 80, "expand tiles K=3 (planes 2.3MB) U=2, %d blocks", g); run(nm, [&] { expand_tiles<3, 2><<<g, 256>>>(d, tab, c3, 375, rows); });
       snprintf(nm, 80, "expand tiles K=3 (planes 2.3MB) U=4, %d blocks", g); run(nm, [&] { expand_tiles<3, 4><<<g, 256>>>(d, tab, c3, 375, rows); });
     }
+  }
+  {
+    u64* d2; CK(hipMalloc(&d2, (size_t)rows * 1024 * 8));
+    CK(hipMemset(d2, 0, (size_t)rows * 1024 * 8));
+    for (int used : {784, 1024})
+      for (int rpb : {64, 8}) { char nm[96]; snprintf(nm, 96, "rows stride 8KiB, %d words written, %d rows/block", used, rpb);
+        run(nm, [&] { fill_rows_padded<<<(rows + rpb - 1) / rpb, 256>>>(d2, 1024, used, rpb, rows, 7); }); }
+    for (int g : {256, 512, 2048}) { char nm[96]; snprintf(nm, 96, "rows stride 8KiB, 784 words, persistent %d blocks", g);
+      run(nm, [&] { fill_rows_padded_persistent<<<g, 256>>>(d2, 1024, 784, rows, 7); }); }
+    for (int g : {256, 512}) { char nm[96]; snprintf(nm, 96, "rows stride 8KiB, 1024 words, persistent %d blocks", g);
+      run(nm, [&] { fill_rows_padded_persistent<<<g, 256>>>(d2, 1024, 1024, rows, 7); }); }
+    (void)hipFree(d2);
   }
   for (int bs : {1024})
     for (int g : {256 * 1024 / bs * 2, 256 * 1024 / bs * 8})

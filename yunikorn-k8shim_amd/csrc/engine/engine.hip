@@ -80,7 +80,9 @@ struct ykpred_engine {
   // per-family signature tables
   std::vector<int32_t> spec_sig_res, spec_sig_tol, spec_sig_aff;
   Family fam_res, fam_tol, fam_aff, fam_spread;
-  DevBuf planes_canon, planes_ranked;  // [total rows][row_stride] u64; families are row ranges
+  DevBuf planes_canon, planes_ranked;  // [total rows][row_stride] u64; families are row ranges (res, spread, tol, aff)
+  DevBuf base_canon, base_ranked;      // bit-sliced dictionaries: [64W requirement | 64KT taint | unsched | exists][row_stride]
+  u64 taint_used[ykk::kMaxKT] = {0, 0, 0, 0};  // OR of every node's taint words
   int plane_rows_alloc = 0;
   // PodTopologySpread signatures (host copies; device tables are rebuilt when nodes or specs change)
   std::vector<int32_t> spec_sig_spread;                 // [S] -1 = no hard constraints
@@ -294,7 +296,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
 // against the kernels that follow. The zero fill matters for the padding words [row_words, row_stride).
 int ensure_planes(ykpred_engine* e, hipStream_t st) {
   int rows = 0;
-  for (Family* f : {&e->fam_res, &e->fam_tol, &e->fam_aff, &e->fam_spread}) {
+  for (Family* f : {&e->fam_res, &e->fam_spread, &e->fam_tol, &e->fam_aff}) {  // ballot families first (see k_permute_planes)
     f->base = rows;
     rows += std::max(f->D, 1);
   }
@@ -306,6 +308,13 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
     }
   }
   e->plane_rows_alloc = rows;
+  size_t base_need = (size_t)(64 * (e->W + e->KT) + 2) * (size_t)e->row_stride * sizeof(u64);
+  for (DevBuf* b : {&e->base_canon, &e->base_ranked}) {
+    if (b->cap < base_need) {
+      HIPCHK(b->ensure(base_need));
+      HIPCHK(hipMemsetAsync(b->p, 0, base_need, st));
+    }
+  }
   return YKPRED_OK;
 }
 
@@ -479,7 +488,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   (void)hipDeviceSynchronize();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount,
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
-                    &e->planes_canon, &e->planes_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
+                    &e->planes_canon, &e->planes_ranked, &e->base_canon, &e->base_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
@@ -516,6 +525,9 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   TRY(upload(e, e->d_labels, n->label_bits, N * (size_t)e->W, st));
   TRY(upload(e, e->d_domain, n->domain_id, N * (size_t)e->KD, st));
   TRY(upload(e, e->d_selcount, n->selector_count, N * (size_t)e->KS, st));
+  for (int k = 0; k < ykk::kMaxKT; ++k) e->taint_used[k] = 0;
+  for (int k = 0; k < e->KT; ++k)
+    for (size_t i = 0; i < N; ++i) e->taint_used[k] |= n->taint_bits[(size_t)k * N + i];
   e->h_domain_sizes.assign(n->domain_sizes, n->domain_sizes + e->KD);
   e->spread_dirty = true;
   HIPCHK(e->d_score.ensure(N * sizeof(double)));
@@ -529,6 +541,8 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
     // plane rows change length: drop them so ensure_planes() re-zeroes the padding
     e->planes_canon.release();
     e->planes_ranked.release();
+    e->base_canon.release();
+    e->base_ranked.release();
   }
   e->N = n->count;
   e->row_words = (e->N + 63) / 64;
@@ -550,8 +564,10 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
   HIPCHK(hipMemcpyAsync(e->d_allowed.as<int>() + idx, n->allowed_pods, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_count.as<int>() + idx, n->pod_count, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_nflags.as<unsigned>() + idx, n->flags, sizeof(unsigned), hipMemcpyHostToDevice, st));
-  for (int k = 0; k < e->KT; ++k)
+  for (int k = 0; k < e->KT; ++k) {
+    e->taint_used[k] |= n->taint_bits[k];
     HIPCHK(hipMemcpyAsync(e->d_taints.as<u64>() + (size_t)k * N + idx, n->taint_bits + k, sizeof(u64), hipMemcpyHostToDevice, st));
+  }
   for (int w = 0; w < e->W; ++w)
     HIPCHK(hipMemcpyAsync(e->d_labels.as<u64>() + (size_t)w * N + idx, n->label_bits + w, sizeof(u64), hipMemcpyHostToDevice, st));
   for (int k = 0; k < e->KD; ++k) {
@@ -782,7 +798,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool aff_on = (filt | pre) & YKPRED_PLUGIN_NODE_AFFINITY;
   const int fit_error = (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1;
   auto sig_chunks = [](int D) { return (unsigned)((D + ykk::kSigsPerBlock - 1) / ykk::kSigsPerBlock); };
-  const unsigned aff_chunks = (unsigned)((e->fam_aff.D + ykk::kAffSigsPerBlock - 1) / ykk::kAffSigsPerBlock);
   ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
                   e->d_sig_pre_terms.as<u64>()};
   auto canon_of = [&](const Family& f) { return e->planes_canon.as<u64>() + (size_t)f.base * e->row_stride; };
@@ -822,40 +837,74 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                        bucket_off, members, e->d_member_key.as<u64>(), e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.end(sb, "k_rank");
   }
-  // ---- stream A: signature planes in canonical node order, all families in one launch (grid.z = family). The tol
-  // family always runs: it also carries "node exists" for the padding bits of the last word.
-  {
+  // Bit-sliced dictionaries + signature planes of one node order (perm == nullptr: canonical) on stream s.
+  auto base_of = [&](DevBuf& buf) {
+    ykk::BasePlanes bp;
+    bp.req = buf.as<u64>();
+    bp.taint = bp.req + (size_t)64 * e->W * e->row_stride;
+    bp.unsched = bp.taint + (size_t)64 * e->KT * e->row_stride;
+    bp.exists = bp.unsched + e->row_stride;
+    bp.stride = e->row_stride;
+    return bp;
+  };
+  auto launch_dictionary_planes = [&](hipStream_t s, const int* perm, bool ranked, const char* base_name, const char* sig_name) {
+    ykk::BasePlanes bp = base_of(ranked ? e->base_ranked : e->base_canon);
+    tm.begin(s);
+    hipLaunchKernelGGL(ykk::k_base_planes, dim3((unsigned)(e->W + e->KT + 1), wgroups), dim3(ykk::kBlock), 0, s, nt, perm, bp, e->row_words);
+    tm.end(s, base_name);
+    ykk::SigPlaneArgs sa{};
+    sa.base = bp;
+    sa.tol = o_tol;
+    sa.aff = o_aff;
+    if (ranked) {
+      sa.tol.canon = o_tol.ranked;
+      sa.aff.canon = o_aff.ranked;
+    }
+    if (!aff_on) sa.aff.D = 0;
+    sa.sig_tol = e->d_sig_tol.as<u64>();
+    sa.sig_tolflags = e->d_sig_tolflags.as<unsigned>();
+    for (int k = 0; k < ykk::kMaxKT; ++k) sa.taint_used[k] = e->taint_used[k];
+    sa.affs = as;
+    sa.KT = e->KT;
+    sa.W = e->W;
+    sa.pre_mask = pre;
+    sa.filt_mask = filt;
+    sa.n_words = e->row_words;
+    const unsigned chunks = (unsigned)((std::max(sa.tol.D, sa.aff.D) + ykk::kBitSigsPerBlock - 1) / ykk::kBitSigsPerBlock);
+    tm.begin(s);
+    hipLaunchKernelGGL(ykk::k_sig_planes, dim3(std::max(chunks, 1u), (unsigned)((e->row_words + ykk::kBlock - 1) / ykk::kBlock), 2u),
+                       dim3(ykk::kBlock), 0, s, sa);
+    tm.end(s, sig_name);
+  };
+  // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order)
+  if (want_dec) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
+  // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
+  if (res_on || spread_on) {
     ykk::PlaneArgs pa{};
     pa.perm = nullptr;
     pa.res = o_res;
-    pa.tol = o_tol;
-    pa.aff = o_aff;
     pa.spread = o_spread;
     if (!res_on) pa.res.D = 0;
-    if (!aff_on) pa.aff.D = 0;
     if (!spread_on) pa.spread.D = 0;
     pa.sig_req = e->d_sig_req.as<i64>();
-    pa.sig_tol = e->d_sig_tol.as<u64>();
-    pa.sig_tolflags = e->d_sig_tolflags.as<unsigned>();
-    pa.affs = as;
     pa.spreads = spread_sigs(e);
-    pa.pre_mask = pre;
-    pa.filt_mask = filt;
     pa.fit_error = fit_error;
     pa.n_words = e->row_words;
-    unsigned ychunks = std::max(std::max(sig_chunks(pa.res.D), sig_chunks(pa.tol.D)), std::max(aff_chunks, sig_chunks(pa.spread.D)));
+    unsigned xchunks = std::max(sig_chunks(pa.res.D), sig_chunks(pa.spread.D));
     tm.begin(st);
-    hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(ychunks, 1u), wgroups, spread_on ? 4u : 3u), dim3(ykk::kBlock), 0, st, nt, pa);
+    hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, st, nt, pa);
     tm.end(st, "k_planes");
   }
-  // ---- stream B, part 2 (after the canonical planes): rank-ordered planes by bit permutation, then the first
-  // feasible node of every class. Overlaps the start of k_combine.
+  launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes");
+  // ---- stream B, part 3 (after the canonical ballot planes): their rank-ordered copies by bit permutation, then the
+  // first feasible node of every class. Overlaps the start of k_combine.
   if (want_dec) {
     HIPCHK(hipEventRecord(e->ev_planes, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_planes, 0));
+    const int ballot_rows = e->fam_tol.base;  // res + spread rows come first in the plane buffers
     tm.begin(sb);
-    hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(e->plane_rows_alloc), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
-                       e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, e->plane_rows_alloc, e->row_words);
+    hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(ballot_rows), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
+                       e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, ballot_rows, e->row_words);
     tm.end(sb, "k_permute_planes");
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,

@@ -224,42 +224,6 @@ __device__ __forceinline__ void plane_res(const NodeTable& t, const int* __restr
   plane_store(o, perm != nullptr, word, d0, dend - d0, keep);
 }
 
-// TaintToleration.Filter + NodeUnschedulable.Filter (A.4, A.7). Signature = (tolerated mask, tolerates-unschedulable).
-__device__ __forceinline__ void plane_tol(const NodeTable& t, const int* __restrict__ perm, const u64* __restrict__ sig_tol /*[D][KT]*/,
-                                          const unsigned* __restrict__ sig_flags /*[D]*/, const PlaneOut& o, unsigned filt_mask,
-                                          int n_words) {
-  int word;
-  int n = plane_node(t.n, perm, &word);
-  if (word >= n_words) return;
-  u64 tn[kMaxKT];
-  bool unsched = false;
-#pragma unroll
-  for (int k = 0; k < kMaxKT; ++k) tn[k] = 0;
-  if (n >= 0) {
-#pragma unroll
-    for (int k = 0; k < kMaxKT; ++k)
-      if (k < t.KT) tn[k] = t.taints[(size_t)k * t.n + n];
-    unsched = t.flags[n] & kNodeUnschedulable;
-  }
-  const bool taint_en = filt_mask & kPlugTaint, unsched_en = filt_mask & kPlugUnsched;
-  int d0 = blockIdx.x * kSigsPerBlock;
-  int dend = min(d0 + kSigsPerBlock, o.D);
-  u64 keep = 0;
-  for (int d = d0; d < dend; ++d) {
-    const u64* tol = sig_tol + (size_t)d * t.KT;
-    bool ok = n >= 0;
-    if (taint_en) {
-#pragma unroll
-      for (int k = 0; k < kMaxKT; ++k)
-        if (k < t.KT) ok = ok && (tn[k] & ~tol[k]) == 0;
-    }
-    if (unsched_en) ok = ok && (!unsched || (sig_flags[d] & kSpecToleratesUnsched));
-    u64 b = __ballot(ok);
-    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
-  }
-  plane_store(o, perm != nullptr, word, d0, dend - d0, keep);
-}
-
 // NodeAffinity PreFilter + Filter (A.5). Signature = (flags, Filter DNF, PreFilter node-name DNF).
 struct AffSigs {
   const unsigned* flags;  // [D]
@@ -280,81 +244,116 @@ __device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0,
   }
   return any;
 }
-// The block's kSigsPerBlock signatures own CONTIGUOUS rows of the two term tables (CSR), so their offsets, flags and —
-// when they fit — all their term masks are staged into LDS with coalesced loads first; the 64-signature walk then
-// reads wave-uniform LDS words instead of chasing three dependent global loads per signature.
-constexpr int kAffLdsWords = 1024;   // 8 KiB per table
-constexpr int kAffSigsPerBlock = 16;  // fewer signatures per block than the other families: the DNF walk is latency-bound,
-                                      // more (shorter) blocks keep more waves in flight
-__device__ __forceinline__ bool dnf_match_any(const u64* terms, int t0, int t1, const u64 (&lb)[kMaxW], int W) {
-  bool any = false;
+// ---------------------------------------------------------------------------------------------------
+// Bit-sliced signature planes for the two dictionary-based families (TaintToleration+NodeUnschedulable, NodeAffinity).
+// Every dictionary bit (taint t, requirement q) first becomes its own N-bit BASE PLANE (k_base_planes: lane = node,
+// 64 ballots per dictionary word). A signature's plane is then pure bitwise algebra on 64-node words — lane = word:
+//   tol plane = exists & ~(OR of the base planes of the dictionary taints the spec does NOT tolerate) [& ~unschedulable]
+//   aff plane = exists & prefilter-names-DNF & filter-DNF,  DNF = OR over terms of (AND of the term's requirement planes)
+// i.e. per 64 (signature,node) verdicts a handful of loads and ANDs instead of 64 lane-wise mask compares.
+// ---------------------------------------------------------------------------------------------------
+struct BasePlanes {
+  u64* req;      // [64*W][stride]  requirement q
+  u64* taint;    // [64*KT][stride] dictionary taint t
+  u64* unsched;  // [stride] node.Spec.Unschedulable
+  u64* exists;   // [stride] bit set for positions < N (zero padding of the last word)
+  int stride;
+};
+// blockIdx.x: dictionary word (0..W-1 labels, W..W+KT-1 taints, W+KT flags); blockIdx.y: group of 4 node words.
+__global__ __launch_bounds__(kBlock) void k_base_planes(NodeTable t, const int* __restrict__ perm, BasePlanes o, int n_words) {
+  int word;
+  const int n = plane_node(t.n, perm, &word);
+  if (word >= n_words) return;
+  const int lane = threadIdx.x % kWave;
+  const int c = blockIdx.x;
+  if (c < t.W + t.KT) {
+    const bool is_label = c < t.W;
+    const u64 v = n < 0 ? 0ull : (is_label ? t.labels[(size_t)c * t.n + n] : t.taints[(size_t)(c - t.W) * t.n + n]);
+    u64 keep = 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+      u64 m = __ballot((v >> b) & 1ull);
+      if (b == lane) keep = m;
+    }
+    u64* dst = is_label ? o.req + (size_t)(c * 64 + lane) * o.stride : o.taint + (size_t)((c - t.W) * 64 + lane) * o.stride;
+    dst[word] = keep;
+  } else {
+    u64 un = __ballot(n >= 0 && (t.flags[n >= 0 ? n : 0] & kNodeUnschedulable));
+    u64 ex = __ballot(n >= 0);
+    if (lane == 0) {
+      o.unsched[word] = un;
+      o.exists[word] = ex;
+    }
+  }
+}
+
+struct SigPlaneArgs {
+  BasePlanes base;
+  PlaneOut tol, aff;                 // outputs (canon or ranked pointer pre-selected in `.canon`)
+  const u64* sig_tol;                // [Dtol][KT]
+  const unsigned* sig_tolflags;      // [Dtol]
+  u64 taint_used[kMaxKT];            // dictionary taints that occur on some node (other base planes are all zero)
+  AffSigs affs;
+  int KT, W;
+  unsigned pre_mask, filt_mask;
+  int n_words;
+};
+constexpr int kBitSigsPerBlock = 8;  // signatures per block; thread = one 64-node word of the row
+
+__device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride, int w) {
+  u64 any = 0;
   for (int t = t0; t < t1; ++t) {
-    const u64* m = terms + (size_t)t * W;
-    bool all = true;
-#pragma unroll
-    for (int w = 0; w < kMaxW; ++w)
-      if (w < W) all = all && (lb[w] & m[w]) == m[w];
-    any = any || all;
+    u64 all = ~0ull;
+    for (int k = 0; k < W; ++k) {
+      u64 m = terms[(size_t)t * W + k];  // wave-uniform
+      while (m) {
+        int q = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        all &= req[(size_t)(k * 64 + q) * stride + w];
+      }
+    }
+    any |= all;
   }
   return any;
 }
-__device__ __forceinline__ void plane_aff(const NodeTable& t, const int* __restrict__ perm, const AffSigs& s, const PlaneOut& o,
-                                          unsigned pre_mask, unsigned filt_mask, int n_words) {
-  __shared__ u64 s_terms[kAffLdsWords];
-  __shared__ u64 s_pre[kAffLdsWords];
-  __shared__ int s_off[kAffSigsPerBlock + 1], s_poff[kAffSigsPerBlock + 1];
-  __shared__ unsigned s_flags[kAffSigsPerBlock];
-  const int d0 = blockIdx.x * kAffSigsPerBlock;
-  const int nd = min(kAffSigsPerBlock, o.D - d0);
-  if ((int)threadIdx.x <= nd) {
-    s_off[threadIdx.x] = s.term_off[d0 + threadIdx.x];
-    s_poff[threadIdx.x] = s.pre_off[d0 + threadIdx.x];
-    if ((int)threadIdx.x < nd) s_flags[threadIdx.x] = s.flags[d0 + threadIdx.x];
-  }
-  __syncthreads();
-  const int tb = s_off[0], pb = s_poff[0];
-  const int tw = (s_off[nd] - tb) * t.W, pw = (s_poff[nd] - pb) * t.W;
-  const bool t_lds = tw <= kAffLdsWords, p_lds = pw <= kAffLdsWords;
-  if (t_lds)
-    for (int i = threadIdx.x; i < tw; i += kBlock) s_terms[i] = s.terms[(size_t)tb * t.W + i];
-  if (p_lds)
-    for (int i = threadIdx.x; i < pw; i += kBlock) s_pre[i] = s.pre_terms[(size_t)pb * t.W + i];
-  __syncthreads();
-
-  int word;
-  int n = plane_node(t.n, perm, &word);
-  if (word >= n_words) return;
-  u64 lb[kMaxW];
-#pragma unroll
-  for (int w = 0; w < kMaxW; ++w) lb[w] = 0;
-  if (n >= 0) {
-#pragma unroll
-    for (int w = 0; w < kMaxW; ++w)
-      if (w < t.W) lb[w] = t.labels[(size_t)w * t.n + n];
-  }
-  const bool pre_en = pre_mask & kPlugAffinity, filt_en = filt_mask & kPlugAffinity;
-  u64 keep = 0;
-  for (int i = 0; i < nd; ++i) {
-    const unsigned f = s_flags[i];
-    const bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
-    bool ok = n >= 0;
-    if (pre_en && !skip) {
-      if (f & kSpecPreReject) ok = false;  // PreFilter rejected the pod (:236-238)
-      if (f & kSpecPreNames) {             // "node not eligible" (:248-250)
-        bool m = p_lds ? dnf_match_any(s_pre, s_poff[i] - pb, s_poff[i + 1] - pb, lb, t.W)
-                       : dnf_match_any(s.pre_terms, s_poff[i], s_poff[i + 1], lb, t.W);
-        ok = ok && m;
+// blockIdx.x: chunk of kBitSigsPerBlock signatures, blockIdx.y: block of 256 row words, blockIdx.z: 0 = tol family, 1 = aff family
+__global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
+  const int w = blockIdx.y * kBlock + threadIdx.x;
+  if (w >= a.n_words) return;
+  const u64 exists = a.base.exists[w];
+  const int d0 = blockIdx.x * kBitSigsPerBlock;
+  if (blockIdx.z == 0) {
+    const bool taint_en = a.filt_mask & kPlugTaint, unsched_en = a.filt_mask & kPlugUnsched;
+    const u64 unsched = unsched_en ? a.base.unsched[w] : 0ull;
+    for (int d = d0; d < min(d0 + kBitSigsPerBlock, a.tol.D); ++d) {
+      u64 bad = 0;  // nodes carrying a taint this signature does not tolerate
+      if (taint_en)
+        for (int k = 0; k < a.KT; ++k) {
+          u64 m = ~a.sig_tol[(size_t)d * a.KT + k] & a.taint_used[k];
+          while (m) {
+            int tt = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            bad |= a.base.taint[(size_t)(k * 64 + tt) * a.base.stride + w];
+          }
+        }
+      if (!(a.sig_tolflags[d] & kSpecToleratesUnsched)) bad |= unsched;
+      a.tol.canon[(size_t)d * a.tol.stride + w] = exists & ~bad;
+    }
+  } else {
+    const bool pre_en = a.pre_mask & kPlugAffinity, filt_en = a.filt_mask & kPlugAffinity;
+    for (int d = d0; d < min(d0 + kBitSigsPerBlock, a.aff.D); ++d) {
+      const unsigned f = a.affs.flags[d];
+      const bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
+      u64 ok = exists;
+      if (pre_en && !skip) {
+        if (f & kSpecPreReject) ok = 0;  // PreFilter rejected the pod (:236-238)
+        if (f & kSpecPreNames)            // "node not eligible" (:248-250)
+          ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w);
       }
+      if (filt_en && !skip) ok &= dnf_words(a.affs.terms, a.affs.term_off[d], a.affs.term_off[d + 1], a.W, a.base.req, a.base.stride, w);
+      a.aff.canon[(size_t)d * a.aff.stride + w] = ok;
     }
-    if (filt_en && !skip) {
-      bool m = t_lds ? dnf_match_any(s_terms, s_off[i] - tb, s_off[i + 1] - tb, lb, t.W)
-                     : dnf_match_any(s.terms, s_off[i], s_off[i + 1], lb, t.W);
-      ok = ok && m;
-    }
-    u64 b = __ballot(ok);
-    if (i == (int)(threadIdx.x % kWave)) keep = b;
   }
-  plane_store(o, perm != nullptr, word, d0, nd, keep);
 }
 
 // Rank-ordered planes by bit permutation: ranked[d] bit i = canonical[d] bit perm[i]. One launch covers every family
@@ -491,33 +490,20 @@ __device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __re
   plane_store(o, perm != nullptr, word, d0, dend - d0, keep);
 }
 
-// One launch for all plugin families: blockIdx.z selects the family, so their (latency-bound, cache-cold) signature
-// walks overlap instead of queueing behind each other. A family that is disabled for this eval has D = 0.
+// Ballot-based families (NodeResourcesFit request vectors, PodTopologySpread) in one launch: blockIdx.z selects the
+// family so their (latency-bound, cache-cold) signature walks overlap. A disabled family has D = 0.
 struct PlaneArgs {
   const int* perm;
-  PlaneOut res, tol, aff, spread;
+  PlaneOut res, spread;
   const i64* sig_req;
-  const u64* sig_tol;
-  const unsigned* sig_tolflags;
-  AffSigs affs;
   SpreadSigs spreads;
-  unsigned pre_mask, filt_mask;
   int fit_error, n_words;
 };
 __global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
-  switch (blockIdx.z) {
-    case 0:
-      if ((int)blockIdx.x * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
-      break;
-    case 1:
-      if ((int)blockIdx.x * kSigsPerBlock < a.tol.D) plane_tol(t, a.perm, a.sig_tol, a.sig_tolflags, a.tol, a.filt_mask, a.n_words);
-      break;
-    case 2:
-      if ((int)blockIdx.x * kAffSigsPerBlock < a.aff.D) plane_aff(t, a.perm, a.affs, a.aff, a.pre_mask, a.filt_mask, a.n_words);
-      break;
-    default:
-      if ((int)blockIdx.x * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words);
-      break;
+  if (blockIdx.z == 0) {
+    if ((int)blockIdx.x * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
+  } else {
+    if ((int)blockIdx.x * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words);
   }
 }
 
