@@ -53,7 +53,7 @@ extern "C" {
 #define YKPRED_PLUGIN_NODE_NAME (1u << 1)
 #define YKPRED_PLUGIN_TAINT_TOLERATION (1u << 2)
 #define YKPRED_PLUGIN_NODE_AFFINITY (1u << 3)
-#define YKPRED_PLUGIN_NODE_PORTS (1u << 4) /* reserved: not evaluated by the engine */
+#define YKPRED_PLUGIN_NODE_PORTS (1u << 4)
 #define YKPRED_PLUGIN_NODE_RESOURCES_FIT (1u << 5)
 #define YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD (1u << 6)
 #define YKPRED_PLUGIN_ALL 0x7fu
@@ -98,7 +98,8 @@ typedef struct ykpred_config {
   int32_t label_words;      /* W  >= 1: 64-bit words of the node-selector requirement dictionary */
   int32_t topology_keys;    /* KD >= 0: topology keys used by hard spread constraints */
   int32_t selector_classes; /* KS >= 0: distinct (namespace, labelSelector) classes of spread constraints */
-  int32_t reserved[9];
+  int32_t port_words;       /* KP >= 0: 64-bit words of the host-port dictionary (NodePorts) */
+  int32_t reserved[8];      /* [0..2]: engine tunables for experiments, 0 = defaults */
 } ykpred_config_t;
 
 /* Node table, structure-of-arrays. Arrays documented [A][count] are A consecutive runs of `count` values. */
@@ -114,6 +115,8 @@ typedef struct ykpred_nodes {
   const int32_t* domain_id;      /* [KD][count]  id of the node's value for topology key k, -1 = label missing */
   const int32_t* selector_count; /* [KS][count]  # pods on the node matching selector class s */
   const int32_t* domain_sizes;   /* [KD]         number of distinct values (domain ids 0..size-1) of topology key k */
+  const uint64_t* port_bits;     /* [KP][count]  bit k: some pod on the node uses a host port that conflicts with dictionary
+                                                 port k (HostPortInfo.CheckConflict: same protocol+port, equal or wildcard IP) */
 } ykpred_nodes_t;
 
 /* One hard (DoNotSchedule) topology spread constraint of a pod spec. */
@@ -141,6 +144,7 @@ typedef struct ykpred_specs {
   const uint64_t* pre_terms;     /* [m][W] */
   const int32_t* spread_off;     /* [count+1]   may be NULL when no spec has hard spread constraints */
   const ykpred_spread_t* spread; /* [k] */
+  const uint64_t* wanted_ports;  /* [count][KP] bit k: the pod requests dictionary host port k (NodePorts); may be NULL if KP == 0 */
 } ykpred_specs_t;
 
 typedef struct ykpred_pods {
@@ -241,6 +245,10 @@ int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod_index, int32_t node_in
                           const int64_t* victim_requests /* [num_victims][R]; a nil victim is an all-zero row with present=0 */,
                           const uint8_t* victim_present /* [num_victims] */, int32_t start_index,
                           uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t* out_index);
+/* Same, for nodes whose victims hold host ports: port_bits_after[i][KP] = the node's port_bits once victims 0..i are gone. */
+int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod_index, int32_t node_index, int32_t num_victims,
+                                const int64_t* victim_requests, const uint8_t* victim_present, const uint64_t* port_bits_after,
+                                int32_t start_index, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t* out_index);
 
 #ifdef __cplusplus
 }

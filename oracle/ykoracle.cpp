@@ -31,6 +31,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -47,7 +48,7 @@ enum PluginBit : uint32_t {
   kNodeName = 1u << 1,
   kTaintToleration = 1u << 2,
   kNodeAffinity = 1u << 3,
-  kNodePorts = 1u << 4,  // not modelled: pods carrying host ports are rejected at load time
+  kNodePorts = 1u << 4,
   kNodeResourcesFit = 1u << 5,
   kPodTopologySpread = 1u << 6,
 };
@@ -95,10 +96,16 @@ struct SpreadConstraint {
   std::string node_affinity_policy = "Honor", node_taints_policy = "Ignore";
   std::vector<std::string> match_label_keys;
 };
+struct HostPort {  // v1.ContainerPort with HostPort > 0, sanitized like HostPortInfo.sanitize ("" ip → 0.0.0.0, "" protocol → TCP)
+  std::string protocol, ip;
+  int64_t port = 0;
+  bool operator<(const HostPort& o) const { return std::tie(ip, protocol, port) < std::tie(o.ip, o.protocol, o.port); }
+};
 struct Container {
   std::string name;
   StrMap requests;
   bool sidecar = false;  // initContainer with restartPolicy: Always (resource.go:184-186)
+  std::vector<HostPort> host_ports;
 };
 struct Pod {
   std::string name, uid, ns;
@@ -211,12 +218,33 @@ static Resource to_resource(const ResMap& m) {
   return r;
 }
 
+// schedutil.GetHostPorts: host ports of the containers and of the init containers that keep running (restartPolicy
+// Always). k8s.io/kubernetes v1.36.1, not vendored; the reference pins only regular containers
+// (predicate_manager_test.go:199-222).
+static std::vector<HostPort> get_host_ports(const Pod& p) {
+  std::vector<HostPort> out;
+  for (auto& c : p.init_containers)
+    if (c.sidecar) out.insert(out.end(), c.host_ports.begin(), c.host_ports.end());
+  for (auto& c : p.containers) out.insert(out.end(), c.host_ports.begin(), c.host_ports.end());
+  return out;
+}
+// framework.HostPortInfo.CheckConflict
+static bool ports_conflict(const HostPort& want, const std::set<HostPort>& used) {
+  if (want.port <= 0) return false;
+  for (auto& u : used) {
+    if (u.protocol != want.protocol || u.port != want.port) continue;
+    if (want.ip == "0.0.0.0" || u.ip == "0.0.0.0" || u.ip == want.ip) return true;
+  }
+  return false;
+}
+
 // framework.NodeInfo: SetNode / AddPod / RemovePod as driven by scheduler_cache.go:166,179,324,363 and
 // predicate_manager.go:158,185.
 struct NodeInfo {
   Node node;
   std::vector<const Pod*> pods;
   Resource requested, allocatable;
+  std::set<HostPort> used_ports;  // NodeInfo.UsedPorts (set semantics: Add / Remove per pod)
 
   void set_node(const Node& n) {
     node = n;
@@ -224,6 +252,7 @@ struct NodeInfo {
   }
   void add_pod(const Pod* p) {
     pods.push_back(p);
+    for (auto& hp : get_host_ports(*p)) used_ports.insert(hp);
     Resource r = to_resource(pod_requests(*p));
     requested.milli_cpu += r.milli_cpu;
     requested.memory += r.memory;
@@ -233,6 +262,7 @@ struct NodeInfo {
   bool remove_pod(const Pod* p) {  // by UID, like upstream; false if absent (removePodFromNodeNoFail ignores)
     for (size_t i = 0; i < pods.size(); ++i) {
       if (pods[i]->uid == p->uid) {
+        for (auto& hp : get_host_ports(*pods[i])) used_ports.erase(hp);
         Resource r = to_resource(pod_requests(*pods[i]));
         requested.milli_cpu -= r.milli_cpu;
         requested.memory -= r.memory;
@@ -467,8 +497,18 @@ static std::vector<Container> read_containers(const mj::Value* v, bool init, std
       if (const mj::Value* res = e->get_nn("resources")) c.requests = read_strmap(res->get_nn("requests"));
       if (init) c.sidecar = e->str_or("restartPolicy", "") == "Always";
       if (const mj::Value* ports = e->get_nn("ports"))
-        for (auto& pt : ports->arr)
-          if (pt->int_or("hostPort", 0) != 0) *err = "hostPort not modelled (NodePorts is outside this path)";
+        for (auto& pt : ports->arr) {
+          int64_t hp = pt->int_or("hostPort", 0);
+          if (hp <= 0) continue;  // "Only return ports with a host port specified"
+          HostPort h;
+          h.protocol = pt->str_or("protocol", "");
+          h.ip = pt->str_or("hostIP", "");
+          if (h.protocol.empty()) h.protocol = "TCP";
+          if (h.ip.empty()) h.ip = "0.0.0.0";
+          h.port = hp;
+          c.host_ports.push_back(h);
+        }
+      (void)err;
       out.push_back(std::move(c));
     }
   return out;
@@ -619,6 +659,8 @@ struct SpreadState {  // podtopologyspread preFilterState
 };
 struct CycleState {
   bool affinity_written = false;
+  bool ports_written = false;
+  std::vector<HostPort> want_ports;
   FitState fit;
   SpreadState spread;
 };
@@ -680,6 +722,22 @@ static Status nodeaffinity_prefilter(const Pod& p, CycleState& st, PreFilterResu
 static Status nodeaffinity_filter(const Pod& p, const NodeInfo& ni) {
   if (!required_node_affinity_matches(p, ni.node))
     return {Status::UnschedulableAndUnresolvable, "node(s) didn't match Pod's node affinity/selector"};
+  return {};
+}
+
+// --- NodePorts (pins: predicate_manager_test.go:224-335, 1147-1157) -----------------------------------
+static Status nodeports_prefilter(const Pod& p, CycleState& st) {
+  std::vector<HostPort> want = get_host_ports(p);
+  if (want.empty()) return {Status::Skip, ""};
+  st.ports_written = true;
+  st.want_ports = want;
+  return {};
+}
+static Status nodeports_filter(const Pod& p, const CycleState& st, const NodeInfo& ni) {
+  // Filter reads the PreFilter state; without it (PreFilter plugin disabled) the plugin returns an Error status
+  if (!st.ports_written) return {Status::Error, "reading \"PreFilterNodePorts\" from cycleState: not found"};
+  for (auto& w : st.want_ports)
+    if (ports_conflict(w, ni.used_ports)) return {Status::Unschedulable, "node(s) didn't have free ports for the requested pod ports"};
   return {};
 }
 
@@ -819,13 +877,18 @@ static bool run_prefilters(const Snapshot& snap, const Pod& p, const NodeInfo& t
     int code;
   };
   // PreFilter-implementing plugins of this path, in MultiPoint order (comment block :307-318).
-  static const Pre order[] = {{kNodeAffinity, kCodeNodeAffinity}, {kNodeResourcesFit, kCodeNodeResourcesFit}, {kPodTopologySpread, kCodePodTopologySpread}};
+  static const Pre order[] = {{kNodeAffinity, kCodeNodeAffinity},
+                              {kNodePorts, kCodeNodePorts},
+                              {kNodeResourcesFit, kCodeNodeResourcesFit},
+                              {kPodTopologySpread, kCodePodTopologySpread}};
   for (const Pre& pl : order) {
     if (!(pre_mask & pl.bit)) continue;
     PreFilterResult res;
     Status s;
     if (pl.bit == kNodeAffinity)
       s = nodeaffinity_prefilter(p, st, &res);
+    else if (pl.bit == kNodePorts)
+      s = nodeports_prefilter(p, st);
     else if (pl.bit == kNodeResourcesFit)
       s = fit_prefilter(p, st);
     else
@@ -857,7 +920,8 @@ static void run_filters(const Pod& p, const NodeInfo& ni, uint32_t filt_mask, ui
   };
   static const Filt order[] = {{kNodeUnschedulable, kCodeNodeUnschedulable}, {kNodeName, kCodeNodeName},
                                {kTaintToleration, kCodeTaintToleration},     {kNodeAffinity, kCodeNodeAffinity},
-                               {kNodeResourcesFit, kCodeNodeResourcesFit},   {kPodTopologySpread, kCodePodTopologySpread}};
+                               {kNodePorts, kCodeNodePorts},                 {kNodeResourcesFit, kCodeNodeResourcesFit},
+                               {kPodTopologySpread, kCodePodTopologySpread}};
   for (const Filt& pl : order) {
     if (!(filt_mask & pl.bit)) continue;
     if (skip & pl.bit) continue;  // :264-266
@@ -867,6 +931,7 @@ static void run_filters(const Pod& p, const NodeInfo& ni, uint32_t filt_mask, ui
       case kNodeName: s = nodename_filter(p, ni); break;
       case kTaintToleration: s = tainttoleration_filter(p, ni); break;
       case kNodeAffinity: s = nodeaffinity_filter(p, ni); break;
+      case kNodePorts: s = nodeports_filter(p, st, ni); break;
       case kNodeResourcesFit: s = fit_filter(st, ni); break;
       case kPodTopologySpread: s = spread_filter(p, st, ni); break;
       default: break;

@@ -9,6 +9,16 @@ CPU = ["0", "1m", "100m", "250m", "500m", "1", "2", "3500m", "8"]
 MEM = ["0", "1", "1M", "128Mi", "1Gi", "4Gi", "1e9", "1500M"]
 
 
+def rand_port(rng):
+    """A container port; hostPort 0 = no host port (ignored by NodePorts)."""
+    p = {"hostPort": rng.choice([0, 80, 80, 443, 8080, 9090]), "containerPort": 8000}
+    if rng.random() < 0.6:
+        p["protocol"] = rng.choice(["TCP", "UDP", "SCTP"])
+    if rng.random() < 0.5:
+        p["hostIP"] = rng.choice(["0.0.0.0", "127.0.0.1", "10.0.0.1", ""])
+    return p
+
+
 def rand_node(rng, i, scalars=True):
     name = f"node-{i}" if not (i == 0 and rng.random() < 0.3) else ""
     labels = {}
@@ -47,7 +57,10 @@ def rand_node(rng, i, scalars=True):
                 "labels": {"app": rng.choice(TEAMS)}}
         if rng.random() < 0.05:
             meta["deletionTimestamp"] = "2026-01-01T00:00:00Z"  # terminating pods are not counted by PodTopologySpread
-        entry = {"metadata": meta, "spec": {"containers": [{"name": "c", "resources": {"requests": req}}]}}
+        cont = {"name": "c", "resources": {"requests": req}}
+        if rng.random() < 0.15:
+            cont["ports"] = [rand_port(rng) for _ in range(rng.choice([1, 1, 2]))]
+        entry = {"metadata": meta, "spec": {"containers": [cont]}}
         if rng.random() < 0.2:
             entry["replicas"] = rng.choice([2, 3])
         pods.append(entry)
@@ -126,6 +139,8 @@ def rand_pod(rng, i, n_nodes, scalars=True, spread=False):
     if scalars and rng.random() < 0.1:
         req["hugepages-2Mi"] = "512Mi"
     containers = [{"name": "main", "resources": {"requests": req}}]
+    if rng.random() < 0.25:
+        containers[0]["ports"] = [rand_port(rng) for _ in range(rng.choice([1, 2, 3]))]
     if rng.random() < 0.3:
         containers.append({"name": "side", "resources": {"requests": {"cpu": rng.choice(CPU)}}})
     spec["containers"] = containers
@@ -135,6 +150,8 @@ def rand_pod(rng, i, n_nodes, scalars=True, spread=False):
             ic = {"name": f"ic{k}", "resources": {"requests": {"cpu": rng.choice(CPU), "memory": rng.choice(MEM)}}}
             if rng.random() < 0.4:
                 ic["restartPolicy"] = "Always"
+            if rng.random() < 0.2:
+                ic["ports"] = [rand_port(rng)]
             ics.append(ic)
         spec["initContainers"] = ics
     if rng.random() < 0.15:

@@ -133,8 +133,42 @@ SELECTOR = [
 ]
 
 
+def port_pod(host, *infos, **meta):
+    """newPod(host, "PROTO/IP/PORT", ...) of predicate_manager_test.go:199-222."""
+    ports = []
+    for info in infos:
+        proto, ip, port = info.split("/")
+        ports.append({"hostIP": ip, "hostPort": int(port), "protocol": proto})
+    return pod({"nodeName": host, "containers": [{"ports": ports}]}, **meta)
+
+
+# TestPodFitsHostPorts — :224-335, plugin NodePorts (:225); NodeInfo without a Node object, only its pods (:237-321)
+HOST_PORTS = [
+    (235, "nothing running", pod(), [], True),
+    (241, "other port", port_pod("m1", "UDP/127.0.0.1/8080"), ["UDP/127.0.0.1/9090"], True),
+    (248, "same udp port", port_pod("m1", "UDP/127.0.0.1/8080"), ["UDP/127.0.0.1/8080"], False),
+    (255, "same tcp port", port_pod("m1", "TCP/127.0.0.1/8080"), ["TCP/127.0.0.1/8080"], False),
+    (262, "different host ip", port_pod("m1", "TCP/127.0.0.1/8080"), ["TCP/127.0.0.2/8080"], True),
+    (269, "different protocol", port_pod("m1", "UDP/127.0.0.1/8080"), ["TCP/127.0.0.1/8080"], True),
+    (276, "second udp port conflict", port_pod("m1", "UDP/127.0.0.1/8000", "UDP/127.0.0.1/8080"), ["UDP/127.0.0.1/8080"], False),
+    (283, "first tcp port conflict", port_pod("m1", "TCP/127.0.0.1/8001", "UDP/127.0.0.1/8080"),
+     ["TCP/127.0.0.1/8001", "UDP/127.0.0.1/8081"], False),
+    (290, "first tcp port conflict due to 0.0.0.0 hostIP", port_pod("m1", "TCP/0.0.0.0/8001"), ["TCP/127.0.0.1/8001"], False),
+    (297, "TCP hostPort conflict due to 0.0.0.0 hostIP", port_pod("m1", "TCP/10.0.10.10/8001", "TCP/0.0.0.0/8001"),
+     ["TCP/127.0.0.1/8001"], False),
+    (304, "second tcp port conflict to 0.0.0.0 hostIP", port_pod("m1", "TCP/127.0.0.1/8001"), ["TCP/0.0.0.0/8001"], False),
+    (311, "second different protocol", port_pod("m1", "UDP/127.0.0.1/8001"), ["TCP/0.0.0.0/8001"], True),
+    (318, "UDP hostPort conflict due to 0.0.0.0 hostIP", port_pod("m1", "UDP/127.0.0.1/8001"),
+     ["TCP/0.0.0.0/8001", "UDP/0.0.0.0/8001"], False),
+]
+
+
 def predicate_cases():
     cases = []
+    for line, name, p, existing, fits in HOST_PORTS:
+        on_node = [port_pod("m1", *existing, uid="existing")] if existing else []
+        cases.append({"test": "TestPodFitsHostPorts", "name": name, "source": f"{PM}:{line}", "plugins": ["NodePorts"],
+                      "allocate": True, "pod": p, "node": node("", pods=on_node), "fits": fits})
     for line, name, p, labels, node_name, fits in SELECTOR:
         cases.append({"test": "TestPodFitsSelector", "name": name, "source": f"{PM}:{line}",
                       "plugins": ["NodePorts", "NodeAffinity"], "allocate": True,
@@ -150,12 +184,13 @@ def predicate_cases():
                       "allocate": True, "pod": p, "node": n, "fits": fits})
 
     # TestRunGeneralPredicates — :1095-1168, plugins NodeResourcesFit, NodeName, NodePorts, NodeVolumeLimits (:1096).
-    # The fourth case (:1147-1157, host-port conflict) exercises NodePorts, which is outside this path.
     alloc = make_resources(10, 20, 32)
     for line, name, p, existing, fits in [
         (1108, "no resources/port/host requested always fits", pod(), [resource_pod(9, 19)], True),
         (1120, "not enough cpu and memory resource", resource_pod(8, 10), [resource_pod(5, 19)], False),
         (1132, "host not match", pod({"nodeName": "machine2"}), [], False),
+        (1147, "host port conflict", pod({"containers": [{"ports": [{"hostPort": 123}]}]}),
+         [pod({"containers": [{"ports": [{"hostPort": 123}]}]}, uid="port-holder")], False),
     ]:
         cases.append({"test": "TestRunGeneralPredicates", "name": name, "source": f"{PM}:{line}",
                       "plugins": ["NodeResourcesFit", "NodeName", "NodePorts"], "allocate": True,

@@ -338,10 +338,27 @@ def test_incremental_at_full_size(pm):
 
 
 def test_unsupported_pods_are_rejected_loudly(pm):
-    pod = {"metadata": {"name": "p", "uid": "p"}, "spec": {"containers": [{"ports": [{"hostPort": 80}]}]}}
+    pod = {"metadata": {"name": "p", "uid": "p"},
+           "spec": {"affinity": {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": []}}, "containers": []}}
     pm.load_snapshot({"nodes": [{"metadata": {"name": "n"}}], "pods": [pod]})
-    with pytest.raises(RuntimeError, match="NodePorts"):
+    with pytest.raises(RuntimeError, match="InterPodAffinity"):
         pm.evaluate()
+
+
+def test_node_ports_preemption(pm):
+    """PreemptionPredicates with NodePorts: removing the victim that holds the port frees it (NodeInfo.UsedPorts)."""
+    def holder(uid, port):
+        return {"metadata": {"name": uid, "uid": uid}, "spec": {"containers": [{"ports": [{"hostPort": port, "protocol": "TCP"}]}]}}
+    node = {"metadata": {"name": "n0"}, "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "10"}},
+            "pods": [holder("v0", 81), holder("v1", 80), holder("v2", 82)]}
+    ask = {"metadata": {"name": "ask", "uid": "ask"}, "spec": {"containers": [{"ports": [{"hostPort": 80, "hostIP": "10.0.0.1"}]}]}}
+    snap = {"nodes": [node], "pods": [ask]}
+    pm.load_snapshot(snap)
+    o = orc.Oracle(snap)
+    for victims, start in ((["v0", "v1", "v2"], 0), (["v0", "v2"], 0), (["v1"], 0), (["v0", None, "v1"], 1), ([], 0)):
+        idx = [-1 if v is None else ["v0", "v1", "v2"].index(v) for v in victims]
+        assert pm.preemption_predicates("ask", "n0", victims, start) == o.preemption(0, 0, idx, start), (victims, start)
+    assert pm.preemption_predicates("ask", "n0", ["v0", "v1", "v2"], 0) == 1
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -10,19 +10,20 @@ c_i32p = C.POINTER(C.c_int32)
 class YkpredConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("num_resources", C.c_int32), ("taint_words", C.c_int32),
                 ("label_words", C.c_int32), ("topology_keys", C.c_int32), ("selector_classes", C.c_int32),
-                ("reserved", C.c_int32 * 9)]
+                ("port_words", C.c_int32), ("reserved", C.c_int32 * 8)]
 
 
 class YkpredNodes(C.Structure):
     _fields_ = [("count", C.c_int32), ("allocatable", C.c_void_p), ("requested", C.c_void_p), ("allowed_pods", C.c_void_p),
                 ("pod_count", C.c_void_p), ("flags", C.c_void_p), ("taint_bits", C.c_void_p), ("label_bits", C.c_void_p),
-                ("domain_id", C.c_void_p), ("selector_count", C.c_void_p), ("domain_sizes", C.c_void_p)]
+                ("domain_id", C.c_void_p), ("selector_count", C.c_void_p), ("domain_sizes", C.c_void_p),
+                ("port_bits", C.c_void_p)]
 
 
 class YkpredSpecs(C.Structure):
     _fields_ = [("count", C.c_int32), ("requests", C.c_void_p), ("tolerated", C.c_void_p), ("flags", C.c_void_p),
                 ("aff_term_off", C.c_void_p), ("aff_terms", C.c_void_p), ("pre_term_off", C.c_void_p), ("pre_terms", C.c_void_p),
-                ("spread_off", C.c_void_p), ("spread", C.c_void_p)]
+                ("spread_off", C.c_void_p), ("spread", C.c_void_p), ("wanted_ports", C.c_void_p)]
 
 
 class YkpredPods(C.Structure):
@@ -92,6 +93,8 @@ def load_ykpred():
                                C.c_void_p]
     L.ykpred_preemption.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32,
                                     C.c_uint32, C.POINTER(C.c_int32)]
+    L.ykpred_preemption_ports.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]
     _pred = L
     return L
 

@@ -63,8 +63,8 @@ struct ykpred_engine {
   // --- node table
   int N = 0;
   int row_words = 0, row_stride = 0;
-  DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels, d_domain, d_selcount;
-  int KD = 0, KS = 0;
+  DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels, d_domain, d_selcount, d_ports;
+  int KD = 0, KS = 0, KP = 0;
   std::vector<int32_t> h_domain_sizes;
   DevBuf d_score, d_key, d_rank, d_perm, d_rankbuf, d_member_key;
   bool nodes_set = false;
@@ -72,7 +72,7 @@ struct ykpred_engine {
   // --- specs (host copies kept for class building)
   int S = 0;
   std::vector<i64> h_req;
-  std::vector<u64> h_tol;
+  std::vector<u64> h_tol, h_wanted;
   std::vector<uint32_t> h_sflags;
   std::vector<int32_t> h_aff_off, h_pre_off;
   std::vector<u64> h_aff_terms, h_pre_terms;
@@ -93,7 +93,7 @@ struct ykpred_engine {
   int64_t spread_cells = 0;
   bool spread_dirty = true;
   DevBuf d_sig_req;                                                            // [Dres][R]
-  DevBuf d_sig_tol, d_sig_tolflags;                                            // [Dtol][KT], [Dtol]
+  DevBuf d_sig_tol, d_sig_tolflags, d_sig_ports, d_swanted;                    // [Dtol][KT], [Dtol], [Dtol][KP]; [S][KP]
   DevBuf d_sig_aff_flags, d_sig_aff_off, d_sig_aff_terms, d_sig_pre_off, d_sig_pre_terms;
   bool specs_set = false;
 
@@ -172,6 +172,8 @@ ykk::NodeTable node_table(const ykpred_engine* e) {
   t.KS = e->KS;
   t.domain = e->d_domain.as<int>();
   t.selcount = e->d_selcount.as<int>();
+  t.KP = e->KP;
+  t.ports = e->d_ports.as<u64>();
   return t;
 }
 ykk::SpreadSigs spread_sigs(const ykpred_engine* e) {
@@ -199,6 +201,8 @@ ykk::SpecTable spec_table(const ykpred_engine* e) {
   s.aff.terms = e->d_aff_terms.as<u64>();
   s.aff.pre_off = e->d_pre_off.as<int>();
   s.aff.pre_terms = e->d_pre_terms.as<u64>();
+  s.KP = e->KP;
+  s.wanted_ports = e->d_swanted.as<u64>();
   s.spread_sig = e->d_spec_spread.as<int>();
   s.spread = spread_sigs(e);
   return s;
@@ -308,7 +312,7 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
     }
   }
   e->plane_rows_alloc = rows;
-  size_t base_need = (size_t)(64 * (e->W + e->KT) + 2) * (size_t)e->row_stride * sizeof(u64);
+  size_t base_need = (size_t)(64 * (e->W + e->KT + e->KP) + 2) * (size_t)e->row_stride * sizeof(u64);
   for (DevBuf* b : {&e->base_canon, &e->base_ranked}) {
     if (b->cap < base_need) {
       HIPCHK(b->ensure(base_need));
@@ -431,8 +435,9 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
     g_create_error = "config out of range: need 3<=R<=8, 1<=KT<=4, 1<=W<=8";
     return YKPRED_E_UNSUPPORTED;
   }
-  if (cfg->topology_keys < 0 || cfg->topology_keys > ykk::kMaxKD || cfg->selector_classes < 0 || cfg->selector_classes > 4096) {
-    g_create_error = "config out of range: need 0<=KD<=4 topology keys, 0<=KS<=4096 selector classes";
+  if (cfg->topology_keys < 0 || cfg->topology_keys > ykk::kMaxKD || cfg->selector_classes < 0 || cfg->selector_classes > 4096 ||
+      cfg->port_words < 0 || cfg->port_words > ykk::kMaxKP) {
+    g_create_error = "config out of range: need 0<=KD<=4 topology keys, 0<=KS<=4096 selector classes, 0<=KP<=4 port words";
     return YKPRED_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -457,6 +462,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->W = cfg->label_words;
   e->KD = cfg->topology_keys;
   e->KS = cfg->selector_classes;
+  e->KP = cfg->port_words;
   if (cfg->reserved[0] >= 1 && cfg->reserved[0] <= ykk::kChunkMembers) e->chunk_members = cfg->reserved[0];
   e->chunk_sorted = cfg->reserved[1] != 1;
   if (cfg->reserved[2] > 0 && cfg->reserved[2] <= 160 * 1024) e->combine_lds_bytes = cfg->reserved[2];
@@ -486,7 +492,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
-  for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount,
+  for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount, &e->d_ports, &e->d_sig_ports, &e->d_swanted,
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
                     &e->planes_canon, &e->planes_ranked, &e->base_canon, &e->base_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
@@ -513,6 +519,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
     return fail(e, YKPRED_E_INVALID, "set_nodes: null column");
   if ((e->KD > 0 && (!n->domain_sizes || (n->count > 0 && !n->domain_id))) || (e->KS > 0 && n->count > 0 && !n->selector_count))
     return fail(e, YKPRED_E_INVALID, "set_nodes: topology / selector columns missing (config has KD/KS > 0)");
+  if (e->KP > 0 && n->count > 0 && !n->port_bits) return fail(e, YKPRED_E_INVALID, "set_nodes: port_bits missing (config has KP > 0)");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   const size_t N = (size_t)n->count;
@@ -525,6 +532,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   TRY(upload(e, e->d_labels, n->label_bits, N * (size_t)e->W, st));
   TRY(upload(e, e->d_domain, n->domain_id, N * (size_t)e->KD, st));
   TRY(upload(e, e->d_selcount, n->selector_count, N * (size_t)e->KS, st));
+  TRY(upload(e, e->d_ports, n->port_bits, N * (size_t)e->KP, st));
   for (int k = 0; k < ykk::kMaxKT; ++k) e->taint_used[k] = 0;
   for (int k = 0; k < e->KT; ++k)
     for (size_t i = 0; i < N; ++i) e->taint_used[k] |= n->taint_bits[(size_t)k * N + i];
@@ -576,6 +584,8 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
   }
   for (int k = 0; k < e->KS; ++k)
     HIPCHK(hipMemcpyAsync(e->d_selcount.as<int>() + (size_t)k * N + idx, n->selector_count + k, sizeof(int), hipMemcpyHostToDevice, st));
+  for (int k = 0; k < e->KP; ++k)
+    HIPCHK(hipMemcpyAsync(e->d_ports.as<u64>() + (size_t)k * N + idx, n->port_bits + k, sizeof(u64), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   return YKPRED_OK;
 }
@@ -588,12 +598,15 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     return fail(e, YKPRED_E_INVALID, "set_specs: spread_off without spread rows");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
-  const int S = s->count, R = e->R, KT = e->KT, W = e->W;
+  const int S = s->count, R = e->R, KT = e->KT, W = e->W, KP = e->KP;
+  if (KP > 0 && S > 0 && !s->wanted_ports) return fail(e, YKPRED_E_INVALID, "set_specs: wanted_ports missing (config has KP > 0)");
   const int T = S ? s->aff_term_off[S] : 0, M = S ? s->pre_term_off[S] : 0;
   if (T < 0 || M < 0 || (T > 0 && !s->aff_terms) || (M > 0 && !s->pre_terms)) return fail(e, YKPRED_E_INVALID, "set_specs: bad term tables");
   e->S = S;
   e->h_req.assign(s->requests, s->requests + (size_t)S * R);
   e->h_tol.assign(s->tolerated, s->tolerated + (size_t)S * KT);
+  if (KP > 0) e->h_wanted.assign(s->wanted_ports, s->wanted_ports + (size_t)S * KP); else e->h_wanted.clear();
+  TRY(upload(e, e->d_swanted, e->h_wanted.data(), e->h_wanted.size(), st));
   e->h_sflags.assign(s->flags, s->flags + S);
   e->h_aff_off.assign(s->aff_term_off, s->aff_term_off + S + (S ? 1 : 0));
   e->h_pre_off.assign(s->pre_term_off, s->pre_term_off + S + (S ? 1 : 0));
@@ -617,7 +630,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   e->spec_sig_aff.assign((size_t)S, 0);
   std::unordered_map<std::string, int32_t> m_res, m_tol, m_aff;
   std::vector<i64> sig_req;
-  std::vector<u64> sig_tol, sig_aff_terms, sig_pre_terms;
+  std::vector<u64> sig_tol, sig_ports, sig_aff_terms, sig_pre_terms;
   std::vector<uint32_t> sig_tolflags, sig_aff_flags;
   std::vector<int32_t> sig_aff_off{0}, sig_pre_off{0};
   const uint32_t aff_flag_mask = YKPRED_SPEC_AFFINITY_SKIP | YKPRED_SPEC_PREFILTER_REJECT | YKPRED_SPEC_PREFILTER_NAMES;
@@ -633,11 +646,13 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     uint32_t tf = s->flags[i] & YKPRED_SPEC_TOLERATES_UNSCHEDULABLE;
     std::string kt((const char*)(s->tolerated + (size_t)i * KT), (size_t)KT * sizeof(u64));
     kt.append((const char*)&tf, sizeof(tf));
+    if (KP > 0) kt.append((const char*)(s->wanted_ports + (size_t)i * KP), (size_t)KP * sizeof(u64));  // NodePorts rides in this family
     auto jt = m_tol.find(kt);
     if (jt == m_tol.end()) {
       jt = m_tol.emplace(std::move(kt), (int32_t)m_tol.size()).first;
       sig_tol.insert(sig_tol.end(), s->tolerated + (size_t)i * KT, s->tolerated + (size_t)(i + 1) * KT);
       sig_tolflags.push_back(tf);
+      if (KP > 0) sig_ports.insert(sig_ports.end(), s->wanted_ports + (size_t)i * KP, s->wanted_ports + (size_t)(i + 1) * KP);
     }
     e->spec_sig_tol[(size_t)i] = jt->second;
 
@@ -697,6 +712,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   TRY(upload(e, e->d_sig_req, sig_req.data(), sig_req.size(), st));
   TRY(upload(e, e->d_sig_tol, sig_tol.data(), sig_tol.size(), st));
   TRY(upload(e, e->d_sig_tolflags, sig_tolflags.data(), sig_tolflags.size(), st));
+  TRY(upload(e, e->d_sig_ports, sig_ports.data(), sig_ports.size(), st));
   TRY(upload(e, e->d_sig_aff_flags, sig_aff_flags.data(), sig_aff_flags.size(), st));
   TRY(upload(e, e->d_sig_aff_off, sig_aff_off.data(), sig_aff_off.size(), st));
   TRY(upload(e, e->d_sig_pre_off, sig_pre_off.data(), sig_pre_off.size(), st));
@@ -743,7 +759,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   const unsigned pre = a->prefilter_plugins, filt = a->filter_plugins;
   const bool spread_filt = filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD, spread_pre = pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
-  const bool spread_err = spread_filt && !spread_pre;  // Filter without PreFilter state: every pair fails with an Error status
+  // Filter without PreFilter state (PodTopologySpread, NodePorts): every pair fails with an Error status
+  const bool spread_err = (spread_filt && !spread_pre) || ((filt & YKPRED_PLUGIN_NODE_PORTS) && !(pre & YKPRED_PLUGIN_NODE_PORTS));
   if (e->spread_dirty) TRY(build_spread_tables(e, e->own_stream));
   const bool spread_on = spread_filt && spread_pre && e->fam_spread.D > 0;
   const int N = e->N, P = e->P;
@@ -842,7 +859,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     ykk::BasePlanes bp;
     bp.req = buf.as<u64>();
     bp.taint = bp.req + (size_t)64 * e->W * e->row_stride;
-    bp.unsched = bp.taint + (size_t)64 * e->KT * e->row_stride;
+    bp.port = bp.taint + (size_t)64 * e->KT * e->row_stride;
+    bp.unsched = bp.port + (size_t)64 * e->KP * e->row_stride;
     bp.exists = bp.unsched + e->row_stride;
     bp.stride = e->row_stride;
     return bp;
@@ -850,7 +868,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   auto launch_dictionary_planes = [&](hipStream_t s, const int* perm, bool ranked, const char* base_name, const char* sig_name) {
     ykk::BasePlanes bp = base_of(ranked ? e->base_ranked : e->base_canon);
     tm.begin(s);
-    hipLaunchKernelGGL(ykk::k_base_planes, dim3((unsigned)(e->W + e->KT + 1), wgroups), dim3(ykk::kBlock), 0, s, nt, perm, bp, e->row_words);
+    hipLaunchKernelGGL(ykk::k_base_planes, dim3((unsigned)(e->W + e->KT + e->KP + 1), wgroups), dim3(ykk::kBlock), 0, s, nt, perm, bp,
+                       e->row_words);
     tm.end(s, base_name);
     ykk::SigPlaneArgs sa{};
     sa.base = bp;
@@ -863,6 +882,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (!aff_on) sa.aff.D = 0;
     sa.sig_tol = e->d_sig_tol.as<u64>();
     sa.sig_tolflags = e->d_sig_tolflags.as<unsigned>();
+    sa.sig_ports = e->d_sig_ports.as<u64>();
+    sa.KP = e->KP;
     for (int k = 0; k < ykk::kMaxKT; ++k) sa.taint_used[k] = e->taint_used[k];
     sa.affs = as;
     sa.KT = e->KT;
@@ -1147,8 +1168,8 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
   return YKPRED_OK;
 }
 
-int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
-                          int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
+int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
+                                const uint64_t* ports_after, int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
   if (!e || !out || nv < 0 || start < 0 || (nv > 0 && (!vreq || !vpresent))) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "preemption: tables not uploaded");
   if (pod < 0 || pod >= e->P || node < 0 || node >= e->N) return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
@@ -1156,21 +1177,29 @@ int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t
   hipStream_t st = e->own_stream;
   if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) TRY(run_spread_prefilter(e, st, nullptr, true, true));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
-  size_t vbytes = (size_t)nv * (size_t)e->R * sizeof(i64);
-  HIPCHK(e->d_scratch.ensure(vbytes + (size_t)nv + 64));
-  i64* d_v = e->d_scratch.as<i64>();
-  uint8_t* d_pr = (uint8_t*)e->d_scratch.p + vbytes;
-  int* d_out = (int*)((uint8_t*)e->d_scratch.p + ((vbytes + (size_t)nv + 7) / 8 * 8));
+  const size_t vbytes = (size_t)nv * (size_t)e->R * sizeof(i64);
+  const size_t pbytes = (ports_after && e->KP > 0) ? (size_t)nv * (size_t)e->KP * sizeof(u64) : 0;
+  const size_t flag_off = vbytes + pbytes;
+  const size_t out_off = (flag_off + (size_t)nv + 7) / 8 * 8;
+  HIPCHK(e->d_scratch.ensure(out_off + 64));
+  char* base = (char*)e->d_scratch.p;
   if (nv) {
-    HIPCHK(hipMemcpyAsync(d_v, vreq, vbytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_pr, vpresent, (size_t)nv, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(base, vreq, vbytes, hipMemcpyHostToDevice, st));
+    if (pbytes) HIPCHK(hipMemcpyAsync(base + vbytes, ports_after, pbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(base + flag_off, vpresent, (size_t)nv, hipMemcpyHostToDevice, st));
   }
   hipLaunchKernelGGL(ykk::k_preempt, dim3(1), dim3(64), 0, st, node_table(e), spec_table(e), e->h_pod_spec[(size_t)pod],
-                     e->h_pod_pin[(size_t)pod], node, nv, d_v, d_pr, start, pre, filt, d_out);
+                     e->h_pod_pin[(size_t)pod], node, nv, (const i64*)base, (const unsigned char*)(base + flag_off),
+                     pbytes ? (const u64*)(base + vbytes) : (const u64*)nullptr, start, pre, filt, (int*)(base + out_off));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, d_out, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out, base + out_off, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return YKPRED_OK;
+}
+
+int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
+                          int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
+  return ykpred_preemption_ports(e, pod, node, nv, vreq, vpresent, nullptr, start, pre, filt, out);
 }
 
 }  // extern "C"

@@ -33,6 +33,7 @@ constexpr int kMaxR = 8;   // resource dimensions
 constexpr int kMaxKT = 4;  // taint dictionary words (256 taints)
 constexpr int kMaxW = 8;   // requirement dictionary words (512 requirements)
 constexpr int kMaxKD = 4;  // topology keys used by hard spread constraints
+constexpr int kMaxKP = 4;  // host-port dictionary words (256 distinct requested host ports)
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
@@ -45,7 +46,7 @@ constexpr int kCombineUnroll = 4;   // row words per thread held in registers by
 // plugin bits (mirror include/ykpred.h)
 constexpr unsigned kSpreadHonorAffinity = 1u << 0, kSpreadHonorTaints = 1u << 1;
 constexpr unsigned kPlugUnsched = 1u << 0, kPlugNodeName = 1u << 1, kPlugTaint = 1u << 2, kPlugAffinity = 1u << 3,
-                   kPlugFit = 1u << 5, kPlugSpread = 1u << 6;
+                   kPlugPorts = 1u << 4, kPlugFit = 1u << 5, kPlugSpread = 1u << 6;
 constexpr unsigned kSpecToleratesUnsched = 1u << 0, kSpecAffSkip = 1u << 1, kSpecPreReject = 1u << 2, kSpecPreNames = 1u << 3;
 constexpr unsigned kNodeUnschedulable = 1u << 0;
 
@@ -62,6 +63,8 @@ struct NodeTable {
   int KD, KS;          // PodTopologySpread: topology keys, selector classes
   const int* domain;   // [KD][n] id of the node's value for topology key k, -1 = label missing
   const int* selcount; // [KS][n] pods on the node matching selector class s
+  int KP;              // NodePorts: host-port dictionary words
+  const u64* ports;    // [KP][n] bit k: a pod on the node conflicts with dictionary host port k
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -255,27 +258,32 @@ __device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0,
 struct BasePlanes {
   u64* req;      // [64*W][stride]  requirement q
   u64* taint;    // [64*KT][stride] dictionary taint t
+  u64* port;     // [64*KP][stride] dictionary host port k in conflict on the node
   u64* unsched;  // [stride] node.Spec.Unschedulable
   u64* exists;   // [stride] bit set for positions < N (zero padding of the last word)
   int stride;
 };
-// blockIdx.x: dictionary word (0..W-1 labels, W..W+KT-1 taints, W+KT flags); blockIdx.y: group of 4 node words.
+// blockIdx.x: dictionary word (0..W-1 labels, then KT taint words, then KP port words, last = flags); blockIdx.y: group of 4 node words.
 __global__ __launch_bounds__(kBlock) void k_base_planes(NodeTable t, const int* __restrict__ perm, BasePlanes o, int n_words) {
   int word;
   const int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
   const int lane = threadIdx.x % kWave;
   const int c = blockIdx.x;
-  if (c < t.W + t.KT) {
-    const bool is_label = c < t.W;
-    const u64 v = n < 0 ? 0ull : (is_label ? t.labels[(size_t)c * t.n + n] : t.taints[(size_t)(c - t.W) * t.n + n]);
+  if (c < t.W + t.KT + t.KP) {
+    const bool is_label = c < t.W, is_taint = !is_label && c < t.W + t.KT;
+    const u64 v = n < 0 ? 0ull
+                        : (is_label ? t.labels[(size_t)c * t.n + n]
+                                    : (is_taint ? t.taints[(size_t)(c - t.W) * t.n + n] : t.ports[(size_t)(c - t.W - t.KT) * t.n + n]));
     u64 keep = 0;
 #pragma unroll 8
     for (int b = 0; b < 64; ++b) {
       u64 m = __ballot((v >> b) & 1ull);
       if (b == lane) keep = m;
     }
-    u64* dst = is_label ? o.req + (size_t)(c * 64 + lane) * o.stride : o.taint + (size_t)((c - t.W) * 64 + lane) * o.stride;
+    u64* dst = is_label ? o.req + (size_t)(c * 64 + lane) * o.stride
+                        : (is_taint ? o.taint + (size_t)((c - t.W) * 64 + lane) * o.stride
+                                    : o.port + (size_t)((c - t.W - t.KT) * 64 + lane) * o.stride);
     dst[word] = keep;
   } else {
     u64 un = __ballot(n >= 0 && (t.flags[n >= 0 ? n : 0] & kNodeUnschedulable));
@@ -292,6 +300,8 @@ struct SigPlaneArgs {
   PlaneOut tol, aff;                 // outputs (canon or ranked pointer pre-selected in `.canon`)
   const u64* sig_tol;                // [Dtol][KT]
   const unsigned* sig_tolflags;      // [Dtol]
+  const u64* sig_ports;              // [Dtol][KP] requested host ports of the signature
+  int KP;
   u64 taint_used[kMaxKT];            // dictionary taints that occur on some node (other base planes are all zero)
   AffSigs affs;
   int KT, W;
@@ -324,6 +334,7 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
   const int d0 = blockIdx.x * kBitSigsPerBlock;
   if (blockIdx.z == 0) {
     const bool taint_en = a.filt_mask & kPlugTaint, unsched_en = a.filt_mask & kPlugUnsched;
+    const bool ports_en = (a.filt_mask & kPlugPorts) && (a.pre_mask & kPlugPorts);
     const u64 unsched = unsched_en ? a.base.unsched[w] : 0ull;
     for (int d = d0; d < min(d0 + kBitSigsPerBlock, a.tol.D); ++d) {
       u64 bad = 0;  // nodes carrying a taint this signature does not tolerate
@@ -337,6 +348,15 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           }
         }
       if (!(a.sig_tolflags[d] & kSpecToleratesUnsched)) bad |= unsched;
+      if (ports_en)  // NodePorts: a requested host port that is in conflict on the node
+        for (int k = 0; k < a.KP; ++k) {
+          u64 m = a.sig_ports[(size_t)d * a.KP + k];
+          while (m) {
+            int pp = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            bad |= a.base.port[(size_t)(k * 64 + pp) * a.base.stride + w];
+          }
+        }
       a.tol.canon[(size_t)d * a.tol.stride + w] = exists & ~bad;
     }
   } else {
@@ -665,6 +685,8 @@ struct SpecTable {
   const u64* tol;        // [S][KT]
   const unsigned* flags; // [S]
   AffSigs aff;           // indexed by spec
+  int KP;
+  const u64* wanted_ports; // [S][KP]
   const int* spread_sig; // [S] spread signature of the spec, -1 = no hard constraints (PreFilter Skip)
   SpreadSigs spread;
 };
@@ -673,6 +695,7 @@ struct NodeRegs {
   i64 fr[kMaxR];
   u64 tn[kMaxKT];
   u64 lb[kMaxW];
+  u64 pt[kMaxKP];
   int dom[kMaxKD];
   bool slots_ok, unsched;
 };
@@ -683,6 +706,8 @@ __device__ __forceinline__ void load_node(const NodeTable& t, int n, NodeRegs* r
   for (int i = 0; i < kMaxKT; ++i) r->tn[i] = (i < t.KT && n >= 0) ? t.taints[(size_t)i * t.n + n] : 0;
 #pragma unroll
   for (int i = 0; i < kMaxW; ++i) r->lb[i] = (i < t.W && n >= 0) ? t.labels[(size_t)i * t.n + n] : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxKP; ++i) r->pt[i] = (i < t.KP && n >= 0) ? t.ports[(size_t)i * t.n + n] : 0;
 #pragma unroll
   for (int i = 0; i < kMaxKD; ++i) r->dom[i] = (i < t.KD && n >= 0) ? t.domain[(size_t)i * t.n + n] : -1;
   r->slots_ok = n >= 0 && (i64)t.count[n] + 1 <= (i64)t.allowed[n];
@@ -733,6 +758,24 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
     bool skip = (pre_mask & kPlugAffinity) && (f & kSpecAffSkip);
     if (!skip && !dnf_match(s.aff.terms, s.aff.term_off[spec], s.aff.term_off[spec + 1], nr.lb, s.W)) {
       *code = 4;
+      return false;
+    }
+  }
+  if (filt_mask & kPlugPorts) {
+    const u64* want = s.wanted_ports + (size_t)spec * s.KP;
+    bool any = false, conflict = false;
+#pragma unroll
+    for (int k = 0; k < kMaxKP; ++k)
+      if (k < s.KP) {
+        any = any || want[k] != 0;
+        conflict = conflict || (nr.pt[k] & want[k]) != 0;
+      }
+    if (!(pre_mask & kPlugPorts)) {
+      *code = 5;  // Filter without PreFilter state: Error status
+      return false;
+    }
+    if (any && conflict) {  // no requested host port ⇒ PreFilter Skip ⇒ Filter not run
+      *code = 5;
       return false;
     }
   }
@@ -870,8 +913,8 @@ __global__ __launch_bounds__(kBlock) void k_column_patch(ColumnGroups cg, int n_
 
 // PreemptionPredicates (predicate_manager.go:141-179): single (pod,node); victims removed in order.
 __global__ void k_preempt(NodeTable t, SpecTable s, int spec, int pin, int node, int n_victims, const i64* __restrict__ vreq,
-                          const unsigned char* __restrict__ vpresent, int start, unsigned pre_mask, unsigned filt_mask,
-                          int* __restrict__ out) {
+                          const unsigned char* __restrict__ vpresent, const u64* __restrict__ ports_after /*[n_victims][KP] or null*/,
+                          int start, unsigned pre_mask, unsigned filt_mask, int* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   NodeRegs nr;
   load_node(t, node, &nr);
@@ -890,6 +933,8 @@ __global__ void k_preempt(NodeTable t, SpecTable s, int spec, int pin, int node,
       for (int r = 0; r < s.R && r < kMaxR; ++r) nr.fr[r] += vreq[(size_t)i * s.R + r];
       pods_on_node -= 1;
     }
+    if (ports_after)
+      for (int k = 0; k < t.KP && k < kMaxKP; ++k) nr.pt[k] = ports_after[(size_t)i * t.KP + k];
     if (i < start) continue;  // :161-163
     nr.slots_ok = pods_on_node + 1 <= allowed;
     // PreFilter outcomes were accepted above; eval_pair re-checks them (idempotent) and runs the filters (:168)

@@ -9,9 +9,11 @@
 //     expressions, nodeSelector pairs, matchFields, PreFilter node names) gets a bit, evaluated once per node
 //     with the full apimachinery semantics (validation, In/NotIn/Exists/DoesNotExist/Gt/Lt); a selector
 //     term becomes a mask and NodeAffinity.Filter becomes "some term's mask ⊆ node bits".
-// Pods carrying features the engine does not evaluate (host ports, inter-pod affinity, volumes, hard
-// topology-spread constraints in this build) are REJECTED with an error — never silently passed, and there
-// is no CPU evaluation fallback in this library.
+//   * a host-port dictionary (NodePorts): every distinct (protocol, hostIP, hostPort) some ask requests gets a bit; a
+//     node's bit says "a pod already here conflicts with it" (HostPortInfo.CheckConflict incl. the 0.0.0.0 wildcard),
+//   * topology-domain ids and per-selector matching-pod counts for PodTopologySpread.
+// Pods carrying features the engine does not evaluate (inter-pod affinity, volumes, matchLabelKeys) are REJECTED
+// with an error — never silently passed, and there is no CPU evaluation fallback in this library.
 #pragma once
 #include <algorithm>
 #include <limits>
@@ -189,7 +191,8 @@ class Encoder {
   std::vector<std::string> scalar_names;  // resource dimension 3+i
   std::vector<Taint> taint_dict;
   std::vector<DictReq> req_dict;
-  int KD = 0, KS = 0;
+  int KD = 0, KS = 0, KP = 0;
+  std::vector<HostPort> port_dict;                                    // requested host port k (NodePorts)
   std::vector<std::string> topo_keys;                                 // topology key k
   std::vector<std::unordered_map<std::string, int>> domain_ids;       // value → id, per key (ids follow sorted values)
   std::vector<SelectorClass> sel_classes;                             // selector class s
@@ -209,10 +212,12 @@ class Encoder {
     sel_classes.clear();
     sel_ix_.clear();
     sel_memo_.clear();
+    port_dict.clear();
+    port_ix_.clear();
     for (const PodTemplate* t : templates) {
       if (t->pod_affinity) return fail("inter-pod affinity is outside the engine's plugin set (InterPodAffinity)");
-      for (auto& c : t->containers)
-        if (c.host_ports) return fail("host ports are outside the engine's plugin set (NodePorts)");
+      for (const HostPort& hp : template_host_ports(*t))
+        if (port_ix_.emplace(port_key(hp), (int)port_dict.size()).second) port_dict.push_back(hp);
       std::set<std::string> keys_seen;
       for (auto& c : t->spread) {
         if (c.when_unsatisfiable != "DoNotSchedule") continue;  // ScheduleAnyway constraints only score
@@ -232,6 +237,8 @@ class Encoder {
     }
     KD = (int)topo_keys.size();
     KS = (int)sel_classes.size();
+    KP = ((int)port_dict.size() + 63) / 64;
+    if (KP > 4) return fail("more than 256 distinct requested host ports (engine limit)");
     if (KD > 4) return fail("more than 4 distinct topology keys in DoNotSchedule constraints (engine limit)");
     domain_ids.assign((size_t)KD, {});
     for (int k = 0; k < KD; ++k) {
@@ -258,6 +265,30 @@ class Encoder {
     if (KT > 4) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
     if (W > 8) return fail("more than 512 distinct node-selector requirements (engine limit)");
     return true;
+  }
+
+  // NodePorts: bit k = some pod in `pods` uses a host port that conflicts with dictionary port k
+  // (HostPortInfo.CheckConflict: same protocol and port, equal or wildcard host IP).
+  void encode_ports(const std::vector<const Pod*>& pods, uint64_t* bits) const {
+    std::fill(bits, bits + KP, 0);
+    if (port_dict.empty()) return;
+    for (const Pod* p : pods) {
+      std::vector<HostPort> used = template_host_ports(*p->tpl);
+      if (used.empty()) continue;
+      for (size_t k = 0; k < port_dict.size(); ++k)
+        for (const HostPort& u : used)
+          if (host_ports_conflict(port_dict[k], u)) {
+            bits[k >> 6] |= 1ull << (k & 63);
+            break;
+          }
+    }
+  }
+  void encode_wanted_ports(const PodTemplate& t, uint64_t* bits) const {
+    std::fill(bits, bits + KP, 0);
+    for (const HostPort& hp : template_host_ports(t)) {
+      auto it = port_ix_.find(port_key(hp));
+      if (it != port_ix_.end()) bits[it->second >> 6] |= 1ull << (it->second & 63);
+    }
   }
 
   std::vector<int32_t> domain_sizes() const {
@@ -457,7 +488,8 @@ class Encoder {
       return std::hash<const void*>()(k.first) * 31u + (size_t)k.second;
     }
   };
-  std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_, topo_ix_, sel_ix_;
+  std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_, topo_ix_, sel_ix_, port_ix_;
+  static std::string port_key(const HostPort& h) { return h.protocol + '\x1f' + h.ip + '\x1f' + std::to_string(h.port); }
   std::unordered_map<std::pair<const PodTemplate*, int>, bool, MemoHash> sel_memo_;
 
   bool fail(const std::string& m) {

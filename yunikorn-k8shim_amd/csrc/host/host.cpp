@@ -69,7 +69,7 @@ struct ykhost {
   uint32_t last_eval_options = 0;
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
-  int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1;
+  int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1, cfgKP = -1;
 
   void clear_state() {
     pool.clear();
@@ -126,7 +126,8 @@ Pod* add_pod_object(ykhost* h, const mj::Value& v, size_t* anon) {
 
 // ---- encode + upload -------------------------------------------------------------------------------
 int recreate_engine(ykhost* h) {
-  if (h->eng && h->cfgR == h->enc.R && h->cfgKT == h->enc.KT && h->cfgW == h->enc.W && h->cfgKD == h->enc.KD && h->cfgKS == h->enc.KS)
+  if (h->eng && h->cfgR == h->enc.R && h->cfgKT == h->enc.KT && h->cfgW == h->enc.W && h->cfgKD == h->enc.KD && h->cfgKS == h->enc.KS &&
+      h->cfgKP == h->enc.KP)
     return 0;
   if (h->eng) ykpred_destroy(h->eng);
   h->eng = nullptr;
@@ -138,6 +139,7 @@ int recreate_engine(ykhost* h) {
   c.label_words = h->enc.W;
   c.topology_keys = h->enc.KD;
   c.selector_classes = h->enc.KS;
+  c.port_words = h->enc.KP;
   // engine tunables for experiments: YKPRED_CHUNK_MEMBERS=1..64, YKPRED_CHUNK_UNSORTED=1
   if (const char* v = getenv("YKPRED_CHUNK_MEMBERS")) c.reserved[0] = atoi(v);
   if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
@@ -149,6 +151,7 @@ int recreate_engine(ykhost* h) {
   h->cfgW = c.label_words;
   h->cfgKD = c.topology_keys;
   h->cfgKS = c.selector_classes;
+  h->cfgKP = c.port_words;
   return 0;
 }
 
@@ -167,8 +170,9 @@ int full_sync(ykhost* h) {
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
   int rc = recreate_engine(h);
   if (rc) return rc;
-  const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS;
+  const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS, KP = h->enc.KP;
   const size_t N = h->nodes.size();
+  std::vector<uint64_t> ports(N * KP + 1), p1(KP + 1);
   std::vector<int64_t> alloc(N * R), req(N * R), a1(R), r1(R);
   std::vector<int32_t> allowed(N), count(N), domain(N * KD + 1), selcount(N * KS + 1), d1(KD + 1), s1(KS + 1);
   std::vector<uint32_t> flags(N);
@@ -179,6 +183,8 @@ int full_sync(ykhost* h) {
     h->enc.encode_node_spread(*h->nodes[n], d1.data(), s1.data());
     for (int k = 0; k < KD; ++k) domain[(size_t)k * N + n] = d1[(size_t)k];
     for (int k = 0; k < KS; ++k) selcount[(size_t)k * N + n] = s1[(size_t)k];
+    h->enc.encode_ports(h->nodes[n]->pods, p1.data());
+    for (int k = 0; k < KP; ++k) ports[(size_t)k * N + n] = p1[(size_t)k];
     for (int r = 0; r < R; ++r) {
       alloc[(size_t)r * N + n] = a1[(size_t)r];
       req[(size_t)r * N + n] = r1[(size_t)r];
@@ -200,12 +206,13 @@ int full_sync(ykhost* h) {
   nt.domain_id = domain.data();
   nt.selector_count = selcount.data();
   nt.domain_sizes = dsizes.data();
+  nt.port_bits = ports.data();
   rc = ykpred_set_nodes(h->eng, &nt);
   if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
 
   const size_t S = h->spec_templates.size();
   std::vector<int64_t> sreq(S * R);
-  std::vector<uint64_t> stol(S * KT), aff_terms, pre_terms;
+  std::vector<uint64_t> stol(S * KT), aff_terms, pre_terms, wanted(S * KP + 1);
   std::vector<uint32_t> sflags(S);
   std::vector<int32_t> aff_off{0}, pre_off{0}, spread_off{0};
   std::vector<ykpred_spread_t> spread;
@@ -216,6 +223,7 @@ int full_sync(ykhost* h) {
     std::copy(es.req.begin(), es.req.end(), sreq.begin() + (long)(s * R));
     std::copy(es.tol.begin(), es.tol.end(), stol.begin() + (long)(s * KT));
     sflags[s] = es.flags;
+    h->enc.encode_wanted_ports(*h->spec_templates[s], wanted.data() + s * KP);
     for (auto& t : es.terms) aff_terms.insert(aff_terms.end(), t.begin(), t.end());
     for (auto& t : es.pre_terms) pre_terms.insert(pre_terms.end(), t.begin(), t.end());
     aff_off.push_back((int32_t)(aff_terms.size() / (size_t)W));
@@ -234,6 +242,7 @@ int full_sync(ykhost* h) {
   ykpred_spread_t no_spread{};
   sp.spread_off = spread_off.data();
   sp.spread = spread.empty() ? &no_spread : spread.data();
+  sp.wanted_ports = wanted.data();
   rc = ykpred_set_specs(h->eng, &sp);
   if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
   h->dirty_all = false;
@@ -278,10 +287,13 @@ int node_row_sync(ykhost* h, int n) {
     h->dirty_all = true;  // a topology value outside the dictionary: rebuild everything
     return full_sync(h);
   }
+  std::vector<uint64_t> pb((size_t)h->enc.KP + 1);
+  h->enc.encode_ports(h->nodes[(size_t)n]->pods, pb.data());
   ykpred_nodes_t nt{};
   nt.count = 1;
   nt.domain_id = dom.data();
   nt.selector_count = sel.data();
+  nt.port_bits = pb.data();
   nt.allocatable = a.data();
   nt.requested = r.data();
   nt.allowed_pods = &allowed;
@@ -334,6 +346,7 @@ std::string compose_message(ykhost* h, const Pod& pod, const NodeInfo& ni, int c
     case YKPRED_CODE_NODE_AFFINITY:
       if (reason & YKPRED_REASON_PREFILTER_NODE_NOT_ELIGIBLE) return "node not eligible";
       return "node(s) didn't match Pod's node affinity/selector";
+    case YKPRED_CODE_NODE_PORTS: return "node(s) didn't have free ports for the requested pod ports";
     case YKPRED_CODE_NODE_RESOURCES_FIT: {
       std::string m;
       auto add = [&](const std::string& s) {
@@ -884,15 +897,26 @@ int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, con
   const NodeInfo& ni = *h->nodes[(size_t)node];
   std::vector<int64_t> vreq((size_t)std::max(nv, 1) * (size_t)R, 0);
   std::vector<uint8_t> present((size_t)std::max(nv, 1), 0);
+  const int KP = h->enc.KP;
+  std::vector<uint64_t> ports_after((size_t)std::max(nv, 1) * (size_t)std::max(KP, 1), 0);
+  std::vector<const Pod*> remaining(ni.pods.begin(), ni.pods.end());
   std::vector<const Pod*> gone;
   for (int i = 0; i < nv; ++i) {
-    if (!victim_uids || !victim_uids[i]) continue;  // nil victim (:182-184)
+    if (!victim_uids || !victim_uids[i]) {  // nil victim (:182-184): the node is unchanged
+      if (KP) h->enc.encode_ports(remaining, ports_after.data() + (size_t)i * KP);
+      continue;
+    }
     const Pod* v = nullptr;
     for (const Pod* q : ni.pods)
       if (q->uid == victim_uids[i]) v = q;
     // RemovePod fails (and is ignored) when the pod is not on the node or was already removed (:185-191)
-    if (!v || std::find(gone.begin(), gone.end(), v) != gone.end()) continue;
+    if (!v || std::find(gone.begin(), gone.end(), v) != gone.end()) {
+      if (KP) h->enc.encode_ports(remaining, ports_after.data() + (size_t)i * KP);
+      continue;
+    }
     gone.push_back(v);
+    remaining.erase(std::find(remaining.begin(), remaining.end(), v));
+    if (KP) h->enc.encode_ports(remaining, ports_after.data() + (size_t)i * KP);  // NodeInfo.UsedPorts after this removal
     present[(size_t)i] = 1;
     Resource r = to_resource(v->tpl->requests);
     vreq[(size_t)i * R + 0] = r.milli_cpu;
@@ -904,7 +928,8 @@ int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, con
     }
   }
   int32_t out = -1;
-  rc = ykpred_preemption(h->eng, pod, node, nv, vreq.data(), present.data(), start, h->alloc_pre, h->alloc_filt, &out);
+  rc = ykpred_preemption_ports(h->eng, pod, node, nv, vreq.data(), present.data(), KP ? ports_after.data() : nullptr, start, h->alloc_pre,
+                               h->alloc_filt, &out);
   if (rc) {
     fail(h, std::string("ykpred_preemption: ") + ykpred_last_error(h->eng), rc);
     return -2;

@@ -48,11 +48,15 @@ struct SpreadConstraint {
   std::string node_affinity_policy = "Honor", node_taints_policy = "Ignore";
   std::vector<std::string> match_label_keys;
 };
+struct HostPort {  // v1.ContainerPort with hostPort > 0; "" hostIP = 0.0.0.0, "" protocol = TCP (HostPortInfo.sanitize)
+  std::string protocol, ip;
+  int64_t port = 0;
+};
 struct Container {
   std::string name;
   StrMap requests;
   bool sidecar = false;
-  bool host_ports = false;
+  std::vector<HostPort> host_ports;
 };
 
 // Everything of a pod except uid / name / nodeName.
@@ -127,6 +131,9 @@ inline Resource to_resource(const ResMap& m) {
   return r;
 }
 
+// schedutil.GetHostPorts: containers + init containers with restartPolicy Always
+inline std::vector<HostPort> template_host_ports(const PodTemplate& t);
+
 // Request vector of a template: containers summed, init containers / native sidecars folded in, pod-level
 // override for cpu/memory/hugepages, overhead added (resource.go:56-109,164-182,287-301).
 inline ResMap compute_requests(const PodTemplate& t) {
@@ -160,6 +167,19 @@ inline ResMap compute_requests(const PodTemplate& t) {
     if (kv.first == "cpu" || kv.first == "memory" || has_prefix(kv.first, "hugepages-")) total[kv.first] = kv.second;
   if (t.has_overhead) add(total, get_resource(t.overhead));
   return total;
+}
+
+inline std::vector<HostPort> template_host_ports(const PodTemplate& t) {
+  std::vector<HostPort> out;
+  for (auto& c : t.init_containers)
+    if (c.sidecar) out.insert(out.end(), c.host_ports.begin(), c.host_ports.end());
+  for (auto& c : t.containers) out.insert(out.end(), c.host_ports.begin(), c.host_ports.end());
+  return out;
+}
+// HostPortInfo.CheckConflict between one wanted and one used port
+inline bool host_ports_conflict(const HostPort& want, const HostPort& used) {
+  return want.port > 0 && want.protocol == used.protocol && want.port == used.port &&
+         (want.ip == "0.0.0.0" || used.ip == "0.0.0.0" || want.ip == used.ip);
 }
 
 // framework.NodeInfo
@@ -227,8 +247,17 @@ inline std::vector<Container> read_containers(const mj::Value* v, bool init) {
       if (const mj::Value* res = e->get_nn("resources")) c.requests = read_strmap(res->get_nn("requests"));
       if (init) c.sidecar = e->str_or("restartPolicy", "") == "Always";
       if (const mj::Value* ports = e->get_nn("ports"))
-        for (auto& pt : ports->arr)
-          if (pt->int_or("hostPort", 0) != 0) c.host_ports = true;
+        for (auto& pt : ports->arr) {
+          int64_t hp = pt->int_or("hostPort", 0);
+          if (hp <= 0) continue;
+          HostPort h;
+          h.protocol = pt->str_or("protocol", "");
+          h.ip = pt->str_or("hostIP", "");
+          if (h.protocol.empty()) h.protocol = "TCP";
+          if (h.ip.empty()) h.ip = "0.0.0.0";
+          h.port = hp;
+          c.host_ports.push_back(h);
+        }
       out.push_back(std::move(c));
     }
   return out;
@@ -295,7 +324,19 @@ inline void js_containers(std::string& o, const std::vector<Container>& cs) {
     js_map(o, cs[i].requests);
     o += "}";
     if (cs[i].sidecar) o += ",\"restartPolicy\":\"Always\"";
-    if (cs[i].host_ports) o += ",\"ports\":[{\"hostPort\":1}]";
+    if (!cs[i].host_ports.empty()) {
+      o += ",\"ports\":[";
+      for (size_t k = 0; k < cs[i].host_ports.size(); ++k) {
+        const HostPort& h = cs[i].host_ports[k];
+        if (k) o.push_back(',');
+        o += "{\"hostIP\":";
+        js_str(o, h.ip);
+        o += ",\"hostPort\":" + std::to_string(h.port) + ",\"protocol\":";
+        js_str(o, h.protocol);
+        o.push_back('}');
+      }
+      o.push_back(']');
+    }
     o.push_back('}');
   }
   o.push_back(']');
