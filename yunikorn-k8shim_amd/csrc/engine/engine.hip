@@ -850,8 +850,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     hipLaunchKernelGGL(ykk::k_rank_scan, dim3(1), dim3(ykk::kRankBuckets), 0, sb, hist, bucket_off, cursor);
     hipLaunchKernelGGL(ykk::k_rank_fill, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), e->d_key.as<u64>(),
                        cursor, members, e->d_member_key.as<u64>());
-    hipLaunchKernelGGL(ykk::k_rank_final, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), e->d_key.as<u64>(),
-                       bucket_off, members, e->d_member_key.as<u64>(), e->d_rank.as<int>(), e->d_perm.as<int>());
+    hipLaunchKernelGGL(ykk::k_rank_final, dim3((unsigned)ykk::kRankBuckets), dim3(ykk::kBlock), 0, sb, bucket_off, members,
+                       e->d_member_key.as<u64>(), e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.end(sb, "k_rank");
   }
   // Bit-sliced dictionaries + signature planes of one node order (perm == nullptr: canonical) on stream s.

@@ -140,24 +140,38 @@ __global__ __launch_bounds__(kBlock) void k_rank_fill(int n_nodes, const double*
   members[pos] = n;
   member_key[pos] = key[n];  // keys travel with the ids: the final pass streams them instead of chasing key[members[i]]
 }
-__global__ __launch_bounds__(kBlock) void k_rank_final(int n_nodes, const double* __restrict__ score, const u64* __restrict__ key,
-                                                       const int* __restrict__ bucket_off, const int* __restrict__ members,
+// One block per bucket: the bucket's (key, node) pairs are staged through LDS in tiles and every member counts the
+// entries that sort before it. LDS keeps this independent of global-memory latency (the kernel runs beside the
+// bandwidth-saturating k_combine) and of bucket skew (e.g. all idle nodes share score 1.0 and one bucket).
+constexpr int kRankTile = 1024;
+__global__ __launch_bounds__(kBlock) void k_rank_final(const int* __restrict__ bucket_off, const int* __restrict__ members,
                                                        const u64* __restrict__ member_key, int* __restrict__ rank,
                                                        int* __restrict__ perm) {
-  int n = blockIdx.x * kBlock + threadIdx.x;
-  if (n >= n_nodes) return;
-  const int b = rank_bucket(score[n]);
-  const int lo = bucket_off[b], hi = bucket_off[b + 1];
-  const u64 mine = key[n];
-  int r = lo;
-#pragma unroll 4
-  for (int i = lo; i < hi; ++i) {
-    int m = members[i];
-    u64 k = member_key[i];
-    r += (k < mine) || (k == mine && m < n);
+  __shared__ u64 t_key[kRankTile];
+  __shared__ int t_idx[kRankTile];
+  const int lo = bucket_off[blockIdx.x], hi = bucket_off[blockIdx.x + 1];
+  for (int base = lo; base < hi; base += kBlock) {  // this pass ranks members base + tid
+    const int i = base + threadIdx.x;
+    const bool live = i < hi;
+    const u64 mine = live ? member_key[i] : 0ull;
+    const int me = live ? members[i] : 0;
+    int r = lo;
+    for (int tb = lo; tb < hi; tb += kRankTile) {
+      __syncthreads();
+      for (int j = threadIdx.x; j < kRankTile && tb + j < hi; j += kBlock) {
+        t_key[j] = member_key[tb + j];
+        t_idx[j] = members[tb + j];
+      }
+      __syncthreads();
+      const int lim = min(kRankTile, hi - tb);
+      if (live)
+        for (int j = 0; j < lim; ++j) r += (t_key[j] < mine) || (t_key[j] == mine && t_idx[j] < me);
+    }
+    if (live) {
+      rank[me] = r;
+      perm[r] = me;
+    }
   }
-  rank[n] = r;
-  perm[r] = n;
 }
 
 // ---------------------------------------------------------------------------------------------------
