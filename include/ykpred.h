@@ -56,7 +56,8 @@ extern "C" {
 #define YKPRED_PLUGIN_NODE_PORTS (1u << 4)
 #define YKPRED_PLUGIN_NODE_RESOURCES_FIT (1u << 5)
 #define YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD (1u << 6)
-#define YKPRED_PLUGIN_ALL 0x7fu
+#define YKPRED_PLUGIN_INTER_POD_AFFINITY (1u << 7)
+#define YKPRED_PLUGIN_ALL 0xffu
 
 /* "failing plugin" codes returned by ykpred_query (0 = "" — a PreFilter plugin rejected the pod, :236-238) */
 #define YKPRED_CODE_NONE 0
@@ -67,6 +68,7 @@ extern "C" {
 #define YKPRED_CODE_NODE_PORTS 5
 #define YKPRED_CODE_NODE_RESOURCES_FIT 6
 #define YKPRED_CODE_POD_TOPOLOGY_SPREAD 7
+#define YKPRED_CODE_INTER_POD_AFFINITY 8
 
 /* reason bits returned by ykpred_query next to the plugin code (the host composes the status message) */
 #define YKPRED_REASON_TOO_MANY_PODS (1u << 0)
@@ -119,17 +121,26 @@ typedef struct ykpred_nodes {
                                                  port k (HostPortInfo.CheckConflict: same protocol+port, equal or wildcard IP) */
 } ykpred_nodes_t;
 
-/* One hard (DoNotSchedule) topology spread constraint of a pod spec. */
+/* One topology constraint of a pod spec: a hard (DoNotSchedule) topology spread constraint, or one InterPodAffinity
+ * rule. All kinds share the mechanics "per-node match counts (selector_count) → histogram per topology domain → test of
+ * the candidate node's domain"; a spec's PodTopologySpread constraints must precede its InterPodAffinity ones. */
 typedef struct ykpred_spread {
   int32_t topology_key;   /* index into domain_id[KD] */
-  int32_t selector_class; /* index into selector_count[KS]; -1 = selector counts nothing (nil / empty selector) */
-  int32_t max_skew;
-  int32_t min_domains;    /* nil => 1 */
-  int32_t self_match;     /* 1 if the incoming pod's own labels match the selector */
-  uint32_t flags;         /* bit0: nodeAffinityPolicy == Honor, bit1: nodeTaintsPolicy == Honor */
+  int32_t selector_class; /* index into selector_count[KS]; -1 = counts nothing (nil / empty selector) */
+  int32_t max_skew;       /* SPREAD only */
+  int32_t min_domains;    /* SPREAD only; nil => 1 */
+  int32_t self_match;     /* SPREAD: the pod's labels match the selector. POD_AFFINITY: the pod matches ALL its own
+                             affinity terms (same value on every affinity term of the spec) */
+  uint32_t flags;         /* SPREAD only. bit0: nodeAffinityPolicy == Honor, bit1: nodeTaintsPolicy == Honor */
+  int32_t kind;           /* YKPRED_CONSTRAINT_* */
+  int32_t reserved;
 } ykpred_spread_t;
 #define YKPRED_SPREAD_HONOR_AFFINITY (1u << 0)
 #define YKPRED_SPREAD_HONOR_TAINTS (1u << 1)
+#define YKPRED_CONSTRAINT_SPREAD 0
+#define YKPRED_CONSTRAINT_POD_AFFINITY 1          /* selector_class counts pods matching ALL required affinity terms of the spec */
+#define YKPRED_CONSTRAINT_POD_ANTI_AFFINITY 2     /* selector_class counts pods matching this required anti-affinity term */
+#define YKPRED_CONSTRAINT_EXISTING_ANTI_AFFINITY 3 /* selector_class counts (pod, anti-affinity term on this key) pairs matching the spec's pod */
 
 /* Pod specs (one per distinct pod template / task group; pods reference them by index). */
 typedef struct ykpred_specs {

@@ -51,6 +51,7 @@ enum PluginBit : uint32_t {
   kNodePorts = 1u << 4,
   kNodeResourcesFit = 1u << 5,
   kPodTopologySpread = 1u << 6,
+  kInterPodAffinity = 1u << 7,
 };
 // Codes returned as "failing plugin": 0 = "" (a PreFilter plugin rejected the pod itself, :236-238).
 enum PluginCode : int {
@@ -62,6 +63,7 @@ enum PluginCode : int {
   kCodeNodePorts = 5,
   kCodeNodeResourcesFit = 6,
   kCodePodTopologySpread = 7,
+  kCodeInterPodAffinity = 8,
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -96,6 +98,12 @@ struct SpreadConstraint {
   std::string node_affinity_policy = "Honor", node_taints_policy = "Ignore";
   std::vector<std::string> match_label_keys;
 };
+struct PodAffinityTerm {  // v1.PodAffinityTerm (required terms only)
+  LabelSelector selector;
+  std::vector<std::string> namespaces;
+  bool has_namespace_selector = false;  // not modelled (needs Namespace objects): rejected at load time
+  std::string topology_key;
+};
 struct HostPort {  // v1.ContainerPort with HostPort > 0, sanitized like HostPortInfo.sanitize ("" ip → 0.0.0.0, "" protocol → TCP)
   std::string protocol, ip;
   int64_t port = 0;
@@ -121,6 +129,7 @@ struct Pod {
   StrMap overhead;
   StrMap pod_level_requests;
   std::vector<SpreadConstraint> spread;
+  std::vector<PodAffinityTerm> pod_affinity, pod_anti_affinity;  // requiredDuringSchedulingIgnoredDuringExecution
   bool terminating = false;  // metadata.deletionTimestamp set
   std::string phase;
 };
@@ -543,8 +552,28 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
           }
       }
     }
-    if (aff->get_nn("podAffinity") || aff->get_nn("podAntiAffinity"))
-      *err = "inter-pod affinity not modelled (InterPodAffinity is outside this path)";
+    auto read_terms = [&](const mj::Value* pa, std::vector<PodAffinityTerm>* out) {
+      if (!pa) return;
+      const mj::Value* req = pa->get_nn("requiredDuringSchedulingIgnoredDuringExecution");
+      if (!req || !req->is_arr()) return;
+      for (auto& t : req->arr) {
+        PodAffinityTerm term;
+        if (const mj::Value* ls = t->get_nn("labelSelector")) {
+          term.selector.present = true;
+          term.selector.match_labels = read_strmap(ls->get_nn("matchLabels"));
+          term.selector.match_exprs = read_requirements(ls->get_nn("matchExpressions"));
+        }
+        if (const mj::Value* nss = t->get_nn("namespaces"))
+          for (auto& x : nss->arr) term.namespaces.push_back(x->s);
+        term.has_namespace_selector = t->get_nn("namespaceSelector") != nullptr;
+        term.topology_key = t->str_or("topologyKey", "");
+        if (term.has_namespace_selector) *err = "podAffinityTerm.namespaceSelector not modelled";
+        if (t->get_nn("matchLabelKeys") || t->get_nn("mismatchLabelKeys")) *err = "podAffinityTerm.matchLabelKeys not modelled";
+        out->push_back(std::move(term));
+      }
+    };
+    read_terms(aff->get_nn("podAffinity"), &p->pod_affinity);
+    read_terms(aff->get_nn("podAntiAffinity"), &p->pod_anti_affinity);
   }
   if (const mj::Value* tols = spec->get_nn("tolerations"))
     for (auto& t : tols->arr) {
@@ -657,7 +686,13 @@ struct SpreadState {  // podtopologyspread preFilterState
   std::map<std::string, int> key_to_domains;                         // TpKeyToDomainsNum
   std::map<std::string, int> key_to_min;                             // criticalPaths[0].MatchNum
 };
+using TopologyPair = std::pair<std::string, std::string>;
+struct InterPodState {  // interpodaffinity preFilterState
+  bool written = false;
+  std::map<TopologyPair, int64_t> existing_anti, affinity, anti;  // existingAntiAffinityCounts, affinityCounts, antiAffinityCounts
+};
 struct CycleState {
+  InterPodState ipa;
   bool affinity_written = false;
   bool ports_written = false;
   std::vector<HostPort> want_ports;
@@ -841,6 +876,82 @@ static Status spread_filter(const Pod& p, const CycleState& st, const NodeInfo& 
   return {};
 }
 
+// --- InterPodAffinity (pins: predicate_manager_test.go:1171-2113) --------------------------------------
+// framework.AffinityTerm.Matches(pod, nil): the term's namespaces (default: the OWNING pod's namespace) contain the
+// pod's namespace and the selector matches its labels.
+static bool affinity_term_matches(const PodAffinityTerm& t, const std::string& owner_ns, const Pod& target) {
+  bool ns_ok = t.namespaces.empty() ? target.ns == owner_ns
+                                    : std::find(t.namespaces.begin(), t.namespaces.end(), target.ns) != t.namespaces.end();
+  if (!ns_ok) return false;
+  bool e = false;
+  return selector_matches(t.selector, target.labels, &e);
+}
+static bool pod_matches_all_affinity_terms(const std::vector<PodAffinityTerm>& terms, const std::string& owner_ns, const Pod& target) {
+  if (terms.empty()) return false;
+  for (auto& t : terms)
+    if (!affinity_term_matches(t, owner_ns, target)) return false;
+  return true;
+}
+static void topo_update(std::map<TopologyPair, int64_t>& m, const Node& node, const std::string& key, int64_t v) {
+  auto it = node.labels.find(key);
+  if (it != node.labels.end()) m[{key, it->second}] += v;
+}
+static Status interpod_prefilter(const Pod& p, const std::vector<NodeInfo>& all, CycleState& st) {
+  InterPodState& s = st.ipa;
+  for (auto* terms : {&p.pod_affinity, &p.pod_anti_affinity})
+    for (auto& t : *terms) {
+      bool e = false;
+      selector_matches(t.selector, p.labels, &e);
+      if (e) return {Status::UnschedulableAndUnresolvable, "parsing pod: invalid label selector in pod (anti)affinity term"};
+    }
+  // getExistingAntiAffinityCounts: existing pods whose required anti-affinity terms match the incoming pod
+  for (auto& ni : all)
+    for (const Pod* ep : ni.pods)
+      for (auto& t : ep->pod_anti_affinity)
+        if (affinity_term_matches(t, ep->ns, p)) topo_update(s.existing_anti, ni.node, t.topology_key, 1);
+  // getIncomingAffinityAntiAffinityCounts
+  for (auto& ni : all)
+    for (const Pod* ep : ni.pods) {
+      if (pod_matches_all_affinity_terms(p.pod_affinity, p.ns, *ep))
+        for (auto& t : p.pod_affinity) topo_update(s.affinity, ni.node, t.topology_key, 1);
+      for (auto& t : p.pod_anti_affinity)
+        if (affinity_term_matches(t, p.ns, *ep)) topo_update(s.anti, ni.node, t.topology_key, 1);
+    }
+  if (s.existing_anti.empty() && p.pod_affinity.empty() && p.pod_anti_affinity.empty()) return {Status::Skip, ""};
+  s.written = true;
+  return {};
+}
+static Status interpod_filter(const Pod& p, const CycleState& st, const NodeInfo& ni) {
+  const InterPodState& s = st.ipa;
+  if (!s.written) return {Status::Error, "reading \"PreFilterInterPodAffinity\" from cycleState: not found"};
+  const Node& node = ni.node;
+  // satisfyPodAffinity
+  bool pods_exist = true;
+  for (auto& t : p.pod_affinity) {
+    auto it = node.labels.find(t.topology_key);
+    if (it == node.labels.end())
+      return {Status::UnschedulableAndUnresolvable, "node(s) didn't match pod affinity rules"};  // all topology labels must exist
+    auto c = s.affinity.find({t.topology_key, it->second});
+    if (c == s.affinity.end() || c->second <= 0) pods_exist = false;
+  }
+  if (!pods_exist && !(s.affinity.empty() && pod_matches_all_affinity_terms(p.pod_affinity, p.ns, p)))
+    return {Status::UnschedulableAndUnresolvable, "node(s) didn't match pod affinity rules"};
+  // satisfyPodAntiAffinity
+  for (auto& t : p.pod_anti_affinity) {
+    auto it = node.labels.find(t.topology_key);
+    if (it == node.labels.end()) continue;
+    auto c = s.anti.find({t.topology_key, it->second});
+    if (c != s.anti.end() && c->second > 0) return {Status::Unschedulable, "node(s) didn't match pod anti-affinity rules"};
+  }
+  // satisfyExistingPodsAntiAffinity
+  for (auto& kv : node.labels) {
+    auto c = s.existing_anti.find({kv.first, kv.second});
+    if (c != s.existing_anti.end() && c->second > 0)
+      return {Status::Unschedulable, "node(s) didn't satisfy existing pods anti-affinity rules"};
+  }
+  return {};
+}
+
 // --- the three stateless filters --------------------------------------------------------------------
 static Status nodeunschedulable_filter(const Pod& p, const NodeInfo& ni) {
   if (!ni.node.unschedulable) return {};
@@ -880,7 +991,8 @@ static bool run_prefilters(const Snapshot& snap, const Pod& p, const NodeInfo& t
   static const Pre order[] = {{kNodeAffinity, kCodeNodeAffinity},
                               {kNodePorts, kCodeNodePorts},
                               {kNodeResourcesFit, kCodeNodeResourcesFit},
-                              {kPodTopologySpread, kCodePodTopologySpread}};
+                              {kPodTopologySpread, kCodePodTopologySpread},
+                              {kInterPodAffinity, kCodeInterPodAffinity}};
   for (const Pre& pl : order) {
     if (!(pre_mask & pl.bit)) continue;
     PreFilterResult res;
@@ -891,8 +1003,10 @@ static bool run_prefilters(const Snapshot& snap, const Pod& p, const NodeInfo& t
       s = nodeports_prefilter(p, st);
     else if (pl.bit == kNodeResourcesFit)
       s = fit_prefilter(p, st);
-    else
+    else if (pl.bit == kPodTopologySpread)
       s = spread_prefilter(p, snap.nodes, st);
+    else
+      s = interpod_prefilter(p, snap.nodes, st);
     if (s.is_skip()) {
       *skip |= pl.bit;  // :233-234
     } else if (!s.is_success()) {
@@ -921,7 +1035,7 @@ static void run_filters(const Pod& p, const NodeInfo& ni, uint32_t filt_mask, ui
   static const Filt order[] = {{kNodeUnschedulable, kCodeNodeUnschedulable}, {kNodeName, kCodeNodeName},
                                {kTaintToleration, kCodeTaintToleration},     {kNodeAffinity, kCodeNodeAffinity},
                                {kNodePorts, kCodeNodePorts},                 {kNodeResourcesFit, kCodeNodeResourcesFit},
-                               {kPodTopologySpread, kCodePodTopologySpread}};
+                               {kPodTopologySpread, kCodePodTopologySpread}, {kInterPodAffinity, kCodeInterPodAffinity}};
   for (const Filt& pl : order) {
     if (!(filt_mask & pl.bit)) continue;
     if (skip & pl.bit) continue;  // :264-266
@@ -934,6 +1048,7 @@ static void run_filters(const Pod& p, const NodeInfo& ni, uint32_t filt_mask, ui
       case kNodePorts: s = nodeports_filter(p, st, ni); break;
       case kNodeResourcesFit: s = fit_filter(st, ni); break;
       case kPodTopologySpread: s = spread_filter(p, st, ni); break;
+      case kInterPodAffinity: s = interpod_filter(p, st, ni); break;
       default: break;
     }
     if (!s.is_success()) {

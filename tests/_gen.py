@@ -19,7 +19,7 @@ def rand_port(rng):
     return p
 
 
-def rand_node(rng, i, scalars=True):
+def rand_node(rng, i, scalars=True, interpod=False):
     name = f"node-{i}" if not (i == 0 and rng.random() < 0.3) else ""
     labels = {}
     if rng.random() < 0.9:
@@ -61,6 +61,8 @@ def rand_node(rng, i, scalars=True):
         if rng.random() < 0.15:
             cont["ports"] = [rand_port(rng) for _ in range(rng.choice([1, 1, 2]))]
         entry = {"metadata": meta, "spec": {"containers": [cont]}}
+        if interpod and rng.random() < 0.2:
+            entry["spec"]["affinity"] = rand_pod_affinity(rng)
         if rng.random() < 0.2:
             entry["replicas"] = rng.choice([2, 3])
         pods.append(entry)
@@ -91,6 +93,37 @@ def rand_field(rng, n_nodes):
     key = rng.choice(["metadata.name", "metadata.name", "metadata.name", "metadata.namespace"])
     vals = [rng.choice([f"node-{rng.randrange(max(n_nodes, 1))}", "nope", ""]) for _ in range(rng.choice([1, 1, 1, 2, 0]))]
     return {"key": key, "operator": op, "values": vals}
+
+
+def rand_pod_terms(rng):
+    """1-2 required pod (anti)affinity terms over the app / tier labels and a few topology keys."""
+    terms = []
+    for _ in range(rng.choice([1, 1, 2])):
+        k = rng.random()
+        if k < 0.5:
+            selector = {"matchLabels": {"app": rng.choice(TEAMS)}}
+        elif k < 0.8:
+            selector = {"matchExpressions": [{"key": "app", "operator": rng.choice(["In", "NotIn"]), "values": rng.sample(TEAMS, rng.choice([1, 2]))}]}
+        elif k < 0.9:
+            selector = {"matchExpressions": [{"key": "app", "operator": "Exists"}]}
+        else:
+            selector = {}
+        t = {"labelSelector": selector, "topologyKey": rng.choice(["zone", "zone", "kubernetes.io/hostname", "example.com/tier", "missing-key"])}
+        if rng.random() < 0.25:
+            t["namespaces"] = rng.sample(["default", "other", "third"], rng.choice([1, 2]))
+        if rng.random() < 0.05:
+            t.pop("labelSelector")
+        terms.append(t)
+    return terms
+
+
+def rand_pod_affinity(rng):
+    a = {}
+    if rng.random() < 0.5:
+        a["podAffinity"] = {"requiredDuringSchedulingIgnoredDuringExecution": rand_pod_terms(rng)}
+    if rng.random() < 0.6 or not a:
+        a["podAntiAffinity"] = {"requiredDuringSchedulingIgnoredDuringExecution": rand_pod_terms(rng)}
+    return a
 
 
 def rand_spread(rng):
@@ -125,7 +158,7 @@ def rand_spread(rng):
     return out
 
 
-def rand_pod(rng, i, n_nodes, scalars=True, spread=False):
+def rand_pod(rng, i, n_nodes, scalars=True, spread=False, interpod=False):
     spec = {}
     req = {}
     if rng.random() < 0.8:
@@ -197,13 +230,16 @@ def rand_pod(rng, i, n_nodes, scalars=True, spread=False):
         spec["nodeName"] = rng.choice([f"node-{rng.randrange(max(n_nodes, 1))}", "ghost"])
     if spread and rng.random() < 0.5:
         spec["topologySpreadConstraints"] = rand_spread(rng)
-    return {"metadata": {"name": f"pod-{i}", "uid": f"pod-{i}", "namespace": "default", "labels": {"app": rng.choice(TEAMS)}}, "spec": spec}
+    if interpod and rng.random() < 0.5:
+        spec.setdefault("affinity", {}).update(rand_pod_affinity(rng))
+    ns = rng.choice(["default", "default", "other"]) if interpod else "default"
+    return {"metadata": {"name": f"pod-{i}", "uid": f"pod-{i}", "namespace": ns, "labels": {"app": rng.choice(TEAMS)}}, "spec": spec}
 
 
-def random_snapshot(seed, n_nodes, n_pods, scalars=True, spread=False):
+def random_snapshot(seed, n_nodes, n_pods, scalars=True, spread=False, interpod=False):
     rng = random.Random(seed)
-    nodes = [rand_node(rng, i, scalars) for i in range(n_nodes)]
-    pods = [rand_pod(rng, i, n_nodes, scalars, spread) for i in range(n_pods)]
+    nodes = [rand_node(rng, i, scalars, interpod) for i in range(n_nodes)]
+    pods = [rand_pod(rng, i, n_nodes, scalars, spread, interpod) for i in range(n_pods)]
     # a few exact duplicates so that classes have several members
     for i in range(min(n_pods // 4, 16)):
         src = pods[rng.randrange(len(pods))]

@@ -18,14 +18,17 @@ PLUGIN_BITS = {
     "NodePorts": 1 << 4,
     "NodeResourcesFit": 1 << 5,
     "PodTopologySpread": 1 << 6,
+    "InterPodAffinity": 1 << 7,
 }
 PLUGIN_NAMES = ["", "NodeUnschedulable", "NodeName", "TaintToleration", "NodeAffinity", "NodePorts", "NodeResourcesFit",
-                "PodTopologySpread"]
+                "PodTopologySpread", "InterPodAffinity"]
 ALL = sum(PLUGIN_BITS.values())
 # predicate_manager.go:321-368 — reservation phase lists restricted to the plugins of this path
-RESERVE_PRE = PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"]
+RESERVE_PRE = (PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"]
+               | PLUGIN_BITS["InterPodAffinity"])
 RESERVE_FILT = (PLUGIN_BITS["NodeUnschedulable"] | PLUGIN_BITS["NodeName"] | PLUGIN_BITS["TaintToleration"]
-                | PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"])
+                | PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"]
+                | PLUGIN_BITS["InterPodAffinity"])
 
 
 def mask_of(names):

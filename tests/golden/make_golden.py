@@ -163,8 +163,108 @@ HOST_PORTS = [
 ]
 
 
+# ---------------------------------------------------------------------------------------------------------
+# TestInterPodAffinity — predicate_manager_test.go:1171-2113; plugins InterPodAffinity + NodeAffinity (:1172); the node is
+# machine1 {region: r1, zone: z11} (:1177-1182) and only the listed pods whose nodeName is machine1 are on it (:2097-2107).
+# ---------------------------------------------------------------------------------------------------------
+def sel(*exprs):
+    return {"matchExpressions": list(exprs)}
+
+
+def pterm(selector, key=None, namespaces=None):
+    t = {"labelSelector": selector}
+    if key is not None:
+        t["topologyKey"] = key
+    if namespaces is not None:
+        t["namespaces"] = namespaces
+    return t
+
+
+def aff_spec(affinity=None, anti=None, node_name=None):
+    a = {}
+    if affinity is not None:
+        a["podAffinity"] = {"requiredDuringSchedulingIgnoredDuringExecution": affinity}
+    if anti is not None:
+        a["podAntiAffinity"] = {"requiredDuringSchedulingIgnoredDuringExecution": anti}
+    spec = {"affinity": a} if a else {}
+    if node_name:
+        spec["nodeName"] = node_name
+    return spec
+
+
+POD_LABEL = {"service": "securityscan"}
+POD_LABEL2 = {"security": "S1"}
+IN_SCAN = expr("service", "In", ["securityscan", "value2"])
+IN_ANTIVIRUS = expr("service", "In", ["antivirusscan", "value2"])
+NOTIN_SCAN = expr("service", "NotIn", ["securityscan", "value2"])
+EX_SERVICE, EX_SECURITY = expr("service", "Exists"), expr("security", "Exists")
+EX_ABC, EX_DEF = expr("abc", "Exists"), expr("def", "Exists")
+
+
+def existing(labels, spec=None, ns=None, uid="existing"):
+    meta = {"labels": labels, "uid": uid}
+    if ns:
+        meta["namespace"] = ns
+    return {"metadata": meta, "spec": dict(spec or {}, nodeName="machine1")}
+
+
+INTERPOD = [
+    (1194, "no required pod affinity rules, no existing pods", pod(), [], True),
+    (1225, "PodAffinity In matches the existing pod", pod(aff_spec([pterm(sel(IN_SCAN), "region")]), labels=POD_LABEL2),
+     [existing(POD_LABEL)], True),
+    (1256, "PodAffinity NotIn matches the existing pod",
+     pod(aff_spec([pterm(sel(expr("service", "NotIn", ["securityscan3", "value3"])), "region")]), labels=POD_LABEL2),
+     [existing(POD_LABEL)], True),
+    (1287, "PodAffinity: different namespace", pod(aff_spec([pterm(sel(IN_SCAN), None, ["DiffNameSpace"])]), labels=POD_LABEL2),
+     [existing(POD_LABEL, ns="ns")], False),
+    (1317, "PodAffinity: unmatching labelSelector", pod(aff_spec([pterm(sel(IN_ANTIVIRUS))]), labels=POD_LABEL),
+     [existing(POD_LABEL)], False),
+    (1365, "PodAffinity: different operators in multiple terms",
+     pod(aff_spec([pterm(sel(EX_SERVICE, expr("wrongkey", "DoesNotExist")), "region"),
+                   pterm(sel(expr("service", "In", ["securityscan"]), expr("service", "NotIn", ["WrongValue"])), "region")]),
+         labels=POD_LABEL2), [existing(POD_LABEL)], True),
+    (1413, "PodAffinity: matchExpressions are ANDed, one does not match",
+     pod(aff_spec([pterm(sel(EX_SERVICE, expr("wrongkey", "DoesNotExist")), "region"),
+                   pterm(sel(expr("service", "In", ["securityscan2"]), expr("service", "NotIn", ["WrongValue"])), "region")]),
+         labels=POD_LABEL2), [existing(POD_LABEL)], False),
+    (1460, "PodAffinity and PodAntiAffinity satisfied",
+     pod(aff_spec([pterm(sel(IN_SCAN), "region")], [pterm(sel(IN_ANTIVIRUS), "node")]), labels=POD_LABEL2),
+     [existing(POD_LABEL)], True),
+    (1532, "PodAffinity, PodAntiAffinity and symmetry satisfied",
+     pod(aff_spec([pterm(sel(IN_SCAN), "region")], [pterm(sel(IN_ANTIVIRUS), "node")]), labels=POD_LABEL2),
+     [existing(POD_LABEL, aff_spec(anti=[pterm(sel(IN_ANTIVIRUS), "node")]))], True),
+    (1579, "PodAffinity satisfied, PodAntiAffinity not",
+     pod(aff_spec([pterm(sel(IN_SCAN), "region")], [pterm(sel(IN_SCAN), "zone")]), labels=POD_LABEL2),
+     [existing(POD_LABEL)], False),
+    (1651, "PodAntiAffinity symmetry with the existing pod violated",
+     pod(aff_spec([pterm(sel(IN_SCAN), "region")], [pterm(sel(IN_ANTIVIRUS), "node")]), labels=POD_LABEL),
+     [existing(POD_LABEL, aff_spec(anti=[pterm(sel(IN_SCAN), "zone")]))], False),
+    (1682, "pod does not match its own affinity term and no pod is on the node",
+     pod(aff_spec([pterm(sel(NOTIN_SCAN), "region")]), labels=POD_LABEL), [], False),  # the listed pod sits on machine2
+    (1717, "existing pod's anti-affinity respected (violated)", pod(labels=POD_LABEL),
+     [existing(POD_LABEL, aff_spec(anti=[pterm(sel(IN_SCAN), "zone")]))], False),
+    (1752, "existing pod's anti-affinity respected (satisfied)", pod(labels=POD_LABEL),
+     [existing(POD_LABEL, aff_spec(anti=[pterm(sel(NOTIN_SCAN), "zone")]))], True),
+    (1816, "incoming anti-affinity ok, symmetry with incoming pod violated",
+     pod(aff_spec(anti=[pterm(sel(EX_SERVICE), "region"), pterm(sel(EX_SECURITY), "region")]), labels=POD_LABEL),
+     [existing(POD_LABEL2, aff_spec(anti=[pterm(sel(EX_SECURITY), "zone")]))], False),
+    (1879, "symmetry check a1", pod(aff_spec(anti=[pterm(sel(EX_SERVICE), "zone"), pterm(sel(EX_SECURITY), "zone")]), labels=POD_LABEL),
+     [existing(POD_LABEL2, aff_spec(anti=[pterm(sel(EX_SECURITY), "zone")]))], False),
+    (1942, "symmetry check a2", pod(aff_spec(anti=[pterm(sel(EX_SECURITY), "zone")]), labels=POD_LABEL2),
+     [existing(POD_LABEL, aff_spec(anti=[pterm(sel(EX_SERVICE), "zone"), pterm(sel(EX_SECURITY), "zone")]))], False),
+    (2016, "symmetry check b1", pod(aff_spec(anti=[pterm(sel(EX_ABC), "zone"), pterm(sel(EX_DEF), "zone")]), labels={"abc": "", "xyz": ""}),
+     [existing({"def": "", "xyz": ""}, aff_spec(anti=[pterm(sel(EX_ABC), "zone"), pterm(sel(EX_DEF), "zone")]))], False),
+    (2090, "symmetry check b2", pod(aff_spec(anti=[pterm(sel(EX_ABC), "zone"), pterm(sel(EX_DEF), "zone")]), labels={"def": "", "xyz": ""}),
+     [existing({"abc": "", "xyz": ""}, aff_spec(anti=[pterm(sel(EX_ABC), "zone"), pterm(sel(EX_DEF), "zone")]))], False),
+]
+
+
 def predicate_cases():
     cases = []
+    for line, name, p, on_node, fits in INTERPOD:
+        cases.append({"test": "TestInterPodAffinity", "name": name, "source": f"{PM}:{line}",
+                      "plugins": ["InterPodAffinity", "NodeAffinity"], "allocate": True, "pod": p,
+                      "node": node("machine1", {"region": "r1", "zone": "z11"}, pods=on_node), "fits": fits})
     for line, name, p, existing, fits in HOST_PORTS:
         on_node = [port_pod("m1", *existing, uid="existing")] if existing else []
         cases.append({"test": "TestPodFitsHostPorts", "name": name, "source": f"{PM}:{line}", "plugins": ["NodePorts"],

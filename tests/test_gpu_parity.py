@@ -148,6 +148,42 @@ def test_random_clusters_with_topology_spread(pm, seed, allocate):
     check_against_oracle(pm, snap, allocate)
 
 
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("allocate", [True, False])
+def test_random_clusters_with_inter_pod_affinity(pm, seed, allocate):
+    """InterPodAffinity: required affinity (all terms on one pod, self-match escape), anti-affinity, and the symmetry rule
+    from existing pods' anti-affinity; namespaces, nil/empty selectors, missing topology keys — combined with spread."""
+    snap = _gen.random_snapshot(7000 + seed, n_nodes=50 + 19 * seed, n_pods=70, spread=(seed % 2 == 0), interpod=True)
+    pm.load_snapshot(snap)
+    check_against_oracle(pm, snap, allocate)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("plugins", [["InterPodAffinity"], ["PodTopologySpread"], ["InterPodAffinity", "PodTopologySpread", "NodePorts"]])
+def test_topology_plugins_alone(seed, plugins):
+    """Only the topology plugins enabled, so that every verdict of the grid is theirs (with the full default set most
+    random pairs already fail an earlier plugin)."""
+    snap = _gen.random_snapshot(7200 + seed, n_nodes=64 + 21 * seed, n_pods=80, spread=True, interpod=True)
+    m = pkg.GpuPredicateManager.internal(plugins, plugins, plugins, plugins)
+    try:
+        m.load_snapshot(snap)
+        mask = orc.mask_of(plugins)
+        o, want = check_against_oracle(m, snap, True, pre=mask, filt=mask)
+        assert 0 < want.sum() < want.size, "degenerate case: the plugins accept or reject everything"
+    finally:
+        m.close()
+
+
+def test_inter_pod_affinity_filter_without_prefilter():
+    snap = _gen.random_snapshot(7100, n_nodes=60, n_pods=40, interpod=True)
+    m = pkg.GpuPredicateManager.internal([], [], ["InterPodAffinity"], ["InterPodAffinity"])
+    try:
+        m.load_snapshot(snap)
+        check_against_oracle(m, snap, True, pre=0, filt=orc.PLUGIN_BITS["InterPodAffinity"])
+    finally:
+        m.close()
+
+
 def test_topology_spread_filter_without_prefilter():
     snap = _gen.random_snapshot(5100, n_nodes=80, n_pods=40, spread=True)
     m = pkg.GpuPredicateManager.internal([], [], ["PodTopologySpread"], ["PodTopologySpread"])
@@ -339,9 +375,10 @@ def test_incremental_at_full_size(pm):
 
 def test_unsupported_pods_are_rejected_loudly(pm):
     pod = {"metadata": {"name": "p", "uid": "p"},
-           "spec": {"affinity": {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": []}}, "containers": []}}
+           "spec": {"affinity": {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+               {"topologyKey": "zone", "labelSelector": {}, "namespaceSelector": {}}]}}, "containers": []}}
     pm.load_snapshot({"nodes": [{"metadata": {"name": "n"}}], "pods": [pod]})
-    with pytest.raises(RuntimeError, match="InterPodAffinity"):
+    with pytest.raises(RuntimeError, match="namespaceSelector"):
         pm.evaluate()
 
 

@@ -339,6 +339,7 @@ int build_spread_tables(ykpred_engine* e, hipStream_t st) {
       r.min_domains = c.min_domains;
       r.self_match = c.self_match;
       r.flags = c.flags;
+      r.kind = c.kind;
       r.dom_size = (size_t)c.topology_key < e->h_domain_sizes.size() ? e->h_domain_sizes[(size_t)c.topology_key] : 0;
       r.cnt_off = (int)cells;
       cells += r.dom_size;
@@ -437,7 +438,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   }
   if (cfg->topology_keys < 0 || cfg->topology_keys > ykk::kMaxKD || cfg->selector_classes < 0 || cfg->selector_classes > 4096 ||
       cfg->port_words < 0 || cfg->port_words > ykk::kMaxKP) {
-    g_create_error = "config out of range: need 0<=KD<=4 topology keys, 0<=KS<=4096 selector classes, 0<=KP<=4 port words";
+    g_create_error = "config out of range: need 0<=KD<=8 topology keys, 0<=KS<=4096 selector classes, 0<=KP<=4 port words";
     return YKPRED_E_UNSUPPORTED;
   }
   int ndev = 0;
@@ -759,10 +760,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   const unsigned pre = a->prefilter_plugins, filt = a->filter_plugins;
   const bool spread_filt = filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD, spread_pre = pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
-  // Filter without PreFilter state (PodTopologySpread, NodePorts): every pair fails with an Error status
-  const bool spread_err = (spread_filt && !spread_pre) || ((filt & YKPRED_PLUGIN_NODE_PORTS) && !(pre & YKPRED_PLUGIN_NODE_PORTS));
+  const bool ipa_filt = filt & YKPRED_PLUGIN_INTER_POD_AFFINITY, ipa_pre = pre & YKPRED_PLUGIN_INTER_POD_AFFINITY;
+  // Filter without PreFilter state (PodTopologySpread, NodePorts, InterPodAffinity): every pair fails with an Error status
+  const bool spread_err = (spread_filt && !spread_pre) || (ipa_filt && !ipa_pre) ||
+                          ((filt & YKPRED_PLUGIN_NODE_PORTS) && !(pre & YKPRED_PLUGIN_NODE_PORTS));
   if (e->spread_dirty) TRY(build_spread_tables(e, e->own_stream));
-  const bool spread_on = spread_filt && spread_pre && e->fam_spread.D > 0;
+  const bool pts_en = spread_filt && spread_pre, ipa_en = ipa_filt && ipa_pre;
+  const bool spread_on = (pts_en || ipa_en) && e->fam_spread.D > 0;  // the topology-constraint family (spread + inter-pod affinity)
   const int N = e->N, P = e->P;
   const size_t bitmap_bytes = (size_t)std::max(P, 1) * (size_t)e->row_stride * sizeof(u64);
   u64* bitmap = (u64*)a->bitmap;
@@ -911,6 +915,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     pa.spreads = spread_sigs(e);
     pa.fit_error = fit_error;
     pa.n_words = e->row_words;
+    pa.spread_en = pts_en ? 1 : 0;
+    pa.ipa_en = ipa_en ? 1 : 0;
     unsigned xchunks = std::max(sig_chunks(pa.res.D), sig_chunks(pa.spread.D));
     tm.begin(st);
     hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, st, nt, pa);
@@ -982,8 +988,8 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   u64* bitmap = a->bitmap ? (u64*)a->bitmap : e->d_bitmap.as<u64>();
   if (e->classes_dirty || !e->last_eval_valid || pre != e->last_pre || filt != e->last_filt || (void*)bitmap != e->last_bitmap)
     return fail(e, YKPRED_E_STATE, "eval_nodes: no matching previous ykpred_eval (tables, plugin lists or bitmap changed)");
-  if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) && e->fam_spread.D > 0)
-    return fail(e, YKPRED_E_UNSUPPORTED, "eval_nodes: PodTopologySpread histograms couple all nodes — run ykpred_eval");
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0)
+    return fail(e, YKPRED_E_UNSUPPORTED, "eval_nodes: PodTopologySpread / InterPodAffinity histograms couple all nodes — run ykpred_eval");
   for (int i = 0; i < num_nodes; ++i)
     if (node_index[i] < 0 || node_index[i] >= e->N) return fail(e, YKPRED_E_INVALID, "eval_nodes: node index out of range");
   Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
@@ -1154,7 +1160,7 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
   uint32_t* d_r = (uint32_t*)(d_n + n);
   uint8_t* d_f = (uint8_t*)(d_r + n);
   uint8_t* d_c = d_f + n;
-  if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   HIPCHK(hipMemcpyAsync(d_p, pods, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_n, nodes, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1175,7 +1181,7 @@ int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod, int32_t node, i
   if (pod < 0 || pod >= e->P || node < 0 || node >= e->N) return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
-  if ((pre & filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   const size_t vbytes = (size_t)nv * (size_t)e->R * sizeof(i64);
   const size_t pbytes = (ports_after && e->KP > 0) ? (size_t)nv * (size_t)e->KP * sizeof(u64) : 0;

@@ -32,7 +32,7 @@ typedef long long i64;
 constexpr int kMaxR = 8;   // resource dimensions
 constexpr int kMaxKT = 4;  // taint dictionary words (256 taints)
 constexpr int kMaxW = 8;   // requirement dictionary words (512 requirements)
-constexpr int kMaxKD = 4;  // topology keys used by hard spread constraints
+constexpr int kMaxKD = 8;  // topology keys used by spread / inter-pod-affinity constraints
 constexpr int kMaxKP = 4;  // host-port dictionary words (256 distinct requested host ports)
 
 constexpr int kWave = 64;
@@ -46,7 +46,8 @@ constexpr int kCombineUnroll = 4;   // row words per thread held in registers by
 // plugin bits (mirror include/ykpred.h)
 constexpr unsigned kSpreadHonorAffinity = 1u << 0, kSpreadHonorTaints = 1u << 1;
 constexpr unsigned kPlugUnsched = 1u << 0, kPlugNodeName = 1u << 1, kPlugTaint = 1u << 2, kPlugAffinity = 1u << 3,
-                   kPlugPorts = 1u << 4, kPlugFit = 1u << 5, kPlugSpread = 1u << 6;
+                   kPlugPorts = 1u << 4, kPlugFit = 1u << 5, kPlugSpread = 1u << 6, kPlugInterPod = 1u << 7;
+constexpr int kKindSpread = 0, kKindPodAffinity = 1, kKindPodAntiAffinity = 2, kKindExistingAnti = 3;
 constexpr unsigned kSpecToleratesUnsched = 1u << 0, kSpecAffSkip = 1u << 1, kSpecPreReject = 1u << 2, kSpecPreNames = 1u << 3;
 constexpr unsigned kNodeUnschedulable = 1u << 0;
 
@@ -416,10 +417,11 @@ __global__ __launch_bounds__(kBlock) void k_permute_planes(int n_nodes, const in
 // The reference recomputes the histogram for EVERY (pod,node) call (predicate_manager.go:221-254 lists all nodes per
 // pair); here it is built once per distinct (constraints, eligibility) signature.
 // ---------------------------------------------------------------------------------------------------
-struct SpreadC {  // one hard constraint of one spread signature
+struct SpreadC {  // one constraint of one topology signature (PodTopologySpread constraints first, then InterPodAffinity)
   int kd, ks, max_skew, min_domains, self_match;
   unsigned flags;
   int cnt_off, dom_size;  // cells [cnt_off, cnt_off + dom_size) of cnt/present belong to this constraint
+  int kind;               // kKind*
 };
 struct SpreadSigs {
   int D;                // signatures
@@ -432,40 +434,43 @@ struct SpreadSigs {
   int* minv;            // [G] global minimum after the minDomains rule                           (criticalPaths / minMatchNum)
 };
 
-// thread = node; blockIdx.x = signature, blockIdx.y = block of 256 nodes. Eligible nodes add their selector counts to
-// their domain's cell.
+// thread = node; blockIdx.x = signature, blockIdx.y = block of 256 nodes. Eligible nodes add their match counts to their
+// domain's cell. PodTopologySpread: the node must carry ALL topology keys of the signature's spread constraints and
+// pass the inclusion policies. InterPodAffinity: the node only needs the constraint's own key (topologyToMatchedTermCount.update).
 __global__ __launch_bounds__(kBlock) void k_spread_count(NodeTable t, SpreadSigs sp, AffSigs aff, const u64* __restrict__ sig_tol) {
   const int n = blockIdx.y * kBlock + threadIdx.x;
   if (n >= t.n) return;
   const int d = blockIdx.x;
   const int c0 = sp.c_off[d], c1 = sp.c_off[d + 1];
-  // nodeLabelsMatchSpreadConstraints: all topology keys of the signature must be present on the node
-  for (int g = c0; g < c1; ++g)
-    if (t.domain[(size_t)sp.c[g].kd * t.n + n] < 0) return;
-  bool need_aff = false, need_tol = false;
+  bool spread_keys = true, need_aff = false, need_tol = false;
   for (int g = c0; g < c1; ++g) {
+    if (sp.c[g].kind != kKindSpread) continue;
+    if (t.domain[(size_t)sp.c[g].kd * t.n + n] < 0) spread_keys = false;  // nodeLabelsMatchSpreadConstraints
     need_aff |= (sp.c[g].flags & kSpreadHonorAffinity) != 0;
     need_tol |= (sp.c[g].flags & kSpreadHonorTaints) != 0;
   }
   bool aff_ok = true, tol_ok = true;
-  if (need_aff) {
+  if (spread_keys && need_aff) {
     u64 lb[kMaxW];
 #pragma unroll
     for (int w = 0; w < kMaxW; ++w) lb[w] = w < t.W ? t.labels[(size_t)w * t.n + n] : 0;
     const int a = sp.aff_sig[d];
     aff_ok = dnf_match(aff.terms, aff.term_off[a], aff.term_off[a + 1], lb, t.W);
   }
-  if (need_tol) {
+  if (spread_keys && need_tol) {
     const u64* tol = sig_tol + (size_t)sp.tol_sig[d] * t.KT;
     for (int k = 0; k < t.KT; ++k) tol_ok = tol_ok && (t.taints[(size_t)k * t.n + n] & ~tol[k]) == 0;
   }
   for (int g = c0; g < c1; ++g) {
     const SpreadC c = sp.c[g];
-    if ((c.flags & kSpreadHonorAffinity) && !aff_ok) continue;  // matchNodeInclusionPolicies
-    if ((c.flags & kSpreadHonorTaints) && !tol_ok) continue;
     const int dom = t.domain[(size_t)c.kd * t.n + n];
-    if (dom >= c.dom_size) continue;
-    sp.present[c.cnt_off + dom] = 1;
+    if (dom < 0 || dom >= c.dom_size) continue;
+    if (c.kind == kKindSpread) {
+      if (!spread_keys) continue;
+      if ((c.flags & kSpreadHonorAffinity) && !aff_ok) continue;  // matchNodeInclusionPolicies
+      if ((c.flags & kSpreadHonorTaints) && !tol_ok) continue;
+      sp.present[c.cnt_off + dom] = 1;
+    }
     const int v = c.ks >= 0 ? t.selcount[(size_t)c.ks * t.n + n] : 0;
     if (v) atomicAdd(&sp.cnt[c.cnt_off + dom], v);
   }
@@ -486,27 +491,61 @@ __global__ __launch_bounds__(kWave) void k_spread_min(SpreadSigs sp, int n_const
     mn = min(mn, __shfl_down(mn, off, kWave));
     nd += __shfl_down(nd, off, kWave);
   }
+  if (c.kind != kKindSpread) {
+    // InterPodAffinity: minv holds the total number of matches over all domains (len(affinityCounts) == 0 test)
+    int tot = 0;
+    for (int i = threadIdx.x; i < c.dom_size; i += kWave) tot += sp.cnt[c.cnt_off + i] > 0 ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, kWave);
+    if (threadIdx.x == 0) sp.minv[g] = tot;
+    return;
+  }
   if (threadIdx.x == 0) sp.minv[g] = nd < c.min_domains ? 0 : mn;
 }
-// Filter: fail ⇔ some constraint's topology label is missing, or matchNum + selfMatch − min > maxSkew
-__device__ __forceinline__ bool spread_ok(const SpreadSigs& sp, int d, const int (&dom)[kMaxKD], unsigned* missing) {
+// Filters of the topology constraints of signature d, PodTopologySpread first (Filter order of predicate_manager.go:339-352):
+//   spread:  fail ⇔ the topology label is missing, or matchNum + selfMatch − min > maxSkew
+//   InterPodAffinity (satisfyPodAffinity / satisfyPodAntiAffinity / satisfyExistingPodsAntiAffinity):
+//     every required-affinity key must be on the node; each needs a matching pod in the node's domain unless NO pod
+//     matches anywhere and the pod matches its own terms; an anti-affinity / existing-anti-affinity match in the node's
+//     domain fails.
+// Returns 0 = ok, 7 = PodTopologySpread failed, 8 = InterPodAffinity failed.
+__device__ __forceinline__ int constraints_fail(const SpreadSigs& sp, int d, const int (&dom)[kMaxKD], bool spread_en, bool ipa_en,
+                                                unsigned* missing) {
+  bool pods_exist = true, any_affinity = false, self_match = false;
+  int aff_domains = 0;
+  int ipa_fail = 0;
   for (int g = sp.c_off[d]; g < sp.c_off[d + 1]; ++g) {
     const SpreadC c = sp.c[g];
     int dm = -1;
 #pragma unroll
     for (int k = 0; k < kMaxKD; ++k)
       if (k == c.kd) dm = dom[k];
-    if (dm < 0) {
-      if (missing) *missing = 1;
-      return false;
+    const i64 match = (dm >= 0 && dm < c.dom_size) ? sp.cnt[c.cnt_off + dm] : 0;
+    if (c.kind == kKindSpread) {
+      if (!spread_en) continue;
+      if (dm < 0) {
+        if (missing) *missing = 1;
+        return 7;
+      }
+      const i64 m = (dm < c.dom_size && sp.present[c.cnt_off + dm]) ? match : 0;
+      if (m + c.self_match - (i64)sp.minv[g] > (i64)c.max_skew) return 7;
+    } else if (ipa_en && !ipa_fail) {
+      if (c.kind == kKindPodAffinity) {
+        any_affinity = true;
+        self_match = c.self_match != 0;
+        aff_domains += sp.minv[g];
+        if (dm < 0) ipa_fail = 8;  // all topology labels must exist on the node
+        if (match <= 0) pods_exist = false;
+      } else if (dm >= 0 && match > 0) {
+        ipa_fail = 8;
+      }
     }
-    i64 match = (dm < c.dom_size && sp.present[c.cnt_off + dm]) ? sp.cnt[c.cnt_off + dm] : 0;
-    if (match + c.self_match - (i64)sp.minv[g] > (i64)c.max_skew) return false;
   }
-  return true;
+  if (ipa_en && !ipa_fail && any_affinity && !pods_exist && !(aff_domains == 0 && self_match)) ipa_fail = 8;
+  return ipa_fail;
 }
 __device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __restrict__ perm, const SpreadSigs& sp, const PlaneOut& o,
-                                             int n_words) {
+                                             int n_words, bool spread_en, bool ipa_en) {
   int word;
   int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
@@ -517,7 +556,7 @@ __device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __re
   int dend = min(d0 + kSigsPerBlock, o.D);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
-    bool ok = n >= 0 && spread_ok(sp, d, dom, nullptr);
+    bool ok = n >= 0 && constraints_fail(sp, d, dom, spread_en, ipa_en, nullptr) == 0;
     u64 b = __ballot(ok);
     if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
   }
@@ -532,12 +571,13 @@ struct PlaneArgs {
   const i64* sig_req;
   SpreadSigs spreads;
   int fit_error, n_words;
+  int spread_en, ipa_en;
 };
 __global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
   if (blockIdx.z == 0) {
     if ((int)blockIdx.x * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
   } else {
-    if ((int)blockIdx.x * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words);
+    if ((int)blockIdx.x * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words, a.spread_en != 0, a.ipa_en != 0);
   }
 }
 
@@ -810,20 +850,34 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
       return false;
     }
   }
-  if (filt_mask & kPlugSpread) {
-    if (!(pre_mask & kPlugSpread)) {
-      *code = 7;  // Filter without PreFilter state: Error status
-      return false;
-    }
+  if ((filt_mask & kPlugSpread) && !(pre_mask & kPlugSpread)) {
+    *code = 7;  // Filter without PreFilter state: Error status
+    return false;
+  }
+  {
     const int d = s.spread_sig ? s.spread_sig[spec] : -1;
-    if (d >= 0) {
+    const bool spread_en = filt_mask & kPlugSpread, ipa_en = (filt_mask & kPlugInterPod) && (pre_mask & kPlugInterPod);
+    if (d >= 0 && (spread_en || ipa_en)) {
       unsigned missing = 0;
-      if (!spread_ok(s.spread, d, nr.dom, &missing)) {
+      int f = constraints_fail(s.spread, d, nr.dom, spread_en, ipa_en, &missing);
+      if (f == 7) {
         *code = 7;
         *reason = missing ? (1u << 3) : 0u;
         return false;
       }
+      if ((filt_mask & kPlugInterPod) && !(pre_mask & kPlugInterPod)) {
+        *code = 8;
+        return false;
+      }
+      if (f) {
+        *code = f;
+        return false;
+      }
     }
+  }
+  if ((filt_mask & kPlugInterPod) && !(pre_mask & kPlugInterPod)) {
+    *code = 8;  // Filter without PreFilter state: Error status
+    return false;
   }
   return true;
 }

@@ -179,10 +179,32 @@ struct EncodedSpec {
   std::vector<std::vector<uint64_t>> terms, pre_terms;  // each [W]
   std::vector<ykpred_spread_t> spread;                  // hard (DoNotSchedule) topology spread constraints
 };
+// A "count class": how many pods (or pod/term pairs) on a node match something. One column of selector_count[KS][N].
 struct SelectorClass {
-  std::string ns;
-  LabelSelector selector;
+  enum Kind { kSpread, kAffinityAll, kAntiTerm, kExistingAnti } kind = kSpread;
+  std::string ns;                      // kSpread: the constraint's namespace; others: the owning (incoming) pod's namespace
+  LabelSelector selector;              // kSpread
+  std::vector<PodAffinityTerm> terms;  // kAffinityAll: all required affinity terms; kAntiTerm: one anti-affinity term
+  StrMap labels;                       // kExistingAnti: the incoming pod's labels
+  std::string topology_key;            // kExistingAnti
 };
+// framework.AffinityTerm.Matches(pod, nil): namespace rule (default = owner's namespace) and label selector
+inline bool pod_term_matches(const PodAffinityTerm& t, const std::string& owner_ns, const std::string& target_ns, const StrMap& target_labels) {
+  bool ns_ok = t.namespaces.empty() ? target_ns == owner_ns
+                                    : std::find(t.namespaces.begin(), t.namespaces.end(), target_ns) != t.namespaces.end();
+  if (!ns_ok) return false;
+  bool invalid = false;
+  return selector_matches(t.selector, target_labels, &invalid);
+}
+inline std::string pod_terms_key(const std::vector<PodAffinityTerm>& terms) {
+  std::string k;
+  for (auto& t : terms) {
+    k += selector_key(t.selector.present ? "+" : "-", t.selector);
+    for (auto& n : t.namespaces) k += '\x1c' + n;
+    k += '\x1b';
+  }
+  return k;
+}
 
 class Encoder {
  public:
@@ -214,8 +236,41 @@ class Encoder {
     sel_memo_.clear();
     port_dict.clear();
     port_ix_.clear();
+    // InterPodAffinity: topology keys of the anti-affinity terms carried by pods that are already on nodes
+    existing_anti_templates_.clear();
+    {
+      std::set<const PodTemplate*> seen;
+      for (const NodeInfo* ni : nodes)
+        for (const Pod* p : ni->pods)
+          if (!p->tpl->pod_anti_affinity.empty() && seen.insert(p->tpl).second) {
+            if (p->tpl->pod_affinity_unsupported) return fail("an existing pod uses namespaceSelector / matchLabelKeys in pod (anti)affinity (unsupported)");
+            existing_anti_templates_.push_back(p->tpl);
+            for (auto& term : p->tpl->pod_anti_affinity) {
+              bool invalid = false;
+              selector_matches(term.selector, p->tpl->labels, &invalid);
+              if (invalid) return fail("invalid labelSelector in an existing pod's anti-affinity term");
+              topo_key(term.topology_key);
+            }
+          }
+    }
     for (const PodTemplate* t : templates) {
-      if (t->pod_affinity) return fail("inter-pod affinity is outside the engine's plugin set (InterPodAffinity)");
+      if (t->pod_affinity_unsupported) return fail("pod (anti)affinity namespaceSelector / matchLabelKeys are not supported by the engine");
+      for (auto* terms : {&t->pod_affinity, &t->pod_anti_affinity})
+        for (auto& term : *terms) {
+          bool invalid = false;
+          selector_matches(term.selector, t->labels, &invalid);
+          if (invalid) return fail("invalid labelSelector in a pod (anti)affinity term (InterPodAffinity.PreFilter would reject the pod)");
+          topo_key(term.topology_key);
+        }
+      if (!t->pod_affinity.empty())
+        count_class("A|" + t->ns + '\x1f' + pod_terms_key(t->pod_affinity), SelectorClass{SelectorClass::kAffinityAll, t->ns, {}, t->pod_affinity, {}, ""});
+      for (auto& term : t->pod_anti_affinity)
+        count_class("B|" + t->ns + '\x1f' + pod_terms_key({term}), SelectorClass{SelectorClass::kAntiTerm, t->ns, {}, {term}, {}, ""});
+      for (const PodTemplate* et : existing_anti_templates_)
+        for (auto& term : et->pod_anti_affinity)
+          if (pod_term_matches(term, et->ns, t->ns, t->labels))
+            count_class("E|" + t->ns + '\x1f' + labels_key(t->labels) + '\x1f' + term.topology_key,
+                        SelectorClass{SelectorClass::kExistingAnti, t->ns, {}, {}, t->labels, term.topology_key});
       for (const HostPort& hp : template_host_ports(*t))
         if (port_ix_.emplace(port_key(hp), (int)port_dict.size()).second) port_dict.push_back(hp);
       std::set<std::string> keys_seen;
@@ -226,11 +281,9 @@ class Encoder {
         bool invalid = false;
         selector_matches(c.selector, t->labels, &invalid);
         if (invalid) return fail("invalid labelSelector in topologySpreadConstraints (PodTopologySpread.PreFilter would error)");
-        if (topo_ix_.emplace(c.topology_key, (int)topo_keys.size()).second) topo_keys.push_back(c.topology_key);
-        if (!selector_counts_nothing(c.selector)) {
-          std::string k = selector_key(t->ns, c.selector);
-          if (sel_ix_.emplace(k, (int)sel_classes.size()).second) sel_classes.push_back({t->ns, c.selector});
-        }
+        topo_key(c.topology_key);
+        if (!selector_counts_nothing(c.selector))
+          count_class("S|" + selector_key(t->ns, c.selector), SelectorClass{SelectorClass::kSpread, t->ns, c.selector, {}, {}, ""});
       }
       for (auto& kv : t->requests)
         if (is_scalar_resource_name(kv.first)) scalar(kv.first);
@@ -239,7 +292,7 @@ class Encoder {
     KS = (int)sel_classes.size();
     KP = ((int)port_dict.size() + 63) / 64;
     if (KP > 4) return fail("more than 256 distinct requested host ports (engine limit)");
-    if (KD > 4) return fail("more than 4 distinct topology keys in DoNotSchedule constraints (engine limit)");
+    if (KD > 8) return fail("more than 8 distinct topology keys in spread / pod-affinity constraints (engine limit)");
     domain_ids.assign((size_t)KD, {});
     for (int k = 0; k < KD; ++k) {
       std::set<std::string> values;
@@ -319,18 +372,17 @@ class Encoder {
       const SelectorClass& sc = sel_classes[(size_t)s];
       int32_t c = 0;
       for (const Pod* p : ni.pods) {
-        if (p->terminating || p->tpl->ns != sc.ns) continue;  // countPodsMatchSelector: same namespace, not terminating
+        if (sc.kind == SelectorClass::kSpread && p->terminating) continue;  // countPodsMatchSelector skips terminating pods
         auto key = std::make_pair(p->tpl, s);
         auto m = sel_memo_.find(key);
-        bool match;
+        int contrib;
         if (m == sel_memo_.end()) {
-          bool invalid = false;
-          match = selector_matches(sc.selector, p->tpl->labels, &invalid);
-          sel_memo_.emplace(key, match);
+          contrib = class_contribution(sc, *p->tpl);
+          sel_memo_.emplace(key, contrib);
         } else {
-          match = m->second;
+          contrib = m->second;
         }
-        c += match ? 1 : 0;
+        c += contrib;
       }
       selcount[s] = c;
     }
@@ -470,14 +522,50 @@ class Encoder {
       ykpred_spread_t r{};
       r.topology_key = topo_ix_.at(c.topology_key);
       r.selector_class = -1;
-      if (!selector_counts_nothing(c.selector)) r.selector_class = sel_ix_.at(selector_key(t.ns, c.selector));
+      if (!selector_counts_nothing(c.selector)) r.selector_class = sel_ix_.at("S|" + selector_key(t.ns, c.selector));
       r.max_skew = c.max_skew;
       r.min_domains = c.has_min_domains ? c.min_domains : 1;
       bool invalid = false;
       r.self_match = selector_matches(c.selector, t.labels, &invalid) ? 1 : 0;
       r.flags = (c.node_affinity_policy == "Honor" ? YKPRED_SPREAD_HONOR_AFFINITY : 0u) |
                 (c.node_taints_policy == "Honor" ? YKPRED_SPREAD_HONOR_TAINTS : 0u);
+      r.kind = YKPRED_CONSTRAINT_SPREAD;
       s.spread.push_back(r);
+    }
+    // InterPodAffinity rules (after the spread constraints: Filter order)
+    if (!t.pod_affinity.empty()) {
+      int self = 1;  // podMatchesAllAffinityTerms(terms, the pod itself)
+      for (auto& term : t.pod_affinity)
+        if (!pod_term_matches(term, t.ns, t.ns, t.labels)) self = 0;
+      int cls = sel_ix_.at("A|" + t.ns + '\x1f' + pod_terms_key(t.pod_affinity));
+      for (auto& term : t.pod_affinity) {
+        ykpred_spread_t r{};
+        r.kind = YKPRED_CONSTRAINT_POD_AFFINITY;
+        r.topology_key = topo_ix_.at(term.topology_key);
+        r.selector_class = cls;
+        r.self_match = self;
+        s.spread.push_back(r);
+      }
+    }
+    for (auto& term : t.pod_anti_affinity) {
+      ykpred_spread_t r{};
+      r.kind = YKPRED_CONSTRAINT_POD_ANTI_AFFINITY;
+      r.topology_key = topo_ix_.at(term.topology_key);
+      r.selector_class = sel_ix_.at("B|" + t.ns + '\x1f' + pod_terms_key({term}));
+      s.spread.push_back(r);
+    }
+    {
+      std::set<std::string> keys;  // one symmetry rule per topology key on which some existing term matches this pod
+      for (const PodTemplate* et : existing_anti_templates_)
+        for (auto& term : et->pod_anti_affinity)
+          if (pod_term_matches(term, et->ns, t.ns, t.labels)) keys.insert(term.topology_key);
+      for (auto& k : keys) {
+        ykpred_spread_t r{};
+        r.kind = YKPRED_CONSTRAINT_EXISTING_ANTI_AFFINITY;
+        r.topology_key = topo_ix_.at(k);
+        r.selector_class = sel_ix_.at("E|" + t.ns + '\x1f' + labels_key(t.labels) + '\x1f' + k);
+        s.spread.push_back(r);
+      }
     }
     return s;
   }
@@ -489,8 +577,47 @@ class Encoder {
     }
   };
   std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_, topo_ix_, sel_ix_, port_ix_;
+  std::vector<const PodTemplate*> existing_anti_templates_;  // distinct templates of on-node pods that carry anti-affinity terms
   static std::string port_key(const HostPort& h) { return h.protocol + '\x1f' + h.ip + '\x1f' + std::to_string(h.port); }
-  std::unordered_map<std::pair<const PodTemplate*, int>, bool, MemoHash> sel_memo_;
+  std::unordered_map<std::pair<const PodTemplate*, int>, int, MemoHash> sel_memo_;
+  // how much one pod with template `t` on a node adds to count class `sc`
+  static int class_contribution(const SelectorClass& sc, const PodTemplate& t) {
+    switch (sc.kind) {
+      case SelectorClass::kSpread: {
+        if (t.ns != sc.ns) return 0;
+        bool invalid = false;
+        return selector_matches(sc.selector, t.labels, &invalid) ? 1 : 0;
+      }
+      case SelectorClass::kAffinityAll:  // podMatchesAllAffinityTerms(incoming terms, existing pod)
+        for (auto& term : sc.terms)
+          if (!pod_term_matches(term, sc.ns, t.ns, t.labels)) return 0;
+        return sc.terms.empty() ? 0 : 1;
+      case SelectorClass::kAntiTerm: return pod_term_matches(sc.terms[0], sc.ns, t.ns, t.labels) ? 1 : 0;
+      case SelectorClass::kExistingAnti: {  // the EXISTING pod's anti-affinity terms on this key that match the incoming pod
+        int c = 0;
+        for (auto& term : t.pod_anti_affinity)
+          if (term.topology_key == sc.topology_key && pod_term_matches(term, t.ns, sc.ns, sc.labels)) ++c;
+        return c;
+      }
+    }
+    return 0;
+  }
+  int count_class(const std::string& key, SelectorClass&& sc) {
+    auto it = sel_ix_.find(key);
+    if (it != sel_ix_.end()) return it->second;
+    int id = (int)sel_classes.size();
+    sel_ix_.emplace(key, id);
+    sel_classes.push_back(std::move(sc));
+    return id;
+  }
+  void topo_key(const std::string& k) {
+    if (topo_ix_.emplace(k, (int)topo_keys.size()).second) topo_keys.push_back(k);
+  }
+  static std::string labels_key(const StrMap& m) {
+    std::string k;
+    for (auto& kv : m) k += kv.first + '=' + kv.second + '\x1e';
+    return k;
+  }
 
   bool fail(const std::string& m) {
     error = m;

@@ -21,12 +21,14 @@ namespace ykh {
 
 // Default plugin lists of NewPredicateManager (predicate_manager.go:321-373), restricted to the engine's plugins.
 constexpr uint32_t kAllPlugins = YKPRED_PLUGIN_ALL;
-constexpr uint32_t kReservationPre = YKPRED_PLUGIN_NODE_AFFINITY | YKPRED_PLUGIN_NODE_PORTS | YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
+constexpr uint32_t kReservationPre = YKPRED_PLUGIN_NODE_AFFINITY | YKPRED_PLUGIN_NODE_PORTS | YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD |
+                                     YKPRED_PLUGIN_INTER_POD_AFFINITY;
 constexpr uint32_t kReservationFilt = YKPRED_PLUGIN_NODE_UNSCHEDULABLE | YKPRED_PLUGIN_NODE_NAME | YKPRED_PLUGIN_TAINT_TOLERATION |
-                                      YKPRED_PLUGIN_NODE_AFFINITY | YKPRED_PLUGIN_NODE_PORTS | YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD;
+                                      YKPRED_PLUGIN_NODE_AFFINITY | YKPRED_PLUGIN_NODE_PORTS | YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD |
+                                      YKPRED_PLUGIN_INTER_POD_AFFINITY;
 
 static const char* kPluginNames[] = {"", "NodeUnschedulable", "NodeName", "TaintToleration", "NodeAffinity", "NodePorts",
-                                     "NodeResourcesFit", "PodTopologySpread"};
+                                     "NodeResourcesFit", "PodTopologySpread", "InterPodAffinity"};
 
 struct Rng {  // splitmix64
   uint64_t s;
@@ -363,6 +365,7 @@ std::string compose_message(ykhost* h, const Pod& pod, const NodeInfo& ni, int c
     case YKPRED_CODE_POD_TOPOLOGY_SPREAD:
       if (reason & YKPRED_REASON_MISSING_TOPOLOGY_LABEL) return "node(s) didn't match pod topology spread constraints (missing required label)";
       return "node(s) didn't match pod topology spread constraints";
+    case YKPRED_CODE_INTER_POD_AFFINITY: return "node(s) didn't match pod affinity/anti-affinity rules";
     default: return "unschedulable";
   }
 }
@@ -850,6 +853,7 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
 
 int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched) {
   if (columns_patched) *columns_patched = -1;
+  // topology constraints (spread, inter-pod affinity) couple all nodes through their histograms: full evaluation
   const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0) && h->enc.KD == 0;
   if (!incremental) return ykhost_evaluate(h, allocate, options);
   int rc = sync(h);  // uploads the touched node rows
@@ -883,7 +887,7 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
     copy_out("", msg, msg_len);
     return 1;
   }
-  copy_out(code < 8 ? kPluginNames[code] : "", plugin, plugin_len);
+  copy_out(code < 9 ? kPluginNames[code] : "", plugin, plugin_len);
   copy_out(compose_message(h, *h->pending[(size_t)pod], *h->nodes[(size_t)node], code, reason), msg, msg_len);
   return 0;
 }

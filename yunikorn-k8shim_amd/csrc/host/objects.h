@@ -48,6 +48,11 @@ struct SpreadConstraint {
   std::string node_affinity_policy = "Honor", node_taints_policy = "Ignore";
   std::vector<std::string> match_label_keys;
 };
+struct PodAffinityTerm {  // v1.PodAffinityTerm of a required (anti)affinity rule
+  LabelSelector selector;
+  std::vector<std::string> namespaces;  // empty = the owning pod's namespace
+  std::string topology_key;
+};
 struct HostPort {  // v1.ContainerPort with hostPort > 0; "" hostIP = 0.0.0.0, "" protocol = TCP (HostPortInfo.sanitize)
   std::string protocol, ip;
   int64_t port = 0;
@@ -73,7 +78,8 @@ struct PodTemplate {
   StrMap overhead;
   StrMap pod_level_requests;
   std::vector<SpreadConstraint> spread;
-  bool pod_affinity = false;  // inter-pod (anti)affinity present: outside this path
+  std::vector<PodAffinityTerm> pod_affinity, pod_anti_affinity;  // requiredDuringSchedulingIgnoredDuringExecution
+  bool pod_affinity_unsupported = false;  // namespaceSelector / matchLabelKeys / mismatchLabelKeys present
   std::string canonical;      // interning key (canonical JSON of the fields above)
   // derived once at interning time
   ResMap requests;            // upstream PodRequests (resource.go:56-109 minus the "pods" entry)
@@ -360,7 +366,34 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
     spec += ",\"nodeSelector\":";
     js_map(spec, t.node_selector);
   }
-  if (t.has_required || t.pod_affinity) {
+  auto js_pod_terms = [&](const char* name, const std::vector<PodAffinityTerm>& terms, bool comma) {
+    if (comma) spec.push_back(',');
+    spec += std::string("\"") + name + "\":{\"requiredDuringSchedulingIgnoredDuringExecution\":[";
+    for (size_t i = 0; i < terms.size(); ++i) {
+      if (i) spec.push_back(',');
+      spec += "{\"topologyKey\":";
+      js_str(spec, terms[i].topology_key);
+      if (terms[i].selector.present) {
+        spec += ",\"labelSelector\":{\"matchLabels\":";
+        js_map(spec, terms[i].selector.match_labels);
+        spec += ",\"matchExpressions\":";
+        js_reqs(spec, terms[i].selector.match_exprs);
+        spec += "}";
+      }
+      if (!terms[i].namespaces.empty()) {
+        spec += ",\"namespaces\":[";
+        for (size_t j = 0; j < terms[i].namespaces.size(); ++j) {
+          if (j) spec.push_back(',');
+          js_str(spec, terms[i].namespaces[j]);
+        }
+        spec.push_back(']');
+      }
+      spec.push_back('}');
+    }
+    spec += "]}";
+  };
+  const bool any_pod_aff = !t.pod_affinity.empty() || !t.pod_anti_affinity.empty() || t.pod_affinity_unsupported;
+  if (t.has_required || any_pod_aff) {
     spec += ",\"affinity\":{";
     if (t.has_required) {
       spec += "\"nodeAffinity\":{\"requiredDuringSchedulingIgnoredDuringExecution\":{\"nodeSelectorTerms\":[";
@@ -374,7 +407,16 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
       }
       spec += "]}}";
     }
-    if (t.pod_affinity) spec += std::string(t.has_required ? "," : "") + "\"podAffinity\":{}";
+    bool comma = t.has_required;
+    if (!t.pod_affinity.empty()) {
+      js_pod_terms("podAffinity", t.pod_affinity, comma);
+      comma = true;
+    }
+    if (!t.pod_anti_affinity.empty()) {
+      js_pod_terms("podAntiAffinity", t.pod_anti_affinity, comma);
+      comma = true;
+    }
+    if (t.pod_affinity_unsupported) spec += std::string(comma ? "," : "") + "\"x-unsupported-pod-affinity-fields\":true";
     spec += "}";
   }
   if (!t.tolerations.empty()) {
@@ -543,7 +585,27 @@ inline PodTemplate read_template(const mj::Value& v) {
             t.terms.push_back(std::move(term));
           }
       }
-    if (aff->get_nn("podAffinity") || aff->get_nn("podAntiAffinity")) t.pod_affinity = true;
+    auto read_pod_terms = [&](const mj::Value* pa, std::vector<PodAffinityTerm>* out) {
+      if (!pa) return;
+      const mj::Value* req = pa->get_nn("requiredDuringSchedulingIgnoredDuringExecution");
+      if (!req || !req->is_arr()) return;
+      for (auto& x : req->arr) {
+        PodAffinityTerm term;
+        if (const mj::Value* ls = x->get_nn("labelSelector")) {
+          term.selector.present = true;
+          term.selector.match_labels = read_strmap(ls->get_nn("matchLabels"));
+          term.selector.match_exprs = read_requirements(ls->get_nn("matchExpressions"));
+        }
+        if (const mj::Value* nss = x->get_nn("namespaces"))
+          for (auto& y : nss->arr) term.namespaces.push_back(y->s);
+        term.topology_key = x->str_or("topologyKey", "");
+        if (x->get_nn("namespaceSelector") || x->get_nn("matchLabelKeys") || x->get_nn("mismatchLabelKeys")) t.pod_affinity_unsupported = true;
+        out->push_back(std::move(term));
+      }
+    };
+    read_pod_terms(aff->get_nn("podAffinity"), &t.pod_affinity);
+    read_pod_terms(aff->get_nn("podAntiAffinity"), &t.pod_anti_affinity);
+    if (aff->get_nn("x-unsupported-pod-affinity-fields")) t.pod_affinity_unsupported = true;
   }
   if (const mj::Value* tols = spec->get_nn("tolerations"))
     for (auto& x : tols->arr)

@@ -25,8 +25,9 @@ PLUGIN_BITS = {
     "NodePorts": 1 << 4,
     "NodeResourcesFit": 1 << 5,
     "PodTopologySpread": 1 << 6,
+    "InterPodAffinity": 1 << 7,
 }
-ALL_PLUGINS = 0x7F
+ALL_PLUGINS = 0xFF
 OUT_BITMAP, OUT_COUNTS, OUT_DECISIONS, OUT_DECISION_KEYS = 1, 2, 4, 8
 EVAL_PROFILE, EVAL_DIRECT = 1 << 8, 1 << 9
 EVAL_SPREAD_COUNT_ONLY, EVAL_SPREAD_COUNTS_READY = 1 << 10, 1 << 11
@@ -62,7 +63,8 @@ class GpuPredicateManager:
         if not self._h:
             raise RuntimeError("ykhost_create failed (the engine has no CPU fallback): " + err.value.decode())
         # NewPredicateManager's phase lists (predicate_manager.go:321-373), restricted to the engine's plugins
-        reserve_pre = PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"]
+        reserve_pre = (PLUGIN_BITS["NodeAffinity"] | PLUGIN_BITS["NodePorts"] | PLUGIN_BITS["PodTopologySpread"]
+                       | PLUGIN_BITS["InterPodAffinity"])
         reserve_filt = reserve_pre | PLUGIN_BITS["NodeUnschedulable"] | PLUGIN_BITS["NodeName"] | PLUGIN_BITS["TaintToleration"]
         self._masks = (reserve_pre, ALL_PLUGINS, reserve_filt, ALL_PLUGINS)
 
