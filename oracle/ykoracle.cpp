@@ -471,6 +471,7 @@ static bool selector_is_empty(const LabelSelector& s) {  // labels.Selector.Empt
 // Snapshot
 // ---------------------------------------------------------------------------------------------------
 struct Snapshot {
+  std::vector<size_t> nodes_with_anti;      // NodeInfoLister.HavePodsWithRequiredAntiAffinityList (nodeinfo_lister.go)
   std::vector<std::unique_ptr<Pod>> owned;  // every pod object (pending + assigned)
   std::vector<const Pod*> pending;          // the asks
   std::vector<NodeInfo> nodes;
@@ -660,6 +661,12 @@ static Snapshot* load_snapshot(const std::string& text) {
       snap->pending.push_back(p.get());
       snap->owned.push_back(std::move(p));
     }
+  for (size_t i = 0; i < snap->nodes.size(); ++i)
+    for (const Pod* p : snap->nodes[i].pods)
+      if (!p->pod_anti_affinity.empty()) {
+        snap->nodes_with_anti.push_back(i);
+        break;
+      }
   snap->load_error = err;
   return snap.release();
 }
@@ -896,7 +903,8 @@ static void topo_update(std::map<TopologyPair, int64_t>& m, const Node& node, co
   auto it = node.labels.find(key);
   if (it != node.labels.end()) m[{key, it->second}] += v;
 }
-static Status interpod_prefilter(const Pod& p, const std::vector<NodeInfo>& all, CycleState& st) {
+static Status interpod_prefilter(const Pod& p, const std::vector<NodeInfo>& all, const std::vector<size_t>& nodes_with_anti,
+                                 CycleState& st) {
   InterPodState& s = st.ipa;
   for (auto* terms : {&p.pod_affinity, &p.pod_anti_affinity})
     for (auto& t : *terms) {
@@ -904,14 +912,16 @@ static Status interpod_prefilter(const Pod& p, const std::vector<NodeInfo>& all,
       selector_matches(t.selector, p.labels, &e);
       if (e) return {Status::UnschedulableAndUnresolvable, "parsing pod: invalid label selector in pod (anti)affinity term"};
     }
-  // getExistingAntiAffinityCounts: existing pods whose required anti-affinity terms match the incoming pod
-  for (auto& ni : all)
-    for (const Pod* ep : ni.pods)
+  // getExistingAntiAffinityCounts: existing pods whose required anti-affinity terms match the incoming pod; upstream
+  // walks only the nodes that hold such pods (HavePodsWithRequiredAntiAffinityList)
+  for (size_t i : nodes_with_anti)
+    for (const Pod* ep : all[i].pods)
       for (auto& t : ep->pod_anti_affinity)
-        if (affinity_term_matches(t, ep->ns, p)) topo_update(s.existing_anti, ni.node, t.topology_key, 1);
-  // getIncomingAffinityAntiAffinityCounts
-  for (auto& ni : all)
-    for (const Pod* ep : ni.pods) {
+        if (affinity_term_matches(t, ep->ns, p)) topo_update(s.existing_anti, all[i].node, t.topology_key, 1);
+  // getIncomingAffinityAntiAffinityCounts (returns at once for a pod without required terms)
+  if (!p.pod_affinity.empty() || !p.pod_anti_affinity.empty())
+    for (auto& ni : all)
+      for (const Pod* ep : ni.pods) {
       if (pod_matches_all_affinity_terms(p.pod_affinity, p.ns, *ep))
         for (auto& t : p.pod_affinity) topo_update(s.affinity, ni.node, t.topology_key, 1);
       for (auto& t : p.pod_anti_affinity)
@@ -1006,7 +1016,7 @@ static bool run_prefilters(const Snapshot& snap, const Pod& p, const NodeInfo& t
     else if (pl.bit == kPodTopologySpread)
       s = spread_prefilter(p, snap.nodes, st);
     else
-      s = interpod_prefilter(p, snap.nodes, st);
+      s = interpod_prefilter(p, snap.nodes, snap.nodes_with_anti, st);
     if (s.is_skip()) {
       *skip |= pl.bit;  // :233-234
     } else if (!s.is_success()) {
