@@ -5,6 +5,8 @@
 
 hipcc cross-compiles gfx950 without a GPU, so this runs in the build container as well as on the GPU box.
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -27,6 +29,28 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-
 CXXFLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter"]
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time: bench.py is launched as N ranks that all import the package at once."""
+    os.makedirs(LIB, exist_ok=True)
+    with open(os.path.join(LIB, ".build.lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
+def _compile(cmd, target, verbose):
+    """Compile to a temporary name and rename: a concurrently starting process never maps a half-written library."""
+    tmp = target + f".tmp{os.getpid()}"
+    cmd = [tmp if c == target else c for c in cmd]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, target)
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -35,22 +59,17 @@ def _stale(target, deps):
 
 
 def build_engine(force=False, verbose=False):
-    os.makedirs(LIB, exist_ok=True)
-    if force or _stale(LIBYKPRED, ENGINE_DEPS):
-        cmd = [HIPCC] + HIPFLAGS + [ENGINE_SRC, "-o", LIBYKPRED]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    with _build_lock():
+        if force or _stale(LIBYKPRED, ENGINE_DEPS):
+            _compile([HIPCC] + HIPFLAGS + [ENGINE_SRC, "-o", LIBYKPRED], LIBYKPRED, verbose)
     return LIBYKPRED
 
 
 def build_host(force=False, verbose=False):
     build_engine(force=False, verbose=verbose)
-    if force or _stale(LIBYKHOST, HOST_DEPS + [LIBYKPRED]):
-        cmd = ["g++"] + CXXFLAGS + [HOST_SRC, "-o", LIBYKHOST, "-L" + LIB, "-lykpred", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    with _build_lock():
+        if force or _stale(LIBYKHOST, HOST_DEPS + [LIBYKPRED]):
+            _compile(["g++"] + CXXFLAGS + [HOST_SRC, "-o", LIBYKHOST, "-L" + LIB, "-lykpred", "-Wl,-rpath,$ORIGIN"], LIBYKHOST, verbose)
     return LIBYKHOST
 
 
