@@ -174,6 +174,10 @@ typedef struct ykpred_pods {
 #define YKPRED_EVAL_SPREAD_COUNT_ONLY (1u << 10)   /* node-sharded clusters: only build this shard's PodTopologySpread
                                                       histograms (layout.spread_counts / spread_present) and return */
 #define YKPRED_EVAL_SPREAD_COUNTS_READY (1u << 11) /* the histograms already hold the cluster-wide (all-reduced) values */
+#define YKPRED_EVAL_SKIP_BITMAP (1u << 12)         /* refresh planes / counts scatter / decisions only; the bitmap and the class
+                                                      counts are already current (used by ykpred_eval_nodes) */
+#define YKPRED_EVAL_STORE_VARIANT_SHIFT 16         /* bits 16-17: experimental k_combine store flavour (0 = dwordx4, default;
+                                                      1 = dwordx2; 2/3 = the same non-temporal) — measured equal, DESIGN.md §4 */
 
 typedef struct ykpred_eval_args {
   uint32_t prefilter_plugins; /* enabled PreFilter plugins (YKPRED_PLUGIN_* bits) */

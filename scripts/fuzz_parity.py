@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU vs oracle) beyond the seeds baked into tests/: full grid, both phases, fit bits,
+failing plugin, counts; every feature of tests/_gen.py switched on. Usage: python scripts/fuzz_parity.py [first] [count]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _gen  # noqa: E402
+import _oracle as orc  # noqa: E402
+
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+pm = pkg.GpuPredicateManager()
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    n_nodes, n_pods = int(rng.integers(1, 260)), int(rng.integers(1, 120))
+    snap = _gen.random_snapshot(seed, n_nodes, n_pods, scalars=bool(seed % 2), spread=bool(seed % 3), interpod=bool(seed % 5 != 1))
+    try:
+        pm.load_snapshot(snap)
+        o = orc.Oracle(snap)
+        for allocate in (True, False):
+            pre, filt = (orc.ALL, orc.ALL) if allocate else (orc.RESERVE_PRE, orc.RESERVE_FILT)
+            want, wplug = o.eval_grid(pre_mask=pre, filt_mask=filt, threads=16, want_plugin=True)
+            pm.evaluate(allocate=allocate)
+            lay = pm.layout()
+            got = np.unpackbits(pm.read_bitmap().view(np.uint8), axis=1, bitorder="little")[:, :lay.num_nodes]
+            P, N = want.shape
+            pods, nodes = np.divmod(np.arange(P * N, dtype=np.int64), N)
+            fit, code, _ = pm.query(pods.astype(np.int32), nodes.astype(np.int32), pre_mask=pre, filt_mask=filt)
+            ok = (np.array_equal(got, want) and np.array_equal(pm.read_counts(), want.sum(axis=1)) and
+                  np.array_equal(fit.reshape(P, N), want) and not ((code.reshape(P, N) != wplug) & (want == 0)).any())
+            if not ok:
+                bad += 1
+                print(f"MISMATCH seed={seed} allocate={allocate} nodes={n_nodes} pods={n_pods}", flush=True)
+    except RuntimeError as e:
+        if "engine limit" in str(e) or "not supported" in str(e):
+            continue
+        bad += 1
+        print(f"ERROR seed={seed}: {e}", flush=True)
+print(f"fuzz: {count} snapshots from seed {first}, {bad} failures")
+sys.exit(1 if bad else 0)

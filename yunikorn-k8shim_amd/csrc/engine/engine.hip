@@ -941,11 +941,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   // ---- stream A: combine → bitmap (skipped by ykpred_eval_nodes' decision refresh: bitmap and class counts were
   // patched incrementally)
-  const bool skip_combine = a->options & (1u << 12);
+  const bool skip_combine = a->options & YKPRED_EVAL_SKIP_BITMAP;
   if (!skip_combine) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   if (!skip_combine) {
     // store flavour: bits 16-17 of options select an experimental variant (0 = default)
-    const unsigned variant = (a->options >> 16) & 3u;
+    const unsigned variant = (a->options >> YKPRED_EVAL_STORE_VARIANT_SHIFT) & 3u;
     const int wpl = (variant & 1u) ? 1 : 2;
     const int seg = ykk::kBlock * ykk::kCombineUnroll * wpl;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
@@ -1035,7 +1035,7 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   if (want_dec) {
     // the bin-pack order moved with the node's Requested: rerun the (cheap) plane + decision kernels, not the bitmap
     ykpred_eval_args_t b = *a;
-    b.options = (a->options & ~(uint32_t)YKPRED_OUT_BITMAP) | (1u << 12);  // internal: skip k_combine
+    b.options = (a->options & ~(uint32_t)YKPRED_OUT_BITMAP) | YKPRED_EVAL_SKIP_BITMAP;
     int rc = ykpred_eval(e, &b);
     if (rc != YKPRED_OK) return rc;
   }
