@@ -197,7 +197,7 @@ typedef struct ykpred_layout {
   int32_t num_specs;
   int32_t num_classes;
   int32_t row_words;   /* ceil(N/64): meaningful 64-bit words per bitmap row */
-  int32_t row_stride;  /* words between consecutive rows (>= row_words, multiple of 8; padding words are 0) */
+  int32_t row_stride;  /* words between consecutive rows (>= row_words, multiple of 16 = 128 B; padding words are 0) */
   int32_t num_chunks;
   int32_t plane_rows;  /* total signature planes evaluated per eval */
   uint64_t bitmap_bytes;

@@ -555,7 +555,8 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   }
   e->N = n->count;
   e->row_words = (e->N + 63) / 64;
-  e->row_stride = std::max(8, (e->row_words + 7) / 8 * 8);
+  // rows start on 128-byte lines (16 words): a line shared by two rows would be written in two partial pieces
+  e->row_stride = std::max(16, (e->row_words + 15) / 16 * 16);
   e->nodes_set = true;
   return YKPRED_OK;
 }
@@ -947,12 +948,15 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     // store flavour: bits 16-17 of options select an experimental variant (0 = default)
     const unsigned variant = (a->options >> YKPRED_EVAL_STORE_VARIANT_SHIFT) & 3u;
     const int wpl = (variant & 1u) ? 1 : 2;
-    const int seg = ykk::kBlock * ykk::kCombineUnroll * wpl;
+    // threads per group: the smallest whole number of waves (64/128/256) whose single pass covers a row
+    int tpg = ykk::kBlock;
+    while (tpg > ykk::kWave && (tpg / 2) * wpl >= e->row_stride) tpg /= 2;
+    const int seg = tpg * ykk::kCombineUnroll * wpl;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
     auto launch = [&](auto kern) {
       // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
       hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pc, bitmap, e->row_words, e->row_stride,
-                         pin_on, e->d_class_count.as<int>());
+                         pin_on, e->d_class_count.as<int>(), tpg);
     };
     tm.begin(st);
     switch (variant) {

@@ -611,14 +611,17 @@ __device__ __forceinline__ u64 class_word(const Planes& pl, int sr, int st, int 
   return v;
 }
 
-// grid.x = chunks, grid.y = row super-segments of kBlock*kCombineUnroll*WPL words. Each thread owns kCombineUnroll
-// groups of WPL adjacent words of the class row (group g of thread t covers words seg_base + (u*kBlock + t)*WPL ...),
-// so one wave store instruction writes 64*WPL*8 contiguous bytes (512 B at WPL=1, 1 KiB = dwordx4 per lane at WPL=2).
+// grid.x = chunks, grid.y = row super-segments of tpg*kCombineUnroll*WPL words. The block is split into kBlock/tpg
+// thread groups (tpg = threads per group: 64, 128 or 256, a whole number of waves) that write DIFFERENT member rows
+// concurrently: wide rows (≥ 512 words, e.g. 50 k nodes) use one group of 256 threads, narrow rows of a node shard
+// (e.g. 200 words for 12.5 k nodes) are covered by 128 or 64 threads so that no lane idles. Each thread owns
+// kCombineUnroll groups of WPL adjacent words of the class row (word = seg_base + (u*tpg + t)*WPL ...), so one wave
+// store writes 64*WPL*8 contiguous bytes (512 B at WPL=1, 1 KiB = dwordx4 per lane at WPL=2).
 // NT selects non-temporal stores: the bitmap is written once and never re-read by this kernel.
 template <int WPL, bool NT>
 __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
-                                                    int pin_enabled, int* __restrict__ class_count) {
-  // pin_enabled bit 0: NodeName filter on; bit 1: PodTopologySpread.Filter has no PreFilter state ⇒ every pair fails
+                                                    int pin_enabled, int* __restrict__ class_count, int tpg) {
+  // pin_enabled bit 0: NodeName filter on; bit 1: a Filter has no PreFilter state ⇒ every pair fails
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int chunk = blockIdx.x;
@@ -628,7 +631,8 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const int pin = pin_enabled ? ct.pin[cls] : -1;
   const int lane = threadIdx.x % kWave;
-  const int seg_base = blockIdx.y * (kBlock * kCombineUnroll * WPL);
+  const int group = threadIdx.x / tpg, groups = kBlock / tpg, t = threadIdx.x % tpg;
+  const int seg_base = blockIdx.y * (tpg * kCombineUnroll * WPL);
 
   u64 v[kCombineUnroll][WPL];
   int pc = 0;
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   for (int u = 0; u < kCombineUnroll; ++u) {
 #pragma unroll
     for (int j = 0; j < WPL; ++j) {
-      int w = seg_base + (u * kBlock + threadIdx.x) * WPL + j;
+      int w = seg_base + (u * tpg + t) * WPL + j;
       u64 x = 0;
       if (w < row_words) {
         x = class_word(pl, sr, st, sa, ss, w);
@@ -649,21 +653,21 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
       pc += __popcll(x);
     }
   }
-  if (ct.chunk_first[chunk]) {
-    // feasible-node count of the class: wave reduce, one atomic per wave
+  if (ct.chunk_first[chunk] && group == 0) {
+    // feasible-node count of the class: wave reduce, one atomic per wave (thread group 0 holds the whole segment)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
     if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
   }
   // member ids: lane i of every wave holds member i (one coalesced 256 B load), broadcast by v_readlane
   int mine = lane < len ? ct.members[begin + lane] : 0;
-  for (int i = 0; i < len; ++i) {
+  for (int i = group; i < len; i += groups) {  // `group` is wave-uniform: tpg is a multiple of the wave size
     int p = __builtin_amdgcn_readlane(mine, i);
     u64* row = bitmap + (size_t)p * row_stride;
 #pragma unroll
     for (int u = 0; u < kCombineUnroll; ++u) {
-      int w = seg_base + (u * kBlock + threadIdx.x) * WPL;
-      if (w < row_stride) {  // row_stride is a multiple of 8 ⇒ a WPL=2 group never straddles the end
+      int w = seg_base + (u * tpg + t) * WPL;
+      if (w < row_stride) {  // row_stride is a multiple of 16 ⇒ a WPL=2 group never straddles the end
         if (WPL == 2) {
           typedef u64 u64x2 __attribute__((ext_vector_type(2)));
           u64x2 val = {v[u][0], v[u][WPL - 1]};
