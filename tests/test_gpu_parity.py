@@ -487,3 +487,40 @@ def test_topology_spread_sharded_histograms():
     finally:
         for m in (full, a, b):
             m.close()
+
+
+def test_sharded_decisions_match_single_engine():
+    """Node-axis sharding: two engines hold half of the nodes each; merging their (count, decision, key) outputs the way
+    sharding.exchange_decisions does (SUM / MIN key / MIN global node id) must reproduce the single-engine result."""
+    import torch
+    full, a, b = pkg.GpuPredicateManager(), pkg.GpuPredicateManager(), pkg.GpuPredicateManager()
+    try:
+        full.generate_kwok(seed=31337, num_nodes=1024, num_pods=3000, num_templates=150, node_affinity=1)
+        snap = json.loads(full.dump_snapshot())
+        half = 512
+        a.load_snapshot({"nodes": snap["nodes"][:half], "pods": snap["pods"]})
+        b.load_snapshot({"nodes": snap["nodes"][half:], "pods": snap["pods"]})
+        full.evaluate()
+        want_counts, want_dec = full.read_counts(), full.read_decisions()
+        outs = []
+        for m in (a, b):
+            P = m.num_pods
+            c = torch.empty(P, dtype=torch.int32, device="cuda")
+            d = torch.empty(P, dtype=torch.int32, device="cuda")
+            k = torch.empty(P, dtype=torch.int64, device="cuda")
+            m.evaluate_into(counts=c, decisions=d, keys=k)
+            m.synchronize()
+            outs.append((c.cpu().numpy(), d.cpu().numpy(), k.cpu().numpy()))
+        (ca, da, ka), (cb, db, kb) = outs
+        counts = ca + cb
+        best_key = np.minimum(ka, kb)
+        big = np.iinfo(np.int32).max
+        cand_a = np.where((ka == best_key) & (da >= 0), da, big)
+        cand_b = np.where((kb == best_key) & (db >= 0), db + half, big)
+        cand = np.minimum(cand_a, cand_b)
+        dec = np.where(cand == big, -1, cand)
+        assert np.array_equal(counts, want_counts)
+        assert np.array_equal(dec, want_dec)
+    finally:
+        for m in (full, a, b):
+            m.close()
