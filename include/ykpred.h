@@ -255,6 +255,11 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t num_pairs, const int32_t* pod_i
                      uint32_t prefilter_plugins, uint32_t filter_plugins, uint8_t* fit /* [num_pairs] */,
                      uint8_t* plugin_code /* [num_pairs], may be NULL */, uint32_t* reason /* [num_pairs], may be NULL */);
 
+/* All Predicates() answers of ONE pod in one call: out arrays have one entry per node. The core tries an ask on many nodes
+ * in a row (one callback per node); the Go side fetches the ask's answers once and serves those callbacks from host memory. */
+int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod_index, uint32_t prefilter_plugins, uint32_t filter_plugins,
+                         uint8_t* fit /* [N] */, uint8_t* plugin_code /* [N], may be NULL */, uint32_t* reason /* [N], may be NULL */);
+
 /* PreemptionPredicates (predicate_manager.go:141-179): victims are described by their request vectors, in order. */
 int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod_index, int32_t node_index, int32_t num_victims,
                           const int64_t* victim_requests /* [num_victims][R]; a nil victim is an all-zero row with present=0 */,

@@ -1178,6 +1178,30 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
   return YKPRED_OK;
 }
 
+int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t filt, uint8_t* fit, uint8_t* code, uint32_t* reason) {
+  if (!e || !fit) return fail(e, YKPRED_E_INVALID, "query_pod: bad argument");
+  if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query_pod: tables not uploaded");
+  if (pod < 0 || pod >= e->P) return fail(e, YKPRED_E_INVALID, "query_pod: index out of range");
+  if (e->N == 0) return YKPRED_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  else if (e->spread_dirty) TRY(build_spread_tables(e, st));
+  const size_t N = (size_t)e->N;
+  HIPCHK(e->d_scratch.ensure(N * 6 + 64));
+  uint32_t* d_r = e->d_scratch.as<uint32_t>();
+  uint8_t* d_f = (uint8_t*)(d_r + N);
+  uint8_t* d_c = d_f + N;
+  hipLaunchKernelGGL(ykk::k_query_pod, dim3((unsigned)((N + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, node_table(e),
+                     spec_table(e), e->h_pod_spec[(size_t)pod], e->h_pod_pin[(size_t)pod], pre, filt, d_f, d_c, d_r);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(fit, d_f, N, hipMemcpyDeviceToHost, st));
+  if (code) HIPCHK(hipMemcpyAsync(code, d_c, N, hipMemcpyDeviceToHost, st));
+  if (reason) HIPCHK(hipMemcpyAsync(reason, d_r, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
 int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
                                 const uint64_t* ports_after, int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
   if (!e || !out || nv < 0 || start < 0 || (nv > 0 && (!vreq || !vpresent))) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");

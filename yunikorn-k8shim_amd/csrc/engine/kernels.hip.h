@@ -904,6 +904,22 @@ __global__ __launch_bounds__(kBlock) void k_query(NodeTable t, SpecTable s, int 
   if (reason_out) reason_out[i] = reason;
 }
 
+// one pod against every node (thread = node): the answers of all Predicates(pod, ·) callbacks of a scheduling attempt
+__global__ __launch_bounds__(kBlock) void k_query_pod(NodeTable t, SpecTable s, int spec, int pin, unsigned pre_mask, unsigned filt_mask,
+                                                      unsigned char* __restrict__ fit, unsigned char* __restrict__ code_out,
+                                                      unsigned* __restrict__ reason_out) {
+  int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= t.n) return;
+  NodeRegs nr;
+  load_node(t, n, &nr);
+  int code;
+  unsigned reason;
+  bool ok = eval_pair(s, spec, pin, n, nr, pre_mask, filt_mask, &code, &reason);
+  fit[n] = ok ? 1 : 0;
+  code_out[n] = (unsigned char)code;
+  reason_out[n] = reason;
+}
+
 // Per-pair grid: blockIdx.x = chunk of 64 pods (the unbounded axis), blockIdx.y = group of 4 node words. lane = node, the wave walks the
 // 64 pods of its chunk (pod data wave-uniform), ballot → lane (i) keeps pod i's word → 64 row stores.
 __global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int n_pods, const int* __restrict__ pod_spec,

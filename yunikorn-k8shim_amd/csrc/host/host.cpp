@@ -67,6 +67,13 @@ struct ykhost {
   bool dirty_all = true, dirty_pods = false;
   std::vector<int> dirty_nodes;       // node rows to re-upload
   std::vector<int> eval_dirty_nodes;  // node columns changed since the last evaluation
+  // answers of one ask against every node (ykpred_query_pod), so that the core's per-node Predicates() callbacks of a
+  // scheduling attempt are served from host memory; dropped whenever any table changes
+  struct AskAnswers {
+    int pod = -1, phase = -1;
+    std::vector<uint8_t> fit, code;
+    std::vector<uint32_t> reason;
+  } answers;
   int last_eval_phase = -1;           // 1 allocate / 0 reserve / -1 none: the phase of the bitmap on the device
   uint32_t last_eval_options = 0;
   std::vector<PodTemplate*> spec_templates;  // spec id → template
@@ -309,6 +316,7 @@ int node_row_sync(ykhost* h, int n) {
 }
 
 int sync(ykhost* h) {
+  if (h->dirty_all || h->dirty_pods || !h->dirty_nodes.empty()) h->answers.pod = -1;
   if (h->dirty_all) {
     int rc = full_sync(h);
     if (rc) return rc;
@@ -625,6 +633,7 @@ void ykhost_destroy(ykhost_t* h) {
 const char* ykhost_last_error(const ykhost_t* h) { return h ? h->err.c_str() : ""; }
 
 int32_t ykhost_set_plugins(ykhost_t* h, uint32_t rp, uint32_t ap, uint32_t rf, uint32_t af) {
+  h->answers.pod = -1;
   h->res_pre = rp;
   h->alloc_pre = ap;
   h->res_filt = rf;
@@ -878,10 +887,20 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
   if (pod < 0 || pod >= (int)h->pending.size() || node < 0 || node >= (int)h->nodes.size()) return fail(h, "index out of range", -1);
   int rc = sync(h);
   if (rc) return rc;
-  uint8_t fit = 0, code = 0;
-  uint32_t reason = 0;
-  rc = ykpred_query(h->eng, 1, &pod, &node, allocate ? h->alloc_pre : h->res_pre, allocate ? h->alloc_filt : h->res_filt, &fit, &code, &reason);
-  if (rc) return fail(h, std::string("ykpred_query: ") + ykpred_last_error(h->eng), rc);
+  // one device round trip per (ask, phase): the answers for all nodes are fetched together and cached
+  if (h->answers.pod != pod || h->answers.phase != (allocate ? 1 : 0)) {
+    const size_t N = h->nodes.size();
+    h->answers.fit.assign(N, 0);
+    h->answers.code.assign(N, 0);
+    h->answers.reason.assign(N, 0);
+    rc = ykpred_query_pod(h->eng, pod, allocate ? h->alloc_pre : h->res_pre, allocate ? h->alloc_filt : h->res_filt, h->answers.fit.data(),
+                          h->answers.code.data(), h->answers.reason.data());
+    if (rc) return fail(h, std::string("ykpred_query_pod: ") + ykpred_last_error(h->eng), rc);
+    h->answers.pod = pod;
+    h->answers.phase = allocate ? 1 : 0;
+  }
+  const uint8_t fit = h->answers.fit[(size_t)node], code = h->answers.code[(size_t)node];
+  const uint32_t reason = h->answers.reason[(size_t)node];
   if (fit) {
     copy_out("", plugin, plugin_len);
     copy_out("", msg, msg_len);
