@@ -107,6 +107,33 @@ __global__ __launch_bounds__(256) void fill_rows_padded_persistent(u64* p, int s
     for (int w = threadIdx.x * 2; w < used_words; w += 512) *(u64x2*)(base + w) = val;
   }
 }
+// (k) tile-linear gather with a launch-time block size: block b walks 16-B groups (b*T + tid) + k*G*T, T = blockDim.x
+template <int K, int U>
+__global__ void expand_linear(u64* __restrict__ out, const u64* __restrict__ tab, const int* __restrict__ cls, long n_rows) {
+  const long n16 = n_rows * 6272 / 16;
+  const long step = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n16; i0 += step * U) {
+    u64x2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long i = i0 + u * step;
+      if (i < n16) {
+        long off = i * 16;
+        long row = off / 6272;
+        int col = (int)(off - row * 6272) / 8;
+        u64x2 acc = {~0ull, ~0ull};
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc &= *(const u64x2*)(tab + (size_t)cls[row * K + k] * 784 + col);
+        v[u] = acc;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long i = i0 + u * step;
+      if (i < n16) *(u64x2*)((char*)out + i * 16) = v[u];
+    }
+  }
+}
 // (f) one block per row (no inner row loop): 1M blocks
 __global__ __launch_bounds__(256) void fill_row_per_block(u64* p, int stride_words, u64 v) {
   u64x2 val = {v, v};
@@ -144,6 +171,14 @@ int main() {
     CK(hipMalloc(&tab, (size_t)2061 * 784 * 8)); CK(hipMemset(tab, 0xff, (size_t)2061 * 784 * 8));
     CK(hipMalloc(&c1, rows * 4)); CK(hipMalloc(&c3, rows * 12));
     CK(hipMemcpy(c1, h1.data(), rows * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(c3, h3.data(), rows * 12, hipMemcpyHostToDevice));
+    for (int bs : {256, 512, 1024})
+      for (int g : {256, 512}) {
+        char nm[96];
+        snprintf(nm, 96, "linear fill, %d blocks x %d threads", g, bs); run(nm, [&] { fill_linear_u<1><<<g, bs>>>((u64x2*)d, bytes / 16, 7); });
+        snprintf(nm, 96, "expand linear K=1 U=4, %d blocks x %d threads", g, bs); run(nm, [&] { expand_linear<1, 4><<<g, bs>>>(d, tab, c1, rows); });
+        snprintf(nm, 96, "expand linear K=1 U=8, %d blocks x %d threads", g, bs); run(nm, [&] { expand_linear<1, 8><<<g, bs>>>(d, tab, c1, rows); });
+        snprintf(nm, 96, "expand linear K=3 U=4, %d blocks x %d threads", g, bs); run(nm, [&] { expand_linear<3, 4><<<g, bs>>>(d, tab, c3, rows); });
+      }
     for (int g : {128, 256, 512})
     { char nm[80];
       snprintf(nm, 80, "expand tiles K=1 (class rows 12.9MB) U=2, %d blocks", g); run(nm, [&] { expand_tiles<1, 2><<<g, 256>>>(d, tab, c1, 2061, rows); });
