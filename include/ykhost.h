@@ -92,6 +92,11 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
 int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t num_victims,
                                      int32_t start_index);
 
+/* Batched form: query q = (pods[q], nodes[q], victim UIDs victim_uids[victim_off[q] .. victim_off[q+1]), start_index[q]). */
+int32_t ykhost_preemption_predicates_batch(ykhost_t* h, int32_t num_queries, const int32_t* pods, const int32_t* nodes,
+                                           const int32_t* victim_off, const char* const* victim_uids, const int32_t* start_index,
+                                           int32_t* out_index);
+
 /* request vector of pending pod #pod as JSON {"cpu": milli, "memory": bytes, ...} */
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len);
 

@@ -270,6 +270,14 @@ int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod_index, int32_t n
                                 const int64_t* victim_requests, const uint8_t* victim_present, const uint64_t* port_bits_after,
                                 int32_t start_index, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t* out_index);
 
+/* Batched PreemptionPredicates: query q uses victims [victim_off[q], victim_off[q+1]) of the flattened victim arrays
+ * (same per-victim meaning as above) and writes out_index[q]. One launch, one thread per query. */
+int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t num_queries, const int32_t* pod_index, const int32_t* node_index,
+                                const int32_t* victim_off /* [num_queries+1] */, const int64_t* victim_requests /* [total][R] */,
+                                const uint8_t* victim_present /* [total] */, const uint64_t* port_bits_after /* [total][KP] or NULL */,
+                                const int32_t* start_index /* [num_queries] */, uint32_t prefilter_plugins, uint32_t filter_plugins,
+                                int32_t* out_index /* [num_queries] */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -524,3 +524,35 @@ def test_sharded_decisions_match_single_engine():
     finally:
         for m in (full, a, b):
             m.close()
+
+
+def test_preemption_predicates_batch(pm):
+    """Random PreemptionPredicates queries (victim prefixes, nil and foreign victims, host ports) in ONE launch, each
+    against the oracle's sequential restatement of predicate_manager.go:141-179."""
+    import random
+    rng = random.Random(9)
+    snap = _gen.random_snapshot(4321, n_nodes=120, n_pods=60, scalars=True)
+    pm.load_snapshot(snap)
+    o = orc.Oracle(snap)
+    queries, want = [], []
+    for _ in range(300):
+        p = rng.randrange(len(snap["pods"]))
+        n = rng.randrange(len(snap["nodes"]))
+        on_node = []
+        for e in snap["nodes"][n].get("pods", []):
+            reps = e.get("replicas", 1)
+            on_node += [e["metadata"]["uid"] + (f"#{r}" if reps > 1 else "") for r in range(reps)]
+        k = rng.randrange(0, len(on_node) + 1)
+        idx = rng.sample(range(len(on_node)), k)
+        victims = [on_node[i] for i in idx]
+        oidx = list(idx)
+        if rng.random() < 0.3:
+            pos = rng.randrange(len(victims) + 1)
+            victims.insert(pos, None)  # nil victim
+            oidx.insert(pos, -1)
+        start = rng.randrange(0, len(victims) + 1)
+        queries.append((p, n, victims, start))
+        want.append(o.preemption(p, n, oidx, start))
+    got = pm.preemption_predicates_batch(queries)
+    assert got == want
+    assert sum(1 for w in want if w >= 0) > 5, "degenerate: no query finds a victim index"

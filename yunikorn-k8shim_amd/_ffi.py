@@ -91,6 +91,8 @@ def load_ykpred():
     L.ykpred_bitmap_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ykpred_query.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p]
+    L.ykpred_preemption_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.ykpred_query_pod.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ykpred_preemption.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32,
                                     C.c_uint32, C.POINTER(C.c_int32)]
@@ -132,6 +134,8 @@ def load_ykhost():
     L.ykhost_evaluate_dirty.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.POINTER(C.c_int32)]
     L.ykhost_predicates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_preemption_predicates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
+    L.ykhost_preemption_predicates_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p),
+                                                     C.c_void_p, C.c_void_p]
     L.ykhost_pod_request_json.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_stats.argtypes = [C.c_void_p, C.c_void_p]
     _host = L

@@ -1202,33 +1202,61 @@ int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t
   return YKPRED_OK;
 }
 
-int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
-                                const uint64_t* ports_after, int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
-  if (!e || !out || nv < 0 || start < 0 || (nv > 0 && (!vreq || !vpresent))) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");
+int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t nq, const int32_t* pods, const int32_t* nodes, const int32_t* voff,
+                                const int64_t* vreq, const uint8_t* vpresent, const uint64_t* ports_after, const int32_t* start,
+                                uint32_t pre, uint32_t filt, int32_t* out) {
+  if (!e || nq < 0 || (nq > 0 && (!pods || !nodes || !voff || !start || !out))) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "preemption: tables not uploaded");
-  if (pod < 0 || pod >= e->P || node < 0 || node >= e->N) return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
+  if (nq == 0) return YKPRED_OK;
+  const int total = voff[nq];
+  if (voff[0] != 0 || total < 0 || (total > 0 && (!vreq || !vpresent))) return fail(e, YKPRED_E_INVALID, "preemption: bad victim arrays");
+  for (int q = 0; q < nq; ++q)
+    if (pods[q] < 0 || pods[q] >= e->P || nodes[q] < 0 || nodes[q] >= e->N || voff[q + 1] < voff[q] || start[q] < 0)
+      return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
-  const size_t vbytes = (size_t)nv * (size_t)e->R * sizeof(i64);
-  const size_t pbytes = (ports_after && e->KP > 0) ? (size_t)nv * (size_t)e->KP * sizeof(u64) : 0;
-  const size_t flag_off = vbytes + pbytes;
-  const size_t out_off = (flag_off + (size_t)nv + 7) / 8 * 8;
-  HIPCHK(e->d_scratch.ensure(out_off + 64));
+  // scratch layout (8-byte aligned pieces): vreq | ports_after | q_pod | q_node | voff | q_start | out | vpresent
+  const size_t vbytes = (size_t)total * (size_t)e->R * sizeof(i64);
+  const size_t pbytes = (ports_after && e->KP > 0) ? (size_t)total * (size_t)e->KP * sizeof(u64) : 0;
+  const size_t ibytes = ((size_t)nq * 4 + 7) / 8 * 8, obytes = ((size_t)(nq + 1) * 4 + 7) / 8 * 8;
+  size_t off = 0;
+  const size_t o_vreq = off; off += vbytes;
+  const size_t o_ports = off; off += pbytes;
+  const size_t o_pod = off; off += ibytes;
+  const size_t o_node = off; off += ibytes;
+  const size_t o_voff = off; off += obytes;
+  const size_t o_start = off; off += ibytes;
+  const size_t o_out = off; off += ibytes;
+  const size_t o_pres = off; off += (size_t)total + 8;
+  HIPCHK(e->d_scratch.ensure(off + 64));
   char* base = (char*)e->d_scratch.p;
-  if (nv) {
-    HIPCHK(hipMemcpyAsync(base, vreq, vbytes, hipMemcpyHostToDevice, st));
-    if (pbytes) HIPCHK(hipMemcpyAsync(base + vbytes, ports_after, pbytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(base + flag_off, vpresent, (size_t)nv, hipMemcpyHostToDevice, st));
+  if (total) {
+    HIPCHK(hipMemcpyAsync(base + o_vreq, vreq, vbytes, hipMemcpyHostToDevice, st));
+    if (pbytes) HIPCHK(hipMemcpyAsync(base + o_ports, ports_after, pbytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(base + o_pres, vpresent, (size_t)total, hipMemcpyHostToDevice, st));
   }
-  hipLaunchKernelGGL(ykk::k_preempt, dim3(1), dim3(64), 0, st, node_table(e), spec_table(e), e->h_pod_spec[(size_t)pod],
-                     e->h_pod_pin[(size_t)pod], node, nv, (const i64*)base, (const unsigned char*)(base + flag_off),
-                     pbytes ? (const u64*)(base + vbytes) : (const u64*)nullptr, start, pre, filt, (int*)(base + out_off));
+  HIPCHK(hipMemcpyAsync(base + o_pod, pods, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(base + o_node, nodes, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(base + o_voff, voff, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(base + o_start, start, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ykk::k_preempt, dim3((unsigned)((nq + ykk::kWave - 1) / ykk::kWave)), dim3(ykk::kWave), 0, st, node_table(e), spec_table(e),
+                     nq, (const int*)(base + o_pod), (const int*)(base + o_node), (const int*)(base + o_voff), e->d_pod_spec.as<int>(),
+                     e->d_pod_pin.as<int>(), (const i64*)(base + o_vreq), (const unsigned char*)(base + o_pres),
+                     pbytes ? (const u64*)(base + o_ports) : (const u64*)nullptr, (const int*)(base + o_start), pre, filt,
+                     (int*)(base + o_out));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(out, base + out_off, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out, base + o_out, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return YKPRED_OK;
+}
+
+int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
+                                const uint64_t* ports_after, int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
+  if (!out || nv < 0) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");
+  const int32_t voff[2] = {0, nv};
+  return ykpred_preemption_batch(e, 1, &pod, &node, voff, vreq, vpresent, ports_after, &start, pre, filt, out);
 }
 
 int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,

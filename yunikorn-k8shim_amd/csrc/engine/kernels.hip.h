@@ -999,23 +999,20 @@ __global__ __launch_bounds__(kBlock) void k_column_patch(ColumnGroups cg, int n_
   if (counts) counts[p] = class_count[c];
 }
 
-// PreemptionPredicates (predicate_manager.go:141-179): single (pod,node); victims removed in order.
-__global__ void k_preempt(NodeTable t, SpecTable s, int spec, int pin, int node, int n_victims, const i64* __restrict__ vreq,
-                          const unsigned char* __restrict__ vpresent, const u64* __restrict__ ports_after /*[n_victims][KP] or null*/,
-                          int start, unsigned pre_mask, unsigned filt_mask, int* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// PreemptionPredicates (predicate_manager.go:141-179) for one (pod,node): victims are removed in order; returns the first
+// index >= start at which the pod fits, or -1.
+__device__ __forceinline__ int preempt_one(const NodeTable& t, const SpecTable& s, int spec, int pin, int node, int n_victims,
+                                           const i64* __restrict__ vreq, const unsigned char* __restrict__ vpresent,
+                                           const u64* __restrict__ ports_after /*[n_victims][KP] or null*/, int start, unsigned pre_mask,
+                                           unsigned filt_mask) {
   NodeRegs nr;
   load_node(t, node, &nr);
   int code;
   unsigned reason;
   // PreFilter check first (:146-155): evaluate with filters disabled to see only PreFilter failures
-  if (!eval_pair(s, spec, pin, node, nr, pre_mask, 0u, &code, &reason)) {
-    *out = -1;
-    return;
-  }
+  if (!eval_pair(s, spec, pin, node, nr, pre_mask, 0u, &code, &reason)) return -1;
   i64 pods_on_node = t.count[node];
-  i64 allowed = t.allowed[node];
-  int result = -1;
+  const i64 allowed = t.allowed[node];
   for (int i = 0; i < n_victims; ++i) {
     if (vpresent[i]) {  // removePodFromNodeNoFail (:181-192)
       for (int r = 0; r < s.R && r < kMaxR; ++r) nr.fr[r] += vreq[(size_t)i * s.R + r];
@@ -1026,12 +1023,22 @@ __global__ void k_preempt(NodeTable t, SpecTable s, int spec, int pin, int node,
     if (i < start) continue;  // :161-163
     nr.slots_ok = pods_on_node + 1 <= allowed;
     // PreFilter outcomes were accepted above; eval_pair re-checks them (idempotent) and runs the filters (:168)
-    if (eval_pair(s, spec, pin, node, nr, pre_mask, filt_mask, &code, &reason)) {
-      result = i;
-      break;
-    }
+    if (eval_pair(s, spec, pin, node, nr, pre_mask, filt_mask, &code, &reason)) return i;
   }
-  *out = result;
+  return -1;
+}
+// thread = query; query q owns victims [voff[q], voff[q+1]) of the flattened victim arrays
+__global__ __launch_bounds__(kWave) void k_preempt(NodeTable t, SpecTable s, int n_queries, const int* __restrict__ q_pod,
+                                                   const int* __restrict__ q_node, const int* __restrict__ voff,
+                                                   const int* __restrict__ pod_spec, const int* __restrict__ pod_pin,
+                                                   const i64* __restrict__ vreq, const unsigned char* __restrict__ vpresent,
+                                                   const u64* __restrict__ ports_after, const int* __restrict__ q_start,
+                                                   unsigned pre_mask, unsigned filt_mask, int* __restrict__ out) {
+  int q = blockIdx.x * kWave + threadIdx.x;
+  if (q >= n_queries) return;
+  const int v0 = voff[q], nv = voff[q + 1] - v0, p = q_pod[q];
+  out[q] = preempt_one(t, s, pod_spec[p], pod_pin[p], q_node[q], nv, vreq + (size_t)v0 * s.R, vpresent + v0,
+                       ports_after ? ports_after + (size_t)v0 * t.KP : nullptr, q_start[q], pre_mask, filt_mask);
 }
 
 // order-independent checksum of the bitmap: Σ mix64(word ⊕ position-salt) over the meaningful words

@@ -911,53 +911,66 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
   return 0;
 }
 
-int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t nv, int32_t start) {
-  if (pod < 0 || pod >= (int)h->pending.size() || node < 0 || node >= (int)h->nodes.size()) return fail(h, "index out of range", -2);
-  int rc = sync(h);
-  if (rc) return -2;
-  ensure_uid_index(h);
-  const int R = h->enc.R;
-  const NodeInfo& ni = *h->nodes[(size_t)node];
-  std::vector<int64_t> vreq((size_t)std::max(nv, 1) * (size_t)R, 0);
-  std::vector<uint8_t> present((size_t)std::max(nv, 1), 0);
-  const int KP = h->enc.KP;
-  std::vector<uint64_t> ports_after((size_t)std::max(nv, 1) * (size_t)std::max(KP, 1), 0);
+// Appends the victim columns of one PreemptionPredicates query: request vectors, "really removed" flags (nil victims and
+// victims that are not on the node are ignored, predicate_manager.go:181-192) and the node's host-port bits after each removal.
+static void append_victims(ykhost* h, const NodeInfo& ni, const char* const* victim_uids, int32_t nv, std::vector<int64_t>* vreq,
+                           std::vector<uint8_t>* present, std::vector<uint64_t>* ports_after) {
+  const int R = h->enc.R, KP = h->enc.KP;
+  const size_t base = present->size();
+  vreq->resize((base + (size_t)nv) * (size_t)R, 0);
+  present->resize(base + (size_t)nv, 0);
+  ports_after->resize((base + (size_t)nv) * (size_t)std::max(KP, 1), 0);
   std::vector<const Pod*> remaining(ni.pods.begin(), ni.pods.end());
-  std::vector<const Pod*> gone;
   for (int i = 0; i < nv; ++i) {
-    if (!victim_uids || !victim_uids[i]) {  // nil victim (:182-184): the node is unchanged
-      if (KP) h->enc.encode_ports(remaining, ports_after.data() + (size_t)i * KP);
-      continue;
-    }
     const Pod* v = nullptr;
-    for (const Pod* q : ni.pods)
-      if (q->uid == victim_uids[i]) v = q;
-    // RemovePod fails (and is ignored) when the pod is not on the node or was already removed (:185-191)
-    if (!v || std::find(gone.begin(), gone.end(), v) != gone.end()) {
-      if (KP) h->enc.encode_ports(remaining, ports_after.data() + (size_t)i * KP);
-      continue;
+    if (victim_uids && victim_uids[i])
+      for (const Pod* q : remaining)
+        if (q->uid == victim_uids[i]) v = q;
+    if (v) {
+      remaining.erase(std::find(remaining.begin(), remaining.end(), v));
+      (*present)[base + (size_t)i] = 1;
+      Resource r = to_resource(v->tpl->requests);
+      int64_t* row = vreq->data() + (base + (size_t)i) * (size_t)R;
+      row[0] = r.milli_cpu;
+      row[1] = r.memory;
+      row[2] = r.ephemeral;
+      for (size_t s = 0; s < h->enc.scalar_names.size(); ++s) {
+        auto it = r.scalar.find(h->enc.scalar_names[s]);
+        if (it != r.scalar.end()) row[3 + s] = it->second;
+      }
     }
-    gone.push_back(v);
-    remaining.erase(std::find(remaining.begin(), remaining.end(), v));
-    if (KP) h->enc.encode_ports(remaining, ports_after.data() + (size_t)i * KP);  // NodeInfo.UsedPorts after this removal
-    present[(size_t)i] = 1;
-    Resource r = to_resource(v->tpl->requests);
-    vreq[(size_t)i * R + 0] = r.milli_cpu;
-    vreq[(size_t)i * R + 1] = r.memory;
-    vreq[(size_t)i * R + 2] = r.ephemeral;
-    for (size_t s = 0; s < h->enc.scalar_names.size(); ++s) {
-      auto it = r.scalar.find(h->enc.scalar_names[s]);
-      if (it != r.scalar.end()) vreq[(size_t)i * R + 3 + s] = it->second;
-    }
+    if (KP) h->enc.encode_ports(remaining, ports_after->data() + (base + (size_t)i) * (size_t)KP);  // NodeInfo.UsedPorts after this step
   }
+}
+
+int32_t ykhost_preemption_predicates_batch(ykhost_t* h, int32_t nq, const int32_t* pods, const int32_t* nodes, const int32_t* victim_off,
+                                           const char* const* victim_uids, const int32_t* start_index, int32_t* out_index) {
+  if (nq < 0 || (nq > 0 && (!pods || !nodes || !victim_off || !start_index || !out_index))) return fail(h, "bad argument", -2);
+  int rc = sync(h);
+  if (rc) return rc;
+  ensure_uid_index(h);
+  std::vector<int64_t> vreq;
+  std::vector<uint8_t> present;
+  std::vector<uint64_t> ports_after;
+  for (int q = 0; q < nq; ++q) {
+    if (pods[q] < 0 || pods[q] >= (int)h->pending.size() || nodes[q] < 0 || nodes[q] >= (int)h->nodes.size() || victim_off[q + 1] < victim_off[q])
+      return fail(h, "index out of range", -2);
+    append_victims(h, *h->nodes[(size_t)nodes[q]], victim_uids ? victim_uids + victim_off[q] : nullptr, victim_off[q + 1] - victim_off[q], &vreq,
+                   &present, &ports_after);
+  }
+  int64_t no_req = 0;
+  uint8_t no_flag = 0;
+  rc = ykpred_preemption_batch(h->eng, nq, pods, nodes, victim_off, vreq.empty() ? &no_req : vreq.data(), present.empty() ? &no_flag : present.data(),
+                               h->enc.KP ? ports_after.data() : nullptr, start_index, h->alloc_pre, h->alloc_filt, out_index);
+  if (rc) return fail(h, std::string("ykpred_preemption_batch: ") + ykpred_last_error(h->eng), rc);
+  return 0;
+}
+
+int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t nv, int32_t start) {
+  const int32_t off[2] = {0, nv};
   int32_t out = -1;
-  rc = ykpred_preemption_ports(h->eng, pod, node, nv, vreq.data(), present.data(), KP ? ports_after.data() : nullptr, start, h->alloc_pre,
-                               h->alloc_filt, &out);
-  if (rc) {
-    fail(h, std::string("ykpred_preemption: ") + ykpred_last_error(h->eng), rc);
-    return -2;
-  }
-  return out;
+  int rc = ykhost_preemption_predicates_batch(h, 1, &pod, &node, off, victim_uids, &start, &out);
+  return rc ? -2 : out;
 }
 
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len) {

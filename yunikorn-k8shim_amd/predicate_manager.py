@@ -183,6 +183,27 @@ class GpuPredicateManager:
             raise RuntimeError(self._L.ykhost_last_error(self._h).decode())
         return r
 
+    def preemption_predicates_batch(self, queries):
+        """queries: iterable of (pod, node, victim_uids, start_index) → list of indices; one device launch for all."""
+        queries = list(queries)
+        pods, nodes, off, starts, flat = [], [], [0], [], []
+        for pod, node, victims, start in queries:
+            p, n = self._resolve(pod, node)
+            pods.append(p)
+            nodes.append(n)
+            flat.extend(victims)
+            off.append(len(flat))
+            starts.append(start)
+        arr = (C.c_char_p * max(len(flat), 1))()
+        for i, v in enumerate(flat):
+            arr[i] = None if v is None else v.encode()
+        pa, na = np.asarray(pods, dtype=np.int32), np.asarray(nodes, dtype=np.int32)
+        oa, sa = np.asarray(off, dtype=np.int32), np.asarray(starts, dtype=np.int32)
+        out = np.full(len(queries), -1, dtype=np.int32)
+        self._check(self._L.ykhost_preemption_predicates_batch(self._h, len(queries), pa.ctypes.data, na.ctypes.data, oa.ctypes.data, arr,
+                                                               sa.ctypes.data, out.ctypes.data))
+        return out.tolist()
+
     def pod_request(self, pod):
         buf = C.create_string_buffer(4096)
         self._check(self._L.ykhost_pod_request_json(self._h, pod, buf, 4096))
