@@ -526,12 +526,15 @@ def test_sharded_decisions_match_single_engine():
             m.close()
 
 
-def test_preemption_predicates_batch(pm):
+@pytest.mark.parametrize("plugins", [["NodeResourcesFit", "NodePorts"], ["*"]])
+def test_preemption_predicates_batch(plugins):
     """Random PreemptionPredicates queries (victim prefixes, nil and foreign victims, host ports) in ONE launch, each
     against the oracle's sequential restatement of predicate_manager.go:141-179."""
     import random
     rng = random.Random(9)
     snap = _gen.random_snapshot(4321, n_nodes=120, n_pods=60, scalars=True)
+    pm = pkg.GpuPredicateManager.internal(plugins, plugins, plugins, plugins)
+    mask = orc.ALL if plugins == ["*"] else orc.mask_of(plugins)
     pm.load_snapshot(snap)
     o = orc.Oracle(snap)
     queries, want = [], []
@@ -552,7 +555,9 @@ def test_preemption_predicates_batch(pm):
             oidx.insert(pos, -1)
         start = rng.randrange(0, len(victims) + 1)
         queries.append((p, n, victims, start))
-        want.append(o.preemption(p, n, oidx, start))
+        want.append(o.preemption(p, n, oidx, start, mask, mask))
     got = pm.preemption_predicates_batch(queries)
+    pm.close()
     assert got == want
-    assert sum(1 for w in want if w >= 0) > 5, "degenerate: no query finds a victim index"
+    if plugins != ["*"]:
+        assert sum(1 for w in want if w >= 0) >= 10, "degenerate: hardly any query finds a victim index"
