@@ -819,7 +819,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool res_on = filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT;
   const bool aff_on = (filt | pre) & YKPRED_PLUGIN_NODE_AFFINITY;
   const int fit_error = (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1;
-  auto sig_chunks = [](int D) { return (unsigned)((D + ykk::kSigsPerBlock - 1) / ykk::kSigsPerBlock); };
+  auto sig_chunks = [](int D) {
+    const int spb = ykk::sigs_per_block(D);
+    return (unsigned)((D + spb - 1) / spb);
+  };
   ykk::AffSigs as{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
                   e->d_sig_pre_terms.as<u64>()};
   auto canon_of = [&](const Family& f) { return e->planes_canon.as<u64>() + (size_t)f.base * e->row_stride; };

@@ -39,7 +39,10 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kSigsPerBlock = 16;   // signatures walked by one plane block (lane i keeps the ballot word of signature i):
-                                    // the walk is latency-bound, so short walks in many blocks beat long ones
+                                    // the walk is latency-bound, so short walks in many blocks beat long ones ...
+constexpr int kSigsPerBlockMany = 64;  // ... until there are so many signatures that per-block overhead dominates
+constexpr int kManySigs = 4096;
+__host__ __device__ inline int sigs_per_block(int D) { return D > kManySigs ? kSigsPerBlockMany : kSigsPerBlock; }
 constexpr int kChunkMembers = 64;   // member pods per combine chunk (member ids live in the lanes of a wave)
 constexpr int kCombineUnroll = 4;   // row words per thread held in registers by k_combine
 
@@ -224,8 +227,9 @@ __device__ __forceinline__ void plane_res(const NodeTable& t, const int* __restr
       if (r < t.R) fr[r] = t.alloc[(size_t)r * t.n + n] - t.req[(size_t)r * t.n + n];
     slots_ok = (i64)t.count[n] + 1 <= (i64)t.allowed[n];
   }
-  int d0 = blockIdx.x * kSigsPerBlock;
-  int dend = min(d0 + kSigsPerBlock, o.D);
+  const int spb = sigs_per_block(o.D);
+  int d0 = blockIdx.x * spb;
+  int dend = min(d0 + spb, o.D);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
     const i64* v = sig_req + (size_t)d * t.R;
@@ -401,8 +405,9 @@ __global__ __launch_bounds__(kBlock) void k_permute_planes(int n_nodes, const in
   const int pos = w * kWave + lane;
   const int src = pos < n_nodes ? perm[pos] : -1;
   const int sw = src >> 6, sb = src & 63;
-  const int d0 = blockIdx.x * kSigsPerBlock;
-  const int dend = min(d0 + kSigsPerBlock, n_rows);
+  const int spb = sigs_per_block(n_rows);
+  const int d0 = blockIdx.x * spb;
+  const int dend = min(d0 + spb, n_rows);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
     bool bit = src >= 0 && ((canon[(size_t)d * stride + sw] >> sb) & 1ull);
@@ -552,8 +557,9 @@ __device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __re
   int dom[kMaxKD];
 #pragma unroll
   for (int k = 0; k < kMaxKD; ++k) dom[k] = (n >= 0 && k < t.KD) ? t.domain[(size_t)k * t.n + n] : -1;
-  int d0 = blockIdx.x * kSigsPerBlock;
-  int dend = min(d0 + kSigsPerBlock, o.D);
+  const int spb = sigs_per_block(o.D);
+  int d0 = blockIdx.x * spb;
+  int dend = min(d0 + spb, o.D);
   u64 keep = 0;
   for (int d = d0; d < dend; ++d) {
     bool ok = n >= 0 && constraints_fail(sp, d, dom, spread_en, ipa_en, nullptr) == 0;
@@ -575,9 +581,9 @@ struct PlaneArgs {
 };
 __global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
   if (blockIdx.z == 0) {
-    if ((int)blockIdx.x * kSigsPerBlock < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
+    if ((int)blockIdx.x * sigs_per_block(a.res.D) < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
   } else {
-    if ((int)blockIdx.x * kSigsPerBlock < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words, a.spread_en != 0, a.ipa_en != 0);
+    if ((int)blockIdx.x * sigs_per_block(a.spread.D) < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words, a.spread_en != 0, a.ipa_en != 0);
   }
 }
 
