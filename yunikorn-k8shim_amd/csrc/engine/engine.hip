@@ -908,9 +908,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order)
   if (want_dec) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
   // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
-  if (res_on || spread_on) {
+  auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name) {
     ykk::PlaneArgs pa{};
-    pa.perm = nullptr;
+    pa.perm = perm;
     pa.res = o_res;
     pa.spread = o_spread;
     if (!res_on) pa.res.D = 0;
@@ -922,10 +922,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     pa.spread_en = pts_en ? 1 : 0;
     pa.ipa_en = ipa_en ? 1 : 0;
     unsigned xchunks = std::max(sig_chunks(pa.res.D), sig_chunks(pa.spread.D));
-    tm.begin(st);
-    hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, st, nt, pa);
-    tm.end(st, "k_planes");
-  }
+    tm.begin(s);
+    hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, s, nt, pa);
+    tm.end(s, name);
+  };
+  if (res_on || spread_on) launch_ballot_planes(st, nullptr, "k_planes");
   launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes");
   // ---- stream B, part 3 (after the canonical ballot planes): their rank-ordered copies by bit permutation, then the
   // first feasible node of every class. Overlaps the start of k_combine.
@@ -933,10 +934,16 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     HIPCHK(hipEventRecord(e->ev_planes, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_planes, 0));
     const int ballot_rows = e->fam_tol.base;  // res + spread rows come first in the plane buffers
-    tm.begin(sb);
-    hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(ballot_rows), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
-                       e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, ballot_rows, e->row_words);
-    tm.end(sb, "k_permute_planes");
+    if (ballot_rows <= ykk::kManySigs) {
+      tm.begin(sb);
+      hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(ballot_rows), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
+                         e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, ballot_rows, e->row_words);
+      tm.end(sb, "k_permute_planes");
+    } else if (res_on || spread_on) {
+      // very many request / spread signatures: the bit gather would touch one cache line per lane and row; evaluating
+      // the signatures again in permuted node order is cheaper
+      launch_ballot_planes(sb, e->d_perm.as<int>(), "k_planes(ranked)");
+    }
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
                        pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
