@@ -15,7 +15,9 @@
  *                                /root/reference/pkg/cache/external/scheduler_cache.go:148-239,303-484
  *   ykhost_evaluate              the batched form of the core's loop over (ask, node) → Predicates()
  *
- * All functions return 0 on success, negative on error (text via ykhost_last_error).
+ * All functions return >= 0 on success, negative on error (text via ykhost_last_error). One lock per handle serialises
+ * the entry points: the reference's callers hold read locks only (pkg/cache/context.go:697,709), so several threads may be
+ * inside ykhost_predicates at once.
  */
 #ifndef YKHOST_H_
 #define YKHOST_H_
@@ -29,7 +31,9 @@ extern "C" {
 
 typedef struct ykhost ykhost_t;
 
-ykhost_t* ykhost_create(int32_t device, char* err, int32_t errlen); /* NULL on failure (no GPU ⇒ failure) */
+/* NULL on failure (no GPU ⇒ failure). device < 0 makes a mirror-only handle: cache bookkeeping, request vectors and
+ * snapshot dumps work, every evaluation fails (there is no CPU evaluation path). */
+ykhost_t* ykhost_create(int32_t device, char* err, int32_t errlen);
 void ykhost_destroy(ykhost_t* h);
 const char* ykhost_last_error(const ykhost_t* h);
 
@@ -39,12 +43,26 @@ int32_t ykhost_set_plugins(ykhost_t* h, uint32_t reservation_prefilters, uint32_
 
 /* --- cluster state (SchedulerCache mirror). JSON uses Kubernetes field names; see INTEGRATION.md. */
 int32_t ykhost_load_snapshot(ykhost_t* h, const char* json); /* {"nodes":[{..., "pods":[...]}], "pods":[pending asks]} — replaces all state */
-int32_t ykhost_update_node(ykhost_t* h, const char* node_json);
-int32_t ykhost_remove_node(ykhost_t* h, const char* node_name);
-int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json); /* spec.nodeName set ⇒ assigned to that node, else a pending ask */
-int32_t ykhost_remove_pod(ykhost_t* h, const char* uid);
-int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name); /* the ask keeps its index (row); it is skipped by dump */
+/* The six functions below restate the bookkeeping of scheduler_cache.go (podsMap / assignedPods / assumedPods /
+ * orphanedPods), pinned by the scenarios of pkg/cache/external/scheduler_cache_test.go (tests/test_host_cache.py). */
+int32_t ykhost_update_node(ykhost_t* h, const char* node_json);  /* → number of orphaned pods the (new) node adopted (:165-172) */
+int32_t ykhost_remove_node(ykhost_t* h, const char* node_name);  /* → number of pods orphaned; assumed pods are reverted to pending (:205-219);
+                                                                    unknown node: 0 */
+/* → 1, or 0 when the pod was stored as an orphan (spec.nodeName names an unknown node, :352-360). spec.nodeName set ⇒
+ * accounted on that node; unset ⇒ a pending ask (it inherits the node of the cached version, :336-339). status.phase
+ * Running clears the assumed mark, Failed / Succeeded drops the pod (:344-347,374-383). */
+int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json);
+int32_t ykhost_remove_pod(ykhost_t* h, const char* uid);         /* → 1 removed, 0 unknown uid (:390-417) */
+/* AssumePod: the cached pod gets spec.nodeName = node and is accounted there (moved from a node it was assumed on
+ * before); the ask keeps its index (row) and is skipped by dump. Unknown pod / node: error. */
+int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name);
+/* ForgetPod: the assumed mark is dropped; the cached pod keeps its node name and STAYS accounted on the node
+ * (scheduler_cache.go:471-476 re-runs updatePod on the cached pod). → 1, or 0 for an unknown uid. */
 int32_t ykhost_forget_pod(ykhost_t* h, const char* uid);
+/* cache introspection: bit0 in podsMap, bit1 assigned (accounted on a node), bit2 assumed, bit3 orphan, bit4 holds an ask
+ * row; node_out = spec.nodeName of the cached pod. 0 = unknown uid. */
+int32_t ykhost_pod_state(ykhost_t* h, const char* uid, char* node_out, int32_t node_len);
+int32_t ykhost_node_pod_count(ykhost_t* h, const char* node_name); /* len(NodeInfo.Pods), -1 = unknown node */
 
 /* synthetic KWOK-style cluster, replaces all state */
 typedef struct ykhost_kwok {

@@ -90,6 +90,48 @@ def test_default_manager_phases_and_messages(pm):
     assert plugin == "TaintToleration" and "taint" in err.message  # e2e `.*taint.*`, test/e2e/predicates/predicates_test.go:439
 
 
+def test_concurrent_readers(pm):
+    """Several core goroutines may sit in Predicates() at once (context.go:697,709 hold read locks only): 8 threads ask
+    for interleaved pairs in both phases while another evaluates the whole grid; every answer must equal the oracle's."""
+    import threading
+    snap = _gen.random_snapshot(4242, n_nodes=130, n_pods=48, spread=True, interpod=True)
+    pm.load_snapshot(snap)
+    o = orc.Oracle(snap)
+    want = {True: o.eval_grid(threads=8, want_plugin=True),
+            False: o.eval_grid(pre_mask=orc.RESERVE_PRE, filt_mask=orc.RESERVE_FILT, threads=8, want_plugin=True)}
+    P, N = want[True][0].shape
+    errors = []
+
+    def reader(tid):
+        try:
+            rng = np.random.default_rng(tid)
+            for _ in range(400):
+                p, n, allocate = int(rng.integers(P)), int(rng.integers(N)), bool(rng.integers(2))
+                plugin, err = pm.predicates(p, n, allocate)
+                fit, code = want[allocate][0][p, n], want[allocate][1][p, n]
+                if (plugin == "") != bool(fit) or (not fit and plugin != NAMES[code]):
+                    errors.append((tid, p, n, allocate, plugin, NAMES[code] if not fit else ""))
+        except Exception as exc:  # noqa: BLE001 - reported by the main thread
+            errors.append((tid, repr(exc)))
+
+    def evaluator():
+        try:
+            for i in range(20):
+                pm.evaluate(allocate=bool(i & 1))
+                got = unpack(pm.read_bitmap(), N)
+                if not np.array_equal(got, want[bool(i & 1)][0]):
+                    errors.append(("evaluate", i))
+        except Exception as exc:  # noqa: BLE001
+            errors.append(("evaluate", repr(exc)))
+
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(8)] + [threading.Thread(target=evaluator)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # randomized edge-case clusters: full grid, both phases, bits + failing plugin
 # ------------------------------------------------------------------------------------------------------------
@@ -322,23 +364,34 @@ def test_incremental_assume_forget(pm):
     names = [n["metadata"]["name"] for n in snap["nodes"] if n["metadata"]["name"]]
     cur = snap
     bound = []
-    for step in range(12):
-        if bound and rng.random() < 0.3:
+    for step in range(14):
+        r = rng.random()
+        if bound and r < 0.2:
+            # ForgetPod (scheduler_cache.go:463-484): the cached pod keeps spec.nodeName and stays accounted on the node; its
+            # row now answers like Predicates(cache.GetPod(uid), ...) would: only that node can pass the NodeName filter
             uid, target = bound.pop(rng.randrange(len(bound)))
             pm.forget_pod(uid)
             pod = next(p for p in snap["pods"] if p["metadata"]["uid"] == uid)
+            cur = {"nodes": cur["nodes"], "pods": cur["pods"] + [dict(pod, spec=dict(pod["spec"], nodeName=target))]}
+            expect_patched = -1  # the ask table changed (the row's node pin): full evaluation
+        elif bound and r < 0.4:
+            # RemovePod of a bound pod (:390-417): it leaves the node and the ask table
+            uid, target = bound.pop(rng.randrange(len(bound)))
+            pm.remove_pod(uid)
             nodes = json.loads(json.dumps(cur["nodes"]))
             tn = next(n for n in nodes if n["metadata"]["name"] == target)
             tn["pods"] = [q for q in tn["pods"] if q["metadata"]["uid"] != uid]
-            cur = {"nodes": nodes, "pods": cur["pods"] + [pod]}
+            cur = {"nodes": nodes, "pods": cur["pods"]}
+            expect_patched = -1
         else:
             uid = rng.choice([p for p in cur["pods"] if not p["spec"].get("nodeName")])["metadata"]["uid"]
             target = rng.choice(names)
             pm.assume_pod(uid, target)
             bound.append((uid, target))
             cur = _move(cur, uid, target)
+            expect_patched = 1  # exactly one node column changed
         patched = pm.evaluate_dirty(decisions=(step % 3 == 0))
-        assert patched == 1, "exactly one node column changed"
+        assert patched == expect_patched
         _compare_live_rows(pm, cur, decisions=(step % 3 == 0))
     # several nodes touched between two evaluations, some sharing a bitmap word
     free = [p["metadata"]["uid"] for p in cur["pods"] if not p["spec"].get("nodeName")]

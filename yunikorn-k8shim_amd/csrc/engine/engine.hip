@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -55,6 +56,9 @@ struct Family {
 }  // namespace
 
 struct ykpred_engine {
+  // The reference's PredicateManager is called by concurrent readers (context.go:697,709 take read locks only), and
+  // every entry point below uses engine-owned staging buffers and streams: calls on one engine are serialised here.
+  mutable std::recursive_mutex mu;
   ykpred_config_t cfg{};
   int R = 3, KT = 1, W = 1;
   hipStream_t own_stream = nullptr;
@@ -416,6 +420,11 @@ int run_spread_prefilter(ykpred_engine* e, hipStream_t st, Timer* tm, bool do_co
 
 }  // namespace
 
+// null handles fall through to the entry point's own argument check
+#define YK_SERIALISE(eng) \
+  std::unique_lock<std::recursive_mutex> engine_lock; \
+  if (eng) engine_lock = std::unique_lock<std::recursive_mutex>((eng)->mu)
+
 extern "C" {
 
 int32_t ykpred_abi_version(void) { return YKPRED_ABI_VERSION; }
@@ -514,6 +523,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
 }
 
 int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
+  YK_SERIALISE(e);
   if (!e || !n || n->count < 0) return fail(e, YKPRED_E_INVALID, "set_nodes: bad argument");
   if (n->count > 0 && (!n->allocatable || !n->requested || !n->allowed_pods || !n->pod_count || !n->flags || !n->taint_bits ||
                        !n->label_bits))
@@ -562,6 +572,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
 }
 
 int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t* n) {
+  YK_SERIALISE(e);
   if (!e || !n || n->count != 1) return fail(e, YKPRED_E_INVALID, "update_node: count must be 1");
   if (!e->nodes_set || idx < 0 || idx >= e->N) return fail(e, YKPRED_E_INVALID, "update_node: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -593,6 +604,7 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
 }
 
 int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
+  YK_SERIALISE(e);
   if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
   if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
     return fail(e, YKPRED_E_INVALID, "set_specs: null column");
@@ -727,6 +739,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
 }
 
 int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* p) {
+  YK_SERIALISE(e);
   if (!e || !p || p->count < 0) return fail(e, YKPRED_E_INVALID, "set_pods: bad argument");
   if (p->count > 0 && (!p->spec_index || !p->node_name_index)) return fail(e, YKPRED_E_INVALID, "set_pods: null column");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -752,6 +765,7 @@ static int validate_state(ykpred_engine* e) {
 }
 
 int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
+  YK_SERIALISE(e);
   if (!e || !a) return fail(e, YKPRED_E_INVALID, "eval: bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
@@ -995,6 +1009,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
 }
 
 int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_t num_nodes, const int32_t* node_index) {
+  YK_SERIALISE(e);
   if (!e || !a || num_nodes < 0 || (num_nodes > 0 && !node_index)) return fail(e, YKPRED_E_INVALID, "eval_nodes: bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
@@ -1057,6 +1072,7 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
 }
 
 int32_t ykpred_synchronize(ykpred_engine_t* e) {
+  YK_SERIALISE(e);
   if (!e) return YKPRED_E_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
@@ -1064,6 +1080,7 @@ int32_t ykpred_synchronize(ykpred_engine_t* e) {
 }
 
 int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
+  YK_SERIALISE(e);
   if (!e || !o) return YKPRED_E_INVALID;
   o->num_nodes = e->N;
   o->num_pods = e->P;
@@ -1085,6 +1102,7 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
 }
 
 int32_t ykpred_last_timing(const ykpred_engine_t* ce, ykpred_timing_t* o) {
+  YK_SERIALISE(ce);
   ykpred_engine_t* e = const_cast<ykpred_engine_t*>(ce);
   if (!e || !o) return YKPRED_E_INVALID;
   if (!e->timing_valid) return fail(e, YKPRED_E_STATE, "last eval was not run with YKPRED_EVAL_PROFILE");
@@ -1103,6 +1121,7 @@ int32_t ykpred_last_timing(const ykpred_engine_t* ce, ykpred_timing_t* o) {
 }
 
 int32_t ykpred_read_bitmap(ykpred_engine_t* e, int32_t first, int32_t num, uint64_t* out) {
+  YK_SERIALISE(e);
   if (!e || !out || first < 0 || num < 0 || first + num > e->P) return fail(e, YKPRED_E_INVALID, "read_bitmap: range");
   if (!e->last_bitmap) return fail(e, YKPRED_E_STATE, "read_bitmap: no eval yet");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -1115,6 +1134,7 @@ int32_t ykpred_read_bitmap(ykpred_engine_t* e, int32_t first, int32_t num, uint6
 }
 
 int32_t ykpred_read_counts(ykpred_engine_t* e, int32_t* out) {
+  YK_SERIALISE(e);
   if (!e || !out) return YKPRED_E_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
@@ -1122,6 +1142,7 @@ int32_t ykpred_read_counts(ykpred_engine_t* e, int32_t* out) {
   return YKPRED_OK;
 }
 int32_t ykpred_read_decisions(ykpred_engine_t* e, int32_t* out) {
+  YK_SERIALISE(e);
   if (!e || !out) return YKPRED_E_INVALID;
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
@@ -1129,6 +1150,7 @@ int32_t ykpred_read_decisions(ykpred_engine_t* e, int32_t* out) {
   return YKPRED_OK;
 }
 int32_t ykpred_read_scores(ykpred_engine_t* e, double* out) {
+  YK_SERIALISE(e);
   if (!e || !out) return YKPRED_E_INVALID;
   if (!e->nodes_set) return fail(e, YKPRED_E_STATE, "read_scores: no nodes");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -1143,6 +1165,7 @@ int32_t ykpred_read_scores(ykpred_engine_t* e, double* out) {
 }
 
 int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
+  YK_SERIALISE(e);
   if (!e || !out) return YKPRED_E_INVALID;
   if (!e->last_bitmap) return fail(e, YKPRED_E_STATE, "checksum: no eval yet");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -1159,6 +1182,7 @@ int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
 
 int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const int32_t* nodes, uint32_t pre, uint32_t filt, uint8_t* fit,
                      uint8_t* code, uint32_t* reason) {
+  YK_SERIALISE(e);
   if (!e || n < 0 || (n > 0 && (!pods || !nodes || !fit))) return fail(e, YKPRED_E_INVALID, "query: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query: tables not uploaded");
   for (int i = 0; i < n; ++i)
@@ -1189,6 +1213,7 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
 }
 
 int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t filt, uint8_t* fit, uint8_t* code, uint32_t* reason) {
+  YK_SERIALISE(e);
   if (!e || !fit) return fail(e, YKPRED_E_INVALID, "query_pod: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query_pod: tables not uploaded");
   if (pod < 0 || pod >= e->P) return fail(e, YKPRED_E_INVALID, "query_pod: index out of range");
@@ -1215,6 +1240,7 @@ int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t
 int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t nq, const int32_t* pods, const int32_t* nodes, const int32_t* voff,
                                 const int64_t* vreq, const uint8_t* vpresent, const uint64_t* ports_after, const int32_t* start,
                                 uint32_t pre, uint32_t filt, int32_t* out) {
+  YK_SERIALISE(e);
   if (!e || nq < 0 || (nq > 0 && (!pods || !nodes || !voff || !start || !out))) return fail(e, YKPRED_E_INVALID, "preemption: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "preemption: tables not uploaded");
   if (nq == 0) return YKPRED_OK;

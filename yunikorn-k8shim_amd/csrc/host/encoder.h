@@ -344,6 +344,17 @@ class Encoder {
     }
   }
 
+  // True when accounting a pod of this template on a node needs no dictionary that does not exist yet (scalar resource
+  // names, topology keys / count classes of its required anti-affinity terms). False → rebuild the dictionaries.
+  bool node_pod_known(const PodTemplate& t) const {
+    for (auto& kv : t.requests)
+      if (is_scalar_resource_name(kv.first) && !scalar_ix_.count(kv.first)) return false;
+    if (!t.pod_anti_affinity.empty() &&
+        std::find(existing_anti_templates_.begin(), existing_anti_templates_.end(), &t) == existing_anti_templates_.end())
+      return false;
+    return true;
+  }
+
   std::vector<int32_t> domain_sizes() const {
     std::vector<int32_t> out;
     for (auto& m : domain_ids) out.push_back((int32_t)m.size());

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -47,6 +48,9 @@ struct Rng {  // splitmix64
 using namespace ykh;
 
 struct ykhost {
+  // Context.IsPodFitNode runs under read locks only (context.go:697,709), so several core goroutines may be inside
+  // Predicates() at once while the mirror's answer cache and lazy sync mutate state: one lock around every entry point.
+  mutable std::recursive_mutex mu;
   ykpred_engine_t* eng = nullptr;
   int device = 0;
   std::string err;
@@ -140,6 +144,7 @@ int recreate_engine(ykhost* h) {
     return 0;
   if (h->eng) ykpred_destroy(h->eng);
   h->eng = nullptr;
+  if (h->device < 0) return fail(h, "mirror-only handle (device < 0): no device engine, nothing can be evaluated", YKPRED_E_STATE);
   ykpred_config_t c{};
   c.abi_version = YKPRED_ABI_VERSION;
   c.device = h->device;
@@ -335,6 +340,79 @@ void touch_node(ykhost* h, int n) {
   if (!h->dirty_all) {
     h->dirty_nodes.push_back(n);
     h->eval_dirty_nodes.push_back(n);
+  }
+}
+
+// ---- SchedulerCache bookkeeping (scheduler_cache.go:303-388) ---------------------------------------------
+// Placing a pod on a node may need dictionary entries that were built from the pods already on nodes.
+void touch_node_for(ykhost* h, int n, const Pod* p) {
+  if (!h->enc.node_pod_known(*p->tpl)) h->dirty_all = true;
+  touch_node(h, n);
+}
+// Drops the assignedPods entry of `p` and takes it off its NodeInfo (:321-340).
+void detach_from_node(ykhost* h, Pod* p) {
+  if (p->assigned_node.empty()) return;
+  auto nt = h->node_ix.find(p->assigned_node);
+  if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
+  p->assigned_node.clear();
+}
+// cache.updatePod for the new version `p` of the cached pod `old` (null: not cached; == p: re-evaluate in place).
+// Returns false when the pod ends up orphaned (:352-360).
+bool cache_update_pod(ykhost* h, Pod* old, Pod* p, bool running, bool terminated) {
+  if (old) {
+    const std::string prev = old->assigned_node;
+    const bool was_assumed = old->assumed;
+    detach_from_node(h, old);
+    old->orphan = false;
+    if (!prev.empty() && p->node_name.empty()) p->node_name = prev;  // "new pod wasn't assigned to a node, so use existing assignment"
+    p->assumed = was_assumed;
+  }
+  if (running || terminated) p->assumed = false;  // "pod has now been bound" (:344-347)
+  bool result = true;
+  p->orphan = false;
+  if (!p->node_name.empty() && !terminated) {
+    auto nt = h->node_ix.find(p->node_name);
+    if (nt == h->node_ix.end()) {
+      p->orphan = true;
+      result = false;
+    } else {
+      h->nodes[(size_t)nt->second]->add_pod(p);
+      p->assigned_node = p->node_name;
+      touch_node_for(h, nt->second, p);
+    }
+  }
+  if (!terminated) {
+    h->by_uid[p->uid] = p;
+  } else {
+    p->assumed = p->orphan = false;
+    h->by_uid.erase(p->uid);
+  }
+  return result;
+}
+// Row bookkeeping of the ask table: `old` leaves its row (if it has one), `now` (may be null) takes it over in place or
+// is appended.
+void set_ask_row(ykhost* h, Pod* old, Pod* now) {
+  long row = -1;
+  if (old && old->ask)
+    for (size_t i = 0; i < h->pending.size(); ++i)
+      if (h->pending[i] == old) {
+        row = (long)i;
+        break;
+      }
+  if (old) old->ask = false;
+  if (now) {
+    now->ask = true;
+    if (row >= 0)
+      h->pending[(size_t)row] = now;
+    else
+      h->pending.push_back(now);
+    if (now->tpl->spec_id < 0)
+      h->dirty_all = true;  // new template: dictionaries may grow
+    else
+      h->dirty_pods = true;
+  } else if (row >= 0) {
+    h->pending.erase(h->pending.begin() + row);
+    h->dirty_pods = true;
   }
 }
 
@@ -555,7 +633,7 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
       const PodTemplate* at = h->pool.intern(std::move(a));
       Pod p;
       p.uid = p.name = fmt("n%d-p0", n);
-      p.node_name = nd.name;
+      p.node_name = p.assigned_node = nd.name;
       p.tpl = at;
       h->pod_store.push_back(std::move(p));
       ni.add_pod(&h->pod_store.back());
@@ -569,7 +647,7 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
       for (int i = 1; i < k; ++i) {
         Pod q;
         q.uid = q.name = "n" + std::to_string(n) + "-p" + std::to_string(i);
-        q.node_name = nd.name;
+        q.node_name = q.assigned_node = nd.name;
         q.tpl = bt;
         h->pod_store.push_back(std::move(q));
         ni.add_pod(&h->pod_store.back());
@@ -599,6 +677,7 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
       pod.node_name = fmt("kwok-node-%06d", (int)g.below((uint32_t)N));  // a GLOBAL name of shard 0's range
     else if (pin == 10)
       pod.node_name = "no-such-node";
+    pod.ask = true;
     h->pod_store.push_back(std::move(pod));
     h->pending.push_back(&h->pod_store.back());
   }
@@ -609,16 +688,19 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
 }  // namespace
 
 // =====================================================================================================
+#define YKHOST_LOCKED(h) std::lock_guard<std::recursive_mutex> host_lock((h)->mu)
+
 extern "C" {
 
 ykhost_t* ykhost_create(int32_t device, char* err, int32_t errlen) {
   auto* h = new ykhost();
   h->device = device;
-  // create the engine eagerly with the minimal shape so that a missing GPU fails here, loudly
+  // create the engine eagerly with the minimal shape so that a missing GPU fails here, loudly; device < 0 makes a
+  // mirror-only handle (cache bookkeeping, request vectors, snapshot dumps) on which every evaluation fails
   h->enc.R = 3;
   h->enc.KT = 1;
   h->enc.W = 1;
-  if (recreate_engine(h) != 0) {
+  if (device >= 0 && recreate_engine(h) != 0) {
     copy_out(h->err, err, errlen);
     delete h;
     return nullptr;
@@ -633,6 +715,7 @@ void ykhost_destroy(ykhost_t* h) {
 const char* ykhost_last_error(const ykhost_t* h) { return h ? h->err.c_str() : ""; }
 
 int32_t ykhost_set_plugins(ykhost_t* h, uint32_t rp, uint32_t ap, uint32_t rf, uint32_t af) {
+  YKHOST_LOCKED(h);
   h->answers.pod = -1;
   h->res_pre = rp;
   h->alloc_pre = ap;
@@ -642,6 +725,7 @@ int32_t ykhost_set_plugins(ykhost_t* h, uint32_t rp, uint32_t ap, uint32_t rf, u
 }
 
 int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
+  YKHOST_LOCKED(h);
   try {
     mj::ValuePtr root = mj::parse(json);
     h->clear_state();
@@ -660,7 +744,7 @@ int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
             for (int64_t r = 0; r < reps; ++r) {
               Pod* p = add_pod_object(h, *pv, &anon);
               if (reps > 1) p->uid += "#" + std::to_string(r);
-              p->node_name = ni.node.name;
+              p->node_name = p->assigned_node = ni.node.name;
               ni.add_pod(p);
               h->by_uid[p->uid] = p;
             }
@@ -668,7 +752,8 @@ int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
       }
     if (const mj::Value* pods = root->get_nn("pods"))
       for (auto& pv : pods->arr) {
-        Pod* p = add_pod_object(h, *pv, &anon);
+        Pod* p = add_pod_object(h, *pv, &anon);  // an ask of the snapshot; a spec.nodeName it carries is only the NodeName filter's input
+        p->ask = true;
         h->pending.push_back(p);
         h->by_uid[p->uid] = p;
       }
@@ -679,11 +764,14 @@ int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
   }
 }
 
-// SchedulerCache.UpdateNode (scheduler_cache.go:148-187): add or replace the node object, keep its pods.
+// SchedulerCache.UpdateNode (scheduler_cache.go:148-187): add or replace the node object, keep its pods; a NEW node
+// adopts the orphaned pods whose spec.nodeName is its name (:165-172). Returns the number of adopted pods.
 int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
+  YKHOST_LOCKED(h);
   try {
     mj::ValuePtr v = mj::parse(node_json);
     Node n = read_node(*v);
+    int adopted = 0;
     auto it = h->node_ix.find(n.name);
     if (it == h->node_ix.end()) {
       h->node_store.emplace_back();
@@ -692,21 +780,48 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
       ni.index = (int32_t)h->nodes.size();
       h->node_ix[n.name] = ni.index;
       h->nodes.push_back(&ni);
+      ensure_uid_index(h);
+      std::vector<Pod*> orphans;
+      for (auto& kv : h->by_uid)
+        if (kv.second->orphan && kv.second->node_name == n.name) orphans.push_back(kv.second);
+      for (Pod* p : orphans)
+        if (cache_update_pod(h, p, p, false, false)) ++adopted;
     } else {
       h->nodes[(size_t)it->second]->set_node(n);
     }
     h->dirty_all = true;  // labels / taints / scalars may extend the dictionaries
-    return 0;
+    return adopted;
   } catch (const std::exception& e) {
     return fail(h, e.what());
   }
 }
 
-// SchedulerCache.RemoveNode (:189-239): pods that were on the node become unassigned (orphans are dropped here).
+// SchedulerCache.RemoveNode (:189-239). A pod that is still assumed was never bound: its assignment is reverted and it
+// is a pending ask again (:205-219); every other pod of the node becomes an orphan that the node adopts again if it
+// comes back. Returns the number of orphans; removing an unknown node is a no-op (:192-195).
 int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
+  YKHOST_LOCKED(h);
   auto it = h->node_ix.find(name);
-  if (it == h->node_ix.end()) return fail(h, "node not found");
+  if (it == h->node_ix.end()) return 0;
   int idx = it->second;
+  ensure_uid_index(h);
+  int orphans = 0;
+  for (const Pod* cp : h->nodes[(size_t)idx]->pods) {
+    auto pt = h->by_uid.find(cp->uid);
+    if (pt == h->by_uid.end() || pt->second != cp) continue;  // not in podsMap any more
+    Pod* p = pt->second;
+    const bool revert = p->assumed;
+    p->assigned_node.clear();
+    p->assumed = false;
+    if (revert) {
+      p->node_name.clear();
+      if (p->ask) h->dirty_pods = true;  // the row loses its nodeName pin
+    } else {
+      p->orphan = true;
+      ++orphans;
+    }
+  }
+  h->nodes[(size_t)idx]->pods.clear();
   h->nodes.erase(h->nodes.begin() + idx);
   h->node_ix.clear();
   for (size_t i = 0; i < h->nodes.size(); ++i) {
@@ -714,112 +829,127 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
     h->node_ix[h->nodes[i]->node.name] = (int)i;
   }
   h->dirty_all = true;
-  return 0;
+  return orphans;
 }
 
-// SchedulerCache.UpdatePod (:303-388): drop the old version, then account the pod on its node if assigned.
+// SchedulerCache.UpdatePod (:303-388). Returns 1, or 0 when the pod was stored as an orphan (its node is unknown).
+// Ask table: an unassigned, not yet running pod is a pending ask and holds a row; a pod that arrives with a
+// spec.nodeName of its own was bound by the cluster and holds none. A pod that already holds a row keeps it (in place)
+// while it is neither running nor terminated, so that rows stay stable while binds are in flight.
 int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json) {
+  YKHOST_LOCKED(h);
   try {
     mj::ValuePtr v = mj::parse(pod_json);
     ensure_uid_index(h);
-    std::string uid;
-    if (const mj::Value* md = v->get_nn("metadata")) uid = md->str_or("uid", "");
-    if (!uid.empty() && h->by_uid.count(uid)) ykhost_remove_pod(h, uid.c_str());
     size_t anon = h->pod_store.size();
     Pod* p = add_pod_object(h, *v, &anon);
-    h->by_uid[p->uid] = p;
     std::string phase;
     if (const mj::Value* st = v->get_nn("status")) phase = st->str_or("phase", "");
-    bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated
-    if (!p->node_name.empty() && !terminated) {
-      auto it = h->node_ix.find(p->node_name);
-      if (it != h->node_ix.end()) {
-        h->nodes[(size_t)it->second]->add_pod(p);
-        touch_node(h, it->second);
-      }
-    } else if (p->node_name.empty() && !terminated) {
-      h->pending.push_back(p);
-      if (p->tpl->spec_id < 0)
-        h->dirty_all = true;  // new template: dictionaries may grow
-      else
-        h->dirty_pods = true;
-    }
-    return 0;
+    const bool running = phase == "Running";                           // utils.IsPodRunning (utils.go:89-91)
+    const bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated (:93-95)
+    auto it = h->by_uid.find(p->uid);
+    Pod* old = it == h->by_uid.end() ? nullptr : it->second;
+    const bool bound_by_cluster = !p->node_name.empty();
+    const bool ok = cache_update_pod(h, old, p, running, terminated);
+    const bool wants_row = !terminated && !running && (old && old->ask ? true : !bound_by_cluster);
+    set_ask_row(h, old, wants_row ? p : nullptr);
+    return ok ? 1 : 0;
   } catch (const std::exception& e) {
     return fail(h, e.what());
   }
 }
 
+// SchedulerCache.RemovePod (:390-417): unknown pods are ignored.
 int32_t ykhost_remove_pod(ykhost_t* h, const char* uid) {
+  YKHOST_LOCKED(h);
   ensure_uid_index(h);
   auto it = h->by_uid.find(uid);
-  if (it == h->by_uid.end()) return fail(h, "pod not found");
+  if (it == h->by_uid.end()) return 0;
   Pod* p = it->second;
-  for (size_t i = 0; i < h->pending.size(); ++i)
-    if (h->pending[i] == p) {
-      h->pending.erase(h->pending.begin() + (long)i);
-      h->dirty_pods = true;
-      break;
-    }
-  if (!p->node_name.empty()) {
-    auto nt = h->node_ix.find(p->node_name);
-    if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
-  }
+  detach_from_node(h, p);
+  set_ask_row(h, p, nullptr);
+  p->assumed = p->orphan = false;
   h->by_uid.erase(it);
-  return 0;
+  return 1;
 }
 
-// Context.AssumePod → SchedulerCache.AssumePod (context.go:828-885, scheduler_cache.go:443-461): the ask is bound
-// to the node in the cache; the node's Requested / pod count grow and later predicate calls see it.
+// Context.AssumePod → SchedulerCache.AssumePod (context.go:828-885, scheduler_cache.go:443-461): the cached pod gets
+// spec.nodeName = node and goes through updatePod, i.e. it is accounted on the node (moving there from a node it was
+// assumed on before), and is marked assumed. Unknown pod or node: nothing happens (context.go:831,835).
 int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name) {
+  YKHOST_LOCKED(h);
   ensure_uid_index(h);
   auto it = h->by_uid.find(uid);
   auto nt = h->node_ix.find(node_name);
   if (it == h->by_uid.end()) return fail(h, "pod not found");
   if (nt == h->node_ix.end()) return fail(h, "node not found");
   Pod* p = it->second;
-  if (p->assumed || !p->node_name.empty()) return fail(h, "pod is already assigned");
-  // The ask keeps its row in the ask table (marked assumed) so that pod indices — bitmap rows — stay stable during a
-  // scheduling cycle; only the node's row and bitmap column change.
-  p->assumed = true;
+  // The ask keeps its row in the ask table so that pod indices (bitmap rows) stay stable during a scheduling cycle; only
+  // node rows and bitmap columns change. The core does not ask about an ask it has allocated, so the row is left
+  // evaluating the spec without the nodeName pin until something else rebuilds the ask table.
+  detach_from_node(h, p);
   p->node_name = node_name;
-  h->nodes[(size_t)nt->second]->add_pod(p);
-  touch_node(h, nt->second);
+  cache_update_pod(h, p, p, false, false);
+  p->assumed = true;
   return 0;
 }
 
-// SchedulerCache.ForgetPod (:463-484): undo an assumption; the pod is a pending ask again.
+// Context.ForgetPod → SchedulerCache.ForgetPod (context.go:887-898, scheduler_cache.go:463-484): updatePod of the
+// CACHED pod — which still carries the node name it was assumed on, so it stays accounted on that node — and the
+// assumed mark is dropped. The ask's answers are from now on those of a pod with spec.nodeName set (NodeName filter).
 int32_t ykhost_forget_pod(ykhost_t* h, const char* uid) {
+  YKHOST_LOCKED(h);
   ensure_uid_index(h);
   auto it = h->by_uid.find(uid);
-  if (it == h->by_uid.end()) return fail(h, "pod not found");
+  if (it == h->by_uid.end()) return 0;  // "unable to forget pod: not found in cache" (context.go:897)
   Pod* p = it->second;
-  if (!p->assumed) return fail(h, "pod is not assumed");
-  auto nt = h->node_ix.find(p->node_name);
-  if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
-  p->node_name.clear();
+  cache_update_pod(h, p, p, false, false);
+  if (p->assumed && p->ask) h->dirty_pods = true;  // the row now follows the cached pod: pinned to its node
   p->assumed = false;
-  return 0;
+  return 1;
+}
+
+// Cache introspection for tests: flags bit0 in podsMap, bit1 assigned (accounted on a node), bit2 assumed, bit3 orphan,
+// bit4 holds an ask row. node_out receives spec.nodeName of the cached pod.
+int32_t ykhost_pod_state(ykhost_t* h, const char* uid, char* node_out, int32_t node_len) {
+  YKHOST_LOCKED(h);
+  ensure_uid_index(h);
+  copy_out("", node_out, node_len);
+  auto it = h->by_uid.find(uid);
+  if (it == h->by_uid.end()) return 0;
+  const Pod* p = it->second;
+  copy_out(p->node_name, node_out, node_len);
+  return 1 | (p->assigned_node.empty() ? 0 : 2) | (p->assumed ? 4 : 0) | (p->orphan ? 8 : 0) | (p->ask ? 16 : 0);
+}
+// len(NodeInfo.Pods) of a cached node, -1 when the node is not in the cache.
+int32_t ykhost_node_pod_count(ykhost_t* h, const char* name) {
+  YKHOST_LOCKED(h);
+  auto it = h->node_ix.find(name);
+  return it == h->node_ix.end() ? -1 : (int32_t)h->nodes[(size_t)it->second]->pods.size();
 }
 
 int32_t ykhost_generate_kwok(ykhost_t* h, const ykhost_kwok_t* cfg) {
+  YKHOST_LOCKED(h);
   if (!cfg || cfg->num_nodes < 0 || cfg->num_pods < 0) return fail(h, "bad kwok config");
   return generate_kwok(h, *cfg);
 }
 
-int32_t ykhost_num_nodes(const ykhost_t* h) { return (int32_t)h->nodes.size(); }
-int32_t ykhost_num_pods(const ykhost_t* h) { return (int32_t)h->pending.size(); }
+int32_t ykhost_num_nodes(const ykhost_t* h) { YKHOST_LOCKED(h); return (int32_t)h->nodes.size(); }
+int32_t ykhost_num_pods(const ykhost_t* h) { YKHOST_LOCKED(h); return (int32_t)h->pending.size(); }
 int32_t ykhost_pod_index(const ykhost_t* h, const char* uid) {
+  YKHOST_LOCKED(h);
   for (size_t i = 0; i < h->pending.size(); ++i)
     if (h->pending[i]->uid == uid) return (int32_t)i;
   return -1;
 }
 int32_t ykhost_node_index(const ykhost_t* h, const char* name) {
+  YKHOST_LOCKED(h);
   auto it = h->node_ix.find(name);
   return it == h->node_ix.end() ? -1 : it->second;
 }
 
 int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len) {
+  YKHOST_LOCKED(h);
   std::string o = "{\"nodes\":[";
   int count_n = nodes ? nn : (int)h->nodes.size();
   for (int i = 0; i < count_n; ++i) {
@@ -842,10 +972,11 @@ int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const
   return (int64_t)o.size() + 1;
 }
 
-int32_t ykhost_sync(ykhost_t* h) { return sync(h); }
+int32_t ykhost_sync(ykhost_t* h) { YKHOST_LOCKED(h); return sync(h); }
 ykpred_engine_t* ykhost_engine(ykhost_t* h) { return h->eng; }
 
 int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
+  YKHOST_LOCKED(h);
   int rc = sync(h);
   if (rc) return rc;
   ykpred_eval_args_t a{};
@@ -861,6 +992,7 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
 }
 
 int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched) {
+  YKHOST_LOCKED(h);
   if (columns_patched) *columns_patched = -1;
   // topology constraints (spread, inter-pod affinity) couple all nodes through their histograms: full evaluation
   const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0) && h->enc.KD == 0;
@@ -884,6 +1016,7 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
 
 int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t allocate, char* plugin, int32_t plugin_len, char* msg,
                           int32_t msg_len) {
+  YKHOST_LOCKED(h);
   if (pod < 0 || pod >= (int)h->pending.size() || node < 0 || node >= (int)h->nodes.size()) return fail(h, "index out of range", -1);
   int rc = sync(h);
   if (rc) return rc;
@@ -945,6 +1078,7 @@ static void append_victims(ykhost* h, const NodeInfo& ni, const char* const* vic
 
 int32_t ykhost_preemption_predicates_batch(ykhost_t* h, int32_t nq, const int32_t* pods, const int32_t* nodes, const int32_t* victim_off,
                                            const char* const* victim_uids, const int32_t* start_index, int32_t* out_index) {
+  YKHOST_LOCKED(h);
   if (nq < 0 || (nq > 0 && (!pods || !nodes || !victim_off || !start_index || !out_index))) return fail(h, "bad argument", -2);
   int rc = sync(h);
   if (rc) return rc;
@@ -967,6 +1101,7 @@ int32_t ykhost_preemption_predicates_batch(ykhost_t* h, int32_t nq, const int32_
 }
 
 int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t nv, int32_t start) {
+  YKHOST_LOCKED(h);
   const int32_t off[2] = {0, nv};
   int32_t out = -1;
   int rc = ykhost_preemption_predicates_batch(h, 1, &pod, &node, off, victim_uids, &start, &out);
@@ -974,6 +1109,7 @@ int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, con
 }
 
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len) {
+  YKHOST_LOCKED(h);
   if (pod < 0 || pod >= (int)h->pending.size()) return fail(h, "index out of range");
   std::string js = "{";
   bool first = true;
@@ -988,6 +1124,7 @@ int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len
 }
 
 int32_t ykhost_stats(const ykhost_t* h, int64_t* o) {
+  YKHOST_LOCKED(h);
   o[0] = h->enc.R;
   o[1] = h->enc.KT;
   o[2] = h->enc.W;

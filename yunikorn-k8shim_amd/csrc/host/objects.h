@@ -90,7 +90,12 @@ struct Pod {
   std::string uid, name;
   std::string node_name;  // spec.nodeName ("" = pending ask)
   bool terminating = false;
-  bool assumed = false;  // a pending ask that was bound to node_name by AssumePod: it keeps its row in the ask table
+  // SchedulerCache membership (scheduler_cache.go:57-62): podsMap = the mirror's uid index; the other three maps are
+  // per-pod fields here.
+  std::string assigned_node;  // assignedPods[uid]: the NodeInfo that holds (and accounts) this pod, "" = none
+  bool assumed = false;       // assumedPods has uid (set by AssumePod, cleared by ForgetPod / Running / terminated)
+  bool orphan = false;        // orphanedPods has uid: spec.nodeName names a node that is not in the cache
+  bool ask = false;           // holds a row of the ask table (bitmap row); rows stay put across AssumePod / ForgetPod
   const PodTemplate* tpl = nullptr;
 };
 

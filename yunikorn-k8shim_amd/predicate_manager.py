@@ -95,22 +95,39 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_load_snapshot(self._h, text.encode() if isinstance(text, str) else text))
 
     def update_node(self, node):
-        self._check(self._L.ykhost_update_node(self._h, json.dumps(node).encode()))
+        """SchedulerCache.UpdateNode → number of orphaned pods the node adopted."""
+        return self._check(self._L.ykhost_update_node(self._h, json.dumps(node).encode()))
 
     def remove_node(self, name):
-        self._check(self._L.ykhost_remove_node(self._h, name.encode()))
+        """SchedulerCache.RemoveNode → number of pods orphaned (assumed pods are reverted to pending instead)."""
+        return self._check(self._L.ykhost_remove_node(self._h, name.encode()))
 
     def update_pod(self, pod):
-        self._check(self._L.ykhost_update_pod(self._h, json.dumps(pod).encode()))
+        """SchedulerCache.UpdatePod → False when the pod was stored as an orphan (its node is unknown)."""
+        return bool(self._check(self._L.ykhost_update_pod(self._h, json.dumps(pod).encode())))
 
     def remove_pod(self, uid):
-        self._check(self._L.ykhost_remove_pod(self._h, uid.encode()))
+        return bool(self._check(self._L.ykhost_remove_pod(self._h, uid.encode())))
 
     def assume_pod(self, uid, node_name):
         self._check(self._L.ykhost_assume_pod(self._h, uid.encode(), node_name.encode()))
 
     def forget_pod(self, uid):
-        self._check(self._L.ykhost_forget_pod(self._h, uid.encode()))
+        """SchedulerCache.ForgetPod: drops the assumed mark; the pod stays accounted on its node."""
+        return bool(self._check(self._L.ykhost_forget_pod(self._h, uid.encode())))
+
+    def pod_state(self, uid):
+        """Cache membership of a pod: None if not cached, else dict(node, assigned, assumed, orphan, ask)."""
+        node = C.create_string_buffer(256)
+        f = self._L.ykhost_pod_state(self._h, uid.encode(), node, 256)
+        if not f & 1:
+            return None
+        return {"node": node.value.decode(), "assigned": bool(f & 2), "assumed": bool(f & 4), "orphan": bool(f & 8), "ask": bool(f & 16)}
+
+    def node_pod_count(self, name):
+        """len(NodeInfo.Pods) of a cached node; None if the node is not cached."""
+        c = self._L.ykhost_node_pod_count(self._h, name.encode())
+        return None if c < 0 else c
 
     def generate_kwok(self, seed, num_nodes, num_pods, num_templates=0, node_affinity=1, tolerations=1, unique_requests=0,
                       gang_size=0, node_index_offset=0, spread=0):
