@@ -109,7 +109,8 @@ def test_concurrent_readers(pm):
                 p, n, allocate = int(rng.integers(P)), int(rng.integers(N)), bool(rng.integers(2))
                 plugin, err = pm.predicates(p, n, allocate)
                 fit, code = want[allocate][0][p, n], want[allocate][1][p, n]
-                if (plugin == "") != bool(fit) or (not fit and plugin != NAMES[code]):
+                # a PreFilter rejection returns an error with an EMPTY plugin name (predicate_manager.go:236-238)
+                if (err is None) != bool(fit) or (not fit and plugin != NAMES[code]):
                     errors.append((tid, p, n, allocate, plugin, NAMES[code] if not fit else ""))
         except Exception as exc:  # noqa: BLE001 - reported by the main thread
             errors.append((tid, repr(exc)))
