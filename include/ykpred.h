@@ -239,6 +239,19 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* args);
  * previous evaluation, YKPRED_E_UNSUPPORTED when a PodTopologySpread signature is active (its histograms couple all
  * nodes — run ykpred_eval). */
 int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* args, int32_t num_nodes, const int32_t* node_index);
+/* Row-level maintenance of the ask table (SchedulerCache.UpdatePod for a new / changed / finished ask,
+ * /root/reference/pkg/cache/external/scheduler_cache.go:303-388) without re-uploading it: the table gets `num_pods_after`
+ * rows (rows beyond it are dropped, every appended row must be listed) and the `count` listed rows (each at most once) take
+ * new (spec, nodeName) values. The engine moves those rows between pod classes in O(count); their bitmap rows are stale
+ * until ykpred_eval_pods (or a full ykpred_eval) has run. The specs must already be uploaded. */
+int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t count, const int32_t* rows, const int32_t* spec_index,
+                           const int32_t* node_name_index);
+/* Re-evaluates ONLY the listed bitmap rows (per pair, against every node) into the bitmap of the last ykpred_eval (same
+ * plugin lists, same output buffers; engine-owned outputs grow with the table, caller-owned ones must already hold
+ * layout.num_pods rows), with their feasible counts and — YKPRED_OUT_DECISIONS / _KEYS — their decisions.
+ * YKPRED_E_STATE if there is no matching previous evaluation, or decisions are requested while the bin-pack order of
+ * the last evaluation is stale (a node changed since). */
+int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* args, int32_t num_rows, const int32_t* rows);
 int32_t ykpred_synchronize(ykpred_engine_t* e);
 int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* out);
 int32_t ykpred_last_timing(const ykpred_engine_t* e, ykpred_timing_t* out);

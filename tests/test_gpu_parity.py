@@ -409,6 +409,101 @@ def test_incremental_assume_forget(pm):
     assert np.array_equal(before, pm.read_bitmap())
 
 
+def _compare_with_mirror_dump(pm, decisions=False):
+    """Every live ask row (uid → row) against the oracle run on the mirror's own snapshot dump. The mirror's bookkeeping
+    itself is pinned by tests/test_host_cache.py."""
+    snap = json.loads(pm.dump_snapshot())
+    o = orc.Oracle(snap)
+    want = o.eval_grid(threads=8)
+    idx = [pm.pod_index(p["metadata"]["uid"]) for p in snap["pods"]]
+    assert min(idx, default=0) >= 0 and len(set(idx)) == len(idx)
+    lay = pm.layout()
+    assert lay.num_pods == pm.num_pods
+    got = unpack(pm.read_bitmap(), lay.num_nodes)[idx]
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} differing bits, first (ask,node)={bad[0].tolist()} uid={snap['pods'][bad[0][0]]['metadata']['uid']}"
+    assert np.array_equal(pm.read_counts()[idx], want.sum(axis=1))
+    if decisions:
+        dec = pm.read_decisions()[idx]
+        for k in range(len(idx)):
+            assert o.decide(k) == (int(want[k].sum()), int(dec[k])), snap["pods"][k]["metadata"]["uid"]
+    return snap
+
+
+@pytest.mark.parametrize("topology", [False, True])
+def test_incremental_ask_rows(pm, topology):
+    """New asks, finished binds, removed asks and node-pin changes move single rows of the ask table between pod classes
+    (ykpred_update_pods) and only those bitmap rows are re-evaluated (ykpred_eval_pods) — no table re-upload, no full pass."""
+    import copy
+    import random
+    rng = random.Random(11)
+    snap = _gen.random_snapshot(777, n_nodes=140, n_pods=50, scalars=False, spread=topology, interpod=topology)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    names = [n["metadata"]["name"] for n in snap["nodes"] if n["metadata"]["name"]]
+    asks = [p for p in snap["pods"] if not p["spec"].get("nodeName")]
+    live = {p["metadata"]["uid"] for p in snap["pods"]}
+    bound = []
+    serial = 0
+    for step in range(24):
+        r = rng.random()
+        want_dec = step % 2 == 0
+        if r < 0.35:  # a new ask whose template is already known (a deployment scaling up): row appended
+            src = copy.deepcopy(rng.choice(asks))
+            serial += 1
+            src["metadata"].update(uid=f"new-{serial}", name=f"new-{serial}")
+            pm.update_pod(src)
+            live.add(src["metadata"]["uid"])
+        elif r < 0.55 and live:  # an ask goes away (deleted): its row is refilled with the last row's ask
+            uid = rng.choice(sorted(live))
+            pm.remove_pod(uid)
+            live.discard(uid)
+            bound = [b for b in bound if b != uid]
+        elif r < 0.8:  # AssumePod, later completed by the informer update (Running) which drops the row
+            cands = sorted(u for u in live if u not in bound and pm.pod_state(u) and not pm.pod_state(u)["node"])
+            if not cands:
+                continue
+            uid = rng.choice(cands)
+            pm.assume_pod(uid, rng.choice(names))
+            bound.append(uid)
+        elif bound:
+            uid = bound.pop(0)
+            if rng.random() < 0.5:
+                pm.forget_pod(uid)  # row pinned to the node it was assumed on
+            else:
+                pod = next((p for p in snap["pods"] if p["metadata"]["uid"] == uid), None)
+                if pod is None:
+                    continue
+                pm.update_pod(dict(pod, status={"phase": "Running"}))
+                live.discard(uid)
+        else:
+            continue
+        patched = pm.evaluate_dirty(decisions=want_dec, profile=True)
+        kernels = [k for k, _ in pm.timing()["kernels"]]
+        if patched >= 0:
+            assert "k_combine" not in kernels, kernels
+        _compare_with_mirror_dump(pm, decisions=want_dec)
+    # the patched state equals a full evaluation of the same tables
+    before = pm.read_bitmap().copy()
+    pm.evaluate()
+    assert np.array_equal(before, pm.read_bitmap())
+    _compare_with_mirror_dump(pm, decisions=True)
+
+
+def test_incremental_rows_use_the_row_kernels(pm):
+    snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    src = json.loads(json.dumps(snap["pods"][3]))
+    src["metadata"].update(uid="extra", name="extra")
+    src["spec"].pop("nodeName", None)
+    pm.update_pod(src)
+    assert pm.evaluate_dirty(decisions=True, profile=True) == 0  # no node column, one row
+    assert [k for k, _ in pm.timing()["kernels"]] == ["k_rows", "k_rows_finish"]
+    assert pm.num_pods == len(snap["pods"]) + 1 and pm.pod_index("extra") == len(snap["pods"])
+    _compare_with_mirror_dump(pm, decisions=True)
+
+
 def test_incremental_at_full_size(pm):
     """configs[2] size: one AssumePod → one column patch; checked against the per-pair kernel on that column and against
     a full re-evaluation (checksum)."""

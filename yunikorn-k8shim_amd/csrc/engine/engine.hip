@@ -37,6 +37,27 @@ struct DevBuf {
     if (e == hipSuccess) cap = bytes;
     return e;
   }
+  // Grows to at least `bytes` (with slack) and KEEPS the first `used` bytes. Other streams may still read the old block:
+  // the device is drained before it is freed (growth is rare: the slack absorbs the row-by-row updates).
+  hipError_t reserve_keep(size_t bytes, size_t used) {
+    if (bytes <= cap && p) return hipSuccess;
+    size_t ncap = bytes + bytes / 4 + 4096;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, ncap);
+    if (e != hipSuccess) return e;
+    (void)hipDeviceSynchronize();  // the engine's streams do not synchronise with the null stream used below
+    if (p && used) {
+      e = hipMemcpy(q, p, std::min(used, cap), hipMemcpyDeviceToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(q);
+        return e;
+      }
+    }
+    if (p) (void)hipFree(p);
+    p = q;
+    cap = ncap;
+    return hipSuccess;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -45,6 +66,22 @@ struct DevBuf {
   template <class T>
   T* as() const {
     return static_cast<T*>(p);
+  }
+};
+
+// A pod class: the four plugin-family signatures of the pod's spec + its pinned node (spec.nodeName).
+struct ClassKey {
+  int32_t a, b, c, d, pin;
+  bool operator==(const ClassKey& o) const { return a == o.a && b == o.b && c == o.c && d == o.d && pin == o.pin; }
+};
+struct ClassKeyHash {
+  size_t operator()(const ClassKey& k) const {
+    uint64_t h = (uint64_t)(uint32_t)k.a * 0x9e3779b97f4a7c15ull;
+    h ^= ((uint64_t)(uint32_t)k.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+    h ^= ((uint64_t)(uint32_t)k.c + 0x1ce4e5b9ull) * 0x94d049bb133111ebull;
+    h ^= ((uint64_t)(uint32_t)k.pin + 0x133111ebull) * 0xd6e8feb86659fd93ull;
+    h ^= ((uint64_t)(uint32_t)k.d + 0x6659fd93ull) * 0xff51afd7ed558ccdull;
+    return (size_t)(h ^ (h >> 29));
   }
 };
 
@@ -106,6 +143,16 @@ struct ykpred_engine {
   std::vector<int32_t> h_pod_spec, h_pod_pin;
   DevBuf d_pod_spec, d_pod_pin, d_pod_class;
   DevBuf d_class_sig, d_class_pin, d_class_first, d_class_word, d_chunk_class, d_chunk_begin, d_chunk_len, d_chunk_first, d_members;
+  // class index kept on the host so that ykpred_update_pods can move single rows between classes (mirrors of the device
+  // tables above; `h_members` has -1 holes where a row left its class, chunks are only ever appended between rebuilds)
+  std::unordered_map<ClassKey, int32_t, ClassKeyHash> class_ids;
+  std::vector<int32_t> h_pod_class, h_pod_slot;                       // per pod: class, slot in h_members
+  std::vector<int32_t> h_class_sig, h_class_pin, h_class_first, h_class_live;
+  std::vector<std::vector<int32_t>> h_class_chunks;                   // chunk ids of a class, creation order
+  std::vector<int32_t> h_members, h_ch_class, h_ch_begin, h_ch_len, h_ch_first;
+  int patch_chunks = 0;     // chunks appended since the last build_classes
+  bool rank_valid = false;  // d_rank / d_perm / d_key describe the current node table
+  DevBuf d_patches, d_rows, d_row_count, d_row_best;
   unsigned last_pre = 0, last_filt = 0;  // plugin lists of the last full evaluation (ykpred_eval_nodes must match them)
   bool last_eval_valid = false;
   DevBuf d_class_count, d_class_best;
@@ -215,28 +262,19 @@ ykk::SpecTable spec_table(const ykpred_engine* e) {
 // Groups pods into classes (same signatures + same pinned node) and classes into chunks of <= kChunkMembers pods.
 int build_classes(ykpred_engine* e, hipStream_t st) {
   const int P = e->P;
-  struct Key {
-    int32_t a, b, c, d, pin;
-    bool operator==(const Key& o) const { return a == o.a && b == o.b && c == o.c && d == o.d && pin == o.pin; }
-  };
-  struct KeyHash {
-    size_t operator()(const Key& k) const {
-      uint64_t h = (uint64_t)(uint32_t)k.a * 0x9e3779b97f4a7c15ull;
-      h ^= ((uint64_t)(uint32_t)k.b + 0x7f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
-      h ^= ((uint64_t)(uint32_t)k.c + 0x1ce4e5b9ull) * 0x94d049bb133111ebull;
-      h ^= ((uint64_t)(uint32_t)k.pin + 0x133111ebull) * 0xd6e8feb86659fd93ull;
-      h ^= ((uint64_t)(uint32_t)k.d + 0x6659fd93ull) * 0xff51afd7ed558ccdull;
-      return (size_t)(h ^ (h >> 29));
-    }
-  };
-  std::unordered_map<Key, int32_t, KeyHash> ids;
+  auto& ids = e->class_ids;
+  ids.clear();
   ids.reserve(1024);
-  std::vector<int32_t> pod_class((size_t)P);
-  std::vector<int32_t> class_sig, class_pin, class_size;
+  auto& pod_class = e->h_pod_class;
+  pod_class.assign((size_t)P, 0);
+  auto &class_sig = e->h_class_sig, &class_pin = e->h_class_pin, &class_size = e->h_class_live;
+  class_sig.clear();
+  class_pin.clear();
+  class_size.clear();
   for (int p = 0; p < P; ++p) {
     int s = e->h_pod_spec[(size_t)p];
-    Key k{e->spec_sig_res[(size_t)s], e->spec_sig_tol[(size_t)s], e->spec_sig_aff[(size_t)s], e->spec_sig_spread[(size_t)s],
-          e->h_pod_pin[(size_t)p]};
+    ClassKey k{e->spec_sig_res[(size_t)s], e->spec_sig_tol[(size_t)s], e->spec_sig_aff[(size_t)s], e->spec_sig_spread[(size_t)s],
+               e->h_pod_pin[(size_t)p]};
     auto it = ids.find(k);
     int32_t c;
     if (it == ids.end()) {
@@ -254,8 +292,15 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   const int C = (int)class_pin.size();
   std::vector<int32_t> class_off((size_t)C + 1, 0);
   for (int c = 0; c < C; ++c) class_off[(size_t)c + 1] = class_off[(size_t)c] + class_size[(size_t)c];
-  std::vector<int32_t> members((size_t)P), cursor(class_off.begin(), class_off.end() - 1);
-  for (int p = 0; p < P; ++p) members[(size_t)cursor[(size_t)pod_class[(size_t)p]]++] = p;
+  auto& members = e->h_members;
+  members.assign((size_t)P, 0);
+  e->h_pod_slot.assign((size_t)P, 0);
+  std::vector<int32_t> cursor(class_off.begin(), class_off.end() - 1);
+  for (int p = 0; p < P; ++p) {
+    int slot = cursor[(size_t)pod_class[(size_t)p]]++;
+    members[(size_t)slot] = p;
+    e->h_pod_slot[(size_t)p] = slot;
+  }
   // Chunks of <= chunk_members pods of one class. Members of a class are in ascending pod order, and the chunks are
   // dispatched in ascending order of their first pod: the ~2k blocks resident at any moment then write bitmap rows
   // of one narrow, advancing window instead of rows scattered over the whole bitmap (DRAM page locality).
@@ -269,23 +314,28 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       chunks.push_back({c, b, std::min(cm, class_off[(size_t)c + 1] - b), b == class_off[(size_t)c] ? 1 : 0, members[(size_t)b]});
   if (e->chunk_sorted)
     std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return x.first_pod < y.first_pod; });
-  std::vector<int32_t> ch_class, ch_begin, ch_len, ch_first;
+  auto &ch_class = e->h_ch_class, &ch_begin = e->h_ch_begin, &ch_len = e->h_ch_len, &ch_first = e->h_ch_first;
+  ch_class.clear();
+  ch_begin.clear();
+  ch_len.clear();
+  ch_first.clear();
+  e->h_class_chunks.assign((size_t)C, {});
   for (const Chunk& k : chunks) {
+    e->h_class_chunks[(size_t)k.cls].push_back((int32_t)ch_class.size());
     ch_class.push_back(k.cls);
     ch_begin.push_back(k.begin);
     ch_len.push_back(k.len);
     ch_first.push_back(k.first);
   }
+  e->h_class_first.assign((size_t)C, -1);
+  for (int c = 0; c < C; ++c) e->h_class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
   e->C = C;
   e->NC = (int)ch_class.size();
+  e->patch_chunks = 0;
   TRY(upload(e, e->d_pod_class, pod_class.data(), pod_class.size(), st));
   TRY(upload(e, e->d_class_sig, class_sig.data(), class_sig.size(), st));
   TRY(upload(e, e->d_class_pin, class_pin.data(), class_pin.size(), st));
-  {
-    std::vector<int32_t> class_first((size_t)C);
-    for (int c = 0; c < C; ++c) class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
-    TRY(upload(e, e->d_class_first, class_first.data(), class_first.size(), st));
-  }
+  TRY(upload(e, e->d_class_first, e->h_class_first.data(), e->h_class_first.size(), st));
   TRY(upload(e, e->d_members, members.data(), members.size(), st));
   TRY(upload(e, e->d_chunk_class, ch_class.data(), ch_class.size(), st));
   TRY(upload(e, e->d_chunk_begin, ch_begin.data(), ch_begin.size(), st));
@@ -293,7 +343,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   TRY(upload(e, e->d_chunk_first, ch_first.data(), ch_first.size(), st));
   HIPCHK(e->d_class_count.ensure((size_t)std::max(C, 1) * sizeof(int)));
   HIPCHK(e->d_class_best.ensure((size_t)std::max(C, 1) * sizeof(int)));
-  HIPCHK(hipStreamSynchronize(st));  // host vectors go out of scope
+  HIPCHK(hipStreamSynchronize(st));  // the uploads read pageable host vectors
   e->classes_dirty = false;
   e->last_eval_valid = false;
   return YKPRED_OK;
@@ -509,7 +559,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
-                    &e->d_members, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
+                    &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
                     &e->d_member_key})
     b->release();
   if (e->ev_ready)
@@ -533,6 +583,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   if (e->KP > 0 && n->count > 0 && !n->port_bits) return fail(e, YKPRED_E_INVALID, "set_nodes: port_bits missing (config has KP > 0)");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
+  e->rank_valid = false;
   const size_t N = (size_t)n->count;
   TRY(upload(e, e->d_alloc, n->allocatable, N * (size_t)e->R, st));
   TRY(upload(e, e->d_req, n->requested, N * (size_t)e->R, st));
@@ -577,6 +628,7 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
   if (!e->nodes_set || idx < 0 || idx >= e->N) return fail(e, YKPRED_E_INVALID, "update_node: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
+  e->rank_valid = false;  // the node's score may move
   const size_t N = (size_t)e->N;
   for (int r = 0; r < e->R; ++r) {
     HIPCHK(hipMemcpyAsync(e->d_alloc.as<i64>() + (size_t)r * N + idx, n->allocatable + r, sizeof(i64), hipMemcpyHostToDevice, st));
@@ -1005,6 +1057,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_pre = pre;
   e->last_filt = filt;
   e->last_eval_valid = true;
+  if (want_dec) e->rank_valid = true;
   return YKPRED_OK;
 }
 
@@ -1068,6 +1121,236 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
     int rc = ykpred_eval(e, &b);
     if (rc != YKPRED_OK) return rc;
   }
+  return YKPRED_OK;
+}
+
+// Row-level maintenance of the ask table. See ykpred.h.
+int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t count, const int32_t* rows, const int32_t* spec_index,
+                           const int32_t* node_name_index) {
+  YK_SERIALISE(e);
+  if (!e || num_pods_after < 0 || count < 0 || (count > 0 && (!rows || !spec_index || !node_name_index)))
+    return fail(e, YKPRED_E_INVALID, "update_pods: bad argument");
+  if (!e->pods_set || !e->specs_set) return fail(e, YKPRED_E_STATE, "update_pods: ykpred_set_specs and ykpred_set_pods come first");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const int oldP = e->P, newP = num_pods_after;
+  {
+    std::vector<uint8_t> listed((size_t)std::max(newP - oldP, 0), 0);
+    std::vector<int32_t> sorted(rows, rows + count);
+    std::sort(sorted.begin(), sorted.end());
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(e, YKPRED_E_INVALID, "update_pods: a row is listed twice");
+    for (int i = 0; i < count; ++i) {
+      if (rows[i] < 0 || rows[i] >= newP) return fail(e, YKPRED_E_INVALID, "update_pods: row out of range");
+      if (spec_index[i] < 0 || spec_index[i] >= e->S) return fail(e, YKPRED_E_INVALID, "update_pods: pod references a spec that was not uploaded");
+      if (node_name_index[i] < YKPRED_UNKNOWN_NODE_NAME || (e->nodes_set && node_name_index[i] >= e->N))
+        return fail(e, YKPRED_E_INVALID, "update_pods: node_name_index out of range");
+      if (rows[i] >= oldP) listed[(size_t)(rows[i] - oldP)] = 1;
+    }
+    for (uint8_t l : listed)
+      if (!l) return fail(e, YKPRED_E_INVALID, "update_pods: every appended row must be listed");
+  }
+  hipStream_t st = e->own_stream;
+  if (e->classes_dirty) {
+    // no class index yet (or it is due for a rebuild): only the pod table changes, the next ykpred_eval builds the classes
+    e->h_pod_spec.resize((size_t)newP);
+    e->h_pod_pin.resize((size_t)newP);
+    for (int i = 0; i < count; ++i) {
+      e->h_pod_spec[(size_t)rows[i]] = spec_index[i];
+      e->h_pod_pin[(size_t)rows[i]] = node_name_index[i];
+    }
+    e->P = newP;
+    TRY(upload(e, e->d_pod_spec, e->h_pod_spec.data(), e->h_pod_spec.size(), st));
+    TRY(upload(e, e->d_pod_pin, e->h_pod_pin.data(), e->h_pod_pin.size(), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return YKPRED_OK;
+  }
+
+  enum { T_POD_SPEC, T_POD_PIN, T_POD_CLASS, T_MEMBERS, T_CH_CLASS, T_CH_BEGIN, T_CH_LEN, T_CH_FIRST, T_CLASS_SIG, T_CLASS_PIN, T_CLASS_FIRST };
+  std::vector<ykk::TablePatch> patches;
+  auto put = [&](int table, int index, int value) { patches.push_back({table, index, value, 0}); };
+  std::vector<int32_t> orphaned;  // classes whose representative row left
+  auto leave = [&](int p) {
+    const int c = e->h_pod_class[(size_t)p], slot = e->h_pod_slot[(size_t)p];
+    e->h_members[(size_t)slot] = -1;
+    put(T_MEMBERS, slot, -1);
+    e->h_class_live[(size_t)c]--;
+    if (e->h_class_first[(size_t)c] == p) {
+      e->h_class_first[(size_t)c] = -1;
+      orphaned.push_back(c);
+    }
+  };
+  for (int p = newP; p < oldP; ++p) leave(p);  // truncated rows
+  for (int i = 0; i < count; ++i)
+    if (rows[i] < oldP) leave(rows[i]);
+  e->h_pod_spec.resize((size_t)newP);
+  e->h_pod_pin.resize((size_t)newP);
+  e->h_pod_class.resize((size_t)newP);
+  e->h_pod_slot.resize((size_t)newP);
+  const int cm = e->chunk_members;
+  for (int i = 0; i < count; ++i) {
+    const int p = rows[i], sp = spec_index[i], pin = node_name_index[i];
+    e->h_pod_spec[(size_t)p] = sp;
+    e->h_pod_pin[(size_t)p] = pin;
+    put(T_POD_SPEC, p, sp);
+    put(T_POD_PIN, p, pin);
+    ClassKey k{e->spec_sig_res[(size_t)sp], e->spec_sig_tol[(size_t)sp], e->spec_sig_aff[(size_t)sp], e->spec_sig_spread[(size_t)sp], pin};
+    auto it = e->class_ids.find(k);
+    int c;
+    if (it == e->class_ids.end()) {
+      c = e->C++;
+      e->class_ids.emplace(k, c);
+      e->h_class_sig.insert(e->h_class_sig.end(), {k.a, k.b, k.c, k.d});
+      e->h_class_pin.push_back(pin);
+      e->h_class_first.push_back(-1);
+      e->h_class_live.push_back(0);
+      e->h_class_chunks.emplace_back();
+      put(T_CLASS_SIG, c * 4 + 0, k.a);
+      put(T_CLASS_SIG, c * 4 + 1, k.b);
+      put(T_CLASS_SIG, c * 4 + 2, k.c);
+      put(T_CLASS_SIG, c * 4 + 3, k.d);
+      put(T_CLASS_PIN, c, pin);
+    } else {
+      c = it->second;
+    }
+    const int slot = (int)e->h_members.size();
+    e->h_members.push_back(p);
+    put(T_MEMBERS, slot, p);
+    auto& cc = e->h_class_chunks[(size_t)c];
+    const int tail = cc.empty() ? -1 : cc.back();
+    if (tail >= 0 && e->h_ch_begin[(size_t)tail] + e->h_ch_len[(size_t)tail] == slot && e->h_ch_len[(size_t)tail] < cm) {
+      e->h_ch_len[(size_t)tail]++;  // consecutive appends to one class share a chunk
+      put(T_CH_LEN, tail, e->h_ch_len[(size_t)tail]);
+    } else {
+      const int ch = e->NC++;
+      e->h_ch_class.push_back(c);
+      e->h_ch_begin.push_back(slot);
+      e->h_ch_len.push_back(1);
+      e->h_ch_first.push_back(cc.empty() ? 1 : 0);  // the first chunk of a class adds the class's feasible count
+      put(T_CH_CLASS, ch, c);
+      put(T_CH_BEGIN, ch, slot);
+      put(T_CH_LEN, ch, 1);
+      put(T_CH_FIRST, ch, cc.empty() ? 1 : 0);
+      cc.push_back(ch);
+      e->patch_chunks++;
+    }
+    e->h_pod_class[(size_t)p] = c;
+    e->h_pod_slot[(size_t)p] = slot;
+    put(T_POD_CLASS, p, c);
+    e->h_class_live[(size_t)c]++;
+    if (e->h_class_first[(size_t)c] < 0) e->h_class_first[(size_t)c] = p;
+  }
+  // a class that lost its representative row but still has members: any live member's row serves (all are identical)
+  for (int c : orphaned)
+    if (e->h_class_first[(size_t)c] < 0 && e->h_class_live[(size_t)c] > 0)
+      for (int ch : e->h_class_chunks[(size_t)c]) {
+        for (int j = 0; j < e->h_ch_len[(size_t)ch] && e->h_class_first[(size_t)c] < 0; ++j) {
+          int m = e->h_members[(size_t)(e->h_ch_begin[(size_t)ch] + j)];
+          if (m >= 0) e->h_class_first[(size_t)c] = m;
+        }
+        if (e->h_class_first[(size_t)c] >= 0) break;
+      }
+  for (int c : orphaned) put(T_CLASS_FIRST, c, e->h_class_first[(size_t)c]);
+  for (int i = 0; i < count; ++i) {
+    const int c = e->h_pod_class[(size_t)rows[i]];
+    if (e->h_class_first[(size_t)c] == rows[i]) put(T_CLASS_FIRST, c, rows[i]);
+  }
+  e->P = newP;
+
+  // device side: grow what has to grow (contents kept), then apply every change with one copy + one launch
+  const size_t I = sizeof(int32_t);
+  HIPCHK(e->d_pod_spec.reserve_keep((size_t)newP * I, (size_t)oldP * I));
+  HIPCHK(e->d_pod_pin.reserve_keep((size_t)newP * I, (size_t)oldP * I));
+  HIPCHK(e->d_pod_class.reserve_keep((size_t)newP * I, (size_t)oldP * I));
+  HIPCHK(e->d_members.reserve_keep(e->h_members.size() * I, e->h_members.size() * I));
+  for (DevBuf* b : {&e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first}) HIPCHK(b->reserve_keep((size_t)e->NC * I, (size_t)e->NC * I));
+  HIPCHK(e->d_class_sig.reserve_keep((size_t)e->C * 4 * I, (size_t)e->C * 4 * I));
+  for (DevBuf* b : {&e->d_class_pin, &e->d_class_first, &e->d_class_count, &e->d_class_best}) HIPCHK(b->reserve_keep((size_t)e->C * I, (size_t)e->C * I));
+  if (!patches.empty()) {
+    ykk::TablePtrs tp{};
+    tp.t[T_POD_SPEC] = e->d_pod_spec.as<int>();
+    tp.t[T_POD_PIN] = e->d_pod_pin.as<int>();
+    tp.t[T_POD_CLASS] = e->d_pod_class.as<int>();
+    tp.t[T_MEMBERS] = e->d_members.as<int>();
+    tp.t[T_CH_CLASS] = e->d_chunk_class.as<int>();
+    tp.t[T_CH_BEGIN] = e->d_chunk_begin.as<int>();
+    tp.t[T_CH_LEN] = e->d_chunk_len.as<int>();
+    tp.t[T_CH_FIRST] = e->d_chunk_first.as<int>();
+    tp.t[T_CLASS_SIG] = e->d_class_sig.as<int>();
+    tp.t[T_CLASS_PIN] = e->d_class_pin.as<int>();
+    tp.t[T_CLASS_FIRST] = e->d_class_first.as<int>();
+    TRY(upload(e, e->d_patches, patches.data(), patches.size(), st));
+    hipLaunchKernelGGL(ykk::k_apply_patches, dim3((unsigned)((patches.size() + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, tp,
+                       (int)patches.size(), e->d_patches.as<ykk::TablePatch>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));  // `patches` is pageable host memory
+  }
+  // many small chunks make k_combine re-read planes for little output: rebuild the classes at the next full evaluation
+  if (e->patch_chunks > std::max(4096, (e->NC - e->patch_chunks) / 4)) e->classes_dirty = true;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_t num_rows, const int32_t* rows) {
+  YK_SERIALISE(e);
+  if (!e || !a || num_rows < 0 || (num_rows > 0 && !rows)) return fail(e, YKPRED_E_INVALID, "eval_pods: bad argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
+  const unsigned pre = a->prefilter_plugins, filt = a->filter_plugins;
+  const bool own_bitmap = !a->bitmap && e->last_bitmap == e->d_bitmap.p;
+  if (e->classes_dirty || !e->last_eval_valid || pre != e->last_pre || filt != e->last_filt || (a->bitmap && a->bitmap != e->last_bitmap) ||
+      (!a->bitmap && !own_bitmap))
+    return fail(e, YKPRED_E_STATE, "eval_pods: no matching previous ykpred_eval (tables, plugin lists or bitmap changed)");
+  const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
+  const bool want_keys = a->options & YKPRED_OUT_DECISION_KEYS;
+  const bool want_dec = (a->options & YKPRED_OUT_DECISIONS) || want_keys;
+  if (want_dec && !e->rank_valid) return fail(e, YKPRED_E_STATE, "eval_pods: the bin-pack order is stale — run ykpred_eval with decisions");
+  for (int i = 0; i < num_rows; ++i)
+    if (rows[i] < 0 || rows[i] >= e->P) return fail(e, YKPRED_E_INVALID, "eval_pods: row out of range");
+  // engine-owned outputs grow with the table (caller-owned ones must already hold layout.num_pods rows)
+  const size_t P = (size_t)std::max(e->P, 1);
+  if (own_bitmap) {
+    HIPCHK(e->d_bitmap.reserve_keep(P * (size_t)e->row_stride * sizeof(u64), e->d_bitmap.cap));
+    e->last_bitmap = e->d_bitmap.p;
+  }
+  if (!a->counts && e->last_counts == e->d_counts.p) {
+    HIPCHK(e->d_counts.reserve_keep(P * sizeof(int), e->d_counts.cap));
+    e->last_counts = e->d_counts.p;
+  }
+  if (!a->decisions && e->last_decisions == e->d_decisions.p) {
+    HIPCHK(e->d_decisions.reserve_keep(P * sizeof(int), e->d_decisions.cap));
+    e->last_decisions = e->d_decisions.p;
+  }
+  if (!a->decision_keys && e->last_keys == e->d_keys.p) {
+    HIPCHK(e->d_keys.reserve_keep(P * sizeof(i64), e->d_keys.cap));
+    e->last_keys = e->d_keys.p;
+  }
+  Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
+  tm.start(st);
+  if (num_rows > 0 && e->N > 0) {
+    u64* bitmap = (u64*)e->last_bitmap;
+    TRY(upload(e, e->d_rows, rows, (size_t)num_rows, st));
+    HIPCHK(e->d_row_count.ensure((size_t)num_rows * sizeof(int)));
+    HIPCHK(e->d_row_best.ensure((size_t)num_rows * sizeof(int)));
+    HIPCHK(hipMemsetAsync(e->d_row_count.p, 0, (size_t)num_rows * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(e->d_row_best.p, 0x7f, (size_t)num_rows * sizeof(int), st));  // 0x7f7f7f7f > any rank; mapped to "none" below
+    ykk::NodeTable nt = node_table(e);
+    ykk::SpecTable stbl = spec_table(e);
+    const unsigned wgroups = (unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock);
+    tm.begin(st);
+    hipLaunchKernelGGL(ykk::k_rows, dim3((unsigned)num_rows, wgroups), dim3(ykk::kBlock), 0, st, nt, stbl, num_rows, e->d_rows.as<int>(),
+                       e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre, filt, bitmap, e->row_words, e->row_stride,
+                       want_dec ? e->d_rank.as<int>() : nullptr, e->d_row_count.as<int>(), e->d_row_best.as<int>());
+    tm.end(st, "k_rows");
+    tm.begin(st);
+    hipLaunchKernelGGL(ykk::k_rows_finish, dim3((unsigned)((num_rows + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, num_rows,
+                       e->d_rows.as<int>(), e->d_pod_class.as<int>(), e->d_row_count.as<int>(), e->d_row_best.as<int>(),
+                       want_dec ? e->d_perm.as<int>() : nullptr, e->d_key.as<u64>(), e->d_class_count.as<int>(), e->d_class_best.as<int>(),
+                       want_cnt ? (int*)(a->counts ? a->counts : e->last_counts) : nullptr,
+                       (a->options & YKPRED_OUT_DECISIONS) ? (int*)(a->decisions ? a->decisions : e->last_decisions) : nullptr,
+                       want_keys ? (i64*)(a->decision_keys ? a->decision_keys : e->last_keys) : nullptr);
+    tm.end(st, "k_rows_finish");
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));  // `rows` was staged from caller memory
+  }
+  tm.done(st);
   return YKPRED_OK;
 }
 

@@ -669,6 +669,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   int mine = lane < len ? ct.members[begin + lane] : 0;
   for (int i = group; i < len; i += groups) {  // `group` is wave-uniform: tpg is a multiple of the wave size
     int p = __builtin_amdgcn_readlane(mine, i);
+    if (p < 0) continue;  // slot vacated by ykpred_update_pods (wave-uniform)
     u64* row = bitmap + (size_t)p * row_stride;
 #pragma unroll
     for (int u = 0; u < kCombineUnroll; ++u) {
@@ -973,6 +974,7 @@ __global__ __launch_bounds__(kBlock) void k_column_class(NodeTable t, SpecTable 
   int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= n_classes) return;
   const int p0 = class_first[c];
+  if (p0 < 0) return;  // no live member (ykpred_update_pods moved them all away)
   const int spec = pod_spec[p0];
   const int pin = (filt_mask & kPlugNodeName) ? class_pin[c] : -1;
   int delta = 0;
@@ -1003,6 +1005,75 @@ __global__ __launch_bounds__(kBlock) void k_column_patch(ColumnGroups cg, int n_
   const int c = pod_class[p];
   for (int g = 0; g < cg.n_groups; ++g) bitmap[(size_t)p * row_stride + cg.word[g]] = class_word[(size_t)c * kMaxColGroups + g];
   if (counts) counts[p] = class_count[c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// incremental row patch: ask-table rows rewritten by ykpred_update_pods are re-evaluated per pair
+// ---------------------------------------------------------------------------------------------------
+// Small integer patches of the engine's int32 tables in one launch: {table, index, value}.
+struct TablePatch {
+  int table, index, value, pad;
+};
+constexpr int kPatchTables = 12;
+constexpr int kNoRank = 0x7f7f7f7f;  // row_best is initialised with memset(0x7f); ranks are < 2^24
+struct TablePtrs {
+  int* t[kPatchTables];
+};
+__global__ __launch_bounds__(kBlock) void k_apply_patches(TablePtrs tp, int n, const TablePatch* __restrict__ patches) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  TablePatch q = patches[i];
+  tp.t[q.table][q.index] = q.value;
+}
+
+// blockIdx.x = listed row, blockIdx.y = group of 4 node words, lane = node: the whole bitmap row of the pod is rebuilt
+// with the per-pair routine (same as k_direct), its popcount and the smallest bin-pack rank among its feasible nodes
+// are accumulated in row_count / row_best (zeroed / set to kNoRank by the caller).
+__global__ __launch_bounds__(kBlock) void k_rows(NodeTable t, SpecTable s, int n_rows, const int* __restrict__ rows,
+                                                 const int* __restrict__ pod_spec, const int* __restrict__ pod_pin, unsigned pre_mask,
+                                                 unsigned filt_mask, u64* __restrict__ bitmap, int row_words, int row_stride,
+                                                 const int* __restrict__ rank /* null: no decisions */, int* __restrict__ row_count,
+                                                 int* __restrict__ row_best) {
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int w = blockIdx.y * kWavesPerBlock + wave;
+  if (w >= row_stride) return;
+  const int p = rows[blockIdx.x];
+  int n = w * kWave + lane;
+  if (n >= t.n) n = -1;
+  NodeRegs nr;
+  load_node(t, n, &nr);
+  int code;
+  unsigned reason;
+  const bool ok = n >= 0 && eval_pair(s, pod_spec[p], pod_pin[p], n, nr, pre_mask, filt_mask, &code, &reason);
+  const u64 b = __ballot(ok);
+  int best = (ok && rank) ? rank[n] : kNoRank;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_down(best, off, kWave));
+  if (lane == 0) {
+    bitmap[(size_t)p * row_stride + w] = (w < row_words) ? b : 0ull;
+    if (b) {
+      atomicAdd(&row_count[blockIdx.x], __popcll(b));
+      if (rank) atomicMin(&row_best[blockIdx.x], best);
+    }
+  }
+}
+// thread = listed row: publish count / decision of the row and of its class (every member row of a class is identical)
+__global__ __launch_bounds__(kBlock) void k_rows_finish(int n_rows, const int* __restrict__ rows, const int* __restrict__ pod_class,
+                                                        const int* __restrict__ row_count, const int* __restrict__ row_best,
+                                                        const int* __restrict__ perm, const u64* __restrict__ node_key,
+                                                        int* __restrict__ class_count, int* __restrict__ class_best,
+                                                        int* __restrict__ counts, int* __restrict__ decisions, i64* __restrict__ keys) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_rows) return;
+  const int p = rows[i], c = pod_class[p];
+  class_count[c] = row_count[i];
+  if (counts) counts[p] = row_count[i];
+  if (perm) {
+    const int b = row_best[i] >= kNoRank ? -1 : perm[row_best[i]];
+    class_best[c] = b;
+    if (decisions) decisions[p] = b;
+    if (keys) keys[p] = b >= 0 ? (i64)(node_key[b] ^ 0x8000000000000000ull) : 0x7fffffffffffffffll;
+  }
 }
 
 // PreemptionPredicates (predicate_manager.go:141-179) for one (pod,node): victims are removed in order; returns the first

@@ -71,6 +71,9 @@ struct ykhost {
   bool dirty_all = true, dirty_pods = false;
   std::vector<int> dirty_nodes;       // node rows to re-upload
   std::vector<int> eval_dirty_nodes;  // node columns changed since the last evaluation
+  std::vector<int> dirty_rows;        // ask rows to re-upload (ykpred_update_pods)
+  std::vector<int> eval_dirty_rows;   // bitmap rows changed since the last evaluation
+  bool table_shrunk = false;          // the ask table lost rows at its end since the last upload
   // answers of one ask against every node (ykpred_query_pod), so that the core's per-node Predicates() callbacks of a
   // scheduling attempt are served from host memory; dropped whenever any table changes
   struct AskAnswers {
@@ -96,6 +99,9 @@ struct ykhost {
     dirty_all = true;
     dirty_nodes.clear();
     eval_dirty_nodes.clear();
+    dirty_rows.clear();
+    eval_dirty_rows.clear();
+    table_shrunk = false;
     last_eval_phase = -1;
     spec_templates.clear();
   }
@@ -266,19 +272,21 @@ int full_sync(ykhost* h) {
   return 0;
 }
 
+// (spec, nodeName pin) of one ask row as the engine sees it
+void encode_row(ykhost* h, const Pod* pod, int32_t* spec, int32_t* pin) {
+  *spec = pod->tpl->spec_id;
+  if (pod->node_name.empty() || pod->assumed) {  // an assumed ask keeps evaluating its spec without the pin (see ykhost_assume_pod)
+    *pin = YKPRED_NO_NODE_NAME;
+  } else {
+    auto it = h->node_ix.find(pod->node_name);
+    *pin = it == h->node_ix.end() ? YKPRED_UNKNOWN_NODE_NAME : it->second;
+  }
+}
+
 int pods_sync(ykhost* h) {
   const size_t P = h->pending.size();
   std::vector<int32_t> spec(P), pin(P);
-  for (size_t p = 0; p < P; ++p) {
-    const Pod* pod = h->pending[p];
-    spec[p] = pod->tpl->spec_id;
-    if (pod->node_name.empty() || pod->assumed) {  // an assumed ask keeps its (now meaningless) row; spec.nodeName was set by the bind
-      pin[p] = YKPRED_NO_NODE_NAME;
-    } else {
-      auto it = h->node_ix.find(pod->node_name);
-      pin[p] = it == h->node_ix.end() ? YKPRED_UNKNOWN_NODE_NAME : it->second;
-    }
-  }
+  for (size_t p = 0; p < P; ++p) encode_row(h, h->pending[p], &spec[p], &pin[p]);
   ykpred_pods_t pp{};
   pp.count = (int32_t)P;
   pp.spec_index = spec.data();
@@ -286,6 +294,27 @@ int pods_sync(ykhost* h) {
   int rc = ykpred_set_pods(h->eng, &pp);
   if (rc) return fail(h, std::string("ykpred_set_pods: ") + ykpred_last_error(h->eng), rc);
   h->dirty_pods = false;
+  h->dirty_rows.clear();
+  h->eval_dirty_rows.clear();
+  h->table_shrunk = false;
+  return 0;
+}
+
+// Uploads only the ask rows that changed (new ask, ask bound / removed, node pin changed).
+int rows_sync(ykhost* h) {
+  std::sort(h->dirty_rows.begin(), h->dirty_rows.end());
+  h->dirty_rows.erase(std::unique(h->dirty_rows.begin(), h->dirty_rows.end()), h->dirty_rows.end());
+  const int P = (int)h->pending.size();
+  while (!h->dirty_rows.empty() && h->dirty_rows.back() >= P) h->dirty_rows.pop_back();  // rows dropped again meanwhile
+  std::vector<int32_t> spec(h->dirty_rows.size()), pin(h->dirty_rows.size());
+  for (size_t i = 0; i < h->dirty_rows.size(); ++i) encode_row(h, h->pending[(size_t)h->dirty_rows[i]], &spec[i], &pin[i]);
+  int32_t none = 0;
+  int rc = ykpred_update_pods(h->eng, P, (int32_t)h->dirty_rows.size(), h->dirty_rows.empty() ? &none : h->dirty_rows.data(),
+                              spec.empty() ? &none : spec.data(), pin.empty() ? &none : pin.data());
+  if (rc) return fail(h, std::string("ykpred_update_pods: ") + ykpred_last_error(h->eng), rc);
+  h->eval_dirty_rows.insert(h->eval_dirty_rows.end(), h->dirty_rows.begin(), h->dirty_rows.end());
+  h->dirty_rows.clear();
+  h->table_shrunk = false;
   return 0;
 }
 
@@ -321,7 +350,7 @@ int node_row_sync(ykhost* h, int n) {
 }
 
 int sync(ykhost* h) {
-  if (h->dirty_all || h->dirty_pods || !h->dirty_nodes.empty()) h->answers.pod = -1;
+  if (h->dirty_all || h->dirty_pods || !h->dirty_nodes.empty() || !h->dirty_rows.empty() || h->table_shrunk) h->answers.pod = -1;
   if (h->dirty_all) {
     int rc = full_sync(h);
     if (rc) return rc;
@@ -332,6 +361,7 @@ int sync(ykhost* h) {
   }
   h->dirty_nodes.clear();
   if (h->dirty_pods) return pods_sync(h);
+  if (!h->dirty_rows.empty() || h->table_shrunk) return rows_sync(h);
   return 0;
 }
 
@@ -390,29 +420,44 @@ bool cache_update_pod(ykhost* h, Pod* old, Pod* p, bool running, bool terminated
   return result;
 }
 // Row bookkeeping of the ask table: `old` leaves its row (if it has one), `now` (may be null) takes it over in place or
-// is appended.
+// is appended. A vacated row is refilled with the LAST row's ask, so the table stays dense and all other rows keep their
+// index. Touched rows are re-uploaded one by one (ykpred_update_pods) and re-evaluated alone (ykpred_eval_pods).
+void mark_row(ykhost* h, int row) {
+  if (h->dirty_all || h->dirty_pods) return;
+  h->dirty_rows.push_back(row);
+  if (h->dirty_rows.size() > 8192) {  // a bulk change: re-upload the whole ask table instead
+    h->dirty_pods = true;
+    h->dirty_rows.clear();
+  }
+}
 void set_ask_row(ykhost* h, Pod* old, Pod* now) {
-  long row = -1;
-  if (old && old->ask)
-    for (size_t i = 0; i < h->pending.size(); ++i)
-      if (h->pending[i] == old) {
-        row = (long)i;
-        break;
-      }
-  if (old) old->ask = false;
+  int row = (old && old->ask) ? old->row : -1;
+  if (old) {
+    old->ask = false;
+    old->row = -1;
+  }
   if (now) {
     now->ask = true;
-    if (row >= 0)
-      h->pending[(size_t)row] = now;
-    else
+    if (row < 0) {
+      row = (int)h->pending.size();
       h->pending.push_back(now);
+    } else {
+      h->pending[(size_t)row] = now;
+    }
+    now->row = row;
     if (now->tpl->spec_id < 0)
       h->dirty_all = true;  // new template: dictionaries may grow
     else
-      h->dirty_pods = true;
+      mark_row(h, row);
   } else if (row >= 0) {
-    h->pending.erase(h->pending.begin() + row);
-    h->dirty_pods = true;
+    Pod* last = h->pending.back();
+    h->pending.pop_back();
+    if (last != old) {
+      h->pending[(size_t)row] = last;
+      last->row = row;
+      mark_row(h, row);
+    }
+    h->table_shrunk = true;
   }
 }
 
@@ -678,6 +723,7 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
     else if (pin == 10)
       pod.node_name = "no-such-node";
     pod.ask = true;
+    pod.row = (int32_t)h->pending.size();
     h->pod_store.push_back(std::move(pod));
     h->pending.push_back(&h->pod_store.back());
   }
@@ -754,6 +800,7 @@ int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
       for (auto& pv : pods->arr) {
         Pod* p = add_pod_object(h, *pv, &anon);  // an ask of the snapshot; a spec.nodeName it carries is only the NodeName filter's input
         p->ask = true;
+        p->row = (int32_t)h->pending.size();
         h->pending.push_back(p);
         h->by_uid[p->uid] = p;
       }
@@ -814,8 +861,7 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
     p->assigned_node.clear();
     p->assumed = false;
     if (revert) {
-      p->node_name.clear();
-      if (p->ask) h->dirty_pods = true;  // the row loses its nodeName pin
+      p->node_name.clear();  // (the whole table is re-uploaded below: node indices shift)
     } else {
       p->orphan = true;
       ++orphans;
@@ -904,7 +950,7 @@ int32_t ykhost_forget_pod(ykhost_t* h, const char* uid) {
   if (it == h->by_uid.end()) return 0;  // "unable to forget pod: not found in cache" (context.go:897)
   Pod* p = it->second;
   cache_update_pod(h, p, p, false, false);
-  if (p->assumed && p->ask) h->dirty_pods = true;  // the row now follows the cached pod: pinned to its node
+  if (p->assumed && p->ask) mark_row(h, p->row);  // the row now follows the cached pod: pinned to its node
   p->assumed = false;
   return 1;
 }
@@ -936,8 +982,13 @@ int32_t ykhost_generate_kwok(ykhost_t* h, const ykhost_kwok_t* cfg) {
 
 int32_t ykhost_num_nodes(const ykhost_t* h) { YKHOST_LOCKED(h); return (int32_t)h->nodes.size(); }
 int32_t ykhost_num_pods(const ykhost_t* h) { YKHOST_LOCKED(h); return (int32_t)h->pending.size(); }
-int32_t ykhost_pod_index(const ykhost_t* h, const char* uid) {
+int32_t ykhost_pod_index(const ykhost_t* ch, const char* uid) {
+  ykhost_t* h = const_cast<ykhost_t*>(ch);
   YKHOST_LOCKED(h);
+  ensure_uid_index(h);
+  auto it = h->by_uid.find(uid);
+  if (it != h->by_uid.end() && it->second->ask) return it->second->row;
+  // asks of a snapshot may share a uid with a pod on a node (or carry none that is unique): fall back to the table
   for (size_t i = 0; i < h->pending.size(); ++i)
     if (h->pending[i]->uid == uid) return (int32_t)i;
   return -1;
@@ -986,6 +1037,7 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
   rc = ykpred_eval(h->eng, &a);
   if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
   h->eval_dirty_nodes.clear();
+  h->eval_dirty_rows.clear();
   h->last_eval_phase = allocate ? 1 : 0;
   h->last_eval_options = options;
   return 0;
@@ -994,23 +1046,38 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
 int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched) {
   YKHOST_LOCKED(h);
   if (columns_patched) *columns_patched = -1;
-  // topology constraints (spread, inter-pod affinity) couple all nodes through their histograms: full evaluation
-  const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0) && h->enc.KD == 0;
+  // topology constraints (spread, inter-pod affinity) couple all nodes through their histograms: a node change needs a
+  // full evaluation (row changes alone do not: the histograms depend on the nodes only)
+  const bool nodes_touched = !h->eval_dirty_nodes.empty();
+  const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0) && !(nodes_touched && h->enc.KD != 0);
   if (!incremental) return ykhost_evaluate(h, allocate, options);
-  int rc = sync(h);  // uploads the touched node rows
+  int rc = sync(h);  // uploads the touched node rows and ask rows
   if (rc) return rc;
+  if (h->dirty_all || h->dirty_pods) return ykhost_evaluate(h, allocate, options);  // the sync had to rebuild tables
   ykpred_eval_args_t a{};
   a.prefilter_plugins = allocate ? h->alloc_pre : h->res_pre;
   a.filter_plugins = allocate ? h->alloc_filt : h->res_filt;
   a.options = options;
-  rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.data());
-  if (rc == YKPRED_E_STATE || rc == YKPRED_E_UNSUPPORTED) return ykhost_evaluate(h, allocate, options);
-  if (rc) return fail(h, std::string("ykpred_eval_nodes: ") + ykpred_last_error(h->eng), rc);
+  // columns first (they patch every row through its class), then the changed rows as a whole
+  if (nodes_touched) {
+    rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.data());
+    if (rc == YKPRED_E_STATE || rc == YKPRED_E_UNSUPPORTED) return ykhost_evaluate(h, allocate, options);
+    if (rc) return fail(h, std::string("ykpred_eval_nodes: ") + ykpred_last_error(h->eng), rc);
+  }
+  if (!h->eval_dirty_rows.empty()) {
+    std::sort(h->eval_dirty_rows.begin(), h->eval_dirty_rows.end());
+    h->eval_dirty_rows.erase(std::unique(h->eval_dirty_rows.begin(), h->eval_dirty_rows.end()), h->eval_dirty_rows.end());
+    while (!h->eval_dirty_rows.empty() && h->eval_dirty_rows.back() >= (int)h->pending.size()) h->eval_dirty_rows.pop_back();
+    rc = ykpred_eval_pods(h->eng, &a, (int32_t)h->eval_dirty_rows.size(), h->eval_dirty_rows.data());
+    if (rc == YKPRED_E_STATE) return ykhost_evaluate(h, allocate, options);
+    if (rc) return fail(h, std::string("ykpred_eval_pods: ") + ykpred_last_error(h->eng), rc);
+  }
   if (columns_patched) {
     std::sort(h->eval_dirty_nodes.begin(), h->eval_dirty_nodes.end());
     *columns_patched = (int32_t)(std::unique(h->eval_dirty_nodes.begin(), h->eval_dirty_nodes.end()) - h->eval_dirty_nodes.begin());
   }
   h->eval_dirty_nodes.clear();
+  h->eval_dirty_rows.clear();
   return 0;
 }
 

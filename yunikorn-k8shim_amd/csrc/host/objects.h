@@ -96,6 +96,7 @@ struct Pod {
   bool assumed = false;       // assumedPods has uid (set by AssumePod, cleared by ForgetPod / Running / terminated)
   bool orphan = false;        // orphanedPods has uid: spec.nodeName names a node that is not in the cache
   bool ask = false;           // holds a row of the ask table (bitmap row); rows stay put across AssumePod / ForgetPod
+  int32_t row = -1;           // that row
   const PodTemplate* tpl = nullptr;
 };
 
