@@ -374,7 +374,7 @@ def test_incremental_assume_forget(pm):
             pm.forget_pod(uid)
             pod = next(p for p in snap["pods"] if p["metadata"]["uid"] == uid)
             cur = {"nodes": cur["nodes"], "pods": cur["pods"] + [dict(pod, spec=dict(pod["spec"], nodeName=target))]}
-            expect_patched = -1  # the ask table changed (the row's node pin): full evaluation
+            expect_patched = 1  # the node's row is re-accounted (one column) and the ask's row gets its node pin (one row)
         elif bound and r < 0.4:
             # RemovePod of a bound pod (:390-417): it leaves the node and the ask table
             uid, target = bound.pop(rng.randrange(len(bound)))
@@ -383,7 +383,7 @@ def test_incremental_assume_forget(pm):
             tn = next(n for n in nodes if n["metadata"]["name"] == target)
             tn["pods"] = [q for q in tn["pods"] if q["metadata"]["uid"] != uid]
             cur = {"nodes": nodes, "pods": cur["pods"]}
-            expect_patched = -1
+            expect_patched = 1  # one node column; the vacated row is refilled with the last row's ask
         else:
             uid = rng.choice([p for p in cur["pods"] if not p["spec"].get("nodeName")])["metadata"]["uid"]
             target = rng.choice(names)

@@ -198,7 +198,8 @@ def test_ask_rows_stay_put_while_binds_are_in_flight(cache):
     cache.update_pod(pod("ask-1", node_name=HOST1, phase="Pending"))  # bind acknowledged by the API server, not running yet
     assert [cache.pod_index(f"ask-{i}") for i in range(4)] == [0, 1, 2, 3]
     cache.update_pod(pod("ask-1", node_name=HOST1, phase="Running"))
-    assert [cache.pod_index(f"ask-{i}") for i in range(4)] == [0, -1, 1, 2]
+    # the vacated row is refilled with the LAST row's ask; every other row keeps its index
+    assert [cache.pod_index(f"ask-{i}") for i in range(4)] == [0, -1, 2, 1]
 
 
 def test_dump_snapshot_lists_assumed_pods_under_their_node(cache):
