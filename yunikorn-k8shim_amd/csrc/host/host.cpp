@@ -74,6 +74,7 @@ struct ykhost {
   std::vector<int> dirty_rows;        // ask rows to re-upload (ykpred_update_pods)
   std::vector<int> eval_dirty_rows;   // bitmap rows changed since the last evaluation
   bool table_shrunk = false;          // the ask table lost rows at its end since the last upload
+  bool decisions_stale = true;        // something was (re)evaluated without decisions since they were last produced
   // answers of one ask against every node (ykpred_query_pod), so that the core's per-node Predicates() callbacks of a
   // scheduling attempt are served from host memory; dropped whenever any table changes
   struct AskAnswers {
@@ -1038,6 +1039,7 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
   if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
   h->eval_dirty_nodes.clear();
   h->eval_dirty_rows.clear();
+  h->decisions_stale = !(options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS));
   h->last_eval_phase = allocate ? 1 : 0;
   h->last_eval_options = options;
   return 0;
@@ -1058,7 +1060,16 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
   a.prefilter_plugins = allocate ? h->alloc_pre : h->res_pre;
   a.filter_plugins = allocate ? h->alloc_filt : h->res_filt;
   a.options = options;
+  const bool want_dec = options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS);
+  const bool rows_touched = !h->eval_dirty_rows.empty();
   // columns first (they patch every row through its class), then the changed rows as a whole
+  if (want_dec && h->decisions_stale && !nodes_touched) {
+    // earlier patches ran without decisions: refresh bin-pack order, class decisions and the per-pod scatter (no bitmap pass)
+    ykpred_eval_args_t b = a;
+    b.options = (options & ~(uint32_t)YKPRED_OUT_BITMAP) | YKPRED_EVAL_SKIP_BITMAP;
+    rc = ykpred_eval(h->eng, &b);
+    if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
+  }
   if (nodes_touched) {
     rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.data());
     if (rc == YKPRED_E_STATE || rc == YKPRED_E_UNSUPPORTED) return ykhost_evaluate(h, allocate, options);
@@ -1078,6 +1089,10 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
   }
   h->eval_dirty_nodes.clear();
   h->eval_dirty_rows.clear();
+  if (want_dec)
+    h->decisions_stale = false;
+  else if (nodes_touched || rows_touched)
+    h->decisions_stale = true;
   return 0;
 }
 
