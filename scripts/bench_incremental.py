@@ -36,8 +36,31 @@ def timed(decisions, n=40, offset=0):
     return float(np.median(wall)), float(np.median(dev))
 
 
+def timed_rows(n=40):
+    """A new ask of a known template arrives (row appended) / an assumed ask is reported Running (row vacated and refilled)."""
+    wall_new, wall_done = [], []
+    for i in range(n):
+        ask = json.loads(pm.dump_snapshot(pods=[(104729 * i) % 1_000_000], nodes=[]))["pods"][0]
+        ask["metadata"].update(uid=f"late-{i}", name=f"late-{i}")
+        ask["spec"].pop("nodeName", None)
+        t0 = time.perf_counter()
+        pm.update_pod(ask)
+        pm.evaluate_dirty(counts=True, decisions=True)
+        pm.synchronize()
+        wall_new.append((time.perf_counter() - t0) * 1e3)
+    for i in range(n):
+        t0 = time.perf_counter()
+        pm.update_pod({"metadata": {"uid": f"late-{i}", "name": f"late-{i}"}, "spec": {}, "status": {"phase": "Succeeded"}})
+        pm.evaluate_dirty(counts=True, decisions=True)
+        pm.synchronize()
+        wall_done.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(wall_new)), float(np.median(wall_done))
+
+
 w0, d0 = timed(False, offset=0)
 w1, d1 = timed(True, offset=1000)
+pm.evaluate()
+rn, rd = timed_rows()
 t0 = time.perf_counter()
 for _ in range(5):
     pm.evaluate()
@@ -45,4 +68,5 @@ pm.synchronize()
 full = (time.perf_counter() - t0) / 5 * 1e3
 print(json.dumps({"workload": "configs[2]: 50k nodes x 1M asks", "assume+column_patch_ms_wall": round(w0, 4),
                   "column_patch_kernels_ms": round(d0, 4), "assume+column_patch+decisions_ms_wall": round(w1, 4),
-                  "decision_refresh_kernels_ms": round(d1, 4), "full_eval_ms_wall": round(full, 4)}))
+                  "decision_refresh_kernels_ms": round(d1, 4), "new_ask_row_patch_ms_wall": round(rn, 4),
+                  "finished_ask_row_patch_ms_wall": round(rd, 4), "full_eval_ms_wall": round(full, 4)}))

@@ -505,8 +505,8 @@ def test_incremental_rows_use_the_row_kernels(pm):
 
 
 def test_incremental_at_full_size(pm):
-    """configs[2] size: one AssumePod → one column patch; checked against the per-pair kernel on that column and against
-    a full re-evaluation (checksum)."""
+    """configs[2] size: AssumePod → one column patch; new asks / finished binds → single row patches. Checked against the
+    per-pair kernel on that column and against a full re-evaluation (checksum of the whole bitmap)."""
     pm.generate_kwok(seed=0x59554E49 + 21, num_nodes=50_000, num_pods=1_000_000, num_templates=2000, node_affinity=1)
     pm.evaluate()
     node = "kwok-node-012345"
@@ -520,6 +520,31 @@ def test_incremental_at_full_size(pm):
     assert np.array_equal((col >> np.uint64(n_idx & 63)) & np.uint64(1), fit.astype(np.uint64))
     pm.evaluate()
     assert pm.checksum() == patched_sum
+    # ask rows: three new asks of known templates are appended, one bind completes (its row is refilled with the last ask)
+    classes = pm.layout().num_classes
+    for k, src_row in enumerate((5, 123_456, 999_999)):
+        ask = json.loads(pm.dump_snapshot(pods=[src_row], nodes=[]))["pods"][0]
+        ask["metadata"].update(uid=f"late-{k}", name=f"late-{k}")
+        ask["spec"].pop("nodeName", None)
+        pm.update_pod(ask)
+    done = json.loads(pm.dump_snapshot(pods=[40], nodes=[]))["pods"][0]
+    pm.assume_pod(done["metadata"]["uid"], node)
+    pm.update_pod(dict(done, status={"phase": "Running"}))
+    assert pm.num_pods == 1_000_002 and pm.pod_index("late-2") == 40 and pm.pod_index(done["metadata"]["uid"]) == -1
+    assert pm.evaluate_dirty(decisions=True, profile=True) == 1
+    assert "k_combine" not in [k for k, _ in pm.timing()["kernels"]]
+    assert pm.layout().num_pods == 1_000_002 and pm.layout().num_classes <= classes + 3
+    rows = np.array([40, 1_000_000, 1_000_001, 7], dtype=np.int32)
+    nodes = np.random.default_rng(5).integers(0, 50_000, size=(4, 3000)).astype(np.int32)
+    fit, _, _ = pm.query(np.repeat(rows, 3000), nodes.reshape(-1))
+    bm = pm.read_bitmap(0, 1_000_002)
+    got = (bm[np.repeat(rows, 3000), nodes.reshape(-1) >> 6] >> (nodes.reshape(-1) & 63).astype(np.uint64)) & np.uint64(1)
+    assert np.array_equal(got, fit.astype(np.uint64))
+    counts, dec = pm.read_counts(), pm.read_decisions()
+    patched_sum = pm.checksum()
+    pm.evaluate()
+    assert pm.checksum() == patched_sum
+    assert np.array_equal(counts, pm.read_counts()) and np.array_equal(dec, pm.read_decisions())
 
 
 def test_unsupported_pods_are_rejected_loudly(pm):
