@@ -40,7 +40,7 @@ def timed_rows(n=40):
     """A new ask of a known template arrives (row appended) / an assumed ask is reported Running (row vacated and refilled)."""
     wall_new, wall_done = [], []
     for i in range(n):
-        ask = json.loads(pm.dump_snapshot(pods=[(104729 * i) % 1_000_000], nodes=[]))["pods"][0]
+        ask = json.loads(pm.dump_snapshot(pods=[500_000 + 7919 * i], nodes=[]))["pods"][0]
         ask["metadata"].update(uid=f"late-{i}", name=f"late-{i}")
         ask["spec"].pop("nodeName", None)
         t0 = time.perf_counter()

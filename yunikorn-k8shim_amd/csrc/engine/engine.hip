@@ -442,6 +442,29 @@ struct Timer {
   }
 };
 
+// Engine-owned outputs of the last evaluation grow with the ask table and keep their contents (caller-owned ones must
+// already hold layout.num_pods rows): the incremental kernels address rows up to the CURRENT table length.
+int grow_owned_outputs(ykpred_engine* e) {
+  const size_t P = (size_t)std::max(e->P, 1);
+  if (e->last_bitmap && e->last_bitmap == e->d_bitmap.p) {
+    HIPCHK(e->d_bitmap.reserve_keep(P * (size_t)e->row_stride * sizeof(u64), e->d_bitmap.cap));
+    e->last_bitmap = e->d_bitmap.p;
+  }
+  if (e->last_counts && e->last_counts == e->d_counts.p) {
+    HIPCHK(e->d_counts.reserve_keep(P * sizeof(int), e->d_counts.cap));
+    e->last_counts = e->d_counts.p;
+  }
+  if (e->last_decisions && e->last_decisions == e->d_decisions.p) {
+    HIPCHK(e->d_decisions.reserve_keep(P * sizeof(int), e->d_decisions.cap));
+    e->last_decisions = e->d_decisions.p;
+  }
+  if (e->last_keys && e->last_keys == e->d_keys.p) {
+    HIPCHK(e->d_keys.reserve_keep(P * sizeof(i64), e->d_keys.cap));
+    e->last_keys = e->d_keys.p;
+  }
+  return YKPRED_OK;
+}
+
 // PodTopologySpread PreFilter for every spread signature: histogram over nodes, then the per-constraint minimum.
 // count_only / counts_ready split the two halves for node-sharded clusters (all-reduce of the histograms in between).
 int run_spread_prefilter(ykpred_engine* e, hipStream_t st, Timer* tm, bool do_count, bool do_min) {
@@ -1254,6 +1277,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     if (e->h_class_first[(size_t)c] == rows[i]) put(T_CLASS_FIRST, c, rows[i]);
   }
   e->P = newP;
+  TRY(grow_owned_outputs(e));
 
   // device side: grow what has to grow (contents kept), then apply every change with one copy + one launch
   const size_t I = sizeof(int32_t);
@@ -1304,24 +1328,7 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_
   if (want_dec && !e->rank_valid) return fail(e, YKPRED_E_STATE, "eval_pods: the bin-pack order is stale — run ykpred_eval with decisions");
   for (int i = 0; i < num_rows; ++i)
     if (rows[i] < 0 || rows[i] >= e->P) return fail(e, YKPRED_E_INVALID, "eval_pods: row out of range");
-  // engine-owned outputs grow with the table (caller-owned ones must already hold layout.num_pods rows)
-  const size_t P = (size_t)std::max(e->P, 1);
-  if (own_bitmap) {
-    HIPCHK(e->d_bitmap.reserve_keep(P * (size_t)e->row_stride * sizeof(u64), e->d_bitmap.cap));
-    e->last_bitmap = e->d_bitmap.p;
-  }
-  if (!a->counts && e->last_counts == e->d_counts.p) {
-    HIPCHK(e->d_counts.reserve_keep(P * sizeof(int), e->d_counts.cap));
-    e->last_counts = e->d_counts.p;
-  }
-  if (!a->decisions && e->last_decisions == e->d_decisions.p) {
-    HIPCHK(e->d_decisions.reserve_keep(P * sizeof(int), e->d_decisions.cap));
-    e->last_decisions = e->d_decisions.p;
-  }
-  if (!a->decision_keys && e->last_keys == e->d_keys.p) {
-    HIPCHK(e->d_keys.reserve_keep(P * sizeof(i64), e->d_keys.cap));
-    e->last_keys = e->d_keys.p;
-  }
+  TRY(grow_owned_outputs(e));
   Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
   tm.start(st);
   if (num_rows > 0 && e->N > 0) {
