@@ -490,6 +490,45 @@ def test_incremental_ask_rows(pm, topology):
     _compare_with_mirror_dump(pm, decisions=True)
 
 
+def test_incremental_node_object_updates(pm):
+    """SchedulerCache.UpdateNode of a known node (scheduler_cache.go:173-177): allocatable, labels, taints, unschedulable.
+    As long as no dictionary grows only that node's row is re-encoded and ONE bitmap column is re-evaluated."""
+    snap = _gen.random_snapshot(99, n_nodes=120, n_pods=60, scalars=False)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    nodes = {n["metadata"]["name"]: n for n in snap["nodes"] if n["metadata"]["name"]}
+    names = sorted(nodes)
+    donor_taints = next(n["spec"]["taints"] for n in snap["nodes"] if n["spec"].get("taints"))
+    donor_labels = next(n["metadata"]["labels"] for n in snap["nodes"] if n["metadata"].get("labels"))
+
+    def strip(n):
+        return {k: v for k, v in n.items() if k != "pods"}
+
+    edits = [
+        lambda n: n["status"]["allocatable"].update(cpu="1", memory="1Mi"),
+        lambda n: n["metadata"].update(labels=dict(donor_labels)),
+        lambda n: n["spec"].update(unschedulable=True),
+        lambda n: n["spec"].update(taints=list(donor_taints)),
+        lambda n: n["spec"].update(taints=[], unschedulable=False),
+        lambda n: n["metadata"].update(labels={}),
+    ]
+    for k, edit in enumerate(edits):
+        n = json.loads(json.dumps(strip(nodes[names[(k * 17) % len(names)]])))
+        n.setdefault("spec", {})
+        n.setdefault("status", {}).setdefault("allocatable", {})
+        n.setdefault("metadata", {})
+        edit(n)
+        assert pm.update_node(n) == 0
+        assert pm.evaluate_dirty(decisions=True) == 1
+        _compare_with_mirror_dump(pm, decisions=True)
+    # a taint nobody carried before extends the taint dictionary: everything is re-encoded, and still exact
+    n = json.loads(json.dumps(strip(nodes[names[3]])))
+    n.setdefault("spec", {})["taints"] = [{"key": "brand-new", "value": "x", "effect": "NoSchedule"}]
+    pm.update_node(n)
+    assert pm.evaluate_dirty(decisions=True) == -1
+    _compare_with_mirror_dump(pm, decisions=True)
+
+
 def test_incremental_rows_use_the_row_kernels(pm):
     snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
     pm.load_snapshot(snap)

@@ -344,6 +344,16 @@ class Encoder {
     }
   }
 
+  // True when every taint and scalar resource of the node object already has its dictionary entry, i.e. the node's row
+  // can be re-encoded alone (label requirements are evaluated per node, topology values are checked by
+  // encode_node_spread).
+  bool node_known(const NodeInfo& ni) const {
+    for (auto& t : ni.node.taints)
+      if ((t.effect == "NoSchedule" || t.effect == "NoExecute") && !taint_ix_.count(taint_key(t))) return false;
+    for (auto& kv : ni.allocatable.scalar)
+      if (!scalar_ix_.count(kv.first)) return false;
+    return true;
+  }
   // True when accounting a pod of this template on a node needs no dictionary that does not exist yet (scalar resource
   // names, topology keys / count classes of its required anti-affinity terms). False → rebuild the dictionaries.
   bool node_pod_known(const PodTemplate& t) const {

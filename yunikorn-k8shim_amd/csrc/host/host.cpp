@@ -834,10 +834,15 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
         if (kv.second->orphan && kv.second->node_name == n.name) orphans.push_back(kv.second);
       for (Pod* p : orphans)
         if (cache_update_pod(h, p, p, false, false)) ++adopted;
+      h->dirty_all = true;  // the node axis grew: every table is re-uploaded
     } else {
-      h->nodes[(size_t)it->second]->set_node(n);
+      NodeInfo* ni = h->nodes[(size_t)it->second];
+      ni->set_node(n);
+      if (h->enc.node_known(*ni))
+        touch_node(h, it->second);  // same dictionaries: only this node's row (and bitmap column) changes
+      else
+        h->dirty_all = true;  // a new taint or scalar resource extends the dictionaries
     }
-    h->dirty_all = true;  // labels / taints / scalars may extend the dictionaries
     return adopted;
   } catch (const std::exception& e) {
     return fail(h, e.what());
