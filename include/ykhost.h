@@ -90,6 +90,10 @@ int32_t ykhost_node_index(const ykhost_t* h, const char* node_name); /* -1 = unk
  * as a snapshot document. Returns the required length (incl. NUL); writes at most `len` bytes. */
 int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len);
 
+/* The encoded (structure-of-arrays) tables that cross the C ABI, as JSON (64-bit masks as hex strings); works on a
+ * mirror-only handle. For encoder tests on machines without a device. Returns the required length like dump_snapshot. */
+int64_t ykhost_encoded_tables_json(ykhost_t* h, char* out, int64_t len);
+
 /* encode + upload whatever changed since the last sync (called implicitly by the functions below) */
 int32_t ykhost_sync(ykhost_t* h);
 ykpred_engine_t* ykhost_engine(ykhost_t* h); /* the underlying engine, for layout / readback / timing calls */

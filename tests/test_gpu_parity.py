@@ -529,6 +529,40 @@ def test_incremental_node_object_updates(pm):
     _compare_with_mirror_dump(pm, decisions=True)
 
 
+def test_update_pods_argument_checks(pm):
+    """The C entry point itself: bad row lists are refused and leave the table untouched."""
+    snap = _gen.random_snapshot(5, n_nodes=70, n_pods=20, scalars=False)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    P = pm.num_pods
+    before = pm.read_bitmap().copy()
+
+    def call(after, rows, specs, pins):
+        r, sp, pi = (np.asarray(x, dtype=np.int32) for x in (rows, specs, pins))
+        return pm._P.ykpred_update_pods(pm.engine, after, len(r), r.ctypes.data, sp.ctypes.data, pi.ctypes.data)
+
+    assert call(P, [1, 1], [0, 0], [-1, -1]) < 0          # a row listed twice
+    assert call(P + 2, [P], [0], [-1]) < 0                 # an appended row is not listed
+    assert call(P, [P], [0], [-1]) < 0                     # row beyond the table
+    assert call(P, [0], [10_000], [-1]) < 0                # unknown spec
+    assert call(P, [0], [0], [10_000]) < 0                 # node index out of range
+    assert pm.layout().num_pods == P
+    assert np.array_equal(before, pm.read_bitmap())
+    # a valid call straight at the C ABI: row 2 takes spec 0 unpinned, the row patch then equals the per-pair answers
+    import ctypes
+    ffi = importlib.import_module("yunikorn-k8shim_amd._ffi")
+    assert call(P, [2], [0], [-1]) == 0
+    a = ffi.YkpredEvalArgs()
+    a.prefilter_plugins, a.filter_plugins = pm._masks[1], pm._masks[3]
+    a.options = 1 | 2
+    row = np.array([2], dtype=np.int32)
+    assert pm._P.ykpred_eval_pods(pm.engine, ctypes.byref(a), 1, row.ctypes.data) == 0
+    N = pm.num_nodes
+    fit, _, _ = pm.query(np.full(N, 2, dtype=np.int32), np.arange(N, dtype=np.int32))
+    assert np.array_equal(unpack(pm.read_bitmap(2, 1), N)[0], fit)
+    assert pm.read_counts()[2] == fit.sum()
+
+
 def test_incremental_rows_use_the_row_kernels(pm):
     snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
     pm.load_snapshot(snap)

@@ -81,6 +81,8 @@ def load_ykpred():
     L.ykpred_set_pods.argtypes = [C.c_void_p, C.POINTER(YkpredPods)]
     L.ykpred_eval.argtypes = [C.c_void_p, C.POINTER(YkpredEvalArgs)]
     L.ykpred_eval_nodes.argtypes = [C.c_void_p, C.POINTER(YkpredEvalArgs), C.c_int32, C.c_void_p]
+    L.ykpred_update_pods.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_eval_pods.argtypes = [C.c_void_p, C.POINTER(YkpredEvalArgs), C.c_int32, C.c_void_p]
     L.ykpred_synchronize.argtypes = [C.c_void_p]
     L.ykpred_get_layout.argtypes = [C.c_void_p, C.POINTER(YkpredLayout)]
     L.ykpred_last_timing.argtypes = [C.c_void_p, C.POINTER(YkpredTiming)]
@@ -130,6 +132,8 @@ def load_ykhost():
     L.ykhost_dump_snapshot.restype = C.c_int64
     L.ykhost_dump_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
     L.ykhost_sync.argtypes = [C.c_void_p]
+    L.ykhost_encoded_tables_json.restype = C.c_int64
+    L.ykhost_encoded_tables_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.ykhost_engine.restype = C.c_void_p
     L.ykhost_engine.argtypes = [C.c_void_p]
     L.ykhost_evaluate.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]

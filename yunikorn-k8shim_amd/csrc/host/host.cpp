@@ -176,8 +176,21 @@ int recreate_engine(ykhost* h) {
   return 0;
 }
 
-int full_sync(ykhost* h) {
-  auto t0 = std::chrono::steady_clock::now();
+// The encoded (structure-of-arrays) form of the mirror: exactly what crosses the C ABI in ykpred_set_nodes / set_specs.
+struct EncodedTables {
+  std::vector<uint64_t> ports, taints, labels, stol, aff_terms, pre_terms, wanted;
+  std::vector<int64_t> alloc, req, sreq;
+  std::vector<int32_t> allowed, count, domain, selcount, dsizes, aff_off, pre_off, spread_off;
+  std::vector<uint32_t> flags, sflags;
+  std::vector<ykpred_spread_t> spread;
+  ykpred_nodes_t nt{};
+  ykpred_specs_t sp{};
+  uint64_t dummy = 0;
+  ykpred_spread_t no_spread{};
+};
+
+// Dictionaries + node rows + spec rows from the current objects (no device involved).
+int encode_tables(ykhost* h, EncodedTables* T) {
   // templates of pending asks, in first-use order → spec ids
   h->spec_templates.clear();
   for (PodTemplate* t : h->pool.all()) t->spec_id = -1;
@@ -189,82 +202,103 @@ int full_sync(ykhost* h) {
     }
   }
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
-  int rc = recreate_engine(h);
-  if (rc) return rc;
   const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS, KP = h->enc.KP;
   const size_t N = h->nodes.size();
-  std::vector<uint64_t> ports(N * KP + 1), p1(KP + 1);
-  std::vector<int64_t> alloc(N * R), req(N * R), a1(R), r1(R);
-  std::vector<int32_t> allowed(N), count(N), domain(N * KD + 1), selcount(N * KS + 1), d1(KD + 1), s1(KS + 1);
-  std::vector<uint32_t> flags(N);
-  std::vector<uint64_t> taints(N * KT), labels(N * W), t1(KT), l1(W);
+  T->ports.assign(N * KP + 1, 0);
+  T->alloc.assign(N * R, 0);
+  T->req.assign(N * R, 0);
+  T->allowed.assign(N, 0);
+  T->count.assign(N, 0);
+  T->domain.assign(N * KD + 1, 0);
+  T->selcount.assign(N * KS + 1, 0);
+  T->flags.assign(N, 0);
+  T->taints.assign(N * KT, 0);
+  T->labels.assign(N * W, 0);
+  std::vector<uint64_t> p1(KP + 1), t1(KT), l1(W);
+  std::vector<int64_t> a1(R), r1(R);
+  std::vector<int32_t> d1(KD + 1), s1(KS + 1);
   for (size_t n = 0; n < N; ++n) {
     h->nodes[n]->index = (int32_t)n;
-    h->enc.encode_node(*h->nodes[n], a1.data(), r1.data(), &allowed[n], &count[n], &flags[n], t1.data(), l1.data());
+    h->enc.encode_node(*h->nodes[n], a1.data(), r1.data(), &T->allowed[n], &T->count[n], &T->flags[n], t1.data(), l1.data());
     h->enc.encode_node_spread(*h->nodes[n], d1.data(), s1.data());
-    for (int k = 0; k < KD; ++k) domain[(size_t)k * N + n] = d1[(size_t)k];
-    for (int k = 0; k < KS; ++k) selcount[(size_t)k * N + n] = s1[(size_t)k];
+    for (int k = 0; k < KD; ++k) T->domain[(size_t)k * N + n] = d1[(size_t)k];
+    for (int k = 0; k < KS; ++k) T->selcount[(size_t)k * N + n] = s1[(size_t)k];
     h->enc.encode_ports(h->nodes[n]->pods, p1.data());
-    for (int k = 0; k < KP; ++k) ports[(size_t)k * N + n] = p1[(size_t)k];
+    for (int k = 0; k < KP; ++k) T->ports[(size_t)k * N + n] = p1[(size_t)k];
     for (int r = 0; r < R; ++r) {
-      alloc[(size_t)r * N + n] = a1[(size_t)r];
-      req[(size_t)r * N + n] = r1[(size_t)r];
+      T->alloc[(size_t)r * N + n] = a1[(size_t)r];
+      T->req[(size_t)r * N + n] = r1[(size_t)r];
     }
-    for (int k = 0; k < KT; ++k) taints[(size_t)k * N + n] = t1[(size_t)k];
-    for (int w = 0; w < W; ++w) labels[(size_t)w * N + n] = l1[(size_t)w];
+    for (int k = 0; k < KT; ++k) T->taints[(size_t)k * N + n] = t1[(size_t)k];
+    for (int w = 0; w < W; ++w) T->labels[(size_t)w * N + n] = l1[(size_t)w];
   }
-  ykpred_nodes_t nt{};
+  ykpred_nodes_t& nt = T->nt;
+  nt = ykpred_nodes_t{};
   nt.count = (int32_t)N;
-  nt.allocatable = alloc.data();
-  nt.requested = req.data();
-  nt.allowed_pods = allowed.data();
-  nt.pod_count = count.data();
-  nt.flags = flags.data();
-  nt.taint_bits = taints.data();
-  nt.label_bits = labels.data();
-  std::vector<int32_t> dsizes = h->enc.domain_sizes();
-  dsizes.push_back(0);
-  nt.domain_id = domain.data();
-  nt.selector_count = selcount.data();
-  nt.domain_sizes = dsizes.data();
-  nt.port_bits = ports.data();
-  rc = ykpred_set_nodes(h->eng, &nt);
-  if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
+  nt.allocatable = T->alloc.data();
+  nt.requested = T->req.data();
+  nt.allowed_pods = T->allowed.data();
+  nt.pod_count = T->count.data();
+  nt.flags = T->flags.data();
+  nt.taint_bits = T->taints.data();
+  nt.label_bits = T->labels.data();
+  T->dsizes = h->enc.domain_sizes();
+  T->dsizes.push_back(0);
+  nt.domain_id = T->domain.data();
+  nt.selector_count = T->selcount.data();
+  nt.domain_sizes = T->dsizes.data();
+  nt.port_bits = T->ports.data();
 
   const size_t S = h->spec_templates.size();
-  std::vector<int64_t> sreq(S * R);
-  std::vector<uint64_t> stol(S * KT), aff_terms, pre_terms, wanted(S * KP + 1);
-  std::vector<uint32_t> sflags(S);
-  std::vector<int32_t> aff_off{0}, pre_off{0}, spread_off{0};
-  std::vector<ykpred_spread_t> spread;
+  T->sreq.assign(S * R, 0);
+  T->stol.assign(S * KT, 0);
+  T->wanted.assign(S * KP + 1, 0);
+  T->sflags.assign(S, 0);
+  T->aff_terms.clear();
+  T->pre_terms.clear();
+  T->aff_off.assign(1, 0);
+  T->pre_off.assign(1, 0);
+  T->spread_off.assign(1, 0);
+  T->spread.clear();
   for (size_t s = 0; s < S; ++s) {
     EncodedSpec es = h->enc.encode_spec(*h->spec_templates[s]);
-    spread.insert(spread.end(), es.spread.begin(), es.spread.end());
-    spread_off.push_back((int32_t)spread.size());
-    std::copy(es.req.begin(), es.req.end(), sreq.begin() + (long)(s * R));
-    std::copy(es.tol.begin(), es.tol.end(), stol.begin() + (long)(s * KT));
-    sflags[s] = es.flags;
-    h->enc.encode_wanted_ports(*h->spec_templates[s], wanted.data() + s * KP);
-    for (auto& t : es.terms) aff_terms.insert(aff_terms.end(), t.begin(), t.end());
-    for (auto& t : es.pre_terms) pre_terms.insert(pre_terms.end(), t.begin(), t.end());
-    aff_off.push_back((int32_t)(aff_terms.size() / (size_t)W));
-    pre_off.push_back((int32_t)(pre_terms.size() / (size_t)W));
+    T->spread.insert(T->spread.end(), es.spread.begin(), es.spread.end());
+    T->spread_off.push_back((int32_t)T->spread.size());
+    std::copy(es.req.begin(), es.req.end(), T->sreq.begin() + (long)(s * R));
+    std::copy(es.tol.begin(), es.tol.end(), T->stol.begin() + (long)(s * KT));
+    T->sflags[s] = es.flags;
+    h->enc.encode_wanted_ports(*h->spec_templates[s], T->wanted.data() + s * KP);
+    for (auto& t : es.terms) T->aff_terms.insert(T->aff_terms.end(), t.begin(), t.end());
+    for (auto& t : es.pre_terms) T->pre_terms.insert(T->pre_terms.end(), t.begin(), t.end());
+    T->aff_off.push_back((int32_t)(T->aff_terms.size() / (size_t)W));
+    T->pre_off.push_back((int32_t)(T->pre_terms.size() / (size_t)W));
   }
-  uint64_t dummy = 0;
-  ykpred_specs_t sp{};
+  ykpred_specs_t& sp = T->sp;
+  sp = ykpred_specs_t{};
   sp.count = (int32_t)S;
-  sp.requests = sreq.data();
-  sp.tolerated = stol.data();
-  sp.flags = sflags.data();
-  sp.aff_term_off = aff_off.data();
-  sp.aff_terms = aff_terms.empty() ? &dummy : aff_terms.data();
-  sp.pre_term_off = pre_off.data();
-  sp.pre_terms = pre_terms.empty() ? &dummy : pre_terms.data();
-  ykpred_spread_t no_spread{};
-  sp.spread_off = spread_off.data();
-  sp.spread = spread.empty() ? &no_spread : spread.data();
-  sp.wanted_ports = wanted.data();
-  rc = ykpred_set_specs(h->eng, &sp);
+  sp.requests = T->sreq.data();
+  sp.tolerated = T->stol.data();
+  sp.flags = T->sflags.data();
+  sp.aff_term_off = T->aff_off.data();
+  sp.aff_terms = T->aff_terms.empty() ? &T->dummy : T->aff_terms.data();
+  sp.pre_term_off = T->pre_off.data();
+  sp.pre_terms = T->pre_terms.empty() ? &T->dummy : T->pre_terms.data();
+  sp.spread_off = T->spread_off.data();
+  sp.spread = T->spread.empty() ? &T->no_spread : T->spread.data();
+  sp.wanted_ports = T->wanted.data();
+  return 0;
+}
+
+int full_sync(ykhost* h) {
+  auto t0 = std::chrono::steady_clock::now();
+  EncodedTables T;
+  int rc = encode_tables(h, &T);
+  if (rc) return rc;
+  rc = recreate_engine(h);
+  if (rc) return rc;
+  rc = ykpred_set_nodes(h->eng, &T.nt);
+  if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
+  rc = ykpred_set_specs(h->eng, &T.sp);
   if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
   h->dirty_all = false;
   h->dirty_nodes.clear();
@@ -1025,6 +1059,67 @@ int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const
     pod_json(*h->pending[(size_t)idx], o);
   }
   o += "]}";
+  if (out && len > 0) copy_out(o, out, len);
+  return (int64_t)o.size() + 1;
+}
+
+// The encoded tables as JSON (64-bit masks as hex strings) — lets the encoder be checked without a device: tests
+// evaluate the tables with a straightforward table-driven checker and compare with the per-pair object-model results.
+int64_t ykhost_encoded_tables_json(ykhost_t* h, char* out, int64_t len) {
+  YKHOST_LOCKED(h);
+  EncodedTables T;
+  int rc = encode_tables(h, &T);
+  h->dirty_all = true;  // spec ids were re-assigned: the device tables (if any) are re-uploaded at the next sync
+  if (rc) return rc;
+  std::string o = "{";
+  auto ints = [&](const char* name, auto begin, size_t n) {
+    o += std::string("\"") + name + "\":[";
+    for (size_t i = 0; i < n; ++i) {
+      if (i) o.push_back(',');
+      o += std::to_string(begin[i]);
+    }
+    o += "],";
+  };
+  auto masks = [&](const char* name, const uint64_t* v, size_t n) {
+    o += std::string("\"") + name + "\":[";
+    char buf[24];
+    for (size_t i = 0; i < n; ++i) {
+      if (i) o.push_back(',');
+      snprintf(buf, sizeof buf, "\"%llx\"", (unsigned long long)v[i]);
+      o += buf;
+    }
+    o += "],";
+  };
+  const size_t N = h->nodes.size(), S = h->spec_templates.size(), P = h->pending.size();
+  const size_t R = (size_t)h->enc.R, KT = (size_t)h->enc.KT, W = (size_t)h->enc.W, KD = (size_t)h->enc.KD, KS = (size_t)h->enc.KS,
+               KP = (size_t)h->enc.KP;
+  o += "\"R\":" + std::to_string(R) + ",\"KT\":" + std::to_string(KT) + ",\"W\":" + std::to_string(W) + ",\"KD\":" + std::to_string(KD) +
+       ",\"KS\":" + std::to_string(KS) + ",\"KP\":" + std::to_string(KP) + ",\"N\":" + std::to_string(N) + ",\"S\":" + std::to_string(S) +
+       ",\"P\":" + std::to_string(P) + ",";
+  ints("allocatable", T.alloc.data(), N * R);
+  ints("requested", T.req.data(), N * R);
+  ints("allowed_pods", T.allowed.data(), N);
+  ints("pod_count", T.count.data(), N);
+  ints("node_flags", T.flags.data(), N);
+  masks("taint_bits", T.taints.data(), N * KT);
+  masks("label_bits", T.labels.data(), N * W);
+  masks("port_bits", T.ports.data(), N * KP);
+  ints("domain_id", T.domain.data(), N * KD);
+  ints("selector_count", T.selcount.data(), N * KS);
+  ints("requests", T.sreq.data(), S * R);
+  masks("tolerated", T.stol.data(), S * KT);
+  ints("spec_flags", T.sflags.data(), S);
+  ints("aff_term_off", T.aff_off.data(), S + 1);
+  masks("aff_terms", T.aff_terms.data(), T.aff_terms.size());
+  ints("pre_term_off", T.pre_off.data(), S + 1);
+  masks("pre_terms", T.pre_terms.data(), T.pre_terms.size());
+  masks("wanted_ports", T.wanted.data(), S * KP);
+  ints("spread_off", T.spread_off.data(), S + 1);
+  std::vector<int32_t> spec(P), pin(P);
+  for (size_t p = 0; p < P; ++p) encode_row(h, h->pending[p], &spec[p], &pin[p]);
+  ints("pod_spec", spec.data(), P);
+  ints("pod_node_name", pin.data(), P);
+  o += "\"spread_constraints\":" + std::to_string(T.spread.size()) + "}";
   if (out && len > 0) copy_out(o, out, len);
   return (int64_t)o.size() + 1;
 }

@@ -162,6 +162,17 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_dump_snapshot(self._h, *args, buf, need))
         return buf.value.decode()
 
+    def encoded_tables(self):
+        """The structure-of-arrays tables the encoder produces (dict; masks as Python ints). Needs no device."""
+        need = self._L.ykhost_encoded_tables_json(self._h, None, 0)
+        self._check(need)
+        buf = C.create_string_buffer(need)
+        self._check(self._L.ykhost_encoded_tables_json(self._h, buf, need))
+        t = json.loads(buf.value.decode())
+        for k in ("taint_bits", "label_bits", "port_bits", "tolerated", "aff_terms", "pre_terms", "wanted_ports"):
+            t[k] = [int(x, 16) for x in t[k]]
+        return t
+
     def sync(self):
         self._check(self._L.ykhost_sync(self._h))
 
