@@ -172,6 +172,23 @@ struct ykpred_engine {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr;
 
+  // --- hipGraph cache of the full evaluation: the ~15 launches / memsets / cross-stream events of one pass are captured
+  // once per (tables version, plugin lists, options, output buffers) and replayed; any table change bumps the version
+  struct GraphKey {
+    uint64_t version;
+    unsigned pre, filt, options;
+    void *bitmap, *counts, *decisions, *keys;
+    bool operator==(const GraphKey& o) const {
+      return version == o.version && pre == o.pre && filt == o.filt && options == o.options && bitmap == o.bitmap && counts == o.counts &&
+             decisions == o.decisions && keys == o.keys;
+    }
+  };
+  std::vector<std::pair<GraphKey, hipGraphExec_t>> graphs;
+  std::vector<GraphKey> seen;  // a pass is captured the SECOND time it is asked for unchanged: one-off passes (after every
+                               // table change of the incremental path) never pay for capture + instantiation
+  uint64_t tables_version = 1;
+  bool graph_disabled = false;  // YKPRED_NO_GRAPH=1, or a capture failed once: plain launches from then on
+
   // --- timing: one (start, stop) event pair per kernel, recorded on the stream the kernel is launched on
   hipEvent_t ev[2 * YKPRED_MAX_TIMED_KERNELS + 2]{};
   bool ev_ready = false;
@@ -261,6 +278,7 @@ ykk::SpecTable spec_table(const ykpred_engine* e) {
 
 // Groups pods into classes (same signatures + same pinned node) and classes into chunks of <= kChunkMembers pods.
 int build_classes(ykpred_engine* e, hipStream_t st) {
+  e->tables_version++;
   const int P = e->P;
   auto& ids = e->class_ids;
   ids.clear();
@@ -361,6 +379,7 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
   size_t need = (size_t)rows * (size_t)e->row_stride * sizeof(u64);
   for (DevBuf* b : {&e->planes_canon, &e->planes_ranked}) {
     if (b->cap < need || e->plane_rows_alloc != rows) {
+      e->tables_version++;
       HIPCHK(b->ensure(need));
       HIPCHK(hipMemsetAsync(b->p, 0, need, st));
     }
@@ -369,6 +388,7 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
   size_t base_need = (size_t)(64 * (e->W + e->KT + e->KP) + 2) * (size_t)e->row_stride * sizeof(u64);
   for (DevBuf* b : {&e->base_canon, &e->base_ranked}) {
     if (b->cap < base_need) {
+      e->tables_version++;
       HIPCHK(b->ensure(base_need));
       HIPCHK(hipMemsetAsync(b->p, 0, base_need, st));
     }
@@ -379,6 +399,7 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
 // Device tables of the PodTopologySpread signatures: constraint rows with their histogram cell ranges (which depend on
 // the per-key domain counts of the current node table).
 int build_spread_tables(ykpred_engine* e, hipStream_t st) {
+  e->tables_version++;
   std::vector<int32_t> coff{0}, aff, tol;
   std::vector<ykk::SpreadC> rows;
   int64_t cells = 0;
@@ -550,6 +571,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->chunk_sorted = cfg->reserved[1] != 1;
   if (cfg->reserved[2] > 0 && cfg->reserved[2] <= 160 * 1024) e->combine_lds_bytes = cfg->reserved[2];
   if (cfg->reserved[2] < 0) e->combine_lds_bytes = 0;
+  if (cfg->reserved[3] == 1) e->graph_disabled = true;  // tunable: plain launches instead of hipGraph replay
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(s);
@@ -575,6 +597,8 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
+  for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
+  e->graphs.clear();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount, &e->d_ports, &e->d_sig_ports, &e->d_swanted,
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
                     &e->planes_canon, &e->planes_ranked, &e->base_canon, &e->base_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
@@ -597,6 +621,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
 
 int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   YK_SERIALISE(e);
+  if (e) e->tables_version++;
   if (!e || !n || n->count < 0) return fail(e, YKPRED_E_INVALID, "set_nodes: bad argument");
   if (n->count > 0 && (!n->allocatable || !n->requested || !n->allowed_pods || !n->pod_count || !n->flags || !n->taint_bits ||
                        !n->label_bits))
@@ -647,6 +672,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
 
 int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t* n) {
   YK_SERIALISE(e);
+  if (e) e->tables_version++;
   if (!e || !n || n->count != 1) return fail(e, YKPRED_E_INVALID, "update_node: count must be 1");
   if (!e->nodes_set || idx < 0 || idx >= e->N) return fail(e, YKPRED_E_INVALID, "update_node: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -680,6 +706,7 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
 
 int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   YK_SERIALISE(e);
+  if (e) e->tables_version++;
   if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
   if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
     return fail(e, YKPRED_E_INVALID, "set_specs: null column");
@@ -815,6 +842,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
 
 int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* p) {
   YK_SERIALISE(e);
+  if (e) e->tables_version++;
   if (!e || !p || p->count < 0) return fail(e, YKPRED_E_INVALID, "set_pods: bad argument");
   if (p->count > 0 && (!p->spec_index || !p->node_name_index)) return fail(e, YKPRED_E_INVALID, "set_pods: null column");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -884,13 +912,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
   const int nblk_nodes = (N + ykk::kBlock - 1) / ykk::kBlock;
 
+  // Everything below only ENQUEUES work (kernels, memsets, cross-stream events) on `st` / the decision stream, so one pass
+  // can be captured into a hipGraph. Returns 1 when the pass ends early (histograms only, per-pair kernel).
+  auto enqueue = [&]() -> int {
   if (spread_on || (a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY)) {
     const bool ready = a->options & YKPRED_EVAL_SPREAD_COUNTS_READY, only = a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY;
     TRY(run_spread_prefilter(e, st, &tm, !ready, !only));
-    if (only) {
-      tm.done(st);
-      return YKPRED_OK;
-    }
+    if (only) return 1;
   }
   if (a->options & YKPRED_EVAL_DIRECT) {
     ykk::SpecTable stbl = spec_table(e);
@@ -900,8 +928,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                        filt, bitmap, e->row_words, e->row_stride);
     tm.end(st, "k_direct");
     HIPCHK(hipGetLastError());
-    tm.done(st);
-    return YKPRED_OK;
+    return 1;
   }
 
   const unsigned wgroups = (unsigned)((e->row_words + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock);
@@ -1076,6 +1103,62 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     tm.end(st, "k_scatter");
   }
   HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+  };
+  const bool graphable = !tm.on && !e->graph_disabled && !(a->options & (YKPRED_EVAL_DIRECT | YKPRED_EVAL_SPREAD_COUNT_ONLY));
+  hipGraphExec_t exec = nullptr;
+  if (graphable) {
+    ykpred_engine::GraphKey key{e->tables_version, pre, filt, a->options, (void*)bitmap, e->last_counts, e->last_decisions, e->last_keys};
+    for (size_t i = 0; i < e->graphs.size();) {
+      if (e->graphs[i].first.version != e->tables_version) {
+        (void)hipGraphExecDestroy(e->graphs[i].second);
+        e->graphs.erase(e->graphs.begin() + (long)i);
+      } else {
+        if (e->graphs[i].first == key) exec = e->graphs[i].second;
+        ++i;
+      }
+    }
+    bool repeated = false;
+    for (size_t i = 0; i < e->seen.size();) {
+      if (e->seen[i].version != e->tables_version) {
+        e->seen.erase(e->seen.begin() + (long)i);
+        continue;
+      }
+      repeated = repeated || e->seen[i] == key;
+      ++i;
+    }
+    if (!repeated && e->seen.size() < 8) e->seen.push_back(key);
+    if (!exec && repeated) {
+      hipGraph_t g = nullptr;
+      int crc = YKPRED_E_DEVICE;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        crc = enqueue();
+        if (hipStreamEndCapture(st, &g) != hipSuccess) crc = YKPRED_E_DEVICE;
+      }
+      if (crc == YKPRED_OK && g && hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess) {
+        if (e->graphs.size() >= 8) {
+          (void)hipGraphExecDestroy(e->graphs.front().second);
+          e->graphs.erase(e->graphs.begin());
+        }
+        e->graphs.emplace_back(key, exec);
+      } else {
+        exec = nullptr;
+        e->graph_disabled = true;  // plain launches from now on
+        (void)hipGetLastError();
+      }
+      if (g) (void)hipGraphDestroy(g);
+    }
+  }
+  if (exec) {
+    HIPCHK(hipGraphLaunch(exec, st));
+  } else {
+    int rc = enqueue();
+    if (rc < 0) return rc;
+    if (rc == 1) {
+      tm.done(st);
+      return YKPRED_OK;
+    }
+  }
   tm.done(st);
   e->last_pre = pre;
   e->last_filt = filt;
@@ -1151,6 +1234,7 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
 int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t count, const int32_t* rows, const int32_t* spec_index,
                            const int32_t* node_name_index) {
   YK_SERIALISE(e);
+  if (e) e->tables_version++;
   if (!e || num_pods_after < 0 || count < 0 || (count > 0 && (!rows || !spec_index || !node_name_index)))
     return fail(e, YKPRED_E_INVALID, "update_pods: bad argument");
   if (!e->pods_set || !e->specs_set) return fail(e, YKPRED_E_STATE, "update_pods: ykpred_set_specs and ykpred_set_pods come first");
