@@ -187,7 +187,7 @@ struct ykpred_engine {
   std::vector<GraphKey> seen;  // a pass is captured the SECOND time it is asked for unchanged: one-off passes (after every
                                // table change of the incremental path) never pay for capture + instantiation
   uint64_t tables_version = 1;
-  bool graph_disabled = false;  // YKPRED_NO_GRAPH=1, or a capture failed once: plain launches from then on
+  bool graph_disabled = true;   // opt-in (cfg.reserved[3] == 1 / YKPRED_GRAPH=1); also set when a capture failed once
 
   // --- timing: one (start, stop) event pair per kernel, recorded on the stream the kernel is launched on
   hipEvent_t ev[2 * YKPRED_MAX_TIMED_KERNELS + 2]{};
@@ -571,7 +571,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->chunk_sorted = cfg->reserved[1] != 1;
   if (cfg->reserved[2] > 0 && cfg->reserved[2] <= 160 * 1024) e->combine_lds_bytes = cfg->reserved[2];
   if (cfg->reserved[2] < 0) e->combine_lds_bytes = 0;
-  if (cfg->reserved[3] == 1) e->graph_disabled = true;  // tunable: plain launches instead of hipGraph replay
+  e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(s);

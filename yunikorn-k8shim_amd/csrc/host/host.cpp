@@ -165,7 +165,7 @@ int recreate_engine(ykhost* h) {
   if (const char* v = getenv("YKPRED_CHUNK_MEMBERS")) c.reserved[0] = atoi(v);
   if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
   if (const char* v = getenv("YKPRED_COMBINE_LDS")) c.reserved[2] = atoi(v);
-  if (const char* v = getenv("YKPRED_NO_GRAPH")) c.reserved[3] = atoi(v);
+  if (const char* v = getenv("YKPRED_GRAPH")) c.reserved[3] = atoi(v);
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;
