@@ -119,7 +119,10 @@ def main():
     nbuf = 2 if world > 1 else 1
     outs = [(torch.empty(P, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.int32, device=dev),
              torch.empty(P, dtype=torch.int64, device=dev)) for _ in range(nbuf)]
-    stream = torch.cuda.current_stream(dev)
+    # A dedicated (non-default) stream: the engine launches on the stream it is handed, and handle 0 — torch's default
+    # stream — would mean "use the engine's own stream", which the events below could not order against.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
     exchanged = [torch.cuda.Event() for _ in range(nbuf)]  # exchange that last used buffer set b has finished
     step_no = [0]
