@@ -132,6 +132,15 @@ struct Pod {
   std::vector<PodAffinityTerm> pod_affinity, pod_anti_affinity;  // requiredDuringSchedulingIgnoredDuringExecution
   bool terminating = false;  // metadata.deletionTimestamp set
   std::string phase;
+  // KEP-1287 in-place resize inputs of computeContainerResource (resource.go:110-127): status.containerStatuses and
+  // status.initContainerStatuses by container name, and "the pending resize is infeasible" (isResizeInfeasible :132-142)
+  struct ContainerStatus {
+    StrMap allocated;        // allocatedResources
+    bool has_resources = false;
+    StrMap resources_requests;  // resources.requests
+  };
+  std::map<std::string, ContainerStatus> container_status;
+  bool resize_infeasible = false;
 };
 struct Node {
   std::string name;
@@ -183,15 +192,27 @@ static bool is_supported_pod_level(const std::string& n) {  // resourcehelper.Is
 
 // Pod request vector. Follows resource.go:56-109 (GetPodResource) minus the YuniKorn-only "pods":1 entry
 // (:58), i.e. upstream PodRequests — equality of the two is asserted by resource_test.go:201-202,219-220.
-// Container status / in-place-resize inputs (:113-142) are not part of the snapshot format, so
-// computeContainerResource reduces to the spec requests.
+// computeContainerResource (:110-127): max(spec requests, status allocatedResources, status resources.requests) per
+// resource, unless the pending resize is infeasible — then the status requests stand.
+static ResMap container_requests(const Pod& p, const Container& c) {
+  ResMap combined;
+  res_update_max(combined, get_resource(c.requests));
+  auto it = p.container_status.find(c.name);
+  if (it != p.container_status.end()) {
+    const Pod::ContainerStatus& st = it->second;
+    if (p.resize_infeasible && st.has_resources) return get_resource(st.resources_requests);
+    res_update_max(combined, get_resource(st.allocated));
+    if (st.has_resources) res_update_max(combined, get_resource(st.resources_requests));
+  }
+  return combined;
+}
 static ResMap pod_requests(const Pod& p) {
   ResMap total;
-  for (auto& c : p.containers) res_add(total, get_resource(c.requests));  // :74-76
+  for (auto& c : p.containers) res_add(total, container_requests(p, c));  // :74-76
   if (!p.init_containers.empty()) {                                      // :81-83 → checkInitContainerRequest :164-182
     ResMap init_max, sidecars;
     for (auto& c : p.init_containers) {
-      ResMap ic = get_resource(c.requests);
+      ResMap ic = container_requests(p, c);
       ResMap cur = ic;
       res_add(cur, sidecars);
       if (c.sidecar) res_add(sidecars, ic);
@@ -532,7 +553,24 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
     p->labels = read_strmap(md->get_nn("labels"));
     p->terminating = md->get_nn("deletionTimestamp") != nullptr;
   }
-  if (const mj::Value* st = v.get_nn("status")) p->phase = st->str_or("phase", "");
+  if (const mj::Value* st = v.get_nn("status")) {
+    p->phase = st->str_or("phase", "");
+    for (const char* field : {"containerStatuses", "initContainerStatuses"})  // resource.go:65-71: one map, init statuses last
+      if (const mj::Value* css = st->get_nn(field))
+        for (auto& cs : css->arr) {
+          Pod::ContainerStatus out;
+          out.allocated = read_strmap(cs->get_nn("allocatedResources"));
+          if (const mj::Value* r = cs->get_nn("resources")) {
+            out.has_resources = true;
+            out.resources_requests = read_strmap(r->get_nn("requests"));
+          }
+          p->container_status[cs->str_or("name", "")] = std::move(out);
+        }
+    p->resize_infeasible = st->str_or("resize", "") == "Infeasible";  // v1.PodResizeStatusInfeasible
+    if (const mj::Value* conds = st->get_nn("conditions"))
+      for (auto& c : conds->arr)
+        if (c->str_or("type", "") == "PodResizePending" && c->str_or("reason", "") == "Infeasible") p->resize_infeasible = true;
+  }
   const mj::Value* spec = v.get_nn("spec");
   if (!spec) return p;
   p->node_name = spec->str_or("nodeName", "");

@@ -405,6 +405,72 @@ def request_cases():
         {"name": "pod-level requests override cpu/memory only", "source": f"{RT}:614-620",
          "pod": pod({"containers": [c1, c2], "resources": {"requests": {"memory": "128M", "cpu": "5", "invalid": "1"}}}),
          "expect": {"cpu": 5000, "memory": 128 * M, gpu: 5}},
+    ] + resize_cases() + [
+        # TestBestEffortPod (:746-788) and TestGPUOnlyResources (:790-832): zero-valued requests stay in the map
+        {"name": "best effort pod", "source": f"{RT}:772-774", "pod": pod({"containers": [container("container-01", {})]}), "expect": {}},
+        {"name": "cpu only", "source": f"{RT}:779-782", "pod": pod({"containers": [container("container-01", {"cpu": "1"})]}),
+         "expect": {"cpu": 1000}},
+        {"name": "explicit zero cpu and memory", "source": f"{RT}:784-791",
+         "pod": pod({"containers": [container("container-01", {"memory": "0", "cpu": "0"})]}), "expect": {"cpu": 0, "memory": 0}},
+        {"name": "gpu only", "source": f"{RT}:818-821", "pod": pod({"containers": [container("container-01", {gpu: "1"})]}),
+         "expect": {gpu: 1}},
+        {"name": "gpu only, zero", "source": f"{RT}:823-827", "pod": pod({"containers": [container("container-01", {gpu: "0"})]}),
+         "expect": {gpu: 0}},
+    ]
+
+
+def resize_cases():
+    """TestGetPodResourcesWithInPlacePodVerticalScaling (resource_test.go:624-744): KEP-1287 in-place resize. One pod walks
+    through the states of a resize; every step asserts cpu (milli) and memory."""
+    M = 1000 * 1000
+    before = [{"memory": "1000M", "cpu": "1"}, {"memory": "2000M", "cpu": "2"}]
+    after = [{"memory": "2000M", "cpu": "500m"}, {"memory": "4000M", "cpu": "1"}]
+    names = ["container-01", "container-02"]
+
+    def make(requests, statuses=None, resize=None, conditions=None):
+        p = pod({"containers": [container(n, dict(r)) for n, r in zip(names, requests)]}, name="pod-resource-test-00001", uid="UID-00001")
+        st = {}
+        if statuses is not None:
+            st["containerStatuses"] = statuses
+        if resize is not None:
+            st["resize"] = resize
+        if conditions is not None:
+            st["conditions"] = conditions
+        if st:
+            p["status"] = st
+        return p
+
+    def status(allocated, resources):
+        out = []
+        for n, a, r in zip(names, allocated, resources):
+            cs = {"name": n}
+            if a is not None:
+                cs["allocatedResources"] = dict(a)
+            if r is not None:
+                cs["resources"] = {"requests": dict(r)}
+            out.append(cs)
+        return out
+
+    running = status(before, before)
+    pending = [{"type": "PodResizePending", "status": "True", "reason": "Infeasible"}]
+    return [
+        {"name": "resize: no container statuses", "source": f"{RT}:664-668", "pod": make(before), "expect": {"cpu": 3000, "memory": 3000 * M}},
+        {"name": "resize: empty container statuses", "source": f"{RT}:670-675", "pod": make(before, []), "expect": {"cpu": 3000, "memory": 3000 * M}},
+        {"name": "resize: statuses without resources", "source": f"{RT}:677-685", "pod": make(before, status([None, None], [None, None])),
+         "expect": {"cpu": 3000, "memory": 3000 * M}},
+        {"name": "resize: running, status equals spec", "source": f"{RT}:687-695", "pod": make(before, running),
+         "expect": {"cpu": 3000, "memory": 3000 * M}},
+        {"name": "resize: proposed (memory up, cpu down)", "source": f"{RT}:697-706", "pod": make(after, running, resize=""),
+         "expect": {"cpu": 3000, "memory": 6000 * M}},
+        {"name": "resize: infeasible (status.resize)", "source": f"{RT}:708-713", "pod": make(after, running, resize="Infeasible"),
+         "expect": {"cpu": 3000, "memory": 3000 * M}},
+        {"name": "resize: infeasible (PodResizePending condition)", "source": f"{RT}:715-721",
+         "pod": make(after, running, resize="", conditions=pending), "expect": {"cpu": 3000, "memory": 3000 * M}},
+        {"name": "resize: in progress (allocated = new spec)", "source": f"{RT}:723-731",
+         "pod": make(after, status(after, before), resize="InProgress", conditions=[{"type": "PodResizing", "status": "True"}]),
+         "expect": {"cpu": 3000, "memory": 6000 * M}},
+        {"name": "resize: completed", "source": f"{RT}:733-741", "pod": make(after, status(after, after), resize="", conditions=[]),
+         "expect": {"cpu": 1500, "memory": 6000 * M}},
     ]
 
 

@@ -567,6 +567,49 @@ class TemplatePool {
   std::vector<PodTemplate*> order_;
 };
 
+// KEP-1287 in-place resize (resource.go:110-142, computeContainerResource / isResizeInfeasible): a container that has a
+// status entry counts with max(spec requests, status.allocatedResources, status.resources.requests) per resource, or —
+// when the pending resize is infeasible — with the status requests alone. The template stores that effective request
+// (cpu as "<milli>m", everything else as its integer Value()), so interning, dumps and the encoder see one plain spec.
+inline void fold_container_statuses(const mj::Value& pod, PodTemplate* t) {
+  const mj::Value* st = pod.get_nn("status");
+  if (!st) return;
+  bool infeasible = st->str_or("resize", "") == "Infeasible";
+  if (const mj::Value* conds = st->get_nn("conditions"))
+    for (auto& c : conds->arr)
+      if (c->str_or("type", "") == "PodResizePending" && c->str_or("reason", "") == "Infeasible") infeasible = true;
+  std::map<std::string, const mj::Value*> by_name;  // containerStatuses first, initContainerStatuses override (:65-71)
+  for (const char* field : {"containerStatuses", "initContainerStatuses"})
+    if (const mj::Value* css = st->get_nn(field))
+      for (auto& cs : css->arr) by_name[cs->str_or("name", "")] = cs.get();
+  if (by_name.empty()) return;
+  auto upmax = [](ResMap& l, const ResMap& r) {
+    for (auto& kv : r) {
+      auto it = l.find(kv.first);
+      if (it == l.end())
+        l[kv.first] = kv.second;
+      else if (kv.second > it->second)
+        it->second = kv.second;
+    }
+  };
+  for (auto* list : {&t->containers, &t->init_containers})
+    for (Container& c : *list) {
+      auto it = by_name.find(c.name);
+      if (it == by_name.end()) continue;
+      const mj::Value* res = it->second->get_nn("resources");
+      ResMap combined;
+      if (infeasible && res) {
+        combined = get_resource(read_strmap(res->get_nn("requests")));
+      } else {
+        upmax(combined, get_resource(c.requests));
+        upmax(combined, get_resource(read_strmap(it->second->get_nn("allocatedResources"))));
+        if (res) upmax(combined, get_resource(read_strmap(res->get_nn("requests"))));
+      }
+      c.requests.clear();
+      for (auto& kv : combined) c.requests[kv.first] = std::to_string(kv.second) + (kv.first == "cpu" ? "m" : "");
+    }
+}
+
 inline PodTemplate read_template(const mj::Value& v) {
   PodTemplate t;
   if (const mj::Value* md = v.get_nn("metadata")) {
@@ -618,6 +661,7 @@ inline PodTemplate read_template(const mj::Value& v) {
       t.tolerations.push_back({x->str_or("key", ""), x->str_or("operator", ""), x->str_or("value", ""), x->str_or("effect", "")});
   t.containers = read_containers(spec->get_nn("containers"), false);
   t.init_containers = read_containers(spec->get_nn("initContainers"), true);
+  fold_container_statuses(v, &t);
   if (const mj::Value* oh = spec->get_nn("overhead")) {
     t.has_overhead = true;
     t.overhead = read_strmap(oh);
