@@ -481,7 +481,7 @@ QUANTITIES = [
     ("1Gi", 1073741824, 1073741824000), ("256Gi", 274877906944, 274877906944000), ("128Mi", 134217728, 134217728000),
     ("1Ki", 1024, 1024000), ("1k", 1000, 1000000), ("1e3", 1000, 1000000), ("1E3", 1000, 1000000), ("1E", 10**18, 9223372036854775807),
     ("1.5Gi", 1610612736, 1610612736000), ("0", 0, 0), ("32", 32, 32000), ("110", 110, 110000), ("1u", 1, 1), ("1n", 1, 1),
-    ("1500u", 1, 2), ("0.0001", 1, 1), ("12e-1", 2, 1200),
+    ("1500u", 1, 2), ("0.0001", 1, 1), ("12e-1", 2, 1200), ("14500m", 15, 14500), ("1G", 10**9, 10**12), ("1000M", 10**9, 10**12),
 ]
 
 

@@ -147,3 +147,11 @@ def test_spread_rules():
     # Filter enabled without its PreFilter: Error status ⇒ does not fit
     o = orc.Oracle({"nodes": nodes[:2], "pods": [_spread_pod(selector=sel)]})
     assert not o.predicates(0, 1, 0, SPREAD)[0]
+
+
+def test_node_resource_conversion():
+    """TestNodeResource (pkg/common/resource_test.go:833-841): allocatable cpu "14500m" is 14500 milli-cores; memory and
+    pods go through Value() (resource.go:273-285)."""
+    node = {"metadata": {"name": "n"}, "status": {"allocatable": {"cpu": "14500m", "memory": "1Gi", "pods": "110"}}}
+    info = orc.Oracle({"nodes": [node], "pods": []}).node_info(0)
+    assert info["alloc"][:2] == [14500, 1 << 30] and info["allowed_pods"] == 110
