@@ -64,6 +64,17 @@ int32_t ykhost_forget_pod(ykhost_t* h, const char* uid);
 int32_t ykhost_pod_state(ykhost_t* h, const char* uid, char* node_out, int32_t node_len);
 int32_t ykhost_node_pod_count(ykhost_t* h, const char* node_name); /* len(NodeInfo.Pods), -1 = unknown node */
 
+/* Gang scheduling. `task_groups_json` is the value of the pod annotation yunikorn.apache.org/task-groups (TaskGroup schema,
+ * /root/reference/pkg/cache/amprotocol.go:47-57). ykhost_validate_task_groups restates GetTaskGroupsFromAnnotation +
+ * validateTaskGroupResources (pkg/cache/utils.go:33-121: name / minMember / minResource present, no negative quantity, no
+ * int64 overflow of minMember x minResource or of the cross-group aggregate, no cpu/vcore or explicit-"pods" collision) →
+ * number of groups, negative = rejected (reason in ykhost_last_error). ykhost_add_task_groups also creates the minMember
+ * placeholder pods of every group as pending asks, built like newPlaceholder (pkg/cache/placeholder.go:40-157): identical
+ * labels (+ app id, queue), requests = minResource, nodeSelector, tolerations, affinity, topologySpreadConstraints — one
+ * pod class per group. `app_json`: {"applicationId", "queue", "namespace"}. → number of placeholders created. */
+int32_t ykhost_validate_task_groups(ykhost_t* h, const char* task_groups_json);
+int32_t ykhost_add_task_groups(ykhost_t* h, const char* app_json, const char* task_groups_json);
+
 /* synthetic KWOK-style cluster, replaces all state */
 typedef struct ykhost_kwok {
   uint64_t seed;

@@ -329,6 +329,29 @@ def test_kwok_gang_placeholders_share_rows(pm):
     assert np.array_equal(unpack(bm[0:4000:37], lay.num_nodes), want)
 
 
+def test_task_group_placeholders_are_one_class_per_group(pm):
+    """configs[3] shape from the real input: the task-groups annotation (pkg/cache/amprotocol.go:47-57) expands into
+    minMember identical placeholder asks per group (placeholder.go:40-157) = one pod class, one plane set, shared rows."""
+    snap = _gen.random_snapshot(4321, n_nodes=150, n_pods=10, scalars=False)
+    pm.load_snapshot(snap)
+    groups = [{"name": f"tg-{k}", "minMember": 40 + k, "minResource": {"cpu": f"{250 * (k + 1)}m", "memory": f"{64 * (k + 1)}Mi"},
+               "tolerations": [{"operator": "Exists"}] if k % 2 else [],
+               "nodeSelector": ({"kubernetes.io/os": "linux"} if k == 2 else {})} for k in range(4)]
+    before = pm.num_pods
+    pm.evaluate()
+    classes_before = pm.layout().num_classes
+    assert pm.add_task_groups("spark-app-0001", "root.batch", "default", groups) == sum(g["minMember"] for g in groups)
+    # known dictionaries but new templates: everything is re-encoded once; afterwards the group members share classes
+    pm.evaluate()
+    assert pm.layout().num_classes <= classes_before + len(groups)
+    bm = pm.read_bitmap()
+    row = before
+    for g in groups:
+        assert (bm[row:row + g["minMember"]] == bm[row]).all()
+        row += g["minMember"]
+    _compare_with_mirror_dump(pm, decisions=True)
+
+
 def _compare_live_rows(pm, snap_now, decisions=False):
     """Rows of the asks that are still pending (assumed asks keep their row but are skipped) against the oracle."""
     o = orc.Oracle(snap_now)

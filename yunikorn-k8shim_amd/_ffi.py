@@ -122,6 +122,8 @@ def load_ykhost():
                "ykhost_forget_pod"):
         getattr(L, fn).argtypes = [C.c_void_p, C.c_char_p]
     L.ykhost_assume_pod.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.ykhost_validate_task_groups.argtypes = [C.c_void_p, C.c_char_p]
+    L.ykhost_add_task_groups.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.ykhost_pod_state.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32]
     L.ykhost_node_pod_count.argtypes = [C.c_void_p, C.c_char_p]
     L.ykhost_generate_kwok.argtypes = [C.c_void_p, C.POINTER(YkhostKwok)]

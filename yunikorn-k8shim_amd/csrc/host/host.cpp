@@ -10,7 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <limits>
+#include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -75,6 +78,7 @@ struct ykhost {
   std::vector<int> eval_dirty_rows;   // bitmap rows changed since the last evaluation
   bool table_shrunk = false;          // the ask table lost rows at its end since the last upload
   bool decisions_stale = true;        // something was (re)evaluated without decisions since they were last produced
+  uint64_t placeholder_serial = 0;    // nonce source of generated placeholder names
   // answers of one ask against every node (ykpred_query_pod), so that the core's per-node Predicates() callbacks of a
   // scheduling attempt are served from host memory; dropped whenever any table changes
   struct AskAnswers {
@@ -923,24 +927,173 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
 // Ask table: an unassigned, not yet running pod is a pending ask and holds a row; a pod that arrives with a
 // spec.nodeName of its own was bound by the cluster and holds none. A pod that already holds a row keeps it (in place)
 // while it is neither running nor terminated, so that rows stay stable while binds are in flight.
+static int update_pod_value(ykhost* h, const mj::Value& v) {
+  ensure_uid_index(h);
+  size_t anon = h->pod_store.size();
+  Pod* p = add_pod_object(h, v, &anon);
+  std::string phase;
+  if (const mj::Value* st = v.get_nn("status")) phase = st->str_or("phase", "");
+  const bool running = phase == "Running";                           // utils.IsPodRunning (utils.go:89-91)
+  const bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated (:93-95)
+  auto it = h->by_uid.find(p->uid);
+  Pod* old = it == h->by_uid.end() ? nullptr : it->second;
+  const bool bound_by_cluster = !p->node_name.empty();
+  const bool ok = cache_update_pod(h, old, p, running, terminated);
+  const bool wants_row = !terminated && !running && (old && old->ask ? true : !bound_by_cluster);
+  set_ask_row(h, old, wants_row ? p : nullptr);
+  return ok ? 1 : 0;
+}
 int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json) {
   YKHOST_LOCKED(h);
   try {
     mj::ValuePtr v = mj::parse(pod_json);
-    ensure_uid_index(h);
-    size_t anon = h->pod_store.size();
-    Pod* p = add_pod_object(h, *v, &anon);
-    std::string phase;
-    if (const mj::Value* st = v->get_nn("status")) phase = st->str_or("phase", "");
-    const bool running = phase == "Running";                           // utils.IsPodRunning (utils.go:89-91)
-    const bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated (:93-95)
-    auto it = h->by_uid.find(p->uid);
-    Pod* old = it == h->by_uid.end() ? nullptr : it->second;
-    const bool bound_by_cluster = !p->node_name.empty();
-    const bool ok = cache_update_pod(h, old, p, running, terminated);
-    const bool wants_row = !terminated && !running && (old && old->ask ? true : !bound_by_cluster);
-    set_ask_row(h, old, wants_row ? p : nullptr);
-    return ok ? 1 : 0;
+    return update_pod_value(h, *v);
+  } catch (const std::exception& e) {
+    return fail(h, e.what());
+  }
+}
+
+// ---- gang scheduling: task groups → placeholder asks ----------------------------------------------------------
+// GetTaskGroupsFromAnnotation + validateTaskGroupResources (pkg/cache/utils.go:33-121). Returns "" when the annotation
+// value is acceptable, else the reason it is rejected.
+static std::string validate_task_groups(const mj::Value& groups) {
+  if (!groups.is_arr()) return "task-groups annotation is not a JSON array";
+  const int64_t kMax = std::numeric_limits<int64_t>::max();
+  std::map<std::string, int64_t> totals;
+  for (auto& g : groups.arr) {
+    if (!g->is_obj()) return "task group is not an object";
+    const mj::Value* name = g->get_nn("name");
+    if (name && !name->is_str()) return "taskGroup name is not a string";
+    if (!name || name->s.empty()) return "can't get taskGroup Name from pod annotation";
+    const mj::Value* mm = g->get_nn("minMember");
+    if (mm && !mm->is_num()) return "taskGroup minMember is not a number";
+    const mj::Value* mr = g->get_nn("minResource");
+    if (!mr) return "can't get taskGroup MinResource from pod annotation";
+    if (!mr->is_obj()) return "taskGroup minResource is not an object";
+    const int64_t members = mm ? std::strtoll(mm->s.c_str(), nullptr, 10) : 0;
+    if (mm && (mm->s.find_first_of(".eE") != std::string::npos || members > std::numeric_limits<int32_t>::max() ||
+               members < std::numeric_limits<int32_t>::min()))
+      return "taskGroup minMember is not an int32";
+    if (members == 0) return "can't get taskGroup MinMember from pod annotation";
+    if (members < 0) return "minMember cannot be negative";
+    // validateTaskGroupResources (:79-121): the placeholder ask of the group, folded into the cross-group totals under
+    // canonical keys ("cpu" → "vcore" in milli-units; the implicit "pods" count claims its key)
+    std::set<std::string> seen{"pods"};
+    if (totals["pods"] > kMax - members) return "aggregate placeholder request for \"pods\" overflows int64 across taskGroups";
+    totals["pods"] += members;
+    for (auto& kv : mr->obj) {
+      if (!kv.second->is_str() && !kv.second->is_num()) return "minResource " + kv.first + " is not a quantity";
+      Quantity q = parse_quantity(kv.second->s);
+      if (!q.ok) return "minResource " + kv.first + " is not a quantity";
+      if (q.mant < 0) return "minResource \"" + kv.first + "\" in taskGroup \"" + name->s + "\" cannot be negative";
+      const bool cpu = kv.first == "cpu";
+      const std::string canonical = cpu ? "vcore" : kv.first;
+      if (!seen.insert(canonical).second)
+        return "minResource \"" + kv.first + "\" in taskGroup \"" + name->s + "\" collides with another resource under canonical key \"" + canonical + "\"";
+      if (quantity_cmp_int64(q, kMax / (members * (cpu ? 1000 : 1))) > 0)
+        return "minResource \"" + kv.first + "\" in taskGroup \"" + name->s + "\" overflows int64 when scaled by minMember";
+      const int64_t contribution = members * scaled_value(q, cpu ? -3 : 0);
+      if (totals[canonical] > kMax - contribution) return "aggregate placeholder request for \"" + canonical + "\" overflows int64 across taskGroups";
+      totals[canonical] += contribution;
+    }
+  }
+  return "";
+}
+
+int32_t ykhost_validate_task_groups(ykhost_t* h, const char* task_groups_json) {
+  YKHOST_LOCKED(h);
+  try {
+    mj::ValuePtr groups = mj::parse(task_groups_json);
+    std::string why = validate_task_groups(*groups);
+    if (!why.empty()) return fail(h, why);
+    return (int32_t)groups->arr.size();
+  } catch (const std::exception& e) {
+    return fail(h, e.what());
+  }
+}
+
+// PlaceholderManager.createAppPlaceholders + newPlaceholder (placeholder_manager.go:72-99, placeholder.go:40-157): every
+// task group yields minMember placeholder pods with IDENTICAL scheduling-relevant fields — labels (the group's + app id +
+// queue), one container whose requests are the group's minResource, nodeSelector, tolerations, affinity and
+// topologySpreadConstraints — i.e. one pod class per group. They enter the cache like any pending pod.
+int32_t ykhost_add_task_groups(ykhost_t* h, const char* app_json, const char* task_groups_json) {
+  YKHOST_LOCKED(h);
+  try {
+    mj::ValuePtr app = mj::parse(app_json);
+    mj::ValuePtr groups = mj::parse(task_groups_json);
+    std::string why = validate_task_groups(*groups);
+    if (!why.empty()) return fail(h, why);
+    const std::string app_id = app->str_or("applicationId", ""), queue = app->str_or("queue", ""), ns = app->str_or("namespace", "");
+    auto mk = [](mj::Kind k) {
+      auto v = std::make_shared<mj::Value>();
+      v->kind = k;
+      return v;
+    };
+    auto str = [&](const std::string& s) {
+      auto v = mk(mj::Kind::String);
+      v->s = s;
+      return v;
+    };
+    auto child = [](const mj::Value& o, const char* key) -> mj::ValuePtr {
+      for (auto& kv : o.obj)
+        if (kv.first == key && !kv.second->is_null()) return kv.second;
+      return nullptr;
+    };
+    int created = 0;
+    for (auto& g : groups->arr) {
+      const std::string tg = g->str_or("name", "");
+      auto labels = mk(mj::Kind::Object);
+      if (auto l = child(*g, "labels")) labels->obj = l->obj;
+      auto set_label = [&](const std::string& k, const std::string& v) {  // utils.MergeMaps: the app's entries win
+        for (auto& kv : labels->obj)
+          if (kv.first == k) {
+            kv.second = str(v);
+            return;
+          }
+        labels->obj.emplace_back(k, str(v));
+      };
+      set_label("yunikorn.apache.org/app-id", app_id);
+      set_label("yunikorn.apache.org/queue", queue);
+      auto requests = mk(mj::Kind::Object);  // GetPlaceholderResourceRequests (gang_utils.go:83-92): empty names dropped
+      for (auto& kv : g->get_nn("minResource")->obj)
+        if (!kv.first.empty()) requests->obj.emplace_back(kv.first, kv.second);
+      auto resources = mk(mj::Kind::Object);
+      resources->obj.emplace_back("requests", requests);
+      resources->obj.emplace_back("limits", requests);
+      auto container = mk(mj::Kind::Object);
+      container->obj.emplace_back("name", str("pause"));
+      container->obj.emplace_back("resources", resources);
+      auto containers = mk(mj::Kind::Array);
+      containers->arr.push_back(container);
+      auto spec = mk(mj::Kind::Object);
+      spec->obj.emplace_back("containers", containers);
+      for (const char* field : {"nodeSelector", "tolerations", "affinity", "topologySpreadConstraints"})
+        if (auto v = child(*g, field)) spec->obj.emplace_back(field, v);
+      const int64_t members = g->int_or("minMember", 0);
+      for (int64_t i = 0; i < members; ++i) {
+        // GeneratePlaceholderName (gang_utils.go:61-67): "tg-%.28s-%.20s-<10 base-36 chars>"; the nonce is drawn from a
+        // per-handle counter here so that runs are reproducible
+        uint64_t z = (h->placeholder_serial++ + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+        z ^= z >> 29;
+        std::string nonce;
+        for (int k = 0; k < 10; ++k) {
+          nonce.push_back("abcdefghijklmnopqrstuvwxyz0123456789"[z % 36]);
+          z = z / 36 + (z << 7);
+        }
+        const std::string pname = "tg-" + app_id.substr(0, 28) + "-" + tg.substr(0, 20) + "-" + nonce;
+        auto meta = mk(mj::Kind::Object);
+        meta->obj.emplace_back("name", str(pname));
+        meta->obj.emplace_back("uid", str(pname));
+        meta->obj.emplace_back("namespace", str(ns));
+        meta->obj.emplace_back("labels", labels);
+        auto pod = mk(mj::Kind::Object);
+        pod->obj.emplace_back("metadata", meta);
+        pod->obj.emplace_back("spec", spec);
+        update_pod_value(h, *pod);
+        ++created;
+      }
+    }
+    return created;
   } catch (const std::exception& e) {
     return fail(h, e.what());
   }

@@ -129,6 +129,45 @@ inline int64_t scaled_value(const Quantity& q, int scale10) {
   return neg ? -v : v;
 }
 
+// Exact sign of (q − bound): resource.Quantity.CmpInt64 (no rounding, no saturation).
+inline int quantity_cmp_int64(const Quantity& q, int64_t bound) {
+  if (!q.ok) return 0;
+  if (q.mant == 0) return bound > 0 ? -1 : (bound < 0 ? 1 : 0);
+  const bool neg = q.mant < 0;
+  if (neg != (bound < 0)) return neg ? -1 : 1;  // different signs (bound == 0 counts as non-negative)
+  __int128 m = neg ? -q.mant : q.mant;
+  __int128 b = bound < 0 ? -static_cast<__int128>(bound) : static_cast<__int128>(bound);
+  const __int128 lim = static_cast<__int128>(1) << 120;
+  int mag = 0;  // sign of (|q| − |bound|)
+  bool decided = false;
+  for (int i = 0; i < q.bin_shift && !decided; ++i) {
+    if (m >= lim / 2) {
+      mag = 1;
+      decided = true;
+    } else {
+      m *= 2;
+    }
+  }
+  for (int e = q.dec_exp; e > 0 && !decided; --e) {
+    if (m >= lim / 10) {
+      mag = 1;
+      decided = true;
+    } else {
+      m *= 10;
+    }
+  }
+  for (int e = q.dec_exp; e < 0 && !decided; ++e) {
+    if (b >= lim / 10) {
+      mag = -1;
+      decided = true;
+    } else {
+      b *= 10;
+    }
+  }
+  if (!decided) mag = m > b ? 1 : (m < b ? -1 : 0);
+  return neg ? -mag : mag;
+}
+
 inline int64_t quantity_value(const std::string& s) { return scaled_value(parse_quantity(s), 0); }
 inline int64_t quantity_milli(const std::string& s) { return scaled_value(parse_quantity(s), -3); }
 

@@ -116,6 +116,17 @@ class GpuPredicateManager:
         """SchedulerCache.ForgetPod: drops the assumed mark; the pod stays accounted on its node."""
         return bool(self._check(self._L.ykhost_forget_pod(self._h, uid.encode())))
 
+    def validate_task_groups(self, annotation):
+        """GetTaskGroupsFromAnnotation: number of task groups; raises RuntimeError with the reason when rejected."""
+        text = annotation if isinstance(annotation, str) else json.dumps(annotation)
+        return self._check(self._L.ykhost_validate_task_groups(self._h, text.encode()))
+
+    def add_task_groups(self, application_id, queue, namespace, annotation):
+        """Creates the minMember placeholder asks of every task group (newPlaceholder); returns how many."""
+        text = annotation if isinstance(annotation, str) else json.dumps(annotation)
+        app = json.dumps({"applicationId": application_id, "queue": queue, "namespace": namespace})
+        return self._check(self._L.ykhost_add_task_groups(self._h, app.encode(), text.encode()))
+
     def pod_state(self, uid):
         """Cache membership of a pod: None if not cached, else dict(node, assigned, assumed, orphan, ask)."""
         node = C.create_string_buffer(256)
