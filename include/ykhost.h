@@ -75,6 +75,20 @@ int32_t ykhost_node_pod_count(ykhost_t* h, const char* node_name); /* len(NodeIn
 int32_t ykhost_validate_task_groups(ykhost_t* h, const char* task_groups_json);
 int32_t ykhost_add_task_groups(ykhost_t* h, const char* app_json, const char* task_groups_json);
 
+/* The scheduler-interface callbacks as the core issues them — by allocation key (pod UID) and node id:
+ * Context.IsPodFitNode (/root/reference/pkg/cache/context.go:696-716) behind AsyncRMCallback.Predicates
+ * (pkg/cache/scheduler_callback.go:203-205). → 1 fit (err = ""), 0 does not fit (err = "failed plugin: '<name>'\n<message>",
+ * the errors.Join of :713), YKHOST_E_POD_NOT_FOUND / YKHOST_E_NODE_NOT_FOUND with the texts of ErrorPodNotFound /
+ * ErrorNodeNotFound (:66-69), YKHOST_E_NOT_AN_ASK for a cached pod that holds no ask row. */
+#define YKHOST_E_POD_NOT_FOUND (-10)
+#define YKHOST_E_NODE_NOT_FOUND (-11)
+#define YKHOST_E_NOT_AN_ASK (-12)
+int32_t ykhost_is_pod_fit_node(ykhost_t* h, const char* allocation_key, const char* node_id, int32_t allocate, char* err, int32_t err_len);
+/* Context.IsPodFitNodeViaPreemption (context.go:718-742) behind AsyncRMCallback.PreemptionPredicates
+ * (scheduler_callback.go:207-216): → Index, or -1 for {Success: false} (no prefix of victims helps, unknown ask or node). */
+int32_t ykhost_is_pod_fit_node_via_preemption(ykhost_t* h, const char* allocation_key, const char* node_id,
+                                              const char* const* preempt_allocation_keys, int32_t num_keys, int32_t start_index);
+
 /* synthetic KWOK-style cluster, replaces all state */
 typedef struct ykhost_kwok {
   uint64_t seed;

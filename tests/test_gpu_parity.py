@@ -133,6 +133,29 @@ def test_concurrent_readers(pm):
     assert not errors, errors[:5]
 
 
+def test_scheduler_interface_callbacks(pm):
+    """The callbacks as the core issues them (scheduler_callback.go:203-216 → context.go:696-742): allocation key + node id
+    in, error text / {Success, Index} out."""
+    node = {"metadata": {"name": "node-1"}, "status": {"allocatable": {"cpu": "1", "memory": "100M", "pods": "10"}},
+            "pods": [{"metadata": {"name": f"v{i}", "uid": f"v{i}"}, "spec": {"nodeName": "node-1", "containers": [
+                {"resources": {"requests": {"cpu": c, "memory": m}}}]}} for i, (c, m) in
+                enumerate([("100m", "1M"), ("100m", "1M"), ("300m", "3M"), ("500m", "5M")])]}
+    small = {"metadata": {"name": "small", "uid": "task-1"}, "spec": {"containers": [{"resources": {"requests": {"cpu": "500m", "memory": "5M"}}}]}}
+    none = {"metadata": {"name": "none", "uid": "task-0"}, "spec": {"containers": []}}
+    pm.load_snapshot({"nodes": [node], "pods": [small, none]})
+    assert pm.is_pod_fit_node("unknown", "node-1", True) == "predicates were not run because pod was not found in cache"
+    assert pm.is_pod_fit_node("task-1", "unknown", True) == "predicates were not run because node was not found in cache"
+    assert pm.is_pod_fit_node("task-0", "node-1", True) is None
+    err = pm.is_pod_fit_node("task-1", "node-1", True)  # 1000m used of 1000m
+    assert err.startswith("failed plugin: 'NodeResourcesFit'\n") and "Insufficient cpu" in err
+    assert pm.is_pod_fit_node("task-1", "node-1", False) is None  # reservation phase has no NodeResourcesFit
+    # TestPreemptionPredicates' node (predicate_manager_test.go:71-117) through the callback form
+    assert pm.is_pod_fit_node_via_preemption("task-1", "node-1", ["v0", "v1", "v2", "v3"], 1) == (2, True)
+    assert pm.is_pod_fit_node_via_preemption("task-1", "node-1", [], 0) == (-1, False)
+    assert pm.is_pod_fit_node_via_preemption("unknown", "node-1", ["v0"], 0) == (-1, False)
+    assert pm.is_pod_fit_node_via_preemption("task-1", "node-1", ["not-cached", "v3"], 0) == (1, True)  # unknown victim = nil pod
+
+
 # ------------------------------------------------------------------------------------------------------------
 # randomized edge-case clusters: full grid, both phases, bits + failing plugin
 # ------------------------------------------------------------------------------------------------------------

@@ -218,3 +218,16 @@ def test_request_vectors_on_cpu(cache, case):
     cache.load_snapshot({"nodes": [], "pods": [case["pod"]]})
     got = {k: v for k, v in cache.pod_request(0).items() if v != 0 or k in case["expect"]}
     assert got == case["expect"], case["source"]
+
+
+def test_callbacks_report_the_sentinel_errors(cache):
+    """AsyncRMCallback.Predicates / PreemptionPredicates for an unknown allocation key or node id
+    (scheduler_callback_test.go:484-513, context.go:66-69, 696-742): decided above the predicate manager, no device needed."""
+    cache.update_node(node(HOST1))
+    cache.update_pod(pod(POD1))
+    assert cache.is_pod_fit_node("unknown", HOST1, True) == "predicates were not run because pod was not found in cache"
+    assert cache.is_pod_fit_node(POD1, "unknown", True) == "predicates were not run because node was not found in cache"
+    assert cache.is_pod_fit_node_via_preemption("unknown", HOST1, [], 0) == (-1, False)
+    assert cache.is_pod_fit_node_via_preemption(POD1, "unknown", [POD1], 0) == (-1, False)
+    with pytest.raises(RuntimeError, match="mirror-only"):  # a known pair needs the engine
+        cache.is_pod_fit_node(POD1, HOST1, True)

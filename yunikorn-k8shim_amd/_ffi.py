@@ -144,6 +144,8 @@ def load_ykhost():
     L.ykhost_preemption_predicates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
     L.ykhost_preemption_predicates_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p),
                                                      C.c_void_p, C.c_void_p]
+    L.ykhost_is_pod_fit_node.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32]
+    L.ykhost_is_pod_fit_node_via_preemption.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
     L.ykhost_pod_request_json.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_stats.argtypes = [C.c_void_p, C.c_void_p]
     _host = L

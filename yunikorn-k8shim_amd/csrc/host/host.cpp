@@ -1444,6 +1444,50 @@ int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, con
   return rc ? -2 : out;
 }
 
+// Context.IsPodFitNode (context.go:696-716) behind AsyncRMCallback.Predicates (scheduler_callback.go:203-205): the core
+// names the ask by allocation key (= pod UID) and the node by id.
+int32_t ykhost_is_pod_fit_node(ykhost_t* h, const char* allocation_key, const char* node_id, int32_t allocate, char* err, int32_t err_len) {
+  YKHOST_LOCKED(h);
+  copy_out("", err, err_len);
+  ensure_uid_index(h);
+  auto it = h->by_uid.find(allocation_key ? allocation_key : "");
+  if (it == h->by_uid.end()) {
+    copy_out("predicates were not run because pod was not found in cache", err, err_len);  // ErrorPodNotFound (context.go:67)
+    return YKHOST_E_POD_NOT_FOUND;
+  }
+  auto nt = h->node_ix.find(node_id ? node_id : "");
+  if (nt == h->node_ix.end()) {
+    copy_out("predicates were not run because node was not found in cache", err, err_len);  // ErrorNodeNotFound (:68)
+    return YKHOST_E_NODE_NOT_FOUND;
+  }
+  if (!it->second->ask) {
+    copy_out("pod is cached but holds no row of the ask table (it is bound, not a pending ask)", err, err_len);
+    return fail(h, "pod holds no ask row", YKHOST_E_NOT_AN_ASK);
+  }
+  char plugin[64], msg[1024];
+  int rc = ykhost_predicates(h, it->second->row, nt->second, allocate, plugin, sizeof plugin, msg, sizeof msg);
+  if (rc < 0) {
+    copy_out(h->err, err, err_len);
+    return rc;
+  }
+  if (rc == 0) copy_out(std::string("failed plugin: '") + plugin + "'\n" + msg, err, err_len);  // errors.Join (:713)
+  return rc;
+}
+
+// Context.IsPodFitNodeViaPreemption (context.go:718-742) behind AsyncRMCallback.PreemptionPredicates
+// (scheduler_callback.go:207-216): → index of the last victim that has to go, -1 = {Success: false} (also for an unknown
+// ask or node; victims that are not in the cache count as nil pods).
+int32_t ykhost_is_pod_fit_node_via_preemption(ykhost_t* h, const char* allocation_key, const char* node_id,
+                                              const char* const* preempt_allocation_keys, int32_t num_keys, int32_t start_index) {
+  YKHOST_LOCKED(h);
+  ensure_uid_index(h);
+  auto it = h->by_uid.find(allocation_key ? allocation_key : "");
+  auto nt = h->node_ix.find(node_id ? node_id : "");
+  if (it == h->by_uid.end() || nt == h->node_ix.end() || !it->second->ask) return -1;
+  int r = ykhost_preemption_predicates(h, it->second->row, nt->second, preempt_allocation_keys, num_keys, start_index);
+  return r < -1 ? r : r;
+}
+
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len) {
   YKHOST_LOCKED(h);
   if (pod < 0 || pod >= (int)h->pending.size()) return fail(h, "index out of range");

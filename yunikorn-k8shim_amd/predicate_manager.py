@@ -211,6 +211,29 @@ class GpuPredicateManager:
             return "", None
         return plugin.value.decode(), PredicateError(plugin.value.decode(), msg.value.decode())
 
+    # ---- the scheduler-interface callbacks (by allocation key / node id) -------------------------------------
+    def is_pod_fit_node(self, allocation_key, node_id, allocate):
+        """Context.IsPodFitNode: None when the ask fits, else the error text the core receives (sentinel texts for an
+        unknown pod / node, "failed plugin: '<name>'" + message otherwise)."""
+        err = C.create_string_buffer(1200)
+        rc = self._L.ykhost_is_pod_fit_node(self._h, allocation_key.encode(), node_id.encode(), 1 if allocate else 0, err, 1200)
+        if rc == 1:
+            return None
+        if rc in (0, -10, -11):
+            return err.value.decode()
+        raise RuntimeError(err.value.decode() or self._L.ykhost_last_error(self._h).decode())
+
+    def is_pod_fit_node_via_preemption(self, allocation_key, node_id, preempt_allocation_keys, start_index):
+        """Context.IsPodFitNodeViaPreemption → (index, ok) as PreemptionPredicatesResponse{Index, Success}."""
+        arr = (C.c_char_p * max(len(preempt_allocation_keys), 1))()
+        for i, v in enumerate(preempt_allocation_keys):
+            arr[i] = None if v is None else v.encode()
+        r = self._L.ykhost_is_pod_fit_node_via_preemption(self._h, allocation_key.encode(), node_id.encode(), arr,
+                                                          len(preempt_allocation_keys), start_index)
+        if r < -1:
+            raise RuntimeError(self._L.ykhost_last_error(self._h).decode())
+        return r, r != -1
+
     def preemption_predicates(self, pod, node, victims, start_index):
         """PreemptionPredicates(pod, node, victims, startIndex) → index or -1. victims: UIDs (None = nil pod)."""
         p, n = self._resolve(pod, node)
