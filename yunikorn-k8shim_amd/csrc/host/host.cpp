@@ -65,6 +65,7 @@ struct ykhost {
   std::vector<NodeInfo*> nodes;  // index = engine node index
   std::unordered_map<std::string, int> node_ix;
   std::deque<Pod> pod_store;
+  std::vector<Pod*> free_pods;  // slots of pod versions nothing refers to any more (reused by the next update)
   std::vector<Pod*> pending;  // index = engine pod index
   std::unordered_map<std::string, Pod*> by_uid;
   bool uid_index = true;  // false for generated clusters until first needed
@@ -98,6 +99,7 @@ struct ykhost {
     nodes.clear();
     node_ix.clear();
     pod_store.clear();
+    free_pods.clear();
     pending.clear();
     by_uid.clear();
     uid_index = true;
@@ -144,8 +146,19 @@ Pod* add_pod_object(ykhost* h, const mj::Value& v, size_t* anon) {
   if (const mj::Value* spec = v.get_nn("spec")) p.node_name = spec->str_or("nodeName", "");
   if (p.uid.empty()) p.uid = "anon-" + std::to_string((*anon)++);
   p.tpl = h->pool.intern(read_template(v));
+  if (!h->free_pods.empty()) {
+    Pod* slot = h->free_pods.back();
+    h->free_pods.pop_back();
+    *slot = std::move(p);
+    return slot;
+  }
   h->pod_store.push_back(std::move(p));
   return &h->pod_store.back();
+}
+// A pod version that is in no map, on no node and holds no row any more: its slot can be reused.
+void recycle_pod(ykhost* h, Pod* p) {
+  *p = Pod{};  // tpl == nullptr marks the slot as empty for ensure_uid_index
+  h->free_pods.push_back(p);
 }
 
 // ---- encode + upload -------------------------------------------------------------------------------
@@ -941,6 +954,8 @@ static int update_pod_value(ykhost* h, const mj::Value& v) {
   const bool ok = cache_update_pod(h, old, p, running, terminated);
   const bool wants_row = !terminated && !running && (old && old->ask ? true : !bound_by_cluster);
   set_ask_row(h, old, wants_row ? p : nullptr);
+  if (old && old != p) recycle_pod(h, old);  // replaced by the new version everywhere
+  if (terminated) recycle_pod(h, p);          // dropped from every map (scheduler_cache.go:377-383)
   return ok ? 1 : 0;
 }
 int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json) {
@@ -1108,8 +1123,8 @@ int32_t ykhost_remove_pod(ykhost_t* h, const char* uid) {
   Pod* p = it->second;
   detach_from_node(h, p);
   set_ask_row(h, p, nullptr);
-  p->assumed = p->orphan = false;
   h->by_uid.erase(it);
+  recycle_pod(h, p);
   return 1;
 }
 
