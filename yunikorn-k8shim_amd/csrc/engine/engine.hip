@@ -147,6 +147,8 @@ struct ykpred_engine {
   // tables above; `h_members` has -1 holes where a row left its class, chunks are only ever appended between rebuilds)
   std::unordered_map<ClassKey, int32_t, ClassKeyHash> class_ids;
   std::vector<int32_t> h_pod_class, h_pod_slot;                       // per pod: class, slot in h_members
+  std::vector<uint8_t> h_row_stale;  // bitmap row rewritten by ykpred_update_pods and not re-evaluated yet: it must not serve
+                                     // as the representative row of its class (k_column_class reads that row)
   std::vector<int32_t> h_class_sig, h_class_pin, h_class_first, h_class_live;
   std::vector<std::vector<int32_t>> h_class_chunks;                   // chunk ids of a class, creation order
   std::vector<int32_t> h_members, h_ch_class, h_ch_begin, h_ch_len, h_ch_first;
@@ -347,6 +349,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   }
   e->h_class_first.assign((size_t)C, -1);
   for (int c = 0; c < C; ++c) e->h_class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
+  e->h_row_stale.assign((size_t)P, 0);
   e->C = C;
   e->NC = (int)ch_class.size();
   e->patch_chunks = 0;
@@ -1163,6 +1166,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_pre = pre;
   e->last_filt = filt;
   e->last_eval_valid = true;
+  if (!(a->options & YKPRED_EVAL_SKIP_BITMAP)) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
   if (want_dec) e->rank_valid = true;
   return YKPRED_OK;
 }
@@ -1345,20 +1349,37 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     e->h_class_live[(size_t)c]++;
     if (e->h_class_first[(size_t)c] < 0) e->h_class_first[(size_t)c] = p;
   }
-  // a class that lost its representative row but still has members: any live member's row serves (all are identical)
-  for (int c : orphaned)
-    if (e->h_class_first[(size_t)c] < 0 && e->h_class_live[(size_t)c] > 0)
-      for (int ch : e->h_class_chunks[(size_t)c]) {
-        for (int j = 0; j < e->h_ch_len[(size_t)ch] && e->h_class_first[(size_t)c] < 0; ++j) {
-          int m = e->h_members[(size_t)(e->h_ch_begin[(size_t)ch] + j)];
-          if (m >= 0) e->h_class_first[(size_t)c] = m;
-        }
-        if (e->h_class_first[(size_t)c] >= 0) break;
-      }
-  for (int c : orphaned) put(T_CLASS_FIRST, c, e->h_class_first[(size_t)c]);
+  // Representative rows. k_column_class reads the class's bitmap row from its representative, so that row must be a LIVE
+  // member whose bitmap row is current: not one rewritten by this (or an earlier, not yet evaluated) update. Only when
+  // every member of a class is stale may a stale row represent it — then all of its rows are rebuilt by ykpred_eval_pods.
+  e->h_row_stale.resize((size_t)newP, 0);
+  std::vector<int32_t> touched(orphaned);
   for (int i = 0; i < count; ++i) {
-    const int c = e->h_pod_class[(size_t)rows[i]];
-    if (e->h_class_first[(size_t)c] == rows[i]) put(T_CLASS_FIRST, c, rows[i]);
+    e->h_row_stale[(size_t)rows[i]] = 1;
+    touched.push_back(e->h_pod_class[(size_t)rows[i]]);
+  }
+  std::sort(touched.begin(), touched.end());
+  touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+  for (int c : touched) {
+    const int first = e->h_class_first[(size_t)c];
+    int want = first;
+    if (e->h_class_live[(size_t)c] == 0) {
+      want = -1;
+    } else if (first < 0 || e->h_row_stale[(size_t)first]) {
+      int fresh = -1, any = -1;
+      for (int ch : e->h_class_chunks[(size_t)c]) {
+        for (int j = 0; j < e->h_ch_len[(size_t)ch] && fresh < 0; ++j) {
+          const int m = e->h_members[(size_t)(e->h_ch_begin[(size_t)ch] + j)];
+          if (m < 0) continue;
+          if (any < 0) any = m;
+          if (!e->h_row_stale[(size_t)m]) fresh = m;
+        }
+        if (fresh >= 0) break;
+      }
+      want = fresh >= 0 ? fresh : any;
+    }
+    e->h_class_first[(size_t)c] = want;
+    put(T_CLASS_FIRST, c, want);
   }
   e->P = newP;
   TRY(grow_owned_outputs(e));
@@ -1440,6 +1461,8 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_
     tm.end(st, "k_rows_finish");
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));  // `rows` was staged from caller memory
+    for (int i = 0; i < num_rows; ++i)
+      if ((size_t)rows[i] < e->h_row_stale.size()) e->h_row_stale[(size_t)rows[i]] = 0;
   }
   tm.done(st);
   return YKPRED_OK;
