@@ -609,6 +609,31 @@ def test_update_pods_argument_checks(pm):
     assert pm.read_counts()[2] == fit.sum()
 
 
+def test_column_patch_never_reads_a_stale_representative_row(pm):
+    """Found by scripts/fuzz_incremental.py: when the LAST row is the representative of its class and moves into a vacated
+    row in the same batch that touches a node, the column patch must take the class's old word from a member whose bitmap
+    row is current — not from the moved row, which still holds the vacated ask's bits."""
+    def ask(uid, cpu):
+        return {"metadata": {"name": uid, "uid": uid}, "spec": {"containers": [{"resources": {"requests": {"cpu": cpu}}}]}}
+
+    nodes = [{"metadata": {"name": f"n{i:02d}"}, "status": {"allocatable": {"cpu": "8", "memory": "8Gi", "pods": "20"}}} for i in range(70)]
+    pods = [ask("x0", "1"), ask("x1", "2"), ask("x2", "1000"), ask("x3", "3"), ask("x4", "4"), ask("b2", "500m")]
+    pm.load_snapshot({"nodes": nodes, "pods": pods})
+    pm.evaluate()
+    pm.update_pod(ask("b3", "500m"))  # same class as b2, appended as row 6
+    pm.remove_pod("x1")                # row 1 is refilled with the last row: b3
+    assert pm.evaluate_dirty(decisions=True) == 0
+    assert (pm.pod_index("b3"), pm.pod_index("b2")) == (1, 5)  # b2, the class's representative, is now the last row
+    pm.assume_pod("x3", "n03")         # touches a node of bitmap word 0 ...
+    pm.remove_pod("x2")                # ... and vacates row 2 (an ask that fits nowhere): b2 moves there
+    assert pm.evaluate_dirty(decisions=True) == 1
+    assert pm.pod_index("b2") == 2
+    _compare_with_mirror_dump(pm, decisions=True)
+    before = pm.read_bitmap().copy()
+    pm.evaluate()
+    assert np.array_equal(before, pm.read_bitmap())
+
+
 def test_incremental_rows_use_the_row_kernels(pm):
     snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
     pm.load_snapshot(snap)
