@@ -634,6 +634,26 @@ def test_column_patch_never_reads_a_stale_representative_row(pm):
     assert np.array_equal(before, pm.read_bitmap())
 
 
+def test_graph_replay_matches_plain_launches(monkeypatch):
+    """YKPRED_GRAPH=1: a pass that repeats unchanged is captured into a hipGraph the second time and replayed afterwards;
+    table changes in between invalidate the capture. Results must not depend on the launch mode."""
+    monkeypatch.setenv("YKPRED_GRAPH", "1")
+    m = pkg.GpuPredicateManager()
+    try:
+        snap = _gen.random_snapshot(808, n_nodes=130, n_pods=50, spread=True, interpod=True)
+        m.load_snapshot(snap)
+        for _ in range(4):  # plain, capture + replay, replay, replay
+            check_against_oracle(m, snap, True, check_plugins=False)
+        check_against_oracle(m, snap, False, check_plugins=False)  # other plugin lists: another graph
+        free = next(p["metadata"]["uid"] for p in snap["pods"] if not p["spec"].get("nodeName"))
+        m.assume_pod(free, snap["nodes"][3]["metadata"]["name"] or snap["nodes"][4]["metadata"]["name"])
+        for _ in range(3):
+            m.evaluate()
+            _compare_with_mirror_dump(m, decisions=True)
+    finally:
+        m.close()
+
+
 def test_incremental_rows_use_the_row_kernels(pm):
     snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
     pm.load_snapshot(snap)

@@ -1499,8 +1499,7 @@ int32_t ykhost_is_pod_fit_node_via_preemption(ykhost_t* h, const char* allocatio
   auto it = h->by_uid.find(allocation_key ? allocation_key : "");
   auto nt = h->node_ix.find(node_id ? node_id : "");
   if (it == h->by_uid.end() || nt == h->node_ix.end() || !it->second->ask) return -1;
-  int r = ykhost_preemption_predicates(h, it->second->row, nt->second, preempt_allocation_keys, num_keys, start_index);
-  return r < -1 ? r : r;
+  return ykhost_preemption_predicates(h, it->second->row, nt->second, preempt_allocation_keys, num_keys, start_index);
 }
 
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len) {
