@@ -654,6 +654,36 @@ def test_graph_replay_matches_plain_launches(monkeypatch):
         m.close()
 
 
+def test_new_template_covered_by_the_dictionaries_is_a_row_patch(pm):
+    """A new pod template whose selector requirements, scalar resources, host ports and topology classes are already in the
+    dictionaries only appends a spec row (ykpred_set_specs keeps the pod classes for an append): no re-encode, no full pass."""
+    snap = _gen.random_snapshot(515, n_nodes=120, n_pods=40, scalars=False)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    stats = pm.stats()
+    donor = next(p for p in snap["pods"] if p["spec"].get("nodeSelector") or p["spec"].get("affinity"))
+    new = json.loads(json.dumps(donor))
+    new["metadata"].update(uid="fresh", name="fresh", labels={"only": "here"})   # a template nobody has ...
+    new["spec"].pop("nodeName", None)
+    new["spec"]["containers"] = [{"resources": {"requests": {"cpu": "123m", "memory": "77Mi"}}}]  # ... with its own requests
+    pm.update_pod(new)
+    assert pm.evaluate_dirty(decisions=True, profile=True) == 0
+    assert [k for k, _ in pm.timing()["kernels"]] == ["k_rows", "k_rows_finish"]
+    after = pm.stats()
+    assert after["specs"] == stats["specs"] + 1 and after["requirements"] == stats["requirements"]
+    _compare_with_mirror_dump(pm, decisions=True)
+    # a requirement nobody used before does need a new dictionary bit: full re-encode, still exact
+    other = json.loads(json.dumps(new))
+    other["metadata"].update(uid="fresh-2", name="fresh-2")
+    other["spec"]["nodeSelector"] = {"never-seen-key": "v"}
+    pm.update_pod(other)
+    assert pm.evaluate_dirty(decisions=True) == -1
+    _compare_with_mirror_dump(pm, decisions=True)
+    before = pm.read_bitmap().copy()
+    pm.evaluate()
+    assert np.array_equal(before, pm.read_bitmap())
+
+
 def test_incremental_rows_use_the_row_kernels(pm):
     snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
     pm.load_snapshot(snap)

@@ -115,7 +115,8 @@ struct ykpred_engine {
   std::vector<i64> h_req;
   std::vector<u64> h_tol, h_wanted;
   std::vector<uint32_t> h_sflags;
-  std::vector<int32_t> h_aff_off, h_pre_off;
+  std::vector<int32_t> h_aff_off, h_pre_off, h_spread_off;
+  std::vector<ykpred_spread_t> h_spread;
   std::vector<u64> h_aff_terms, h_pre_terms;
   DevBuf d_sreq, d_stol, d_sflags, d_aff_off, d_aff_terms, d_pre_off, d_pre_terms;  // per-spec tables (k_query / k_direct)
   // per-family signature tables
@@ -721,6 +722,39 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   if (KP > 0 && S > 0 && !s->wanted_ports) return fail(e, YKPRED_E_INVALID, "set_specs: wanted_ports missing (config has KP > 0)");
   const int T = S ? s->aff_term_off[S] : 0, M = S ? s->pre_term_off[S] : 0;
   if (T < 0 || M < 0 || (T > 0 && !s->aff_terms) || (M > 0 && !s->pre_terms)) return fail(e, YKPRED_E_INVALID, "set_specs: bad term tables");
+  // A spec table that only APPENDS to the previous one (the first old-S specs byte-identical) keeps every signature id of
+  // the old specs — signatures are numbered in first-use order — so the class index, the last evaluation and the
+  // incremental paths stay valid: a new pod template costs one small upload, not a rebuild of 10^6 pod classes.
+  const int oldS = e->S, old_spread_D = e->fam_spread.D;
+  bool append_only = e->specs_set && !e->classes_dirty && oldS <= S;
+  if (append_only && oldS > 0) {
+    auto same = [](const void* a, const void* b, size_t n) { return n == 0 || memcmp(a, b, n) == 0; };
+    const int oT = e->h_aff_off[(size_t)oldS], oM = e->h_pre_off[(size_t)oldS];
+    append_only = same(e->h_req.data(), s->requests, (size_t)oldS * R * sizeof(i64)) &&
+                  same(e->h_tol.data(), s->tolerated, (size_t)oldS * KT * sizeof(u64)) &&
+                  (KP == 0 || same(e->h_wanted.data(), s->wanted_ports, (size_t)oldS * KP * sizeof(u64))) &&
+                  same(e->h_sflags.data(), s->flags, (size_t)oldS * sizeof(uint32_t)) &&
+                  same(e->h_aff_off.data(), s->aff_term_off, (size_t)(oldS + 1) * sizeof(int32_t)) &&
+                  same(e->h_pre_off.data(), s->pre_term_off, (size_t)(oldS + 1) * sizeof(int32_t)) &&
+                  same(e->h_aff_terms.data(), s->aff_terms, (size_t)oT * W * sizeof(u64)) &&
+                  same(e->h_pre_terms.data(), s->pre_terms, (size_t)oM * W * sizeof(u64));
+    const bool had_spread = !e->h_spread_off.empty() && e->h_spread_off[(size_t)oldS] > 0;
+    if (append_only && (had_spread || s->spread_off)) {
+      if (e->h_spread_off.empty() || !s->spread_off) {
+        append_only = !had_spread && s->spread_off && s->spread_off[oldS] == 0;
+      } else {
+        append_only = same(e->h_spread_off.data(), s->spread_off, (size_t)(oldS + 1) * sizeof(int32_t)) &&
+                      same(e->h_spread.data(), s->spread, (size_t)e->h_spread_off[(size_t)oldS] * sizeof(ykpred_spread_t));
+      }
+    }
+  }
+  if (s->spread_off && S > 0) {
+    e->h_spread_off.assign(s->spread_off, s->spread_off + S + 1);
+    e->h_spread.assign(s->spread, s->spread + s->spread_off[S]);
+  } else {
+    e->h_spread_off.assign((size_t)S + 1, 0);
+    e->h_spread.clear();
+  }
   e->S = S;
   e->h_req.assign(s->requests, s->requests + (size_t)S * R);
   e->h_tol.assign(s->tolerated, s->tolerated + (size_t)S * KT);
@@ -823,7 +857,9 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     e->spec_sig_spread[(size_t)i] = it->second;
   }
   e->fam_spread.D = (int)m_spread.size();
-  e->spread_dirty = true;
+  // appended specs that bring no new topology signature leave the device tables and the histograms of the last pass valid
+  const bool spread_unchanged = append_only && e->fam_spread.D == old_spread_D && !e->spread_dirty;
+  if (!spread_unchanged) e->spread_dirty = true;
   TRY(upload(e, e->d_spec_spread, e->spec_sig_spread.data(), e->spec_sig_spread.size(), st));
   e->fam_res.D = (int)m_res.size();
   e->fam_tol.D = (int)m_tol.size();
@@ -839,7 +875,8 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   TRY(upload(e, e->d_sig_pre_terms, sig_pre_terms.data(), sig_pre_terms.size(), st));
   HIPCHK(hipStreamSynchronize(st));
   e->specs_set = true;
-  e->classes_dirty = true;
+  if (!append_only) e->classes_dirty = true;
+  if (!spread_unchanged) e->last_eval_valid = false;  // new topology signatures have no histogram yet: full pass first
   return YKPRED_OK;
 }
 

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <limits>
 #include <set>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -254,14 +255,12 @@ class Encoder {
           }
     }
     for (const PodTemplate* t : templates) {
-      if (t->pod_affinity_unsupported) return fail("pod (anti)affinity namespaceSelector / matchLabelKeys are not supported by the engine");
+      {
+        std::string why = template_error(*t);
+        if (!why.empty()) return fail(why);
+      }
       for (auto* terms : {&t->pod_affinity, &t->pod_anti_affinity})
-        for (auto& term : *terms) {
-          bool invalid = false;
-          selector_matches(term.selector, t->labels, &invalid);
-          if (invalid) return fail("invalid labelSelector in a pod (anti)affinity term (InterPodAffinity.PreFilter would reject the pod)");
-          topo_key(term.topology_key);
-        }
+        for (auto& term : *terms) topo_key(term.topology_key);
       if (!t->pod_affinity.empty())
         count_class("A|" + t->ns + '\x1f' + pod_terms_key(t->pod_affinity), SelectorClass{SelectorClass::kAffinityAll, t->ns, {}, t->pod_affinity, {}, ""});
       for (auto& term : t->pod_anti_affinity)
@@ -273,14 +272,8 @@ class Encoder {
                         SelectorClass{SelectorClass::kExistingAnti, t->ns, {}, {}, t->labels, term.topology_key});
       for (const HostPort& hp : template_host_ports(*t))
         if (port_ix_.emplace(port_key(hp), (int)port_dict.size()).second) port_dict.push_back(hp);
-      std::set<std::string> keys_seen;
       for (auto& c : t->spread) {
         if (c.when_unsatisfiable != "DoNotSchedule") continue;  // ScheduleAnyway constraints only score
-        if (!c.match_label_keys.empty()) return fail("topologySpreadConstraints.matchLabelKeys is not supported by the engine");
-        if (!keys_seen.insert(c.topology_key).second) return fail("duplicate topologyKey among DoNotSchedule constraints (rejected by API validation)");
-        bool invalid = false;
-        selector_matches(c.selector, t->labels, &invalid);
-        if (invalid) return fail("invalid labelSelector in topologySpreadConstraints (PodTopologySpread.PreFilter would error)");
         topo_key(c.topology_key);
         if (!selector_counts_nothing(c.selector))
           count_class("S|" + selector_key(t->ns, c.selector), SelectorClass{SelectorClass::kSpread, t->ns, c.selector, {}, {}, ""});
@@ -318,6 +311,47 @@ class Encoder {
     if (KT > 4) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
     if (W > 8) return fail("more than 512 distinct node-selector requirements (engine limit)");
     return true;
+  }
+
+  // What build_dictionaries refuses in a pending ask's template ("" = acceptable): features the engine does not evaluate
+  // and inputs the upstream PreFilters reject.
+  std::string template_error(const PodTemplate& t) const {
+    if (t.pod_affinity_unsupported) return "pod (anti)affinity namespaceSelector / matchLabelKeys are not supported by the engine";
+    for (auto* terms : {&t.pod_affinity, &t.pod_anti_affinity})
+      for (auto& term : *terms) {
+        bool invalid = false;
+        selector_matches(term.selector, t.labels, &invalid);
+        if (invalid) return "invalid labelSelector in a pod (anti)affinity term (InterPodAffinity.PreFilter would reject the pod)";
+      }
+    std::set<std::string> keys_seen;
+    for (auto& c : t.spread) {
+      if (c.when_unsatisfiable != "DoNotSchedule") continue;
+      if (!c.match_label_keys.empty()) return "topologySpreadConstraints.matchLabelKeys is not supported by the engine";
+      if (!keys_seen.insert(c.topology_key).second) return "duplicate topologyKey among DoNotSchedule constraints (rejected by API validation)";
+      bool invalid = false;
+      selector_matches(c.selector, t.labels, &invalid);
+      if (invalid) return "invalid labelSelector in topologySpreadConstraints (PodTopologySpread.PreFilter would error)";
+    }
+    return "";
+  }
+  // Encodes a template against the EXISTING dictionaries. Returns false when it needs an entry that is not there yet
+  // (a new selector requirement, scalar resource, host port, topology key or count class) or is not acceptable at all:
+  // the caller then rebuilds the dictionaries.
+  bool encode_spec_if_covered(const PodTemplate& t, EncodedSpec* spec, std::vector<uint64_t>* wanted) const {
+    if (!template_error(t).empty()) return false;
+    missing_ = false;
+    try {
+      *spec = encode_spec(t);
+    } catch (const std::out_of_range&) {
+      return false;  // topology key / count class not in the dictionaries
+    }
+    for (auto& kv : t.requests)
+      if (is_scalar_resource_name(kv.first) && !scalar_ix_.count(kv.first)) missing_ = true;
+    for (const HostPort& hp : template_host_ports(t))
+      if (!port_ix_.count(port_key(hp))) missing_ = true;
+    wanted->assign((size_t)std::max(KP, 1), 0);
+    encode_wanted_ports(t, wanted->data());
+    return !missing_;
   }
 
   // NodePorts: bit k = some pod in `pods` uses a host port that conflicts with dictionary port k
@@ -598,6 +632,7 @@ class Encoder {
     }
   };
   std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_, topo_ix_, sel_ix_, port_ix_;
+  mutable bool missing_ = false;  // set by a dictionary lookup that found nothing (see encode_spec_if_covered)
   std::vector<const PodTemplate*> existing_anti_templates_;  // distinct templates of on-node pods that carry anti-affinity terms
   static std::string port_key(const HostPort& h) { return h.protocol + '\x1f' + h.ip + '\x1f' + std::to_string(h.port); }
   std::unordered_map<std::pair<const PodTemplate*, int>, int, MemoHash> sel_memo_;
@@ -682,6 +717,7 @@ class Encoder {
   }
   int find_req(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) const {
     auto it = req_ix_.find(req_key(k, key, op, values));
+    if (it == req_ix_.end()) missing_ = true;
     return it == req_ix_.end() ? -1 : it->second;
   }
   static void set_bit(std::vector<uint64_t>& m, int q) {

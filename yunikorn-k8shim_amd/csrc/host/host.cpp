@@ -12,6 +12,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -50,6 +51,19 @@ struct Rng {  // splitmix64
 
 using namespace ykh;
 
+// The encoded (structure-of-arrays) form of the mirror: exactly what crosses the C ABI in ykpred_set_nodes / set_specs.
+struct EncodedTables {
+  std::vector<uint64_t> ports, taints, labels, stol, aff_terms, pre_terms, wanted;
+  std::vector<int64_t> alloc, req, sreq;
+  std::vector<int32_t> allowed, count, domain, selcount, dsizes, aff_off, pre_off, spread_off;
+  std::vector<uint32_t> flags, sflags;
+  std::vector<ykpred_spread_t> spread;
+  ykpred_nodes_t nt{};
+  ykpred_specs_t sp{};
+  uint64_t dummy = 0;
+  ykpred_spread_t no_spread{};
+};
+
 struct ykhost {
   // Context.IsPodFitNode runs under read locks only (context.go:697,709), so several core goroutines may be inside
   // Predicates() at once while the mirror's answer cache and lazy sync mutate state: one lock around every entry point.
@@ -80,6 +94,8 @@ struct ykhost {
   bool table_shrunk = false;          // the ask table lost rows at its end since the last upload
   bool decisions_stale = true;        // something was (re)evaluated without decisions since they were last produced
   uint64_t placeholder_serial = 0;    // nonce source of generated placeholder names
+  std::shared_ptr<EncodedTables> tables;  // what the last full encode uploaded; spec rows are appended for new templates
+  bool specs_dirty = false;               // spec rows were appended since the last ykpred_set_specs
   // answers of one ask against every node (ykpred_query_pod), so that the core's per-node Predicates() callbacks of a
   // scheduling attempt are served from host memory; dropped whenever any table changes
   struct AskAnswers {
@@ -194,18 +210,7 @@ int recreate_engine(ykhost* h) {
   return 0;
 }
 
-// The encoded (structure-of-arrays) form of the mirror: exactly what crosses the C ABI in ykpred_set_nodes / set_specs.
-struct EncodedTables {
-  std::vector<uint64_t> ports, taints, labels, stol, aff_terms, pre_terms, wanted;
-  std::vector<int64_t> alloc, req, sreq;
-  std::vector<int32_t> allowed, count, domain, selcount, dsizes, aff_off, pre_off, spread_off;
-  std::vector<uint32_t> flags, sflags;
-  std::vector<ykpred_spread_t> spread;
-  ykpred_nodes_t nt{};
-  ykpred_specs_t sp{};
-  uint64_t dummy = 0;
-  ykpred_spread_t no_spread{};
-};
+void refresh_spec_view(ykhost* h, EncodedTables* T);
 
 // Dictionaries + node rows + spec rows from the current objects (no device involved).
 int encode_tables(ykhost* h, EncodedTables* T) {
@@ -291,6 +296,13 @@ int encode_tables(ykhost* h, EncodedTables* T) {
     T->aff_off.push_back((int32_t)(T->aff_terms.size() / (size_t)W));
     T->pre_off.push_back((int32_t)(T->pre_terms.size() / (size_t)W));
   }
+  refresh_spec_view(h, T);
+  return 0;
+}
+
+// Points T->sp at the (possibly re-allocated) spec vectors.
+void refresh_spec_view(ykhost* h, EncodedTables* T) {
+  const size_t S = h->spec_templates.size();
   ykpred_specs_t& sp = T->sp;
   sp = ykpred_specs_t{};
   sp.count = (int32_t)S;
@@ -304,12 +316,43 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   sp.spread_off = T->spread_off.data();
   sp.spread = T->spread.empty() ? &T->no_spread : T->spread.data();
   sp.wanted_ports = T->wanted.data();
-  return 0;
+}
+
+// A pending ask arrived with a pod template the device has no spec for. If the existing dictionaries cover it, its spec
+// row is appended (ykpred_set_specs keeps the pod classes for an append) and the ask is an ordinary new row; otherwise
+// everything is re-encoded.
+bool append_spec(ykhost* h, const PodTemplate* tpl) {
+  if (h->dirty_all || !h->tables || !h->eng) return false;
+  EncodedTables& T = *h->tables;
+  EncodedSpec es;
+  std::vector<uint64_t> wanted;
+  if (!h->enc.encode_spec_if_covered(*tpl, &es, &wanted)) return false;
+  const size_t W = (size_t)h->enc.W, KP = (size_t)h->enc.KP;
+  const size_t S = h->spec_templates.size();
+  const_cast<PodTemplate*>(tpl)->spec_id = (int32_t)S;
+  h->spec_templates.push_back(const_cast<PodTemplate*>(tpl));
+  T.sreq.insert(T.sreq.end(), es.req.begin(), es.req.end());
+  T.stol.insert(T.stol.end(), es.tol.begin(), es.tol.end());
+  T.sflags.push_back(es.flags);
+  T.wanted.resize(S * KP);  // drop the padding element, append, pad again
+  T.wanted.insert(T.wanted.end(), wanted.begin(), wanted.begin() + (long)KP);
+  T.wanted.push_back(0);
+  for (auto& t : es.terms) T.aff_terms.insert(T.aff_terms.end(), t.begin(), t.end());
+  for (auto& t : es.pre_terms) T.pre_terms.insert(T.pre_terms.end(), t.begin(), t.end());
+  T.aff_off.push_back((int32_t)(T.aff_terms.size() / W));
+  T.pre_off.push_back((int32_t)(T.pre_terms.size() / W));
+  T.spread.insert(T.spread.end(), es.spread.begin(), es.spread.end());
+  T.spread_off.push_back((int32_t)T.spread.size());
+  refresh_spec_view(h, &T);
+  h->specs_dirty = true;
+  return true;
 }
 
 int full_sync(ykhost* h) {
   auto t0 = std::chrono::steady_clock::now();
-  EncodedTables T;
+  h->tables = std::make_shared<EncodedTables>();
+  h->specs_dirty = false;
+  EncodedTables& T = *h->tables;
   int rc = encode_tables(h, &T);
   if (rc) return rc;
   rc = recreate_engine(h);
@@ -413,6 +456,12 @@ int sync(ykhost* h) {
     if (rc) return rc;
   }
   h->dirty_nodes.clear();
+  if (h->specs_dirty && !h->dirty_all) {
+    int rc = ykpred_set_specs(h->eng, &h->tables->sp);
+    if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
+    h->specs_dirty = false;
+    h->answers.pod = -1;
+  }
   if (h->dirty_pods) return pods_sync(h);
   if (!h->dirty_rows.empty() || h->table_shrunk) return rows_sync(h);
   return 0;
@@ -498,8 +547,8 @@ void set_ask_row(ykhost* h, Pod* old, Pod* now) {
       h->pending[(size_t)row] = now;
     }
     now->row = row;
-    if (now->tpl->spec_id < 0)
-      h->dirty_all = true;  // new template: dictionaries may grow
+    if (now->tpl->spec_id < 0 && !append_spec(h, now->tpl))
+      h->dirty_all = true;  // new template that needs new dictionary entries
     else
       mark_row(h, row);
   } else if (row >= 0) {
