@@ -310,6 +310,28 @@ class Encoder {
     if (R > 8) return fail("more than 5 scalar resource names in use (engine limit R<=8)");
     if (KT > 4) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
     if (W > 8) return fail("more than 512 distinct node-selector requirements (engine limit)");
+    label_keys_.clear();
+    label_reqs_.clear();
+    name_reqs_.clear();
+    name_other_.clear();
+    name_equals_.clear();
+    label_memo_.clear();
+    std::set<std::string> keys;
+    for (size_t q = 0; q < req_dict.size(); ++q) {
+      if (req_dict[q].kind == DictReq::kLabel || req_dict[q].kind == DictReq::kEquals) {
+        label_reqs_.push_back((int)q);
+        keys.insert(req_dict[q].req.key);
+      } else {
+        name_reqs_.push_back((int)q);
+        const DictReq& d = req_dict[q];
+        const bool equals_name = d.kind == DictReq::kNameIn || (d.kind == DictReq::kField && d.req.key == "metadata.name" && d.req.op == "In");
+        if (equals_name)
+          name_equals_[d.req.values[0]].push_back((int)q);  // true exactly on the node of that name
+        else
+          name_other_.push_back((int)q);
+      }
+    }
+    label_keys_.assign(keys.begin(), keys.end());
     return true;
   }
 
@@ -470,9 +492,38 @@ class Encoder {
       auto it = taint_ix_.find(taint_key(t));
       if (it != taint_ix_.end()) taints[it->second >> 6] |= 1ull << (it->second & 63);
     }
-    std::fill(labels, labels + W, 0);
-    for (size_t q = 0; q < req_dict.size(); ++q)
-      if (req_dict[q].eval(ni.node)) labels[q >> 6] |= 1ull << (q & 63);
+    // Requirement bits. Label requirements depend only on the node's values for the few label keys the dictionary
+    // mentions, and most nodes share those values (zones, instance types ...): the words are computed once per distinct
+    // value tuple; the requirements on the node NAME (matchFields) are evaluated per node.
+    std::string sig;
+    for (const std::string& key : label_keys_) {
+      auto it = ni.node.labels.find(key);
+      if (it == ni.node.labels.end()) {
+        sig.push_back('\x01');
+      } else {
+        sig.push_back('\x02');
+        sig += it->second;
+      }
+      sig.push_back('\x1f');
+    }
+    auto memo = label_memo_.find(sig);
+    if (memo == label_memo_.end()) {
+      std::vector<uint64_t> words((size_t)W, 0);
+      for (int q : label_reqs_)
+        if (req_dict[(size_t)q].eval(ni.node)) words[(size_t)q >> 6] |= 1ull << (q & 63);
+      memo = label_memo_.emplace(std::move(sig), std::move(words)).first;
+    }
+    std::copy(memo->second.begin(), memo->second.end(), labels);
+    if (ni.node.name.empty()) {  // matchFields are not consulted for a nameless node (DictReq::eval)
+      for (int q : name_reqs_)
+        if (req_dict[(size_t)q].eval(ni.node)) labels[q >> 6] |= 1ull << (q & 63);
+    } else {
+      for (int q : name_other_)
+        if (req_dict[(size_t)q].eval(ni.node)) labels[q >> 6] |= 1ull << (q & 63);
+      auto hit = name_equals_.find(ni.node.name);  // "metadata.name In [x]" / NodeNames entries naming this node
+      if (hit != name_equals_.end())
+        for (int q : hit->second) labels[q >> 6] |= 1ull << (q & 63);
+    }
   }
 
   // ---- spec rows -----------------------------------------------------------------------------------
@@ -633,6 +684,11 @@ class Encoder {
   };
   std::unordered_map<std::string, int> scalar_ix_, taint_ix_, req_ix_, topo_ix_, sel_ix_, port_ix_;
   mutable bool missing_ = false;  // set by a dictionary lookup that found nothing (see encode_spec_if_covered)
+  std::vector<std::string> label_keys_;  // distinct label keys of the label requirements (sorted)
+  std::vector<int> label_reqs_, name_reqs_;  // dictionary indices: requirements on labels / on the node name
+  std::vector<int> name_other_;              // name requirements that are not "name == x" (NotIn, other field keys)
+  std::unordered_map<std::string, std::vector<int>> name_equals_;  // node name → requirements that hold exactly there
+  mutable std::unordered_map<std::string, std::vector<uint64_t>> label_memo_;  // label-value tuple → requirement words
   std::vector<const PodTemplate*> existing_anti_templates_;  // distinct templates of on-node pods that carry anti-affinity terms
   static std::string port_key(const HostPort& h) { return h.protocol + '\x1f' + h.ip + '\x1f' + std::to_string(h.port); }
   std::unordered_map<std::pair<const PodTemplate*, int>, int, MemoHash> sel_memo_;

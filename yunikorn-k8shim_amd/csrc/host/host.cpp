@@ -224,7 +224,9 @@ int encode_tables(ykhost* h, EncodedTables* T) {
       h->spec_templates.push_back(t);
     }
   }
+  auto _t1 = std::chrono::steady_clock::now();
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
+  auto _t2 = std::chrono::steady_clock::now();
   const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS, KP = h->enc.KP;
   const size_t N = h->nodes.size();
   T->ports.assign(N * KP + 1, 0);
@@ -255,6 +257,8 @@ int encode_tables(ykhost* h, EncodedTables* T) {
     for (int k = 0; k < KT; ++k) T->taints[(size_t)k * N + n] = t1[(size_t)k];
     for (int w = 0; w < W; ++w) T->labels[(size_t)w * N + n] = l1[(size_t)w];
   }
+  auto _t3 = std::chrono::steady_clock::now();
+  if (getenv("YKHOST_PROFILE")) fprintf(stderr, "encode: dict %.1f ms, nodes %.1f ms\n", std::chrono::duration<double, std::milli>(_t2 - _t1).count(), std::chrono::duration<double, std::milli>(_t3 - _t2).count());
   ykpred_nodes_t& nt = T->nt;
   nt = ykpred_nodes_t{};
   nt.count = (int32_t)N;
@@ -1286,7 +1290,9 @@ int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const
 int64_t ykhost_encoded_tables_json(ykhost_t* h, char* out, int64_t len) {
   YKHOST_LOCKED(h);
   EncodedTables T;
+  auto t0 = std::chrono::steady_clock::now();
   int rc = encode_tables(h, &T);
+  h->last_encode_us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
   h->dirty_all = true;  // spec ids were re-assigned: the device tables (if any) are re-uploaded at the next sync
   if (rc) return rc;
   std::string o = "{";
