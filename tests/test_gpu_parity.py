@@ -684,6 +684,18 @@ def test_new_template_covered_by_the_dictionaries_is_a_row_patch(pm):
     assert np.array_equal(before, pm.read_bitmap())
 
 
+def test_incremental_fuzz_seeds():
+    """A short slice of scripts/fuzz_incremental.py (random cache-operation sequences, every live row / count / decision
+    checked against the oracle after every evaluate_dirty) so that every GPU run of the suite re-plays it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_incremental.py"), "710040", "10", "25"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 failures" in r.stdout
+
+
 def test_incremental_rows_use_the_row_kernels(pm):
     snap = _gen.random_snapshot(31, n_nodes=100, n_pods=30, scalars=False)
     pm.load_snapshot(snap)
