@@ -114,6 +114,10 @@ int32_t ykhost_node_index(const ykhost_t* h, const char* node_name); /* -1 = unk
 /* Serialises pending pods `pods[0..np)` (NULL = all) and nodes `nodes[0..nn)` (NULL = all, with their assigned pods)
  * as a snapshot document. Returns the required length (incl. NUL); writes at most `len` bytes. */
 int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len);
+/* on != 0: ykhost_dump_snapshot writes runs of on-node pods that share a pod template once, with "replicas": k (the loaders
+ * expand them; their uids get a "#r" suffix) — what keeps the dump of a 50 000-node cluster small enough to hand to the
+ * oracle for full-grid parity. */
+int32_t ykhost_set_dump_compact(ykhost_t* h, int32_t on);
 
 /* The encoded (structure-of-arrays) tables that cross the C ABI, as JSON (64-bit masks as hex strings); works on a
  * mirror-only handle. For encoder tests on machines without a device. Returns the required length like dump_snapshot. */

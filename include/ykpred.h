@@ -266,6 +266,13 @@ int32_t ykpred_read_counts(ykpred_engine_t* e, int32_t* out /* [P] */);
 int32_t ykpred_read_decisions(ykpred_engine_t* e, int32_t* out /* [P] */);
 int32_t ykpred_read_scores(ykpred_engine_t* e, double* out /* [N] bin-pack score per node */);
 int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out); /* order-independent hash of (pod,word,value) */
+/* Parity support for bitmaps too large to read back (50k x 1M = 6.27 GB): the rows of the listed pods, densely; the pod →
+ * class map with one representative pod per class (-1 = class without live member); and the number of bitmap words that
+ * differ between a pod's row and the row of its class's representative, plus non-zero padding words. With these a checker
+ * evaluates ONE pod per class against every node on the CPU and still covers every (pod, node) pair of the bitmap. */
+int32_t ykpred_read_rows(ykpred_engine_t* e, int32_t n, const int32_t* pod_index, uint64_t* out /* [n][row_words] */);
+int32_t ykpred_read_pod_classes(ykpred_engine_t* e, int32_t* pod_class /* [P] or NULL */, int32_t* class_rep /* [num_classes] or NULL */);
+int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
 
 /* one Predicates() answer per (pod,node) pair, evaluated on the device straight from the tables */
 int32_t ykpred_query(ykpred_engine_t* e, int32_t num_pairs, const int32_t* pod_index, const int32_t* node_index,
@@ -294,6 +301,38 @@ int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t num_queries, const i
                                 const uint8_t* victim_present /* [total] */, const uint64_t* port_bits_after /* [total][KP] or NULL */,
                                 const int32_t* start_index /* [num_queries] */, uint32_t prefilter_plugins, uint32_t filter_plugins,
                                 int32_t* out_index /* [num_queries] */);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: node-axis shards. One engine per GPU / process holds a contiguous shard of the node table and
+ * the full ask table; every (ask, node) pair is independent, so each shard evaluates its own bitmap columns with no
+ * data-path collective. The exchanges below run over RCCL (xGMI inside one box) on the stream they are given, ordered after
+ * the work already queued there; librccl is loaded on first use (dlopen), so a single-GPU process never maps it.
+ *
+ *   ykpred_comm_unique_id   rank 0 draws the 128-byte id; the host distributes it out of band (the Go side: over whatever
+ *                           already connects the shard processes; bench.py: its torch.distributed bootstrap group)
+ *   ykpred_comm_init        ncclCommInitRank; node_offset = global index of this shard's node 0
+ *   ykpred_gather_bitmap    all-gather of the shard bitmaps of the last ykpred_eval into the shard-major layout
+ *                           [world][P][row_stride] (BASELINE configs[3]); every shard must use the same row_stride
+ *                           (ykpred_set_row_stride) and hold the same asks in the same order
+ *   ykpred_exchange_decisions  in place on the outputs of the last ykpred_eval (which must have produced decision keys):
+ *                           counts → cluster-wide feasible counts (SUM); decisions → GLOBAL node index of the best
+ *                           feasible node in bin-pack order, ties by global node index (MIN key, then MIN index), -1 = none
+ *   PodTopologySpread / InterPodAffinity histograms: once a communicator is attached, ykpred_eval itself sums the
+ *                           per-shard histograms (SUM of matches, MAX of "domain present") between its count and min
+ *                           passes — the shards must share the topology-domain dictionaries — and ykpred_query /
+ *                           ykpred_preemption reuse those cluster-wide histograms instead of rebuilding shard-local ones.
+ * Not sharded: PreemptionPredicates (one node, sequential victim prefix) runs on the shard that owns the node. */
+#define YKPRED_COMM_ID_BYTES 128
+int32_t ykpred_comm_unique_id(uint8_t* id /* [YKPRED_COMM_ID_BYTES] */);
+int32_t ykpred_comm_init(ykpred_engine_t* e, const uint8_t* id, int32_t rank, int32_t world, int32_t node_offset);
+int32_t ykpred_comm_destroy(ykpred_engine_t* e);
+/* Rows of the NEXT ykpred_set_nodes get this stride (64-bit words, multiple of 16, >= the shard's own need); 0 = automatic.
+ * Shards of unequal size agree on the stride of the largest one so that the gathered layout is regular. */
+int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words);
+int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered /* DEVICE [world][P][row_stride] u64, NULL = engine-owned */, void* stream);
+int32_t ykpred_exchange_decisions(ykpred_engine_t* e, void* stream);
+/* readback of the engine-owned gathered bitmap: rows [first_pod, first_pod + num_pods) of shard `shard`, row_stride words each */
+int32_t ykpred_read_gathered(ykpred_engine_t* e, int32_t shard, int32_t first_pod, int32_t num_pods, uint64_t* out);
 
 #ifdef __cplusplus
 }

@@ -817,6 +817,35 @@ def test_full_size_configs(pm, n_nodes, n_pods, affinity):
     assert pm.checksum() == sum_plane
 
 
+@pytest.mark.parametrize("n_nodes,n_pods,affinity,gang", [(10_000, 100_000, 0, 0), (50_000, 1_000_000, 1, 0), (50_000, 1_000_000, 1, 100)])
+def test_full_grid_oracle_parity(pm, n_nodes, n_pods, affinity, gang):
+    """EVERY (pod, node) pair of configs[1], configs[2] and the configs[3] gang shape against the oracle
+    (predicate_manager.go:206-283 per pair): the oracle evaluates one representative ask per pod class against all N
+    nodes — C x N Predicates() calls, 1e8 for configs[2] — and the device proves that each of the P rows equals the row
+    of its class's representative (and that every padding word is zero). Together: all P x N bits are the oracle's."""
+    import time
+    pm.generate_kwok(seed=0x59554E49 + 20 + affinity + gang, num_nodes=n_nodes, num_pods=n_pods, num_templates=2000,
+                     node_affinity=affinity, gang_size=gang)
+    pm.evaluate()
+    lay = pm.layout()
+    assert (lay.num_nodes, lay.num_pods) == (n_nodes, n_pods)
+    pod_class, rep = pm.pod_classes()
+    assert len(rep) == lay.num_classes and (rep >= 0).all()
+    assert np.array_equal(pod_class[rep], np.arange(len(rep))), "a representative must belong to its own class"
+    assert pm.check_class_rows() == 0
+    t0 = time.perf_counter()
+    o = orc.Oracle(pm.dump_snapshot(pods=rep, compact=True))
+    assert (o.num_pods, o.num_nodes) == (len(rep), n_nodes)
+    want = o.eval_grid(threads=os.cpu_count() or 8)
+    t_oracle = time.perf_counter() - t0
+    got = unpack(pm.read_rows(rep), n_nodes)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} representative pairs differ from the oracle"
+    counts = pm.read_counts()
+    assert np.array_equal(counts, want.sum(axis=1)[pod_class])
+    print(f"full grid {n_pods} x {n_nodes}: {len(rep)} classes x {n_nodes} nodes = {want.size} oracle calls in {t_oracle:.1f} s")
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """The N>1 path of bench.py (node shards + decision exchange) end to end: 2 ranks share this box's GPU, gloo
     carries the all-reduces (RCCL needs one GPU per rank; the driver's multi-GPU runs use nccl)."""

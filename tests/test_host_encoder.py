@@ -70,3 +70,18 @@ def test_dictionaries_are_shared_and_minimal(mirror):
     assert st["requirements"] == 3 and t["S"] == 6  # 3 selectors x 2 toleration variants
     assert all(b == 1 for b in t["taint_bits"]) and t["KT"] == 1 and t["W"] == 1
     assert sorted(set(t["tolerated"])) == [0, 1]
+
+
+def test_compact_snapshot_dump_is_equivalent(mirror):
+    """ykhost_set_dump_compact: runs of on-node pods that share a template are written once with "replicas": k. The oracle
+    must see the same cluster either way (this is what makes the 50 000-node dumps of the full-grid parity test small)."""
+    mirror.generate_kwok(seed=99, num_nodes=120, num_pods=60, num_templates=0, node_affinity=1, spread=1)
+    plain, compact = mirror.dump_snapshot(), mirror.dump_snapshot(compact=True)
+    assert len(compact) < len(plain) // 3 and '"replicas"' in compact and '"replicas"' not in plain
+    a, b = orc.Oracle(plain), orc.Oracle(compact)
+    assert (a.num_nodes, a.num_pods) == (b.num_nodes, b.num_pods) == (120, 60)
+    fa, pa = a.eval_grid(threads=4, want_plugin=True)
+    fb, pb = b.eval_grid(threads=4, want_plugin=True)
+    assert np.array_equal(fa, fb) and np.array_equal(pa, pb)
+    for n in range(0, 120, 17):
+        assert a.node_info(n) == b.node_info(n)

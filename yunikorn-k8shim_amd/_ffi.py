@@ -91,6 +91,9 @@ def load_ykpred():
     L.ykpred_read_decisions.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_read_scores.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_bitmap_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ykpred_read_rows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.ykpred_read_pod_classes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_check_class_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ykpred_query.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p]
     L.ykpred_preemption_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -133,6 +136,7 @@ def load_ykhost():
     L.ykhost_node_index.argtypes = [C.c_void_p, C.c_char_p]
     L.ykhost_dump_snapshot.restype = C.c_int64
     L.ykhost_dump_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
+    L.ykhost_set_dump_compact.argtypes = [C.c_void_p, C.c_int32]
     L.ykhost_sync.argtypes = [C.c_void_p]
     L.ykhost_encoded_tables_json.restype = C.c_int64
     L.ykhost_encoded_tables_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]

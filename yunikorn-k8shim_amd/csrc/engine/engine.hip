@@ -6,6 +6,8 @@
 #include "../../../include/ykpred.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is loaded on first use of a ykpred_comm_* entry point
 
 #include <algorithm>
 #include <cstdio>
@@ -191,6 +193,15 @@ struct ykpred_engine {
                                // table change of the incremental path) never pay for capture + instantiation
   uint64_t tables_version = 1;
   bool graph_disabled = true;   // opt-in (cfg.reserved[3] == 1 / YKPRED_GRAPH=1); also set when a capture failed once
+
+  // --- multi-GPU (node-axis shards): RCCL communicator, this shard's place in the cluster, exchange scratch
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1, node_offset = 0;
+  int forced_stride = 0;  // ykpred_set_row_stride
+  DevBuf d_gathered, d_xkey, d_xcand;
+  bool last_has_keys = false;
+  // PodTopologySpread / InterPodAffinity histograms: valid for the node / spec tables of `hist_epoch`
+  uint64_t nodes_epoch = 1, hist_epoch = 0;
 
   // --- timing: one (start, stop) event pair per kernel, recorded on the stream the kernel is launched on
   hipEvent_t ev[2 * YKPRED_MAX_TIMED_KERNELS + 2]{};
@@ -516,6 +527,74 @@ int run_spread_prefilter(ykpred_engine* e, hipStream_t st, Timer* tm, bool do_co
   return YKPRED_OK;
 }
 
+// librccl, resolved on first use. torch ships a librccl.so.1 of its own: a copy that is already mapped is reused.
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+      if (r.lib) break;
+    }
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      if (r.lib) break;
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!r.lib) {
+      r.error = std::string("cannot load librccl: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char* n) {
+      void* p = dlsym(r.lib, n);
+      if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n;
+      return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  });
+  return &r;
+}
+#define NCCLCHK(call)                                                                                     \
+  do {                                                                                                    \
+    ncclResult_t _s = (call);                                                                             \
+    if (_s != ncclSuccess) return fail(e, YKPRED_E_DEVICE, std::string(#call) + ": " + rccl()->GetErrorString(_s)); \
+  } while (0)
+
+// Cluster-wide PreFilter state of the topology plugins on a node-sharded cluster: matches per (constraint, domain) add up,
+// "an eligible node carries the domain" is an OR (MAX of 0/1). Two small all-reduces (KBs) between count and min.
+int allreduce_spread(ykpred_engine* e, hipStream_t st) {
+  if (!e->comm || e->comm_world <= 1 || e->spread_cells == 0) return YKPRED_OK;
+  NCCLCHK(rccl()->AllReduce(e->d_sp_cnt.p, e->d_sp_cnt.p, (size_t)e->spread_cells, ncclInt32, ncclSum, e->comm, st));
+  NCCLCHK(rccl()->AllReduce(e->d_sp_present.p, e->d_sp_present.p, (size_t)e->spread_cells, ncclInt32, ncclMax, e->comm, st));
+  return YKPRED_OK;
+}
+
+// The topology histograms for the per-pair entry points (query / preemption): reuse what the last full pass left when the
+// tables have not moved since — on a sharded engine those are the cluster-wide sums, which a local rebuild would destroy.
+int ensure_histograms(ykpred_engine* e, hipStream_t st) {
+  if (e->spread_dirty) TRY(build_spread_tables(e, st));
+  if (e->fam_spread.D == 0 || e->hist_epoch == e->nodes_epoch) return YKPRED_OK;
+  if (e->comm && e->comm_world > 1)
+    return fail(e, YKPRED_E_STATE, "topology histograms are stale on a sharded engine: run ykpred_eval on every shard first (it sums them across shards)");
+  TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  e->hist_epoch = e->nodes_epoch;
+  return YKPRED_OK;
+}
+
 }  // namespace
 
 // null handles fall through to the entry point's own argument check
@@ -601,6 +680,9 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
+  if (e->comm) (void)rccl()->CommDestroy(e->comm);
+  e->comm = nullptr;
+  for (DevBuf* b : {&e->d_gathered, &e->d_xkey, &e->d_xcand}) b->release();
   for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
   e->graphs.clear();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount, &e->d_ports, &e->d_sig_ports, &e->d_swanted,
@@ -626,6 +708,8 @@ void ykpred_destroy(ykpred_engine_t* e) {
 int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   YK_SERIALISE(e);
   if (e) e->tables_version++;
+  if (e) e->nodes_epoch++;
+  if (e) e->last_eval_valid = false;  // every row and column of an earlier bitmap is stale (and N / row_stride may change)
   if (!e || !n || n->count < 0) return fail(e, YKPRED_E_INVALID, "set_nodes: bad argument");
   if (n->count > 0 && (!n->allocatable || !n->requested || !n->allowed_pods || !n->pod_count || !n->flags || !n->taint_bits ||
                        !n->label_bits))
@@ -670,6 +754,10 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   e->row_words = (e->N + 63) / 64;
   // rows start on 128-byte lines (16 words): a line shared by two rows would be written in two partial pieces
   e->row_stride = std::max(16, (e->row_words + 15) / 16 * 16);
+  if (e->forced_stride) {
+    if (e->forced_stride < e->row_stride) return fail(e, YKPRED_E_INVALID, "set_nodes: ykpred_set_row_stride is smaller than this shard needs");
+    e->row_stride = e->forced_stride;
+  }
   e->nodes_set = true;
   return YKPRED_OK;
 }
@@ -679,6 +767,9 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
   if (e) e->tables_version++;
   if (!e || !n || n->count != 1) return fail(e, YKPRED_E_INVALID, "update_node: count must be 1");
   if (!e->nodes_set || idx < 0 || idx >= e->N) return fail(e, YKPRED_E_INVALID, "update_node: index out of range");
+  for (int k = 0; k < e->KD; ++k)  // validate before any column is overwritten
+    if (n->domain_id[k] >= e->h_domain_sizes[(size_t)k]) return fail(e, YKPRED_E_INVALID, "update_node: new topology domain — re-upload the node table");
+  e->nodes_epoch++;
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   e->rank_valid = false;  // the node's score may move
@@ -697,7 +788,6 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
   for (int w = 0; w < e->W; ++w)
     HIPCHK(hipMemcpyAsync(e->d_labels.as<u64>() + (size_t)w * N + idx, n->label_bits + w, sizeof(u64), hipMemcpyHostToDevice, st));
   for (int k = 0; k < e->KD; ++k) {
-    if (n->domain_id[k] >= e->h_domain_sizes[(size_t)k]) return fail(e, YKPRED_E_INVALID, "update_node: new topology domain — re-upload the node table");
     HIPCHK(hipMemcpyAsync(e->d_domain.as<int>() + (size_t)k * N + idx, n->domain_id + k, sizeof(int), hipMemcpyHostToDevice, st));
   }
   for (int k = 0; k < e->KS; ++k)
@@ -860,6 +950,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   // appended specs that bring no new topology signature leave the device tables and the histograms of the last pass valid
   const bool spread_unchanged = append_only && e->fam_spread.D == old_spread_D && !e->spread_dirty;
   if (!spread_unchanged) e->spread_dirty = true;
+  if (!spread_unchanged) e->nodes_epoch++;  // the histograms of the last pass do not describe the new signatures
   TRY(upload(e, e->d_spec_spread, e->spec_sig_spread.data(), e->spec_sig_spread.size(), st));
   e->fam_res.D = (int)m_res.size();
   e->fam_tol.D = (int)m_tol.size();
@@ -957,8 +1048,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   auto enqueue = [&]() -> int {
   if (spread_on || (a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY)) {
     const bool ready = a->options & YKPRED_EVAL_SPREAD_COUNTS_READY, only = a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY;
-    TRY(run_spread_prefilter(e, st, &tm, !ready, !only));
+    TRY(run_spread_prefilter(e, st, &tm, !ready, false));
     if (only) return 1;
+    if (!ready) TRY(allreduce_spread(e, st));  // node-sharded cluster: the histograms become cluster-wide here
+    TRY(run_spread_prefilter(e, st, &tm, false, true));
+    e->hist_epoch = e->nodes_epoch;
   }
   if (a->options & YKPRED_EVAL_DIRECT) {
     ykk::SpecTable stbl = spec_table(e);
@@ -1145,7 +1239,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   HIPCHK(hipGetLastError());
   return YKPRED_OK;
   };
-  const bool graphable = !tm.on && !e->graph_disabled && !(a->options & (YKPRED_EVAL_DIRECT | YKPRED_EVAL_SPREAD_COUNT_ONLY));
+  const bool graphable = !tm.on && !e->graph_disabled && !(e->comm && e->comm_world > 1) && !(a->options & (YKPRED_EVAL_DIRECT | YKPRED_EVAL_SPREAD_COUNT_ONLY));
   hipGraphExec_t exec = nullptr;
   if (graphable) {
     ykpred_engine::GraphKey key{e->tables_version, pre, filt, a->options, (void*)bitmap, e->last_counts, e->last_decisions, e->last_keys};
@@ -1205,6 +1299,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_eval_valid = true;
   if (!(a->options & YKPRED_EVAL_SKIP_BITMAP)) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
   if (want_dec) e->rank_valid = true;
+  e->last_has_keys = want_keys;
   return YKPRED_OK;
 }
 
@@ -1614,6 +1709,54 @@ int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
   return YKPRED_OK;
 }
 
+int32_t ykpred_read_rows(ykpred_engine_t* e, int32_t n, const int32_t* pods, uint64_t* out) {
+  YK_SERIALISE(e);
+  if (!e || n < 0 || (n > 0 && (!pods || !out))) return fail(e, YKPRED_E_INVALID, "read_rows: bad argument");
+  if (!e->last_bitmap) return fail(e, YKPRED_E_STATE, "read_rows: no eval yet");
+  for (int i = 0; i < n; ++i)
+    if (pods[i] < 0 || pods[i] >= e->P) return fail(e, YKPRED_E_INVALID, "read_rows: pod index out of range");
+  if (n == 0 || e->row_words == 0) return YKPRED_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  hipStream_t st = e->own_stream;
+  const size_t idx_bytes = ((size_t)n * sizeof(int32_t) + 15) / 16 * 16, out_bytes = (size_t)n * (size_t)e->row_words * sizeof(u64);
+  HIPCHK(e->d_scratch.ensure(idx_bytes + out_bytes));
+  char* base = (char*)e->d_scratch.p;
+  HIPCHK(hipMemcpyAsync(base, pods, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(ykk::k_gather_rows, dim3((unsigned)n), dim3(ykk::kBlock), 0, st, (const u64*)e->last_bitmap, n, (const int*)base, e->row_words,
+                     e->row_stride, (u64*)(base + idx_bytes));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, base + idx_bytes, out_bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_read_pod_classes(ykpred_engine_t* e, int32_t* pod_class, int32_t* class_rep) {
+  YK_SERIALISE(e);
+  if (!e) return YKPRED_E_INVALID;
+  if (e->classes_dirty || !e->last_eval_valid) return fail(e, YKPRED_E_STATE, "read_pod_classes: no current evaluation");
+  if (pod_class) std::copy(e->h_pod_class.begin(), e->h_pod_class.begin() + e->P, pod_class);
+  if (class_rep) std::copy(e->h_class_first.begin(), e->h_class_first.begin() + e->C, class_rep);
+  return YKPRED_OK;
+}
+
+int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words) {
+  YK_SERIALISE(e);
+  if (!e || !bad_words) return YKPRED_E_INVALID;
+  if (e->classes_dirty || !e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "check_class_rows: no current evaluation");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(e->d_scratch.ensure(sizeof(u64)));
+  HIPCHK(hipMemsetAsync(e->d_scratch.p, 0, sizeof(u64), e->own_stream));
+  if (e->P && e->row_stride)
+    hipLaunchKernelGGL(ykk::k_check_class_rows, dim3(4096), dim3(ykk::kBlock), 0, e->own_stream, (const u64*)e->last_bitmap, e->P, e->row_words,
+                       e->row_stride, e->d_pod_class.as<int>(), e->d_class_first.as<int>(), e->d_scratch.as<u64>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->own_stream));
+  HIPCHK(hipMemcpy(bad_words, e->d_scratch.p, sizeof(u64), hipMemcpyDeviceToHost));
+  return YKPRED_OK;
+}
+
 int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const int32_t* nodes, uint32_t pre, uint32_t filt, uint8_t* fit,
                      uint8_t* code, uint32_t* reason) {
   YK_SERIALISE(e);
@@ -1632,7 +1775,7 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
   uint32_t* d_r = (uint32_t*)(d_n + n);
   uint8_t* d_f = (uint8_t*)(d_r + n);
   uint8_t* d_c = d_f + n;
-  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(ensure_histograms(e, st));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   HIPCHK(hipMemcpyAsync(d_p, pods, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(d_n, nodes, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1654,7 +1797,7 @@ int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t
   if (e->N == 0) return YKPRED_OK;
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
-  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(ensure_histograms(e, st));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   const size_t N = (size_t)e->N;
   HIPCHK(e->d_scratch.ensure(N * 6 + 64));
@@ -1685,7 +1828,7 @@ int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t nq, const int32_t* p
       return fail(e, YKPRED_E_INVALID, "preemption: index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
-  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(run_spread_prefilter(e, st, nullptr, true, true));
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(ensure_histograms(e, st));
   else if (e->spread_dirty) TRY(build_spread_tables(e, st));
   // scratch layout (8-byte aligned pieces): vreq | ports_after | q_pod | q_node | voff | q_start | out | vpresent
   const size_t vbytes = (size_t)total * (size_t)e->R * sizeof(i64);
@@ -1732,6 +1875,120 @@ int32_t ykpred_preemption_ports(ykpred_engine_t* e, int32_t pod, int32_t node, i
 int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t nv, const int64_t* vreq, const uint8_t* vpresent,
                           int32_t start, uint32_t pre, uint32_t filt, int32_t* out) {
   return ykpred_preemption_ports(e, pod, node, nv, vreq, vpresent, nullptr, start, pre, filt, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU exchanges over RCCL (see ykpred.h)
+// ---------------------------------------------------------------------------------------------------
+int32_t ykpred_comm_unique_id(uint8_t* id) {
+  if (!id) return YKPRED_E_INVALID;
+  Rccl* r = rccl();
+  if (!r->error.empty()) {
+    g_create_error = r->error;
+    return YKPRED_E_DEVICE;
+  }
+  ncclUniqueId u;
+  ncclResult_t s = r->GetUniqueId(&u);
+  if (s != ncclSuccess) {
+    g_create_error = std::string("ncclGetUniqueId: ") + r->GetErrorString(s);
+    return YKPRED_E_DEVICE;
+  }
+  static_assert(sizeof(u) == YKPRED_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(id, &u, sizeof u);
+  return YKPRED_OK;
+}
+
+int32_t ykpred_comm_init(ykpred_engine_t* e, const uint8_t* id, int32_t rank, int32_t world, int32_t node_offset) {
+  YK_SERIALISE(e);
+  if (!e || !id || world < 1 || rank < 0 || rank >= world || node_offset < 0) return fail(e, YKPRED_E_INVALID, "comm_init: bad argument");
+  if (e->comm) return fail(e, YKPRED_E_STATE, "comm_init: a communicator is already attached");
+  Rccl* r = rccl();
+  if (!r->error.empty()) return fail(e, YKPRED_E_DEVICE, r->error);
+  HIPCHK(hipSetDevice(e->cfg.device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  NCCLCHK(r->CommInitRank(&e->comm, world, u, rank));
+  e->comm_rank = rank;
+  e->comm_world = world;
+  e->node_offset = node_offset;
+  e->hist_epoch = 0;  // shard-local histograms are not the cluster's
+  return YKPRED_OK;
+}
+
+int32_t ykpred_comm_destroy(ykpred_engine_t* e) {
+  YK_SERIALISE(e);
+  if (!e) return YKPRED_E_INVALID;
+  if (e->comm) {
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    (void)rccl()->CommDestroy(e->comm);
+    e->comm = nullptr;
+  }
+  e->comm_rank = 0;
+  e->comm_world = 1;
+  e->node_offset = 0;
+  e->hist_epoch = 0;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words) {
+  YK_SERIALISE(e);
+  if (!e || words < 0 || words % 16 != 0) return fail(e, YKPRED_E_INVALID, "set_row_stride: need a multiple of 16 words (0 = automatic)");
+  e->forced_stride = words;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered, void* stream) {
+  YK_SERIALISE(e);
+  if (!e) return YKPRED_E_INVALID;
+  if (!e->comm) return fail(e, YKPRED_E_STATE, "gather_bitmap: no communicator (ykpred_comm_init)");
+  if (!e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "gather_bitmap: no current evaluation");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+  const size_t words = (size_t)e->P * (size_t)e->row_stride;
+  if (!gathered) {
+    HIPCHK(e->d_gathered.ensure(std::max<size_t>(words, 1) * (size_t)e->comm_world * sizeof(u64)));
+    gathered = e->d_gathered.p;
+  }
+  if (words) NCCLCHK(rccl()->AllGather(e->last_bitmap, gathered, words, ncclUint64, e->comm, st));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_exchange_decisions(ykpred_engine_t* e, void* stream) {
+  YK_SERIALISE(e);
+  if (!e) return YKPRED_E_INVALID;
+  if (!e->comm) return fail(e, YKPRED_E_STATE, "exchange_decisions: no communicator (ykpred_comm_init)");
+  if (!e->last_eval_valid || !e->last_has_keys)
+    return fail(e, YKPRED_E_STATE, "exchange_decisions: the last ykpred_eval must have produced counts, decisions and decision keys");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+  const size_t P = (size_t)e->P;
+  if (P == 0) return YKPRED_OK;
+  HIPCHK(e->d_xkey.ensure(P * sizeof(i64)));
+  HIPCHK(e->d_xcand.ensure(P * sizeof(int)));
+  Rccl* r = rccl();
+  NCCLCHK(r->AllReduce(e->last_counts, e->last_counts, P, ncclInt32, ncclSum, e->comm, st));
+  NCCLCHK(r->AllReduce(e->last_keys, e->d_xkey.p, P, ncclInt64, ncclMin, e->comm, st));
+  const unsigned blocks = (unsigned)((P + ykk::kBlock - 1) / ykk::kBlock);
+  hipLaunchKernelGGL(ykk::k_decision_candidates, dim3(blocks), dim3(ykk::kBlock), 0, st, (int)P, (const int*)e->last_decisions,
+                     (const i64*)e->last_keys, e->d_xkey.as<i64>(), e->node_offset, e->d_xcand.as<int>());
+  NCCLCHK(r->AllReduce(e->d_xcand.p, e->d_xcand.p, P, ncclInt32, ncclMin, e->comm, st));
+  hipLaunchKernelGGL(ykk::k_decision_finalize, dim3(blocks), dim3(ykk::kBlock), 0, st, (int)P, e->d_xcand.as<int>(), e->d_xkey.as<i64>(),
+                     (int*)e->last_decisions, (i64*)e->last_keys);
+  HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+}
+
+int32_t ykpred_read_gathered(ykpred_engine_t* e, int32_t shard, int32_t first, int32_t num, uint64_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out || shard < 0 || shard >= e->comm_world || first < 0 || num < 0 || first + num > e->P) return fail(e, YKPRED_E_INVALID, "read_gathered: range");
+  if (!e->d_gathered.p) return fail(e, YKPRED_E_STATE, "read_gathered: no engine-owned gathered bitmap (ykpred_gather_bitmap with gathered = NULL)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  if (num == 0) return YKPRED_OK;
+  const u64* src = e->d_gathered.as<u64>() + ((size_t)shard * (size_t)e->P + (size_t)first) * (size_t)e->row_stride;
+  HIPCHK(hipMemcpy(out, src, (size_t)num * (size_t)e->row_stride * sizeof(u64), hipMemcpyDeviceToHost));
+  return YKPRED_OK;
 }
 
 }  // extern "C"

@@ -1138,4 +1138,51 @@ __global__ __launch_bounds__(kBlock) void k_checksum(const u64* __restrict__ bit
   if (threadIdx.x % kWave == 0) atomicAdd(out, acc);
 }
 
+
+// Decision exchange of a node-sharded cluster (ykpred_exchange_decisions): after the MIN all-reduce of the order keys, the
+// shards that hold a node with the winning key offer its GLOBAL index; a second MIN picks the smallest (ties by node index).
+__global__ __launch_bounds__(kBlock) void k_decision_candidates(int n_pods, const int* __restrict__ decisions, const i64* __restrict__ keys,
+                                                                const i64* __restrict__ best_key, int node_offset, int* __restrict__ cand) {
+  int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pods) return;
+  const int d = decisions[p];
+  cand[p] = (d >= 0 && keys[p] == best_key[p]) ? d + node_offset : 0x7fffffff;
+}
+__global__ __launch_bounds__(kBlock) void k_decision_finalize(int n_pods, const int* __restrict__ cand, const i64* __restrict__ best_key,
+                                                              int* __restrict__ decisions, i64* __restrict__ keys) {
+  int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n_pods) return;
+  decisions[p] = cand[p] == 0x7fffffff ? -1 : cand[p];
+  keys[p] = best_key[p];
+}
+
+// Parity support: (a) every member row must equal the row of its class's representative pod, padding words must be zero —
+// counts the offending words; (b) gather of listed rows into a dense [n][row_words] buffer for readback.
+__global__ __launch_bounds__(kBlock) void k_check_class_rows(const u64* __restrict__ bitmap, int n_pods, int row_words, int row_stride,
+                                                             const int* __restrict__ pod_class, const int* __restrict__ class_first,
+                                                             u64* __restrict__ bad) {
+  const size_t total = (size_t)n_pods * row_stride;
+  u64 acc = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
+    const size_t p = i / row_stride, w = i % row_stride;
+    const u64 x = bitmap[i];
+    if (w >= (size_t)row_words) {
+      acc += x != 0;
+    } else {
+      const int rep = class_first[pod_class[p]];
+      acc += rep < 0 || x != bitmap[(size_t)rep * row_stride + w];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
+  if (threadIdx.x % kWave == 0 && acc) atomicAdd(bad, acc);
+}
+__global__ __launch_bounds__(kBlock) void k_gather_rows(const u64* __restrict__ bitmap, int n, const int* __restrict__ rows, int row_words,
+                                                        int row_stride, u64* __restrict__ out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const u64* src = bitmap + (size_t)rows[i] * row_stride;
+  for (int w = threadIdx.x; w < row_words; w += kBlock) out[(size_t)i * row_words + w] = src[w];
+}
+
 }  // namespace ykk

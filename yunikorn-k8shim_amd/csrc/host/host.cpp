@@ -105,6 +105,7 @@ struct ykhost {
   } answers;
   int last_eval_phase = -1;           // 1 allocate / 0 reserve / -1 none: the phase of the bitmap on the device
   uint32_t last_eval_options = 0;
+  bool dump_compact = false;                 // ykhost_set_dump_compact
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
   int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1, cfgKP = -1;
@@ -1261,6 +1262,12 @@ int32_t ykhost_node_index(const ykhost_t* h, const char* name) {
   return it == h->node_ix.end() ? -1 : it->second;
 }
 
+int32_t ykhost_set_dump_compact(ykhost_t* h, int32_t on) {
+  YKHOST_LOCKED(h);
+  h->dump_compact = on != 0;
+  return 0;
+}
+
 int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len) {
   YKHOST_LOCKED(h);
   std::string o = "{\"nodes\":[";
@@ -1269,7 +1276,7 @@ int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const
     int idx = nodes ? nodes[i] : i;
     if (idx < 0 || idx >= (int)h->nodes.size()) return fail(h, "dump: node index out of range");
     if (i) o.push_back(',');
-    node_json(*h->nodes[(size_t)idx], o);
+    node_json(*h->nodes[(size_t)idx], o, h->dump_compact);
   }
   o += "],\"pods\":[";
   int count_p = pods ? np : (int)h->pending.size();

@@ -508,7 +508,9 @@ inline void pod_json(const Pod& p, std::string& o, int replicas = 1) {
   o += "}";
 }
 
-inline void node_json(const NodeInfo& ni, std::string& o) {
+// compact: runs of pods that share a template (and are not terminating) are written once with "replicas": k — the loaders
+// expand them again (uids get a "#r" suffix). Keeps the snapshot of a 50 000-node cluster at tens of MB.
+inline void node_json(const NodeInfo& ni, std::string& o, bool compact = false) {
   const Node& n = ni.node;
   o += "{\"metadata\":{\"name\":";
   js_str(o, n.name);
@@ -530,9 +532,13 @@ inline void node_json(const NodeInfo& ni, std::string& o) {
   o += "]},\"status\":{\"allocatable\":";
   js_map(o, n.allocatable);
   o += "},\"pods\":[";
-  for (size_t i = 0; i < ni.pods.size(); ++i) {
+  for (size_t i = 0; i < ni.pods.size();) {
     if (i) o.push_back(',');
-    pod_json(*ni.pods[i], o);
+    size_t run = 1;
+    if (compact && !ni.pods[i]->terminating)
+      while (i + run < ni.pods.size() && ni.pods[i + run]->tpl == ni.pods[i]->tpl && !ni.pods[i + run]->terminating) ++run;
+    pod_json(*ni.pods[i], o, (int)run);
+    i += run;
   }
   o += "]}";
 }

@@ -161,8 +161,10 @@ class GpuPredicateManager:
     def node_index(self, name):
         return self._L.ykhost_node_index(self._h, name.encode())
 
-    def dump_snapshot(self, pods=None, nodes=None):
-        """Snapshot JSON (text) of the selected pending pods / nodes — what the oracle is fed in parity tests."""
+    def dump_snapshot(self, pods=None, nodes=None, compact=False):
+        """Snapshot JSON (text) of the selected pending pods / nodes — what the oracle is fed in parity tests. compact: runs
+        of on-node pods sharing a template are written once with "replicas": k."""
+        self._L.ykhost_set_dump_compact(self._h, 1 if compact else 0)
         pa = None if pods is None else np.ascontiguousarray(pods, dtype=np.int32)
         na = None if nodes is None else np.ascontiguousarray(nodes, dtype=np.int32)
         args = (pa.ctypes.data if pa is not None else None, 0 if pa is None else len(pa),
@@ -339,6 +341,27 @@ class GpuPredicateManager:
         out = np.zeros((count, lay.row_words), dtype=np.uint64)
         self._pcheck(self._P.ykpred_read_bitmap(self.engine, first, count, out.ctypes.data))
         return out
+
+    def read_rows(self, pods):
+        """Bitmap rows of the listed pods, [len(pods)][row_words] uint64 (one device gather + one copy)."""
+        pa = np.ascontiguousarray(pods, dtype=np.int32)
+        out = np.zeros((len(pa), self.layout().row_words), dtype=np.uint64)
+        self._pcheck(self._P.ykpred_read_rows(self.engine, len(pa), pa.ctypes.data, out.ctypes.data))
+        return out
+
+    def pod_classes(self):
+        """(pod_class[P], class_rep[C]): the engine's pod → class map and one representative pod per class (-1 = none)."""
+        lay = self.layout()
+        pc = np.zeros(lay.num_pods, dtype=np.int32)
+        rep = np.zeros(lay.num_classes, dtype=np.int32)
+        self._pcheck(self._P.ykpred_read_pod_classes(self.engine, pc.ctypes.data, rep.ctypes.data))
+        return pc, rep
+
+    def check_class_rows(self):
+        """Number of bitmap words that differ from the row of the class representative, plus non-zero padding words."""
+        v = C.c_uint64(0)
+        self._pcheck(self._P.ykpred_check_class_rows(self.engine, C.byref(v)))
+        return v.value
 
     def read_counts(self):
         out = np.zeros(self.layout().num_pods, dtype=np.int32)
