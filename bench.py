@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — pod×node predicate evaluations/s of the MI355X engine on BASELINE.json's metric config.
 
-A "step" is ONE pass of the hot path over one snapshot: every pending ask against every node through the whole
-default allocation-phase Filter set (NodeUnschedulable, NodeName, TaintToleration, NodeAffinity, NodeResourcesFit;
-PodTopologySpread skips — no pod carries hard constraints), producing the P×N feasibility bitmap, the per-pod
-feasible-node count and the per-pod bin-pack decision. Tables are resident in HBM when the timed region starts.
+A "step" is ONE pass of the hot path over one snapshot: every pending ask against every node through the whole default
+allocation-phase Filter set (NodeUnschedulable, NodeName, TaintToleration, NodeAffinity, NodeResourcesFit; the topology
+plugins skip — no ask carries hard constraints unless --spread), producing the P×N feasibility bitmap, the per-ask
+feasible-node count and the per-ask bin-pack decision. Tables are resident in HBM when the timed region starts.
 
-  N = 1   workload = configs[2]: 50 000 nodes × 1 000 000 pods (KWOK-style synthetic, 2 000 pod templates).
-  N > 1   node-axis sharding, WEAK scaling: every rank holds its own 50 000-node shard of a N·50 000-node cluster
-          and the same 1 M asks. The only exchange the path needs for decisions is per-pod (count, best node):
-          one SUM and two MIN all-reduces of P-element vectors over RCCL — not the bitmap (`--gather-bitmap`
-          adds the config-4 style all-gather of shard bitmaps and is reported separately, never in `value`).
+  N = 1   workload = configs[2]: 50 000 nodes × 1 000 000 asks (KWOK-style synthetic, 2 000 pod templates).
+  N > 1   workload = configs[3]: the SAME 50 000 nodes sharded N-way on the node axis (multiple-of-64 shards, one common
+          row stride) × 1 000 000 gang-placeholder asks (10 000 task groups × 100 members) — STRONG scaling. A step =
+          shard evaluation + RCCL all-gather of the shard bitmaps into [N][P][row_stride] + the per-ask decision exchange
+          (SUM count, MIN key, MIN global node), all behind the C ABI (ykpred_gather_bitmap / ykpred_exchange_decisions).
+          `--weak` keeps round 1's weak-scaling variant (50 000 nodes PER GPU, decision exchange only).
 
-Prints ONE JSON line (rank 0). `roofline` describes k_combine, the kernel that writes the bitmap.
+Prints ONE JSON line (rank 0): `value` = whole-job evals/s of the timed steps; `roofline` describes the kernel with the
+largest share of a step (HIP events on the launch stream) and the whole step; `variants` re-times the two other ask
+populations of SURVEY.md §8d (every ask its own template; adversarial distinct request vectors); `end_to_end` is one cold
+pass including encode + upload + class build; `cpu_baseline` is the oracle on the host cores.
 """
 import argparse
 import importlib
@@ -44,18 +48,22 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nodes", type=int, default=50_000, help="nodes per GPU")
+    ap.add_argument("--nodes", type=int, default=50_000, help="nodes of the cluster (with --weak: per GPU)")
     ap.add_argument("--pods", type=int, default=1_000_000)
     ap.add_argument("--templates", type=int, default=2000, help="distinct pod templates (0 = every pod draws its own)")
     ap.add_argument("--unique-requests", action="store_true", help="adversarial: a distinct cpu request per pod")
     ap.add_argument("--no-affinity", action="store_true", help="configs[1] plugin mix (no nodeSelector/affinity on pods)")
     ap.add_argument("--spread", action="store_true", help="configs[4] plugin mix: 10 %% of the templates carry a hard zone-spread constraint")
-    ap.add_argument("--gang", type=int, default=0, help="configs[3] shape: asks are gang placeholders, this many identical members per group")
+    ap.add_argument("--gang", type=int, default=-1, help="asks are gang placeholders, this many identical members per task group "
+                                                          "(default: 0 at N=1, 100 at N>1 = configs[3])")
+    ap.add_argument("--weak", action="store_true", help="N>1: weak scaling, --nodes per GPU, decision exchange only")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the bitmap all-gather out of the step")
     ap.add_argument("--direct", action="store_true", help="time the per-pair kernel instead of the plane/class path")
-    ap.add_argument("--gather-bitmap", action="store_true", help="N>1: also all-gather the shard bitmaps (reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="k_combine store flavour (0 dwordx4, 1 dwordx2, 2/3 = non-temporal)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps run with per-kernel HIP events for `roofline`")
+    ap.add_argument("--no-variants", action="store_true", help="N=1: skip the `variants` and `end_to_end` legs")
+    ap.add_argument("--variant-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -112,14 +120,86 @@ def cpu_baseline(pm, budget_s, seed):
     return out
 
 
+def algorithmic_bytes(pm, lay):
+    """ALGORITHMIC bytes of one pass over the local table: the bitmap written once, the node table, the
+    per-ask ids, the class table and the signature planes read once."""
+    st = pm.stats()
+    b_node = 8 * 2 * st["R"] + 4 + 4 + 4 + 8 * st["KT"] + 8 * st["W"]
+    return (lay.num_pods * lay.row_words * 8 + lay.num_nodes * b_node + lay.num_pods * (4 + 4 + 4) + lay.num_classes * 4 * 4 +
+            lay.plane_rows * lay.row_words * 8)
+
+
+def profile_kernels(pm, run_step, n):
+    kern = {}
+    for _ in range(max(n, 0)):
+        run_step(True)
+        for name, ms in pm.timing()["kernels"]:
+            kern.setdefault(name, []).append(ms)
+    return {k: float(np.mean(v)) for k, v in kern.items()}
+
+
+def roofline_of(kern, algo_bytes, ms_per_step, traffic=None):
+    """The kernel with the largest average duration + the whole step, both against the HBM peak."""
+    if not kern:
+        return None
+    dom = max(kern, key=kern.get)
+    achieved = algo_bytes / (kern[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),
+            "algorithmic_bytes": int(algo_bytes),
+            "whole_step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
+    """A fresh manager on the same GPU: generate, upload, then `steps` timed full passes. Used for `variants` / `end_to_end`."""
+    pm = pkg.GpuPredicateManager(device=dev.index)
+    out = {}
+    try:
+        t0 = time.perf_counter()
+        pm.generate_kwok(**kwok)
+        out["generate_s"] = round(time.perf_counter() - t0, 2)
+        P = pm.num_pods
+        counts = torch.empty(P, dtype=torch.int32, device=dev)
+        decisions = torch.empty(P, dtype=torch.int32, device=dev)
+        # cold pass: encode (objects → dictionaries + tables), upload, pod classes, evaluation
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pm.sync()
+        t_sync = time.perf_counter() - t0
+        pm.evaluate_into(counts=counts, decisions=decisions, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t_cold = time.perf_counter() - t0
+        for _ in range(warmup):
+            pm.evaluate_into(counts=counts, decisions=decisions, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pm.evaluate_into(counts=counts, decisions=decisions, stream=stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        lay = pm.layout()
+        kern = profile_kernels(pm, lambda prof: pm.evaluate_into(counts=counts, decisions=decisions, stream=stream.cuda_stream, profile=prof),
+                               profile_steps)
+        algo = algorithmic_bytes(pm, lay)
+        out.update({"ms_per_step": round(ms, 4), "evals_per_sec": float(P) * lay.num_nodes / (ms * 1e-3), "pod_classes": lay.num_classes,
+                    "signature_planes": lay.plane_rows, "distinct_evals_per_step": lay.num_classes * lay.num_nodes,
+                    "roofline": roofline_of(kern, algo, ms), "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+                    "cold_pass": {"encode_upload_ms": round(t_sync * 1e3, 1), "class_build_and_first_eval_ms": round((t_cold - t_sync) * 1e3, 1),
+                                  "total_ms": round(t_cold * 1e3, 1), "encode_ms": round(pm.stats()["encode_us"] / 1e3, 1)}})
+    finally:
+        pm.close()
+    return out
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    # BENCH_BACKEND=gloo lets the N>1 path be exercised on a single-GPU box (all ranks share cuda:0); the driver's
-    # multi-GPU runs use the default: nccl = RCCL over xGMI, one rank per GPU.
+    # BENCH_BACKEND=gloo lets the N>1 path be exercised on a single-GPU box (all ranks share cuda:0; the exchanges then use
+    # the torch.distributed reference forms — RCCL refuses two ranks on one device). The driver's multi-GPU runs use the
+    # default: one rank per GPU, nccl (= RCCL) for the bootstrap group, the data-path exchanges through the C ABI.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -133,28 +213,61 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     pkg = importlib.import_module("yunikorn-k8shim_amd")
-    from importlib import import_module
-    shard = import_module("yunikorn-k8shim_amd.sharding")
+    shard = importlib.import_module("yunikorn-k8shim_amd.sharding")
+    strong = world > 1 and not a.weak
+    gang = a.gang if a.gang >= 0 else (100 if strong else 0)
+    if strong:
+        ranges = shard.shard_ranges(a.nodes, world)
+        total_nodes = a.nodes
+    else:
+        ranges = [(r * a.nodes, a.nodes) for r in range(world)]
+        total_nodes = a.nodes * world
+    first, count = ranges[rank]
     pm = pkg.GpuPredicateManager(device=local_rank)
     t_gen = time.perf_counter()
-    pm.generate_kwok(seed=SEED + 2, num_nodes=a.nodes, num_pods=a.pods, num_templates=a.templates,
-                     node_affinity=0 if a.no_affinity else 1, unique_requests=1 if a.unique_requests else 0,
-                     node_index_offset=rank * a.nodes, spread=1 if a.spread else 0, gang_size=a.gang)
+    kwok = dict(seed=SEED + 2, num_pods=a.pods, num_templates=a.templates, node_affinity=0 if a.no_affinity else 1,
+                unique_requests=1 if a.unique_requests else 0, spread=1 if a.spread else 0, gang_size=gang)
+    pm.generate_kwok(num_nodes=count, node_index_offset=first, total_nodes=total_nodes, **kwok)
+    if world > 1:
+        pm.set_row_stride(shard.common_row_stride(ranges))
     pm.sync()
     t_gen = time.perf_counter() - t_gen
     P, N = pm.num_pods, pm.num_nodes
 
-    # caller-owned outputs (torch tensors) so that the exchange step can run on them. Two sets: for N>1 the decision
-    # exchange of step k (RCCL all-reduces on a side stream) overlaps the evaluation of step k+1 on the main stream.
+    # ---- the exchanges of the N>1 step: C ABI over RCCL, or (single-GPU test rig / RCCL unavailable) torch.distributed
+    collectives = None
+    if world > 1:
+        collectives = "c-abi rccl"
+        if backend != "nccl" or os.environ.get("BENCH_COLLECTIVES") == "torch":
+            collectives = "torch.distributed reference (" + backend + ")"
+        else:
+            try:
+                shard.attach_communicator(pm, dist, rank, world, first)
+            except Exception as exc:  # noqa: BLE001 - a scaling run must not die on the communicator; the line says what ran
+                collectives = f"torch.distributed fallback (ykpred_comm_init failed: {exc})"
+        flags_all = [None] * world
+        dist.all_gather_object(flags_all, collectives)
+        if any(f != "c-abi rccl" for f in flags_all) and collectives == "c-abi rccl":
+            pm.comm_destroy()  # all ranks must take the same path
+            collectives = "torch.distributed fallback (another rank could not create the communicator)"
+    use_abi = collectives == "c-abi rccl"
+    do_gather = strong and not a.no_gather
+
+    # caller-owned outputs (torch tensors). Two sets at N>1: the exchanges of step k (comm stream) overlap the evaluation of
+    # step k+1 (main stream).
+    lay0 = pm.layout()
     nbuf = 2 if world > 1 else 1
     outs = [(torch.empty(P, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.int32, device=dev),
              torch.empty(P, dtype=torch.int64, device=dev)) for _ in range(nbuf)]
+    bitmaps = [torch.empty((P, lay0.row_stride), dtype=torch.int64, device=dev) for _ in range(nbuf)] if do_gather else [None] * nbuf
+    gathered = torch.empty((world, P, lay0.row_stride), dtype=torch.int64, device=dev) if do_gather else None
     # A dedicated (non-default) stream: the engine launches on the stream it is handed, and handle 0 — torch's default
     # stream — would mean "use the engine's own stream", which the events below could not order against.
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
-    exchanged = [torch.cuda.Event() for _ in range(nbuf)]  # exchange that last used buffer set b has finished
+    exchanged = [torch.cuda.Event() for _ in range(nbuf)]  # the exchange that last used buffer set b has finished
+    gather_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nbuf)]
     step_no = [0]
 
     def step(profile=False):
@@ -163,14 +276,24 @@ def main():
         counts, decisions, keys = outs[b]
         if world > 1:
             stream.wait_event(exchanged[b])  # the eval below overwrites set b: its previous exchange must be done
-        pm.evaluate_into(counts=counts, decisions=decisions, keys=keys if world > 1 else None, stream=stream.cuda_stream,
-                         profile=profile, direct=a.direct, variant=a.variant)
+        pm.evaluate_into(bitmap=bitmaps[b], counts=counts, decisions=decisions, keys=keys if world > 1 else None,
+                         stream=stream.cuda_stream, profile=profile, direct=a.direct, variant=a.variant)
         if world > 1:
             evaluated = torch.cuda.Event()
             evaluated.record(stream)
             comm.wait_event(evaluated)
             with torch.cuda.stream(comm):
-                shard.exchange_decisions(counts, decisions, keys, rank * a.nodes, dist)
+                if do_gather:
+                    gather_ev[b][0].record(comm)
+                    if use_abi:
+                        pm.gather_bitmap(gathered=gathered, stream=comm.cuda_stream)
+                    else:
+                        dist.all_gather_into_tensor(gathered.view(-1), bitmaps[b].view(-1))
+                    gather_ev[b][1].record(comm)
+                if use_abi:
+                    pm.exchange_decisions(stream=comm.cuda_stream)
+                else:
+                    shard.ref_exchange_decisions(counts, decisions, keys, first, dist)
                 exchanged[b].record(comm)
 
     def drain():
@@ -196,63 +319,96 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
 
     lay = pm.layout()
-    # ---- roofline of the dominant kernel (HIP events on the launch stream, bracketing each kernel)
-    kern = {}
-    for _ in range(max(a.profile_steps, 0)):
-        step(profile=True)
+    # ---- roofline (HIP events on the launch stream, bracketing each kernel)
+    def prof_step(prof):
+        step(profile=prof)
         drain()
-        for name, ms in pm.timing()["kernels"]:
-            kern.setdefault(name, []).append(ms)
-    dom = "k_direct" if a.direct else "k_combine"
-    st = pm.stats()
-    b_node = 8 * 2 * st["R"] + 4 + 4 + 4 + 8 * st["KT"] + 8 * st["W"]
-    bitmap_bytes = P * lay.row_words * 8
-    # ALGORITHMIC bytes of one launch: bitmap written once + node table + pod table read once
-    algo_bytes = bitmap_bytes + N * b_node + P * (4 + 4 + 4) + lay.num_classes * 4 * 4 + lay.plane_rows * lay.row_words * 8
-    roof = None
-    if dom in kern:
-        avg_ms = float(np.mean(kern[dom]))
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if tj.get("pods") == P and tj.get("nodes") == N and tj.get("kernel") == dom:
-                traffic = tj.get("hbm_bytes_per_launch")
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes": int(algo_bytes)}
+    kern = profile_kernels(pm, prof_step, a.profile_steps)
+    algo_bytes = algorithmic_bytes(pm, lay)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if tj.get("pods") == P and tj.get("nodes") == N and tj.get("kernel") == (max(kern, key=kern.get) if kern else None):
+            traffic = tj.get("hbm_bytes_per_launch")
+    roof = roofline_of(kern, algo_bytes, ms_per_step, traffic)
 
     gather = None
-    if a.gather_bitmap and dist:
-        gather = shard.time_bitmap_allgather(pm, dist, dev)
+    if do_gather:
+        g_ms = max(gather_ev[b][0].elapsed_time(gather_ev[b][1]) for b in range(nbuf))
+        t = torch.tensor([g_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g_ms = float(t.item())
+        nbytes = P * lay.row_stride * 8
+        gather = {"shard_bytes": nbytes, "ms": round(g_ms, 3), "recv_GBps_per_gpu": round(nbytes * (world - 1) / (g_ms * 1e-3) / 1e9, 1),
+                  "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][P][row_stride] u64 (shard-major)",
+                  "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "
+                          "world-1 peers, per_peer_link = one shard / that time"}
 
     cpu = cpu_baseline(pm, a.cpu_seconds, SEED) if rank == 0 else None
+    stats = pm.stats()
+    if use_abi:
+        pm.comm_destroy()
+    pm.close()
+    del outs, bitmaps, gathered
+    torch.cuda.empty_cache()
+
+    variants = end_to_end = None
+    if rank == 0 and world == 1 and not a.no_variants and not a.direct:
+        base = dict(seed=SEED + 2, num_nodes=a.nodes, num_pods=a.pods, node_affinity=0 if a.no_affinity else 1, spread=1 if a.spread else 0)
+        variants = {}
+        for name, kw in (("own_template_per_ask", dict(num_templates=0)),
+                         ("unique_request_vectors", dict(num_templates=0, unique_requests=1))):
+            try:
+                variants[name] = timed_leg(pkg, dev, stream, a, a.variant_steps, 2, 2, **base, **kw)
+            except Exception as exc:  # noqa: BLE001
+                variants[name] = {"error": str(exc)}
+        try:
+            e2e = timed_leg(pkg, dev, stream, a, 1, 0, 0, **base, num_templates=a.templates, gang_size=gang)
+            end_to_end = dict(e2e["cold_pass"], note="one cold pass of the default workload: objects → dictionaries/tables (encode) → H2D "
+                                                      "upload → pod classes → evaluation, bitmap stays on the device")
+        except Exception as exc:  # noqa: BLE001
+            end_to_end = {"error": str(exc)}
+
     if rank == 0:
-        evals = float(P) * float(N) * world * a.steps
+        evals = float(P) * float(total_nodes) * a.steps
+        if world == 1:
+            workload = ("configs[2]: 50k nodes x 1M pods, NodeResourcesFit + TaintToleration + NodeAffinity"
+                        if (N, P, a.no_affinity, a.spread, gang) == (50_000, 1_000_000, False, False, 0) else
+                        f"{N} nodes x {P} pods, affinity={'off' if a.no_affinity else 'on'}")
+            parallelism = "single GPU"
+        elif strong:
+            workload = (f"configs[3]: {total_nodes} nodes sharded {world}-way x {P} gang-placeholder asks ({gang} members per task group), "
+                        f"bitmap all-gather {'in' if do_gather else 'NOT in'} the step")
+            parallelism = (f"node-axis shards x{world} ({ranges[0][1]} nodes per shard, last {ranges[-1][1]}; row stride {lay.row_stride} words); "
+                           f"all-gather of shard bitmaps + decision exchange of step k overlap the evaluation of step k+1")
+        else:
+            workload = f"weak: {N} nodes/GPU x {P} pods, affinity={'off' if a.no_affinity else 'on'}"
+            parallelism = f"node-axis shards x{world}; per-pod decision exchange of step k overlaps the evaluation of step k+1"
         out = {
             "metric": baseline_metric(), "value": evals / elapsed, "unit": "evals/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": ("configs[2]: 50k nodes x 1M pods, NodeResourcesFit + TaintToleration + NodeAffinity"
-                                    if (N, P, a.no_affinity, a.spread, a.gang) == (50_000, 1_000_000, False, False, 0) else
-                                    f"{N} nodes/GPU x {P} pods, affinity={'off' if a.no_affinity else 'on'}"),
-                       "nodes_per_gpu": N, "pods": P, "templates": a.templates, "pod_classes": lay.num_classes,
-                       "signature_planes": lay.plane_rows, "unique_requests": bool(a.unique_requests), "spread": bool(a.spread), "gang_size": a.gang,
-                       "path": "direct" if a.direct else "planes+combine",
-                       "parallelism": "single GPU" if world == 1 else
-                       f"node-axis shards x{world}; per-pod decision all-reduces of step k overlap the evaluation of step k+1"},
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": workload, "nodes_per_gpu": N, "total_nodes": total_nodes, "pods": P, "templates": a.templates,
+                       "pod_classes": lay.num_classes, "signature_planes": lay.plane_rows, "unique_requests": bool(a.unique_requests),
+                       "spread": bool(a.spread), "gang_size": gang, "path": "direct" if a.direct else "planes+combine",
+                       "parallelism": parallelism, "collectives": collectives},
             "decisions_per_sec": float(P) * a.steps / elapsed,
+            "distinct_evals_per_step": lay.num_classes * N,
             "roofline": roof, "cpu_baseline": cpu,
-            "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in kern.items()},
-            "host_setup_s": round(t_gen, 2), "encode_ms": round(st["encode_us"] / 1e3, 1),
+            "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+            "host_setup_s": round(t_gen, 2), "encode_ms": round(stats["encode_us"] / 1e3, 1),
         }
         if gather:
             out["bitmap_allgather"] = gather
+        if variants is not None:
+            out["variants"] = variants
+        if end_to_end is not None:
+            out["end_to_end"] = end_to_end
         print(json.dumps(out))
-    pm.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

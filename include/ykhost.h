@@ -99,10 +99,13 @@ typedef struct ykhost_kwok {
   int32_t tolerations;     /* 0 = no tolerations and no node taints (config 1), 1 = KWOK taints + tolerations */
   int32_t unique_requests; /* 1 = adversarial: every pod a distinct cpu request (no signature sharing) */
   int32_t gang_size;       /* >0: pods are gang placeholders, `gang_size` identical members per task group */
-  int32_t node_index_offset; /* node-sharded clusters: this shard holds global nodes [offset, offset+num_nodes); node draws
-                                are seeded per global index range, pod draws depend on `seed` only (identical on all shards) */
+  int32_t node_index_offset; /* node-sharded clusters: this shard holds global nodes [offset, offset+num_nodes); every node
+                                draws from a stream keyed by its global index, so a shard holds exactly those nodes of the
+                                unsharded cluster; pod draws depend on `seed` only (identical on all shards) */
   int32_t spread;            /* 1 = 10 % of the templates carry one DoNotSchedule zone-spread constraint (configs[4]) */
-  int32_t reserved[3];
+  int32_t total_nodes;       /* node-sharded clusters: node count of the whole cluster (0 = num_nodes); the asks' node pins
+                                and matchFields names are drawn against it, so every shard holds the same asks */
+  int32_t reserved[2];
 } ykhost_kwok_t;
 int32_t ykhost_generate_kwok(ykhost_t* h, const ykhost_kwok_t* cfg);
 
@@ -126,6 +129,14 @@ int64_t ykhost_encoded_tables_json(ykhost_t* h, char* out, int64_t len);
 /* encode + upload whatever changed since the last sync (called implicitly by the functions below) */
 int32_t ykhost_sync(ykhost_t* h);
 ykpred_engine_t* ykhost_engine(ykhost_t* h); /* the underlying engine, for layout / readback / timing calls */
+
+/* Node-sharded clusters (one handle per GPU, each mirroring a contiguous shard of the nodes and all asks): the shards agree
+ * on one bitmap row stride (that of the largest shard) so that ykpred_gather_bitmap yields the regular layout
+ * [world][P][row_stride]; ykhost_comm_init uploads the tables and attaches the RCCL communicator to the engine
+ * (ykpred_comm_init). The gather / decision exchange are then called on ykhost_engine(h). */
+int32_t ykhost_set_row_stride(ykhost_t* h, int32_t words /* multiple of 16; 0 = automatic */);
+int32_t ykhost_comm_init(ykhost_t* h, const uint8_t* id /* [YKPRED_COMM_ID_BYTES] */, int32_t rank, int32_t world, int32_t node_offset);
+int32_t ykhost_comm_destroy(ykhost_t* h);
 
 /* batched evaluation of every pending ask against every node: phase selects the plugin lists */
 int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options /* YKPRED_OUT_* | YKPRED_EVAL_* */);

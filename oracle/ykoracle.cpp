@@ -35,8 +35,8 @@
 #include <unordered_map>
 #include <vector>
 
-#include "minijson.h"
-#include "quantity.h"
+#include "orc_json.h"
+#include "orc_quantity.h"
 
 namespace orc {
 
@@ -499,35 +499,35 @@ struct Snapshot {
   std::string load_error;
 };
 
-static StrMap read_strmap(const mj::Value* v) {
+static StrMap read_strmap(const oj::Node* v) {
   StrMap out;
   if (v && v->is_obj())
     for (auto& kv : v->obj)
       if (kv.second->is_str() || kv.second->is_num()) out[kv.first] = kv.second->s;
   return out;
 }
-static std::vector<Requirement> read_requirements(const mj::Value* v) {
+static std::vector<Requirement> read_requirements(const oj::Node* v) {
   std::vector<Requirement> out;
   if (v && v->is_arr())
     for (auto& e : v->arr) {
       Requirement r;
       r.key = e->str_or("key", "");
       r.op = e->str_or("operator", "");
-      if (const mj::Value* vals = e->get_nn("values"))
+      if (const oj::Node* vals = e->get_nn("values"))
         for (auto& x : vals->arr) r.values.push_back(x->s);
       out.push_back(std::move(r));
     }
   return out;
 }
-static std::vector<Container> read_containers(const mj::Value* v, bool init, std::string* err) {
+static std::vector<Container> read_containers(const oj::Node* v, bool init, std::string* err) {
   std::vector<Container> out;
   if (v && v->is_arr())
     for (auto& e : v->arr) {
       Container c;
       c.name = e->str_or("name", "");
-      if (const mj::Value* res = e->get_nn("resources")) c.requests = read_strmap(res->get_nn("requests"));
+      if (const oj::Node* res = e->get_nn("resources")) c.requests = read_strmap(res->get_nn("requests"));
       if (init) c.sidecar = e->str_or("restartPolicy", "") == "Always";
-      if (const mj::Value* ports = e->get_nn("ports"))
+      if (const oj::Node* ports = e->get_nn("ports"))
         for (auto& pt : ports->arr) {
           int64_t hp = pt->int_or("hostPort", 0);
           if (hp <= 0) continue;  // "Only return ports with a host port specified"
@@ -544,45 +544,45 @@ static std::vector<Container> read_containers(const mj::Value* v, bool init, std
     }
   return out;
 }
-static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
+static std::unique_ptr<Pod> read_pod(const oj::Node& v, std::string* err) {
   auto p = std::make_unique<Pod>();
-  if (const mj::Value* md = v.get_nn("metadata")) {
+  if (const oj::Node* md = v.get_nn("metadata")) {
     p->name = md->str_or("name", "");
     p->uid = md->str_or("uid", "");
     p->ns = md->str_or("namespace", "");
     p->labels = read_strmap(md->get_nn("labels"));
     p->terminating = md->get_nn("deletionTimestamp") != nullptr;
   }
-  if (const mj::Value* st = v.get_nn("status")) {
+  if (const oj::Node* st = v.get_nn("status")) {
     p->phase = st->str_or("phase", "");
     for (const char* field : {"containerStatuses", "initContainerStatuses"})  // resource.go:65-71: one map, init statuses last
-      if (const mj::Value* css = st->get_nn(field))
+      if (const oj::Node* css = st->get_nn(field))
         for (auto& cs : css->arr) {
           Pod::ContainerStatus out;
           out.allocated = read_strmap(cs->get_nn("allocatedResources"));
-          if (const mj::Value* r = cs->get_nn("resources")) {
+          if (const oj::Node* r = cs->get_nn("resources")) {
             out.has_resources = true;
             out.resources_requests = read_strmap(r->get_nn("requests"));
           }
           p->container_status[cs->str_or("name", "")] = std::move(out);
         }
     p->resize_infeasible = st->str_or("resize", "") == "Infeasible";  // v1.PodResizeStatusInfeasible
-    if (const mj::Value* conds = st->get_nn("conditions"))
+    if (const oj::Node* conds = st->get_nn("conditions"))
       for (auto& c : conds->arr)
         if (c->str_or("type", "") == "PodResizePending" && c->str_or("reason", "") == "Infeasible") p->resize_infeasible = true;
   }
-  const mj::Value* spec = v.get_nn("spec");
+  const oj::Node* spec = v.get_nn("spec");
   if (!spec) return p;
   p->node_name = spec->str_or("nodeName", "");
-  if (const mj::Value* ns = spec->get_nn("nodeSelector")) {
+  if (const oj::Node* ns = spec->get_nn("nodeSelector")) {
     p->has_node_selector = true;
     p->node_selector = read_strmap(ns);
   }
-  if (const mj::Value* aff = spec->get_nn("affinity")) {
-    if (const mj::Value* na = aff->get_nn("nodeAffinity")) {
-      if (const mj::Value* req = na->get_nn("requiredDuringSchedulingIgnoredDuringExecution")) {
+  if (const oj::Node* aff = spec->get_nn("affinity")) {
+    if (const oj::Node* na = aff->get_nn("nodeAffinity")) {
+      if (const oj::Node* req = na->get_nn("requiredDuringSchedulingIgnoredDuringExecution")) {
         p->has_required = true;
-        if (const mj::Value* terms = req->get_nn("nodeSelectorTerms"))
+        if (const oj::Node* terms = req->get_nn("nodeSelectorTerms"))
           for (auto& t : terms->arr) {
             Term term;
             term.exprs = read_requirements(t->get_nn("matchExpressions"));
@@ -591,18 +591,18 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
           }
       }
     }
-    auto read_terms = [&](const mj::Value* pa, std::vector<PodAffinityTerm>* out) {
+    auto read_terms = [&](const oj::Node* pa, std::vector<PodAffinityTerm>* out) {
       if (!pa) return;
-      const mj::Value* req = pa->get_nn("requiredDuringSchedulingIgnoredDuringExecution");
+      const oj::Node* req = pa->get_nn("requiredDuringSchedulingIgnoredDuringExecution");
       if (!req || !req->is_arr()) return;
       for (auto& t : req->arr) {
         PodAffinityTerm term;
-        if (const mj::Value* ls = t->get_nn("labelSelector")) {
+        if (const oj::Node* ls = t->get_nn("labelSelector")) {
           term.selector.present = true;
           term.selector.match_labels = read_strmap(ls->get_nn("matchLabels"));
           term.selector.match_exprs = read_requirements(ls->get_nn("matchExpressions"));
         }
-        if (const mj::Value* nss = t->get_nn("namespaces"))
+        if (const oj::Node* nss = t->get_nn("namespaces"))
           for (auto& x : nss->arr) term.namespaces.push_back(x->s);
         term.has_namespace_selector = t->get_nn("namespaceSelector") != nullptr;
         term.topology_key = t->str_or("topologyKey", "");
@@ -614,7 +614,7 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
     read_terms(aff->get_nn("podAffinity"), &p->pod_affinity);
     read_terms(aff->get_nn("podAntiAffinity"), &p->pod_anti_affinity);
   }
-  if (const mj::Value* tols = spec->get_nn("tolerations"))
+  if (const oj::Node* tols = spec->get_nn("tolerations"))
     for (auto& t : tols->arr) {
       Toleration tol;
       tol.key = t->str_or("key", "");
@@ -625,18 +625,18 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
     }
   p->containers = read_containers(spec->get_nn("containers"), false, err);
   p->init_containers = read_containers(spec->get_nn("initContainers"), true, err);
-  if (const mj::Value* oh = spec->get_nn("overhead")) {
+  if (const oj::Node* oh = spec->get_nn("overhead")) {
     p->has_overhead = true;
     p->overhead = read_strmap(oh);
   }
-  if (const mj::Value* res = spec->get_nn("resources")) p->pod_level_requests = read_strmap(res->get_nn("requests"));
-  if (const mj::Value* tsc = spec->get_nn("topologySpreadConstraints"))
+  if (const oj::Node* res = spec->get_nn("resources")) p->pod_level_requests = read_strmap(res->get_nn("requests"));
+  if (const oj::Node* tsc = spec->get_nn("topologySpreadConstraints"))
     for (auto& c : tsc->arr) {
       SpreadConstraint sc;
       sc.max_skew = static_cast<int32_t>(c->int_or("maxSkew", 1));
       sc.topology_key = c->str_or("topologyKey", "");
       sc.when_unsatisfiable = c->str_or("whenUnsatisfiable", "DoNotSchedule");
-      if (const mj::Value* ls = c->get_nn("labelSelector")) {
+      if (const oj::Node* ls = c->get_nn("labelSelector")) {
         sc.selector.present = true;
         sc.selector.match_labels = read_strmap(ls->get_nn("matchLabels"));
         sc.selector.match_exprs = read_requirements(ls->get_nn("matchExpressions"));
@@ -647,7 +647,7 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
       }
       sc.node_affinity_policy = c->str_or("nodeAffinityPolicy", "Honor");
       sc.node_taints_policy = c->str_or("nodeTaintsPolicy", "Ignore");
-      if (const mj::Value* mk = c->get_nn("matchLabelKeys"))
+      if (const oj::Node* mk = c->get_nn("matchLabelKeys"))
         for (auto& x : mk->arr) sc.match_label_keys.push_back(x->s);
       if (!sc.match_label_keys.empty()) *err = "matchLabelKeys not modelled";
       p->spread.push_back(std::move(sc));
@@ -657,29 +657,29 @@ static std::unique_ptr<Pod> read_pod(const mj::Value& v, std::string* err) {
 
 static Snapshot* load_snapshot(const std::string& text) {
   auto snap = std::make_unique<Snapshot>();
-  mj::ValuePtr root = mj::parse(text);
+  oj::NodePtr root = oj::parse(text);
   std::string err;
   size_t anon = 0;
-  if (const mj::Value* nodes = root->get_nn("nodes")) {
+  if (const oj::Node* nodes = root->get_nn("nodes")) {
     snap->nodes.reserve(nodes->arr.size());
     for (auto& nv : nodes->arr) {
       Node n;
-      if (const mj::Value* md = nv->get_nn("metadata")) {
+      if (const oj::Node* md = nv->get_nn("metadata")) {
         n.name = md->str_or("name", "");
         n.labels = read_strmap(md->get_nn("labels"));
       }
-      if (const mj::Value* spec = nv->get_nn("spec")) {
+      if (const oj::Node* spec = nv->get_nn("spec")) {
         n.unschedulable = spec->bool_or("unschedulable", false);
-        if (const mj::Value* ts = spec->get_nn("taints"))
+        if (const oj::Node* ts = spec->get_nn("taints"))
           for (auto& t : ts->arr) n.taints.push_back({t->str_or("key", ""), t->str_or("value", ""), t->str_or("effect", "")});
       }
-      if (const mj::Value* st = nv->get_nn("status")) n.allocatable = read_strmap(st->get_nn("allocatable"));
+      if (const oj::Node* st = nv->get_nn("status")) n.allocatable = read_strmap(st->get_nn("allocatable"));
       NodeInfo ni;
       ni.set_node(n);
       snap->nodes.push_back(std::move(ni));
       // NodeInfo.Pods: "pods" lists pod objects; an entry may carry "replicas": k (snapshot-format
       // extension) meaning k identical pods with distinct UIDs.
-      if (const mj::Value* pods = nv->get_nn("pods"))
+      if (const oj::Node* pods = nv->get_nn("pods"))
         for (auto& pv : pods->arr) {
           int64_t reps = pv->int_or("replicas", 1);
           for (int64_t r = 0; r < reps; ++r) {
@@ -692,7 +692,7 @@ static Snapshot* load_snapshot(const std::string& text) {
         }
     }
   }
-  if (const mj::Value* pods = root->get_nn("pods"))
+  if (const oj::Node* pods = root->get_nn("pods"))
     for (auto& pv : pods->arr) {
       auto p = read_pod(*pv, &err);
       if (p->uid.empty()) p->uid = "ask-" + std::to_string(anon++);

@@ -41,7 +41,7 @@ def mask_of(names):
 def build():
     src_newer = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(LIB_PATH)
-        for f in ("ykoracle.cpp", "minijson.h", "quantity.h"))
+        for f in ("ykoracle.cpp", "orc_json.h", "orc_quantity.h"))
     if src_newer:
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return LIB_PATH

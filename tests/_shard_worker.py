@@ -1,0 +1,92 @@
+"""Two (or more) ranks of a node-sharded cluster against one single-engine evaluation of the whole cluster. Launched by
+tests/test_gpu_parity.py::test_sharded_cluster_two_ranks through torch.distributed.run.
+
+  >= world GPUs visible: one GPU per rank, every exchange through the C ABI over RCCL (ykpred_comm_init / gather / exchange,
+                         the histogram all-reduce inside ykpred_eval) — the product path.
+  one GPU:               the ranks share cuda:0 (RCCL refuses two ranks on one device) and the torch.distributed
+                         reference forms of the same exchanges run over gloo on host copies.
+Every rank checks: gathered rows == single-engine rows for EVERY ask, exchanged counts / decisions == single-engine ones.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+sharding = importlib.import_module("yunikorn-k8shim_amd.sharding")
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    total_nodes, n_pods = int(sys.argv[1]), int(sys.argv[2])
+    use_rccl = torch.cuda.device_count() >= world and os.environ.get("SHARD_FORCE_GLOO") != "1"
+    device = rank if use_rccl else 0
+    torch.cuda.set_device(device)
+    dist.init_process_group("gloo")
+    kw = dict(seed=0x59554E49 + 77, num_pods=n_pods, num_templates=60, node_affinity=1, spread=1)
+    ranges = sharding.shard_ranges(total_nodes, world)
+    first, count = ranges[rank]
+    pm = pkg.GpuPredicateManager(device=device)
+    pm.generate_kwok(num_nodes=count, node_index_offset=first, total_nodes=total_nodes, **kw)
+    pm.set_row_stride(sharding.common_row_stride(ranges))
+    dev = torch.device("cuda", device)
+    P = n_pods
+    counts = torch.empty(P, dtype=torch.int32, device=dev)
+    decisions = torch.empty(P, dtype=torch.int32, device=dev)
+    keys = torch.empty(P, dtype=torch.int64, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    if use_rccl:
+        sharding.attach_communicator(pm, dist, rank, world, first)
+        pm.evaluate_into(counts=counts, decisions=decisions, keys=keys, stream=stream.cuda_stream)  # sums the histograms itself
+        pm.gather_bitmap(stream=stream.cuda_stream)
+        pm.exchange_decisions(stream=stream.cuda_stream)
+        pm.synchronize()
+        lay = pm.layout()
+        shard_rows = [pm.read_gathered(g) for g in range(world)]
+    else:
+        pm.sync()
+        pm.evaluate_into(spread_count_only=True, stream=stream.cuda_stream)
+        pm.synchronize()
+        c, p = pm.spread_tensors()
+        ch, ph = c.cpu(), p.cpu()
+        sharding.ref_exchange_spread_histograms(ch, ph, dist)
+        c.copy_(ch)
+        p.copy_(ph)
+        torch.cuda.synchronize()
+        lay = pm.layout()
+        local = torch.empty((P, lay.row_stride), dtype=torch.int64, device=dev)
+        pm.evaluate_into(bitmap=local, counts=counts, decisions=decisions, keys=keys, stream=stream.cuda_stream, spread_counts_ready=True)
+        pm.synchronize()
+        g = sharding.ref_gather_bitmap(local.cpu(), dist)
+        shard_rows = [g[s].numpy().view(np.uint64) for s in range(world)]
+        ch, dh, kh = counts.cpu(), decisions.cpu(), keys.cpu()
+        sharding.ref_exchange_decisions(ch, dh, kh, first, dist)
+        counts.copy_(ch)
+        decisions.copy_(dh)
+    rows = sharding.assemble_rows(shard_rows, ranges)
+    # the whole cluster on one engine
+    full = pkg.GpuPredicateManager(device=device)
+    full.generate_kwok(num_nodes=total_nodes, **kw)
+    full.evaluate()
+    want = full.read_bitmap()
+    ok = rows.shape == want.shape and np.array_equal(rows, want)
+    ok_counts = np.array_equal(counts.cpu().numpy(), full.read_counts())
+    ok_dec = np.array_equal(decisions.cpu().numpy(), full.read_decisions())
+    print(f"rank {rank}/{world} {'rccl' if use_rccl else 'gloo-reference'}: rows {ok} counts {ok_counts} decisions {ok_dec} "
+          f"({P} asks x {total_nodes} nodes, stride {lay.row_stride})", flush=True)
+    full.close()
+    dist.barrier()
+    if use_rccl:
+        pm.comm_destroy()
+    pm.close()
+    dist.destroy_process_group()
+    sys.exit(0 if (ok and ok_counts and ok_dec) else 3)
+
+
+if __name__ == "__main__":
+    main()

@@ -846,22 +846,77 @@ def test_full_grid_oracle_parity(pm, n_nodes, n_pods, affinity, gang):
     print(f"full grid {n_pods} x {n_nodes}: {len(rep)} classes x {n_nodes} nodes = {want.size} oracle calls in {t_oracle:.1f} s")
 
 
-def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """The N>1 path of bench.py (node shards + decision exchange) end to end: 2 ranks share this box's GPU, gloo
-    carries the all-reduces (RCCL needs one GPU per rank; the driver's multi-GPU runs use nccl)."""
+@pytest.mark.parametrize("weak", [False, True])
+def test_bench_two_ranks_on_one_gpu(tmp_path, weak):
+    """The N>1 paths of bench.py end to end: 2 ranks share this box's GPU, gloo carries the reference exchanges (RCCL needs
+    one GPU per rank; the driver's multi-GPU runs go through the C ABI). Default = configs[3] shape, strong scaling with the
+    bitmap all-gather in the step; --weak = round 1's variant."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--nodes", "4000", "--pods", "50000", "--cpu-seconds", "0", "--profile-steps", "1"]
+           "--nodes", "4000", "--pods", "50000", "--cpu-seconds", "0", "--profile-steps", "1"] + (["--weak"] if weak else [])
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["nodes_per_gpu"] == 4000 and d["config"]["pods"] == 50000
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["pods"] == 50000
+    if weak:
+        assert d["scaling"] == "weak" and d["config"]["nodes_per_gpu"] == 4000 and d["config"]["total_nodes"] == 8000
+    else:
+        assert d["scaling"] == "strong" and d["config"]["total_nodes"] == 4000 and d["config"]["gang_size"] == 100
+        assert d["config"]["nodes_per_gpu"] == 2048 and d["bitmap_allgather"]["shard_bytes"] == 50000 * 32 * 8
+    assert "reference" in d["config"]["collectives"]
+
+
+@pytest.mark.parametrize("world,total_nodes", [(2, 200), (2, 5000), (3, 1000)])
+def test_sharded_cluster_ranks(world, total_nodes):
+    """BASELINE configs[3] in small: `world` processes hold node shards (unequal, one common row stride) and all asks; the
+    gathered bitmap [G][P][row_stride] must reassemble to the single-engine rows for EVERY ask, the exchanged counts and
+    decisions must equal the single engine's, with hard spread constraints on (cluster-wide histograms). On a box with
+    >= world GPUs the exchanges run through the C ABI over RCCL; on one GPU the torch.distributed reference forms run over
+    gloo (tests/_shard_worker.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + world * 7 + total_nodes % 89), os.path.join(root, "tests", "_shard_worker.py"),
+           str(total_nodes), "700"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    assert out.stdout.count("rows True counts True decisions True") == world, out.stdout[-1500:]
+
+
+def test_rccl_communicator_single_rank():
+    """The C-ABI communicator with world = 1 on this box's GPU: librccl is loaded on first use, the all-gather of a
+    one-shard cluster is the bitmap itself, the decision exchange maps local to global node indices (node_offset)."""
+    import torch
+    pm = pkg.GpuPredicateManager()
+    pm.generate_kwok(seed=99, num_nodes=300, num_pods=400, num_templates=50, node_affinity=1, spread=1)
+    uid = pm.comm_unique_id()
+    assert len(uid) == 128
+    pm.comm_init(uid, 0, 1, 1000)
+    dev = torch.device("cuda", 0)
+    counts = torch.empty(400, dtype=torch.int32, device=dev)
+    decisions = torch.empty(400, dtype=torch.int32, device=dev)
+    keys = torch.empty(400, dtype=torch.int64, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    pm.evaluate_into(counts=counts, decisions=decisions, keys=keys, stream=stream.cuda_stream)
+    pm.synchronize()
+    want_rows, local_dec, local_counts = pm.read_bitmap(), decisions.cpu().numpy().copy(), counts.cpu().numpy().copy()
+    pm.gather_bitmap(stream=stream.cuda_stream)
+    pm.exchange_decisions(stream=stream.cuda_stream)
+    pm.synchronize()
+    lay = pm.layout()
+    assert np.array_equal(pm.read_gathered(0)[:, :lay.row_words], want_rows)
+    assert np.array_equal(counts.cpu().numpy(), local_counts)
+    assert np.array_equal(decisions.cpu().numpy(), np.where(local_dec >= 0, local_dec + 1000, -1))
+    o = orc.Oracle(pm.dump_snapshot())
+    assert np.array_equal(unpack(want_rows, 300), o.eval_grid(threads=8))
+    pm.comm_destroy()
+    pm.close()
 
 
 def test_topology_spread_sharded_histograms():

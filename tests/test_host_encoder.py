@@ -85,3 +85,20 @@ def test_compact_snapshot_dump_is_equivalent(mirror):
     assert np.array_equal(fa, fb) and np.array_equal(pa, pb)
     for n in range(0, 120, 17):
         assert a.node_info(n) == b.node_info(n)
+
+
+def test_kwok_shards_reproduce_the_unsharded_cluster():
+    """generate_kwok(node_index_offset, num_nodes, total_nodes): the shards of a node-sharded cluster hold exactly the nodes
+    of the unsharded one (per-node streams keyed by the global index) and identical asks."""
+    full, a, b = (pkg.GpuPredicateManager(device=-1) for _ in range(3))
+    try:
+        kw = dict(seed=4242, num_pods=80, num_templates=20, node_affinity=1, spread=1)
+        full.generate_kwok(num_nodes=200, **kw)
+        a.generate_kwok(num_nodes=128, node_index_offset=0, total_nodes=200, **kw)
+        b.generate_kwok(num_nodes=72, node_index_offset=128, total_nodes=200, **kw)
+        sf, sa, sb = (json.loads(m.dump_snapshot()) for m in (full, a, b))
+        assert sa["nodes"] + sb["nodes"] == sf["nodes"]
+        assert sa["pods"] == sf["pods"] == sb["pods"]
+    finally:
+        for m in (full, a, b):
+            m.close()

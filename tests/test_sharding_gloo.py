@@ -92,3 +92,43 @@ def test_exchange_spread_histograms_world2(tmp_path):
         pr.append((g.random(64) < 0.5).astype(np.int32))
     assert np.array_equal(got["counts"].numpy(), c[0] + c[1])
     assert np.array_equal(got["present"].numpy(), np.maximum(pr[0], pr[1]))
+
+
+def test_shard_geometry():
+    """configs[3]: 50 000 nodes over 8 GPUs — every shard but the last a multiple of 64 nodes, one common row stride."""
+    r = sharding.shard_ranges(50_000, 8)
+    assert r[0] == (0, 6272) and r[-1] == (43_904, 6096) and sum(c for _, c in r) == 50_000
+    assert all(c % 64 == 0 for _, c in r[:-1]) and all(f == sum(c for _, c in r[:i]) for i, (f, _) in enumerate(r))
+    assert sharding.row_stride_words(6272) == 112 and sharding.row_stride_words(6096) == 96 and sharding.common_row_stride(r) == 112
+    assert sharding.row_stride_words(50_000) == 784 and sharding.row_stride_words(1) == 16
+    assert sharding.shard_ranges(100, 4) == [(0, 64), (64, 36), (100, 0), (100, 0)]
+    assert sharding.shard_ranges(50_000, 1) == [(0, 50_000)]
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranges = sharding.shard_ranges(200, world)  # (0,128), (128,72)
+    stride = sharding.common_row_stride(ranges)
+    rng = np.random.default_rng(1234)  # the same full bitmap on every rank; a rank keeps only its node columns
+    full = rng.random((37, 200)) < 0.3
+    first, count = ranges[rank]
+    local = np.zeros((37, stride * 64), dtype=np.uint8)
+    local[:, :count] = full[:, first:first + count]
+    words = np.packbits(local.reshape(37, stride, 64), axis=2, bitorder="little").view(np.uint64).reshape(37, stride)
+    g = sharding.ref_gather_bitmap(torch.from_numpy(words.view(np.int64)), dist)
+    if rank == 0:
+        rows = sharding.assemble_rows([g[s].numpy().view(np.uint64) for s in range(world)], ranges)
+        torch.save({"rows": torch.from_numpy(rows.view(np.int64)), "full": torch.from_numpy(full)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_bitmap_reference_world2(tmp_path):
+    """The shard-major gathered layout [G][P][row_stride] reassembles to the single-engine rows (unequal shards, common stride)."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_gather_worker, args=(2, 29535, out), nprocs=2, join=True)
+    got = torch.load(out)
+    rows = got["rows"].numpy().view(np.uint64)
+    bits = np.unpackbits(rows.view(np.uint8), axis=1, bitorder="little")[:, :200]
+    assert np.array_equal(bits.astype(bool), got["full"].numpy())

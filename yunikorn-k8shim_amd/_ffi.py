@@ -55,7 +55,8 @@ class YkpredTiming(C.Structure):
 class YkhostKwok(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("num_nodes", C.c_int32), ("num_pods", C.c_int32), ("num_templates", C.c_int32),
                 ("node_affinity", C.c_int32), ("tolerations", C.c_int32), ("unique_requests", C.c_int32),
-                ("gang_size", C.c_int32), ("node_index_offset", C.c_int32), ("spread", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("gang_size", C.c_int32), ("node_index_offset", C.c_int32), ("spread", C.c_int32), ("total_nodes", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 _pred = None
@@ -94,6 +95,13 @@ def load_ykpred():
     L.ykpred_read_rows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.ykpred_read_pod_classes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ykpred_check_class_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ykpred_comm_unique_id.argtypes = [C.c_void_p]
+    L.ykpred_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.ykpred_comm_destroy.argtypes = [C.c_void_p]
+    L.ykpred_set_row_stride.argtypes = [C.c_void_p, C.c_int32]
+    L.ykpred_gather_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_exchange_decisions.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykpred_read_gathered.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.ykpred_query.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p]
     L.ykpred_preemption_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -137,6 +145,9 @@ def load_ykhost():
     L.ykhost_dump_snapshot.restype = C.c_int64
     L.ykhost_dump_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
     L.ykhost_set_dump_compact.argtypes = [C.c_void_p, C.c_int32]
+    L.ykhost_set_row_stride.argtypes = [C.c_void_p, C.c_int32]
+    L.ykhost_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    L.ykhost_comm_destroy.argtypes = [C.c_void_p]
     L.ykhost_sync.argtypes = [C.c_void_p]
     L.ykhost_encoded_tables_json.restype = C.c_int64
     L.ykhost_encoded_tables_json.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]

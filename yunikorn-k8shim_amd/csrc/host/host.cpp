@@ -106,6 +106,8 @@ struct ykhost {
   int last_eval_phase = -1;           // 1 allocate / 0 reserve / -1 none: the phase of the bitmap on the device
   uint32_t last_eval_options = 0;
   bool dump_compact = false;                 // ykhost_set_dump_compact
+  int row_stride_words = 0;                  // ykhost_set_row_stride: bitmap row stride shared by the shards of a cluster
+  bool comm_attached = false;                // ykhost_comm_init: the engine carries an RCCL communicator
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
   int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1, cfgKP = -1;
@@ -183,6 +185,9 @@ int recreate_engine(ykhost* h) {
   if (h->eng && h->cfgR == h->enc.R && h->cfgKT == h->enc.KT && h->cfgW == h->enc.W && h->cfgKD == h->enc.KD && h->cfgKS == h->enc.KS &&
       h->cfgKP == h->enc.KP)
     return 0;
+  if (h->eng && h->comm_attached)
+    return fail(h, "the dictionary shape changed on an engine that carries an RCCL communicator: the shard has to be re-created "
+                   "(ykhost_comm_init is collective and cannot be repeated silently)", YKPRED_E_STATE);
   if (h->eng) ykpred_destroy(h->eng);
   h->eng = nullptr;
   if (h->device < 0) return fail(h, "mirror-only handle (device < 0): no device engine, nothing can be evaluated", YKPRED_E_STATE);
@@ -362,6 +367,8 @@ int full_sync(ykhost* h) {
   if (rc) return rc;
   rc = recreate_engine(h);
   if (rc) return rc;
+  rc = ykpred_set_row_stride(h->eng, h->row_stride_words);
+  if (rc) return fail(h, std::string("ykpred_set_row_stride: ") + ykpred_last_error(h->eng), rc);
   rc = ykpred_set_nodes(h->eng, &T.nt);
   if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
   rc = ykpred_set_specs(h->eng, &T.sp);
@@ -730,10 +737,13 @@ PodTemplate draw_template(Rng& g, const ykhost_kwok_t& c, int n_nodes) {
 int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
   h->clear_state();
   h->uid_index = false;
-  Rng g{(c.seed ^ 0x4e4f444553ull) + (uint64_t)c.node_index_offset * 0x9e3779b97f4a7c15ull};  // node stream
+  Rng g{0};
   const int N = c.num_nodes, P = c.num_pods;
-  // ---- nodes
+  // ---- nodes: every node draws from its own stream, keyed by its GLOBAL index, so that any sharding of a cluster
+  // (node_index_offset, num_nodes) reproduces exactly the nodes of the unsharded one
   for (int n = 0; n < N; ++n) {
+    g = Rng{(c.seed ^ 0x4e4f444553ull) + (uint64_t)(c.node_index_offset + n) * 0xd1342543de82ef95ull};
+    g.next();
     Node nd;
     nd.name = fmt("kwok-node-%06d", c.node_index_offset + n);
     bool big = g.chance(80, 100);
@@ -784,7 +794,7 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
       a.containers.push_back(ct);
       const PodTemplate* at = h->pool.intern(std::move(a));
       Pod p;
-      p.uid = p.name = fmt("n%d-p0", n);
+      p.uid = p.name = fmt("n%d-p0", c.node_index_offset + n);
       p.node_name = p.assigned_node = nd.name;
       p.tpl = at;
       h->pod_store.push_back(std::move(p));
@@ -798,7 +808,7 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
       const PodTemplate* bt = h->pool.intern(std::move(b));
       for (int i = 1; i < k; ++i) {
         Pod q;
-        q.uid = q.name = "n" + std::to_string(n) + "-p" + std::to_string(i);
+        q.uid = q.name = "n" + std::to_string(c.node_index_offset + n) + "-p" + std::to_string(i);
         q.node_name = q.assigned_node = nd.name;
         q.tpl = bt;
         h->pod_store.push_back(std::move(q));
@@ -811,22 +821,23 @@ int generate_kwok(ykhost* h, const ykhost_kwok_t& c) {
   std::vector<const PodTemplate*> tpls;
   int T = c.num_templates;
   if (c.gang_size > 0) T = (P + c.gang_size - 1) / c.gang_size;
-  for (int i = 0; i < T; ++i) tpls.push_back(h->pool.intern(draw_template(g, c, N)));
+  const int NT = c.total_nodes > 0 ? c.total_nodes : N;  // asks are drawn against the WHOLE cluster: identical on every shard
+  for (int i = 0; i < T; ++i) tpls.push_back(h->pool.intern(draw_template(g, c, NT)));
   for (int p = 0; p < P; ++p) {
     Pod pod;
     pod.uid = pod.name = fmt("pod-%07d", p);
     if (c.unique_requests) {
-      PodTemplate t = draw_template(g, c, N);
+      PodTemplate t = draw_template(g, c, NT);
       t.containers[0].requests["cpu"] = std::to_string(p + 1) + "m";
       pod.tpl = h->pool.intern(std::move(t));
     } else if (T > 0) {
       pod.tpl = c.gang_size > 0 ? tpls[(size_t)(p / c.gang_size)] : tpls[(size_t)(p % T)];
     } else {
-      pod.tpl = h->pool.intern(draw_template(g, c, N));
+      pod.tpl = h->pool.intern(draw_template(g, c, NT));
     }
     uint32_t pin = g.below(10000);
-    if (N > 0 && pin < 10)
-      pod.node_name = fmt("kwok-node-%06d", (int)g.below((uint32_t)N));  // a GLOBAL name of shard 0's range
+    if (NT > 0 && pin < 10)
+      pod.node_name = fmt("kwok-node-%06d", (int)g.below((uint32_t)NT));  // a GLOBAL node name (on another shard: unknown here)
     else if (pin == 10)
       pod.node_name = "no-such-node";
     pod.ask = true;
@@ -1356,6 +1367,31 @@ int64_t ykhost_encoded_tables_json(ykhost_t* h, char* out, int64_t len) {
 }
 
 int32_t ykhost_sync(ykhost_t* h) { YKHOST_LOCKED(h); return sync(h); }
+
+int32_t ykhost_set_row_stride(ykhost_t* h, int32_t words) {
+  YKHOST_LOCKED(h);
+  if (words < 0 || words % 16 != 0) return fail(h, "row stride must be a multiple of 16 words (0 = automatic)");
+  if (words != h->row_stride_words) h->dirty_all = true;
+  h->row_stride_words = words;
+  return 0;
+}
+
+int32_t ykhost_comm_init(ykhost_t* h, const uint8_t* id, int32_t rank, int32_t world, int32_t node_offset) {
+  YKHOST_LOCKED(h);
+  int rc = sync(h);  // the engine of the final dictionary shape must exist before the communicator is attached to it
+  if (rc) return rc;
+  rc = ykpred_comm_init(h->eng, id, rank, world, node_offset);
+  if (rc) return fail(h, std::string("ykpred_comm_init: ") + ykpred_last_error(h->eng), rc);
+  h->comm_attached = true;
+  return 0;
+}
+
+int32_t ykhost_comm_destroy(ykhost_t* h) {
+  YKHOST_LOCKED(h);
+  if (h->eng) ykpred_comm_destroy(h->eng);
+  h->comm_attached = false;
+  return 0;
+}
 ykpred_engine_t* ykhost_engine(ykhost_t* h) { return h->eng; }
 
 int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {

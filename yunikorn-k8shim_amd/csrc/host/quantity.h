@@ -100,33 +100,62 @@ inline Quantity parse_quantity(const std::string& s) {
   return q;
 }
 
+// |q| * 10^(-scale10) split EXACTLY into an integer part (saturating at 2^64) and "a non-zero fraction remains".
+// The value is mant * 2^bin_shift * 10^dec_exp. With a negative decimal exponent the binary shift is applied to the pair
+// (quotient, remainder) of the division by 10^k, one bit at a time: nothing is ever rounded or saturated before the final
+// magnitude is known (a 25-digit fraction with an Ei suffix needs ~160 bits as a plain product).
+struct Magnitude {
+  unsigned __int128 whole = 0;
+  bool fraction = false, huge = false;  // huge: whole part >= 2^64 (saturates every int64 use)
+};
+inline Magnitude quantity_magnitude(const Quantity& q, int scale10) {
+  Magnitude out;
+  unsigned __int128 m = static_cast<unsigned __int128>(q.mant < 0 ? -q.mant : q.mant);
+  const unsigned __int128 cap = static_cast<unsigned __int128>(1) << 64;
+  const int e = q.dec_exp - scale10;
+  if (m == 0) return out;
+  if (e >= 0) {
+    for (int i = 0; i < e && !out.huge; ++i) {
+      m *= 10;  // m < 2^101 here: no wrap before the cap test
+      if (m >= cap) out.huge = true;
+    }
+    for (int i = 0; i < q.bin_shift && !out.huge; ++i) {
+      m *= 2;
+      if (m >= cap) out.huge = true;
+    }
+    out.whole = m;
+    return out;
+  }
+  const int k = -e;
+  if (k > 38) {  // only reachable with a decimal suffix (no binary shift): 0 < value < 1
+    out.fraction = true;
+    return out;
+  }
+  unsigned __int128 p = 1;
+  for (int i = 0; i < k; ++i) p *= 10;  // <= 10^38 < 2^127
+  unsigned __int128 whole = m / p, rem = m % p;
+  for (int i = 0; i < q.bin_shift && !out.huge; ++i) {
+    rem *= 2;  // < 2^128
+    const bool carry = rem >= p;
+    if (carry) rem -= p;
+    whole = whole * 2 + (carry ? 1 : 0);
+    if (whole >= cap) out.huge = true;
+  }
+  out.whole = whole;
+  out.fraction = rem != 0;
+  return out;
+}
+
 // value * 10^(-scale10) as int64, rounding away from zero, saturating.
 inline int64_t scaled_value(const Quantity& q, int scale10) {
   const int64_t kMax = std::numeric_limits<int64_t>::max();
   if (!q.ok || q.mant == 0) return 0;
-  bool neg = q.mant < 0;
-  __int128 m = neg ? -q.mant : q.mant;
-  const __int128 lim = static_cast<__int128>(1) << 120;
-  for (int i = 0; i < q.bin_shift; ++i) {
-    if (m >= lim / 2) return neg ? -kMax : kMax;
-    m *= 2;
-  }
-  int e = q.dec_exp - scale10;
-  bool inexact = false;
-  while (e > 0) {
-    if (m >= lim / 10) return neg ? -kMax : kMax;
-    m *= 10;
-    --e;
-  }
-  while (e < 0 && m != 0) {
-    if (m % 10 != 0) inexact = true;
-    m /= 10;
-    ++e;
-  }
-  if (inexact) m += 1;
-  if (m > static_cast<__int128>(kMax)) return neg ? -kMax : kMax;
-  int64_t v = static_cast<int64_t>(m);
-  return neg ? -v : v;
+  const bool neg = q.mant < 0;
+  const Magnitude g = quantity_magnitude(q, scale10);
+  if (g.huge) return neg ? -kMax : kMax;
+  const unsigned __int128 v = g.whole + (g.fraction ? 1 : 0);
+  if (v > static_cast<unsigned __int128>(kMax)) return neg ? -kMax : kMax;
+  return neg ? -static_cast<int64_t>(v) : static_cast<int64_t>(v);
 }
 
 // Exact sign of (q − bound): resource.Quantity.CmpInt64 (no rounding, no saturation).
@@ -135,36 +164,15 @@ inline int quantity_cmp_int64(const Quantity& q, int64_t bound) {
   if (q.mant == 0) return bound > 0 ? -1 : (bound < 0 ? 1 : 0);
   const bool neg = q.mant < 0;
   if (neg != (bound < 0)) return neg ? -1 : 1;  // different signs (bound == 0 counts as non-negative)
-  __int128 m = neg ? -q.mant : q.mant;
-  __int128 b = bound < 0 ? -static_cast<__int128>(bound) : static_cast<__int128>(bound);
-  const __int128 lim = static_cast<__int128>(1) << 120;
-  int mag = 0;  // sign of (|q| − |bound|)
-  bool decided = false;
-  for (int i = 0; i < q.bin_shift && !decided; ++i) {
-    if (m >= lim / 2) {
-      mag = 1;
-      decided = true;
-    } else {
-      m *= 2;
-    }
-  }
-  for (int e = q.dec_exp; e > 0 && !decided; --e) {
-    if (m >= lim / 10) {
-      mag = 1;
-      decided = true;
-    } else {
-      m *= 10;
-    }
-  }
-  for (int e = q.dec_exp; e < 0 && !decided; ++e) {
-    if (b >= lim / 10) {
-      mag = -1;
-      decided = true;
-    } else {
-      b *= 10;
-    }
-  }
-  if (!decided) mag = m > b ? 1 : (m < b ? -1 : 0);
+  const unsigned __int128 b = bound < 0 ? static_cast<unsigned __int128>(-static_cast<__int128>(bound)) : static_cast<unsigned __int128>(bound);
+  const Magnitude g = quantity_magnitude(q, 0);
+  int mag;  // sign of (|q| − |bound|)
+  if (g.huge || g.whole > b)
+    mag = 1;
+  else if (g.whole < b)
+    mag = -1;
+  else
+    mag = g.fraction ? 1 : 0;
   return neg ? -mag : mag;
 }
 

@@ -141,10 +141,10 @@ class GpuPredicateManager:
         return None if c < 0 else c
 
     def generate_kwok(self, seed, num_nodes, num_pods, num_templates=0, node_affinity=1, tolerations=1, unique_requests=0,
-                      gang_size=0, node_index_offset=0, spread=0):
+                      gang_size=0, node_index_offset=0, spread=0, total_nodes=0):
         cfg = _ffi.YkhostKwok(seed=seed, num_nodes=num_nodes, num_pods=num_pods, num_templates=num_templates,
                               node_affinity=node_affinity, tolerations=tolerations, unique_requests=unique_requests,
-                              gang_size=gang_size, node_index_offset=node_index_offset, spread=spread)
+                              gang_size=gang_size, node_index_offset=node_index_offset, spread=spread, total_nodes=total_nodes)
         self._check(self._L.ykhost_generate_kwok(self._h, C.byref(cfg)))
 
     @property
@@ -304,6 +304,42 @@ class GpuPredicateManager:
         a.decision_keys = None if keys is None else keys.data_ptr()
         a.stream = stream
         self._pcheck(self._P.ykpred_eval(self.engine, C.byref(a)))
+
+    # ---- node-sharded clusters: RCCL exchanges behind the C ABI (include/ykpred.h) ---------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId through the C ABI: 128 bytes that rank 0 hands to the other shard processes out of band."""
+        P = _ffi.load_ykpred()
+        buf = (C.c_uint8 * 128)()
+        if P.ykpred_comm_unique_id(buf) != 0:
+            raise RuntimeError("ykpred_comm_unique_id: " + P.ykpred_last_error(None).decode())
+        return bytes(buf)
+
+    def set_row_stride(self, words):
+        self._check(self._L.ykhost_set_row_stride(self._h, words))
+
+    def comm_init(self, unique_id, rank, world, node_offset):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self._L.ykhost_comm_init(self._h, buf, rank, world, node_offset))
+
+    def comm_destroy(self):
+        self._check(self._L.ykhost_comm_destroy(self._h))
+
+    def gather_bitmap(self, gathered=None, stream=None):
+        """All-gather of the shard bitmaps of the last evaluation into [world][P][row_stride] (device; engine-owned when
+        `gathered` is None), on `stream`."""
+        self._pcheck(self._P.ykpred_gather_bitmap(self.engine, None if gathered is None else gathered.data_ptr(), stream))
+
+    def exchange_decisions(self, stream=None):
+        """In place on the last evaluation's outputs: cluster-wide counts and GLOBAL best node per ask."""
+        self._pcheck(self._P.ykpred_exchange_decisions(self.engine, stream))
+
+    def read_gathered(self, shard, first=0, count=None):
+        lay = self.layout()
+        count = lay.num_pods - first if count is None else count
+        out = np.zeros((count, lay.row_stride), dtype=np.uint64)
+        self._pcheck(self._P.ykpred_read_gathered(self.engine, shard, first, count, out.ctypes.data))
+        return out
 
     def spread_tensors(self):
         """(counts, present) int32 torch tensors VIEWING the engine's PodTopologySpread histograms on the device

@@ -1,27 +1,64 @@
-"""Node-axis sharding across the GPUs of one box (one process per GPU, torch.distributed over RCCL/xGMI).
+"""Node-axis sharding across the GPUs of one box: one process per GPU, each holding a contiguous shard of the node table
+and the full ask table.
 
-Every (pod,node) pair is independent for NodeResourcesFit / TaintToleration / NodeAffinity / NodeUnschedulable /
-NodeName, so each rank evaluates all asks against its own contiguous shard of nodes with no data-path collective.
-What the path does exchange:
-  * decisions: per pod (feasible count, best node) — a SUM and two MIN all-reduces of P-element vectors
-    (exchange_decisions), ≈16 MB per rank for 1 M asks;
-  * optionally the shard bitmaps themselves (config 4 of BASELINE.json): all_gather_into_tensor of
-    [P][row_stride] u64 per rank into the shard-major layout [G][P][row_stride].
-torch is plumbing here (device tensors + the collective); the verdicts come from the engine.
+Every (ask, node) pair is independent, so a shard produces its bitmap columns with no data-path collective. The exchanges
+of the path live BEHIND THE C ABI (include/ykpred.h: ykpred_comm_init, ykpred_gather_bitmap, ykpred_exchange_decisions, and
+the histogram all-reduce inside ykpred_eval) and run over RCCL / xGMI on the engine's streams:
+
+  * bitmaps (BASELINE configs[3]): all-gather of the shard bitmaps into the shard-major layout [G][P][row_stride];
+  * decisions: per ask (feasible count, best node) — SUM, MIN order key, MIN global node index;
+  * PodTopologySpread / InterPodAffinity: SUM / MAX of the per-shard histograms between the count and min passes.
+
+This module holds the glue a host needs around them (shard geometry, bootstrap of the communicator id, row assembly) and
+torch.distributed REFERENCE forms of the same exchanges (`ref_*`): they are what the world-size-2 tests use on machines
+where RCCL cannot run (gloo on CPU; two ranks sharing one GPU) and what the product path is checked against.
 """
-import time
-
+import numpy as np
 import torch
 
 INT32_MAX = 2**31 - 1
 
 
-def exchange_decisions(counts, decisions, keys, node_offset, dist):
-    """In place: counts → cluster-wide feasible counts; decisions → GLOBAL node index of the best feasible node
-    (bin-pack order, ties by global node index) or -1.
+# ---- shard geometry ----------------------------------------------------------------------------------------------------
+def shard_ranges(total_nodes, world):
+    """Contiguous node ranges [(first, count)] — every shard but the last is a multiple of 64 nodes so that bitmap words
+    never straddle two shards and the gathered rows concatenate word by word."""
+    per = -(-total_nodes // world)
+    per = -(-per // 64) * 64
+    out, first = [], 0
+    for _ in range(world):
+        count = max(0, min(per, total_nodes - first))
+        out.append((first, count))
+        first += count
+    return out
 
-    counts int32[P], decisions int32[P] (local node index or -1), keys int64[P] (order key of the local best,
-    INT64_MAX if none) are this rank's outputs of ykpred_eval; node_offset = global index of local node 0."""
+
+def row_stride_words(num_nodes):
+    """The engine's automatic row stride for a node count: ceil(N/64) words rounded up to 16 words (128 B), at least 16."""
+    return max(16, -(-(-(-num_nodes // 64)) // 16) * 16)
+
+
+def common_row_stride(ranges):
+    return max(row_stride_words(count) for _, count in ranges)
+
+
+def attach_communicator(pm, dist, rank, world, node_offset):
+    """Rank 0 draws the RCCL unique id through the C ABI, the bootstrap group broadcasts it, every rank attaches."""
+    box = [pm.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    pm.comm_init(box[0], rank, world, node_offset)
+
+
+def assemble_rows(shard_rows, ranges):
+    """Rows in canonical (global) node order from per-shard rows: shard_rows[g] is [n][>= ceil(count_g/64)] uint64."""
+    parts = [np.asarray(rows)[:, : -(-count // 64)] for rows, (_, count) in zip(shard_rows, ranges) if count > 0]
+    return np.concatenate(parts, axis=1)
+
+
+# ---- torch.distributed reference forms (tests; fallback when the C-ABI communicator cannot be created) ---------------------
+def ref_exchange_decisions(counts, decisions, keys, node_offset, dist):
+    """In place: counts → cluster-wide feasible counts; decisions → GLOBAL node index of the best feasible node
+    (bin-pack order, ties by global node index) or -1. Same contract as ykpred_exchange_decisions."""
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     best_key = keys.clone()
     dist.all_reduce(best_key, op=dist.ReduceOp.MIN)
@@ -29,43 +66,30 @@ def exchange_decisions(counts, decisions, keys, node_offset, dist):
     cand = torch.where(mine, decisions + node_offset, torch.full_like(decisions, INT32_MAX))
     dist.all_reduce(cand, op=dist.ReduceOp.MIN)
     decisions.copy_(torch.where(cand == INT32_MAX, torch.full_like(cand, -1), cand))
+    keys.copy_(best_key)
     return counts, decisions
 
 
-def exchange_spread_histograms(counts, present, dist):
-    """PodTopologySpread on a node-sharded cluster: every shard builds partial per-(constraint, domain) histograms
-    over ITS nodes (ykpred_eval with YKPRED_EVAL_SPREAD_COUNT_ONLY); the cluster-wide PreFilter state is their SUM
-    (matching pods) and MAX (domain present on some eligible node). Afterwards each shard evaluates with
-    YKPRED_EVAL_SPREAD_COUNTS_READY. Requires identical topology-domain dictionaries on all shards (the host side
-    builds them from the whole cluster). In place; KBs of traffic."""
+def ref_exchange_spread_histograms(counts, present, dist):
+    """SUM of matching pods, MAX of "domain present" over the shards (what ykpred_eval does on an engine with a communicator)."""
     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     dist.all_reduce(present, op=dist.ReduceOp.MAX)
     return counts, present
 
 
-def gathered_row(gathered, pod, num_shards, row_words):
-    """Row of `pod` in the canonical node order from the shard-major gathered layout [G][P][row_stride]."""
-    return torch.cat([gathered[g, pod, :row_words] for g in range(num_shards)])
-
-
-def time_bitmap_allgather(pm, dist, dev, repeats=3):
-    """Evaluates into a torch-owned bitmap and times the RCCL all-gather of the shard bitmaps (BASELINE config 4)."""
-    lay = pm.layout()
+def ref_gather_bitmap(local, dist):
+    """all_gather of [P][row_stride] int64 shard bitmaps into [G][P][row_stride] (same layout as ykpred_gather_bitmap)."""
     world = dist.get_world_size()
-    local = torch.empty((lay.num_pods, lay.row_stride), dtype=torch.int64, device=dev)
-    pm.evaluate_into(bitmap=local, stream=torch.cuda.current_stream(dev).cuda_stream)
-    out = torch.empty((world, lay.num_pods, lay.row_stride), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize(dev)
-    dist.barrier()
-    times = []
-    for _ in range(repeats):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        dist.all_gather_into_tensor(out.view(-1), local.view(-1))
-        torch.cuda.synchronize(dev)
-        times.append(time.perf_counter() - t0)
-    t = torch.tensor([min(times)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    nbytes = local.numel() * 8
-    return {"shard_bytes": nbytes, "ms": float(t.item()) * 1e3, "recv_GBps_per_gpu": nbytes * (world - 1) / float(t.item()) / 1e9,
-            "layout": "[G][P][row_stride] u64 (shard-major)"}
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
+    return out
+
+
+# names kept for callers of the round-1 module
+exchange_decisions = ref_exchange_decisions
+exchange_spread_histograms = ref_exchange_spread_histograms
+
+
+def gathered_row(gathered, pod, num_shards, row_words):
+    """Row of `pod` in the canonical node order from the shard-major gathered layout [G][P][row_stride] (equal shards)."""
+    return torch.cat([gathered[g, pod, :row_words] for g in range(num_shards)])
