@@ -101,8 +101,10 @@ typedef struct ykpred_config {
   int32_t topology_keys;    /* KD >= 0: topology keys used by hard spread constraints */
   int32_t selector_classes; /* KS >= 0: distinct (namespace, labelSelector) classes of spread constraints */
   int32_t port_words;       /* KP >= 0: 64-bit words of the host-port dictionary (NodePorts) */
-  int32_t reserved[8];      /* [0..3]: engine tunables for experiments, 0 = defaults; [3] == 1 replays a repeated
-                               ykpred_eval as a hipGraph (opt-in: measured equal to plain launches) */
+  int32_t reserved[8];      /* [0..4]: engine tunables for experiments, 0 = defaults; [3] == 1 replays a repeated
+                               ykpred_eval as a hipGraph (opt-in: measured equal to plain launches); [4] = number of distinct
+                               request values per resource dimension from which the sorted-walk plane kernels are used (256);
+                               [5] = average members per combine chunk below which the wave-per-chunk combine runs (16, -1 never) */
 } ykpred_config_t;
 
 /* Node table, structure-of-arrays. Arrays documented [A][count] are A consecutive runs of `count` values. */

@@ -192,6 +192,45 @@ def test_random_clusters_full_grid(pm, seed, allocate):
     check_against_oracle(pm, snap, allocate)
 
 
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("walk_rows", [1, 3])
+def test_request_value_planes_sorted_walk(monkeypatch, seed, walk_rows):
+    """NodeResourcesFit planes are kept per (dimension, distinct request value); dimensions with many distinct values are
+    evaluated by the sorted walk (k_dim_sort / k_dim_walk) instead of one compare per (value, node). YKPRED_WALK_ROWS forces
+    that path at test sizes: random clusters with scalar resources (> 4 dimensions), over-committed nodes (negative free),
+    zero and absent requests, word-boundary node counts — bits, counts, failing plugins and decisions against the oracle,
+    both phases, and NodeResourcesFit alone (so that every verdict is that plugin's)."""
+    monkeypatch.setenv("YKPRED_WALK_ROWS", str(walk_rows))
+    snap = _gen.random_snapshot(8800 + seed, n_nodes=[63, 64, 65, 129, 200, 333][seed], n_pods=90, scalars=True)
+    for plugins in (["*"], ["NodeResourcesFit"]):
+        m = pkg.GpuPredicateManager.internal(plugins, plugins, plugins, plugins)
+        try:
+            m.load_snapshot(snap)
+            mask = orc.ALL if plugins == ["*"] else orc.mask_of(plugins)
+            o, want = check_against_oracle(m, snap, True, pre=mask, filt=mask)
+            dec = m.read_decisions()
+            for p in range(0, len(snap["pods"]), 7):
+                assert o.decide(p, mask, mask) == (int(want[p].sum()), int(dec[p]))
+        finally:
+            m.close()
+
+
+def test_unique_request_vectors_midsize(pm):
+    """bench.py's adversarial variant in small: every ask a distinct cpu request (5 000 values in one dimension → the sorted
+    walk at its default threshold), full grid against the oracle."""
+    pm.generate_kwok(seed=4711, num_nodes=1500, num_pods=5000, num_templates=0, node_affinity=1, unique_requests=1)
+    pm.evaluate()
+    lay = pm.layout()
+    assert lay.num_classes >= 4990
+    o = orc.Oracle(pm.dump_snapshot(compact=True))
+    want = o.eval_grid(threads=os.cpu_count() or 8)
+    assert np.array_equal(unpack(pm.read_bitmap(), 1500), want)
+    assert np.array_equal(pm.read_counts(), want.sum(axis=1))
+    dec = pm.read_decisions()
+    for p in range(0, 5000, 250):
+        assert o.decide(p) == (int(want[p].sum()), int(dec[p]))
+
+
 @pytest.mark.parametrize("plugins", [["NodeResourcesFit"], ["TaintToleration", "NodeUnschedulable"], ["NodeAffinity"], ["NodeName"], []])
 def test_random_clusters_plugin_subsets(plugins):
     snap = _gen.random_snapshot(77, n_nodes=130, n_pods=80)

@@ -136,7 +136,18 @@ struct ykpred_engine {
   int spread_constraints = 0;
   int64_t spread_cells = 0;
   bool spread_dirty = true;
-  DevBuf d_sig_req;                                                            // [Dres][R]
+  // NodeResourcesFit value planes: row 0 = pod-independent part, then one row per (dimension, distinct request value) in
+  // first-use order (kernels.hip.h: plane_dim). A request vector = res_rows[vec][1 + R] rows ANDed together.
+  int res_vectors = 0;                                    // distinct request vectors (class key component)
+  std::vector<i64> h_dim_val;                             // [rows]
+  std::vector<int32_t> h_dim_of;                          // [rows] dimension, -1 for row 0
+  DevBuf d_dim_val, d_dim_order, d_dim_chunk_dim, d_dim_chunk_begin, d_dim_chunk_len, d_res_rows;
+  int dim_chunks = 0;
+  // dimensions with >= walk_rows distinct values are evaluated by the sorted walk (k_dim_sort / k_dim_walk)
+  int walk_rows = 256;  // tunable: cfg.reserved[4]
+  int wave_combine_below = 16;  // tunable: cfg.reserved[5] — average members per chunk below which k_combine_wave is used
+  int n_big = 0, walk_chunks = 0;
+  DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
   DevBuf d_sig_tol, d_sig_tolflags, d_sig_ports, d_swanted;                    // [Dtol][KT], [Dtol], [Dtol][KP]; [S][KP]
   DevBuf d_sig_aff_flags, d_sig_aff_off, d_sig_aff_terms, d_sig_pre_off, d_sig_pre_terms;
   bool specs_set = false;
@@ -654,6 +665,9 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   e->chunk_sorted = cfg->reserved[1] != 1;
   if (cfg->reserved[2] > 0 && cfg->reserved[2] <= 160 * 1024) e->combine_lds_bytes = cfg->reserved[2];
   if (cfg->reserved[2] < 0) e->combine_lds_bytes = 0;
+  if (cfg->reserved[4] > 0) e->walk_rows = cfg->reserved[4];
+  if (cfg->reserved[5] > 0) e->wave_combine_below = cfg->reserved[5];
+  if (cfg->reserved[5] < 0) e->wave_combine_below = 0;
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -689,7 +703,9 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
                     &e->planes_canon, &e->planes_ranked, &e->base_canon, &e->base_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
-                    &e->d_pre_terms, &e->d_sig_req, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
+                    &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
@@ -872,7 +888,10 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   e->spec_sig_tol.assign((size_t)S, 0);
   e->spec_sig_aff.assign((size_t)S, 0);
   std::unordered_map<std::string, int32_t> m_res, m_tol, m_aff;
-  std::vector<i64> sig_req;
+  std::vector<std::unordered_map<i64, int32_t>> m_dim((size_t)R);  // per dimension: request value → plane row
+  std::vector<int32_t> res_rows;                                   // [vectors][1 + R]
+  e->h_dim_val.assign(1, 0);
+  e->h_dim_of.assign(1, -1);
   std::vector<u64> sig_tol, sig_ports, sig_aff_terms, sig_pre_terms;
   std::vector<uint32_t> sig_tolflags, sig_aff_flags;
   std::vector<int32_t> sig_aff_off{0}, sig_pre_off{0};
@@ -882,7 +901,21 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     auto it = m_res.find(k);
     if (it == m_res.end()) {
       it = m_res.emplace(std::move(k), (int32_t)m_res.size()).first;
-      sig_req.insert(sig_req.end(), s->requests + (size_t)i * R, s->requests + (size_t)(i + 1) * R);
+      res_rows.push_back(0);  // the pod-independent row
+      for (int r = 0; r < R; ++r) {
+        const i64 q = s->requests[(size_t)i * R + r];
+        int32_t row = -1;
+        if (q > 0) {  // "req_r > 0 ∧ req_r > free_r" fails: a non-positive request never does
+          auto dv = m_dim[(size_t)r].find(q);
+          if (dv == m_dim[(size_t)r].end()) {
+            dv = m_dim[(size_t)r].emplace(q, (int32_t)e->h_dim_val.size()).first;
+            e->h_dim_val.push_back(q);
+            e->h_dim_of.push_back(r);
+          }
+          row = dv->second;
+        }
+        res_rows.push_back(row);
+      }
     }
     e->spec_sig_res[(size_t)i] = it->second;
 
@@ -952,10 +985,52 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   if (!spread_unchanged) e->spread_dirty = true;
   if (!spread_unchanged) e->nodes_epoch++;  // the histograms of the last pass do not describe the new signatures
   TRY(upload(e, e->d_spec_spread, e->spec_sig_spread.data(), e->spec_sig_spread.size(), st));
-  e->fam_res.D = (int)m_res.size();
+  e->res_vectors = (int)m_res.size();
+  e->fam_res.D = (int)e->h_dim_val.size();
   e->fam_tol.D = (int)m_tol.size();
   e->fam_aff.D = (int)m_aff.size();
-  TRY(upload(e, e->d_sig_req, sig_req.data(), sig_req.size(), st));
+  {
+    // rows grouped by dimension. Dimensions with few distinct values are cut into ballot chunks of one dimension each (a
+    // plane block reads one node-table column); dimensions with many are sorted by value and cut into walk chunks.
+    const int rows = e->fam_res.D;
+    std::vector<int32_t> order((size_t)rows), start((size_t)R + 2, 0);
+    for (int d = 0; d < rows; ++d) start[(size_t)(e->h_dim_of[(size_t)d] + 1) + 1]++;
+    for (size_t g = 1; g < start.size(); ++g) start[g] += start[g - 1];
+    std::vector<int32_t> cursor(start.begin(), start.end() - 1);
+    for (int d = 0; d < rows; ++d) order[(size_t)cursor[(size_t)(e->h_dim_of[(size_t)d] + 1)]++] = d;
+    std::vector<int32_t> cdim, cbegin, clen, big_dim, wbig, wbegin, wlen;
+    for (int g = 0; g <= R; ++g) {
+      const int b0 = start[(size_t)g], b1 = start[(size_t)g + 1];
+      if (g > 0 && b1 - b0 >= e->walk_rows) {
+        std::sort(order.begin() + b0, order.begin() + b1, [&](int32_t x, int32_t y) { return e->h_dim_val[(size_t)x] < e->h_dim_val[(size_t)y]; });
+        for (int b = b0; b < b1; b += ykk::kWalkRows) {
+          wbig.push_back((int32_t)big_dim.size());
+          wbegin.push_back(b);
+          wlen.push_back(std::min(ykk::kWalkRows, b1 - b));
+        }
+        big_dim.push_back(g - 1);
+        continue;
+      }
+      for (int b = b0; b < b1; b += ykk::kDimRowsPerBlock) {
+        cdim.push_back(g - 1);
+        cbegin.push_back(b);
+        clen.push_back(std::min(ykk::kDimRowsPerBlock, b1 - b));
+      }
+    }
+    e->dim_chunks = (int)cdim.size();
+    e->n_big = (int)big_dim.size();
+    e->walk_chunks = (int)wbig.size();
+    TRY(upload(e, e->d_dim_val, e->h_dim_val.data(), e->h_dim_val.size(), st));
+    TRY(upload(e, e->d_dim_order, order.data(), order.size(), st));
+    TRY(upload(e, e->d_dim_chunk_dim, cdim.data(), cdim.size(), st));
+    TRY(upload(e, e->d_dim_chunk_begin, cbegin.data(), cbegin.size(), st));
+    TRY(upload(e, e->d_dim_chunk_len, clen.data(), clen.size(), st));
+    TRY(upload(e, e->d_big_dim, big_dim.data(), big_dim.size(), st));
+    TRY(upload(e, e->d_walk_big, wbig.data(), wbig.size(), st));
+    TRY(upload(e, e->d_walk_begin, wbegin.data(), wbegin.size(), st));
+    TRY(upload(e, e->d_walk_len, wlen.data(), wlen.size(), st));
+    TRY(upload(e, e->d_res_rows, res_rows.data(), res_rows.size(), st));
+  }
   TRY(upload(e, e->d_sig_tol, sig_tol.data(), sig_tol.size(), st));
   TRY(upload(e, e->d_sig_tolflags, sig_tolflags.data(), sig_tolflags.size(), st));
   TRY(upload(e, e->d_sig_ports, sig_ports.data(), sig_ports.size(), st));
@@ -1031,6 +1106,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_decisions = a->decisions ? a->decisions : e->d_decisions.p;
   e->last_keys = a->decision_keys ? a->decision_keys : e->d_keys.p;
   TRY(ensure_planes(e, st));
+  if (e->n_big > 0) {
+    const size_t cells = (size_t)e->n_big * (size_t)std::max(e->row_words, 1);
+    for (DevBuf* b : {&e->d_sfree_c, &e->d_sfree_r}) HIPCHK(b->ensure(cells * 64 * sizeof(i64)));
+    for (DevBuf* b : {&e->d_pmask_c, &e->d_pmask_r}) HIPCHK(b->ensure(cells * 65 * sizeof(u64)));
+  }
   Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
   tm.start(st);
   if (N == 0 || P == 0) {
@@ -1084,9 +1164,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
-                 e->row_stride};
+                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R};
   ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
-                 e->row_stride};
+                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R};
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -1163,18 +1243,33 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     pa.perm = perm;
     pa.res = o_res;
     pa.spread = o_spread;
-    if (!res_on) pa.res.D = 0;
     if (!spread_on) pa.spread.D = 0;
-    pa.sig_req = e->d_sig_req.as<i64>();
+    pa.dims = ykk::DimPlanes{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_dim_chunk_dim.as<int>(), e->d_dim_chunk_begin.as<int>(),
+                             e->d_dim_chunk_len.as<int>(), res_on ? e->dim_chunks : 0};
     pa.spreads = spread_sigs(e);
     pa.fit_error = fit_error;
     pa.n_words = e->row_words;
     pa.spread_en = pts_en ? 1 : 0;
     pa.ipa_en = ipa_en ? 1 : 0;
-    unsigned xchunks = std::max(sig_chunks(pa.res.D), sig_chunks(pa.spread.D));
+    unsigned xchunks = std::max((unsigned)pa.dims.n_chunks, sig_chunks(pa.spread.D));
     tm.begin(s);
     hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, s, nt, pa);
     tm.end(s, name);
+    if (res_on && e->n_big > 0 && !fit_error) {
+      // many-valued dimensions: sort every word's free values once, then one thread per word walks the sorted rows
+      const bool ranked = perm != nullptr;
+      ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
+                      e->d_walk_len.as<int>(), (ranked ? e->d_sfree_r : e->d_sfree_c).as<i64>(), (ranked ? e->d_pmask_r : e->d_pmask_c).as<u64>(),
+                      e->n_big, e->walk_chunks, e->row_words};
+      tm.begin(s);
+      hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
+      hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock),
+                         0, s, dw, ranked ? o_res.ranked : o_res.canon, e->row_stride);
+      tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
+    } else if (res_on && e->n_big > 0) {
+      // Filter without PreFilter state: the walked rows are all zero like every other row of the family
+      (void)hipMemsetAsync((perm ? o_res.ranked : o_res.canon), 0, (size_t)e->fam_res.D * (size_t)e->row_stride * sizeof(u64), s);
+    }
   };
   if (res_on || spread_on) launch_ballot_planes(st, nullptr, "k_planes");
   launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes");
@@ -1219,11 +1314,17 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          pin_on, e->d_class_count.as<int>(), tpg);
     };
     tm.begin(st);
-    switch (variant) {
-      case 0: launch(ykk::k_combine<2, false>); break;
-      case 1: launch(ykk::k_combine<1, false>); break;
-      case 2: launch(ykk::k_combine<2, true>); break;
-      default: launch(ykk::k_combine<1, true>); break;
+    if ((long)e->NC * e->wave_combine_below > (long)P) {
+      // few members per chunk: one wave per chunk (see k_combine_wave)
+      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct,
+                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC);
+    } else {
+      switch (variant) {
+        case 0: launch(ykk::k_combine<2, false>); break;
+        case 1: launch(ykk::k_combine<1, false>); break;
+        case 2: launch(ykk::k_combine<2, true>); break;
+        default: launch(ykk::k_combine<1, true>); break;
+      }
     }
     tm.end(st, "k_combine");
   }

@@ -211,39 +211,151 @@ __device__ __forceinline__ void plane_store(const PlaneOut& o, bool ranked, int 
 }
 
 // NodeResourcesFit.Filter: fail ⇔ count+1 > allowed ∨ ∃r: req_r > 0 ∧ req_r > alloc_r − requested_r.
-// One signature = one distinct request vector. `fit_error`: Filter enabled without its PreFilter (no cycle state).
-__device__ __forceinline__ void plane_res(const NodeTable& t, const int* __restrict__ perm, const i64* __restrict__ sig_req /*[D][R]*/,
-                                          const PlaneOut& o, int fit_error, int n_words) {
+// The Filter is a conjunction over resource dimensions, and every conjunct depends on ONE number of the pod — so planes are
+// kept per (dimension, distinct request value), not per request vector: plane(r, v) = {n : alloc_r − requested_r ≥ v}, and
+// row 0 of the family is the pod-independent part (a pod slot is free; the PreFilter state exists). A request vector is
+// the AND of row 0 and one row per dimension it asks for (res_rows table, applied in class_rows). The number of planes is
+// Σ_r #distinct values — at most, and usually far below, #distinct vectors × R: 10^6 asks with distinct cpu requests cost
+// 10^6 ONE-compare rows instead of 10^6 R-compare rows, and a realistic population (dozens of cpu values × dozens of
+// memory values) costs dozens of rows instead of thousands.
+// Rows are numbered in first-use order (stable when spec tables only append); `order` lists them grouped by dimension and
+// a chunk (dim, begin, len <= kDimRowsPerBlock) never mixes dimensions, so a block reads a single column of the node table.
+constexpr int kDimRowsPerBlock = 64;
+struct DimPlanes {
+  const i64* val;       // [rows] request value of the row (row 0: unused)
+  const int* order;     // [rows] row ids grouped by dimension (row 0 first, as the pseudo-dimension -1)
+  const int* chunk_dim;    // [chunks] dimension of the chunk, -1 = the base row
+  const int* chunk_begin;  // [chunks] first entry of `order`
+  const int* chunk_len;    // [chunks] 1..kDimRowsPerBlock
+  int n_chunks;
+};
+__device__ __forceinline__ i64 readlane_i64(i64 x, int lane) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)(u64)x, lane), hi = __builtin_amdgcn_readlane((unsigned)((u64)x >> 32), lane);
+  return (i64)(((u64)hi << 32) | lo);
+}
+__device__ __forceinline__ void plane_dim(const NodeTable& t, const int* __restrict__ perm, const DimPlanes& dp, const PlaneOut& o,
+                                          int fit_error, int n_words) {
   int word;
-  int n = plane_node(t.n, perm, &word);
+  const int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
-  i64 fr[kMaxR];
-  bool slots_ok = false;
-#pragma unroll
-  for (int r = 0; r < kMaxR; ++r) fr[r] = 0;
-  if (n >= 0) {
-#pragma unroll
-    for (int r = 0; r < kMaxR; ++r)
-      if (r < t.R) fr[r] = t.alloc[(size_t)r * t.n + n] - t.req[(size_t)r * t.n + n];
-    slots_ok = (i64)t.count[n] + 1 <= (i64)t.allowed[n];
+  const int chunk = blockIdx.x;
+  const int dim = dp.chunk_dim[chunk], begin = dp.chunk_begin[chunk], len = dp.chunk_len[chunk];
+  const int lane = threadIdx.x % kWave;
+  // lane i fetches (row id, value) of the chunk's i-th row once; the walk below reads them with v_readlane — no memory
+  // latency inside the loop
+  const int my_row = lane < len ? dp.order[begin + lane] : 0;
+  const i64 my_val = (lane < len && dim >= 0) ? dp.val[my_row] : 0;
+  unsigned keep_lo = 0, keep_hi = 0;
+  if (dim < 0) {
+    const bool ok = n >= 0 && !fit_error && (i64)t.count[n] + 1 <= (i64)t.allowed[n];
+    const u64 b = __ballot(ok);
+    keep_lo = (unsigned)b;
+    keep_hi = (unsigned)(b >> 32);
+  } else if (!fit_error) {
+    // invalid positions (past N) never fit: every row value is > 0 > INT64_MIN
+    const i64 fr = n >= 0 ? t.alloc[(size_t)dim * t.n + n] - t.req[(size_t)dim * t.n + n] : (i64)0x8000000000000000ull;
+    for (int i = 0; i < len; ++i) {
+      const i64 v = readlane_i64(my_val, i);
+      const u64 b = __ballot(fr >= v);
+      // lane i keeps the word of the chunk's i-th row: two v_writelane instead of a compare + two selects per row
+      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+      // (VOP3 takes one SGPR operand besides M0: the lane select travels in M0, which is saved and restored)
+      unsigned saved_m0;
+      asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                   : "+v"(keep_lo), "+v"(keep_hi), "=&s"(saved_m0)
+                   : "s"(blo), "s"(i), "s"(bhi));
+    }
   }
-  const int spb = sigs_per_block(o.D);
-  int d0 = blockIdx.x * spb;
-  int dend = min(d0 + spb, o.D);
+  if (lane < len) {
+    u64* base = perm ? o.ranked : o.canon;
+    base[(size_t)my_row * o.stride + word] = ((u64)keep_hi << 32) | keep_lo;
+  }
+}
+
+// Dimensions with MANY distinct request values (10^3 … 10^6: every ask its own cpu request) use the monotone structure
+// instead of one compare per (value, node): plane(r, v) shrinks as v grows, and inside one 64-node word it changes at most
+// 64 times. k_dim_sort orders the 64 free values of every word once per evaluation (sfree ascending, pmask[j] = the nodes of
+// the entries j..63); k_dim_walk then gives a THREAD one word: it walks the dimension's rows in ascending value order,
+// advances its position in the sorted list while the free value there is below the row's value, and stores pmask[position]
+// — lanes are consecutive words, so a wave writes 512 contiguous bytes of a row. Cost: the plane bytes written once
+// (HBM-write bound) instead of rows × N compares (ALU bound).
+constexpr int kWalkRows = 512;  // rows per walk chunk (one binary search per thread and chunk)
+struct DimWalk {
+  const i64* val;          // [rows]
+  const int* order;        // [rows] row ids grouped by dimension; inside a walked dimension ascending by value
+  const int* big_dim;      // [n_big] walked dimensions
+  const int* chunk_big;    // [chunks] index into big_dim
+  const int* chunk_begin;  // [chunks] first entry of `order`
+  const int* chunk_len;    // [chunks] 1..kWalkRows
+  i64* sfree;              // [n_big][n_words][64]
+  u64* pmask;              // [n_big][n_words][65]
+  int n_big, n_chunks, n_words;
+};
+// blockIdx.x: walked dimension, blockIdx.y: group of 4 words; wave = word, lane = node position
+__global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __restrict__ perm, DimWalk a) {
+  int word;
+  const int n = plane_node(t.n, perm, &word);
+  if (word >= a.n_words) return;
+  const int lane = threadIdx.x % kWave;
+  const int dim = a.big_dim[blockIdx.x];
+  const bool valid = n >= 0;
+  const i64 fr = valid ? t.alloc[(size_t)dim * t.n + n] - t.req[(size_t)dim * t.n + n] : (i64)0x8000000000000000ull;
+  int rank = 0;  // position in ascending (free, lane) order
+  for (int j = 0; j < kWave; ++j) {
+    const i64 o = readlane_i64(fr, j);
+    rank += (o < fr || (o == fr && j < lane)) ? 1 : 0;
+  }
+  const size_t cell = (size_t)blockIdx.x * a.n_words + word;
+  a.sfree[cell * 64 + rank] = fr;
   u64 keep = 0;
-  for (int d = d0; d < dend; ++d) {
-    const i64* v = sig_req + (size_t)d * t.R;
-    bool ok = n >= 0 && slots_ok && !fit_error;
-#pragma unroll
-    for (int r = 0; r < kMaxR; ++r)
-      if (r < t.R) {
-        i64 q = v[r];
-        ok = ok && !(q > 0 && q > fr[r]);
-      }
-    u64 b = __ballot(ok);
-    if ((d - d0) == (int)(threadIdx.x % kWave)) keep = b;
+  for (int j = 0; j < kWave; ++j) {
+    const u64 b = __ballot(valid && rank >= j);
+    if (j == lane) keep = b;
   }
-  plane_store(o, perm != nullptr, word, d0, dend - d0, keep);
+  a.pmask[cell * 65 + lane] = keep;
+  if (lane == 0) a.pmask[cell * 65 + 64] = 0;
+}
+// blockIdx.x: walk chunk, blockIdx.y: block of 256 words; thread = word
+__global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, u64* __restrict__ out, int stride) {
+  const int chunk = blockIdx.x;
+  const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
+  const int w_raw = blockIdx.y * kBlock + threadIdx.x;
+  const bool live = w_raw < a.n_words;
+  const int w = live ? w_raw : a.n_words - 1;  // every lane takes part in the v_readlane exchanges
+  const int lane = threadIdx.x % kWave;
+  const size_t cell = (size_t)big * a.n_words + w;
+  const i64* sf = a.sfree + cell * 64;
+  const u64* pm = a.pmask + cell * 65;
+  const i64 kMax = 0x7fffffffffffffffll;
+  int ptr = 0;
+  {  // lower bound: entries [0, ptr) are below the chunk's first value
+    const i64 v0 = a.val[a.order[begin]];
+    int lo = 0, hi = 64;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sf[mid] < v0) lo = mid + 1; else hi = mid;
+    }
+    ptr = lo;
+  }
+  i64 next = ptr < 64 ? sf[ptr] : kMax;
+  u64 mask = pm[ptr];
+  for (int i0 = 0; i0 < len; i0 += kWave) {
+    const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
+    const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
+    const int m = min(kWave, len - i0);
+    for (int i = 0; i < m; ++i) {
+      const i64 v = readlane_i64(my_val, i);
+      const int row = __builtin_amdgcn_readlane(my_row, i);
+      if (next < v) {
+        do {
+          ++ptr;
+          next = ptr < 64 ? sf[ptr] : kMax;
+        } while (next < v);
+        mask = pm[ptr];
+      }
+      if (live) out[(size_t)row * stride + w] = mask;
+    }
+  }
 }
 
 // NodeAffinity PreFilter + Filter (A.5). Signature = (flags, Filter DNF, PreFilter node-name DNF).
@@ -569,19 +681,19 @@ __device__ __forceinline__ void plane_spread(const NodeTable& t, const int* __re
   plane_store(o, perm != nullptr, word, d0, dend - d0, keep);
 }
 
-// Ballot-based families (NodeResourcesFit request vectors, PodTopologySpread) in one launch: blockIdx.z selects the
-// family so their (latency-bound, cache-cold) signature walks overlap. A disabled family has D = 0.
+// Ballot-based families (NodeResourcesFit value planes, PodTopologySpread) in one launch: blockIdx.z selects the
+// family so their (latency-bound, cache-cold) walks overlap. A disabled family has no chunks / D = 0.
 struct PlaneArgs {
   const int* perm;
   PlaneOut res, spread;
-  const i64* sig_req;
+  DimPlanes dims;  // the ballot-evaluated dimensions (few distinct values); the others go through k_dim_sort / k_dim_walk
   SpreadSigs spreads;
   int fit_error, n_words;
   int spread_en, ipa_en;
 };
 __global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
   if (blockIdx.z == 0) {
-    if ((int)blockIdx.x * sigs_per_block(a.res.D) < a.res.D) plane_res(t, a.perm, a.sig_req, a.res, a.fit_error, a.n_words);
+    if ((int)blockIdx.x < a.dims.n_chunks) plane_dim(t, a.perm, a.dims, a.res, a.fit_error, a.n_words);
   } else {
     if ((int)blockIdx.x * sigs_per_block(a.spread.D) < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words, a.spread_en != 0, a.ipa_en != 0);
   }
@@ -600,20 +712,50 @@ struct ClassTable {
   const int* members;      // [P] pod ids grouped by class
 };
 struct Planes {
-  const u64* res;
+  const u64* res;         // value planes of NodeResourcesFit (row 0 = pod-independent part); null = family disabled
   const u64* tol;
   const u64* aff;
   const u64* spread;
   int stride;
+  const int* res_rows;    // [Dvec][res_slots]: rows of `res` a request vector ANDs together, -1 = unused slot
+  int res_slots;          // 1 + R
 };
+constexpr int kMaxClassRows = 3 + 1 + kMaxR;
 
-__device__ __forceinline__ u64 class_word(const Planes& pl, int sr, int st, int sa, int ss, int w) {
+// The plane rows whose AND is the bitmap row of a class: pointers to their first words, families disabled for this
+// evaluation left out (a null family pointer; wave-uniform).
+struct ClassRows {
+  const u64* row[kMaxClassRows];
+  int n;
+};
+__device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st, int sa, int ss) {
+  ClassRows cr;
+  cr.n = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxClassRows; ++i) cr.row[i] = nullptr;
+  auto add = [&](const u64* p) {
+#pragma unroll
+    for (int i = 0; i < kMaxClassRows; ++i)
+      if (i == cr.n) cr.row[i] = p;
+    ++cr.n;
+  };
+  if (pl.tol && st >= 0) add(pl.tol + (size_t)st * pl.stride);
+  if (pl.aff && sa >= 0) add(pl.aff + (size_t)sa * pl.stride);
+  if (pl.spread && ss >= 0) add(pl.spread + (size_t)ss * pl.stride);
+  if (pl.res && sr >= 0) {
+    const int* rr = pl.res_rows + (size_t)sr * pl.res_slots;
+    for (int k = 0; k < pl.res_slots; ++k) {
+      const int r = rr[k];
+      if (r >= 0) add(pl.res + (size_t)r * pl.stride);
+    }
+  }
+  return cr;
+}
+__device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
   u64 v = ~0ull;
-  // a null family pointer = plugin family disabled for this eval (wave-uniform branches)
-  if (pl.res && sr >= 0) v &= pl.res[(size_t)sr * pl.stride + w];
-  if (pl.tol && st >= 0) v &= pl.tol[(size_t)st * pl.stride + w];
-  if (pl.aff && sa >= 0) v &= pl.aff[(size_t)sa * pl.stride + w];
-  if (pl.spread && ss >= 0) v &= pl.spread[(size_t)ss * pl.stride + w];
+#pragma unroll
+  for (int i = 0; i < kMaxClassRows; ++i)
+    if (i < cr.n) v &= cr.row[i][w];
   return v;
 }
 
@@ -639,6 +781,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   const int lane = threadIdx.x % kWave;
   const int group = threadIdx.x / tpg, groups = kBlock / tpg, t = threadIdx.x % tpg;
   const int seg_base = blockIdx.y * (tpg * kCombineUnroll * WPL);
+  const ClassRows cr = class_rows(pl, sr, st, sa, ss);
 
   u64 v[kCombineUnroll][WPL];
   int pc = 0;
@@ -649,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
       int w = seg_base + (u * tpg + t) * WPL + j;
       u64 x = 0;
       if (w < row_words) {
-        x = class_word(pl, sr, st, sa, ss, w);
+        x = class_word(cr, w);
         if (pin == -2 || all_fail)
           x = 0;
         else if (pin >= 0)
@@ -693,6 +836,61 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   }
 }
 
+// Wave-per-chunk form of k_combine for ask populations whose classes have few members (every ask its own template or its
+// own request vector): a chunk is then a handful of rows, and what limits the block-per-chunk kernel is the number of
+// independent (class → signature rows → plane words → store) chains in flight, not bandwidth. Here every WAVE owns a chunk —
+// 4x as many chains per workgroup and no occupancy cap; lane = a pair of adjacent row words (dwordx4 loads and stores).
+__global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
+                                                         int pin_enabled, int* __restrict__ class_count, int n_chunks) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const bool all_fail = pin_enabled & 2;
+  pin_enabled &= 1;
+  const int chunk = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (chunk >= n_chunks) return;
+  const int lane = threadIdx.x % kWave;
+  const int cls = ct.chunk_class[chunk];
+  const int begin = ct.chunk_begin[chunk], len = ct.chunk_len[chunk];
+  const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
+  const int pin = pin_enabled ? ct.pin[cls] : -1;
+  const ClassRows cr = class_rows(pl, sr, st, sa, ss);
+  const int mine = lane < len ? ct.members[begin + lane] : -1;
+  int pc = 0;
+  // the pair of words [w, w+1] of the class row (row_stride is a multiple of 16: a pair never straddles the end)
+  auto class_pair = [&](int w) {
+    u64x2 x = {0, 0};
+    if (w < row_words && pin != -2 && !all_fail) {
+      x = u64x2{~0ull, ~0ull};
+#pragma unroll
+      for (int i = 0; i < kMaxClassRows; ++i)
+        if (i < cr.n) x &= *(const u64x2*)(cr.row[i] + w);
+      if (w + 1 >= row_words) x.y = 0;  // planes are zero there anyway (padding); keep the contract explicit
+      if (pin >= 0) {
+        x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+        x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+      }
+    }
+    return x;
+  };
+  // two-stage pipeline: the plane words of the next 1 KiB piece are in flight while this piece is stored
+  u64x2 next = class_pair(2 * lane);
+  for (int w0 = 0; w0 < row_stride; w0 += 2 * kWave) {
+    const int w = w0 + 2 * lane;
+    const u64x2 x = next;
+    if (w0 + 2 * kWave < row_stride) next = class_pair(w + 2 * kWave);
+    pc += __popcll(x.x) + __popcll(x.y);
+    if (w < row_stride)
+      for (int i = 0; i < len; ++i) {
+        const int p = __builtin_amdgcn_readlane(mine, i);
+        if (p >= 0) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
+      }
+  }
+  if (ct.chunk_first[chunk]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
+    if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // decide: best feasible node of a class = first set bit in bin-pack rank order
 // ---------------------------------------------------------------------------------------------------
@@ -705,16 +903,17 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
   const bool all_fail = pin_enabled & 2;
   const int pin = (pin_enabled & 1) ? ct.pin[cls] : -1;
   int best = -1;
+  const ClassRows cr = class_rows(ranked, sr, st, sa, ss);
   if (pin == -2 || all_fail) {
     best = -1;
   } else if (pin >= 0) {
     int pos = rank[pin];
-    u64 x = class_word(ranked, sr, st, sa, ss, pos >> 6);
+    u64 x = class_word(cr, pos >> 6);
     best = ((x >> (pos & 63)) & 1ull) ? pin : -1;
   } else {
     for (int base = 0; base < row_words; base += kWave) {
       int w = base + lane;
-      u64 x = w < row_words ? class_word(ranked, sr, st, sa, ss, w) : 0ull;
+      u64 x = w < row_words ? class_word(cr, w) : 0ull;
       u64 any = __ballot(x != 0);
       if (any) {
         int first_lane = __ffsll((long long)any) - 1;

@@ -205,6 +205,8 @@ int recreate_engine(ykhost* h) {
   if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
   if (const char* v = getenv("YKPRED_COMBINE_LDS")) c.reserved[2] = atoi(v);
   if (const char* v = getenv("YKPRED_GRAPH")) c.reserved[3] = atoi(v);
+  if (const char* v = getenv("YKPRED_WALK_ROWS")) c.reserved[4] = atoi(v);
+  if (const char* v = getenv("YKPRED_WAVE_COMBINE_BELOW")) c.reserved[5] = atoi(v);  // avg members per chunk below which k_combine_wave runs (-1 = never)  // distinct request values per dimension from which the sorted walk is used
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;
