@@ -83,6 +83,8 @@ int32_t ykhost_add_task_groups(ykhost_t* h, const char* app_json, const char* ta
 #define YKHOST_E_POD_NOT_FOUND (-10)
 #define YKHOST_E_NODE_NOT_FOUND (-11)
 #define YKHOST_E_NOT_AN_ASK (-12)
+#define YKHOST_E_UNSUPPORTED (-13) /* the ask is not evaluated by the engine (volumes, DRA claims, dictionary limits, specs the API
+                                      server rejects): the caller's CPU PredicateManager answers this one; msg / err = the reason */
 int32_t ykhost_is_pod_fit_node(ykhost_t* h, const char* allocation_key, const char* node_id, int32_t allocate, char* err, int32_t err_len);
 /* Context.IsPodFitNodeViaPreemption (context.go:718-742) behind AsyncRMCallback.PreemptionPredicates
  * (scheduler_callback.go:207-216): → Index, or -1 for {Success: false} (no prefix of victims helps, unknown ask or node). */
@@ -158,6 +160,12 @@ int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, con
 int32_t ykhost_preemption_predicates_batch(ykhost_t* h, int32_t num_queries, const int32_t* pods, const int32_t* nodes,
                                            const int32_t* victim_off, const char* const* victim_uids, const int32_t* start_index,
                                            int32_t* out_index);
+
+/* Individual routing: 1 = pending pod #pod is evaluated on the device, 0 = it is routed to the CPU predicate manager
+ * (`reason` says why). ykhost_routing_stats: out[0] = asks marked unsupported at the last encode, out[1] = Predicates() calls
+ * answered YKHOST_E_UNSUPPORTED so far (what the Go side exports as its fallback counter). */
+int32_t ykhost_ask_supported(ykhost_t* h, int32_t pod, char* reason, int32_t reason_len);
+int32_t ykhost_routing_stats(ykhost_t* h, int64_t* out2);
 
 /* request vector of pending pod #pod as JSON {"cpu": milli, "memory": bytes, ...} */
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len);

@@ -69,6 +69,7 @@ extern "C" {
 #define YKPRED_CODE_NODE_RESOURCES_FIT 6
 #define YKPRED_CODE_POD_TOPOLOGY_SPREAD 7
 #define YKPRED_CODE_INTER_POD_AFFINITY 8
+#define YKPRED_CODE_UNSUPPORTED 255 /* the ask's spec carries YKPRED_SPEC_UNSUPPORTED: not evaluated, route it to the CPU manager */
 
 /* reason bits returned by ykpred_query next to the plugin code (the host composes the status message) */
 #define YKPRED_REASON_TOO_MANY_PODS (1u << 0)
@@ -85,6 +86,10 @@ extern "C" {
 #define YKPRED_SPEC_AFFINITY_SKIP (1u << 1)           /* NodeAffinity.PreFilter returns Skip (no selector, no required affinity) */
 #define YKPRED_SPEC_PREFILTER_REJECT (1u << 2)        /* NodeAffinity.PreFilter: conflicting metadata.name terms */
 #define YKPRED_SPEC_PREFILTER_NAMES (1u << 3)         /* NodeAffinity.PreFilter returned a NodeNames set (pre_terms) */
+#define YKPRED_SPEC_UNSUPPORTED (1u << 4)             /* the host could not encode this ask (volumes, DRA claims, dictionary limits ...):
+                                                         its bitmap row is all zero, its count 0, its decision -1 and every query
+                                                         answers YKPRED_CODE_UNSUPPORTED, whatever the plugin lists — the host
+                                                         routes exactly these asks to the CPU predicate manager */
 
 /* special values for pods.node_name_index */
 #define YKPRED_NO_NODE_NAME (-1)      /* pod.Spec.NodeName == "" */
@@ -122,6 +127,11 @@ typedef struct ykpred_nodes {
   const int32_t* domain_sizes;   /* [KD]         number of distinct values (domain ids 0..size-1) of topology key k */
   const uint64_t* port_bits;     /* [KP][count]  bit k: some pod on the node uses a host port that conflicts with dictionary
                                                  port k (HostPortInfo.CheckConflict: same protocol+port, equal or wildcard IP) */
+  const int32_t* name_rank;      /* [count]      position of the node's NodeID in lexicographic order: the tie-break of the
+                                                 bin-pack order between nodes of equal score (yunikorn-core sorts by score,
+                                                 then node id). NULL = ties by node index. In a node-sharded cluster the
+                                                 shards are ranges of a name-sorted node list, so that the cross-shard
+                                                 tie-break (global node index) agrees with it. */
 } ykpred_nodes_t;
 
 /* One topology constraint of a pod spec: a hard (DoNotSchedule) topology spread constraint, or one InterPodAffinity

@@ -724,12 +724,17 @@ struct FitState {  // noderesources preFilterState
   bool written = false;
   Resource req;
 };
-struct SpreadState {  // podtopologyspread preFilterState
+// podtopologyspread preFilterState, restated for k8s.io/kubernetes v1.36.1 (go.mod:46): since the 1.3x refactor the state is
+// held PER CONSTRAINT (TpValueToMatchNum []map[string]int, CriticalPaths []*criticalPaths — slices indexed by the constraint),
+// no longer in maps keyed by {topologyKey, value} as up to 1.2x, where two hard constraints on the SAME topologyKey with
+// different selectors shared (and overwrote) one counter. API validation rejects that shape anyway ("duplicate
+// {topologyKey, whenUnsatisfiable}", ValidateTopologySpreadConstraints), and the product's encoder refuses it with that
+// reason; the oracle still evaluates it constraint by constraint (tests/test_oracle_golden.py pins the shape).
+struct SpreadState {
   bool written = false;
   std::vector<const SpreadConstraint*> constraints;
-  std::map<std::pair<std::string, std::string>, int> pair_to_match;  // TpPairToMatchNum
-  std::map<std::string, int> key_to_domains;                         // TpKeyToDomainsNum
-  std::map<std::string, int> key_to_min;                             // criticalPaths[0].MatchNum
+  std::vector<std::map<std::string, int>> value_to_match;  // [constraint] TpValueToMatchNum
+  std::vector<int> min_match;                              // [constraint] CriticalPaths[i][0].MatchNum
 };
 using TopologyPair = std::pair<std::string, std::string>;
 struct InterPodState {  // interpodaffinity preFilterState
@@ -869,14 +874,16 @@ static Status spread_prefilter(const Pod& p, const std::vector<NodeInfo>& all, C
   }
   if (sel_err) return {Status::Error, "invalid label selector in topologySpreadConstraints"};
   s.written = true;
+  s.value_to_match.assign(s.constraints.size(), {});
+  s.min_match.assign(s.constraints.size(), 0);
   for (auto& ni : all) {
     const Node& node = ni.node;
     bool has_all = true;
     for (auto* c : s.constraints)
       if (!node.labels.count(c->topology_key)) has_all = false;
     if (!has_all) continue;  // nodeLabelsMatchSpreadConstraints
-    std::map<std::pair<std::string, std::string>, int> tp_counts;
-    for (auto* c : s.constraints) {
+    for (size_t i = 0; i < s.constraints.size(); ++i) {
+      const SpreadConstraint* c = s.constraints[i];
       // matchNodeInclusionPolicies
       if (c->node_affinity_policy == "Honor" && !required_node_affinity_matches(p, node)) continue;
       if (c->node_taints_policy == "Honor" && find_untolerated_taint(node, p)) continue;
@@ -888,33 +895,31 @@ static Status spread_prefilter(const Pod& p, const std::vector<NodeInfo>& all, C
           if (selector_matches(c->selector, ep->labels, &e)) ++count;
         }
       }
-      tp_counts[{c->topology_key, node.labels.at(c->topology_key)}] = count;
+      s.value_to_match[i][node.labels.at(c->topology_key)] += count;
     }
-    for (auto& kv : tp_counts) s.pair_to_match[kv.first] += kv.second;
   }
-  for (auto& kv : s.pair_to_match) s.key_to_domains[kv.first.first]++;
-  for (auto* c : s.constraints) s.key_to_min[c->topology_key] = std::numeric_limits<int32_t>::max();
-  for (auto& kv : s.pair_to_match) {
-    int& m = s.key_to_min[kv.first.first];
-    if (kv.second < m) m = kv.second;
+  for (size_t i = 0; i < s.constraints.size(); ++i) {
+    int m = std::numeric_limits<int32_t>::max();
+    for (auto& kv : s.value_to_match[i]) m = std::min(m, kv.second);
+    s.min_match[i] = m;
   }
   return {};
 }
 static Status spread_filter(const Pod& p, const CycleState& st, const NodeInfo& ni) {
   const SpreadState& s = st.spread;
   if (!s.written) return {Status::Error, "reading \"PreFilterPodTopologySpread\" from cycleState: not found"};
-  for (auto* c : s.constraints) {
+  for (size_t i = 0; i < s.constraints.size(); ++i) {
+    const SpreadConstraint* c = s.constraints[i];
     auto lit = ni.node.labels.find(c->topology_key);
     if (lit == ni.node.labels.end())
       return {Status::UnschedulableAndUnresolvable, "node(s) didn't match pod topology spread constraints (missing required label)"};
-    int64_t min_match = s.key_to_min.at(c->topology_key);
-    auto dn = s.key_to_domains.find(c->topology_key);
-    int domains = dn == s.key_to_domains.end() ? 0 : dn->second;
+    int64_t min_match = s.min_match[i];
+    const int domains = static_cast<int>(s.value_to_match[i].size());
     if (domains < (c->has_min_domains ? c->min_domains : 1)) min_match = 0;
     bool e = false;
     int64_t self = selector_matches(c->selector, p.labels, &e) ? 1 : 0;
-    auto mit = s.pair_to_match.find({c->topology_key, lit->second});
-    int64_t match = mit == s.pair_to_match.end() ? 0 : mit->second;
+    auto mit = s.value_to_match[i].find(lit->second);
+    int64_t match = mit == s.value_to_match[i].end() ? 0 : mit->second;
     int64_t skew = match + self - min_match;
     if (skew > c->max_skew) return {Status::Unschedulable, "node(s) didn't match pod topology spread constraints"};
   }
@@ -1268,7 +1273,8 @@ int orc_binpack_scores(void* h, double* out) {
   return 0;
 }
 
-// Snapshot decision for one pod: feasible count and the feasible node with the smallest (score, index).
+// Snapshot decision for one pod: feasible count and the feasible node with the smallest (score, NodeID string) — the
+// bin-packing order of yunikorn-core (recollection, A.9: nodes sorted by score, ties by node id; PARITY UNPINNED).
 int orc_decide(void* h, int pod, unsigned pre_mask, unsigned filt_mask, int* count, int* best) {
   Snapshot* s = static_cast<Snapshot*>(h);
   const orc::Pod& p = *s->pending[static_cast<size_t>(pod)];
@@ -1278,7 +1284,7 @@ int orc_decide(void* h, int pod, unsigned pre_mask, unsigned filt_mask, int* cou
     if (!orc::pod_fits_node(*s, p, s->nodes[j], pre_mask, filt_mask).fit) continue;
     ++c;
     double sc = orc::binpack_score(s->nodes[j]);
-    if (b < 0 || sc < bs) {
+    if (b < 0 || sc < bs || (sc == bs && s->nodes[j].node.name < s->nodes[static_cast<size_t>(b)].node.name)) {
       b = static_cast<int>(j);
       bs = sc;
     }

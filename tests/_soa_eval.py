@@ -7,7 +7,7 @@ Test infrastructure only: it lets the CPU suite check the host ENCODER against t
 a device. It is written from the table layout, not from the HIP kernels.
 """
 UNSCHED, NODE_NAME, TAINT, AFFINITY, PORTS, FIT, SPREAD, INTERPOD = 1, 2, 4, 8, 16, 32, 64, 128
-SPEC_TOLERATES_UNSCHEDULABLE, SPEC_AFFINITY_SKIP, SPEC_PREFILTER_REJECT, SPEC_PREFILTER_NAMES = 1, 2, 4, 8
+SPEC_TOLERATES_UNSCHEDULABLE, SPEC_AFFINITY_SKIP, SPEC_PREFILTER_REJECT, SPEC_PREFILTER_NAMES, SPEC_UNSUPPORTED = 1, 2, 4, 8, 16
 NO_NODE_NAME = -1
 
 
@@ -23,6 +23,8 @@ def eval_pair(t, p, n, pre, filt):
     N, R, KT, W, KP = t["N"], t["R"], t["KT"], t["W"], t["KP"]
     s, pin = t["pod_spec"][p], t["pod_node_name"][p]
     f = t["spec_flags"][s]
+    if f & SPEC_UNSUPPORTED:  # not evaluated by the engine: routed to the CPU manager (YKPRED_CODE_UNSUPPORTED)
+        return 0, 255
     lb = [t["label_bits"][w * N + n] for w in range(W)]
     if pre & AFFINITY and not f & SPEC_AFFINITY_SKIP:
         if f & SPEC_PREFILTER_REJECT:

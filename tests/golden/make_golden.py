@@ -485,7 +485,60 @@ QUANTITIES = [
 ]
 
 
+E2E = "test/e2e/predicates/predicates_test.go"
+KWOK_SETUP = "deployments/kwok-perf-test/kwok-setup.sh"
+KWOK_DEPLOY = "deployments/kwok-perf-test/deploy-tool.sh"
+
+
+def taint_cases():
+    """TaintToleration has no unit-level vector in the reference (the plugin is only enabled through "*"); what the reference
+    DOES hold is behaviour: two e2e scenarios and the KWOK perf-test shapes. Transcribed here as single (pod, node) cases with
+    the whole default plugin set ("*", NewPredicateManager) — `plugin` / `message_regex` where the scenario asserts them."""
+    key, value = "kubernetes.io/e2e-taint-key-abcdefghij", "testing-taint-value"
+    label_key, label_value = "kubernetes.io/e2e-label-key-klmnopqrst", "testing-label-value"
+    alloc = {"cpu": "4", "memory": "8Gi", "pods": "110"}
+    tainted = node("e2e-node", labels={label_key: label_value}, alloc=alloc, taints=[{"key": key, "value": value, "effect": "NoSchedule"}])
+    untainted = node("e2e-node", labels={label_key: label_value}, alloc=alloc)
+    sleep = [{"name": "sleepcontainer", "resources": {"requests": {"cpu": "100m", "memory": "100M"}}}]
+    with_tol = pod({"containers": sleep, "nodeSelector": {label_key: label_value},
+                    "tolerations": [{"key": key, "value": value, "effect": "NoSchedule"}]},  # operator unset = Equal
+                   name="with-tolerations", uid="with-tolerations", namespace="ns", labels={"app": "tolerations-app", "applicationId": "app-1"})
+    no_tol = pod({"containers": sleep, "nodeSelector": {label_key: label_value}},
+                 name="with-no-tolerations", uid="with-no-tolerations", namespace="ns", labels={"app": "no-tolerations-app", "applicationId": "app-2"})
+    kwok_node = node("kwok-node-0", labels={"beta.kubernetes.io/arch": "amd64", "beta.kubernetes.io/os": "linux", "kubernetes.io/arch": "amd64",
+                                            "kubernetes.io/hostname": "kwok-node-0", "kubernetes.io/os": "linux", "kubernetes.io/role": "agent",
+                                            "node-role.kubernetes.io/agent": "", "type": "kwok"},
+                     alloc={"cpu": "32", "memory": "256Gi", "pods": "110"}, taints=[{"effect": "NoSchedule", "key": "kwok.x-k8s.io/node", "value": "fake"}])
+    kwok_pod = pod({"containers": [{"name": "sleep300"}], "tolerations": [{"key": "kwok.x-k8s.io/node", "operator": "Exists", "effect": "NoSchedule"}]},
+                   name="sleep-deployment-0-abc", uid="sleep-deployment-0-abc", namespace="default",
+                   labels={"app": "nginx", "applicationId": "sleep-deployment-0", "queue": "root.default"})
+    real_pod = pod({"containers": [{"name": "main"}]}, name="actual-pod", uid="actual-pod", namespace="default", labels={"app": "real"})
+
+    def case(name, source, p, n, fits, plugin=None, regex=None):
+        c = {"test": "TaintToleration", "name": name, "source": source, "plugins": ["*"], "allocate": True, "pod": p, "node": n, "fits": fits}
+        if plugin is not None:
+            c["plugin"] = plugin
+        if regex is not None:
+            c["message_regex"] = regex
+        return c
+
+    return [
+        case("Verify_Matching_Taint_Tolerations_Respected: toleration {Key, Value, Effect} on the tainted, labelled node", f"{E2E}:334-381",
+             with_tol, tainted, True),
+        case("Verify_Not_Matching_Taint_Tolerations_Respected: no toleration, pod stays pending, log matches .*taint.*", f"{E2E}:384-439",
+             no_tol, tainted, False, "TaintToleration", ".*taint.*"),
+        case("Verify_Not_Matching_Taint_Tolerations_Respected: after UntaintNode the pod is scheduled on the node", f"{E2E}:441-447",
+             no_tol, untainted, True),
+        case("KWOK: deploy-tool pod (toleration Exists/NoSchedule, no requests) on a kwok-setup node", f"{KWOK_DEPLOY}:33-63 x {KWOK_SETUP}:31-58",
+             kwok_pod, kwok_node, True),
+        case("KWOK: a pod without the toleration is kept off the fake node ('Avoid scheduling actual running pods to fake Node')",
+             f"{KWOK_SETUP}:50-53", real_pod, kwok_node, False, "TaintToleration", ".*taint.*"),
+    ]
+
+
 def main():
+    with open(os.path.join(HERE, "taint_cases.json"), "w") as f:
+        json.dump(taint_cases(), f, indent=1)
     with open(os.path.join(HERE, "predicate_cases.json"), "w") as f:
         json.dump(predicate_cases(), f, indent=1)
     with open(os.path.join(HERE, "preemption_cases.json"), "w") as f:

@@ -56,6 +56,28 @@ def test_reference_table_tests(case):
         m.close()
 
 
+@pytest.mark.parametrize("case", load("taint_cases.json"), ids=lambda c: c["name"][:60])
+def test_reference_taint_behaviour(case):
+    """TaintToleration as the reference's e2e suite and KWOK tooling pin it (test/e2e/predicates/predicates_test.go:334-447,
+    deployments/kwok-perf-test/*): default manager, allocation phase; the failing plugin and the `.*taint.*` log text too —
+    through Predicates() and through the scheduler-interface callback (Context.IsPodFitNode)."""
+    import re
+    m = pkg.GpuPredicateManager()
+    try:
+        m.load_snapshot({"nodes": [case["node"]], "pods": [case["pod"]]})
+        plugin, err = m.predicates(0, 0, True)
+        assert (err is None) == case["fits"], f"{case['source']}: plugin={plugin!r} err={err}"
+        text = m.is_pod_fit_node(case["pod"]["metadata"]["uid"], case["node"]["metadata"]["name"], True)
+        assert (text is None) == case["fits"]
+        if not case["fits"]:
+            assert plugin == case["plugin"] and re.match(case["message_regex"], err.message)
+            assert text.startswith(f"failed plugin: '{case['plugin']}'") and re.search("taint", text)
+        m.evaluate()
+        assert int(m.read_counts()[0]) == (1 if case["fits"] else 0)
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("case", load("preemption_cases.json"), ids=lambda c: c["source"])
 def test_reference_preemption_tests(case):
     ep = case["plugins"]
@@ -792,13 +814,95 @@ def test_incremental_at_full_size(pm):
     assert np.array_equal(counts, pm.read_counts()) and np.array_equal(dec, pm.read_decisions())
 
 
-def test_unsupported_pods_are_rejected_loudly(pm):
-    pod = {"metadata": {"name": "p", "uid": "p"},
-           "spec": {"affinity": {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
-               {"topologyKey": "zone", "labelSelector": {}, "namespaceSelector": {}}]}}, "containers": []}}
-    pm.load_snapshot({"nodes": [{"metadata": {"name": "n"}}], "pods": [pod]})
-    with pytest.raises(RuntimeError, match="namespaceSelector"):
-        pm.evaluate()
+def test_decisions_break_score_ties_by_node_id(pm):
+    """Bin-pack order = ascending score, ties by NodeID STRING (yunikorn-core sorts nodes by score, then node id —
+    recollection, parity unpinned): the host uploads each node's position in name order (ykpred_nodes_t.name_rank)."""
+    names = ["node-b", "node-10", "node-9", "node-a", "node-1"]
+    alloc = {"cpu": "4", "memory": "8Gi", "pods": "10"}
+    busy = {"metadata": {"name": "busy", "uid": "busy"}, "spec": {"containers": [{"resources": {"requests": {"cpu": "1"}}}]}}
+    nodes = [{"metadata": {"name": n, "labels": {"g": "x" if i % 2 else "y"}}, "status": {"allocatable": alloc}} for i, n in enumerate(names)]
+    nodes.append({"metadata": {"name": "node-0", "labels": {"g": "x"}}, "status": {"allocatable": alloc}, "pods": [busy]})  # better score, alone
+    pods = [{"metadata": {"name": "any", "uid": "any"}, "spec": {"containers": []}},
+            {"metadata": {"name": "y", "uid": "y"}, "spec": {"nodeSelector": {"g": "y"}, "containers": []}},
+            {"metadata": {"name": "idle", "uid": "idle"}, "spec": {"containers": [],
+                                                              "affinity": {"nodeAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [
+                                                                  {"matchFields": [{"key": "metadata.name", "operator": "NotIn", "values": ["node-0"]}]}]}}}}}]
+    snap = {"nodes": nodes, "pods": pods}
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    o = orc.Oracle(snap)
+    dec = pm.read_decisions()
+    assert [o.decide(p)[1] for p in range(3)] == dec.tolist()
+    # "any": the busier node-0 wins on score; "y": among the idle g=y nodes (node-b, node-9, node-1) the smallest NAME is node-1;
+    # "idle": all idle nodes tie → node-1 ("node-1" < "node-10" < "node-9" < "node-a" < "node-b")
+    assert dec.tolist() == [5, 4, 4]
+
+
+def test_unsupported_asks_are_routed_individually(pm):
+    """Asks the engine does not evaluate (a PVC volume, a DRA claim, pod-affinity namespaceSelector, a repeated topologyKey)
+    are marked one by one: their rows are all zero, count 0, decision -1, Predicates() answers "route to the CPU manager"
+    (YKHOST_E_UNSUPPORTED) — and every OTHER ask of the same snapshot is evaluated as usual, bit for bit the oracle's."""
+    snap = _gen.random_snapshot(3131, n_nodes=90, n_pods=40)
+    def odd(i, spec_extra):
+        p = json.loads(json.dumps(snap["pods"][i]))
+        p["metadata"]["uid"] = p["metadata"]["name"] = f"odd-{i}"
+        p.setdefault("spec", {}).update(spec_extra)
+        return p
+    odd_pods = [
+        odd(0, {"volumes": [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc-1"}}]}),
+        odd(1, {"resourceClaims": [{"name": "gpu", "resourceClaimName": "claim-1"}]}),
+        odd(2, {"affinity": {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+            {"topologyKey": "zone", "labelSelector": {}, "namespaceSelector": {}}]}}}),
+        odd(3, {"topologySpreadConstraints": [
+            {"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": {"matchLabels": {"a": "b"}}},
+            {"maxSkew": 2, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": {"matchLabels": {"c": "d"}}}]}),
+        odd(4, {"volumes": [{"name": "scratch", "emptyDir": {}}, {"name": "cfg", "configMap": {"name": "x"}}]}),  # node-local: supported
+    ]
+    mixed = {"nodes": snap["nodes"], "pods": snap["pods"] + odd_pods}
+    pm.load_snapshot(mixed)
+    pm.evaluate()
+    P0 = len(snap["pods"])
+    want = orc.Oracle(snap).eval_grid(threads=8)
+    rows = unpack(pm.read_bitmap(), len(snap["nodes"]))
+    assert np.array_equal(rows[:P0], want)
+    counts, dec = pm.read_counts(), pm.read_decisions()
+    reasons = []
+    for k in range(4):
+        ok, why = pm.ask_supported(P0 + k)
+        assert not ok and why
+        reasons.append(why)
+        assert rows[P0 + k].sum() == 0 and counts[P0 + k] == 0 and dec[P0 + k] == -1
+        with pytest.raises(pkg.UnsupportedAsk):
+            pm.predicates(P0 + k, 0, True)
+        with pytest.raises(pkg.UnsupportedAsk):
+            pm.is_pod_fit_node(f"odd-{k}", snap["nodes"][0]["metadata"]["name"], True)
+    assert "persistentVolumeClaim" in reasons[0] and "resourceClaims" in reasons[1] and "namespaceSelector" in reasons[2] and "topologyKey" in reasons[3]
+    assert pm.ask_supported(P0 + 4) == (True, "")
+    assert np.array_equal(rows[P0 + 4], want[4])  # emptyDir / configMap volumes change nothing
+    fit, code, _ = pm.query(np.full(5, P0, dtype=np.int32), np.arange(5, dtype=np.int32))
+    assert not fit.any() and (code == 255).all()
+    st = pm.routing_stats()
+    assert st["unsupported_asks"] == 4 and st["routed_to_cpu"] >= 8
+
+
+def test_dictionary_overflow_only_drops_the_overflowing_asks(pm):
+    """700 asks that each select a different kubernetes.io/hostname need 700 requirement bits; the dictionary holds 512.
+    The first 512 are evaluated (and equal the oracle), the rest are marked unsupported — nobody else loses the engine."""
+    nodes = [{"metadata": {"name": f"n{i}", "labels": {"kubernetes.io/hostname": f"n{i}", "zone": f"z{i % 3}"}},
+              "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "20"}}} for i in range(700)]
+    pods = [{"metadata": {"name": f"p{i}", "uid": f"p{i}"},
+             "spec": {"nodeSelector": {"kubernetes.io/hostname": f"n{i}"}, "containers": [{"resources": {"requests": {"cpu": "1"}}}]}} for i in range(700)]
+    pods.append({"metadata": {"name": "plain", "uid": "plain"}, "spec": {"nodeSelector": {"zone": "z1"}, "containers": []}})
+    snap = {"nodes": nodes, "pods": pods}
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    supported = np.array([pm.ask_supported(i)[0] for i in range(701)])
+    assert supported[:512].all() and not supported[512:700].any() and supported[700]
+    assert "requirements" in pm.ask_supported(600)[1]
+    want = orc.Oracle(snap).eval_grid(threads=8)
+    rows = unpack(pm.read_bitmap(), 700)
+    assert np.array_equal(rows[supported], want[supported]) and rows[~supported].sum() == 0
+    assert pm.predicates("p5", "n5", True) == ("", None) and pm.predicates("plain", "n1", True) == ("", None)
 
 
 def test_node_ports_preemption(pm):

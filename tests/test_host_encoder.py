@@ -16,6 +16,7 @@ import _soa_eval as soa
 pkg = importlib.import_module("yunikorn-k8shim_amd")
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PRED = [c for c in json.load(open(os.path.join(GOLDEN, "predicate_cases.json"))) if c["test"] != "TestInterPodAffinity"]
+PRED += json.load(open(os.path.join(GOLDEN, "taint_cases.json")))  # e2e / KWOK TaintToleration behaviour, default plugin set
 
 
 @pytest.fixture()
@@ -102,3 +103,39 @@ def test_kwok_shards_reproduce_the_unsharded_cluster():
     finally:
         for m in (full, a, b):
             m.close()
+
+
+def test_unsupported_asks_are_marked_one_by_one(mirror):
+    """pods with PVC / zonal / CSI volumes or DRA claims used to be encoded as if the Volume* and
+    DynamicResources Filters had passed. They — like specs the API server rejects and asks whose dictionary entries do not
+    fit — are marked unsupported individually (spec flag 16 → plugin code 255), everything else still encodes."""
+    def p(name, **spec):
+        return {"metadata": {"name": name, "uid": name}, "spec": dict({"containers": []}, **spec)}
+    pods = [
+        p("pvc", volumes=[{"name": "d", "persistentVolumeClaim": {"claimName": "c"}}]),
+        p("ebs", volumes=[{"name": "d", "awsElasticBlockStore": {"volumeID": "v"}}]),
+        p("eph", volumes=[{"name": "d", "ephemeral": {"volumeClaimTemplate": {}}}]),
+        p("csi", volumes=[{"name": "d", "csi": {"driver": "x"}}]),
+        p("dra", resourceClaims=[{"name": "g"}]),
+        p("local", volumes=[{"name": "a", "emptyDir": {}}, {"name": "b", "secret": {"secretName": "s"}}, {"name": "c", "hostPath": {"path": "/x"}},
+                            {"name": "e", "projected": {"sources": []}}, {"name": "f", "downwardAPI": {}}]),
+        p("plain"),
+    ]
+    mirror.load_snapshot({"nodes": [{"metadata": {"name": "n0"}, "status": {"allocatable": {"cpu": "1", "pods": "10"}}}], "pods": pods})
+    got = [mirror.ask_supported(i) for i in range(len(pods))]
+    assert [ok for ok, _ in got] == [False, False, False, False, False, True, True]
+    assert "persistentVolumeClaim" in got[0][1] and "awsElasticBlockStore" in got[1][1] and "ephemeral" in got[2][1] and "csi" in got[3][1]
+    assert "resourceClaims" in got[4][1]
+    t = mirror.encoded_tables()
+    flags = [t["spec_flags"][t["pod_spec"][i]] for i in range(len(pods))]
+    assert [bool(f & 16) for f in flags] == [True] * 5 + [False, False]
+    for i in range(len(pods)):
+        fit, code = soa.eval_pair(t, i, 0, orc.ALL, orc.ALL)
+        assert (fit, code) == ((0, 255) if i < 5 else (1, 0))
+    # the volumes survive a dump → load round trip (the interning key distinguishes them from the plain template)
+    again = pkg.GpuPredicateManager(device=-1)
+    try:
+        again.load_snapshot(mirror.dump_snapshot())
+        assert [again.ask_supported(i)[0] for i in range(len(pods))] == [False] * 5 + [True, True]
+    finally:
+        again.close()

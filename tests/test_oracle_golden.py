@@ -30,6 +30,18 @@ def test_predicate_cases(case):
         assert msg, "a failing Predicates() call carries a message (predicate_manager.go:210,216)"
 
 
+@pytest.mark.parametrize("case", load("taint_cases.json"), ids=lambda c: c["name"][:60])
+def test_taint_cases(case):
+    """TaintToleration behaviour the reference holds outside unit tests: the two e2e scenarios
+    (test/e2e/predicates/predicates_test.go:334-447) and the KWOK perf-test shapes — whole default plugin set."""
+    import re
+    o = orc.Oracle({"nodes": [case["node"]], "pods": [case["pod"]]})
+    fits, plugin, msg = o.predicates(0, 0, orc.ALL, orc.ALL)
+    assert fits == case["fits"], f"{case['source']}: plugin={plugin!r} msg={msg!r}"
+    if not fits:
+        assert plugin == case["plugin"] and re.match(case["message_regex"], msg), (plugin, msg)
+
+
 @pytest.mark.parametrize("case", load("preemption_cases.json"), ids=lambda c: c["source"])
 def test_preemption_cases(case):
     mask = orc.mask_of(case["plugins"])
@@ -155,3 +167,38 @@ def test_node_resource_conversion():
     node = {"metadata": {"name": "n"}, "status": {"allocatable": {"cpu": "14500m", "memory": "1Gi", "pods": "110"}}}
     info = orc.Oracle({"nodes": [node], "pods": []}).node_info(0)
     assert info["alloc"][:2] == [14500, 1 << 30] and info["allowed_pods"] == 110
+
+
+def test_spread_state_is_kept_per_constraint():
+    """Two hard constraints on the SAME topologyKey with different selectors (a shape API validation rejects, and the
+    product's encoder refuses with that reason): the oracle restates k8s v1.36.1, where the PreFilter state is a slice
+    indexed by constraint (TpValueToMatchNum) — up to 1.2x one map keyed by {topologyKey, value} was shared, the second
+    constraint's per-node count overwrote the first's, and node n1 below would have been feasible."""
+    def existing(uid, labels):
+        return {"metadata": {"name": uid, "uid": uid, "namespace": "ns", "labels": labels}, "spec": {"containers": []}}
+    nodes = [{"metadata": {"name": "n1", "labels": {"zone": "a"}}, "status": {"allocatable": {"pods": "10"}},
+              "pods": [existing("e1", {"x": "1"}), existing("e2", {"x": "1"})]},
+             {"metadata": {"name": "n2", "labels": {"zone": "b"}}, "status": {"allocatable": {"pods": "10"}},
+              "pods": [existing("e3", {"y": "1"})]}]
+    def constraint(key, value):
+        return {"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": {"matchLabels": {key: value}}}
+    pod = {"metadata": {"name": "p", "uid": "p", "namespace": "ns", "labels": {"x": "1", "y": "1"}},
+           "spec": {"containers": [], "topologySpreadConstraints": [constraint("x", "1"), constraint("y", "1")]}}
+    o = orc.Oracle({"nodes": nodes, "pods": [pod]})
+    # constraint 0: zone a holds 2 matches, zone b 0 → n1: 2 + 1 - 0 > 1; constraint 1: a 0, b 1 → n2: 1 + 1 - 0 > 1
+    assert [o.predicates(0, n)[:2] for n in range(2)] == [(False, "PodTopologySpread"), (False, "PodTopologySpread")]
+    # each constraint alone leaves the other zone's node feasible
+    for keep, fits in ((0, [False, True]), (1, [True, False])):
+        single = json.loads(json.dumps(pod))
+        single["spec"]["topologySpreadConstraints"] = [pod["spec"]["topologySpreadConstraints"][keep]]
+        o1 = orc.Oracle({"nodes": nodes, "pods": [single]})
+        assert [o1.predicates(0, n)[0] for n in range(2)] == fits
+    # the product refuses the two-constraint shape (ValidateTopologySpreadConstraints: duplicate {topologyKey, whenUnsatisfiable})
+    import importlib
+    m = importlib.import_module("yunikorn-k8shim_amd").GpuPredicateManager(device=-1)
+    try:
+        m.load_snapshot({"nodes": nodes, "pods": [pod]})
+        ok, why = m.ask_supported(0)
+        assert not ok and "duplicate topologyKey" in why
+    finally:
+        m.close()

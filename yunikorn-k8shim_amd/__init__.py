@@ -6,6 +6,6 @@ The package name contains a hyphen; import it with importlib.import_module("yuni
 """
 from . import build  # noqa: F401
 from .predicate_manager import (ALL_PLUGINS, PLUGIN_BITS, GpuPredicateManager, PredicateError,  # noqa: F401
-                                plugin_mask)
+                                UnsupportedAsk, plugin_mask)
 
 build_all = build.build_all

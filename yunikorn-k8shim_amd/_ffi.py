@@ -17,7 +17,7 @@ class YkpredNodes(C.Structure):
     _fields_ = [("count", C.c_int32), ("allocatable", C.c_void_p), ("requested", C.c_void_p), ("allowed_pods", C.c_void_p),
                 ("pod_count", C.c_void_p), ("flags", C.c_void_p), ("taint_bits", C.c_void_p), ("label_bits", C.c_void_p),
                 ("domain_id", C.c_void_p), ("selector_count", C.c_void_p), ("domain_sizes", C.c_void_p),
-                ("port_bits", C.c_void_p)]
+                ("port_bits", C.c_void_p), ("name_rank", C.c_void_p)]
 
 
 class YkpredSpecs(C.Structure):
@@ -163,5 +163,7 @@ def load_ykhost():
     L.ykhost_is_pod_fit_node_via_preemption.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32]
     L.ykhost_pod_request_json.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykhost_ask_supported.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
+    L.ykhost_routing_stats.argtypes = [C.c_void_p, C.c_void_p]
     _host = L
     return L

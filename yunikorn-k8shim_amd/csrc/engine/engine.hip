@@ -109,7 +109,8 @@ struct ykpred_engine {
   DevBuf d_alloc, d_req, d_allowed, d_count, d_nflags, d_taints, d_labels, d_domain, d_selcount, d_ports;
   int KD = 0, KS = 0, KP = 0;
   std::vector<int32_t> h_domain_sizes;
-  DevBuf d_score, d_key, d_rank, d_perm, d_rankbuf, d_member_key;
+  DevBuf d_score, d_key, d_rank, d_perm, d_rankbuf, d_member_key, d_name_rank, d_member_tie;
+  bool has_name_rank = false;
   bool nodes_set = false;
 
   // --- specs (host copies kept for class building)
@@ -709,7 +710,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
-                    &e->d_member_key})
+                    &e->d_member_key, &e->d_name_rank, &e->d_member_tie})
     b->release();
   if (e->ev_ready)
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
@@ -747,6 +748,9 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   TRY(upload(e, e->d_domain, n->domain_id, N * (size_t)e->KD, st));
   TRY(upload(e, e->d_selcount, n->selector_count, N * (size_t)e->KS, st));
   TRY(upload(e, e->d_ports, n->port_bits, N * (size_t)e->KP, st));
+  e->has_name_rank = n->name_rank != nullptr && N > 0;
+  if (e->has_name_rank) TRY(upload(e, e->d_name_rank, n->name_rank, N, st));
+  HIPCHK(e->d_member_tie.ensure(std::max<size_t>(N, 1) * sizeof(int)));
   for (int k = 0; k < ykk::kMaxKT; ++k) e->taint_used[k] = 0;
   for (int k = 0; k < e->KT; ++k)
     for (size_t i = 0; i < N; ++i) e->taint_used[k] |= n->taint_bits[(size_t)k * N + i];
@@ -810,6 +814,8 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
     HIPCHK(hipMemcpyAsync(e->d_selcount.as<int>() + (size_t)k * N + idx, n->selector_count + k, sizeof(int), hipMemcpyHostToDevice, st));
   for (int k = 0; k < e->KP; ++k)
     HIPCHK(hipMemcpyAsync(e->d_ports.as<u64>() + (size_t)k * N + idx, n->port_bits + k, sizeof(u64), hipMemcpyHostToDevice, st));
+  if (e->has_name_rank && n->name_rank)
+    HIPCHK(hipMemcpyAsync(e->d_name_rank.as<int>() + idx, n->name_rank, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
   return YKPRED_OK;
 }
@@ -919,7 +925,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     }
     e->spec_sig_res[(size_t)i] = it->second;
 
-    uint32_t tf = s->flags[i] & YKPRED_SPEC_TOLERATES_UNSCHEDULABLE;
+    uint32_t tf = s->flags[i] & (YKPRED_SPEC_TOLERATES_UNSCHEDULABLE | YKPRED_SPEC_UNSUPPORTED);
     std::string kt((const char*)(s->tolerated + (size_t)i * KT), (size_t)KT * sizeof(u64));
     kt.append((const char*)&tf, sizeof(tf));
     if (KP > 0) kt.append((const char*)(s->wanted_ports + (size_t)i * KP), (size_t)KP * sizeof(u64));  // NodePorts rides in this family
@@ -1187,9 +1193,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     hipLaunchKernelGGL(ykk::k_rank_hist, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), hist);
     hipLaunchKernelGGL(ykk::k_rank_scan, dim3(1), dim3(ykk::kRankBuckets), 0, sb, hist, bucket_off, cursor);
     hipLaunchKernelGGL(ykk::k_rank_fill, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, N, e->d_score.as<double>(), e->d_key.as<u64>(),
-                       cursor, members, e->d_member_key.as<u64>());
+                       e->has_name_rank ? e->d_name_rank.as<int>() : (const int*)nullptr, cursor, members, e->d_member_tie.as<int>(),
+                       e->d_member_key.as<u64>());
     hipLaunchKernelGGL(ykk::k_rank_final, dim3((unsigned)ykk::kRankBuckets), dim3(ykk::kBlock), 0, sb, bucket_off, members,
-                       e->d_member_key.as<u64>(), e->d_rank.as<int>(), e->d_perm.as<int>());
+                       e->d_member_tie.as<int>(), e->d_member_key.as<u64>(), e->d_rank.as<int>(), e->d_perm.as<int>());
     tm.end(sb, "k_rank");
   }
   // Bit-sliced dictionaries + signature planes of one node order (perm == nullptr: canonical) on stream s.

@@ -51,7 +51,8 @@ constexpr unsigned kSpreadHonorAffinity = 1u << 0, kSpreadHonorTaints = 1u << 1;
 constexpr unsigned kPlugUnsched = 1u << 0, kPlugNodeName = 1u << 1, kPlugTaint = 1u << 2, kPlugAffinity = 1u << 3,
                    kPlugPorts = 1u << 4, kPlugFit = 1u << 5, kPlugSpread = 1u << 6, kPlugInterPod = 1u << 7;
 constexpr int kKindSpread = 0, kKindPodAffinity = 1, kKindPodAntiAffinity = 2, kKindExistingAnti = 3;
-constexpr unsigned kSpecToleratesUnsched = 1u << 0, kSpecAffSkip = 1u << 1, kSpecPreReject = 1u << 2, kSpecPreNames = 1u << 3;
+constexpr unsigned kSpecToleratesUnsched = 1u << 0, kSpecAffSkip = 1u << 1, kSpecPreReject = 1u << 2, kSpecPreNames = 1u << 3,
+                   kSpecUnsupported = 1u << 4;
 constexpr unsigned kNodeUnschedulable = 1u << 0;
 
 struct NodeTable {
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(kBlock) void k_score(NodeTable t, double* __restric
   score[n] = s;
   key[n] = sortable_key(s);
 }
-// Bin-pack ORDER: rank[n] = #{m : (key_m, m) < (key_n, n)}, perm[rank[n]] = n — an exact sort by (score, node index).
+// Bin-pack ORDER: rank[n] = #{m : (key_m, tie_m) < (key_n, tie_n)}, perm[rank[n]] = n — an exact sort by (score, tie) with
+// tie = the node's position in NodeID order (ykpred_nodes_t.name_rank) or its index.
 // Nodes are first bucketed by a monotone function of the score (kRankBuckets equal-width bins of [0,1], clamped), so
 // the bucket sequence already agrees with the key order; the exact rank is the bucket's start plus the rank among
 // the ~N/1024 members of the same bucket. Four tiny kernels instead of N² compares (50k nodes: 2.5e9 → ~3e6).
@@ -137,11 +139,13 @@ __global__ __launch_bounds__(kRankBuckets) void k_rank_scan(const int* __restric
   if (t == kRankBuckets - 1) bucket_off[kRankBuckets] = tmp[t];
 }
 __global__ __launch_bounds__(kBlock) void k_rank_fill(int n_nodes, const double* __restrict__ score, const u64* __restrict__ key,
-                                                      int* __restrict__ cursor, int* __restrict__ members, u64* __restrict__ member_key) {
+                                                      const int* __restrict__ name_rank, int* __restrict__ cursor, int* __restrict__ members,
+                                                      int* __restrict__ member_tie, u64* __restrict__ member_key) {
   int n = blockIdx.x * kBlock + threadIdx.x;
   if (n >= n_nodes) return;
   int pos = atomicAdd(&cursor[rank_bucket(score[n])], 1);
   members[pos] = n;
+  member_tie[pos] = name_rank ? name_rank[n] : n;  // tie-break between equal scores: NodeID order (or node index)
   member_key[pos] = key[n];  // keys travel with the ids: the final pass streams them instead of chasing key[members[i]]
 }
 // One block per bucket: the bucket's (key, node) pairs are staged through LDS in tiles and every member counts the
@@ -149,8 +153,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_fill(int n_nodes, const double*
 // bandwidth-saturating k_combine) and of bucket skew (e.g. all idle nodes share score 1.0 and one bucket).
 constexpr int kRankTile = 1024;
 __global__ __launch_bounds__(kBlock) void k_rank_final(const int* __restrict__ bucket_off, const int* __restrict__ members,
-                                                       const u64* __restrict__ member_key, int* __restrict__ rank,
-                                                       int* __restrict__ perm) {
+                                                       const int* __restrict__ member_tie, const u64* __restrict__ member_key,
+                                                       int* __restrict__ rank, int* __restrict__ perm) {
   __shared__ u64 t_key[kRankTile];
   __shared__ int t_idx[kRankTile];
   const int lo = bucket_off[blockIdx.x], hi = bucket_off[blockIdx.x + 1];
@@ -158,13 +162,13 @@ __global__ __launch_bounds__(kBlock) void k_rank_final(const int* __restrict__ b
     const int i = base + threadIdx.x;
     const bool live = i < hi;
     const u64 mine = live ? member_key[i] : 0ull;
-    const int me = live ? members[i] : 0;
+    const int me = live ? member_tie[i] : 0, me_node = live ? members[i] : 0;
     int r = lo;
     for (int tb = lo; tb < hi; tb += kRankTile) {
       __syncthreads();
       for (int j = threadIdx.x; j < kRankTile && tb + j < hi; j += kBlock) {
         t_key[j] = member_key[tb + j];
-        t_idx[j] = members[tb + j];
+        t_idx[j] = member_tie[tb + j];
       }
       __syncthreads();
       const int lim = min(kRankTile, hi - tb);
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_final(const int* __restrict__ b
         for (int j = 0; j < lim; ++j) r += (t_key[j] < mine) || (t_key[j] == mine && t_idx[j] < me);
     }
     if (live) {
-      rank[me] = r;
-      perm[r] = me;
+      rank[me_node] = r;
+      perm[r] = me_node;
     }
   }
 }
@@ -479,6 +483,7 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           }
         }
       if (!(a.sig_tolflags[d] & kSpecToleratesUnsched)) bad |= unsched;
+      if (a.sig_tolflags[d] & kSpecUnsupported) bad = ~0ull;  // not evaluated by the engine: fits nowhere (this family is always on)
       if (ports_en)  // NodePorts: a requested host port that is in conflict on the node
         for (int k = 0; k < a.KP; ++k) {
           u64 m = a.sig_ports[(size_t)d * a.KP + k];
@@ -985,6 +990,10 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
   unsigned f = s.flags[spec];
   *code = 0;
   *reason = 0;
+  if (f & kSpecUnsupported) {  // the host routes this ask to the CPU manager
+    *code = 255;
+    return false;
+  }
   // --- PreFilter plugins, MultiPoint order: NodeAffinity, NodeResourcesFit (never rejects), PodTopologySpread
   if ((pre_mask & kPlugAffinity) && !(f & kSpecAffSkip)) {
     if (f & kSpecPreReject) {

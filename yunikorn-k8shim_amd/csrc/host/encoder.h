@@ -12,8 +12,11 @@
 //   * a host-port dictionary (NodePorts): every distinct (protocol, hostIP, hostPort) some ask requests gets a bit; a
 //     node's bit says "a pod already here conflicts with it" (HostPortInfo.CheckConflict incl. the 0.0.0.0 wildcard),
 //   * topology-domain ids and per-selector matching-pod counts for PodTopologySpread.
-// Pods carrying features the engine does not evaluate (inter-pod affinity, volumes, matchLabelKeys) are REJECTED
-// with an error — never silently passed, and there is no CPU evaluation fallback in this library.
+// Asks carrying features the engine does not evaluate (volumes / DRA claims, namespaceSelector, matchLabelKeys, specs the
+// API server would have rejected) or whose dictionary entries do not fit the engine's limits are marked UNSUPPORTED one by
+// one (Encoder::unsupported: template → reason): their spec row carries YKPRED_SPEC_UNSUPPORTED, every pair of their bitmap
+// row is 0 with plugin code YKPRED_CODE_UNSUPPORTED, and the host routes exactly those asks to the CPU predicate manager
+//  — never silently passed, and every other ask keeps evaluating on the device.
 #pragma once
 #include <algorithm>
 #include <limits>
@@ -219,6 +222,9 @@ class Encoder {
   std::vector<std::string> topo_keys;                                 // topology key k
   std::vector<std::unordered_map<std::string, int>> domain_ids;       // value → id, per key (ids follow sorted values)
   std::vector<SelectorClass> sel_classes;                             // selector class s
+  std::unordered_map<const PodTemplate*, std::string> unsupported;    // asks' templates the engine does not evaluate → why
+  // engine limits (kernels.hip.h: kMaxR / kMaxKT / kMaxW / kMaxKP / kMaxKD; selector classes: ykpred_create)
+  static constexpr int kLimitR = 8, kLimitTaints = 256, kLimitRequirements = 512, kLimitPorts = 256, kLimitTopoKeys = 8, kLimitClasses = 4096;
 
   // Builds every dictionary from the current objects. Returns false (error set) on unsupported input.
   bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates) {
@@ -234,6 +240,9 @@ class Encoder {
     domain_ids.clear();
     sel_classes.clear();
     sel_ix_.clear();
+    sel_keys_.clear();
+    req_keys_.clear();
+    unsupported.clear();
     sel_memo_.clear();
     port_dict.clear();
     port_ix_.clear();
@@ -254,11 +263,27 @@ class Encoder {
             }
           }
     }
+    // node-driven entries first (they cannot be attributed to an ask: exceeding a limit here fails the whole encode)
+    for (const NodeInfo* ni : nodes) {
+      for (auto& kv : ni->allocatable.scalar) scalar(kv.first);
+      for (auto& kv : ni->requested.scalar) scalar(kv.first);
+      for (auto& t : ni->node.taints)
+        if (t.effect == "NoSchedule" || t.effect == "NoExecute") taint(t);
+    }
+    if (3 + (int)scalar_names.size() > kLimitR) return fail("more than 5 scalar resource names on the nodes (engine limit R<=8)");
+    if ((int)taint_dict.size() > kLimitTaints) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
+    if ((int)topo_keys.size() > kLimitTopoKeys) return fail("more than 8 topology keys in the anti-affinity terms of pods already on nodes (engine limit)");
+    // ask-driven entries, template by template: a template whose entries would not fit is rolled back and marked
+    // unsupported on its own — the asks before and after it keep their place in the dictionaries
     for (const PodTemplate* t : templates) {
       {
         std::string why = template_error(*t);
-        if (!why.empty()) return fail(why);
+        if (!why.empty()) {
+          unsupported[t] = why;
+          continue;
+        }
       }
+      const Mark mark = mark_now();
       for (auto* terms : {&t->pod_affinity, &t->pod_anti_affinity})
         for (auto& term : *terms) topo_key(term.topology_key);
       if (!t->pod_affinity.empty())
@@ -280,12 +305,21 @@ class Encoder {
       }
       for (auto& kv : t->requests)
         if (is_scalar_resource_name(kv.first)) scalar(kv.first);
+      collect_requirements(*t);
+      const char* over = nullptr;
+      if (3 + (int)scalar_names.size() > kLimitR) over = "scalar resource names (engine limit: 5 besides cpu, memory, ephemeral-storage)";
+      else if ((int)req_dict.size() > kLimitRequirements) over = "distinct node-selector requirements (engine limit: 512)";
+      else if ((int)port_dict.size() > kLimitPorts) over = "distinct requested host ports (engine limit: 256)";
+      else if ((int)topo_keys.size() > kLimitTopoKeys) over = "topology keys in spread / pod-affinity constraints (engine limit: 8)";
+      else if ((int)sel_classes.size() > kLimitClasses) over = "distinct pod-selector classes (engine limit: 4096)";
+      if (over) {
+        rollback(mark);
+        unsupported[t] = std::string("the ask needs more ") + over + " than the dictionaries can still take";
+      }
     }
     KD = (int)topo_keys.size();
     KS = (int)sel_classes.size();
     KP = ((int)port_dict.size() + 63) / 64;
-    if (KP > 4) return fail("more than 256 distinct requested host ports (engine limit)");
-    if (KD > 8) return fail("more than 8 distinct topology keys in spread / pod-affinity constraints (engine limit)");
     domain_ids.assign((size_t)KD, {});
     for (int k = 0; k < KD; ++k) {
       std::set<std::string> values;
@@ -296,20 +330,9 @@ class Encoder {
       int id = 0;
       for (auto& v : values) domain_ids[(size_t)k][v] = id++;
     }
-    for (const NodeInfo* ni : nodes) {
-      for (auto& kv : ni->allocatable.scalar) scalar(kv.first);
-      for (auto& kv : ni->requested.scalar) scalar(kv.first);
-      for (auto& t : ni->node.taints)
-        if (t.effect == "NoSchedule" || t.effect == "NoExecute") taint(t);
-    }
     R = 3 + (int)scalar_names.size();
     KT = std::max(1, ((int)taint_dict.size() + 63) / 64);
-    // requirement dictionary: walk every template's selector AST
-    for (const PodTemplate* t : templates) collect_requirements(*t);
     W = std::max(1, ((int)req_dict.size() + 63) / 64);
-    if (R > 8) return fail("more than 5 scalar resource names in use (engine limit R<=8)");
-    if (KT > 4) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
-    if (W > 8) return fail("more than 512 distinct node-selector requirements (engine limit)");
     label_keys_.clear();
     label_reqs_.clear();
     name_reqs_.clear();
@@ -338,6 +361,13 @@ class Encoder {
   // What build_dictionaries refuses in a pending ask's template ("" = acceptable): features the engine does not evaluate
   // and inputs the upstream PreFilters reject.
   std::string template_error(const PodTemplate& t) const {
+    if (!t.volume_kinds.empty()) {
+      std::string kinds;
+      for (auto& k : t.volume_kinds) kinds += (kinds.empty() ? "" : ", ") + k;
+      return "the pod mounts volumes (" + kinds + ") that VolumeBinding / VolumeZone / VolumeRestrictions / NodeVolumeLimits must check against PV, PVC "
+             "and CSINode state the engine does not hold";
+    }
+    if (t.resource_claims > 0) return "the pod carries spec.resourceClaims (DynamicResources needs ResourceSlice / ResourceClaim state the engine does not hold)";
     if (t.pod_affinity_unsupported) return "pod (anti)affinity namespaceSelector / matchLabelKeys are not supported by the engine";
     for (auto* terms : {&t.pod_affinity, &t.pod_anti_affinity})
       for (auto& term : *terms) {
@@ -360,7 +390,7 @@ class Encoder {
   // (a new selector requirement, scalar resource, host port, topology key or count class) or is not acceptable at all:
   // the caller then rebuilds the dictionaries.
   bool encode_spec_if_covered(const PodTemplate& t, EncodedSpec* spec, std::vector<uint64_t>* wanted) const {
-    if (!template_error(t).empty()) return false;
+    if (!template_error(t).empty() || unsupported.count(&t)) return false;
     missing_ = false;
     try {
       *spec = encode_spec(t);
@@ -530,6 +560,12 @@ class Encoder {
   EncodedSpec encode_spec(const PodTemplate& t) const {
     EncodedSpec s;
     s.req.assign((size_t)R, 0);
+    if (unsupported.count(&t)) {  // a row that fits nowhere, flagged so that the host routes the ask to the CPU manager
+      s.tol.assign((size_t)KT, 0);
+      s.flags = YKPRED_SPEC_UNSUPPORTED | YKPRED_SPEC_AFFINITY_SKIP;
+      s.terms.push_back(std::vector<uint64_t>((size_t)W, 0));
+      return s;
+    }
     for (auto& kv : t.requests) {
       if (kv.first == "cpu")
         s.req[0] = kv.second;
@@ -719,9 +755,40 @@ class Encoder {
     if (it != sel_ix_.end()) return it->second;
     int id = (int)sel_classes.size();
     sel_ix_.emplace(key, id);
+    sel_keys_.push_back(key);
     sel_classes.push_back(std::move(sc));
     return id;
   }
+  // dictionary sizes before one template's entries are added, and their removal again
+  struct Mark {
+    size_t scalars, reqs, topo, sel, ports;
+  };
+  Mark mark_now() const { return Mark{scalar_names.size(), req_dict.size(), topo_keys.size(), sel_classes.size(), port_dict.size()}; }
+  void rollback(const Mark& m) {
+    while (scalar_names.size() > m.scalars) {
+      scalar_ix_.erase(scalar_names.back());
+      scalar_names.pop_back();
+    }
+    while (req_dict.size() > m.reqs) {
+      req_ix_.erase(req_keys_.back());
+      req_keys_.pop_back();
+      req_dict.pop_back();
+    }
+    while (topo_keys.size() > m.topo) {
+      topo_ix_.erase(topo_keys.back());
+      topo_keys.pop_back();
+    }
+    while (sel_classes.size() > m.sel) {
+      sel_ix_.erase(sel_keys_.back());
+      sel_keys_.pop_back();
+      sel_classes.pop_back();
+    }
+    while (port_dict.size() > m.ports) {
+      port_ix_.erase(port_key(port_dict.back()));
+      port_dict.pop_back();
+    }
+  }
+  std::vector<std::string> sel_keys_, req_keys_;  // keys of sel_classes / req_dict entries, in order (for rollback)
   void topo_key(const std::string& k) {
     if (topo_ix_.emplace(k, (int)topo_keys.size()).second) topo_keys.push_back(k);
   }
@@ -763,6 +830,7 @@ class Encoder {
   void add_req(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) {
     std::string rk = req_key(k, key, op, values);
     if (req_ix_.count(rk)) return;
+    req_keys_.push_back(rk);
     req_ix_.emplace(std::move(rk), (int)req_dict.size());
     DictReq d;
     d.kind = k;

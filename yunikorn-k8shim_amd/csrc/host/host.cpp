@@ -55,7 +55,7 @@ using namespace ykh;
 struct EncodedTables {
   std::vector<uint64_t> ports, taints, labels, stol, aff_terms, pre_terms, wanted;
   std::vector<int64_t> alloc, req, sreq;
-  std::vector<int32_t> allowed, count, domain, selcount, dsizes, aff_off, pre_off, spread_off;
+  std::vector<int32_t> allowed, count, domain, selcount, dsizes, aff_off, pre_off, spread_off, name_rank;
   std::vector<uint32_t> flags, sflags;
   std::vector<ykpred_spread_t> spread;
   ykpred_nodes_t nt{};
@@ -110,6 +110,8 @@ struct ykhost {
   bool comm_attached = false;                // ykhost_comm_init: the engine carries an RCCL communicator
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
+  int64_t unsupported_asks = 0;    // asks whose template the encoder marked unsupported at the last full encode
+  int64_t routed_to_cpu = 0;       // Predicates() calls answered YKHOST_E_UNSUPPORTED (the Go side's fallback counter)
   int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1, cfgKP = -1;
 
   void clear_state() {
@@ -234,6 +236,9 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   }
   auto _t1 = std::chrono::steady_clock::now();
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
+  h->unsupported_asks = 0;
+  if (!h->enc.unsupported.empty())
+    for (const Pod* p : h->pending) h->unsupported_asks += h->enc.unsupported.count(p->tpl) ? 1 : 0;
   auto _t2 = std::chrono::steady_clock::now();
   const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS, KP = h->enc.KP;
   const size_t N = h->nodes.size();
@@ -283,6 +288,14 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   nt.selector_count = T->selcount.data();
   nt.domain_sizes = T->dsizes.data();
   nt.port_bits = T->ports.data();
+  {  // NodeID order: the tie-break of the bin-pack order between nodes of equal score
+    std::vector<int32_t> by_name(N);
+    for (size_t n = 0; n < N; ++n) by_name[n] = (int32_t)n;
+    std::sort(by_name.begin(), by_name.end(), [&](int32_t x, int32_t y) { return h->nodes[(size_t)x]->node.name < h->nodes[(size_t)y]->node.name; });
+    T->name_rank.assign(N, 0);
+    for (size_t r = 0; r < N; ++r) T->name_rank[(size_t)by_name[r]] = (int32_t)r;
+    nt.name_rank = T->name_rank.data();
+  }
 
   const size_t S = h->spec_templates.size();
   T->sreq.assign(S * R, 0);
@@ -454,6 +467,8 @@ int node_row_sync(ykhost* h, int n) {
   nt.flags = &flags;
   nt.taint_bits = t.data();
   nt.label_bits = l.data();
+  const int32_t keep_rank = h->tables && (size_t)n < h->tables->name_rank.size() ? h->tables->name_rank[(size_t)n] : n;
+  nt.name_rank = &keep_rank;  // a node keeps its name, hence its place in NodeID order
   int rc = ykpred_update_node(h->eng, n, &nt);
   if (rc) return fail(h, std::string("ykpred_update_node: ") + ykpred_last_error(h->eng), rc);
   return 0;
@@ -1471,6 +1486,15 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
   if (pod < 0 || pod >= (int)h->pending.size() || node < 0 || node >= (int)h->nodes.size()) return fail(h, "index out of range", -1);
   int rc = sync(h);
   if (rc) return rc;
+  {
+    auto un = h->enc.unsupported.find(h->pending[(size_t)pod]->tpl);
+    if (un != h->enc.unsupported.end()) {  // not evaluated by the engine: the caller's CPU predicate manager answers
+      h->routed_to_cpu++;
+      copy_out("", plugin, plugin_len);
+      copy_out(un->second, msg, msg_len);
+      return fail(h, "ask is not evaluated by the engine (route it to the CPU predicate manager): " + un->second, YKHOST_E_UNSUPPORTED);
+    }
+  }
   // one device round trip per (ask, phase): the answers for all nodes are fetched together and cached
   if (h->answers.pod != pod || h->answers.phase != (allocate ? 1 : 0)) {
     const size_t N = h->nodes.size();
@@ -1581,7 +1605,7 @@ int32_t ykhost_is_pod_fit_node(ykhost_t* h, const char* allocation_key, const ch
   }
   char plugin[64], msg[1024];
   int rc = ykhost_predicates(h, it->second->row, nt->second, allocate, plugin, sizeof plugin, msg, sizeof msg);
-  if (rc < 0) {
+  if (rc < 0) {  // includes YKHOST_E_UNSUPPORTED: the Go side calls the CPU manager for this ask
     copy_out(h->err, err, err_len);
     return rc;
   }
@@ -1614,6 +1638,31 @@ int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len
   }
   js += "}";
   copy_out(js, out, len);
+  return 0;
+}
+
+// 1 = the ask is evaluated on the device, 0 = it is routed to the CPU predicate manager (reason copied out)
+int32_t ykhost_ask_supported(ykhost_t* h, int32_t pod, char* reason, int32_t reason_len) {
+  YKHOST_LOCKED(h);
+  if (pod < 0 || pod >= (int)h->pending.size()) return fail(h, "index out of range");
+  if (h->device < 0) {  // mirror-only handle: encode without a device (like ykhost_encoded_tables_json)
+    EncodedTables T;
+    int rc = encode_tables(h, &T);
+    h->dirty_all = true;
+    if (rc) return rc;
+  } else {
+    int rc = sync(h);
+    if (rc) return rc;
+  }
+  auto un = h->enc.unsupported.find(h->pending[(size_t)pod]->tpl);
+  copy_out(un == h->enc.unsupported.end() ? "" : un->second, reason, reason_len);
+  return un == h->enc.unsupported.end() ? 1 : 0;
+}
+// out[0] = asks marked unsupported at the last encode, out[1] = Predicates() calls answered YKHOST_E_UNSUPPORTED so far
+int32_t ykhost_routing_stats(ykhost_t* h, int64_t* out2) {
+  YKHOST_LOCKED(h);
+  out2[0] = h->unsupported_asks;
+  out2[1] = h->routed_to_cpu;
   return 0;
 }
 

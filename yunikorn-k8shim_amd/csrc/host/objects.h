@@ -6,6 +6,7 @@
 // of the pod except its identity (uid/name) and spec.nodeName, so a million replicas of a few thousand
 // Deployments / gang task groups cost one template each (placeholder.go:113-157 builds exactly such clones).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -80,6 +81,12 @@ struct PodTemplate {
   std::vector<SpreadConstraint> spread;
   std::vector<PodAffinityTerm> pod_affinity, pod_anti_affinity;  // requiredDuringSchedulingIgnoredDuringExecution
   bool pod_affinity_unsupported = false;  // namespaceSelector / matchLabelKeys / mismatchLabelKeys present
+  // spec.volumes entries of a kind one of the Volume* Filters inspects (VolumeBinding, VolumeZone, VolumeRestrictions,
+  // NodeVolumeLimits: everything except the node-local kinds below) and the number of spec.resourceClaims (DynamicResources).
+  // Those plugins need PV / PVC / StorageClass / CSINode / ResourceSlice state the engine does not hold: such an ask is
+  // marked unsupported and routed to the CPU predicate manager, never answered "fits" by omission.
+  std::vector<std::string> volume_kinds;
+  int32_t resource_claims = 0;
   std::string canonical;      // interning key (canonical JSON of the fields above)
   // derived once at interning time
   ResMap requests;            // upstream PodRequests (resource.go:56-109 minus the "pods" entry)
@@ -442,6 +449,21 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
     }
     spec.push_back(']');
   }
+  if (!t.volume_kinds.empty()) {
+    spec += ",\"volumes\":[";
+    for (size_t i = 0; i < t.volume_kinds.size(); ++i) {
+      if (i) spec.push_back(',');
+      spec += "{\"name\":\"v" + std::to_string(i) + "\",";
+      js_str(spec, t.volume_kinds[i]);
+      spec += ":{}}";
+    }
+    spec.push_back(']');
+  }
+  if (t.resource_claims > 0) {
+    spec += ",\"resourceClaims\":[";
+    for (int32_t i = 0; i < t.resource_claims; ++i) spec += std::string(i ? "," : "") + "{\"name\":\"c" + std::to_string(i) + "\"}";
+    spec.push_back(']');
+  }
   if (t.has_overhead) {
     spec += ",\"overhead\":";
     js_map(spec, t.overhead);
@@ -673,6 +695,21 @@ inline PodTemplate read_template(const mj::Value& v) {
     t.overhead = read_strmap(oh);
   }
   if (const mj::Value* res = spec->get_nn("resources")) t.pod_level_requests = read_strmap(res->get_nn("requests"));
+  if (const mj::Value* vols = spec->get_nn("volumes"))
+    for (auto& vol : vols->arr) {
+      if (!vol->is_obj()) continue;
+      for (auto& kv : vol->obj) {
+        if (kv.first == "name" || kv.second->is_null()) continue;
+        // node-local volume sources no Volume* Filter looks at
+        static const char* kLocal[] = {"emptyDir", "configMap", "secret", "downwardAPI", "projected", "hostPath", "image"};
+        bool local = false;
+        for (const char* k : kLocal) local = local || kv.first == k;
+        if (!local && std::find(t.volume_kinds.begin(), t.volume_kinds.end(), kv.first) == t.volume_kinds.end()) t.volume_kinds.push_back(kv.first);
+      }
+    }
+  std::sort(t.volume_kinds.begin(), t.volume_kinds.end());
+  if (const mj::Value* rc = spec->get_nn("resourceClaims"))
+    if (rc->is_arr()) t.resource_claims = (int32_t)rc->arr.size();
   if (const mj::Value* tsc = spec->get_nn("topologySpreadConstraints"))
     for (auto& c : tsc->arr) {
       SpreadConstraint sc;

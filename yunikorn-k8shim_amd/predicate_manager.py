@@ -45,6 +45,10 @@ def plugin_mask(names):
     return m
 
 
+class UnsupportedAsk(Exception):
+    """Predicates() on an ask the engine does not evaluate (YKHOST_E_UNSUPPORTED): the CPU PredicateManager must answer it."""
+
+
 class PredicateError(Exception):
     """The error value returned by Predicates(): carries the failing plugin like Context.IsPodFitNode's joined error."""
 
@@ -208,7 +212,10 @@ class GpuPredicateManager:
         p, n = self._resolve(pod, node)
         plugin = C.create_string_buffer(64)
         msg = C.create_string_buffer(512)
-        rc = self._check(self._L.ykhost_predicates(self._h, p, n, 1 if allocate else 0, plugin, 64, msg, 512))
+        rc = self._L.ykhost_predicates(self._h, p, n, 1 if allocate else 0, plugin, 64, msg, 512)
+        if rc == -13:
+            raise UnsupportedAsk(msg.value.decode())
+        self._check(rc)
         if rc == 1:
             return "", None
         return plugin.value.decode(), PredicateError(plugin.value.decode(), msg.value.decode())
@@ -223,6 +230,8 @@ class GpuPredicateManager:
             return None
         if rc in (0, -10, -11):
             return err.value.decode()
+        if rc == -13:
+            raise UnsupportedAsk(err.value.decode())
         raise RuntimeError(err.value.decode() or self._L.ykhost_last_error(self._h).decode())
 
     def is_pod_fit_node_via_preemption(self, allocation_key, node_id, preempt_allocation_keys, start_index):
@@ -267,6 +276,18 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_preemption_predicates_batch(self._h, len(queries), pa.ctypes.data, na.ctypes.data, oa.ctypes.data, arr,
                                                                sa.ctypes.data, out.ctypes.data))
         return out.tolist()
+
+    def ask_supported(self, pod):
+        """(True, "") when the engine evaluates pending pod #pod, else (False, reason): that ask goes to the CPU manager."""
+        p = pod if isinstance(pod, int) else self.pod_index(pod)
+        buf = C.create_string_buffer(600)
+        rc = self._check(self._L.ykhost_ask_supported(self._h, p, buf, 600))
+        return rc == 1, buf.value.decode()
+
+    def routing_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._L.ykhost_routing_stats(self._h, out.ctypes.data)
+        return {"unsupported_asks": int(out[0]), "routed_to_cpu": int(out[1])}
 
     def pod_request(self, pod):
         buf = C.create_string_buffer(4096)
