@@ -892,17 +892,20 @@ def test_dictionary_overflow_only_drops_the_overflowing_asks(pm):
               "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "20"}}} for i in range(700)]
     pods = [{"metadata": {"name": f"p{i}", "uid": f"p{i}"},
              "spec": {"nodeSelector": {"kubernetes.io/hostname": f"n{i}"}, "containers": [{"resources": {"requests": {"cpu": "1"}}}]}} for i in range(700)]
-    pods.append({"metadata": {"name": "plain", "uid": "plain"}, "spec": {"nodeSelector": {"zone": "z1"}, "containers": []}})
+    pods.insert(0, {"metadata": {"name": "plain", "uid": "plain"}, "spec": {"nodeSelector": {"zone": "z1"}, "containers": []}})
     snap = {"nodes": nodes, "pods": pods}
     pm.load_snapshot(snap)
     pm.evaluate()
     supported = np.array([pm.ask_supported(i)[0] for i in range(701)])
-    assert supported[:512].all() and not supported[512:700].any() and supported[700]
+    # first come, first served: "plain" takes one bit, 511 hostname selectors take the rest, the other 189 asks are routed
+    assert supported[:512].all() and not supported[512:].any()
     assert "requirements" in pm.ask_supported(600)[1]
     want = orc.Oracle(snap).eval_grid(threads=8)
     rows = unpack(pm.read_bitmap(), 700)
     assert np.array_equal(rows[supported], want[supported]) and rows[~supported].sum() == 0
     assert pm.predicates("p5", "n5", True) == ("", None) and pm.predicates("plain", "n1", True) == ("", None)
+    with pytest.raises(pkg.UnsupportedAsk):
+        pm.predicates("p650", "n650", True)
 
 
 def test_node_ports_preemption(pm):
