@@ -189,6 +189,8 @@ typedef struct ykpred_pods {
 #define YKPRED_EVAL_SPREAD_COUNTS_READY (1u << 11) /* the histograms already hold the cluster-wide (all-reduced) values */
 #define YKPRED_EVAL_SKIP_BITMAP (1u << 12)         /* refresh planes / counts scatter / decisions only; the bitmap and the class
                                                       counts are already current (used by ykpred_eval_nodes) */
+#define YKPRED_EVAL_DIRTY_CLASSES (1u << 13)       /* internal (ykpred_eval_nodes): rewrite only the rows of classes whose topology
+                                                      signature changed (flagged on the device), keep every other row */
 #define YKPRED_EVAL_STORE_VARIANT_SHIFT 16         /* bits 16-17: experimental k_combine store flavour (0 = dwordx4, default;
                                                       1 = dwordx2; 2/3 = the same non-temporal) — measured equal, DESIGN.md §4 */
 
@@ -251,9 +253,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* args);
 /* Incremental form for the sequential scheduling loop (AssumePod / ForgetPod / UpdateNode between two asks,
  * /root/reference/pkg/cache/context.go:828-898): after ykpred_update_node on `num_nodes` nodes, re-evaluates ONLY those
  * node columns of the bitmap produced by the last ykpred_eval (same plugin lists, same output buffers) and patches the
- * feasible counts; decisions are recomputed when YKPRED_OUT_DECISIONS is set. YKPRED_E_STATE if there is no matching
- * previous evaluation, YKPRED_E_UNSUPPORTED when a PodTopologySpread signature is active (its histograms couple all
- * nodes — run ykpred_eval). */
+ * feasible counts; decisions are recomputed when YKPRED_OUT_DECISIONS is set. With PodTopologySpread / InterPodAffinity
+ * signatures active the histograms are rebuilt (they couple all nodes), the signatures whose PreFilter state moved are
+ * found on the device, and the classes that use them get their WHOLE rows rewritten — all other classes still only the
+ * touched columns. YKPRED_E_STATE if there is no matching previous evaluation; YKPRED_E_UNSUPPORTED on a node-sharded engine
+ * with topology signatures (the histogram all-reduce is collective — run ykpred_eval on every shard). */
 int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* args, int32_t num_nodes, const int32_t* node_index);
 /* Row-level maintenance of the ask table (SchedulerCache.UpdatePod for a new / changed / finished ask,
  * /root/reference/pkg/cache/external/scheduler_cache.go:303-388) without re-uploading it: the table gets `num_pods_after`

@@ -66,7 +66,36 @@ for _ in range(5):
     pm.evaluate()
 pm.synchronize()
 full = (time.perf_counter() - t0) / 5 * 1e3
-print(json.dumps({"workload": "configs[2]: 50k nodes x 1M asks", "assume+column_patch_ms_wall": round(w0, 4),
-                  "column_patch_kernels_ms": round(d0, 4), "assume+column_patch+decisions_ms_wall": round(w1, 4),
-                  "decision_refresh_kernels_ms": round(d1, 4), "new_ask_row_patch_ms_wall": round(rn, 4),
-                  "finished_ask_row_patch_ms_wall": round(rd, 4), "full_eval_ms_wall": round(full, 4)}))
+out = {"workload": "configs[2]: 50k nodes x 1M asks", "assume+column_patch_ms_wall": round(w0, 4),
+       "column_patch_kernels_ms": round(d0, 4), "assume+column_patch+decisions_ms_wall": round(w1, 4),
+       "decision_refresh_kernels_ms": round(d1, 4), "new_ask_row_patch_ms_wall": round(rn, 4),
+       "finished_ask_row_patch_ms_wall": round(rd, 4), "full_eval_ms_wall": round(full, 4)}
+pm.close()
+
+# the same AssumePod loop with 10 % of the templates carrying a hard zone-spread constraint: the histograms couple all nodes,
+# ykpred_eval_nodes rebuilds them and rewrites the whole rows of the classes whose PreFilter state moved
+pm = pkg.GpuPredicateManager()
+pm.generate_kwok(seed=0x59554E49 + 2, num_nodes=50_000, num_pods=1_000_000, num_templates=2000, node_affinity=1, spread=1)
+pm.evaluate()
+pm.synchronize()
+wall, incremental = [], 0
+for i in range(40):
+    uid, node = f"pod-{i:07d}", f"kwok-node-{(7919 * i) % 50_000:06d}"
+    t0 = time.perf_counter()
+    try:
+        pm.assume_pod(uid, node)
+    except RuntimeError:
+        continue
+    k = pm.evaluate_dirty(counts=True, decisions=False)
+    pm.synchronize()
+    wall.append((time.perf_counter() - t0) * 1e3)
+    incremental += k >= 0
+t0 = time.perf_counter()
+for _ in range(5):
+    pm.evaluate()
+pm.synchronize()
+out["with_hard_spread_constraints"] = {"assume+incremental_ms_wall_median": round(float(np.median(wall)), 4),
+                                       "assume+incremental_ms_wall_max": round(float(np.max(wall)), 4),
+                                       "incremental_steps": incremental, "steps": len(wall),
+                                       "full_eval_ms_wall": round((time.perf_counter() - t0) / 5 * 1e3, 4)}
+print(json.dumps(out))

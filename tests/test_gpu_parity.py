@@ -331,8 +331,42 @@ def test_kwok_with_spread_constraints(pm):
     # incremental: binding an ask changes the selector counts of its node and therefore the histograms
     uid = json.loads(snap)["pods"][5]["metadata"]["uid"]
     pm.assume_pod(uid, "kwok-node-000007")
-    assert pm.evaluate_dirty() == -1, "spread histograms couple all nodes: a full evaluation is required"
+    assert pm.evaluate_dirty() == 1, "one column patched; the rows of the classes whose histograms moved are rewritten"
     _compare_live_rows(pm, json.loads(pm.dump_snapshot()))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_incremental_node_changes_with_topology_constraints(pm, seed):
+    """AssumePod / ForgetPod / RemovePod with hard spread constraints AND inter-pod (anti)affinity in the ask population:
+    the histograms couple all nodes, so ykpred_eval_nodes rebuilds them, finds the signatures whose PreFilter state moved
+    and rewrites the whole rows of their classes — without a full pass. Every live row, count and decision against the
+    oracle after every step."""
+    import random
+    rng = random.Random(100 + seed)
+    snap = _gen.random_snapshot(9100 + seed, n_nodes=90 + 20 * seed, n_pods=70, spread=True, interpod=(seed % 2 == 0))
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    names = [n["metadata"]["name"] for n in snap["nodes"] if n["metadata"]["name"]]
+    cur, bound, incremental = snap, [], 0
+    for step in range(12):
+        if bound and rng.random() < 0.3:
+            uid, target = bound.pop(rng.randrange(len(bound)))
+            pm.remove_pod(uid)
+            nodes = json.loads(json.dumps(cur["nodes"]))
+            tn = next(n for n in nodes if n["metadata"]["name"] == target)
+            tn["pods"] = [q for q in tn["pods"] if q["metadata"]["uid"] != uid]
+            cur = {"nodes": nodes, "pods": cur["pods"]}
+        else:
+            uid = rng.choice([p for p in cur["pods"] if not p["spec"].get("nodeName")])["metadata"]["uid"]
+            target = rng.choice(names)
+            pm.assume_pod(uid, target)
+            bound.append((uid, target))
+            cur = _move(cur, uid, target)
+        patched = pm.evaluate_dirty(decisions=(step % 2 == 0))
+        incremental += patched >= 0
+        _compare_live_rows(pm, cur, decisions=(step % 2 == 0))
+    # a pod with anti-affinity terms of its own landing on a node extends the dictionaries (full pass); everything else patches
+    assert incremental >= 6, f"only {incremental} of 12 steps were incremental"
 
 
 def test_empty_and_ragged_inputs(pm):

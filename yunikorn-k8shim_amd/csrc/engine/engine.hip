@@ -134,6 +134,7 @@ struct ykpred_engine {
   std::vector<std::vector<ykpred_spread_t>> spread_sig; // constraints of each signature
   std::vector<int32_t> spread_sig_aff, spread_sig_tol;  // eligibility signatures
   DevBuf d_spec_spread, d_sp_coff, d_sp_c, d_sp_aff, d_sp_tol, d_sp_cnt, d_sp_present, d_sp_min;
+  DevBuf d_sp_cnt_prev, d_sp_present_prev, d_sp_min_prev, d_sig_changed, d_class_dirty;  // incremental path: what moved
   int spread_constraints = 0;
   int64_t spread_cells = 0;
   bool spread_dirty = true;
@@ -701,6 +702,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
   e->graphs.clear();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount, &e->d_ports, &e->d_sig_ports, &e->d_swanted,
+                    &e->d_sp_cnt_prev, &e->d_sp_present_prev, &e->d_sp_min_prev, &e->d_sig_changed, &e->d_class_dirty,
                     &e->d_spec_spread, &e->d_sp_coff, &e->d_sp_c, &e->d_sp_aff, &e->d_sp_tol, &e->d_sp_cnt, &e->d_sp_present, &e->d_sp_min,
                     &e->planes_canon, &e->planes_ranked, &e->base_canon, &e->base_ranked, &e->d_rankbuf, &e->d_score, &e->d_key,
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
@@ -1305,7 +1307,16 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   // ---- stream A: combine → bitmap (skipped by ykpred_eval_nodes' decision refresh: bitmap and class counts were
   // patched incrementally)
   const bool skip_combine = a->options & YKPRED_EVAL_SKIP_BITMAP;
-  if (!skip_combine) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
+  const bool dirty_only = a->options & YKPRED_EVAL_DIRTY_CLASSES;
+  const int* class_dirty = nullptr;
+  if (!skip_combine && dirty_only) {
+    // classes whose topology signature changed (d_sig_changed was filled by ykpred_eval_nodes): flag them, zero their counts
+    HIPCHK(e->d_class_dirty.ensure((size_t)std::max(e->C, 1) * sizeof(int)));
+    hipLaunchKernelGGL(ykk::k_mark_dirty_classes, dim3((unsigned)((e->C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, e->C,
+                       e->d_class_sig.as<int>(), e->d_sig_changed.as<int>(), e->d_class_dirty.as<int>(), e->d_class_count.as<int>());
+    class_dirty = e->d_class_dirty.as<int>();
+  }
+  if (!skip_combine && !dirty_only) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   if (!skip_combine) {
     // store flavour: bits 16-17 of options select an experimental variant (0 = default)
     const unsigned variant = (a->options >> YKPRED_EVAL_STORE_VARIANT_SHIFT) & 3u;
@@ -1318,13 +1329,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     auto launch = [&](auto kern) {
       // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
       hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pc, bitmap, e->row_words, e->row_stride,
-                         pin_on, e->d_class_count.as<int>(), tpg);
+                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty);
     };
     tm.begin(st);
     if ((long)e->NC * e->wave_combine_below > (long)P) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct,
-                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC);
+                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty);
     } else {
       switch (variant) {
         case 0: launch(ykk::k_combine<2, false>); break;
@@ -1333,7 +1344,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         default: launch(ykk::k_combine<1, true>); break;
       }
     }
-    tm.end(st, "k_combine");
+    tm.end(st, dirty_only ? "k_combine(dirty classes)" : "k_combine");
   }
   if (want_dec) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
   if (want_dec || want_cnt) {
@@ -1405,7 +1416,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_pre = pre;
   e->last_filt = filt;
   e->last_eval_valid = true;
-  if (!(a->options & YKPRED_EVAL_SKIP_BITMAP)) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
+  if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
   if (want_dec) e->rank_valid = true;
   e->last_has_keys = want_keys;
   return YKPRED_OK;
@@ -1420,8 +1431,10 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   u64* bitmap = a->bitmap ? (u64*)a->bitmap : e->d_bitmap.as<u64>();
   if (e->classes_dirty || !e->last_eval_valid || pre != e->last_pre || filt != e->last_filt || (void*)bitmap != e->last_bitmap)
     return fail(e, YKPRED_E_STATE, "eval_nodes: no matching previous ykpred_eval (tables, plugin lists or bitmap changed)");
-  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0)
-    return fail(e, YKPRED_E_UNSUPPORTED, "eval_nodes: PodTopologySpread / InterPodAffinity histograms couple all nodes — run ykpred_eval");
+  const bool topo = (pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0;
+  if (topo && e->comm && e->comm_world > 1)
+    return fail(e, YKPRED_E_UNSUPPORTED, "eval_nodes: on a node-sharded engine the topology histograms change through a collective — run ykpred_eval on every shard");
+  if (topo && e->spread_dirty) return fail(e, YKPRED_E_STATE, "eval_nodes: topology tables changed — run ykpred_eval");
   for (int i = 0; i < num_nodes; ++i)
     if (node_index[i] < 0 || node_index[i] >= e->N) return fail(e, YKPRED_E_INVALID, "eval_nodes: node index out of range");
   Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
@@ -1429,6 +1442,25 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
   const bool want_keys = a->options & YKPRED_OUT_DECISION_KEYS;
   const bool want_dec = (a->options & YKPRED_OUT_DECISIONS) || want_keys;
+  if (topo && num_nodes > 0 && e->P > 0) {
+    // The PreFilter state of the topology plugins couples all nodes: rebuild the histograms (cheap: one thread per
+    // signature and node), then find the signatures whose cells or minima moved.
+    const size_t cells = (size_t)std::max<int64_t>(e->spread_cells, 1) * sizeof(int), mins = (size_t)std::max(e->spread_constraints, 1) * sizeof(int);
+    HIPCHK(e->d_sp_cnt_prev.ensure(cells));
+    HIPCHK(e->d_sp_present_prev.ensure(cells));
+    HIPCHK(e->d_sp_min_prev.ensure(mins));
+    HIPCHK(e->d_sig_changed.ensure((size_t)e->fam_spread.D * sizeof(int)));
+    if (e->hist_epoch == 0) return fail(e, YKPRED_E_STATE, "eval_nodes: no topology histograms from a previous ykpred_eval");
+    HIPCHK(hipMemcpyAsync(e->d_sp_cnt_prev.p, e->d_sp_cnt.p, cells, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_sp_present_prev.p, e->d_sp_present.p, cells, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_sp_min_prev.p, e->d_sp_min.p, mins, hipMemcpyDeviceToDevice, st));
+    TRY(run_spread_prefilter(e, st, &tm, true, true));
+    e->hist_epoch = e->nodes_epoch;
+    tm.begin(st);
+    hipLaunchKernelGGL(ykk::k_spread_diff, dim3((unsigned)e->fam_spread.D), dim3(ykk::kWave), 0, st, spread_sigs(e), e->d_sp_cnt_prev.as<int>(),
+                       e->d_sp_present_prev.as<int>(), e->d_sp_min_prev.as<int>(), e->d_sig_changed.as<int>());
+    tm.end(st, "k_spread_diff");
+  }
   if (num_nodes > 0 && e->P > 0) {
     // unique nodes, grouped by bitmap word, at most kMaxColGroups words / 64 nodes per launch
     std::vector<int32_t> nodes(node_index, node_index + num_nodes);
@@ -1464,7 +1496,15 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   }
   HIPCHK(hipGetLastError());
   tm.done(st);
-  if (want_dec) {
+  if (topo && num_nodes > 0 && e->P > 0) {
+    // planes again (cheap), then the whole rows of the classes whose topology signature moved; with decisions requested the
+    // same pass refreshes the bin-pack order and the class decisions
+    ykpred_eval_args_t b = *a;
+    b.bitmap = bitmap;
+    b.options = a->options | YKPRED_OUT_BITMAP | YKPRED_EVAL_DIRTY_CLASSES | YKPRED_EVAL_SPREAD_COUNTS_READY;
+    int rc = ykpred_eval(e, &b);
+    if (rc != YKPRED_OK) return rc;
+  } else if (want_dec) {
     // the bin-pack order moved with the node's Requested: rerun the (cheap) plane + decision kernels, not the bitmap
     ykpred_eval_args_t b = *a;
     b.options = (a->options & ~(uint32_t)YKPRED_OUT_BITMAP) | YKPRED_EVAL_SKIP_BITMAP;

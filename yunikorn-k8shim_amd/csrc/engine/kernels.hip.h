@@ -624,6 +624,35 @@ __global__ __launch_bounds__(kWave) void k_spread_min(SpreadSigs sp, int n_const
   }
   if (threadIdx.x == 0) sp.minv[g] = nd < c.min_domains ? 0 : mn;
 }
+// Incremental path (ykpred_eval_nodes): which topology signatures see different PreFilter state than before the node
+// change? One wave per signature compares its cells of (cnt, present) and its minv entries with the copies taken before the
+// histograms were rebuilt. A pod class whose signature changed gets its whole row rewritten; every other class only the
+// columns of the touched nodes.
+__global__ __launch_bounds__(kWave) void k_spread_diff(SpreadSigs sp, const int* __restrict__ cnt_prev, const int* __restrict__ present_prev,
+                                                       const int* __restrict__ minv_prev, int* __restrict__ sig_changed) {
+  const int d = blockIdx.x;
+  if (d >= sp.D) return;
+  bool diff = false;
+  for (int g = sp.c_off[d]; g < sp.c_off[d + 1]; ++g) {
+    const SpreadC c = sp.c[g];
+    if (sp.minv[g] != minv_prev[g]) diff = true;
+    for (int i = threadIdx.x; i < c.dom_size; i += kWave)
+      diff = diff || sp.cnt[c.cnt_off + i] != cnt_prev[c.cnt_off + i] || sp.present[c.cnt_off + i] != present_prev[c.cnt_off + i];
+  }
+  const u64 any = __ballot(diff);
+  if (threadIdx.x == 0) sig_changed[d] = any != 0 ? 1 : 0;
+}
+// thread = class: dirty ⇔ its topology signature changed; a dirty class's feasible count is rebuilt by the combine pass
+__global__ __launch_bounds__(kBlock) void k_mark_dirty_classes(int n_classes, const int* __restrict__ class_sig, const int* __restrict__ sig_changed,
+                                                               int* __restrict__ class_dirty, int* __restrict__ class_count) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= n_classes) return;
+  const int ss = class_sig[c * 4 + 3];
+  const int dirty = ss >= 0 && sig_changed[ss] ? 1 : 0;
+  class_dirty[c] = dirty;
+  if (dirty) class_count[c] = 0;
+}
+
 // Filters of the topology constraints of signature d, PodTopologySpread first (Filter order of predicate_manager.go:339-352):
 //   spread:  fail ⇔ the topology label is missing, or matchNum + selfMatch − min > maxSkew
 //   InterPodAffinity (satisfyPodAffinity / satisfyPodAntiAffinity / satisfyExistingPodsAntiAffinity):
@@ -773,12 +802,14 @@ __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
 // NT selects non-temporal stores: the bitmap is written once and never re-read by this kernel.
 template <int WPL, bool NT>
 __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
-                                                    int pin_enabled, int* __restrict__ class_count, int tpg) {
+                                                    int pin_enabled, int* __restrict__ class_count, int tpg,
+                                                    const int* __restrict__ class_dirty /* null = every class */) {
   // pin_enabled bit 0: NodeName filter on; bit 1: a Filter has no PreFilter state ⇒ every pair fails
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int chunk = blockIdx.x;
   const int cls = ct.chunk_class[chunk];
+  if (class_dirty && !class_dirty[cls]) return;  // incremental pass: only classes whose topology signature changed
   const int begin = ct.chunk_begin[chunk];
   const int len = ct.chunk_len[chunk];
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
@@ -846,7 +877,8 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
 // independent (class → signature rows → plane words → store) chains in flight, not bandwidth. Here every WAVE owns a chunk —
 // 4x as many chains per workgroup and no occupancy cap; lane = a pair of adjacent row words (dwordx4 loads and stores).
 __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
-                                                         int pin_enabled, int* __restrict__ class_count, int n_chunks) {
+                                                         int pin_enabled, int* __restrict__ class_count, int n_chunks,
+                                                         const int* __restrict__ class_dirty /* null = every class */) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
@@ -854,6 +886,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
   if (chunk >= n_chunks) return;
   const int lane = threadIdx.x % kWave;
   const int cls = ct.chunk_class[chunk];
+  if (class_dirty && !class_dirty[cls]) return;
   const int begin = ct.chunk_begin[chunk], len = ct.chunk_len[chunk];
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const int pin = pin_enabled ? ct.pin[cls] : -1;

@@ -480,11 +480,22 @@ int sync(ykhost* h) {
     int rc = full_sync(h);
     if (rc) return rc;
   }
-  for (int n : h->dirty_nodes) {
-    int rc = node_row_sync(h, n);
-    if (rc) return rc;
+  {
+    // node_row_sync may fall back to full_sync (a topology value outside the dictionaries), which clears dirty_nodes and
+    // uploads every row: iterate over a detached copy and stop at that point
+    std::vector<int> todo;
+    todo.swap(h->dirty_nodes);
+    std::sort(todo.begin(), todo.end());
+    todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+    for (int n : todo) {
+      if ((size_t)n >= h->nodes.size()) continue;
+      const std::shared_ptr<EncodedTables> before = h->tables;
+      int rc = node_row_sync(h, n);
+      if (rc) return rc;
+      if (h->tables != before) break;  // everything was re-encoded and re-uploaded
+    }
+    h->dirty_nodes.clear();
   }
-  h->dirty_nodes.clear();
   if (h->specs_dirty && !h->dirty_all) {
     int rc = ykpred_set_specs(h->eng, &h->tables->sp);
     if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
@@ -994,9 +1005,12 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
   ensure_uid_index(h);
   int orphans = 0;
   for (const Pod* cp : h->nodes[(size_t)idx]->pods) {
+    // every pod of the NodeInfo is handled (scheduler_cache.go:205-224), also one the uid index does not (or no longer)
+    // point at: it becomes an orphan under its uid unless a newer version of the pod holds that uid
     auto pt = h->by_uid.find(cp->uid);
-    if (pt == h->by_uid.end() || pt->second != cp) continue;  // not in podsMap any more
-    Pod* p = pt->second;
+    if (pt != h->by_uid.end() && pt->second != cp) continue;  // a newer version owns the uid: the stale copy just leaves with the node
+    Pod* p = const_cast<Pod*>(cp);                            // the mirror owns every Pod object (pod_store)
+    if (pt == h->by_uid.end()) h->by_uid[p->uid] = p;
     const bool revert = p->assumed;
     p->assigned_node.clear();
     p->assumed = false;
@@ -1432,10 +1446,10 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
 int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched) {
   YKHOST_LOCKED(h);
   if (columns_patched) *columns_patched = -1;
-  // topology constraints (spread, inter-pod affinity) couple all nodes through their histograms: a node change needs a
-  // full evaluation (row changes alone do not: the histograms depend on the nodes only)
+  // topology constraints (spread, inter-pod affinity) couple all nodes through their histograms: ykpred_eval_nodes rebuilds
+  // them and rewrites the rows of the classes whose PreFilter state moved (row changes alone never touch the histograms)
   const bool nodes_touched = !h->eval_dirty_nodes.empty();
-  const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0) && !(nodes_touched && h->enc.KD != 0);
+  const bool incremental = !h->dirty_all && !h->dirty_pods && h->last_eval_phase == (allocate ? 1 : 0);
   if (!incremental) return ykhost_evaluate(h, allocate, options);
   int rc = sync(h);  // uploads the touched node rows and ask rows
   if (rc) return rc;
