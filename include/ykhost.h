@@ -163,9 +163,10 @@ int32_t ykhost_preemption_predicates_batch(ykhost_t* h, int32_t num_queries, con
 
 /* Individual routing: 1 = pending pod #pod is evaluated on the device, 0 = it is routed to the CPU predicate manager
  * (`reason` says why). ykhost_routing_stats: out[0] = asks marked unsupported at the last encode, out[1] = Predicates() calls
- * answered YKHOST_E_UNSUPPORTED so far (what the Go side exports as its fallback counter). */
+ * answered YKHOST_E_UNSUPPORTED so far (what the Go side exports as its fallback counter), out[2] = new asks whose selector
+ * requirements were added to the dictionaries in place (one label-word column uploaded, nothing re-encoded). */
 int32_t ykhost_ask_supported(ykhost_t* h, int32_t pod, char* reason, int32_t reason_len);
-int32_t ykhost_routing_stats(ykhost_t* h, int64_t* out2);
+int32_t ykhost_routing_stats(ykhost_t* h, int64_t* out3);
 
 /* request vector of pending pod #pod as JSON {"cpu": milli, "memory": bytes, ...} */
 int32_t ykhost_pod_request_json(ykhost_t* h, int32_t pod, char* out, int32_t len);

@@ -242,6 +242,10 @@ int32_t ykpred_abi_version(void);
 /* state upload (externally serialised against evals) */
 int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* nodes);
 int32_t ykpred_update_node(ykpred_engine_t* e, int32_t index, const ykpred_nodes_t* one_node); /* count must be 1 */
+/* Dictionary growth without a re-upload: replaces ONE 64-bit word column of label_bits ([count] values, one per node) — how a
+ * requirement that no spec used before gets its bit. Bits that no uploaded spec references may change freely: the last
+ * evaluation stays valid. */
+int32_t ykpred_update_label_word(ykpred_engine_t* e, int32_t word, const uint64_t* column /* [N] */);
 /* A table whose first specs are byte-identical to the previous one (new specs appended) keeps the engine's pod classes and
  * the last evaluation valid, so that a new pod template is followed by ykpred_update_pods / ykpred_eval_pods, not by a full
  * pass (unless the new specs bring a new topology-constraint signature). */

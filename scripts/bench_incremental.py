@@ -57,10 +57,28 @@ def timed_rows(n=40):
     return float(np.median(wall_new)), float(np.median(wall_done))
 
 
+def timed_new_label(n=20):
+    """A new ask whose nodeSelector uses a (key, value) nobody selected before: dictionary growth in place — the new
+    requirement bit is evaluated on all 50k nodes on the host, one label-word column (400 KB) is uploaded, the row is patched."""
+    wall = []
+    for i in range(n):
+        ask = {"metadata": {"uid": f"newlabel-{i}", "name": f"newlabel-{i}", "namespace": "default"},
+               "spec": {"nodeSelector": {"kubernetes.io/hostname": f"kwok-node-{1000 + i:06d}"}, "containers": [{"name": "c"}],
+                        "tolerations": [{"key": "kwok.x-k8s.io/node", "operator": "Exists", "effect": "NoSchedule"}]}}
+        t0 = time.perf_counter()
+        pm.update_pod(ask)
+        k = pm.evaluate_dirty(counts=True, decisions=True)
+        pm.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        assert k >= 0, "dictionary growth must stay incremental"
+    return float(np.median(wall)), pm.routing_stats()["dictionary_growths"]
+
+
 w0, d0 = timed(False, offset=0)
 w1, d1 = timed(True, offset=1000)
 pm.evaluate()
 rn, rd = timed_rows()
+nl, growths = timed_new_label()
 t0 = time.perf_counter()
 for _ in range(5):
     pm.evaluate()
@@ -69,7 +87,8 @@ full = (time.perf_counter() - t0) / 5 * 1e3
 out = {"workload": "configs[2]: 50k nodes x 1M asks", "assume+column_patch_ms_wall": round(w0, 4),
        "column_patch_kernels_ms": round(d0, 4), "assume+column_patch+decisions_ms_wall": round(w1, 4),
        "decision_refresh_kernels_ms": round(d1, 4), "new_ask_row_patch_ms_wall": round(rn, 4),
-       "finished_ask_row_patch_ms_wall": round(rd, 4), "full_eval_ms_wall": round(full, 4)}
+       "finished_ask_row_patch_ms_wall": round(rd, 4), "new_label_ask_ms_wall": round(nl, 4), "dictionary_growths": growths,
+       "full_eval_ms_wall": round(full, 4)}
 pm.close()
 
 # the same AssumePod loop with 10 % of the templates carrying a hard zone-spread constraint: the histograms couple all nodes,

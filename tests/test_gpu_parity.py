@@ -459,8 +459,10 @@ def test_task_group_placeholders_are_one_class_per_group(pm):
     pm.evaluate()
     classes_before = pm.layout().num_classes
     assert pm.add_task_groups("spark-app-0001", "root.batch", "default", groups) == sum(g["minMember"] for g in groups)
-    # known dictionaries but new templates: everything is re-encoded once; afterwards the group members share classes
+    # new templates, one of them with a nodeSelector requirement nobody used before: spec rows are appended, the requirement
+    # takes a spare dictionary bit (in-place growth), 166 rows join 4 new classes in one ykpred_update_pods call
     pm.evaluate()
+    assert pm.check_class_rows() == 0
     assert pm.layout().num_classes <= classes_before + len(groups)
     bm = pm.read_bitmap()
     row = before
@@ -767,11 +769,19 @@ def test_new_template_covered_by_the_dictionaries_is_a_row_patch(pm):
     after = pm.stats()
     assert after["specs"] == stats["specs"] + 1 and after["requirements"] == stats["requirements"]
     _compare_with_mirror_dump(pm, decisions=True)
-    # a requirement nobody used before does need a new dictionary bit: full re-encode, still exact
+    # a requirement nobody used before takes a spare dictionary bit in place (one label-word column uploaded): still a row patch
     other = json.loads(json.dumps(new))
     other["metadata"].update(uid="fresh-2", name="fresh-2")
     other["spec"]["nodeSelector"] = {"never-seen-key": "v"}
     pm.update_pod(other)
+    assert pm.evaluate_dirty(decisions=True) == 0
+    assert pm.stats()["requirements"] == stats["requirements"] + 1
+    _compare_with_mirror_dump(pm, decisions=True)
+    # a scalar resource nobody requested before adds a resource dimension: that does re-encode everything, still exact
+    third = json.loads(json.dumps(new))
+    third["metadata"].update(uid="fresh-3", name="fresh-3")
+    third["spec"]["containers"] = [{"resources": {"requests": {"example.com/never-seen": "1"}}}]
+    pm.update_pod(third)
     assert pm.evaluate_dirty(decisions=True) == -1
     _compare_with_mirror_dump(pm, decisions=True)
     before = pm.read_bitmap().copy()
@@ -919,27 +929,67 @@ def test_unsupported_asks_are_routed_individually(pm):
     assert st["unsupported_asks"] == 4 and st["routed_to_cpu"] >= 8
 
 
-def test_dictionary_overflow_only_drops_the_overflowing_asks(pm):
-    """700 asks that each select a different kubernetes.io/hostname need 700 requirement bits; the dictionary holds 512.
-    The first 512 are evaluated (and equal the oracle), the rest are marked unsupported — nobody else loses the engine."""
+@pytest.mark.parametrize("count", [700, 2100])
+def test_large_requirement_dictionaries_and_overflow(pm, count):
+    """`count` asks that each select a different kubernetes.io/hostname need `count` requirement bits. 700 of them
+    (the probe that used to take the engine away from every ask) fit: the bit-sliced plane kernels size the
+    dictionary at run time and the per-pair kernels read label words beyond their 8 register-held ones from the node table.
+    The dictionary holds 2048 requirements: beyond that the overflowing asks — and only they — are routed to the CPU manager."""
     nodes = [{"metadata": {"name": f"n{i}", "labels": {"kubernetes.io/hostname": f"n{i}", "zone": f"z{i % 3}"}},
-              "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "20"}}} for i in range(700)]
+              "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "20"}}} for i in range(count)]
     pods = [{"metadata": {"name": f"p{i}", "uid": f"p{i}"},
-             "spec": {"nodeSelector": {"kubernetes.io/hostname": f"n{i}"}, "containers": [{"resources": {"requests": {"cpu": "1"}}}]}} for i in range(700)]
+             "spec": {"nodeSelector": {"kubernetes.io/hostname": f"n{i}"}, "containers": [{"resources": {"requests": {"cpu": "1"}}}]}} for i in range(count)]
     pods.insert(0, {"metadata": {"name": "plain", "uid": "plain"}, "spec": {"nodeSelector": {"zone": "z1"}, "containers": []}})
     snap = {"nodes": nodes, "pods": pods}
     pm.load_snapshot(snap)
     pm.evaluate()
-    supported = np.array([pm.ask_supported(i)[0] for i in range(701)])
-    # first come, first served: "plain" takes one bit, 511 hostname selectors take the rest, the other 189 asks are routed
-    assert supported[:512].all() and not supported[512:].any()
-    assert "requirements" in pm.ask_supported(600)[1]
-    want = orc.Oracle(snap).eval_grid(threads=8)
-    rows = unpack(pm.read_bitmap(), 700)
+    supported = np.array([pm.ask_supported(i)[0] for i in range(count + 1)])
+    fit_in = min(count + 1, 2048)  # first come, first served: "plain" takes one bit, the hostname selectors the rest
+    assert supported[:fit_in].all() and not supported[fit_in:].any()
+    want = orc.Oracle(snap).eval_grid(threads=os.cpu_count() or 8)
+    rows = unpack(pm.read_bitmap(), count)
     assert np.array_equal(rows[supported], want[supported]) and rows[~supported].sum() == 0
-    assert pm.predicates("p5", "n5", True) == ("", None) and pm.predicates("plain", "n1", True) == ("", None)
-    with pytest.raises(pkg.UnsupportedAsk):
-        pm.predicates("p650", "n650", True)
+    assert pm.predicates("plain", "n1", True) == ("", None)
+    for i in (5, 511, 512, 640, 699):  # requirement bits below and above the 8 register-held words, per-pair path
+        assert pm.predicates(f"p{i}", f"n{i}", True) == ("", None)
+        plugin, err = pm.predicates(f"p{i}", f"n{(i + 1) % count}", True)
+        assert plugin == "NodeAffinity" and err is not None
+    if count > 2048:
+        assert "requirements" in pm.ask_supported(2090)[1]
+        with pytest.raises(pkg.UnsupportedAsk):
+            pm.predicates("p2090", "n2090", True)
+
+
+def test_dictionary_growth_in_place(pm):
+    """An ask whose nodeSelector / affinity uses requirements nobody used before: the requirement gets a spare dictionary bit,
+    the bit is evaluated on every node and ONE label-word column is uploaded (ykpred_update_label_word) — the cluster is not
+    re-encoded, the engine keeps its bitmap, the new ask is an ordinary appended row."""
+    snap = _gen.random_snapshot(616, n_nodes=140, n_pods=50, scalars=False)
+    for i, n in enumerate(snap["nodes"]):
+        n["metadata"].setdefault("labels", {})["rack"] = f"r{i % 7}"
+        n["metadata"]["labels"]["tier"] = str(i % 5)
+    pm.load_snapshot(snap)
+    pm.evaluate()
+    growths_before = pm.routing_stats()["dictionary_growths"]  # the fixture is shared: the counter is cumulative
+    late = [
+        {"metadata": {"name": "late-0", "uid": "late-0"}, "spec": {"nodeSelector": {"rack": "r3"}, "containers": []}},
+        {"metadata": {"name": "late-1", "uid": "late-1"}, "spec": {"containers": [], "affinity": {"nodeAffinity": {
+            "requiredDuringSchedulingIgnoredDuringExecution": {"nodeSelectorTerms": [
+                {"matchExpressions": [{"key": "tier", "operator": "Gt", "values": ["2"]}, {"key": "rack", "operator": "NotIn", "values": ["r1", "r2"]}]},
+                {"matchFields": [{"key": "metadata.name", "operator": "In", "values": [snap["nodes"][9]["metadata"]["name"]]}]}]}}}}},
+        {"metadata": {"name": "late-2", "uid": "late-2"}, "spec": {"nodeSelector": {"rack": "r3"}, "containers": [{"resources": {"requests": {"cpu": "100m"}}}]}},
+    ]
+    cur = snap
+    for k, ask in enumerate(late):
+        pm.update_pod(ask)
+        assert pm.evaluate_dirty(decisions=True) >= 0, "a new selector requirement must not force a full pass"
+        cur = {"nodes": cur["nodes"], "pods": cur["pods"] + [ask]}
+        _compare_live_rows(pm, cur, decisions=True)
+    st = pm.routing_stats()
+    assert st["dictionary_growths"] == growths_before + 2, st  # late-2 reuses late-0's requirement
+    before = pm.read_bitmap().copy()
+    pm.evaluate()
+    assert np.array_equal(before, pm.read_bitmap())
 
 
 def test_node_ports_preemption(pm):

@@ -78,6 +78,7 @@ def load_ykpred():
     L.ykpred_destroy.restype = None
     L.ykpred_set_nodes.argtypes = [C.c_void_p, C.POINTER(YkpredNodes)]
     L.ykpred_update_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(YkpredNodes)]
+    L.ykpred_update_label_word.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.ykpred_set_specs.argtypes = [C.c_void_p, C.POINTER(YkpredSpecs)]
     L.ykpred_set_pods.argtypes = [C.c_void_p, C.POINTER(YkpredPods)]
     L.ykpred_eval.argtypes = [C.c_void_p, C.POINTER(YkpredEvalArgs)]

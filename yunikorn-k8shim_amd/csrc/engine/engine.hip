@@ -631,8 +631,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
     return YKPRED_E_INVALID;
   }
   if (cfg->num_resources < 3 || cfg->num_resources > ykk::kMaxR || cfg->taint_words < 1 || cfg->taint_words > ykk::kMaxKT ||
-      cfg->label_words < 1 || cfg->label_words > ykk::kMaxW) {
-    g_create_error = "config out of range: need 3<=R<=8, 1<=KT<=4, 1<=W<=8";
+      cfg->label_words < 1 || cfg->label_words > ykk::kMaxWTotal) {
+    g_create_error = "config out of range: need 3<=R<=8, 1<=KT<=4, 1<=W<=32";
     return YKPRED_E_UNSUPPORTED;
   }
   if (cfg->topology_keys < 0 || cfg->topology_keys > ykk::kMaxKD || cfg->selector_classes < 0 || cfg->selector_classes > 4096 ||
@@ -819,6 +819,19 @@ int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t
   if (e->has_name_rank && n->name_rank)
     HIPCHK(hipMemcpyAsync(e->d_name_rank.as<int>() + idx, n->name_rank, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_update_label_word(ykpred_engine_t* e, int32_t word, const uint64_t* column) {
+  YK_SERIALISE(e);
+  if (!e || !column || word < 0 || word >= (e ? e->W : 0)) return fail(e, YKPRED_E_INVALID, "update_label_word: bad argument");
+  if (!e->nodes_set) return fail(e, YKPRED_E_STATE, "update_label_word: no node table");
+  e->tables_version++;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (e->N) {
+    HIPCHK(hipMemcpyAsync(e->d_labels.as<u64>() + (size_t)word * (size_t)e->N, column, (size_t)e->N * sizeof(u64), hipMemcpyHostToDevice, e->own_stream));
+    HIPCHK(hipStreamSynchronize(e->own_stream));
+  }
   return YKPRED_OK;
 }
 
@@ -1674,6 +1687,20 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
   HIPCHK(e->d_class_sig.reserve_keep((size_t)e->C * 4 * I, (size_t)e->C * 4 * I));
   for (DevBuf* b : {&e->d_class_pin, &e->d_class_first, &e->d_class_count, &e->d_class_best}) HIPCHK(b->reserve_keep((size_t)e->C * I, (size_t)e->C * I));
   if (!patches.empty()) {
+    // one thread per patch: several patches of one (table, index) — a chunk length that grows member by member within this
+    // call — must not race; only the LAST value of each cell is uploaded
+    {
+      std::unordered_map<uint64_t, size_t> last;
+      last.reserve(patches.size());
+      for (size_t i = 0; i < patches.size(); ++i) last[((uint64_t)(uint32_t)patches[i].table << 32) | (uint32_t)patches[i].index] = i;
+      if (last.size() != patches.size()) {
+        std::vector<ykk::TablePatch> unique;
+        unique.reserve(last.size());
+        for (size_t i = 0; i < patches.size(); ++i)
+          if (last[((uint64_t)(uint32_t)patches[i].table << 32) | (uint32_t)patches[i].index] == i) unique.push_back(patches[i]);
+        patches.swap(unique);
+      }
+    }
     ykk::TablePtrs tp{};
     tp.t[T_POD_SPEC] = e->d_pod_spec.as<int>();
     tp.t[T_POD_PIN] = e->d_pod_pin.as<int>();

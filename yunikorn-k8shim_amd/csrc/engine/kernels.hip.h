@@ -31,7 +31,8 @@ typedef long long i64;
 // compile-time ceilings of the register-resident node columns (checked in ykpred_create)
 constexpr int kMaxR = 8;   // resource dimensions
 constexpr int kMaxKT = 4;  // taint dictionary words (256 taints)
-constexpr int kMaxW = 8;   // requirement dictionary words (512 requirements)
+constexpr int kMaxW = 8;   // requirement dictionary words held in REGISTERS by the per-pair kernels (512 requirements) ...
+constexpr int kMaxWTotal = 32;  // ... words beyond them are read from the node table when a term references them (2048)
 constexpr int kMaxKD = 8;  // topology keys used by spread / inter-pod-affinity constraints
 constexpr int kMaxKP = 4;  // host-port dictionary words (256 distinct requested host ports)
 
@@ -370,7 +371,10 @@ struct AffSigs {
   const int* pre_off;     // [D+1]
   const u64* pre_terms;   // [M][W]
 };
-__device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0, int t1, const u64 (&lb)[kMaxW], int W) {
+// `more` = the node's label words from kMaxW on (stride = nodes), consulted only where a term has bits there: large
+// dictionaries (one requirement per hostname ...) are sparse per term.
+__device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0, int t1, const u64 (&lb)[kMaxW], int W,
+                                          const u64* __restrict__ more, size_t more_stride) {
   bool any = false;
   for (int t = t0; t < t1; ++t) {
     const u64* m = terms + (size_t)t * W;
@@ -378,6 +382,10 @@ __device__ __forceinline__ bool dnf_match(const u64* __restrict__ terms, int t0,
 #pragma unroll
     for (int w = 0; w < kMaxW; ++w)
       if (w < W) all = all && (lb[w] & m[w]) == m[w];
+    for (int w = kMaxW; w < W; ++w) {
+      const u64 mw = m[w];  // wave-uniform
+      if (mw) all = all && more && (more[(size_t)(w - kMaxW) * more_stride] & mw) == mw;
+    }
     any = any || all;
   }
   return any;
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void k_spread_count(NodeTable t, SpreadSigs
 #pragma unroll
     for (int w = 0; w < kMaxW; ++w) lb[w] = w < t.W ? t.labels[(size_t)w * t.n + n] : 0;
     const int a = sp.aff_sig[d];
-    aff_ok = dnf_match(aff.terms, aff.term_off[a], aff.term_off[a + 1], lb, t.W);
+    aff_ok = dnf_match(aff.terms, aff.term_off[a], aff.term_off[a + 1], lb, t.W, t.labels + (size_t)kMaxW * t.n + n, (size_t)t.n);
   }
   if (spread_keys && need_tol) {
     const u64* tol = sig_tol + (size_t)sp.tol_sig[d] * t.KT;
@@ -997,6 +1005,8 @@ struct NodeRegs {
   i64 fr[kMaxR];
   u64 tn[kMaxKT];
   u64 lb[kMaxW];
+  const u64* lb_more;  // label words kMaxW.. of this node (stride lb_stride), null past the table
+  size_t lb_stride;
   u64 pt[kMaxKP];
   int dom[kMaxKD];
   bool slots_ok, unsched;
@@ -1008,6 +1018,8 @@ __device__ __forceinline__ void load_node(const NodeTable& t, int n, NodeRegs* r
   for (int i = 0; i < kMaxKT; ++i) r->tn[i] = (i < t.KT && n >= 0) ? t.taints[(size_t)i * t.n + n] : 0;
 #pragma unroll
   for (int i = 0; i < kMaxW; ++i) r->lb[i] = (i < t.W && n >= 0) ? t.labels[(size_t)i * t.n + n] : 0;
+  r->lb_more = (t.W > kMaxW && n >= 0) ? t.labels + (size_t)kMaxW * t.n + n : nullptr;
+  r->lb_stride = (size_t)t.n;
 #pragma unroll
   for (int i = 0; i < kMaxKP; ++i) r->pt[i] = (i < t.KP && n >= 0) ? t.ports[(size_t)i * t.n + n] : 0;
 #pragma unroll
@@ -1034,7 +1046,7 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
       *reason = 1u << 2;
       return false;
     }
-    if ((f & kSpecPreNames) && !dnf_match(s.aff.pre_terms, s.aff.pre_off[spec], s.aff.pre_off[spec + 1], nr.lb, s.W)) {
+    if ((f & kSpecPreNames) && !dnf_match(s.aff.pre_terms, s.aff.pre_off[spec], s.aff.pre_off[spec + 1], nr.lb, s.W, nr.lb_more, nr.lb_stride)) {
       *code = 4;
       *reason = 1u << 1;
       return false;
@@ -1062,7 +1074,7 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
   }
   if (filt_mask & kPlugAffinity) {
     bool skip = (pre_mask & kPlugAffinity) && (f & kSpecAffSkip);
-    if (!skip && !dnf_match(s.aff.terms, s.aff.term_off[spec], s.aff.term_off[spec + 1], nr.lb, s.W)) {
+    if (!skip && !dnf_match(s.aff.terms, s.aff.term_off[spec], s.aff.term_off[spec + 1], nr.lb, s.W, nr.lb_more, nr.lb_stride)) {
       *code = 4;
       return false;
     }

@@ -224,7 +224,7 @@ class Encoder {
   std::vector<SelectorClass> sel_classes;                             // selector class s
   std::unordered_map<const PodTemplate*, std::string> unsupported;    // asks' templates the engine does not evaluate → why
   // engine limits (kernels.hip.h: kMaxR / kMaxKT / kMaxW / kMaxKP / kMaxKD; selector classes: ykpred_create)
-  static constexpr int kLimitR = 8, kLimitTaints = 256, kLimitRequirements = 512, kLimitPorts = 256, kLimitTopoKeys = 8, kLimitClasses = 4096;
+  static constexpr int kLimitR = 8, kLimitTaints = 256, kLimitRequirements = 2048, kLimitPorts = 256, kLimitTopoKeys = 8, kLimitClasses = 4096;
 
   // Builds every dictionary from the current objects. Returns false (error set) on unsupported input.
   bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates) {
@@ -308,7 +308,7 @@ class Encoder {
       collect_requirements(*t);
       const char* over = nullptr;
       if (3 + (int)scalar_names.size() > kLimitR) over = "scalar resource names (engine limit: 5 besides cpu, memory, ephemeral-storage)";
-      else if ((int)req_dict.size() > kLimitRequirements) over = "distinct node-selector requirements (engine limit: 512)";
+      else if ((int)req_dict.size() > kLimitRequirements) over = "distinct node-selector requirements (engine limit: 2048)";
       else if ((int)port_dict.size() > kLimitPorts) over = "distinct requested host ports (engine limit: 256)";
       else if ((int)topo_keys.size() > kLimitTopoKeys) over = "topology keys in spread / pod-affinity constraints (engine limit: 8)";
       else if ((int)sel_classes.size() > kLimitClasses) over = "distinct pod-selector classes (engine limit: 4096)";
@@ -332,7 +332,38 @@ class Encoder {
     }
     R = 3 + (int)scalar_names.size();
     KT = std::max(1, ((int)taint_dict.size() + 63) / 64);
-    W = std::max(1, ((int)req_dict.size() + 63) / 64);
+    // at least 32 spare requirement bits: an ask that arrives later with a selector nobody used before gets its bit(s)
+    // without re-encoding the cluster (extend_requirements)
+    W = std::min(kLimitRequirements / 64, std::max(1, ((int)req_dict.size() + 32 + 63) / 64));
+    rebuild_requirement_index();
+    return true;
+  }
+
+  // Dictionary growth: the node-selector requirements of template `t` that have no bit yet get the next free bits — if the
+  // allocated words (W) still hold them and the template needs nothing else that is missing (scalar resource, host port,
+  // topology key, count class). `new_bits` receives their indices: the caller evaluates each on every node
+  // (req_dict[q].eval) and patches the label words. False = not possible this way (the caller re-encodes everything).
+  bool extend_requirements(const PodTemplate& t, std::vector<int>* new_bits) {
+    new_bits->clear();
+    if (!template_error(t).empty() || unsupported.count(&t)) return false;
+    const Mark mark = mark_now();
+    collect_requirements(t);
+    bool ok = (int)req_dict.size() <= 64 * W;
+    if (ok) {
+      EncodedSpec es;
+      std::vector<uint64_t> wanted;
+      ok = encode_spec_if_covered(t, &es, &wanted);
+    }
+    if (!ok) {
+      rollback(mark);
+      return false;
+    }
+    for (size_t q = mark.reqs; q < req_dict.size(); ++q) new_bits->push_back((int)q);
+    rebuild_requirement_index();
+    return true;
+  }
+
+  void rebuild_requirement_index() {
     label_keys_.clear();
     label_reqs_.clear();
     name_reqs_.clear();
@@ -355,7 +386,6 @@ class Encoder {
       }
     }
     label_keys_.assign(keys.begin(), keys.end());
-    return true;
   }
 
   // What build_dictionaries refuses in a pending ask's template ("" = acceptable): features the engine does not evaluate

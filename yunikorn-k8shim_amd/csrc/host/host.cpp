@@ -111,7 +111,8 @@ struct ykhost {
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
   int64_t unsupported_asks = 0;    // asks whose template the encoder marked unsupported at the last full encode
-  int64_t routed_to_cpu = 0;       // Predicates() calls answered YKHOST_E_UNSUPPORTED (the Go side's fallback counter)
+  int64_t routed_to_cpu = 0;
+  int64_t dictionary_growths = 0;  // new asks whose selector requirements were added to the dictionaries in place       // Predicates() calls answered YKHOST_E_UNSUPPORTED (the Go side's fallback counter)
   int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1, cfgKP = -1;
 
   void clear_state() {
@@ -351,7 +352,27 @@ bool append_spec(ykhost* h, const PodTemplate* tpl) {
   EncodedTables& T = *h->tables;
   EncodedSpec es;
   std::vector<uint64_t> wanted;
-  if (!h->enc.encode_spec_if_covered(*tpl, &es, &wanted)) return false;
+  if (!h->enc.encode_spec_if_covered(*tpl, &es, &wanted)) {
+    // Dictionary growth: selector requirements nobody used before take spare bits of the allocated label words — each new bit
+    // is evaluated on every node and only the touched word columns are uploaded (ykpred_update_label_word); nothing else of
+    // the cluster is re-encoded.
+    std::vector<int> new_bits;
+    if (!h->enc.extend_requirements(*tpl, &new_bits)) return false;
+    const size_t N = h->nodes.size();
+    std::set<int> words;
+    for (int q : new_bits) {
+      const DictReq& d = h->enc.req_dict[(size_t)q];
+      uint64_t* col = T.labels.data() + (size_t)(q >> 6) * N;
+      const uint64_t bit = 1ull << (q & 63);
+      for (size_t n = 0; n < N; ++n)
+        if (d.eval(h->nodes[n]->node)) col[n] |= bit;
+      words.insert(q >> 6);
+    }
+    for (int w : words)
+      if (ykpred_update_label_word(h->eng, w, T.labels.data() + (size_t)w * N) != YKPRED_OK) return false;
+    h->dictionary_growths++;
+    if (!h->enc.encode_spec_if_covered(*tpl, &es, &wanted)) return false;
+  }
   const size_t W = (size_t)h->enc.W, KP = (size_t)h->enc.KP;
   const size_t S = h->spec_templates.size();
   const_cast<PodTemplate*>(tpl)->spec_id = (int32_t)S;
@@ -1672,11 +1693,13 @@ int32_t ykhost_ask_supported(ykhost_t* h, int32_t pod, char* reason, int32_t rea
   copy_out(un == h->enc.unsupported.end() ? "" : un->second, reason, reason_len);
   return un == h->enc.unsupported.end() ? 1 : 0;
 }
-// out[0] = asks marked unsupported at the last encode, out[1] = Predicates() calls answered YKHOST_E_UNSUPPORTED so far
+// out[0] = asks marked unsupported at the last encode, out[1] = Predicates() calls answered YKHOST_E_UNSUPPORTED so far,
+// out[2] = new asks whose selector requirements were added to the dictionaries in place (no re-encode)
 int32_t ykhost_routing_stats(ykhost_t* h, int64_t* out2) {
   YKHOST_LOCKED(h);
   out2[0] = h->unsupported_asks;
   out2[1] = h->routed_to_cpu;
+  out2[2] = h->dictionary_growths;
   return 0;
 }
 

@@ -285,9 +285,9 @@ class GpuPredicateManager:
         return rc == 1, buf.value.decode()
 
     def routing_stats(self):
-        out = np.zeros(2, dtype=np.int64)
+        out = np.zeros(3, dtype=np.int64)
         self._L.ykhost_routing_stats(self._h, out.ctypes.data)
-        return {"unsupported_asks": int(out[0]), "routed_to_cpu": int(out[1])}
+        return {"unsupported_asks": int(out[0]), "routed_to_cpu": int(out[1]), "dictionary_growths": int(out[2])}
 
     def pod_request(self, pod):
         buf = C.create_string_buffer(4096)
