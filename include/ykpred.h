@@ -279,6 +279,11 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* args, int
 int32_t ykpred_synchronize(ykpred_engine_t* e);
 int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* out);
 int32_t ykpred_last_timing(const ykpred_engine_t* e, ykpred_timing_t* out);
+/* Engine counters since create: out[0] full evaluations, [1] ykpred_eval_nodes calls, [2] ykpred_eval_pods calls, [3] query calls,
+ * [4] bitmap gathers, [5] table uploads / patches. Every upload / eval / gather entry point is also bracketed by a roctx
+ * range ("ykpred:eval", "ykpred:upload_nodes", "ykpred:gather_bitmap" ...) when the process runs under a profiler that has
+ * the marker library mapped, or with YKPRED_ROCTX=1. */
+int32_t ykpred_get_counters(const ykpred_engine_t* e, int64_t* out6);
 
 /* readback (device -> caller host buffers); each implies a synchronize */
 int32_t ykpred_read_bitmap(ykpred_engine_t* e, int32_t first_pod, int32_t num_pods, uint64_t* out /* [num_pods][row_words] */);

@@ -1,0 +1,343 @@
+/*
+ Licensed to the Apache Software Foundation (ASF) under one
+ or more contributor license agreements.  See the NOTICE file
+ distributed with this work for additional information
+ regarding copyright ownership.  The ASF licenses this file
+ to you under the Apache License, Version 2.0 (the
+ "License"); you may not use this file except in compliance
+ with the License.  You may obtain a copy of the License at
+
+     http://www.apache.org/licenses/LICENSE-2.0
+
+ Unless required by applicable law or agreed to in writing, software
+ distributed under the License is distributed on an "AS IS" BASIS,
+ WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND, either express or implied.
+ See the License for the specific language governing permissions and
+ limitations under the License.
+*/
+
+// Package predicates: gpu_predicate_manager.go is the drop-in for pkg/plugin/predicates of apache/yunikorn-k8shim.
+//
+// It implements the PredicateManager interface (predicate_manager.go:47-55) on top of the MI355X engine. The Go side is
+// deliberately thin: pods and nodes cross the cgo boundary as the JSON the API machinery already produces for them
+// (encoding/json on v1.Pod / v1.Node emits exactly the Kubernetes field names libykhost parses), libykhost.so keeps the
+// encoded mirror of pkg/cache/external.SchedulerCache and drives libykpred.so (include/ykhost.h, include/ykpred.h).
+// What stays in Go: the interface, the hooks in the cache's critical sections, the routing of asks the engine does not
+// evaluate to the existing CPU manager, the configuration key and the counters.
+//
+// Place this file in pkg/plugin/predicates/, the two headers and libraries under third_party/ykpred/, and apply the
+// three one-line changes listed in INTEGRATION.md §2 (context.go:130, scheduler_cache.go hooks, schedulerconf.go key).
+// This file cannot be compiled in the build image of this repository (no Go toolchain); scripts/check_go_bindings.py
+// checks every C symbol and constant it uses against the headers.
+package predicates
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../../third_party/ykpred/include
+#cgo LDFLAGS: -L${SRCDIR}/../../../third_party/ykpred/lib -lykhost -lykpred -Wl,-rpath,${SRCDIR}/../../../third_party/ykpred/lib
+#include <stdlib.h>
+#include "ykhost.h"
+#include "ykpred.h"
+*/
+import "C"
+
+import (
+	"encoding/json"
+	"errors"
+	"fmt"
+	"strings"
+	"sync"
+	"sync/atomic"
+	"unsafe"
+
+	"go.uber.org/zap"
+	v1 "k8s.io/api/core/v1"
+	fwk "k8s.io/kube-scheduler/framework"
+	"k8s.io/kubernetes/pkg/scheduler/framework"
+
+	"github.com/apache/yunikorn-k8shim/pkg/log"
+)
+
+// Values of the configuration key service.predicateEngine (pkg/conf/schedulerconf.go, next to the other service.* keys).
+const (
+	PredicateEngineCPU = "cpu" // the reference's predicateManagerImpl (default)
+	PredicateEngineGPU = "gpu" // this file; falls back to "cpu" when no device can be opened
+)
+
+// GPUPredicateCounters are exported through the scheduler's metrics / state dump.
+type GPUPredicateCounters struct {
+	DeviceAnswers     atomic.Int64 // Predicates() calls answered by the engine
+	RoutedUnsupported atomic.Int64 // asks the engine does not evaluate (volumes, DRA claims, dictionary limits): CPU manager
+	RoutedNotMirrored atomic.Int64 // pod or node not (yet) in the mirror: CPU manager
+	RoutedOnError     atomic.Int64 // the engine reported an error: CPU manager
+	PreemptionAnswers atomic.Int64
+	MirrorUpdates     atomic.Int64
+	MirrorErrors      atomic.Int64
+}
+
+// CacheObserver is what SchedulerCache calls from inside its own critical sections (INTEGRATION.md §2 lists the six call
+// sites: scheduler_cache.go:149,190,304,392,444,464). The cache write lock is held, so mirror updates are serialised
+// against each other exactly like the cache's; evaluations take the handle's own lock inside libykhost.
+type CacheObserver interface {
+	OnUpdateNode(node *v1.Node)
+	OnRemoveNode(node *v1.Node)
+	OnUpdatePod(pod *v1.Pod)
+	OnRemovePod(pod *v1.Pod)
+	OnAssumePod(pod *v1.Pod)
+	OnForgetPod(pod *v1.Pod)
+}
+
+type gpuPredicateManager struct {
+	cpu      PredicateManager // the existing implementation: EventsToRegister and every ask that is routed
+	host     *C.ykhost_t
+	lock     sync.Mutex // guards host against destroy; libykhost serialises its own entry points
+	Counters GPUPredicateCounters
+}
+
+var _ PredicateManager = &gpuPredicateManager{}
+var _ CacheObserver = &gpuPredicateManager{}
+
+// NewGPUPredicateManager opens the device and returns the GPU-backed manager, or the CPU manager itself when the engine
+// cannot be created (no GPU visible, library mismatch): the scheduler never starts without a working PredicateManager.
+func NewGPUPredicateManager(cpu PredicateManager, device int) PredicateManager {
+	errBuf := (*C.char)(C.malloc(512))
+	defer C.free(unsafe.Pointer(errBuf))
+	host := C.ykhost_create(C.int32_t(device), errBuf, 512)
+	if host == nil {
+		log.Log(log.ShimPredicates).Warn("GPU predicate engine unavailable, using the CPU predicate manager",
+			zap.String("reason", C.GoString(errBuf)))
+		return cpu
+	}
+	if C.ykpred_abi_version() != C.YKPRED_ABI_VERSION {
+		log.Log(log.ShimPredicates).Warn("GPU predicate engine ABI mismatch, using the CPU predicate manager")
+		C.ykhost_destroy(host)
+		return cpu
+	}
+	log.Log(log.ShimPredicates).Info("GPU predicate engine created", zap.Int("device", device))
+	return &gpuPredicateManager{cpu: cpu, host: host}
+}
+
+// NewConfiguredPredicateManager is what pkg/cache/context.go:130 calls instead of NewPredicateManager: the configuration
+// key service.predicateEngine selects the implementation.
+func NewConfiguredPredicateManager(handle fwk.Handle, engine string, device int) PredicateManager {
+	cpu := NewPredicateManager(handle)
+	if strings.EqualFold(engine, PredicateEngineGPU) {
+		return NewGPUPredicateManager(cpu, device)
+	}
+	return cpu
+}
+
+// Close releases the device; the manager must not be used afterwards.
+func (m *gpuPredicateManager) Close() {
+	m.lock.Lock()
+	defer m.lock.Unlock()
+	if m.host != nil {
+		C.ykhost_destroy(m.host)
+		m.host = nil
+	}
+}
+
+// EventsToRegister is pod-independent bookkeeping of the scheduling queue: unchanged (predicate_manager.go:70-132).
+func (m *gpuPredicateManager) EventsToRegister(queueingHintFn fwk.QueueingHintFn) []fwk.ClusterEventWithHint {
+	return m.cpu.EventsToRegister(queueingHintFn)
+}
+
+// Predicates keeps the reference contract (predicate_manager.go:134-139,206-219): ("", nil) when the pod fits, else the
+// name of the first failing plugin ("" when a PreFilter plugin rejected the pod) and an error carrying the status message.
+func (m *gpuPredicateManager) Predicates(pod *v1.Pod, node *framework.NodeInfo, allocate bool) (string, error) {
+	if pod == nil || node == nil || node.Node() == nil {
+		return m.cpu.Predicates(pod, node, allocate)
+	}
+	uid := C.CString(string(pod.UID))
+	defer C.free(unsafe.Pointer(uid))
+	name := C.CString(node.Node().Name)
+	defer C.free(unsafe.Pointer(name))
+	podIndex := C.ykhost_pod_index(m.host, uid)
+	nodeIndex := C.ykhost_node_index(m.host, name)
+	if podIndex < 0 || nodeIndex < 0 {
+		m.Counters.RoutedNotMirrored.Add(1)
+		return m.cpu.Predicates(pod, node, allocate)
+	}
+	var plugin [64]C.char
+	var message [1024]C.char
+	alloc := C.int32_t(0)
+	if allocate {
+		alloc = 1
+	}
+	rc := C.ykhost_predicates(m.host, podIndex, nodeIndex, alloc, &plugin[0], 64, &message[0], 1024)
+	switch {
+	case rc == 1:
+		m.Counters.DeviceAnswers.Add(1)
+		return "", nil
+	case rc == 0:
+		m.Counters.DeviceAnswers.Add(1)
+		return C.GoString(&plugin[0]), errors.New(C.GoString(&message[0]))
+	case rc == C.YKHOST_E_UNSUPPORTED:
+		m.Counters.RoutedUnsupported.Add(1)
+		return m.cpu.Predicates(pod, node, allocate)
+	default:
+		m.Counters.RoutedOnError.Add(1)
+		log.Log(log.ShimPredicates).Warn("GPU predicate engine error, routing the call to the CPU predicate manager",
+			zap.String("error", C.GoString(C.ykhost_last_error(m.host))))
+		return m.cpu.Predicates(pod, node, allocate)
+	}
+}
+
+// PreemptionPredicates keeps the reference contract (predicate_manager.go:141-179): the first index >= startIndex at
+// which the pod fits once victims[0..index] are removed from the node, or -1.
+func (m *gpuPredicateManager) PreemptionPredicates(pod *v1.Pod, node *framework.NodeInfo, victims []*v1.Pod, startIndex int) int {
+	if pod == nil || node == nil || node.Node() == nil {
+		return m.cpu.PreemptionPredicates(pod, node, victims, startIndex)
+	}
+	uid := C.CString(string(pod.UID))
+	defer C.free(unsafe.Pointer(uid))
+	name := C.CString(node.Node().Name)
+	defer C.free(unsafe.Pointer(name))
+	podIndex := C.ykhost_pod_index(m.host, uid)
+	nodeIndex := C.ykhost_node_index(m.host, name)
+	reason := make([]C.char, 600)
+	if podIndex < 0 || nodeIndex < 0 || C.ykhost_ask_supported(m.host, podIndex, &reason[0], 600) != 1 {
+		m.Counters.RoutedNotMirrored.Add(1)
+		return m.cpu.PreemptionPredicates(pod, node, victims, startIndex)
+	}
+	// victim UIDs as a C array of C strings; a nil victim stays a NULL entry (predicate_manager.go:181-192 skips it)
+	count := len(victims)
+	slots := count
+	if slots == 0 {
+		slots = 1
+	}
+	array := (**C.char)(C.calloc(C.size_t(slots), C.size_t(unsafe.Sizeof(uintptr(0)))))
+	defer C.free(unsafe.Pointer(array))
+	entries := unsafe.Slice(array, slots)
+	for i, victim := range victims {
+		if victim != nil {
+			entries[i] = C.CString(string(victim.UID))
+		}
+	}
+	defer func() {
+		for _, entry := range entries {
+			if entry != nil {
+				C.free(unsafe.Pointer(entry))
+			}
+		}
+	}()
+	index := C.ykhost_preemption_predicates(m.host, podIndex, nodeIndex, array, C.int32_t(count), C.int32_t(startIndex))
+	if index < -1 {
+		m.Counters.RoutedOnError.Add(1)
+		return m.cpu.PreemptionPredicates(pod, node, victims, startIndex)
+	}
+	m.Counters.PreemptionAnswers.Add(1)
+	return int(index)
+}
+
+// ---- mirror maintenance (CacheObserver) ----------------------------------------------------------------------------------
+
+func (m *gpuPredicateManager) marshal(object interface{}) *C.char {
+	data, err := json.Marshal(object)
+	if err != nil {
+		m.Counters.MirrorErrors.Add(1)
+		log.Log(log.ShimPredicates).Warn("unable to marshal object for the GPU predicate mirror", zap.Error(err))
+		return nil
+	}
+	return C.CString(string(data))
+}
+
+func (m *gpuPredicateManager) mirrorResult(call string, rc C.int32_t) {
+	m.Counters.MirrorUpdates.Add(1)
+	if rc < 0 {
+		m.Counters.MirrorErrors.Add(1)
+		log.Log(log.ShimPredicates).Warn("GPU predicate mirror update failed",
+			zap.String("call", call), zap.String("error", C.GoString(C.ykhost_last_error(m.host))))
+	}
+}
+
+// OnUpdateNode: SchedulerCache.UpdateNode (scheduler_cache.go:148-187).
+func (m *gpuPredicateManager) OnUpdateNode(node *v1.Node) {
+	if text := m.marshal(node); text != nil {
+		defer C.free(unsafe.Pointer(text))
+		m.mirrorResult("ykhost_update_node", C.ykhost_update_node(m.host, text))
+	}
+}
+
+// OnRemoveNode: SchedulerCache.RemoveNode (scheduler_cache.go:189-239).
+func (m *gpuPredicateManager) OnRemoveNode(node *v1.Node) {
+	name := C.CString(node.Name)
+	defer C.free(unsafe.Pointer(name))
+	m.mirrorResult("ykhost_remove_node", C.ykhost_remove_node(m.host, name))
+}
+
+// OnUpdatePod: SchedulerCache.UpdatePod (scheduler_cache.go:303-388).
+func (m *gpuPredicateManager) OnUpdatePod(pod *v1.Pod) {
+	if text := m.marshal(pod); text != nil {
+		defer C.free(unsafe.Pointer(text))
+		m.mirrorResult("ykhost_update_pod", C.ykhost_update_pod(m.host, text))
+	}
+}
+
+// OnRemovePod: SchedulerCache.RemovePod (scheduler_cache.go:390-421).
+func (m *gpuPredicateManager) OnRemovePod(pod *v1.Pod) {
+	uid := C.CString(string(pod.UID))
+	defer C.free(unsafe.Pointer(uid))
+	m.mirrorResult("ykhost_remove_pod", C.ykhost_remove_pod(m.host, uid))
+}
+
+// OnAssumePod: SchedulerCache.AssumePod (scheduler_cache.go:443-461); the pod carries the node it was assumed on.
+func (m *gpuPredicateManager) OnAssumePod(pod *v1.Pod) {
+	uid := C.CString(string(pod.UID))
+	defer C.free(unsafe.Pointer(uid))
+	name := C.CString(pod.Spec.NodeName)
+	defer C.free(unsafe.Pointer(name))
+	m.mirrorResult("ykhost_assume_pod", C.ykhost_assume_pod(m.host, uid, name))
+}
+
+// OnForgetPod: SchedulerCache.ForgetPod (scheduler_cache.go:463-484).
+func (m *gpuPredicateManager) OnForgetPod(pod *v1.Pod) {
+	uid := C.CString(string(pod.UID))
+	defer C.free(unsafe.Pointer(uid))
+	m.mirrorResult("ykhost_forget_pod", C.ykhost_forget_pod(m.host, uid))
+}
+
+// ---- batched evaluation ------------------------------------------------------------------------------------------------------
+
+// Refresh brings the device-resident P x N feasibility bitmap, the per-ask feasible counts and the per-ask bin-pack
+// decisions up to date with the mirror: only the bitmap columns of changed nodes and the rows of changed asks are
+// re-evaluated when that is possible (ykhost_evaluate_dirty), a full pass otherwise. Returns the number of node columns that
+// were patched, or -1 after a full pass. A scheduling cycle that wants candidates for every pending ask calls this once and
+// reads the results through Layout(); the per-pair Predicates() callback does not depend on it.
+func (m *gpuPredicateManager) Refresh(allocate bool) (int, error) {
+	alloc := C.int32_t(0)
+	if allocate {
+		alloc = 1
+	}
+	var patched C.int32_t
+	options := C.uint32_t(C.YKPRED_OUT_BITMAP | C.YKPRED_OUT_COUNTS | C.YKPRED_OUT_DECISIONS)
+	if rc := C.ykhost_evaluate_dirty(m.host, alloc, options, &patched); rc < 0 {
+		return 0, fmt.Errorf("ykhost_evaluate_dirty: %s", C.GoString(C.ykhost_last_error(m.host)))
+	}
+	return int(patched), nil
+}
+
+// BitmapLayout describes the device-resident results of the last Refresh (device pointers: for consumers on the GPU side,
+// e.g. a batched scheduler-interface callback; host code reads single answers through Predicates()).
+type BitmapLayout struct {
+	Nodes, Asks, RowWords, RowStride int
+	Bitmap, Counts, Decisions        unsafe.Pointer
+}
+
+// Layout returns where the results of the last Refresh live.
+func (m *gpuPredicateManager) Layout() (BitmapLayout, error) {
+	var layout C.ykpred_layout_t
+	if rc := C.ykpred_get_layout(C.ykhost_engine(m.host), &layout); rc != C.YKPRED_OK {
+		return BitmapLayout{}, errors.New("ykpred_get_layout failed")
+	}
+	return BitmapLayout{
+		Nodes: int(layout.num_nodes), Asks: int(layout.num_pods), RowWords: int(layout.row_words), RowStride: int(layout.row_stride),
+		Bitmap: layout.bitmap, Counts: layout.counts, Decisions: layout.decisions,
+	}, nil
+}
+
+// RoutingStats: asks marked unsupported at the last encode, Predicates() calls the engine refused, dictionary growths.
+func (m *gpuPredicateManager) RoutingStats() (unsupported, refused, growths int64) {
+	var out [3]C.int64_t
+	C.ykhost_routing_stats(m.host, &out[0])
+	return int64(out[0]), int64(out[1]), int64(out[2])
+}

@@ -33,7 +33,7 @@ out["write_calibration"] = {"kernel": "fill_linear (writes exactly 6 272 000 000
                             "expected_KiB": expected_kib, "ratio": fill_w["fill_linear"]["avg_KiB"] / expected_kib}
 out["bench_WRITE_SIZE"] = per_kernel("bench", "WRITE_SIZE")
 out["bench_FETCH_SIZE"] = per_kernel("bench", "FETCH_SIZE")
-key = [k for k in out["bench_WRITE_SIZE"] if "k_combine" in k][0]
+key = [k for k in out["bench_WRITE_SIZE"] if "k_combine" in k and "wave" not in k][0]
 w = out["bench_WRITE_SIZE"][key]["avg_KiB"] * 1024 / out["write_calibration"]["ratio"]
 f_raw = out["bench_FETCH_SIZE"][key]["avg_KiB"] * 1024
 traffic = {"round": rnd, "kernel": "k_combine", "pods": 1_000_000, "nodes": 50_000,

@@ -51,3 +51,14 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"ykoracle|oracle/|import _oracle|orc_", text):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_go_side_only_uses_the_declared_abi():
+    """integration/gpu_predicate_manager.go (the Go drop-in; no Go toolchain here) may only call what include/*.h declares,
+    with the declared argument counts, and contains no elisions."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_go_bindings.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "checked" in r.stdout and "PROBLEM" not in r.stdout

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -215,6 +216,9 @@ struct ykpred_engine {
   bool last_has_keys = false;
   // PodTopologySpread / InterPodAffinity histograms: valid for the node / spec tables of `hist_epoch`
   uint64_t nodes_epoch = 1, hist_epoch = 0;
+
+  // --- counters (ykpred_get_counters)
+  int64_t n_full_evals = 0, n_node_patches = 0, n_row_patches = 0, n_queries = 0, n_gathers = 0, n_uploads = 0;
 
   // --- timing: one (start, stop) event pair per kernel, recorded on the stream the kernel is launched on
   hipEvent_t ev[2 * YKPRED_MAX_TIMED_KERNELS + 2]{};
@@ -540,6 +544,41 @@ int run_spread_prefilter(ykpred_engine* e, hipStream_t st, Timer* tm, bool do_co
   return YKPRED_OK;
 }
 
+// roctx ranges around upload / eval / gather: visible in rocprofv3 --marker-trace timelines. The marker
+// library is only used when it is already mapped (the process runs under a profiler) or YKPRED_ROCTX=1 asks for it.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+Roctx* roctx() {
+  static Roctx r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* lib = nullptr;
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"};
+    for (const char* n : names)
+      if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    const char* want = getenv("YKPRED_ROCTX");
+    if (!lib && want && want[0] == '1')
+      for (const char* n : names)
+        if (!lib) lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    r.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+    r.pop = (int (*)())dlsym(lib, "roctxRangePop");
+    if (!r.push || !r.pop) r.push = nullptr;
+  });
+  return &r;
+}
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx()->push != nullptr) {
+    if (on) roctx()->push(name);
+  }
+  ~Range() {
+    if (on) roctx()->pop();
+  }
+};
+
 // librccl, resolved on first use. torch ships a librccl.so.1 of its own: a copy that is already mapped is reused.
 struct Rccl {
   void* lib = nullptr;
@@ -726,6 +765,8 @@ void ykpred_destroy(ykpred_engine_t* e) {
 
 int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:upload_nodes");
+  if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (e) e->nodes_epoch++;
   if (e) e->last_eval_valid = false;  // every row and column of an earlier bitmap is stale (and N / row_stride may change)
@@ -786,6 +827,8 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
 
 int32_t ykpred_update_node(ykpred_engine_t* e, int32_t idx, const ykpred_nodes_t* n) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:update_node");
+  if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (!e || !n || n->count != 1) return fail(e, YKPRED_E_INVALID, "update_node: count must be 1");
   if (!e->nodes_set || idx < 0 || idx >= e->N) return fail(e, YKPRED_E_INVALID, "update_node: index out of range");
@@ -837,6 +880,8 @@ int32_t ykpred_update_label_word(ykpred_engine_t* e, int32_t word, const uint64_
 
 int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:upload_specs");
+  if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
   if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
@@ -1069,6 +1114,8 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
 
 int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* p) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:upload_asks");
+  if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (!e || !p || p->count < 0) return fail(e, YKPRED_E_INVALID, "set_pods: bad argument");
   if (p->count > 0 && (!p->spec_index || !p->node_name_index)) return fail(e, YKPRED_E_INVALID, "set_pods: null column");
@@ -1096,6 +1143,7 @@ static int validate_state(ykpred_engine* e) {
 
 int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:eval");
   if (!e || !a) return fail(e, YKPRED_E_INVALID, "eval: bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
@@ -1429,6 +1477,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_pre = pre;
   e->last_filt = filt;
   e->last_eval_valid = true;
+  if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) e->n_full_evals++;
   if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
   if (want_dec) e->rank_valid = true;
   e->last_has_keys = want_keys;
@@ -1437,6 +1486,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
 
 int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_t num_nodes, const int32_t* node_index) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:eval_nodes");
+  if (e) e->n_node_patches++;
   if (!e || !a || num_nodes < 0 || (num_nodes > 0 && !node_index)) return fail(e, YKPRED_E_INVALID, "eval_nodes: bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
@@ -1531,6 +1582,8 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
 int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t count, const int32_t* rows, const int32_t* spec_index,
                            const int32_t* node_name_index) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:update_asks");
+  if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (!e || num_pods_after < 0 || count < 0 || (count > 0 && (!rows || !spec_index || !node_name_index)))
     return fail(e, YKPRED_E_INVALID, "update_pods: bad argument");
@@ -1726,6 +1779,8 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
 
 int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_t num_rows, const int32_t* rows) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:eval_pods");
+  if (e) e->n_row_patches++;
   if (!e || !a || num_rows < 0 || (num_rows > 0 && !rows)) return fail(e, YKPRED_E_INVALID, "eval_pods: bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
@@ -1884,6 +1939,18 @@ int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
   return YKPRED_OK;
 }
 
+int32_t ykpred_get_counters(const ykpred_engine_t* e, int64_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out) return YKPRED_E_INVALID;
+  out[0] = e->n_full_evals;
+  out[1] = e->n_node_patches;
+  out[2] = e->n_row_patches;
+  out[3] = e->n_queries;
+  out[4] = e->n_gathers;
+  out[5] = e->n_uploads;
+  return YKPRED_OK;
+}
+
 int32_t ykpred_read_rows(ykpred_engine_t* e, int32_t n, const int32_t* pods, uint64_t* out) {
   YK_SERIALISE(e);
   if (!e || n < 0 || (n > 0 && (!pods || !out))) return fail(e, YKPRED_E_INVALID, "read_rows: bad argument");
@@ -1935,6 +2002,8 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words) {
 int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const int32_t* nodes, uint32_t pre, uint32_t filt, uint8_t* fit,
                      uint8_t* code, uint32_t* reason) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:query");
+  if (e) e->n_queries++;
   if (!e || n < 0 || (n > 0 && (!pods || !nodes || !fit))) return fail(e, YKPRED_E_INVALID, "query: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query: tables not uploaded");
   for (int i = 0; i < n; ++i)
@@ -1966,6 +2035,8 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t n, const int32_t* pods, const i
 
 int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t filt, uint8_t* fit, uint8_t* code, uint32_t* reason) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:query_pod");
+  if (e) e->n_queries++;
   if (!e || !fit) return fail(e, YKPRED_E_INVALID, "query_pod: bad argument");
   if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query_pod: tables not uploaded");
   if (pod < 0 || pod >= e->P) return fail(e, YKPRED_E_INVALID, "query_pod: index out of range");
@@ -2115,6 +2186,8 @@ int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words) {
 
 int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered, void* stream) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:gather_bitmap");
+  if (e) e->n_gathers++;
   if (!e) return YKPRED_E_INVALID;
   if (!e->comm) return fail(e, YKPRED_E_STATE, "gather_bitmap: no communicator (ykpred_comm_init)");
   if (!e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "gather_bitmap: no current evaluation");
@@ -2131,6 +2204,7 @@ int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered, void* stream) {
 
 int32_t ykpred_exchange_decisions(ykpred_engine_t* e, void* stream) {
   YK_SERIALISE(e);
+  Range roctx_range("ykpred:exchange_decisions");
   if (!e) return YKPRED_E_INVALID;
   if (!e->comm) return fail(e, YKPRED_E_STATE, "exchange_decisions: no communicator (ykpred_comm_init)");
   if (!e->last_eval_valid || !e->last_has_keys)

@@ -112,7 +112,11 @@ struct ykhost {
   int64_t last_encode_us = 0;
   int64_t unsupported_asks = 0;    // asks whose template the encoder marked unsupported at the last full encode
   int64_t routed_to_cpu = 0;
-  int64_t dictionary_growths = 0;  // new asks whose selector requirements were added to the dictionaries in place       // Predicates() calls answered YKHOST_E_UNSUPPORTED (the Go side's fallback counter)
+  int64_t dictionary_growths = 0;  // new asks whose selector requirements were added to the dictionaries in place
+  // label key → value → nodes carrying it (built on the first dictionary growth, dropped whenever a node object changes): a
+  // new requirement bit is then computed per DISTINCT value of its key instead of per node
+  std::unordered_map<std::string, std::unordered_map<std::string, std::vector<int32_t>>> label_index;
+  bool label_index_valid = false;       // Predicates() calls answered YKHOST_E_UNSUPPORTED (the Go side's fallback counter)
   int cfgR = 0, cfgKT = 0, cfgW = 0, cfgKD = -1, cfgKS = -1, cfgKP = -1;
 
   void clear_state() {
@@ -126,6 +130,7 @@ struct ykhost {
     by_uid.clear();
     uid_index = true;
     dirty_all = true;
+    label_index_valid = false;
     dirty_nodes.clear();
     eval_dirty_nodes.clear();
     dirty_rows.clear();
@@ -360,12 +365,49 @@ bool append_spec(ykhost* h, const PodTemplate* tpl) {
     if (!h->enc.extend_requirements(*tpl, &new_bits)) return false;
     const size_t N = h->nodes.size();
     std::set<int> words;
+    if (!h->label_index_valid) {
+      h->label_index.clear();
+      for (size_t n = 0; n < N; ++n)
+        for (auto& kv : h->nodes[n]->node.labels) h->label_index[kv.first][kv.second].push_back((int32_t)n);
+      h->label_index_valid = true;
+    }
     for (int q : new_bits) {
       const DictReq& d = h->enc.req_dict[(size_t)q];
       uint64_t* col = T.labels.data() + (size_t)(q >> 6) * N;
       const uint64_t bit = 1ull << (q & 63);
-      for (size_t n = 0; n < N; ++n)
-        if (d.eval(h->nodes[n]->node)) col[n] |= bit;
+      if (d.kind == DictReq::kLabel || d.kind == DictReq::kEquals) {
+        // a label requirement depends on the node only through its value of ONE key: In / Equals touch just the nodes of
+        // the listed values, the other operators are decided once per distinct value (and once for "key absent")
+        auto ix = h->label_index.find(d.req.key);
+        const bool listed = d.kind == DictReq::kEquals || d.req.op == "In" || d.req.op == "NotIn";
+        const bool negated = d.kind == DictReq::kLabel && d.req.op == "NotIn";
+        if (listed) {
+          if (negated)
+            for (size_t n = 0; n < N; ++n) col[n] |= bit;
+          if (ix != h->label_index.end())
+            for (auto& v : d.req.values) {
+              auto vn = ix->second.find(v);
+              if (vn == ix->second.end()) continue;
+              for (int32_t n : vn->second) col[(size_t)n] = negated ? (col[(size_t)n] & ~bit) : (col[(size_t)n] | bit);
+            }
+        } else {
+          Node probe;
+          const bool absent_matches = d.eval(probe);
+          if (absent_matches)
+            for (size_t n = 0; n < N; ++n) col[n] |= bit;
+          if (ix != h->label_index.end())
+            for (auto& vn : ix->second) {
+              probe.labels.clear();
+              probe.labels[d.req.key] = vn.first;
+              const bool m = d.eval(probe);
+              if (m == absent_matches) continue;
+              for (int32_t n : vn.second) col[(size_t)n] = m ? (col[(size_t)n] | bit) : (col[(size_t)n] & ~bit);
+            }
+        }
+      } else {
+        for (size_t n = 0; n < N; ++n)
+          if (d.eval(h->nodes[n]->node)) col[n] |= bit;
+      }
       words.insert(q >> 6);
     }
     for (int w : words)
@@ -986,6 +1028,7 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
     mj::ValuePtr v = mj::parse(node_json);
     Node n = read_node(*v);
     int adopted = 0;
+    h->label_index_valid = false;
     auto it = h->node_ix.find(n.name);
     if (it == h->node_ix.end()) {
       h->node_store.emplace_back();
@@ -1022,6 +1065,7 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
   YKHOST_LOCKED(h);
   auto it = h->node_ix.find(name);
   if (it == h->node_ix.end()) return 0;
+  h->label_index_valid = false;
   int idx = it->second;
   ensure_uid_index(h);
   int orphans = 0;

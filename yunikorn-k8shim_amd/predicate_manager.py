@@ -454,6 +454,11 @@ class GpuPredicateManager:
                                           code.ctypes.data, reason.ctypes.data))
         return fit, code, reason
 
+    def counters(self):
+        out = np.zeros(6, dtype=np.int64)
+        self._pcheck(self._P.ykpred_get_counters(self.engine, out.ctypes.data))
+        return dict(zip(["full_evals", "node_patches", "row_patches", "queries", "gathers", "uploads"], out.tolist()))
+
     def timing(self):
         t = _ffi.YkpredTiming()
         self._pcheck(self._P.ykpred_last_timing(self.engine, C.byref(t)))
