@@ -230,6 +230,7 @@ def main():
     pm.generate_kwok(num_nodes=count, node_index_offset=first, total_nodes=total_nodes, **kwok)
     if world > 1:
         pm.set_row_stride(shard.common_row_stride(ranges))
+        pm.set_row_capacity(shard.common_row_capacity(a.pods))
     pm.sync()
     t_gen = time.perf_counter() - t_gen
     P, N = pm.num_pods, pm.num_nodes
@@ -259,8 +260,9 @@ def main():
     nbuf = 2 if world > 1 else 1
     outs = [(torch.empty(P, dtype=torch.int32, device=dev), torch.empty(P, dtype=torch.int32, device=dev),
              torch.empty(P, dtype=torch.int64, device=dev)) for _ in range(nbuf)]
-    bitmaps = [torch.empty((P, lay0.row_stride), dtype=torch.int64, device=dev) for _ in range(nbuf)] if do_gather else [None] * nbuf
-    gathered = torch.empty((world, P, lay0.row_stride), dtype=torch.int64, device=dev) if do_gather else None
+    rows_cap = shard.common_row_capacity(a.pods) if world > 1 else 0
+    bitmaps = [torch.empty((rows_cap, lay0.row_stride), dtype=torch.int64, device=dev) for _ in range(nbuf)] if do_gather else [None] * nbuf
+    gathered = torch.empty((world, rows_cap, lay0.row_stride), dtype=torch.int64, device=dev) if do_gather else None
     # A dedicated (non-default) stream: the engine launches on the stream it is handed, and handle 0 — torch's default
     # stream — would mean "use the engine's own stream", which the events below could not order against.
     stream = torch.cuda.Stream(device=dev)
@@ -342,7 +344,7 @@ def main():
         t = torch.tensor([g_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         g_ms = float(t.item())
-        nbytes = P * lay.row_stride * 8
+        nbytes = rows_cap * lay.row_stride * 8
         gather = {"shard_bytes": nbytes, "ms": round(g_ms, 3), "recv_GBps_per_gpu": round(nbytes * (world - 1) / (g_ms * 1e-3) / 1e9, 1),
                   "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][P][row_stride] u64 (shard-major)",
                   "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "

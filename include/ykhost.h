@@ -137,6 +137,7 @@ ykpred_engine_t* ykhost_engine(ykhost_t* h); /* the underlying engine, for layou
  * [world][P][row_stride]; ykhost_comm_init uploads the tables and attaches the RCCL communicator to the engine
  * (ykpred_comm_init). The gather / decision exchange are then called on ykhost_engine(h). */
 int32_t ykhost_set_row_stride(ykhost_t* h, int32_t words /* multiple of 16; 0 = automatic */);
+int32_t ykhost_set_row_capacity(ykhost_t* h, int32_t rows /* physical bitmap rows every shard allocates; 0 = automatic */);
 int32_t ykhost_comm_init(ykhost_t* h, const uint8_t* id /* [YKPRED_COMM_ID_BYTES] */, int32_t rank, int32_t world, int32_t node_offset);
 int32_t ykhost_comm_destroy(ykhost_t* h);
 

@@ -216,16 +216,21 @@ typedef struct ykpred_layout {
   int32_t num_chunks;
   int32_t plane_rows;  /* total signature planes evaluated per eval */
   uint64_t bitmap_bytes;
-  void* bitmap;        /* device pointer of the last evaluated bitmap: bit (n & 63) of word [p*row_stride + (n >> 6)] */
+  void* bitmap;        /* device pointer of the last evaluated bitmap; rows are addressed through row_of_pod (below) */
   void* counts;        /* device int32[P] */
   void* decisions;     /* device int32[P] */
   void* decision_keys; /* device int64[P] */
   void* spread_counts;  /* device int32[spread_cells]: matching pods per (spread constraint, topology domain) — SUM across shards */
   void* spread_present; /* device int32[spread_cells]: 1 = an eligible node carries the domain — MAX across shards */
   int64_t spread_cells;
+  int32_t num_rows;     /* physical rows of the bitmap (>= num_pods: rows are laid out for the writer and never reused between two
+                           class builds); bitmap_bytes = num_rows * row_stride * 8 — what a caller-owned bitmap must hold */
+  int32_t reserved0;
+  void* row_of_pod;     /* device int32[P]: the bitmap row of pod p. Bit (n & 63) of word [row_of_pod[p] * row_stride + (n >> 6)]
+                           says whether pod p fits node n */
 } ykpred_layout_t;
 
-#define YKPRED_MAX_TIMED_KERNELS 16
+#define YKPRED_MAX_TIMED_KERNELS 24
 typedef struct ykpred_timing {
   int32_t num_kernels;
   float total_ms;                         /* first launch to last completion, device time */
@@ -296,6 +301,7 @@ int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out); /* order-inde
  * differ between a pod's row and the row of its class's representative, plus non-zero padding words. With these a checker
  * evaluates ONE pod per class against every node on the CPU and still covers every (pod, node) pair of the bitmap. */
 int32_t ykpred_read_rows(ykpred_engine_t* e, int32_t n, const int32_t* pod_index, uint64_t* out /* [n][row_words] */);
+int32_t ykpred_read_row_map(ykpred_engine_t* e, int32_t* out /* [P]: layout.row_of_pod on the host */);
 int32_t ykpred_read_pod_classes(ykpred_engine_t* e, int32_t* pod_class /* [P] or NULL */, int32_t* class_rep /* [num_classes] or NULL */);
 int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
 
@@ -337,8 +343,9 @@ int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t num_queries, const i
  *                           already connects the shard processes; bench.py: its torch.distributed bootstrap group)
  *   ykpred_comm_init        ncclCommInitRank; node_offset = global index of this shard's node 0
  *   ykpred_gather_bitmap    all-gather of the shard bitmaps of the last ykpred_eval into the shard-major layout
- *                           [world][P][row_stride] (BASELINE configs[3]); every shard must use the same row_stride
- *                           (ykpred_set_row_stride) and hold the same asks in the same order
+ *                           [world][num_rows][row_stride] (BASELINE configs[3]) plus the shards' row_of_pod maps
+ *                           [world][P]; every shard must use the same row_stride and row capacity
+ *                           (ykpred_set_row_stride / ykpred_set_row_capacity) and hold the same asks in the same order
  *   ykpred_exchange_decisions  in place on the outputs of the last ykpred_eval (which must have produced decision keys):
  *                           counts → cluster-wide feasible counts (SUM); decisions → GLOBAL node index of the best
  *                           feasible node in bin-pack order, ties by global node index (MIN key, then MIN index), -1 = none
@@ -354,9 +361,13 @@ int32_t ykpred_comm_destroy(ykpred_engine_t* e);
 /* Rows of the NEXT ykpred_set_nodes get this stride (64-bit words, multiple of 16, >= the shard's own need); 0 = automatic.
  * Shards of unequal size agree on the stride of the largest one so that the gathered layout is regular. */
 int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words);
-int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered /* DEVICE [world][P][row_stride] u64, NULL = engine-owned */, void* stream);
+/* The bitmap is sized for at least `rows` physical rows (0 = as many as needed). Shards agree on one capacity (>= every
+ * shard's layout.num_rows) so that the gathered layout [world][rows][row_stride] is regular. */
+int32_t ykpred_set_row_capacity(ykpred_engine_t* e, int32_t rows);
+int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered /* DEVICE [world][num_rows][row_stride] u64, NULL = engine-owned */, void* stream);
 int32_t ykpred_exchange_decisions(ykpred_engine_t* e, void* stream);
-/* readback of the engine-owned gathered bitmap: rows [first_pod, first_pod + num_pods) of shard `shard`, row_stride words each */
+/* readback of the engine-owned gathered bitmap: the rows of pods [first_pod, first_pod + num_pods) in shard `shard` (through
+ * that shard's gathered row_of_pod map), row_stride words each */
 int32_t ykpred_read_gathered(ykpred_engine_t* e, int32_t shard, int32_t first_pod, int32_t num_pods, uint64_t* out);
 
 #ifdef __cplusplus

@@ -34,6 +34,7 @@ def main():
     pm = pkg.GpuPredicateManager(device=device)
     pm.generate_kwok(num_nodes=count, node_index_offset=first, total_nodes=total_nodes, **kw)
     pm.set_row_stride(sharding.common_row_stride(ranges))
+    pm.set_row_capacity(sharding.common_row_capacity(n_pods))
     dev = torch.device("cuda", device)
     P = n_pods
     counts = torch.empty(P, dtype=torch.int32, device=dev)
@@ -59,11 +60,12 @@ def main():
         p.copy_(ph)
         torch.cuda.synchronize()
         lay = pm.layout()
-        local = torch.empty((P, lay.row_stride), dtype=torch.int64, device=dev)
+        local = torch.empty((lay.num_rows, lay.row_stride), dtype=torch.int64, device=dev)
         pm.evaluate_into(bitmap=local, counts=counts, decisions=decisions, keys=keys, stream=stream.cuda_stream, spread_counts_ready=True)
         pm.synchronize()
         g = sharding.ref_gather_bitmap(local.cpu(), dist)
-        shard_rows = [g[s].numpy().view(np.uint64) for s in range(world)]
+        maps = sharding.ref_gather_bitmap(torch.from_numpy(pm.row_map().astype(np.int64)), dist)  # every shard's row_of_pod
+        shard_rows = [g[s].numpy().view(np.uint64)[maps[s].numpy()] for s in range(world)]
         ch, dh, kh = counts.cpu(), decisions.cpu(), keys.cpu()
         sharding.ref_exchange_decisions(ch, dh, kh, first, dist)
         counts.copy_(ch)

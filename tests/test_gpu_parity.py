@@ -1097,7 +1097,8 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, weak):
         assert d["scaling"] == "weak" and d["config"]["nodes_per_gpu"] == 4000 and d["config"]["total_nodes"] == 8000
     else:
         assert d["scaling"] == "strong" and d["config"]["total_nodes"] == 4000 and d["config"]["gang_size"] == 100
-        assert d["config"]["nodes_per_gpu"] == 2048 and d["bitmap_allgather"]["shard_bytes"] == 50000 * 32 * 8
+        rows_cap = importlib.import_module("yunikorn-k8shim_amd.sharding").common_row_capacity(50000)
+        assert d["config"]["nodes_per_gpu"] == 2048 and d["bitmap_allgather"]["shard_bytes"] == rows_cap * 32 * 8
     assert "reference" in d["config"]["collectives"]
 
 

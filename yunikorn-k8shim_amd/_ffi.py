@@ -41,10 +41,10 @@ class YkpredLayout(C.Structure):
                 ("row_words", C.c_int32), ("row_stride", C.c_int32), ("num_chunks", C.c_int32), ("plane_rows", C.c_int32),
                 ("bitmap_bytes", C.c_uint64), ("bitmap", C.c_void_p), ("counts", C.c_void_p), ("decisions", C.c_void_p),
                 ("decision_keys", C.c_void_p), ("spread_counts", C.c_void_p), ("spread_present", C.c_void_p),
-                ("spread_cells", C.c_int64)]
+                ("spread_cells", C.c_int64), ("num_rows", C.c_int32), ("reserved0", C.c_int32), ("row_of_pod", C.c_void_p)]
 
 
-MAX_TIMED = 16
+MAX_TIMED = 24
 
 
 class YkpredTiming(C.Structure):
@@ -96,11 +96,13 @@ def load_ykpred():
     L.ykpred_bitmap_checksum.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ykpred_read_rows.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.ykpred_read_pod_classes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_read_row_map.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_check_class_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ykpred_comm_unique_id.argtypes = [C.c_void_p]
     L.ykpred_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.ykpred_comm_destroy.argtypes = [C.c_void_p]
     L.ykpred_set_row_stride.argtypes = [C.c_void_p, C.c_int32]
+    L.ykpred_set_row_capacity.argtypes = [C.c_void_p, C.c_int32]
     L.ykpred_gather_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ykpred_exchange_decisions.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_read_gathered.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -148,6 +150,7 @@ def load_ykhost():
     L.ykhost_dump_snapshot.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
     L.ykhost_set_dump_compact.argtypes = [C.c_void_p, C.c_int32]
     L.ykhost_set_row_stride.argtypes = [C.c_void_p, C.c_int32]
+    L.ykhost_set_row_capacity.argtypes = [C.c_void_p, C.c_int32]
     L.ykhost_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.ykhost_comm_destroy.argtypes = [C.c_void_p]
     L.ykhost_sync.argtypes = [C.c_void_p]

@@ -163,7 +163,20 @@ struct ykpred_engine {
   // class index kept on the host so that ykpred_update_pods can move single rows between classes (mirrors of the device
   // tables above; `h_members` has -1 holes where a row left its class, chunks are only ever appended between rebuilds)
   std::unordered_map<ClassKey, int32_t, ClassKeyHash> class_ids;
-  std::vector<int32_t> h_pod_class, h_pod_slot;                       // per pod: class, slot in h_members
+  std::vector<int32_t> h_pod_class, h_pod_slot;                       // per pod: class, entry in h_members
+  // Physical bitmap rows. The row of pod p is h_pod_row[p] (device: d_pod_row, ykpred_layout_t.row_of_pod): rows are laid
+  // out for the WRITER — zone A [0, rows_a) in band order (see k_expand_bands), zone B after it class by class, rows of asks
+  // that arrived or changed class since the last build appended at the end. Rows are never reused between two builds.
+  std::vector<int32_t> h_pod_row;
+  int rows_total = 0, rows_a = 0, row_capacity = 0;  // rows in use; rows of zone A; ykpred_set_row_capacity (0 = automatic)
+  DevBuf d_pod_row;
+  // zone A: band layout tables (built by build_classes, read by k_class_rows / k_expand_bands / k_fix_rows)
+  bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
+  int band_steps = 128;            // tunable: cfg.reserved[6] > 0
+  int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
+  std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
+  DevBuf d_band_tab, d_class_rows_a, d_class_list_a, d_class_slot_a, d_fix_row, d_fix_slot, d_chunk_zone;
+  std::vector<int32_t> h_ch_zone;
   std::vector<uint8_t> h_row_stale;  // bitmap row rewritten by ykpred_update_pods and not re-evaluated yet: it must not serve
                                      // as the representative row of its class (k_column_class reads that row)
   std::vector<int32_t> h_class_sig, h_class_pin, h_class_first, h_class_live;
@@ -212,7 +225,7 @@ struct ykpred_engine {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1, node_offset = 0;
   int forced_stride = 0;  // ykpred_set_row_stride
-  DevBuf d_gathered, d_xkey, d_xcand;
+  DevBuf d_gathered, d_gathered_map, d_xkey, d_xcand;
   bool last_has_keys = false;
   // PodTopologySpread / InterPodAffinity histograms: valid for the node / spec tables of `hist_epoch`
   uint64_t nodes_epoch = 1, hist_epoch = 0;
@@ -350,24 +363,187 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     members[(size_t)slot] = p;
     e->h_pod_slot[(size_t)p] = slot;
   }
-  // Chunks of <= chunk_members pods of one class. Members of a class are in ascending pod order, and the chunks are
-  // dispatched in ascending order of their first pod: the ~2k blocks resident at any moment then write bitmap rows
-  // of one narrow, advancing window instead of rows scattered over the whole bitmap (DRAM page locality).
+  // ---- physical rows. Zone A (band layout): the bitmap is written like a linear fill — ykk::kBandGroups
+  // workgroups, 4 KiB aligned tiles, a window of kBandGroups * 4 KiB that advances one step at a time — so the rows are
+  // permuted for the writer: inside a band of `band_steps` windows a class owns the rows whose start offset inside their
+  // window, X(r) = (r * row_bytes) mod window, falls into one interval. Workgroup b always writes window bytes
+  // [4096 b, 4096 b + 4096): during a band it needs the rows of at most kBandClasses classes, which it keeps in LDS.
+  const long row_b = (long)e->row_stride * 8, win = (long)ykk::kBandGroups * 4096;
+  const int S = e->band_steps, KC = ykk::kBandClasses;
+  // a piece of a class inside one band must be wide enough in X that no workgroup range (4096 + row bytes) meets more
+  // than KC pieces: (rows of the piece / S) * row_b >= (4096 + row_b) / (KC - 1), with a margin; verified below
+  const int piece_min = (int)((double)S * (4096.0 + (double)row_b) / (double)row_b / (double)(KC - 1) * 1.3) + 3;
+  e->h_class_slot_a.assign((size_t)C, -1);
+  e->h_pod_row.assign((size_t)P, -1);
+  std::vector<ykk::BandEntry> band_tab;
+  std::vector<int32_t> class_list_a, fix_row, fix_slot;
+  int n_steps = 0, n_bands = 0, rows_a = 0;
+  const bool geometry_ok = e->bands_enabled && e->N > 0 && (size_t)2 * KC * (size_t)row_b <= (size_t)ykk::kBandMaxLds &&
+                           e->row_stride <= ykk::kBandFetch * 512;
+  if (geometry_ok) {
+    long rows_needed = 0;
+    for (int c = 0; c < C; ++c)
+      if (class_size[(size_t)c] >= 2 * piece_min) {
+        e->h_class_slot_a[(size_t)c] = (int32_t)class_list_a.size();
+        class_list_a.push_back(c);
+        rows_needed += class_size[(size_t)c];
+      }
+    if (rows_needed < (long)S * win / row_b / 4) {  // not even a quarter of a band: the chunk kernel does it all
+      class_list_a.clear();
+      std::fill(e->h_class_slot_a.begin(), e->h_class_slot_a.end(), -1);
+    }
+  }
+  if (!class_list_a.empty()) {
+    // band by band: the band's rows in (X, step) order, filled with class pieces in class order
+    struct Piece {
+      int32_t x, s, slot;  // key of the piece's first row, class-row slot
+    };
+    size_t ci = 0;            // next zone-A class
+    int32_t left = class_size[(size_t)class_list_a[0]], taken = 0;  // rows of class ci still to place / already placed
+    bool ok = true;
+    std::vector<uint64_t> keys;
+    std::vector<Piece> pieces;
+    int band = 0;
+    while (ci < class_list_a.size() && ok) {
+      // rows still to place decide the height of this band (the last one is shorter: no tail of unused windows)
+      const long band_rows = (long)S * win / row_b;
+      long remaining = left;
+      for (size_t k = ci + 1; k < class_list_a.size() && remaining <= band_rows; ++k) remaining += class_size[(size_t)class_list_a[k]];
+      const long s_lo = (long)band * S;
+      long band_steps_now = S;
+      if (remaining + piece_min + 2 < band_rows) {  // the last band: only as many windows as the remaining rows need
+        band_steps_now = ((remaining + piece_min + 2) * row_b + win - 1) / win;
+        band_steps_now = std::min<long>(S, std::max<long>(4, (band_steps_now + 3) / 4 * 4));
+      }
+      const long s_hi = s_lo + band_steps_now;
+      const long r_lo = (s_lo * win + row_b - 1) / row_b, r_hi = (s_hi * win + row_b - 1) / row_b;
+      // key = X (< 2^20 … 2^22) | step | row-in-band: sorting the keys orders the band's rows by (X, step)
+      keys.resize((size_t)(r_hi - r_lo));
+      for (size_t i = 0; i < keys.size(); ++i) {
+        const long r = r_lo + (long)i, start = r * row_b;
+        keys[i] = ((uint64_t)(start % win) << 42) | ((uint64_t)(start / win) << 21) | (uint64_t)i;
+      }
+      std::sort(keys.begin(), keys.end());
+      pieces.clear();
+      size_t pos = 0;  // next free position of the sorted order
+      const size_t cap = keys.size();
+      while (pos < cap && ci < class_list_a.size()) {
+        const size_t room = cap - pos;
+        if (room < (size_t)piece_min) break;  // the rest of the band stays unused
+        size_t take = std::min<size_t>((size_t)left, room);
+        if ((size_t)left > take && (size_t)left - take < (size_t)piece_min) {
+          // the remainder would be too narrow in the next band: leave it piece_min rows
+          if (take < (size_t)piece_min + (size_t)piece_min) break;
+          take = (size_t)left - (size_t)piece_min;
+        }
+        const int c = class_list_a[ci];
+        const uint64_t k0 = keys[pos];
+        pieces.push_back({(int32_t)(k0 >> 42), (int32_t)((k0 >> 21) & 0x1fffff), (int32_t)ci});
+        for (size_t i = 0; i < take; ++i) {
+          const long r = r_lo + (long)(keys[pos + i] & 0x1fffff);
+          const int p = members[(size_t)(class_off[(size_t)c] + taken + (int32_t)i)];
+          e->h_pod_row[(size_t)p] = (int32_t)r;
+        }
+        pos += take;
+        taken += (int32_t)take;
+        left -= (int32_t)take;
+        if (left == 0) {
+          ++ci;
+          taken = 0;
+          if (ci < class_list_a.size()) left = class_size[(size_t)class_list_a[ci]];
+        }
+      }
+      // what every workgroup needs during this band
+      for (int b = 0; b < ykk::kBandGroups && ok; ++b) {
+        ykk::BandEntry be{};
+        for (int i = 0; i < KC; ++i) be.slot[i] = pieces.empty() ? 0 : pieces[0].slot;
+        for (int i = 0; i < KC - 1; ++i) {
+          be.xb[i] = 0x7fffffff;
+          be.sb[i] = 0;
+        }
+        const long x_lo = std::max<long>(0, (long)b * 4096 - row_b + 1), x_hi = (long)(b + 1) * 4096;  // rows starting in [x_lo, x_hi) meet the tile
+        // first piece: the last one whose first key is not after (x_lo, first step)
+        size_t ia = 0;
+        for (size_t i = 0; i < pieces.size(); ++i)
+          if ((long)pieces[i].x < x_lo) ia = i;
+        if (!pieces.empty()) be.slot[0] = pieces[ia].slot;
+        int n = 1;
+        for (size_t i = ia + 1; i < pieces.size() && (long)pieces[i].x < x_hi; ++i) {
+          if (n >= KC) {
+            ok = false;
+            break;
+          }
+          be.slot[n] = pieces[i].slot;
+          be.xb[n - 1] = pieces[i].x;
+          be.sb[n - 1] = pieces[i].s;
+          ++n;
+        }
+        for (int i = n; i < KC; ++i) be.slot[i] = be.slot[n - 1];
+        be.steps = (int32_t)band_steps_now;
+        be.first_step = (int32_t)s_lo;
+        band_tab.push_back(be);
+      }
+      ++band;
+      n_steps = (int)s_hi;
+      rows_a = (int)r_hi;
+      if (band_steps_now < S) break;  // a shorter band is the last one
+    }
+    if (ci < class_list_a.size()) ok = false;  // (a shortened last band that turned out too small)
+    if (!ok) {
+      // fall back: everything in zone B
+      class_list_a.clear();
+      std::fill(e->h_class_slot_a.begin(), e->h_class_slot_a.end(), -1);
+      std::fill(e->h_pod_row.begin(), e->h_pod_row.end(), -1);
+      band_tab.clear();
+      n_steps = n_bands = rows_a = 0;
+    } else {
+      n_bands = band;
+      // the rows that straddle a window boundary: the band kernel writes only the part of a row that lies in the window it
+      // starts in — one row per window is finished by k_fix_rows
+      std::vector<int32_t> row_slot((size_t)rows_a, -1);
+      for (int c : class_list_a)
+        for (int i = class_off[(size_t)c]; i < class_off[(size_t)c + 1]; ++i) row_slot[(size_t)e->h_pod_row[(size_t)members[(size_t)i]]] = e->h_class_slot_a[(size_t)c];
+      for (long s1 = 1; s1 <= n_steps; ++s1) {
+        const long r = (s1 * win - 1) / row_b;  // the row that holds the last byte before the boundary
+        if (r * row_b + row_b > s1 * win && r < rows_a && row_slot[(size_t)r] >= 0) {
+          fix_row.push_back((int32_t)r);
+          fix_slot.push_back(row_slot[(size_t)r]);
+        }
+      }
+    }
+  }
+  // zone B: the remaining classes, class by class after zone A
+  int next_row = rows_a;
+  for (int c = 0; c < C; ++c) {
+    if (e->h_class_slot_a[(size_t)c] >= 0) continue;
+    for (int i = class_off[(size_t)c]; i < class_off[(size_t)c + 1]; ++i) e->h_pod_row[(size_t)members[(size_t)i]] = next_row++;
+  }
+  e->rows_total = next_row;
+  e->rows_a = rows_a;
+  e->n_bands = n_bands;
+  e->n_band_steps = n_steps;
+  e->n_classes_a = (int)class_list_a.size();
+  e->n_fix_rows = (int)fix_row.size();
+  if (e->row_capacity && e->rows_total > e->row_capacity)
+    return fail(e, YKPRED_E_INVALID, "the bitmap needs more rows than ykpred_set_row_capacity allows");
+  // Chunks of <= chunk_members members of one class with their explicit row lists. The full pass runs them for zone B only
+  // (zone A is written by the band kernel); the incremental "dirty classes" pass runs them for any class.
   const int cm = e->chunk_members;
   struct Chunk {
-    int32_t cls, begin, len, first, first_pod;
+    int32_t cls, begin, len, first, first_row;
   };
   std::vector<Chunk> chunks;
   for (int c = 0; c < C; ++c)
     for (int b = class_off[(size_t)c]; b < class_off[(size_t)c + 1]; b += cm)
-      chunks.push_back({c, b, std::min(cm, class_off[(size_t)c + 1] - b), b == class_off[(size_t)c] ? 1 : 0, members[(size_t)b]});
+      chunks.push_back({c, b, std::min(cm, class_off[(size_t)c + 1] - b), b == class_off[(size_t)c] ? 1 : 0, e->h_pod_row[(size_t)members[(size_t)b]]});
   if (e->chunk_sorted)
-    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return x.first_pod < y.first_pod; });
+    std::stable_sort(chunks.begin(), chunks.end(), [](const Chunk& x, const Chunk& y) { return x.first_row < y.first_row; });
   auto &ch_class = e->h_ch_class, &ch_begin = e->h_ch_begin, &ch_len = e->h_ch_len, &ch_first = e->h_ch_first;
   ch_class.clear();
   ch_begin.clear();
   ch_len.clear();
   ch_first.clear();
+  e->h_ch_zone.clear();
   e->h_class_chunks.assign((size_t)C, {});
   for (const Chunk& k : chunks) {
     e->h_class_chunks[(size_t)k.cls].push_back((int32_t)ch_class.size());
@@ -375,9 +551,12 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     ch_begin.push_back(k.begin);
     ch_len.push_back(k.len);
     ch_first.push_back(k.first);
+    e->h_ch_zone.push_back(e->h_class_slot_a[(size_t)k.cls] >= 0 ? 1 : 0);
   }
   e->h_class_first.assign((size_t)C, -1);
   for (int c = 0; c < C; ++c) e->h_class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
+  std::vector<int32_t> member_rows((size_t)P);
+  for (int i = 0; i < P; ++i) member_rows[(size_t)i] = e->h_pod_row[(size_t)members[(size_t)i]];
   e->h_row_stale.assign((size_t)P, 0);
   e->C = C;
   e->NC = (int)ch_class.size();
@@ -386,7 +565,15 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   TRY(upload(e, e->d_class_sig, class_sig.data(), class_sig.size(), st));
   TRY(upload(e, e->d_class_pin, class_pin.data(), class_pin.size(), st));
   TRY(upload(e, e->d_class_first, e->h_class_first.data(), e->h_class_first.size(), st));
-  TRY(upload(e, e->d_members, members.data(), members.size(), st));
+  TRY(upload(e, e->d_members, member_rows.data(), member_rows.size(), st));
+  TRY(upload(e, e->d_pod_row, e->h_pod_row.data(), e->h_pod_row.size(), st));
+  TRY(upload(e, e->d_chunk_zone, e->h_ch_zone.data(), e->h_ch_zone.size(), st));
+  TRY(upload(e, e->d_band_tab, band_tab.data(), band_tab.size(), st));
+  TRY(upload(e, e->d_class_list_a, class_list_a.data(), class_list_a.size(), st));
+  TRY(upload(e, e->d_class_slot_a, e->h_class_slot_a.data(), e->h_class_slot_a.size(), st));
+  TRY(upload(e, e->d_fix_row, fix_row.data(), fix_row.size(), st));
+  TRY(upload(e, e->d_fix_slot, fix_slot.data(), fix_slot.size(), st));
+  HIPCHK(e->d_class_rows_a.ensure((size_t)std::max<size_t>(class_list_a.size(), 1) * (size_t)e->row_stride * sizeof(u64)));
   TRY(upload(e, e->d_chunk_class, ch_class.data(), ch_class.size(), st));
   TRY(upload(e, e->d_chunk_begin, ch_begin.data(), ch_begin.size(), st));
   TRY(upload(e, e->d_chunk_len, ch_len.data(), ch_len.size(), st));
@@ -500,7 +687,7 @@ struct Timer {
 int grow_owned_outputs(ykpred_engine* e) {
   const size_t P = (size_t)std::max(e->P, 1);
   if (e->last_bitmap && e->last_bitmap == e->d_bitmap.p) {
-    HIPCHK(e->d_bitmap.reserve_keep(P * (size_t)e->row_stride * sizeof(u64), e->d_bitmap.cap));
+    HIPCHK(e->d_bitmap.reserve_keep((size_t)std::max(std::max(e->rows_total, e->row_capacity), 1) * (size_t)e->row_stride * sizeof(u64), e->d_bitmap.cap));
     e->last_bitmap = e->d_bitmap.p;
   }
   if (e->last_counts && e->last_counts == e->d_counts.p) {
@@ -709,6 +896,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (cfg->reserved[4] > 0) e->walk_rows = cfg->reserved[4];
   if (cfg->reserved[5] > 0) e->wave_combine_below = cfg->reserved[5];
   if (cfg->reserved[5] < 0) e->wave_combine_below = 0;
+  if (cfg->reserved[6] < 0) e->bands_enabled = false;
+  if (cfg->reserved[6] > 0) e->band_steps = (cfg->reserved[6] + 3) / 4 * 4;
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -737,7 +926,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   (void)hipDeviceSynchronize();
   if (e->comm) (void)rccl()->CommDestroy(e->comm);
   e->comm = nullptr;
-  for (DevBuf* b : {&e->d_gathered, &e->d_xkey, &e->d_xcand}) b->release();
+  for (DevBuf* b : {&e->d_gathered, &e->d_gathered_map, &e->d_xkey, &e->d_xcand}) b->release();
   for (auto& g : e->graphs) (void)hipGraphExecDestroy(g.second);
   e->graphs.clear();
   for (DevBuf* b : {&e->d_alloc, &e->d_req, &e->d_allowed, &e->d_count, &e->d_nflags, &e->d_taints, &e->d_labels, &e->d_domain, &e->d_selcount, &e->d_ports, &e->d_sig_ports, &e->d_swanted,
@@ -750,6 +939,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_sfree_r, &e->d_pmask_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
+                    &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
                     &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
                     &e->d_member_key, &e->d_name_rank, &e->d_member_tie})
     b->release();
@@ -1161,7 +1351,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool pts_en = spread_filt && spread_pre, ipa_en = ipa_filt && ipa_pre;
   const bool spread_on = (pts_en || ipa_en) && e->fam_spread.D > 0;  // the topology-constraint family (spread + inter-pod affinity)
   const int N = e->N, P = e->P;
-  const size_t bitmap_bytes = (size_t)std::max(P, 1) * (size_t)e->row_stride * sizeof(u64);
+  const size_t bitmap_bytes = (size_t)std::max(std::max(e->rows_total, e->row_capacity), 1) * (size_t)e->row_stride * sizeof(u64);
   u64* bitmap = (u64*)a->bitmap;
   if (!bitmap) {
     HIPCHK(e->d_bitmap.ensure(bitmap_bytes));
@@ -1207,8 +1397,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     ykk::SpecTable stbl = spec_table(e);
     dim3 grid((unsigned)((P + ykk::kWave - 1) / ykk::kWave), (unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
     tm.begin(st);
-    hipLaunchKernelGGL(ykk::k_direct, grid, dim3(ykk::kBlock), 0, st, nt, stbl, P, e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre,
-                       filt, bitmap, e->row_words, e->row_stride);
+    hipLaunchKernelGGL(ykk::k_direct, grid, dim3(ykk::kBlock), 0, st, nt, stbl, P, e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(),
+                       e->d_pod_row.as<int>(), pre, filt, bitmap, e->row_words, e->row_stride);
     tm.end(st, "k_direct");
     HIPCHK(hipGetLastError());
     return 1;
@@ -1231,7 +1421,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   ykk::PlaneOut o_aff{canon_of(e->fam_aff), ranked_of(e->fam_aff), e->row_stride, e->fam_aff.D};
   ykk::PlaneOut o_spread{canon_of(e->fam_spread), ranked_of(e->fam_spread), e->row_stride, e->fam_spread.D};
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>()};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R};
   ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
@@ -1392,6 +1582,24 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pc, bitmap, e->row_words, e->row_stride,
                          pin_on, e->d_class_count.as<int>(), tpg, class_dirty);
     };
+    if (!dirty_only && e->n_classes_a > 0) {
+      // zone A: class rows → table (and the classes' feasible counts), then the fill-pattern expansion over the band layout
+      tm.begin(st);
+      hipLaunchKernelGGL(ykk::k_class_rows, dim3((unsigned)((e->n_classes_a + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
+                         ct, pc, e->d_class_list_a.as<int>(), e->n_classes_a, e->row_words, e->row_stride, pin_on, e->d_class_rows_a.as<u64>(),
+                         e->d_class_count.as<int>(), (const int*)nullptr);
+      tm.end(st, "k_class_rows");
+      const size_t lds_bytes = (size_t)2 * ykk::kBandClasses * (size_t)e->row_stride * sizeof(u64);
+      if (lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_expand_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      tm.begin(st);
+      hipLaunchKernelGGL(ykk::k_expand_bands, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBlock), lds_bytes, st, bitmap, e->d_class_rows_a.as<u64>(),
+                         e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
+      if (e->n_fix_rows > 0)
+        hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, bitmap, e->d_class_rows_a.as<u64>(),
+                           e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
+      tm.end(st, "k_expand_bands");
+    }
     tm.begin(st);
     if ((long)e->NC * e->wave_combine_below > (long)P) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
@@ -1548,12 +1756,12 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
       cg.first[cg.n_groups] = filled;
       tm.begin(st);
       hipLaunchKernelGGL(ykk::k_column_class, dim3((unsigned)((e->C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, nt, stbl, cg,
-                         e->C, e->d_class_first.as<int>(), e->d_class_pin.as<int>(), e->d_pod_spec.as<int>(), pre, filt, bitmap, e->row_stride,
-                         e->d_class_word.as<u64>(), e->d_class_count.as<int>());
+                         e->C, e->d_class_first.as<int>(), e->d_class_pin.as<int>(), e->d_pod_spec.as<int>(), e->d_pod_row.as<int>(), pre, filt, bitmap,
+                         e->row_stride, e->d_class_word.as<u64>(), e->d_class_count.as<int>());
       tm.end(st, "k_column_class");
       tm.begin(st);
       hipLaunchKernelGGL(ykk::k_column_patch, dim3((unsigned)((e->P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, cg, e->P,
-                         e->d_pod_class.as<int>(), e->d_class_word.as<u64>(), e->d_class_count.as<int>(), bitmap, e->row_stride,
+                         e->d_pod_class.as<int>(), e->d_pod_row.as<int>(), e->d_class_word.as<u64>(), e->d_class_count.as<int>(), bitmap, e->row_stride,
                          want_cnt ? (int*)(a->counts ? a->counts : e->last_counts) : nullptr);
       tm.end(st, "k_column_patch");
     }
@@ -1621,7 +1829,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     return YKPRED_OK;
   }
 
-  enum { T_POD_SPEC, T_POD_PIN, T_POD_CLASS, T_MEMBERS, T_CH_CLASS, T_CH_BEGIN, T_CH_LEN, T_CH_FIRST, T_CLASS_SIG, T_CLASS_PIN, T_CLASS_FIRST };
+  enum { T_POD_SPEC, T_POD_PIN, T_POD_CLASS, T_MEMBERS, T_CH_CLASS, T_CH_BEGIN, T_CH_LEN, T_CH_FIRST, T_CLASS_SIG, T_CLASS_PIN, T_CLASS_FIRST, T_POD_ROW, T_CH_ZONE };
   std::vector<ykk::TablePatch> patches;
   auto put = [&](int table, int index, int value) { patches.push_back({table, index, value, 0}); };
   std::vector<int32_t> orphaned;  // classes whose representative row left
@@ -1642,6 +1850,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
   e->h_pod_pin.resize((size_t)newP);
   e->h_pod_class.resize((size_t)newP);
   e->h_pod_slot.resize((size_t)newP);
+  e->h_pod_row.resize((size_t)newP, -1);
   const int cm = e->chunk_members;
   for (int i = 0; i < count; ++i) {
     const int p = rows[i], sp = spec_index[i], pin = node_name_index[i];
@@ -1659,6 +1868,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
       e->h_class_pin.push_back(pin);
       e->h_class_first.push_back(-1);
       e->h_class_live.push_back(0);
+      e->h_class_slot_a.push_back(-1);
       e->h_class_chunks.emplace_back();
       put(T_CLASS_SIG, c * 4 + 0, k.a);
       put(T_CLASS_SIG, c * 4 + 1, k.b);
@@ -1668,9 +1878,14 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     } else {
       c = it->second;
     }
+    // a row of its own at the end of the bitmap: the row it had may lie inside another class's band interval (zone A), and
+    // rows are never reused between two class builds
+    const int row = e->rows_total++;
+    e->h_pod_row[(size_t)p] = row;
+    put(T_POD_ROW, p, row);
     const int slot = (int)e->h_members.size();
     e->h_members.push_back(p);
-    put(T_MEMBERS, slot, p);
+    put(T_MEMBERS, slot, row);
     auto& cc = e->h_class_chunks[(size_t)c];
     const int tail = cc.empty() ? -1 : cc.back();
     if (tail >= 0 && e->h_ch_begin[(size_t)tail] + e->h_ch_len[(size_t)tail] == slot && e->h_ch_len[(size_t)tail] < cm) {
@@ -1682,6 +1897,8 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
       e->h_ch_begin.push_back(slot);
       e->h_ch_len.push_back(1);
       e->h_ch_first.push_back(cc.empty() ? 1 : 0);  // the first chunk of a class adds the class's feasible count
+      e->h_ch_zone.push_back(0);                     // appended rows lie behind both zones: the chunk kernel writes them
+      put(T_CH_ZONE, ch, 0);
       put(T_CH_CLASS, ch, c);
       put(T_CH_BEGIN, ch, slot);
       put(T_CH_LEN, ch, 1);
@@ -1728,6 +1945,10 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     put(T_CLASS_FIRST, c, want);
   }
   e->P = newP;
+  if (e->row_capacity && e->rows_total > e->row_capacity) {
+    e->classes_dirty = true;  // (the next full pass re-packs the rows)
+    return fail(e, YKPRED_E_INVALID, "update_pods: the bitmap needs more rows than ykpred_set_row_capacity allows");
+  }
   TRY(grow_owned_outputs(e));
 
   // device side: grow what has to grow (contents kept), then apply every change with one copy + one launch
@@ -1735,8 +1956,10 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
   HIPCHK(e->d_pod_spec.reserve_keep((size_t)newP * I, (size_t)oldP * I));
   HIPCHK(e->d_pod_pin.reserve_keep((size_t)newP * I, (size_t)oldP * I));
   HIPCHK(e->d_pod_class.reserve_keep((size_t)newP * I, (size_t)oldP * I));
+  HIPCHK(e->d_pod_row.reserve_keep((size_t)newP * I, (size_t)oldP * I));
   HIPCHK(e->d_members.reserve_keep(e->h_members.size() * I, e->h_members.size() * I));
-  for (DevBuf* b : {&e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first}) HIPCHK(b->reserve_keep((size_t)e->NC * I, (size_t)e->NC * I));
+  for (DevBuf* b : {&e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first, &e->d_chunk_zone})
+    HIPCHK(b->reserve_keep((size_t)e->NC * I, (size_t)e->NC * I));
   HIPCHK(e->d_class_sig.reserve_keep((size_t)e->C * 4 * I, (size_t)e->C * 4 * I));
   for (DevBuf* b : {&e->d_class_pin, &e->d_class_first, &e->d_class_count, &e->d_class_best}) HIPCHK(b->reserve_keep((size_t)e->C * I, (size_t)e->C * I));
   if (!patches.empty()) {
@@ -1766,6 +1989,8 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     tp.t[T_CLASS_SIG] = e->d_class_sig.as<int>();
     tp.t[T_CLASS_PIN] = e->d_class_pin.as<int>();
     tp.t[T_CLASS_FIRST] = e->d_class_first.as<int>();
+    tp.t[T_POD_ROW] = e->d_pod_row.as<int>();
+    tp.t[T_CH_ZONE] = e->d_chunk_zone.as<int>();
     TRY(upload(e, e->d_patches, patches.data(), patches.size(), st));
     hipLaunchKernelGGL(ykk::k_apply_patches, dim3((unsigned)((patches.size() + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, tp,
                        (int)patches.size(), e->d_patches.as<ykk::TablePatch>());
@@ -1773,7 +1998,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     HIPCHK(hipStreamSynchronize(st));  // `patches` is pageable host memory
   }
   // many small chunks make k_combine re-read planes for little output: rebuild the classes at the next full evaluation
-  if (e->patch_chunks > std::max(4096, (e->NC - e->patch_chunks) / 4)) e->classes_dirty = true;
+  if (e->patch_chunks > std::max(4096, (e->NC - e->patch_chunks) / 4) || e->rows_total > newP + std::max(8192, newP / 4)) e->classes_dirty = true;
   return YKPRED_OK;
 }
 
@@ -1810,7 +2035,7 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_
     const unsigned wgroups = (unsigned)((e->row_stride + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock);
     tm.begin(st);
     hipLaunchKernelGGL(ykk::k_rows, dim3((unsigned)num_rows, wgroups), dim3(ykk::kBlock), 0, st, nt, stbl, num_rows, e->d_rows.as<int>(),
-                       e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), pre, filt, bitmap, e->row_words, e->row_stride,
+                       e->d_pod_spec.as<int>(), e->d_pod_pin.as<int>(), e->d_pod_row.as<int>(), pre, filt, bitmap, e->row_words, e->row_stride,
                        want_dec ? e->d_rank.as<int>() : nullptr, e->d_row_count.as<int>(), e->d_row_best.as<int>());
     tm.end(st, "k_rows");
     tm.begin(st);
@@ -1849,7 +2074,9 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->row_stride = e->row_stride;
   o->num_chunks = e->NC;
   o->plane_rows = e->fam_res.D + e->fam_tol.D + e->fam_aff.D + e->fam_spread.D;
-  o->bitmap_bytes = (uint64_t)e->P * (uint64_t)e->row_stride * sizeof(u64);
+  o->num_rows = std::max(e->rows_total, e->row_capacity);
+  o->row_of_pod = e->d_pod_row.p;
+  o->bitmap_bytes = (uint64_t)std::max(o->num_rows, 1) * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
   o->counts = e->last_counts ? e->last_counts : e->d_counts.p;
   o->decisions = e->last_decisions ? e->last_decisions : e->d_decisions.p;
@@ -1885,10 +2112,19 @@ int32_t ykpred_read_bitmap(ykpred_engine_t* e, int32_t first, int32_t num, uint6
   if (!e->last_bitmap) return fail(e, YKPRED_E_STATE, "read_bitmap: no eval yet");
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
-  if (num == 0) return YKPRED_OK;
-  const u64* src = (const u64*)e->last_bitmap + (size_t)first * e->row_stride;
-  HIPCHK(hipMemcpy2D(out, (size_t)e->row_words * sizeof(u64), src, (size_t)e->row_stride * sizeof(u64), (size_t)e->row_words * sizeof(u64),
-                     (size_t)num, hipMemcpyDeviceToHost));
+  if (num == 0 || e->row_words == 0) return YKPRED_OK;
+  // rows are addressed through row_of_pod: gather them densely on the device (in slabs), then copy
+  const size_t row_bytes = (size_t)e->row_words * sizeof(u64);
+  const int slab = (int)std::max<size_t>(1, std::min<size_t>((size_t)num, ((size_t)1 << 30) / row_bytes));
+  HIPCHK(e->d_scratch.ensure((size_t)slab * row_bytes));
+  for (int done = 0; done < num; done += slab) {
+    const int n = std::min(slab, num - done);
+    hipLaunchKernelGGL(ykk::k_gather_rows, dim3((unsigned)n), dim3(ykk::kBlock), 0, e->own_stream, (const u64*)e->last_bitmap, n, (const int*)nullptr,
+                       first + done, e->d_pod_row.as<int>(), e->row_words, e->row_stride, e->d_scratch.as<u64>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->own_stream));
+    HIPCHK(hipMemcpy((char*)out + (size_t)done * row_bytes, e->d_scratch.p, (size_t)n * row_bytes, hipMemcpyDeviceToHost));
+  }
   return YKPRED_OK;
 }
 
@@ -1933,7 +2169,7 @@ int32_t ykpred_bitmap_checksum(ykpred_engine_t* e, uint64_t* out) {
   HIPCHK(hipMemsetAsync(e->d_scratch.p, 0, sizeof(u64), e->own_stream));
   if (e->P && e->row_words)
     hipLaunchKernelGGL(ykk::k_checksum, dim3(2048), dim3(ykk::kBlock), 0, e->own_stream, (const u64*)e->last_bitmap, e->P, e->row_words,
-                       e->row_stride, e->d_scratch.as<u64>());
+                       e->row_stride, e->d_pod_row.as<int>(), e->d_scratch.as<u64>());
   HIPCHK(hipStreamSynchronize(e->own_stream));
   HIPCHK(hipMemcpy(out, e->d_scratch.p, sizeof(u64), hipMemcpyDeviceToHost));
   return YKPRED_OK;
@@ -1965,11 +2201,19 @@ int32_t ykpred_read_rows(ykpred_engine_t* e, int32_t n, const int32_t* pods, uin
   HIPCHK(e->d_scratch.ensure(idx_bytes + out_bytes));
   char* base = (char*)e->d_scratch.p;
   HIPCHK(hipMemcpyAsync(base, pods, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(ykk::k_gather_rows, dim3((unsigned)n), dim3(ykk::kBlock), 0, st, (const u64*)e->last_bitmap, n, (const int*)base, e->row_words,
-                     e->row_stride, (u64*)(base + idx_bytes));
+  hipLaunchKernelGGL(ykk::k_gather_rows, dim3((unsigned)n), dim3(ykk::kBlock), 0, st, (const u64*)e->last_bitmap, n, (const int*)base, 0,
+                     e->d_pod_row.as<int>(), e->row_words, e->row_stride, (u64*)(base + idx_bytes));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, base + idx_bytes, out_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+int32_t ykpred_read_row_map(ykpred_engine_t* e, int32_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out) return YKPRED_E_INVALID;
+  if (e->classes_dirty || (int)e->h_pod_row.size() < e->P) return fail(e, YKPRED_E_STATE, "read_row_map: no current class build (run ykpred_eval)");
+  std::copy(e->h_pod_row.begin(), e->h_pod_row.begin() + e->P, out);
   return YKPRED_OK;
 }
 
@@ -1992,7 +2236,7 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words) {
   HIPCHK(hipMemsetAsync(e->d_scratch.p, 0, sizeof(u64), e->own_stream));
   if (e->P && e->row_stride)
     hipLaunchKernelGGL(ykk::k_check_class_rows, dim3(4096), dim3(ykk::kBlock), 0, e->own_stream, (const u64*)e->last_bitmap, e->P, e->row_words,
-                       e->row_stride, e->d_pod_class.as<int>(), e->d_class_first.as<int>(), e->d_scratch.as<u64>());
+                       e->row_stride, e->d_pod_class.as<int>(), e->d_class_first.as<int>(), e->d_pod_row.as<int>(), e->d_scratch.as<u64>());
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->own_stream));
   HIPCHK(hipMemcpy(bad_words, e->d_scratch.p, sizeof(u64), hipMemcpyDeviceToHost));
@@ -2177,6 +2421,15 @@ int32_t ykpred_comm_destroy(ykpred_engine_t* e) {
   return YKPRED_OK;
 }
 
+int32_t ykpred_set_row_capacity(ykpred_engine_t* e, int32_t rows) {
+  YK_SERIALISE(e);
+  if (!e || rows < 0) return fail(e, YKPRED_E_INVALID, "set_row_capacity: bad argument");
+  if (rows && e->rows_total > rows) return fail(e, YKPRED_E_INVALID, "set_row_capacity: the bitmap already uses more rows");
+  if (rows != e->row_capacity) e->last_eval_valid = false;  // the bitmap buffer changes size
+  e->row_capacity = rows;
+  return YKPRED_OK;
+}
+
 int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words) {
   YK_SERIALISE(e);
   if (!e || words < 0 || words % 16 != 0) return fail(e, YKPRED_E_INVALID, "set_row_stride: need a multiple of 16 words (0 = automatic)");
@@ -2193,12 +2446,18 @@ int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered, void* stream) {
   if (!e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "gather_bitmap: no current evaluation");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
-  const size_t words = (size_t)e->P * (size_t)e->row_stride;
+  if (e->comm_world > 1 && e->row_capacity == 0)
+    return fail(e, YKPRED_E_STATE, "gather_bitmap: the shards must agree on a row capacity first (ykpred_set_row_capacity)");
+  const size_t rows = (size_t)std::max(std::max(e->rows_total, e->row_capacity), 1);
+  const size_t words = rows * (size_t)e->row_stride;
   if (!gathered) {
-    HIPCHK(e->d_gathered.ensure(std::max<size_t>(words, 1) * (size_t)e->comm_world * sizeof(u64)));
+    HIPCHK(e->d_gathered.ensure(words * (size_t)e->comm_world * sizeof(u64)));
     gathered = e->d_gathered.p;
   }
-  if (words) NCCLCHK(rccl()->AllGather(e->last_bitmap, gathered, words, ncclUint64, e->comm, st));
+  NCCLCHK(rccl()->AllGather(e->last_bitmap, gathered, words, ncclUint64, e->comm, st));
+  // every shard lays its rows out for its own writer: the row_of_pod maps travel with the bitmaps
+  HIPCHK(e->d_gathered_map.ensure((size_t)std::max(e->P, 1) * (size_t)e->comm_world * sizeof(int)));
+  if (e->P) NCCLCHK(rccl()->AllGather(e->d_pod_row.p, e->d_gathered_map.p, (size_t)e->P, ncclInt32, e->comm, st));
   return YKPRED_OK;
 }
 
@@ -2235,8 +2494,15 @@ int32_t ykpred_read_gathered(ykpred_engine_t* e, int32_t shard, int32_t first, i
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
   if (num == 0) return YKPRED_OK;
-  const u64* src = e->d_gathered.as<u64>() + ((size_t)shard * (size_t)e->P + (size_t)first) * (size_t)e->row_stride;
-  HIPCHK(hipMemcpy(out, src, (size_t)num * (size_t)e->row_stride * sizeof(u64), hipMemcpyDeviceToHost));
+  const size_t rows = (size_t)std::max(std::max(e->rows_total, e->row_capacity), 1);
+  const u64* shard_bitmap = e->d_gathered.as<u64>() + (size_t)shard * rows * (size_t)e->row_stride;
+  const int* shard_map = e->d_gathered_map.as<int>() + (size_t)shard * (size_t)e->P;
+  HIPCHK(e->d_scratch.ensure((size_t)num * (size_t)e->row_stride * sizeof(u64)));
+  hipLaunchKernelGGL(ykk::k_gather_rows, dim3((unsigned)num), dim3(ykk::kBlock), 0, e->own_stream, shard_bitmap, num, (const int*)nullptr, first, shard_map,
+                     e->row_stride, e->row_stride, e->d_scratch.as<u64>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->own_stream));
+  HIPCHK(hipMemcpy(out, e->d_scratch.p, (size_t)num * (size_t)e->row_stride * sizeof(u64), hipMemcpyDeviceToHost));
   return YKPRED_OK;
 }
 

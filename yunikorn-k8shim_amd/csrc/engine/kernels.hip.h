@@ -751,7 +751,8 @@ struct ClassTable {
   const int* chunk_begin;  // [NC] offset into members
   const int* chunk_len;    // [NC] 1..kChunkMembers
   const int* chunk_first;  // [NC] 1 = first chunk of its class (owns the popcount)
-  const int* members;      // [P] pod ids grouped by class
+  const int* members;      // chunk row lists: PHYSICAL bitmap rows (ykpred_layout_t.row_of_pod), -1 = unused entry
+  const int* chunk_zone;   // [NC] 1 = the chunk's class lives in zone A (the full pass writes it with k_expand_bands)
 };
 struct Planes {
   const u64* res;         // value planes of NodeResourcesFit (row 0 = pod-independent part); null = family disabled
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   pin_enabled &= 1;
   const int chunk = blockIdx.x;
   const int cls = ct.chunk_class[chunk];
-  if (class_dirty && !class_dirty[cls]) return;  // incremental pass: only classes whose topology signature changed
+  if (class_dirty ? !class_dirty[cls] : ct.chunk_zone[chunk] != 0) return;  // full pass: zone B only; incremental pass: the dirty classes
   const int begin = ct.chunk_begin[chunk];
   const int len = ct.chunk_len[chunk];
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
@@ -852,11 +853,11 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
     for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
     if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
   }
-  // member ids: lane i of every wave holds member i (one coalesced 256 B load), broadcast by v_readlane
+  // member rows: lane i of every wave holds the bitmap row of member i (one coalesced 256 B load), broadcast by v_readlane
   int mine = lane < len ? ct.members[begin + lane] : 0;
   for (int i = group; i < len; i += groups) {  // `group` is wave-uniform: tpg is a multiple of the wave size
     int p = __builtin_amdgcn_readlane(mine, i);
-    if (p < 0) continue;  // slot vacated by ykpred_update_pods (wave-uniform)
+    if (p < 0) continue;  // unused entry (wave-uniform)
     u64* row = bitmap + (size_t)p * row_stride;
 #pragma unroll
     for (int u = 0; u < kCombineUnroll; ++u) {
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
   if (chunk >= n_chunks) return;
   const int lane = threadIdx.x % kWave;
   const int cls = ct.chunk_class[chunk];
-  if (class_dirty && !class_dirty[cls]) return;
+  if (class_dirty ? !class_dirty[cls] : ct.chunk_zone[chunk] != 0) return;
   const int begin = ct.chunk_begin[chunk], len = ct.chunk_len[chunk];
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const int pin = pin_enabled ? ct.pin[cls] : -1;
@@ -935,6 +936,153 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
     for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
     if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// zone A of the bitmap: written with the store pattern of a linear fill (scripts/fill_probe*.hip)
+// ---------------------------------------------------------------------------------------------------
+// Measured on MI355X: of all ways to write the 6.27 GB bitmap only ONE reaches the hipMemset rate (6.4 TB/s against 5.4 for
+// anything row-shaped): 256 (or 128) workgroups, each storing one 4 KiB-aligned tile per step, all tiles of a step forming
+// one contiguous 1 MiB window that advances. k_expand_bands writes exactly that pattern and sources the data from LDS:
+//   * the physical rows are permuted (row_of_pod) so that inside a band of S windows a class owns the rows whose start
+//     offset inside their window, X = (row * row_bytes) mod window, lies in one interval (engine.hip: build_classes);
+//   * workgroup b always writes window bytes [4096 b, 4096 b + 4096), so for the S steps of a band it needs the rows of at
+//     most kBandClasses classes: they sit in LDS; the next band's rows are fetched into registers mid-band and committed
+//     to the second LDS buffer at the band boundary, so the steady state issues no global load at all;
+//   * per step and thread: the column of its 16 bytes inside their row advances by (window mod row_bytes); the row started
+//     in this window iff col <= p (p = the thread's offset in the window) and then X = p - col; X against the band's class
+//     boundaries selects the LDS row; one ds_read_b128, one global_store_dwordx4.
+// The head of every window belongs to a row that started in the previous window: k_fix_rows rewrites those rows (one per
+// window) whole. Class rows come from k_class_rows (AND of the class's planes, popcount = the class's feasible count).
+constexpr int kBandGroups = 256;   // workgroups = 4 KiB tiles per window (power of two: the HBM channel interleave)
+constexpr int kBandClasses = 4;    // class rows a workgroup can hold per band
+constexpr int kBandFetch = 4;      // 16-byte pieces of a class row per thread when (pre)fetching: row_stride <= 2048 words
+constexpr int kBandMaxLds = 150 * 1024;
+struct BandEntry {  // what one workgroup needs during one band
+  int slot[kBandClasses];    // class-row table slots, in X order (unused entries repeat the last one)
+  int xb[kBandClasses - 1];  // first row of class i + 1: its X ...
+  int sb[kBandClasses - 1];  // ... and step; INT_MAX X = no further class
+  int steps, first_step;     // height of the band, its first window
+};
+
+// one wave per zone-A class: class row = AND of its planes (+ NodeName pin), written to the class-row table
+__global__ __launch_bounds__(kBlock) void k_class_rows(ClassTable ct, Planes pl, const int* __restrict__ class_list, int n_list, int row_words,
+                                                       int row_stride, int pin_enabled, u64* __restrict__ row_table,
+                                                       int* __restrict__ class_count, const int* __restrict__ class_dirty) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const bool all_fail = pin_enabled & 2;
+  pin_enabled &= 1;
+  const int k = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (k >= n_list) return;
+  const int cls = class_list[k];
+  if (class_dirty && !class_dirty[cls]) return;
+  const int lane = threadIdx.x % kWave;
+  const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
+  const int pin = pin_enabled ? ct.pin[cls] : -1;
+  const ClassRows cr = class_rows(pl, sr, st, sa, ss);
+  u64* dst = row_table + (size_t)k * row_stride;
+  int pc = 0;
+  for (int w = 2 * lane; w < row_stride; w += 2 * kWave) {
+    u64x2 x = {0, 0};
+    if (w < row_words && pin != -2 && !all_fail) {
+      x = u64x2{~0ull, ~0ull};
+#pragma unroll
+      for (int i = 0; i < kMaxClassRows; ++i)
+        if (i < cr.n) x &= *(const u64x2*)(cr.row[i] + w);
+      if (w + 1 >= row_words) x.y = 0;
+      if (pin >= 0) {
+        x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+        x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+      }
+    }
+    pc += __popcll(x.x) + __popcll(x.y);
+    *(u64x2*)(dst + w) = x;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
+  if (lane == 0) class_count[cls] = pc;
+}
+
+// grid = kBandGroups workgroups of 256 threads; dynamic LDS = 2 * kBandClasses * row_stride * 8 bytes
+__global__ __launch_bounds__(kBlock) void k_expand_bands(u64* __restrict__ out, const u64* __restrict__ class_rows, const BandEntry* __restrict__ tab,
+                                                         int n_bands, int row_stride) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ u64 band_lds[];  // [2][kBandClasses][row_stride]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int row_b = row_stride * 8;
+  constexpr long kWin = (long)kBandGroups * 4096;
+  const int dcol = (int)(kWin % row_b);
+  const int p = b * 4096 + tid * 16;
+  int col = p % row_b;  // step 0
+  char* wr = (char*)out + p;
+  u64x2 nx[kBandClasses][kBandFetch];
+  auto fetch = [&](const BandEntry& be) {
+#pragma unroll
+    for (int c = 0; c < kBandClasses; ++c)
+#pragma unroll
+      for (int i = 0; i < kBandFetch; ++i) {
+        const int word = (i * kBlock + tid) * 2;
+        nx[c][i] = word < row_stride ? *(const u64x2*)(class_rows + (size_t)be.slot[c] * row_stride + word) : u64x2{0, 0};
+      }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < kBandClasses; ++c)
+#pragma unroll
+      for (int i = 0; i < kBandFetch; ++i) {
+        const int word = (i * kBlock + tid) * 2;
+        if (word < row_stride) *(u64x2*)(band_lds + ((size_t)(buf * kBandClasses + c) * row_stride + word)) = nx[c][i];
+      }
+  };
+  BandEntry cur = tab[(size_t)0 * kBandGroups + b];
+  fetch(cur);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int band = 0; band < n_bands; ++band) {
+    const int s0 = cur.first_step, s1 = s0 + cur.steps;
+    BandEntry nxt = cur;
+    const u64* lds = band_lds + (size_t)buf * kBandClasses * row_stride;
+    for (int s = s0; s < s1; s += 4) {
+      if (s == s0 + (cur.steps / 8) * 4 && band + 1 < n_bands) {  // mid-band: the next band's rows land while this one finishes
+        nxt = tab[(size_t)(band + 1) * kBandGroups + b];
+        fetch(nxt);
+      }
+      u64x2 v[4];
+      bool live[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int x = p - col;  // start of the row inside this window (negative: it started in the previous one)
+        live[u] = x >= 0;
+        int idx = 0;
+#pragma unroll
+        for (int i = 0; i < kBandClasses - 1; ++i) idx += (x > cur.xb[i] || (x == cur.xb[i] && s + u >= cur.sb[i])) ? 1 : 0;
+        v[u] = *(const u64x2*)(lds + (size_t)idx * row_stride + (col >> 3));
+        col += dcol;
+        col -= col >= row_b ? row_b : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (live[u]) *(u64x2*)wr = v[u];
+        wr += kWin;
+      }
+    }
+    if (band + 1 < n_bands) {
+      commit(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+      cur = nxt;
+    }
+  }
+}
+// one block per row that straddles a window boundary: the whole row from its class row
+__global__ __launch_bounds__(kBlock) void k_fix_rows(u64* __restrict__ out, const u64* __restrict__ class_rows, const int* __restrict__ rows,
+                                                     const int* __restrict__ slots, int n, int row_stride) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  if ((int)blockIdx.x >= n) return;
+  const u64* src = class_rows + (size_t)slots[blockIdx.x] * row_stride;
+  u64* dst = out + (size_t)rows[blockIdx.x] * row_stride;
+  for (int w = threadIdx.x * 2; w < row_stride; w += 2 * kBlock) *(u64x2*)(dst + w) = *(const u64x2*)(src + w);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1183,8 +1331,8 @@ __global__ __launch_bounds__(kBlock) void k_query_pod(NodeTable t, SpecTable s, 
 // Per-pair grid: blockIdx.x = chunk of 64 pods (the unbounded axis), blockIdx.y = group of 4 node words. lane = node, the wave walks the
 // 64 pods of its chunk (pod data wave-uniform), ballot → lane (i) keeps pod i's word → 64 row stores.
 __global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int n_pods, const int* __restrict__ pod_spec,
-                                                   const int* __restrict__ pod_pin, unsigned pre_mask, unsigned filt_mask,
-                                                   u64* __restrict__ bitmap, int row_words, int row_stride) {
+                                                   const int* __restrict__ pod_pin, const int* __restrict__ pod_row, unsigned pre_mask,
+                                                   unsigned filt_mask, u64* __restrict__ bitmap, int row_words, int row_stride) {
   int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   int w = blockIdx.y * kWavesPerBlock + wave;
   if (w >= row_stride) return;
@@ -1203,7 +1351,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int
     if (p - p0 == lane) keep = b;
   }
   int p = p0 + lane;
-  if (p < n_pods) bitmap[(size_t)p * row_stride + w] = (w < row_words) ? keep : 0ull;
+  if (p < n_pods) bitmap[(size_t)pod_row[p] * row_stride + w] = (w < row_words) ? keep : 0ull;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1221,9 +1369,9 @@ constexpr int kMaxColGroups = 64;
 // feasible count moves by the popcount difference.
 __global__ __launch_bounds__(kBlock) void k_column_class(NodeTable t, SpecTable s, ColumnGroups cg, int n_classes,
                                                          const int* __restrict__ class_first, const int* __restrict__ class_pin,
-                                                         const int* __restrict__ pod_spec, unsigned pre_mask, unsigned filt_mask,
-                                                         const u64* __restrict__ bitmap, int row_stride, u64* __restrict__ class_word,
-                                                         int* __restrict__ class_count) {
+                                                         const int* __restrict__ pod_spec, const int* __restrict__ pod_row, unsigned pre_mask,
+                                                         unsigned filt_mask, const u64* __restrict__ bitmap, int row_stride,
+                                                         u64* __restrict__ class_word, int* __restrict__ class_count) {
   int c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= n_classes) return;
   const int p0 = class_first[c];
@@ -1232,7 +1380,7 @@ __global__ __launch_bounds__(kBlock) void k_column_class(NodeTable t, SpecTable 
   const int pin = (filt_mask & kPlugNodeName) ? class_pin[c] : -1;
   int delta = 0;
   for (int g = 0; g < cg.n_groups; ++g) {
-    const u64 old = bitmap[(size_t)p0 * row_stride + cg.word[g]];
+    const u64 old = bitmap[(size_t)pod_row[p0] * row_stride + cg.word[g]];
     u64 neu = old;
     for (int i = cg.first[g]; i < cg.first[g + 1]; ++i) {
       const int n = cg.nodes[i];
@@ -1251,12 +1399,14 @@ __global__ __launch_bounds__(kBlock) void k_column_class(NodeTable t, SpecTable 
 }
 // thread = pod: store the class's new words into the pod's row, refresh its count
 __global__ __launch_bounds__(kBlock) void k_column_patch(ColumnGroups cg, int n_pods, const int* __restrict__ pod_class,
-                                                         const u64* __restrict__ class_word, const int* __restrict__ class_count,
-                                                         u64* __restrict__ bitmap, int row_stride, int* __restrict__ counts) {
+                                                         const int* __restrict__ pod_row, const u64* __restrict__ class_word,
+                                                         const int* __restrict__ class_count, u64* __restrict__ bitmap, int row_stride,
+                                                         int* __restrict__ counts) {
   int p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= n_pods) return;
   const int c = pod_class[p];
-  for (int g = 0; g < cg.n_groups; ++g) bitmap[(size_t)p * row_stride + cg.word[g]] = class_word[(size_t)c * kMaxColGroups + g];
+  const size_t row = (size_t)pod_row[p] * row_stride;
+  for (int g = 0; g < cg.n_groups; ++g) bitmap[row + cg.word[g]] = class_word[(size_t)c * kMaxColGroups + g];
   if (counts) counts[p] = class_count[c];
 }
 
@@ -1267,7 +1417,7 @@ __global__ __launch_bounds__(kBlock) void k_column_patch(ColumnGroups cg, int n_
 struct TablePatch {
   int table, index, value, pad;
 };
-constexpr int kPatchTables = 12;
+constexpr int kPatchTables = 14;
 constexpr int kNoRank = 0x7f7f7f7f;  // row_best is initialised with memset(0x7f); ranks are < 2^24
 struct TablePtrs {
   int* t[kPatchTables];
@@ -1283,8 +1433,9 @@ __global__ __launch_bounds__(kBlock) void k_apply_patches(TablePtrs tp, int n, c
 // with the per-pair routine (same as k_direct), its popcount and the smallest bin-pack rank among its feasible nodes
 // are accumulated in row_count / row_best (zeroed / set to kNoRank by the caller).
 __global__ __launch_bounds__(kBlock) void k_rows(NodeTable t, SpecTable s, int n_rows, const int* __restrict__ rows,
-                                                 const int* __restrict__ pod_spec, const int* __restrict__ pod_pin, unsigned pre_mask,
-                                                 unsigned filt_mask, u64* __restrict__ bitmap, int row_words, int row_stride,
+                                                 const int* __restrict__ pod_spec, const int* __restrict__ pod_pin,
+                                                 const int* __restrict__ pod_row, unsigned pre_mask, unsigned filt_mask,
+                                                 u64* __restrict__ bitmap, int row_words, int row_stride,
                                                  const int* __restrict__ rank /* null: no decisions */, int* __restrict__ row_count,
                                                  int* __restrict__ row_best) {
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
@@ -1303,7 +1454,7 @@ __global__ __launch_bounds__(kBlock) void k_rows(NodeTable t, SpecTable s, int n
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_down(best, off, kWave));
   if (lane == 0) {
-    bitmap[(size_t)p * row_stride + w] = (w < row_words) ? b : 0ull;
+    bitmap[(size_t)pod_row[p] * row_stride + w] = (w < row_words) ? b : 0ull;
     if (b) {
       atomicAdd(&row_count[blockIdx.x], __popcll(b));
       if (rank) atomicMin(&row_best[blockIdx.x], best);
@@ -1378,12 +1529,12 @@ __device__ __forceinline__ u64 mix64(u64 z) {
   return z ^ (z >> 31);
 }
 __global__ __launch_bounds__(kBlock) void k_checksum(const u64* __restrict__ bitmap, int n_pods, int row_words, int row_stride,
-                                                     u64* __restrict__ out) {
+                                                     const int* __restrict__ pod_row, u64* __restrict__ out) {
   size_t total = (size_t)n_pods * row_words;
   u64 acc = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
     size_t p = i / row_words, w = i % row_words;
-    u64 x = bitmap[p * row_stride + w];
+    u64 x = bitmap[(size_t)pod_row[p] * row_stride + w];
     acc += mix64(x ^ ((i + 1) * 0x9e3779b97f4a7c15ull));
   }
 #pragma unroll
@@ -1413,28 +1564,29 @@ __global__ __launch_bounds__(kBlock) void k_decision_finalize(int n_pods, const 
 // counts the offending words; (b) gather of listed rows into a dense [n][row_words] buffer for readback.
 __global__ __launch_bounds__(kBlock) void k_check_class_rows(const u64* __restrict__ bitmap, int n_pods, int row_words, int row_stride,
                                                              const int* __restrict__ pod_class, const int* __restrict__ class_first,
-                                                             u64* __restrict__ bad) {
+                                                             const int* __restrict__ pod_row, u64* __restrict__ bad) {
   const size_t total = (size_t)n_pods * row_stride;
   u64 acc = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
     const size_t p = i / row_stride, w = i % row_stride;
-    const u64 x = bitmap[i];
+    const u64 x = bitmap[(size_t)pod_row[p] * row_stride + w];
     if (w >= (size_t)row_words) {
       acc += x != 0;
     } else {
       const int rep = class_first[pod_class[p]];
-      acc += rep < 0 || x != bitmap[(size_t)rep * row_stride + w];
+      acc += rep < 0 || x != bitmap[(size_t)pod_row[rep] * row_stride + w];
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
   if (threadIdx.x % kWave == 0 && acc) atomicAdd(bad, acc);
 }
-__global__ __launch_bounds__(kBlock) void k_gather_rows(const u64* __restrict__ bitmap, int n, const int* __restrict__ rows, int row_words,
-                                                        int row_stride, u64* __restrict__ out) {
+// pods == null: pods first, first + 1, ...
+__global__ __launch_bounds__(kBlock) void k_gather_rows(const u64* __restrict__ bitmap, int n, const int* __restrict__ pods, int first,
+                                                        const int* __restrict__ pod_row, int row_words, int row_stride, u64* __restrict__ out) {
   const int i = blockIdx.x;
   if (i >= n) return;
-  const u64* src = bitmap + (size_t)rows[i] * row_stride;
+  const u64* src = bitmap + (size_t)pod_row[pods ? pods[i] : first + i] * row_stride;
   for (int w = threadIdx.x; w < row_words; w += kBlock) out[(size_t)i * row_words + w] = src[w];
 }
 

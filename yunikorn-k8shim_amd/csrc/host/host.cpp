@@ -107,6 +107,7 @@ struct ykhost {
   uint32_t last_eval_options = 0;
   bool dump_compact = false;                 // ykhost_set_dump_compact
   int row_stride_words = 0;                  // ykhost_set_row_stride: bitmap row stride shared by the shards of a cluster
+  int row_capacity = 0;                      // ykhost_set_row_capacity: bitmap rows shared by the shards of a cluster
   bool comm_attached = false;                // ykhost_comm_init: the engine carries an RCCL communicator
   std::vector<PodTemplate*> spec_templates;  // spec id → template
   int64_t last_encode_us = 0;
@@ -447,6 +448,9 @@ int full_sync(ykhost* h) {
   if (rc) return rc;
   rc = ykpred_set_row_stride(h->eng, h->row_stride_words);
   if (rc) return fail(h, std::string("ykpred_set_row_stride: ") + ykpred_last_error(h->eng), rc);
+  rc = ykpred_set_row_capacity(h->eng, 0);  // (re-applied below: a smaller table may follow a larger one)
+  if (rc == YKPRED_OK) rc = ykpred_set_row_capacity(h->eng, h->row_capacity);
+  if (rc) return fail(h, std::string("ykpred_set_row_capacity: ") + ykpred_last_error(h->eng), rc);
   rc = ykpred_set_nodes(h->eng, &T.nt);
   if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
   rc = ykpred_set_specs(h->eng, &T.sp);
@@ -1469,6 +1473,14 @@ int32_t ykhost_set_row_stride(ykhost_t* h, int32_t words) {
   if (words < 0 || words % 16 != 0) return fail(h, "row stride must be a multiple of 16 words (0 = automatic)");
   if (words != h->row_stride_words) h->dirty_all = true;
   h->row_stride_words = words;
+  return 0;
+}
+
+int32_t ykhost_set_row_capacity(ykhost_t* h, int32_t rows) {
+  YKHOST_LOCKED(h);
+  if (rows < 0) return fail(h, "row capacity must be >= 0 (0 = automatic)");
+  if (rows != h->row_capacity) h->dirty_all = true;
+  h->row_capacity = rows;
   return 0;
 }
 

@@ -339,6 +339,15 @@ class GpuPredicateManager:
     def set_row_stride(self, words):
         self._check(self._L.ykhost_set_row_stride(self._h, words))
 
+    def set_row_capacity(self, rows):
+        self._check(self._L.ykhost_set_row_capacity(self._h, rows))
+
+    def row_map(self):
+        """row_of_pod on the host: the physical bitmap row of every pending ask (rows are laid out for the writer)."""
+        out = np.zeros(self.layout().num_pods, dtype=np.int32)
+        self._pcheck(self._P.ykpred_read_row_map(self.engine, out.ctypes.data))
+        return out
+
     def comm_init(self, unique_id, rank, world, node_offset):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self._L.ykhost_comm_init(self._h, buf, rank, world, node_offset))

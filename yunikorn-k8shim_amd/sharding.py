@@ -42,6 +42,12 @@ def common_row_stride(ranges):
     return max(row_stride_words(count) for _, count in ranges)
 
 
+def common_row_capacity(num_pods):
+    """Physical bitmap rows every shard allocates: the asks plus room for the writer's layout (band padding, rows appended by
+    ask-table patches). Identical on every shard so that the gathered layout [G][rows][row_stride] is regular."""
+    return num_pods + num_pods // 64 + 16384
+
+
 def attach_communicator(pm, dist, rank, world, node_offset):
     """Rank 0 draws the RCCL unique id through the C ABI, the bootstrap group broadcasts it, every rank attaches."""
     box = [pm.comm_unique_id() if rank == 0 else None]
@@ -78,7 +84,7 @@ def ref_exchange_spread_histograms(counts, present, dist):
 
 
 def ref_gather_bitmap(local, dist):
-    """all_gather of [P][row_stride] int64 shard bitmaps into [G][P][row_stride] (same layout as ykpred_gather_bitmap)."""
+    """all_gather of [rows][row_stride] int64 shard bitmaps into [G][rows][row_stride] (same layout as ykpred_gather_bitmap)."""
     world = dist.get_world_size()
     out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
