@@ -120,6 +120,11 @@ def cpu_baseline(pm, budget_s, seed):
     return out
 
 
+def node_row_bytes(pm):
+    st = pm.stats()
+    return 8 * 2 * st["R"] + 4 + 4 + 4 + 8 * st["KT"] + 8 * st["W"]
+
+
 def algorithmic_bytes(pm, lay):
     """ALGORITHMIC bytes of one pass over the local table: the bitmap written once, the node table, the
     per-ask ids, the class table and the signature planes read once."""
@@ -138,15 +143,29 @@ def profile_kernels(pm, run_step, n):
     return {k: float(np.mean(v)) for k, v in kern.items()}
 
 
-def roofline_of(kern, algo_bytes, ms_per_step, traffic=None):
-    """The kernel with the largest average duration + the whole step, both against the HBM peak."""
+BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_direct")
+
+
+def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0):
+    """The kernel with the largest average duration + the whole step, both against the HBM peak.
+
+    `achieved` prices the kernel with ITS algorithmic bytes: a bitmap writer is charged the whole step's bytes (it writes
+    the bitmap; the other inputs are < 0.1 % of that on the headline workload); the plane kernels are charged the planes they
+    write plus the node table they read; kernels without a byte model here (the decision pass reads class rows out of L2 and
+    is bound by the ordered scan, not by HBM) report achieved / frac = null — `whole_step_frac` always stands."""
     if not kern:
         return None
     dom = max(kern, key=kern.get)
-    achieved = algo_bytes / (kern[dom] * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),
-            "algorithmic_bytes": int(algo_bytes),
+    base = dom.split("(")[0]
+    own = None
+    if base in BITMAP_WRITERS:
+        own = algo_bytes
+    elif lay is not None and base in ("k_sig_planes", "k_base_planes", "k_planes", "k_dim_walk"):
+        own = lay.plane_rows * lay.row_words * 8 + lay.num_nodes * b_node
+    achieved = own / (kern[dom] * 1e-3) / 1e9 if own else None
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1) if own else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4) if own else None, "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),
+            "algorithmic_bytes": int(own) if own else None, "step_algorithmic_bytes": int(algo_bytes),
             "whole_step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
@@ -183,7 +202,7 @@ def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
         algo = algorithmic_bytes(pm, lay)
         out.update({"ms_per_step": round(ms, 4), "evals_per_sec": float(P) * lay.num_nodes / (ms * 1e-3), "pod_classes": lay.num_classes,
                     "signature_planes": lay.plane_rows, "distinct_evals_per_step": lay.num_classes * lay.num_nodes,
-                    "roofline": roofline_of(kern, algo, ms), "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+                    "roofline": roofline_of(kern, algo, ms, lay=lay, b_node=node_row_bytes(pm)), "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
                     "cold_pass": {"encode_upload_ms": round(t_sync * 1e3, 1), "class_build_and_first_eval_ms": round((t_cold - t_sync) * 1e3, 1),
                                   "total_ms": round(t_cold * 1e3, 1), "encode_ms": round(pm.stats()["encode_us"] / 1e3, 1)}})
     finally:
@@ -336,7 +355,7 @@ def main():
         tj = json.load(open(tpath))
         if tj.get("pods") == P and tj.get("nodes") == N and tj.get("kernel") == (max(kern, key=kern.get) if kern else None):
             traffic = tj.get("hbm_bytes_per_launch")
-    roof = roofline_of(kern, algo_bytes, ms_per_step, traffic)
+    roof = roofline_of(kern, algo_bytes, ms_per_step, traffic, lay=lay, b_node=node_row_bytes(pm))
 
     gather = None
     if do_gather:

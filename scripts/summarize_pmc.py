@@ -33,10 +33,13 @@ out["write_calibration"] = {"kernel": "fill_linear (writes exactly 6 272 000 000
                             "expected_KiB": expected_kib, "ratio": fill_w["fill_linear"]["avg_KiB"] / expected_kib}
 out["bench_WRITE_SIZE"] = per_kernel("bench", "WRITE_SIZE")
 out["bench_FETCH_SIZE"] = per_kernel("bench", "FETCH_SIZE")
-key = [k for k in out["bench_WRITE_SIZE"] if "k_combine" in k and "wave" not in k][0]
+# the dominant kernel of the step = the one that writes the bitmap (largest WRITE_SIZE among the engine's kernels)
+engine_kernels = {k: v for k, v in out["bench_WRITE_SIZE"].items() if "ykk::" in k or k.startswith("k_")}
+key = max(engine_kernels, key=lambda k: engine_kernels[k]["avg_KiB"])
+short = key.split("::")[-1].split("<")[0]
 w = out["bench_WRITE_SIZE"][key]["avg_KiB"] * 1024 / out["write_calibration"]["ratio"]
 f_raw = out["bench_FETCH_SIZE"][key]["avg_KiB"] * 1024
-traffic = {"round": rnd, "kernel": "k_combine", "pods": 1_000_000, "nodes": 50_000,
+traffic = {"round": rnd, "kernel": short, "pods": 1_000_000, "nodes": 50_000,
            "write_bytes_per_launch": int(w), "fetch_bytes_per_launch_raw": int(f_raw),
            "fetch_bytes_per_launch_corrected_x2": int(2 * f_raw),
            "hbm_bytes_per_launch": int(w + 2 * f_raw),

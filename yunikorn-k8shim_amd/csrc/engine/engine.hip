@@ -479,6 +479,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
           ++n;
         }
         for (int i = n; i < KC; ++i) be.slot[i] = be.slot[n - 1];
+        be.n = n;
         be.steps = (int32_t)band_steps_now;
         be.first_step = (int32_t)s_lo;
         band_tab.push_back(be);
@@ -1590,11 +1591,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          e->d_class_count.as<int>(), (const int*)nullptr);
       tm.end(st, "k_class_rows");
       const size_t lds_bytes = (size_t)2 * ykk::kBandClasses * (size_t)e->row_stride * sizeof(u64);
-      if (lds_bytes > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_expand_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      auto launch_bands = [&](auto kern) -> int {
+        if (lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBlock), lds_bytes, st, bitmap, e->d_class_rows_a.as<u64>(),
+                           e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
+        return YKPRED_OK;
+      };
       tm.begin(st);
-      hipLaunchKernelGGL(ykk::k_expand_bands, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBlock), lds_bytes, st, bitmap, e->d_class_rows_a.as<u64>(),
-                         e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
+      TRY(launch_bands(ykk::k_expand_bands<4, true>));  // unroll 4, predicated stores: the other flavours measured within box noise
       if (e->n_fix_rows > 0)
         hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, bitmap, e->d_class_rows_a.as<u64>(),
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);

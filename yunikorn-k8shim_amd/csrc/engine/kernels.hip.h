@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ykk {
 
 typedef unsigned long long u64;
@@ -963,6 +965,7 @@ struct BandEntry {  // what one workgroup needs during one band
   int xb[kBandClasses - 1];  // first row of class i + 1: its X ...
   int sb[kBandClasses - 1];  // ... and step; INT_MAX X = no further class
   int steps, first_step;     // height of the band, its first window
+  int n, pad;                // classes this workgroup really needs (1..kBandClasses): selects the loop variant
 };
 
 // one wave per zone-A class: class row = AND of its planes (+ NodeName pin), written to the class-row table
@@ -1004,6 +1007,7 @@ __global__ __launch_bounds__(kBlock) void k_class_rows(ClassTable ct, Planes pl,
 }
 
 // grid = kBandGroups workgroups of 256 threads; dynamic LDS = 2 * kBandClasses * row_stride * 8 bytes
+template <int KU, bool PRED>
 __global__ __launch_bounds__(kBlock) void k_expand_bands(u64* __restrict__ out, const u64* __restrict__ class_rows, const BandEntry* __restrict__ tab,
                                                          int n_bands, int row_stride) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -1039,34 +1043,59 @@ __global__ __launch_bounds__(kBlock) void k_expand_bands(u64* __restrict__ out, 
   commit(0);
   __syncthreads();
   int buf = 0;
+  const unsigned urow_b = (unsigned)row_b;
+  unsigned ucol = (unsigned)col;
   for (int band = 0; band < n_bands; ++band) {
     const int s0 = cur.first_step, s1 = s0 + cur.steps;
     BandEntry nxt = cur;
-    const u64* lds = band_lds + (size_t)buf * kBandClasses * row_stride;
-    for (int s = s0; s < s1; s += 4) {
-      if (s == s0 + (cur.steps / 8) * 4 && band + 1 < n_bands) {  // mid-band: the next band's rows land while this one finishes
-        nxt = tab[(size_t)(band + 1) * kBandGroups + b];
-        fetch(nxt);
-      }
-      u64x2 v[4];
-      bool live[4];
+    const char* lds = (const char*)(band_lds + (size_t)buf * kBandClasses * row_stride);
+    // class boundaries as ONE comparable number: (X << 8) | step-in-band — a row belongs to class i + 1.. iff its key >= kb[i]
+    unsigned kb[kBandClasses - 1];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int x = p - col;  // start of the row inside this window (negative: it started in the previous one)
-        live[u] = x >= 0;
-        int idx = 0;
+    for (int i = 0; i < kBandClasses - 1; ++i)
+      kb[i] = cur.xb[i] == 0x7fffffff ? 0xffffffffu : (((unsigned)cur.xb[i] << 8) | (unsigned)(cur.sb[i] - s0));
+    char* win_base = (char*)out + (long)s0 * kWin;  // wave-uniform: the stores use it as scalar base + the thread's p
+    // One loop body per number of classes the workgroup has to tell apart in this band: every VALU instruction of the step
+    // costs ~1.5 % of the kernel (it runs at the issue rate of 4 waves per CU), and more than half of the (workgroup, band)
+    // pairs see a single class — no compare at all — most of the rest two.
+    auto run_band = [&](auto ncls_tag) {
+      constexpr int kN = decltype(ncls_tag)::value;
+      constexpr int kU = KU;
+      for (int s = s0; s < s1; s += kU) {
+        if (s == s0 + (cur.steps / 8) * 4 && band + 1 < n_bands) {  // mid-band: the next band's rows land while this one finishes
+          nxt = tab[(size_t)(band + 1) * kBandGroups + b];
+          fetch(nxt);
+        }
+        u64x2 v[kU];
+        bool live[kU];
 #pragma unroll
-        for (int i = 0; i < kBandClasses - 1; ++i) idx += (x > cur.xb[i] || (x == cur.xb[i] && s + u >= cur.sb[i])) ? 1 : 0;
-        v[u] = *(const u64x2*)(lds + (size_t)idx * row_stride + (col >> 3));
-        col += dcol;
-        col -= col >= row_b ? row_b : 0;
-      }
+        for (int u = 0; u < kU; ++u) {
+          unsigned off = ucol;  // LDS byte offset: class index * row bytes + column
+          live[u] = !PRED || p >= (int)ucol;
+          if (kN > 1) {
+            // x = p - col: start of the row inside this window. Negative = the row started in the previous window: whatever is
+            // stored there is overwritten by k_fix_rows, which runs after this kernel and rewrites those rows whole.
+            const unsigned key = ((unsigned)(p - (int)ucol) << 8) | (unsigned)(s + u - s0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (live[u]) *(u64x2*)wr = v[u];
-        wr += kWin;
+            for (int i = 0; i < kN - 1; ++i) off += key >= kb[i] ? urow_b : 0u;
+          }
+          v[u] = *(const u64x2*)(lds + off);
+          const unsigned t = ucol + (unsigned)dcol;
+          ucol = min(t, t - urow_b);  // t < row_b: t - row_b wraps to a huge value
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (live[u]) *(u64x2*)(win_base + p) = v[u];  // (PRED = false: unconditional, like the linear fill)
+          win_base += kWin;
+        }
       }
-    }
+    };
+    if (cur.n <= 1)
+      run_band(std::integral_constant<int, 1>{});
+    else if (cur.n == 2)
+      run_band(std::integral_constant<int, 2>{});
+    else
+      run_band(std::integral_constant<int, kBandClasses>{});
     if (band + 1 < n_bands) {
       commit(buf ^ 1);
       __syncthreads();
