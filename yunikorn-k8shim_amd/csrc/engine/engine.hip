@@ -378,8 +378,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   std::vector<ykk::BandEntry> band_tab;
   std::vector<int32_t> class_list_a, fix_row, fix_slot;
   int n_steps = 0, n_bands = 0, rows_a = 0;
-  const bool geometry_ok = e->bands_enabled && e->N > 0 && (size_t)2 * KC * (size_t)row_b <= (size_t)ykk::kBandMaxLds &&
-                           e->row_stride <= ykk::kBandFetch * 512;
+  const bool geometry_ok = e->bands_enabled && e->N > 0 && (size_t)2 * KC * (size_t)row_b <= (size_t)ykk::kBandMaxLds;
   if (geometry_ok) {
     long rows_needed = 0;
     for (int c = 0; c < C; ++c)
@@ -1591,14 +1590,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          e->d_class_count.as<int>(), (const int*)nullptr);
       tm.end(st, "k_class_rows");
       const size_t lds_bytes = (size_t)2 * ykk::kBandClasses * (size_t)e->row_stride * sizeof(u64);
-      auto launch_bands = [&](auto kern) -> int {
-        if (lds_bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(kern, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBlock), lds_bytes, st, bitmap, e->d_class_rows_a.as<u64>(),
-                           e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
-        return YKPRED_OK;
-      };
+      if (lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_expand_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       tm.begin(st);
-      TRY(launch_bands(ykk::k_expand_bands<4, true>));  // unroll 4, predicated stores: the other flavours measured within box noise
+      hipLaunchKernelGGL(ykk::k_expand_bands, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBandBlock), lds_bytes, st, bitmap,
+                         e->d_class_rows_a.as<u64>(), e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
       if (e->n_fix_rows > 0)
         hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, bitmap, e->d_class_rows_a.as<u64>(),
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);

@@ -958,7 +958,6 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
 // window) whole. Class rows come from k_class_rows (AND of the class's planes, popcount = the class's feasible count).
 constexpr int kBandGroups = 256;   // workgroups = 4 KiB tiles per window (power of two: the HBM channel interleave)
 constexpr int kBandClasses = 4;    // class rows a workgroup can hold per band
-constexpr int kBandFetch = 4;      // 16-byte pieces of a class row per thread when (pre)fetching: row_stride <= 2048 words
 constexpr int kBandMaxLds = 150 * 1024;
 struct BandEntry {  // what one workgroup needs during one band
   int slot[kBandClasses];    // class-row table slots, in X order (unused entries repeat the last one)
@@ -1006,86 +1005,89 @@ __global__ __launch_bounds__(kBlock) void k_class_rows(ClassTable ct, Planes pl,
   if (lane == 0) class_count[cls] = pc;
 }
 
-// grid = kBandGroups workgroups of 256 threads; dynamic LDS = 2 * kBandClasses * row_stride * 8 bytes
-template <int KU, bool PRED>
-__global__ __launch_bounds__(kBlock) void k_expand_bands(u64* __restrict__ out, const u64* __restrict__ class_rows, const BandEntry* __restrict__ tab,
-                                                         int n_bands, int row_stride) {
+// grid = kBandGroups workgroups of kBandBlock = 256 + 64 threads; dynamic LDS = 2 * kBandClasses * row_stride * 8 bytes.
+// Waves 0-3 are the STORE waves: thread t of workgroup b owns bytes [4096 b + 16 t, +16) of every window, reads its 16 bytes
+// of the right class row from LDS and stores them; they never load from global memory, so their vmcnt is never waited on
+// (gfx9 counts loads and stores in ONE in-order counter: a wave that both prefetches class rows and streams stores has to
+// drain its whole store queue before it can use the prefetch). Wave 4 is the LOADER: during band k it copies the class rows
+// of band k + 1 into the other LDS buffer. One s_barrier per band joins them.
+constexpr int kBandBlock = kBlock + kWave;
+__global__ __launch_bounds__(kBandBlock) void k_expand_bands(u64* __restrict__ out, const u64* __restrict__ class_rows,
+                                                             const BandEntry* __restrict__ tab, int n_bands, int row_stride) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   extern __shared__ u64 band_lds[];  // [2][kBandClasses][row_stride]
   const int b = blockIdx.x, tid = threadIdx.x;
   const int row_b = row_stride * 8;
   constexpr long kWin = (long)kBandGroups * 4096;
-  const int dcol = (int)(kWin % row_b);
-  const int p = b * 4096 + tid * 16;
-  int col = p % row_b;  // step 0
-  char* wr = (char*)out + p;
-  u64x2 nx[kBandClasses][kBandFetch];
-  auto fetch = [&](const BandEntry& be) {
+  if (tid >= kBlock) {  // ---- loader wave
+    const int lane = tid - kBlock;
+    const int pieces = row_stride / 2;  // 16-byte pieces per row
+    auto load_rows = [&](int band) {
+      const BandEntry be = tab[(size_t)band * kBandGroups + b];
 #pragma unroll
-    for (int c = 0; c < kBandClasses; ++c)
+      for (int c = 0; c < kBandClasses; ++c) {
+        if (c >= be.n && c > 0) break;
+        const u64x2* src = (const u64x2*)(class_rows + (size_t)be.slot[c] * row_stride);
+        u64x2* dst = (u64x2*)(band_lds + (size_t)((band & 1) * kBandClasses + c) * row_stride);
+        for (int i0 = 0; i0 < pieces; i0 += 4 * kWave) {
+          u64x2 r[4];
 #pragma unroll
-      for (int i = 0; i < kBandFetch; ++i) {
-        const int word = (i * kBlock + tid) * 2;
-        nx[c][i] = word < row_stride ? *(const u64x2*)(class_rows + (size_t)be.slot[c] * row_stride + word) : u64x2{0, 0};
+          for (int k = 0; k < 4; ++k)
+            if (i0 + k * kWave + lane < pieces) r[k] = src[i0 + k * kWave + lane];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (i0 + k * kWave + lane < pieces) dst[i0 + k * kWave + lane] = r[k];
+        }
       }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int c = 0; c < kBandClasses; ++c)
-#pragma unroll
-      for (int i = 0; i < kBandFetch; ++i) {
-        const int word = (i * kBlock + tid) * 2;
-        if (word < row_stride) *(u64x2*)(band_lds + ((size_t)(buf * kBandClasses + c) * row_stride + word)) = nx[c][i];
-      }
-  };
-  BandEntry cur = tab[(size_t)0 * kBandGroups + b];
-  fetch(cur);
-  commit(0);
+    };
+    load_rows(0);
+    __syncthreads();
+    for (int band = 0; band < n_bands; ++band) {
+      if (band + 1 < n_bands) load_rows(band + 1);
+      __syncthreads();
+    }
+    return;
+  }
+  // ---- store waves
   __syncthreads();
-  int buf = 0;
+  const int p = b * 4096 + tid * 16;
   const unsigned urow_b = (unsigned)row_b;
-  unsigned ucol = (unsigned)col;
+  const unsigned dcol = (unsigned)(kWin % row_b);  // column advance per step
+  unsigned ucol = (unsigned)(p % row_b);           // column (byte) of the thread's 16 bytes in their row, step 0
   for (int band = 0; band < n_bands; ++band) {
+    const BandEntry cur = tab[(size_t)band * kBandGroups + b];
     const int s0 = cur.first_step, s1 = s0 + cur.steps;
-    BandEntry nxt = cur;
-    const char* lds = (const char*)(band_lds + (size_t)buf * kBandClasses * row_stride);
+    const char* lds = (const char*)(band_lds + (size_t)(band & 1) * kBandClasses * row_stride);
     // class boundaries as ONE comparable number: (X << 8) | step-in-band — a row belongs to class i + 1.. iff its key >= kb[i]
     unsigned kb[kBandClasses - 1];
 #pragma unroll
     for (int i = 0; i < kBandClasses - 1; ++i)
       kb[i] = cur.xb[i] == 0x7fffffff ? 0xffffffffu : (((unsigned)cur.xb[i] << 8) | (unsigned)(cur.sb[i] - s0));
-    char* win_base = (char*)out + (long)s0 * kWin;  // wave-uniform: the stores use it as scalar base + the thread's p
-    // One loop body per number of classes the workgroup has to tell apart in this band: every VALU instruction of the step
-    // costs ~1.5 % of the kernel (it runs at the issue rate of 4 waves per CU), and more than half of the (workgroup, band)
-    // pairs see a single class — no compare at all — most of the rest two.
+    char* win_base = (char*)out + (long)s0 * kWin;
+    // One loop body per number of classes the workgroup has to tell apart in this band: more than half of the (workgroup,
+    // band) pairs see a single class — no compare at all — most of the rest two.
     auto run_band = [&](auto ncls_tag) {
       constexpr int kN = decltype(ncls_tag)::value;
-      constexpr int kU = KU;
+      constexpr int kU = 4;
       for (int s = s0; s < s1; s += kU) {
-        if (s == s0 + (cur.steps / 8) * 4 && band + 1 < n_bands) {  // mid-band: the next band's rows land while this one finishes
-          nxt = tab[(size_t)(band + 1) * kBandGroups + b];
-          fetch(nxt);
-        }
         u64x2 v[kU];
         bool live[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          unsigned off = ucol;  // LDS byte offset: class index * row bytes + column
-          live[u] = !PRED || p >= (int)ucol;
+          unsigned off = ucol;       // LDS byte offset: class index * row bytes + column
+          live[u] = p >= (int)ucol;  // x = p - col >= 0: the row started in this window (else k_fix_rows writes it whole)
           if (kN > 1) {
-            // x = p - col: start of the row inside this window. Negative = the row started in the previous window: whatever is
-            // stored there is overwritten by k_fix_rows, which runs after this kernel and rewrites those rows whole.
             const unsigned key = ((unsigned)(p - (int)ucol) << 8) | (unsigned)(s + u - s0);
 #pragma unroll
             for (int i = 0; i < kN - 1; ++i) off += key >= kb[i] ? urow_b : 0u;
           }
           v[u] = *(const u64x2*)(lds + off);
-          const unsigned t = ucol + (unsigned)dcol;
+          const unsigned t = ucol + dcol;
           ucol = min(t, t - urow_b);  // t < row_b: t - row_b wraps to a huge value
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          if (live[u]) *(u64x2*)(win_base + p) = v[u];  // (PRED = false: unconditional, like the linear fill)
+          if (live[u]) *(u64x2*)(win_base + p) = v[u];
           win_base += kWin;
         }
       }
@@ -1096,12 +1098,7 @@ __global__ __launch_bounds__(kBlock) void k_expand_bands(u64* __restrict__ out, 
       run_band(std::integral_constant<int, 2>{});
     else
       run_band(std::integral_constant<int, kBandClasses>{});
-    if (band + 1 < n_bands) {
-      commit(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
-      cur = nxt;
-    }
+    __syncthreads();
   }
 }
 // one block per row that straddles a window boundary: the whole row from its class row

@@ -217,7 +217,6 @@ int recreate_engine(ykhost* h) {
   if (const char* v = getenv("YKPRED_WALK_ROWS")) c.reserved[4] = atoi(v);
   if (const char* v = getenv("YKPRED_WAVE_COMBINE_BELOW")) c.reserved[5] = atoi(v);
   if (const char* v = getenv("YKPRED_BAND_STEPS")) c.reserved[6] = atoi(v);      // band height of the zone-A layout (-1 = no band layout)
-  if (const char* v = getenv("YKPRED_BAND_VARIANT")) c.reserved[7] = atoi(v);    // k_expand_bands flavour (experiments)  // avg members per chunk below which k_combine_wave runs (-1 = never)  // distinct request values per dimension from which the sorted walk is used
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;
