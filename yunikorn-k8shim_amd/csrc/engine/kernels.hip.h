@@ -471,44 +471,97 @@ __device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, 
   }
   return any;
 }
-// blockIdx.x: chunk of kBitSigsPerBlock signatures, blockIdx.y: block of 256 row words, blockIdx.z: 0 = tol family, 1 = aff family
+// The same DNF with the term masks of the block's signatures held in registers (lane j of tw[r] = word r * 64 + j of the
+// block's slice of `terms`): j0 / j1 index that slice. One v_readlane pair per mask word instead of a scalar load whose
+// address depends on the previous one.
+constexpr int kSigTermRegs = 4;  // 256 mask words per block of signatures; larger slices take the scalar path
+__device__ __forceinline__ u64 dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride, int w) {
+  u64 any = 0;
+  for (int j = j0; j < j1;) {
+    u64 all = ~0ull;
+    for (int k = 0; k < W; ++k, ++j) {
+      const int r = j >> 6, l = j & 63;  // wave-uniform
+      u64 m = (u64)readlane_i64((i64)(r == 0 ? tw[0] : (r == 1 ? tw[1] : (r == 2 ? tw[2] : tw[3]))), l);
+      while (m) {
+        int q = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        all &= req[(size_t)(k * 64 + q) * stride + w];
+      }
+    }
+    any |= all;
+  }
+  return any;
+}
+// blockIdx.x: chunk of kBitSigsPerBlock signatures, blockIdx.y: block of 256 row words, blockIdx.z: 0 = tol family, 1 = aff family.
+// The signature tables of a block (flags, offsets, tolerated-taint words, term masks) are fetched ONCE with vector loads —
+// lane i holds signature d0 + i's entry — and broadcast with v_readlane: the per-signature chain of dependent scalar loads
+// (flags → offsets → masks, each a cold miss when every ask has its own template) was what the kernel waited on.
 __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
-  const int w = blockIdx.y * kBlock + threadIdx.x;
-  if (w >= a.n_words) return;
+  const int w_raw = blockIdx.y * kBlock + threadIdx.x;
+  if (w_raw - (int)(threadIdx.x % kWave) >= a.n_words) return;  // whole wave beyond the row
+  const bool live = w_raw < a.n_words;
+  const int w = live ? w_raw : a.n_words - 1;  // every lane of a live wave takes part in the v_readlane exchanges
+  const int lane = threadIdx.x % kWave;
   const u64 exists = a.base.exists[w];
   const int d0 = blockIdx.x * kBitSigsPerBlock;
   if (blockIdx.z == 0) {
+    const int nd = min(kBitSigsPerBlock, a.tol.D - d0);
+    if (nd <= 0) return;
     const bool taint_en = a.filt_mask & kPlugTaint, unsched_en = a.filt_mask & kPlugUnsched;
     const bool ports_en = (a.filt_mask & kPlugPorts) && (a.pre_mask & kPlugPorts);
     const u64 unsched = unsched_en ? a.base.unsched[w] : 0ull;
-    for (int d = d0; d < min(d0 + kBitSigsPerBlock, a.tol.D); ++d) {
+    const bool batch = nd * a.KT <= kWave && nd * a.KP <= kWave;
+    const unsigned fl_l = lane < nd ? a.sig_tolflags[d0 + lane] : 0u;
+    u64 tol_l = 0, port_l = 0;
+    if (batch) {
+      if (lane < nd * a.KT) tol_l = a.sig_tol[(size_t)d0 * a.KT + lane];
+      if (ports_en && lane < nd * a.KP) port_l = a.sig_ports[(size_t)d0 * a.KP + lane];
+    }
+    for (int i = 0; i < nd; ++i) {
+      const int d = d0 + i;
+      const unsigned fl = (unsigned)__builtin_amdgcn_readlane((int)fl_l, i);
       u64 bad = 0;  // nodes carrying a taint this signature does not tolerate
       if (taint_en)
         for (int k = 0; k < a.KT; ++k) {
-          u64 m = ~a.sig_tol[(size_t)d * a.KT + k] & a.taint_used[k];
+          const u64 tolerated = batch ? (u64)readlane_i64((i64)tol_l, i * a.KT + k) : a.sig_tol[(size_t)d * a.KT + k];
+          u64 m = ~tolerated & a.taint_used[k];
           while (m) {
             int tt = __ffsll((long long)m) - 1;
             m &= m - 1;
             bad |= a.base.taint[(size_t)(k * 64 + tt) * a.base.stride + w];
           }
         }
-      if (!(a.sig_tolflags[d] & kSpecToleratesUnsched)) bad |= unsched;
-      if (a.sig_tolflags[d] & kSpecUnsupported) bad = ~0ull;  // not evaluated by the engine: fits nowhere (this family is always on)
+      if (!(fl & kSpecToleratesUnsched)) bad |= unsched;
+      if (fl & kSpecUnsupported) bad = ~0ull;  // not evaluated by the engine: fits nowhere (this family is always on)
       if (ports_en)  // NodePorts: a requested host port that is in conflict on the node
         for (int k = 0; k < a.KP; ++k) {
-          u64 m = a.sig_ports[(size_t)d * a.KP + k];
+          u64 m = batch ? (u64)readlane_i64((i64)port_l, i * a.KP + k) : a.sig_ports[(size_t)d * a.KP + k];
           while (m) {
             int pp = __ffsll((long long)m) - 1;
             m &= m - 1;
             bad |= a.base.port[(size_t)(k * 64 + pp) * a.base.stride + w];
           }
         }
-      a.tol.canon[(size_t)d * a.tol.stride + w] = exists & ~bad;
+      if (live) a.tol.canon[(size_t)d * a.tol.stride + w] = exists & ~bad;
     }
   } else {
+    const int nd = min(kBitSigsPerBlock, a.aff.D - d0);
+    if (nd <= 0) return;
     const bool pre_en = a.pre_mask & kPlugAffinity, filt_en = a.filt_mask & kPlugAffinity;
-    for (int d = d0; d < min(d0 + kBitSigsPerBlock, a.aff.D); ++d) {
-      const unsigned f = a.affs.flags[d];
+    const unsigned f_l = lane < nd ? a.affs.flags[d0 + lane] : 0u;
+    const int to_l = lane <= nd ? a.affs.term_off[d0 + lane] : 0;
+    const int tbase = __builtin_amdgcn_readlane(to_l, 0);
+    const int n_mask_words = (__builtin_amdgcn_readlane(to_l, nd) - tbase) * a.W;
+    const bool batch = filt_en && n_mask_words <= kSigTermRegs * kWave;
+    u64 tw[kSigTermRegs];
+#pragma unroll
+    for (int r = 0; r < kSigTermRegs; ++r) {
+      const int j = r * kWave + lane;
+      tw[r] = batch && j < n_mask_words ? a.affs.terms[(size_t)tbase * a.W + j] : 0ull;
+    }
+    for (int i = 0; i < nd; ++i) {
+      const int d = d0 + i;
+      const unsigned f = (unsigned)__builtin_amdgcn_readlane((int)f_l, i);
       const bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
       u64 ok = exists;
       if (pre_en && !skip) {
@@ -516,8 +569,12 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
         if (f & kSpecPreNames)            // "node not eligible" (:248-250)
           ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w);
       }
-      if (filt_en && !skip) ok &= dnf_words(a.affs.terms, a.affs.term_off[d], a.affs.term_off[d + 1], a.W, a.base.req, a.base.stride, w);
-      a.aff.canon[(size_t)d * a.aff.stride + w] = ok;
+      if (filt_en && !skip) {
+        const int t0 = __builtin_amdgcn_readlane(to_l, i), t1 = __builtin_amdgcn_readlane(to_l, i + 1);
+        ok &= batch ? dnf_words_regs(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w)
+                    : dnf_words(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w);
+      }
+      if (live) a.aff.canon[(size_t)d * a.aff.stride + w] = ok;
     }
   }
 }
