@@ -149,17 +149,20 @@ BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_direct")
 def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0):
     """The kernel with the largest average duration + the whole step, both against the HBM peak.
 
-    `achieved` prices the kernel with ITS algorithmic bytes: a bitmap writer is charged the whole step's bytes (it writes
-    the bitmap; the other inputs are < 0.1 % of that on the headline workload); the plane kernels are charged the planes they
-    write plus the node table they read; kernels without a byte model here (the decision pass reads class rows out of L2 and
+    `achieved` prices the kernel with ITS algorithmic bytes: the band writer is charged the bitmap rows it writes
+    (layout.band_rows), the class-by-class writer the rest of the step's bytes (its rows + every input read once); the plane
+    kernels are charged the planes they write plus the node table they read; kernels without a byte model here (the decision pass reads class rows out of L2 and
     is bound by the ordered scan, not by HBM) report achieved / frac = null — `whole_step_frac` always stands."""
     if not kern:
         return None
     dom = max(kern, key=kern.get)
     base = dom.split("(")[0]
     own = None
-    if base in BITMAP_WRITERS:
-        own = algo_bytes
+    band_bytes = (lay.band_rows * lay.row_words * 8) if lay is not None else 0
+    if base == "k_expand_bands":
+        own = band_bytes if lay is not None else algo_bytes
+    elif base in BITMAP_WRITERS:
+        own = max(algo_bytes - band_bytes, 0)
     elif lay is not None and base in ("k_sig_planes", "k_base_planes", "k_planes", "k_dim_walk"):
         own = lay.plane_rows * lay.row_words * 8 + lay.num_nodes * b_node
     achieved = own / (kern[dom] * 1e-3) / 1e9 if own else None

@@ -225,7 +225,7 @@ typedef struct ykpred_layout {
   int64_t spread_cells;
   int32_t num_rows;     /* physical rows of the bitmap (>= num_pods: rows are laid out for the writer and never reused between two
                            class builds); bitmap_bytes = num_rows * row_stride * 8 — what a caller-owned bitmap must hold */
-  int32_t reserved0;
+  int32_t band_rows;    /* rows [0, band_rows) are written by the band writer (k_expand_bands), the rest class by class (k_combine) */
   void* row_of_pod;     /* device int32[P]: the bitmap row of pod p. Bit (n & 63) of word [row_of_pod[p] * row_stride + (n >> 6)]
                            says whether pod p fits node n */
 } ykpred_layout_t;

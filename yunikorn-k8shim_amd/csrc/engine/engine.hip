@@ -2075,6 +2075,7 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->num_chunks = e->NC;
   o->plane_rows = e->fam_res.D + e->fam_tol.D + e->fam_aff.D + e->fam_spread.D;
   o->num_rows = std::max(e->rows_total, e->row_capacity);
+  o->band_rows = e->rows_a;
   o->row_of_pod = e->d_pod_row.p;
   o->bitmap_bytes = (uint64_t)std::max(o->num_rows, 1) * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
