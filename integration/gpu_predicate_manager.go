@@ -319,8 +319,9 @@ func (m *gpuPredicateManager) Refresh(allocate bool) (int, error) {
 // BitmapLayout describes the device-resident results of the last Refresh (device pointers: for consumers on the GPU side,
 // e.g. a batched scheduler-interface callback; host code reads single answers through Predicates()).
 type BitmapLayout struct {
-	Nodes, Asks, RowWords, RowStride int
-	Bitmap, Counts, Decisions        unsafe.Pointer
+	Nodes, Asks, RowWords, RowStride, Rows int
+	// Bitmap rows are permuted for the writer: bit (n & 63) of word RowOfPod[p]*RowStride + (n >> 6) says whether ask p fits node n.
+	Bitmap, RowOfPod, Counts, Decisions unsafe.Pointer
 }
 
 // Layout returns where the results of the last Refresh live.
@@ -331,7 +332,7 @@ func (m *gpuPredicateManager) Layout() (BitmapLayout, error) {
 	}
 	return BitmapLayout{
 		Nodes: int(layout.num_nodes), Asks: int(layout.num_pods), RowWords: int(layout.row_words), RowStride: int(layout.row_stride),
-		Bitmap: layout.bitmap, Counts: layout.counts, Decisions: layout.decisions,
+		Rows: int(layout.num_rows), Bitmap: layout.bitmap, RowOfPod: layout.row_of_pod, Counts: layout.counts, Decisions: layout.decisions,
 	}, nil
 }
 
