@@ -237,7 +237,7 @@ int run_case(u64* d, size_t bytes, long rows, const std::vector<int>& sizes, uns
       const size_t lds = (size_t)2 * ykk::kBandClasses * kW * 8;
       CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       auto launch2 = [&] {
-        hipLaunchKernelGGL(kern, dim3(256), dim3(ykk::kBandBlock), lds, 0, d, tab, det, n_bands, kW);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(sets), lds, 0, d, tab, det, n_bands, kW);
         fixup_rows<<<(unsigned)fix.size(), 256>>>(d, tab, fx, rc, (int)fix.size());
       };
       (void)hipMemset(d, 0, bytes); (void)hipMemset(bad, 0, 8);
@@ -249,10 +249,10 @@ int run_case(u64* d, size_t bytes, long rows, const std::vector<int>& sizes, uns
       for (int i = 0; i < 8; ++i) launch2();
       (void)hipEventRecord(ev1); (void)hipEventSynchronize(ev1);
       float ms2; (void)hipEventElapsedTime(&ms2, ev0, ev1); ms2 /= 8;
-      printf("  ENGINE k_expand_bands (x%d), same tables S=%d: wrong words %llu   %.3f ms  %.0f GB/s\n", sets, S, hb2, ms2, bytes / ms2 / 1e6);
+      printf("  ENGINE k_expand_bands (%d threads), same tables S=%d: wrong words %llu   %.3f ms  %.0f GB/s\n", sets, S, hb2, ms2, bytes / ms2 / 1e6);
       return 0;
     };
-    if (run_ws(ykk::k_expand_bands, 1)) return 1;
+    if (run_ws(ykk::k_expand_bands, ykk::kBandBlock)) return 1;
     (void)hipFree(det);
   }
   (void)hipFree(tab); (void)hipFree(rc); (void)hipFree(fx); (void)hipFree(dwb);
