@@ -1190,7 +1190,13 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
   } else {
     for (int base = 0; base < row_words; base += kWave) {
       int w = base + lane;
-      u64 x = w < row_words ? class_word(cr, w) : 0ull;
+      // Lane-predicated AND, request-value planes first (they come last in `cr`): bin-pack order tries the fullest nodes
+      // first, where those planes are mostly zero — a lane whose word is already zero loads nothing more, so the scan to the
+      // first feasible node reads little beyond one plane.
+      u64 x = w < row_words ? ~0ull : 0ull;
+#pragma unroll
+      for (int i = kMaxClassRows - 1; i >= 0; --i)
+        if (i < cr.n && x) x &= cr.row[i][w];
       u64 any = __ballot(x != 0);
       if (any) {
         int first_lane = __ffsll((long long)any) - 1;
