@@ -9,8 +9,10 @@ feasible-node count and the per-ask bin-pack decision. Tables are resident in HB
   N = 1   workload = configs[2]: 50 000 nodes × 1 000 000 asks (KWOK-style synthetic, 2 000 pod templates).
   N > 1   workload = configs[3]: the SAME 50 000 nodes sharded N-way on the node axis (multiple-of-64 shards, one common
           row stride) × 1 000 000 gang-placeholder asks (10 000 task groups × 100 members) — STRONG scaling. A step =
-          shard evaluation + RCCL all-gather of the shard bitmaps into [N][P][row_stride] + the per-ask decision exchange
-          (SUM count, MIN key, MIN global node), all behind the C ABI (ykpred_gather_bitmap / ykpred_exchange_decisions).
+          shard evaluation + all-gather of the shard bitmaps into [N][rows][row_stride] + the per-ask decision exchange
+          (SUM count, MIN key, MIN global node), all behind the C ABI over RCCL. The gather moves the shards' CLASS rows
+          over xGMI and expands the N slabs locally at HBM speed (ykpred_gather_bitmap_compressed; same layout as the
+          plain ncclAllGather of the P-row bitmaps, which `--raw-gather` selects).
           `--weak` keeps round 1's weak-scaling variant (50 000 nodes PER GPU, decision exchange only).
 
 Prints ONE JSON line (rank 0): `value` = whole-job evals/s of the timed steps; `roofline` describes the kernel with the
@@ -58,6 +60,8 @@ def parse_args():
                                                           "(default: 0 at N=1, 100 at N>1 = configs[3])")
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling, --nodes per GPU, decision exchange only")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the bitmap all-gather out of the step")
+    ap.add_argument("--raw-gather", action="store_true",
+                    help="N>1: all-gather the P-row shard bitmaps themselves over xGMI instead of their class rows + local expansion")
     ap.add_argument("--direct", action="store_true", help="time the per-pair kernel instead of the plane/class path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--variant", type=int, default=0, help="k_combine store flavour (0 dwordx4, 1 dwordx2, 2/3 = non-temporal)")
@@ -292,6 +296,10 @@ def main():
     comm = torch.cuda.Stream(device=dev) if world > 1 else None
     exchanged = [torch.cuda.Event() for _ in range(nbuf)]  # the exchange that last used buffer set b has finished
     gather_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nbuf)]
+    # C-ABI path: the shards exchange CLASS rows and every GPU expands the world slabs at HBM speed (ykpred_gather_bitmap_compressed);
+    # --raw-gather moves the P-row bitmaps over xGMI instead. Same gathered layout either way.
+    compressed = [use_abi and not a.raw_gather]
+    gather_note = []
     step_no = [0]
 
     def step(profile=False):
@@ -310,7 +318,14 @@ def main():
                 if do_gather:
                     gather_ev[b][0].record(comm)
                     if use_abi:
-                        pm.gather_bitmap(gathered=gathered, stream=comm.cuda_stream)
+                        if compressed[0]:
+                            try:
+                                pm.gather_bitmap(gathered=gathered, stream=comm.cuda_stream, compressed=True)
+                            except RuntimeError as exc:  # e.g. the shards built different layouts: the plain form always works
+                                compressed[0] = False
+                                gather_note.append(f"class-compressed gather refused ({exc}); plain all-gather used")
+                        if not compressed[0]:
+                            pm.gather_bitmap(gathered=gathered, stream=comm.cuda_stream)
                     else:
                         dist.all_gather_into_tensor(gathered.view(-1), bitmaps[b].view(-1))
                     gather_ev[b][1].record(comm)
@@ -367,10 +382,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         g_ms = float(t.item())
         nbytes = rows_cap * lay.row_stride * 8
-        gather = {"shard_bytes": nbytes, "ms": round(g_ms, 3), "recv_GBps_per_gpu": round(nbytes * (world - 1) / (g_ms * 1e-3) / 1e9, 1),
-                  "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][P][row_stride] u64 (shard-major)",
-                  "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "
-                          "world-1 peers, per_peer_link = one shard / that time"}
+        if compressed[0]:
+            link = lay.num_classes * lay.row_stride * 8
+            gather = {"mode": "class rows over xGMI + local expansion of the world slabs (ykpred_gather_bitmap_compressed)",
+                      "shard_bytes": nbytes, "link_bytes_per_shard": link, "ms": round(g_ms, 3),
+                      "expanded_GBps_per_gpu": round(nbytes * world / (g_ms * 1e-3) / 1e9, 1),
+                      "layout": "[G][rows][row_stride] u64 (shard-major), identical to the plain all-gather",
+                      "note": "device time of the last gather (max over ranks): collect class rows, ncclAllGather of "
+                              f"{link} B per shard, {world} slab expansions by the writer kernels"}
+        else:
+            gather = {"mode": "plain ncclAllGather of the shard bitmaps", "shard_bytes": nbytes, "ms": round(g_ms, 3),
+                      "recv_GBps_per_gpu": round(nbytes * (world - 1) / (g_ms * 1e-3) / 1e9, 1),
+                      "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][rows][row_stride] u64 (shard-major)",
+                      "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "
+                              "world-1 peers, per_peer_link = one shard / that time" + ("; " + gather_note[0] if gather_note else "")}
 
     cpu = cpu_baseline(pm, a.cpu_seconds, SEED) if rank == 0 else None
     stats = pm.stats()

@@ -366,6 +366,27 @@ int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words);
 int32_t ykpred_set_row_capacity(ykpred_engine_t* e, int32_t rows);
 int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered /* DEVICE [world][num_rows][row_stride] u64, NULL = engine-owned */, void* stream);
 int32_t ykpred_exchange_decisions(ykpred_engine_t* e, void* stream);
+/* Class-compressed form of the same gather. The member rows of a pod class are identical, so a shard's bitmap IS its
+ * [num_classes][row_stride] class-row table plus its pod -> class map. xGMI is per-link bound (7 links x ~50 GB/s in a ring)
+ * while the local HBM takes > 5 TB/s of writes: the shards exchange class rows (MBs instead of GBs) and every GPU writes all
+ * `world` slabs locally. Result: [world][num_rows][row_stride] like ykpred_gather_bitmap, with EVERY slab in the row order
+ * of the receiving engine (its own row_of_pod; ykpred_read_gathered hides the difference).
+ * Shards merge signatures relative to their own taint / node-name dictionaries, so their class partitions may differ:
+ *   ykpred_layout_hash            64-bit digest of the class partition + row layout; a peer with MY digest is expanded with my
+ *                                 writer kernels and tables (band writer + class-by-class writer), any other peer ask by ask
+ *                                 through its pod -> class map (k_expand_by_pod)
+ *   ykpred_collect_class_rows     out = DEVICE [num_classes][row_stride] u64 of the last evaluation
+ *   ykpred_expand_class_rows      bitmap_out (DEVICE [num_rows][row_stride]) = the bitmap whose class rows are `class_rows`
+ *                                 (indexed by this engine's classes, or by a peer's with that peer's pod -> class map), in this
+ *                                 engine's row layout
+ *   ykpred_gather_bitmap_compressed  header exchange (digest, class count), ncclAllGather of the class rows (and of the pod ->
+ *                                 class maps when digests differ), `world` expansions; the slab of this rank is skipped when
+ *                                 `gathered` + rank * slab is the bitmap the last evaluation wrote */
+int32_t ykpred_layout_hash(ykpred_engine_t* e, uint64_t* out);
+int32_t ykpred_collect_class_rows(ykpred_engine_t* e, void* out, void* stream);
+int32_t ykpred_expand_class_rows(ykpred_engine_t* e, const void* class_rows, const int32_t* pod_class /* DEVICE int32[P]: the pod -> class map
+    the table is indexed by (a peer's); NULL = this engine's own classes */, void* bitmap_out, void* stream);
+int32_t ykpred_gather_bitmap_compressed(ykpred_engine_t* e, void* gathered /* DEVICE [world][num_rows][row_stride] u64, NULL = engine-owned */, void* stream);
 /* readback of the engine-owned gathered bitmap: the rows of pods [first_pod, first_pod + num_pods) in shard `shard` (through
  * that shard's gathered row_of_pod map), row_stride words each */
 int32_t ykpred_read_gathered(ykpred_engine_t* e, int32_t shard, int32_t first_pod, int32_t num_pods, uint64_t* out);

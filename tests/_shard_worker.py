@@ -49,6 +49,10 @@ def main():
         pm.synchronize()
         lay = pm.layout()
         shard_rows = [pm.read_gathered(g) for g in range(world)]
+        # the class-compressed gather must reproduce the plain one, slab by slab
+        pm.gather_bitmap(stream=stream.cuda_stream, compressed=True)
+        pm.synchronize()
+        compressed_ok = all(np.array_equal(pm.read_gathered(g), shard_rows[g]) for g in range(world))
     else:
         pm.sync()
         pm.evaluate_into(spread_count_only=True, stream=stream.cuda_stream)
@@ -66,6 +70,26 @@ def main():
         g = sharding.ref_gather_bitmap(local.cpu(), dist)
         maps = sharding.ref_gather_bitmap(torch.from_numpy(pm.row_map().astype(np.int64)), dist)  # every shard's row_of_pod
         shard_rows = [g[s].numpy().view(np.uint64)[maps[s].numpy()] for s in range(world)]
+        # the class-compressed gather, transport emulated over gloo: every rank expands every shard's class rows with ITS OWN
+        # tables (equal layout digests) and must find that shard's rows
+        digests, n_classes = [None] * world, [None] * world
+        dist.all_gather_object(digests, pm.layout_hash())
+        dist.all_gather_object(n_classes, lay.num_classes)
+        cmax = max(n_classes)
+        cls = torch.zeros((cmax, lay.row_stride), dtype=torch.int64, device=dev)  # own class rows, padded to the largest count
+        pm.collect_class_rows(cls)
+        pm.synchronize()
+        all_cls = sharding.ref_gather_bitmap(cls.cpu(), dist)
+        all_maps = sharding.ref_gather_bitmap(torch.from_numpy(pm.pod_classes()[0].astype(np.int32)), dist)
+        compressed_ok = True
+        my_map = pm.row_map()
+        for s in range(world):
+            slab = torch.full((lay.num_rows, lay.row_stride), -1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the expansion on the engine's
+            peer_map = None if digests[s] == digests[rank] else all_maps[s].to(dev)
+            pm.expand_class_rows(all_cls[s].to(dev), slab, pod_class=peer_map)
+            pm.synchronize()
+            compressed_ok = compressed_ok and np.array_equal(slab.cpu().numpy().view(np.uint64)[my_map], shard_rows[s])
         ch, dh, kh = counts.cpu(), decisions.cpu(), keys.cpu()
         sharding.ref_exchange_decisions(ch, dh, kh, first, dist)
         counts.copy_(ch)
@@ -76,11 +100,11 @@ def main():
     full.generate_kwok(num_nodes=total_nodes, **kw)
     full.evaluate()
     want = full.read_bitmap()
-    ok = rows.shape == want.shape and np.array_equal(rows, want)
+    ok = rows.shape == want.shape and np.array_equal(rows, want) and compressed_ok
     ok_counts = np.array_equal(counts.cpu().numpy(), full.read_counts())
     ok_dec = np.array_equal(decisions.cpu().numpy(), full.read_decisions())
     print(f"rank {rank}/{world} {'rccl' if use_rccl else 'gloo-reference'}: rows {ok} counts {ok_counts} decisions {ok_dec} "
-          f"({P} asks x {total_nodes} nodes, stride {lay.row_stride})", flush=True)
+          f"({P} asks x {total_nodes} nodes, stride {lay.row_stride}; class-compressed gather {compressed_ok})", flush=True)
     full.close()
     dist.barrier()
     if use_rccl:

@@ -16,6 +16,7 @@ import _oracle as orc
 
 pytestmark = pytest.mark.gpu
 pkg = importlib.import_module("yunikorn-k8shim_amd")
+sharding = importlib.import_module("yunikorn-k8shim_amd.sharding")
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 NAMES = orc.PLUGIN_NAMES
 
@@ -1146,8 +1147,60 @@ def test_rccl_communicator_single_rank():
     assert np.array_equal(decisions.cpu().numpy(), np.where(local_dec >= 0, local_dec + 1000, -1))
     o = orc.Oracle(pm.dump_snapshot())
     assert np.array_equal(unpack(want_rows, 300), o.eval_grid(threads=8))
+    # the class-compressed form of the same gather: class rows through the all-gather, slabs expanded by the writer kernels
+    gathered = torch.full((1, lay.num_rows, lay.row_stride), -1, dtype=torch.int64, device=dev)  # all ones: every word must be rewritten
+    torch.cuda.synchronize()
+    pm.gather_bitmap(gathered=gathered, stream=stream.cuda_stream, compressed=True)
+    pm.synchronize()
+    rows = gathered[0].cpu().numpy().view(np.uint64)[pm.row_map()]
+    assert np.array_equal(rows[:, :lay.row_words], want_rows) and not rows[:, lay.row_words:].any()
+    pm.gather_bitmap(stream=stream.cuda_stream, compressed=True)  # engine-owned
+    pm.synchronize()
+    assert np.array_equal(pm.read_gathered(0)[:, :lay.row_words], want_rows)
     pm.comm_destroy()
     pm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_nodes,n_pods,templates,gang", [(300, 400, 50, 0), (50_000, 200_000, 400, 0), (6_250, 300_000, 2000, 100)])
+def test_class_rows_expand_to_the_bitmap(n_nodes, n_pods, templates, gang):
+    """The building blocks of the compressed gather on one engine, with and without the band layout: collect the class rows
+    of an evaluation, expand them into a fresh buffer, and every ask's row (through row_of_pod) must be the evaluated one.
+    A second engine over OTHER nodes but the same asks expands the first engine's class rows to the first engine's bitmap in
+    its own row order — what a shard does with a peer's class rows."""
+    import torch
+    dev = torch.device("cuda", 0)
+    a, b = pkg.GpuPredicateManager(), pkg.GpuPredicateManager()
+    try:
+        kw = dict(seed=4242, num_pods=n_pods, num_templates=templates, node_affinity=1, gang_size=gang, total_nodes=2 * n_nodes)
+        a.generate_kwok(num_nodes=n_nodes, node_index_offset=0, **kw)
+        b.generate_kwok(num_nodes=n_nodes, node_index_offset=n_nodes, **kw)
+        for m in (a, b):
+            m.set_row_capacity(sharding.common_row_capacity(n_pods))
+            m.evaluate()
+        la, lb = a.layout(), b.layout()
+        assert (la.num_rows, la.row_stride) == (lb.num_rows, lb.row_stride)
+        want_a, want_b = a.read_bitmap(), b.read_bitmap()
+        assert not np.array_equal(want_a, want_b)  # different nodes: different bits
+        rows_a = torch.empty((la.num_classes, la.row_stride), dtype=torch.int64, device=dev)
+        a.collect_class_rows(rows_a)
+        a.synchronize()
+        map_a = torch.from_numpy(a.pod_classes()[0].astype(np.int32)).to(dev)
+        # own class rows with the writer kernels; own class rows ask by ask; a peer's (the peer may merge signatures differently:
+        # its class count and layout digest need not equal this engine's — then only the ask-by-ask form applies)
+        cases = [(a, None), (a, map_a), (b, map_a)]
+        if a.layout_hash() == b.layout_hash():
+            cases.append((b, None))
+        for engine, pod_class in cases:
+            out = torch.full((la.num_rows, la.row_stride), -1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()  # the fill runs on torch's stream, the expansion on the engine's
+            engine.expand_class_rows(rows_a, out, pod_class=pod_class)
+            engine.synchronize()
+            got = out.cpu().numpy().view(np.uint64)[engine.row_map()]
+            assert np.array_equal(got[:, :la.row_words], want_a) and not got[:, la.row_words:].any()
+    finally:
+        a.close()
+        b.close()
 
 
 def test_topology_spread_sharded_histograms():

@@ -104,6 +104,10 @@ def load_ykpred():
     L.ykpred_set_row_stride.argtypes = [C.c_void_p, C.c_int32]
     L.ykpred_set_row_capacity.argtypes = [C.c_void_p, C.c_int32]
     L.ykpred_gather_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_gather_bitmap_compressed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_layout_hash.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ykpred_collect_class_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ykpred_expand_class_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ykpred_exchange_decisions.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_read_gathered.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.ykpred_query.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,

@@ -227,6 +227,10 @@ struct ykpred_engine {
   int forced_stride = 0;  // ykpred_set_row_stride
   DevBuf d_gathered, d_gathered_map, d_xkey, d_xcand;
   bool last_has_keys = false;
+  // class-compressed gather (ykpred_gather_bitmap_compressed): this shard's class rows, everybody's, expansion scratch
+  DevBuf d_class_rows_all, d_gathered_classes, d_class_rows_slot, d_class_sig_ident, d_expand_count, d_layout_hash, d_gathered_pod_class;
+  int ident_classes = 0;                                     // d_class_sig_ident is filled for this many classes
+  uint64_t layout_version = 1, layout_hashed_version = 0, layout_hash_value = 0;
   // PodTopologySpread / InterPodAffinity histograms: valid for the node / spec tables of `hist_epoch`
   uint64_t nodes_epoch = 1, hist_epoch = 0;
 
@@ -582,6 +586,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   HIPCHK(e->d_class_best.ensure((size_t)std::max(C, 1) * sizeof(int)));
   HIPCHK(hipStreamSynchronize(st));  // the uploads read pageable host vectors
   e->classes_dirty = false;
+  e->layout_version++;
   e->last_eval_valid = false;
   return YKPRED_OK;
 }
@@ -941,7 +946,8 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
                     &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
-                    &e->d_member_key, &e->d_name_rank, &e->d_member_tie})
+                    &e->d_member_key, &e->d_name_rank, &e->d_member_tie, &e->d_class_rows_all, &e->d_gathered_classes, &e->d_class_rows_slot,
+                    &e->d_class_sig_ident, &e->d_expand_count, &e->d_layout_hash, &e->d_gathered_pod_class})
     b->release();
   if (e->ev_ready)
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
@@ -1793,6 +1799,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
   Range roctx_range("ykpred:update_asks");
   if (e) e->n_uploads++;
   if (e) e->tables_version++;
+  if (e) e->layout_version++;
   if (!e || num_pods_after < 0 || count < 0 || (count > 0 && (!rows || !spec_index || !node_name_index)))
     return fail(e, YKPRED_E_INVALID, "update_pods: bad argument");
   if (!e->pods_set || !e->specs_set) return fail(e, YKPRED_E_STATE, "update_pods: ykpred_set_specs and ykpred_set_pods come first");
@@ -2459,6 +2466,176 @@ int32_t ykpred_gather_bitmap(ykpred_engine_t* e, void* gathered, void* stream) {
   // every shard lays its rows out for its own writer: the row_of_pod maps travel with the bitmaps
   HIPCHK(e->d_gathered_map.ensure((size_t)std::max(e->P, 1) * (size_t)e->comm_world * sizeof(int)));
   if (e->P) NCCLCHK(rccl()->AllGather(e->d_pod_row.p, e->d_gathered_map.p, (size_t)e->P, ncclInt32, e->comm, st));
+  return YKPRED_OK;
+}
+
+// ---- class-compressed gather -------------------------------------------------------------------------------------------------
+namespace {
+uint64_t layout_digest(ykpred_engine_t* e) {
+  if (e->layout_hashed_version == e->layout_version) return e->layout_hash_value;
+  uint64_t h = 1469598103934665603ull;  // FNV-1a over everything the expansion of a REMOTE class-row table relies on
+  auto mix = [&](uint64_t v) {
+    h ^= v;
+    h *= 1099511628211ull;
+  };
+  mix((uint64_t)e->C);
+  mix((uint64_t)e->P);
+  mix((uint64_t)e->row_stride);  // (not row_words: shards of unequal node counts share the stride, class rows travel at full stride)
+  mix((uint64_t)std::max(e->rows_total, e->row_capacity));
+  mix((uint64_t)e->rows_a);
+  for (int p = 0; p < e->P; ++p) mix(((uint64_t)(uint32_t)e->h_pod_row[(size_t)p] << 32) | (uint32_t)e->h_pod_class[(size_t)p]);
+  e->layout_hash_value = h;
+  e->layout_hashed_version = e->layout_version;
+  return h;
+}
+// the bitmap whose class rows are `class_rows` ([C][row_stride], device), written with this engine's row layout
+int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, hipStream_t st) {
+  const int C = e->C, P = e->P;
+  if (C == 0 || P == 0) return YKPRED_OK;
+  if (e->ident_classes < C) {
+    HIPCHK(e->d_class_sig_ident.ensure((size_t)C * 4 * sizeof(int)));
+    hipLaunchKernelGGL(ykk::k_identity_sigs, dim3((unsigned)((C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, C, e->d_class_sig_ident.as<int>());
+    e->ident_classes = C;
+  }
+  HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
+  ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0};
+  if (e->n_classes_a > 0) {
+    HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
+    hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),
+                       e->n_classes_a, e->row_stride, e->d_class_rows_slot.as<u64>());
+    const size_t lds_bytes = (size_t)2 * ykk::kBandClasses * (size_t)e->row_stride * sizeof(u64);
+    if (lds_bytes > 64 * 1024)
+      HIPCHK(hipFuncSetAttribute((const void*)ykk::k_expand_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(ykk::k_expand_bands, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBandBlock), lds_bytes, st, out, e->d_class_rows_slot.as<u64>(),
+                       e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
+    if (e->n_fix_rows > 0)
+      hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, out, e->d_class_rows_slot.as<u64>(),
+                         e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
+  }
+  // classes outside the band layout (and rows appended since the last class build): chunk by chunk, like the evaluation
+  if ((long)e->NC * e->wave_combine_below > (long)P) {
+    hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
+                       out, e->row_stride, e->row_stride, 0, e->d_expand_count.as<int>(), e->NC, (const int*)nullptr);
+  } else {
+    int tpg = ykk::kBlock;
+    while (tpg > ykk::kWave && (tpg / 2) * 2 >= e->row_stride) tpg /= 2;
+    const int seg = tpg * ykk::kCombineUnroll * 2;
+    dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
+    hipLaunchKernelGGL((ykk::k_combine<2, false>), grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pl, out, e->row_stride, e->row_stride, 0,
+                       e->d_expand_count.as<int>(), tpg, (const int*)nullptr);
+  }
+  HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+}
+int collect_class_rows_into(ykpred_engine_t* e, u64* out, hipStream_t st) {
+  if (e->C == 0) return YKPRED_OK;
+  hipLaunchKernelGGL(ykk::k_collect_class_rows, dim3((unsigned)e->C), dim3(ykk::kBlock), 0, st, (const u64*)e->last_bitmap, e->C,
+                     e->d_class_first.as<int>(), e->d_pod_row.as<int>(), e->row_stride, out);
+  HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+}
+}  // namespace
+
+int32_t ykpred_layout_hash(ykpred_engine_t* e, uint64_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out) return fail(e, YKPRED_E_INVALID, "layout_hash: null argument");
+  if (e->classes_dirty || (int)e->h_pod_row.size() < e->P) return fail(e, YKPRED_E_STATE, "layout_hash: no current class build (run ykpred_eval)");
+  *out = layout_digest(e);
+  return YKPRED_OK;
+}
+
+int32_t ykpred_collect_class_rows(ykpred_engine_t* e, void* out, void* stream) {
+  YK_SERIALISE(e);
+  if (!e || !out) return fail(e, YKPRED_E_INVALID, "collect_class_rows: null argument");
+  if (e->classes_dirty || !e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "collect_class_rows: no current evaluation");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  return collect_class_rows_into(e, (u64*)out, stream ? (hipStream_t)stream : e->own_stream);
+}
+
+int32_t ykpred_expand_class_rows(ykpred_engine_t* e, const void* class_rows, const int32_t* pod_class, void* bitmap_out, void* stream) {
+  YK_SERIALISE(e);
+  if (!e || !class_rows || !bitmap_out) return fail(e, YKPRED_E_INVALID, "expand_class_rows: null argument");
+  if (e->classes_dirty) return fail(e, YKPRED_E_STATE, "expand_class_rows: no current class build (run ykpred_eval)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+  if (!pod_class) return expand_class_rows_into(e, (const u64*)class_rows, (u64*)bitmap_out, st);
+  if (e->P)
+    hipLaunchKernelGGL(ykk::k_expand_by_pod, dim3((unsigned)((e->P + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
+                       (u64*)bitmap_out, (const u64*)class_rows, (const int*)pod_class, e->d_pod_row.as<int>(), e->P, e->row_stride);
+  HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+}
+
+int32_t ykpred_gather_bitmap_compressed(ykpred_engine_t* e, void* gathered, void* stream) {
+  YK_SERIALISE(e);
+  Range roctx_range("ykpred:gather_bitmap_compressed");
+  if (e) e->n_gathers++;
+  if (!e) return YKPRED_E_INVALID;
+  if (!e->comm) return fail(e, YKPRED_E_STATE, "gather_bitmap_compressed: no communicator (ykpred_comm_init)");
+  if (e->classes_dirty || !e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "gather_bitmap_compressed: no current evaluation");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
+  const int G = e->comm_world;
+  if (G > 1 && e->row_capacity == 0)
+    return fail(e, YKPRED_E_STATE, "gather_bitmap_compressed: the shards must agree on a row capacity first (ykpred_set_row_capacity)");
+  Rccl* r = rccl();
+  // header exchange: {layout digest, class count, ask count} of every shard. Shards merge signatures relative to their OWN
+  // dictionaries, so class counts (and layouts) may differ; a peer with my digest is expanded with my writer tables, any
+  // other peer ask by ask through its pod -> class map.
+  struct Header {
+    uint64_t digest, classes, pods, pad;
+  };
+  std::vector<Header> hdr((size_t)G);
+  const Header mine{layout_digest(e), (uint64_t)e->C, (uint64_t)e->P, 0};
+  if (G > 1) {
+    HIPCHK(e->d_layout_hash.ensure((size_t)(G + 1) * sizeof(Header)));
+    HIPCHK(hipMemcpyAsync(e->d_layout_hash.p, &mine, sizeof(mine), hipMemcpyHostToDevice, st));
+    NCCLCHK(r->AllGather(e->d_layout_hash.p, (char*)e->d_layout_hash.p + sizeof(Header), sizeof(Header) / 8, ncclUint64, e->comm, st));
+    HIPCHK(hipMemcpyAsync(hdr.data(), (char*)e->d_layout_hash.p + sizeof(Header), (size_t)G * sizeof(Header), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  } else {
+    hdr[0] = mine;
+  }
+  uint64_t cmax = 1;
+  bool same_everywhere = true;
+  for (const Header& h : hdr) {
+    if (h.pods != mine.pods) return fail(e, YKPRED_E_STATE, "gather_bitmap_compressed: the shards hold different ask tables");
+    cmax = std::max(cmax, h.classes);
+    same_everywhere = same_everywhere && h.digest == mine.digest;
+  }
+  const size_t rows = (size_t)std::max(std::max(e->rows_total, e->row_capacity), 1);
+  const size_t words = rows * (size_t)e->row_stride;
+  if (!gathered) {
+    HIPCHK(e->d_gathered.ensure(words * (size_t)G * sizeof(u64)));
+    gathered = e->d_gathered.p;
+  }
+  const size_t class_words = (size_t)cmax * (size_t)e->row_stride;  // every shard sends cmax rows (its own count padded)
+  HIPCHK(e->d_class_rows_all.ensure(class_words * sizeof(u64)));
+  HIPCHK(e->d_gathered_classes.ensure(class_words * (size_t)G * sizeof(u64)));
+  TRY(collect_class_rows_into(e, e->d_class_rows_all.as<u64>(), st));
+  NCCLCHK(r->AllGather(e->d_class_rows_all.p, e->d_gathered_classes.p, class_words, ncclUint64, e->comm, st));
+  if (!same_everywhere && e->P) {  // the peers' pod -> class maps
+    HIPCHK(e->d_gathered_pod_class.ensure((size_t)e->P * (size_t)G * sizeof(int)));
+    NCCLCHK(r->AllGather(e->d_pod_class.p, e->d_gathered_pod_class.p, (size_t)e->P, ncclInt32, e->comm, st));
+  }
+  for (int g = 0; g < G; ++g) {
+    u64* slab = (u64*)gathered + (size_t)g * words;
+    if (g == e->comm_rank && (void*)slab == e->last_bitmap) continue;  // the evaluation wrote this rank's slab itself
+    const u64* rows_g = e->d_gathered_classes.as<u64>() + (size_t)g * class_words;
+    if (hdr[(size_t)g].digest == mine.digest) {
+      TRY(expand_class_rows_into(e, rows_g, slab, st));
+    } else if (e->P) {
+      hipLaunchKernelGGL(ykk::k_expand_by_pod, dim3((unsigned)((e->P + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, slab,
+                         rows_g, e->d_gathered_pod_class.as<int>() + (size_t)g * (size_t)e->P, e->d_pod_row.as<int>(), e->P, e->row_stride);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  // every slab is written in THIS engine's row order: ykpred_read_gathered reads all of them through this engine's map
+  HIPCHK(e->d_gathered_map.ensure((size_t)std::max(e->P, 1) * (size_t)G * sizeof(int)));
+  for (int g = 0; g < G && e->P; ++g)
+    HIPCHK(hipMemcpyAsync(e->d_gathered_map.as<int>() + (size_t)g * (size_t)e->P, e->d_pod_row.p, (size_t)e->P * sizeof(int), hipMemcpyDeviceToDevice, st));
   return YKPRED_OK;
 }
 

@@ -1670,6 +1670,47 @@ __global__ __launch_bounds__(kBlock) void k_check_class_rows(const u64* __restri
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, kWave);
   if (threadIdx.x % kWave == 0 && acc) atomicAdd(bad, acc);
 }
+// Class rows out of an evaluated bitmap: out[c] = the row of class c's representative ask (zeros for a class without asks),
+// full stride. Member rows of a class are identical, so [C][row_stride] is the whole bitmap in class-compressed form —
+// what a node shard sends over xGMI instead of its P rows (ykpred_gather_bitmap_compressed).
+__global__ __launch_bounds__(kBlock) void k_collect_class_rows(const u64* __restrict__ bitmap, int n_classes, const int* __restrict__ class_first,
+                                                               const int* __restrict__ pod_row, int row_stride, u64* __restrict__ out) {
+  const int c = blockIdx.x;
+  if (c >= n_classes) return;
+  const int rep = class_first[c];
+  const u64* src = rep >= 0 ? bitmap + (size_t)pod_row[rep] * row_stride : nullptr;
+  for (int w = threadIdx.x; w < row_stride; w += kBlock) out[(size_t)c * row_stride + w] = src ? src[w] : 0ull;
+}
+// rows of the listed classes in list order (the band writer addresses class rows by zone-A slot)
+__global__ __launch_bounds__(kBlock) void k_pick_class_rows(const u64* __restrict__ class_rows, const int* __restrict__ list, int n, int row_stride,
+                                                            u64* __restrict__ out) {
+  const int i = blockIdx.x;
+  if (i >= n) return;
+  const u64* src = class_rows + (size_t)list[i] * row_stride;
+  for (int w = threadIdx.x; w < row_stride; w += kBlock) out[(size_t)i * row_stride + w] = src[w];
+}
+// Expansion of a PEER shard's class rows when the peer partitions the asks into classes differently (signatures are merged
+// relative to the shard's own taint / node-name dictionaries): one wave per ask copies its class's row — class rows come out
+// of L2 — to the ask's row of the slab, in THIS engine's row order.
+__global__ __launch_bounds__(kBlock) void k_expand_by_pod(u64* __restrict__ out, const u64* __restrict__ class_rows, const int* __restrict__ pod_class,
+                                                          const int* __restrict__ pod_row, int n_pods, int row_stride) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  const int p = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (p >= n_pods) return;
+  const int lane = threadIdx.x % kWave;
+  const u64x2* src = (const u64x2*)(class_rows + (size_t)pod_class[p] * row_stride);
+  u64x2* dst = (u64x2*)(out + (size_t)pod_row[p] * row_stride);
+  for (int i = lane; i < row_stride / 2; i += kWave) dst[i] = src[i];
+}
+// sig table that makes class c's only plane row c of the `tol` family: k_combine / k_combine_wave then expand a class-row table
+__global__ __launch_bounds__(kBlock) void k_identity_sigs(int n_classes, int* __restrict__ sig) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= n_classes) return;
+  sig[c * 4 + 0] = -1;
+  sig[c * 4 + 1] = c;
+  sig[c * 4 + 2] = -1;
+  sig[c * 4 + 3] = -1;
+}
 // pods == null: pods first, first + 1, ...
 __global__ __launch_bounds__(kBlock) void k_gather_rows(const u64* __restrict__ bitmap, int n, const int* __restrict__ pods, int first,
                                                         const int* __restrict__ pod_row, int row_words, int row_stride, u64* __restrict__ out) {

@@ -355,10 +355,28 @@ class GpuPredicateManager:
     def comm_destroy(self):
         self._check(self._L.ykhost_comm_destroy(self._h))
 
-    def gather_bitmap(self, gathered=None, stream=None):
-        """All-gather of the shard bitmaps of the last evaluation into [world][P][row_stride] (device; engine-owned when
-        `gathered` is None), on `stream`."""
-        self._pcheck(self._P.ykpred_gather_bitmap(self.engine, None if gathered is None else gathered.data_ptr(), stream))
+    def gather_bitmap(self, gathered=None, stream=None, compressed=False):
+        """All-gather of the shard bitmaps of the last evaluation into [world][rows][row_stride] (device; engine-owned when
+        `gathered` is None), on `stream`. compressed=True: the shards exchange their CLASS rows and every GPU expands the
+        slabs locally (same result; raises when the shards' row layouts differ — then use the plain form)."""
+        fn = self._P.ykpred_gather_bitmap_compressed if compressed else self._P.ykpred_gather_bitmap
+        self._pcheck(fn(self.engine, None if gathered is None else gathered.data_ptr(), stream))
+
+    def layout_hash(self):
+        """Digest of the class / row layout: shards with equal digests can expand each other's class rows."""
+        out = C.c_uint64(0)
+        self._pcheck(self._P.ykpred_layout_hash(self.engine, C.byref(out)))
+        return int(out.value)
+
+    def collect_class_rows(self, out, stream=None):
+        """out: device int64 tensor [num_classes][row_stride] <- the class rows of the last evaluation."""
+        self._pcheck(self._P.ykpred_collect_class_rows(self.engine, out.data_ptr(), stream))
+
+    def expand_class_rows(self, class_rows, bitmap_out, pod_class=None, stream=None):
+        """bitmap_out (device [num_rows][row_stride]) <- the bitmap whose class rows are `class_rows`, in this engine's row
+        layout. pod_class (device int32[P]): the pod -> class map `class_rows` is indexed by when it is a PEER's table."""
+        self._pcheck(self._P.ykpred_expand_class_rows(self.engine, class_rows.data_ptr(), None if pod_class is None else pod_class.data_ptr(),
+                                                      bitmap_out.data_ptr(), stream))
 
     def exchange_decisions(self, stream=None):
         """In place on the last evaluation's outputs: cluster-wide counts and GLOBAL best node per ask."""
