@@ -374,7 +374,7 @@ int32_t ykpred_exchange_decisions(ykpred_engine_t* e, void* stream);
  * Shards merge signatures relative to their own taint / node-name dictionaries, so their class partitions may differ:
  *   ykpred_layout_hash            64-bit digest of the class partition + row layout; a peer with MY digest is expanded with my
  *                                 writer kernels and tables (band writer + class-by-class writer), any other peer ask by ask
- *                                 through its pod -> class map (k_expand_by_pod)
+ *                                 row by row through its pod -> class map (k_expand_by_row)
  *   ykpred_collect_class_rows     out = DEVICE [num_classes][row_stride] u64 of the last evaluation
  *   ykpred_expand_class_rows      bitmap_out (DEVICE [num_rows][row_stride]) = the bitmap whose class rows are `class_rows`
  *                                 (indexed by this engine's classes, or by a peer's with that peer's pod -> class map), in this

@@ -228,9 +228,9 @@ struct ykpred_engine {
   DevBuf d_gathered, d_gathered_map, d_xkey, d_xcand;
   bool last_has_keys = false;
   // class-compressed gather (ykpred_gather_bitmap_compressed): this shard's class rows, everybody's, expansion scratch
-  DevBuf d_class_rows_all, d_gathered_classes, d_class_rows_slot, d_class_sig_ident, d_expand_count, d_layout_hash, d_gathered_pod_class;
+  DevBuf d_class_rows_all, d_gathered_classes, d_class_rows_slot, d_class_sig_ident, d_expand_count, d_layout_hash, d_gathered_pod_class, d_row_pod;
   int ident_classes = 0;                                     // d_class_sig_ident is filled for this many classes
-  uint64_t layout_version = 1, layout_hashed_version = 0, layout_hash_value = 0;
+  uint64_t layout_version = 1, layout_hashed_version = 0, layout_hash_value = 0, row_pod_version = 0;
   // PodTopologySpread / InterPodAffinity histograms: valid for the node / spec tables of `hist_epoch`
   uint64_t nodes_epoch = 1, hist_epoch = 0;
 
@@ -947,7 +947,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
                     &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
                     &e->d_member_key, &e->d_name_rank, &e->d_member_tie, &e->d_class_rows_all, &e->d_gathered_classes, &e->d_class_rows_slot,
-                    &e->d_class_sig_ident, &e->d_expand_count, &e->d_layout_hash, &e->d_gathered_pod_class})
+                    &e->d_class_sig_ident, &e->d_expand_count, &e->d_layout_hash, &e->d_gathered_pod_class, &e->d_row_pod})
     b->release();
   if (e->ev_ready)
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
@@ -2529,6 +2529,23 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(hipGetLastError());
   return YKPRED_OK;
 }
+// a PEER's class rows (indexed through the peer's ask -> class map) into this engine's row order
+int expand_peer_rows_into(ykpred_engine_t* e, const u64* class_rows, const int* pod_class, u64* out, hipStream_t st) {
+  if (e->P == 0) return YKPRED_OK;
+  const int n_rows = std::max(std::max(e->rows_total, e->row_capacity), 1);
+  if (e->row_pod_version != e->layout_version) {
+    HIPCHK(e->d_row_pod.ensure((size_t)n_rows * sizeof(int)));
+    HIPCHK(hipMemsetAsync(e->d_row_pod.p, 0xff, (size_t)n_rows * sizeof(int), st));
+    hipLaunchKernelGGL(ykk::k_invert_row_map, dim3((unsigned)((e->P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, e->d_pod_row.as<int>(), e->P,
+                       e->d_row_pod.as<int>());
+    e->row_pod_version = e->layout_version;
+  }
+  const int row_groups = (n_rows + ykk::kExpandRows - 1) / ykk::kExpandRows;
+  hipLaunchKernelGGL(ykk::k_expand_by_row, dim3((unsigned)((row_groups + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, out, class_rows,
+                     pod_class, e->d_row_pod.as<int>(), n_rows, e->row_stride);
+  HIPCHK(hipGetLastError());
+  return YKPRED_OK;
+}
 int collect_class_rows_into(ykpred_engine_t* e, u64* out, hipStream_t st) {
   if (e->C == 0) return YKPRED_OK;
   hipLaunchKernelGGL(ykk::k_collect_class_rows, dim3((unsigned)e->C), dim3(ykk::kBlock), 0, st, (const u64*)e->last_bitmap, e->C,
@@ -2561,11 +2578,7 @@ int32_t ykpred_expand_class_rows(ykpred_engine_t* e, const void* class_rows, con
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = stream ? (hipStream_t)stream : e->own_stream;
   if (!pod_class) return expand_class_rows_into(e, (const u64*)class_rows, (u64*)bitmap_out, st);
-  if (e->P)
-    hipLaunchKernelGGL(ykk::k_expand_by_pod, dim3((unsigned)((e->P + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
-                       (u64*)bitmap_out, (const u64*)class_rows, (const int*)pod_class, e->d_pod_row.as<int>(), e->P, e->row_stride);
-  HIPCHK(hipGetLastError());
-  return YKPRED_OK;
+  return expand_peer_rows_into(e, (const u64*)class_rows, (const int*)pod_class, (u64*)bitmap_out, st);
 }
 
 int32_t ykpred_gather_bitmap_compressed(ykpred_engine_t* e, void* gathered, void* stream) {
@@ -2626,9 +2639,8 @@ int32_t ykpred_gather_bitmap_compressed(ykpred_engine_t* e, void* gathered, void
     const u64* rows_g = e->d_gathered_classes.as<u64>() + (size_t)g * class_words;
     if (hdr[(size_t)g].digest == mine.digest) {
       TRY(expand_class_rows_into(e, rows_g, slab, st));
-    } else if (e->P) {
-      hipLaunchKernelGGL(ykk::k_expand_by_pod, dim3((unsigned)((e->P + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, slab,
-                         rows_g, e->d_gathered_pod_class.as<int>() + (size_t)g * (size_t)e->P, e->d_pod_row.as<int>(), e->P, e->row_stride);
+    } else {
+      TRY(expand_peer_rows_into(e, rows_g, e->d_gathered_pod_class.as<int>() + (size_t)g * (size_t)e->P, slab, st));
     }
   }
   HIPCHK(hipGetLastError());

@@ -1690,17 +1690,44 @@ __global__ __launch_bounds__(kBlock) void k_pick_class_rows(const u64* __restric
   for (int w = threadIdx.x; w < row_stride; w += kBlock) out[(size_t)i * row_stride + w] = src[w];
 }
 // Expansion of a PEER shard's class rows when the peer partitions the asks into classes differently (signatures are merged
-// relative to the shard's own taint / node-name dictionaries): one wave per ask copies its class's row — class rows come out
-// of L2 — to the ask's row of the slab, in THIS engine's row order.
-__global__ __launch_bounds__(kBlock) void k_expand_by_pod(u64* __restrict__ out, const u64* __restrict__ class_rows, const int* __restrict__ pod_class,
-                                                          const int* __restrict__ pod_row, int n_pods, int row_stride) {
+// relative to the shard's own taint / node-name dictionaries): one wave per PHYSICAL row — consecutive waves write consecutive
+// rows, the class rows come out of L2 — through the inverse row map (row -> ask, -1 = no ask owns the row) and the peer's
+// ask -> class map.
+__global__ __launch_bounds__(kBlock) void k_invert_row_map(const int* __restrict__ pod_row, int n_pods, int* __restrict__ row_pod) {
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p < n_pods) row_pod[pod_row[p]] = p;
+}
+// One wave covers kExpandRows consecutive rows as ONE run of 16-byte pieces (narrow rows of a node shard are < 1 KiB: a wave
+// per row would issue a single store per lane behind a chain of three dependent loads).
+constexpr int kExpandRows = 8;
+__global__ __launch_bounds__(kBlock) void k_expand_by_row(u64* __restrict__ out, const u64* __restrict__ class_rows, const int* __restrict__ pod_class,
+                                                          const int* __restrict__ row_pod, int n_rows, int row_stride) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-  const int p = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  if (p >= n_pods) return;
+  const int r0 = (blockIdx.x * kWavesPerBlock + threadIdx.x / kWave) * kExpandRows;
+  if (r0 >= n_rows) return;
   const int lane = threadIdx.x % kWave;
-  const u64x2* src = (const u64x2*)(class_rows + (size_t)pod_class[p] * row_stride);
-  u64x2* dst = (u64x2*)(out + (size_t)pod_row[p] * row_stride);
-  for (int i = lane; i < row_stride / 2; i += kWave) dst[i] = src[i];
+  const int ppr = row_stride / 2;  // 16-byte pieces per row
+  const int rows = min(kExpandRows, n_rows - r0);
+  // lane i < rows: the class row of row r0 + i (or -1), fetched once and broadcast
+  int src_l = -1;
+  if (lane < rows) {
+    const int p = row_pod[r0 + lane];
+    src_l = p >= 0 ? pod_class[p] : -1;
+  }
+  const int total = rows * ppr;
+  u64x2* dst = (u64x2*)(out + (size_t)r0 * row_stride);
+  int rr = lane / ppr, cc = lane - rr * ppr;        // piece `lane`: row in the run, piece in the row
+  const int drr = kWave / ppr, dcc = kWave - drr * ppr;  // advance of 64 pieces
+  for (int j = lane; j < total; j += kWave) {
+    const int cls = __shfl(src_l, rr, kWave);
+    if (cls >= 0) dst[j] = ((const u64x2*)(class_rows + (size_t)cls * row_stride))[cc];
+    rr += drr;
+    cc += dcc;
+    if (cc >= ppr) {
+      cc -= ppr;
+      ++rr;
+    }
+  }
 }
 // sig table that makes class c's only plane row c of the `tol` family: k_combine / k_combine_wave then expand a class-row table
 __global__ __launch_bounds__(kBlock) void k_identity_sigs(int n_classes, int* __restrict__ sig) {
