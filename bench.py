@@ -391,7 +391,8 @@ def main():
                       "note": "device time of the last gather (max over ranks): collect class rows, ncclAllGather of "
                               f"{link} B per shard, {world} slab expansions by the writer kernels"}
         else:
-            gather = {"mode": "plain ncclAllGather of the shard bitmaps", "shard_bytes": nbytes, "ms": round(g_ms, 3),
+            gather = {"mode": "plain ncclAllGather of the shard bitmaps" if use_abi else "all_gather_into_tensor of the shard bitmaps (torch.distributed reference)",
+                      "shard_bytes": nbytes, "ms": round(g_ms, 3),
                       "recv_GBps_per_gpu": round(nbytes * (world - 1) / (g_ms * 1e-3) / 1e9, 1),
                       "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][rows][row_stride] u64 (shard-major)",
                       "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "
