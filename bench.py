@@ -300,6 +300,7 @@ def main():
     # --raw-gather moves the P-row bitmaps over xGMI instead. Same gathered layout either way.
     compressed = [use_abi and not a.raw_gather]
     gather_note = []
+    gather_on = [True]  # switched off for the extra "step without the gather" leg after the timed region
     step_no = [0]
 
     def step(profile=False):
@@ -315,7 +316,7 @@ def main():
             evaluated.record(stream)
             comm.wait_event(evaluated)
             with torch.cuda.stream(comm):
-                if do_gather:
+                if do_gather and gather_on[0]:
                     gather_ev[b][0].record(comm)
                     if use_abi:
                         if compressed[0]:
@@ -377,6 +378,22 @@ def main():
 
     gather = None
     if do_gather:
+        # extra leg, outside the timed region: the same step without the bitmap gather (shard evaluation + decision exchange)
+        gather_on[0] = False
+        step()
+        drain()
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        drain()
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        no_gather_ms = float(t.item()) / a.steps * 1e3
+        gather_on[0] = True
         g_ms = max(gather_ev[b][0].elapsed_time(gather_ev[b][1]) for b in range(nbuf))
         t = torch.tensor([g_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -397,6 +414,8 @@ def main():
                       "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][rows][row_stride] u64 (shard-major)",
                       "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "
                               "world-1 peers, per_peer_link = one shard / that time" + ("; " + gather_note[0] if gather_note else "")}
+        gather["step_without_gather_ms"] = round(no_gather_ms, 4)
+        gather["evals_per_sec_without_gather"] = float(P) * total_nodes / (no_gather_ms * 1e-3)
 
     cpu = cpu_baseline(pm, a.cpu_seconds, SEED) if rank == 0 else None
     stats = pm.stats()
