@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define YKPRED_ABI_VERSION 1
+/* 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
+ *    gather / exchange entry points (version 1 = the round-1 ABI: rows in ask order, no collectives) */
+#define YKPRED_ABI_VERSION 2
 
 /* status codes */
 #define YKPRED_OK 0
