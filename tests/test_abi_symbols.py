@@ -62,3 +62,28 @@ def test_go_side_only_uses_the_declared_abi():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_go_bindings.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "checked" in r.stdout and "PROBLEM" not in r.stdout
+
+
+def test_python_binding_matches_the_headers():
+    """yunikorn-k8shim_amd/_ffi.py declares ctypes argtypes by hand: every function it types must exist in include/*.h with
+    that many parameters (a drifted binding would pass garbage through the C ABI without any compile error)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import check_go_bindings as cg
+    headers = ""
+    for h in ("ykpred.h", "ykhost.h"):
+        headers += cg.strip_comments(open(os.path.join(ROOT, "include", h)).read()) + "\n"
+    declared = {}
+    for m in re.finditer(r"\b(yk(?:pred|host)_\w+)\s*\(", headers):
+        args = cg.call_args(headers, m.end() - 1)
+        declared[m.group(1)] = 0 if args.strip() in ("", "void") else len(cg.split_args(args))
+    ffi = importlib.import_module("yunikorn-k8shim_amd._ffi")
+    checked = 0
+    for lib in (ffi.load_ykpred(), ffi.load_ykhost()):
+        for name, want in declared.items():
+            fn = getattr(lib, name, None)
+            if fn is None or fn.argtypes is None:
+                continue
+            assert len(fn.argtypes) == want, f"{name}: _ffi.py declares {len(fn.argtypes)} parameters, the header {want}"
+            checked += 1
+    assert checked >= 40, checked
