@@ -217,11 +217,38 @@ def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: re-executes this script as N ranks of one node (one per GPU) under
+    torch.distributed.run — the same command form the driver uses itself — so that the flag can never silently measure one GPU."""
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs (RCCL wants one device per rank), {have} visible; "
+                 f"BENCH_BACKEND=gloo runs the ranks on the GPUs there are with the torch.distributed reference exchanges")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     a = parse_args()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s): the line would report the wrong job")
     dist = None
     # BENCH_BACKEND=gloo lets the N>1 path be exercised on a single-GPU box (all ranks share cuda:0; the exchanges then use
     # the torch.distributed reference forms — RCCL refuses two ranks on one device). The driver's multi-GPU runs use the
@@ -460,7 +487,7 @@ def main():
         out = {
             "metric": baseline_metric(), "value": evals / elapsed, "unit": "evals/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "higher_is_better": True, "scaling": None if world == 1 else ("strong" if strong else "weak"), "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": workload, "nodes_per_gpu": N, "total_nodes": total_nodes, "pods": P, "templates": a.templates,
                        "pod_classes": lay.num_classes, "signature_planes": lay.plane_rows, "unique_requests": bool(a.unique_requests),
                        "spread": bool(a.spread), "gang_size": gang, "path": "direct" if a.direct else "planes+combine",

@@ -146,13 +146,26 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options /* YKPRE
 
 /* Like ykhost_evaluate, but when only node rows changed since the last evaluation of this phase (AssumePod / ForgetPod /
  * pods added to or removed from nodes) it patches just those node columns (ykpred_eval_nodes). *columns_patched receives
- * the number of columns re-evaluated, or -1 when a full evaluation was required. */
+ * the number of columns re-evaluated, or -1 when a full evaluation was required. On a node-sharded handle (ykhost_comm_init)
+ * whose asks carry topology constraints the call is COLLECTIVE: every shard's host makes it for the step, with or without
+ * changes of its own — the engine exchanges the topology histograms inside. */
 int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, int32_t* columns_patched);
 
 /* PredicateManager.Predicates for pending pod #pod on node #node. Returns 1 = fits ("", nil), 0 = error returned.
  * plugin receives the failing plugin name ("" when a PreFilter plugin rejected the pod), msg the status message. */
 int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t allocate, char* plugin, int32_t plugin_len, char* msg,
                           int32_t msg_len);
+/* The callbacks above are served from the RESIDENT answer whenever an evaluation of the phase is current: on the first
+ * callback after ykhost_evaluate the class-compressed bitmap ([classes][row_words]; YKHOST_RESIDENT_MB, default 256, bounds it —
+ * beyond that one row per ask) is mirrored to the host, and a callback becomes ask → class → bit. A node whose column changed
+ * since (AssumePod between two asks) is answered per pair from the tables; a pair that does not fit costs one packed
+ * whole-class query for its failing plugin (cached). Without a current evaluation: one ykpred_query_pod per ask, as before.
+ * ykhost_candidates: the first k feasible nodes of the ask in bin-pack order — the node loop of the core in one call.
+ * → nodes written, YKPRED_E_STATE (-4) if no evaluation WITH decisions is current. ykhost_resident_stats: out[0] callbacks served
+ * from the mirror, [1] per pair (changed column), [2] by whole-ask queries, [3] answer fetches, [4] failing-plugin fetches. */
+int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k, int32_t* out_nodes /* [k] */);
+int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5);
+
 /* victims: UIDs of pods assigned to the node (NULL / unknown UID = nil victim). Returns the index or -1. */
 int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t num_victims,
                                      int32_t start_index);

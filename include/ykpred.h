@@ -38,9 +38,11 @@
 extern "C" {
 #endif
 
-/* 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
+/* 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row / ykpred_peek_outputs (the resident
+ *    answer served to single Predicates() callbacks), ykpred_eval_nodes is collective on a sharded engine with topology signatures
+ * 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
  *    gather / exchange entry points (version 1 = the round-1 ABI: rows in ask order, no collectives) */
-#define YKPRED_ABI_VERSION 2
+#define YKPRED_ABI_VERSION 3
 
 /* status codes */
 #define YKPRED_OK 0
@@ -108,10 +110,13 @@ typedef struct ykpred_config {
   int32_t topology_keys;    /* KD >= 0: topology keys used by hard spread constraints */
   int32_t selector_classes; /* KS >= 0: distinct (namespace, labelSelector) classes of spread constraints */
   int32_t port_words;       /* KP >= 0: 64-bit words of the host-port dictionary (NodePorts) */
-  int32_t reserved[8];      /* [0..4]: engine tunables for experiments, 0 = defaults; [3] == 1 replays a repeated
+  int32_t reserved[8];      /* [0..7]: engine tunables for experiments, 0 = defaults; [3] == 1 replays a repeated
                                ykpred_eval as a hipGraph (opt-in: measured equal to plain launches); [4] = number of distinct
                                request values per resource dimension from which the sorted-walk plane kernels are used (256);
-                               [5] = average members per combine chunk below which the wave-per-chunk combine runs (16, -1 never) */
+                               [5] = average members per combine chunk below which the wave-per-chunk combine runs (16, -1 never);
+                               [6] = band height of the zone-A row layout in windows (4..256, multiple of 4; 0 = chosen from the row
+                               length so that classes of ~100 asks still get band rows; -1 = no band layout);
+                               [7] == 1 runs the class-by-class writer AFTER the band writer instead of beside it */
 } ykpred_config_t;
 
 /* Node table, structure-of-arrays. Arrays documented [A][count] are A consecutive runs of `count` values. */
@@ -200,8 +205,11 @@ typedef struct ykpred_eval_args {
   uint32_t prefilter_plugins; /* enabled PreFilter plugins (YKPRED_PLUGIN_* bits) */
   uint32_t filter_plugins;    /* enabled Filter plugins */
   uint32_t options;           /* YKPRED_OUT_* | YKPRED_EVAL_* */
-  uint32_t reserved;
-  void* bitmap;               /* optional caller-owned DEVICE buffer of layout.bitmap_bytes; NULL = engine-owned */
+  uint32_t bitmap_rows;       /* caller-owned bitmap: the physical rows it holds (row_stride words each). The engine never writes
+                                 a row >= bitmap_rows: an evaluation or ask-table patch that would need one fails with
+                                 YKPRED_E_INVALID / invalidates the evaluation instead. 0 = ykpred_set_row_capacity rows (one
+                                 of the two must be given with a caller-owned bitmap) */
+  void* bitmap;               /* optional caller-owned DEVICE buffer of bitmap_rows x row_stride x 8 bytes; NULL = engine-owned */
   void* stream;               /* hipStream_t to launch on; NULL = the engine's own stream */
   void* counts;               /* optional caller-owned DEVICE int32[P]; NULL = engine-owned */
   void* decisions;            /* optional caller-owned DEVICE int32[P]; NULL = engine-owned */
@@ -267,8 +275,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* args);
  * feasible counts; decisions are recomputed when YKPRED_OUT_DECISIONS is set. With PodTopologySpread / InterPodAffinity
  * signatures active the histograms are rebuilt (they couple all nodes), the signatures whose PreFilter state moved are
  * found on the device, and the classes that use them get their WHOLE rows rewritten — all other classes still only the
- * touched columns. YKPRED_E_STATE if there is no matching previous evaluation; YKPRED_E_UNSUPPORTED on a node-sharded engine
- * with topology signatures (the histogram all-reduce is collective — run ykpred_eval on every shard). */
+ * touched columns. YKPRED_E_STATE if there is no matching previous evaluation. On a node-sharded engine (communicator attached)
+ * with topology signatures the call is COLLECTIVE: every shard enters it — with its own, possibly empty, node list — and
+ * performs exactly the histogram exchange of a full ykpred_eval (SUM of matches, MAX of "domain present"), so a shard may
+ * answer the same step with ykpred_eval instead. Hosts that move the histograms themselves split the call like ykpred_eval:
+ * YKPRED_EVAL_SPREAD_COUNT_ONLY (rebuild this shard's histograms, return), then YKPRED_EVAL_SPREAD_COUNTS_READY. */
 int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* args, int32_t num_nodes, const int32_t* node_index);
 /* Row-level maintenance of the ask table (SchedulerCache.UpdatePod for a new / changed / finished ask,
  * /root/reference/pkg/cache/external/scheduler_cache.go:303-388) without re-uploading it: the table gets `num_pods_after`
@@ -307,6 +318,26 @@ int32_t ykpred_read_row_map(ykpred_engine_t* e, int32_t* out /* [P]: layout.row_
 int32_t ykpred_read_pod_classes(ykpred_engine_t* e, int32_t* pod_class /* [P] or NULL */, int32_t* class_rep /* [num_classes] or NULL */);
 int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
 
+/* The RESIDENT answer served to single callbacks. yunikorn-core walks asks, not nodes: for one ask it calls Predicates() node
+ * after node (Context.IsPodFitNode, /root/reference/pkg/cache/context.go:696-716, behind scheduler_callback.go:203-205). When
+ * the last evaluation is still current, every fit bit of that ask already sits in its bitmap row: ykpred_peek_row copies that
+ * ONE row (row_words words; plus the ask's feasible count and bin-pack decision when the pointers are given) to the host on a
+ * copy stream that waits for the evaluation's completion event — no kernel, no device-wide synchronize. The host then serves
+ * the ask's callbacks from memory and needs ykpred_query only to name the failing plugin of a pair that does not fit.
+ * YKPRED_E_STATE when the bitmap does not describe the current tables and these plugin lists (a node or ask changed and was not
+ * re-evaluated): the caller falls back to ykpred_query_pod. ykpred_read_order: the bin-pack order of the last evaluation that
+ * produced decisions (perm[i] = node at position i) — with a row, "the first k feasible nodes in bin-pack order". */
+int32_t ykpred_peek_row(ykpred_engine_t* e, int32_t pod_index, uint32_t prefilter_plugins, uint32_t filter_plugins,
+                        uint64_t* out_row /* [row_words] */, int32_t* out_count /* may be NULL */, int32_t* out_decision /* may be NULL */);
+int32_t ykpred_read_order(ykpred_engine_t* e, int32_t* out_perm /* [N] */);
+/* Building blocks of a host-side mirror of the resident answer (libykhost keeps one): YKPRED_OK iff the bitmap of the last
+ * evaluation is the answer for the current tables and these plugin lists (*num_classes = classes of that evaluation); the class
+ * of an ask in the engine's current class index (host-side lookup: asks that join an existing class after the evaluation are
+ * answered by that class's row); the whole answer in class-compressed form, [num_classes][row_words] on the host. */
+int32_t ykpred_answer_state(ykpred_engine_t* e, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t* num_classes /* may be NULL */);
+int32_t ykpred_pod_class(ykpred_engine_t* e, int32_t pod_index, int32_t* out_class);
+int32_t ykpred_read_class_rows(ykpred_engine_t* e, uint64_t* out /* [num_classes][row_words] */);
+
 /* one Predicates() answer per (pod,node) pair, evaluated on the device straight from the tables */
 int32_t ykpred_query(ykpred_engine_t* e, int32_t num_pairs, const int32_t* pod_index, const int32_t* node_index,
                      uint32_t prefilter_plugins, uint32_t filter_plugins, uint8_t* fit /* [num_pairs] */,
@@ -316,6 +347,10 @@ int32_t ykpred_query(ykpred_engine_t* e, int32_t num_pairs, const int32_t* pod_i
  * in a row (one callback per node); the Go side fetches the ask's answers once and serves those callbacks from host memory. */
 int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod_index, uint32_t prefilter_plugins, uint32_t filter_plugins,
                          uint8_t* fit /* [N] */, uint8_t* plugin_code /* [N], may be NULL */, uint32_t* reason /* [N], may be NULL */);
+
+/* ykpred_query_pod with one 4-byte word per node and a single device → host copy: bits 0-7 plugin code, bit 8 fit, bits 9-12
+ * reason bits 0-3, bits 13.. the insufficient-resource bits (reason >> YKPRED_REASON_RESOURCE_SHIFT). */
+int32_t ykpred_query_pod_packed(ykpred_engine_t* e, int32_t pod_index, uint32_t prefilter_plugins, uint32_t filter_plugins, uint32_t* out /* [N] */);
 
 /* PreemptionPredicates (predicate_manager.go:141-179): victims are described by their request vectors, in order. */
 int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod_index, int32_t node_index, int32_t num_victims,

@@ -32,7 +32,7 @@ class YkpredPods(C.Structure):
 
 class YkpredEvalArgs(C.Structure):
     _fields_ = [("prefilter_plugins", C.c_uint32), ("filter_plugins", C.c_uint32), ("options", C.c_uint32),
-                ("reserved", C.c_uint32), ("bitmap", C.c_void_p), ("stream", C.c_void_p), ("counts", C.c_void_p),
+                ("bitmap_rows", C.c_uint32), ("bitmap", C.c_void_p), ("stream", C.c_void_p), ("counts", C.c_void_p),
                 ("decisions", C.c_void_p), ("decision_keys", C.c_void_p)]
 
 
@@ -119,6 +119,12 @@ def load_ykpred():
                                     C.c_uint32, C.POINTER(C.c_int32)]
     L.ykpred_preemption_ports.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                           C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]
+    L.ykpred_peek_row.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.ykpred_read_order.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykpred_answer_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_int32)]
+    L.ykpred_pod_class.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.ykpred_read_class_rows.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykpred_query_pod_packed.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
     _pred = L
     return L
 
@@ -174,5 +180,7 @@ def load_ykhost():
     L.ykhost_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.ykhost_ask_supported.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_routing_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykhost_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    L.ykhost_resident_stats.argtypes = [C.c_void_p, C.c_void_p]
     _host = L
     return L

@@ -172,7 +172,10 @@ struct ykpred_engine {
   DevBuf d_pod_row;
   // zone A: band layout tables (built by build_classes, read by k_class_rows / k_expand_bands / k_fix_rows)
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
-  int band_steps = 128;            // tunable: cfg.reserved[6] > 0
+  int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
+  int band_steps_now = 128;        // the band height the current class build used
+  bool combine_beside = true;      // tunable: cfg.reserved[7] == 1 runs the class-by-class writer after the band writer, not beside it
+  int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
   DevBuf d_band_tab, d_class_rows_a, d_class_list_a, d_class_slot_a, d_fix_row, d_fix_slot, d_chunk_zone;
@@ -198,11 +201,21 @@ struct ykpred_engine {
   // --- outputs
   DevBuf d_bitmap, d_counts, d_decisions, d_keys, d_scratch;
   void* last_bitmap = nullptr;
+  int64_t last_bitmap_rows = 0;  // rows the buffer of the last evaluation holds (caller-owned: eval_args.bitmap_rows / row capacity)
   void *last_counts = nullptr, *last_decisions = nullptr, *last_keys = nullptr;
 
   // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr;
+  // --- zone-B stream: the class-by-class writer runs beside the band writer (they write disjoint rows)
+  hipStream_t zb_stream = nullptr;
+  hipEvent_t ev_zb_fork = nullptr, ev_zb_join = nullptr;
+  // --- the resident answer served to single callbacks (ykpred_peek_row / ykpred_peek_outputs): a copy stream ordered after the
+  // last evaluation by an event, pinned staging memory
+  hipStream_t peek_stream = nullptr;
+  hipEvent_t ev_eval_done = nullptr;
+  void* peek_pinned = nullptr;
+  size_t peek_pinned_bytes = 0;
 
   // --- hipGraph cache of the full evaluation: the ~15 launches / memsets / cross-stream events of one pass are captured
   // once per (tables version, plugin lists, options, output buffers) and replayed; any table change bumps the version
@@ -231,8 +244,14 @@ struct ykpred_engine {
   DevBuf d_class_rows_all, d_gathered_classes, d_class_rows_slot, d_class_sig_ident, d_expand_count, d_layout_hash, d_gathered_pod_class, d_row_pod;
   int ident_classes = 0;                                     // d_class_sig_ident is filled for this many classes
   uint64_t layout_version = 1, layout_hashed_version = 0, layout_hash_value = 0, row_pod_version = 0;
+  // Bumped by every call that can change the class layout (set_nodes / set_specs / set_pods / update_pods / set_row_*): the
+  // shards of a cluster make those calls in lockstep (they hold the same asks), so "ask_epoch moved" is a COLLECTIVE fact and
+  // the header exchange of the compressed gather can be cached by it without one shard skipping a collective the others enter.
+  uint64_t ask_epoch = 1, hdr_epoch = 0;
+  std::vector<uint64_t> hdr_cache;  // [world][4] of the last header exchange
   // PodTopologySpread / InterPodAffinity histograms: valid for the node / spec tables of `hist_epoch`
   uint64_t nodes_epoch = 1, hist_epoch = 0;
+  uint64_t bitmap_epoch = 0;  // nodes_epoch the bitmap of the last evaluation (full pass or column patch) describes
 
   // --- counters (ykpred_get_counters)
   int64_t n_full_evals = 0, n_node_patches = 0, n_row_patches = 0, n_queries = 0, n_gathers = 0, n_uploads = 0;
@@ -373,16 +392,39 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   // window, X(r) = (r * row_bytes) mod window, falls into one interval. Workgroup b always writes window bytes
   // [4096 b, 4096 b + 4096): during a band it needs the rows of at most kBandClasses classes, which it keeps in LDS.
   const long row_b = (long)e->row_stride * 8, win = (long)ykk::kBandGroups * 4096;
-  const int S = e->band_steps, KC = ykk::kBandClasses;
+  const int KC = ykk::kBandClasses;
   // a piece of a class inside one band must be wide enough in X that no workgroup range (4096 + row bytes) meets more
   // than KC pieces: (rows of the piece / S) * row_b >= (4096 + row_b) / (KC - 1), with a margin; verified below
-  const int piece_min = (int)((double)S * (4096.0 + (double)row_b) / (double)row_b / (double)(KC - 1) * 1.3) + 3;
+  auto piece_min_of = [&](int steps) { return (int)((double)steps * (4096.0 + (double)row_b) / (double)row_b / (double)(KC - 1) * 1.3) + 3; };
+  // Band height S. A class is admitted to the band layout from 2 * piece_min(S) rows on, and piece_min grows with S and with
+  // (4096 + row bytes) / row bytes — 190 rows at 50 000 nodes, but 620 at the 6 272-node shard of an 8-way cluster, where the
+  // 100-member task groups of BASELINE configs[3] would all fall to the class-by-class writer. So S is chosen per build from
+  // the class sizes: the tallest band that still admits (nearly) every row a short band would, but never so short that the
+  // class rows re-read per band (KC rows per S tiles of 4 KiB) become a visible share of the traffic.
+  int S = e->band_steps;
+  if (S <= 0) {
+    int s_min = 8;
+    while (s_min < 128 && (long)s_min * 4096 < 5L * KC * row_b) s_min *= 2;
+    auto coverage = [&](int steps) {
+      const int need = 2 * piece_min_of(steps);
+      long rows = 0;
+      for (int c = 0; c < C; ++c)
+        if (class_size[(size_t)c] >= need) rows += class_size[(size_t)c];
+      return rows;
+    };
+    const long best = coverage(s_min);
+    S = 128;
+    while (S > s_min && (double)coverage(S) < 0.97 * (double)best) S /= 2;
+  }
+  while (S > 4 && (long)S * win / row_b >= (1L << 21)) S -= 4;  // the builder's sort key holds the row-in-band in 21 bits
+  e->band_steps_now = S;
+  const int piece_min = piece_min_of(S);
   e->h_class_slot_a.assign((size_t)C, -1);
   e->h_pod_row.assign((size_t)P, -1);
   std::vector<ykk::BandEntry> band_tab;
   std::vector<int32_t> class_list_a, fix_row, fix_slot;
   int n_steps = 0, n_bands = 0, rows_a = 0;
-  const bool geometry_ok = e->bands_enabled && e->N > 0 && (size_t)2 * KC * (size_t)row_b <= (size_t)ykk::kBandMaxLds;
+  const bool geometry_ok = e->bands_enabled && e->N > 0 && (size_t)2 * KC * (size_t)row_b <= (size_t)std::min(ykk::kBandMaxLds, e->max_lds_bytes);
   if (geometry_ok) {
     long rows_needed = 0;
     for (int c = 0; c < C; ++c)
@@ -902,7 +944,13 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (cfg->reserved[5] > 0) e->wave_combine_below = cfg->reserved[5];
   if (cfg->reserved[5] < 0) e->wave_combine_below = 0;
   if (cfg->reserved[6] < 0) e->bands_enabled = false;
-  if (cfg->reserved[6] > 0) e->band_steps = (cfg->reserved[6] + 3) / 4 * 4;
+  // the band kernel packs the step-in-band into 8 bits of its class key: at most 256 windows per band
+  if (cfg->reserved[6] > 0) e->band_steps = std::min(256, std::max(4, (cfg->reserved[6] + 3) / 4 * 4));
+  e->combine_beside = cfg->reserved[7] != 1;
+  {
+    int lds = 0;  // what a workgroup may ask for with hipFuncAttributeMaxDynamicSharedMemorySize (64 KiB on gfx90a / gfx942, 160 KiB on gfx950)
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) e->max_lds_bytes = lds;
+  }
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -916,6 +964,11 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
     if (hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
       (void)hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking);
   }
+  if (hipStreamCreateWithFlags(&e->zb_stream, hipStreamNonBlocking) != hipSuccess) e->zb_stream = nullptr;
+  if (hipStreamCreateWithFlags(&e->peek_stream, hipStreamNonBlocking) != hipSuccess) e->peek_stream = nullptr;
+  (void)hipEventCreateWithFlags(&e->ev_zb_fork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&e->ev_zb_join, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&e->ev_eval_done, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_planes, hipEventDisableTiming);
@@ -954,6 +1007,12 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
+  if (e->ev_zb_fork) (void)hipEventDestroy(e->ev_zb_fork);
+  if (e->ev_zb_join) (void)hipEventDestroy(e->ev_zb_join);
+  if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
+  if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
+  if (e->zb_stream) (void)hipStreamDestroy(e->zb_stream);
+  if (e->peek_stream) (void)hipStreamDestroy(e->peek_stream);
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -965,6 +1024,7 @@ int32_t ykpred_set_nodes(ykpred_engine_t* e, const ykpred_nodes_t* n) {
   if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (e) e->nodes_epoch++;
+  if (e) e->ask_epoch++;
   if (e) e->last_eval_valid = false;  // every row and column of an earlier bitmap is stale (and N / row_stride may change)
   if (!e || !n || n->count < 0) return fail(e, YKPRED_E_INVALID, "set_nodes: bad argument");
   if (n->count > 0 && (!n->allocatable || !n->requested || !n->allowed_pods || !n->pod_count || !n->flags || !n->taint_bits ||
@@ -1079,6 +1139,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   Range roctx_range("ykpred:upload_specs");
   if (e) e->n_uploads++;
   if (e) e->tables_version++;
+  if (e) e->ask_epoch++;
   if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
   if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
     return fail(e, YKPRED_E_INVALID, "set_specs: null column");
@@ -1313,6 +1374,7 @@ int32_t ykpred_set_pods(ykpred_engine_t* e, const ykpred_pods_t* p) {
   Range roctx_range("ykpred:upload_asks");
   if (e) e->n_uploads++;
   if (e) e->tables_version++;
+  if (e) e->ask_epoch++;
   if (!e || !p || p->count < 0) return fail(e, YKPRED_E_INVALID, "set_pods: bad argument");
   if (p->count > 0 && (!p->spec_index || !p->node_name_index)) return fail(e, YKPRED_E_INVALID, "set_pods: null column");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -1359,11 +1421,23 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const int N = e->N, P = e->P;
   const size_t bitmap_bytes = (size_t)std::max(std::max(e->rows_total, e->row_capacity), 1) * (size_t)e->row_stride * sizeof(u64);
   u64* bitmap = (u64*)a->bitmap;
-  if (!bitmap) {
+  int64_t bitmap_rows = 0;
+  if (!bitmap || (void*)bitmap == e->d_bitmap.p) {  // (ykpred_eval_nodes hands the engine's own buffer back)
     HIPCHK(e->d_bitmap.ensure(bitmap_bytes));
     bitmap = e->d_bitmap.as<u64>();
+    bitmap_rows = (int64_t)(e->d_bitmap.cap / ((size_t)std::max(e->row_stride, 1) * sizeof(u64)));
+  } else {
+    // A caller-owned bitmap has to say how many rows it holds: rows are laid out for the writer (band padding) and every
+    // changed or appended ask takes a fresh row, so the row count is not the ask count — and the engine must never store
+    // past the end of memory it does not own.
+    bitmap_rows = a->bitmap_rows ? (int64_t)a->bitmap_rows : (int64_t)e->row_capacity;
+    if (bitmap_rows == 0)
+      return fail(e, YKPRED_E_INVALID, "eval: a caller-owned bitmap needs eval_args.bitmap_rows or ykpred_set_row_capacity (it must hold layout.num_rows rows)");
+    if ((int64_t)e->rows_total > bitmap_rows)
+      return fail(e, YKPRED_E_INVALID, "eval: the caller-owned bitmap holds fewer rows than the layout needs (layout.num_rows)");
   }
   e->last_bitmap = bitmap;
+  e->last_bitmap_rows = bitmap_rows;
   HIPCHK(e->d_counts.ensure((size_t)std::max(P, 1) * sizeof(int)));
   HIPCHK(e->d_decisions.ensure((size_t)std::max(P, 1) * sizeof(int)));
   HIPCHK(e->d_keys.ensure((size_t)std::max(P, 1) * sizeof(i64)));
@@ -1583,11 +1657,19 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     while (tpg > ykk::kWave && (tpg / 2) * wpl >= e->row_stride) tpg /= 2;
     const int seg = tpg * ykk::kCombineUnroll * wpl;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
+    // The class-by-class writer (zone B, rows disjoint from the band rows) runs BESIDE the band writer on its own stream:
+    // both only need the planes. Its chunks of zone-A classes return at once, so with nothing in zone B it is a no-op beside.
+    const bool beside = e->combine_beside && e->zb_stream && !dirty_only && e->n_classes_a > 0 && e->NC > 0;
+    hipStream_t sz = beside ? e->zb_stream : st;
     auto launch = [&](auto kern) {
       // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
-      hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pc, bitmap, e->row_words, e->row_stride,
+      hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, sz, ct, pc, bitmap, e->row_words, e->row_stride,
                          pin_on, e->d_class_count.as<int>(), tpg, class_dirty);
     };
+    if (beside) {
+      HIPCHK(hipEventRecord(e->ev_zb_fork, st));  // planes and the zeroed class counts are ready here
+      HIPCHK(hipStreamWaitEvent(sz, e->ev_zb_fork, 0));
+    }
     if (!dirty_only && e->n_classes_a > 0) {
       // zone A: class rows → table (and the classes' feasible counts), then the fill-pattern expansion over the band layout
       tm.begin(st);
@@ -1606,10 +1688,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
       tm.end(st, "k_expand_bands");
     }
-    tm.begin(st);
+    tm.begin(sz);
     if ((long)e->NC * e->wave_combine_below > (long)P) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
-      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct,
+      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty);
     } else {
       switch (variant) {
@@ -1619,7 +1701,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         default: launch(ykk::k_combine<1, true>); break;
       }
     }
-    tm.end(st, dirty_only ? "k_combine(dirty classes)" : "k_combine");
+    tm.end(sz, dirty_only ? "k_combine(dirty classes)" : "k_combine");
+    if (sz != st) {
+      HIPCHK(hipEventRecord(e->ev_zb_join, sz));
+      HIPCHK(hipStreamWaitEvent(st, e->ev_zb_join, 0));
+    }
   }
   if (want_dec) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
   if (want_dec || want_cnt) {
@@ -1688,6 +1774,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     }
   }
   tm.done(st);
+  if (e->ev_eval_done) (void)hipEventRecord(e->ev_eval_done, st);
+  e->bitmap_epoch = e->nodes_epoch;
   e->last_pre = pre;
   e->last_filt = filt;
   e->last_eval_valid = true;
@@ -1710,8 +1798,14 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   if (e->classes_dirty || !e->last_eval_valid || pre != e->last_pre || filt != e->last_filt || (void*)bitmap != e->last_bitmap)
     return fail(e, YKPRED_E_STATE, "eval_nodes: no matching previous ykpred_eval (tables, plugin lists or bitmap changed)");
   const bool topo = (pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0;
-  if (topo && e->comm && e->comm_world > 1)
-    return fail(e, YKPRED_E_UNSUPPORTED, "eval_nodes: on a node-sharded engine the topology histograms change through a collective — run ykpred_eval on every shard");
+  // On a node-sharded engine the topology histograms couple the shards: with a communicator attached the call is COLLECTIVE
+  // when topology signatures are active — every shard enters it (with its own, possibly empty, node list) and performs exactly
+  // the histogram exchange a full ykpred_eval performs (SUM of matches, MAX of "domain present"), so shards may even mix the
+  // two calls. Hosts that move the histograms themselves use the same two-phase flags as ykpred_eval
+  // (YKPRED_EVAL_SPREAD_COUNT_ONLY, then YKPRED_EVAL_SPREAD_COUNTS_READY).
+  const bool sharded = e->comm && e->comm_world > 1;
+  const bool hist_ready = a->options & YKPRED_EVAL_SPREAD_COUNTS_READY, hist_only = a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY;
+  const bool topo_pass = topo && e->P > 0 && (num_nodes > 0 || sharded || hist_ready || hist_only);
   if (topo && e->spread_dirty) return fail(e, YKPRED_E_STATE, "eval_nodes: topology tables changed — run ykpred_eval");
   for (int i = 0; i < num_nodes; ++i)
     if (node_index[i] < 0 || node_index[i] >= e->N) return fail(e, YKPRED_E_INVALID, "eval_nodes: node index out of range");
@@ -1720,7 +1814,7 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   const bool want_cnt = a->options & YKPRED_OUT_COUNTS;
   const bool want_keys = a->options & YKPRED_OUT_DECISION_KEYS;
   const bool want_dec = (a->options & YKPRED_OUT_DECISIONS) || want_keys;
-  if (topo && num_nodes > 0 && e->P > 0) {
+  if (topo_pass) {
     // The PreFilter state of the topology plugins couples all nodes: rebuild the histograms (cheap: one thread per
     // signature and node), then find the signatures whose cells or minima moved.
     const size_t cells = (size_t)std::max<int64_t>(e->spread_cells, 1) * sizeof(int), mins = (size_t)std::max(e->spread_constraints, 1) * sizeof(int);
@@ -1729,10 +1823,18 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
     HIPCHK(e->d_sp_min_prev.ensure(mins));
     HIPCHK(e->d_sig_changed.ensure((size_t)e->fam_spread.D * sizeof(int)));
     if (e->hist_epoch == 0) return fail(e, YKPRED_E_STATE, "eval_nodes: no topology histograms from a previous ykpred_eval");
-    HIPCHK(hipMemcpyAsync(e->d_sp_cnt_prev.p, e->d_sp_cnt.p, cells, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_sp_present_prev.p, e->d_sp_present.p, cells, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_sp_min_prev.p, e->d_sp_min.p, mins, hipMemcpyDeviceToDevice, st));
-    TRY(run_spread_prefilter(e, st, &tm, true, true));
+    if (!hist_ready) {
+      HIPCHK(hipMemcpyAsync(e->d_sp_cnt_prev.p, e->d_sp_cnt.p, cells, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(e->d_sp_present_prev.p, e->d_sp_present.p, cells, hipMemcpyDeviceToDevice, st));
+      HIPCHK(hipMemcpyAsync(e->d_sp_min_prev.p, e->d_sp_min.p, mins, hipMemcpyDeviceToDevice, st));
+      TRY(run_spread_prefilter(e, st, &tm, true, false));
+    }
+    if (hist_only) {  // the caller sums layout.spread_counts / spread_present over the shards and comes back with COUNTS_READY
+      tm.done(st);
+      return YKPRED_OK;
+    }
+    if (!hist_ready) TRY(allreduce_spread(e, st));
+    TRY(run_spread_prefilter(e, st, &tm, false, true));
     e->hist_epoch = e->nodes_epoch;
     tm.begin(st);
     hipLaunchKernelGGL(ykk::k_spread_diff, dim3((unsigned)e->fam_spread.D), dim3(ykk::kWave), 0, st, spread_sigs(e), e->d_sp_cnt_prev.as<int>(),
@@ -1774,12 +1876,14 @@ int32_t ykpred_eval_nodes(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32
   }
   HIPCHK(hipGetLastError());
   tm.done(st);
-  if (topo && num_nodes > 0 && e->P > 0) {
+  if (e->ev_eval_done) (void)hipEventRecord(e->ev_eval_done, st);
+  e->bitmap_epoch = e->nodes_epoch;  // the caller lists every node it changed since the last evaluation
+  if (topo_pass) {
     // planes again (cheap), then the whole rows of the classes whose topology signature moved; with decisions requested the
     // same pass refreshes the bin-pack order and the class decisions
     ykpred_eval_args_t b = *a;
     b.bitmap = bitmap;
-    b.options = a->options | YKPRED_OUT_BITMAP | YKPRED_EVAL_DIRTY_CLASSES | YKPRED_EVAL_SPREAD_COUNTS_READY;
+    b.options = (a->options & ~(uint32_t)YKPRED_EVAL_SPREAD_COUNT_ONLY) | YKPRED_OUT_BITMAP | YKPRED_EVAL_DIRTY_CLASSES | YKPRED_EVAL_SPREAD_COUNTS_READY;
     int rc = ykpred_eval(e, &b);
     if (rc != YKPRED_OK) return rc;
   } else if (want_dec) {
@@ -1800,6 +1904,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
   if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (e) e->layout_version++;
+  if (e) e->ask_epoch++;
   if (!e || num_pods_after < 0 || count < 0 || (count > 0 && (!rows || !spec_index || !node_name_index)))
     return fail(e, YKPRED_E_INVALID, "update_pods: bad argument");
   if (!e->pods_set || !e->specs_set) return fail(e, YKPRED_E_STATE, "update_pods: ykpred_set_specs and ykpred_set_pods come first");
@@ -1821,6 +1926,17 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
       if (!l) return fail(e, YKPRED_E_INVALID, "update_pods: every appended row must be listed");
   }
   hipStream_t st = e->own_stream;
+  if (!e->classes_dirty) {
+    // Every listed row takes a fresh physical row at the end of the bitmap. If those do not fit the row capacity the shards
+    // agreed on — or the caller-owned bitmap of the last evaluation — nothing is patched in place: the class index is dropped
+    // BEFORE any mirror is touched and the call takes the table-only branch below; the next ykpred_eval re-packs the rows.
+    const int64_t after = (int64_t)e->rows_total + count;
+    const bool caller_owned = e->last_bitmap && e->last_bitmap != e->d_bitmap.p;
+    if ((e->row_capacity && after > (int64_t)e->row_capacity) || (caller_owned && e->last_eval_valid && after > e->last_bitmap_rows)) {
+      e->classes_dirty = true;
+      e->last_eval_valid = false;
+    }
+  }
   if (e->classes_dirty) {
     // no class index yet (or it is due for a rebuild): only the pod table changes, the next ykpred_eval builds the classes
     e->h_pod_spec.resize((size_t)newP);
@@ -1952,10 +2068,6 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     put(T_CLASS_FIRST, c, want);
   }
   e->P = newP;
-  if (e->row_capacity && e->rows_total > e->row_capacity) {
-    e->classes_dirty = true;  // (the next full pass re-packs the rows)
-    return fail(e, YKPRED_E_INVALID, "update_pods: the bitmap needs more rows than ykpred_set_row_capacity allows");
-  }
   TRY(grow_owned_outputs(e));
 
   // device side: grow what has to grow (contents kept), then apply every change with one copy + one launch
@@ -2059,6 +2171,7 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_
       if ((size_t)rows[i] < e->h_row_stale.size()) e->h_row_stale[(size_t)rows[i]] = 0;
   }
   tm.done(st);
+  if (e->ev_eval_done) (void)hipEventRecord(e->ev_eval_done, st);
   return YKPRED_OK;
 }
 
@@ -2217,6 +2330,73 @@ int32_t ykpred_read_rows(ykpred_engine_t* e, int32_t n, const int32_t* pods, uin
   return YKPRED_OK;
 }
 
+// The resident answer, one ask at a time. See ykpred.h.
+int32_t ykpred_peek_row(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t filt, uint64_t* out_row, int32_t* out_count, int32_t* out_decision) {
+  YK_SERIALISE(e);
+  if (!e || !out_row) return fail(e, YKPRED_E_INVALID, "peek_row: bad argument");
+  if (e->classes_dirty || !e->last_eval_valid || !e->last_bitmap || e->bitmap_epoch != e->nodes_epoch || pre != e->last_pre || filt != e->last_filt)
+    return fail(e, YKPRED_E_STATE, "peek_row: no current evaluation of these plugin lists (tables changed since)");
+  if (pod < 0 || pod >= e->P || (size_t)pod >= e->h_pod_row.size()) return fail(e, YKPRED_E_INVALID, "peek_row: ask index out of range");
+  if ((size_t)pod < e->h_row_stale.size() && e->h_row_stale[(size_t)pod]) return fail(e, YKPRED_E_STATE, "peek_row: the ask's row was patched and not re-evaluated yet");
+  const int row = e->h_pod_row[(size_t)pod];
+  if (row < 0 || (int64_t)row >= e->last_bitmap_rows) return fail(e, YKPRED_E_STATE, "peek_row: the ask has no bitmap row");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->peek_stream ? e->peek_stream : e->own_stream;
+  const size_t row_bytes = (size_t)e->row_words * sizeof(u64), need = row_bytes + 16;
+  if (e->peek_pinned_bytes < need) {
+    if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
+    e->peek_pinned = nullptr;
+    e->peek_pinned_bytes = 0;
+    HIPCHK(hipHostMalloc(&e->peek_pinned, need + 4096, hipHostMallocDefault));
+    e->peek_pinned_bytes = need + 4096;
+  }
+  // ordered after the evaluation by its completion event, not by draining the device: other streams keep running
+  if (e->ev_eval_done) HIPCHK(hipStreamWaitEvent(st, e->ev_eval_done, 0));
+  char* pin = (char*)e->peek_pinned;
+  if (row_bytes) HIPCHK(hipMemcpyAsync(pin + 16, (const u64*)e->last_bitmap + (size_t)row * (size_t)e->row_stride, row_bytes, hipMemcpyDeviceToHost, st));
+  if (out_count) HIPCHK(hipMemcpyAsync(pin, (const int*)e->last_counts + pod, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (out_decision) HIPCHK(hipMemcpyAsync(pin + 4, (const int*)e->last_decisions + pod, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (row_bytes) memcpy(out_row, pin + 16, row_bytes);
+  if (out_count) memcpy(out_count, pin, sizeof(int));
+  if (out_decision) memcpy(out_decision, pin + 4, sizeof(int));
+  return YKPRED_OK;
+}
+
+// Is the bitmap of the last evaluation the answer for the current tables and these plugin lists?
+int32_t ykpred_answer_state(ykpred_engine_t* e, uint32_t pre, uint32_t filt, int32_t* num_classes) {
+  YK_SERIALISE(e);
+  if (!e) return YKPRED_E_INVALID;
+  if (e->classes_dirty || !e->last_eval_valid || !e->last_bitmap || e->bitmap_epoch != e->nodes_epoch || pre != e->last_pre || filt != e->last_filt)
+    return fail(e, YKPRED_E_STATE, "answer_state: no current evaluation of these plugin lists");
+  for (uint8_t stale : e->h_row_stale)
+    if (stale) return fail(e, YKPRED_E_STATE, "answer_state: ask rows were patched and not re-evaluated yet");
+  if (num_classes) *num_classes = e->C;
+  return YKPRED_OK;
+}
+
+// The class of an ask in the engine's current class index (host-side lookup, no device work)
+int32_t ykpred_pod_class(ykpred_engine_t* e, int32_t pod, int32_t* out_class) {
+  YK_SERIALISE(e);
+  if (!e || !out_class) return YKPRED_E_INVALID;
+  if (e->classes_dirty || pod < 0 || pod >= e->P || (size_t)pod >= e->h_pod_class.size()) return fail(e, YKPRED_E_STATE, "pod_class: no current class index for this ask");
+  *out_class = e->h_pod_class[(size_t)pod];
+  return YKPRED_OK;
+}
+
+// perm[i] = the node at position i of the bin-pack order of the last evaluation that produced decisions
+int32_t ykpred_read_order(ykpred_engine_t* e, int32_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out) return fail(e, YKPRED_E_INVALID, "read_order: bad argument");
+  if (!e->rank_valid) return fail(e, YKPRED_E_STATE, "read_order: no current bin-pack order (run ykpred_eval with YKPRED_OUT_DECISIONS)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->peek_stream ? e->peek_stream : e->own_stream;
+  if (e->ev_eval_done) HIPCHK(hipStreamWaitEvent(st, e->ev_eval_done, 0));
+  if (e->N) HIPCHK(hipMemcpyAsync(out, e->d_perm.p, (size_t)e->N * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
 int32_t ykpred_read_row_map(ykpred_engine_t* e, int32_t* out) {
   YK_SERIALISE(e);
   if (!e || !out) return YKPRED_E_INVALID;
@@ -2308,6 +2488,30 @@ int32_t ykpred_query_pod(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t
   HIPCHK(hipMemcpyAsync(fit, d_f, N, hipMemcpyDeviceToHost, st));
   if (code) HIPCHK(hipMemcpyAsync(code, d_c, N, hipMemcpyDeviceToHost, st));
   if (reason) HIPCHK(hipMemcpyAsync(reason, d_r, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
+// ykpred_query_pod with ONE 4-byte word per node and one device → host copy: bits 0-7 plugin code, bit 8 fit, bits 9-12 the
+// four reason flags, bits 13.. the insufficient-resource flags (reason >> YKPRED_REASON_RESOURCE_SHIFT).
+int32_t ykpred_query_pod_packed(ykpred_engine_t* e, int32_t pod, uint32_t pre, uint32_t filt, uint32_t* out) {
+  YK_SERIALISE(e);
+  Range roctx_range("ykpred:query_pod");
+  if (e) e->n_queries++;
+  if (!e || !out) return fail(e, YKPRED_E_INVALID, "query_pod_packed: bad argument");
+  if (!e->nodes_set || !e->specs_set || !e->pods_set) return fail(e, YKPRED_E_STATE, "query_pod_packed: tables not uploaded");
+  if (pod < 0 || pod >= e->P) return fail(e, YKPRED_E_INVALID, "query_pod_packed: index out of range");
+  if (e->N == 0) return YKPRED_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY))) TRY(ensure_histograms(e, st));
+  else if (e->spread_dirty) TRY(build_spread_tables(e, st));
+  const size_t N = (size_t)e->N;
+  HIPCHK(e->d_scratch.ensure(N * sizeof(uint32_t) + 64));
+  hipLaunchKernelGGL(ykk::k_query_pod_packed, dim3((unsigned)((N + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, node_table(e),
+                     spec_table(e), e->h_pod_spec[(size_t)pod], e->h_pod_pin[(size_t)pod], pre, filt, e->d_scratch.as<uint32_t>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, e->d_scratch.p, N * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return YKPRED_OK;
 }
@@ -2435,6 +2639,7 @@ int32_t ykpred_set_row_capacity(ykpred_engine_t* e, int32_t rows) {
   if (rows && e->rows_total > rows) return fail(e, YKPRED_E_INVALID, "set_row_capacity: the bitmap already uses more rows");
   if (rows != e->row_capacity) e->last_eval_valid = false;  // the bitmap buffer changes size
   e->row_capacity = rows;
+  e->ask_epoch++;
   return YKPRED_OK;
 }
 
@@ -2442,6 +2647,7 @@ int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words) {
   YK_SERIALISE(e);
   if (!e || words < 0 || words % 16 != 0) return fail(e, YKPRED_E_INVALID, "set_row_stride: need a multiple of 16 words (0 = automatic)");
   e->forced_stride = words;
+  e->ask_epoch++;
   return YKPRED_OK;
 }
 
@@ -2571,6 +2777,24 @@ int32_t ykpred_collect_class_rows(ykpred_engine_t* e, void* out, void* stream) {
   return collect_class_rows_into(e, (u64*)out, stream ? (hipStream_t)stream : e->own_stream);
 }
 
+// The whole answer in class-compressed form on the host: [num_classes][row_words] (classes without a live ask: zeros)
+int32_t ykpred_read_class_rows(ykpred_engine_t* e, uint64_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out) return fail(e, YKPRED_E_INVALID, "read_class_rows: null argument");
+  if (e->classes_dirty || !e->last_eval_valid || !e->last_bitmap) return fail(e, YKPRED_E_STATE, "read_class_rows: no current evaluation");
+  if (e->C == 0 || e->row_words == 0) return YKPRED_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->peek_stream ? e->peek_stream : e->own_stream;
+  if (e->ev_eval_done) HIPCHK(hipStreamWaitEvent(st, e->ev_eval_done, 0));
+  const size_t bytes = (size_t)e->C * (size_t)e->row_stride * sizeof(u64);
+  HIPCHK(e->d_class_rows_all.ensure(bytes));
+  TRY(collect_class_rows_into(e, e->d_class_rows_all.as<u64>(), st));
+  HIPCHK(hipMemcpy2DAsync(out, (size_t)e->row_words * sizeof(u64), e->d_class_rows_all.p, (size_t)e->row_stride * sizeof(u64), (size_t)e->row_words * sizeof(u64),
+                          (size_t)e->C, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
 int32_t ykpred_expand_class_rows(ykpred_engine_t* e, const void* class_rows, const int32_t* pod_class, void* bitmap_out, void* stream) {
   YK_SERIALISE(e);
   if (!e || !class_rows || !bitmap_out) return fail(e, YKPRED_E_INVALID, "expand_class_rows: null argument");
@@ -2602,12 +2826,23 @@ int32_t ykpred_gather_bitmap_compressed(ykpred_engine_t* e, void* gathered, void
   };
   std::vector<Header> hdr((size_t)G);
   const Header mine{layout_digest(e), (uint64_t)e->C, (uint64_t)e->P, 0};
-  if (G > 1) {
+  static_assert(sizeof(Header) == 4 * sizeof(uint64_t), "header layout");
+  if (G > 1 && e->hdr_epoch == e->ask_epoch && e->hdr_cache.size() == (size_t)G * 4) {
+    if (e->hdr_cache[(size_t)e->comm_rank * 4] != mine.digest)  // cannot happen by the rule below; an error beats a lone rank in a collective
+      return fail(e, YKPRED_E_STATE, "gather_bitmap_compressed: the class layout moved without an ask-table call");
+    // Headers only move with the class layout, and that only moves in calls every shard makes (ask_epoch): the exchange — a
+    // host round trip that would hold the host thread until the evaluation in front of it has drained — runs once per epoch;
+    // in the steady state of a scheduling cycle the gather is enqueued without waiting for anything.
+    memcpy(hdr.data(), e->hdr_cache.data(), (size_t)G * sizeof(Header));
+  } else if (G > 1) {
     HIPCHK(e->d_layout_hash.ensure((size_t)(G + 1) * sizeof(Header)));
     HIPCHK(hipMemcpyAsync(e->d_layout_hash.p, &mine, sizeof(mine), hipMemcpyHostToDevice, st));
     NCCLCHK(r->AllGather(e->d_layout_hash.p, (char*)e->d_layout_hash.p + sizeof(Header), sizeof(Header) / 8, ncclUint64, e->comm, st));
     HIPCHK(hipMemcpyAsync(hdr.data(), (char*)e->d_layout_hash.p + sizeof(Header), (size_t)G * sizeof(Header), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    e->hdr_cache.resize((size_t)G * 4);
+    memcpy(e->hdr_cache.data(), hdr.data(), (size_t)G * sizeof(Header));
+    e->hdr_epoch = e->ask_epoch;
   } else {
     hdr[0] = mine;
   }

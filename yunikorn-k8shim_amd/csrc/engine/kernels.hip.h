@@ -1417,6 +1417,19 @@ __global__ __launch_bounds__(kBlock) void k_query_pod(NodeTable t, SpecTable s, 
   reason_out[n] = reason;
 }
 
+// the same answers packed into one word per node: code | fit << 8 | (reason & 15) << 9 | (reason >> 8) << 13
+__global__ __launch_bounds__(kBlock) void k_query_pod_packed(NodeTable t, SpecTable s, int spec, int pin, unsigned pre_mask, unsigned filt_mask,
+                                                             unsigned* __restrict__ out) {
+  int n = blockIdx.x * kBlock + threadIdx.x;
+  if (n >= t.n) return;
+  NodeRegs nr;
+  load_node(t, n, &nr);
+  int code;
+  unsigned reason;
+  bool ok = eval_pair(s, spec, pin, n, nr, pre_mask, filt_mask, &code, &reason);
+  out[n] = (unsigned)(code & 0xff) | (ok ? 0x100u : 0u) | ((reason & 0xfu) << 9) | ((reason >> 8) << 13);
+}
+
 // Per-pair grid: blockIdx.x = chunk of 64 pods (the unbounded axis), blockIdx.y = group of 4 node words. lane = node, the wave walks the
 // 64 pods of its chunk (pod data wave-uniform), ballot → lane (i) keeps pod i's word → 64 row stores.
 __global__ __launch_bounds__(kBlock) void k_direct(NodeTable t, SpecTable s, int n_pods, const int* __restrict__ pod_spec,

@@ -103,6 +103,25 @@ struct ykhost {
     std::vector<uint8_t> fit, code;
     std::vector<uint32_t> reason;
   } answers;
+  // The RESIDENT answer. yunikorn-core walks asks, and for one ask calls Predicates() node after node; when an evaluation is
+  // current every one of those answers already sits in the bitmap. The mirror holds it in class-compressed form on the host
+  // ([classes][row_words], fetched once per evaluation on the first callback): a callback is then a lookup — ask → class
+  // (the engine's class index) → bit. Node columns that changed since the mirror was taken (AssumePod between two asks) are
+  // answered per pair by the device straight from the tables (ykpred_query); only a pair that does NOT fit needs the device
+  // for its failing plugin (one packed ykpred_query_pod per class, cached).
+  struct Resident {
+    bool valid = false;
+    int phase = -1, C = 0, N = 0, row_words = 0;
+    std::vector<uint64_t> rows;        // [C][row_words]; empty when C * row_words is over the budget (then: one row per ask, below)
+    std::vector<uint8_t> node_dirty;   // [N] 1 = the node changed since the mirror was taken
+    int n_dirty = 0;
+    std::unordered_map<int, std::vector<uint32_t>> class_codes;  // class → packed answers of ykpred_query_pod_packed (clean columns)
+    int peek_pod = -1;                 // per-ask form: the row of the ask that was asked about last
+    std::vector<uint64_t> peek_row;
+    std::vector<int32_t> order;        // bin-pack order of the evaluation (perm), fetched on the first ykhost_candidates call
+  } resident;
+  int64_t resident_budget_bytes = 256ll << 20;  // YKHOST_RESIDENT_MB
+  int64_t served_resident = 0, served_dirty_column = 0, served_query = 0, resident_fetches = 0, code_fetches = 0;
   int last_eval_phase = -1;           // 1 allocate / 0 reserve / -1 none: the phase of the bitmap on the device
   uint32_t last_eval_options = 0;
   bool dump_compact = false;                 // ykhost_set_dump_compact
@@ -138,6 +157,7 @@ struct ykhost {
     eval_dirty_rows.clear();
     table_shrunk = false;
     last_eval_phase = -1;
+    resident.valid = false;
     spec_templates.clear();
   }
 };
@@ -544,6 +564,7 @@ int node_row_sync(ykhost* h, int n) {
 
 int sync(ykhost* h) {
   if (h->dirty_all || h->dirty_pods || !h->dirty_nodes.empty() || !h->dirty_rows.empty() || h->table_shrunk) h->answers.pod = -1;
+  if (h->dirty_all || h->dirty_pods) h->resident.valid = false;  // dictionaries / class index are rebuilt
   if (h->dirty_all) {
     int rc = full_sync(h);
     if (rc) return rc;
@@ -580,6 +601,16 @@ void touch_node(ykhost* h, int n) {
   if (!h->dirty_all) {
     h->dirty_nodes.push_back(n);
     h->eval_dirty_nodes.push_back(n);
+  }
+  ykhost::Resident& R = h->resident;
+  if (R.valid) {
+    // topology constraints couple every node through the histograms: one changed node can move any column
+    if (h->enc.KD > 0 || n < 0 || n >= R.N) {
+      R.valid = false;
+    } else if (!R.node_dirty[(size_t)n]) {
+      R.node_dirty[(size_t)n] = 1;
+      if (++R.n_dirty > 4096) R.valid = false;  // mostly stale: the next evaluation brings a fresh one
+    }
   }
 }
 
@@ -960,6 +991,7 @@ ykhost_t* ykhost_create(int32_t device, char* err, int32_t errlen) {
   h->enc.R = 3;
   h->enc.KT = 1;
   h->enc.W = 1;
+  if (const char* v = getenv("YKHOST_RESIDENT_MB")) h->resident_budget_bytes = (int64_t)atoll(v) << 20;
   if (device >= 0 && recreate_engine(h) != 0) {
     copy_out(h->err, err, errlen);
     delete h;
@@ -977,6 +1009,7 @@ const char* ykhost_last_error(const ykhost_t* h) { return h ? h->err.c_str() : "
 int32_t ykhost_set_plugins(ykhost_t* h, uint32_t rp, uint32_t ap, uint32_t rf, uint32_t af) {
   YKHOST_LOCKED(h);
   h->answers.pod = -1;
+  h->resident.valid = false;
   h->res_pre = rp;
   h->alloc_pre = ap;
   h->res_filt = rf;
@@ -1516,8 +1549,9 @@ int32_t ykhost_evaluate(ykhost_t* h, int32_t allocate, uint32_t options) {
   h->eval_dirty_nodes.clear();
   h->eval_dirty_rows.clear();
   h->decisions_stale = !(options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS));
-  h->last_eval_phase = allocate ? 1 : 0;
+  h->last_eval_phase = (options & YKPRED_EVAL_DIRECT) || !(options & YKPRED_OUT_BITMAP) ? -1 : (allocate ? 1 : 0);
   h->last_eval_options = options;
+  h->resident.valid = false;  // a new answer: mirrored on the first callback that wants it
   return 0;
 }
 
@@ -1546,8 +1580,14 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
     rc = ykpred_eval(h->eng, &b);
     if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
   }
-  if (nodes_touched) {
-    rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.data());
+  // A node-sharded engine with topology constraints: the histograms couple the shards, so the step is COLLECTIVE — every
+  // shard's host calls ykhost_evaluate_dirty for it, whether or not one of ITS nodes changed, and the engine call below is
+  // entered with an empty node list too. Both ykpred_eval_nodes and the full ykpred_eval it may fall back to perform exactly
+  // one histogram exchange, so the shards stay in step whichever of the two each of them takes.
+  const bool collective_step = h->comm_attached && h->enc.KD > 0;
+  if (nodes_touched || collective_step) {
+    int32_t none = 0;
+    rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.empty() ? &none : h->eval_dirty_nodes.data());
     if (rc == YKPRED_E_STATE || rc == YKPRED_E_UNSUPPORTED) return ykhost_evaluate(h, allocate, options);
     if (rc) return fail(h, std::string("ykpred_eval_nodes: ") + ykpred_last_error(h->eng), rc);
   }
@@ -1587,20 +1627,100 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
       return fail(h, "ask is not evaluated by the engine (route it to the CPU predicate manager): " + un->second, YKHOST_E_UNSUPPORTED);
     }
   }
-  // one device round trip per (ask, phase): the answers for all nodes are fetched together and cached
-  if (h->answers.pod != pod || h->answers.phase != (allocate ? 1 : 0)) {
-    const size_t N = h->nodes.size();
-    h->answers.fit.assign(N, 0);
-    h->answers.code.assign(N, 0);
-    h->answers.reason.assign(N, 0);
-    rc = ykpred_query_pod(h->eng, pod, allocate ? h->alloc_pre : h->res_pre, allocate ? h->alloc_filt : h->res_filt, h->answers.fit.data(),
-                          h->answers.code.data(), h->answers.reason.data());
-    if (rc) return fail(h, std::string("ykpred_query_pod: ") + ykpred_last_error(h->eng), rc);
-    h->answers.pod = pod;
-    h->answers.phase = allocate ? 1 : 0;
+  const uint32_t pre = allocate ? h->alloc_pre : h->res_pre, filt = allocate ? h->alloc_filt : h->res_filt;
+  const int phase = allocate ? 1 : 0;
+  int fit = -1, code = 0;
+  uint32_t reason = 0;
+  bool have_code = false;
+  auto unpack = [&](uint32_t w) {
+    fit = (w >> 8) & 1;
+    code = (int)(w & 0xff);
+    reason = ((w >> 9) & 0xfu) | ((w >> 13) << YKPRED_REASON_RESOURCE_SHIFT);
+    have_code = true;
+  };
+  // (1) the resident answer: mirror it on the first callback after an evaluation of this phase
+  ykhost::Resident& R = h->resident;
+  if (!R.valid && h->last_eval_phase == phase && h->eval_dirty_nodes.empty() && h->eval_dirty_rows.empty()) {
+    int32_t C = 0;
+    if (ykpred_answer_state(h->eng, pre, filt, &C) == YKPRED_OK) {
+      ykpred_layout_t lay{};
+      ykpred_get_layout(h->eng, &lay);
+      R = ykhost::Resident{};
+      R.phase = phase;
+      R.C = C;
+      R.N = lay.num_nodes;
+      R.row_words = lay.row_words;
+      R.node_dirty.assign((size_t)R.N, 0);
+      bool ok = true;
+      if ((int64_t)C * R.row_words * 8 <= h->resident_budget_bytes) {
+        R.rows.assign((size_t)C * (size_t)R.row_words, 0);
+        ok = ykpred_read_class_rows(h->eng, R.rows.data()) == YKPRED_OK;
+        h->resident_fetches++;
+      }
+      R.valid = ok;
+    }
   }
-  const uint8_t fit = h->answers.fit[(size_t)node], code = h->answers.code[(size_t)node];
-  const uint32_t reason = h->answers.reason[(size_t)node];
+  int cls = -1;
+  if (R.valid && R.phase == phase && node < R.N && ykpred_pod_class(h->eng, pod, &cls) == YKPRED_OK && cls >= 0 && cls < R.C) {
+    if (R.node_dirty[(size_t)node]) {
+      // the column moved since the mirror was taken (AssumePod / UpdateNode): this one pair straight from the tables
+      uint8_t f = 0, c = 0;
+      uint32_t why = 0;
+      const int32_t p1 = pod, n1 = node;
+      rc = ykpred_query(h->eng, 1, &p1, &n1, pre, filt, &f, &c, &why);
+      if (rc) return fail(h, std::string("ykpred_query: ") + ykpred_last_error(h->eng), rc);
+      fit = f;
+      code = c;
+      reason = why;
+      have_code = true;
+      h->served_dirty_column++;
+    } else if (!R.rows.empty()) {
+      fit = (int)((R.rows[(size_t)cls * (size_t)R.row_words + (size_t)(node >> 6)] >> (node & 63)) & 1ull);
+      h->served_resident++;
+    } else {
+      // too many classes to mirror: the ask's own row (one small copy per ask), kept for its following callbacks
+      if (R.peek_pod != pod) {
+        R.peek_row.assign((size_t)R.row_words, 0);
+        R.peek_pod = ykpred_peek_row(h->eng, pod, pre, filt, R.peek_row.data(), nullptr, nullptr) == YKPRED_OK ? pod : -1;
+        h->resident_fetches++;
+      }
+      if (R.peek_pod == pod) {
+        fit = (int)((R.peek_row[(size_t)(node >> 6)] >> (node & 63)) & 1ull);
+        h->served_resident++;
+      }
+    }
+    if (fit == 0 && !have_code) {
+      // the failing plugin of the pair: the packed per-node answers of this CLASS (its members share every projection a
+      // plugin sees), one device round trip per class
+      auto it = R.class_codes.find(cls);
+      if (it == R.class_codes.end()) {
+        if (R.class_codes.size() >= 1024) R.class_codes.clear();
+        std::vector<uint32_t> packed((size_t)R.N, 0);
+        rc = ykpred_query_pod_packed(h->eng, pod, pre, filt, packed.data());
+        if (rc) return fail(h, std::string("ykpred_query_pod_packed: ") + ykpred_last_error(h->eng), rc);
+        it = R.class_codes.emplace(cls, std::move(packed)).first;
+        h->code_fetches++;
+      }
+      unpack(it->second[(size_t)node]);
+    }
+  }
+  // (2) no resident answer for this pair: one device round trip per (ask, phase), the answers for all nodes cached
+  if (fit < 0) {
+    if (h->answers.pod != pod || h->answers.phase != phase) {
+      const size_t N = h->nodes.size();
+      h->answers.fit.assign(N, 0);
+      h->answers.code.assign(N, 0);
+      h->answers.reason.assign(N, 0);
+      rc = ykpred_query_pod(h->eng, pod, pre, filt, h->answers.fit.data(), h->answers.code.data(), h->answers.reason.data());
+      if (rc) return fail(h, std::string("ykpred_query_pod: ") + ykpred_last_error(h->eng), rc);
+      h->answers.pod = pod;
+      h->answers.phase = phase;
+    }
+    fit = h->answers.fit[(size_t)node];
+    code = h->answers.code[(size_t)node];
+    reason = h->answers.reason[(size_t)node];
+    h->served_query++;
+  }
   if (fit) {
     copy_out("", plugin, plugin_len);
     copy_out("", msg, msg_len);
@@ -1608,6 +1728,62 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
   }
   copy_out(code < 9 ? kPluginNames[code] : "", plugin, plugin_len);
   copy_out(compose_message(h, *h->pending[(size_t)pod], *h->nodes[(size_t)node], code, reason), msg, msg_len);
+  return 0;
+}
+
+// The first `k` feasible nodes of an ask in bin-pack order (what the core's node iterator would find, without one callback
+// per node): the ask's row of the resident answer walked in the order of the evaluation that produced the decisions.
+// → number of nodes written; YKPRED_E_STATE (-4) when no evaluation with decisions of this phase is current (a node or
+// ask changed since: evaluate first), YKHOST_E_UNSUPPORTED for a routed ask.
+int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k, int32_t* out_nodes) {
+  YKHOST_LOCKED(h);
+  if (pod < 0 || pod >= (int)h->pending.size() || k < 0 || (k > 0 && !out_nodes)) return fail(h, "bad argument", -1);
+  if (k == 0 || h->nodes.empty()) return 0;
+  char plugin[8], msg[8];
+  int rc = ykhost_predicates(h, pod, 0, allocate, plugin, sizeof plugin, msg, sizeof msg);  // sync + routing + mirrors the answer
+  if (rc < 0) return rc;
+  ykhost::Resident& R = h->resident;
+  const uint32_t pre = allocate ? h->alloc_pre : h->res_pre, filt = allocate ? h->alloc_filt : h->res_filt;
+  int cls = -1;
+  if (!R.valid || R.phase != (allocate ? 1 : 0) || R.n_dirty > 0 || h->decisions_stale || !h->eval_dirty_nodes.empty() ||
+      ykpred_pod_class(h->eng, pod, &cls) != YKPRED_OK || cls < 0 || cls >= R.C)
+    return fail(h, "no current evaluation with decisions for this ask (a node or the ask changed since): evaluate first", YKPRED_E_STATE);
+  if (R.order.empty()) {
+    R.order.assign((size_t)R.N, 0);
+    if (ykpred_read_order(h->eng, R.order.data()) != YKPRED_OK) {
+      R.order.clear();
+      return fail(h, std::string("ykpred_read_order: ") + ykpred_last_error(h->eng), YKPRED_E_STATE);
+    }
+  }
+  const uint64_t* row = nullptr;
+  if (!R.rows.empty()) {
+    row = R.rows.data() + (size_t)cls * (size_t)R.row_words;
+  } else {
+    if (R.peek_pod != pod) {
+      R.peek_row.assign((size_t)R.row_words, 0);
+      R.peek_pod = ykpred_peek_row(h->eng, pod, pre, filt, R.peek_row.data(), nullptr, nullptr) == YKPRED_OK ? pod : -1;
+    }
+    if (R.peek_pod != pod) return fail(h, std::string("ykpred_peek_row: ") + ykpred_last_error(h->eng), YKPRED_E_STATE);
+    row = R.peek_row.data();
+  }
+  int found = 0;
+  for (int i = 0; i < R.N && found < k; ++i) {
+    const int n = R.order[(size_t)i];
+    if ((row[(size_t)(n >> 6)] >> (n & 63)) & 1ull) out_nodes[found++] = n;
+  }
+  return found;
+}
+
+// out[0] = Predicates() calls answered from the mirrored resident answer, [1] = answered per pair because the node's column
+// changed since, [2] = answered by a whole-ask device query (no current evaluation), [3] = answer fetches (class-row mirror
+// or single rows), [4] = failing-plugin fetches (one per class)
+int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5) {
+  YKHOST_LOCKED(h);
+  out5[0] = h->served_resident;
+  out5[1] = h->served_dirty_column;
+  out5[2] = h->served_query;
+  out5[3] = h->resident_fetches;
+  out5[4] = h->code_fetches;
   return 0;
 }
 

@@ -284,6 +284,28 @@ class GpuPredicateManager:
         rc = self._check(self._L.ykhost_ask_supported(self._h, p, buf, 600))
         return rc == 1, buf.value.decode()
 
+    def candidates(self, pod, k, allocate=True):
+        """The first k feasible nodes of the ask in bin-pack order, from the resident answer (needs a current evaluation
+        with decisions; raises otherwise)."""
+        p = pod if isinstance(pod, int) else self.pod_index(pod)
+        out = np.full(max(k, 1), -1, dtype=np.int32)
+        n = self._check(self._L.ykhost_candidates(self._h, p, 1 if allocate else 0, k, out.ctypes.data))
+        return out[:n].copy()
+
+    def resident_stats(self):
+        out = np.zeros(5, dtype=np.int64)
+        self._L.ykhost_resident_stats(self._h, out.ctypes.data)
+        return dict(zip(["served_resident", "served_dirty_column", "served_query", "answer_fetches", "code_fetches"], out.tolist()))
+
+    def peek_row(self, pod, allocate=True):
+        """(row[row_words] uint64, count, decision) of one ask straight from the bitmap of the last evaluation (ykpred_peek_row)."""
+        lay = self.layout()
+        row = np.zeros(lay.row_words, dtype=np.uint64)
+        cnt, dec = C.c_int32(0), C.c_int32(0)
+        self._pcheck(self._P.ykpred_peek_row(self.engine, pod, self._masks[1] if allocate else self._masks[0],
+                                             self._masks[3] if allocate else self._masks[2], row.ctypes.data, C.byref(cnt), C.byref(dec)))
+        return row, cnt.value, dec.value
+
     def routing_stats(self):
         out = np.zeros(3, dtype=np.int64)
         self._L.ykhost_routing_stats(self._h, out.ctypes.data)
@@ -320,6 +342,7 @@ class GpuPredicateManager:
         a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0) | ((variant & 3) << 16)
         a.options |= (EVAL_SPREAD_COUNT_ONLY if spread_count_only else 0) | (EVAL_SPREAD_COUNTS_READY if spread_counts_ready else 0)
         a.bitmap = None if bitmap is None else bitmap.data_ptr()
+        a.bitmap_rows = 0 if bitmap is None else int(bitmap.shape[0])  # a caller-owned bitmap states the rows it holds
         a.counts = None if counts is None else counts.data_ptr()
         a.decisions = None if decisions is None else decisions.data_ptr()
         a.decision_keys = None if keys is None else keys.data_ptr()
