@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=5, help="steps run with per-kernel HIP events for `roofline`")
     ap.add_argument("--no-variants", action="store_true", help="N=1: skip the `variants` and `end_to_end` legs")
     ap.add_argument("--variant-steps", type=int, default=5)
+    ap.add_argument("--no-configs4", action="store_true", help="N=1: leave the configs[4] (100k x 5M, one GPU) leg out of `variants`")
     return ap.parse_args()
 
 
@@ -462,6 +463,17 @@ def main():
                 variants[name] = timed_leg(pkg, dev, stream, a, a.variant_steps, 2, 2, **base, **kw)
             except Exception as exc:  # noqa: BLE001
                 variants[name] = {"error": str(exc)}
+        if (a.nodes, a.pods) == (50_000, 1_000_000) and not a.no_configs4:
+            # BASELINE configs[4] whole on ONE GPU: 100 000 nodes x 5 000 000 asks, the full Filter set (10 % of the templates carry
+            # a hard zone-spread constraint: PodTopologySpread PreFilter histograms + Filter) + bin-pack decisions; 62.6 GB bitmap
+            try:
+                variants["configs4_one_gpu"] = dict(
+                    timed_leg(pkg, dev, stream, a, a.variant_steps, 1, 2, seed=SEED + 4, num_nodes=100_000, num_pods=5_000_000,
+                              num_templates=a.templates, node_affinity=1, spread=1),
+                    workload="configs[4]: 100k nodes x 5M pods, full Filter set (NodeResourcesFit, TaintToleration, NodeAffinity, "
+                             "PodTopologySpread DoNotSchedule on 10 % of the templates, ...) + bin-pack decisions, one GPU")
+            except Exception as exc:  # noqa: BLE001
+                variants["configs4_one_gpu"] = {"error": str(exc)}
         try:
             e2e = timed_leg(pkg, dev, stream, a, 1, 0, 0, **base, num_templates=a.templates, gang_size=gang)
             end_to_end = dict(e2e["cold_pass"], note="one cold pass of the default workload: objects → dictionaries/tables (encode) → H2D "

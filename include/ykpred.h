@@ -116,7 +116,7 @@ typedef struct ykpred_config {
                                [5] = average members per combine chunk below which the wave-per-chunk combine runs (16, -1 never);
                                [6] = band height of the zone-A row layout in windows (4..256, multiple of 4; 0 = chosen from the row
                                length so that classes of ~100 asks still get band rows; -1 = no band layout);
-                               [7] == 1 runs the class-by-class writer AFTER the band writer instead of beside it */
+                               [7] == 2 runs the class-by-class writer BESIDE the band writer on a third stream (measured slower) */
 } ykpred_config_t;
 
 /* Node table, structure-of-arrays. Arrays documented [A][count] are A consecutive runs of `count` values. */

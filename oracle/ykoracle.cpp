@@ -101,7 +101,9 @@ struct SpreadConstraint {
 struct PodAffinityTerm {  // v1.PodAffinityTerm (required terms only)
   LabelSelector selector;
   std::vector<std::string> namespaces;
-  bool has_namespace_selector = false;  // not modelled (needs Namespace objects): rejected at load time
+  // namespaceSelector: {} = labels.Everything() selects every namespace; a non-empty one needs Namespace objects (not modelled:
+  // rejected at load time)
+  bool has_namespace_selector = false;
   std::string topology_key;
 };
 struct HostPort {  // v1.ContainerPort with HostPort > 0, sanitized like HostPortInfo.sanitize ("" ip → 0.0.0.0, "" protocol → TCP)
@@ -604,10 +606,15 @@ static std::unique_ptr<Pod> read_pod(const oj::Node& v, std::string* err) {
         }
         if (const oj::Node* nss = t->get_nn("namespaces"))
           for (auto& x : nss->arr) term.namespaces.push_back(x->s);
-        term.has_namespace_selector = t->get_nn("namespaceSelector") != nullptr;
         term.topology_key = t->str_or("topologyKey", "");
-        if (term.has_namespace_selector) *err = "podAffinityTerm.namespaceSelector not modelled";
-        if (t->get_nn("matchLabelKeys") || t->get_nn("mismatchLabelKeys")) *err = "podAffinityTerm.matchLabelKeys not modelled";
+        if (const oj::Node* nsel = t->get_nn("namespaceSelector")) {
+          term.has_namespace_selector = true;
+          const oj::Node* ml = nsel->get_nn("matchLabels");
+          const oj::Node* me = nsel->get_nn("matchExpressions");
+          if ((ml && !ml->obj.empty()) || (me && !me->arr.empty())) *err = "podAffinityTerm.namespaceSelector with requirements not modelled (needs Namespace labels)";
+        }
+        // matchLabelKeys / mismatchLabelKeys: the API server merges them into labelSelector when the pod is created; the
+        // scheduler's framework.newAffinityTerm reads labelSelector, namespaces and namespaceSelector only
         out->push_back(std::move(term));
       }
     };
@@ -649,7 +656,6 @@ static std::unique_ptr<Pod> read_pod(const oj::Node& v, std::string* err) {
       sc.node_taints_policy = c->str_or("nodeTaintsPolicy", "Ignore");
       if (const oj::Node* mk = c->get_nn("matchLabelKeys"))
         for (auto& x : mk->arr) sc.match_label_keys.push_back(x->s);
-      if (!sc.match_label_keys.empty()) *err = "matchLabelKeys not modelled";
       p->spread.push_back(std::move(sc));
     }
   return p;
@@ -733,6 +739,7 @@ struct FitState {  // noderesources preFilterState
 struct SpreadState {
   bool written = false;
   std::vector<const SpreadConstraint*> constraints;
+  std::vector<LabelSelector> selectors;                    // [constraint] labelSelector with the matchLabelKeys folded in
   std::vector<std::map<std::string, int>> value_to_match;  // [constraint] TpValueToMatchNum
   std::vector<int> min_match;                              // [constraint] CriticalPaths[i][0].MatchNum
 };
@@ -866,10 +873,27 @@ static Status spread_prefilter(const Pod& p, const std::vector<NodeInfo>& all, C
     if (c.when_unsatisfiable == "DoNotSchedule") s.constraints.push_back(&c);
   // no hard constraints (system defaults are ScheduleAnyway) ⇒ Skip
   if (s.constraints.empty()) return {Status::Skip, ""};
-  bool sel_err = false;
+  // filterTopologySpreadConstraints: matchLabelKeys are folded into the selector — for every listed key the incoming pod
+  // carries, "key = the pod's value" is ANDed on (mergeLabelSetWithSelector; labels.Nothing() of a nil selector stays Nothing)
+  s.selectors.clear();
   for (auto* c : s.constraints) {
+    LabelSelector merged = c->selector;
+    if (merged.present)
+      for (const std::string& key : c->match_label_keys) {
+        auto own = p.labels.find(key);
+        if (own == p.labels.end()) continue;
+        Requirement eq;  // labels.SelectorFromSet: one equality requirement per key, ANDed with whatever the selector already asks of it
+        eq.key = key;
+        eq.op = "In";
+        eq.values.push_back(own->second);
+        merged.match_exprs.push_back(std::move(eq));
+      }
+    s.selectors.push_back(std::move(merged));
+  }
+  bool sel_err = false;
+  for (auto& sel : s.selectors) {
     bool e = false;
-    selector_matches(c->selector, p.labels, &e);
+    selector_matches(sel, p.labels, &e);
     sel_err |= e;
   }
   if (sel_err) return {Status::Error, "invalid label selector in topologySpreadConstraints"};
@@ -888,11 +912,11 @@ static Status spread_prefilter(const Pod& p, const std::vector<NodeInfo>& all, C
       if (c->node_affinity_policy == "Honor" && !required_node_affinity_matches(p, node)) continue;
       if (c->node_taints_policy == "Honor" && find_untolerated_taint(node, p)) continue;
       int count = 0;
-      if (!selector_is_empty(c->selector)) {  // countPodsMatchSelector
+      if (!selector_is_empty(s.selectors[i])) {  // countPodsMatchSelector
         for (const Pod* ep : ni.pods) {
           if (ep->terminating || ep->ns != p.ns) continue;
           bool e = false;
-          if (selector_matches(c->selector, ep->labels, &e)) ++count;
+          if (selector_matches(s.selectors[i], ep->labels, &e)) ++count;
         }
       }
       s.value_to_match[i][node.labels.at(c->topology_key)] += count;
@@ -917,7 +941,7 @@ static Status spread_filter(const Pod& p, const CycleState& st, const NodeInfo& 
     const int domains = static_cast<int>(s.value_to_match[i].size());
     if (domains < (c->has_min_domains ? c->min_domains : 1)) min_match = 0;
     bool e = false;
-    int64_t self = selector_matches(c->selector, p.labels, &e) ? 1 : 0;
+    int64_t self = selector_matches(s.selectors[i], p.labels, &e) ? 1 : 0;
     auto mit = s.value_to_match[i].find(lit->second);
     int64_t match = mit == s.value_to_match[i].end() ? 0 : mit->second;
     int64_t skew = match + self - min_match;
@@ -930,8 +954,10 @@ static Status spread_filter(const Pod& p, const CycleState& st, const NodeInfo& 
 // framework.AffinityTerm.Matches(pod, nil): the term's namespaces (default: the OWNING pod's namespace) contain the
 // pod's namespace and the selector matches its labels.
 static bool affinity_term_matches(const PodAffinityTerm& t, const std::string& owner_ns, const Pod& target) {
-  bool ns_ok = t.namespaces.empty() ? target.ns == owner_ns
-                                    : std::find(t.namespaces.begin(), t.namespaces.end(), target.ns) != t.namespaces.end();
+  // newAffinityTerm: no namespaces and a nil namespaceSelector = the owner's namespace; Matches: the namespace is listed OR the
+  // namespaceSelector (here only ever Everything) selects it
+  bool ns_ok = t.has_namespace_selector ||
+               (t.namespaces.empty() ? target.ns == owner_ns : std::find(t.namespaces.begin(), t.namespaces.end(), target.ns) != t.namespaces.end());
   if (!ns_ok) return false;
   bool e = false;
   return selector_matches(t.selector, target.labels, &e);
@@ -1113,6 +1139,84 @@ static void run_filters(const Pod& p, const NodeInfo& ni, uint32_t filt_mask, ui
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same verdicts for ONE pod against MANY nodes with the PreFilter pass run once. Nothing a PreFilter plugin writes into
+// the cycle state depends on the candidate node — the reference rebuilds identical state for every pair (:196,202,221-254)
+// and only the membership test of the merged NodeNames result (:247-250) looks at the node. This form exists so that the
+// parity tests can afford BASELINE configs[4] (100 000 nodes with hard spread constraints: the per-pair form costs O(N) node
+// visits per PAIR); tests/test_oracle_golden.py holds it equal to pod_fits_node, pair by pair, on random clusters.
+// ---------------------------------------------------------------------------------------------------
+struct PreFilterReplay {
+  CycleState st;
+  uint32_t skip = 0;
+  struct Step {
+    bool failed = false;        // the plugin returned a non-Skip failure: every node that got this far fails with `fail`
+    Outcome fail;
+    PreFilterResult merged;     // result merged up to and including this plugin
+    int code = kCodeNone;
+  };
+  std::vector<Step> steps;
+};
+static PreFilterReplay prefilter_once(const Snapshot& snap, const Pod& p, uint32_t pre_mask) {
+  PreFilterReplay r;
+  PreFilterResult merged;
+  struct Pre {
+    uint32_t bit;
+    int code;
+  };
+  static const Pre order[] = {{kNodeAffinity, kCodeNodeAffinity},
+                              {kNodePorts, kCodeNodePorts},
+                              {kNodeResourcesFit, kCodeNodeResourcesFit},
+                              {kPodTopologySpread, kCodePodTopologySpread},
+                              {kInterPodAffinity, kCodeInterPodAffinity}};
+  for (const Pre& pl : order) {
+    if (!(pre_mask & pl.bit)) continue;
+    PreFilterResult res;
+    Status s;
+    if (pl.bit == kNodeAffinity)
+      s = nodeaffinity_prefilter(p, r.st, &res);
+    else if (pl.bit == kNodePorts)
+      s = nodeports_prefilter(p, r.st);
+    else if (pl.bit == kNodeResourcesFit)
+      s = fit_prefilter(p, r.st);
+    else if (pl.bit == kPodTopologySpread)
+      s = spread_prefilter(p, snap.nodes, r.st);
+    else
+      s = interpod_prefilter(p, snap.nodes, snap.nodes_with_anti, r.st);
+    PreFilterReplay::Step step;
+    step.code = pl.code;
+    if (s.is_skip()) {
+      r.skip |= pl.bit;
+    } else if (!s.is_success()) {
+      step.failed = true;
+      step.fail.fit = false;
+      step.fail.msg = s.msg;
+      step.fail.plugin = s.is_rejected() ? kCodeNone : pl.code;
+      r.steps.push_back(std::move(step));
+      break;  // (:236-244 return here: later plugins never run)
+    }
+    merged.merge(res);
+    step.merged = merged;
+    r.steps.push_back(std::move(step));
+  }
+  return r;
+}
+static Outcome pod_fits_node_replayed(const PreFilterReplay& r, const Pod& p, const NodeInfo& ni, uint32_t filt_mask) {
+  for (const PreFilterReplay::Step& step : r.steps) {
+    if (step.failed) return step.fail;
+    if (!step.merged.all_nodes && !step.merged.names.count(ni.node.name)) {
+      Outcome out;
+      out.fit = false;
+      out.plugin = step.code;
+      out.msg = "node not eligible";
+      return out;
+    }
+  }
+  Outcome out;
+  run_filters(p, ni, filt_mask, r.skip, r.st, &out);
+  return out;
+}
+
 // podFitsNode (:206-219) with a NEW CycleState per call (:196,202).
 static Outcome pod_fits_node(const Snapshot& snap, const Pod& p, const NodeInfo& ni, uint32_t pre_mask, uint32_t filt_mask) {
   Outcome out;
@@ -1218,6 +1322,25 @@ int orc_eval_grid(void* h, const int* pods, int np, const int* nodes, int nn, un
     for (int j = 0; j < nn; ++j) {
       const orc::NodeInfo& ni = s->nodes[static_cast<size_t>(nodes ? nodes[j] : j)];
       orc::Outcome o = orc::pod_fits_node(*s, p, ni, pre_mask, filt_mask);
+      fit[static_cast<size_t>(i) * static_cast<size_t>(nn) + static_cast<size_t>(j)] = o.fit ? 1 : 0;
+      if (plugin) plugin[static_cast<size_t>(i) * static_cast<size_t>(nn) + static_cast<size_t>(j)] = static_cast<uint8_t>(o.plugin);
+    }
+  }
+  return 0;
+}
+
+// orc_eval_grid with the PreFilter pass of a pod run once for all its nodes (see prefilter_once)
+int orc_eval_rows(void* h, const int* pods, int np, const int* nodes, int nn, unsigned pre_mask, unsigned filt_mask, uint8_t* fit,
+                  uint8_t* plugin, int threads) {
+  Snapshot* s = static_cast<Snapshot*>(h);
+  if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+  for (int i = 0; i < np; ++i) {
+    const orc::Pod& p = *s->pending[static_cast<size_t>(pods ? pods[i] : i)];
+    const orc::PreFilterReplay replay = orc::prefilter_once(*s, p, pre_mask);
+    for (int j = 0; j < nn; ++j) {
+      const orc::NodeInfo& ni = s->nodes[static_cast<size_t>(nodes ? nodes[j] : j)];
+      orc::Outcome o = orc::pod_fits_node_replayed(replay, p, ni, filt_mask);
       fit[static_cast<size_t>(i) * static_cast<size_t>(nn) + static_cast<size_t>(j)] = o.fit ? 1 : 0;
       if (plugin) plugin[static_cast<size_t>(i) * static_cast<size_t>(nn) + static_cast<size_t>(j)] = static_cast<uint8_t>(o.plugin);
     }

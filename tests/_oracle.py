@@ -63,6 +63,7 @@ def lib():
                                      ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
         L.orc_eval_grid.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                     ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.orc_eval_rows.argtypes = L.orc_eval_grid.argtypes
         L.orc_preemption.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_uint, ctypes.c_uint]
         L.orc_pod_request_json.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
@@ -109,13 +110,17 @@ class Oracle:
             raise IndexError("pod/node index out of range")
         return bool(r), PLUGIN_NAMES[plugin.value], msg.value.decode()
 
-    def eval_grid(self, pods=None, nodes=None, pre_mask=ALL, filt_mask=ALL, threads=1, want_plugin=False):
+    def eval_grid(self, pods=None, nodes=None, pre_mask=ALL, filt_mask=ALL, threads=1, want_plugin=False, prefilter_once=False):
+        """[len(pods)][len(nodes)] verdicts (+ failing-plugin codes). prefilter_once: the PreFilter pass of a pod is run once for
+        all its nodes instead of once per pair — same verdicts (held equal by tests/test_oracle_golden.py), affordable at 10^5
+        nodes with hard spread constraints."""
         pods = np.arange(self.num_pods, dtype=np.int32) if pods is None else np.ascontiguousarray(pods, dtype=np.int32)
         nodes = np.arange(self.num_nodes, dtype=np.int32) if nodes is None else np.ascontiguousarray(nodes, dtype=np.int32)
         fit = np.zeros((len(pods), len(nodes)), dtype=np.uint8)
         plug = np.zeros((len(pods), len(nodes)), dtype=np.uint8) if want_plugin else None
-        lib().orc_eval_grid(self._h, pods.ctypes.data, len(pods), nodes.ctypes.data, len(nodes), pre_mask, filt_mask,
-                            fit.ctypes.data, plug.ctypes.data if want_plugin else None, threads)
+        fn = lib().orc_eval_rows if prefilter_once else lib().orc_eval_grid
+        fn(self._h, pods.ctypes.data, len(pods), nodes.ctypes.data, len(nodes), pre_mask, filt_mask,
+           fit.ctypes.data, plug.ctypes.data if want_plugin else None, threads)
         return (fit, plug) if want_plugin else fit
 
     def preemption(self, pod, node, victims, start, pre_mask=ALL, filt_mask=ALL):

@@ -202,3 +202,25 @@ def test_spread_state_is_kept_per_constraint():
         assert not ok and "duplicate topologyKey" in why
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("allocate", [True, False])
+def test_prefilter_once_form_equals_the_per_pair_form(seed, allocate):
+    """orc_eval_rows runs a pod's PreFilter pass once for all its nodes; orc_eval_grid restates the reference line by line (a
+    new CycleState and a full PreFilter pass per pair, predicate_manager.go:196,202,221-254). Same fit bit and same failing
+    plugin for every pair — with hard spread constraints, inter-pod affinity, NodeNames PreFilter results and PreFilter
+    rejections in the mix — is what lets the full-grid parity test afford BASELINE configs[4]."""
+    import _gen
+    snap = _gen.random_snapshot(9100 + seed, n_nodes=60 + 11 * seed, n_pods=50, spread=seed % 2 == 0, interpod=seed % 3 != 1)
+    o = orc.Oracle(snap)
+    pre, filt = (orc.ALL, orc.ALL) if allocate else (orc.RESERVE_PRE, orc.RESERVE_FILT)
+    a, pa = o.eval_grid(pre_mask=pre, filt_mask=filt, threads=4, want_plugin=True)
+    b, pb = o.eval_grid(pre_mask=pre, filt_mask=filt, threads=4, want_plugin=True, prefilter_once=True)
+    assert (a == b).all() and (pa == pb).all()
+    assert 0 < a.sum() < a.size
+    # plugin subsets: a Filter without its PreFilter (Error status), PreFilters alone
+    for pre2, filt2 in ((0, orc.ALL), (orc.ALL, 0), (orc.PLUGIN_BITS["NodeAffinity"], orc.PLUGIN_BITS["NodeAffinity"] | orc.PLUGIN_BITS["PodTopologySpread"])):
+        a, pa = o.eval_grid(pre_mask=pre2, filt_mask=filt2, threads=4, want_plugin=True)
+        b, pb = o.eval_grid(pre_mask=pre2, filt_mask=filt2, threads=4, want_plugin=True, prefilter_once=True)
+        assert (a == b).all() and (pa == pb).all()

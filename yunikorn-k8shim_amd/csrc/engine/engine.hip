@@ -174,7 +174,8 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
-  bool combine_beside = true;      // tunable: cfg.reserved[7] == 1 runs the class-by-class writer after the band writer, not beside it
+  int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
+  bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
@@ -412,9 +413,12 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
         if (class_size[(size_t)c] >= need) rows += class_size[(size_t)c];
       return rows;
     };
+    // (measured, profiles/r03_writer_knobs.txt: where a tall band already takes most rows, admitting the smaller classes too
+    // LOSES — many short pieces per band slow the band writer more than the chunk writer gains; a shorter band is for
+    // populations the tall one would leave almost entirely to the chunk writer)
     const long best = coverage(s_min);
     S = 128;
-    while (S > s_min && (double)coverage(S) < 0.97 * (double)best) S /= 2;
+    while (S > s_min && (double)coverage(S) < 0.5 * (double)best) S /= 2;
   }
   while (S > 4 && (long)S * win / row_b >= (1L << 21)) S -= 4;  // the builder's sort key holds the row-in-band in 21 bits
   e->band_steps_now = S;
@@ -946,11 +950,14 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (cfg->reserved[6] < 0) e->bands_enabled = false;
   // the band kernel packs the step-in-band into 8 bits of its class key: at most 256 windows per band
   if (cfg->reserved[6] > 0) e->band_steps = std::min(256, std::max(4, (cfg->reserved[6] + 3) / 4 * 4));
-  e->combine_beside = cfg->reserved[7] != 1;
+  // measured (profiles/r03_writer_knobs.txt): beside the band writer the chunk kernel's workgroups upset the one-workgroup-per-CU
+  // placement the band writer's store pattern lives on (default workload 1.22 -> 1.45 ms) and gain nothing where zone B is large
+  e->combine_beside = cfg->reserved[7] == 2;
   {
     int lds = 0;  // what a workgroup may ask for with hipFuncAttributeMaxDynamicSharedMemorySize (64 KiB on gfx90a / gfx942, 160 KiB on gfx950)
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) e->max_lds_bytes = lds;
   }
+  if (const char* v = getenv("YKPRED_DECIDE_GROUPS_FROM")) e->decide_groups_from = atoi(v);
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -1630,8 +1637,15 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       launch_ballot_planes(sb, e->d_perm.as<int>(), "k_planes(ranked)");
     }
     tm.begin(sb);
-    hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
-                       pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
+    if (e->C >= e->decide_groups_from) {
+      // many classes: four per wave (k_decide_groups)
+      const int per_block = ykk::kWavesPerBlock * ykk::kDecideGroups;
+      hipLaunchKernelGGL(ykk::k_decide_groups, dim3((unsigned)((e->C + per_block - 1) / per_block)), dim3(ykk::kBlock), 0, sb, ct, pr, e->C,
+                         e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
+    } else {
+      hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
+                         pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
+    }
     tm.end(sb, "k_decide");
     HIPCHK(hipEventRecord(e->ev_join, sb));
   }

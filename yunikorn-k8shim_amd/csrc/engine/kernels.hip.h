@@ -1210,6 +1210,74 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
   if (lane == 0) class_best[cls] = best;
 }
 
+// Sub-wave form for many small classes (every ask its own template / request vector: 10^5 ... 10^6 classes). The whole-wave
+// form above spends one wave — a chain of dependent loads class -> signatures -> row ids -> plane words, and 5 x 512 bytes of
+// plane words per step — on a class whose first feasible node usually sits in the first few hundred positions of the bin-pack
+// order. Here a wave serves kDecideGroups classes at once: group g = 16 lanes = 16 words = 1 024 positions per step; the
+// classes' table entries are fetched by the lanes in parallel (one load round for four classes), plane words are loaded
+// lane-predicated as above, and a group that has found its node idles while the others go on.
+constexpr int kDecideGroups = 4, kDecideLanes = kWave / kDecideGroups;
+__global__ __launch_bounds__(kBlock) void k_decide_groups(ClassTable ct, Planes ranked, int n_classes, int row_words, const int* __restrict__ perm,
+                                                          const int* __restrict__ rank, int pin_enabled, int* __restrict__ class_best) {
+  const int wave = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int lane = threadIdx.x % kWave, g = lane / kDecideLanes, l = lane % kDecideLanes;
+  const int cls_raw = wave * kDecideGroups + g;
+  const bool live = cls_raw < n_classes;
+  const int cls = live ? cls_raw : n_classes - 1;
+  const bool all_fail = pin_enabled & 2;
+  // every lane of the group reads the same table entries (one broadcast load each): no cross-lane traffic needed afterwards
+  const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
+  const int pin = (pin_enabled & 1) ? ct.pin[cls] : -1;
+  const u64* row[kMaxClassRows];
+  int n_rows = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxClassRows; ++i) row[i] = nullptr;
+  auto add = [&](const u64* p) {
+#pragma unroll
+    for (int i = 0; i < kMaxClassRows; ++i)
+      if (i == n_rows) row[i] = p;
+    ++n_rows;
+  };
+  if (ranked.tol && st >= 0) add(ranked.tol + (size_t)st * ranked.stride);
+  if (ranked.aff && sa >= 0) add(ranked.aff + (size_t)sa * ranked.stride);
+  if (ranked.spread && ss >= 0) add(ranked.spread + (size_t)ss * ranked.stride);
+  if (ranked.res && sr >= 0) {
+    const int* rr = ranked.res_rows + (size_t)sr * ranked.res_slots;
+    for (int k = 0; k < ranked.res_slots; ++k) {
+      const int r = rr[k];
+      if (r >= 0) add(ranked.res + (size_t)r * ranked.stride);
+    }
+  }
+  auto word_at = [&](int w) {
+    u64 x = w < row_words ? ~0ull : 0ull;
+#pragma unroll
+    for (int i = kMaxClassRows - 1; i >= 0; --i)
+      if (i < n_rows && x) x &= row[i][w];
+    return x;
+  };
+  int best = -1;
+  bool done = !live || pin == -2 || all_fail;
+  if (!done && pin >= 0) {
+    const int pos = rank[pin];
+    const u64 x = word_at(pos >> 6);
+    best = ((x >> (pos & 63)) & 1ull) ? pin : -1;
+    done = true;
+  }
+  for (int base = 0; base < row_words; base += kDecideLanes) {
+    if (__ballot(!done) == 0) break;
+    const u64 x = done ? 0ull : word_at(base + l);
+    const u64 any = __ballot(x != 0);
+    const unsigned mine = (unsigned)((any >> (g * kDecideLanes)) & ((1u << kDecideLanes) - 1u));
+    const int first = mine ? __ffs((int)mine) - 1 : 0;  // first lane of MY group with a feasible position
+    const u64 xw = __shfl(x, g * kDecideLanes + first, kWave);  // (executed by every lane: the exchange stays convergent)
+    if (!done && mine) {
+      best = perm[(base + first) * kWave + (__ffsll((long long)xw) - 1)];
+      done = true;
+    }
+  }
+  if (live && l == 0) class_best[cls] = best;
+}
+
 // decision key = order-preserving signed image of the node's sortable score key (smaller = earlier in bin-pack order)
 __global__ __launch_bounds__(kBlock) void k_scatter(int n_pods, const int* __restrict__ pod_class, const int* __restrict__ class_count,
                                                     const int* __restrict__ class_best, const u64* __restrict__ node_key,

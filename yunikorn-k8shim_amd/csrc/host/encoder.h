@@ -194,8 +194,9 @@ struct SelectorClass {
 };
 // framework.AffinityTerm.Matches(pod, nil): namespace rule (default = owner's namespace) and label selector
 inline bool pod_term_matches(const PodAffinityTerm& t, const std::string& owner_ns, const std::string& target_ns, const StrMap& target_labels) {
-  bool ns_ok = t.namespaces.empty() ? target_ns == owner_ns
-                                    : std::find(t.namespaces.begin(), t.namespaces.end(), target_ns) != t.namespaces.end();
+  // namespaces ∪ namespaceSelector; both empty/nil = the owner's namespace (framework.newAffinityTerm / getNamespacesFromPodAffinityTerm)
+  bool ns_ok = t.all_namespaces ||
+               (t.namespaces.empty() ? target_ns == owner_ns : std::find(t.namespaces.begin(), t.namespaces.end(), target_ns) != t.namespaces.end());
   if (!ns_ok) return false;
   bool invalid = false;
   return selector_matches(t.selector, target_labels, &invalid);
@@ -205,6 +206,7 @@ inline std::string pod_terms_key(const std::vector<PodAffinityTerm>& terms) {
   for (auto& t : terms) {
     k += selector_key(t.selector.present ? "+" : "-", t.selector);
     for (auto& n : t.namespaces) k += '\x1c' + n;
+    if (t.all_namespaces) k += "\x1c*";
     k += '\x1b';
   }
   return k;
@@ -215,7 +217,14 @@ class Encoder {
   std::string error;
   int R = 3, KT = 1, W = 1;
   std::vector<std::string> scalar_names;  // resource dimension 3+i
+  // Taints. Every distinct NoSchedule / NoExecute (key, value, effect) on any node is an entry of taint_dict — unbounded: a
+  // cluster autoscaler stamps a unique ToBeDeletedByClusterAutoscaler=<timestamp> on every node it drains. What is bounded
+  // is the number of BITS: taints that no pending ask can tell apart (the same set of toleration lists tolerates them)
+  // share one bit, taint_bit[i]; a node's word is the OR over its taints' bits, a spec's word says which bits it tolerates.
   std::vector<Taint> taint_dict;
+  std::vector<int32_t> taint_bit;                    // [taint] → bit
+  std::vector<std::vector<int32_t>> taint_members;   // [bit] → taints
+  int overflow_taint_bit = -1;                       // the bit that took every group beyond the engine's 256 (-1: none had to)
   std::vector<DictReq> req_dict;
   int KD = 0, KS = 0, KP = 0;
   std::vector<HostPort> port_dict;                                    // requested host port k (NodePorts)
@@ -224,13 +233,17 @@ class Encoder {
   std::vector<SelectorClass> sel_classes;                             // selector class s
   std::unordered_map<const PodTemplate*, std::string> unsupported;    // asks' templates the engine does not evaluate → why
   // engine limits (kernels.hip.h: kMaxR / kMaxKT / kMaxW / kMaxKP / kMaxKD; selector classes: ykpred_create)
-  static constexpr int kLimitR = 8, kLimitTaints = 256, kLimitRequirements = 2048, kLimitPorts = 256, kLimitTopoKeys = 8, kLimitClasses = 4096;
+  static constexpr int kLimitR = 8, kLimitTaintBits = 256, kLimitRequirements = 2048, kLimitPorts = 256, kLimitTopoKeys = 8, kLimitClasses = 4096;
 
   // Builds every dictionary from the current objects. Returns false (error set) on unsupported input.
   bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates) {
     error.clear();
     scalar_names.clear();
     taint_dict.clear();
+    taint_bit.clear();
+    taint_members.clear();
+    overflow_taint_bit = -1;
+    wild_anti_terms_.clear();
     req_dict.clear();
     scalar_ix_.clear();
     taint_ix_.clear();
@@ -253,26 +266,31 @@ class Encoder {
       for (const NodeInfo* ni : nodes)
         for (const Pod* p : ni->pods)
           if (!p->tpl->pod_anti_affinity.empty() && seen.insert(p->tpl).second) {
-            if (p->tpl->pod_affinity_unsupported) return fail("an existing pod uses namespaceSelector / matchLabelKeys in pod (anti)affinity (unsupported)");
-            existing_anti_templates_.push_back(p->tpl);
+            // An anti-affinity term of a pod that already runs constrains the asks its selector matches. A term the mirror
+            // cannot decide (non-empty namespaceSelector: needs Namespace labels; a selector that does not parse) costs
+            // exactly THOSE asks their place on the engine — whoever it cannot match (labels) is unaffected whatever the
+            // namespaces turn out to be. Topology keys beyond the engine's 8 are handled the same way.
+            bool any_evaluable = false;
             for (auto& term : p->tpl->pod_anti_affinity) {
               bool invalid = false;
               selector_matches(term.selector, p->tpl->labels, &invalid);
-              if (invalid) return fail("invalid labelSelector in an existing pod's anti-affinity term");
+              const bool new_key = !topo_ix_.count(term.topology_key);
+              if (invalid || term.namespace_selector_unsupported || (new_key && (int)topo_keys.size() >= kLimitTopoKeys)) {
+                wild_anti_terms_.push_back(&term);
+                continue;
+              }
               topo_key(term.topology_key);
+              any_evaluable = true;
             }
+            if (any_evaluable) existing_anti_templates_.push_back(p->tpl);
           }
     }
-    // node-driven entries first (they cannot be attributed to an ask: exceeding a limit here fails the whole encode)
-    for (const NodeInfo* ni : nodes) {
-      for (auto& kv : ni->allocatable.scalar) scalar(kv.first);
-      for (auto& kv : ni->requested.scalar) scalar(kv.first);
+    // Node-driven entries. Nothing here can cost the cluster its engine: taints are unbounded (their BITS are assigned below,
+    // once the asks' toleration lists are known), and a scalar resource only becomes a dimension when an ask requests it —
+    // NodeResourcesFit never looks at a resource the pod does not ask for, however many device plugins the nodes advertise.
+    for (const NodeInfo* ni : nodes)
       for (auto& t : ni->node.taints)
         if (t.effect == "NoSchedule" || t.effect == "NoExecute") taint(t);
-    }
-    if (3 + (int)scalar_names.size() > kLimitR) return fail("more than 5 scalar resource names on the nodes (engine limit R<=8)");
-    if ((int)taint_dict.size() > kLimitTaints) return fail("more than 256 distinct NoSchedule/NoExecute taints (engine limit)");
-    if ((int)topo_keys.size() > kLimitTopoKeys) return fail("more than 8 topology keys in the anti-affinity terms of pods already on nodes (engine limit)");
     // ask-driven entries, template by template: a template whose entries would not fit is rolled back and marked
     // unsupported on its own — the asks before and after it keep their place in the dictionaries
     for (const PodTemplate* t : templates) {
@@ -292,7 +310,7 @@ class Encoder {
         count_class("B|" + t->ns + '\x1f' + pod_terms_key({term}), SelectorClass{SelectorClass::kAntiTerm, t->ns, {}, {term}, {}, ""});
       for (const PodTemplate* et : existing_anti_templates_)
         for (auto& term : et->pod_anti_affinity)
-          if (pod_term_matches(term, et->ns, t->ns, t->labels))
+          if (!is_wild(&term) && pod_term_matches(term, et->ns, t->ns, t->labels))
             count_class("E|" + t->ns + '\x1f' + labels_key(t->labels) + '\x1f' + term.topology_key,
                         SelectorClass{SelectorClass::kExistingAnti, t->ns, {}, {}, t->labels, term.topology_key});
       for (const HostPort& hp : template_host_ports(*t))
@@ -304,7 +322,7 @@ class Encoder {
           count_class("S|" + selector_key(t->ns, c.selector), SelectorClass{SelectorClass::kSpread, t->ns, c.selector, {}, {}, ""});
       }
       for (auto& kv : t->requests)
-        if (is_scalar_resource_name(kv.first)) scalar(kv.first);
+        if (kv.second > 0 && is_scalar_resource_name(kv.first)) scalar(kv.first);  // a dimension exists because an ask requests it
       collect_requirements(*t);
       const char* over = nullptr;
       if (3 + (int)scalar_names.size() > kLimitR) over = "scalar resource names (engine limit: 5 besides cpu, memory, ephemeral-storage)";
@@ -317,6 +335,7 @@ class Encoder {
         unsupported[t] = std::string("the ask needs more ") + over + " than the dictionaries can still take";
       }
     }
+    assign_taint_bits(templates);
     KD = (int)topo_keys.size();
     KS = (int)sel_classes.size();
     KP = ((int)port_dict.size() + 63) / 64;
@@ -331,7 +350,7 @@ class Encoder {
       for (auto& v : values) domain_ids[(size_t)k][v] = id++;
     }
     R = 3 + (int)scalar_names.size();
-    KT = std::max(1, ((int)taint_dict.size() + 63) / 64);
+    KT = std::max(1, ((int)taint_members.size() + 63) / 64);
     // at least 32 spare requirement bits: an ask that arrives later with a selector nobody used before gets its bit(s)
     // without re-encoding the cluster (extend_requirements)
     W = std::min(kLimitRequirements / 64, std::max(1, ((int)req_dict.size() + 32 + 63) / 64));
@@ -398,7 +417,13 @@ class Encoder {
              "and CSINode state the engine does not hold";
     }
     if (t.resource_claims > 0) return "the pod carries spec.resourceClaims (DynamicResources needs ResourceSlice / ResourceClaim state the engine does not hold)";
-    if (t.pod_affinity_unsupported) return "pod (anti)affinity namespaceSelector / matchLabelKeys are not supported by the engine";
+    if (t.pod_affinity_unsupported) return "a pod (anti)affinity term carries a non-empty namespaceSelector (needs Namespace labels the engine does not hold)";
+    for (const PodAffinityTerm* wt : wild_anti_terms_) {
+      bool invalid = false;
+      if (selector_matches(wt->selector, t.labels, &invalid) || invalid)
+        return "a pod already on a node carries an anti-affinity term the engine cannot decide (non-empty namespaceSelector, unparsable selector or "
+               "a topology key beyond the engine's 8) whose labelSelector matches this ask";
+    }
     for (auto* terms : {&t.pod_affinity, &t.pod_anti_affinity})
       for (auto& term : *terms) {
         bool invalid = false;
@@ -408,7 +433,6 @@ class Encoder {
     std::set<std::string> keys_seen;
     for (auto& c : t.spread) {
       if (c.when_unsatisfiable != "DoNotSchedule") continue;
-      if (!c.match_label_keys.empty()) return "topologySpreadConstraints.matchLabelKeys is not supported by the engine";
       if (!keys_seen.insert(c.topology_key).second) return "duplicate topologyKey among DoNotSchedule constraints (rejected by API validation)";
       bool invalid = false;
       selector_matches(c.selector, t.labels, &invalid);
@@ -428,9 +452,19 @@ class Encoder {
       return false;  // topology key / count class not in the dictionaries
     }
     for (auto& kv : t.requests)
-      if (is_scalar_resource_name(kv.first) && !scalar_ix_.count(kv.first)) missing_ = true;
+      if (kv.second > 0 && is_scalar_resource_name(kv.first) && !scalar_ix_.count(kv.first)) missing_ = true;
     for (const HostPort& hp : template_host_ports(t))
       if (!port_ix_.count(port_key(hp))) missing_ = true;
+    // a toleration list that tells two taints of one bit apart needs new bits: the dictionaries are rebuilt
+    for (auto& members : taint_members) {
+      bool any = false, all = true;
+      for (int32_t i : members) {
+        const bool tol = tolerates(t.tolerations, taint_dict[(size_t)i]);
+        any = any || tol;
+        all = all && tol;
+      }
+      if (any && !all) missing_ = true;
+    }
     wanted->assign((size_t)std::max(KP, 1), 0);
     encode_wanted_ports(t, wanted->data());
     return !missing_;
@@ -466,15 +500,11 @@ class Encoder {
   bool node_known(const NodeInfo& ni) const {
     for (auto& t : ni.node.taints)
       if ((t.effect == "NoSchedule" || t.effect == "NoExecute") && !taint_ix_.count(taint_key(t))) return false;
-    for (auto& kv : ni.allocatable.scalar)
-      if (!scalar_ix_.count(kv.first)) return false;
-    return true;
+    return true;  // (scalar resources are dimensions only when an ask requests them: a new one on a node changes nothing)
   }
   // True when accounting a pod of this template on a node needs no dictionary that does not exist yet (scalar resource
   // names, topology keys / count classes of its required anti-affinity terms). False → rebuild the dictionaries.
   bool node_pod_known(const PodTemplate& t) const {
-    for (auto& kv : t.requests)
-      if (is_scalar_resource_name(kv.first) && !scalar_ix_.count(kv.first)) return false;
     if (!t.pod_anti_affinity.empty() &&
         std::find(existing_anti_templates_.begin(), existing_anti_templates_.end(), &t) == existing_anti_templates_.end())
       return false;
@@ -550,7 +580,9 @@ class Encoder {
     for (auto& t : ni.node.taints) {
       if (t.effect != "NoSchedule" && t.effect != "NoExecute") continue;  // PreferNoSchedule is ignored by the Filter
       auto it = taint_ix_.find(taint_key(t));
-      if (it != taint_ix_.end()) taints[it->second >> 6] |= 1ull << (it->second & 63);
+      if (it == taint_ix_.end() || (size_t)it->second >= taint_bit.size()) continue;
+      const int b = taint_bit[(size_t)it->second];
+      taints[b >> 6] |= 1ull << (b & 63);
     }
     // Requirement bits. Label requirements depend only on the node's values for the few label keys the dictionary
     // mentions, and most nodes share those values (zones, instance types ...): the words are computed once per distinct
@@ -609,12 +641,10 @@ class Encoder {
       }
     }
     s.tol.assign((size_t)KT, 0);
-    for (size_t i = 0; i < taint_dict.size(); ++i)
-      for (auto& tol : t.tolerations)
-        if (toleration_tolerates(tol, taint_dict[i])) {
-          s.tol[i >> 6] |= 1ull << (i & 63);
-          break;
-        }
+    // one representative per bit: the members of a bit are told apart by no toleration list the dictionaries were built for
+    // (assign_taint_bits), and encode_spec_if_covered refuses a later list that would
+    for (size_t b = 0; b < taint_members.size(); ++b)
+      if (!taint_members[b].empty() && tolerates(t.tolerations, taint_dict[(size_t)taint_members[b][0]])) s.tol[b >> 6] |= 1ull << (b & 63);
     Taint unsched{"node.kubernetes.io/unschedulable", "", "NoSchedule"};
     for (auto& tol : t.tolerations)
       if (toleration_tolerates(tol, unsched)) s.flags |= YKPRED_SPEC_TOLERATES_UNSCHEDULABLE;
@@ -756,6 +786,84 @@ class Encoder {
   std::unordered_map<std::string, std::vector<int>> name_equals_;  // node name → requirements that hold exactly there
   mutable std::unordered_map<std::string, std::vector<uint64_t>> label_memo_;  // label-value tuple → requirement words
   std::vector<const PodTemplate*> existing_anti_templates_;  // distinct templates of on-node pods that carry anti-affinity terms
+  std::vector<const PodAffinityTerm*> wild_anti_terms_;  // anti-affinity terms of on-node pods the engine cannot decide
+  bool is_wild(const PodAffinityTerm* t) const { return std::find(wild_anti_terms_.begin(), wild_anti_terms_.end(), t) != wild_anti_terms_.end(); }
+  static bool tolerates(const std::vector<Toleration>& tols, const Taint& taint) {
+    for (auto& tol : tols)
+      if (toleration_tolerates(tol, taint)) return true;
+    return false;
+  }
+  // Bits for the taint dictionary: taints tolerated by exactly the same toleration lists (over every pending template) share a
+  // bit. Keyed tolerations are matched through an index by taint key, so the cost is (#lists x their tolerations + #taints),
+  // not #lists x #taints; a toleration without a key (operator Exists) covers every taint of its effect and never tells two
+  // taints of one effect apart — the effect is part of the group key instead.
+  void assign_taint_bits(const std::vector<PodTemplate*>& templates) {
+    const size_t T = taint_dict.size();
+    taint_bit.assign(T, 0);
+    taint_members.clear();
+    overflow_taint_bit = -1;
+    if (T == 0) return;
+    std::unordered_map<std::string, std::vector<int32_t>> by_key;
+    for (size_t i = 0; i < T; ++i) by_key[taint_dict[i].key].push_back((int32_t)i);
+    std::unordered_map<std::string, int32_t> list_ids;
+    std::vector<const PodTemplate*> list_owner;
+    std::vector<std::vector<int32_t>> tolerated_by(T);  // [taint] → ids of the lists that tolerate it through a keyed toleration
+    for (const PodTemplate* t : templates) {
+      if (unsupported.count(t) || t->tolerations.empty()) continue;
+      std::string k;
+      for (auto& tol : t->tolerations) k += tol.key + '\x1f' + tol.op + '\x1f' + tol.value + '\x1f' + tol.effect + '\x1e';
+      auto ins = list_ids.emplace(std::move(k), (int32_t)list_ids.size());
+      if (!ins.second) continue;
+      list_owner.push_back(t);
+      std::set<int32_t> hit;
+      for (auto& tol : t->tolerations) {
+        if (tol.key.empty()) {
+          if (tol.op == "Exists") continue;  // every taint of its effect: tells no two taints of one effect apart
+          // (API validation wants Exists with an empty key; ToleratesTaint itself would compare values — follow the function)
+          for (size_t i = 0; i < T; ++i)
+            if (toleration_tolerates(tol, taint_dict[i])) hit.insert((int32_t)i);
+          continue;
+        }
+        auto it = by_key.find(tol.key);
+        if (it == by_key.end()) continue;
+        for (int32_t i : it->second)
+          if (toleration_tolerates(tol, taint_dict[(size_t)i])) hit.insert(i);
+      }
+      for (int32_t i : hit) tolerated_by[(size_t)i].push_back(ins.first->second);
+    }
+    std::unordered_map<std::string, int32_t> groups;
+    for (size_t i = 0; i < T; ++i) {
+      std::string g = taint_dict[i].effect + '\x1f';
+      for (int32_t l : tolerated_by[i]) g += std::to_string(l) + ',';
+      auto ins = groups.emplace(std::move(g), (int32_t)taint_members.size());
+      int32_t bit = ins.first->second;
+      if (ins.second) {
+        if (overflow_taint_bit < 0 && (int)taint_members.size() < kLimitTaintBits - 1) {
+          taint_members.emplace_back();  // a bit of its own
+        } else {
+          if (overflow_taint_bit < 0) {  // the engine's last bit takes this and every further group
+            overflow_taint_bit = (int32_t)taint_members.size();
+            taint_members.emplace_back();
+          }
+          bit = overflow_taint_bit;
+          ins.first->second = bit;
+        }
+      }
+      taint_bit[i] = bit;
+      taint_members[(size_t)bit].push_back((int32_t)i);
+    }
+    if (overflow_taint_bit >= 0)  // mixed groups share the last bit: a list that tolerates some but not all of them cannot be encoded
+      for (const PodTemplate* t : templates) {
+        if (unsupported.count(t)) continue;
+        bool any = false, all = true;
+        for (int32_t i : taint_members[(size_t)overflow_taint_bit]) {
+          const bool tol = tolerates(t->tolerations, taint_dict[(size_t)i]);
+          any = any || tol;
+          all = all && tol;
+        }
+        if (any && !all) unsupported[t] = "the ask tolerates some but not all of the taints that share the dictionary's overflow bit (more than 256 distinguishable taint groups)";
+      }
+  }
   static std::string port_key(const HostPort& h) { return h.protocol + '\x1f' + h.ip + '\x1f' + std::to_string(h.port); }
   std::unordered_map<std::pair<const PodTemplate*, int>, int, MemoHash> sel_memo_;
   // how much one pod with template `t` on a node adds to count class `sc`

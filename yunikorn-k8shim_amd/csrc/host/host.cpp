@@ -237,6 +237,7 @@ int recreate_engine(ykhost* h) {
   if (const char* v = getenv("YKPRED_WALK_ROWS")) c.reserved[4] = atoi(v);
   if (const char* v = getenv("YKPRED_WAVE_COMBINE_BELOW")) c.reserved[5] = atoi(v);
   if (const char* v = getenv("YKPRED_BAND_STEPS")) c.reserved[6] = atoi(v);      // band height of the zone-A layout (-1 = no band layout)
+  if (const char* v = getenv("YKPRED_COMBINE_BESIDE")) c.reserved[7] = atoi(v) ? 2 : 0;  // class-by-class writer beside the band writer
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;
@@ -783,6 +784,7 @@ PodTemplate draw_template(Rng& g, const ykhost_kwok_t& c, int n_nodes) {
       sc.has_min_domains = true;
       sc.min_domains = 2 + (int32_t)g.below(20);
     }
+    sc.raw_selector = sc.selector;
     t.spread.push_back(sc);
   }
   if (c.node_affinity) {
@@ -1585,11 +1587,15 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
   // entered with an empty node list too. Both ykpred_eval_nodes and the full ykpred_eval it may fall back to perform exactly
   // one histogram exchange, so the shards stay in step whichever of the two each of them takes.
   const bool collective_step = h->comm_attached && h->enc.KD > 0;
-  if (nodes_touched || collective_step) {
+  // hosts that carry the histograms between the shards themselves (no communicator) split the step in two calls:
+  // YKPRED_EVAL_SPREAD_COUNT_ONLY (this shard's histograms are rebuilt, nothing else happens yet), then ..._COUNTS_READY
+  const bool two_phase = options & (YKPRED_EVAL_SPREAD_COUNT_ONLY | YKPRED_EVAL_SPREAD_COUNTS_READY);
+  if (nodes_touched || collective_step || two_phase) {
     int32_t none = 0;
     rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.empty() ? &none : h->eval_dirty_nodes.data());
     if (rc == YKPRED_E_STATE || rc == YKPRED_E_UNSUPPORTED) return ykhost_evaluate(h, allocate, options);
     if (rc) return fail(h, std::string("ykpred_eval_nodes: ") + ykpred_last_error(h->eng), rc);
+    if (options & YKPRED_EVAL_SPREAD_COUNT_ONLY) return 0;  // the dirty lists stay: the second call finishes the step
   }
   if (!h->eval_dirty_rows.empty()) {
     std::sort(h->eval_dirty_rows.begin(), h->eval_dirty_rows.end());

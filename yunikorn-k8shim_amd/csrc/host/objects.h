@@ -48,11 +48,19 @@ struct SpreadConstraint {
   int32_t min_domains = 1;
   std::string node_affinity_policy = "Honor", node_taints_policy = "Ignore";
   std::vector<std::string> match_label_keys;
+  // `selector` is the selector the plugin matches with: labelSelector with the matchLabelKeys folded in (for every listed key
+  // the pod carries: key In [the pod's value] — podtopologyspread mergeLabelSetWithSelector, or the API server's merge of the
+  // same requirement at admission; folding twice is idempotent). `raw_selector` is what the object said (snapshot dumps).
+  LabelSelector raw_selector;
 };
 struct PodAffinityTerm {  // v1.PodAffinityTerm of a required (anti)affinity rule
   LabelSelector selector;
   std::vector<std::string> namespaces;  // empty = the owning pod's namespace
   std::string topology_key;
+  // namespaceSelector: {} selects every namespace (evaluated); a non-empty one needs Namespace labels the mirror does not
+  // hold (routed). matchLabelKeys / mismatchLabelKeys are merged into labelSelector by the API server at admission and never
+  // read by the scheduler (framework.newAffinityTerm): ignored here as well.
+  bool all_namespaces = false, namespace_selector_unsupported = false;
 };
 struct HostPort {  // v1.ContainerPort with hostPort > 0; "" hostIP = 0.0.0.0, "" protocol = TCP (HostPortInfo.sanitize)
   std::string protocol, ip;
@@ -80,7 +88,7 @@ struct PodTemplate {
   StrMap pod_level_requests;
   std::vector<SpreadConstraint> spread;
   std::vector<PodAffinityTerm> pod_affinity, pod_anti_affinity;  // requiredDuringSchedulingIgnoredDuringExecution
-  bool pod_affinity_unsupported = false;  // namespaceSelector / matchLabelKeys / mismatchLabelKeys present
+  bool pod_affinity_unsupported = false;  // some required (anti)affinity term carries a non-empty namespaceSelector
   // spec.volumes entries of a kind one of the Volume* Filters inspects (VolumeBinding, VolumeZone, VolumeRestrictions,
   // NodeVolumeLimits: everything except the node-local kinds below) and the number of spec.resourceClaims (DynamicResources).
   // Those plugins need PV / PVC / StorageClass / CSINode / ResourceSlice state the engine does not hold: such an ask is
@@ -401,11 +409,13 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
         }
         spec.push_back(']');
       }
+      if (terms[i].all_namespaces) spec += ",\"namespaceSelector\":{}";
+      if (terms[i].namespace_selector_unsupported) spec += ",\"namespaceSelector\":{\"matchLabels\":{\"x-not-mirrored\":\"true\"}}";
       spec.push_back('}');
     }
     spec += "]}";
   };
-  const bool any_pod_aff = !t.pod_affinity.empty() || !t.pod_anti_affinity.empty() || t.pod_affinity_unsupported;
+  const bool any_pod_aff = !t.pod_affinity.empty() || !t.pod_anti_affinity.empty();
   if (t.has_required || any_pod_aff) {
     spec += ",\"affinity\":{";
     if (t.has_required) {
@@ -429,7 +439,6 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
       js_pod_terms("podAntiAffinity", t.pod_anti_affinity, comma);
       comma = true;
     }
-    if (t.pod_affinity_unsupported) spec += std::string(comma ? "," : "") + "\"x-unsupported-pod-affinity-fields\":true";
     spec += "}";
   }
   if (!t.tolerations.empty()) {
@@ -482,11 +491,11 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
       js_str(spec, c.topology_key);
       spec += ",\"whenUnsatisfiable\":";
       js_str(spec, c.when_unsatisfiable);
-      if (c.selector.present) {
+      if (c.raw_selector.present) {
         spec += ",\"labelSelector\":{\"matchLabels\":";
-        js_map(spec, c.selector.match_labels);
+        js_map(spec, c.raw_selector.match_labels);
         spec += ",\"matchExpressions\":";
-        js_reqs(spec, c.selector.match_exprs);
+        js_reqs(spec, c.raw_selector.match_exprs);
         spec += "}";
       }
       if (c.has_min_domains) spec += ",\"minDomains\":" + std::to_string(c.min_domains);
@@ -676,13 +685,19 @@ inline PodTemplate read_template(const mj::Value& v) {
         if (const mj::Value* nss = x->get_nn("namespaces"))
           for (auto& y : nss->arr) term.namespaces.push_back(y->s);
         term.topology_key = x->str_or("topologyKey", "");
-        if (x->get_nn("namespaceSelector") || x->get_nn("matchLabelKeys") || x->get_nn("mismatchLabelKeys")) t.pod_affinity_unsupported = true;
+        if (const mj::Value* nsel = x->get_nn("namespaceSelector")) {
+          const mj::Value* ml = nsel->get_nn("matchLabels");
+          const mj::Value* me = nsel->get_nn("matchExpressions");
+          const bool empty = (!ml || ml->obj.empty()) && (!me || me->arr.empty());
+          term.all_namespaces = empty;  // metav1.LabelSelectorAsSelector({}) = Everything
+          term.namespace_selector_unsupported = !empty;
+          if (!empty) t.pod_affinity_unsupported = true;
+        }
         out->push_back(std::move(term));
       }
     };
     read_pod_terms(aff->get_nn("podAffinity"), &t.pod_affinity);
     read_pod_terms(aff->get_nn("podAntiAffinity"), &t.pod_anti_affinity);
-    if (aff->get_nn("x-unsupported-pod-affinity-fields")) t.pod_affinity_unsupported = true;
   }
   if (const mj::Value* tols = spec->get_nn("tolerations"))
     for (auto& x : tols->arr)
@@ -729,6 +744,17 @@ inline PodTemplate read_template(const mj::Value& v) {
       sc.node_taints_policy = c->str_or("nodeTaintsPolicy", "Ignore");
       if (const mj::Value* mk = c->get_nn("matchLabelKeys"))
         for (auto& x : mk->arr) sc.match_label_keys.push_back(x->s);
+      sc.raw_selector = sc.selector;
+      if (sc.selector.present)  // a nil selector stays labels.Nothing() (mergeLabelSetWithSelector returns it unchanged)
+        for (auto& key : sc.match_label_keys) {
+          auto lv = t.labels.find(key);
+          if (lv == t.labels.end()) continue;  // keys the pod does not carry are ignored
+          Requirement r;
+          r.key = key;
+          r.op = "In";
+          r.values.push_back(lv->second);
+          sc.selector.match_exprs.push_back(std::move(r));
+        }
       t.spread.push_back(std::move(sc));
     }
   return t;

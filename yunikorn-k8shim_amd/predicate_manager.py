@@ -322,10 +322,13 @@ class GpuPredicateManager:
         opts |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0)
         self._check(self._L.ykhost_evaluate(self._h, 1 if allocate else 0, opts))
 
-    def evaluate_dirty(self, allocate=True, counts=True, decisions=False, profile=False):
+    def evaluate_dirty(self, allocate=True, counts=True, decisions=False, profile=False, spread_count_only=False, spread_counts_ready=False):
         """Patches only the node columns touched since the last evaluation (AssumePod / ForgetPod ...). Returns the
-        number of columns re-evaluated, or -1 when a full evaluation had to be run instead."""
+        number of columns re-evaluated, or -1 when a full evaluation had to be run instead. spread_count_only /
+        spread_counts_ready: the two halves of the step on a node-sharded cluster whose host sums the topology histograms
+        itself (with a communicator attached the engine does it inside one call)."""
         opts = OUT_BITMAP | (OUT_COUNTS if counts else 0) | (OUT_DECISIONS if decisions else 0) | (EVAL_PROFILE if profile else 0)
+        opts |= (EVAL_SPREAD_COUNT_ONLY if spread_count_only else 0) | (EVAL_SPREAD_COUNTS_READY if spread_counts_ready else 0)
         n = C.c_int32(-1)
         self._check(self._L.ykhost_evaluate_dirty(self._h, 1 if allocate else 0, opts, C.byref(n)))
         return n.value
