@@ -486,6 +486,8 @@ QUANTITIES = [
 
 
 E2E = "test/e2e/predicates/predicates_test.go"
+E2E_PREEMPT = "test/e2e/preemption/preemption_suite_test.go"
+UPSTREAM_DOC = "k8s.io/api core/v1 Toleration.ToleratesTaint + kube-scheduler TaintToleration.Filter (upstream, not vendored)"
 KWOK_SETUP = "deployments/kwok-perf-test/kwok-setup.sh"
 KWOK_DEPLOY = "deployments/kwok-perf-test/deploy-tool.sh"
 
@@ -514,6 +516,16 @@ def taint_cases():
                    labels={"app": "nginx", "applicationId": "sleep-deployment-0", "queue": "root.default"})
     real_pod = pod({"containers": [{"name": "main"}]}, name="actual-pod", uid="actual-pod", namespace="default", labels={"app": "real"})
 
+    no_tol_plain = pod({"containers": sleep}, name="sleepjob1", uid="sleepjob1", namespace="dev", labels={"app": "sleep", "applicationId": "app-3"})
+    herd_tainted = node("worker-2", alloc=alloc, taints=[{"key": "e2e_test_preemption", "value": "value", "effect": "NoSchedule"}])
+    herd_worker = node("worker-1", alloc=alloc)
+
+    def tol_pod(tolerations):
+        return pod({"containers": sleep, "tolerations": tolerations}, name="t", uid="t", namespace="ns", labels={"app": "t"})
+
+    def tnode(taints):
+        return node("tn", alloc=alloc, taints=[{"key": k, "value": v, "effect": e} for k, v, e in taints])
+
     def case(name, source, p, n, fits, plugin=None, regex=None):
         c = {"test": "TaintToleration", "name": name, "source": source, "plugins": ["*"], "allocate": True, "pod": p, "node": n, "fits": fits}
         if plugin is not None:
@@ -533,7 +545,29 @@ def taint_cases():
              kwok_pod, kwok_node, True),
         case("KWOK: a pod without the toleration is kept off the fake node ('Avoid scheduling actual running pods to fake Node')",
              f"{KWOK_SETUP}:50-53", real_pod, kwok_node, False, "TaintToleration", ".*taint.*"),
-    ]
+        # the preemption / simple_preemptor / recovery suites herd their sleep pods onto ONE worker by tainting every other node
+        # (kClient.TaintNodes(nodesToTaint, taintKey, "value", NoSchedule)): pods without a toleration only fit the untainted worker
+        case("preemption suite: sleep pod without toleration vs a node tainted e2e_test_preemption=value:NoSchedule", f"{E2E_PREEMPT}:85-99",
+             no_tol_plain, herd_tainted, False, "TaintToleration", ".*taint.*"),
+        case("preemption suite: the same pod on the one untainted worker", f"{E2E_PREEMPT}:85-99", no_tol_plain, herd_worker, True),
+    ] + [dict(case(name, UPSTREAM_DOC, p, n, fits, plugin), pinned_by="upstream documentation of v1.Toleration.ToleratesTaint / TaintToleration.Filter — "
+              "NOT held by any test, fixture or script of the reference (SURVEY.md §8c: parity unpinned)") for name, p, n, fits, plugin in [
+        ("upstream rule: an untolerated NoExecute taint filters like NoSchedule", tol_pod([]), tnode([("maint", "true", "NoExecute")]), False, "TaintToleration"),
+        ("upstream rule: a toleration without effect tolerates NoExecute too", tol_pod([{"key": "maint", "operator": "Exists"}]),
+         tnode([("maint", "true", "NoExecute")]), True, None),
+        ("upstream rule: PreferNoSchedule taints are ignored by the Filter", tol_pod([]), tnode([("soft", "x", "PreferNoSchedule")]), True, None),
+        ("upstream rule: effect mismatch (toleration NoExecute, taint NoSchedule) does not tolerate",
+         tol_pod([{"key": "k", "operator": "Equal", "value": "v", "effect": "NoExecute"}]), tnode([("k", "v", "NoSchedule")]), False, "TaintToleration"),
+        ("upstream rule: empty key with Exists tolerates every taint", tol_pod([{"operator": "Exists"}]),
+         tnode([("a", "1", "NoSchedule"), ("b", "2", "NoExecute")]), True, None),
+        ("upstream rule: Equal with an empty value tolerates a taint whose value is empty", tol_pod([{"key": "k", "operator": "Equal", "effect": "NoSchedule"}]),
+         tnode([("k", "", "NoSchedule")]), True, None),
+        ("upstream rule: Equal with an empty value does NOT tolerate value 'value' (the getSchedulerPodTolerations shape, "
+         "test/e2e/recovery_and_restart/recovery_and_restart_test.go:341-347)", tol_pod([{"key": "k", "operator": "Equal", "effect": "NoSchedule"}]),
+         tnode([("k", "value", "NoSchedule")]), False, "TaintToleration"),
+        ("upstream rule: one untolerated taint among tolerated ones fails", tol_pod([{"key": "a", "operator": "Exists"}]),
+         tnode([("a", "1", "NoSchedule"), ("b", "2", "NoSchedule")]), False, "TaintToleration"),
+    ]]
 
 
 def main():
