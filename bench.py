@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=5, help="steps run with per-kernel HIP events for `roofline`")
     ap.add_argument("--no-variants", action="store_true", help="N=1: skip the `variants` and `end_to_end` legs")
     ap.add_argument("--variant-steps", type=int, default=5)
+    ap.add_argument("--no-ingest", action="store_true", help="N=1: leave the JSON ingest leg out of `end_to_end`")
     ap.add_argument("--no-configs4", action="store_true", help="N=1: leave the configs[4] (100k x 5M, one GPU) leg out of `variants`")
     return ap.parse_args()
 
@@ -175,6 +176,46 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
             "frac": round(achieved / HBM_PEAK_GBS, 4) if own else None, "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),
             "algorithmic_bytes": int(own) if own else None, "step_algorithmic_bytes": int(algo_bytes),
             "whole_step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def json_ingest_leg(pkg, dev, a, gang):
+    """The path the Go manager drives (integration/gpu_predicate_manager.go): every Node and Pod of the default workload as JSON
+    text through the batch forms of the cache hooks (Context.InitializeState's replay, /root/reference/pkg/cache/context.go:
+    1411-1484: nodes, then every pod), then encode + upload + first evaluation — and the bitmap checksum of the rebuilt mirror
+    against the directly generated one (asks that name a node are bound pods for the hooks, so the comparison runs without them)."""
+    src = pkg.GpuPredicateManager(device=dev.index)
+    out = {}
+    try:
+        src.generate_kwok(seed=SEED + 2, num_nodes=a.nodes, num_pods=a.pods, num_templates=a.templates, node_affinity=0 if a.no_affinity else 1,
+                          spread=1 if a.spread else 0, gang_size=gang)
+        t0 = time.perf_counter()
+        docs = [src.dump_documents(k) for k in (0, 1, 2)]
+        out["serialise_s"] = round(time.perf_counter() - t0, 2)
+        out["documents"] = {"nodes": docs[0].count(b"\n"), "pods_on_nodes": docs[1].count(b"\n"), "pending_asks": docs[2].count(b"\n")}
+        out["text_MB"] = round(sum(map(len, docs)) / 1e6, 1)
+    finally:
+        src.close()
+    dst = pkg.GpuPredicateManager(device=dev.index)
+    try:
+        t0 = time.perf_counter()
+        dst.update_documents(0, docs[0])
+        t_nodes = time.perf_counter() - t0
+        dst.update_documents(1, docs[1])
+        dst.update_documents(2, docs[2])
+        t_ingest = time.perf_counter() - t0
+        dst.sync()
+        t_sync = time.perf_counter() - t0
+        dst.evaluate()
+        dst.synchronize()
+        t_all = time.perf_counter() - t0
+        n_docs = sum(out["documents"].values())
+        out.update({"json_ingest_ms": round(t_ingest * 1e3, 1), "nodes_ms": round(t_nodes * 1e3, 1), "us_per_document": round(t_ingest / max(n_docs, 1) * 1e6, 2),
+                    "encode_upload_ms": round((t_sync - t_ingest) * 1e3, 1), "first_evaluation_ms": round((t_all - t_sync) * 1e3, 1),
+                    "asks_mirrored": dst.num_pods, "templates": dst.stats()["templates"], "ingest": dst.ingest_stats(),
+                    "note": "one cgo-shaped crossing per object kind (ykhost_update_nodes_batch / ykhost_update_pods_batch), single host thread"})
+    finally:
+        dst.close()
+    return out
 
 
 def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
@@ -480,6 +521,12 @@ def main():
                                                       "upload → pod classes → evaluation, bitmap stays on the device")
         except Exception as exc:  # noqa: BLE001
             end_to_end = {"error": str(exc)}
+
+    if rank == 0 and world == 1 and end_to_end is not None and "error" not in end_to_end and not a.no_ingest:
+        try:
+            end_to_end["json_ingest"] = json_ingest_leg(pkg, dev, a, gang)
+        except Exception as exc:  # noqa: BLE001
+            end_to_end["json_ingest"] = {"error": str(exc)}
 
     if rank == 0:
         evals = float(P) * float(total_nodes) * a.steps

@@ -53,6 +53,13 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* node_name);  /* → number o
  * Running clears the assumed mark, Failed / Succeeded drops the pod (:344-347,374-383). */
 int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json);
 int32_t ykhost_remove_pod(ykhost_t* h, const char* uid);         /* → 1 removed, 0 unknown uid (:390-417) */
+/* The two update hooks for MANY objects at once — what the start-up replay of the informer caches amounts to
+ * (Context.InitializeState, /root/reference/pkg/cache/context.go:1411-1484: every node, then every pod). `text` holds `len`
+ * bytes of JSON documents one after the other (newline- or comma-separated; the body of a JSON array works): one cgo crossing,
+ * one lock, and the pods share the template memo (pods of one Deployment / task group differ in name and uid only: all but the
+ * first skip the JSON tree). → documents applied; on a malformed or rejected document -1 - (documents applied before it). */
+int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len);
+int32_t ykhost_update_pods_batch(ykhost_t* h, const char* text, int64_t len);
 /* AssumePod: the cached pod gets spec.nodeName = node and is accounted there (moved from a node it was assumed on
  * before); the ask keeps its index (row) and is skipped by dump. Unknown pod / node: error. */
 int32_t ykhost_assume_pod(ykhost_t* h, const char* uid, const char* node_name);
@@ -119,6 +126,11 @@ int32_t ykhost_node_index(const ykhost_t* h, const char* node_name); /* -1 = unk
 /* Serialises pending pods `pods[0..np)` (NULL = all) and nodes `nodes[0..nn)` (NULL = all, with their assigned pods)
  * as a snapshot document. Returns the required length (incl. NUL); writes at most `len` bytes. */
 int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const int32_t* nodes, int32_t nn, char* out, int64_t len);
+/* The mirror's objects as the newline-separated documents the cache hooks would deliver: kind 0 = Node objects, 1 = pods on
+ * nodes (spec.nodeName, status.phase Running), 2 = pending asks. Feeds ykhost_update_*_batch in bench.py's ingest leg and tests.
+ * ykhost_ingest_stats: out[0] = pod documents that reused a known template without a parse, out[1] = full parses. */
+int64_t ykhost_dump_documents(ykhost_t* h, int32_t kind, char* out, int64_t len);
+int32_t ykhost_ingest_stats(ykhost_t* h, int64_t* out2);
 /* on != 0: ykhost_dump_snapshot writes runs of on-node pods that share a pod template once, with "replicas": k (the loaders
  * expand them; their uids get a "#r" suffix) — what keeps the dump of a 50 000-node cluster small enough to hand to the
  * oracle for full-grid parity. */

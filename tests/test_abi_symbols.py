@@ -87,3 +87,61 @@ def test_python_binding_matches_the_headers():
             assert len(fn.argtypes) == want, f"{name}: _ffi.py declares {len(fn.argtypes)} parameters, the header {want}"
             checked += 1
     assert checked >= 40, checked
+
+
+def _build_replay(tmp_path, sanitize):
+    """tests/c/replay_cgo_sequence.c + the host library's SOURCES in one binary (so that the sanitizer instruments the
+    library code that could retain a caller's pointer); the engine library is linked as built."""
+    import subprocess
+    lib = os.path.join(ROOT, "yunikorn-k8shim_amd", "lib")
+    importlib.import_module("yunikorn-k8shim_amd").build_all()
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"] if sanitize else []
+    obj, exe = str(tmp_path / "replay.o"), str(tmp_path / "replay")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-Wall", "-Wextra"] + san + ["-I" + os.path.join(ROOT, "include"), "-c",
+                           os.path.join(ROOT, "tests", "c", "replay_cgo_sequence.c"), "-o", obj])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g"] + san + ["-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "yunikorn-k8shim_amd", "csrc", "host", "host.cpp"), obj, "-o", exe, "-L" + lib, "-lykpred",
+                           "-Wl,-rpath," + lib])
+    return exe
+
+
+def test_cgo_call_sequence_replays_under_the_sanitizers(tmp_path):
+    """The Go manager's call sequence and string ownership (every C.CString freed right after its call) replayed from C on a
+    mirror-only handle, libykhost's sources built with AddressSanitizer + UBSan: the library retains no caller pointer."""
+    import subprocess
+    exe = _build_replay(tmp_path, sanitize=True)
+    out = subprocess.run([exe, "-1"], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0"))
+    assert out.returncode == 0 and "replay ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_cgo_call_sequence_replays_on_the_device(tmp_path):
+    """The same sequence against the engine: the verdicts the Go file would hand back to the core."""
+    import subprocess
+    exe = _build_replay(tmp_path, sanitize=False)
+    out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "replay ok (device 0)" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
+def test_go_patches_apply_to_the_reference():
+    """integration/patches/*.diff (scripts/make_go_patches.py): the install line of context.go:130, the observer hooks of
+    scheduler_cache.go:148-484 and the service.predicateEngine key of schedulerconf.go:59-81 apply cleanly to the reference,
+    and are what the generator produces from it today."""
+    import shutil
+    import subprocess
+    if not shutil.which("git"):
+        pytest.skip("git not installed")
+    pdir = os.path.join(ROOT, "integration", "patches")
+    names = sorted(n for n in os.listdir(pdir) if n.endswith(".diff"))
+    assert names == ["context.go.diff", "scheduler_cache.go.diff", "schedulerconf.go.diff"]
+    for n in names:
+        r = subprocess.run(["git", "apply", "--check", "--verbose", os.path.join(pdir, n)], cwd="/root/reference", capture_output=True, text=True)
+        assert r.returncode == 0, (n, r.stderr)
+    # the Go file and the patches agree on the names they share
+    go = open(os.path.join(ROOT, "integration", "gpu_predicate_manager.go")).read()
+    cache_patch = open(os.path.join(pdir, "scheduler_cache.go.diff")).read()
+    for hook in ("OnUpdateNode", "OnRemoveNode", "OnUpdatePod", "OnRemovePod", "OnAssumePod", "OnForgetPod"):
+        assert f"func (m *gpuPredicateManager) {hook}(" in go and f"cache.observer.{hook}(" in cache_patch
+    assert "func NewConfiguredPredicateManager(handle fwk.Handle, engine string, device int) PredicateManager" in go
+    assert "predicates.NewConfiguredPredicateManager(" in open(os.path.join(pdir, "context.go.diff")).read()

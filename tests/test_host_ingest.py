@@ -1,0 +1,82 @@
+"""The ingest path the Go manager drives: v1.Node / v1.Pod documents as JSON text through the cache hooks, one by one or as
+one buffer (ykhost_update_nodes_batch / ykhost_update_pods_batch). The scanner of csrc/host/jsonscan.h lets a pod whose
+template text was seen before skip the JSON tree; the result must be indistinguishable from the full parser's."""
+import importlib
+import json
+
+import pytest
+
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+
+
+@pytest.fixture()
+def cluster_docs():
+    src = pkg.GpuPredicateManager(device=-1)
+    src.generate_kwok(seed=5, num_nodes=300, num_pods=4000, num_templates=120, node_affinity=1, spread=1)
+    docs = [src.dump_documents(k) for k in (0, 1, 2)]
+    n_asks = src.num_pods
+    src.close()
+    return docs, n_asks
+
+
+def test_template_memo_path_equals_the_full_parser(cluster_docs):
+    docs, _ = cluster_docs
+    fast, slow = pkg.GpuPredicateManager(device=-1), pkg.GpuPredicateManager(device=-1)
+    try:
+        assert [fast.update_documents(k, docs[k]) for k in (0, 1, 2)] == [d.count(b"\n") for d in docs]
+        st = fast.ingest_stats()
+        assert st["template_reused"] > 10 * st["full_parse"] > 0
+        # a harmless status.resize makes the scanner hand every pod to the full parser (in-place-resize inputs are its business)
+        slow.update_documents(0, docs[0])
+        for k in (1, 2):
+            slow.update_documents(k, docs[k].replace(b'"status":{', b'"status":{"resize":"InProgress",'))
+        assert slow.ingest_stats()["template_reused"] == 0
+        assert fast.dump_snapshot() == slow.dump_snapshot()
+        assert fast.encoded_tables() == slow.encoded_tables()
+    finally:
+        fast.close()
+        slow.close()
+
+
+def test_batch_equals_one_call_per_object(cluster_docs):
+    docs, n_asks = cluster_docs
+    one, batch = pkg.GpuPredicateManager(device=-1), pkg.GpuPredicateManager(device=-1)
+    try:
+        for d in docs[0].splitlines():
+            one._L.ykhost_update_node(one._h, d)
+        for k in (1, 2):
+            for d in docs[k].splitlines():
+                one._L.ykhost_update_pod(one._h, d)
+        for k in (0, 1, 2):
+            batch.update_documents(k, docs[k])
+        pinned = sum(1 for d in docs[2].splitlines() if b'"nodeName"' in d)
+        assert one.num_pods == batch.num_pods == n_asks - pinned  # an ask that names a node is a bound pod for the hooks
+        assert one.dump_snapshot() == batch.dump_snapshot()
+    finally:
+        one.close()
+        batch.close()
+
+
+def test_real_world_shaped_documents_and_errors():
+    """encoding/json output of real objects: members the mirror ignores (managedFields, ownerReferences, status.images ...),
+    escaped strings, null members; a malformed document stops the batch at its position."""
+    m = pkg.GpuPredicateManager(device=-1)
+    try:
+        node = {"kind": "Node", "metadata": {"name": "n1", "labels": {"zone": "a"}, "managedFields": [{"manager": "kubelet", "fieldsV1": {"f:x": {}}}]},
+                "spec": {"taints": None, "podCIDR": "10.0.0.0/24"},
+                "status": {"allocatable": {"cpu": "4", "memory": "8Gi", "pods": "10"}, "images": [{"names": ['a}]"b'], "sizeBytes": 1}] * 50,
+                           "conditions": [{"type": "Ready", "status": "True", "message": 'kubelet is "ready" {ok}'}]}}
+        text = json.dumps(node).encode().replace(b'"name": "n1"', b'"name": "n\\u0031"')  # an escaped name: still node n1
+        assert m.update_documents(0, text) == 1 and m.node_index("n1") == 0
+        pods = [{"metadata": {"name": f"p-{i}", "uid": f"u-{i}", "namespace": "ns", "labels": {"app": "x"}, "ownerReferences": [{"kind": "ReplicaSet", "name": "rs"}]},
+                 "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": "1"}}}], "schedulerName": "yunikorn", "nodeName": None},
+                 "status": {"phase": "Pending", "conditions": [{"type": "PodScheduled", "status": "False", "lastTransitionTime": f"2026-01-01T00:00:{i:02d}Z"}]}} for i in range(20)]
+        assert m.update_pods_batch(pods) == 20 and m.num_pods == 20
+        assert m.ingest_stats() == {"template_reused": 19, "full_parse": 1}
+        weird = dict(pods[0], metadata=dict(pods[0]["metadata"], name='quo"te', uid="u-weird"))  # an escape in a captured field: full parser
+        assert m.update_pods_batch([weird]) == 1 and m.pod_index("u-weird") == 20
+        bad = json.dumps(pods[1]).encode() + b"\n{\"metadata\": {\"uid\": \"x\"\n" + json.dumps(pods[2]).encode()
+        rc = m._L.ykhost_update_pods_batch(m._h, bad, len(bad))
+        assert rc == -2 and b"malformed" in m._L.ykhost_last_error(m._h)  # -1 - (one document applied)
+    finally:
+        m.close()

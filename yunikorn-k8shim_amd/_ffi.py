@@ -180,6 +180,11 @@ def load_ykhost():
     L.ykhost_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.ykhost_ask_supported.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
     L.ykhost_routing_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykhost_update_nodes_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.ykhost_update_pods_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.ykhost_dump_documents.restype = C.c_int64
+    L.ykhost_dump_documents.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
+    L.ykhost_ingest_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.ykhost_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.ykhost_resident_stats.argtypes = [C.c_void_p, C.c_void_p]
     _host = L

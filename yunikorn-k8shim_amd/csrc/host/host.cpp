@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "encoder.h"
+#include "jsonscan.h"
 #include "objects.h"
 
 namespace ykh {
@@ -75,6 +76,10 @@ struct ykhost {
 
   // ---- SchedulerCache mirror
   TemplatePool pool;
+  // raw template text (namespace | labels | spec without nodeName) → interned template: the pods of one Deployment / task group
+  // differ in name and uid only, so all but the first skip the JSON tree, read_template and the canonical re-serialisation
+  std::unordered_map<std::string, const PodTemplate*> tpl_memo;
+  int64_t ingest_fast = 0, ingest_full = 0;  // pod documents that took the memo / the full parser
   std::deque<NodeInfo> node_store;
   std::vector<NodeInfo*> nodes;  // index = engine node index
   std::unordered_map<std::string, int> node_ix;
@@ -141,6 +146,7 @@ struct ykhost {
 
   void clear_state() {
     pool.clear();
+    tpl_memo.clear();
     node_store.clear();
     nodes.clear();
     node_ix.clear();
@@ -184,6 +190,7 @@ void ensure_uid_index(ykhost* h) {
   h->uid_index = true;
 }
 
+Pod* store_pod(ykhost* h, Pod&& p);
 Pod* add_pod_object(ykhost* h, const mj::Value& v, size_t* anon) {
   Pod p;
   if (const mj::Value* md = v.get_nn("metadata")) {
@@ -194,6 +201,9 @@ Pod* add_pod_object(ykhost* h, const mj::Value& v, size_t* anon) {
   if (const mj::Value* spec = v.get_nn("spec")) p.node_name = spec->str_or("nodeName", "");
   if (p.uid.empty()) p.uid = "anon-" + std::to_string((*anon)++);
   p.tpl = h->pool.intern(read_template(v));
+  return store_pod(h, std::move(p));
+}
+Pod* store_pod(ykhost* h, Pod&& p) {
   if (!h->free_pods.empty()) {
     Pod* slot = h->free_pods.back();
     h->free_pods.pop_back();
@@ -1062,10 +1072,37 @@ int32_t ykhost_load_snapshot(ykhost_t* h, const char* json) {
 
 // SchedulerCache.UpdateNode (scheduler_cache.go:148-187): add or replace the node object, keep its pods; a NEW node
 // adopts the orphaned pods whose spec.nodeName is its name (:165-172). Returns the number of adopted pods.
+static int update_node_text(ykhost* h, js::Range doc);
 int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
   YKHOST_LOCKED(h);
   try {
-    mj::ValuePtr v = mj::parse(node_json);
+    return update_node_text(h, js::Range{node_json, node_json + strlen(node_json)});
+  } catch (const std::exception& e) {
+    return fail(h, e.what());
+  }
+}
+// Many Node documents in one call (see ykhost_update_pods_batch). → documents applied, or -1 - (documents applied before the bad one).
+int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len) {
+  YKHOST_LOCKED(h);
+  if (!text || len < 0) return fail(h, "bad argument");
+  long applied = 0;
+  try {
+    long n = js::documents(text, text + len, [&](js::Range doc) {
+      update_node_text(h, doc);
+      ++applied;
+    });
+    if (n < 0) return fail(h, "malformed JSON document #" + std::to_string(-1 - n) + " in the batch", (int)(-1 - applied));
+    return (int32_t)n;
+  } catch (const std::exception& e) {
+    return fail(h, std::string("document #") + std::to_string(applied) + ": " + e.what(), (int)(-1 - applied));
+  }
+}
+// A real Node object is tens of kilobytes of status.images, conditions and addresses around the five fields the predicates
+// read: the scanner cuts the document down to those before the tree parser sees it.
+static int update_node_text(ykhost* h, js::Range doc) {
+  {
+    std::string reduced;
+    mj::ValuePtr v = js::reduce_node(doc, &reduced) ? mj::parse(reduced) : mj::parse(std::string(doc.b, doc.e));
     Node n = read_node(*v);
     int adopted = 0;
     h->label_index_valid = false;
@@ -1093,8 +1130,6 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
         h->dirty_all = true;  // a new taint or scalar resource extends the dictionaries
     }
     return adopted;
-  } catch (const std::exception& e) {
-    return fail(h, e.what());
   }
 }
 
@@ -1141,12 +1176,47 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
 // Ask table: an unassigned, not yet running pod is a pending ask and holds a row; a pod that arrives with a
 // spec.nodeName of its own was bound by the cluster and holds none. A pod that already holds a row keeps it (in place)
 // while it is neither running nor terminated, so that rows stay stable while binds are in flight.
+static int apply_pod(ykhost* h, Pod* p, const std::string& phase);
 static int update_pod_value(ykhost* h, const mj::Value& v) {
   ensure_uid_index(h);
   size_t anon = h->pod_store.size();
   Pod* p = add_pod_object(h, v, &anon);
   std::string phase;
   if (const mj::Value* st = v.get_nn("status")) phase = st->str_or("phase", "");
+  return apply_pod(h, p, phase);
+}
+// One pod document as TEXT. The scanner (jsonscan.h) pulls out name / uid / nodeName / phase and the raw template text; a
+// template that was seen before costs no parse at all. Anything the scanner does not vouch for takes the full parser.
+static int update_pod_text(ykhost* h, js::Range doc) {
+  js::PodScan sc;
+  static const bool no_memo = getenv("YKHOST_NO_TEMPLATE_MEMO") != nullptr;  // (measurements: the round-2 ingest path)
+  if (no_memo || !js::scan_pod(doc, &sc) || sc.needs_full_parse) {
+    h->ingest_full++;
+    mj::ValuePtr v = mj::parse(std::string(doc.b, doc.e));
+    return update_pod_value(h, *v);
+  }
+  const PodTemplate* tpl = nullptr;
+  auto it = h->tpl_memo.find(sc.key);
+  if (it != h->tpl_memo.end()) {
+    tpl = it->second;
+    h->ingest_fast++;
+  } else {
+    h->ingest_full++;
+    mj::ValuePtr v = mj::parse(std::string(doc.b, doc.e));
+    tpl = h->pool.intern(read_template(*v));
+    if (h->tpl_memo.size() < 262144) h->tpl_memo.emplace(std::move(sc.key), tpl);  // (bounded: every-ask-its-own-template populations)
+  }
+  ensure_uid_index(h);
+  Pod p;
+  p.uid = sc.uid.str();
+  p.name = sc.name.str();
+  p.terminating = sc.terminating;
+  p.node_name = sc.node_name.str();
+  if (p.uid.empty()) p.uid = "anon-" + std::to_string(h->pod_store.size());
+  p.tpl = tpl;
+  return apply_pod(h, store_pod(h, std::move(p)), sc.phase.str());
+}
+static int apply_pod(ykhost* h, Pod* p, const std::string& phase) {
   const bool running = phase == "Running";                           // utils.IsPodRunning (utils.go:89-91)
   const bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated (:93-95)
   auto it = h->by_uid.find(p->uid);
@@ -1162,10 +1232,29 @@ static int update_pod_value(ykhost* h, const mj::Value& v) {
 int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json) {
   YKHOST_LOCKED(h);
   try {
-    mj::ValuePtr v = mj::parse(pod_json);
-    return update_pod_value(h, *v);
+    return update_pod_text(h, js::Range{pod_json, pod_json + strlen(pod_json)});
   } catch (const std::exception& e) {
     return fail(h, e.what());
+  }
+}
+
+// The same hooks for MANY objects in one call: `text` holds `len` bytes of JSON documents one after the other (newline- or
+// comma-separated; a JSON array body works). What InitializeState (context.go:1411-1484) replays at start-up — every node,
+// every pod — crosses cgo once, takes the handle's lock once, and the pods share the template memo. → documents applied;
+// on a malformed or rejected document: -1 - (documents applied before it), reason in ykhost_last_error.
+int32_t ykhost_update_pods_batch(ykhost_t* h, const char* text, int64_t len) {
+  YKHOST_LOCKED(h);
+  if (!text || len < 0) return fail(h, "bad argument");
+  long applied = 0;
+  try {
+    long n = js::documents(text, text + len, [&](js::Range doc) {
+      update_pod_text(h, doc);
+      ++applied;
+    });
+    if (n < 0) return fail(h, "malformed JSON document #" + std::to_string(-1 - n) + " in the batch", (int)(-1 - applied));
+    return (int32_t)n;
+  } catch (const std::exception& e) {
+    return fail(h, std::string("document #") + std::to_string(applied) + ": " + e.what(), (int)(-1 - applied));
   }
 }
 
@@ -1437,6 +1526,51 @@ int64_t ykhost_dump_snapshot(ykhost_t* h, const int32_t* pods, int32_t np, const
   o += "]}";
   if (out && len > 0) copy_out(o, out, len);
   return (int64_t)o.size() + 1;
+}
+
+// The mirror's objects as the documents the cache hooks would deliver, newline-separated: kind 0 = Node objects, 1 = the pods
+// that sit on nodes (spec.nodeName set, status.phase Running), 2 = the pending asks. What bench.py feeds back through
+// ykhost_update_nodes_batch / ykhost_update_pods_batch to time the JSON ingest. Returns the required length (incl. NUL).
+int64_t ykhost_dump_documents(ykhost_t* h, int32_t kind, char* out, int64_t len) {
+  YKHOST_LOCKED(h);
+  std::string o;
+  if (kind == 0) {
+    NodeInfo bare;
+    for (const NodeInfo* ni : h->nodes) {
+      bare.node = ni->node;
+      node_json(bare, o, false);
+      o.push_back('\n');
+    }
+  } else if (kind == 1) {
+    for (const NodeInfo* ni : h->nodes)
+      for (const Pod* p : ni->pods) {
+        pod_json(*p, o);
+        o.pop_back();
+        o += ",\"status\":{\"phase\":\"Running\"}}\n";
+      }
+  } else if (kind == 2) {
+    for (const Pod* p : h->pending) {
+      if (p->assumed) continue;
+      pod_json(*p, o);
+      o.pop_back();
+      o += ",\"status\":{\"phase\":\"Pending\"}}\n";
+    }
+  } else {
+    return fail(h, "dump_documents: kind must be 0 (nodes), 1 (pods on nodes) or 2 (pending asks)");
+  }
+  if (out && len > 0) {
+    const size_t n = std::min((size_t)(len - 1), o.size());
+    memcpy(out, o.data(), n);
+    out[n] = 0;
+  }
+  return (int64_t)o.size() + 1;
+}
+// out[0] = pod documents that reused a known template without a parse, out[1] = pod documents that took the full parser
+int32_t ykhost_ingest_stats(ykhost_t* h, int64_t* out2) {
+  YKHOST_LOCKED(h);
+  out2[0] = h->ingest_fast;
+  out2[1] = h->ingest_full;
+  return 0;
 }
 
 // The encoded tables as JSON (64-bit masks as hex strings) — lets the encoder be checked without a device: tests

@@ -1,0 +1,230 @@
+// jsonscan.h — allocation-free walking of JSON text, for the ingest path of the mirror.
+//
+// The Go manager hands every v1.Pod / v1.Node over as the text encoding/json produces. Most of such a
+// document is of no interest to the predicates (a Node's status.images, conditions, addresses; a Pod's managedFields,
+// ownerReferences, status.conditions ...), and the pods of one Deployment / task group differ in name and uid only. This
+// scanner finds the members the mirror reads WITHOUT building a tree:
+//   * skip(): steps over one JSON value (string-aware bracket matching);
+//   * members(): iterates the (key, raw value range) pairs of an object;
+//   * scan_pod(): name / uid / nodeName / phase / deletionTimestamp as raw ranges plus a TEMPLATE KEY — the raw text of
+//     namespace, labels and every spec member except nodeName. Two pods with the same key have the same PodTemplate, so the
+//     second one needs no parse at all (host.cpp keeps key -> template); a document that carries anything the key does not
+//     cover (container statuses of an in-place resize, escaped strings in the captured fields) says so and takes the full parser;
+//   * reduce_node(): a Node document cut down to what read_node reads (name, labels, spec.taints / unschedulable,
+//     status.allocatable) — the full parser then sees a few hundred bytes instead of tens of kilobytes.
+// Malformed input makes the scanner give up (false); the caller falls back to the full parser, which reports the error.
+#pragma once
+#include <cstddef>
+#include <cstring>
+#include <string>
+
+namespace js {
+
+struct Range {
+  const char* b = nullptr;
+  const char* e = nullptr;
+  bool present() const { return b != nullptr; }
+  size_t size() const { return (size_t)(e - b); }
+  bool is(const char* lit) const { return present() && size() == strlen(lit) && memcmp(b, lit, size()) == 0; }
+  bool is_null() const { return is("null"); }
+  bool is_string() const { return present() && size() >= 2 && *b == '"'; }
+  // contents of a string value without the quotes; only valid when has_escape() is false
+  std::string str() const { return is_string() ? std::string(b + 1, e - 1) : std::string(); }
+  bool has_escape() const { return present() && memchr(b, '\\', size()) != nullptr; }
+};
+
+inline const char* ws(const char* p, const char* end) {
+  while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+  return p;
+}
+// end of the string that starts at p (p points at the opening quote); nullptr = unterminated
+inline const char* skip_string(const char* p, const char* end) {
+  for (++p; p < end; ++p) {
+    if (*p == '\\') {
+      ++p;
+      continue;
+    }
+    if (*p == '"') return p + 1;
+  }
+  return nullptr;
+}
+// end of the value that starts at p; nullptr = malformed
+inline const char* skip(const char* p, const char* end) {
+  p = ws(p, end);
+  if (p >= end) return nullptr;
+  if (*p == '"') return skip_string(p, end);
+  if (*p == '{' || *p == '[') {
+    int depth = 0;
+    while (p < end) {
+      const char c = *p;
+      if (c == '"') {
+        p = skip_string(p, end);
+        if (!p) return nullptr;
+        continue;
+      }
+      if (c == '{' || c == '[') ++depth;
+      if (c == '}' || c == ']') {
+        if (--depth == 0) return p + 1;
+      }
+      ++p;
+    }
+    return nullptr;
+  }
+  const char* s = p;
+  while (p < end && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\t' && *p != '\r') ++p;
+  return p > s ? p : nullptr;
+}
+
+// Iterates the members of the object at [b, e): f(key range WITHOUT quotes, value range). Returns false on malformed input
+// or when f returns false.
+template <class F>
+inline bool members(Range obj, F&& f) {
+  const char* p = ws(obj.b, obj.e);
+  if (p >= obj.e || *p != '{') return false;
+  p = ws(p + 1, obj.e);
+  if (p < obj.e && *p == '}') return true;
+  for (;;) {
+    p = ws(p, obj.e);
+    if (p >= obj.e || *p != '"') return false;
+    const char* ke = skip_string(p, obj.e);
+    if (!ke) return false;
+    Range key{p + 1, ke - 1};
+    p = ws(ke, obj.e);
+    if (p >= obj.e || *p != ':') return false;
+    p = ws(p + 1, obj.e);
+    const char* ve = skip(p, obj.e);
+    if (!ve) return false;
+    if (!f(key, Range{p, ve})) return false;
+    p = ws(ve, obj.e);
+    if (p < obj.e && *p == ',') {
+      ++p;
+      continue;
+    }
+    return p < obj.e && *p == '}';
+  }
+}
+inline bool key_is(Range k, const char* lit) { return k.size() == strlen(lit) && memcmp(k.b, lit, k.size()) == 0; }
+
+struct PodScan {
+  Range name, uid, node_name, phase;
+  bool terminating = false;
+  bool needs_full_parse = false;  // something the template key does not cover
+  std::string key;                // namespace | labels | spec members except nodeName (raw text)
+};
+
+inline bool scan_pod(Range doc, PodScan* out) {
+  Range meta, spec, status;
+  if (!members(doc, [&](Range k, Range v) {
+        if (key_is(k, "metadata")) meta = v;
+        else if (key_is(k, "spec")) spec = v;
+        else if (key_is(k, "status")) status = v;
+        return true;
+      }))
+    return false;
+  Range ns, labels;
+  if (meta.present() && !meta.is_null()) {
+    if (!members(meta, [&](Range k, Range v) {
+          if (key_is(k, "name")) out->name = v;
+          else if (key_is(k, "uid")) out->uid = v;
+          else if (key_is(k, "namespace")) ns = v;
+          else if (key_is(k, "labels")) labels = v;
+          else if (key_is(k, "deletionTimestamp")) out->terminating = !v.is_null();
+          return true;
+        }))
+      return false;
+  }
+  out->key.clear();
+  if (ns.present()) out->key.append(ns.b, ns.size());
+  out->key.push_back('\x1f');
+  if (labels.present()) out->key.append(labels.b, labels.size());
+  out->key.push_back('\x1f');
+  if (spec.present() && !spec.is_null()) {
+    if (!members(spec, [&](Range k, Range v) {
+          if (key_is(k, "nodeName")) {
+            out->node_name = v;
+            return true;
+          }
+          out->key.append(k.b, k.size());
+          out->key.push_back(':');
+          out->key.append(v.b, v.size());
+          out->key.push_back('\x1e');
+          return true;
+        }))
+      return false;
+  }
+  if (status.present() && !status.is_null()) {
+    if (!members(status, [&](Range k, Range v) {
+          if (key_is(k, "phase")) out->phase = v;
+          // in-place resize inputs change the request vector (fold_container_statuses): full parser
+          else if ((key_is(k, "containerStatuses") || key_is(k, "initContainerStatuses") || key_is(k, "resize")) && !v.is_null())
+            out->needs_full_parse = true;
+          else if (key_is(k, "conditions") && v.size() > 16 && memmem(v.b, v.size(), "PodResizePending", 16) != nullptr)
+            out->needs_full_parse = true;
+          return true;
+        }))
+      return false;
+  }
+  for (const Range* r : {&out->name, &out->uid, &out->node_name, &out->phase})
+    if (r->present() && !r->is_null() && (!r->is_string() || r->has_escape())) out->needs_full_parse = true;
+  return true;
+}
+
+// {"metadata":{"name":..,"labels":..},"spec":{"taints":..,"unschedulable":..},"status":{"allocatable":..}} from a Node document
+inline bool reduce_node(Range doc, std::string* out) {
+  Range meta, spec, status;
+  if (!members(doc, [&](Range k, Range v) {
+        if (key_is(k, "metadata")) meta = v;
+        else if (key_is(k, "spec")) spec = v;
+        else if (key_is(k, "status")) status = v;
+        return true;
+      }))
+    return false;
+  auto pick = [&](std::string& dst, Range obj, const char* a, const char* b) {
+    dst.push_back('{');
+    bool first = true, ok = true;
+    if (obj.present() && !obj.is_null())
+      ok = members(obj, [&](Range k, Range v) {
+        if (key_is(k, a) || (b && key_is(k, b))) {
+          if (!first) dst.push_back(',');
+          first = false;
+          dst.push_back('"');
+          dst.append(k.b, k.size());
+          dst.append("\":");
+          dst.append(v.b, v.size());
+        }
+        return true;
+      });
+    dst.push_back('}');
+    return ok;
+  };
+  std::string acc;
+  acc.reserve(1024);
+  acc = "{\"metadata\":";
+  if (!pick(acc, meta, "name", "labels")) return false;
+  acc += ",\"spec\":";
+  if (!pick(acc, spec, "taints", "unschedulable")) return false;
+  acc += ",\"status\":";
+  if (!pick(acc, status, "allocatable", nullptr)) return false;
+  acc += "}";
+  out->swap(acc);
+  return true;
+}
+
+// Splits a buffer of concatenated / newline-separated JSON documents: f(document range). Returns the number of documents,
+// or -1 - (documents before the malformed one).
+template <class F>
+inline long documents(const char* p, const char* end, F&& f) {
+  long n = 0;
+  for (;;) {
+    p = ws(p, end);
+    while (p < end && *p == ',') p = ws(p + 1, end);  // (a JSON array body works as well)
+    if (p >= end) return n;
+    const char* e = skip(p, end);
+    if (!e) return -1 - n;
+    f(Range{p, e});
+    ++n;
+    p = e;
+  }
+}
+
+}  // namespace js

@@ -110,6 +110,16 @@ class GpuPredicateManager:
         """SchedulerCache.UpdatePod → False when the pod was stored as an orphan (its node is unknown)."""
         return bool(self._check(self._L.ykhost_update_pod(self._h, json.dumps(pod).encode())))
 
+    def update_nodes_batch(self, nodes):
+        """Many SchedulerCache.UpdateNode calls in one crossing: `nodes` = objects or JSON documents (bytes)."""
+        text = b"\n".join(n if isinstance(n, bytes) else json.dumps(n).encode() for n in nodes)
+        return self._check(self._L.ykhost_update_nodes_batch(self._h, text, len(text)))
+
+    def update_pods_batch(self, pods):
+        """Many SchedulerCache.UpdatePod calls in one crossing."""
+        text = b"\n".join(p if isinstance(p, bytes) else json.dumps(p).encode() for p in pods)
+        return self._check(self._L.ykhost_update_pods_batch(self._h, text, len(text)))
+
     def remove_pod(self, uid):
         return bool(self._check(self._L.ykhost_remove_pod(self._h, uid.encode())))
 
@@ -178,6 +188,24 @@ class GpuPredicateManager:
         buf = C.create_string_buffer(need)
         self._check(self._L.ykhost_dump_snapshot(self._h, *args, buf, need))
         return buf.value.decode()
+
+    def dump_documents(self, kind):
+        """Newline-separated JSON documents (bytes) as the cache hooks would deliver them: 0 nodes, 1 pods on nodes, 2 asks."""
+        need = self._L.ykhost_dump_documents(self._h, kind, None, 0)
+        self._check(need)
+        buf = C.create_string_buffer(need)
+        self._check(self._L.ykhost_dump_documents(self._h, kind, buf, need))
+        return buf.raw[:need - 1]
+
+    def update_documents(self, kind, text):
+        """ykhost_update_nodes_batch (kind 0) / ykhost_update_pods_batch on a buffer of documents."""
+        fn = self._L.ykhost_update_nodes_batch if kind == 0 else self._L.ykhost_update_pods_batch
+        return self._check(fn(self._h, text, len(text)))
+
+    def ingest_stats(self):
+        out = np.zeros(2, dtype=np.int64)
+        self._L.ykhost_ingest_stats(self._h, out.ctypes.data)
+        return {"template_reused": int(out[0]), "full_parse": int(out[1])}
 
     def encoded_tables(self):
         """The structure-of-arrays tables the encoder produces (dict; masks as Python ints). Needs no device."""
