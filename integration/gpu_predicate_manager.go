@@ -25,8 +25,9 @@
 // What stays in Go: the interface, the hooks in the cache's critical sections, the routing of asks the engine does not
 // evaluate to the existing CPU manager, the configuration key and the counters.
 //
-// Place this file in pkg/plugin/predicates/, the two headers and libraries under third_party/ykpred/, and apply the
-// three one-line changes listed in INTEGRATION.md §2 (context.go:130, scheduler_cache.go hooks, schedulerconf.go key).
+// Place this file in pkg/plugin/predicates/, the two headers and libraries under third_party/ykpred/, and apply the three
+// patches of integration/patches/ (context.go:130, the Observer hooks of scheduler_cache.go, the schedulerconf.go key):
+// `git apply integration/patches/*.diff` from the root of the yunikorn-k8shim checkout.
 // This file cannot be compiled in the build image of this repository (no Go toolchain); scripts/check_go_bindings.py
 // checks every C symbol and constant it uses against the headers.
 package predicates
@@ -74,9 +75,12 @@ type GPUPredicateCounters struct {
 	MirrorErrors      atomic.Int64
 }
 
-// CacheObserver is what SchedulerCache calls from inside its own critical sections (INTEGRATION.md §2 lists the six call
-// sites: scheduler_cache.go:149,190,304,392,444,464). The cache write lock is held, so mirror updates are serialised
-// against each other exactly like the cache's; evaluations take the handle's own lock inside libykhost.
+// CacheObserver is what SchedulerCache calls from inside its own critical sections (six call sites, patch
+// integration/patches/scheduler_cache.go.diff: scheduler_cache.go:149,190,304,392,444,464). The cache declares the same
+// method set as external.Observer — pkg/plugin/support imports pkg/cache/external, so the interface the cache stores cannot
+// live in this package; Go's structural typing makes *gpuPredicateManager satisfy both. The cache write lock is held, so
+// mirror updates are serialised against each other exactly like the cache's; evaluations take the handle's own lock inside
+// libykhost.
 type CacheObserver interface {
 	OnUpdateNode(node *v1.Node)
 	OnRemoveNode(node *v1.Node)
@@ -296,6 +300,48 @@ func (m *gpuPredicateManager) OnForgetPod(pod *v1.Pod) {
 	m.mirrorResult("ykhost_forget_pod", C.ykhost_forget_pod(m.host, uid))
 }
 
+// ReplayState fills the mirror in bulk: every node, then every pod, each kind in ONE cgo crossing
+// (ykhost_update_nodes_batch / ykhost_update_pods_batch). It is what Context.InitializeState (pkg/cache/context.go:1411-1484)
+// amounts to for the mirror when the informer caches are replayed at start-up: the per-object hooks above do the same work
+// with one crossing, one lock round trip and one C string per object. Pods of one Deployment / task group differ in name
+// and uid only; libykhost recognises their template text and parses it once.
+func (m *gpuPredicateManager) ReplayState(nodes []*v1.Node, pods []*v1.Pod) error {
+	join := func(count int, object func(int) interface{}) (*C.char, C.int64_t, error) {
+		var buffer strings.Builder
+		for i := 0; i < count; i++ {
+			data, err := json.Marshal(object(i))
+			if err != nil {
+				return nil, 0, err
+			}
+			buffer.Write(data)
+			buffer.WriteByte('\n')
+		}
+		return C.CString(buffer.String()), C.int64_t(buffer.Len()), nil
+	}
+	text, length, err := join(len(nodes), func(i int) interface{} { return nodes[i] })
+	if err != nil {
+		return err
+	}
+	applied := C.ykhost_update_nodes_batch(m.host, text, length)
+	C.free(unsafe.Pointer(text))
+	if int(applied) != len(nodes) {
+		m.Counters.MirrorErrors.Add(1)
+		return fmt.Errorf("ykhost_update_nodes_batch: %s", C.GoString(C.ykhost_last_error(m.host)))
+	}
+	text, length, err = join(len(pods), func(i int) interface{} { return pods[i] })
+	if err != nil {
+		return err
+	}
+	applied = C.ykhost_update_pods_batch(m.host, text, length)
+	C.free(unsafe.Pointer(text))
+	if int(applied) != len(pods) {
+		m.Counters.MirrorErrors.Add(1)
+		return fmt.Errorf("ykhost_update_pods_batch: %s", C.GoString(C.ykhost_last_error(m.host)))
+	}
+	m.Counters.MirrorUpdates.Add(int64(len(nodes) + len(pods)))
+	return nil
+}
+
 // ---- batched evaluation ------------------------------------------------------------------------------------------------------
 
 // Refresh brings the device-resident P x N feasibility bitmap, the per-ask feasible counts and the per-ask bin-pack
@@ -334,6 +380,43 @@ func (m *gpuPredicateManager) Layout() (BitmapLayout, error) {
 		Nodes: int(layout.num_nodes), Asks: int(layout.num_pods), RowWords: int(layout.row_words), RowStride: int(layout.row_stride),
 		Rows: int(layout.num_rows), Bitmap: layout.bitmap, RowOfPod: layout.row_of_pod, Counts: layout.counts, Decisions: layout.decisions,
 	}, nil
+}
+
+// Candidates returns the first k feasible nodes of an ask in bin-pack order (ascending score, ties by NodeID) — the node
+// loop the core runs through Predicates() callbacks, answered from the resident bitmap row in one call. It needs a Refresh
+// with nothing changed since; (nil, false) tells the caller to fall back to the per-node callbacks.
+func (m *gpuPredicateManager) Candidates(pod *v1.Pod, k int, allocate bool) ([]int32, bool) {
+	if pod == nil || k <= 0 {
+		return nil, false
+	}
+	uid := C.CString(string(pod.UID))
+	defer C.free(unsafe.Pointer(uid))
+	podIndex := C.ykhost_pod_index(m.host, uid)
+	if podIndex < 0 {
+		return nil, false
+	}
+	alloc := C.int32_t(0)
+	if allocate {
+		alloc = 1
+	}
+	nodes := make([]C.int32_t, k)
+	found := C.ykhost_candidates(m.host, podIndex, alloc, C.int32_t(k), &nodes[0])
+	if found < 0 {
+		return nil, false
+	}
+	out := make([]int32, int(found))
+	for i := range out {
+		out[i] = int32(nodes[i])
+	}
+	return out, true
+}
+
+// ResidentStats: Predicates() calls answered from the mirrored resident answer, per pair because the node's column changed,
+// by whole-ask device queries, and the answer / failing-plugin fetches behind them.
+func (m *gpuPredicateManager) ResidentStats() (resident, dirtyColumn, query, answerFetches, codeFetches int64) {
+	var out [5]C.int64_t
+	C.ykhost_resident_stats(m.host, &out[0])
+	return int64(out[0]), int64(out[1]), int64(out[2]), int64(out[3]), int64(out[4])
 }
 
 // RoutingStats: asks marked unsupported at the last encode, Predicates() calls the engine refused, dictionary growths.

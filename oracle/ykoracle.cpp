@@ -1417,6 +1417,28 @@ int orc_decide(void* h, int pod, unsigned pre_mask, unsigned filt_mask, int* cou
   return 0;
 }
 
+// orc_decide with the pod's PreFilter pass run once for all nodes (see prefilter_once: same verdicts, O(N) instead of O(N^2)
+// with hard spread constraints)
+int orc_decide_once(void* h, int pod, unsigned pre_mask, unsigned filt_mask, int* count, int* best) {
+  Snapshot* s = static_cast<Snapshot*>(h);
+  const orc::Pod& p = *s->pending[static_cast<size_t>(pod)];
+  const orc::PreFilterReplay replay = orc::prefilter_once(*s, p, pre_mask);
+  int c = 0, b = -1;
+  double bs = 0.0;
+  for (size_t j = 0; j < s->nodes.size(); ++j) {
+    if (!orc::pod_fits_node_replayed(replay, p, s->nodes[j], filt_mask).fit) continue;
+    ++c;
+    double sc = orc::binpack_score(s->nodes[j]);
+    if (b < 0 || sc < bs || (sc == bs && s->nodes[j].node.name < s->nodes[static_cast<size_t>(b)].node.name)) {
+      b = static_cast<int>(j);
+      bs = sc;
+    }
+  }
+  *count = c;
+  *best = b;
+  return 0;
+}
+
 int64_t orc_quantity_value(const char* s) { return orc::quantity_value(s); }
 int64_t orc_quantity_milli(const char* s) { return orc::quantity_milli(s); }
 

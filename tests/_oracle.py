@@ -71,6 +71,7 @@ def lib():
         L.orc_binpack_scores.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.orc_decide.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint,
                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.orc_decide_once.argtypes = L.orc_decide.argtypes
         L.orc_quantity_value.restype = ctypes.c_int64
         L.orc_quantity_value.argtypes = [ctypes.c_char_p]
         L.orc_quantity_milli.restype = ctypes.c_int64
@@ -143,9 +144,9 @@ class Oracle:
         lib().orc_binpack_scores(self._h, out.ctypes.data)
         return out
 
-    def decide(self, pod, pre_mask=ALL, filt_mask=ALL):
+    def decide(self, pod, pre_mask=ALL, filt_mask=ALL, prefilter_once=False):
         c, b = ctypes.c_int(0), ctypes.c_int(0)
-        lib().orc_decide(self._h, pod, pre_mask, filt_mask, ctypes.byref(c), ctypes.byref(b))
+        (lib().orc_decide_once if prefilter_once else lib().orc_decide)(self._h, pod, pre_mask, filt_mask, ctypes.byref(c), ctypes.byref(b))
         return c.value, b.value
 
 

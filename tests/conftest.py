@@ -20,6 +20,11 @@ def pytest_collection_modifyitems(config, items):
         has_gpu = torch.cuda.is_available()
     except Exception:  # pragma: no cover
         has_gpu = False
+    # no single test may eat a GPU session: pytest-timeout (when installed) fails it after 10 minutes instead
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))
     if has_gpu:
         return
     skip = pytest.mark.skip(reason="no GPU visible")

@@ -886,7 +886,7 @@ def test_decisions_break_score_ties_by_node_id(pm):
 
 
 def test_unsupported_asks_are_routed_individually(pm):
-    """Asks the engine does not evaluate (a PVC volume, a DRA claim, pod-affinity namespaceSelector, a repeated topologyKey)
+    """Asks the engine does not evaluate (a PVC volume, a DRA claim, a pod-affinity namespaceSelector WITH requirements, a repeated topologyKey)
     are marked one by one: their rows are all zero, count 0, decision -1, Predicates() answers "route to the CPU manager"
     (YKHOST_E_UNSUPPORTED) — and every OTHER ask of the same snapshot is evaluated as usual, bit for bit the oracle's."""
     snap = _gen.random_snapshot(3131, n_nodes=90, n_pods=40)
@@ -899,7 +899,7 @@ def test_unsupported_asks_are_routed_individually(pm):
         odd(0, {"volumes": [{"name": "data", "persistentVolumeClaim": {"claimName": "pvc-1"}}]}),
         odd(1, {"resourceClaims": [{"name": "gpu", "resourceClaimName": "claim-1"}]}),
         odd(2, {"affinity": {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
-            {"topologyKey": "zone", "labelSelector": {}, "namespaceSelector": {}}]}}}),
+            {"topologyKey": "zone", "labelSelector": {}, "namespaceSelector": {"matchLabels": {"team": "a"}}}]}}}),
         odd(3, {"topologySpreadConstraints": [
             {"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": {"matchLabels": {"a": "b"}}},
             {"maxSkew": 2, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule", "labelSelector": {"matchLabels": {"c": "d"}}}]}),
@@ -1092,7 +1092,7 @@ def test_full_grid_oracle_parity(pm, n_nodes, n_pods, affinity, gang, spread):
     first = in_order.argmax(axis=1)
     want_dec = np.where(in_order[np.arange(len(rep)), first] != 0, order[first], -1).astype(np.int32)
     for c in np.random.default_rng(3).choice(len(rep), 24, replace=False):  # the shortcut above IS the oracle's decide()
-        assert o.decide(int(c)) == (int(want[c].sum()), int(want_dec[c]))
+        assert o.decide(int(c), prefilter_once=bool(spread)) == (int(want[c].sum()), int(want_dec[c]))
     dec = pm.read_decisions()
     assert np.array_equal(dec, want_dec[pod_class]), f"{int((dec != want_dec[pod_class]).sum())} of {n_pods} decisions differ from the oracle"
     print(f"full grid {n_pods} x {n_nodes}: {len(rep)} classes x {n_nodes} nodes = {want.size} oracle calls in {t_oracle:.1f} s, "
@@ -1611,3 +1611,43 @@ def test_decisions_of_the_sub_wave_decide_kernel(monkeypatch, seed):
             assert o.decide(p) == (int(want[p].sum()), int(dec[p])), p
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_match_label_keys_and_all_namespace_selectors_against_the_oracle(pm, seed):
+    """Round 3: two fields that used to route an ask away are evaluated. topologySpreadConstraints.matchLabelKeys are folded
+    into the selector (podtopologyspread mergeLabelSetWithSelector: for every listed key the pod carries, key = the pod's
+    value), and a pod (anti)affinity term with namespaceSelector: {} matches pods of EVERY namespace. Random clusters with
+    both sprinkled over asks and running pods, full grid + failing plugins + decisions against the oracle."""
+    import random
+    rng = random.Random(700 + seed)
+    snap = _gen.random_snapshot(9500 + seed, n_nodes=90 + 30 * seed, n_pods=60, spread=True, interpod=True)
+    hashes = ["h1", "h2", "h3"]
+    for node in snap["nodes"]:
+        for pod in node.get("pods", []):
+            pod.setdefault("metadata", {}).setdefault("labels", {})["pod-template-hash"] = rng.choice(hashes)
+            if rng.random() < 0.3:
+                pod["metadata"]["namespace"] = rng.choice(["default", "other", "infra"])
+    touched = 0
+    for pod in snap["pods"] + [p for n in snap["nodes"] for p in n.get("pods", [])]:
+        spec = pod.setdefault("spec", {})
+        pod.setdefault("metadata", {}).setdefault("labels", {})["pod-template-hash"] = rng.choice(hashes)
+        for c in spec.get("topologySpreadConstraints") or []:
+            if c.get("labelSelector") is not None and rng.random() < 0.7:
+                c["matchLabelKeys"] = rng.choice([["pod-template-hash"], ["pod-template-hash", "no-such-label"], ["no-such-label"]])
+                touched += 1
+        aff = spec.get("affinity") or {}
+        for kind in ("podAffinity", "podAntiAffinity"):
+            for term in (aff.get(kind) or {}).get("requiredDuringSchedulingIgnoredDuringExecution") or []:
+                if rng.random() < 0.5:
+                    term["namespaceSelector"] = {}
+                    touched += 1
+    assert touched > 5
+    pm.load_snapshot(snap)
+    for p in range(len(snap["pods"])):
+        assert pm.ask_supported(p)[0], pm.ask_supported(p)
+    for allocate in (True, False):
+        o, want = check_against_oracle(pm, snap, allocate)
+    dec = pm.read_decisions()
+    for p in range(0, len(snap["pods"]), 3):
+        assert o.decide(p, orc.RESERVE_PRE, orc.RESERVE_FILT) == (int(want[p].sum()), int(dec[p]))

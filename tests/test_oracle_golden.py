@@ -219,6 +219,8 @@ def test_prefilter_once_form_equals_the_per_pair_form(seed, allocate):
     b, pb = o.eval_grid(pre_mask=pre, filt_mask=filt, threads=4, want_plugin=True, prefilter_once=True)
     assert (a == b).all() and (pa == pb).all()
     assert 0 < a.sum() < a.size
+    for p in range(0, o.num_pods, 5):
+        assert o.decide(p, pre, filt) == o.decide(p, pre, filt, prefilter_once=True)
     # plugin subsets: a Filter without its PreFilter (Error status), PreFilters alone
     for pre2, filt2 in ((0, orc.ALL), (orc.ALL, 0), (orc.PLUGIN_BITS["NodeAffinity"], orc.PLUGIN_BITS["NodeAffinity"] | orc.PLUGIN_BITS["PodTopologySpread"])):
         a, pa = o.eval_grid(pre_mask=pre2, filt_mask=filt2, threads=4, want_plugin=True)

@@ -61,10 +61,15 @@ def test_exchange_decisions_world2(tmp_path):
 
 
 def test_gathered_row_layout():
-    G, P, stride, words = 3, 4, 8, 5
-    g = torch.arange(G * P * stride).reshape(G, P, stride)
-    row = sharding.gathered_row(g, 2, G, words)
-    assert row.tolist() == [int(g[s, 2, w]) for s in range(G) for w in range(words)]
+    """Rows of the gathered layout are addressed through the shards' row maps (rows are permuted for the writer) and cut
+    to every shard's own word count (the last shard is narrower)."""
+    G, rows, stride = 3, 6, 8
+    ranges = [(0, 320), (320, 320), (640, 200)]  # 5, 5 and 4 words
+    g = torch.arange(G * rows * stride).reshape(G, rows, stride)
+    maps = [np.array([3, 0, 5, 1]), np.array([2, 2, 4, 0]), np.array([1, 5, 0, 3])]  # row_of_pod per shard
+    row = sharding.gathered_row(g, maps, 2, ranges)
+    want = [int(g[0, 5, w]) for w in range(5)] + [int(g[1, 4, w]) for w in range(5)] + [int(g[2, 0, w]) for w in range(4)]
+    assert row.tolist() == want
 
 
 def _spread_worker(rank, world, port, out):

@@ -1153,6 +1153,8 @@ __global__ __launch_bounds__(kBandBlock) void k_expand_bands(u64* __restrict__ o
       run_band(std::integral_constant<int, 1>{});
     else if (cur.n == 2)
       run_band(std::integral_constant<int, 2>{});
+    else if (cur.n == 3)
+      run_band(std::integral_constant<int, 3>{});
     else
       run_band(std::integral_constant<int, kBandClasses>{});
     __syncthreads();

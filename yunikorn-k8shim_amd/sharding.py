@@ -96,6 +96,10 @@ exchange_decisions = ref_exchange_decisions
 exchange_spread_histograms = ref_exchange_spread_histograms
 
 
-def gathered_row(gathered, pod, num_shards, row_words):
-    """Row of `pod` in the canonical node order from the shard-major gathered layout [G][P][row_stride] (equal shards)."""
-    return torch.cat([gathered[g, pod, :row_words] for g in range(num_shards)])
+def gathered_row(gathered, row_maps, pod, ranges):
+    """Row of ask `pod` in canonical (global) node order from the shard-major gathered layout [G][rows][row_stride].
+    `row_maps[g][pod]` is the physical row of the ask in shard g's slab — rows are permuted for the writer (layout.row_of_pod):
+    after ykpred_gather_bitmap that is every shard's own map (the gathered maps), after ykpred_gather_bitmap_compressed every
+    slab is in the RECEIVING engine's row order, i.e. its pm.row_map() for every g. `ranges` = shard_ranges(...)."""
+    parts = [gathered[g, int(row_maps[g][pod]), : -(-count // 64)] for g, (_, count) in enumerate(ranges) if count > 0]
+    return torch.cat(parts)
