@@ -137,7 +137,13 @@ def algorithmic_bytes(pm, lay):
     st = pm.stats()
     b_node = 8 * 2 * st["R"] + 4 + 4 + 4 + 8 * st["KT"] + 8 * st["W"]
     return (lay.num_pods * lay.row_words * 8 + lay.num_nodes * b_node + lay.num_pods * (4 + 4 + 4) + lay.num_classes * 4 * 4 +
-            lay.plane_rows * lay.row_words * 8)
+            plane_bytes(lay))
+
+
+def plane_bytes(lay):
+    """Signature planes of one pass: 8 bytes per 64-node word, except the request-value rows of many-valued dimensions, which
+    are index rows of one byte per word (layout.index_rows)."""
+    return (lay.plane_rows - lay.index_rows) * lay.row_words * 8 + lay.index_rows * lay.row_words
 
 
 def profile_kernels(pm, run_step, n):
@@ -170,7 +176,7 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
     elif base in BITMAP_WRITERS:
         own = max(algo_bytes - band_bytes, 0)
     elif lay is not None and base in ("k_sig_planes", "k_base_planes", "k_planes", "k_dim_walk"):
-        own = lay.plane_rows * lay.row_words * 8 + lay.num_nodes * b_node
+        own = plane_bytes(lay) + lay.num_nodes * b_node
     achieved = own / (kern[dom] * 1e-3) / 1e9 if own else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1) if own else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4) if own else None, "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),

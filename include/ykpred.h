@@ -238,6 +238,9 @@ typedef struct ykpred_layout {
   int32_t band_rows;    /* rows [0, band_rows) are written by the band writer (k_expand_bands), the rest class by class (k_combine) */
   void* row_of_pod;     /* device int32[P]: the bitmap row of pod p. Bit (n & 63) of word [row_of_pod[p] * row_stride + (n >> 6)]
                            says whether pod p fits node n */
+  int32_t index_rows;   /* of plane_rows: request-value rows of many-valued resource dimensions, kept as INDEX rows (one byte per
+                           64-node word instead of an 8-byte plane word) */
+  int32_t band_steps;   /* band height (windows) the current row layout was built with */
 } ykpred_layout_t;
 
 #define YKPRED_MAX_TIMED_KERNELS 24

@@ -20,7 +20,7 @@ for name, kw in (("own_template_per_ask", dict(num_templates=0)), ("unique_reque
     pm = pkg.GpuPredicateManager()
     pm.generate_kwok(seed=SEED + 2, num_nodes=50_000, num_pods=1_000_000, node_affinity=1, **kw)
     pm.sync()
-    for decisions in (True, False):
+    for decisions in ((True, False) if os.environ.get("PROBE_BOTH") else (True,)):
         for _ in range(2):
             pm.evaluate(decisions=decisions)
         pm.synchronize()
@@ -35,10 +35,12 @@ for name, kw in (("own_template_per_ask", dict(num_templates=0)), ("unique_reque
             for k, v in pm.timing()["kernels"]:
                 kern.setdefault(k, []).append(v)
         lay = pm.layout()
-        rec = {"workload": name, "decisions": decisions, "ms_per_step": round(ms, 4), "classes": lay.num_classes, "band_rows": lay.band_rows,
-               "rows": lay.num_rows, "planes": lay.plane_rows, "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in kern.items()}}
+        rec = {"knobs": {k: v for k, v in os.environ.items() if k.startswith("YKPRED_")}, "workload": name, "decisions": decisions, "ms_per_step": round(ms, 4), "classes": lay.num_classes, "band_rows": lay.band_rows,
+               "rows": lay.num_rows, "planes": lay.plane_rows, "index_rows": lay.index_rows, "band_steps": lay.band_steps, "kernel_ms": {k: round(float(np.mean(v)), 4) for k, v in kern.items()}}
         out.append(rec)
         print(json.dumps(rec), flush=True)
     pm.close()
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_variant_probe.json"), "w"), indent=1)
+with open(os.path.join(ROOT, "gpurun_out", "r03_variant_probe.jsonl"), "a") as f:
+    for rec in out:
+        f.write(json.dumps(rec) + "\n")

@@ -149,8 +149,10 @@ struct ykpred_engine {
   // dimensions with >= walk_rows distinct values are evaluated by the sorted walk (k_dim_sort / k_dim_walk)
   int walk_rows = 256;  // tunable: cfg.reserved[4]
   int wave_combine_below = 16;  // tunable: cfg.reserved[5] — average members per chunk below which k_combine_wave is used
-  int n_big = 0, walk_chunks = 0;
+  int n_big = 0, walk_chunks = 0, index_rows = 0;
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
+  DevBuf d_idx_c, d_idx_r;  // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical / rank order
+  int idx_stride = 0;
   DevBuf d_sig_tol, d_sig_tolflags, d_sig_ports, d_swanted;                    // [Dtol][KT], [Dtol], [Dtol][KP]; [S][KP]
   DevBuf d_sig_aff_flags, d_sig_aff_off, d_sig_aff_terms, d_sig_pre_off, d_sig_pre_terms;
   bool specs_set = false;
@@ -174,6 +176,9 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
+  bool permute_all_enabled = true;  // YKPRED_PERMUTE_ALL=0: always evaluate the dictionary families a second time in rank order
+  bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
+  int combine_words = 0;           // 0 = never, 1 = k_combine_words where a walked dimension exists, 2 = wherever chunks are small (YKPRED_COMBINE_WORDS)
   int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
   bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
@@ -958,6 +963,9 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) e->max_lds_bytes = lds;
   }
   if (const char* v = getenv("YKPRED_DECIDE_GROUPS_FROM")) e->decide_groups_from = atoi(v);
+  if (const char* v = getenv("YKPRED_COMBINE_WORDS")) e->combine_words = atoi(v);
+  if (const char* v = getenv("YKPRED_PERMUTE_ALL")) e->permute_all_enabled = atoi(v) != 0;
+  if (const char* v = getenv("YKPRED_ZONE_B_FIRST")) e->zone_b_first = atoi(v) != 0;
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -1001,7 +1009,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1331,7 +1339,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     std::vector<int32_t> cdim, cbegin, clen, big_dim, wbig, wbegin, wlen;
     for (int g = 0; g <= R; ++g) {
       const int b0 = start[(size_t)g], b1 = start[(size_t)g + 1];
-      if (g > 0 && b1 - b0 >= e->walk_rows) {
+      if (g > 0 && b1 - b0 >= e->walk_rows && (int)big_dim.size() < ykk::kMaxIdxRows) {
         std::sort(order.begin() + b0, order.begin() + b1, [&](int32_t x, int32_t y) { return e->h_dim_val[(size_t)x] < e->h_dim_val[(size_t)y]; });
         for (int b = b0; b < b1; b += ykk::kWalkRows) {
           wbig.push_back((int32_t)big_dim.size());
@@ -1347,6 +1355,16 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
         clen.push_back(std::min(ykk::kDimRowsPerBlock, b1 - b));
       }
     }
+    // rows of a walked dimension are INDEX rows: their entries of the request-vector table say so (and which mask table decodes them)
+    if (!big_dim.empty()) {
+      if (rows >= (1 << ykk::kRowBigShift)) return fail(e, YKPRED_E_UNSUPPORTED, "more than 2^28 request-value rows");
+      std::vector<int32_t> big_of_dim((size_t)R, 0);
+      for (size_t b = 0; b < big_dim.size(); ++b) big_of_dim[(size_t)big_dim[b]] = (int32_t)b + 1;
+      for (int32_t& r : res_rows)
+        if (r > 0 && big_of_dim[(size_t)e->h_dim_of[(size_t)r]]) r |= big_of_dim[(size_t)e->h_dim_of[(size_t)r]] << ykk::kRowBigShift;
+    }
+    e->index_rows = 0;
+    for (int32_t len : wlen) e->index_rows += len;
     e->dim_chunks = (int)cdim.size();
     e->n_big = (int)big_dim.size();
     e->walk_chunks = (int)wbig.size();
@@ -1456,6 +1474,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const size_t cells = (size_t)e->n_big * (size_t)std::max(e->row_words, 1);
     for (DevBuf* b : {&e->d_sfree_c, &e->d_sfree_r}) HIPCHK(b->ensure(cells * 64 * sizeof(i64)));
     for (DevBuf* b : {&e->d_pmask_c, &e->d_pmask_r}) HIPCHK(b->ensure(cells * 65 * sizeof(u64)));
+    e->idx_stride = (e->row_words + 63) / 64 * 64;
+    for (DevBuf* b : {&e->d_idx_c, &e->d_idx_r}) HIPCHK(b->ensure((size_t)e->fam_res.D * (size_t)e->idx_stride));
   }
   Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
   tm.start(st);
@@ -1510,9 +1530,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
-                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R};
+                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words};
   ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
-                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R};
+                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(), e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words};
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -1582,9 +1602,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                        dim3(ykk::kBlock), 0, s, sa);
     tm.end(s, sig_name);
   };
-  // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order)
-  if (want_dec) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
+  // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order). With few signature planes
+  // altogether the rank-ordered copies of ALL of them come from one bit permutation of the canonical planes (part 3) — a
+  // fraction of the work of evaluating the dictionary families a second time, and less traffic beside the band writer.
+  const int total_rows = e->plane_rows_alloc;
+  const bool permute_all = total_rows <= ykk::kManySigs && e->n_big == 0 && e->permute_all_enabled;
+  if (want_dec && !permute_all) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
   // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
+  auto ranked_walk = [](const int* perm) { return perm != nullptr; };
   auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name) {
     ykk::PlaneArgs pa{};
     pa.perm = perm;
@@ -1611,11 +1636,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
       hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock),
-                         0, s, dw, ranked ? o_res.ranked : o_res.canon, e->row_stride);
+                         0, s, dw, (ranked ? e->d_idx_r : e->d_idx_c).as<unsigned char>(), e->idx_stride);
       tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
     } else if (res_on && e->n_big > 0) {
-      // Filter without PreFilter state: the walked rows are all zero like every other row of the family
-      (void)hipMemsetAsync((perm ? o_res.ranked : o_res.canon), 0, (size_t)e->fam_res.D * (size_t)e->row_stride * sizeof(u64), s);
+      // Filter without PreFilter state: the walked rows fit nowhere like every other row of the family — position 64 of every
+      // mask table is the empty mask (the tables are only written by k_dim_sort: clear them as well)
+      (void)hipMemsetAsync((ranked_walk(perm) ? e->d_idx_r : e->d_idx_c).p, 64, (size_t)e->fam_res.D * (size_t)e->idx_stride, s);
+      (void)hipMemsetAsync((ranked_walk(perm) ? e->d_pmask_r : e->d_pmask_c).p, 0, (size_t)e->n_big * (size_t)e->row_words * 65 * sizeof(u64), s);
     }
   };
   if (res_on || spread_on) launch_ballot_planes(st, nullptr, "k_planes");
@@ -1625,8 +1652,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) {
     HIPCHK(hipEventRecord(e->ev_planes, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_planes, 0));
-    const int ballot_rows = e->fam_tol.base;  // res + spread rows come first in the plane buffers
-    if (ballot_rows <= ykk::kManySigs) {
+    const int ballot_rows = permute_all ? total_rows : e->fam_tol.base;  // res + spread rows come first in the plane buffers
+    if (ballot_rows <= ykk::kManySigs && e->n_big == 0) {  // (index rows of walked dimensions are not bit planes: they are re-walked in rank order)
       tm.begin(sb);
       hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(ballot_rows), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
                          e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, ballot_rows, e->row_words);
@@ -1684,7 +1711,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       HIPCHK(hipEventRecord(e->ev_zb_fork, st));  // planes and the zeroed class counts are ready here
       HIPCHK(hipStreamWaitEvent(sz, e->ev_zb_fork, 0));
     }
-    if (!dirty_only && e->n_classes_a > 0) {
+    auto launch_zone_a = [&]() -> int {
+      if (dirty_only || e->n_classes_a == 0) return YKPRED_OK;
       // zone A: class rows → table (and the classes' feasible counts), then the fill-pattern expansion over the band layout
       tm.begin(st);
       hipLaunchKernelGGL(ykk::k_class_rows, dim3((unsigned)((e->n_classes_a + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
@@ -1701,9 +1729,24 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, bitmap, e->d_class_rows_a.as<u64>(),
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
       tm.end(st, "k_expand_bands");
-    }
+      return YKPRED_OK;
+    };
+    // Order of the two writers. The band writer is the one the decision branch (aux stream) disturbs — it lives on one
+    // workgroup per CU issuing stores back to back — while the chunk writer does not care (measured: own-template population,
+    // band writer 0.62 ms alone / 1.12 ms beside the decision kernels, chunk writer 0.78 ms either way). With a large zone B the
+    // chunk writer can go FIRST and absorb the decision branch.
+    if (!e->zone_b_first) TRY(launch_zone_a());
     tm.begin(sz);
-    if ((long)e->NC * e->wave_combine_below > (long)P) {
+    const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
+    if (small_chunks && e->combine_words > 0 && (e->combine_words > 1 || e->n_big > 0) && e->n_big <= 2) {
+      // few members per chunk AND request values of a walked dimension: word-major, index rows decoded through LDS (k_combine_words)
+      const int per_block = 1024;
+      const size_t lds = (size_t)e->n_big * ykk::kWave * 65 * sizeof(u64);
+      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ykk::k_combine_words, dim3((unsigned)((e->NC + per_block - 1) / per_block), (unsigned)((e->row_stride + ykk::kWave - 1) / ykk::kWave)),
+                         dim3(ykk::kWave), lds, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, per_block,
+                         class_dirty, e->n_big);
+    } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty);
@@ -1716,6 +1759,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       }
     }
     tm.end(sz, dirty_only ? "k_combine(dirty classes)" : "k_combine");
+    if (e->zone_b_first) TRY(launch_zone_a());
     if (sz != st) {
       HIPCHK(hipEventRecord(e->ev_zb_join, sz));
       HIPCHK(hipStreamWaitEvent(st, e->ev_zb_join, 0));
@@ -2211,6 +2255,8 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->num_rows = std::max(e->rows_total, e->row_capacity);
   o->band_rows = e->rows_a;
   o->row_of_pod = e->d_pod_row.p;
+  o->index_rows = e->index_rows;
+  o->band_steps = e->band_steps_now;
   o->bitmap_bytes = (uint64_t)std::max(o->num_rows, 1) * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
   o->counts = e->last_counts ? e->last_counts : e->d_counts.p;
@@ -2720,7 +2766,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
-  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
     hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),

@@ -322,8 +322,12 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
   a.pmask[cell * 65 + lane] = keep;
   if (lane == 0) a.pmask[cell * 65 + 64] = 0;
 }
-// blockIdx.x: walk chunk, blockIdx.y: block of 256 words; thread = word
-__global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, u64* __restrict__ out, int stride) {
+// blockIdx.x: walk chunk, blockIdx.y: block of 256 words; thread = word.
+// The rows it produces are INDEX rows: one BYTE per 64-node word — the position `ptr` in the word's sorted free list — instead of
+// the 8-byte plane word pmask[word][ptr] itself. A walked dimension has up to 10^6 rows; as u64 planes they are 6.5 GB written
+// here and read again by the combine / decide kernels (half of that population's traffic), as index rows 0.8 GB. Consumers
+// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word / k_combine_words).
+__global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* __restrict__ out, int stride) {
   const int chunk = blockIdx.x;
   const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
   const int w_raw = blockIdx.y * kBlock + threadIdx.x;
@@ -332,7 +336,6 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, u64* __restrict_
   const int lane = threadIdx.x % kWave;
   const size_t cell = (size_t)big * a.n_words + w;
   const i64* sf = a.sfree + cell * 64;
-  const u64* pm = a.pmask + cell * 65;
   const i64 kMax = 0x7fffffffffffffffll;
   int ptr = 0;
   {  // lower bound: entries [0, ptr) are below the chunk's first value
@@ -345,7 +348,6 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, u64* __restrict_
     ptr = lo;
   }
   i64 next = ptr < 64 ? sf[ptr] : kMax;
-  u64 mask = pm[ptr];
   for (int i0 = 0; i0 < len; i0 += kWave) {
     const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
     const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
@@ -353,14 +355,11 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, u64* __restrict_
     for (int i = 0; i < m; ++i) {
       const i64 v = readlane_i64(my_val, i);
       const int row = __builtin_amdgcn_readlane(my_row, i);
-      if (next < v) {
-        do {
-          ++ptr;
-          next = ptr < 64 ? sf[ptr] : kMax;
-        } while (next < v);
-        mask = pm[ptr];
+      while (next < v) {
+        ++ptr;
+        next = ptr < 64 ? sf[ptr] : kMax;
       }
-      if (live) out[(size_t)row * stride + w] = mask;
+      if (live) out[(size_t)row * stride + w] = (unsigned char)ptr;
     }
   }
 }
@@ -819,22 +818,38 @@ struct Planes {
   const u64* aff;
   const u64* spread;
   int stride;
-  const int* res_rows;    // [Dvec][res_slots]: rows of `res` a request vector ANDs together, -1 = unused slot
+  const int* res_rows;    // [Dvec][res_slots]: rows of `res` a request vector ANDs together, -1 = unused slot; a row of a
+                          // sorted-walk dimension carries (walked dimension + 1) << kRowBigShift: it is an INDEX row
   int res_slots;          // 1 + R
+  const unsigned char* res_idx;  // [rows][idx_stride] index rows of the sorted-walk dimensions (k_dim_walk), indexed by plane row id
+  int idx_stride;
+  const u64* pmask;       // [walked dimensions][n_words][65] mask tables of k_dim_sort (entry 64 = no node)
+  int n_words;
 };
 constexpr int kMaxClassRows = 3 + 1 + kMaxR;
+constexpr int kMaxIdxRows = 2;     // sorted-walk dimensions (further many-valued dimensions stay on ballot planes)
+constexpr int kRowBigShift = 28;   // plane row ids stay below 2^28
 
 // The plane rows whose AND is the bitmap row of a class: pointers to their first words, families disabled for this
 // evaluation left out (a null family pointer; wave-uniform).
 struct ClassRows {
   const u64* row[kMaxClassRows];
   int n;
+  const unsigned char* irow[kMaxIdxRows];  // index rows (sorted-walk dimensions) ...
+  const u64* ipm[kMaxIdxRows];             // ... and the mask table of their dimension
+  int ni;
 };
 __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st, int sa, int ss) {
   ClassRows cr;
   cr.n = 0;
+  cr.ni = 0;
 #pragma unroll
   for (int i = 0; i < kMaxClassRows; ++i) cr.row[i] = nullptr;
+#pragma unroll
+  for (int i = 0; i < kMaxIdxRows; ++i) {
+    cr.irow[i] = nullptr;
+    cr.ipm[i] = nullptr;
+  }
   auto add = [&](const u64* p) {
 #pragma unroll
     for (int i = 0; i < kMaxClassRows; ++i)
@@ -848,16 +863,37 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
     const int* rr = pl.res_rows + (size_t)sr * pl.res_slots;
     for (int k = 0; k < pl.res_slots; ++k) {
       const int r = rr[k];
-      if (r >= 0) add(pl.res + (size_t)r * pl.stride);
+      if (r < 0) continue;
+      const int big = r >> kRowBigShift, rid = r & ((1 << kRowBigShift) - 1);
+      if (big) {
+#pragma unroll
+        for (int i = 0; i < kMaxIdxRows; ++i)
+          if (i == cr.ni) {
+            cr.irow[i] = pl.res_idx + (size_t)rid * pl.idx_stride;
+            cr.ipm[i] = pl.pmask + (size_t)(big - 1) * pl.n_words * 65;
+          }
+        ++cr.ni;
+      } else {
+        add(pl.res + (size_t)rid * pl.stride);
+      }
     }
   }
   return cr;
+}
+// the words of the class's INDEX rows at word w (w < n_words): position byte -> entry of the word's mask table
+__device__ __forceinline__ u64 class_idx_word(const ClassRows& cr, int w) {
+  u64 v = ~0ull;
+#pragma unroll
+  for (int i = 0; i < kMaxIdxRows; ++i)
+    if (i < cr.ni) v &= cr.ipm[i][(size_t)w * 65 + cr.irow[i][w]];
+  return v;
 }
 __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
   u64 v = ~0ull;
 #pragma unroll
   for (int i = 0; i < kMaxClassRows; ++i)
     if (i < cr.n) v &= cr.row[i][w];
+  if (cr.ni) v &= class_idx_word(cr, w);
   return v;
 }
 
@@ -969,6 +1005,10 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
 #pragma unroll
       for (int i = 0; i < kMaxClassRows; ++i)
         if (i < cr.n) x &= *(const u64x2*)(cr.row[i] + w);
+      if (cr.ni) {
+        x.x &= class_idx_word(cr, w);
+        if (w + 1 < row_words) x.y &= class_idx_word(cr, w + 1);
+      }
       if (w + 1 >= row_words) x.y = 0;  // planes are zero there anyway (padding); keep the contract explicit
       if (pin >= 0) {
         x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
@@ -994,6 +1034,96 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
     if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+  }
+}
+
+// Word-major form of the class-by-class writer for populations of SMALL classes with request values of a sorted-walk dimension
+// (10^5 ... 10^6 classes of a few asks each). One single-wave workgroup owns 64 consecutive row words and walks a slice of
+// the chunks: lane = word, so the mask tables of its words (Planes::pmask, 65 entries each) sit in LDS and an index-row byte
+// is decoded with one ds_read — no per-class plane of 6 KB ever exists for the walked dimension. Chunk tables are fetched 64
+// chunks at a time by the lanes (one round of loads for 64 chunks instead of a dependent chain per chunk) and broadcast
+// with v_readlane; kCwUnroll chunks are in flight per wave (LDS bounds the occupancy to a few waves per CU, so the
+// memory-level parallelism has to come from inside the wave). Stores: 512 contiguous bytes of a row per wave.
+constexpr int kCwUnroll = 4;
+constexpr int kCwSlots = 1 + kMaxR;
+__global__ __launch_bounds__(kWave) void k_combine_words(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
+                                                         int pin_enabled, int* __restrict__ class_count, int n_chunks, int chunks_per_block,
+                                                         const int* __restrict__ class_dirty /* null = every zone-B class */, int n_big) {
+  extern __shared__ u64 cw_lds[];  // [n_big][kWave][65]
+  const int lane = threadIdx.x;
+  const int w_raw = blockIdx.y * kWave + lane;
+  const bool live = w_raw < row_words, in_row = w_raw < row_stride;
+  const int w = live ? w_raw : 0;  // address-safe word for lanes beyond the row
+  for (int b = 0; b < n_big; ++b)
+    for (int i = 0; i <= 64; ++i) cw_lds[((size_t)b * kWave + lane) * 65 + i] = live ? pl.pmask[((size_t)b * pl.n_words + w) * 65 + i] : 0ull;
+  __syncthreads();
+  const bool all_fail = pin_enabled & 2;
+  pin_enabled &= 1;
+  const int c0 = blockIdx.x * chunks_per_block, c1 = min(c0 + chunks_per_block, n_chunks);
+  const int slots = pl.res_slots;
+  for (int base = c0; base < c1; base += kWave) {
+    // ---- lane i fetches everything about chunk base + i
+    const int c = base + lane;
+    const bool have = c < c1;
+    const int cls_l = have ? ct.chunk_class[c] : 0;
+    const int skip_l = (!have || (class_dirty ? !class_dirty[cls_l] : ct.chunk_zone[c] != 0)) ? 1 : 0;
+    const int begin_l = have ? ct.chunk_begin[c] : 0, len_l = have ? ct.chunk_len[c] : 0, first_l = have ? ct.chunk_first[c] : 0;
+    const int sr_l = ct.sig[cls_l * 4 + 0], st_l = ct.sig[cls_l * 4 + 1], sa_l = ct.sig[cls_l * 4 + 2], ss_l = ct.sig[cls_l * 4 + 3];
+    const int pin_l = pin_enabled ? ct.pin[cls_l] : -1;
+    const int m0_l = (have && len_l > 0) ? ct.members[begin_l] : -1;
+    int rr_l[kCwSlots];
+#pragma unroll
+    for (int k = 0; k < kCwSlots; ++k) rr_l[k] = (k < slots && pl.res && sr_l >= 0) ? pl.res_rows[(size_t)sr_l * slots + k] : -1;
+    const int m = min(kWave, c1 - base);
+    for (int i0 = 0; i0 < m; i0 += kCwUnroll) {
+      u64 x[kCwUnroll];
+#pragma unroll
+      for (int u = 0; u < kCwUnroll; ++u) {
+        const int i = min(i0 + u, m - 1);  // (a repeated last chunk is computed and dropped below)
+        u64 v = live ? ~0ull : 0ull;
+        const int st = __builtin_amdgcn_readlane(st_l, i), sa = __builtin_amdgcn_readlane(sa_l, i), ss = __builtin_amdgcn_readlane(ss_l, i);
+        if (pl.tol && st >= 0) v &= pl.tol[(size_t)st * pl.stride + w];
+        if (pl.aff && sa >= 0) v &= pl.aff[(size_t)sa * pl.stride + w];
+        if (pl.spread && ss >= 0) v &= pl.spread[(size_t)ss * pl.stride + w];
+#pragma unroll
+        for (int k = 0; k < kCwSlots; ++k) {
+          if (k >= slots) continue;
+          const int r = __builtin_amdgcn_readlane(rr_l[k], i);
+          if (r < 0) continue;
+          const int big = r >> kRowBigShift, rid = r & ((1 << kRowBigShift) - 1);
+          if (big) {
+            const int pos = pl.res_idx[(size_t)rid * pl.idx_stride + w];
+            v &= cw_lds[((size_t)(big - 1) * kWave + lane) * 65 + pos];
+          } else {
+            v &= pl.res[(size_t)rid * pl.stride + w];
+          }
+        }
+        const int pin = __builtin_amdgcn_readlane(pin_l, i);
+        if (pin == -2 || all_fail)
+          v = 0;
+        else if (pin >= 0)
+          v &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+        x[u] = live ? v : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kCwUnroll; ++u) {
+        const int i = i0 + u;
+        if (i >= m) break;
+        if (__builtin_amdgcn_readlane(skip_l, i)) continue;
+        if (__builtin_amdgcn_readlane(first_l, i)) {  // this word block's share of the class's feasible count
+          int pc = __popcll(x[u]);
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
+          if (lane == 0 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, i)], pc);
+        }
+        const int len = __builtin_amdgcn_readlane(len_l, i), begin = __builtin_amdgcn_readlane(begin_l, i);
+        int p = __builtin_amdgcn_readlane(m0_l, i);
+        for (int j = 0; j < len; ++j) {
+          if (j) p = ct.members[begin + j];
+          if (p >= 0 && in_row) bitmap[(size_t)p * row_stride + w_raw] = x[u];
+        }
+      }
+    }
   }
 }
 
@@ -1048,6 +1178,10 @@ __global__ __launch_bounds__(kBlock) void k_class_rows(ClassTable ct, Planes pl,
 #pragma unroll
       for (int i = 0; i < kMaxClassRows; ++i)
         if (i < cr.n) x &= *(const u64x2*)(cr.row[i] + w);
+      if (cr.ni) {
+        x.x &= class_idx_word(cr, w);
+        if (w + 1 < row_words) x.y &= class_idx_word(cr, w + 1);
+      }
       if (w + 1 >= row_words) x.y = 0;
       if (pin >= 0) {
         x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
@@ -1196,6 +1330,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
       // first, where those planes are mostly zero — a lane whose word is already zero loads nothing more, so the scan to the
       // first feasible node reads little beyond one plane.
       u64 x = w < row_words ? ~0ull : 0ull;
+      if (cr.ni && x) x &= class_idx_word(cr, w);  // (the request-value rows first: see above)
 #pragma unroll
       for (int i = kMaxClassRows - 1; i >= 0; --i)
         if (i < cr.n && x) x &= cr.row[i][w];
@@ -1230,31 +1365,13 @@ __global__ __launch_bounds__(kBlock) void k_decide_groups(ClassTable ct, Planes 
   // every lane of the group reads the same table entries (one broadcast load each): no cross-lane traffic needed afterwards
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const int pin = (pin_enabled & 1) ? ct.pin[cls] : -1;
-  const u64* row[kMaxClassRows];
-  int n_rows = 0;
-#pragma unroll
-  for (int i = 0; i < kMaxClassRows; ++i) row[i] = nullptr;
-  auto add = [&](const u64* p) {
-#pragma unroll
-    for (int i = 0; i < kMaxClassRows; ++i)
-      if (i == n_rows) row[i] = p;
-    ++n_rows;
-  };
-  if (ranked.tol && st >= 0) add(ranked.tol + (size_t)st * ranked.stride);
-  if (ranked.aff && sa >= 0) add(ranked.aff + (size_t)sa * ranked.stride);
-  if (ranked.spread && ss >= 0) add(ranked.spread + (size_t)ss * ranked.stride);
-  if (ranked.res && sr >= 0) {
-    const int* rr = ranked.res_rows + (size_t)sr * ranked.res_slots;
-    for (int k = 0; k < ranked.res_slots; ++k) {
-      const int r = rr[k];
-      if (r >= 0) add(ranked.res + (size_t)r * ranked.stride);
-    }
-  }
+  const ClassRows cr = class_rows(ranked, sr, st, sa, ss);  // (per lane group here, not wave-uniform: the pointers live in VGPRs)
   auto word_at = [&](int w) {
     u64 x = w < row_words ? ~0ull : 0ull;
+    if (cr.ni && x) x &= class_idx_word(cr, w);
 #pragma unroll
     for (int i = kMaxClassRows - 1; i >= 0; --i)
-      if (i < n_rows && x) x &= row[i][w];
+      if (i < cr.n && x) x &= cr.row[i][w];
     return x;
   };
   int best = -1;

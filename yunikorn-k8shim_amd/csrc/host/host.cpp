@@ -1749,6 +1749,8 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
     h->decisions_stale = false;
   else if (nodes_touched || rows_touched)
     h->decisions_stale = true;
+  h->resident.order.clear();     // the bin-pack order may have moved
+  h->resident.peek_pod = -1;     // and so may any row
   return 0;
 }
 
@@ -1885,7 +1887,7 @@ int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k,
   ykhost::Resident& R = h->resident;
   const uint32_t pre = allocate ? h->alloc_pre : h->res_pre, filt = allocate ? h->alloc_filt : h->res_filt;
   int cls = -1;
-  if (!R.valid || R.phase != (allocate ? 1 : 0) || R.n_dirty > 0 || h->decisions_stale || !h->eval_dirty_nodes.empty() ||
+  if (!R.valid || R.phase != (allocate ? 1 : 0) || h->decisions_stale || !h->eval_dirty_nodes.empty() || !h->eval_dirty_rows.empty() ||
       ykpred_pod_class(h->eng, pod, &cls) != YKPRED_OK || cls < 0 || cls >= R.C)
     return fail(h, "no current evaluation with decisions for this ask (a node or the ask changed since): evaluate first", YKPRED_E_STATE);
   if (R.order.empty()) {
@@ -1896,9 +1898,10 @@ int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k,
     }
   }
   const uint64_t* row = nullptr;
-  if (!R.rows.empty()) {
+  if (!R.rows.empty() && R.n_dirty == 0) {
     row = R.rows.data() + (size_t)cls * (size_t)R.row_words;
   } else {
+    // columns were patched on the device since the mirror was taken (ykhost_evaluate_dirty): the ask's CURRENT row
     if (R.peek_pod != pod) {
       R.peek_row.assign((size_t)R.row_words, 0);
       R.peek_pod = ykpred_peek_row(h->eng, pod, pre, filt, R.peek_row.data(), nullptr, nullptr) == YKPRED_OK ? pod : -1;
