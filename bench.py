@@ -158,6 +158,19 @@ def profile_kernels(pm, run_step, n):
 BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_direct")
 
 
+def measured_traffic(workload, pods, nodes):
+    """profiles/traffic_r03.json (scripts/pmc_passes.sh + summarize_pmc.py: separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes,
+    calibrated and corrected as MI355X_MICROARCH.md prescribes): HBM bytes per launch of every engine kernel for this population."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r03.json")) as f:
+            tj = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if tj.get("pods") != pods or tj.get("nodes") != nodes:
+        return None
+    return tj.get("workloads", {}).get(workload)
+
+
 def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0):
     """The kernel with the largest average duration + the whole step, both against the HBM peak.
 
@@ -169,6 +182,11 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
         return None
     dom = max(kern, key=kern.get)
     base = dom.split("(")[0]
+    step_traffic = None
+    if isinstance(traffic, dict):  # measured_traffic(): pick the dominant kernel's bytes per launch, keep the step's total
+        step_traffic = traffic.get("step_hbm_bytes")
+        k = traffic.get("kernels_per_step", {}).get(base)
+        traffic = int(k["hbm_bytes"] / max(k.get("launches_per_step", 1.0), 1.0)) if k else None
     own = None
     band_bytes = (lay.band_rows * lay.row_words * 8) if lay is not None else 0
     if base == "k_expand_bands":
@@ -180,7 +198,7 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
     achieved = own / (kern[dom] * 1e-3) / 1e9 if own else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1) if own else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4) if own else None, "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),
-            "algorithmic_bytes": int(own) if own else None, "step_algorithmic_bytes": int(algo_bytes),
+            "algorithmic_bytes": int(own) if own else None, "step_algorithmic_bytes": int(algo_bytes), "step_traffic": step_traffic,
             "whole_step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
@@ -226,6 +244,7 @@ def json_ingest_leg(pkg, dev, a, gang):
 
 def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
     """A fresh manager on the same GPU: generate, upload, then `steps` timed full passes. Used for `variants` / `end_to_end`."""
+    workload = kwok.pop("_workload", None)
     pm = pkg.GpuPredicateManager(device=dev.index)
     out = {}
     try:
@@ -257,7 +276,8 @@ def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
         algo = algorithmic_bytes(pm, lay)
         out.update({"ms_per_step": round(ms, 4), "evals_per_sec": float(P) * lay.num_nodes / (ms * 1e-3), "pod_classes": lay.num_classes,
                     "signature_planes": lay.plane_rows, "distinct_evals_per_step": lay.num_classes * lay.num_nodes,
-                    "roofline": roofline_of(kern, algo, ms, lay=lay, b_node=node_row_bytes(pm)), "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
+                    "roofline": roofline_of(kern, algo, ms, traffic=measured_traffic(workload, P, lay.num_nodes), lay=lay,
+                                            b_node=node_row_bytes(pm)), "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
                     "cold_pass": {"encode_upload_ms": round(t_sync * 1e3, 1), "class_build_and_first_eval_ms": round((t_cold - t_sync) * 1e3, 1),
                                   "total_ms": round(t_cold * 1e3, 1), "encode_ms": round(pm.stats()["encode_us"] / 1e3, 1)}})
     finally:
@@ -444,11 +464,9 @@ def main():
     kern = profile_kernels(pm, prof_step, a.profile_steps)
     algo_bytes = algorithmic_bytes(pm, lay)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        if tj.get("pods") == P and tj.get("nodes") == N and tj.get("kernel") == (max(kern, key=kern.get) if kern else None):
-            traffic = tj.get("hbm_bytes_per_launch")
+    if world == 1 and not a.direct and not a.spread and gang == 0:
+        traffic = measured_traffic("unique_request_vectors" if a.unique_requests else ("own_template_per_ask" if a.templates == 0 else
+                                   ("default" if a.templates == 2000 else None)), P, N)
     roof = roofline_of(kern, algo_bytes, ms_per_step, traffic, lay=lay, b_node=node_row_bytes(pm))
 
     gather = None
@@ -507,7 +525,7 @@ def main():
         for name, kw in (("own_template_per_ask", dict(num_templates=0)),
                          ("unique_request_vectors", dict(num_templates=0, unique_requests=1))):
             try:
-                variants[name] = timed_leg(pkg, dev, stream, a, a.variant_steps, 2, 2, **base, **kw)
+                variants[name] = timed_leg(pkg, dev, stream, a, a.variant_steps, 2, 2, **base, **kw, _workload=name)
             except Exception as exc:  # noqa: BLE001
                 variants[name] = {"error": str(exc)}
         if (a.nodes, a.pods) == (50_000, 1_000_000) and not a.no_configs4:

@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+rm -f gpurun_out/r03_variant_probe.jsonl
+python -c "import importlib; importlib.import_module('yunikorn-k8shim_amd').build_all()" || exit 1
+make -C oracle -s || exit 1
+timeout 900 python -m pytest tests -m gpu -q --timeout 240 -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+grep -v "^\.\+ *\[" gpurun_out/pytest_gpu.log | tail -40
+PROBE_BOTH=1 timeout 300 python scripts/r03_variant_probe.py 2>&1 | grep '^{' | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print(d['workload'], 'decisions', d['decisions'], d['ms_per_step'], d['kernel_ms'])"

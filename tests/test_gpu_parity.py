@@ -1652,48 +1652,3 @@ def test_match_label_keys_and_all_namespace_selectors_against_the_oracle(pm, see
     dec = pm.read_decisions()
     for p in range(0, len(snap["pods"]), 3):
         assert o.decide(p, orc.RESERVE_PRE, orc.RESERVE_FILT) == (int(want[p].sum()), int(dec[p]))
-
-
-@pytest.mark.parametrize("mode", ["walked", "plain"])
-def test_word_major_combine_kernel(monkeypatch, mode):
-    """k_combine_words (YKPRED_COMBINE_WORDS): the class-by-class writer with lane = row word, index rows of sorted-walk
-    dimensions decoded through LDS-resident mask tables. "walked": every cpu AND memory request value distinct enough to take
-    the sorted walk (YKPRED_WALK_ROWS=2), scalar resources, negative free, word-boundary node counts; "plain": no walked
-    dimension at all (the kernel then only ANDs plane rows). Bits, counts, decisions against the oracle; then bench.py's
-    adversarial population in small with the default walk threshold."""
-    monkeypatch.setenv("YKPRED_COMBINE_WORDS", "2")
-    if mode == "walked":
-        monkeypatch.setenv("YKPRED_WALK_ROWS", "2")
-    for seed, n_nodes in enumerate([63, 64, 65, 130, 1100]):
-        snap = _gen.random_snapshot(9700 + seed, n_nodes=n_nodes, n_pods=120, scalars=True, spread=seed == 3)
-        m = pkg.GpuPredicateManager()
-        try:
-            m.load_snapshot(snap)
-            o, want = check_against_oracle(m, snap, True, check_plugins=False)
-            assert "k_combine" in dict(_profile_kernels(m))
-            dec = m.read_decisions()
-            for p in range(0, len(snap["pods"]), 5):
-                assert o.decide(p) == (int(want[p].sum()), int(dec[p]))
-        finally:
-            m.close()
-    if mode == "walked":
-        monkeypatch.delenv("YKPRED_WALK_ROWS")
-        m = pkg.GpuPredicateManager()
-        try:
-            m.generate_kwok(seed=4712, num_nodes=1500, num_pods=5000, num_templates=0, node_affinity=1, unique_requests=1)
-            m.evaluate()
-            assert m.layout().index_rows >= 4990, "the distinct cpu requests are index rows (one byte per word), not planes"
-            o = orc.Oracle(m.dump_snapshot(compact=True))
-            want = o.eval_grid(threads=os.cpu_count() or 8)
-            assert np.array_equal(unpack(m.read_bitmap(), 1500), want)
-            assert np.array_equal(m.read_counts(), want.sum(axis=1))
-            dec = m.read_decisions()
-            for p in range(0, 5000, 125):
-                assert o.decide(p) == (int(want[p].sum()), int(dec[p]))
-        finally:
-            m.close()
-
-
-def _profile_kernels(m):
-    m.evaluate(profile=True)
-    return m.timing()["kernels"]

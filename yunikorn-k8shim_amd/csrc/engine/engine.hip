@@ -176,9 +176,9 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
-  bool permute_all_enabled = true;  // YKPRED_PERMUTE_ALL=0: always evaluate the dictionary families a second time in rank order
+  bool permute_all_enabled = false; // YKPRED_PERMUTE_ALL=1: with few planes, rank-ordered copies of ALL of them by bit permutation instead of
+                                    // evaluating the dictionary families a second time (measured equal: profiles/r03_session4_knobs.txt)
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
-  int combine_words = 0;           // 0 = never, 1 = k_combine_words where a walked dimension exists, 2 = wherever chunks are small (YKPRED_COMBINE_WORDS)
   int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
   bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
@@ -567,11 +567,24 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       }
     }
   }
-  // zone B: the remaining classes, class by class after zone A
+  // zone B: the remaining classes, class by class after zone A — in the order of their SIGNATURES (node-affinity signature
+  // first: the family with the most planes), so that the chunk kernel's neighbouring workgroups AND the same plane rows at the
+  // same time and find them in L2 instead of fetching 6 KB rows from the far cache or HBM once per class
   int next_row = rows_a;
-  for (int c = 0; c < C; ++c) {
-    if (e->h_class_slot_a[(size_t)c] >= 0) continue;
-    for (int i = class_off[(size_t)c]; i < class_off[(size_t)c + 1]; ++i) e->h_pod_row[(size_t)members[(size_t)i]] = next_row++;
+  {
+    std::vector<int32_t> order_b;
+    for (int c = 0; c < C; ++c)
+      if (e->h_class_slot_a[(size_t)c] < 0) order_b.push_back(c);
+    auto key = [&](int32_t c, int f) { return class_sig[(size_t)c * 4 + (size_t)f]; };
+    std::sort(order_b.begin(), order_b.end(), [&](int32_t x, int32_t y) {
+      if (key(x, 2) != key(y, 2)) return key(x, 2) < key(y, 2);  // aff
+      if (key(x, 1) != key(y, 1)) return key(x, 1) < key(y, 1);  // tol
+      if (key(x, 3) != key(y, 3)) return key(x, 3) < key(y, 3);  // spread
+      if (key(x, 0) != key(y, 0)) return key(x, 0) < key(y, 0);  // request vector
+      return x < y;
+    });
+    for (int32_t c : order_b)
+      for (int i = class_off[(size_t)c]; i < class_off[(size_t)c + 1]; ++i) e->h_pod_row[(size_t)members[(size_t)i]] = next_row++;
   }
   e->rows_total = next_row;
   e->rows_a = rows_a;
@@ -660,7 +673,7 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
     }
   }
   e->plane_rows_alloc = rows;
-  size_t base_need = (size_t)(64 * (e->W + e->KT + e->KP) + 2) * (size_t)e->row_stride * sizeof(u64);
+  size_t base_need = (size_t)(64 * (e->W + e->KT + e->KP) + 3) * (size_t)e->row_stride * sizeof(u64);  // + unsched, exists, zero
   for (DevBuf* b : {&e->base_canon, &e->base_ranked}) {
     if (b->cap < base_need) {
       e->tables_version++;
@@ -963,7 +976,6 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) e->max_lds_bytes = lds;
   }
   if (const char* v = getenv("YKPRED_DECIDE_GROUPS_FROM")) e->decide_groups_from = atoi(v);
-  if (const char* v = getenv("YKPRED_COMBINE_WORDS")) e->combine_words = atoi(v);
   if (const char* v = getenv("YKPRED_PERMUTE_ALL")) e->permute_all_enabled = atoi(v) != 0;
   if (const char* v = getenv("YKPRED_ZONE_B_FIRST")) e->zone_b_first = atoi(v) != 0;
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
@@ -1567,6 +1579,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     bp.port = bp.taint + (size_t)64 * e->KT * e->row_stride;
     bp.unsched = bp.port + (size_t)64 * e->KP * e->row_stride;
     bp.exists = bp.unsched + e->row_stride;
+    bp.zero = bp.exists + e->row_stride;  // zeroed when the buffer is allocated (ensure_planes), written by nobody
     bp.stride = e->row_stride;
     return bp;
   };
@@ -1671,7 +1684,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
     } else {
       hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
-                         pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
+                         pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>(), e->C <= 4096 ? 1 : 0);
     }
     tm.end(sb, "k_decide");
     HIPCHK(hipEventRecord(e->ev_join, sb));
@@ -1738,15 +1751,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (!e->zone_b_first) TRY(launch_zone_a());
     tm.begin(sz);
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
-    if (small_chunks && e->combine_words > 0 && (e->combine_words > 1 || e->n_big > 0) && e->n_big <= 2) {
-      // few members per chunk AND request values of a walked dimension: word-major, index rows decoded through LDS (k_combine_words)
-      const int per_block = 1024;
-      const size_t lds = (size_t)e->n_big * ykk::kWave * 65 * sizeof(u64);
-      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_words, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(ykk::k_combine_words, dim3((unsigned)((e->NC + per_block - 1) / per_block), (unsigned)((e->row_stride + ykk::kWave - 1) / ykk::kWave)),
-                         dim3(ykk::kWave), lds, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, per_block,
-                         class_dirty, e->n_big);
-    } else if (small_chunks) {
+    if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty);

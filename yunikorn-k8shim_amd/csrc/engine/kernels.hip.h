@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
 // The rows it produces are INDEX rows: one BYTE per 64-node word — the position `ptr` in the word's sorted free list — instead of
 // the 8-byte plane word pmask[word][ptr] itself. A walked dimension has up to 10^6 rows; as u64 planes they are 6.5 GB written
 // here and read again by the combine / decide kernels (half of that population's traffic), as index rows 0.8 GB. Consumers
-// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word / k_combine_words).
+// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word).
 __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* __restrict__ out, int stride) {
   const int chunk = blockIdx.x;
   const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
@@ -405,6 +405,7 @@ struct BasePlanes {
   u64* port;     // [64*KP][stride] dictionary host port k in conflict on the node
   u64* unsched;  // [stride] node.Spec.Unschedulable
   u64* exists;   // [stride] bit set for positions < N (zero padding of the last word)
+  u64* zero;     // [stride] all zero (never written): the neutral row of an OR of planes
   int stride;
 };
 // blockIdx.x: dictionary word (0..W-1 labels, then KT taint words, then KP port words, last = flags); blockIdx.y: group of 4 node words.
@@ -454,18 +455,59 @@ struct SigPlaneArgs {
 };
 constexpr int kBitSigsPerBlock = 8;  // signatures per block; thread = one 64-node word of the row
 
-__device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride, int w) {
+// The plane words a term ANDs (or a toleration signature ORs) are few — a nodeSelector pair and one or two expressions; a
+// handful of untolerated taints — but a loop "next set bit → load → combine" makes every load wait for the one before it,
+// and these kernels are pure latency: PlaneBatch collects up to four plane rows (wave-uniform pointers) and
+// loads them TOGETHER; empty slots point at the neutral row (`exists` for AND — every result is ANDed with it anyway — the
+// all-zero row for OR), so the four loads are unconditional and issue back to back.
+struct PlaneBatch {
+  const u64* p[4];
+  int n;
+  const u64* neutral;
+  __device__ __forceinline__ explicit PlaneBatch(const u64* neutral_row) : n(0), neutral(neutral_row) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = neutral_row;
+  }
+  __device__ __forceinline__ void add(const u64* row) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i == n) p[i] = row;
+    ++n;
+  }
+  __device__ __forceinline__ bool full() const { return n >= 4; }
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = neutral;
+    n = 0;
+  }
+  __device__ __forceinline__ u64 and_at(int w) const {
+    const u64 a = p[0][w], b = p[1][w], c = p[2][w], d = p[3][w];
+    return (a & b) & (c & d);
+  }
+  __device__ __forceinline__ u64 or_at(int w) const {
+    const u64 a = p[0][w], b = p[1][w], c = p[2][w], d = p[3][w];
+    return (a | b) | (c | d);
+  }
+};
+__device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride, int w,
+                                         const u64* __restrict__ exists_row) {
   u64 any = 0;
   for (int t = t0; t < t1; ++t) {
     u64 all = ~0ull;
+    PlaneBatch pb(exists_row);
     for (int k = 0; k < W; ++k) {
       u64 m = terms[(size_t)t * W + k];  // wave-uniform
       while (m) {
         int q = __ffsll((long long)m) - 1;
         m &= m - 1;
-        all &= req[(size_t)(k * 64 + q) * stride + w];
+        if (pb.full()) {
+          all &= pb.and_at(w);
+          pb.reset();
+        }
+        pb.add(req + (size_t)(k * 64 + q) * stride);
       }
     }
+    all &= pb.and_at(w);  // (an empty term = `exists`: matches every node)
     any |= all;
   }
   return any;
@@ -474,19 +516,26 @@ __device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, 
 // block's slice of `terms`): j0 / j1 index that slice. One v_readlane pair per mask word instead of a scalar load whose
 // address depends on the previous one.
 constexpr int kSigTermRegs = 4;  // 256 mask words per block of signatures; larger slices take the scalar path
-__device__ __forceinline__ u64 dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride, int w) {
+__device__ __forceinline__ u64 dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride, int w,
+                                              const u64* __restrict__ exists_row) {
   u64 any = 0;
   for (int j = j0; j < j1;) {
     u64 all = ~0ull;
+    PlaneBatch pb(exists_row);
     for (int k = 0; k < W; ++k, ++j) {
       const int r = j >> 6, l = j & 63;  // wave-uniform
       u64 m = (u64)readlane_i64((i64)(r == 0 ? tw[0] : (r == 1 ? tw[1] : (r == 2 ? tw[2] : tw[3]))), l);
       while (m) {
         int q = __ffsll((long long)m) - 1;
         m &= m - 1;
-        all &= req[(size_t)(k * 64 + q) * stride + w];
+        if (pb.full()) {
+          all &= pb.and_at(w);
+          pb.reset();
+        }
+        pb.add(req + (size_t)(k * 64 + q) * stride);
       }
     }
+    all &= pb.and_at(w);
     any |= all;
   }
   return any;
@@ -520,6 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
       const int d = d0 + i;
       const unsigned fl = (unsigned)__builtin_amdgcn_readlane((int)fl_l, i);
       u64 bad = 0;  // nodes carrying a taint this signature does not tolerate
+      PlaneBatch pb(a.base.zero);
       if (taint_en)
         for (int k = 0; k < a.KT; ++k) {
           const u64 tolerated = batch ? (u64)readlane_i64((i64)tol_l, i * a.KT + k) : a.sig_tol[(size_t)d * a.KT + k];
@@ -527,7 +577,11 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           while (m) {
             int tt = __ffsll((long long)m) - 1;
             m &= m - 1;
-            bad |= a.base.taint[(size_t)(k * 64 + tt) * a.base.stride + w];
+            if (pb.full()) {
+              bad |= pb.or_at(w);
+              pb.reset();
+            }
+            pb.add(a.base.taint + (size_t)(k * 64 + tt) * a.base.stride);
           }
         }
       if (!(fl & kSpecToleratesUnsched)) bad |= unsched;
@@ -538,9 +592,14 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           while (m) {
             int pp = __ffsll((long long)m) - 1;
             m &= m - 1;
-            bad |= a.base.port[(size_t)(k * 64 + pp) * a.base.stride + w];
+            if (pb.full()) {
+              bad |= pb.or_at(w);
+              pb.reset();
+            }
+            pb.add(a.base.port + (size_t)(k * 64 + pp) * a.base.stride);
           }
         }
+      bad |= pb.or_at(w);
       if (live) a.tol.canon[(size_t)d * a.tol.stride + w] = exists & ~bad;
     }
   } else {
@@ -566,12 +625,12 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
       if (pre_en && !skip) {
         if (f & kSpecPreReject) ok = 0;  // PreFilter rejected the pod (:236-238)
         if (f & kSpecPreNames)            // "node not eligible" (:248-250)
-          ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w);
+          ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w, a.base.exists);
       }
       if (filt_en && !skip) {
         const int t0 = __builtin_amdgcn_readlane(to_l, i), t1 = __builtin_amdgcn_readlane(to_l, i + 1);
-        ok &= batch ? dnf_words_regs(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w)
-                    : dnf_words(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w);
+        ok &= batch ? dnf_words_regs(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w, a.base.exists)
+                    : dnf_words(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w, a.base.exists);
       }
       if (live) a.aff.canon[(size_t)d * a.aff.stride + w] = ok;
     }
@@ -1037,96 +1096,6 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
   }
 }
 
-// Word-major form of the class-by-class writer for populations of SMALL classes with request values of a sorted-walk dimension
-// (10^5 ... 10^6 classes of a few asks each). One single-wave workgroup owns 64 consecutive row words and walks a slice of
-// the chunks: lane = word, so the mask tables of its words (Planes::pmask, 65 entries each) sit in LDS and an index-row byte
-// is decoded with one ds_read — no per-class plane of 6 KB ever exists for the walked dimension. Chunk tables are fetched 64
-// chunks at a time by the lanes (one round of loads for 64 chunks instead of a dependent chain per chunk) and broadcast
-// with v_readlane; kCwUnroll chunks are in flight per wave (LDS bounds the occupancy to a few waves per CU, so the
-// memory-level parallelism has to come from inside the wave). Stores: 512 contiguous bytes of a row per wave.
-constexpr int kCwUnroll = 4;
-constexpr int kCwSlots = 1 + kMaxR;
-__global__ __launch_bounds__(kWave) void k_combine_words(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
-                                                         int pin_enabled, int* __restrict__ class_count, int n_chunks, int chunks_per_block,
-                                                         const int* __restrict__ class_dirty /* null = every zone-B class */, int n_big) {
-  extern __shared__ u64 cw_lds[];  // [n_big][kWave][65]
-  const int lane = threadIdx.x;
-  const int w_raw = blockIdx.y * kWave + lane;
-  const bool live = w_raw < row_words, in_row = w_raw < row_stride;
-  const int w = live ? w_raw : 0;  // address-safe word for lanes beyond the row
-  for (int b = 0; b < n_big; ++b)
-    for (int i = 0; i <= 64; ++i) cw_lds[((size_t)b * kWave + lane) * 65 + i] = live ? pl.pmask[((size_t)b * pl.n_words + w) * 65 + i] : 0ull;
-  __syncthreads();
-  const bool all_fail = pin_enabled & 2;
-  pin_enabled &= 1;
-  const int c0 = blockIdx.x * chunks_per_block, c1 = min(c0 + chunks_per_block, n_chunks);
-  const int slots = pl.res_slots;
-  for (int base = c0; base < c1; base += kWave) {
-    // ---- lane i fetches everything about chunk base + i
-    const int c = base + lane;
-    const bool have = c < c1;
-    const int cls_l = have ? ct.chunk_class[c] : 0;
-    const int skip_l = (!have || (class_dirty ? !class_dirty[cls_l] : ct.chunk_zone[c] != 0)) ? 1 : 0;
-    const int begin_l = have ? ct.chunk_begin[c] : 0, len_l = have ? ct.chunk_len[c] : 0, first_l = have ? ct.chunk_first[c] : 0;
-    const int sr_l = ct.sig[cls_l * 4 + 0], st_l = ct.sig[cls_l * 4 + 1], sa_l = ct.sig[cls_l * 4 + 2], ss_l = ct.sig[cls_l * 4 + 3];
-    const int pin_l = pin_enabled ? ct.pin[cls_l] : -1;
-    const int m0_l = (have && len_l > 0) ? ct.members[begin_l] : -1;
-    int rr_l[kCwSlots];
-#pragma unroll
-    for (int k = 0; k < kCwSlots; ++k) rr_l[k] = (k < slots && pl.res && sr_l >= 0) ? pl.res_rows[(size_t)sr_l * slots + k] : -1;
-    const int m = min(kWave, c1 - base);
-    for (int i0 = 0; i0 < m; i0 += kCwUnroll) {
-      u64 x[kCwUnroll];
-#pragma unroll
-      for (int u = 0; u < kCwUnroll; ++u) {
-        const int i = min(i0 + u, m - 1);  // (a repeated last chunk is computed and dropped below)
-        u64 v = live ? ~0ull : 0ull;
-        const int st = __builtin_amdgcn_readlane(st_l, i), sa = __builtin_amdgcn_readlane(sa_l, i), ss = __builtin_amdgcn_readlane(ss_l, i);
-        if (pl.tol && st >= 0) v &= pl.tol[(size_t)st * pl.stride + w];
-        if (pl.aff && sa >= 0) v &= pl.aff[(size_t)sa * pl.stride + w];
-        if (pl.spread && ss >= 0) v &= pl.spread[(size_t)ss * pl.stride + w];
-#pragma unroll
-        for (int k = 0; k < kCwSlots; ++k) {
-          if (k >= slots) continue;
-          const int r = __builtin_amdgcn_readlane(rr_l[k], i);
-          if (r < 0) continue;
-          const int big = r >> kRowBigShift, rid = r & ((1 << kRowBigShift) - 1);
-          if (big) {
-            const int pos = pl.res_idx[(size_t)rid * pl.idx_stride + w];
-            v &= cw_lds[((size_t)(big - 1) * kWave + lane) * 65 + pos];
-          } else {
-            v &= pl.res[(size_t)rid * pl.stride + w];
-          }
-        }
-        const int pin = __builtin_amdgcn_readlane(pin_l, i);
-        if (pin == -2 || all_fail)
-          v = 0;
-        else if (pin >= 0)
-          v &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-        x[u] = live ? v : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < kCwUnroll; ++u) {
-        const int i = i0 + u;
-        if (i >= m) break;
-        if (__builtin_amdgcn_readlane(skip_l, i)) continue;
-        if (__builtin_amdgcn_readlane(first_l, i)) {  // this word block's share of the class's feasible count
-          int pc = __popcll(x[u]);
-#pragma unroll
-          for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
-          if (lane == 0 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, i)], pc);
-        }
-        const int len = __builtin_amdgcn_readlane(len_l, i), begin = __builtin_amdgcn_readlane(begin_l, i);
-        int p = __builtin_amdgcn_readlane(m0_l, i);
-        for (int j = 0; j < len; ++j) {
-          if (j) p = ct.members[begin + j];
-          if (p >= 0 && in_row) bitmap[(size_t)p * row_stride + w_raw] = x[u];
-        }
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // zone A of the bitmap: written with the store pattern of a linear fill (scripts/fill_probe*.hip)
 // ---------------------------------------------------------------------------------------------------
@@ -1308,7 +1277,7 @@ __global__ __launch_bounds__(kBlock) void k_fix_rows(u64* __restrict__ out, cons
 // decide: best feasible node of a class = first set bit in bin-pack rank order
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked, int n_classes, int row_words, const int* __restrict__ perm,
-                                                   const int* __restrict__ rank, int pin_enabled, int* __restrict__ class_best) {
+                                                   const int* __restrict__ rank, int pin_enabled, int* __restrict__ class_best, int eager) {
   int cls = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   if (cls >= n_classes) return;
   const int lane = threadIdx.x % kWave;
@@ -1330,10 +1299,22 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
       // first, where those planes are mostly zero — a lane whose word is already zero loads nothing more, so the scan to the
       // first feasible node reads little beyond one plane.
       u64 x = w < row_words ? ~0ull : 0ull;
-      if (cr.ni && x) x &= class_idx_word(cr, w);  // (the request-value rows first: see above)
+      if (eager) {
+        // few classes (< one wave per SIMD): nothing to save by skipping loads, everything to gain from issuing a step's plane
+        // words together instead of one after the other — the scan is a chain of memory latencies beside a saturated HBM
+        const int ws = w < row_words ? w : 0;
+        u64 y = ~0ull;
 #pragma unroll
-      for (int i = kMaxClassRows - 1; i >= 0; --i)
-        if (i < cr.n && x) x &= cr.row[i][w];
+        for (int i = 0; i < kMaxClassRows; ++i)
+          if (i < cr.n) y &= cr.row[i][ws];
+        if (cr.ni) y &= class_idx_word(cr, ws);
+        x &= y;
+      } else {
+        if (cr.ni && x) x &= class_idx_word(cr, w);  // (the request-value rows first: see above)
+#pragma unroll
+        for (int i = kMaxClassRows - 1; i >= 0; --i)
+          if (i < cr.n && x) x &= cr.row[i][w];
+      }
       u64 any = __ballot(x != 0);
       if (any) {
         int first_lane = __ffsll((long long)any) - 1;
