@@ -151,6 +151,8 @@ struct ykpred_engine {
   int wave_combine_below = 16;  // tunable: cfg.reserved[5] — average members per chunk below which k_combine_wave is used
   int n_big = 0, walk_chunks = 0, index_rows = 0;
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
+  DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
+  bool decide_skip = true;  // YKPRED_DECIDE_SKIP=0: scan every class from the first position
   DevBuf d_idx_c, d_idx_r;  // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical / rank order
   int idx_stride = 0;
   DevBuf d_sig_tol, d_sig_tolflags, d_sig_ports, d_swanted;                    // [Dtol][KT], [Dtol], [Dtol][KP]; [S][KP]
@@ -673,7 +675,7 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
     }
   }
   e->plane_rows_alloc = rows;
-  size_t base_need = (size_t)(64 * (e->W + e->KT + e->KP) + 3) * (size_t)e->row_stride * sizeof(u64);  // + unsched, exists, zero
+  size_t base_need = (size_t)(64 * (e->W + e->KT + e->KP) + 2) * (size_t)e->row_stride * sizeof(u64);
   for (DevBuf* b : {&e->base_canon, &e->base_ranked}) {
     if (b->cap < base_need) {
       e->tables_version++;
@@ -977,6 +979,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   }
   if (const char* v = getenv("YKPRED_DECIDE_GROUPS_FROM")) e->decide_groups_from = atoi(v);
   if (const char* v = getenv("YKPRED_PERMUTE_ALL")) e->permute_all_enabled = atoi(v) != 0;
+  if (const char* v = getenv("YKPRED_DECIDE_SKIP")) e->decide_skip = atoi(v) != 0;
   if (const char* v = getenv("YKPRED_ZONE_B_FIRST")) e->zone_b_first = atoi(v) != 0;
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -1021,7 +1024,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1535,16 +1538,24 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                   e->d_sig_pre_terms.as<u64>()};
   auto canon_of = [&](const Family& f) { return e->planes_canon.as<u64>() + (size_t)f.base * e->row_stride; };
   auto ranked_of = [&](const Family& f) { return e->planes_ranked.as<u64>() + (size_t)f.base * e->row_stride; };
-  ykk::PlaneOut o_res{canon_of(e->fam_res), ranked_of(e->fam_res), e->row_stride, e->fam_res.D};
-  ykk::PlaneOut o_tol{canon_of(e->fam_tol), ranked_of(e->fam_tol), e->row_stride, e->fam_tol.D};
-  ykk::PlaneOut o_aff{canon_of(e->fam_aff), ranked_of(e->fam_aff), e->row_stride, e->fam_aff.D};
-  ykk::PlaneOut o_spread{canon_of(e->fam_spread), ranked_of(e->fam_spread), e->row_stride, e->fam_spread.D};
+  ykk::PlaneOut o_res{canon_of(e->fam_res), ranked_of(e->fam_res), e->row_stride, e->fam_res.D, nullptr};
+  ykk::PlaneOut o_tol{canon_of(e->fam_tol), ranked_of(e->fam_tol), e->row_stride, e->fam_tol.D, nullptr};
+  ykk::PlaneOut o_aff{canon_of(e->fam_aff), ranked_of(e->fam_aff), e->row_stride, e->fam_aff.D, nullptr};
+  ykk::PlaneOut o_spread{canon_of(e->fam_spread), ranked_of(e->fam_spread), e->row_stride, e->fam_spread.D, nullptr};
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
-                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words};
+                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
+                 nullptr, 0, 0, 0, 0};
+  // first non-zero word of every rank-ordered plane row (whole buffer: families at their base rows), reset per pass
+  int* first_r = nullptr;
+  if ((a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->decide_skip) {
+    HIPCHK(e->d_first_r.ensure((size_t)std::max(e->plane_rows_alloc, 1) * sizeof(int)));
+    first_r = e->d_first_r.as<int>();
+  }
   ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
-                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(), e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words};
+                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(), e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words,
+                 first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base, e->fam_spread.base};
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -1552,6 +1563,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) {
     HIPCHK(hipEventRecord(e->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_fork, 0));
+    if (first_r) HIPCHK(hipMemsetAsync(first_r, 0x7f, (size_t)std::max(e->plane_rows_alloc, 1) * sizeof(int), sb));  // = ykk::kNoWord
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, nt, e->d_score.as<double>(), e->d_key.as<u64>());
     tm.end(sb, "k_score");
@@ -1579,7 +1591,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     bp.port = bp.taint + (size_t)64 * e->KT * e->row_stride;
     bp.unsched = bp.port + (size_t)64 * e->KP * e->row_stride;
     bp.exists = bp.unsched + e->row_stride;
-    bp.zero = bp.exists + e->row_stride;  // zeroed when the buffer is allocated (ensure_planes), written by nobody
     bp.stride = e->row_stride;
     return bp;
   };
@@ -1596,6 +1607,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (ranked) {
       sa.tol.canon = o_tol.ranked;
       sa.aff.canon = o_aff.ranked;
+      sa.tol.first = first_r ? first_r + e->fam_tol.base : nullptr;
+      sa.aff.first = first_r ? first_r + e->fam_aff.base : nullptr;
     }
     if (!aff_on) sa.aff.D = 0;
     sa.sig_tol = e->d_sig_tol.as<u64>();
@@ -1628,6 +1641,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     pa.perm = perm;
     pa.res = o_res;
     pa.spread = o_spread;
+    if (perm && first_r) {
+      pa.res.first = first_r + e->fam_res.base;
+      pa.spread.first = first_r + e->fam_spread.base;
+    }
     if (!spread_on) pa.spread.D = 0;
     pa.dims = ykk::DimPlanes{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_dim_chunk_dim.as<int>(), e->d_dim_chunk_begin.as<int>(),
                              e->d_dim_chunk_len.as<int>(), res_on ? e->dim_chunks : 0};
@@ -1669,7 +1686,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (ballot_rows <= ykk::kManySigs && e->n_big == 0) {  // (index rows of walked dimensions are not bit planes: they are re-walked in rank order)
       tm.begin(sb);
       hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(ballot_rows), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
-                         e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, ballot_rows, e->row_words);
+                         e->planes_canon.as<u64>(), e->planes_ranked.as<u64>(), e->row_stride, ballot_rows, e->row_words, first_r);
       tm.end(sb, "k_permute_planes");
     } else if (res_on || spread_on) {
       // very many request / spread signatures: the bit gather would touch one cache line per lane and row; evaluating
@@ -2771,7 +2788,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
-  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
     hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),

@@ -193,7 +193,10 @@ struct PlaneOut {
   u64* ranked;  // [D][stride] (node axis permuted by bin-pack rank), may be null
   int stride;   // words per plane row
   int D;        // signatures
+  int* first;   // rank-ordered planes only (may be null): first[d] = index of the first non-zero word of row d (atomicMin; preset
+                // to kNoWord): k_decide starts its scan there and gives up at once on an empty row
 };
+constexpr int kNoWord = 0x7f7f7f7f;
 
 // blockIdx.x: chunk of kSigsPerBlock signatures (the unbounded axis: up to 2^31 blocks); blockIdx.y: group of 4 node
 // words (≤ 65 535 groups = 16.7 M nodes). `perm` != null selects the
@@ -214,6 +217,7 @@ __device__ __forceinline__ void plane_store(const PlaneOut& o, bool ranked, int 
   if (word < o.stride && lane < nsig && d < o.D) {
     u64* base = ranked ? o.ranked : o.canon;
     base[(size_t)d * o.stride + word] = keep;
+    if (ranked && o.first && keep) atomicMin(&o.first[d], word);
   }
 }
 
@@ -276,6 +280,7 @@ __device__ __forceinline__ void plane_dim(const NodeTable& t, const int* __restr
   if (lane < len) {
     u64* base = perm ? o.ranked : o.canon;
     base[(size_t)my_row * o.stride + word] = ((u64)keep_hi << 32) | keep_lo;
+    if (perm && o.first && (keep_lo | keep_hi)) atomicMin(&o.first[my_row], word);
   }
 }
 
@@ -405,7 +410,6 @@ struct BasePlanes {
   u64* port;     // [64*KP][stride] dictionary host port k in conflict on the node
   u64* unsched;  // [stride] node.Spec.Unschedulable
   u64* exists;   // [stride] bit set for positions < N (zero padding of the last word)
-  u64* zero;     // [stride] all zero (never written): the neutral row of an OR of planes
   int stride;
 };
 // blockIdx.x: dictionary word (0..W-1 labels, then KT taint words, then KP port words, last = flags); blockIdx.y: group of 4 node words.
@@ -455,59 +459,21 @@ struct SigPlaneArgs {
 };
 constexpr int kBitSigsPerBlock = 8;  // signatures per block; thread = one 64-node word of the row
 
-// The plane words a term ANDs (or a toleration signature ORs) are few — a nodeSelector pair and one or two expressions; a
-// handful of untolerated taints — but a loop "next set bit → load → combine" makes every load wait for the one before it,
-// and these kernels are pure latency: PlaneBatch collects up to four plane rows (wave-uniform pointers) and
-// loads them TOGETHER; empty slots point at the neutral row (`exists` for AND — every result is ANDed with it anyway — the
-// all-zero row for OR), so the four loads are unconditional and issue back to back.
-struct PlaneBatch {
-  const u64* p[4];
-  int n;
-  const u64* neutral;
-  __device__ __forceinline__ explicit PlaneBatch(const u64* neutral_row) : n(0), neutral(neutral_row) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = neutral_row;
-  }
-  __device__ __forceinline__ void add(const u64* row) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i == n) p[i] = row;
-    ++n;
-  }
-  __device__ __forceinline__ bool full() const { return n >= 4; }
-  __device__ __forceinline__ void reset() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = neutral;
-    n = 0;
-  }
-  __device__ __forceinline__ u64 and_at(int w) const {
-    const u64 a = p[0][w], b = p[1][w], c = p[2][w], d = p[3][w];
-    return (a & b) & (c & d);
-  }
-  __device__ __forceinline__ u64 or_at(int w) const {
-    const u64 a = p[0][w], b = p[1][w], c = p[2][w], d = p[3][w];
-    return (a | b) | (c | d);
-  }
-};
-__device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride, int w,
-                                         const u64* __restrict__ exists_row) {
+// (Round 3 tried loading the plane words of a term four at a time — unconditional loads, empty slots pointed at a neutral
+// row — to break the "next set bit → load → combine" dependency: k_sig_planes got SLOWER, 0.50 → 0.65 ms on 46 k signatures;
+// the extra loads of the neutral row cost more L2 throughput than the shorter chain saved. profiles/r03_session5_*.txt)
+__device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride, int w) {
   u64 any = 0;
   for (int t = t0; t < t1; ++t) {
     u64 all = ~0ull;
-    PlaneBatch pb(exists_row);
     for (int k = 0; k < W; ++k) {
       u64 m = terms[(size_t)t * W + k];  // wave-uniform
       while (m) {
         int q = __ffsll((long long)m) - 1;
         m &= m - 1;
-        if (pb.full()) {
-          all &= pb.and_at(w);
-          pb.reset();
-        }
-        pb.add(req + (size_t)(k * 64 + q) * stride);
+        all &= req[(size_t)(k * 64 + q) * stride + w];
       }
     }
-    all &= pb.and_at(w);  // (an empty term = `exists`: matches every node)
     any |= all;
   }
   return any;
@@ -516,26 +482,19 @@ __device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, 
 // block's slice of `terms`): j0 / j1 index that slice. One v_readlane pair per mask word instead of a scalar load whose
 // address depends on the previous one.
 constexpr int kSigTermRegs = 4;  // 256 mask words per block of signatures; larger slices take the scalar path
-__device__ __forceinline__ u64 dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride, int w,
-                                              const u64* __restrict__ exists_row) {
+__device__ __forceinline__ u64 dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride, int w) {
   u64 any = 0;
   for (int j = j0; j < j1;) {
     u64 all = ~0ull;
-    PlaneBatch pb(exists_row);
     for (int k = 0; k < W; ++k, ++j) {
       const int r = j >> 6, l = j & 63;  // wave-uniform
       u64 m = (u64)readlane_i64((i64)(r == 0 ? tw[0] : (r == 1 ? tw[1] : (r == 2 ? tw[2] : tw[3]))), l);
       while (m) {
         int q = __ffsll((long long)m) - 1;
         m &= m - 1;
-        if (pb.full()) {
-          all &= pb.and_at(w);
-          pb.reset();
-        }
-        pb.add(req + (size_t)(k * 64 + q) * stride);
+        all &= req[(size_t)(k * 64 + q) * stride + w];
       }
     }
-    all &= pb.and_at(w);
     any |= all;
   }
   return any;
@@ -569,7 +528,6 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
       const int d = d0 + i;
       const unsigned fl = (unsigned)__builtin_amdgcn_readlane((int)fl_l, i);
       u64 bad = 0;  // nodes carrying a taint this signature does not tolerate
-      PlaneBatch pb(a.base.zero);
       if (taint_en)
         for (int k = 0; k < a.KT; ++k) {
           const u64 tolerated = batch ? (u64)readlane_i64((i64)tol_l, i * a.KT + k) : a.sig_tol[(size_t)d * a.KT + k];
@@ -577,11 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           while (m) {
             int tt = __ffsll((long long)m) - 1;
             m &= m - 1;
-            if (pb.full()) {
-              bad |= pb.or_at(w);
-              pb.reset();
-            }
-            pb.add(a.base.taint + (size_t)(k * 64 + tt) * a.base.stride);
+            bad |= a.base.taint[(size_t)(k * 64 + tt) * a.base.stride + w];
           }
         }
       if (!(fl & kSpecToleratesUnsched)) bad |= unsched;
@@ -592,15 +546,15 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           while (m) {
             int pp = __ffsll((long long)m) - 1;
             m &= m - 1;
-            if (pb.full()) {
-              bad |= pb.or_at(w);
-              pb.reset();
-            }
-            pb.add(a.base.port + (size_t)(k * 64 + pp) * a.base.stride);
+            bad |= a.base.port[(size_t)(k * 64 + pp) * a.base.stride + w];
           }
         }
-      bad |= pb.or_at(w);
-      if (live) a.tol.canon[(size_t)d * a.tol.stride + w] = exists & ~bad;
+      const u64 val = exists & ~bad;
+      if (live) a.tol.canon[(size_t)d * a.tol.stride + w] = val;
+      if (a.tol.first) {
+        const u64 nz = __ballot(live && val != 0);
+        if (nz && lane == 0) atomicMin(&a.tol.first[d], w_raw + __ffsll((long long)nz) - 1);
+      }
     }
   } else {
     const int nd = min(kBitSigsPerBlock, a.aff.D - d0);
@@ -625,14 +579,18 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
       if (pre_en && !skip) {
         if (f & kSpecPreReject) ok = 0;  // PreFilter rejected the pod (:236-238)
         if (f & kSpecPreNames)            // "node not eligible" (:248-250)
-          ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w, a.base.exists);
+          ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w);
       }
       if (filt_en && !skip) {
         const int t0 = __builtin_amdgcn_readlane(to_l, i), t1 = __builtin_amdgcn_readlane(to_l, i + 1);
-        ok &= batch ? dnf_words_regs(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w, a.base.exists)
-                    : dnf_words(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w, a.base.exists);
+        ok &= batch ? dnf_words_regs(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w)
+                    : dnf_words(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w);
       }
       if (live) a.aff.canon[(size_t)d * a.aff.stride + w] = ok;
+      if (a.aff.first) {
+        const u64 nz = __ballot(live && ok != 0);
+        if (nz && lane == 0) atomicMin(&a.aff.first[d], w_raw + __ffsll((long long)nz) - 1);
+      }
     }
   }
 }
@@ -640,7 +598,8 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
 // Rank-ordered planes by bit permutation: ranked[d] bit i = canonical[d] bit perm[i]. One launch covers every family
 // (their planes are rows of one buffer), replacing a second evaluation of all predicates in permuted node order.
 __global__ __launch_bounds__(kBlock) void k_permute_planes(int n_nodes, const int* __restrict__ perm, const u64* __restrict__ canon,
-                                                           u64* __restrict__ ranked, int stride, int n_rows, int n_words) {
+                                                           u64* __restrict__ ranked, int stride, int n_rows, int n_words,
+                                                           int* __restrict__ first /* may be null */) {
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const int w = blockIdx.y * kWavesPerBlock + wave;
   if (w >= n_words) return;
@@ -656,7 +615,10 @@ __global__ __launch_bounds__(kBlock) void k_permute_planes(int n_nodes, const in
     u64 b = __ballot(bit);
     if (d - d0 == lane) keep = b;
   }
-  if (lane < dend - d0) ranked[(size_t)(d0 + lane) * stride + w] = keep;
+  if (lane < dend - d0) {
+    ranked[(size_t)(d0 + lane) * stride + w] = keep;
+    if (first && keep) atomicMin(&first[d0 + lane], w);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -884,6 +846,8 @@ struct Planes {
   int idx_stride;
   const u64* pmask;       // [walked dimensions][n_words][65] mask tables of k_dim_sort (entry 64 = no node)
   int n_words;
+  const int* first;       // rank-ordered planes: first non-zero word per plane row of the whole buffer (null: not kept) ...
+  int base_res, base_tol, base_aff, base_spread;  // ... indexed by family base + signature
 };
 constexpr int kMaxClassRows = 3 + 1 + kMaxR;
 constexpr int kMaxIdxRows = 2;     // sorted-walk dimensions (further many-valued dimensions stay on ballot planes)
@@ -897,11 +861,13 @@ struct ClassRows {
   const unsigned char* irow[kMaxIdxRows];  // index rows (sorted-walk dimensions) ...
   const u64* ipm[kMaxIdxRows];             // ... and the mask table of their dimension
   int ni;
+  int start;                               // no row of the class has a bit before this word (kNoWord: some row is empty)
 };
 __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st, int sa, int ss) {
   ClassRows cr;
   cr.n = 0;
   cr.ni = 0;
+  cr.start = 0;
 #pragma unroll
   for (int i = 0; i < kMaxClassRows; ++i) cr.row[i] = nullptr;
 #pragma unroll
@@ -909,15 +875,16 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
     cr.irow[i] = nullptr;
     cr.ipm[i] = nullptr;
   }
-  auto add = [&](const u64* p) {
+  auto add = [&](const u64* p, int global_row) {
 #pragma unroll
     for (int i = 0; i < kMaxClassRows; ++i)
       if (i == cr.n) cr.row[i] = p;
     ++cr.n;
+    if (pl.first) cr.start = max(cr.start, pl.first[global_row]);
   };
-  if (pl.tol && st >= 0) add(pl.tol + (size_t)st * pl.stride);
-  if (pl.aff && sa >= 0) add(pl.aff + (size_t)sa * pl.stride);
-  if (pl.spread && ss >= 0) add(pl.spread + (size_t)ss * pl.stride);
+  if (pl.tol && st >= 0) add(pl.tol + (size_t)st * pl.stride, pl.base_tol + st);
+  if (pl.aff && sa >= 0) add(pl.aff + (size_t)sa * pl.stride, pl.base_aff + sa);
+  if (pl.spread && ss >= 0) add(pl.spread + (size_t)ss * pl.stride, pl.base_spread + ss);
   if (pl.res && sr >= 0) {
     const int* rr = pl.res_rows + (size_t)sr * pl.res_slots;
     for (int k = 0; k < pl.res_slots; ++k) {
@@ -933,7 +900,7 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
           }
         ++cr.ni;
       } else {
-        add(pl.res + (size_t)rid * pl.stride);
+        add(pl.res + (size_t)rid * pl.stride, pl.base_res + rid);
       }
     }
   }
@@ -1293,7 +1260,8 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
     u64 x = class_word(cr, pos >> 6);
     best = ((x >> (pos & 63)) & 1ull) ? pin : -1;
   } else {
-    for (int base = 0; base < row_words; base += kWave) {
+    // (cr.start = kNoWord ≥ row_words: some row of the class has no node at all — nothing to scan)
+    for (int base = cr.start & ~(kWave - 1); base < row_words; base += kWave) {
       int w = base + lane;
       // Lane-predicated AND, request-value planes first (they come last in `cr`): bin-pack order tries the fullest nodes
       // first, where those planes are mostly zero — a lane whose word is already zero loads nothing more, so the scan to the
@@ -1363,7 +1331,11 @@ __global__ __launch_bounds__(kBlock) void k_decide_groups(ClassTable ct, Planes 
     best = ((x >> (pos & 63)) & 1ull) ? pin : -1;
     done = true;
   }
-  for (int base = 0; base < row_words; base += kDecideLanes) {
+  // every group starts where its class's rows first have a bit at all (cr.start; kNoWord = an empty row: nothing to scan)
+  const int w0 = cr.start >= row_words ? row_words : (cr.start & ~(kDecideLanes - 1));
+  for (int t = 0;; ++t) {
+    const int base = w0 + t * kDecideLanes;
+    if (base >= row_words) done = true;
     if (__ballot(!done) == 0) break;
     const u64 x = done ? 0ull : word_at(base + l);
     const u64 any = __ballot(x != 0);
