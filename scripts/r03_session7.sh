@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 3, GPU session 7: k_combine_slices (LDS mask tables), k_sig_planes<WPL>, aux-stream priority — knob sweep with parity checks
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+rm -f gpurun_out/r03_probe2.jsonl
+python -c "import importlib; importlib.import_module('yunikorn-k8shim_amd').build_all()" || exit 1
+export PROBE_SETS='[
+ {"knobs":{"YKPRED_COMBINE_SLICES":"0","YKPRED_SIG_WPL":"1"},"workloads":"own,unique,default"},
+ {"knobs":{},"workloads":"own,unique,default","check":true,"both":true},
+ {"knobs":{"YKPRED_COMBINE_SLICES":"2"},"workloads":"own,unique","check":true},
+ {"knobs":{"YKPRED_SIG_WPL":"2"},"workloads":"own"},
+ {"knobs":{"YKPRED_AUX_PRIORITY":"-1"},"workloads":"own,unique"},
+ {"knobs":{"YKPRED_AUX_PRIORITY":"0"},"workloads":"own"},
+ {"knobs":{"YKPRED_SLICE_CHUNKS":"512"},"workloads":"unique"},
+ {"knobs":{"YKPRED_SLICE_CHUNKS":"64"},"workloads":"unique"}
+]'
+timeout 600 python scripts/r03_probe2.py 2>&1 | grep '^{' | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l)
+    print(d['knobs'], d['workload'], d['ms_per_step'], d.get('ms_per_step_nodec'), d.get('parity'))
+    print('    ', d['kernel_ms'])
+    if 'kernel_ms_nodec' in d: print('    nodec', d['kernel_ms_nodec'])"

@@ -181,6 +181,9 @@ struct ykpred_engine {
   bool permute_all_enabled = false; // YKPRED_PERMUTE_ALL=1: with few planes, rank-ordered copies of ALL of them by bit permutation instead of
                                     // evaluating the dictionary families a second time (measured equal: profiles/r03_session4_knobs.txt)
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
+  int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
+  int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
+  int slice_chunks_per_wave = 128;  // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
   int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
   bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
@@ -981,6 +984,9 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (const char* v = getenv("YKPRED_PERMUTE_ALL")) e->permute_all_enabled = atoi(v) != 0;
   if (const char* v = getenv("YKPRED_DECIDE_SKIP")) e->decide_skip = atoi(v) != 0;
   if (const char* v = getenv("YKPRED_ZONE_B_FIRST")) e->zone_b_first = atoi(v) != 0;
+  if (const char* v = getenv("YKPRED_COMBINE_SLICES")) e->combine_slices = atoi(v);
+  if (const char* v = getenv("YKPRED_SIG_WPL")) e->sig_wpl = atoi(v);
+  if (const char* v = getenv("YKPRED_SLICE_CHUNKS")) e->slice_chunks_per_wave = atoi(v);
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -991,7 +997,10 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   {
     int lo = 0, hi = 0;  // numerically lower = higher priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
+    // YKPRED_AUX_PRIORITY: 1 (default) = the decision stream gets the greatest priority, -1 = the least, 0 = none
+    int want = 1;
+    if (const char* v = getenv("YKPRED_AUX_PRIORITY")) want = atoi(v);
+    if (want == 0 || hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, want > 0 ? hi : lo) != hipSuccess)
       (void)hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking);
   }
   if (hipStreamCreateWithFlags(&e->zb_stream, hipStreamNonBlocking) != hipSuccess) e->zb_stream = nullptr;
@@ -1546,7 +1555,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
-                 nullptr, 0, 0, 0, 0};
+                 nullptr, 0, 0, 0, 0, 0};
   // first non-zero word of every rank-ordered plane row (whole buffer: families at their base rows), reset per pass
   int* first_r = nullptr;
   if ((a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->decide_skip) {
@@ -1555,7 +1564,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(), e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words,
-                 first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base, e->fam_spread.base};
+                 first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base, e->fam_spread.base, 0};
+  pc.n_big = pr.n_big = res_on ? e->n_big : 0;
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -1624,8 +1634,15 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     sa.n_words = e->row_words;
     const unsigned chunks = (unsigned)((std::max(sa.tol.D, sa.aff.D) + ykk::kBitSigsPerBlock - 1) / ykk::kBitSigsPerBlock);
     tm.begin(s);
-    hipLaunchKernelGGL(ykk::k_sig_planes, dim3(std::max(chunks, 1u), (unsigned)((e->row_words + ykk::kBlock - 1) / ykk::kBlock), 2u),
-                       dim3(ykk::kBlock), 0, s, sa);
+    // words per lane: wide rows give a lane 4 (or 2) words 64 apart — the per-signature latency chain moves more bytes
+    const int wpl = e->sig_wpl > 0 ? e->sig_wpl : (e->row_words >= 4 * ykk::kWave ? 4 : (e->row_words >= 2 * ykk::kWave ? 2 : 1));
+    const unsigned ygroups = (unsigned)((e->row_words + ykk::kBlock * wpl - 1) / (ykk::kBlock * wpl));
+    if (wpl >= 4)
+      hipLaunchKernelGGL(ykk::k_sig_planes<4>, dim3(std::max(chunks, 1u), ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
+    else if (wpl >= 2)
+      hipLaunchKernelGGL(ykk::k_sig_planes<2>, dim3(std::max(chunks, 1u), ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
+    else
+      hipLaunchKernelGGL(ykk::k_sig_planes<1>, dim3(std::max(chunks, 1u), ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
     tm.end(s, sig_name);
   };
   // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order). With few signature planes
@@ -1768,7 +1785,18 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (!e->zone_b_first) TRY(launch_zone_a());
     tm.begin(sz);
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
-    if (small_chunks) {
+    const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0));
+    if (slices) {
+      // index rows to decode: a workgroup per 64-word slice of the row, mask tables in LDS (see k_combine_slices)
+      const int n_slices = (e->row_stride + ykk::kSliceWords - 1) / ykk::kSliceWords;
+      const int per_wave = std::max(64, e->slice_chunks_per_wave / 64 * 64);
+      const int per_block = per_wave * ykk::kSliceWaves;
+      const size_t lds = (size_t)pc.n_big * ykk::kSliceTable * sizeof(u64);
+      if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ykk::k_combine_slices, dim3((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices)), dim3(ykk::kSliceBlock), lds, sz, ct,
+                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, per_wave);
+    } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty);
@@ -2788,7 +2816,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
-  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
     hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),

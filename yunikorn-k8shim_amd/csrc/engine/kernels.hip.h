@@ -461,62 +461,103 @@ constexpr int kBitSigsPerBlock = 8;  // signatures per block; thread = one 64-no
 
 // (Round 3 tried loading the plane words of a term four at a time — unconditional loads, empty slots pointed at a neutral
 // row — to break the "next set bit → load → combine" dependency: k_sig_planes got SLOWER, 0.50 → 0.65 ms on 46 k signatures;
-// the extra loads of the neutral row cost more L2 throughput than the shorter chain saved. profiles/r03_session5_*.txt)
-__device__ __forceinline__ u64 dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride, int w) {
-  u64 any = 0;
+// the extra loads of the neutral row cost more than the shorter chain saved. profiles/r03_session5_*.txt)
+//
+// What the kernel waits on is LATENCY, signature after signature: the loads of signature i + 1 sit behind the store of
+// signature i in the one in-order vmcnt of gfx9, and every signature is a couple of loads and one store. WPL > 1 gives a lane
+// WPL words of the row, 64 apart (each load / store of a wave is still 512 contiguous bytes): the same chain per signature
+// moves WPL times the bytes, with WPL independent loads in flight per base plane and no extra traffic.
+template <int WPL>
+__device__ __forceinline__ void dnf_words(const u64* __restrict__ terms, int t0, int t1, int W, const u64* __restrict__ req, int stride,
+                                          const int (&w)[WPL], u64 (&any)[WPL]) {
+#pragma unroll
+  for (int j = 0; j < WPL; ++j) any[j] = 0;
   for (int t = t0; t < t1; ++t) {
-    u64 all = ~0ull;
+    u64 all[WPL];
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) all[j] = ~0ull;
     for (int k = 0; k < W; ++k) {
       u64 m = terms[(size_t)t * W + k];  // wave-uniform
       while (m) {
         int q = __ffsll((long long)m) - 1;
         m &= m - 1;
-        all &= req[(size_t)(k * 64 + q) * stride + w];
+        const u64* row = req + (size_t)(k * 64 + q) * stride;
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) all[j] &= row[w[j]];
       }
     }
-    any |= all;
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) any[j] |= all[j];
   }
-  return any;
 }
 // The same DNF with the term masks of the block's signatures held in registers (lane j of tw[r] = word r * 64 + j of the
 // block's slice of `terms`): j0 / j1 index that slice. One v_readlane pair per mask word instead of a scalar load whose
 // address depends on the previous one.
 constexpr int kSigTermRegs = 4;  // 256 mask words per block of signatures; larger slices take the scalar path
-__device__ __forceinline__ u64 dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride, int w) {
-  u64 any = 0;
-  for (int j = j0; j < j1;) {
-    u64 all = ~0ull;
-    for (int k = 0; k < W; ++k, ++j) {
-      const int r = j >> 6, l = j & 63;  // wave-uniform
+template <int WPL>
+__device__ __forceinline__ void dnf_words_regs(const u64 (&tw)[kSigTermRegs], int j0, int j1, int W, const u64* __restrict__ req, int stride,
+                                               const int (&w)[WPL], u64 (&any)[WPL]) {
+#pragma unroll
+  for (int j = 0; j < WPL; ++j) any[j] = 0;
+  for (int jj = j0; jj < j1;) {
+    u64 all[WPL];
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) all[j] = ~0ull;
+    for (int k = 0; k < W; ++k, ++jj) {
+      const int r = jj >> 6, l = jj & 63;  // wave-uniform
       u64 m = (u64)readlane_i64((i64)(r == 0 ? tw[0] : (r == 1 ? tw[1] : (r == 2 ? tw[2] : tw[3]))), l);
       while (m) {
         int q = __ffsll((long long)m) - 1;
         m &= m - 1;
-        all &= req[(size_t)(k * 64 + q) * stride + w];
+        const u64* row = req + (size_t)(k * 64 + q) * stride;
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) all[j] &= row[w[j]];
       }
     }
-    any |= all;
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) any[j] |= all[j];
   }
-  return any;
 }
-// blockIdx.x: chunk of kBitSigsPerBlock signatures, blockIdx.y: block of 256 row words, blockIdx.z: 0 = tol family, 1 = aff family.
+// blockIdx.x: chunk of kBitSigsPerBlock signatures, blockIdx.y: block of 256 * WPL row words, blockIdx.z: 0 = tol family, 1 = aff family.
+// Wave v of the block owns words [(blockIdx.y * 4 + v) * 64 * WPL, +64 * WPL); lane l its words base + j * 64 + l, j < WPL.
 // The signature tables of a block (flags, offsets, tolerated-taint words, term masks) are fetched ONCE with vector loads —
 // lane i holds signature d0 + i's entry — and broadcast with v_readlane: the per-signature chain of dependent scalar loads
 // (flags → offsets → masks, each a cold miss when every ask has its own template) was what the kernel waited on.
+template <int WPL>
 __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
-  const int w_raw = blockIdx.y * kBlock + threadIdx.x;
-  if (w_raw - (int)(threadIdx.x % kWave) >= a.n_words) return;  // whole wave beyond the row
-  const bool live = w_raw < a.n_words;
-  const int w = live ? w_raw : a.n_words - 1;  // every lane of a live wave takes part in the v_readlane exchanges
   const int lane = threadIdx.x % kWave;
-  const u64 exists = a.base.exists[w];
+  const int wbase = (blockIdx.y * kWavesPerBlock + threadIdx.x / kWave) * (kWave * WPL);
+  if (wbase >= a.n_words) return;  // whole wave beyond the row
+  int w[WPL], w_raw[WPL];
+  bool live[WPL];
+  u64 exists[WPL];
+#pragma unroll
+  for (int j = 0; j < WPL; ++j) {
+    w_raw[j] = wbase + j * kWave + lane;
+    live[j] = w_raw[j] < a.n_words;
+    w[j] = live[j] ? w_raw[j] : a.n_words - 1;  // every lane of a live wave takes part in the v_readlane exchanges
+    exists[j] = a.base.exists[w[j]];
+  }
+  // first non-zero word of the signature's row among this wave's words (rank-ordered planes only)
+  auto note_first = [&](int* first, int d, const u64 (&val)[WPL]) {
+    if (!first) return;
+    int fw = kNoWord;
+#pragma unroll
+    for (int j = WPL - 1; j >= 0; --j) {
+      const u64 nz = __ballot(live[j] && val[j] != 0);
+      if (nz) fw = wbase + j * kWave + __ffsll((long long)nz) - 1;
+    }
+    if (fw != kNoWord && lane == 0) atomicMin(&first[d], fw);
+  };
   const int d0 = blockIdx.x * kBitSigsPerBlock;
   if (blockIdx.z == 0) {
     const int nd = min(kBitSigsPerBlock, a.tol.D - d0);
     if (nd <= 0) return;
     const bool taint_en = a.filt_mask & kPlugTaint, unsched_en = a.filt_mask & kPlugUnsched;
     const bool ports_en = (a.filt_mask & kPlugPorts) && (a.pre_mask & kPlugPorts);
-    const u64 unsched = unsched_en ? a.base.unsched[w] : 0ull;
+    u64 unsched[WPL];
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) unsched[j] = unsched_en ? a.base.unsched[w[j]] : 0ull;
     const bool batch = nd * a.KT <= kWave && nd * a.KP <= kWave;
     const unsigned fl_l = lane < nd ? a.sig_tolflags[d0 + lane] : 0u;
     u64 tol_l = 0, port_l = 0;
@@ -527,7 +568,9 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
     for (int i = 0; i < nd; ++i) {
       const int d = d0 + i;
       const unsigned fl = (unsigned)__builtin_amdgcn_readlane((int)fl_l, i);
-      u64 bad = 0;  // nodes carrying a taint this signature does not tolerate
+      u64 bad[WPL];  // nodes carrying a taint this signature does not tolerate
+#pragma unroll
+      for (int j = 0; j < WPL; ++j) bad[j] = 0;
       if (taint_en)
         for (int k = 0; k < a.KT; ++k) {
           const u64 tolerated = batch ? (u64)readlane_i64((i64)tol_l, i * a.KT + k) : a.sig_tol[(size_t)d * a.KT + k];
@@ -535,26 +578,32 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
           while (m) {
             int tt = __ffsll((long long)m) - 1;
             m &= m - 1;
-            bad |= a.base.taint[(size_t)(k * 64 + tt) * a.base.stride + w];
+            const u64* row = a.base.taint + (size_t)(k * 64 + tt) * a.base.stride;
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) bad[j] |= row[w[j]];
           }
         }
-      if (!(fl & kSpecToleratesUnsched)) bad |= unsched;
-      if (fl & kSpecUnsupported) bad = ~0ull;  // not evaluated by the engine: fits nowhere (this family is always on)
       if (ports_en)  // NodePorts: a requested host port that is in conflict on the node
         for (int k = 0; k < a.KP; ++k) {
           u64 m = batch ? (u64)readlane_i64((i64)port_l, i * a.KP + k) : a.sig_ports[(size_t)d * a.KP + k];
           while (m) {
             int pp = __ffsll((long long)m) - 1;
             m &= m - 1;
-            bad |= a.base.port[(size_t)(k * 64 + pp) * a.base.stride + w];
+            const u64* row = a.base.port + (size_t)(k * 64 + pp) * a.base.stride;
+#pragma unroll
+            for (int j = 0; j < WPL; ++j) bad[j] |= row[w[j]];
           }
         }
-      const u64 val = exists & ~bad;
-      if (live) a.tol.canon[(size_t)d * a.tol.stride + w] = val;
-      if (a.tol.first) {
-        const u64 nz = __ballot(live && val != 0);
-        if (nz && lane == 0) atomicMin(&a.tol.first[d], w_raw + __ffsll((long long)nz) - 1);
+      u64 val[WPL];
+#pragma unroll
+      for (int j = 0; j < WPL; ++j) {
+        u64 b = bad[j];
+        if (!(fl & kSpecToleratesUnsched)) b |= unsched[j];
+        if (fl & kSpecUnsupported) b = ~0ull;  // not evaluated by the engine: fits nowhere (this family is always on)
+        val[j] = exists[j] & ~b;
+        if (live[j]) a.tol.canon[(size_t)d * a.tol.stride + w[j]] = val[j];
       }
+      note_first(a.tol.first, d, val);
     }
   } else {
     const int nd = min(kBitSigsPerBlock, a.aff.D - d0);
@@ -575,22 +624,35 @@ __global__ __launch_bounds__(kBlock) void k_sig_planes(SigPlaneArgs a) {
       const int d = d0 + i;
       const unsigned f = (unsigned)__builtin_amdgcn_readlane((int)f_l, i);
       const bool skip = pre_en && (f & kSpecAffSkip);  // predicate_manager.go:233-234,264-266
-      u64 ok = exists;
+      u64 ok[WPL];
+#pragma unroll
+      for (int j = 0; j < WPL; ++j) ok[j] = exists[j];
       if (pre_en && !skip) {
-        if (f & kSpecPreReject) ok = 0;  // PreFilter rejected the pod (:236-238)
-        if (f & kSpecPreNames)            // "node not eligible" (:248-250)
-          ok &= dnf_words(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w);
+        if (f & kSpecPreReject) {  // PreFilter rejected the pod (:236-238)
+#pragma unroll
+          for (int j = 0; j < WPL; ++j) ok[j] = 0;
+        }
+        if (f & kSpecPreNames) {  // "node not eligible" (:248-250)
+          u64 any[WPL];
+          dnf_words<WPL>(a.affs.pre_terms, a.affs.pre_off[d], a.affs.pre_off[d + 1], a.W, a.base.req, a.base.stride, w, any);
+#pragma unroll
+          for (int j = 0; j < WPL; ++j) ok[j] &= any[j];
+        }
       }
       if (filt_en && !skip) {
         const int t0 = __builtin_amdgcn_readlane(to_l, i), t1 = __builtin_amdgcn_readlane(to_l, i + 1);
-        ok &= batch ? dnf_words_regs(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w)
-                    : dnf_words(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w);
+        u64 any[WPL];
+        if (batch)
+          dnf_words_regs<WPL>(tw, (t0 - tbase) * a.W, (t1 - tbase) * a.W, a.W, a.base.req, a.base.stride, w, any);
+        else
+          dnf_words<WPL>(a.affs.terms, t0, t1, a.W, a.base.req, a.base.stride, w, any);
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) ok[j] &= any[j];
       }
-      if (live) a.aff.canon[(size_t)d * a.aff.stride + w] = ok;
-      if (a.aff.first) {
-        const u64 nz = __ballot(live && ok != 0);
-        if (nz && lane == 0) atomicMin(&a.aff.first[d], w_raw + __ffsll((long long)nz) - 1);
-      }
+#pragma unroll
+      for (int j = 0; j < WPL; ++j)
+        if (live[j]) a.aff.canon[(size_t)d * a.aff.stride + w[j]] = ok[j];
+      note_first(a.aff.first, d, ok);
     }
   }
 }
@@ -848,6 +910,7 @@ struct Planes {
   int n_words;
   const int* first;       // rank-ordered planes: first non-zero word per plane row of the whole buffer (null: not kept) ...
   int base_res, base_tol, base_aff, base_spread;  // ... indexed by family base + signature
+  int n_big;              // walked dimensions with a mask table in `pmask` (k_combine_slices stages their slices in LDS)
 };
 constexpr int kMaxClassRows = 3 + 1 + kMaxR;
 constexpr int kMaxIdxRows = 2;     // sorted-walk dimensions (further many-valued dimensions stay on ballot planes)
@@ -1060,6 +1123,143 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
     if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+  }
+}
+
+// Slice form of the class-by-class writer for populations with INDEX rows (every ask its own request value: 10^6 single-member
+// classes). Decoding an index byte through the word's 65-entry mask table is a gather with a 520-byte lane stride: in
+// k_combine_wave (lane = word) every lane of a wave load hits its own cache line — 128 lines per load instruction, and the
+// texture path, not HBM, sets the pace (6.8 ms for a 6.27 GB bitmap). Here a workgroup owns ONE slice of kSliceWords words of
+// the row for a long run of chunks: the mask tables of the slice (33 KB per walked dimension) sit in LDS, the decode is a
+// ds_read_b64, and global memory only sees coalesced streams (index bytes, plane words, 512-byte row pieces). Consecutive
+// workgroups take consecutive slices of the same chunks, so the pieces written at one moment still tile whole rows.
+// The per-chunk table walk (chunk -> class -> signatures -> plane rows) is done by the LANES for 64 chunks at once and
+// broadcast with v_readlane — no chain of dependent scalar loads per chunk.
+constexpr int kSliceWords = 64;
+constexpr int kSliceWaves = 8;
+constexpr int kSliceBlock = kSliceWaves * kWave;
+constexpr int kSliceTable = kSliceWords * 65;  // u64 entries per walked dimension
+__global__ __launch_bounds__(kSliceBlock) void k_combine_slices(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
+                                                               int pin_enabled, int* __restrict__ class_count, int n_chunks,
+                                                               const int* __restrict__ class_dirty /* null = every class */, int n_slices,
+                                                               int chunks_per_wave) {
+  extern __shared__ u64 s_pm[];  // [n_big][kSliceWords][65]
+  const bool all_fail = pin_enabled & 2;
+  pin_enabled &= 1;
+  const int slice = blockIdx.x % n_slices, batch = blockIdx.x / n_slices;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int w = slice * kSliceWords + lane;
+  if (pl.n_big > 0) {
+    const int cnt = max(min(kSliceWords, pl.n_words - slice * kSliceWords), 0) * 65;
+    for (int b = 0; b < pl.n_big; ++b) {
+      const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)slice * kSliceWords) * 65;
+      for (int i = threadIdx.x; i < kSliceTable; i += kSliceBlock) s_pm[b * kSliceTable + i] = i < cnt ? src[i] : 0ull;
+    }
+    __syncthreads();
+  }
+  const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
+  const int c_end = min(c_begin + chunks_per_wave, n_chunks);
+  const int slots = pl.res_slots;
+  for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
+    // lane j walks the tables of chunk c0 + j
+    const int chunk_l = c0 + lane;
+    bool act = false;
+    int cls_l = 0, begin_l = 0, len_l = 0, first_l = 0, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1, sr_l = -1;
+    int rr_l[kMaxR + 1];
+#pragma unroll
+    for (int k = 0; k <= kMaxR; ++k) rr_l[k] = -1;
+    if (chunk_l < c_end) {
+      cls_l = ct.chunk_class[chunk_l];
+      act = class_dirty ? class_dirty[cls_l] != 0 : ct.chunk_zone[chunk_l] == 0;
+      if (act) {
+        begin_l = ct.chunk_begin[chunk_l];
+        len_l = ct.chunk_len[chunk_l];
+        first_l = ct.chunk_first[chunk_l];
+        const int4 sg = *(const int4*)(ct.sig + (size_t)cls_l * 4);
+        sr_l = sg.x, st_l = sg.y, sa_l = sg.z, ss_l = sg.w;
+        pin_l = pin_enabled ? ct.pin[cls_l] : -1;
+        mem0_l = ct.members[begin_l];
+        if (pl.res && sr_l >= 0) {
+#pragma unroll
+          for (int k = 0; k <= kMaxR; ++k)
+            if (k < slots) rr_l[k] = pl.res_rows[(size_t)sr_l * slots + k];
+        }
+      }
+    }
+    u64 todo = __ballot(act);
+    while (todo) {
+      const int i = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int cls = __builtin_amdgcn_readlane(cls_l, i), begin = __builtin_amdgcn_readlane(begin_l, i), len = __builtin_amdgcn_readlane(len_l, i);
+      const int first = __builtin_amdgcn_readlane(first_l, i), pin = __builtin_amdgcn_readlane(pin_l, i), mem0 = __builtin_amdgcn_readlane(mem0_l, i);
+      const int st = __builtin_amdgcn_readlane(st_l, i), sa = __builtin_amdgcn_readlane(sa_l, i), ss = __builtin_amdgcn_readlane(ss_l, i);
+      // the class's rows (wave-uniform pointers), as class_rows() builds them — from the row ids the lanes fetched
+      const u64* row[kMaxClassRows];
+      size_t irow[kMaxIdxRows];  // offsets into pl.res_idx (offsets, not pointers: the loads stay global_load, not flat)
+      int ibig[kMaxIdxRows];
+      int n = 0, ni = 0;
+#pragma unroll
+      for (int k = 0; k < kMaxClassRows; ++k) row[k] = nullptr;
+#pragma unroll
+      for (int k = 0; k < kMaxIdxRows; ++k) {
+        irow[k] = 0;
+        ibig[k] = 0;
+      }
+      auto add = [&](const u64* p) {
+#pragma unroll
+        for (int k = 0; k < kMaxClassRows; ++k)
+          if (k == n) row[k] = p;
+        ++n;
+      };
+      if (pl.tol && st >= 0) add(pl.tol + (size_t)st * pl.stride);
+      if (pl.aff && sa >= 0) add(pl.aff + (size_t)sa * pl.stride);
+      if (pl.spread && ss >= 0) add(pl.spread + (size_t)ss * pl.stride);
+#pragma unroll
+      for (int k = 0; k <= kMaxR; ++k) {
+        const int r = __builtin_amdgcn_readlane(rr_l[k], i);
+        if (r < 0) continue;
+        const int big = r >> kRowBigShift, rid = r & ((1 << kRowBigShift) - 1);
+        if (big) {
+#pragma unroll
+          for (int j = 0; j < kMaxIdxRows; ++j)
+            if (j == ni) {
+              irow[j] = (size_t)rid * pl.idx_stride;
+              ibig[j] = big - 1;
+            }
+          ++ni;
+        } else {
+          add(pl.res + (size_t)rid * pl.stride);
+        }
+      }
+      u64 x = 0;
+      if (w < row_words && pin != -2 && !all_fail) {
+        x = ~0ull;
+#pragma unroll
+        for (int k = 0; k < kMaxClassRows; ++k)
+          if (k < n) x &= row[k][w];
+#pragma unroll
+        for (int j = 0; j < kMaxIdxRows; ++j)
+          if (j < ni) x &= s_pm[ibig[j] * kSliceTable + lane * 65 + pl.res_idx[irow[j] + w]];
+        if (pin >= 0) x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+      }
+      if (first) {
+        int pc = __popcll(x);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
+        if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+      }
+      if (w < row_stride) {
+        if (len == 1) {
+          if (mem0 >= 0) bitmap[(size_t)mem0 * row_stride + w] = x;
+        } else {
+          const int mine = lane < len ? ct.members[begin + lane] : -1;
+          for (int m = 0; m < len; ++m) {
+            const int p = __builtin_amdgcn_readlane(mine, m);
+            if (p >= 0) bitmap[(size_t)p * row_stride + w] = x;
+          }
+        }
+      }
+    }
   }
 }
 
