@@ -60,12 +60,11 @@ def parity(pm):
 
 for entry in sets:
     # an entry is either the knob dict itself or {"knobs": {...}, "workloads": "own,unique", "check": true, "both": true}
-    knobs = entry.get("knobs", entry) if isinstance(entry.get("knobs", None), dict) or "workloads" in entry or "check" in entry else entry
-    if knobs is entry and any(k in entry for k in ("workloads", "check", "both")):
-        knobs = {}
-    names_here = entry["workloads"].split(",") if "workloads" in entry else names
-    check_here = entry.get("check", check) if knobs is not entry else check
-    both_here = entry.get("both", bool(os.environ.get("PROBE_BOTH"))) if knobs is not entry else bool(os.environ.get("PROBE_BOTH"))
+    structured = "knobs" in entry
+    knobs = entry["knobs"] if structured else entry
+    names_here = entry["workloads"].split(",") if structured and "workloads" in entry else names
+    check_here = entry.get("check", check) if structured else check
+    both_here = entry.get("both", bool(os.environ.get("PROBE_BOTH"))) if structured else bool(os.environ.get("PROBE_BOTH"))
     for k in [k for k in os.environ if k.startswith("YKPRED_")]:
         del os.environ[k]
     os.environ.update({k: str(v) for k, v in knobs.items()})
