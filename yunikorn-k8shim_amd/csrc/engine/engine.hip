@@ -153,6 +153,7 @@ struct ykpred_engine {
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
   DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
   bool decide_skip = true;  // YKPRED_DECIDE_SKIP=0: scan every class from the first position
+  DevBuf d_pfx_r;           // [n_big][row_words] running maximum of the free values along the bin-pack order (k_dim_prefix_max)
   DevBuf d_idx_c, d_idx_r;  // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical / rank order
   int idx_stride = 0;
   DevBuf d_sig_tol, d_sig_tolflags, d_sig_ports, d_swanted;                    // [Dtol][KT], [Dtol], [Dtol][KP]; [S][KP]
@@ -183,7 +184,7 @@ struct ykpred_engine {
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
   int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
-  int slice_chunks_per_wave = 128;  // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
+  int slice_chunks_per_wave = 64;   // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
   int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
   bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
@@ -1033,7 +1034,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1555,7 +1556,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
-                 nullptr, 0, 0, 0, 0, 0};
+                 nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
   // first non-zero word of every rank-ordered plane row (whole buffer: families at their base rows), reset per pass
   int* first_r = nullptr;
   if ((a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->decide_skip) {
@@ -1564,8 +1565,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(), e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words,
-                 first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base, e->fam_spread.base, 0};
+                 first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base, e->fam_spread.base, 0, nullptr, nullptr};
   pc.n_big = pr.n_big = res_on ? e->n_big : 0;
+  if (first_r && res_on && e->n_big > 0 && !fit_error) {
+    HIPCHK(e->d_pfx_r.ensure((size_t)e->n_big * (size_t)std::max(e->row_words, 1) * sizeof(i64)));
+    pr.res_val = e->d_dim_val.as<i64>();
+    pr.pfx = e->d_pfx_r.as<i64>();
+  }
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -1684,6 +1690,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
       hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock),
                          0, s, dw, (ranked ? e->d_idx_r : e->d_idx_c).as<unsigned char>(), e->idx_stride);
+      if (ranked && pr.pfx)  // running maximum of the free values along the bin-pack order: where a value's row can start (k_decide)
+        hipLaunchKernelGGL(ykk::k_dim_prefix_max, dim3((unsigned)e->n_big), dim3(ykk::kPfxBlock), 0, s, dw, e->d_pfx_r.as<i64>());
       tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
     } else if (res_on && e->n_big > 0) {
       // Filter without PreFilter state: the walked rows fit nowhere like every other row of the family — position 64 of every
@@ -2816,7 +2824,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
-  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
     hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),

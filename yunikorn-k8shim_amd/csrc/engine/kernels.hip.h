@@ -369,6 +369,34 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* _
   }
 }
 
+// Rank order only. pfx[big][w] = the largest free value among the nodes of words 0..w of the bin-pack order (the last entry of a
+// word's sorted list is its maximum; positions past N carry INT64_MIN). One block per walked dimension, chunked inclusive
+// max-scan with a carry. k_decide starts a class's scan at the first word whose running maximum reaches the class's value.
+constexpr int kPfxBlock = 1024;
+__global__ __launch_bounds__(kPfxBlock) void k_dim_prefix_max(DimWalk a, i64* __restrict__ pfx) {
+  __shared__ i64 tmp[kPfxBlock];
+  const int big = blockIdx.x, t = threadIdx.x;
+  const i64 kMin = (i64)0x8000000000000000ull;
+  i64 carry = kMin;
+  for (int base = 0; base < a.n_words; base += kPfxBlock) {
+    const int w = base + t;
+    i64 v = w < a.n_words ? a.sfree[((size_t)big * a.n_words + w) * 64 + 63] : kMin;
+    tmp[t] = v;
+    __syncthreads();
+    for (int off = 1; off < kPfxBlock; off <<= 1) {
+      const i64 o = t >= off ? tmp[t - off] : kMin;
+      __syncthreads();
+      v = v > o ? v : o;
+      tmp[t] = v;
+      __syncthreads();
+    }
+    v = v > carry ? v : carry;
+    if (w < a.n_words) pfx[(size_t)big * a.n_words + w] = v;
+    carry = tmp[kPfxBlock - 1] > carry ? tmp[kPfxBlock - 1] : carry;
+    __syncthreads();
+  }
+}
+
 // NodeAffinity PreFilter + Filter (A.5). Signature = (flags, Filter DNF, PreFilter node-name DNF).
 struct AffSigs {
   const unsigned* flags;  // [D]
@@ -911,6 +939,9 @@ struct Planes {
   const int* first;       // rank-ordered planes: first non-zero word per plane row of the whole buffer (null: not kept) ...
   int base_res, base_tol, base_aff, base_spread;  // ... indexed by family base + signature
   int n_big;              // walked dimensions with a mask table in `pmask` (k_combine_slices stages their slices in LDS)
+  const i64* res_val;     // [rows] request value of a plane / index row of `res` (rank-ordered planes: with `pfx`, else null)
+  const i64* pfx;         // [walked dimensions][n_words] rank order only: largest free value among the nodes of words 0..w
+                          // (k_dim_prefix_max) — a row of value v has no bit before the first word with pfx >= v
 };
 constexpr int kMaxClassRows = 3 + 1 + kMaxR;
 constexpr int kMaxIdxRows = 2;     // sorted-walk dimensions (further many-valued dimensions stay on ballot planes)
@@ -962,6 +993,18 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
             cr.ipm[i] = pl.pmask + (size_t)(big - 1) * pl.n_words * 65;
           }
         ++cr.ni;
+        if (pl.first && pl.pfx) {
+          // index rows keep no first-word table (10^6 rows); the walked dimension is monotone instead: nodes with free >= v
+          // first appear in the first word whose running maximum reaches v — one binary search in an L1-resident array
+          const i64 v = pl.res_val[rid];
+          const i64* px = pl.pfx + (size_t)(big - 1) * pl.n_words;
+          int lo = 0, hi = pl.n_words;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (px[mid] < v) lo = mid + 1; else hi = mid;
+          }
+          cr.start = max(cr.start, lo < pl.n_words ? lo : kNoWord);
+        }
       } else {
         add(pl.res + (size_t)rid * pl.stride, pl.base_res + rid);
       }
@@ -1128,27 +1171,34 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
 
 // Slice form of the class-by-class writer for populations with INDEX rows (every ask its own request value: 10^6 single-member
 // classes). Decoding an index byte through the word's 65-entry mask table is a gather with a 520-byte lane stride: in
-// k_combine_wave (lane = word) every lane of a wave load hits its own cache line — 128 lines per load instruction, and the
-// texture path, not HBM, sets the pace (6.8 ms for a 6.27 GB bitmap). Here a workgroup owns ONE slice of kSliceWords words of
-// the row for a long run of chunks: the mask tables of the slice (33 KB per walked dimension) sit in LDS, the decode is a
-// ds_read_b64, and global memory only sees coalesced streams (index bytes, plane words, 512-byte row pieces). Consecutive
-// workgroups take consecutive slices of the same chunks, so the pieces written at one moment still tile whole rows.
-// The per-chunk table walk (chunk -> class -> signatures -> plane rows) is done by the LANES for 64 chunks at once and
-// broadcast with v_readlane — no chain of dependent scalar loads per chunk.
-constexpr int kSliceWords = 64;
-constexpr int kSliceWaves = 8;
+// k_combine_wave (lane = word) every lane of a wave load hits its own cache line, ≈ 100 KB of L2 → L1 line traffic per 6 KB row
+// written, and that — not HBM — sets the pace (4.5 ms alone, 6.8 ms beside the decision kernels for a 6.27 GB bitmap).
+// Here a workgroup owns ONE slice of kSliceWords words of the row for a long run of chunks:
+//   * the mask tables of the slice (65 KB per walked dimension) sit in LDS — the decode is a ds_read_b64, and global memory only
+//     sees coalesced streams (index bytes, plane words, 1 KiB row pieces: lane = two adjacent words);
+//   * the per-chunk table walk (chunk → class → signatures → plane rows) is done by the LANES for 64 chunks at once and
+//     broadcast with v_readlane — no chain of dependent scalar loads per chunk;
+//   * zone-B chunks come in signature order (aff, tol, spread, request vector: build_classes), so the toleration / affinity /
+//     spread words of a lane are kept in registers and reloaded only when the signature changes;
+//   * consecutive workgroups take consecutive slices of the same chunks, so the pieces in flight at one moment tile whole rows.
+// (First form, one word per lane and every row pointer rebuilt per (chunk, slice): 9.3 ms — 250 instructions and a full
+// load → store round trip per 512 bytes. profiles/r03_session7_*.txt)
+constexpr int kSliceWords = 128;
+constexpr int kSliceWaves = 16;
 constexpr int kSliceBlock = kSliceWaves * kWave;
 constexpr int kSliceTable = kSliceWords * 65;  // u64 entries per walked dimension
-__global__ __launch_bounds__(kSliceBlock) void k_combine_slices(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
+constexpr int kSlicePlaneRows = 4;             // request-value plane rows of a class served by the fast path (row 0 + 3 dimensions)
+__global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_combine_slices(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                                int pin_enabled, int* __restrict__ class_count, int n_chunks,
                                                                const int* __restrict__ class_dirty /* null = every class */, int n_slices,
                                                                int chunks_per_wave) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   extern __shared__ u64 s_pm[];  // [n_big][kSliceWords][65]
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int slice = blockIdx.x % n_slices, batch = blockIdx.x / n_slices;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int w = slice * kSliceWords + lane;
+  const int w = slice * kSliceWords + 2 * lane;  // this lane's words: w, w + 1 (row_stride is a multiple of 16: never straddled)
   if (pl.n_big > 0) {
     const int cnt = max(min(kSliceWords, pl.n_words - slice * kSliceWords), 0) * 65;
     for (int b = 0; b < pl.n_big; ++b) {
@@ -1160,29 +1210,50 @@ __global__ __launch_bounds__(kSliceBlock) void k_combine_slices(ClassTable ct, P
   const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
   const int c_end = min(c_begin + chunks_per_wave, n_chunks);
   const int slots = pl.res_slots;
+  const bool in0 = w < row_words, in1 = w + 1 < row_words;
+  // words of the signature families, cached across chunks (wave-uniform keys; -3 = nothing cached)
+  int cur_st = -3, cur_sa = -3, cur_ss = -3;
+  u64x2 w_tol = {~0ull, ~0ull}, w_aff = {~0ull, ~0ull}, w_spread = {~0ull, ~0ull};
   for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
     // lane j walks the tables of chunk c0 + j
     const int chunk_l = c0 + lane;
     bool act = false;
-    int cls_l = 0, begin_l = 0, len_l = 0, first_l = 0, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1, sr_l = -1;
-    int rr_l[kMaxR + 1];
+    int cls_l = 0, begin_l = 0, meta_l = 0 /* len | first << 8 | slow << 9 */, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1;
+    int prow_l[kSlicePlaneRows], irow_l[kMaxIdxRows];
 #pragma unroll
-    for (int k = 0; k <= kMaxR; ++k) rr_l[k] = -1;
+    for (int k = 0; k < kSlicePlaneRows; ++k) prow_l[k] = -1;
+#pragma unroll
+    for (int k = 0; k < kMaxIdxRows; ++k) irow_l[k] = -1;
     if (chunk_l < c_end) {
       cls_l = ct.chunk_class[chunk_l];
       act = class_dirty ? class_dirty[cls_l] != 0 : ct.chunk_zone[chunk_l] == 0;
       if (act) {
         begin_l = ct.chunk_begin[chunk_l];
-        len_l = ct.chunk_len[chunk_l];
-        first_l = ct.chunk_first[chunk_l];
+        meta_l = ct.chunk_len[chunk_l] | (ct.chunk_first[chunk_l] ? 1 << 8 : 0);
         const int4 sg = *(const int4*)(ct.sig + (size_t)cls_l * 4);
-        sr_l = sg.x, st_l = sg.y, sa_l = sg.z, ss_l = sg.w;
+        st_l = sg.y, sa_l = sg.z, ss_l = sg.w;
         pin_l = pin_enabled ? ct.pin[cls_l] : -1;
         mem0_l = ct.members[begin_l];
-        if (pl.res && sr_l >= 0) {
+        if (pl.res && sg.x >= 0) {
+          // the class's request-value rows, compacted: plane rows first come first served, index rows (walked dimensions) apart
+          int np = 0, ni = 0;
 #pragma unroll
-          for (int k = 0; k <= kMaxR; ++k)
-            if (k < slots) rr_l[k] = pl.res_rows[(size_t)sr_l * slots + k];
+          for (int k = 0; k <= kMaxR; ++k) {
+            const int r = k < slots ? pl.res_rows[(size_t)sg.x * slots + k] : -1;
+            if (r < 0) continue;
+            if (r >> kRowBigShift) {
+#pragma unroll
+              for (int j = 0; j < kMaxIdxRows; ++j)
+                if (j == ni) irow_l[j] = r;
+              ++ni;
+            } else {
+#pragma unroll
+              for (int j = 0; j < kSlicePlaneRows; ++j)
+                if (j == np) prow_l[j] = r;
+              if (np >= kSlicePlaneRows) meta_l |= 1 << 9;  // more rows than the fast path holds: this chunk takes class_rows()
+              ++np;
+            }
+          }
         }
       }
     }
@@ -1190,73 +1261,68 @@ __global__ __launch_bounds__(kSliceBlock) void k_combine_slices(ClassTable ct, P
     while (todo) {
       const int i = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      const int cls = __builtin_amdgcn_readlane(cls_l, i), begin = __builtin_amdgcn_readlane(begin_l, i), len = __builtin_amdgcn_readlane(len_l, i);
-      const int first = __builtin_amdgcn_readlane(first_l, i), pin = __builtin_amdgcn_readlane(pin_l, i), mem0 = __builtin_amdgcn_readlane(mem0_l, i);
+      const int begin = __builtin_amdgcn_readlane(begin_l, i), meta = __builtin_amdgcn_readlane(meta_l, i);
+      const int len = meta & 0xff, first = meta & (1 << 8), slow = meta & (1 << 9);
+      const int pin = __builtin_amdgcn_readlane(pin_l, i), mem0 = __builtin_amdgcn_readlane(mem0_l, i);
       const int st = __builtin_amdgcn_readlane(st_l, i), sa = __builtin_amdgcn_readlane(sa_l, i), ss = __builtin_amdgcn_readlane(ss_l, i);
-      // the class's rows (wave-uniform pointers), as class_rows() builds them — from the row ids the lanes fetched
-      const u64* row[kMaxClassRows];
-      size_t irow[kMaxIdxRows];  // offsets into pl.res_idx (offsets, not pointers: the loads stay global_load, not flat)
-      int ibig[kMaxIdxRows];
-      int n = 0, ni = 0;
-#pragma unroll
-      for (int k = 0; k < kMaxClassRows; ++k) row[k] = nullptr;
-#pragma unroll
-      for (int k = 0; k < kMaxIdxRows; ++k) {
-        irow[k] = 0;
-        ibig[k] = 0;
-      }
-      auto add = [&](const u64* p) {
-#pragma unroll
-        for (int k = 0; k < kMaxClassRows; ++k)
-          if (k == n) row[k] = p;
-        ++n;
-      };
-      if (pl.tol && st >= 0) add(pl.tol + (size_t)st * pl.stride);
-      if (pl.aff && sa >= 0) add(pl.aff + (size_t)sa * pl.stride);
-      if (pl.spread && ss >= 0) add(pl.spread + (size_t)ss * pl.stride);
-#pragma unroll
-      for (int k = 0; k <= kMaxR; ++k) {
-        const int r = __builtin_amdgcn_readlane(rr_l[k], i);
-        if (r < 0) continue;
-        const int big = r >> kRowBigShift, rid = r & ((1 << kRowBigShift) - 1);
-        if (big) {
-#pragma unroll
-          for (int j = 0; j < kMaxIdxRows; ++j)
-            if (j == ni) {
-              irow[j] = (size_t)rid * pl.idx_stride;
-              ibig[j] = big - 1;
-            }
-          ++ni;
+      u64x2 x = {0, 0};
+      if (pin != -2 && !all_fail && w < row_stride) {
+        if (slow) {
+          const int cls = __builtin_amdgcn_readlane(cls_l, i);
+          const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
+          if (in0) x.x = class_word(cr, w);
+          if (in1) x.y = class_word(cr, w + 1);
         } else {
-          add(pl.res + (size_t)rid * pl.stride);
+          if (st != cur_st) {
+            cur_st = st;
+            w_tol = (pl.tol && st >= 0) ? *(const u64x2*)(pl.tol + (size_t)st * pl.stride + w) : u64x2{~0ull, ~0ull};
+          }
+          if (sa != cur_sa) {
+            cur_sa = sa;
+            w_aff = (pl.aff && sa >= 0) ? *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + w) : u64x2{~0ull, ~0ull};
+          }
+          if (ss != cur_ss) {
+            cur_ss = ss;
+            w_spread = (pl.spread && ss >= 0) ? *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + w) : u64x2{~0ull, ~0ull};
+          }
+          x = w_tol & w_aff & w_spread;
+#pragma unroll
+          for (int k = 0; k < kSlicePlaneRows; ++k) {
+            const int r = __builtin_amdgcn_readlane(prow_l[k], i);
+            if (r >= 0) x &= *(const u64x2*)(pl.res + (size_t)r * pl.stride + w);
+          }
+#pragma unroll
+          for (int k = 0; k < kMaxIdxRows; ++k) {
+            const int r = __builtin_amdgcn_readlane(irow_l[k], i);
+            if (r >= 0) {
+              const int big = (r >> kRowBigShift) - 1, rid = r & ((1 << kRowBigShift) - 1);
+              const unsigned two = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + w);  // index bytes of w, w + 1
+              const u64* tab = s_pm + big * kSliceTable + (2 * lane) * 65;
+              x.x &= tab[two & 0xffu];
+              x.y &= tab[65 + (two >> 8)];
+            }
+          }
+          if (!in0) x.x = 0;  // (planes are zero in the padding anyway; index bytes there are not defined)
+          if (!in1) x.y = 0;
+        }
+        if (pin >= 0) {
+          x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+          x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
         }
       }
-      u64 x = 0;
-      if (w < row_words && pin != -2 && !all_fail) {
-        x = ~0ull;
-#pragma unroll
-        for (int k = 0; k < kMaxClassRows; ++k)
-          if (k < n) x &= row[k][w];
-#pragma unroll
-        for (int j = 0; j < kMaxIdxRows; ++j)
-          if (j < ni) x &= s_pm[ibig[j] * kSliceTable + lane * 65 + pl.res_idx[irow[j] + w]];
-        if (pin >= 0) x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-      }
       if (first) {
-        int pc = __popcll(x);
+        int pc = __popcll(x.x) + __popcll(x.y);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
-        if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+        if (lane == 0 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, i)], pc);
       }
-      if (w < row_stride) {
-        if (len == 1) {
-          if (mem0 >= 0) bitmap[(size_t)mem0 * row_stride + w] = x;
-        } else {
-          const int mine = lane < len ? ct.members[begin + lane] : -1;
-          for (int m = 0; m < len; ++m) {
-            const int p = __builtin_amdgcn_readlane(mine, m);
-            if (p >= 0) bitmap[(size_t)p * row_stride + w] = x;
-          }
+      if (len == 1) {
+        if (w < row_stride && mem0 >= 0) *(u64x2*)(bitmap + (size_t)mem0 * row_stride + w) = x;
+      } else {
+        const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
+        for (int m = 0; m < len; ++m) {
+          const int p = __builtin_amdgcn_readlane(mine, m);
+          if (p >= 0 && w < row_stride) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
         }
       }
     }
