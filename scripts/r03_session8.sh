@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU session 8: k_combine_slices v2 (128-word slices, cached signature words), decide start from the running maximum
+# round 3, GPU session 8+: k_combine_slices (128-word slices, cached signature words, batches of chunks), decide start from the running maximum
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 rm -f gpurun_out/r03_probe2.jsonl

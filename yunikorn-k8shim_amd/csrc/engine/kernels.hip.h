@@ -1169,6 +1169,18 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
   }
 }
 
+// Sum of an int over the 64 lanes of the wave, valid in LANE 63: the DPP row-shift / row-broadcast ladder (VALU only — six
+// ds_bpermute round trips per reduction were a visible part of k_combine_slices' per-chunk latency).
+__device__ __forceinline__ int wave_sum_lane63(int v) {
+  int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);         // row_shr:2
+  t += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);         // row_shr:3
+  t += __builtin_amdgcn_update_dpp(0, t, 0x114, 0xf, 0xe, true);         // row_shr:4, lanes 4..15 of every row
+  t += __builtin_amdgcn_update_dpp(0, t, 0x118, 0xf, 0xc, true);         // row_shr:8, lanes 8..15: lane 15 holds the row sum
+  t += __builtin_amdgcn_update_dpp(0, t, 0x142, 0xa, 0xf, true);         // row_bcast:15 into rows 1 and 3
+  t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, true);         // row_bcast:31 into rows 2 and 3
+  return t;
+}
 // Slice form of the class-by-class writer for populations with INDEX rows (every ask its own request value: 10^6 single-member
 // classes). Decoding an index byte through the word's 65-entry mask table is a gather with a 520-byte lane stride: in
 // k_combine_wave (lane = word) every lane of a wave load hits its own cache line, ≈ 100 KB of L2 → L1 line traffic per 6 KB row
@@ -1184,14 +1196,14 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
 // (First form, one word per lane and every row pointer rebuilt per (chunk, slice): 9.3 ms — 250 instructions and a full
 // load → store round trip per 512 bytes. profiles/r03_session7_*.txt)
 constexpr int kSliceWords = 128;
-constexpr int kSliceWaves = 16;
+constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
 constexpr int kSliceTable = kSliceWords * 65;  // u64 entries per walked dimension
-constexpr int kSlicePlaneRows = 4;             // request-value plane rows of a class served by the fast path (row 0 + 3 dimensions)
-__global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_combine_slices(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
-                                                               int pin_enabled, int* __restrict__ class_count, int n_chunks,
-                                                               const int* __restrict__ class_dirty /* null = every class */, int n_slices,
-                                                               int chunks_per_wave) {
+constexpr int kSlicePlaneRows = 2;             // request-value plane rows of a class served by the fast path (row 0 + one dimension)
+constexpr int kSliceBatch = 8;                 // chunks whose loads are in flight together (one wait, then kSliceBatch stores)
+__global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
+    ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
+    const int* __restrict__ class_dirty /* null = every class */, int n_slices, int chunks_per_wave) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   extern __shared__ u64 s_pm[];  // [n_big][kSliceWords][65]
   const bool all_fail = pin_enabled & 2;
@@ -1210,15 +1222,18 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(8, 
   const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
   const int c_end = min(c_begin + chunks_per_wave, n_chunks);
   const int slots = pl.res_slots;
-  const bool in0 = w < row_words, in1 = w + 1 < row_words;
-  // words of the signature families, cached across chunks (wave-uniform keys; -3 = nothing cached)
+  const bool store_lane = w < row_stride;
+  const int ws = store_lane ? w : 0;  // lanes past the row load from its first words and store nothing
+  const u64x2 keep = {w < row_words ? ~0ull : 0ull, w + 1 < row_words ? ~0ull : 0ull};  // padding words stay zero
+  const u64x2 ones = {~0ull, ~0ull};
+  // AND of the toleration / affinity / spread words of the current signature triple (wave-uniform keys; -3 = nothing cached)
   int cur_st = -3, cur_sa = -3, cur_ss = -3;
-  u64x2 w_tol = {~0ull, ~0ull}, w_aff = {~0ull, ~0ull}, w_spread = {~0ull, ~0ull};
+  u64x2 w_base = ones;
   for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
     // lane j walks the tables of chunk c0 + j
     const int chunk_l = c0 + lane;
     bool act = false;
-    int cls_l = 0, begin_l = 0, meta_l = 0 /* len | first << 8 | slow << 9 */, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1;
+    int cls_l = 0, meta_l = 0 /* len | first << 8 | slow << 9 */, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1;
     int prow_l[kSlicePlaneRows], irow_l[kMaxIdxRows];
 #pragma unroll
     for (int k = 0; k < kSlicePlaneRows; ++k) prow_l[k] = -1;
@@ -1228,12 +1243,13 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(8, 
       cls_l = ct.chunk_class[chunk_l];
       act = class_dirty ? class_dirty[cls_l] != 0 : ct.chunk_zone[chunk_l] == 0;
       if (act) {
-        begin_l = ct.chunk_begin[chunk_l];
-        meta_l = ct.chunk_len[chunk_l] | (ct.chunk_first[chunk_l] ? 1 << 8 : 0);
+        const int len = ct.chunk_len[chunk_l];
+        meta_l = len | (ct.chunk_first[chunk_l] ? 1 << 8 : 0);
         const int4 sg = *(const int4*)(ct.sig + (size_t)cls_l * 4);
         st_l = sg.y, sa_l = sg.z, ss_l = sg.w;
         pin_l = pin_enabled ? ct.pin[cls_l] : -1;
-        mem0_l = ct.members[begin_l];
+        mem0_l = ct.members[ct.chunk_begin[chunk_l]];
+        if (len != 1 || pin_l == -2) meta_l |= 1 << 9;  // several member rows / an unknown pinned node: the general path
         if (pl.res && sg.x >= 0) {
           // the class's request-value rows, compacted: plane rows first come first served, index rows (walked dimensions) apart
           int np = 0, ni = 0;
@@ -1250,7 +1266,7 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
               for (int j = 0; j < kSlicePlaneRows; ++j)
                 if (j == np) prow_l[j] = r;
-              if (np >= kSlicePlaneRows) meta_l |= 1 << 9;  // more rows than the fast path holds: this chunk takes class_rows()
+              if (np >= kSlicePlaneRows) meta_l |= 1 << 9;  // more rows than the fast path holds
               ++np;
             }
           }
@@ -1259,71 +1275,119 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(8, 
     }
     u64 todo = __ballot(act);
     while (todo) {
-      const int i = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const int begin = __builtin_amdgcn_readlane(begin_l, i), meta = __builtin_amdgcn_readlane(meta_l, i);
-      const int len = meta & 0xff, first = meta & (1 << 8), slow = meta & (1 << 9);
-      const int pin = __builtin_amdgcn_readlane(pin_l, i), mem0 = __builtin_amdgcn_readlane(mem0_l, i);
-      const int st = __builtin_amdgcn_readlane(st_l, i), sa = __builtin_amdgcn_readlane(sa_l, i), ss = __builtin_amdgcn_readlane(ss_l, i);
-      u64x2 x = {0, 0};
-      if (pin != -2 && !all_fail && w < row_stride) {
-        if (slow) {
-          const int cls = __builtin_amdgcn_readlane(cls_l, i);
+      const int i0 = __ffsll((long long)todo) - 1;
+      const int st = __builtin_amdgcn_readlane(st_l, i0), sa = __builtin_amdgcn_readlane(sa_l, i0), ss = __builtin_amdgcn_readlane(ss_l, i0);
+      const int meta0 = __builtin_amdgcn_readlane(meta_l, i0);
+      if (meta0 & (1 << 9)) {
+        // general path, one chunk: any number of rows and members (class_rows / class_word as in k_combine_wave)
+        todo &= todo - 1;
+        const int cls = __builtin_amdgcn_readlane(cls_l, i0), pin = __builtin_amdgcn_readlane(pin_l, i0), len = meta0 & 0xff;
+        u64x2 x = {0, 0};
+        if (pin != -2 && !all_fail && store_lane) {
           const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
-          if (in0) x.x = class_word(cr, w);
-          if (in1) x.y = class_word(cr, w + 1);
-        } else {
-          if (st != cur_st) {
-            cur_st = st;
-            w_tol = (pl.tol && st >= 0) ? *(const u64x2*)(pl.tol + (size_t)st * pl.stride + w) : u64x2{~0ull, ~0ull};
+          if (w < row_words) x.x = class_word(cr, w);
+          if (w + 1 < row_words) x.y = class_word(cr, w + 1);
+          if (pin >= 0) {
+            x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+            x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
           }
-          if (sa != cur_sa) {
-            cur_sa = sa;
-            w_aff = (pl.aff && sa >= 0) ? *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + w) : u64x2{~0ull, ~0ull};
-          }
-          if (ss != cur_ss) {
-            cur_ss = ss;
-            w_spread = (pl.spread && ss >= 0) ? *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + w) : u64x2{~0ull, ~0ull};
-          }
-          x = w_tol & w_aff & w_spread;
+        }
+        if (meta0 & (1 << 8)) {
+          const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));
+          if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+        }
+        const int begin = ct.chunk_begin[c0 + i0];
+        const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
+        for (int m = 0; m < len; ++m) {
+          const int p = __builtin_amdgcn_readlane(mine, m);
+          if (p >= 0 && store_lane) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
+        }
+        continue;
+      }
+      if (st != cur_st || sa != cur_sa || ss != cur_ss) {
+        cur_st = st, cur_sa = sa, cur_ss = ss;
+        w_base = keep;
+        if (pl.tol && st >= 0) w_base &= *(const u64x2*)(pl.tol + (size_t)st * pl.stride + ws);
+        if (pl.aff && sa >= 0) w_base &= *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + ws);
+        if (pl.spread && ss >= 0) w_base &= *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + ws);
+        if (all_fail) w_base = u64x2{0, 0};
+      }
+      // up to kSliceBatch single-row chunks of this signature triple: every load first, then the masks, then the stores
+      int id[kSliceBatch];
+      {
+        u64 rest = todo;
+        bool open = true;
 #pragma unroll
-          for (int k = 0; k < kSlicePlaneRows; ++k) {
-            const int r = __builtin_amdgcn_readlane(prow_l[k], i);
-            if (r >= 0) x &= *(const u64x2*)(pl.res + (size_t)r * pl.stride + w);
-          }
-#pragma unroll
-          for (int k = 0; k < kMaxIdxRows; ++k) {
-            const int r = __builtin_amdgcn_readlane(irow_l[k], i);
-            if (r >= 0) {
-              const int big = (r >> kRowBigShift) - 1, rid = r & ((1 << kRowBigShift) - 1);
-              const unsigned two = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + w);  // index bytes of w, w + 1
-              const u64* tab = s_pm + big * kSliceTable + (2 * lane) * 65;
-              x.x &= tab[two & 0xffu];
-              x.y &= tab[65 + (two >> 8)];
+        for (int j = 0; j < kSliceBatch; ++j) {
+          id[j] = -1;
+          if (open && rest) {
+            const int c = __ffsll((long long)rest) - 1;
+            const bool same = j == 0 || (__builtin_amdgcn_readlane(st_l, c) == st && __builtin_amdgcn_readlane(sa_l, c) == sa &&
+                                         __builtin_amdgcn_readlane(ss_l, c) == ss && !(__builtin_amdgcn_readlane(meta_l, c) & (1 << 9)));
+            if (same) {
+              id[j] = c;
+              rest &= rest - 1;
+            } else {
+              open = false;
             }
           }
-          if (!in0) x.x = 0;  // (planes are zero in the padding anyway; index bytes there are not defined)
-          if (!in1) x.y = 0;
         }
+        todo = rest;  // (chunks are taken in order: what is left is exactly `rest`)
+      }
+      u64x2 v[kSliceBatch][kSlicePlaneRows];
+      unsigned two[kSliceBatch][kMaxIdxRows];
+#pragma unroll
+      for (int j = 0; j < kSliceBatch; ++j) {
+        const int c = id[j] < 0 ? i0 : id[j];  // unused slots repeat the first chunk's loads (cache hits) and store nothing
+#pragma unroll
+        for (int k = 0; k < kSlicePlaneRows; ++k) {
+          const int r = __builtin_amdgcn_readlane(prow_l[k], c);
+          v[j][k] = pl.res ? *(const u64x2*)(pl.res + (size_t)max(r, 0) * pl.stride + ws) : ones;
+          if (r < 0) v[j][k] = ones;  // (wave-uniform select after the load: the loads themselves stay unconditional)
+        }
+        if (pl.n_big > 0) {
+#pragma unroll
+          for (int k = 0; k < kMaxIdxRows; ++k) {
+            const int r = __builtin_amdgcn_readlane(irow_l[k], c);
+            const int rid = r < 0 ? 0 : (r & ((1 << kRowBigShift) - 1));
+            two[j][k] = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + ws);  // index bytes of w, w + 1
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kSliceBatch; ++j) {
+        const int c = id[j] < 0 ? i0 : id[j];
+        u64x2 x = w_base;
+#pragma unroll
+        for (int k = 0; k < kSlicePlaneRows; ++k) x &= v[j][k];
+        if (pl.n_big > 0) {
+#pragma unroll
+          for (int k = 0; k < kMaxIdxRows; ++k) {
+            const int r = __builtin_amdgcn_readlane(irow_l[k], c);
+            if (r >= 0) {
+              const u64* tab = s_pm + ((r >> kRowBigShift) - 1) * kSliceTable + (2 * lane) * 65;
+              x.x &= tab[two[j][k] & 0xffu];
+              x.y &= tab[65 + (two[j][k] >> 8)];
+            }
+          }
+        }
+        const int pin = __builtin_amdgcn_readlane(pin_l, c);
         if (pin >= 0) {
           x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
           x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
         }
+        v[j][0] = x;
       }
-      if (first) {
-        int pc = __popcll(x.x) + __popcll(x.y);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
-        if (lane == 0 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, i)], pc);
-      }
-      if (len == 1) {
-        if (w < row_stride && mem0 >= 0) *(u64x2*)(bitmap + (size_t)mem0 * row_stride + w) = x;
-      } else {
-        const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
-        for (int m = 0; m < len; ++m) {
-          const int p = __builtin_amdgcn_readlane(mine, m);
-          if (p >= 0 && w < row_stride) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
+      for (int j = 0; j < kSliceBatch; ++j) {
+        if (id[j] < 0) continue;
+        const u64x2 x = v[j][0];
+        if (__builtin_amdgcn_readlane(meta_l, id[j]) & (1 << 8)) {
+          const int pc = wave_sum_lane63(store_lane ? __popcll(x.x) + __popcll(x.y) : 0);
+          if (lane == 63 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, id[j])], pc);
         }
+        const int p = __builtin_amdgcn_readlane(mem0_l, id[j]);
+        if (p >= 0 && store_lane) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
       }
     }
   }
