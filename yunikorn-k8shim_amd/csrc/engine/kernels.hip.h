@@ -1203,12 +1203,14 @@ constexpr int kSlicePlaneRows = 2;             // request-value plane rows of a 
 constexpr int kSliceBatch = 8;                 // chunks whose loads are in flight together (one wait, then kSliceBatch stores)
 __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
     ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
-    const int* __restrict__ class_dirty /* null = every class */, int n_slices, int chunks_per_wave) {
+    const int* __restrict__ class_dirty /* null = every class */, int n_slices, int chunks_per_wave, int mode /* experiments: bit 0 = no
+    stores, bit 1 = consecutive workgroups take consecutive chunk batches of ONE slice */) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   extern __shared__ u64 s_pm[];  // [n_big][kSliceWords][65]
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
-  const int slice = blockIdx.x % n_slices, batch = blockIdx.x / n_slices;
+  const int n_batches = gridDim.x / n_slices;
+  const int slice = (mode & 2) ? blockIdx.x / n_batches : blockIdx.x % n_slices, batch = (mode & 2) ? blockIdx.x % n_batches : blockIdx.x / n_slices;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const int w = slice * kSliceWords + 2 * lane;  // this lane's words: w, w + 1 (row_stride is a multiple of 16: never straddled)
   if (pl.n_big > 0) {
@@ -1222,8 +1224,9 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
   const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
   const int c_end = min(c_begin + chunks_per_wave, n_chunks);
   const int slots = pl.res_slots;
-  const bool store_lane = w < row_stride;
-  const int ws = store_lane ? w : 0;  // lanes past the row load from its first words and store nothing
+  const bool in_row = w < row_stride;
+  const bool store_lane = in_row && !(mode & 1);
+  const int ws = in_row ? w : 0;  // lanes past the row load from its first words and store nothing
   const u64x2 keep = {w < row_words ? ~0ull : 0ull, w + 1 < row_words ? ~0ull : 0ull};  // padding words stay zero
   const u64x2 ones = {~0ull, ~0ull};
   // AND of the toleration / affinity / spread words of the current signature triple (wave-uniform keys; -3 = nothing cached)
@@ -1383,7 +1386,7 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
         if (id[j] < 0) continue;
         const u64x2 x = v[j][0];
         if (__builtin_amdgcn_readlane(meta_l, id[j]) & (1 << 8)) {
-          const int pc = wave_sum_lane63(store_lane ? __popcll(x.x) + __popcll(x.y) : 0);
+          const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y))  // (lanes past the row hold zeros: `keep`);
           if (lane == 63 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, id[j])], pc);
         }
         const int p = __builtin_amdgcn_readlane(mem0_l, id[j]);
