@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
         if (id[j] < 0) continue;
         const u64x2 x = v[j][0];
         if (__builtin_amdgcn_readlane(meta_l, id[j]) & (1 << 8)) {
-          const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y))  // (lanes past the row hold zeros: `keep`);
+          const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (lanes past the row hold zeros: `keep`)
           if (lane == 63 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, id[j])], pc);
         }
         const int p = __builtin_amdgcn_readlane(mem0_l, id[j]);
