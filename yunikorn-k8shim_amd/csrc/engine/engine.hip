@@ -184,6 +184,7 @@ struct ykpred_engine {
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
   int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
+  int slice_pairs = 0;              // YKPRED_SLICE_PAIRS=1: one word pair per lane even with a single walked dimension
   int slice_mode = 0;               // YKPRED_SLICE_MODE: experiments of k_combine_slices (bit 0 = no stores: WRONG bitmap, timing only)
   int slice_chunks_per_wave = 64;   // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
   int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
@@ -990,6 +991,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (const char* v = getenv("YKPRED_SIG_WPL")) e->sig_wpl = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_CHUNKS")) e->slice_chunks_per_wave = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_MODE")) e->slice_mode = atoi(v);
+  if (const char* v = getenv("YKPRED_SLICE_PAIRS")) e->slice_pairs = atoi(v);
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
@@ -1797,15 +1799,28 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
     const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0));
     if (slices) {
-      // index rows to decode: a workgroup per 64-word slice of the row, mask tables in LDS (see k_combine_slices)
-      const int n_slices = (e->row_stride + ykk::kSliceWords - 1) / ykk::kSliceWords;
+      // index rows to decode: a workgroup per slice of the row, mask tables in LDS (see k_combine_slices). One walked dimension:
+      // two word pairs per lane (slices of <= 256 words, 133 KB of tables); two: one pair per lane (<= 128 words).
+      const int pairs = (pc.n_big <= 1 && e->slice_pairs != 1) ? 2 : 1;
+      const int max_words = 128 * pairs;
+      const int n_slices = (e->row_stride + max_words - 1) / max_words;
+      const int unit = 2 * pairs;
+      const int slice_words = ((e->row_stride + n_slices - 1) / n_slices + unit - 1) / unit * unit;  // (row_stride is a multiple of 16)
       const int per_wave = std::max(64, e->slice_chunks_per_wave / 64 * 64);
       const int per_block = per_wave * ykk::kSliceWaves;
-      const size_t lds = (size_t)pc.n_big * ykk::kSliceTable * sizeof(u64);
-      if (lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(ykk::k_combine_slices, dim3((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices)), dim3(ykk::kSliceBlock), lds, sz, ct,
-                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, per_wave, e->slice_mode);
+      const size_t lds = (size_t)pc.n_big * (size_t)slice_words * 65 * sizeof(u64);
+      const dim3 sgrid((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices));
+      if (pairs == 2) {
+        if (lds > 64 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ykk::k_combine_slices<2>, sgrid, dim3(ykk::kSliceBlock), lds, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                           e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, slice_words, per_wave, e->slice_mode);
+      } else {
+        if (lds > 64 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ykk::k_combine_slices<1>, sgrid, dim3(ykk::kSliceBlock), lds, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                           e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, slice_words, per_wave, e->slice_mode);
+      }
     } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,

@@ -1185,63 +1185,162 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // classes). Decoding an index byte through the word's 65-entry mask table is a gather with a 520-byte lane stride: in
 // k_combine_wave (lane = word) every lane of a wave load hits its own cache line, ≈ 100 KB of L2 → L1 line traffic per 6 KB row
 // written, and that — not HBM — sets the pace (4.5 ms alone, 6.8 ms beside the decision kernels for a 6.27 GB bitmap).
-// Here a workgroup owns ONE slice of kSliceWords words of the row for a long run of chunks:
-//   * the mask tables of the slice (65 KB per walked dimension) sit in LDS — the decode is a ds_read_b64, and global memory only
-//     sees coalesced streams (index bytes, plane words, 1 KiB row pieces: lane = two adjacent words);
+// Here a workgroup owns ONE slice of `slice_words` words of the row for a long run of chunks:
+//   * the mask tables of the slice (520 bytes per word and walked dimension) sit in LDS — the decode is a ds_read_b64, and
+//     global memory only sees coalesced streams (index bytes, plane words, row pieces of 1 KiB: lane = PAIRS pairs of words);
 //   * the per-chunk table walk (chunk → class → signatures → plane rows) is done by the LANES for 64 chunks at once and
 //     broadcast with v_readlane — no chain of dependent scalar loads per chunk;
 //   * zone-B chunks come in signature order (aff, tol, spread, request vector: build_classes), so the toleration / affinity /
 //     spread words of a lane are kept in registers and reloaded only when the signature changes;
-//   * consecutive workgroups take consecutive slices of the same chunks, so the pieces in flight at one moment tile whole rows.
-// (First form, one word per lane and every row pointer rebuilt per (chunk, slice): 9.3 ms — 250 instructions and a full
-// load → store round trip per 512 bytes. profiles/r03_session7_*.txt)
-constexpr int kSliceWords = 128;
+//   * single-row chunks of one signature triple and one SHAPE (number of plane rows, number of index rows) are served in
+//     batches by straight-line code specialised for the shape: every load of the batch first, one wait, the masks, the stores.
+// History (profiles/r03_session7…10_*.txt): one word per lane and every row pointer rebuilt per (chunk, slice) 9.3 ms; two words
+// per lane with cached signature words 4.6 ms; batches of 8 with unconditional loads and selects 4.2 ms — 2.4 ms of it with
+// the stores switched off: ≈ 170 instructions per KiB written, the kernel was bound by instruction issue, not by memory.
 constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
-constexpr int kSliceTable = kSliceWords * 65;  // u64 entries per walked dimension
-constexpr int kSlicePlaneRows = 2;             // request-value plane rows of a class served by the fast path (row 0 + one dimension)
-constexpr int kSliceBatch = 8;                 // chunks whose loads are in flight together (one wait, then kSliceBatch stores)
+constexpr int kSlicePlaneRows = 2;  // request-value plane rows of a class served by the fast path (row 0 + one dimension)
+__host__ __device__ inline int slice_batch(int pairs) { return pairs == 2 ? 4 : 8; }  // chunks in flight together per wave
+
+struct SliceCtx {
+  const Planes* pl;
+  u64* bitmap;
+  int* class_count;
+  const u64* s_pm;
+  int row_stride, tab_stride, half, lane, pin_enabled;
+};
+// One batch: chunks i0 .. i0 + n - 1 of the wave's 64 (n <= the batch size), all of shape (NP plane rows, NI index rows).
+template <int PAIRS, int NP, int NI>
+__device__ __forceinline__ void slice_batch_body(const SliceCtx& cx, int i0, int n, const int (&wq)[PAIRS], const bool (&st_ok)[PAIRS],
+                                                 const __attribute__((ext_vector_type(2))) u64 (&w_base)[PAIRS], int cls_l, int meta_l, int pin_l,
+                                                 int mem0_l, const int (&prow_l)[kSlicePlaneRows], const int (&irow_l)[kMaxIdxRows]) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  constexpr int K = PAIRS == 2 ? 4 : 8;
+  const Planes& pl = *cx.pl;
+  u64x2 v[K][NP > 0 ? NP : 1][PAIRS];
+  unsigned two[K][NI > 0 ? NI : 1][PAIRS];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (j < n) {
+      const int c = i0 + j;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const u64* row = pl.res + (size_t)__builtin_amdgcn_readlane(prow_l[k], c) * pl.stride;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) v[j][k][q] = *(const u64x2*)(row + wq[q]);
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int rid = __builtin_amdgcn_readlane(irow_l[k], c) & ((1 << kRowBigShift) - 1);
+        const unsigned char* row = pl.res_idx + (size_t)rid * pl.idx_stride;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) two[j][k][q] = *(const unsigned short*)(row + wq[q]);  // index bytes of the pair
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (j < n) {
+      const int c = i0 + j;
+      u64x2 x[PAIRS];
+#pragma unroll
+      for (int q = 0; q < PAIRS; ++q) {
+        x[q] = w_base[q];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) x[q] &= v[j][k][q];
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int big = (__builtin_amdgcn_readlane(irow_l[k], c) >> kRowBigShift) - 1;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+          const u64* tab = cx.s_pm + big * cx.tab_stride + (q * cx.half + 2 * cx.lane) * 65;
+          x[q].x &= tab[two[j][k][q] & 0xffu];
+          x[q].y &= tab[65 + (two[j][k][q] >> 8)];
+        }
+      }
+      if (cx.pin_enabled) {
+        const int pin = __builtin_amdgcn_readlane(pin_l, c);
+        if (pin >= 0) {
+#pragma unroll
+          for (int q = 0; q < PAIRS; ++q) {
+            x[q].x &= (wq[q] == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+            x[q].y &= (wq[q] + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+          }
+        }
+      }
+      if (__builtin_amdgcn_readlane(meta_l, c) & (1 << 8)) {
+        int pc = 0;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) pc += __popcll(x[q].x) + __popcll(x[q].y);  // (idle lanes and padding words hold zeros: `keep`)
+        pc = wave_sum_lane63(pc);
+        if (cx.lane == 63 && pc) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
+      }
+      const int p = __builtin_amdgcn_readlane(mem0_l, c);
+      if (p >= 0) {
+        u64* dst = cx.bitmap + (size_t)p * cx.row_stride;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
+          if (st_ok[q]) *(u64x2*)(dst + wq[q]) = x[q];
+      }
+    }
+  }
+}
+
+// grid.x = chunk batches x n_slices (consecutive workgroups take consecutive slices of the same chunks); dynamic LDS =
+// n_big * slice_words * 520 bytes. slice_words is a multiple of 2 * PAIRS; lane l owns the word pairs
+// slice * slice_words + q * slice_words / PAIRS + 2 l (q < PAIRS) while 2 l < slice_words / PAIRS.
+template <int PAIRS>
 __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
     ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
-    const int* __restrict__ class_dirty /* null = every class */, int n_slices, int chunks_per_wave, int mode /* experiments: bit 0 = no
-    stores, bit 1 = consecutive workgroups take consecutive chunk batches of ONE slice */) {
+    const int* __restrict__ class_dirty /* null = every class */, int n_slices, int slice_words, int chunks_per_wave,
+    int mode /* experiments: bit 0 = no stores (timing only) */) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-  extern __shared__ u64 s_pm[];  // [n_big][kSliceWords][65]
+  extern __shared__ u64 s_pm[];  // [n_big][slice_words][65]
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
-  const int n_batches = gridDim.x / n_slices;
-  const int slice = (mode & 2) ? blockIdx.x / n_batches : blockIdx.x % n_slices, batch = (mode & 2) ? blockIdx.x % n_batches : blockIdx.x / n_slices;
+  const int slice = blockIdx.x % n_slices, batch = blockIdx.x / n_slices;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int w = slice * kSliceWords + 2 * lane;  // this lane's words: w, w + 1 (row_stride is a multiple of 16: never straddled)
+  const int half = slice_words / PAIRS, tab_stride = slice_words * 65;
   if (pl.n_big > 0) {
-    const int cnt = max(min(kSliceWords, pl.n_words - slice * kSliceWords), 0) * 65;
+    const int cnt = max(min(slice_words, pl.n_words - slice * slice_words), 0) * 65;
     for (int b = 0; b < pl.n_big; ++b) {
-      const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)slice * kSliceWords) * 65;
-      for (int i = threadIdx.x; i < kSliceTable; i += kSliceBlock) s_pm[b * kSliceTable + i] = i < cnt ? src[i] : 0ull;
+      const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)slice * slice_words) * 65;
+      for (int i = threadIdx.x; i < tab_stride; i += kSliceBlock) s_pm[b * tab_stride + i] = i < cnt ? src[i] : 0ull;
     }
     __syncthreads();
   }
   const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
   const int c_end = min(c_begin + chunks_per_wave, n_chunks);
   const int slots = pl.res_slots;
-  const bool in_row = w < row_stride;
-  const bool store_lane = in_row && !(mode & 1);
-  const int ws = in_row ? w : 0;  // lanes past the row load from its first words and store nothing
-  const u64x2 keep = {w < row_words ? ~0ull : 0ull, w + 1 < row_words ? ~0ull : 0ull};  // padding words stay zero
-  const u64x2 ones = {~0ull, ~0ull};
+  // this lane's word pairs; a pair past the slice or the row loads from the row's first words, holds zeros and stores nothing
+  int wq[PAIRS], w_true[PAIRS];
+  bool in_row[PAIRS], st_ok[PAIRS];
+  u64x2 keep[PAIRS];  // padding words stay zero
+#pragma unroll
+  for (int q = 0; q < PAIRS; ++q) {
+    const int w = slice * slice_words + q * half + 2 * lane;
+    in_row[q] = 2 * lane < half && w < row_stride;
+    st_ok[q] = in_row[q] && !(mode & 1);
+    w_true[q] = w;
+    wq[q] = in_row[q] ? w : 0;
+    keep[q] = u64x2{in_row[q] && w < row_words ? ~0ull : 0ull, in_row[q] && w + 1 < row_words ? ~0ull : 0ull};
+  }
+  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, half, lane, pin_enabled};
   // AND of the toleration / affinity / spread words of the current signature triple (wave-uniform keys; -3 = nothing cached)
   int cur_st = -3, cur_sa = -3, cur_ss = -3;
-  u64x2 w_base = ones;
+  u64x2 w_base[PAIRS];
   for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
     // lane j walks the tables of chunk c0 + j
     const int chunk_l = c0 + lane;
     bool act = false;
-    int cls_l = 0, meta_l = 0 /* len | first << 8 | slow << 9 */, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1;
+    int cls_l = 0, meta_l = 0 /* len | first << 8 | general path << 9 | plane rows << 10 | index rows << 12 */, pin_l = -1, mem0_l = -1;
+    int st_l = -1, sa_l = -1, ss_l = -1;
     int prow_l[kSlicePlaneRows], irow_l[kMaxIdxRows];
 #pragma unroll
-    for (int k = 0; k < kSlicePlaneRows; ++k) prow_l[k] = -1;
+    for (int k = 0; k < kSlicePlaneRows; ++k) prow_l[k] = 0;
 #pragma unroll
-    for (int k = 0; k < kMaxIdxRows; ++k) irow_l[k] = -1;
+    for (int k = 0; k < kMaxIdxRows; ++k) irow_l[k] = 1 << kRowBigShift;
     if (chunk_l < c_end) {
       cls_l = ct.chunk_class[chunk_l];
       act = class_dirty ? class_dirty[cls_l] != 0 : ct.chunk_zone[chunk_l] == 0;
@@ -1269,13 +1368,19 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
               for (int j = 0; j < kSlicePlaneRows; ++j)
                 if (j == np) prow_l[j] = r;
-              if (np >= kSlicePlaneRows) meta_l |= 1 << 9;  // more rows than the fast path holds
               ++np;
             }
           }
+          if (np > kSlicePlaneRows || ni > kMaxIdxRows) meta_l |= 1 << 9;  // more rows than the fast path holds
+          meta_l |= (min(np, 3) << 10) | (min(ni, 3) << 12);
         }
       }
     }
+    // chunk j continues the batch of chunk j - 1: both live on the fast path with the same signature triple and shape
+    const int key_l = act ? (meta_l >> 9) : -1;  // general-path flag + shape
+    const bool cont_l = lane > 0 && act && !(meta_l & (1 << 9)) && __shfl_up(key_l, 1, kWave) == key_l && __shfl_up(st_l, 1, kWave) == st_l &&
+                        __shfl_up(sa_l, 1, kWave) == sa_l && __shfl_up(ss_l, 1, kWave) == ss_l;
+    const u64 cont = __ballot(cont_l);
     u64 todo = __ballot(act);
     while (todo) {
       const int i0 = __ffsll((long long)todo) - 1;
@@ -1285,113 +1390,71 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
         // general path, one chunk: any number of rows and members (class_rows / class_word as in k_combine_wave)
         todo &= todo - 1;
         const int cls = __builtin_amdgcn_readlane(cls_l, i0), pin = __builtin_amdgcn_readlane(pin_l, i0), len = meta0 & 0xff;
-        u64x2 x = {0, 0};
-        if (pin != -2 && !all_fail && store_lane) {
-          const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
-          if (w < row_words) x.x = class_word(cr, w);
-          if (w + 1 < row_words) x.y = class_word(cr, w + 1);
-          if (pin >= 0) {
-            x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-            x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+        const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
+        const int begin = ct.chunk_begin[c0 + i0];
+        const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
+        int pc = 0;
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q) {
+          const int w = w_true[q];
+          const bool ok = in_row[q];
+          u64x2 x = {0, 0};
+          if (ok && pin != -2 && !all_fail) {
+            if (w < row_words) x.x = class_word(cr, w);
+            if (w + 1 < row_words) x.y = class_word(cr, w + 1);
+            if (pin >= 0) {
+              x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+              x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+            }
+          }
+          pc += __popcll(x.x) + __popcll(x.y);
+          for (int m = 0; m < len; ++m) {
+            const int p = __builtin_amdgcn_readlane(mine, m);
+            if (p >= 0 && st_ok[q]) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
           }
         }
         if (meta0 & (1 << 8)) {
-          const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));
+          pc = wave_sum_lane63(pc);
           if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
-        }
-        const int begin = ct.chunk_begin[c0 + i0];
-        const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
-        for (int m = 0; m < len; ++m) {
-          const int p = __builtin_amdgcn_readlane(mine, m);
-          if (p >= 0 && store_lane) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
         }
         continue;
       }
       if (st != cur_st || sa != cur_sa || ss != cur_ss) {
         cur_st = st, cur_sa = sa, cur_ss = ss;
-        w_base = keep;
-        if (pl.tol && st >= 0) w_base &= *(const u64x2*)(pl.tol + (size_t)st * pl.stride + ws);
-        if (pl.aff && sa >= 0) w_base &= *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + ws);
-        if (pl.spread && ss >= 0) w_base &= *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + ws);
-        if (all_fail) w_base = u64x2{0, 0};
-      }
-      // up to kSliceBatch single-row chunks of this signature triple: every load first, then the masks, then the stores
-      int id[kSliceBatch];
-      {
-        u64 rest = todo;
-        bool open = true;
 #pragma unroll
-        for (int j = 0; j < kSliceBatch; ++j) {
-          id[j] = -1;
-          if (open && rest) {
-            const int c = __ffsll((long long)rest) - 1;
-            const bool same = j == 0 || (__builtin_amdgcn_readlane(st_l, c) == st && __builtin_amdgcn_readlane(sa_l, c) == sa &&
-                                         __builtin_amdgcn_readlane(ss_l, c) == ss && !(__builtin_amdgcn_readlane(meta_l, c) & (1 << 9)));
-            if (same) {
-              id[j] = c;
-              rest &= rest - 1;
-            } else {
-              open = false;
-            }
-          }
-        }
-        todo = rest;  // (chunks are taken in order: what is left is exactly `rest`)
-      }
-      u64x2 v[kSliceBatch][kSlicePlaneRows];
-      unsigned two[kSliceBatch][kMaxIdxRows];
-#pragma unroll
-      for (int j = 0; j < kSliceBatch; ++j) {
-        const int c = id[j] < 0 ? i0 : id[j];  // unused slots repeat the first chunk's loads (cache hits) and store nothing
-#pragma unroll
-        for (int k = 0; k < kSlicePlaneRows; ++k) {
-          const int r = __builtin_amdgcn_readlane(prow_l[k], c);
-          v[j][k] = pl.res ? *(const u64x2*)(pl.res + (size_t)max(r, 0) * pl.stride + ws) : ones;
-          if (r < 0) v[j][k] = ones;  // (wave-uniform select after the load: the loads themselves stay unconditional)
-        }
-        if (pl.n_big > 0) {
-#pragma unroll
-          for (int k = 0; k < kMaxIdxRows; ++k) {
-            const int r = __builtin_amdgcn_readlane(irow_l[k], c);
-            const int rid = r < 0 ? 0 : (r & ((1 << kRowBigShift) - 1));
-            two[j][k] = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + ws);  // index bytes of w, w + 1
-          }
+        for (int q = 0; q < PAIRS; ++q) {
+          u64x2 b = keep[q];
+          if (pl.tol && st >= 0) b &= *(const u64x2*)(pl.tol + (size_t)st * pl.stride + wq[q]);
+          if (pl.aff && sa >= 0) b &= *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + wq[q]);
+          if (pl.spread && ss >= 0) b &= *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + wq[q]);
+          if (all_fail) b = u64x2{0, 0};
+          w_base[q] = b;
         }
       }
-#pragma unroll
-      for (int j = 0; j < kSliceBatch; ++j) {
-        const int c = id[j] < 0 ? i0 : id[j];
-        u64x2 x = w_base;
-#pragma unroll
-        for (int k = 0; k < kSlicePlaneRows; ++k) x &= v[j][k];
-        if (pl.n_big > 0) {
-#pragma unroll
-          for (int k = 0; k < kMaxIdxRows; ++k) {
-            const int r = __builtin_amdgcn_readlane(irow_l[k], c);
-            if (r >= 0) {
-              const u64* tab = s_pm + ((r >> kRowBigShift) - 1) * kSliceTable + (2 * lane) * 65;
-              x.x &= tab[two[j][k] & 0xffu];
-              x.y &= tab[65 + (two[j][k] >> 8)];
-            }
-          }
+      // the batch: i0 and the chunks after it that continue it
+      const u64 stops = i0 < 63 ? ~(cont >> (i0 + 1)) : ~0ull;
+      const int n = min(slice_batch(PAIRS), 1 + (int)__ffsll((long long)stops) - 1);
+      todo &= ~(((1ull << n) - 1ull) << i0);
+      const int shape = (meta0 >> 10) & 15;
+#define YK_SLICE_CASE(NPv, NIv)                                                                                              \
+  case ((NIv) << 2) | (NPv):                                                                                                 \
+    slice_batch_body<PAIRS, NPv, NIv>(cx, i0, n, wq, st_ok, w_base, cls_l, meta_l, pin_l, mem0_l, prow_l, irow_l);                    \
+    break;
+      if constexpr (PAIRS == 2) {  // (launched with at most one walked dimension: no class has two index rows)
+        switch (shape) {
+          YK_SLICE_CASE(0, 0) YK_SLICE_CASE(1, 0) YK_SLICE_CASE(2, 0)
+          YK_SLICE_CASE(0, 1) YK_SLICE_CASE(1, 1) YK_SLICE_CASE(2, 1)
+          default: break;
         }
-        const int pin = __builtin_amdgcn_readlane(pin_l, c);
-        if (pin >= 0) {
-          x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-          x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+      } else {
+        switch (shape) {
+          YK_SLICE_CASE(0, 0) YK_SLICE_CASE(1, 0) YK_SLICE_CASE(2, 0)
+          YK_SLICE_CASE(0, 1) YK_SLICE_CASE(1, 1) YK_SLICE_CASE(2, 1)
+          YK_SLICE_CASE(0, 2) YK_SLICE_CASE(1, 2) YK_SLICE_CASE(2, 2)
+          default: break;
         }
-        v[j][0] = x;
       }
-#pragma unroll
-      for (int j = 0; j < kSliceBatch; ++j) {
-        if (id[j] < 0) continue;
-        const u64x2 x = v[j][0];
-        if (__builtin_amdgcn_readlane(meta_l, id[j]) & (1 << 8)) {
-          const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (lanes past the row hold zeros: `keep`)
-          if (lane == 63 && pc) atomicAdd(&class_count[__builtin_amdgcn_readlane(cls_l, id[j])], pc);
-        }
-        const int p = __builtin_amdgcn_readlane(mem0_l, id[j]);
-        if (p >= 0 && store_lane) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
-      }
+#undef YK_SLICE_CASE
     }
   }
 }
