@@ -1207,7 +1207,7 @@ struct SliceCtx {
   u64* bitmap;
   int* class_count;
   const u64* s_pm;
-  int row_stride, tab_stride, half, lane, pin_enabled;
+  int row_stride, tab_stride, half, lane, pin_enabled, mode;
 };
 // One batch: chunks i0 .. i0 + n - 1 of the wave's 64 (n <= the batch size), all of shape (NP plane rows, NI index rows).
 template <int PAIRS, int NP, int NI>
@@ -1255,6 +1255,10 @@ __device__ __forceinline__ void slice_batch_body(const SliceCtx& cx, int i0, int
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) {
           const u64* tab = cx.s_pm + big * cx.tab_stride + (q * cx.half + 2 * cx.lane) * 65;
+          if (cx.mode & 8) {  // (experiment: no LDS decode)
+            x[q].x &= two[j][k][q];
+            continue;
+          }
           x[q].x &= tab[two[j][k][q] & 0xffu];
           x[q].y &= tab[65 + (two[j][k][q] >> 8)];
         }
@@ -1274,7 +1278,7 @@ __device__ __forceinline__ void slice_batch_body(const SliceCtx& cx, int i0, int
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) pc += __popcll(x[q].x) + __popcll(x[q].y);  // (idle lanes and padding words hold zeros: `keep`)
         pc = wave_sum_lane63(pc);
-        if (cx.lane == 63 && pc) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
+        if (cx.lane == 63 && pc && !(cx.mode & 4)) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
       }
       const int p = __builtin_amdgcn_readlane(mem0_l, c);
       if (p >= 0) {
@@ -1294,7 +1298,7 @@ template <int PAIRS>
 __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
     ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
     const int* __restrict__ class_dirty /* null = every class */, int n_slices, int slice_words, int chunks_per_wave,
-    int mode /* experiments: bit 0 = no stores (timing only) */) {
+    int mode /* experiments, timing only: 1 = no stores, 4 = no count atomics, 8 = no LDS decode, 16 = signature words never reloaded */) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   extern __shared__ u64 s_pm[];  // [n_big][slice_words][65]
   const bool all_fail = pin_enabled & 2;
@@ -1326,7 +1330,7 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
     wq[q] = in_row[q] ? w : 0;
     keep[q] = u64x2{in_row[q] && w < row_words ? ~0ull : 0ull, in_row[q] && w + 1 < row_words ? ~0ull : 0ull};
   }
-  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, half, lane, pin_enabled};
+  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, half, lane, pin_enabled, mode};
   // AND of the toleration / affinity / spread words of the current signature triple (wave-uniform keys; -3 = nothing cached)
   int cur_st = -3, cur_sa = -3, cur_ss = -3;
   u64x2 w_base[PAIRS];
@@ -1419,7 +1423,7 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
         }
         continue;
       }
-      if (st != cur_st || sa != cur_sa || ss != cur_ss) {
+      if ((st != cur_st || sa != cur_sa || ss != cur_ss) && !((mode & 16) && cur_st != -3)) {
         cur_st = st, cur_sa = sa, cur_ss = ss;
 #pragma unroll
         for (int q = 0; q < PAIRS; ++q) {
