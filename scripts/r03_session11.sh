@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 rm -f gpurun_out/r03_probe2.jsonl
 rm -rf gpurun_out/pmc_slices
 python -c "import importlib; importlib.import_module('yunikorn-k8shim_amd').build_all()" || exit 1
+if [ -z "$PMC_ONLY" ]; then
 export PROBE_SETS='[
  {"knobs":{"YKPRED_SLICE_PAIRS":"1"},"workloads":"unique","both":true},
  {"knobs":{"YKPRED_SLICE_PAIRS":"1","YKPRED_SLICE_MODE":"5"},"workloads":"unique","both":true},
@@ -18,6 +19,8 @@ import sys, json
 for l in sys.stdin:
     d = json.loads(l)
     print(d['knobs'], d['workload'], d['ms_per_step'], d.get('ms_per_step_nodec'), 'k_combine', d['kernel_ms'].get('k_combine'), 'alone', d.get('kernel_ms_nodec', {}).get('k_combine'))"
+fi
+mkdir -p "$ROOT/gpurun_out/pmc_slices"
 cd /tmp && export TMPDIR=/tmp
 export PROBE_SETS='[{"knobs":{"YKPRED_SLICE_PAIRS":"1"},"workloads":"unique"}]'
 export PROBE_OUT=r03_probe2_pmc.jsonl
