@@ -1799,28 +1799,17 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
     const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0));
     if (slices) {
-      // index rows to decode: a workgroup per slice of the row, mask tables in LDS (see k_combine_slices). One walked dimension:
-      // two word pairs per lane (slices of <= 256 words, 133 KB of tables); two: one pair per lane (<= 128 words).
-      const int pairs = (pc.n_big <= 1 && e->slice_pairs != 1) ? 2 : 1;
-      const int max_words = 128 * pairs;
-      const int n_slices = (e->row_stride + max_words - 1) / max_words;
-      const int unit = 2 * pairs;
-      const int slice_words = ((e->row_stride + n_slices - 1) / n_slices + unit - 1) / unit * unit;  // (row_stride is a multiple of 16)
+      // index rows to decode: a workgroup per slice (<= 128 words) of the row, mask tables in LDS (see k_combine_slices)
+      const int n_slices = (e->row_stride + ykk::kSliceMaxWords - 1) / ykk::kSliceMaxWords;
+      const int slice_words = ((e->row_stride + n_slices - 1) / n_slices + 1) / 2 * 2;  // (row_stride is a multiple of 16)
       const int per_wave = std::max(64, e->slice_chunks_per_wave / 64 * 64);
       const int per_block = per_wave * ykk::kSliceWaves;
       const size_t lds = (size_t)pc.n_big * (size_t)slice_words * 65 * sizeof(u64);
-      const dim3 sgrid((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices));
-      if (pairs == 2) {
-        if (lds > 64 * 1024)
-          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ykk::k_combine_slices<2>, sgrid, dim3(ykk::kSliceBlock), lds, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                           e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, slice_words, per_wave, e->slice_mode);
-      } else {
-        if (lds > 64 * 1024)
-          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ykk::k_combine_slices<1>, sgrid, dim3(ykk::kSliceBlock), lds, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                           e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, slice_words, per_wave, e->slice_mode);
-      }
+      if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ykk::k_combine_slices, dim3((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices)), dim3(ykk::kSliceBlock), lds, sz, ct,
+                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, slice_words, per_wave,
+                         e->slice_mode);
     } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,

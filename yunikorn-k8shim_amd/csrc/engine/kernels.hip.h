@@ -1185,127 +1185,112 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // classes). Decoding an index byte through the word's 65-entry mask table is a gather with a 520-byte lane stride: in
 // k_combine_wave (lane = word) every lane of a wave load hits its own cache line, ≈ 100 KB of L2 → L1 line traffic per 6 KB row
 // written, and that — not HBM — sets the pace (4.5 ms alone, 6.8 ms beside the decision kernels for a 6.27 GB bitmap).
-// Here a workgroup owns ONE slice of `slice_words` words of the row for a long run of chunks:
+// Here a workgroup owns ONE slice of `slice_words` (<= 128) words of the row for a long run of chunks:
 //   * the mask tables of the slice (520 bytes per word and walked dimension) sit in LDS — the decode is a ds_read_b64, and
-//     global memory only sees coalesced streams (index bytes, plane words, row pieces of 1 KiB: lane = PAIRS pairs of words);
+//     global memory only sees coalesced streams (index bytes, plane words, row pieces of <= 1 KiB: lane = a pair of words);
 //   * the per-chunk table walk (chunk → class → signatures → plane rows) is done by the LANES for 64 chunks at once and
 //     broadcast with v_readlane — no chain of dependent scalar loads per chunk;
 //   * zone-B chunks come in signature order (aff, tol, spread, request vector: build_classes), so the toleration / affinity /
 //     spread words of a lane are kept in registers and reloaded only when the signature changes;
 //   * single-row chunks of one signature triple and one SHAPE (number of plane rows, number of index rows) are served in
-//     batches by straight-line code specialised for the shape: every load of the batch first, one wait, the masks, the stores.
-// History (profiles/r03_session7…10_*.txt): one word per lane and every row pointer rebuilt per (chunk, slice) 9.3 ms; two words
-// per lane with cached signature words 4.6 ms; batches of 8 with unconditional loads and selects 4.2 ms — 2.4 ms of it with
-// the stores switched off: ≈ 170 instructions per KiB written, the kernel was bound by instruction issue, not by memory.
+//     batches of kSliceBatch by straight-line code specialised for the shape, software-pipelined over two register buffers: the
+//     loads of batch b + 1 (and the signature words, if they change) are issued BEFORE batch b is decoded and stored, so a
+//     wave never sits in front of an empty memory queue and never waits for its own stores.
+// History (profiles/r03_session7…12_*.txt): one word per lane and every row pointer rebuilt per (chunk, slice) 9.3 ms; two words
+// per lane with cached signature words 4.6 ms; batches of 8 (loads, one wait, stores) 3.4 ms alone — SQ counters: 76 % of the
+// wave cycles parked in s_waitcnt, 72 VALU + 69 SALU instructions per KiB: three serialised memory round trips per batch.
 constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
-constexpr int kSlicePlaneRows = 2;  // request-value plane rows of a class served by the fast path (row 0 + one dimension)
-__host__ __device__ inline int slice_batch(int pairs) { return pairs == 2 ? 4 : 8; }  // chunks in flight together per wave
+constexpr int kSliceBatch = 4;      // chunks per batch (two batches are in flight per wave)
+constexpr int kSliceMaxWords = 128;
 
+typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+// A class's rows on the fast path: toleration, affinity, spread and the FIRST request-value plane row (row 0 of the family, the
+// pod-independent part — the same row for every class) are "cached" rows, folded into the lane's base words while they do not
+// change from chunk to chunk; what remains per chunk is at most one more plane row (NP = 0 / 1) and one or two index rows.
+struct SliceBuf {
+  u64x2_t v[kSliceBatch];
+  unsigned two[kSliceBatch][kMaxIdxRows];
+};
 struct SliceCtx {
   const Planes* pl;
   u64* bitmap;
   int* class_count;
   const u64* s_pm;
-  int row_stride, tab_stride, half, lane, pin_enabled, mode;
+  int row_stride, tab_stride, lane, pin_enabled, mode;
+  int wq;        // this lane's word pair (0 when the pair lies outside the row: loads stay valid, nothing is stored)
+  bool st_ok;    // the pair is stored
 };
-// One batch: chunks i0 .. i0 + n - 1 of the wave's 64 (n <= the batch size), all of shape (NP plane rows, NI index rows).
-template <int PAIRS, int NP, int NI>
-__device__ __forceinline__ void slice_batch_body(const SliceCtx& cx, int i0, int n, const int (&wq)[PAIRS], const bool (&st_ok)[PAIRS],
-                                                 const __attribute__((ext_vector_type(2))) u64 (&w_base)[PAIRS], int cls_l, int meta_l, int pin_l,
-                                                 int mem0_l, const int (&prow_l)[kSlicePlaneRows], const int (&irow_l)[kMaxIdxRows]) {
-  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-  constexpr int K = PAIRS == 2 ? 4 : 8;
+// loads of one batch: chunks i0 .. i0 + n - 1 of the wave's window, all of shape (NP per-chunk plane rows, NI index rows)
+template <int NP, int NI>
+__device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, int prow_l, const int (&irow_l)[kMaxIdxRows], SliceBuf& buf) {
   const Planes& pl = *cx.pl;
-  u64x2 v[K][NP > 0 ? NP : 1][PAIRS];
-  unsigned two[K][NI > 0 ? NI : 1][PAIRS];
 #pragma unroll
-  for (int j = 0; j < K; ++j) {
+  for (int j = 0; j < kSliceBatch; ++j) {
     if (j < n) {
       const int c = i0 + j;
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        const u64* row = pl.res + (size_t)__builtin_amdgcn_readlane(prow_l[k], c) * pl.stride;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) v[j][k][q] = *(const u64x2*)(row + wq[q]);
-      }
+      if (NP) buf.v[j] = *(const u64x2_t*)(pl.res + (size_t)__builtin_amdgcn_readlane(prow_l, c) * pl.stride + cx.wq);
 #pragma unroll
       for (int k = 0; k < NI; ++k) {
         const int rid = __builtin_amdgcn_readlane(irow_l[k], c) & ((1 << kRowBigShift) - 1);
-        const unsigned char* row = pl.res_idx + (size_t)rid * pl.idx_stride;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) two[j][k][q] = *(const unsigned short*)(row + wq[q]);  // index bytes of the pair
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < K; ++j) {
-    if (j < n) {
-      const int c = i0 + j;
-      u64x2 x[PAIRS];
-#pragma unroll
-      for (int q = 0; q < PAIRS; ++q) {
-        x[q] = w_base[q];
-#pragma unroll
-        for (int k = 0; k < NP; ++k) x[q] &= v[j][k][q];
-      }
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int big = (__builtin_amdgcn_readlane(irow_l[k], c) >> kRowBigShift) - 1;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-          const u64* tab = cx.s_pm + big * cx.tab_stride + (q * cx.half + 2 * cx.lane) * 65;
-          if (cx.mode & 8) {  // (experiment: no LDS decode)
-            x[q].x &= two[j][k][q];
-            continue;
-          }
-          x[q].x &= tab[two[j][k][q] & 0xffu];
-          x[q].y &= tab[65 + (two[j][k][q] >> 8)];
-        }
-      }
-      if (cx.pin_enabled) {
-        const int pin = __builtin_amdgcn_readlane(pin_l, c);
-        if (pin >= 0) {
-#pragma unroll
-          for (int q = 0; q < PAIRS; ++q) {
-            x[q].x &= (wq[q] == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-            x[q].y &= (wq[q] + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-          }
-        }
-      }
-      if (__builtin_amdgcn_readlane(meta_l, c) & (1 << 8)) {
-        int pc = 0;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) pc += __popcll(x[q].x) + __popcll(x[q].y);  // (idle lanes and padding words hold zeros: `keep`)
-        pc = wave_sum_lane63(pc);
-        if (cx.lane == 63 && pc && !(cx.mode & 4)) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
-      }
-      const int p = __builtin_amdgcn_readlane(mem0_l, c);
-      if (p >= 0) {
-        u64* dst = cx.bitmap + (size_t)p * cx.row_stride;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q)
-          if (st_ok[q]) *(u64x2*)(dst + wq[q]) = x[q];
+        buf.two[j][k] = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + cx.wq);  // index bytes of the pair
       }
     }
   }
 }
+// masks, feasible counts and stores of a batch whose loads were issued by slice_issue<NP, NI>
+template <int NP, int NI>
+__device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, u64x2_t w_base, int cls_l, int meta_l, int pin_l, int mem0_l,
+                                             const int (&irow_l)[kMaxIdxRows], const SliceBuf& buf) {
+#pragma unroll
+  for (int j = 0; j < kSliceBatch; ++j) {
+    if (j < n) {
+      const int c = i0 + j;
+      u64x2_t x = w_base;
+      if (NP) x &= buf.v[j];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int big = (__builtin_amdgcn_readlane(irow_l[k], c) >> kRowBigShift) - 1;
+        const u64* tab = cx.s_pm + big * cx.tab_stride + (2 * cx.lane) * 65;
+        if (cx.mode & 8) {  // (experiment: no LDS decode)
+          x.x &= buf.two[j][k];
+          continue;
+        }
+        x.x &= tab[buf.two[j][k] & 0xffu];
+        x.y &= tab[65 + (buf.two[j][k] >> 8)];
+      }
+      if (cx.pin_enabled) {
+        const int pin = __builtin_amdgcn_readlane(pin_l, c);
+        if (pin >= 0) {
+          x.x &= (cx.wq == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+          x.y &= (cx.wq + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+        }
+      }
+      if (__builtin_amdgcn_readlane(meta_l, c) & (1 << 8)) {
+        const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (idle lanes and padding words hold zeros: `keep`)
+        if (cx.lane == 63 && pc && !(cx.mode & 4)) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
+      }
+      const int p = __builtin_amdgcn_readlane(mem0_l, c);
+      if (p >= 0 && cx.st_ok) *(u64x2_t*)(cx.bitmap + (size_t)p * cx.row_stride + cx.wq) = x;
+    }
+  }
+}
+// shapes of the fast path (per-chunk plane rows, index rows); every other class takes the general path
+#define YK_SLICE_SHAPES(M) M(0, 1) M(1, 1) M(0, 2) M(1, 2)
 
 // grid.x = chunk batches x n_slices (consecutive workgroups take consecutive slices of the same chunks); dynamic LDS =
-// n_big * slice_words * 520 bytes. slice_words is a multiple of 2 * PAIRS; lane l owns the word pairs
-// slice * slice_words + q * slice_words / PAIRS + 2 l (q < PAIRS) while 2 l < slice_words / PAIRS.
-template <int PAIRS>
+// n_big * slice_words * 520 bytes. slice_words is even; lane l owns the word pair slice * slice_words + 2 l while 2 l < slice_words.
 __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
     ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
     const int* __restrict__ class_dirty /* null = every class */, int n_slices, int slice_words, int chunks_per_wave,
-    int mode /* experiments, timing only: 1 = no stores, 4 = no count atomics, 8 = no LDS decode, 16 = signature words never reloaded */) {
-  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    int mode /* experiments, timing only: 1 = no stores, 4 = no count atomics, 8 = no LDS decode, 16 = cached rows never reloaded */) {
+  typedef u64x2_t u64x2;
   extern __shared__ u64 s_pm[];  // [n_big][slice_words][65]
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int slice = blockIdx.x % n_slices, batch = blockIdx.x / n_slices;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int half = slice_words / PAIRS, tab_stride = slice_words * 65;
+  const int tab_stride = slice_words * 65;
   if (pl.n_big > 0) {
     const int cnt = max(min(slice_words, pl.n_words - slice * slice_words), 0) * 65;
     for (int b = 0; b < pl.n_big; ++b) {
@@ -1317,32 +1302,25 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
   const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
   const int c_end = min(c_begin + chunks_per_wave, n_chunks);
   const int slots = pl.res_slots;
-  // this lane's word pairs; a pair past the slice or the row loads from the row's first words, holds zeros and stores nothing
-  int wq[PAIRS], w_true[PAIRS];
-  bool in_row[PAIRS], st_ok[PAIRS];
-  u64x2 keep[PAIRS];  // padding words stay zero
-#pragma unroll
-  for (int q = 0; q < PAIRS; ++q) {
-    const int w = slice * slice_words + q * half + 2 * lane;
-    in_row[q] = 2 * lane < half && w < row_stride;
-    st_ok[q] = in_row[q] && !(mode & 1);
-    w_true[q] = w;
-    wq[q] = in_row[q] ? w : 0;
-    keep[q] = u64x2{in_row[q] && w < row_words ? ~0ull : 0ull, in_row[q] && w + 1 < row_words ? ~0ull : 0ull};
-  }
-  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, half, lane, pin_enabled, mode};
-  // AND of the toleration / affinity / spread words of the current signature triple (wave-uniform keys; -3 = nothing cached)
-  int cur_st = -3, cur_sa = -3, cur_ss = -3;
-  u64x2 w_base[PAIRS];
+  // this lane's word pair; a pair past the slice or the row loads from the row's first words, holds zeros and stores nothing
+  const int w_true = slice * slice_words + 2 * lane;
+  const bool in_row = 2 * lane < slice_words && w_true < row_stride;
+  const u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};  // padding stays zero
+  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, lane, pin_enabled, mode, in_row ? w_true : 0, in_row && !(mode & 1)};
+  // AND of the cached rows' words of the current key (wave-uniform; -3 = nothing cached) ...
+  int cur_st = -3, cur_sa = -3, cur_ss = -3, cur_p0 = -3;
+  u64x2 w_base = keep;
+  // ... and the words of the NEXT key, loaded but not yet folded: the batch in flight before them still needs the old ones
+  u64x2 t_tol = keep, t_aff = keep, t_spread = keep, t_p0 = keep;
+  bool pending = false;
+  SliceBuf buf_a, buf_b;
   for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
     // lane j walks the tables of chunk c0 + j
     const int chunk_l = c0 + lane;
     bool act = false;
-    int cls_l = 0, meta_l = 0 /* len | first << 8 | general path << 9 | plane rows << 10 | index rows << 12 */, pin_l = -1, mem0_l = -1;
-    int st_l = -1, sa_l = -1, ss_l = -1;
-    int prow_l[kSlicePlaneRows], irow_l[kMaxIdxRows];
-#pragma unroll
-    for (int k = 0; k < kSlicePlaneRows; ++k) prow_l[k] = 0;
+    int cls_l = 0, meta_l = 0 /* len | first << 8 | general path << 9 | per-chunk plane rows << 10 | index rows << 12 */, pin_l = -1, mem0_l = -1;
+    int st_l = -1, sa_l = -1, ss_l = -1, p0_l = -1 /* the cached plane row */, prow_l = 0 /* the per-chunk plane row */;
+    int irow_l[kMaxIdxRows];
 #pragma unroll
     for (int k = 0; k < kMaxIdxRows; ++k) irow_l[k] = 1 << kRowBigShift;
     if (chunk_l < c_end) {
@@ -1355,10 +1333,9 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
         st_l = sg.y, sa_l = sg.z, ss_l = sg.w;
         pin_l = pin_enabled ? ct.pin[cls_l] : -1;
         mem0_l = ct.members[ct.chunk_begin[chunk_l]];
-        if (len != 1 || pin_l == -2) meta_l |= 1 << 9;  // several member rows / an unknown pinned node: the general path
+        int np = 0, ni = 0;
         if (pl.res && sg.x >= 0) {
-          // the class's request-value rows, compacted: plane rows first come first served, index rows (walked dimensions) apart
-          int np = 0, ni = 0;
+          // the class's request-value rows: first plane row = cached, second = per chunk; index rows (walked dimensions) apart
 #pragma unroll
           for (int k = 0; k <= kMaxR; ++k) {
             const int r = k < slots ? pl.res_rows[(size_t)sg.x * slots + k] : -1;
@@ -1369,99 +1346,121 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
                 if (j == ni) irow_l[j] = r;
               ++ni;
             } else {
-#pragma unroll
-              for (int j = 0; j < kSlicePlaneRows; ++j)
-                if (j == np) prow_l[j] = r;
+              if (np == 0) p0_l = r;
+              if (np == 1) prow_l = r;
               ++np;
             }
           }
-          if (np > kSlicePlaneRows || ni > kMaxIdxRows) meta_l |= 1 << 9;  // more rows than the fast path holds
-          meta_l |= (min(np, 3) << 10) | (min(ni, 3) << 12);
         }
+        // the general path: several member rows, an unknown pinned node, or a shape the fast path has no code for
+        if (len != 1 || pin_l == -2 || np > 2 || ni < 1 || ni > kMaxIdxRows) meta_l |= 1 << 9;
+        meta_l |= ((np >= 2 ? 1 : 0) << 10) | (min(ni, 3) << 12);
       }
     }
-    // chunk j continues the batch of chunk j - 1: both live on the fast path with the same signature triple and shape
+    // chunk j continues the batch of chunk j - 1: both live on the fast path with the same cached rows and shape
     const int key_l = act ? (meta_l >> 9) : -1;  // general-path flag + shape
     const bool cont_l = lane > 0 && act && !(meta_l & (1 << 9)) && __shfl_up(key_l, 1, kWave) == key_l && __shfl_up(st_l, 1, kWave) == st_l &&
-                        __shfl_up(sa_l, 1, kWave) == sa_l && __shfl_up(ss_l, 1, kWave) == ss_l;
+                        __shfl_up(sa_l, 1, kWave) == sa_l && __shfl_up(ss_l, 1, kWave) == ss_l && __shfl_up(p0_l, 1, kWave) == p0_l;
     const u64 cont = __ballot(cont_l);
     u64 todo = __ballot(act);
-    while (todo) {
-      const int i0 = __ffsll((long long)todo) - 1;
-      const int st = __builtin_amdgcn_readlane(st_l, i0), sa = __builtin_amdgcn_readlane(sa_l, i0), ss = __builtin_amdgcn_readlane(ss_l, i0);
-      const int meta0 = __builtin_amdgcn_readlane(meta_l, i0);
-      if (meta0 & (1 << 9)) {
-        // general path, one chunk: any number of rows and members (class_rows / class_word as in k_combine_wave)
-        todo &= todo - 1;
-        const int cls = __builtin_amdgcn_readlane(cls_l, i0), pin = __builtin_amdgcn_readlane(pin_l, i0), len = meta0 & 0xff;
-        const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
-        const int begin = ct.chunk_begin[c0 + i0];
-        const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
-        int pc = 0;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-          const int w = w_true[q];
-          const bool ok = in_row[q];
-          u64x2 x = {0, 0};
-          if (ok && pin != -2 && !all_fail) {
-            if (w < row_words) x.x = class_word(cr, w);
-            if (w + 1 < row_words) x.y = class_word(cr, w + 1);
-            if (pin >= 0) {
-              x.x &= (w == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-              x.y &= (w + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-            }
-          }
-          pc += __popcll(x.x) + __popcll(x.y);
-          for (int m = 0; m < len; ++m) {
-            const int p = __builtin_amdgcn_readlane(mine, m);
-            if (p >= 0 && st_ok[q]) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
-          }
-        }
-        if (meta0 & (1 << 8)) {
-          pc = wave_sum_lane63(pc);
-          if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
-        }
-        continue;
-      }
-      if ((st != cur_st || sa != cur_sa || ss != cur_ss) && !((mode & 16) && cur_st != -3)) {
-        cur_st = st, cur_sa = sa, cur_ss = ss;
-#pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-          u64x2 b = keep[q];
-          if (pl.tol && st >= 0) b &= *(const u64x2*)(pl.tol + (size_t)st * pl.stride + wq[q]);
-          if (pl.aff && sa >= 0) b &= *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + wq[q]);
-          if (pl.spread && ss >= 0) b &= *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + wq[q]);
-          if (all_fail) b = u64x2{0, 0};
-          w_base[q] = b;
-        }
-      }
-      // the batch: i0 and the chunks after it that continue it
-      const u64 stops = i0 < 63 ? ~(cont >> (i0 + 1)) : ~0ull;
-      const int n = min(slice_batch(PAIRS), 1 + (int)__ffsll((long long)stops) - 1);
-      todo &= ~(((1ull << n) - 1ull) << i0);
-      const int shape = (meta0 >> 10) & 15;
-#define YK_SLICE_CASE(NPv, NIv)                                                                                              \
-  case ((NIv) << 2) | (NPv):                                                                                                 \
-    slice_batch_body<PAIRS, NPv, NIv>(cx, i0, n, wq, st_ok, w_base, cls_l, meta_l, pin_l, mem0_l, prow_l, irow_l);                    \
+    // the batch whose loads are in flight (wave-uniform): first chunk, length, shape; p_n == 0: none
+    int p_i0 = 0, p_n = 0, p_shape = 0;
+    auto finish_prev = [&](const SliceBuf& buf) {
+      if (p_n == 0) return;
+#define YK_SLICE_FINISH(NPv, NIv)                                                                            \
+  case ((NIv) << 2) | (NPv):                                                                                 \
+    slice_finish<NPv, NIv>(cx, p_i0, p_n, w_base, cls_l, meta_l, pin_l, mem0_l, irow_l, buf);                \
     break;
-      if constexpr (PAIRS == 2) {  // (launched with at most one walked dimension: no class has two index rows)
-        switch (shape) {
-          YK_SLICE_CASE(0, 0) YK_SLICE_CASE(1, 0) YK_SLICE_CASE(2, 0)
-          YK_SLICE_CASE(0, 1) YK_SLICE_CASE(1, 1) YK_SLICE_CASE(2, 1)
-          default: break;
-        }
-      } else {
-        switch (shape) {
-          YK_SLICE_CASE(0, 0) YK_SLICE_CASE(1, 0) YK_SLICE_CASE(2, 0)
-          YK_SLICE_CASE(0, 1) YK_SLICE_CASE(1, 1) YK_SLICE_CASE(2, 1)
-          YK_SLICE_CASE(0, 2) YK_SLICE_CASE(1, 2) YK_SLICE_CASE(2, 2)
-          default: break;
+      switch (p_shape) {
+        YK_SLICE_SHAPES(YK_SLICE_FINISH)
+        default: break;
+      }
+#undef YK_SLICE_FINISH
+      p_n = 0;
+    };
+    auto fold = [&]() {
+      if (!pending) return;
+      w_base = all_fail ? u64x2{0, 0} : (keep & t_tol & t_aff & t_spread & t_p0);
+      pending = false;
+    };
+    // one pipeline step: issue the next batch into `into`, then finish the batch in flight from `from`; false = window done
+    auto step = [&](SliceBuf& into, const SliceBuf& from) -> bool {
+      int n_i0 = 0, n_n = 0, n_shape = 0;
+      const bool more = todo != 0;
+      if (todo) {
+        const int i0 = __ffsll((long long)todo) - 1;
+        const int st = __builtin_amdgcn_readlane(st_l, i0), sa = __builtin_amdgcn_readlane(sa_l, i0), ss = __builtin_amdgcn_readlane(ss_l, i0);
+        const int meta0 = __builtin_amdgcn_readlane(meta_l, i0);
+        if (meta0 & (1 << 9)) {
+          // general path, one chunk: any number of rows and members (class_rows / class_word as in k_combine_wave). It runs on
+          // an EMPTY pipeline: with a batch in flight this step only finishes that batch, the next one takes the chunk.
+          if (p_n == 0) {
+            fold();
+            todo &= todo - 1;
+            const int cls = __builtin_amdgcn_readlane(cls_l, i0), pin = __builtin_amdgcn_readlane(pin_l, i0), len = meta0 & 0xff;
+            const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
+            const int begin = ct.chunk_begin[c0 + i0];
+            const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
+            u64x2 x = {0, 0};
+            if (in_row && pin != -2 && !all_fail) {
+              if (w_true < row_words) x.x = class_word(cr, w_true);
+              if (w_true + 1 < row_words) x.y = class_word(cr, w_true + 1);
+              if (pin >= 0) {
+                x.x &= (w_true == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+                x.y &= (w_true + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+              }
+            }
+            if (meta0 & (1 << 8)) {
+              const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));
+              if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+            }
+            for (int m = 0; m < len; ++m) {
+              const int p = __builtin_amdgcn_readlane(mine, m);
+              if (p >= 0 && cx.st_ok) *(u64x2*)(bitmap + (size_t)p * row_stride + w_true) = x;
+            }
+            return true;
+          }
+        } else {
+          const int p0 = __builtin_amdgcn_readlane(p0_l, i0);
+          if ((st != cur_st || sa != cur_sa || ss != cur_ss || p0 != cur_p0) && !((mode & 16) && cur_st != -3)) {
+            // (a second change before the first was folded cannot happen: every step folds after its finish)
+            cur_st = st, cur_sa = sa, cur_ss = ss, cur_p0 = p0;
+            t_tol = (pl.tol && st >= 0) ? *(const u64x2*)(pl.tol + (size_t)st * pl.stride + cx.wq) : keep;
+            t_aff = (pl.aff && sa >= 0) ? *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + cx.wq) : keep;
+            t_spread = (pl.spread && ss >= 0) ? *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + cx.wq) : keep;
+            t_p0 = (pl.res && p0 >= 0) ? *(const u64x2*)(pl.res + (size_t)p0 * pl.stride + cx.wq) : keep;
+            pending = true;
+          }
+          // the batch: i0 and the chunks after it that continue it
+          const u64 stops = i0 < 63 ? ~(cont >> (i0 + 1)) : ~0ull;
+          n_i0 = i0;
+          n_n = min(kSliceBatch, (int)__ffsll((long long)stops));
+          n_shape = (meta0 >> 10) & 15;
+          todo &= ~(((1ull << n_n) - 1ull) << i0);
+#define YK_SLICE_ISSUE(NPv, NIv)                                          \
+  case ((NIv) << 2) | (NPv):                                              \
+    slice_issue<NPv, NIv>(cx, n_i0, n_n, prow_l, irow_l, into);           \
+    break;
+          switch (n_shape) {
+            YK_SLICE_SHAPES(YK_SLICE_ISSUE)
+            default: break;
+          }
+#undef YK_SLICE_ISSUE
         }
       }
-#undef YK_SLICE_CASE
+      finish_prev(from);
+      fold();
+      p_i0 = n_i0, p_n = n_n, p_shape = n_shape;
+      return more || n_n != 0;
+    };
+    // (the pipeline is drained at the end of the window: the lane tables belong to it)
+    while (true) {
+      if (!step(buf_a, buf_b)) break;
+      if (!step(buf_b, buf_a)) break;
     }
   }
 }
+#undef YK_SLICE_SHAPES
 
 // ---------------------------------------------------------------------------------------------------
 // zone A of the bitmap: written with the store pattern of a linear fill (scripts/fill_probe*.hip)
