@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU session 12: k_combine_slices v5 — software-pipelined batches over two register buffers, cached first plane row
+# round 3, GPU session 12+: k_combine_slices v5/v6 — chunk descriptors resolved once per pass (k_slice_desc), cached first plane row, two-pass batches
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 rm -f gpurun_out/r03_probe2.jsonl

@@ -153,6 +153,8 @@ struct ykpred_engine {
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
   DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
   bool decide_skip = true;  // YKPRED_DECIDE_SKIP=0: scan every class from the first position
+  DevBuf d_slice_general;   // one int: chunks of the pass that k_combine_slices leaves to k_combine_wave
+  DevBuf d_slice_desc;      // [NC] chunk descriptors of k_combine_slices (k_slice_desc, refilled per pass)
   DevBuf d_pfx_r;           // [n_big][row_words] running maximum of the free values along the bin-pack order (k_dim_prefix_max)
   DevBuf d_idx_c, d_idx_r;  // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical / rank order
   int idx_stride = 0;
@@ -1038,7 +1040,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1799,21 +1801,31 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
     const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0));
     if (slices) {
-      // index rows to decode: a workgroup per slice (<= 128 words) of the row, mask tables in LDS (see k_combine_slices)
+      // index rows to decode: a workgroup per slice (<= 128 words) of the row, mask tables in LDS (see k_combine_slices); the
+      // chunk descriptors are resolved first, one thread per chunk
       const int n_slices = (e->row_stride + ykk::kSliceMaxWords - 1) / ykk::kSliceMaxWords;
       const int slice_words = ((e->row_stride + n_slices - 1) / n_slices + 1) / 2 * 2;  // (row_stride is a multiple of 16)
       const int per_wave = std::max(64, e->slice_chunks_per_wave / 64 * 64);
       const int per_block = per_wave * ykk::kSliceWaves;
       const size_t lds = (size_t)pc.n_big * (size_t)slice_words * 65 * sizeof(u64);
+      HIPCHK(e->d_slice_desc.ensure((size_t)std::max(e->NC, 1) * sizeof(ykk::SliceDesc)));
+      HIPCHK(e->d_slice_general.ensure(sizeof(int)));
+      HIPCHK(hipMemsetAsync(e->d_slice_general.p, 0, sizeof(int), sz));
+      hipLaunchKernelGGL(ykk::k_slice_desc, dim3((unsigned)((e->NC + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, sz, ct, pc, e->NC, class_dirty,
+                         pin_on, e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
       if (lds > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(ykk::k_combine_slices, dim3((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices)), dim3(ykk::kSliceBlock), lds, sz, ct,
-                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty, n_slices, slice_words, per_wave,
-                         e->slice_mode);
+      hipLaunchKernelGGL(ykk::k_combine_slices, dim3((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices)), dim3(ykk::kSliceBlock), lds, sz,
+                         pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices,
+                         slice_words, per_wave, e->slice_mode);
+      // chunks the slice writer has no fast path for (several member rows, pins to unknown nodes, other row shapes): wave per chunk
+      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
+                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,
+                         e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
     } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
-                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty);
+                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr);
     } else {
       switch (variant) {
         case 0: launch(ykk::k_combine<2, false>); break;
@@ -2847,7 +2859,8 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   // classes outside the band layout (and rows appended since the last class build): chunk by chunk, like the evaluation
   if ((long)e->NC * e->wave_combine_below > (long)P) {
     hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
-                       out, e->row_stride, e->row_stride, 0, e->d_expand_count.as<int>(), e->NC, (const int*)nullptr);
+                       out, e->row_stride, e->row_stride, 0, e->d_expand_count.as<int>(), e->NC, (const int*)nullptr, (const ykk::SliceDesc*)nullptr,
+                       (const int*)nullptr);
   } else {
     int tpg = ykk::kBlock;
     while (tpg > ykk::kWave && (tpg / 2) * 2 >= e->row_stride) tpg /= 2;

@@ -1112,14 +1112,20 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
 // own request vector): a chunk is then a handful of rows, and what limits the block-per-chunk kernel is the number of
 // independent (class → signature rows → plane words → store) chains in flight, not bandwidth. Here every WAVE owns a chunk —
 // 4x as many chains per workgroup and no occupancy cap; lane = a pair of adjacent row words (dwordx4 loads and stores).
+struct SliceDesc;
+__device__ __forceinline__ bool slice_desc_general(const SliceDesc* desc, int chunk);
 __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                          int pin_enabled, int* __restrict__ class_count, int n_chunks,
-                                                         const int* __restrict__ class_dirty /* null = every class */) {
+                                                         const int* __restrict__ class_dirty /* null = every class */,
+                                                         const SliceDesc* __restrict__ only_general /* non-null: only the chunks whose
+                                                         descriptor says `general` (the rest belongs to k_combine_slices) */,
+                                                         const int* __restrict__ n_general /* with only_general: their number */) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int chunk = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   if (chunk >= n_chunks) return;
+  if (only_general && (*n_general == 0 || !slice_desc_general(only_general, chunk))) return;
   const int lane = threadIdx.x % kWave;
   const int cls = ct.chunk_class[chunk];
   if (class_dirty ? !class_dirty[cls] : ct.chunk_zone[chunk] != 0) return;
@@ -1201,17 +1207,66 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // wave cycles parked in s_waitcnt, 72 VALU + 69 SALU instructions per KiB: three serialised memory round trips per batch.
 constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
-constexpr int kSliceBatch = 4;      // chunks per batch (two batches are in flight per wave)
+constexpr int kSliceBatch = 8;      // chunks whose loads are in flight together
 constexpr int kSliceMaxWords = 128;
-
 typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+
+// Chunk descriptors of the slice writer: what a wave needs to know about a chunk, resolved ONCE per pass by one thread per chunk
+// (k_slice_desc) instead of once per (chunk, slice) by the writer — the walk chunk → class → signatures → request-value rows is
+// three levels of dependent, uncoalesced loads from tables that do not fit the L2; seven slices repeated it seven times and every
+// wave of the writer sat through it before its first store (27 M random 64-byte reads per pass: profiles/r03_session11_pmc.txt).
 // A class's rows on the fast path: toleration, affinity, spread and the FIRST request-value plane row (row 0 of the family, the
 // pod-independent part — the same row for every class) are "cached" rows, folded into the lane's base words while they do not
-// change from chunk to chunk; what remains per chunk is at most one more plane row (NP = 0 / 1) and one or two index rows.
-struct SliceBuf {
-  u64x2_t v[kSliceBatch];
-  unsigned two[kSliceBatch][kMaxIdxRows];
+// change from chunk to chunk; what remains per chunk is at most one more plane row and exactly one index row.
+struct SliceDesc {   // 48 bytes = three 16-byte loads
+  int cls, meta, pin, mem0;   // meta: len | first << 8 | general path << 9 | per-chunk plane row << 10 | live << 15
+  int st, sa, ss, p0;         // signature rows + the cached plane row (-1: none)
+  int prow, irow, begin, pad; // per-chunk plane row, index row (walked dimension << kRowBigShift | row), first member slot
 };
+constexpr int kSliceFirst = 1 << 8, kSliceGeneral = 1 << 9, kSlicePlane = 1 << 10, kSliceLive = 1 << 15;
+__device__ __forceinline__ bool slice_desc_general(const SliceDesc* desc, int chunk) {
+  return (desc[chunk].meta & (kSliceLive | kSliceGeneral)) == (kSliceLive | kSliceGeneral);
+}
+// n_general (zeroed by the caller): the number of live chunks left to k_combine_wave
+__global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl, int n_chunks, const int* __restrict__ class_dirty, int pin_enabled,
+                                                       SliceDesc* __restrict__ out, int* __restrict__ n_general) {
+  const int chunk = blockIdx.x * kBlock + threadIdx.x;
+  if (chunk >= n_chunks) return;
+  SliceDesc d{};
+  d.st = d.sa = d.ss = d.p0 = d.pin = d.mem0 = -1;
+  d.irow = 1 << kRowBigShift;
+  d.cls = ct.chunk_class[chunk];
+  const bool act = class_dirty ? class_dirty[d.cls] != 0 : ct.chunk_zone[chunk] == 0;
+  if (act) {
+    const int len = ct.chunk_len[chunk];
+    d.meta = kSliceLive | len | (ct.chunk_first[chunk] ? kSliceFirst : 0);
+    const int4 sg = *(const int4*)(ct.sig + (size_t)d.cls * 4);
+    d.st = sg.y, d.sa = sg.z, d.ss = sg.w;
+    d.pin = (pin_enabled & 1) ? ct.pin[d.cls] : -1;
+    d.begin = ct.chunk_begin[chunk];
+    d.mem0 = ct.members[d.begin];
+    int np = 0, ni = 0;
+    if (pl.res && sg.x >= 0)
+      for (int k = 0; k < pl.res_slots; ++k) {
+        const int r = pl.res_rows[(size_t)sg.x * pl.res_slots + k];
+        if (r < 0) continue;
+        if (r >> kRowBigShift) {
+          if (ni == 0) d.irow = r;
+          ++ni;
+        } else {
+          if (np == 0) d.p0 = r;
+          if (np == 1) d.prow = r;
+          ++np;
+        }
+      }
+    // the general path: several member rows, an unknown pinned node, or a shape the fast path has no code for
+    if (len != 1 || d.pin == -2 || np > 2 || ni != 1) d.meta |= kSliceGeneral;
+    if (np >= 2) d.meta |= kSlicePlane;
+    if (d.meta & kSliceGeneral) atomicAdd(n_general, 1);
+  }
+  out[chunk] = d;
+}
+
 struct SliceCtx {
   const Planes* pl;
   u64* bitmap;
@@ -1221,43 +1276,45 @@ struct SliceCtx {
   int wq;        // this lane's word pair (0 when the pair lies outside the row: loads stay valid, nothing is stored)
   bool st_ok;    // the pair is stored
 };
-// loads of one batch: chunks i0 .. i0 + n - 1 of the wave's window, all of shape (NP per-chunk plane rows, NI index rows)
-template <int NP, int NI>
-__device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, int prow_l, const int (&irow_l)[kMaxIdxRows], SliceBuf& buf) {
+struct SliceBuf {
+  u64x2_t v[kSliceBatch];
+  unsigned short two[kSliceBatch];  // (kept 16 bits wide: a widening right after the load would wait for it)
+};
+// loads of one batch: chunks i0 .. i0 + n - 1 of the wave's window, NP = they carry a per-chunk plane row
+template <int NP>
+__device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, int prow_l, int irow_l, SliceBuf& buf) {
   const Planes& pl = *cx.pl;
 #pragma unroll
   for (int j = 0; j < kSliceBatch; ++j) {
     if (j < n) {
       const int c = i0 + j;
       if (NP) buf.v[j] = *(const u64x2_t*)(pl.res + (size_t)__builtin_amdgcn_readlane(prow_l, c) * pl.stride + cx.wq);
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int rid = __builtin_amdgcn_readlane(irow_l[k], c) & ((1 << kRowBigShift) - 1);
-        buf.two[j][k] = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + cx.wq);  // index bytes of the pair
-      }
+      const int rid = __builtin_amdgcn_readlane(irow_l, c) & ((1 << kRowBigShift) - 1);
+      buf.two[j] = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + cx.wq);  // index bytes of the pair
     }
   }
 }
-// masks, feasible counts and stores of a batch whose loads were issued by slice_issue<NP, NI>
-template <int NP, int NI>
+// masks, feasible counts and stores of a batch whose loads were issued by slice_issue<NP>. Two passes — every mask first, then
+// the counts and stores: the first pass touches every loaded register, so the compiler waits ONCE for the batch's loads; with
+// decode and store interleaved per chunk it put a full `s_waitcnt vmcnt(0)` in front of every chunk (the guards make its
+// counting conservative), i.e. every chunk waited for the previous chunk's store to land.
+template <int NP>
 __device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, u64x2_t w_base, int cls_l, int meta_l, int pin_l, int mem0_l,
-                                             const int (&irow_l)[kMaxIdxRows], const SliceBuf& buf) {
+                                             int irow_l, SliceBuf& buf) {
 #pragma unroll
   for (int j = 0; j < kSliceBatch; ++j) {
     if (j < n) {
       const int c = i0 + j;
       u64x2_t x = w_base;
       if (NP) x &= buf.v[j];
-#pragma unroll
-      for (int k = 0; k < NI; ++k) {
-        const int big = (__builtin_amdgcn_readlane(irow_l[k], c) >> kRowBigShift) - 1;
-        const u64* tab = cx.s_pm + big * cx.tab_stride + (2 * cx.lane) * 65;
-        if (cx.mode & 8) {  // (experiment: no LDS decode)
-          x.x &= buf.two[j][k];
-          continue;
-        }
-        x.x &= tab[buf.two[j][k] & 0xffu];
-        x.y &= tab[65 + (buf.two[j][k] >> 8)];
+      const int big = (__builtin_amdgcn_readlane(irow_l, c) >> kRowBigShift) - 1;
+      const u64* tab = cx.s_pm + big * cx.tab_stride + (2 * cx.lane) * 65;
+      const unsigned two = buf.two[j];
+      if (cx.mode & 8) {  // (experiment: no LDS decode)
+        x.x &= two;
+      } else {
+        x.x &= tab[two & 0xffu];
+        x.y &= tab[65 + (two >> 8)];
       }
       if (cx.pin_enabled) {
         const int pin = __builtin_amdgcn_readlane(pin_l, c);
@@ -1266,7 +1323,15 @@ __device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, 
           x.y &= (cx.wq + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
         }
       }
-      if (__builtin_amdgcn_readlane(meta_l, c) & (1 << 8)) {
+      buf.v[j] = x;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSliceBatch; ++j) {
+    if (j < n) {
+      const int c = i0 + j;
+      const u64x2_t x = buf.v[j];
+      if (__builtin_amdgcn_readlane(meta_l, c) & kSliceFirst) {
         const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (idle lanes and padding words hold zeros: `keep`)
         if (cx.lane == 63 && pc && !(cx.mode & 4)) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
       }
@@ -1275,14 +1340,12 @@ __device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, 
     }
   }
 }
-// shapes of the fast path (per-chunk plane rows, index rows); every other class takes the general path
-#define YK_SLICE_SHAPES(M) M(0, 1) M(1, 1) M(0, 2) M(1, 2)
 
 // grid.x = chunk batches x n_slices (consecutive workgroups take consecutive slices of the same chunks); dynamic LDS =
 // n_big * slice_words * 520 bytes. slice_words is even; lane l owns the word pair slice * slice_words + 2 l while 2 l < slice_words.
 __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
-    ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
-    const int* __restrict__ class_dirty /* null = every class */, int n_slices, int slice_words, int chunks_per_wave,
+    Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled,
+    int* __restrict__ class_count, int n_chunks, int n_slices, int slice_words, int chunks_per_wave,
     int mode /* experiments, timing only: 1 = no stores, 4 = no count atomics, 8 = no LDS decode, 16 = cached rows never reloaded */) {
   typedef u64x2_t u64x2;
   extern __shared__ u64 s_pm[];  // [n_big][slice_words][65]
@@ -1301,166 +1364,67 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
   }
   const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
   const int c_end = min(c_begin + chunks_per_wave, n_chunks);
-  const int slots = pl.res_slots;
   // this lane's word pair; a pair past the slice or the row loads from the row's first words, holds zeros and stores nothing
   const int w_true = slice * slice_words + 2 * lane;
   const bool in_row = 2 * lane < slice_words && w_true < row_stride;
   const u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};  // padding stays zero
   SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, lane, pin_enabled, mode, in_row ? w_true : 0, in_row && !(mode & 1)};
-  // AND of the cached rows' words of the current key (wave-uniform; -3 = nothing cached) ...
+  // AND of the cached rows' words of the current key (wave-uniform; -3 = nothing cached)
   int cur_st = -3, cur_sa = -3, cur_ss = -3, cur_p0 = -3;
   u64x2 w_base = keep;
-  // ... and the words of the NEXT key, loaded but not yet folded: the batch in flight before them still needs the old ones
-  u64x2 t_tol = keep, t_aff = keep, t_spread = keep, t_p0 = keep;
-  bool pending = false;
-  SliceBuf buf_a, buf_b;
+  SliceBuf buf;
   for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
-    // lane j walks the tables of chunk c0 + j
-    const int chunk_l = c0 + lane;
-    bool act = false;
-    int cls_l = 0, meta_l = 0 /* len | first << 8 | general path << 9 | per-chunk plane rows << 10 | index rows << 12 */, pin_l = -1, mem0_l = -1;
-    int st_l = -1, sa_l = -1, ss_l = -1, p0_l = -1 /* the cached plane row */, prow_l = 0 /* the per-chunk plane row */;
-    int irow_l[kMaxIdxRows];
-#pragma unroll
-    for (int k = 0; k < kMaxIdxRows; ++k) irow_l[k] = 1 << kRowBigShift;
-    if (chunk_l < c_end) {
-      cls_l = ct.chunk_class[chunk_l];
-      act = class_dirty ? class_dirty[cls_l] != 0 : ct.chunk_zone[chunk_l] == 0;
-      if (act) {
-        const int len = ct.chunk_len[chunk_l];
-        meta_l = len | (ct.chunk_first[chunk_l] ? 1 << 8 : 0);
-        const int4 sg = *(const int4*)(ct.sig + (size_t)cls_l * 4);
-        st_l = sg.y, sa_l = sg.z, ss_l = sg.w;
-        pin_l = pin_enabled ? ct.pin[cls_l] : -1;
-        mem0_l = ct.members[ct.chunk_begin[chunk_l]];
-        int np = 0, ni = 0;
-        if (pl.res && sg.x >= 0) {
-          // the class's request-value rows: first plane row = cached, second = per chunk; index rows (walked dimensions) apart
-#pragma unroll
-          for (int k = 0; k <= kMaxR; ++k) {
-            const int r = k < slots ? pl.res_rows[(size_t)sg.x * slots + k] : -1;
-            if (r < 0) continue;
-            if (r >> kRowBigShift) {
-#pragma unroll
-              for (int j = 0; j < kMaxIdxRows; ++j)
-                if (j == ni) irow_l[j] = r;
-              ++ni;
-            } else {
-              if (np == 0) p0_l = r;
-              if (np == 1) prow_l = r;
-              ++np;
-            }
-          }
-        }
-        // the general path: several member rows, an unknown pinned node, or a shape the fast path has no code for
-        if (len != 1 || pin_l == -2 || np > 2 || ni < 1 || ni > kMaxIdxRows) meta_l |= 1 << 9;
-        meta_l |= ((np >= 2 ? 1 : 0) << 10) | (min(ni, 3) << 12);
-      }
+    // lane j holds the descriptor of chunk c0 + j
+    int cls_l = 0, meta_l = 0, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1, p0_l = -1, prow_l = 0, irow_l = 1 << kRowBigShift;
+    if (c0 + lane < c_end) {
+      const int4* dp = (const int4*)(desc + c0 + lane);
+      const int4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+      cls_l = d0.x, meta_l = d0.y, pin_l = d0.z, mem0_l = d0.w;
+      st_l = d1.x, sa_l = d1.y, ss_l = d1.z, p0_l = d1.w;
+      prow_l = d2.x, irow_l = d2.y;
     }
+    const bool act = meta_l & kSliceLive;
     // chunk j continues the batch of chunk j - 1: both live on the fast path with the same cached rows and shape
-    const int key_l = act ? (meta_l >> 9) : -1;  // general-path flag + shape
-    const bool cont_l = lane > 0 && act && !(meta_l & (1 << 9)) && __shfl_up(key_l, 1, kWave) == key_l && __shfl_up(st_l, 1, kWave) == st_l &&
+    const int key_l = act ? (meta_l & (kSliceGeneral | kSlicePlane)) : -1;
+    const bool cont_l = lane > 0 && act && !(meta_l & kSliceGeneral) && __shfl_up(key_l, 1, kWave) == key_l && __shfl_up(st_l, 1, kWave) == st_l &&
                         __shfl_up(sa_l, 1, kWave) == sa_l && __shfl_up(ss_l, 1, kWave) == ss_l && __shfl_up(p0_l, 1, kWave) == p0_l;
     const u64 cont = __ballot(cont_l);
     u64 todo = __ballot(act);
-    // the batch whose loads are in flight (wave-uniform): first chunk, length, shape; p_n == 0: none
-    int p_i0 = 0, p_n = 0, p_shape = 0;
-    auto finish_prev = [&](const SliceBuf& buf) {
-      if (p_n == 0) return;
-#define YK_SLICE_FINISH(NPv, NIv)                                                                            \
-  case ((NIv) << 2) | (NPv):                                                                                 \
-    slice_finish<NPv, NIv>(cx, p_i0, p_n, w_base, cls_l, meta_l, pin_l, mem0_l, irow_l, buf);                \
-    break;
-      switch (p_shape) {
-        YK_SLICE_SHAPES(YK_SLICE_FINISH)
-        default: break;
+    while (todo) {
+      const int i0 = __ffsll((long long)todo) - 1;
+      const int st = __builtin_amdgcn_readlane(st_l, i0), sa = __builtin_amdgcn_readlane(sa_l, i0), ss = __builtin_amdgcn_readlane(ss_l, i0);
+      const int meta0 = __builtin_amdgcn_readlane(meta_l, i0);
+      if (meta0 & kSliceGeneral) {  // not this kernel's: k_combine_wave writes the chunks the descriptors mark `general`
+        todo &= todo - 1;
+        continue;
       }
-#undef YK_SLICE_FINISH
-      p_n = 0;
-    };
-    auto fold = [&]() {
-      if (!pending) return;
-      w_base = all_fail ? u64x2{0, 0} : (keep & t_tol & t_aff & t_spread & t_p0);
-      pending = false;
-    };
-    // one pipeline step: issue the next batch into `into`, then finish the batch in flight from `from`; false = window done
-    auto step = [&](SliceBuf& into, const SliceBuf& from) -> bool {
-      int n_i0 = 0, n_n = 0, n_shape = 0;
-      const bool more = todo != 0;
-      if (todo) {
-        const int i0 = __ffsll((long long)todo) - 1;
-        const int st = __builtin_amdgcn_readlane(st_l, i0), sa = __builtin_amdgcn_readlane(sa_l, i0), ss = __builtin_amdgcn_readlane(ss_l, i0);
-        const int meta0 = __builtin_amdgcn_readlane(meta_l, i0);
-        if (meta0 & (1 << 9)) {
-          // general path, one chunk: any number of rows and members (class_rows / class_word as in k_combine_wave). It runs on
-          // an EMPTY pipeline: with a batch in flight this step only finishes that batch, the next one takes the chunk.
-          if (p_n == 0) {
-            fold();
-            todo &= todo - 1;
-            const int cls = __builtin_amdgcn_readlane(cls_l, i0), pin = __builtin_amdgcn_readlane(pin_l, i0), len = meta0 & 0xff;
-            const ClassRows cr = class_rows(pl, ct.sig[cls * 4 + 0], st, sa, ss);
-            const int begin = ct.chunk_begin[c0 + i0];
-            const int mine = lane < len ? ct.members[begin + lane] : -1;  // (every lane: the broadcast below reads all of them)
-            u64x2 x = {0, 0};
-            if (in_row && pin != -2 && !all_fail) {
-              if (w_true < row_words) x.x = class_word(cr, w_true);
-              if (w_true + 1 < row_words) x.y = class_word(cr, w_true + 1);
-              if (pin >= 0) {
-                x.x &= (w_true == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-                x.y &= (w_true + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-              }
-            }
-            if (meta0 & (1 << 8)) {
-              const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));
-              if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
-            }
-            for (int m = 0; m < len; ++m) {
-              const int p = __builtin_amdgcn_readlane(mine, m);
-              if (p >= 0 && cx.st_ok) *(u64x2*)(bitmap + (size_t)p * row_stride + w_true) = x;
-            }
-            return true;
-          }
-        } else {
-          const int p0 = __builtin_amdgcn_readlane(p0_l, i0);
-          if ((st != cur_st || sa != cur_sa || ss != cur_ss || p0 != cur_p0) && !((mode & 16) && cur_st != -3)) {
-            // (a second change before the first was folded cannot happen: every step folds after its finish)
-            cur_st = st, cur_sa = sa, cur_ss = ss, cur_p0 = p0;
-            t_tol = (pl.tol && st >= 0) ? *(const u64x2*)(pl.tol + (size_t)st * pl.stride + cx.wq) : keep;
-            t_aff = (pl.aff && sa >= 0) ? *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + cx.wq) : keep;
-            t_spread = (pl.spread && ss >= 0) ? *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + cx.wq) : keep;
-            t_p0 = (pl.res && p0 >= 0) ? *(const u64x2*)(pl.res + (size_t)p0 * pl.stride + cx.wq) : keep;
-            pending = true;
-          }
-          // the batch: i0 and the chunks after it that continue it
-          const u64 stops = i0 < 63 ? ~(cont >> (i0 + 1)) : ~0ull;
-          n_i0 = i0;
-          n_n = min(kSliceBatch, (int)__ffsll((long long)stops));
-          n_shape = (meta0 >> 10) & 15;
-          todo &= ~(((1ull << n_n) - 1ull) << i0);
-#define YK_SLICE_ISSUE(NPv, NIv)                                          \
-  case ((NIv) << 2) | (NPv):                                              \
-    slice_issue<NPv, NIv>(cx, n_i0, n_n, prow_l, irow_l, into);           \
-    break;
-          switch (n_shape) {
-            YK_SLICE_SHAPES(YK_SLICE_ISSUE)
-            default: break;
-          }
-#undef YK_SLICE_ISSUE
-        }
+      // the batch: i0 and the chunks after it that continue it
+      const u64 stops = i0 < 63 ? ~(cont >> (i0 + 1)) : ~0ull;
+      const int n = min(kSliceBatch, (int)__ffsll((long long)stops));
+      todo &= ~(((1ull << n) - 1ull) << i0);
+      // cached rows of a new key: their loads go out TOGETHER with the batch's loads, one wait serves both
+      const int p0 = __builtin_amdgcn_readlane(p0_l, i0);
+      const bool changed = (st != cur_st || sa != cur_sa || ss != cur_ss || p0 != cur_p0) && !((mode & 16) && cur_st != -3);
+      u64x2 t_tol = keep, t_aff = keep, t_spread = keep, t_p0 = keep;
+      if (changed) {
+        cur_st = st, cur_sa = sa, cur_ss = ss, cur_p0 = p0;
+        if (pl.tol && st >= 0) t_tol = *(const u64x2*)(pl.tol + (size_t)st * pl.stride + cx.wq);
+        if (pl.aff && sa >= 0) t_aff = *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + cx.wq);
+        if (pl.spread && ss >= 0) t_spread = *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + cx.wq);
+        if (pl.res && p0 >= 0) t_p0 = *(const u64x2*)(pl.res + (size_t)p0 * pl.stride + cx.wq);
       }
-      finish_prev(from);
-      fold();
-      p_i0 = n_i0, p_n = n_n, p_shape = n_shape;
-      return more || n_n != 0;
-    };
-    // (the pipeline is drained at the end of the window: the lane tables belong to it)
-    while (true) {
-      if (!step(buf_a, buf_b)) break;
-      if (!step(buf_b, buf_a)) break;
+      if (meta0 & kSlicePlane)
+        slice_issue<1>(cx, i0, n, prow_l, irow_l, buf);
+      else
+        slice_issue<0>(cx, i0, n, prow_l, irow_l, buf);
+      if (changed) w_base = all_fail ? u64x2{0, 0} : (keep & t_tol & t_aff & t_spread & t_p0);
+      if (meta0 & kSlicePlane)
+        slice_finish<1>(cx, i0, n, w_base, cls_l, meta_l, pin_l, mem0_l, irow_l, buf);
+      else
+        slice_finish<0>(cx, i0, n, w_base, cls_l, meta_l, pin_l, mem0_l, irow_l, buf);
     }
   }
 }
-#undef YK_SLICE_SHAPES
 
 // ---------------------------------------------------------------------------------------------------
 // zone A of the bitmap: written with the store pattern of a linear fill (scripts/fill_probe*.hip)
