@@ -1207,7 +1207,7 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // wave cycles parked in s_waitcnt, 72 VALU + 69 SALU instructions per KiB: three serialised memory round trips per batch.
 constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
-constexpr int kSliceBatch = 8;      // chunks whose loads are in flight together
+constexpr int kSliceBatch = 8;      // chunks whose loads are in flight together (16-wave workgroups with 64 VGPRs and batches of 4 spill in the hot loop)
 constexpr int kSliceMaxWords = 128;
 typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
 
