@@ -240,6 +240,66 @@ def test_request_value_planes_sorted_walk(monkeypatch, seed, walk_rows):
             m.close()
 
 
+@pytest.mark.parametrize("wpl", [1, 2, 4])
+@pytest.mark.parametrize("n_nodes", [63, 200, 4100])
+def test_sig_planes_words_per_lane(monkeypatch, wpl, n_nodes):
+    """k_sig_planes<WPL>: a lane owns 1, 2 or 4 words of the row, 64 apart (chosen from the row width; forced here) — rows much
+    shorter than one wave's span, rows ending inside a lane's second / fourth word, both dictionary families, rank-ordered
+    planes with their first-word table (decisions) — against the oracle."""
+    monkeypatch.setenv("YKPRED_SIG_WPL", str(wpl))
+    snap = _gen.random_snapshot(4200 + wpl, n_nodes=n_nodes, n_pods=70)
+    m = pkg.GpuPredicateManager()
+    try:
+        m.load_snapshot(snap)
+        if n_nodes < 1000:
+            o, want = check_against_oracle(m, snap, True)
+            pods = range(0, len(snap["pods"]), 5)
+        else:
+            m.evaluate()
+            o = orc.Oracle(snap)
+            pods = list(range(0, len(snap["pods"]), 9))
+            want_s = o.eval_grid(pods=pods, threads=os.cpu_count() or 8)
+            assert np.array_equal(unpack(m.read_rows(np.array(pods, dtype=np.int32)), n_nodes), want_s)
+            want = {p: want_s[k] for k, p in enumerate(pods)}
+        dec = m.read_decisions()
+        for p in pods:
+            assert o.decide(p) == (int(want[p].sum()), int(dec[p]))
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("walk_rows,n_nodes", [(1, 333), (3, 129), (1, 8300)])
+def test_slice_writer_equals_wave_writer_and_oracle(monkeypatch, walk_rows, n_nodes):
+    """The zone-B writer of populations with index rows (k_slice_desc + k_combine_slices: mask tables of a row slice in LDS,
+    batches of single-row chunks; everything else through the descriptor-filtered k_combine_wave) against the plain
+    wave-per-chunk writer (YKPRED_COMBINE_SLICES=0) on the same snapshot: one / two walked dimensions, pinned pods, duplicated
+    pods (several member rows), rows narrower and wider than one 128-word slice — bitmap, counts, decisions, and the oracle."""
+    monkeypatch.setenv("YKPRED_WALK_ROWS", str(walk_rows))
+    snap = _gen.random_snapshot(9900 + walk_rows, n_nodes=n_nodes, n_pods=150, scalars=True)
+    got = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("YKPRED_COMBINE_SLICES", knob)
+        m = pkg.GpuPredicateManager()
+        try:
+            m.load_snapshot(snap)
+            m.evaluate()
+            assert m.layout().index_rows > 0
+            got[knob] = (unpack(m.read_bitmap(), n_nodes), m.read_counts(), m.read_decisions())
+            if knob == "1" and n_nodes < 1000:
+                check_against_oracle(m, snap, True)
+        finally:
+            m.close()
+    for a, b in zip(got["0"], got["1"]):
+        assert np.array_equal(a, b)
+    # the wide rows (several slices per row): sampled asks against the oracle, decisions included
+    o = orc.Oracle(snap)
+    sample = np.random.default_rng(5).choice(len(snap["pods"]), size=24, replace=False).astype(np.int32)
+    want = o.eval_grid(pods=sample, threads=os.cpu_count() or 8, prefilter_once=True)
+    assert np.array_equal(got["1"][0][sample], want)
+    for k, p in enumerate(sample[:8]):
+        assert o.decide(int(p), prefilter_once=True) == (int(want[k].sum()), int(got["1"][2][p]))
+
+
 def test_unique_request_vectors_midsize(pm):
     """bench.py's adversarial variant in small: every ask a distinct cpu request (5 000 values in one dimension → the sorted
     walk at its default threshold), full grid against the oracle."""

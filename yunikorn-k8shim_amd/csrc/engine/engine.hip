@@ -1694,7 +1694,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                       e->n_big, e->walk_chunks, e->row_words};
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
-      hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock),
+      hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords))), dim3(ykk::kBlock),
                          0, s, dw, (ranked ? e->d_idx_r : e->d_idx_c).as<unsigned char>(), e->idx_stride);
       if (ranked && pr.pfx)  // running maximum of the free values along the bin-pack order: where a value's row can start (k_decide)
         hipLaunchKernelGGL(ykk::k_dim_prefix_max, dim3((unsigned)e->n_big), dim3(ykk::kPfxBlock), 0, s, dw, e->d_pfx_r.as<i64>());

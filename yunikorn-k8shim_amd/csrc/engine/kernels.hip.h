@@ -327,32 +327,39 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
   a.pmask[cell * 65 + lane] = keep;
   if (lane == 0) a.pmask[cell * 65 + 64] = 0;
 }
-// blockIdx.x: walk chunk, blockIdx.y: block of 256 words; thread = word.
+// blockIdx.x: walk chunk, blockIdx.y: block of 256 * kWalkWords words; thread = kWalkWords ADJACENT words.
 // The rows it produces are INDEX rows: one BYTE per 64-node word — the position `ptr` in the word's sorted free list — instead of
 // the 8-byte plane word pmask[word][ptr] itself. A walked dimension has up to 10^6 rows; as u64 planes they are 6.5 GB written
 // here and read again by the combine / decide kernels (half of that population's traffic), as index rows 0.8 GB. Consumers
-// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word).
+// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word; k_combine_slices keeps the tables
+// of a row slice in LDS).
+// Four words per thread, one dword store per row: with a byte per thread the kernel sat on its 13 M byte-store instructions per
+// pass (64 bytes per wave store; SQ counters: 73 % of the wave cycles waiting, 0.55–0.9 ms for 0.78 GB).
+constexpr int kWalkWords = 4;
 __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* __restrict__ out, int stride) {
   const int chunk = blockIdx.x;
   const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
-  const int w_raw = blockIdx.y * kBlock + threadIdx.x;
-  const bool live = w_raw < a.n_words;
-  const int w = live ? w_raw : a.n_words - 1;  // every lane takes part in the v_readlane exchanges
   const int lane = threadIdx.x % kWave;
-  const size_t cell = (size_t)big * a.n_words + w;
-  const i64* sf = a.sfree + cell * 64;
+  const int w0 = (blockIdx.y * kBlock + threadIdx.x) * kWalkWords;
+  if (w0 - lane * kWalkWords >= a.n_words) return;  // whole wave beyond the row
+  const bool live = w0 < a.n_words;                 // (stride is a multiple of 64: the dword of a live thread lies inside the row)
   const i64 kMax = 0x7fffffffffffffffll;
-  int ptr = 0;
-  {  // lower bound: entries [0, ptr) are below the chunk's first value
-    const i64 v0 = a.val[a.order[begin]];
-    int lo = 0, hi = 64;
+  const i64* sf[kWalkWords];
+  int ptr[kWalkWords];
+  i64 next[kWalkWords];
+  const i64 v0 = a.val[a.order[begin]];
+#pragma unroll
+  for (int j = 0; j < kWalkWords; ++j) {
+    const int w = min(w0 + j, a.n_words - 1);  // every lane takes part in the v_readlane exchanges; bytes past the row are never read
+    sf[j] = a.sfree + ((size_t)big * a.n_words + w) * 64;
+    int lo = 0, hi = 64;  // lower bound: entries [0, ptr) are below the chunk's first value
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (sf[mid] < v0) lo = mid + 1; else hi = mid;
+      if (sf[j][mid] < v0) lo = mid + 1; else hi = mid;
     }
-    ptr = lo;
+    ptr[j] = lo;
+    next[j] = lo < 64 ? sf[j][lo] : kMax;
   }
-  i64 next = ptr < 64 ? sf[ptr] : kMax;
   for (int i0 = 0; i0 < len; i0 += kWave) {
     const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
     const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
@@ -360,11 +367,16 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* _
     for (int i = 0; i < m; ++i) {
       const i64 v = readlane_i64(my_val, i);
       const int row = __builtin_amdgcn_readlane(my_row, i);
-      while (next < v) {
-        ++ptr;
-        next = ptr < 64 ? sf[ptr] : kMax;
+      unsigned packed = 0;
+#pragma unroll
+      for (int j = 0; j < kWalkWords; ++j) {
+        while (next[j] < v) {
+          ++ptr[j];
+          next[j] = ptr[j] < 64 ? sf[j][ptr[j]] : kMax;
+        }
+        packed |= (unsigned)ptr[j] << (8 * j);
       }
-      if (live) out[(size_t)row * stride + w] = (unsigned char)ptr;
+      if (live) *(unsigned*)(out + (size_t)row * stride + w0) = packed;
     }
   }
 }
