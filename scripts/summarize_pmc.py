@@ -55,14 +55,20 @@ for wl in WORKLOADS:
         short = TIMER_LABEL.get(short, short)  # kernels the engine times under one label (bench.py looks traffic up by that label)
         wb = w[k]["avg_KiB"] * 1024 / ratio
         fb = f.get(k, {"avg_KiB": 0.0})["avg_KiB"] * 1024
-        e = kernels.setdefault(short, {"write_bytes": 0.0, "fetch_bytes_raw": 0.0, "launches_per_step": 0.0})
+        e = kernels.setdefault(short, {"write_bytes": 0.0, "fetch_bytes_raw": 0.0, "launches_per_step": 0.0, "_top": 0.0})
         steps = 4.0  # --steps 3 --warmup 1
-        e["write_bytes"] += wb * w[k]["launches"] / steps
-        e["fetch_bytes_raw"] += fb * f.get(k, {"launches": 0})["launches"] / steps
-        e["launches_per_step"] += w[k]["launches"] / steps
+        mine_w, mine_f = wb * w[k]["launches"] / steps, fb * f.get(k, {"launches": 0})["launches"] / steps
+        e["write_bytes"] += mine_w
+        e["fetch_bytes_raw"] += mine_f
+        # a label's launches are those of its heaviest kernel (its helpers — descriptor / fix-up / sort kernels — add bytes only):
+        # hbm_bytes / launches_per_step = the bytes of one timed region of that label
+        if mine_w + 2 * mine_f >= e["_top"]:
+            e["_top"] = mine_w + 2 * mine_f
+            e["launches_per_step"] = w[k]["launches"] / steps
     for e in kernels.values():
         e["hbm_bytes"] = int(e["write_bytes"] + 2 * e["fetch_bytes_raw"])
         e["write_bytes"], e["fetch_bytes_raw"] = int(e["write_bytes"]), int(e["fetch_bytes_raw"])
+        e.pop("_top", None)
     traffic["workloads"][wl] = {"kernels_per_step": kernels, "step_hbm_bytes": int(sum(e["hbm_bytes"] for e in kernels.values()))}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", f"traffic_{rnd}.json"), "w"), indent=1)
