@@ -186,6 +186,7 @@ struct ykpred_engine {
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
   int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
+  int wave_rows = 0;                // YKPRED_WAVE_ROWS=1: k_combine_wave writes member rows one after the other (class row in registers)
   int slice_pairs = 0;              // YKPRED_SLICE_PAIRS=1: one word pair per lane even with a single walked dimension
   int slice_mode = 0;               // YKPRED_SLICE_MODE: experiments of k_combine_slices (bit 0 = no stores: WRONG bitmap, timing only)
   int slice_chunks_per_wave = 64;   // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
@@ -993,6 +994,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (const char* v = getenv("YKPRED_SIG_WPL")) e->sig_wpl = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_CHUNKS")) e->slice_chunks_per_wave = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_MODE")) e->slice_mode = atoi(v);
+  if (const char* v = getenv("YKPRED_WAVE_ROWS")) e->wave_rows = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_PAIRS")) e->slice_pairs = atoi(v);
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -1819,13 +1821,19 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices,
                          slice_words, per_wave, e->slice_mode);
       // chunks the slice writer has no fast path for (several member rows, pins to unknown nodes, other row shapes): wave per chunk
-      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
+      hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,
                          e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
     } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
-      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
-                         pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr);
+      // narrow enough rows: the class row in registers, member rows written one after the other (k_combine_wave<true>)
+      const dim3 wgrid((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
+      if (e->wave_rows && e->row_stride <= ykk::kWaveRowPieces * 2 * ykk::kWave)
+        hipLaunchKernelGGL(ykk::k_combine_wave<true>, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                           e->d_class_count.as<int>(), e->NC, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr);
+      else
+        hipLaunchKernelGGL(ykk::k_combine_wave<false>, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                           e->d_class_count.as<int>(), e->NC, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr);
     } else {
       switch (variant) {
         case 0: launch(ykk::k_combine<2, false>); break;
@@ -2858,7 +2866,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   }
   // classes outside the band layout (and rows appended since the last class build): chunk by chunk, like the evaluation
   if ((long)e->NC * e->wave_combine_below > (long)P) {
-    hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
+    hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
                        out, e->row_stride, e->row_stride, 0, e->d_expand_count.as<int>(), e->NC, (const int*)nullptr, (const ykk::SliceDesc*)nullptr,
                        (const int*)nullptr);
   } else {

@@ -1126,7 +1126,9 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
 // 4x as many chains per workgroup and no occupancy cap; lane = a pair of adjacent row words (dwordx4 loads and stores).
 struct SliceDesc;
 __device__ __forceinline__ bool slice_desc_general(const SliceDesc* desc, int chunk);
-__global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
+constexpr int kWaveRowPieces = 8;  // row-major form: rows of up to 8 KiB (65 536 nodes) held in registers
+template <bool ROWS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_combine_wave(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                          int pin_enabled, int* __restrict__ class_count, int n_chunks,
                                                          const int* __restrict__ class_dirty /* null = every class */,
                                                          const SliceDesc* __restrict__ only_general /* non-null: only the chunks whose
@@ -1167,6 +1169,29 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
     }
     return x;
   };
+  if (ROWS) {
+    // Row-major form (rows of <= kWaveRowPieces KiB pieces): the whole class row sits in registers — every plane word of it
+    // is requested at once — and each member row is then written from its first byte to its last, 1 KiB per store: one
+    // sequential 6 KB burst per row instead of a 1 KiB piece in each of the chunk's rows per step.
+    u64x2 xs[kWaveRowPieces];
+    const int pieces = (row_stride + 2 * kWave - 1) / (2 * kWave);
+#pragma unroll
+    for (int k = 0; k < kWaveRowPieces; ++k) {
+      xs[k] = u64x2{0, 0};
+      if (k < pieces) {
+        xs[k] = class_pair(k * 2 * kWave + 2 * lane);
+        pc += __popcll(xs[k].x) + __popcll(xs[k].y);
+      }
+    }
+    for (int i = 0; i < len; ++i) {
+      const int p = __builtin_amdgcn_readlane(mine, i);
+      if (p < 0) continue;
+      u64* row = bitmap + (size_t)p * row_stride + 2 * lane;
+#pragma unroll
+      for (int k = 0; k < kWaveRowPieces; ++k)
+        if (k < pieces && k * 2 * kWave + 2 * lane < row_stride) *(u64x2*)(row + k * 2 * kWave) = xs[k];
+    }
+  } else {
   // two-stage pipeline: the plane words of the next 1 KiB piece are in flight while this piece is stored
   u64x2 next = class_pair(2 * lane);
   for (int w0 = 0; w0 < row_stride; w0 += 2 * kWave) {
@@ -1179,6 +1204,7 @@ __global__ __launch_bounds__(kBlock) void k_combine_wave(ClassTable ct, Planes p
         const int p = __builtin_amdgcn_readlane(mine, i);
         if (p >= 0) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
       }
+  }
   }
   if (ct.chunk_first[chunk]) {
 #pragma unroll
