@@ -242,6 +242,32 @@ def json_ingest_leg(pkg, dev, a, gang):
     return out
 
 
+def predicates_callback_leg(pm, P, N):
+    """The seam the core really calls — Predicates(ask, node) one pair at a time (scheduler_callback.go:203-205) — served from the
+    RESIDENT answer of a current evaluation (host mirror of the class rows): wall time per call through the ctypes
+    binding (≈ 1-2 us of it is Python), a random pair per call and the core's pattern of one ask tried on many nodes."""
+    pm.evaluate(decisions=True)
+    pm.synchronize()
+    rng = np.random.default_rng(3)
+    pods, nodes = rng.integers(0, P, 2200), rng.integers(0, N, 2200)
+    for i in range(200):  # (the first callback after an evaluation mirrors the class rows: outside the timed calls)
+        pm.predicates(int(pods[i]), int(nodes[i]), True)
+    t0 = time.perf_counter()
+    for i in range(200, 2200):
+        pm.predicates(int(pods[i]), int(nodes[i]), True)
+    random_us = (time.perf_counter() - t0) / 2000 * 1e6
+    t0 = time.perf_counter()
+    calls = 0
+    for pod in range(100, 110):
+        for node in range(0, N, max(N // 200, 1)):
+            pm.predicates(pod, node, True)
+            calls += 1
+    return {"resident_us_per_call_random_pair": round(random_us, 2),
+            "resident_us_per_call_one_ask_many_nodes": round((time.perf_counter() - t0) / calls * 1e6, 2),
+            "served": pm.resident_stats(),
+            "note": "Predicates() through the C ABI + ctypes after a current evaluation; a failing pair fetches its plugin code from the device"}
+
+
 def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
     """A fresh manager on the same GPU: generate, upload, then `steps` timed full passes. Used for `variants` / `end_to_end`."""
     workload = kwok.pop("_workload", None)
@@ -511,6 +537,12 @@ def main():
         gather["evals_per_sec_without_gather"] = float(P) * total_nodes / (no_gather_ms * 1e-3)
 
     cpu = cpu_baseline(pm, a.cpu_seconds, SEED) if rank == 0 else None
+    callbacks = None
+    if rank == 0 and world == 1 and not a.no_variants and not a.direct:
+        try:
+            callbacks = predicates_callback_leg(pm, P, N)
+        except Exception as exc:  # noqa: BLE001 — a side leg never takes the line down
+            callbacks = {"error": str(exc)}
     stats = pm.stats()
     if use_abi:
         pm.comm_destroy()
@@ -587,6 +619,8 @@ def main():
             out["variants"] = variants
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
+        if callbacks is not None:
+            out["predicates_callback"] = callbacks
         print(json.dumps(out))
     if dist:
         dist.barrier()

@@ -1801,7 +1801,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (!e->zone_b_first) TRY(launch_zone_a());
     tm.begin(sz);
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
-    const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0));
+    // (the slice writer keeps the mask tables of <= 128 words per walked dimension in LDS: only where the device grants that much)
+    const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0)) &&
+                        (size_t)pc.n_big * ykk::kSliceMaxWords * 65 * sizeof(u64) <= (size_t)e->max_lds_bytes;
     if (slices) {
       // index rows to decode: a workgroup per slice (<= 128 words) of the row, mask tables in LDS (see k_combine_slices); the
       // chunk descriptors are resolved first, one thread per chunk
