@@ -150,9 +150,11 @@ struct ykpred_engine {
   int walk_rows = 256;  // tunable: cfg.reserved[4]
   int wave_combine_below = 16;  // tunable: cfg.reserved[5] — average members per chunk below which k_combine_wave is used
   int n_big = 0, walk_chunks = 0, index_rows = 0;
+  int NCB = 0;                      // zone-B chunks (d_chunk_list_b)
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
   DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
   bool decide_skip = true;  // YKPRED_DECIDE_SKIP=0: scan every class from the first position
+  DevBuf d_chunk_list_b;    // [NCB] numbers of the zone-B chunks (ascending)
   DevBuf d_slice_general;   // one int: chunks of the pass that k_combine_slices leaves to k_combine_wave
   DevBuf d_slice_desc;      // [NC] chunk descriptors of k_combine_slices (k_slice_desc, refilled per pass)
   DevBuf d_pfx_r;           // [n_big][row_words] running maximum of the free values along the bin-pack order (k_dim_prefix_max)
@@ -186,6 +188,7 @@ struct ykpred_engine {
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
   int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
+  int beside_small = 1;             // YKPRED_BESIDE_SMALL=0: a SMALL zone B (< 1/16 of the rows) is written after the band writer, not beside it
   int wave_rows = 0;                // YKPRED_WAVE_ROWS=1: k_combine_wave writes member rows one after the other (class row in registers)
   int slice_pairs = 0;              // YKPRED_SLICE_PAIRS=1: one word pair per lane even with a single walked dimension
   int slice_mode = 0;               // YKPRED_SLICE_MODE: experiments of k_combine_slices (bit 0 = no stores: WRONG bitmap, timing only)
@@ -632,6 +635,11 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     ch_first.push_back(k.first);
     e->h_ch_zone.push_back(e->h_class_slot_a[(size_t)k.cls] >= 0 ? 1 : 0);
   }
+  // the zone-B chunks by number: the full pass launches the class-by-class writer over this list only
+  std::vector<int32_t> chunk_list_b;
+  for (size_t k = 0; k < e->h_ch_zone.size(); ++k)
+    if (!e->h_ch_zone[k]) chunk_list_b.push_back((int32_t)k);
+  e->NCB = (int)chunk_list_b.size();
   e->h_class_first.assign((size_t)C, -1);
   for (int c = 0; c < C; ++c) e->h_class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
   std::vector<int32_t> member_rows((size_t)P);
@@ -647,6 +655,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   TRY(upload(e, e->d_members, member_rows.data(), member_rows.size(), st));
   TRY(upload(e, e->d_pod_row, e->h_pod_row.data(), e->h_pod_row.size(), st));
   TRY(upload(e, e->d_chunk_zone, e->h_ch_zone.data(), e->h_ch_zone.size(), st));
+  TRY(upload(e, e->d_chunk_list_b, chunk_list_b.data(), chunk_list_b.size(), st));
   TRY(upload(e, e->d_band_tab, band_tab.data(), band_tab.size(), st));
   TRY(upload(e, e->d_class_list_a, class_list_a.data(), class_list_a.size(), st));
   TRY(upload(e, e->d_class_slot_a, e->h_class_slot_a.data(), e->h_class_slot_a.size(), st));
@@ -995,6 +1004,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (const char* v = getenv("YKPRED_SLICE_CHUNKS")) e->slice_chunks_per_wave = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_MODE")) e->slice_mode = atoi(v);
   if (const char* v = getenv("YKPRED_WAVE_ROWS")) e->wave_rows = atoi(v);
+  if (const char* v = getenv("YKPRED_BESIDE_SMALL")) e->beside_small = atoi(v);
   if (const char* v = getenv("YKPRED_SLICE_PAIRS")) e->slice_pairs = atoi(v);
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -1042,7 +1052,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1760,15 +1770,22 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     int tpg = ykk::kBlock;
     while (tpg > ykk::kWave && (tpg / 2) * wpl >= e->row_stride) tpg /= 2;
     const int seg = tpg * ykk::kCombineUnroll * wpl;
-    dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
-    // The class-by-class writer (zone B, rows disjoint from the band rows) runs BESIDE the band writer on its own stream:
-    // both only need the planes. Its chunks of zone-A classes return at once, so with nothing in zone B it is a no-op beside.
-    const bool beside = e->combine_beside && e->zb_stream && !dirty_only && e->n_classes_a > 0 && e->NC > 0;
+    // the full pass runs the class-by-class writer over the zone-B chunks only (the dirty-class pass over every chunk)
+    // (chunks appended by ykpred_update_pods since the class build are not in the list: then every chunk runs, as the dirty pass does)
+    const bool listed = !dirty_only && e->patch_chunks == 0;
+    const int* chunk_list = listed ? e->d_chunk_list_b.as<int>() : nullptr;
+    const int n_run = listed ? e->NCB : e->NC;
+    dim3 grid((unsigned)std::max(n_run, 1), (unsigned)((e->row_stride + seg - 1) / seg));
+    // The class-by-class writer (zone B, rows disjoint from the band rows) can run BESIDE the band writer on its own stream:
+    // both only need the planes. Measured (profiles/r03_writer_knobs.txt): with a LARGE zone B that costs the band writer more
+    // than it saves; a small one (a handful of workgroups, e.g. the 241 rows of configs[2]) hides under the band writer.
+    const bool small_b = e->beside_small && !dirty_only && (int64_t)(e->rows_total - e->rows_a) * 16 <= (int64_t)e->rows_total;
+    const bool beside = (e->combine_beside || small_b) && e->zb_stream && !dirty_only && e->n_classes_a > 0 && n_run > 0;
     hipStream_t sz = beside ? e->zb_stream : st;
     auto launch = [&](auto kern) {
       // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
       hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, sz, ct, pc, bitmap, e->row_words, e->row_stride,
-                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty);
+                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty, chunk_list);
     };
     if (beside) {
       HIPCHK(hipEventRecord(e->ev_zb_fork, st));  // planes and the zeroed class counts are ready here
@@ -1825,17 +1842,19 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       // chunks the slice writer has no fast path for (several member rows, pins to unknown nodes, other row shapes): wave per chunk
       hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,
-                         e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
+                         e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>(), (const int*)nullptr);
+    } else if (n_run == 0) {
+      // (no chunk outside the band layout: nothing to launch)
     } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
       // narrow enough rows: the class row in registers, member rows written one after the other (k_combine_wave<true>)
-      const dim3 wgrid((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
+      const dim3 wgrid((unsigned)((std::max(n_run, 1) + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
       if (e->wave_rows && e->row_stride <= ykk::kWaveRowPieces * 2 * ykk::kWave)
         hipLaunchKernelGGL(ykk::k_combine_wave<true>, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                           e->d_class_count.as<int>(), e->NC, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr);
+                           e->d_class_count.as<int>(), n_run, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr, chunk_list);
       else
         hipLaunchKernelGGL(ykk::k_combine_wave<false>, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                           e->d_class_count.as<int>(), e->NC, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr);
+                           e->d_class_count.as<int>(), n_run, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr, chunk_list);
     } else {
       switch (variant) {
         case 0: launch(ykk::k_combine<2, false>); break;
@@ -2870,14 +2889,14 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   if ((long)e->NC * e->wave_combine_below > (long)P) {
     hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
                        out, e->row_stride, e->row_stride, 0, e->d_expand_count.as<int>(), e->NC, (const int*)nullptr, (const ykk::SliceDesc*)nullptr,
-                       (const int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr);
   } else {
     int tpg = ykk::kBlock;
     while (tpg > ykk::kWave && (tpg / 2) * 2 >= e->row_stride) tpg /= 2;
     const int seg = tpg * ykk::kCombineUnroll * 2;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
     hipLaunchKernelGGL((ykk::k_combine<2, false>), grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pl, out, e->row_stride, e->row_stride, 0,
-                       e->d_expand_count.as<int>(), tpg, (const int*)nullptr);
+                       e->d_expand_count.as<int>(), tpg, (const int*)nullptr, (const int*)nullptr);
   }
   HIPCHK(hipGetLastError());
   return YKPRED_OK;

@@ -1051,11 +1051,13 @@ __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
 template <int WPL, bool NT>
 __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                     int pin_enabled, int* __restrict__ class_count, int tpg,
-                                                    const int* __restrict__ class_dirty /* null = every class */) {
+                                                    const int* __restrict__ class_dirty /* null = every class */,
+                                                    const int* __restrict__ chunk_list /* null: grid.x = every chunk; else the chunks
+                                                    to run (the full pass lists the zone-B chunks: no workgroup for the others) */) {
   // pin_enabled bit 0: NodeName filter on; bit 1: a Filter has no PreFilter state ⇒ every pair fails
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
-  const int chunk = blockIdx.x;
+  const int chunk = chunk_list ? chunk_list[blockIdx.x] : (int)blockIdx.x;
   const int cls = ct.chunk_class[chunk];
   if (class_dirty ? !class_dirty[cls] : ct.chunk_zone[chunk] != 0) return;  // full pass: zone B only; incremental pass: the dirty classes
   const int begin = ct.chunk_begin[chunk];
@@ -1133,12 +1135,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                                                          const int* __restrict__ class_dirty /* null = every class */,
                                                          const SliceDesc* __restrict__ only_general /* non-null: only the chunks whose
                                                          descriptor says `general` (the rest belongs to k_combine_slices) */,
-                                                         const int* __restrict__ n_general /* with only_general: their number */) {
+                                                         const int* __restrict__ n_general /* with only_general: their number */,
+                                                         const int* __restrict__ chunk_list /* null: n_chunks = every chunk; else the
+                                                         n_chunks chunks to run */) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
-  const int chunk = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  if (chunk >= n_chunks) return;
+  const int slot = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (slot >= n_chunks) return;
+  const int chunk = chunk_list ? chunk_list[slot] : slot;
   if (only_general && (*n_general == 0 || !slice_desc_general(only_general, chunk))) return;
   const int lane = threadIdx.x % kWave;
   const int cls = ct.chunk_class[chunk];
