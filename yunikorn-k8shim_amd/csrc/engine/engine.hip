@@ -188,7 +188,8 @@ struct ykpred_engine {
   bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
   int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
-  int beside_small = 1;             // YKPRED_BESIDE_SMALL=0: a SMALL zone B (< 1/16 of the rows) is written after the band writer, not beside it
+  int beside_small = 0;             // YKPRED_BESIDE_SMALL=1: a SMALL zone B (< 1/16 of the rows) is written beside the band writer (measured: the
+                                    // third stream's fork / join costs the step 0.25 ms — 1.24 -> 1.50 ms on configs[2]; off)
   int wave_rows = 0;                // YKPRED_WAVE_ROWS=1: k_combine_wave writes member rows one after the other (class row in registers)
   int slice_pairs = 0;              // YKPRED_SLICE_PAIRS=1: one word pair per lane even with a single walked dimension
   int slice_mode = 0;               // YKPRED_SLICE_MODE: experiments of k_combine_slices (bit 0 = no stores: WRONG bitmap, timing only)
@@ -1778,7 +1779,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     dim3 grid((unsigned)std::max(n_run, 1), (unsigned)((e->row_stride + seg - 1) / seg));
     // The class-by-class writer (zone B, rows disjoint from the band rows) can run BESIDE the band writer on its own stream:
     // both only need the planes. Measured (profiles/r03_writer_knobs.txt): with a LARGE zone B that costs the band writer more
-    // than it saves; a small one (a handful of workgroups, e.g. the 241 rows of configs[2]) hides under the band writer.
+    // than it saves; a small one (a handful of workgroups, e.g. the 241 rows of configs[2]) would hide under the band writer,
+    // but the fork / join of the third stream costs more than the 18 us it hides (session 16): opt-in.
     const bool small_b = e->beside_small && !dirty_only && (int64_t)(e->rows_total - e->rows_a) * 16 <= (int64_t)e->rows_total;
     const bool beside = (e->combine_beside || small_b) && e->zb_stream && !dirty_only && e->n_classes_a > 0 && n_run > 0;
     hipStream_t sz = beside ? e->zb_stream : st;
