@@ -240,6 +240,18 @@ def test_request_value_planes_sorted_walk(monkeypatch, seed, walk_rows):
             m.close()
 
 
+def test_pending_pod_in_the_middle_of_a_resize_on_the_device(pm):
+    """Divergence ledger 1: NodeResourcesFit sees yunikorn's GetPodResource — max(spec, allocatedResources,
+    actual requests), or the status requests alone when the resize is infeasible — for a pending pod mid-resize."""
+    import test_host_encoder as enc
+    snap, want = enc._resize_snapshot()
+    pm.load_snapshot(snap)
+    check_against_oracle(pm, snap, True)
+    bits = unpack(pm.read_bitmap(), 3)
+    for p, pod in enumerate(snap["pods"]):
+        assert bits[p].tolist() == want[pod["metadata"]["name"]]
+
+
 @pytest.mark.parametrize("wpl", [1, 2, 4])
 @pytest.mark.parametrize("n_nodes", [63, 200, 4100])
 def test_sig_planes_words_per_lane(monkeypatch, wpl, n_nodes):

@@ -259,3 +259,38 @@ def test_match_label_keys_are_folded_into_the_selector(mirror):
     assert mirror.ask_supported(0) == (True, "")
     dumped = json.loads(mirror.dump_snapshot())["pods"][0]["spec"]["topologySpreadConstraints"][0]
     assert dumped["matchLabelKeys"] == ["pod-template-hash", "absent-key"] and dumped["labelSelector"]["matchExpressions"] == []
+
+
+def _resize_snapshot():
+    """Three nodes with 1, 2 and 4 free cpus; pending pods in the middle of an in-place resize (KEP-1287): the request the Filter
+    sees is yunikorn's GetPodResource (`pkg/common/resource.go:56-142`), for the ask size AND for NodeResourcesFit (DESIGN.md §2,
+    divergence ledger 1)."""
+    def node(i, cpu):
+        return {"metadata": {"name": f"n{i}"}, "status": {"allocatable": {"cpu": str(cpu), "memory": "64Gi", "pods": "110"}}}
+
+    def pod(name, spec_cpu, status):
+        return {"metadata": {"name": name, "uid": name, "namespace": "default"},
+                "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": spec_cpu, "memory": "1Gi"}}}]},
+                "status": dict({"phase": "Pending"}, **status)}
+    cs = lambda alloc=None, req=None: {"containerStatuses": [dict({"name": "c"}, **({"allocatedResources": alloc} if alloc else {}),
+                                                                  **({"resources": {"requests": req}} if req else {}))]}
+    pods = [pod("plain", "2", {}),
+            # growing 1 -> 3: allocatedResources already carries the new size; max(spec, allocated, actual) = 3 cpus
+            pod("growing", "1", dict(cs(alloc={"cpu": "3"}, req={"cpu": "1"}), resize="InProgress")),
+            # shrinking 3 -> 1 not yet actuated: the container still holds 3
+            pod("shrinking", "1", dict(cs(alloc={"cpu": "1"}, req={"cpu": "3"}), resize="InProgress")),
+            # an INFEASIBLE resize to 4: the status requests (1 cpu) stand
+            pod("infeasible", "4", dict(cs(alloc={"cpu": "1"}, req={"cpu": "1"}), resize="Infeasible"))]
+    want = {"plain": [0, 1, 1], "growing": [0, 0, 1], "shrinking": [0, 0, 1], "infeasible": [1, 1, 1]}
+    return {"nodes": [node(0, 1), node(1, 2), node(2, 4)], "pods": pods}, want
+
+
+def test_pending_pod_in_the_middle_of_a_resize(mirror):
+    snap, want = _resize_snapshot()
+    mirror.load_snapshot(snap)
+    t = mirror.encoded_tables()
+    o = orc.Oracle(snap)
+    grid = o.eval_grid(threads=1)
+    for p, pod in enumerate(snap["pods"]):
+        got = [soa.eval_pair(t, p, n, orc.ALL, orc.ALL)[0] for n in range(3)]
+        assert got == want[pod["metadata"]["name"]] == grid[p].tolist(), pod["metadata"]["name"]
