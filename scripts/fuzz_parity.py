@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU vs oracle) beyond the seeds baked into tests/: full grid, both phases, fit bits,
-failing plugin, counts; every feature of tests/_gen.py switched on. Usage: python scripts/fuzz_parity.py [first] [count]"""
+failing plugin, counts, decisions; every feature of tests/_gen.py switched on. Engine tunables come from the environment
+(YKPRED_WALK_ROWS=1 turns every request dimension with a value into index rows: sorted walk, slice writer, prefix-max start of
+the decision scan). Usage: python scripts/fuzz_parity.py [first] [count]"""
 import importlib
 import os
 import sys
@@ -36,6 +38,9 @@ for seed in range(first, first + count):
             fit, code, _ = pm.query(pods.astype(np.int32), nodes.astype(np.int32), pre_mask=pre, filt_mask=filt)
             ok = (np.array_equal(got, want) and np.array_equal(pm.read_counts(), want.sum(axis=1)) and
                   np.array_equal(fit.reshape(P, N), want) and not ((code.reshape(P, N) != wplug) & (want == 0)).any())
+            if ok:  # decisions: (feasible count, first feasible node in bin-pack order) of every 5th ask
+                dec = pm.read_decisions()
+                ok = all(o.decide(p, pre, filt) == (int(want[p].sum()), int(dec[p])) for p in range(0, P, 5))
             if not ok:
                 bad += 1
                 print(f"MISMATCH seed={seed} allocate={allocate} nodes={n_nodes} pods={n_pods}", flush=True)
