@@ -1836,11 +1836,18 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       HIPCHK(hipMemsetAsync(e->d_slice_general.p, 0, sizeof(int), sz));
       hipLaunchKernelGGL(ykk::k_slice_desc, dim3((unsigned)((e->NC + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, sz, ct, pc, e->NC, class_dirty,
                          pin_on, e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
-      if (lds > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(ykk::k_combine_slices, dim3((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices)), dim3(ykk::kSliceBlock), lds, sz,
-                         pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices,
-                         slice_words, per_wave, e->slice_mode);
+      const dim3 sgrid((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices));
+      if (pin_on & 1) {  // (the NodeName filter is a template parameter: without it the fast path carries no pin code at all)
+        if (lds > 64 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ykk::k_combine_slices<true>, sgrid, dim3(ykk::kSliceBlock), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap,
+                           e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices, slice_words, per_wave, e->slice_mode);
+      } else {
+        if (lds > 64 * 1024)
+          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(ykk::k_combine_slices<false>, sgrid, dim3(ykk::kSliceBlock), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap,
+                           e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices, slice_words, per_wave, e->slice_mode);
+      }
       // chunks the slice writer has no fast path for (several member rows, pins to unknown nodes, other row shapes): wave per chunk
       hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,

@@ -1302,8 +1302,9 @@ __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl,
           ++np;
         }
       }
-    // the general path: several member rows, an unknown pinned node, or a shape the fast path has no code for
-    if (len != 1 || d.pin == -2 || np > 2 || ni != 1) d.meta |= kSliceGeneral;
+    // the general path: several member rows, the tail chunk of a longer class (it adds no count), a freed member slot, an
+    // unknown pinned node, or a shape the fast path has no code for — so the fast path needs no test for any of them
+    if (len != 1 || !(d.meta & kSliceFirst) || d.mem0 < 0 || d.pin == -2 || np > 2 || ni != 1) d.meta |= kSliceGeneral;
     if (np >= 2) d.meta |= kSlicePlane;
     if (d.meta & kSliceGeneral) atomicAdd(n_general, 1);
   }
@@ -1323,13 +1324,14 @@ struct SliceBuf {
   u64x2_t v[kSliceBatch];
   unsigned short two[kSliceBatch];  // (kept 16 bits wide: a widening right after the load would wait for it)
 };
-// loads of one batch: chunks i0 .. i0 + n - 1 of the wave's window, NP = they carry a per-chunk plane row
-template <int NP>
+// loads of one batch: chunks i0 .. i0 + n - 1 of the wave's window, NP = they carry a per-chunk plane row; FULL = n is the batch
+// size (no guard per slot: most batches are full, and 18 scalar branches per chunk were a fifth of the kernel's instructions)
+template <int NP, bool FULL>
 __device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, int prow_l, int irow_l, SliceBuf& buf) {
   const Planes& pl = *cx.pl;
 #pragma unroll
   for (int j = 0; j < kSliceBatch; ++j) {
-    if (j < n) {
+    if (FULL || j < n) {
       const int c = i0 + j;
       if (NP) buf.v[j] = *(const u64x2_t*)(pl.res + (size_t)__builtin_amdgcn_readlane(prow_l, c) * pl.stride + cx.wq);
       const int rid = __builtin_amdgcn_readlane(irow_l, c) & ((1 << kRowBigShift) - 1);
@@ -1337,29 +1339,26 @@ __device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, i
     }
   }
 }
-// masks, feasible counts and stores of a batch whose loads were issued by slice_issue<NP>. Two passes — every mask first, then
-// the counts and stores: the first pass touches every loaded register, so the compiler waits ONCE for the batch's loads; with
-// decode and store interleaved per chunk it put a full `s_waitcnt vmcnt(0)` in front of every chunk (the guards make its
-// counting conservative), i.e. every chunk waited for the previous chunk's store to land.
-template <int NP>
-__device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, u64x2_t w_base, int cls_l, int meta_l, int pin_l, int mem0_l,
-                                             int irow_l, SliceBuf& buf) {
+// masks, feasible counts and stores of a batch whose loads were issued by slice_issue<NP, FULL>. Two passes — every mask first,
+// then the counts and stores: the first pass touches every loaded register, so the compiler waits ONCE for the batch's loads;
+// with decode and store interleaved per chunk it put a full `s_waitcnt vmcnt(0)` in front of every chunk (the guards make its
+// counting conservative), i.e. every chunk waited for the previous chunk's store to land. Every chunk here is a single-row
+// first chunk with a live member (k_slice_desc sends the others the general way): no test for any of that.
+template <int NP, bool FULL, bool PIN>
+__device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, u64x2_t w_base, int cls_l, int pin_l, int mem0_l, int irow_l,
+                                             SliceBuf& buf) {
 #pragma unroll
   for (int j = 0; j < kSliceBatch; ++j) {
-    if (j < n) {
+    if (FULL || j < n) {
       const int c = i0 + j;
       u64x2_t x = w_base;
       if (NP) x &= buf.v[j];
       const int big = (__builtin_amdgcn_readlane(irow_l, c) >> kRowBigShift) - 1;
       const u64* tab = cx.s_pm + big * cx.tab_stride + (2 * cx.lane) * 65;
       const unsigned two = buf.two[j];
-      if (cx.mode & 8) {  // (experiment: no LDS decode)
-        x.x &= two;
-      } else {
-        x.x &= tab[two & 0xffu];
-        x.y &= tab[65 + (two >> 8)];
-      }
-      if (cx.pin_enabled) {
+      x.x &= tab[two & 0xffu];
+      x.y &= tab[65 + (two >> 8)];
+      if (PIN) {
         const int pin = __builtin_amdgcn_readlane(pin_l, c);
         if (pin >= 0) {
           x.x &= (cx.wq == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
@@ -1371,25 +1370,23 @@ __device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, 
   }
 #pragma unroll
   for (int j = 0; j < kSliceBatch; ++j) {
-    if (j < n) {
+    if (FULL || j < n) {
       const int c = i0 + j;
       const u64x2_t x = buf.v[j];
-      if (__builtin_amdgcn_readlane(meta_l, c) & kSliceFirst) {
-        const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (idle lanes and padding words hold zeros: `keep`)
-        if (cx.lane == 63 && pc && !(cx.mode & 4)) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
-      }
-      const int p = __builtin_amdgcn_readlane(mem0_l, c);
-      if (p >= 0 && cx.st_ok) *(u64x2_t*)(cx.bitmap + (size_t)p * cx.row_stride + cx.wq) = x;
+      const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (idle lanes and padding words hold zeros: `keep`)
+      if (cx.lane == 63 && pc) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
+      if (cx.st_ok) *(u64x2_t*)(cx.bitmap + (size_t)__builtin_amdgcn_readlane(mem0_l, c) * cx.row_stride + cx.wq) = x;
     }
   }
 }
 
 // grid.x = chunk batches x n_slices (consecutive workgroups take consecutive slices of the same chunks); dynamic LDS =
 // n_big * slice_words * 520 bytes. slice_words is even; lane l owns the word pair slice * slice_words + 2 l while 2 l < slice_words.
+template <bool PIN>
 __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
     Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled,
     int* __restrict__ class_count, int n_chunks, int n_slices, int slice_words, int chunks_per_wave,
-    int mode /* experiments, timing only: 1 = no stores, 4 = no count atomics, 8 = no LDS decode, 16 = cached rows never reloaded */) {
+    int mode /* experiments, timing only: 1 = no stores, 16 = cached rows never reloaded */) {
   typedef u64x2_t u64x2;
   extern __shared__ u64 s_pm[];  // [n_big][slice_words][65]
   const bool all_fail = pin_enabled & 2;
@@ -1456,15 +1453,20 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
         if (pl.spread && ss >= 0) t_spread = *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + cx.wq);
         if (pl.res && p0 >= 0) t_p0 = *(const u64x2*)(pl.res + (size_t)p0 * pl.stride + cx.wq);
       }
-      if (meta0 & kSlicePlane)
-        slice_issue<1>(cx, i0, n, prow_l, irow_l, buf);
-      else
-        slice_issue<0>(cx, i0, n, prow_l, irow_l, buf);
+      const bool full = n == kSliceBatch;
+      if (meta0 & kSlicePlane) {
+        if (full) slice_issue<1, true>(cx, i0, n, prow_l, irow_l, buf); else slice_issue<1, false>(cx, i0, n, prow_l, irow_l, buf);
+      } else {
+        if (full) slice_issue<0, true>(cx, i0, n, prow_l, irow_l, buf); else slice_issue<0, false>(cx, i0, n, prow_l, irow_l, buf);
+      }
       if (changed) w_base = all_fail ? u64x2{0, 0} : (keep & t_tol & t_aff & t_spread & t_p0);
-      if (meta0 & kSlicePlane)
-        slice_finish<1>(cx, i0, n, w_base, cls_l, meta_l, pin_l, mem0_l, irow_l, buf);
-      else
-        slice_finish<0>(cx, i0, n, w_base, cls_l, meta_l, pin_l, mem0_l, irow_l, buf);
+      if (meta0 & kSlicePlane) {
+        if (full) slice_finish<1, true, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
+        else slice_finish<1, false, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
+      } else {
+        if (full) slice_finish<0, true, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
+        else slice_finish<0, false, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
+      }
     }
   }
 }
