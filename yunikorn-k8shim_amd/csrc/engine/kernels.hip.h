@@ -1250,7 +1250,7 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // wave cycles parked in s_waitcnt, 72 VALU + 69 SALU instructions per KiB: three serialised memory round trips per batch.
 constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
-constexpr int kSliceBatch = 8;      // chunks whose loads are in flight together (16-wave workgroups with 64 VGPRs and batches of 4 spill in the hot loop)
+constexpr int kSliceBatch = 6;      // chunks whose loads are in flight together (8 spill a lane offset to scratch: every reload is a vmcnt(0))
 constexpr int kSliceMaxWords = 128;
 typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
 
@@ -1311,6 +1311,17 @@ __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl,
   out[chunk] = d;
 }
 
+// a load / store at (wave-uniform base) + (32-bit lane offset in bytes): written so that the compiler keeps the base in SGPRs and
+// uses the saddr form of global_load / global_store — with 64-bit VGPR addresses the kernel spilled its base pointers to scratch,
+// and every reload waits on vmcnt(0), i.e. on every load and store issued before it
+template <typename T>
+__device__ __forceinline__ T ld_sv(const void* base, unsigned voff) {
+  return *(const T*)((const char*)base + voff);
+}
+template <typename T>
+__device__ __forceinline__ void st_sv(void* base, unsigned voff, T v) {
+  *(T*)((char*)base + voff) = v;
+}
 struct SliceCtx {
   const Planes* pl;
   u64* bitmap;
@@ -1319,6 +1330,7 @@ struct SliceCtx {
   int row_stride, tab_stride, lane, pin_enabled, mode;
   int wq;        // this lane's word pair (0 when the pair lies outside the row: loads stay valid, nothing is stored)
   bool st_ok;    // the pair is stored
+  unsigned voff, ioff;  // byte offset of the pair inside a plane / bitmap row (8 wq) and inside an index row (wq)
 };
 struct SliceBuf {
   u64x2_t v[kSliceBatch];
@@ -1333,9 +1345,9 @@ __device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, i
   for (int j = 0; j < kSliceBatch; ++j) {
     if (FULL || j < n) {
       const int c = i0 + j;
-      if (NP) buf.v[j] = *(const u64x2_t*)(pl.res + (size_t)__builtin_amdgcn_readlane(prow_l, c) * pl.stride + cx.wq);
+      if (NP) buf.v[j] = ld_sv<u64x2_t>(pl.res + (size_t)__builtin_amdgcn_readlane(prow_l, c) * pl.stride, cx.voff);
       const int rid = __builtin_amdgcn_readlane(irow_l, c) & ((1 << kRowBigShift) - 1);
-      buf.two[j] = *(const unsigned short*)(pl.res_idx + (size_t)rid * pl.idx_stride + cx.wq);  // index bytes of the pair
+      buf.two[j] = ld_sv<unsigned short>(pl.res_idx + (size_t)rid * pl.idx_stride, cx.ioff);  // index bytes of the pair
     }
   }
 }
@@ -1375,7 +1387,7 @@ __device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, 
       const u64x2_t x = buf.v[j];
       const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (idle lanes and padding words hold zeros: `keep`)
       if (cx.lane == 63 && pc) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
-      if (cx.st_ok) *(u64x2_t*)(cx.bitmap + (size_t)__builtin_amdgcn_readlane(mem0_l, c) * cx.row_stride + cx.wq) = x;
+      if (cx.st_ok) st_sv<u64x2_t>(cx.bitmap + (size_t)__builtin_amdgcn_readlane(mem0_l, c) * cx.row_stride, cx.voff, x);
     }
   }
 }
@@ -1408,7 +1420,9 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
   const int w_true = slice * slice_words + 2 * lane;
   const bool in_row = 2 * lane < slice_words && w_true < row_stride;
   const u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};  // padding stays zero
-  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, lane, pin_enabled, mode, in_row ? w_true : 0, in_row && !(mode & 1)};
+  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, lane, pin_enabled, mode, in_row ? w_true : 0, in_row && !(mode & 1), 0u, 0u};
+  cx.voff = (unsigned)cx.wq * 8u;
+  cx.ioff = (unsigned)cx.wq;
   // AND of the cached rows' words of the current key (wave-uniform; -3 = nothing cached)
   int cur_st = -3, cur_sa = -3, cur_ss = -3, cur_p0 = -3;
   u64x2 w_base = keep;
@@ -1448,17 +1462,21 @@ __global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 
       u64x2 t_tol = keep, t_aff = keep, t_spread = keep, t_p0 = keep;
       if (changed) {
         cur_st = st, cur_sa = sa, cur_ss = ss, cur_p0 = p0;
-        if (pl.tol && st >= 0) t_tol = *(const u64x2*)(pl.tol + (size_t)st * pl.stride + cx.wq);
-        if (pl.aff && sa >= 0) t_aff = *(const u64x2*)(pl.aff + (size_t)sa * pl.stride + cx.wq);
-        if (pl.spread && ss >= 0) t_spread = *(const u64x2*)(pl.spread + (size_t)ss * pl.stride + cx.wq);
-        if (pl.res && p0 >= 0) t_p0 = *(const u64x2*)(pl.res + (size_t)p0 * pl.stride + cx.wq);
+        if (pl.tol && st >= 0) t_tol = ld_sv<u64x2>(pl.tol + (size_t)st * pl.stride, cx.voff);
+        if (pl.aff && sa >= 0) t_aff = ld_sv<u64x2>(pl.aff + (size_t)sa * pl.stride, cx.voff);
+        if (pl.spread && ss >= 0) t_spread = ld_sv<u64x2>(pl.spread + (size_t)ss * pl.stride, cx.voff);
+        if (pl.res && p0 >= 0) t_p0 = ld_sv<u64x2>(pl.res + (size_t)p0 * pl.stride, cx.voff);
       }
       const bool full = n == kSliceBatch;
+      // (scheduling fences: without them the compiler folds the cached rows' words BEFORE the batch's loads are issued — it frees
+      // 16 registers that way — and the kernel pays a second memory round trip per batch; session 19)
+      __builtin_amdgcn_sched_barrier(0);
       if (meta0 & kSlicePlane) {
         if (full) slice_issue<1, true>(cx, i0, n, prow_l, irow_l, buf); else slice_issue<1, false>(cx, i0, n, prow_l, irow_l, buf);
       } else {
         if (full) slice_issue<0, true>(cx, i0, n, prow_l, irow_l, buf); else slice_issue<0, false>(cx, i0, n, prow_l, irow_l, buf);
       }
+      __builtin_amdgcn_sched_barrier(0);
       if (changed) w_base = all_fail ? u64x2{0, 0} : (keep & t_tol & t_aff & t_spread & t_p0);
       if (meta0 & kSlicePlane) {
         if (full) slice_finish<1, true, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
