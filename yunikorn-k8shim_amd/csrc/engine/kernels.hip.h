@@ -1237,17 +1237,18 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
 // Here a workgroup owns ONE slice of `slice_words` (<= 128) words of the row for a long run of chunks:
 //   * the mask tables of the slice (520 bytes per word and walked dimension) sit in LDS — the decode is a ds_read_b64, and
 //     global memory only sees coalesced streams (index bytes, plane words, row pieces of <= 1 KiB: lane = a pair of words);
-//   * the per-chunk table walk (chunk → class → signatures → plane rows) is done by the LANES for 64 chunks at once and
-//     broadcast with v_readlane — no chain of dependent scalar loads per chunk;
+//   * what a wave has to know about a chunk (class, member row, signature rows, request-value rows) is resolved once per pass
+//     by one thread per chunk (k_slice_desc) and read coalesced: lane j holds the descriptor of chunk c0 + j, broadcast with
+//     v_readlane — no chain of dependent scalar loads per chunk, no table walk repeated per slice;
 //   * zone-B chunks come in signature order (aff, tol, spread, request vector: build_classes), so the toleration / affinity /
-//     spread words of a lane are kept in registers and reloaded only when the signature changes;
-//   * single-row chunks of one signature triple and one SHAPE (number of plane rows, number of index rows) are served in
-//     batches of kSliceBatch by straight-line code specialised for the shape, software-pipelined over two register buffers: the
-//     loads of batch b + 1 (and the signature words, if they change) are issued BEFORE batch b is decoded and stored, so a
-//     wave never sits in front of an empty memory queue and never waits for its own stores.
-// History (profiles/r03_session7…12_*.txt): one word per lane and every row pointer rebuilt per (chunk, slice) 9.3 ms; two words
-// per lane with cached signature words 4.6 ms; batches of 8 (loads, one wait, stores) 3.4 ms alone — SQ counters: 76 % of the
-// wave cycles parked in s_waitcnt, 72 VALU + 69 SALU instructions per KiB: three serialised memory round trips per batch.
+//     spread words and the pod-independent request row of a lane are kept in registers (w_base) and reloaded only when they
+//     change — their loads go out together with the batch's loads, one wait serves both;
+//   * single-row chunks of one such key are served in batches of kSliceBatch: every load, one wait, every mask, then the
+//     counts and the stores (slice_issue / slice_finish); every other chunk is left to k_combine_wave (descriptor filter).
+// History (profiles/r03_sessions7_20_small_class_paths.txt): one word per lane and every row pointer rebuilt per (chunk, slice)
+// 9.3 ms; two words per lane with cached signature words 4.6 ms; batches of 8 3.4 ms alone; chunk descriptors 3.4 ms; 28 % fewer
+// instructions 3.4 ms; no scratch + one wait per batch 3.15 ms. SQ counters: 76 % of the wave cycles in s_waitcnt at two 8-wave
+// workgroups per CU, no back-pressure anywhere in the memory path — the kernel is bound by latency at low occupancy.
 constexpr int kSliceWaves = 8;
 constexpr int kSliceBlock = kSliceWaves * kWave;
 constexpr int kSliceBatch = 6;      // chunks whose loads are in flight together (8 spill a lane offset to scratch: every reload is a vmcnt(0))
