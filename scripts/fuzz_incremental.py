@@ -65,6 +65,8 @@ for seed in range(first, first + count):
     snap = _gen.random_snapshot(seed, n_nodes=rng.randint(3, 200), n_pods=rng.randint(2, 60), scalars=bool(seed % 2), spread=topo, interpod=topo)
     extra = _gen.random_snapshot(seed + 10**6, n_nodes=4, n_pods=12, scalars=bool(seed % 2), spread=topo, interpod=topo)["pods"]
     try:
+        if os.environ.get("FUZZ_TRACE"):
+            print(f"seed {seed} load + full evaluation ({len(snap['nodes'])} nodes, {len(snap['pods'])} pods)", flush=True)
         pm.load_snapshot(snap)
         pm.evaluate()
         node_objs = {n["metadata"]["name"]: {k: v for k, v in n.items() if k != "pods"} for n in snap["nodes"] if n["metadata"]["name"]}
@@ -137,6 +139,8 @@ for seed in range(first, first + count):
             else:
                 continue
             dec = bool(rng.getrandbits(1))
+            if os.environ.get("FUZZ_TRACE"):
+                print(f"seed {seed} step {step} {op} decisions={dec}", flush=True)
             pm.evaluate_dirty(decisions=dec)
             if not check(f"seed={seed} step={step} op={op}", dec):
                 ok = False
