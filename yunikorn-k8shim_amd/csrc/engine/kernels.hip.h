@@ -1029,7 +1029,7 @@ __device__ __forceinline__ u64 class_idx_word(const ClassRows& cr, int w) {
   u64 v = ~0ull;
 #pragma unroll
   for (int i = 0; i < kMaxIdxRows; ++i)
-    if (i < cr.ni) v &= cr.ipm[i][(size_t)w * 65 + cr.irow[i][w]];
+    if (i < cr.ni) v &= cr.ipm[i][(size_t)w * 65 + min((int)cr.irow[i][w], 64)];  // (a byte is 0..64; the clamp keeps a stray one inside the table)
   return v;
 }
 __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
