@@ -27,16 +27,89 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// Debugging aid, OFF unless YKPRED_GUARD_PAGES=1: every device buffer is mapped through the virtual-memory API so that its LAST
+// byte is the last byte of its mapping, with an unmapped granule behind it — an out-of-bounds access past the end of a buffer
+// then faults at the instruction that makes it instead of reading whatever was allocated next. (Written for the one unexplained
+// device fault of round 3; costs a 2 MiB granule per buffer, so for small clusters only. NOT run on hardware in
+// round 3 — the round's GPU budget was spent when it was written.)
+struct GuardAlloc {
+  void* va = nullptr;
+  size_t mapped = 0, reserved = 0;
+  hipMemGenericAllocationHandle_t handle{};
+};
+inline bool guard_pages_on() {
+  static const bool on = [] {
+    const char* v = getenv("YKPRED_GUARD_PAGES");
+    return v && atoi(v) != 0;
+  }();
+  return on;
+}
+inline hipError_t guard_alloc(size_t bytes, GuardAlloc* g, void** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
+  if (gran == 0) gran = 2u << 20;
+  const size_t want = (bytes + 15) / 16 * 16;  // the buffer ends on the mapping's last byte, 16-byte aligned for the vector loads
+  g->mapped = (want + gran - 1) / gran * gran;
+  g->reserved = g->mapped + gran;               // one granule of address space stays unmapped behind the buffer
+  if ((e = hipMemAddressReserve(&g->va, g->reserved, gran, nullptr, 0)) != hipSuccess) return e;
+  if ((e = hipMemCreate(&g->handle, g->mapped, &prop, 0)) != hipSuccess) {
+    (void)hipMemAddressFree(g->va, g->reserved);
+    return e;
+  }
+  if ((e = hipMemMap(g->va, g->mapped, 0, g->handle, 0)) != hipSuccess) {
+    (void)hipMemRelease(g->handle);
+    (void)hipMemAddressFree(g->va, g->reserved);
+    return e;
+  }
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if ((e = hipMemSetAccess(g->va, g->mapped, &acc, 1)) != hipSuccess) {
+    (void)hipMemUnmap(g->va, g->mapped);
+    (void)hipMemRelease(g->handle);
+    (void)hipMemAddressFree(g->va, g->reserved);
+    return e;
+  }
+  *out = (char*)g->va + (g->mapped - want);
+  return hipSuccess;
+}
+inline void guard_free(GuardAlloc* g) {
+  if (!g->va) return;
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(g->va, g->mapped);
+  (void)hipMemRelease(g->handle);
+  (void)hipMemAddressFree(g->va, g->reserved);
+  *g = GuardAlloc{};
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  GuardAlloc guard;  // only with YKPRED_GUARD_PAGES=1
+  hipError_t raw_alloc(size_t bytes, void** out, GuardAlloc* g) {
+    if (guard_pages_on()) return guard_alloc(bytes, g, out);
+    return hipMalloc(out, bytes);
+  }
+  void raw_free(void* q, GuardAlloc* g) {
+    if (g->va)
+      guard_free(g);
+    else if (q)
+      (void)hipFree(q);
+  }
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap && p) return hipSuccess;
-    if (p) (void)hipFree(p);
+    raw_free(p, &guard);
     p = nullptr;
     cap = 0;
     if (bytes == 0) bytes = 8;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = raw_alloc(bytes, &p, &guard);
     if (e == hipSuccess) cap = bytes;
     return e;
   }
@@ -44,25 +117,27 @@ struct DevBuf {
   // the device is drained before it is freed (growth is rare: the slack absorbs the row-by-row updates).
   hipError_t reserve_keep(size_t bytes, size_t used) {
     if (bytes <= cap && p) return hipSuccess;
-    size_t ncap = bytes + bytes / 4 + 4096;
+    size_t ncap = guard_pages_on() ? bytes : bytes + bytes / 4 + 4096;  // (guard mode: no slack, the end of the buffer is the guard)
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, ncap);
+    GuardAlloc ng;
+    hipError_t e = raw_alloc(ncap, &q, &ng);
     if (e != hipSuccess) return e;
     (void)hipDeviceSynchronize();  // the engine's streams do not synchronise with the null stream used below
     if (p && used) {
       e = hipMemcpy(q, p, std::min(used, cap), hipMemcpyDeviceToDevice);
       if (e != hipSuccess) {
-        (void)hipFree(q);
+        raw_free(q, &ng);
         return e;
       }
     }
-    if (p) (void)hipFree(p);
+    raw_free(p, &guard);
     p = q;
+    guard = ng;
     cap = ncap;
     return hipSuccess;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    raw_free(p, &guard);
     p = nullptr;
     cap = 0;
   }
