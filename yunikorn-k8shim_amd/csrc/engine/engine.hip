@@ -836,6 +836,17 @@ struct Timer {
     if (on && e->timed < YKPRED_MAX_TIMED_KERNELS) (void)hipEventRecord(e->ev[2 * e->timed], st);
   }
   void end(hipStream_t st, const char* name) {
+    // YKPRED_TRACE_KERNELS=1 (debugging, with YKPRED_GUARD_PAGES): wait for the stage just launched and say so on stderr — after a
+    // device fault the last line names the last stage that completed, the one after it is the culprit
+    static const bool trace = [] {
+      const char* v = getenv("YKPRED_TRACE_KERNELS");
+      return v && atoi(v) != 0;
+    }();
+    if (trace) {
+      const hipError_t s = hipStreamSynchronize(st);
+      fprintf(stderr, "ykpred: %s %s\n", name, s == hipSuccess ? "done" : hipGetErrorString(s));
+      fflush(stderr);
+    }
     if (!on || e->timed >= YKPRED_MAX_TIMED_KERNELS) return;
     (void)hipEventRecord(e->ev[2 * e->timed + 1], st);
     e->timed_name[e->timed] = name;
