@@ -93,9 +93,13 @@ struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   GuardAlloc guard;  // only with YKPRED_GUARD_PAGES=1
+  // Outside the guard mode every block carries 64 KiB of slack behind it. It is there BECAUSE of the open item of DESIGN.md §9: a
+  // masked out-of-bounds read behind some buffer exists (the guard mode shows it) and is not localised yet; until it is, the slack
+  // keeps it inside memory the engine owns instead of on whatever page follows. `cap` stays the size asked for.
+  static constexpr size_t kSlackBytes = 64 * 1024;
   hipError_t raw_alloc(size_t bytes, void** out, GuardAlloc* g) {
     if (guard_pages_on()) return guard_alloc(bytes, g, out);
-    return hipMalloc(out, bytes);
+    return hipMalloc(out, bytes + kSlackBytes);
   }
   void raw_free(void* q, GuardAlloc* g) {
     if (g->va)
