@@ -270,8 +270,8 @@ struct ykpred_engine {
   int beside_small = 0;             // YKPRED_BESIDE_SMALL=1: a SMALL zone B (< 1/16 of the rows) is written beside the band writer (measured: the
                                     // third stream's fork / join costs the step 0.25 ms — 1.24 -> 1.50 ms on configs[2]; off)
   int wave_rows = 0;                // YKPRED_WAVE_ROWS=1: k_combine_wave writes member rows one after the other (class row in registers)
-  int slice_pairs = 0;              // YKPRED_SLICE_PAIRS=1: one word pair per lane even with a single walked dimension
-  int slice_mode = 0;               // YKPRED_SLICE_MODE: experiments of k_combine_slices (bit 0 = no stores: WRONG bitmap, timing only)
+  int slice_mode = 0;               // YKPRED_SLICE_MODE: timing-only experiments of k_combine_slices (1 = no stores, 16 = cached rows never
+                                    // reloaded): WRONG bitmaps
   int slice_chunks_per_wave = 64;   // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
   int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
   bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
@@ -1096,7 +1096,6 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (const char* v = getenv("YKPRED_SLICE_MODE")) e->slice_mode = atoi(v);
   if (const char* v = getenv("YKPRED_WAVE_ROWS")) e->wave_rows = atoi(v);
   if (const char* v = getenv("YKPRED_BESIDE_SMALL")) e->beside_small = atoi(v);
-  if (const char* v = getenv("YKPRED_SLICE_PAIRS")) e->slice_pairs = atoi(v);
   e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain)
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
