@@ -70,6 +70,7 @@ def parse_args():
     ap.add_argument("--variant-steps", type=int, default=5)
     ap.add_argument("--no-ingest", action="store_true", help="N=1: leave the JSON ingest leg out of `end_to_end`")
     ap.add_argument("--no-configs4", action="store_true", help="N=1: leave the configs[4] (100k x 5M, one GPU) leg out of `variants`")
+    ap.add_argument("--no-verify", action="store_true", help="skip the checks that make every published number self-verifying (verify_leg)")
     return ap.parse_args()
 
 
@@ -123,6 +124,57 @@ def cpu_baseline(pm, budget_s, seed):
                                     "sample": f"{reps} passes over {tables['P']} pods x {tables['N']} nodes, {dt_soa:.1f} s"}
     except Exception as exc:  # noqa: BLE001 - the extra figure must never break the bench line
         out["soa_all_cores"] = {"error": str(exc)}
+    return out
+
+
+def verify_leg(pm, seed=11, n_classes=64, use_direct=True, oracle=True):
+    """Makes a published number self-verifying (outside every timed region): the bitmap the timed steps produced is
+      (1) class-consistent on the device — every one of the P rows equals the row of its class's representative, padding zero;
+      (2) the oracle's on `n_classes` sampled pod classes x ALL nodes, per pair (predicate_manager.go:206-283; the per-pod PreFilter
+          replay form with hard spread constraints) — rows, feasible counts, float64 bin-pack scores and decisions;
+      (3) reproduced bit for bit (checksum of checksums) by the independent per-pair kernel k_direct.
+    (1) + (2) say: all rows of the sampled classes are the oracle's; (3) ties every other row to a second formulation."""
+    t0 = time.perf_counter()
+    out = {}
+    lay = pm.layout()
+    out["class_rows_bad_words"] = int(pm.check_class_rows())
+    ok = out["class_rows_bad_words"] == 0
+    plane_sum = pm.checksum()
+    if oracle:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as orc
+        pod_class, rep = pm.pod_classes()
+        rng = np.random.default_rng(seed)
+        pick = np.sort(rng.choice(len(rep), min(n_classes, len(rep)), replace=False))
+        reps = rep[pick].astype(np.int32)
+        o = orc.Oracle(pm.dump_snapshot(pods=reps, compact=True))
+        want = o.eval_grid(threads=min(os.cpu_count() or 8, 64), prefilter_once=True)
+        rows = pm.read_rows(reps)
+        got = np.unpackbits(rows.view(np.uint8), axis=1, bitorder="little")[:, :lay.num_nodes]
+        rows_ok = bool(np.array_equal(got, want))
+        counts, dec = pm.read_counts(), pm.read_decisions()
+        counts_ok = bool(np.array_equal(counts[reps], want.sum(axis=1)))
+        scores = o.binpack_scores()
+        scores_ok = bool(np.array_equal(scores, pm.read_scores()))
+        order = np.lexsort((np.arange(lay.num_nodes), scores))  # KWOK node names are zero-padded: NodeID order = index order
+        in_order = want[:, order]
+        first = in_order.argmax(axis=1)
+        want_dec = np.where(in_order[np.arange(len(reps)), first] != 0, order[first], -1).astype(np.int32)
+        dec_ok = bool(np.array_equal(dec[reps], want_dec))
+        members_ok = bool(np.array_equal(dec, dec[rep][pod_class]) and np.array_equal(counts, counts[rep][pod_class]))
+        out.update({"oracle_classes": int(len(reps)), "oracle_pairs": int(want.size), "rows": rows_ok, "counts": counts_ok, "scores_bit_equal": scores_ok,
+                    "decisions": dec_ok, "members_share_count_and_decision": members_ok})
+        ok = ok and rows_ok and counts_ok and scores_ok and dec_ok and members_ok
+        o.close()
+    if use_direct:
+        pm.evaluate(direct=True, counts=False, decisions=False)
+        pm.synchronize()
+        out["direct_checksum_equal"] = bool(pm.checksum() == plane_sum)
+        ok = ok and out["direct_checksum_equal"]
+        pm.evaluate()  # the plane path's answer again (later legs read it)
+        pm.synchronize()
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    out["ok"] = bool(ok)
     return out
 
 
@@ -271,6 +323,7 @@ def predicates_callback_leg(pm, P, N):
 def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
     """A fresh manager on the same GPU: generate, upload, then `steps` timed full passes. Used for `variants` / `end_to_end`."""
     workload = kwok.pop("_workload", None)
+    verify = kwok.pop("_verify", not a.no_verify)
     pm = pkg.GpuPredicateManager(device=dev.index)
     out = {}
     try:
@@ -306,6 +359,12 @@ def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
                                             b_node=node_row_bytes(pm)), "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
                     "cold_pass": {"encode_upload_ms": round(t_sync * 1e3, 1), "class_build_and_first_eval_ms": round((t_cold - t_sync) * 1e3, 1),
                                   "total_ms": round(t_cold * 1e3, 1), "encode_ms": round(pm.stats()["encode_us"] / 1e3, 1)}})
+        if verify:
+            # the timed steps wrote caller-owned counts / decisions; the checker reads the engine's own buffers: one more pass
+            pm.evaluate()
+            pm.synchronize()
+            out["verification"] = verify_leg(pm)
+            out["verified"] = out["verification"]["ok"]
     finally:
         pm.close()
     return out
@@ -536,6 +595,21 @@ def main():
         gather["step_without_gather_ms"] = round(no_gather_ms, 4)
         gather["evals_per_sec_without_gather"] = float(P) * total_nodes / (no_gather_ms * 1e-3)
 
+    # ---- the headline number verifies itself (outside the timed region): class rows, sampled classes x all nodes against the
+    # oracle incl. decisions, and the independent per-pair kernel's checksum. Shards verify their own slab on the device.
+    verification = None
+    if not a.no_verify and not a.direct:
+        try:
+            pm.evaluate()
+            pm.synchronize()
+            verification = verify_leg(pm, oracle=(world == 1))
+            if world > 1:
+                flags = [None] * world
+                dist.all_gather_object(flags, bool(verification["ok"]))
+                verification["all_shards_ok"] = all(flags)
+                verification["ok"] = bool(all(flags))
+        except Exception as exc:  # noqa: BLE001 - a failed CHECK must show in the line, not take it down
+            verification = {"ok": False, "error": str(exc)}
     cpu = cpu_baseline(pm, a.cpu_seconds, SEED) if rank == 0 else None
     callbacks = None
     if rank == 0 and world == 1 and not a.no_variants and not a.direct:
@@ -572,7 +646,7 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 variants["configs4_one_gpu"] = {"error": str(exc)}
         try:
-            e2e = timed_leg(pkg, dev, stream, a, 1, 0, 0, **base, num_templates=a.templates, gang_size=gang)
+            e2e = timed_leg(pkg, dev, stream, a, 1, 0, 0, **base, num_templates=a.templates, gang_size=gang, _verify=False)
             end_to_end = dict(e2e["cold_pass"], note="one cold pass of the default workload: objects → dictionaries/tables (encode) → H2D "
                                                       "upload → pod classes → evaluation, bitmap stays on the device")
         except Exception as exc:  # noqa: BLE001
@@ -609,6 +683,7 @@ def main():
                        "parallelism": parallelism, "collectives": collectives},
             "decisions_per_sec": float(P) * a.steps / elapsed,
             "distinct_evals_per_step": lay.num_classes * N,
+            "verified": None if verification is None else bool(verification["ok"]), "verification": verification,
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "host_setup_s": round(t_gen, 2), "encode_ms": round(stats["encode_us"] / 1e3, 1),

@@ -178,6 +178,20 @@ int32_t ykhost_predicates(ykhost_t* h, int32_t pod, int32_t node, int32_t alloca
 int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k, int32_t* out_nodes /* [k] */);
 int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5);
 
+/* One scheduling ROUND with conflict-resolved decisions — what the core's loop decides for the asks asks[0..n) (indices into
+ * the ask table, in decision order; NULL = asks 0..n-1): ask i is decided with asks 0..i-1 ASSUMED on their nodes (the core
+ * decides an ask, AsyncRMCallback.UpdateAllocation → Context.AssumePod runs, scheduler_callback.go:49-98 / context.go:828-885,
+ * and the next Predicates() call sees the node's new Requested / pod list). out_nodes[i] = node index, -1 = no node fits,
+ * -2 = the ask is routed to the CPU manager (not evaluated by the engine) and takes no part in the round.
+ * Where only node resources couple the asks, the whole round is ONE device call (ykpred_allocate_round); with active
+ * topology constraints or host ports the host decides ask by ask (decision → AssumePod → column patch → next decision).
+ * apply != 0: every ask that got a node is assumed in the mirror exactly as ykhost_assume_pod would (the ask-by-ask path
+ * needs that to see its own allocations and refuses apply == 0 with YKHOST_E_UNSUPPORTED). → number of asks that got a node,
+ * or a negative error. ykhost_round_stats: out[0] rounds decided by one device call, [1] asks decided in them, [2] asks decided
+ * ask by ask, [3] asks routed. */
+int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32_t apply, int32_t* out_nodes /* [n] */);
+int32_t ykhost_round_stats(ykhost_t* h, int64_t* out4);
+
 /* victims: UIDs of pods assigned to the node (NULL / unknown UID = nil victim). Returns the index or -1. */
 int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t num_victims,
                                      int32_t start_index);

@@ -321,6 +321,28 @@ int32_t ykpred_read_row_map(ykpred_engine_t* e, int32_t* out /* [P]: layout.row_
 int32_t ykpred_read_pod_classes(ykpred_engine_t* e, int32_t* pod_class /* [P] or NULL */, int32_t* class_rep /* [num_classes] or NULL */);
 int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
 
+/* CONFLICT-RESOLVED decisions: the sequential loop yunikorn-core drives through the shim. For asks[0], asks[1], ... in this
+ * order: the first node of the bin-pack order that passes Predicates() under the state the EARLIER asks of the round left
+ * behind (AsyncRMCallback.Predicates, /root/reference/pkg/cache/scheduler_callback.go:203-205 → Context.IsPodFitNode,
+ * context.go:696-716), then AssumePod (context.go:828-885 → SchedulerCache.AssumePod, scheduler_cache.go:443-461 →
+ * NodeInfo.AddPod): the node's Requested grows by the ask's request vector, len(Pods) by one, its bin-pack score moves.
+ * out_nodes[i] = node index or -1 (no node fits; nothing is assumed for that ask). The engine's TABLES ARE NOT CHANGED — the
+ * round runs on a scratch copy of the node columns; the caller applies the allocations the core accepts through the cache
+ * hooks (ykhost_assume_pod → ykpred_update_node) as it does for any AssumePod.
+ * Needs a current evaluation WITH decisions of the same plugin lists (YKPRED_E_STATE otherwise). YKPRED_E_UNSUPPORTED — decide ask by
+ * ask instead — when something other than node resources couples the asks of the round: active PodTopologySpread /
+ * InterPodAffinity signatures, an ask that requests a host port, or a node-sharded engine. */
+int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t n_asks,
+                              const int32_t* asks /* host, [n_asks] ask indices in decision order */, int32_t* out_nodes /* host, [n_asks] */);
+
+/* Debugging aid (no reference counterpart). With YKPRED_GUARD_PAGES=1 (2) in the environment every device block of the engine
+ * ends (starts) on the last (first) byte of its mapping with an unmapped granule behind (in front of) it. The self-test proves the
+ * guard is armed: it allocates a block the same way and reads `offset` bytes past its end (offset >= 0) or |offset| bytes in front
+ * of its start (offset < 0). Under the guard an offset outside the block kills the process with a GPU memory access fault — that
+ * IS the expected outcome (tests/test_gpu_guard.py runs it in a child process); offsets inside the block return YKPRED_OK.
+ * Without the guard the call returns YKPRED_E_STATE and touches nothing. */
+int32_t ykpred_guard_selftest(ykpred_engine_t* e, int32_t offset);
+
 /* The RESIDENT answer served to single callbacks. yunikorn-core walks asks, not nodes: for one ask it calls Predicates() node
  * after node (Context.IsPodFitNode, /root/reference/pkg/cache/context.go:696-716, behind scheduler_callback.go:203-205). When
  * the last evaluation is still current, every fit bit of that ask already sits in its bitmap row: ykpred_peek_row copies that

@@ -1439,6 +1439,66 @@ int orc_decide_once(void* h, int pod, unsigned pre_mask, unsigned filt_mask, int
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The SEQUENTIAL loop the reference actually runs: yunikorn-core decides one ask, the shim assumes it, and
+// the next Predicates() call sees it. For ask pods[i], in order:
+//   * the core walks the nodes in bin-pack order under the CURRENT state — ascending (score, NodeID), recollection of
+//     yunikorn-core's `binpacking` policy, A.9 — and calls Predicates(ask, node) (scheduler_callback.go:203-205 →
+//     context.go:696-716 → predicate_manager.go:134-139) until the first node that fits;
+//   * the allocation comes back through AsyncRMCallback.UpdateAllocation (scheduler_callback.go:49-98) → Context.AssumePod
+//     (context.go:828-885): assumedPod.Spec.NodeName = node, SchedulerCache.AssumePod (scheduler_cache.go:443-461) → updatePod
+//     → NodeInfo.AddPod (:363): the node's Requested, pod list (labels for the topology plugins), used host ports grow.
+// out[i] = node index or -1 (no node fits: the ask stays pending, nothing is assumed). The snapshot is MUTATED.
+// The node order is kept in an ordered set keyed by (score, name) and only the allocated node is re-keyed — what the core's
+// sorted node collection does; `early_exit` = 0 evaluates every node instead (the naive argmin form; same answers).
+int orc_allocate_sequential(void* h, const int* pods, int np, unsigned pre_mask, unsigned filt_mask, int* out, int early_exit) {
+  Snapshot* s = static_cast<Snapshot*>(h);
+  struct Key {
+    double score;
+    const std::string* name;
+    size_t idx;
+    bool operator<(const Key& o) const {
+      if (score != o.score) return score < o.score;
+      if (*name != *o.name) return *name < *o.name;
+      return idx < o.idx;
+    }
+  };
+  std::set<Key> order;
+  std::vector<Key> key_of(s->nodes.size());
+  for (size_t j = 0; j < s->nodes.size(); ++j) {
+    key_of[j] = Key{orc::binpack_score(s->nodes[j]), &s->nodes[j].node.name, j};
+    order.insert(key_of[j]);
+  }
+  std::set<size_t> anti(s->nodes_with_anti.begin(), s->nodes_with_anti.end());
+  for (int i = 0; i < np; ++i) {
+    const size_t pi = static_cast<size_t>(pods ? pods[i] : i);
+    orc::Pod* p = const_cast<orc::Pod*>(s->pending[pi]);
+    int best = -1;
+    if (early_exit) {
+      for (const Key& k : order)
+        if (orc::pod_fits_node(*s, *p, s->nodes[k.idx], pre_mask, filt_mask).fit) {
+          best = static_cast<int>(k.idx);
+          break;
+        }
+    } else {
+      const Key* bk = nullptr;
+      for (size_t j = 0; j < s->nodes.size(); ++j)
+        if (orc::pod_fits_node(*s, *p, s->nodes[j], pre_mask, filt_mask).fit && (!bk || key_of[j] < *bk)) bk = &key_of[j];
+      if (bk) best = static_cast<int>(bk->idx);
+    }
+    out[i] = best;
+    if (best < 0) continue;
+    orc::NodeInfo& ni = s->nodes[static_cast<size_t>(best)];
+    p->node_name = ni.node.name;  // context.go:879
+    ni.add_pod(p);                // scheduler_cache.go:363
+    if (!p->pod_anti_affinity.empty() && anti.insert(static_cast<size_t>(best)).second) s->nodes_with_anti.push_back(static_cast<size_t>(best));
+    order.erase(key_of[static_cast<size_t>(best)]);
+    key_of[static_cast<size_t>(best)].score = orc::binpack_score(ni);
+    order.insert(key_of[static_cast<size_t>(best)]);
+  }
+  return 0;
+}
+
 int64_t orc_quantity_value(const char* s) { return orc::quantity_value(s); }
 int64_t orc_quantity_milli(const char* s) { return orc::quantity_milli(s); }
 

@@ -72,6 +72,8 @@ def lib():
         L.orc_decide.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint,
                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         L.orc_decide_once.argtypes = L.orc_decide.argtypes
+        L.orc_allocate_sequential.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_int]
         L.orc_quantity_value.restype = ctypes.c_int64
         L.orc_quantity_value.argtypes = [ctypes.c_char_p]
         L.orc_quantity_milli.restype = ctypes.c_int64
@@ -148,6 +150,15 @@ class Oracle:
         c, b = ctypes.c_int(0), ctypes.c_int(0)
         (lib().orc_decide_once if prefilter_once else lib().orc_decide)(self._h, pod, pre_mask, filt_mask, ctypes.byref(c), ctypes.byref(b))
         return c.value, b.value
+
+
+    def allocate_sequential(self, pods=None, pre_mask=ALL, filt_mask=ALL, early_exit=True):
+        """The loop yunikorn-core drives: decide pods[i] on the current state (first fit in bin-pack order), AssumePod it, go on.
+        → node index per ask (-1: none fits). MUTATES the loaded snapshot (the assumed asks now sit on their nodes)."""
+        pods = np.arange(self.num_pods, dtype=np.int32) if pods is None else np.ascontiguousarray(pods, dtype=np.int32)
+        out = np.full(len(pods), -1, dtype=np.int32)
+        lib().orc_allocate_sequential(self._h, pods.ctypes.data, len(pods), pre_mask, filt_mask, out.ctypes.data, 1 if early_exit else 0)
+        return out
 
 
 def pack_bits(fit):

@@ -1123,14 +1123,16 @@ def test_full_size_configs(pm, n_nodes, n_pods, affinity):
 
 
 @pytest.mark.parametrize("n_nodes,n_pods,affinity,gang,spread", [(10_000, 100_000, 0, 0, 0), (50_000, 1_000_000, 1, 0, 0), (50_000, 1_000_000, 1, 100, 0),
-                                                                 (100_000, 1_000_000, 1, 0, 1)],
-                         ids=["configs1", "configs2", "configs3-gang", "configs4-shape"])
+                                                                 (100_000, 1_000_000, 1, 0, 1), (100_000, 5_000_000, 1, 0, 1)],
+                         ids=["configs1", "configs2", "configs3-gang", "configs4-shape", "configs4-size"])
 def test_full_grid_oracle_parity(pm, n_nodes, n_pods, affinity, gang, spread):
     """EVERY (pod, node) pair of configs[1], configs[2], the configs[3] gang shape and the configs[4] shape (100 000 nodes,
     the full Filter set incl. hard PodTopologySpread constraints, 10^6 asks) against the oracle (predicate_manager.go:206-283
     per pair): the oracle evaluates one representative ask per pod class against all N nodes — C x N Predicates() calls, 1e8
     for configs[2] — and the device proves that each of the P rows equals the row of its class's representative (and that
-    every padding word is zero). Together: all P x N bits are the oracle's. The DECISIONS (the metric's second half) are
+    every padding word is zero). Together: all P x N bits are the oracle's. configs4-size is BASELINE configs[4] at its own size —
+    100 000 nodes x 5 000 000 asks, a 62.6 GB bitmap of 7.8e9 words: the first layout past 2^32 words, where an index-width
+    defect would live (the oracle's cost is per class, not per ask). The DECISIONS (the metric's second half) are
     checked at the same size: for every class the first feasible node of the oracle's row in the oracle's bin-pack order
     (score, then NodeID) must be the decision of every member."""
     import time

@@ -1,0 +1,118 @@
+"""Conflict-resolved (sequential) allocation rounds on the device against the oracle run SEQUENTIALLY — decide ask i, AssumePod
+it, decide ask i + 1 (the loop yunikorn-core drives: scheduler_callback.go:203-205 → context.go:696-716, then
+scheduler_callback.go:49-98 → context.go:828-885). Bar: every decision of the round identical, and the state the round leaves
+behind (mirror + device tables after the assumes) identical to the oracle's mutated snapshot on the whole grid."""
+import importlib
+import json
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _seqgen
+
+pytestmark = pytest.mark.gpu
+pkg = importlib.import_module("yunikorn-k8shim_amd")
+
+
+@pytest.fixture(scope="module")
+def pm():
+    m = pkg.GpuPredicateManager()
+    yield m
+    m.close()
+
+
+def unpack(bitmap, n):
+    return np.unpackbits(bitmap.view(np.uint8), axis=1, bitorder="little")[:, :n]
+
+
+def round_against_oracle(pm, snap, asks=None, expect_device=True):
+    pm.load_snapshot(snap)
+    before = pm.round_stats()
+    o = orc.Oracle(pm.dump_snapshot())
+    want = o.allocate_sequential(pods=asks)
+    got = pm.allocate_round(asks=asks)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"{len(bad)} decisions differ, first at position {bad[0]}: gpu={got[bad[0]]} oracle={want[bad[0]]}"
+    st = pm.round_stats()
+    if expect_device:
+        assert st["rounds_on_device"] == before["rounds_on_device"] + 1 and st["asks_one_by_one"] == before["asks_one_by_one"]
+    else:
+        assert st["asks_one_by_one"] > before["asks_one_by_one"]
+    # the state the round left behind: the mirror after its assumes, evaluated on the device, against the oracle's mutated snapshot
+    # (an assumed ask keeps its row in the ask table; the mirror dumps it under its node, not among the pending pods: the grid is
+    # compared on the asks the round left pending)
+    pm.evaluate(allocate=True)
+    lay = pm.layout()
+    o2 = orc.Oracle(pm.dump_snapshot())
+    grid = o2.eval_grid(threads=8)
+    listed = np.arange(lay.num_pods) if asks is None else np.asarray(asks)
+    pending = np.setdiff1d(np.arange(lay.num_pods), listed[got >= 0])
+    assert o2.num_pods == len(pending)
+    assert np.array_equal(unpack(pm.read_bitmap(), lay.num_nodes)[pending], grid)
+    for n in range(o.num_nodes):  # Requested / pod counts of every node: mirror == the oracle that ran the loop
+        assert o.node_info(n) == o2.node_info(n), n
+    return got
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_allocation_round_competing_asks(pm, seed):
+    got = round_against_oracle(pm, _seqgen.competing(seed, scalars=bool(seed % 2)))
+    assert (got >= 0).sum() > 10  # the round really allocates
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_allocation_round_in_a_given_order(pm, seed):
+    snap = _seqgen.competing(100 + seed, n_nodes=25, n_pods=90)
+    order = np.random.default_rng(seed).permutation(90)[:70].astype(np.int32)
+    round_against_oracle(pm, snap, asks=order)
+
+
+@pytest.mark.parametrize("seed,kind", [(0, "spread"), (1, "spread"), (2, "ports"), (3, "ports")])
+def test_allocation_round_goes_ask_by_ask_where_more_than_resources_couples_the_asks(pm, seed, kind):
+    snap = _seqgen.competing(200 + seed, n_nodes=20, n_pods=40, spread=kind == "spread", ports=kind == "ports")
+    round_against_oracle(pm, snap, expect_device=False)
+
+
+def test_allocation_round_kwok_cluster(pm):
+    """KWOK-style nodes (random utilisation, 110 slots, taints, selectors) and 4 000 asks of 40 templates: long runs of asks pile
+    onto the same node until its slots or resources run out."""
+    pm.generate_kwok(seed=0x59554E49 + 7, num_nodes=300, num_pods=4000, num_templates=40, node_affinity=1)
+    o = orc.Oracle(pm.dump_snapshot())
+    want = o.allocate_sequential()
+    got = pm.allocate_round()
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+    assert (got >= 0).sum() > 1000
+    pm.evaluate(allocate=True)
+    o2 = orc.Oracle(pm.dump_snapshot())
+    for n in range(o.num_nodes):
+        assert o.node_info(n) == o2.node_info(n), n
+
+
+def test_allocation_round_reference_perf_shape(pm):
+    """scheduler_perf_test.go's shape at a tenth of its size (the full 5 000 x 50 000 is bench.py's `allocation_round` leg): the
+    asks fill node after node in NodeID order, 110 pods each."""
+    snap = _seqgen.perf_shape(500, 5000)
+    got = round_against_oracle(pm, snap)
+    assert (got >= 0).all()
+    counts = np.bincount(got, minlength=500)
+    assert sorted(counts[counts > 0].tolist(), reverse=True)[:3] == [110, 110, 110] and (counts > 0).sum() == 46
+
+
+def test_second_round_continues_from_the_first(pm):
+    snap = _seqgen.competing(300, n_nodes=30, n_pods=100)
+    pm.load_snapshot(snap)
+    o = orc.Oracle(pm.dump_snapshot())
+    first, second = np.arange(0, 50, dtype=np.int32), np.arange(50, 100, dtype=np.int32)
+    want = np.concatenate([o.allocate_sequential(pods=first), o.allocate_sequential(pods=second)])
+    got = np.concatenate([pm.allocate_round(asks=first), pm.allocate_round(asks=second)])
+    assert np.array_equal(got, want)
+
+
+def test_round_without_apply_leaves_the_cluster_alone(pm):
+    snap = _seqgen.competing(301, n_nodes=30, n_pods=60)
+    pm.load_snapshot(snap)
+    before = json.loads(pm.dump_snapshot())
+    a = pm.allocate_round(apply=False)
+    b = pm.allocate_round(apply=False)
+    assert np.array_equal(a, b) and json.loads(pm.dump_snapshot()) == before

@@ -27,23 +27,28 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Debugging aid, OFF unless YKPRED_GUARD_PAGES=1: every device buffer is mapped through the virtual-memory API so that its LAST
-// byte is the last byte of its mapping, with an unmapped granule behind it — an out-of-bounds access past the end of a buffer
-// then faults at the instruction that makes it instead of reading whatever was allocated next. (Written for the one unexplained
-// device fault of round 3; costs a 2 MiB granule per buffer, so for small clusters only. NOT run on hardware in
-// round 3 — the round's GPU budget was spent when it was written.)
+// Debugging aid, OFF unless YKPRED_GUARD_PAGES is set: every device buffer is mapped through the virtual-memory API with an unmapped
+// granule next to it, so that an out-of-bounds access faults at the instruction that makes it instead of touching whatever was
+// allocated next. YKPRED_GUARD_PAGES=1: the buffer ENDS on the last byte of its mapping (over-reads / over-writes fault; the size is
+// NOT rounded up — the base is then only as aligned as the size is, which every kernel of this file tolerates: global memory takes
+// unaligned vector accesses); =2: the buffer STARTS on the first byte of its mapping with the unmapped granule in front (accesses
+// below the buffer fault); =3: POISON — plain blocks of exactly the size asked for, filled with 0xA5 (a read of memory nobody wrote
+// shows up as a parity failure instead of passing on zeros). Costs one allocation granule per buffer: tests and small clusters only
+// (tests/test_gpu_guard.py).
 struct GuardAlloc {
-  void* va = nullptr;
+  void* va = nullptr;      // start of the reserved address range
+  void* map_at = nullptr;  // start of the mapped part
   size_t mapped = 0, reserved = 0;
   hipMemGenericAllocationHandle_t handle{};
 };
-inline bool guard_pages_on() {
-  static const bool on = [] {
+inline int guard_mode() {
+  static const int mode = [] {
     const char* v = getenv("YKPRED_GUARD_PAGES");
-    return v && atoi(v) != 0;
+    return v ? atoi(v) : 0;
   }();
-  return on;
+  return mode;
 }
+inline bool guard_pages_on() { return guard_mode() != 0; }
 inline hipError_t guard_alloc(size_t bytes, GuardAlloc* g, void** out) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -55,15 +60,16 @@ inline hipError_t guard_alloc(size_t bytes, GuardAlloc* g, void** out) {
   size_t gran = 0;
   if ((e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return e;
   if (gran == 0) gran = 2u << 20;
-  const size_t want = (bytes + 15) / 16 * 16;  // the buffer ends on the mapping's last byte, 16-byte aligned for the vector loads
-  g->mapped = (want + gran - 1) / gran * gran;
-  g->reserved = g->mapped + gran;               // one granule of address space stays unmapped behind the buffer
+  const bool front = guard_mode() == 2;
+  g->mapped = (bytes + gran - 1) / gran * gran;
+  g->reserved = g->mapped + gran;  // one granule of address space stays unmapped behind (mode 1) or in front of (mode 2) the buffer
   if ((e = hipMemAddressReserve(&g->va, g->reserved, gran, nullptr, 0)) != hipSuccess) return e;
+  g->map_at = front ? (void*)((char*)g->va + gran) : g->va;
   if ((e = hipMemCreate(&g->handle, g->mapped, &prop, 0)) != hipSuccess) {
     (void)hipMemAddressFree(g->va, g->reserved);
     return e;
   }
-  if ((e = hipMemMap(g->va, g->mapped, 0, g->handle, 0)) != hipSuccess) {
+  if ((e = hipMemMap(g->map_at, g->mapped, 0, g->handle, 0)) != hipSuccess) {
     (void)hipMemRelease(g->handle);
     (void)hipMemAddressFree(g->va, g->reserved);
     return e;
@@ -71,21 +77,31 @@ inline hipError_t guard_alloc(size_t bytes, GuardAlloc* g, void** out) {
   hipMemAccessDesc acc{};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  if ((e = hipMemSetAccess(g->va, g->mapped, &acc, 1)) != hipSuccess) {
-    (void)hipMemUnmap(g->va, g->mapped);
+  if ((e = hipMemSetAccess(g->map_at, g->mapped, &acc, 1)) != hipSuccess) {
+    (void)hipMemUnmap(g->map_at, g->mapped);
     (void)hipMemRelease(g->handle);
     (void)hipMemAddressFree(g->va, g->reserved);
     return e;
   }
-  *out = (char*)g->va + (g->mapped - want);
+  *out = front ? g->map_at : (void*)((char*)g->map_at + (g->mapped - bytes));
+  static const bool trace = [] {
+    const char* v = getenv("YKPRED_TRACE_KERNELS");
+    return v && atoi(v) != 0;
+  }();
+  // (with the stage trace: every block's address range — the address of a fault names the block that was overrun)
+  if (trace) fprintf(stderr, "ykpred: guard block %zu bytes [%p, %p)\n", bytes, *out, (void*)((char*)*out + bytes));
   return hipSuccess;
 }
 inline void guard_free(GuardAlloc* g) {
   if (!g->va) return;
   (void)hipDeviceSynchronize();
-  (void)hipMemUnmap(g->va, g->mapped);
+  (void)hipMemUnmap(g->map_at, g->mapped);
   (void)hipMemRelease(g->handle);
-  (void)hipMemAddressFree(g->va, g->reserved);
+  // The address range is NEVER handed back (no hipMemAddressFree): on this stack (ROCm 7.2, gfx950) a range that is freed and
+  // reserved again for a later block is served through stale translations — wrong data, or faults at addresses no block ever
+  // had. That, not an engine defect, was the "deterministic fault under the guard" of round 3 (profiles/r04_guard_sessions.txt:
+  // the same sweep with ranges reused: 3 of 4 clusters fail; never reused: 0 failures, no fault, in both modes). A freed block's
+  // range stays reserved and unmapped, so a use-after-free faults as well.
   *g = GuardAlloc{};
 }
 
@@ -93,13 +109,17 @@ struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   GuardAlloc guard;  // only with YKPRED_GUARD_PAGES=1
-  // Outside the guard mode every block carries 64 KiB of slack behind it. It is there BECAUSE of the open item of DESIGN.md §9: a
-  // masked out-of-bounds read behind some buffer exists (the guard mode shows it) and is not localised yet; until it is, the slack
-  // keeps it inside memory the engine owns instead of on whatever page follows. `cap` stays the size asked for.
-  static constexpr size_t kSlackBytes = 64 * 1024;
   hipError_t raw_alloc(size_t bytes, void** out, GuardAlloc* g) {
+    if (guard_mode() == 3) {  // POISON: a plain block of exactly the size asked for, filled with a pattern no table holds
+      hipError_t e = hipMalloc(out, bytes);
+      if (e == hipSuccess) e = hipMemset(*out, 0xA5, bytes);
+      // (the fill runs on the null stream and the engine's streams are non-blocking: without this wait it can land AFTER the first
+      // upload into the block — seen once as a spurious mismatch of this mode itself)
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      return e;
+    }
     if (guard_pages_on()) return guard_alloc(bytes, g, out);
-    return hipMalloc(out, bytes + kSlackBytes);
+    return hipMalloc(out, bytes);
   }
   void raw_free(void* q, GuardAlloc* g) {
     if (g->va)
@@ -287,6 +307,11 @@ struct ykpred_engine {
   std::vector<int32_t> h_members, h_ch_class, h_ch_begin, h_ch_len, h_ch_first;
   int patch_chunks = 0;     // chunks appended since the last build_classes
   bool rank_valid = false;  // d_rank / d_perm / d_key describe the current node table
+  // what the rank-ordered planes (and their first-word table) of the last decision pass describe: ykpred_allocate_round scans them
+  uint64_t specs_version = 1, ranked_specs_version = 0, ranked_nodes_epoch = 0;
+  unsigned ranked_pre = 0, ranked_filt = 0;
+  bool ranked_has_first = false;
+  DevBuf d_round;           // scratch of ykpred_allocate_round
   DevBuf d_patches, d_rows, d_row_count, d_row_best;
   unsigned last_pre = 0, last_filt = 0;  // plugin lists of the last full evaluation (ykpred_eval_nodes must match them)
   bool last_eval_valid = false;
@@ -1014,6 +1039,25 @@ int ensure_histograms(ykpred_engine* e, hipStream_t st) {
   return YKPRED_OK;
 }
 
+// The rank-ordered planes as the decision kernels address them (ykpred_eval's decision branch; ykpred_allocate_round re-reads
+// what that branch left in the buffers).
+ykk::Planes ranked_planes_of(const ykpred_engine* e, unsigned pre, unsigned filt, bool spread_on, bool with_first) {
+  const bool res_on = filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT, aff_on = (filt | pre) & YKPRED_PLUGIN_NODE_AFFINITY;
+  const int fit_error = (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1;
+  auto ranked_of = [&](const Family& f) { return e->planes_ranked.as<u64>() + (size_t)f.base * e->row_stride; };
+  int* first_r = with_first ? e->d_first_r.as<int>() : nullptr;
+  ykk::Planes pr{res_on ? ranked_of(e->fam_res) : nullptr, ranked_of(e->fam_tol), aff_on ? ranked_of(e->fam_aff) : nullptr,
+                 spread_on ? ranked_of(e->fam_spread) : nullptr, e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(),
+                 e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words, first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base,
+                 e->fam_spread.base, 0, nullptr, nullptr};
+  pr.n_big = res_on ? e->n_big : 0;
+  if (first_r && res_on && e->n_big > 0 && !fit_error) {
+    pr.res_val = e->d_dim_val.as<i64>();
+    pr.pfx = e->d_pfx_r.as<i64>();
+  }
+  return pr;
+}
+
 }  // namespace
 
 // null handles fall through to the entry point's own argument check
@@ -1288,6 +1332,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   if (e) e->n_uploads++;
   if (e) e->tables_version++;
   if (e) e->ask_epoch++;
+  if (e) e->specs_version++;
   if (!e || !s || s->count < 0) return fail(e, YKPRED_E_INVALID, "set_specs: bad argument");
   if (s->count > 0 && (!s->requests || !s->tolerated || !s->flags || !s->aff_term_off || !s->pre_term_off))
     return fail(e, YKPRED_E_INVALID, "set_specs: null column");
@@ -1564,6 +1609,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = a->stream ? (hipStream_t)a->stream : e->own_stream;
   if (e->classes_dirty) {
+    // A class build renumbers the classes and re-packs the bitmap rows: a pass that leaves the bitmap alone (decision refresh,
+    // dirty-class rewrite) would publish an evaluation whose rows belong to the OLD layout. The caller runs a full pass instead.
+    if (a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))
+      return fail(e, YKPRED_E_STATE, "eval: the pod classes are due for a rebuild — run a full ykpred_eval (bitmap included)");
     TRY(validate_state(e));
     TRY(build_classes(e, e->own_stream));
   }
@@ -1607,8 +1656,16 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const size_t cells = (size_t)e->n_big * (size_t)std::max(e->row_words, 1);
     for (DevBuf* b : {&e->d_sfree_c, &e->d_sfree_r}) HIPCHK(b->ensure(cells * 64 * sizeof(i64)));
     for (DevBuf* b : {&e->d_pmask_c, &e->d_pmask_r}) HIPCHK(b->ensure(cells * 65 * sizeof(u64)));
-    e->idx_stride = (e->row_words + 63) / 64 * 64;
-    for (DevBuf* b : {&e->d_idx_c, &e->d_idx_r}) HIPCHK(b->ensure((size_t)e->fam_res.D * (size_t)e->idx_stride));
+    // (a forced row stride — unequal shards — may exceed the rounded row length: consumers address index bytes by row word)
+    const int idx_stride_before = e->idx_stride;
+    e->idx_stride = (std::max(e->row_words, e->row_stride) + 63) / 64 * 64;
+    for (DevBuf* b : {&e->d_idx_c, &e->d_idx_r}) {
+      const size_t need = (size_t)e->fam_res.D * (size_t)e->idx_stride;
+      if (b->cap < need || !b->p || idx_stride_before != e->idx_stride) {
+        HIPCHK(b->ensure(need));
+        HIPCHK(hipMemsetAsync(b->p, 64, need, st));  // bytes past the row decode to entry 64 of a mask table: no node
+      }
+    }
   }
   Timer tm{e, (a->options & YKPRED_EVAL_PROFILE) != 0};
   tm.start(st);
@@ -1671,15 +1728,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     HIPCHK(e->d_first_r.ensure((size_t)std::max(e->plane_rows_alloc, 1) * sizeof(int)));
     first_r = e->d_first_r.as<int>();
   }
-  ykk::Planes pr{res_on ? o_res.ranked : nullptr, o_tol.ranked, aff_on ? o_aff.ranked : nullptr, spread_on ? o_spread.ranked : nullptr,
-                 e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(), e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words,
-                 first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base, e->fam_spread.base, 0, nullptr, nullptr};
-  pc.n_big = pr.n_big = res_on ? e->n_big : 0;
-  if (first_r && res_on && e->n_big > 0 && !fit_error) {
-    HIPCHK(e->d_pfx_r.ensure((size_t)e->n_big * (size_t)std::max(e->row_words, 1) * sizeof(i64)));
-    pr.res_val = e->d_dim_val.as<i64>();
-    pr.pfx = e->d_pfx_r.as<i64>();
-  }
+  if (first_r && res_on && e->n_big > 0 && !fit_error) HIPCHK(e->d_pfx_r.ensure((size_t)e->n_big * (size_t)std::max(e->row_words, 1) * sizeof(i64)));
+  ykk::Planes pr = ranked_planes_of(e, pre, filt, spread_on, first_r != nullptr);
+  pc.n_big = pr.n_big;
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -2042,7 +2093,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   e->last_eval_valid = true;
   if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) e->n_full_evals++;
   if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
-  if (want_dec) e->rank_valid = true;
+  if (want_dec) {
+    e->rank_valid = true;
+    e->ranked_specs_version = e->specs_version;
+    e->ranked_nodes_epoch = e->nodes_epoch;
+    e->ranked_pre = pre;
+    e->ranked_filt = filt;
+    e->ranked_has_first = e->decide_skip;
+  }
   e->last_has_keys = want_keys;
   return YKPRED_OK;
 }
@@ -2436,6 +2494,98 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_
   return YKPRED_OK;
 }
 
+// Conflict-resolved decisions for a sequence of asks. See ykpred.h.
+int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, int32_t n_asks, const int32_t* asks, int32_t* out_nodes) {
+  YK_SERIALISE(e);
+  Range roctx_range("ykpred:allocate_round");
+  if (!e || n_asks < 0 || (n_asks > 0 && (!asks || !out_nodes))) return fail(e, YKPRED_E_INVALID, "allocate_round: bad argument");
+  if (e->classes_dirty || !e->last_eval_valid || !e->rank_valid || e->bitmap_epoch != e->nodes_epoch || pre != e->last_pre || filt != e->last_filt ||
+      e->ranked_pre != pre || e->ranked_filt != filt || e->ranked_nodes_epoch != e->nodes_epoch || e->ranked_specs_version != e->specs_version)
+    return fail(e, YKPRED_E_STATE, "allocate_round: no current evaluation WITH decisions of these plugin lists (run ykpred_eval with YKPRED_OUT_DECISIONS)");
+  if (e->comm && e->comm_world > 1)
+    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: node-sharded engines decide ask by ask (the winner of every ask is a cross-shard exchange)");
+  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0)
+    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints are active (an assumed pod's labels move the histograms of later asks): decide ask by ask");
+  const bool ports_on = (pre & filt & YKPRED_PLUGIN_NODE_PORTS) && e->KP > 0;
+  for (int i = 0; i < n_asks; ++i) {
+    if (asks[i] < 0 || asks[i] >= e->P) return fail(e, YKPRED_E_INVALID, "allocate_round: ask index out of range");
+    if ((size_t)asks[i] < e->h_row_stale.size() && e->h_row_stale[(size_t)asks[i]])
+      return fail(e, YKPRED_E_STATE, "allocate_round: an ask of the round was patched and not re-evaluated yet");
+    if (ports_on) {
+      const size_t sp = (size_t)e->h_pod_spec[(size_t)asks[i]];
+      for (int k = 0; k < e->KP; ++k)
+        if (e->h_wanted[sp * (size_t)e->KP + (size_t)k])
+          return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: an ask of the round requests a host port (an assumed pod's ports change later answers): decide ask by ask");
+    }
+  }
+  if (n_asks == 0) return YKPRED_OK;
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  if (e->ev_eval_done) HIPCHK(hipStreamWaitEvent(st, e->ev_eval_done, 0));
+  const size_t N = (size_t)std::max(e->N, 1), R = (size_t)e->R, C = (size_t)std::max(e->C, 1), RW = (size_t)std::max(e->row_words, 1);
+  // scratch layout, 8-byte pieces first: Requested copy | moved keys | moved bits | pod counts | cursors | moved list | asks | out | n_moved
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = off;
+    off += (bytes + 7) / 8 * 8;
+    return at;
+  };
+  const size_t o_req = take(R * N * sizeof(i64)), o_key = take(N * sizeof(u64)), o_bits = take(RW * sizeof(u64)), o_cnt = take(N * sizeof(int)),
+               o_cur = take(C * sizeof(int)), o_list = take(N * sizeof(int)), o_asks = take((size_t)n_asks * sizeof(int)),
+               o_out = take((size_t)n_asks * sizeof(int)), o_nm = take(sizeof(int));
+  HIPCHK(e->d_round.ensure(off));
+  char* base = (char*)e->d_round.p;
+  HIPCHK(hipMemcpyAsync(base + o_req, e->d_req.p, R * (size_t)e->N * sizeof(i64), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(base + o_cnt, e->d_count.p, (size_t)e->N * sizeof(int), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemsetAsync(base + o_bits, 0, RW * sizeof(u64), st));
+  HIPCHK(hipMemsetAsync(base + o_cur, 0xff, C * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(base + o_nm, 0, sizeof(int), st));
+  HIPCHK(hipMemcpyAsync(base + o_asks, asks, (size_t)n_asks * sizeof(int), hipMemcpyHostToDevice, st));
+  ykk::NodeTable nt = node_table(e);
+  nt.req = (const i64*)(base + o_req);
+  nt.count = (const int*)(base + o_cnt);
+  ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
+  const bool spread_err = ((filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) && !(pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) ||
+                          ((filt & YKPRED_PLUGIN_INTER_POD_AFFINITY) && !(pre & YKPRED_PLUGIN_INTER_POD_AFFINITY)) ||
+                          ((filt & YKPRED_PLUGIN_NODE_PORTS) && !(pre & YKPRED_PLUGIN_NODE_PORTS));
+  ykk::RoundArgs ra{};
+  ra.asks = (const int*)(base + o_asks);
+  ra.pod_spec = e->d_pod_spec.as<int>();
+  ra.pod_pin = e->d_pod_pin.as<int>();
+  ra.pod_class = e->d_pod_class.as<int>();
+  ra.perm = e->d_perm.as<int>();
+  ra.rank = e->d_rank.as<int>();
+  ra.key0 = e->d_key.as<u64>();
+  ra.name_rank = e->has_name_rank ? e->d_name_rank.as<int>() : nullptr;
+  ra.pre = pre;
+  ra.filt = filt;
+  ra.row_words = e->row_words;
+  ra.all_fail = spread_err ? 1 : 0;
+  ra.req = (i64*)(base + o_req);
+  ra.count = (int*)(base + o_cnt);
+  ra.moved_bits = (u64*)(base + o_bits);
+  ra.cursor = (int*)(base + o_cur);
+  ra.moved_list = (int*)(base + o_list);
+  ra.moved_key = (u64*)(base + o_key);
+  ra.n_moved = (int*)(base + o_nm);
+  ra.out = (int*)(base + o_out);
+  const ykk::Planes pr = ranked_planes_of(e, pre, filt, false, e->ranked_has_first);
+  const ykk::SpecTable stbl = spec_table(e);
+  // one launch per 32 768 asks: the loop is a single wave, and a bounded launch keeps the queue responsive (the state of the
+  // round — scratch tables, moved list — lives in memory between the launches)
+  const int per_launch = 32768;
+  for (int first = 0; first < n_asks; first += per_launch) {
+    ra.first = first;
+    ra.n_asks = std::min(per_launch, n_asks - first);
+    hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kWave), 0, st, nt, stbl, ct, pr, ra);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_nodes, base + o_out, (size_t)n_asks * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return YKPRED_OK;
+}
+
 int32_t ykpred_synchronize(ykpred_engine_t* e) {
   YK_SERIALISE(e);
   if (!e) return YKPRED_E_INVALID;
@@ -2691,6 +2841,29 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(e->own_stream));
   HIPCHK(hipMemcpy(bad_words, e->d_scratch.p, sizeof(u64), hipMemcpyDeviceToHost));
+  return YKPRED_OK;
+}
+
+// reads one byte at p[off] (the guard self-test)
+__global__ void k_guard_probe(const unsigned char* p, long off, unsigned* sink) {
+  if (threadIdx.x == 0) *sink = p[off];
+}
+int32_t ykpred_guard_selftest(ykpred_engine_t* e, int32_t offset) {
+  YK_SERIALISE(e);
+  if (!e) return YKPRED_E_INVALID;
+  if (!guard_pages_on()) return fail(e, YKPRED_E_STATE, "guard_selftest: YKPRED_GUARD_PAGES is not set");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const size_t bytes = 1000;  // deliberately not a multiple of anything
+  DevBuf block, sink;
+  HIPCHK(block.ensure(bytes));
+  HIPCHK(sink.ensure(sizeof(unsigned)));
+  HIPCHK(hipMemsetAsync(block.p, 0x5a, bytes, e->own_stream));
+  const long off = offset >= 0 ? (long)bytes - 1 + offset : (long)offset;  // offset 0 = the last byte, -1 = the byte before the first
+  hipLaunchKernelGGL(k_guard_probe, dim3(1), dim3(64), 0, e->own_stream, block.as<unsigned char>(), off, sink.as<unsigned>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->own_stream));
+  block.release();
+  sink.release();
   return YKPRED_OK;
 }
 

@@ -80,20 +80,22 @@ struct NodeTable {
 // ---------------------------------------------------------------------------------------------------
 // score(n) = 1 - (Σ_{r∈{cpu,mem}, total_r>0} (1 - avail_r/total_r)) / #r   in float64, the exact operation
 // order written in DESIGN.md §"bin-pack score contract" (no multiplies ⇒ nothing for FMA contraction to fuse).
-__device__ __forceinline__ double node_score(const NodeTable& t, int n) {
+__device__ __forceinline__ double node_score_of(const i64 (&total)[2], const i64 (&used)[2]) {
   double sum = 0.0, wsum = 0.0;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    i64 total = t.alloc[(size_t)r * t.n + n];
-    i64 used = t.req[(size_t)r * t.n + n];
-    if (total <= 0) continue;
-    double avail = (double)(total - used);
-    double share = 1.0 - avail / (double)total;
+    if (total[r] <= 0) continue;
+    double avail = (double)(total[r] - used[r]);
+    double share = 1.0 - avail / (double)total[r];
     sum = sum + share;
     wsum = wsum + 1.0;
   }
   if (wsum == 0.0) return 1.0;
   return 1.0 - sum / wsum;
+}
+__device__ __forceinline__ double node_score(const NodeTable& t, int n) {
+  const i64 total[2] = {t.alloc[n], t.alloc[(size_t)t.n + n]}, used[2] = {t.req[n], t.req[(size_t)t.n + n]};
+  return node_score_of(total, used);
 }
 __device__ __forceinline__ u64 sortable_key(double s) {
   u64 b = (u64)__double_as_longlong(s);
@@ -2189,6 +2191,197 @@ __global__ __launch_bounds__(kWave) void k_preempt(NodeTable t, SpecTable s, int
   const int v0 = voff[q], nv = voff[q + 1] - v0, p = q_pod[q];
   out[q] = preempt_one(t, s, pod_spec[p], pod_pin[p], q_node[q], nv, vreq + (size_t)v0 * s.R, vpresent + v0,
                        ports_after ? ports_after + (size_t)v0 * t.KP : nullptr, q_start[q], pre_mask, filt_mask);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Conflict-resolved decisions: the SEQUENTIAL loop yunikorn-core drives through the shim. For the asks of a
+// round, in order: the first node of the bin-pack order — under the state the EARLIER asks of the round left behind — that
+// passes Predicates() (scheduler_callback.go:203-205 → context.go:696-716); then AssumePod (context.go:828-885 →
+// scheduler_cache.go:443-461 → NodeInfo.AddPod): the node's Requested grows by the ask's request vector, len(Pods) by one, its
+// bin-pack score moves, and the next ask sees that.
+//
+// One wave runs the loop (the asks are a dependency chain); the work per ask stays small because a snapshot evaluation with
+// decisions is current when the round starts:
+//   * UNMOVED nodes (no allocation in this round yet) keep their state and their relative order: the first feasible one of a
+//     class is the first set bit of (AND of the class's rank-ordered planes) & ~moved — one lane-parallel scan from a per-class
+//     cursor that only ever advances (bits only leave);
+//   * MOVED nodes (a short list: bin-packing piles the asks onto few nodes, and a node without a free pod slot leaves the
+//     list for good) are evaluated per pair from the LIVE tables (eval_pair: the routine of k_query / k_direct), lane = node,
+//     with their current score key;
+//   * the winner is the smaller (score key, NodeID rank) of the two candidates — what a walk over the re-sorted node list
+//     would have found first.
+// Mutable state (Requested / pod counts of the scratch copy, moved bits, the list, cursors) is read and written with
+// agent-scope atomics and a fence per ask: lanes of the wave read what lane 0 wrote through L2, never a stale L1 line.
+// The caller guarantees: no topology signature is active and no ask of the round requests a host port — those couple asks
+// through more than the node's resources (pod labels, port sets) and take the host's ask-by-ask path instead.
+template <class T>
+__device__ __forceinline__ T ld_live(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_live(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct RoundArgs {
+  int first, n_asks;        // this launch decides asks [first, first + n_asks) of the round
+  const int* asks;          // [round] ask (pod) indices in decision order
+  const int* pod_spec;
+  const int* pod_pin;
+  const int* pod_class;
+  const int* perm;          // bin-pack order of the snapshot ...
+  const int* rank;
+  const u64* key0;          // ... and its score keys
+  const int* name_rank;     // NodeID order (null: node index)
+  unsigned pre, filt;
+  int row_words, all_fail;
+  i64* req;                 // [R][N] scratch copy of Requested — grows with the round (t.req points here too)
+  int* count;               // [N] scratch copy of len(Pods)
+  u64* moved_bits;          // [row_words], rank order
+  int* cursor;              // [C] -1 = not started
+  int* moved_list;          // [N]
+  u64* moved_key;           // [N] current score key of a moved node
+  int* n_moved;             // carried between the launches of one round
+  int* out;                 // [round] node index, -1 = no node fits
+};
+__device__ __forceinline__ void load_node_live(const NodeTable& t, int n, NodeRegs* r) {
+  load_node(t, n, r);  // immutable columns (the stale-prone ones are overwritten below)
+#pragma unroll
+  for (int i = 0; i < kMaxR; ++i)
+    if (i < t.R) r->fr[i] = t.alloc[(size_t)i * t.n + n] - ld_live(t.req + (size_t)i * t.n + n);
+  r->slots_ok = (i64)ld_live(t.count + n) + 1 <= (i64)t.allowed[n];
+}
+__global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable s, ClassTable ct, Planes ranked, RoundArgs a) {
+  const int lane = threadIdx.x;
+  int n_moved = ld_live(a.n_moved);
+  const bool name_on = a.filt & kPlugNodeName;
+  const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
+  int p_l = 0, spec_l = 0, pin_l = -1, cls_l = 0;
+  for (int i = 0; i < a.n_asks; ++i) {
+    if ((i & (kWave - 1)) == 0) {  // the headers of the next 64 asks, one load round
+      const int j = i + lane;
+      if (j < a.n_asks) {
+        p_l = a.asks[a.first + j];
+        spec_l = a.pod_spec[p_l];
+        pin_l = a.pod_pin[p_l];
+        cls_l = a.pod_class[p_l];
+      }
+    }
+    const int spec = __builtin_amdgcn_readlane(spec_l, i & (kWave - 1)), cls = __builtin_amdgcn_readlane(cls_l, i & (kWave - 1));
+    const int pin = name_on ? __builtin_amdgcn_readlane(pin_l, i & (kWave - 1)) : -1;
+    int win = -1;
+    if (a.all_fail || pin == -2) {
+      // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
+    } else if (pin >= 0) {
+      NodeRegs nr;
+      load_node_live(t, pin, &nr);
+      int code;
+      unsigned reason;
+      if (eval_pair(s, spec, pin, pin, nr, a.pre, a.filt, &code, &reason)) win = pin;
+    } else {
+      // ---- candidate A: the first unmoved feasible node in snapshot order
+      int an = -1, at = 0;
+      u64 ak = 0;
+      {
+        const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
+        const ClassRows cr = class_rows(ranked, sr, st, sa, ss);
+        int w0 = ld_live(a.cursor + cls);
+        if (w0 < 0) w0 = cr.start;  // (kNoWord: some row of the class is empty)
+        int found_w = a.row_words;
+        for (int base = w0 < a.row_words ? (w0 & ~(kWave - 1)) : a.row_words; base < a.row_words; base += kWave) {
+          const int w = base + lane;
+          u64 x = 0;
+          if (w < a.row_words) {
+            x = ~ld_live(a.moved_bits + w);
+            if (x) x &= class_word(cr, w);
+          }
+          const u64 any = __ballot(x != 0);
+          if (any) {
+            const int fl = __ffsll((long long)any) - 1;
+            const u64 xw = __shfl(x, fl, kWave);
+            an = a.perm[(base + fl) * kWave + (__ffsll((long long)xw) - 1)];
+            found_w = base + fl;
+            break;
+          }
+        }
+        if (lane == 0) st_live(a.cursor + cls, found_w);
+        if (an >= 0) {
+          ak = a.key0[an];
+          at = a.name_rank ? a.name_rank[an] : an;
+        }
+      }
+      // ---- candidate B: the best moved node, per pair from the live tables
+      u64 bk = ~0ull;
+      int bt = 0x7fffffff, bn = -1;
+      for (int j0 = 0; j0 < n_moved; j0 += kWave) {
+        const int j = j0 + lane;
+        if (j < n_moved) {
+          const int m = ld_live(a.moved_list + j);
+          NodeRegs nr;
+          load_node_live(t, m, &nr);
+          int code;
+          unsigned reason;
+          if (eval_pair(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) {
+            const u64 k = ld_live(a.moved_key + m);
+            const int tie = a.name_rank ? a.name_rank[m] : m;
+            if (k < bk || (k == bk && tie < bt)) {
+              bk = k;
+              bt = tie;
+              bn = m;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const u64 ok = __shfl_xor(bk, off, kWave);
+        const int ot = __shfl_xor(bt, off, kWave), on = __shfl_xor(bn, off, kWave);
+        if (on >= 0 && (bn < 0 || ok < bk || (ok == bk && ot < bt))) {
+          bk = ok;
+          bt = ot;
+          bn = on;
+        }
+      }
+      win = (an >= 0 && (bn < 0 || ak < bk || (ak == bk && at < bt))) ? an : bn;
+    }
+    if (lane == 0) a.out[a.first + i] = win;
+    if (win < 0) continue;  // (wave-uniform)
+    // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod)
+    i64 used[2] = {0, 0};
+    for (int r = 0; r < t.R; ++r) {
+      const i64 v = ld_live(a.req + (size_t)r * t.n + win) + s.req[(size_t)spec * s.R + r];
+      if (r < 2) used[r] = v;
+      if (lane == 0) st_live(a.req + (size_t)r * t.n + win, v);
+    }
+    const int cnt = ld_live(a.count + win) + 1;
+    if (lane == 0) st_live(a.count + win, cnt);
+    const i64 total[2] = {t.alloc[win], t.alloc[(size_t)t.n + win]};
+    if (lane == 0) st_live(a.moved_key + win, sortable_key(node_score_of(total, used)));
+    const int rk = a.rank[win];
+    const bool was_moved = (ld_live(a.moved_bits + (rk >> 6)) >> (rk & 63)) & 1ull;
+    const bool dead = fit_on && (i64)cnt + 1 > (i64)t.allowed[win];  // no pod slot left: no ask of this phase fits it any more
+    if (!was_moved) {
+      if (lane == 0) atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
+      if (!dead) {
+        if (lane == 0) st_live(a.moved_list + n_moved, win);
+        ++n_moved;
+      }
+    } else if (dead) {
+      // leaves the list: its slot is taken by the last entry
+      int at_l = -1;
+      for (int j0 = 0; j0 < n_moved && at_l < 0; j0 += kWave) {
+        const int j = j0 + lane;
+        const u64 hit = __ballot(j < n_moved && ld_live(a.moved_list + j) == win);
+        if (hit) at_l = j0 + __ffsll((long long)hit) - 1;
+      }
+      if (at_l >= 0) {
+        const int last = ld_live(a.moved_list + n_moved - 1);
+        if (lane == 0) st_live(a.moved_list + at_l, last);
+        --n_moved;
+      }
+    }
+    __threadfence();
+  }
+  if (lane == 0) st_live(a.n_moved, n_moved);
 }
 
 // order-independent checksum of the bitmap: Σ mix64(word ⊕ position-salt) over the meaningful words

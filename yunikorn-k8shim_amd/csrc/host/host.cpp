@@ -137,6 +137,7 @@ struct ykhost {
   int64_t last_encode_us = 0;
   int64_t unsupported_asks = 0;    // asks whose template the encoder marked unsupported at the last full encode
   int64_t routed_to_cpu = 0;
+  int64_t rounds_on_device = 0, round_asks_on_device = 0, round_asks_one_by_one = 0, round_asks_routed = 0;
   int64_t dictionary_growths = 0;  // new asks whose selector requirements were added to the dictionaries in place
   // label key → value → nodes carrying it (built on the first dictionary growth, dropped whenever a node object changes): a
   // new requirement bit is then computed per DISTINCT value of its key instead of per node
@@ -1714,6 +1715,7 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
     ykpred_eval_args_t b = a;
     b.options = (options & ~(uint32_t)YKPRED_OUT_BITMAP) | YKPRED_EVAL_SKIP_BITMAP;
     rc = ykpred_eval(h->eng, &b);
+    if (rc == YKPRED_E_STATE) return ykhost_evaluate(h, allocate, options);  // (the pod classes were due for a rebuild: full pass)
     if (rc) return fail(h, std::string("ykpred_eval: ") + ykpred_last_error(h->eng), rc);
   }
   // A node-sharded engine with topology constraints: the histograms couple the shards, so the step is COLLECTIVE — every
@@ -1724,6 +1726,10 @@ int32_t ykhost_evaluate_dirty(ykhost_t* h, int32_t allocate, uint32_t options, i
   // hosts that carry the histograms between the shards themselves (no communicator) split the step in two calls:
   // YKPRED_EVAL_SPREAD_COUNT_ONLY (this shard's histograms are rebuilt, nothing else happens yet), then ..._COUNTS_READY
   const bool two_phase = options & (YKPRED_EVAL_SPREAD_COUNT_ONLY | YKPRED_EVAL_SPREAD_COUNTS_READY);
+  // The mirrored class rows only survive purely column-local patches of THIS host's own nodes: with topology constraints the
+  // engine rewrites whole rows of every class whose histograms moved — on a sharded cluster also for a node of another shard,
+  // which this host's touch_node never saw.
+  if (h->enc.KD > 0 || collective_step || two_phase) h->resident.valid = false;
   if (nodes_touched || collective_step || two_phase) {
     int32_t none = 0;
     rc = ykpred_eval_nodes(h->eng, &a, (int32_t)h->eval_dirty_nodes.size(), h->eval_dirty_nodes.empty() ? &none : h->eval_dirty_nodes.data());
@@ -1915,6 +1921,96 @@ int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k,
     if ((row[(size_t)(n >> 6)] >> (n & 63)) & 1ull) out_nodes[found++] = n;
   }
   return found;
+}
+
+// One scheduling round with conflict-resolved decisions. See ykhost.h.
+int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32_t apply, int32_t* out_nodes) {
+  YKHOST_LOCKED(h);
+  if (n < 0 || (n > 0 && !out_nodes)) return fail(h, "bad argument", -1);
+  const uint32_t want = YKPRED_OUT_BITMAP | YKPRED_OUT_COUNTS | YKPRED_OUT_DECISIONS;
+  // a current evaluation with decisions (column / row patches where they suffice)
+  int rc = ykhost_evaluate_dirty(h, 1, want, nullptr);
+  if (rc) return rc;
+  const int P = (int)h->pending.size();
+  std::vector<int32_t> list, slot;  // asks of the round that the engine evaluates, and their position in `asks`
+  list.reserve((size_t)n);
+  slot.reserve((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const int row = asks ? asks[i] : i;
+    if (row < 0 || row >= P) return fail(h, "ask index out of range", -1);
+    Pod* p = h->pending[(size_t)row];
+    out_nodes[i] = -1;
+    if (h->enc.unsupported.count(p->tpl)) {
+      out_nodes[i] = -2;
+      h->round_asks_routed++;
+    } else if (p->assumed) {  // allocated by an earlier round and not bound yet: it keeps its node
+      auto nt = h->node_ix.find(p->node_name);
+      out_nodes[i] = nt == h->node_ix.end() ? -1 : nt->second;
+    } else {
+      list.push_back(row);
+      slot.push_back(i);
+    }
+  }
+  auto assume = [&](Pod* p, int node) {  // ykhost_assume_pod without the two name lookups
+    detach_from_node(h, p);
+    p->node_name = h->nodes[(size_t)node]->node.name;
+    cache_update_pod(h, p, p, false, false);
+    p->assumed = true;
+  };
+  int placed = 0;
+  if (list.empty()) return 0;
+  std::vector<int32_t> got(list.size(), -1);
+  rc = ykpred_allocate_round(h->eng, h->alloc_pre, h->alloc_filt, (int32_t)list.size(), list.data(), got.data());
+  if (rc == YKPRED_E_STATE) {
+    // the patched evaluation is current but its rank-ordered planes are not (e.g. a template was appended since the last
+    // decision pass): one full pass, then the round
+    rc = ykhost_evaluate(h, 1, want);
+    if (rc) return rc;
+    rc = ykpred_allocate_round(h->eng, h->alloc_pre, h->alloc_filt, (int32_t)list.size(), list.data(), got.data());
+  }
+  if (rc == YKPRED_OK) {
+    h->rounds_on_device++;
+    h->round_asks_on_device += (int64_t)list.size();
+    ensure_uid_index(h);
+    for (size_t k = 0; k < list.size(); ++k) {
+      out_nodes[(size_t)slot[k]] = got[k];
+      if (got[k] < 0) continue;
+      ++placed;
+      if (apply) assume(h->pending[(size_t)list[k]], got[k]);
+    }
+    return placed;
+  }
+  if (rc != YKPRED_E_UNSUPPORTED) return fail(h, std::string("ykpred_allocate_round: ") + ykpred_last_error(h->eng), rc);
+  // ---- ask by ask: something other than node resources couples the asks (topology histograms, host ports, shards)
+  if (!apply) return fail(h, std::string("this round is decided ask by ask and has to assume as it goes (apply = 1): ") + ykpred_last_error(h->eng), YKHOST_E_UNSUPPORTED);
+  ensure_uid_index(h);
+  ykpred_layout_t lay{};
+  ykpred_get_layout(h->eng, &lay);
+  std::vector<uint64_t> row_buf((size_t)std::max(lay.row_words, 1));
+  for (size_t k = 0; k < list.size(); ++k) {
+    rc = ykhost_evaluate_dirty(h, 1, want, nullptr);  // the allocations so far are columns (and topology rows) to patch
+    if (rc) return rc;
+    ykpred_get_layout(h->eng, &lay);
+    row_buf.resize((size_t)std::max(lay.row_words, 1));
+    int32_t cnt = 0, dec = -1;
+    rc = ykpred_peek_row(h->eng, list[k], h->alloc_pre, h->alloc_filt, row_buf.data(), &cnt, &dec);
+    if (rc) return fail(h, std::string("ykpred_peek_row: ") + ykpred_last_error(h->eng), rc);
+    h->round_asks_one_by_one++;
+    out_nodes[(size_t)slot[k]] = dec;
+    if (dec < 0) continue;
+    ++placed;
+    assume(h->pending[(size_t)list[k]], dec);
+  }
+  return placed;
+}
+
+int32_t ykhost_round_stats(ykhost_t* h, int64_t* out4) {
+  YKHOST_LOCKED(h);
+  out4[0] = h->rounds_on_device;
+  out4[1] = h->round_asks_on_device;
+  out4[2] = h->round_asks_one_by_one;
+  out4[3] = h->round_asks_routed;
+  return 0;
 }
 
 // out[0] = Predicates() calls answered from the mirrored resident answer, [1] = answered per pair because the node's column

@@ -320,6 +320,25 @@ class GpuPredicateManager:
         n = self._check(self._L.ykhost_candidates(self._h, p, 1 if allocate else 0, k, out.ctypes.data))
         return out[:n].copy()
 
+    def allocate_round(self, asks=None, n=None, apply=True):
+        """One scheduling round with conflict-resolved decisions (ykhost_allocate_round): ask i is decided with the earlier
+        asks of the round assumed on their nodes. asks: ask indices in decision order (None: the first n asks, default all).
+        → int32 array: node index, -1 = no node fits, -2 = routed to the CPU manager."""
+        if asks is None:
+            count = self.num_pods if n is None else int(n)
+            ptr = None
+        else:
+            arr = np.ascontiguousarray(asks, dtype=np.int32)
+            count, ptr = len(arr), arr.ctypes.data
+        out = np.full(max(count, 1), -1, dtype=np.int32)
+        self._check(self._L.ykhost_allocate_round(self._h, count, ptr, 1 if apply else 0, out.ctypes.data))
+        return out[:count].copy()
+
+    def round_stats(self):
+        out = np.zeros(4, dtype=np.int64)
+        self._L.ykhost_round_stats(self._h, out.ctypes.data)
+        return dict(zip(["rounds_on_device", "asks_on_device", "asks_one_by_one", "asks_routed"], out.tolist()))
+
     def resident_stats(self):
         out = np.zeros(5, dtype=np.int64)
         self._L.ykhost_resident_stats(self._h, out.ctypes.data)
