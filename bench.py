@@ -294,6 +294,66 @@ def json_ingest_leg(pkg, dev, a, gang):
     return out
 
 
+def allocation_round_leg(pkg, dev, big_pm=None, big_asks=2000):
+    """CONFLICT-RESOLVED decisions — the metric's second half as the reference's loop defines it: the core decides an ask, the shim
+    assumes it (context.go:828-885), the next Predicates() sees it. (a) The reference's own perf shape, scheduler_perf_test.go:62-66,
+    283-352: 5 000 empty nodes of 16 000 m / 16 G / 110 pods x 50 000 asks of 10 m / 1 M — its "allocations/s". One
+    ykhost_allocate_round call; every decision compared with the oracle run SEQUENTIALLY on one host core (timed beside it).
+    (b) A round of the first `big_asks` asks of the main workload (configs[2]: 50 000 nodes), same check."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    import _seqgen
+    out = {}
+    pm = pkg.GpuPredicateManager(device=dev.index)
+    try:
+        snap = _seqgen.perf_shape(5000, 50_000)
+        pm.load_snapshot(snap)
+        pm.evaluate(decisions=True)
+        pm.synchronize()
+        n = pm.num_pods
+        text = pm.dump_snapshot()
+        pm.allocate_round(n=64, apply=False)  # (first call: scratch allocation)
+        t0 = time.perf_counter()
+        got = pm.allocate_round(apply=False)
+        t_round = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        got2 = pm.allocate_round(apply=True)   # + the mirror's AssumePod bookkeeping for every allocation ...
+        pm.evaluate_dirty(decisions=True)      # ... and the engine brought up to date (touched node rows, columns, decisions)
+        pm.synchronize()
+        t_cycle = time.perf_counter() - t0
+        o = orc.Oracle(text)
+        t0 = time.perf_counter()
+        want = o.allocate_sequential()
+        t_cpu = time.perf_counter() - t0
+        out["reference_perf_shape"] = {
+            "nodes": 5000, "asks": int(n), "allocated": int((got >= 0).sum()),
+            "allocations_per_sec": n / t_round, "round_ms": round(t_round * 1e3, 2),
+            "allocations_per_sec_incl_mirror_and_resync": n / t_cycle, "cycle_ms": round(t_cycle * 1e3, 2),
+            "cpu_sequential_per_sec": n / t_cpu, "cpu_cores": 1, "cpu_kind": "port (oracle: per-pair Predicates() over a (score, NodeID)-ordered node set, first fit, AssumePod)",
+            "verified": bool(np.array_equal(got, want) and np.array_equal(got2, want)), "stats": pm.round_stats()}
+    finally:
+        pm.close()
+    if big_pm is not None:
+        pm = big_pm
+        pm.evaluate(decisions=True)
+        pm.synchronize()
+        asks = np.arange(min(big_asks, pm.num_pods), dtype=np.int32)
+        pm.allocate_round(asks=asks[:64], apply=False)
+        t0 = time.perf_counter()
+        got = pm.allocate_round(asks=asks, apply=False)
+        t_round = time.perf_counter() - t0
+        o = orc.Oracle(pm.dump_snapshot(pods=asks, compact=True))
+        t0 = time.perf_counter()
+        want = o.allocate_sequential()
+        t_cpu = time.perf_counter() - t0
+        out["main_workload_round"] = {"nodes": pm.num_nodes, "asks": int(len(asks)), "allocated": int((got >= 0).sum()),
+                                      "allocations_per_sec": len(asks) / t_round, "round_ms": round(t_round * 1e3, 2),
+                                      "cpu_sequential_per_sec": len(asks) / t_cpu, "cpu_cores": 1, "verified": bool(np.array_equal(got, want))}
+    out["definition"] = ("decisions/sec, conflict-resolved: ask i is decided with asks 0..i-1 of the round assumed on their nodes — identical to the "
+                         "oracle run sequentially; `decisions_per_sec` of the line is the SNAPSHOT form (every ask against one state)")
+    return out
+
+
 def predicates_callback_leg(pm, P, N):
     """The seam the core really calls — Predicates(ask, node) one pair at a time (scheduler_callback.go:203-205) — served from the
     RESIDENT answer of a current evaluation (host mirror of the class rows): wall time per call through the ctypes
@@ -611,12 +671,16 @@ def main():
         except Exception as exc:  # noqa: BLE001 - a failed CHECK must show in the line, not take it down
             verification = {"ok": False, "error": str(exc)}
     cpu = cpu_baseline(pm, a.cpu_seconds, SEED) if rank == 0 else None
-    callbacks = None
+    callbacks = rounds = None
     if rank == 0 and world == 1 and not a.no_variants and not a.direct:
         try:
             callbacks = predicates_callback_leg(pm, P, N)
         except Exception as exc:  # noqa: BLE001 — a side leg never takes the line down
             callbacks = {"error": str(exc)}
+        try:
+            rounds = allocation_round_leg(pkg, dev, big_pm=pm if not a.spread else None)
+        except Exception as exc:  # noqa: BLE001
+            rounds = {"error": str(exc)}
     stats = pm.stats()
     if use_abi:
         pm.comm_destroy()
@@ -696,6 +760,11 @@ def main():
             out["end_to_end"] = end_to_end
         if callbacks is not None:
             out["predicates_callback"] = callbacks
+        if rounds is not None:
+            out["allocation_round"] = rounds
+            shape = rounds.get("reference_perf_shape") if isinstance(rounds, dict) else None
+            if shape:
+                out["allocations_per_sec"] = shape["allocations_per_sec"]
         print(json.dumps(out))
     if dist:
         dist.barrier()

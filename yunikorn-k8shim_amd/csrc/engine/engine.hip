@@ -243,6 +243,7 @@ struct ykpred_engine {
   int res_vectors = 0;                                    // distinct request vectors (class key component)
   std::vector<i64> h_dim_val;                             // [rows]
   std::vector<int32_t> h_dim_of;                          // [rows] dimension, -1 for row 0
+  std::vector<int32_t> h_stage_rows;                      // ballot rows (not index rows) of the family, at most ykk::kWalkMaxStage
   DevBuf d_dim_val, d_dim_order, d_dim_chunk_dim, d_dim_chunk_begin, d_dim_chunk_len, d_res_rows;
   int dim_chunks = 0;
   // dimensions with >= walk_rows distinct values are evaluated by the sorted walk (k_dim_sort / k_dim_walk)
@@ -1543,6 +1544,14 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     }
     e->index_rows = 0;
     for (int32_t len : wlen) e->index_rows += len;
+    // the first ballot rows of the family (request values of the few-valued dimensions): k_walk_rows stages their slices in LDS
+    e->h_stage_rows.clear();
+    {
+      std::vector<uint8_t> walked((size_t)R, 0);
+      for (int32_t d : big_dim) walked[(size_t)d] = 1;
+      for (int d = 1; d < rows && (int)e->h_stage_rows.size() < ykk::kWalkMaxStage; ++d)
+        if (!walked[(size_t)e->h_dim_of[(size_t)d]]) e->h_stage_rows.push_back(d);
+    }
     e->dim_chunks = (int)cdim.size();
     e->n_big = (int)big_dim.size();
     e->walk_chunks = (int)wbig.size();
@@ -1960,35 +1969,35 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (!e->zone_b_first) TRY(launch_zone_a());
     tm.begin(sz);
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
-    // (the slice writer keeps the mask tables of <= 128 words per walked dimension in LDS: only where the device grants that much)
-    const bool slices = small_chunks && (e->combine_slices == 2 || (e->combine_slices == 1 && pc.n_big > 0)) &&
-                        (size_t)pc.n_big * ykk::kSliceMaxWords * 65 * sizeof(u64) <= (size_t)e->max_lds_bytes;
+    // Index rows to decode: k_walk_rows — a workgroup per slice (<= 128 words) of the row with the slice's mask tables, staged
+    // plane rows, index bytes and base words in LDS (loader / store waves). Only where the device grants that much LDS.
+    ykk::WalkGeom wg{};
+    bool slices = small_chunks && e->combine_slices != 0 && pc.n_big > 0;
     if (slices) {
-      // index rows to decode: a workgroup per slice (<= 128 words) of the row, mask tables in LDS (see k_combine_slices); the
-      // chunk descriptors are resolved first, one thread per chunk
-      const int n_slices = (e->row_stride + ykk::kSliceMaxWords - 1) / ykk::kSliceMaxWords;
-      const int slice_words = ((e->row_stride + n_slices - 1) / n_slices + 1) / 2 * 2;  // (row_stride is a multiple of 16)
-      const int per_wave = std::max(64, e->slice_chunks_per_wave / 64 * 64);
-      const int per_block = per_wave * ykk::kSliceWaves;
-      const size_t lds = (size_t)pc.n_big * (size_t)slice_words * 65 * sizeof(u64);
+      wg.n_slices = (e->row_stride + ykk::kSliceMaxWords - 1) / ykk::kSliceMaxWords;
+      wg.slice_words = ((e->row_stride + wg.n_slices - 1) / wg.n_slices + 15) / 16 * 16;  // (row_stride is a multiple of 16)
+      wg.n_stage = (int)e->h_stage_rows.size();
+      for (int k = 0; k < wg.n_stage; ++k) wg.stage_row[k] = e->h_stage_rows[(size_t)k];
+      wg.run_slots = 16;
+      // shed what is optional until the workgroup's LDS fits the device: staged plane rows first, then base slots
+      while (ykk::walk_lds_bytes(pc.n_big, wg) > (size_t)e->max_lds_bytes && wg.n_stage > 0) wg.n_stage--;
+      while (ykk::walk_lds_bytes(pc.n_big, wg) > (size_t)e->max_lds_bytes && wg.run_slots > 2) wg.run_slots /= 2;
+      slices = ykk::walk_lds_bytes(pc.n_big, wg) <= (size_t)e->max_lds_bytes;
+    }
+    if (slices) {
+      // chunk descriptors first, one thread per chunk (what a wave needs to know about a chunk, resolved once per pass)
+      const size_t lds = ykk::walk_lds_bytes(pc.n_big, wg);
+      wg.chunks_per_group = 2048;
       HIPCHK(e->d_slice_desc.ensure((size_t)std::max(e->NC, 1) * sizeof(ykk::SliceDesc)));
       HIPCHK(e->d_slice_general.ensure(sizeof(int)));
       HIPCHK(hipMemsetAsync(e->d_slice_general.p, 0, sizeof(int), sz));
       hipLaunchKernelGGL(ykk::k_slice_desc, dim3((unsigned)((e->NC + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, sz, ct, pc, e->NC, class_dirty,
                          pin_on, e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
-      const dim3 sgrid((unsigned)(((e->NC + per_block - 1) / per_block) * n_slices));
-      if (pin_on & 1) {  // (the NodeName filter is a template parameter: without it the fast path carries no pin code at all)
-        if (lds > 64 * 1024)
-          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ykk::k_combine_slices<true>, sgrid, dim3(ykk::kSliceBlock), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap,
-                           e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices, slice_words, per_wave, e->slice_mode);
-      } else {
-        if (lds > 64 * 1024)
-          HIPCHK(hipFuncSetAttribute((const void*)ykk::k_combine_slices<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(ykk::k_combine_slices<false>, sgrid, dim3(ykk::kSliceBlock), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap,
-                           e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, n_slices, slice_words, per_wave, e->slice_mode);
-      }
-      // chunks the slice writer has no fast path for (several member rows, pins to unknown nodes, other row shapes): wave per chunk
+      const dim3 sgrid((unsigned)(((e->NC + wg.chunks_per_group - 1) / wg.chunks_per_group) * wg.n_slices));
+      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ykk::k_walk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(ykk::k_walk_rows, sgrid, dim3(ykk::kWalkThreads), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words,
+                         e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, wg);
+      // chunks the fast path does not cover (several member rows, pins to unknown nodes, other row shapes): wave per chunk
       hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,
                          e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>(), (const int*)nullptr);

@@ -1314,181 +1314,196 @@ __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl,
   out[chunk] = d;
 }
 
-// a load / store at (wave-uniform base) + (32-bit lane offset in bytes): written so that the compiler keeps the base in SGPRs and
-// uses the saddr form of global_load / global_store — with 64-bit VGPR addresses the kernel spilled its base pointers to scratch,
-// and every reload waits on vmcnt(0), i.e. on every load and store issued before it
-template <typename T>
-__device__ __forceinline__ T ld_sv(const void* base, unsigned voff) {
-  return *(const T*)((const char*)base + voff);
-}
-template <typename T>
-__device__ __forceinline__ void st_sv(void* base, unsigned voff, T v) {
-  *(T*)((char*)base + voff) = v;
-}
-struct SliceCtx {
-  const Planes* pl;
-  u64* bitmap;
-  int* class_count;
-  const u64* s_pm;
-  int row_stride, tab_stride, lane, pin_enabled, mode;
-  int wq;        // this lane's word pair (0 when the pair lies outside the row: loads stay valid, nothing is stored)
-  bool st_ok;    // the pair is stored
-  unsigned voff, ioff;  // byte offset of the pair inside a plane / bitmap row (8 wq) and inside an index row (wq)
+// ---------------------------------------------------------------------------------------------------
+// k_walk_rows: the zone-B writer of populations with INDEX rows (10^6 single-member classes), loader / store waves.
+//
+// Round 3's k_combine_slices had the right data flow — a workgroup owns ONE slice (<= 128 words) of the row for a long run of
+// chunks, the 65-entry mask tables of the slice sit in LDS, index bytes and plane words arrive as coalesced streams — and the
+// wrong execution shape: every wave loaded the index bytes of a batch of 6 rows, waited a full memory round trip, decoded,
+// stored; 76 % of its wave cycles were s_waitcnt at 4 waves per SIMD (SQ counters, profiles/r03_sessions7_20_*): 2.0 ms of the
+// 3.15 ms were there with stores, atomics and decode switched OFF. Instruction count was never the limit (27 k (row, slice)
+// pairs per CU x ~140 instructions = 0.4 ms of issue). So the structure of the band writer (k_expand_bands) is applied:
+//   * ONE LOADER wave per workgroup does every global load: per block of <= 64 consecutive chunks it fetches the descriptors
+//     (coalesced), the slice's index bytes of every row (lane = row: <= 8 x 16 bytes, written to LDS as the row's byte string),
+//     and — per RUN of rows with the same cached rows (toleration / affinity / spread signature, pod-independent request row) —
+//     the AND of those rows' slice words ("base", lane = word pair), all into the LDS buffer of the NEXT block;
+//   * the STORE waves never load from global memory: per row one LDS read of its two index bytes, two LDS reads of the mask
+//     tables, one of the run's base words, one of the row's staged request-value plane (the ballot rows of the request family
+//     are staged once per workgroup), AND, popcount, one 16-byte store. Their vmcnt only ever counts stores;
+//   * one s_barrier per block joins them.
+// Chunks without this fast path (several member rows, a pinned unknown node, two index rows, more than two plane rows) are
+// left to k_combine_wave through the descriptor filter, as before.
+constexpr int kWalkStoreWaves = 12;
+constexpr int kWalkThreads = (kWalkStoreWaves + 1) * kWave;
+constexpr int kWalkBlockRows = 64;   // rows (chunks) per block: lane j of the loader = row j
+constexpr int kWalkMaxStage = 16;    // ballot rows of the request family staged in LDS
+struct WalkGeom {
+  int n_slices, slice_words;   // slice_words: multiple of 16 (index bytes travel in 16-byte pieces), <= kSliceMaxWords
+  int run_slots;               // distinct cached-row keys per block (a block ends early when they run out)
+  int chunks_per_group;        // chunks one workgroup walks
+  int n_stage;                 // staged plane rows ...
+  int stage_row[kWalkMaxStage];  // ... their row ids in the request family
 };
-struct SliceBuf {
-  u64x2_t v[kSliceBatch];
-  unsigned short two[kSliceBatch];  // (kept 16 bits wide: a widening right after the load would wait for it)
+struct WalkRow {  // what a store wave needs to know about a row of the block (LDS)
+  int dest, cls, slot, stage;    // bitmap row; class; base slot of the row's run, -1 = row not on the fast path; staged plane slot or -1
+  int prow, pin, big, pad;       // per-row plane row when it is not staged (-1: none); pinned node (-1: none); walked dimension
 };
-// loads of one batch: chunks i0 .. i0 + n - 1 of the wave's window, NP = they carry a per-chunk plane row; FULL = n is the batch
-// size (no guard per slot: most batches are full, and 18 scalar branches per chunk were a fifth of the kernel's instructions)
-template <int NP, bool FULL>
-__device__ __forceinline__ void slice_issue(const SliceCtx& cx, int i0, int n, int prow_l, int irow_l, SliceBuf& buf) {
-  const Planes& pl = *cx.pl;
-#pragma unroll
-  for (int j = 0; j < kSliceBatch; ++j) {
-    if (FULL || j < n) {
-      const int c = i0 + j;
-      if (NP) buf.v[j] = ld_sv<u64x2_t>(pl.res + (size_t)__builtin_amdgcn_readlane(prow_l, c) * pl.stride, cx.voff);
-      const int rid = __builtin_amdgcn_readlane(irow_l, c) & ((1 << kRowBigShift) - 1);
-      buf.two[j] = ld_sv<unsigned short>(pl.res_idx + (size_t)rid * pl.idx_stride, cx.ioff);  // index bytes of the pair
-    }
-  }
+// dynamic LDS: [pmask n_big x sw x 65 u64][stage n_stage x sw u64][base 2 x run_slots x sw u64][idx 2 x 64 x sw bytes][rows 2 x 64 WalkRow][hdr 2 x int4]
+__host__ __device__ inline size_t walk_lds_bytes(int n_big, const WalkGeom& g) {
+  const size_t sw = (size_t)g.slice_words;
+  return (size_t)n_big * sw * 65 * 8 + (size_t)g.n_stage * sw * 8 + (size_t)2 * g.run_slots * sw * 8 + (size_t)2 * kWalkBlockRows * sw +
+         (size_t)2 * kWalkBlockRows * sizeof(WalkRow) + 2 * 16;
 }
-// masks, feasible counts and stores of a batch whose loads were issued by slice_issue<NP, FULL>. Two passes — every mask first,
-// then the counts and stores: the first pass touches every loaded register, so the compiler waits ONCE for the batch's loads;
-// with decode and store interleaved per chunk it put a full `s_waitcnt vmcnt(0)` in front of every chunk (the guards make its
-// counting conservative), i.e. every chunk waited for the previous chunk's store to land. Every chunk here is a single-row
-// first chunk with a live member (k_slice_desc sends the others the general way): no test for any of that.
-template <int NP, bool FULL, bool PIN>
-__device__ __forceinline__ void slice_finish(const SliceCtx& cx, int i0, int n, u64x2_t w_base, int cls_l, int pin_l, int mem0_l, int irow_l,
-                                             SliceBuf& buf) {
-#pragma unroll
-  for (int j = 0; j < kSliceBatch; ++j) {
-    if (FULL || j < n) {
-      const int c = i0 + j;
-      u64x2_t x = w_base;
-      if (NP) x &= buf.v[j];
-      const int big = (__builtin_amdgcn_readlane(irow_l, c) >> kRowBigShift) - 1;
-      const u64* tab = cx.s_pm + big * cx.tab_stride + (2 * cx.lane) * 65;
-      const unsigned two = buf.two[j];
-      x.x &= tab[two & 0xffu];
-      x.y &= tab[65 + (two >> 8)];
-      if (PIN) {
-        const int pin = __builtin_amdgcn_readlane(pin_l, c);
-        if (pin >= 0) {
-          x.x &= (cx.wq == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-          x.y &= (cx.wq + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-        }
-      }
-      buf.v[j] = x;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kSliceBatch; ++j) {
-    if (FULL || j < n) {
-      const int c = i0 + j;
-      const u64x2_t x = buf.v[j];
-      const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));  // (idle lanes and padding words hold zeros: `keep`)
-      if (cx.lane == 63 && pc) atomicAdd(&cx.class_count[__builtin_amdgcn_readlane(cls_l, c)], pc);
-      if (cx.st_ok) st_sv<u64x2_t>(cx.bitmap + (size_t)__builtin_amdgcn_readlane(mem0_l, c) * cx.row_stride, cx.voff, x);
-    }
-  }
-}
-
-// grid.x = chunk batches x n_slices (consecutive workgroups take consecutive slices of the same chunks); dynamic LDS =
-// n_big * slice_words * 520 bytes. slice_words is even; lane l owns the word pair slice * slice_words + 2 l while 2 l < slice_words.
-template <bool PIN>
-__global__ __launch_bounds__(kSliceBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_combine_slices(
-    Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled,
-    int* __restrict__ class_count, int n_chunks, int n_slices, int slice_words, int chunks_per_wave,
-    int mode /* experiments, timing only: 1 = no stores, 16 = cached rows never reloaded */) {
+__global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words,
+                                                            int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
+                                                            WalkGeom g) {
   typedef u64x2_t u64x2;
-  extern __shared__ u64 s_pm[];  // [n_big][slice_words][65]
+  extern __shared__ u64 walk_lds[];
+  const int sw = g.slice_words;
+  u64* s_pm = walk_lds;                                                  // [n_big][sw][65]
+  u64* s_stage = s_pm + (size_t)pl.n_big * sw * 65;                      // [n_stage][sw]
+  u64* s_base = s_stage + (size_t)g.n_stage * sw;                        // [2][run_slots][sw]
+  unsigned char* s_idx = (unsigned char*)(s_base + (size_t)2 * g.run_slots * sw);  // [2][64][sw]
+  WalkRow* s_rows = (WalkRow*)(s_idx + (size_t)2 * kWalkBlockRows * sw);  // [2][64]
+  int* s_hdr = (int*)(s_rows + 2 * kWalkBlockRows);                      // [2][4]: rows of the block
   const bool all_fail = pin_enabled & 2;
-  pin_enabled &= 1;
-  const int slice = blockIdx.x % n_slices, batch = blockIdx.x / n_slices;
+  const bool pin_on = pin_enabled & 1;
+  const int slice = blockIdx.x % g.n_slices, group = blockIdx.x / g.n_slices;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int tab_stride = slice_words * 65;
-  if (pl.n_big > 0) {
-    const int cnt = max(min(slice_words, pl.n_words - slice * slice_words), 0) * 65;
+  const int w_first = slice * sw;  // first row word of the slice
+  // ---- once per workgroup: the mask tables and the staged plane rows of the slice
+  {
+    const int cnt = max(min(sw, pl.n_words - w_first), 0) * 65;
     for (int b = 0; b < pl.n_big; ++b) {
-      const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)slice * slice_words) * 65;
-      for (int i = threadIdx.x; i < tab_stride; i += kSliceBlock) s_pm[b * tab_stride + i] = i < cnt ? src[i] : 0ull;
+      const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)w_first) * 65;
+      for (int i = threadIdx.x; i < sw * 65; i += kWalkThreads) s_pm[(size_t)b * sw * 65 + i] = i < cnt ? src[i] : 0ull;
     }
-    __syncthreads();
+    for (int k = 0; k < g.n_stage; ++k) {
+      const u64* src = pl.res + (size_t)g.stage_row[k] * pl.stride + w_first;
+      for (int i = threadIdx.x; i < sw; i += kWalkThreads) s_stage[(size_t)k * sw + i] = w_first + i < row_words ? src[i] : 0ull;
+    }
   }
-  const int c_begin = (batch * kSliceWaves + wave) * chunks_per_wave;
-  const int c_end = min(c_begin + chunks_per_wave, n_chunks);
-  // this lane's word pair; a pair past the slice or the row loads from the row's first words, holds zeros and stores nothing
-  const int w_true = slice * slice_words + 2 * lane;
-  const bool in_row = 2 * lane < slice_words && w_true < row_stride;
-  const u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};  // padding stays zero
-  SliceCtx cx{&pl, bitmap, class_count, s_pm, row_stride, tab_stride, lane, pin_enabled, mode, in_row ? w_true : 0, in_row && !(mode & 1), 0u, 0u};
-  cx.voff = (unsigned)cx.wq * 8u;
-  cx.ioff = (unsigned)cx.wq;
-  // AND of the cached rows' words of the current key (wave-uniform; -3 = nothing cached)
-  int cur_st = -3, cur_sa = -3, cur_ss = -3, cur_p0 = -3;
-  u64x2 w_base = keep;
-  SliceBuf buf;
-  for (int c0 = c_begin; c0 < c_end; c0 += kWave) {
-    // lane j holds the descriptor of chunk c0 + j
-    int cls_l = 0, meta_l = 0, pin_l = -1, mem0_l = -1, st_l = -1, sa_l = -1, ss_l = -1, p0_l = -1, prow_l = 0, irow_l = 1 << kRowBigShift;
-    if (c0 + lane < c_end) {
+  const int c_begin = group * g.chunks_per_group, c_end = min(c_begin + g.chunks_per_group, n_chunks);
+  // this lane's word pair (store waves, and the loader's base words); pairs past the slice or the row hold zeros and store nothing
+  const int w_true = w_first + 2 * lane;
+  const bool in_row = 2 * lane < sw && w_true < row_stride;
+  const u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};
+  const unsigned voff = in_row ? (unsigned)w_true * 8u : 0u;  // byte offset of the pair in a plane / bitmap row
+  const bool loader = wave == kWalkStoreWaves;
+
+  // The loader fills buffer `buf` with the block that starts at chunk c0; returns nothing (the block's row count goes to s_hdr).
+  auto fill = [&](int buf, int c0) {
+    int n_rows = max(min(kWalkBlockRows, c_end - c0), 0);
+    int cls = 0, meta = 0, pin = -1, mem0 = -1, st = -1, sa = -1, ss = -1, p0 = -1, prow = -1, irow = 1 << kRowBigShift;
+    if (lane < n_rows) {
       const int4* dp = (const int4*)(desc + c0 + lane);
       const int4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
-      cls_l = d0.x, meta_l = d0.y, pin_l = d0.z, mem0_l = d0.w;
-      st_l = d1.x, sa_l = d1.y, ss_l = d1.z, p0_l = d1.w;
-      prow_l = d2.x, irow_l = d2.y;
+      cls = d0.x, meta = d0.y, pin = d0.z, mem0 = d0.w;
+      st = d1.x, sa = d1.y, ss = d1.z, p0 = d1.w;
+      prow = (meta & kSlicePlane) ? d2.x : -1;
+      irow = d2.y;
     }
-    const bool act = meta_l & kSliceLive;
-    // chunk j continues the batch of chunk j - 1: both live on the fast path with the same cached rows and shape
-    const int key_l = act ? (meta_l & (kSliceGeneral | kSlicePlane)) : -1;
-    const bool cont_l = lane > 0 && act && !(meta_l & kSliceGeneral) && __shfl_up(key_l, 1, kWave) == key_l && __shfl_up(st_l, 1, kWave) == st_l &&
-                        __shfl_up(sa_l, 1, kWave) == sa_l && __shfl_up(ss_l, 1, kWave) == ss_l && __shfl_up(p0_l, 1, kWave) == p0_l;
-    const u64 cont = __ballot(cont_l);
-    u64 todo = __ballot(act);
-    while (todo) {
-      const int i0 = __ffsll((long long)todo) - 1;
-      const int st = __builtin_amdgcn_readlane(st_l, i0), sa = __builtin_amdgcn_readlane(sa_l, i0), ss = __builtin_amdgcn_readlane(ss_l, i0);
-      const int meta0 = __builtin_amdgcn_readlane(meta_l, i0);
-      if (meta0 & kSliceGeneral) {  // not this kernel's: k_combine_wave writes the chunks the descriptors mark `general`
-        todo &= todo - 1;
-        continue;
-      }
-      // the batch: i0 and the chunks after it that continue it
-      const u64 stops = i0 < 63 ? ~(cont >> (i0 + 1)) : ~0ull;
-      const int n = min(kSliceBatch, (int)__ffsll((long long)stops));
-      todo &= ~(((1ull << n) - 1ull) << i0);
-      // cached rows of a new key: their loads go out TOGETHER with the batch's loads, one wait serves both
-      const int p0 = __builtin_amdgcn_readlane(p0_l, i0);
-      const bool changed = (st != cur_st || sa != cur_sa || ss != cur_ss || p0 != cur_p0) && !((mode & 16) && cur_st != -3);
-      u64x2 t_tol = keep, t_aff = keep, t_spread = keep, t_p0 = keep;
-      if (changed) {
-        cur_st = st, cur_sa = sa, cur_ss = ss, cur_p0 = p0;
-        if (pl.tol && st >= 0) t_tol = ld_sv<u64x2>(pl.tol + (size_t)st * pl.stride, cx.voff);
-        if (pl.aff && sa >= 0) t_aff = ld_sv<u64x2>(pl.aff + (size_t)sa * pl.stride, cx.voff);
-        if (pl.spread && ss >= 0) t_spread = ld_sv<u64x2>(pl.spread + (size_t)ss * pl.stride, cx.voff);
-        if (pl.res && p0 >= 0) t_p0 = ld_sv<u64x2>(pl.res + (size_t)p0 * pl.stride, cx.voff);
-      }
-      const bool full = n == kSliceBatch;
-      // (scheduling fences: without them the compiler folds the cached rows' words BEFORE the batch's loads are issued — it frees
-      // 16 registers that way — and the kernel pays a second memory round trip per batch; session 19)
-      __builtin_amdgcn_sched_barrier(0);
-      if (meta0 & kSlicePlane) {
-        if (full) slice_issue<1, true>(cx, i0, n, prow_l, irow_l, buf); else slice_issue<1, false>(cx, i0, n, prow_l, irow_l, buf);
-      } else {
-        if (full) slice_issue<0, true>(cx, i0, n, prow_l, irow_l, buf); else slice_issue<0, false>(cx, i0, n, prow_l, irow_l, buf);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (changed) w_base = all_fail ? u64x2{0, 0} : (keep & t_tol & t_aff & t_spread & t_p0);
-      if (meta0 & kSlicePlane) {
-        if (full) slice_finish<1, true, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
-        else slice_finish<1, false, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
-      } else {
-        if (full) slice_finish<0, true, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
-        else slice_finish<0, false, PIN>(cx, i0, n, w_base, cls_l, pin_l, mem0_l, irow_l, buf);
+    const bool fast = (meta & (kSliceLive | kSliceGeneral)) == kSliceLive;
+    // runs: a fast row starts one when no fast row precedes it in the block or its cached rows differ from the previous fast row's
+    const u64 fast_m = __ballot(fast);
+    const u64 below = fast_m & ((1ull << lane) - 1ull);
+    const int prev = below ? 63 - __clzll((long long)below) : lane;
+    const bool change = fast && (below == 0 || __shfl(st, prev, kWave) != st || __shfl(sa, prev, kWave) != sa || __shfl(ss, prev, kWave) != ss ||
+                                 __shfl(p0, prev, kWave) != p0);
+    u64 change_m = __ballot(change);
+    int run = __popcll(change_m & ((2ull << lane) - 1ull)) - 1;  // (lane 63: 2 << 63 wraps to 0, - 1 = all ones)
+    if (__popcll(change_m) > g.run_slots) {
+      // out of base slots: the block ends in front of the row that would start run number run_slots
+      u64 m = change_m;
+      for (int k = 0; k < g.run_slots; ++k) m &= m - 1;
+      n_rows = __ffsll((long long)m) - 1;
+      change_m &= (1ull << n_rows) - 1ull;
+    }
+    const int n_runs = __popcll(change_m);
+    // row records
+    if (lane < n_rows) {
+      int stage = -1;
+      if (fast && prow >= 0)
+        for (int k = 0; k < g.n_stage; ++k)
+          if (g.stage_row[k] == prow) stage = k;
+      WalkRow r;
+      r.dest = mem0;
+      r.cls = cls;
+      r.slot = fast ? run : -1;
+      r.stage = stage;
+      r.prow = stage >= 0 ? -1 : prow;
+      r.pin = pin_on ? pin : -1;
+      r.big = (irow >> kRowBigShift) - 1;
+      r.pad = 0;
+      s_rows[buf * kWalkBlockRows + lane] = r;
+    }
+    // index bytes of the slice, lane = row: 16-byte pieces of the row's byte string (sw is a multiple of 16, so is idx_stride)
+    if (lane < n_rows && fast) {
+      const unsigned char* src = pl.res_idx + (size_t)(irow & ((1 << kRowBigShift) - 1)) * pl.idx_stride;
+      unsigned char* dst = s_idx + ((size_t)buf * kWalkBlockRows + lane) * sw;
+      for (int k = 0; k < sw; k += 16) {
+        uint4 v = {0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u};  // 64 = the empty entry of a mask table
+        if (w_first + k < pl.idx_stride) v = *(const uint4*)(src + w_first + k);
+        *(uint4*)(dst + k) = v;
       }
     }
+    // base words of every run, lane = word pair
+    for (int r = 0; r < n_runs; ++r) {
+      u64 m = change_m;
+      for (int k = 0; k < r; ++k) m &= m - 1;
+      const int lead = __ffsll((long long)m) - 1;
+      const int rst = __builtin_amdgcn_readlane(st, lead), rsa = __builtin_amdgcn_readlane(sa, lead), rss = __builtin_amdgcn_readlane(ss, lead),
+                rp0 = __builtin_amdgcn_readlane(p0, lead);
+      u64x2 b = keep;
+      if (all_fail) b = u64x2{0, 0};
+      if (pl.tol && rst >= 0) b &= *(const u64x2*)((const char*)(pl.tol + (size_t)rst * pl.stride) + voff);
+      if (pl.aff && rsa >= 0) b &= *(const u64x2*)((const char*)(pl.aff + (size_t)rsa * pl.stride) + voff);
+      if (pl.spread && rss >= 0) b &= *(const u64x2*)((const char*)(pl.spread + (size_t)rss * pl.stride) + voff);
+      if (pl.res && rp0 >= 0) b &= *(const u64x2*)((const char*)(pl.res + (size_t)rp0 * pl.stride) + voff);
+      if (2 * lane < sw) *(u64x2*)(s_base + ((size_t)buf * g.run_slots + r) * sw + 2 * lane) = b;
+    }
+    if (lane == 0) s_hdr[buf * 4] = n_rows;
+  };
+
+  if (loader) fill(0, c_begin);
+  __syncthreads();
+  int buf = 0, c0 = c_begin;
+  for (;;) {
+    const int n_rows = s_hdr[buf * 4];
+    if (n_rows == 0) break;  // (the same value for every thread: written before the barrier)
+    if (loader) {
+      fill(buf ^ 1, c0 + n_rows);
+    } else {
+      for (int i = wave; i < n_rows; i += kWalkStoreWaves) {
+        const WalkRow r = s_rows[buf * kWalkBlockRows + i];  // (every lane reads the same record: an LDS broadcast)
+        const int slot = __builtin_amdgcn_readfirstlane(r.slot);
+        if (slot < 0) continue;
+        const int dest = __builtin_amdgcn_readfirstlane(r.dest), cls = __builtin_amdgcn_readfirstlane(r.cls);
+        const int stage = __builtin_amdgcn_readfirstlane(r.stage), prow = __builtin_amdgcn_readfirstlane(r.prow);
+        const int pin = __builtin_amdgcn_readfirstlane(r.pin), big = __builtin_amdgcn_readfirstlane(r.big);
+        u64x2 x = {0, 0};
+        if (2 * lane < sw) {
+          const unsigned two = *(const unsigned short*)(s_idx + ((size_t)buf * kWalkBlockRows + i) * sw + 2 * lane);
+          const u64* tab = s_pm + ((size_t)big * sw + 2 * lane) * 65;
+          x = *(const u64x2*)(s_base + ((size_t)buf * g.run_slots + slot) * sw + 2 * lane);
+          x.x &= tab[two & 0xffu];
+          x.y &= tab[65 + (two >> 8)];
+          if (stage >= 0) x &= *(const u64x2*)(s_stage + (size_t)stage * sw + 2 * lane);
+        }
+        if (prow >= 0) x &= *(const u64x2*)((const char*)(pl.res + (size_t)prow * pl.stride) + voff);  // (a plane row that is not staged)
+        if (pin >= 0) {
+          x.x &= (w_true == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+          x.y &= (w_true + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+        }
+        if (!in_row) x = u64x2{0, 0};
+        const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));
+        if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+        if (in_row) *(u64x2*)((char*)(bitmap + (size_t)dest * row_stride) + voff) = x;
+      }
+    }
+    __syncthreads();
+    c0 += n_rows;
+    buf ^= 1;
   }
 }
 
