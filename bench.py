@@ -64,7 +64,6 @@ def parse_args():
                     help="N>1: all-gather the P-row shard bitmaps themselves over xGMI instead of their class rows + local expansion")
     ap.add_argument("--direct", action="store_true", help="time the per-pair kernel instead of the plane/class path")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--variant", type=int, default=0, help="k_combine store flavour (0 dwordx4, 1 dwordx2, 2/3 = non-temporal)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps run with per-kernel HIP events for `roofline`")
     ap.add_argument("--no-variants", action="store_true", help="N=1: skip the `variants` and `end_to_end` legs")
     ap.add_argument("--variant-steps", type=int, default=5)
@@ -207,7 +206,7 @@ def profile_kernels(pm, run_step, n):
     return {k: float(np.mean(v)) for k, v in kern.items()}
 
 
-BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_direct")
+BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_walk_rows", "k_direct")
 
 
 def measured_traffic(workload, pods, nodes):
@@ -550,7 +549,7 @@ def main():
         if world > 1:
             stream.wait_event(exchanged[b])  # the eval below overwrites set b: its previous exchange must be done
         pm.evaluate_into(bitmap=bitmaps[b], counts=counts, decisions=decisions, keys=keys if world > 1 else None,
-                         stream=stream.cuda_stream, profile=profile, direct=a.direct, variant=a.variant)
+                         stream=stream.cuda_stream, profile=profile, direct=a.direct)
         if world > 1:
             evaluated = torch.cuda.Event()
             evaluated.record(stream)

@@ -115,8 +115,8 @@ typedef struct ykpred_config {
                                request values per resource dimension from which the sorted-walk plane kernels are used (256);
                                [5] = average members per combine chunk below which the wave-per-chunk combine runs (16, -1 never);
                                [6] = band height of the zone-A row layout in windows (4..256, multiple of 4; 0 = chosen from the row
-                               length so that classes of ~100 asks still get band rows; -1 = no band layout);
-                               [7] == 2 runs the class-by-class writer BESIDE the band writer on a third stream (measured slower) */
+                               length so that classes of ~100 asks still get band rows; -1 = no band layout); [7] unused.
+                               The tests force paths through the environment instead: YKPRED_TUNE="walk_rows=1,sig_wpl=2,..." */
 } ykpred_config_t;
 
 /* Node table, structure-of-arrays. Arrays documented [A][count] are A consecutive runs of `count` values. */
@@ -198,8 +198,6 @@ typedef struct ykpred_pods {
                                                       counts are already current (used by ykpred_eval_nodes) */
 #define YKPRED_EVAL_DIRTY_CLASSES (1u << 13)       /* internal (ykpred_eval_nodes): rewrite only the rows of classes whose topology
                                                       signature changed (flagged on the device), keep every other row */
-#define YKPRED_EVAL_STORE_VARIANT_SHIFT 16         /* bits 16-17: experimental k_combine store flavour (0 = dwordx4, default;
-                                                      1 = dwordx2; 2/3 = the same non-temporal) — measured equal, DESIGN.md §4 */
 
 typedef struct ykpred_eval_args {
   uint32_t prefilter_plugins; /* enabled PreFilter plugins (YKPRED_PLUGIN_* bits) */

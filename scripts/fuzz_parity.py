@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU vs oracle) beyond the seeds baked into tests/: full grid, both phases, fit bits,
 failing plugin, counts, decisions; every feature of tests/_gen.py switched on. Engine tunables come from the environment
-(YKPRED_WALK_ROWS=1 turns every request dimension with a value into index rows: sorted walk, slice writer, prefix-max start of
+(YKPRED_TUNE=walk_rows=1 turns every request dimension with a value into index rows: sorted walk, slice writer, prefix-max start of
 the decision scan). Usage: python scripts/fuzz_parity.py [first] [count]"""
 import importlib
 import os

@@ -17,7 +17,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r03"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKLOADS = ("default", "own_template_per_ask", "unique_request_vectors")
-TIMER_LABEL = {"k_combine_slices": "k_combine", "k_slice_desc": "k_combine", "k_combine_wave": "k_combine", "k_fix_rows": "k_expand_bands",
+TIMER_LABEL = {"k_combine_wave": "k_combine", "k_fix_rows": "k_expand_bands",
                "k_dim_sort": "k_dim_walk", "k_dim_prefix_max": "k_dim_walk", "k_rank_hist": "k_rank", "k_rank_scan": "k_rank",
                "k_rank_fill": "k_rank", "k_rank_final": "k_rank", "k_decide_groups": "k_decide"}
 

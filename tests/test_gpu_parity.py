@@ -221,11 +221,11 @@ def test_random_clusters_full_grid(pm, seed, allocate):
 @pytest.mark.parametrize("walk_rows", [1, 3])
 def test_request_value_planes_sorted_walk(monkeypatch, seed, walk_rows):
     """NodeResourcesFit planes are kept per (dimension, distinct request value); dimensions with many distinct values are
-    evaluated by the sorted walk (k_dim_sort / k_dim_walk) instead of one compare per (value, node). YKPRED_WALK_ROWS forces
+    evaluated by the sorted walk (k_dim_sort / k_dim_walk) instead of one compare per (value, node). YKPRED_TUNE walk_rows=… forces
     that path at test sizes: random clusters with scalar resources (> 4 dimensions), over-committed nodes (negative free),
     zero and absent requests, word-boundary node counts — bits, counts, failing plugins and decisions against the oracle,
     both phases, and NodeResourcesFit alone (so that every verdict is that plugin's)."""
-    monkeypatch.setenv("YKPRED_WALK_ROWS", str(walk_rows))
+    monkeypatch.setenv("YKPRED_TUNE", f"walk_rows={walk_rows}")
     snap = _gen.random_snapshot(8800 + seed, n_nodes=[63, 64, 65, 129, 200, 333][seed], n_pods=90, scalars=True)
     for plugins in (["*"], ["NodeResourcesFit"]):
         m = pkg.GpuPredicateManager.internal(plugins, plugins, plugins, plugins)
@@ -258,7 +258,7 @@ def test_sig_planes_words_per_lane(monkeypatch, wpl, n_nodes):
     """k_sig_planes<WPL>: a lane owns 1, 2 or 4 words of the row, 64 apart (chosen from the row width; forced here) — rows much
     shorter than one wave's span, rows ending inside a lane's second / fourth word, both dictionary families, rank-ordered
     planes with their first-word table (decisions) — against the oracle."""
-    monkeypatch.setenv("YKPRED_SIG_WPL", str(wpl))
+    monkeypatch.setenv("YKPRED_TUNE", f"sig_wpl={wpl}")
     snap = _gen.random_snapshot(4200 + wpl, n_nodes=n_nodes, n_pods=70)
     m = pkg.GpuPredicateManager()
     try:
@@ -282,15 +282,14 @@ def test_sig_planes_words_per_lane(monkeypatch, wpl, n_nodes):
 
 @pytest.mark.parametrize("walk_rows,n_nodes", [(1, 333), (3, 129), (1, 8300)])
 def test_slice_writer_equals_wave_writer_and_oracle(monkeypatch, walk_rows, n_nodes):
-    """The zone-B writer of populations with index rows (k_slice_desc + k_combine_slices: mask tables of a row slice in LDS,
-    batches of single-row chunks; everything else through the descriptor-filtered k_combine_wave) against the plain
-    wave-per-chunk writer (YKPRED_COMBINE_SLICES=0) on the same snapshot: one / two walked dimensions, pinned pods, duplicated
+    """The zone-B writer of populations with index rows (k_slice_desc + k_walk_rows: loader / store waves, the mask tables, index
+    bytes and base words of a row slice in LDS; everything else through the descriptor-filtered k_combine_wave) against the plain
+    wave-per-chunk writer (YKPRED_TUNE combine_slices=0) on the same snapshot: one / two walked dimensions, pinned pods, duplicated
     pods (several member rows), rows narrower and wider than one 128-word slice — bitmap, counts, decisions, and the oracle."""
-    monkeypatch.setenv("YKPRED_WALK_ROWS", str(walk_rows))
     snap = _gen.random_snapshot(9900 + walk_rows, n_nodes=n_nodes, n_pods=150, scalars=True)
     got = {}
     for knob in ("0", "1"):
-        monkeypatch.setenv("YKPRED_COMBINE_SLICES", knob)
+        monkeypatch.setenv("YKPRED_TUNE", f"walk_rows={walk_rows},combine_slices={knob}")
         m = pkg.GpuPredicateManager()
         try:
             m.load_snapshot(snap)
@@ -807,9 +806,9 @@ def test_column_patch_never_reads_a_stale_representative_row(pm):
 
 
 def test_graph_replay_matches_plain_launches(monkeypatch):
-    """YKPRED_GRAPH=1: a pass that repeats unchanged is captured into a hipGraph the second time and replayed afterwards;
+    """YKPRED_TUNE graph=1: a pass that repeats unchanged is captured into a hipGraph the second time and replayed afterwards;
     table changes in between invalidate the capture. Results must not depend on the launch mode."""
-    monkeypatch.setenv("YKPRED_GRAPH", "1")
+    monkeypatch.setenv("YKPRED_TUNE", "graph=1")
     m = pkg.GpuPredicateManager()
     try:
         snap = _gen.random_snapshot(808, n_nodes=130, n_pods=50, spread=True, interpod=True)
@@ -1672,10 +1671,10 @@ def test_sharded_column_patch_with_topology_constraints():
 
 @pytest.mark.parametrize("seed", range(5))
 def test_decisions_of_the_sub_wave_decide_kernel(monkeypatch, seed):
-    """k_decide_groups (four classes per wave) is what runs from 16 384 classes on; YKPRED_DECIDE_GROUPS_FROM=0 forces it at
+    """k_decide_groups (four classes per wave) is what runs from 16 384 classes on; YKPRED_TUNE decide_groups_from=0 forces it at
     test sizes: every decision of random clusters (NodeName pins, unknown pins, spread constraints, asks without a feasible
     node, node counts around the 16-word group size) against the oracle's decide()."""
-    monkeypatch.setenv("YKPRED_DECIDE_GROUPS_FROM", "0")
+    monkeypatch.setenv("YKPRED_TUNE", "decide_groups_from=0")
     snap = _gen.random_snapshot(9300 + seed, n_nodes=[63, 1024, 1025, 2111, 700][seed], n_pods=150, scalars=True, spread=seed % 2 == 1)
     m = pkg.GpuPredicateManager()
     try:

@@ -49,6 +49,15 @@ inline int guard_mode() {
   return mode;
 }
 inline bool guard_pages_on() { return guard_mode() != 0; }
+// YKPRED_TRACE_KERNELS=1 (debugging, with YKPRED_GUARD_PAGES): every stage of an evaluation is waited for and named on stderr —
+// after a device fault the last line names the last stage that completed
+inline bool trace_kernels_on() {
+  static const bool on = [] {
+    const char* v = getenv("YKPRED_TRACE_KERNELS");
+    return v && atoi(v) != 0;
+  }();
+  return on;
+}
 inline hipError_t guard_alloc(size_t bytes, GuardAlloc* g, void** out) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -84,12 +93,8 @@ inline hipError_t guard_alloc(size_t bytes, GuardAlloc* g, void** out) {
     return e;
   }
   *out = front ? g->map_at : (void*)((char*)g->map_at + (g->mapped - bytes));
-  static const bool trace = [] {
-    const char* v = getenv("YKPRED_TRACE_KERNELS");
-    return v && atoi(v) != 0;
-  }();
   // (with the stage trace: every block's address range — the address of a fault names the block that was overrun)
-  if (trace) fprintf(stderr, "ykpred: guard block %zu bytes [%p, %p)\n", bytes, *out, (void*)((char*)*out + bytes));
+  if (trace_kernels_on()) fprintf(stderr, "ykpred: guard block %zu bytes [%p, %p)\n", bytes, *out, (void*)((char*)*out + bytes));
   return hipSuccess;
 }
 inline void guard_free(GuardAlloc* g) {
@@ -253,10 +258,10 @@ struct ykpred_engine {
   int NCB = 0;                      // zone-B chunks (d_chunk_list_b)
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
   DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
-  bool decide_skip = true;  // YKPRED_DECIDE_SKIP=0: scan every class from the first position
+  static constexpr bool decide_skip = true;  // k_decide starts a class's scan where its rows can first have a bit
   DevBuf d_chunk_list_b;    // [NCB] numbers of the zone-B chunks (ascending)
-  DevBuf d_slice_general;   // one int: chunks of the pass that k_combine_slices leaves to k_combine_wave
-  DevBuf d_slice_desc;      // [NC] chunk descriptors of k_combine_slices (k_slice_desc, refilled per pass)
+  DevBuf d_slice_general;   // one int: chunks of the pass that k_walk_rows leaves to k_combine_wave
+  DevBuf d_slice_desc;      // [NC] chunk descriptors of k_walk_rows (k_slice_desc, refilled per pass)
   DevBuf d_pfx_r;           // [n_big][row_words] running maximum of the free values along the bin-pack order (k_dim_prefix_max)
   DevBuf d_idx_c, d_idx_r;  // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical / rank order
   int idx_stride = 0;
@@ -283,19 +288,13 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
-  bool permute_all_enabled = false; // YKPRED_PERMUTE_ALL=1: with few planes, rank-ordered copies of ALL of them by bit permutation instead of
-                                    // evaluating the dictionary families a second time (measured equal: profiles/r03_session4_knobs.txt)
-  bool zone_b_first = false;        // YKPRED_ZONE_B_FIRST=1: the class-by-class writer runs before the band writer
-  int sig_wpl = 0;                  // YKPRED_SIG_WPL: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
-  int combine_slices = 1;           // YKPRED_COMBINE_SLICES: 0 = never, 1 = small chunks with index rows (k_combine_slices), 2 = every small-chunk population
-  int beside_small = 0;             // YKPRED_BESIDE_SMALL=1: a SMALL zone B (< 1/16 of the rows) is written beside the band writer (measured: the
-                                    // third stream's fork / join costs the step 0.25 ms — 1.24 -> 1.50 ms on configs[2]; off)
-  int wave_rows = 0;                // YKPRED_WAVE_ROWS=1: k_combine_wave writes member rows one after the other (class row in registers)
-  int slice_mode = 0;               // YKPRED_SLICE_MODE: timing-only experiments of k_combine_slices (1 = no stores, 16 = cached rows never
-                                    // reloaded): WRONG bitmaps
-  int slice_chunks_per_wave = 64;   // YKPRED_SLICE_CHUNKS: chunks one wave of k_combine_slices walks (the LDS tables are staged once per workgroup)
-  int decide_groups_from = 16384;  // classes from which k_decide serves four classes per wave (YKPRED_DECIDE_GROUPS_FROM; experiments)
-  bool combine_beside = false;     // tunable: cfg.reserved[7] == 2 runs the class-by-class writer beside the band writer (measured slower)
+  // Test knobs (YKPRED_TUNE, see ykpred_create): they force paths the populations of the test suite would not choose themselves.
+  int sig_wpl = 0;                  // sig_wpl: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
+  int combine_slices = 1;           // combine_slices: 0 = index-row populations take the wave-per-chunk writer instead of k_walk_rows
+  int decide_groups_from = 16384;   // decide_groups_from: classes from which k_decide serves four classes per wave
+  int walk_mode = 0, walk_run_slots = 10, walk_buffers = 8, walk_debug = 0;
+  DevBuf d_walk_dbg;
+  int walk_chunks_per_group = 2048, walk_throttle = 0;  // (experiments of this round: walk_chunks, walk_throttle)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
@@ -333,9 +332,6 @@ struct ykpred_engine {
   // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr;
-  // --- zone-B stream: the class-by-class writer runs beside the band writer (they write disjoint rows)
-  hipStream_t zb_stream = nullptr;
-  hipEvent_t ev_zb_fork = nullptr, ev_zb_join = nullptr;
   // --- the resident answer served to single callbacks (ykpred_peek_row / ykpred_peek_outputs): a copy stream ordered after the
   // last evaluation by an event, pinned staging memory
   hipStream_t peek_stream = nullptr;
@@ -866,13 +862,7 @@ struct Timer {
     if (on && e->timed < YKPRED_MAX_TIMED_KERNELS) (void)hipEventRecord(e->ev[2 * e->timed], st);
   }
   void end(hipStream_t st, const char* name) {
-    // YKPRED_TRACE_KERNELS=1 (debugging, with YKPRED_GUARD_PAGES): wait for the stage just launched and say so on stderr — after a
-    // device fault the last line names the last stage that completed, the one after it is the culprit
-    static const bool trace = [] {
-      const char* v = getenv("YKPRED_TRACE_KERNELS");
-      return v && atoi(v) != 0;
-    }();
-    if (trace) {
+    if (trace_kernels_on()) {
       const hipError_t s = hipStreamSynchronize(st);
       fprintf(stderr, "ykpred: %s %s\n", name, s == hipSuccess ? "done" : hipGetErrorString(s));
       fflush(stderr);
@@ -1124,24 +1114,48 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (cfg->reserved[6] < 0) e->bands_enabled = false;
   // the band kernel packs the step-in-band into 8 bits of its class key: at most 256 windows per band
   if (cfg->reserved[6] > 0) e->band_steps = std::min(256, std::max(4, (cfg->reserved[6] + 3) / 4 * 4));
-  // measured (profiles/r03_writer_knobs.txt): beside the band writer the chunk kernel's workgroups upset the one-workgroup-per-CU
-  // placement the band writer's store pattern lives on (default workload 1.22 -> 1.45 ms) and gain nothing where zone B is large
-  e->combine_beside = cfg->reserved[7] == 2;
+  e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain, DESIGN.md §4)
   {
     int lds = 0;  // what a workgroup may ask for with hipFuncAttributeMaxDynamicSharedMemorySize (64 KiB on gfx90a / gfx942, 160 KiB on gfx950)
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) e->max_lds_bytes = lds;
   }
-  if (const char* v = getenv("YKPRED_DECIDE_GROUPS_FROM")) e->decide_groups_from = atoi(v);
-  if (const char* v = getenv("YKPRED_PERMUTE_ALL")) e->permute_all_enabled = atoi(v) != 0;
-  if (const char* v = getenv("YKPRED_DECIDE_SKIP")) e->decide_skip = atoi(v) != 0;
-  if (const char* v = getenv("YKPRED_ZONE_B_FIRST")) e->zone_b_first = atoi(v) != 0;
-  if (const char* v = getenv("YKPRED_COMBINE_SLICES")) e->combine_slices = atoi(v);
-  if (const char* v = getenv("YKPRED_SIG_WPL")) e->sig_wpl = atoi(v);
-  if (const char* v = getenv("YKPRED_SLICE_CHUNKS")) e->slice_chunks_per_wave = atoi(v);
-  if (const char* v = getenv("YKPRED_SLICE_MODE")) e->slice_mode = atoi(v);
-  if (const char* v = getenv("YKPRED_WAVE_ROWS")) e->wave_rows = atoi(v);
-  if (const char* v = getenv("YKPRED_BESIDE_SMALL")) e->beside_small = atoi(v);
-  e->graph_disabled = cfg->reserved[3] != 1;  // tunable: replay a repeated pass as a hipGraph (measured: no gain, DESIGN.md §4)
+  // YKPRED_TUNE="key=value,key=value": the ONE environment hook for engine tunables — what the tests use to force a path (index rows
+  // on tiny clusters, a k_sig_planes width, the sub-wave decision kernel ...). Unknown keys are an error, not ignored.
+  if (const char* tune = getenv("YKPRED_TUNE")) {
+    std::string text(tune);
+    size_t at = 0;
+    while (at < text.size()) {
+      size_t stop = text.find(',', at);
+      if (stop == std::string::npos) stop = text.size();
+      const std::string item = text.substr(at, stop - at);
+      at = stop + 1;
+      if (item.empty()) continue;
+      const size_t eq = item.find('=');
+      const std::string key = item.substr(0, eq);
+      const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
+      if (key == "walk_rows") e->walk_rows = std::max(val, 1);
+      else if (key == "sig_wpl") e->sig_wpl = val;
+      else if (key == "combine_slices") e->combine_slices = val;
+      else if (key == "decide_groups_from") e->decide_groups_from = val;
+      else if (key == "graph") e->graph_disabled = val != 1;
+      else if (key == "band_steps") {
+        e->bands_enabled = val >= 0;
+        e->band_steps = val > 0 ? std::min(256, std::max(4, (val + 3) / 4 * 4)) : 0;
+      } else if (key == "chunk_members") e->chunk_members = std::min(std::max(val, 1), (int)ykk::kChunkMembers);
+      else if (key == "wave_combine_below") e->wave_combine_below = std::max(val, 0);
+      else if (key == "walk_chunks") e->walk_chunks_per_group = std::max(val, 64);
+      else if (key == "walk_throttle") e->walk_throttle = val;
+      else if (key == "walk_mode") e->walk_mode = val;
+      else if (key == "walk_debug") e->walk_debug = val;
+      else if (key == "walk_run_slots") e->walk_run_slots = std::max(val, 2);
+      else if (key == "walk_buffers") e->walk_buffers = std::max(val, 2);
+      else {
+        g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
+        delete e;
+        return YKPRED_E_INVALID;
+      }
+    }
+  }
   s = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
   if (s != hipSuccess) {
     g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(s);
@@ -1151,16 +1165,11 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   {
     int lo = 0, hi = 0;  // numerically lower = higher priority
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // YKPRED_AUX_PRIORITY: 1 (default) = the decision stream gets the greatest priority, -1 = the least, 0 = none
-    int want = 1;
-    if (const char* v = getenv("YKPRED_AUX_PRIORITY")) want = atoi(v);
-    if (want == 0 || hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, want > 0 ? hi : lo) != hipSuccess)
+    // the decision stream gets the greatest priority (measured: no effect either way on any population)
+    if (hipStreamCreateWithPriority(&e->aux_stream, hipStreamNonBlocking, hi) != hipSuccess)
       (void)hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking);
   }
-  if (hipStreamCreateWithFlags(&e->zb_stream, hipStreamNonBlocking) != hipSuccess) e->zb_stream = nullptr;
   if (hipStreamCreateWithFlags(&e->peek_stream, hipStreamNonBlocking) != hipSuccess) e->peek_stream = nullptr;
-  (void)hipEventCreateWithFlags(&e->ev_zb_fork, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&e->ev_zb_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_eval_done, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
@@ -1200,11 +1209,8 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
-  if (e->ev_zb_fork) (void)hipEventDestroy(e->ev_zb_fork);
-  if (e->ev_zb_join) (void)hipEventDestroy(e->ev_zb_join);
   if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
   if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
-  if (e->zb_stream) (void)hipStreamDestroy(e->zb_stream);
   if (e->peek_stream) (void)hipStreamDestroy(e->peek_stream);
   if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -1822,9 +1828,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order). With few signature planes
   // altogether the rank-ordered copies of ALL of them come from one bit permutation of the canonical planes (part 3) — a
   // fraction of the work of evaluating the dictionary families a second time, and less traffic beside the band writer.
-  const int total_rows = e->plane_rows_alloc;
-  const bool permute_all = total_rows <= ykk::kManySigs && e->n_big == 0 && e->permute_all_enabled;
-  if (want_dec && !permute_all) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
+  if (want_dec) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
   // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
   auto ranked_walk = [](const int* perm) { return perm != nullptr; };
   auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name) {
@@ -1875,7 +1879,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) {
     HIPCHK(hipEventRecord(e->ev_planes, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_planes, 0));
-    const int ballot_rows = permute_all ? total_rows : e->fam_tol.base;  // res + spread rows come first in the plane buffers
+    const int ballot_rows = e->fam_tol.base;  // res + spread rows come first in the plane buffers
     if (ballot_rows <= ykk::kManySigs && e->n_big == 0) {  // (index rows of walked dimensions are not bit planes: they are re-walked in rank order)
       tm.begin(sb);
       hipLaunchKernelGGL(ykk::k_permute_planes, dim3(sig_chunks(ballot_rows), wgroups), dim3(ykk::kBlock), 0, sb, N, e->d_perm.as<int>(),
@@ -1913,37 +1917,21 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   }
   if (!skip_combine && !dirty_only) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   if (!skip_combine) {
-    // store flavour: bits 16-17 of options select an experimental variant (0 = default)
-    const unsigned variant = (a->options >> YKPRED_EVAL_STORE_VARIANT_SHIFT) & 3u;
-    const int wpl = (variant & 1u) ? 1 : 2;
-    // threads per group: the smallest whole number of waves (64/128/256) whose single pass covers a row
+    // threads per group of k_combine: the smallest whole number of waves (64/128/256) whose single pass covers a row
     int tpg = ykk::kBlock;
-    while (tpg > ykk::kWave && (tpg / 2) * wpl >= e->row_stride) tpg /= 2;
-    const int seg = tpg * ykk::kCombineUnroll * wpl;
+    while (tpg > ykk::kWave && (tpg / 2) * 2 >= e->row_stride) tpg /= 2;
+    const int seg = tpg * ykk::kCombineUnroll * 2;
     // the full pass runs the class-by-class writer over the zone-B chunks only (the dirty-class pass over every chunk)
     // (chunks appended by ykpred_update_pods since the class build are not in the list: then every chunk runs, as the dirty pass does)
     const bool listed = !dirty_only && e->patch_chunks == 0;
     const int* chunk_list = listed ? e->d_chunk_list_b.as<int>() : nullptr;
     const int n_run = listed ? e->NCB : e->NC;
     dim3 grid((unsigned)std::max(n_run, 1), (unsigned)((e->row_stride + seg - 1) / seg));
-    // The class-by-class writer (zone B, rows disjoint from the band rows) can run BESIDE the band writer on its own stream:
-    // both only need the planes. Measured (profiles/r03_writer_knobs.txt): with a LARGE zone B that costs the band writer more
-    // than it saves; a small one (a handful of workgroups, e.g. the 241 rows of configs[2]) would hide under the band writer,
-    // but the fork / join of the third stream costs more than the 18 us it hides (session 16): opt-in.
-    const bool small_b = e->beside_small && !dirty_only && (int64_t)(e->rows_total - e->rows_a) * 16 <= (int64_t)e->rows_total;
-    const bool beside = (e->combine_beside || small_b) && e->zb_stream && !dirty_only && e->n_classes_a > 0 && n_run > 0;
-    hipStream_t sz = beside ? e->zb_stream : st;
-    auto launch = [&](auto kern) {
-      // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
-      hipLaunchKernelGGL(kern, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, sz, ct, pc, bitmap, e->row_words, e->row_stride,
-                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty, chunk_list);
-    };
-    if (beside) {
-      HIPCHK(hipEventRecord(e->ev_zb_fork, st));  // planes and the zeroed class counts are ready here
-      HIPCHK(hipStreamWaitEvent(sz, e->ev_zb_fork, 0));
-    }
-    auto launch_zone_a = [&]() -> int {
-      if (dirty_only || e->n_classes_a == 0) return YKPRED_OK;
+    // Both writers run on the launch stream, the band writer first. (Measured in round 3, profiles/r03_writer_knobs.txt: the
+    // class-by-class writer BESIDE the band writer on a third stream upsets the one-workgroup-per-CU placement the band writer
+    // lives on, 1.22 -> 1.45 ms, and even a 241-row zone B costs 0.25 ms through the fork / join; zone B first gains nothing.)
+    hipStream_t sz = st;
+    if (!dirty_only && e->n_classes_a > 0) {
       // zone A: class rows → table (and the classes' feasible counts), then the fill-pattern expansion over the band layout
       tm.begin(st);
       hipLaunchKernelGGL(ykk::k_class_rows, dim3((unsigned)((e->n_classes_a + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
@@ -1960,13 +1948,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, bitmap, e->d_class_rows_a.as<u64>(),
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
       tm.end(st, "k_expand_bands");
-      return YKPRED_OK;
-    };
-    // Order of the two writers. The band writer is the one the decision branch (aux stream) disturbs — it lives on one
-    // workgroup per CU issuing stores back to back — while the chunk writer does not care (measured: own-template population,
-    // band writer 0.62 ms alone / 1.12 ms beside the decision kernels, chunk writer 0.78 ms either way). With a large zone B the
-    // chunk writer can go FIRST and absorb the decision branch.
-    if (!e->zone_b_first) TRY(launch_zone_a());
+    }
     tm.begin(sz);
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
     // Index rows to decode: k_walk_rows — a workgroup per slice (<= 128 words) of the row with the slice's mask tables, staged
@@ -1978,55 +1960,65 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       wg.slice_words = ((e->row_stride + wg.n_slices - 1) / wg.n_slices + 15) / 16 * 16;  // (row_stride is a multiple of 16)
       wg.n_stage = (int)e->h_stage_rows.size();
       for (int k = 0; k < wg.n_stage; ++k) wg.stage_row[k] = e->h_stage_rows[(size_t)k];
-      wg.run_slots = 16;
-      // shed what is optional until the workgroup's LDS fits the device: staged plane rows first, then base slots
-      while (ykk::walk_lds_bytes(pc.n_big, wg) > (size_t)e->max_lds_bytes && wg.n_stage > 0) wg.n_stage--;
-      while (ykk::walk_lds_bytes(pc.n_big, wg) > (size_t)e->max_lds_bytes && wg.run_slots > 2) wg.run_slots /= 2;
-      slices = ykk::walk_lds_bytes(pc.n_big, wg) <= (size_t)e->max_lds_bytes;
+      wg.run_slots = e->walk_run_slots;
+      wg.n_buffers = e->walk_buffers;
+      // shed what is optional until the workgroup's LDS fits the device: plane rows staged beyond 8, block buffers, base slots, staged rows
+      auto fits = [&]() { return ykk::walk_lds_bytes(pc.n_big, wg) <= (size_t)e->max_lds_bytes; };
+      while (!fits() && wg.n_stage > 8) wg.n_stage--;
+      while (!fits() && wg.n_buffers > 8) wg.n_buffers--;
+      while (!fits() && wg.run_slots > 4) wg.run_slots--;
+      while (!fits() && wg.n_buffers > 2) wg.n_buffers--;
+      while (!fits() && wg.n_stage > 0) wg.n_stage--;
+      while (!fits() && wg.run_slots > 2) wg.run_slots--;
+      slices = fits();
     }
     if (slices) {
       // chunk descriptors first, one thread per chunk (what a wave needs to know about a chunk, resolved once per pass)
       const size_t lds = ykk::walk_lds_bytes(pc.n_big, wg);
-      wg.chunks_per_group = 2048;
+      wg.chunks_per_group = e->walk_chunks_per_group;
+      wg.throttle = e->walk_throttle;
+      wg.mode = e->walk_mode;
       HIPCHK(e->d_slice_desc.ensure((size_t)std::max(e->NC, 1) * sizeof(ykk::SliceDesc)));
       HIPCHK(e->d_slice_general.ensure(sizeof(int)));
       HIPCHK(hipMemsetAsync(e->d_slice_general.p, 0, sizeof(int), sz));
       hipLaunchKernelGGL(ykk::k_slice_desc, dim3((unsigned)((e->NC + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, sz, ct, pc, e->NC, class_dirty,
                          pin_on, e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
+      tm.end(sz, "k_slice_desc");
+      tm.begin(sz);
       const dim3 sgrid((unsigned)(((e->NC + wg.chunks_per_group - 1) / wg.chunks_per_group) * wg.n_slices));
+      if (e->walk_debug && !e->d_walk_dbg.p) {
+        HIPCHK(e->d_walk_dbg.ensure(4 * sizeof(u64)));
+        HIPCHK(hipMemset(e->d_walk_dbg.p, 0, 4 * sizeof(u64)));
+      }
       if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ykk::k_walk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(ykk::k_walk_rows, sgrid, dim3(ykk::kWalkThreads), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words,
-                         e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, wg);
+                         e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, wg, e->walk_debug ? e->d_walk_dbg.as<u64>() : (u64*)nullptr);
+      tm.end(sz, "k_walk_rows");
+      if (e->walk_debug) {
+        u64 h[4] = {0, 0, 0, 0};
+        (void)hipStreamSynchronize(sz);
+        (void)hipMemcpy(h, e->d_walk_dbg.p, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "k_walk_rows cycles (sum over waves): loaders spin %llu work %llu | store waves spin %llu work %llu | groups %u\n", h[0], h[1], h[2], h[3], sgrid.x);
+        (void)hipMemset(e->d_walk_dbg.p, 0, sizeof h);
+      }
+      tm.begin(sz);
       // chunks the fast path does not cover (several member rows, pins to unknown nodes, other row shapes): wave per chunk
-      hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
+      hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,
                          e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>(), (const int*)nullptr);
     } else if (n_run == 0) {
       // (no chunk outside the band layout: nothing to launch)
     } else if (small_chunks) {
       // few members per chunk: one wave per chunk (see k_combine_wave)
-      // narrow enough rows: the class row in registers, member rows written one after the other (k_combine_wave<true>)
       const dim3 wgrid((unsigned)((std::max(n_run, 1) + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
-      if (e->wave_rows && e->row_stride <= ykk::kWaveRowPieces * 2 * ykk::kWave)
-        hipLaunchKernelGGL(ykk::k_combine_wave<true>, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                           e->d_class_count.as<int>(), n_run, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr, chunk_list);
-      else
-        hipLaunchKernelGGL(ykk::k_combine_wave<false>, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                           e->d_class_count.as<int>(), n_run, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr, chunk_list);
+      hipLaunchKernelGGL(ykk::k_combine_wave, wgrid, dim3(ykk::kBlock), 0, sz, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
+                         e->d_class_count.as<int>(), n_run, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr, chunk_list);
     } else {
-      switch (variant) {
-        case 0: launch(ykk::k_combine<2, false>); break;
-        case 1: launch(ykk::k_combine<1, false>); break;
-        case 2: launch(ykk::k_combine<2, true>); break;
-        default: launch(ykk::k_combine<1, true>); break;
-      }
+      // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
+      hipLaunchKernelGGL(ykk::k_combine, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, sz, ct, pc, bitmap, e->row_words, e->row_stride,
+                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty, chunk_list);
     }
     tm.end(sz, dirty_only ? "k_combine(dirty classes)" : "k_combine");
-    if (e->zone_b_first) TRY(launch_zone_a());
-    if (sz != st) {
-      HIPCHK(hipEventRecord(e->ev_zb_join, sz));
-      HIPCHK(hipStreamWaitEvent(st, e->ev_zb_join, 0));
-    }
   }
   if (want_dec) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
   if (want_dec || want_cnt) {
@@ -3167,7 +3159,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   }
   // classes outside the band layout (and rows appended since the last class build): chunk by chunk, like the evaluation
   if ((long)e->NC * e->wave_combine_below > (long)P) {
-    hipLaunchKernelGGL(ykk::k_combine_wave<false>, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
+    hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st, ct, pl,
                        out, e->row_stride, e->row_stride, 0, e->d_expand_count.as<int>(), e->NC, (const int*)nullptr, (const ykk::SliceDesc*)nullptr,
                        (const int*)nullptr, (const int*)nullptr);
   } else {
@@ -3175,7 +3167,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
     while (tpg > ykk::kWave && (tpg / 2) * 2 >= e->row_stride) tpg /= 2;
     const int seg = tpg * ykk::kCombineUnroll * 2;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
-    hipLaunchKernelGGL((ykk::k_combine<2, false>), grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pl, out, e->row_stride, e->row_stride, 0,
+    hipLaunchKernelGGL(ykk::k_combine, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pl, out, e->row_stride, e->row_stride, 0,
                        e->d_expand_count.as<int>(), tpg, (const int*)nullptr, (const int*)nullptr);
   }
   HIPCHK(hipGetLastError());

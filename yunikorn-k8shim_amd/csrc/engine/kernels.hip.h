@@ -1049,14 +1049,14 @@ __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
 // (e.g. 200 words for 12.5 k nodes) are covered by 128 or 64 threads so that no lane idles. Each thread owns
 // kCombineUnroll groups of WPL adjacent words of the class row (word = seg_base + (u*tpg + t)*WPL ...), so one wave
 // store writes 64*WPL*8 contiguous bytes (512 B at WPL=1, 1 KiB = dwordx4 per lane at WPL=2).
-// NT selects non-temporal stores: the bitmap is written once and never re-read by this kernel.
-template <int WPL, bool NT>
+// (Round-1 experiments with one word per lane and with non-temporal stores were not faster; only this form is kept.)
 __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                     int pin_enabled, int* __restrict__ class_count, int tpg,
                                                     const int* __restrict__ class_dirty /* null = every class */,
                                                     const int* __restrict__ chunk_list /* null: grid.x = every chunk; else the chunks
                                                     to run (the full pass lists the zone-B chunks: no workgroup for the others) */) {
   // pin_enabled bit 0: NodeName filter on; bit 1: a Filter has no PreFilter state ⇒ every pair fails
+  constexpr int WPL = 2;  // adjacent words per thread: one wave store writes 64 x 16 contiguous bytes
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int chunk = chunk_list ? chunk_list[blockIdx.x] : (int)blockIdx.x;
@@ -1105,20 +1105,9 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
 #pragma unroll
     for (int u = 0; u < kCombineUnroll; ++u) {
       int w = seg_base + (u * tpg + t) * WPL;
-      if (w < row_stride) {  // row_stride is a multiple of 16 ⇒ a WPL=2 group never straddles the end
-        if (WPL == 2) {
-          typedef u64 u64x2 __attribute__((ext_vector_type(2)));
-          u64x2 val = {v[u][0], v[u][WPL - 1]};
-          if (NT)
-            __builtin_nontemporal_store(val, (u64x2*)(row + w));
-          else
-            *(u64x2*)(row + w) = val;
-        } else {
-          if (NT)
-            __builtin_nontemporal_store(v[u][0], row + w);
-          else
-            row[w] = v[u][0];
-        }
+      if (w < row_stride) {  // row_stride is a multiple of 16 ⇒ a pair never straddles the end
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+        *(u64x2*)(row + w) = u64x2{v[u][0], v[u][1]};
       }
     }
   }
@@ -1130,8 +1119,6 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
 // 4x as many chains per workgroup and no occupancy cap; lane = a pair of adjacent row words (dwordx4 loads and stores).
 struct SliceDesc;
 __device__ __forceinline__ bool slice_desc_general(const SliceDesc* desc, int chunk);
-constexpr int kWaveRowPieces = 8;  // row-major form: rows of up to 8 KiB (65 536 nodes) held in registers
-template <bool ROWS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_combine_wave(ClassTable ct, Planes pl, u64* __restrict__ bitmap, int row_words, int row_stride,
                                                          int pin_enabled, int* __restrict__ class_count, int n_chunks,
                                                          const int* __restrict__ class_dirty /* null = every class */,
@@ -1176,29 +1163,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
     }
     return x;
   };
-  if (ROWS) {
-    // Row-major form (rows of <= kWaveRowPieces KiB pieces): the whole class row sits in registers — every plane word of it
-    // is requested at once — and each member row is then written from its first byte to its last, 1 KiB per store: one
-    // sequential 6 KB burst per row instead of a 1 KiB piece in each of the chunk's rows per step.
-    u64x2 xs[kWaveRowPieces];
-    const int pieces = (row_stride + 2 * kWave - 1) / (2 * kWave);
-#pragma unroll
-    for (int k = 0; k < kWaveRowPieces; ++k) {
-      xs[k] = u64x2{0, 0};
-      if (k < pieces) {
-        xs[k] = class_pair(k * 2 * kWave + 2 * lane);
-        pc += __popcll(xs[k].x) + __popcll(xs[k].y);
-      }
-    }
-    for (int i = 0; i < len; ++i) {
-      const int p = __builtin_amdgcn_readlane(mine, i);
-      if (p < 0) continue;
-      u64* row = bitmap + (size_t)p * row_stride + 2 * lane;
-#pragma unroll
-      for (int k = 0; k < kWaveRowPieces; ++k)
-        if (k < pieces && k * 2 * kWave + 2 * lane < row_stride) *(u64x2*)(row + k * 2 * kWave) = xs[k];
-    }
-  } else {
   // two-stage pipeline: the plane words of the next 1 KiB piece are in flight while this piece is stored
   u64x2 next = class_pair(2 * lane);
   for (int w0 = 0; w0 < row_stride; w0 += 2 * kWave) {
@@ -1211,7 +1175,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
         const int p = __builtin_amdgcn_readlane(mine, i);
         if (p >= 0) *(u64x2*)(bitmap + (size_t)p * row_stride + w) = x;
       }
-  }
   }
   if (ct.chunk_first[chunk]) {
 #pragma unroll
@@ -1333,177 +1296,303 @@ __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl,
 //   * one s_barrier per block joins them.
 // Chunks without this fast path (several member rows, a pinned unknown node, two index rows, more than two plane rows) are
 // left to k_combine_wave through the descriptor filter, as before.
-constexpr int kWalkStoreWaves = 12;
-constexpr int kWalkThreads = (kWalkStoreWaves + 1) * kWave;
-constexpr int kWalkBlockRows = 64;   // rows (chunks) per block: lane j of the loader = row j
+constexpr int kWalkStoreWaves = 8;     // x kWalkRowsPerWave rows of a block each, all their LDS reads in flight together
+constexpr int kWalkLoaders = 6;      // loader waves: each fills whole blocks (block k belongs to loader k % kWalkLoaders)
+constexpr int kWalkThreads = (kWalkStoreWaves + kWalkLoaders) * kWave;
+constexpr int kWalkBlockRows = 32;   // rows (chunks) per block: lanes j and j + 32 of a loader = row j (each takes half of its index bytes)
+constexpr int kWalkRowsPerWave = kWalkBlockRows / kWalkStoreWaves;
 constexpr int kWalkMaxStage = 16;    // ballot rows of the request family staged in LDS
+constexpr int kWalkRunGroup = 8;     // runs whose base loads a loader keeps in flight together (3 planes x 16 bytes x 8 = 96 VGPRs)
 struct WalkGeom {
   int n_slices, slice_words;   // slice_words: multiple of 16 (index bytes travel in 16-byte pieces), <= kSliceMaxWords
-  int run_slots;               // distinct cached-row keys per block (a block ends early when they run out)
+  int run_slots;               // base slots per block: rows of further runs fetch their cached rows themselves
+  int n_buffers;               // LDS block buffers: how far the loaders run ahead of the store waves (>= 2 x loaders wanted)
   int chunks_per_group;        // chunks one workgroup walks
+  int throttle;                // stores a store wave keeps in flight (0 = as many as the counter allows)
+  int mode;                    // EXPERIMENT (timing only, wrong bitmaps): 1 no index loads, 2 no base loads, 4 no stores, 8 store waves idle, 16 no atomics
   int n_stage;                 // staged plane rows ...
   int stage_row[kWalkMaxStage];  // ... their row ids in the request family
 };
-struct WalkRow {  // what a store wave needs to know about a row of the block (LDS)
-  int dest, cls, slot, stage;    // bitmap row; class; base slot of the row's run, -1 = row not on the fast path; staged plane slot or -1
-  int prow, pin, big, pad;       // per-row plane row when it is not staged (-1: none); pinned node (-1: none); walked dimension
+struct WalkRow {  // what a store wave needs to know about a row of the block (LDS, 32 bytes)
+  int dest, cls, slot, chunk;    // bitmap row; class; base slot of the row's run (-1: row not on the fast path, -2: run without a slot); chunk (slot == -2 re-reads its descriptor)
+  int prow, pin, pm_off, stage_off;  // per-row plane row when it is not staged (-1: none); pinned node (-1: none); u64 offsets of the walked
+                                     // dimension's mask table and of the staged plane row (the all-ones row when there is none) in LDS
 };
-// dynamic LDS: [pmask n_big x sw x 65 u64][stage n_stage x sw u64][base 2 x run_slots x sw u64][idx 2 x 64 x sw bytes][rows 2 x 64 WalkRow][hdr 2 x int4]
+// dynamic LDS: [pmask n_big x sw x 65 u64][stage (n_stage + 1) x sw u64, the last row all ones][base NB x run_slots x sw u64][idx NB x 32 x sw bytes][rows NB x 32 WalkRow][flags 2 x NB int]
 __host__ __device__ inline size_t walk_lds_bytes(int n_big, const WalkGeom& g) {
-  const size_t sw = (size_t)g.slice_words;
-  return (size_t)n_big * sw * 65 * 8 + (size_t)g.n_stage * sw * 8 + (size_t)2 * g.run_slots * sw * 8 + (size_t)2 * kWalkBlockRows * sw +
-         (size_t)2 * kWalkBlockRows * sizeof(WalkRow) + 2 * 16;
+  const size_t sw = (size_t)g.slice_words, nb = (size_t)g.n_buffers;
+  return (size_t)n_big * sw * 65 * 8 + (size_t)(g.n_stage + 1) * sw * 8 + nb * g.run_slots * sw * 8 + nb * kWalkBlockRows * sw +
+         nb * kWalkBlockRows * sizeof(WalkRow) + 2 * nb * sizeof(int) + 16;
 }
 __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words,
                                                             int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
-                                                            WalkGeom g) {
+                                                            WalkGeom g, u64* __restrict__ dbg) {
   typedef u64x2_t u64x2;
   extern __shared__ u64 walk_lds[];
-  const int sw = g.slice_words;
+  u64 t_spin = 0, t_work = 0;  // (dbg: cycles this wave spent waiting for the other side / working)
+  const int sw = g.slice_words, NB = g.n_buffers;
   u64* s_pm = walk_lds;                                                  // [n_big][sw][65]
-  u64* s_stage = s_pm + (size_t)pl.n_big * sw * 65;                      // [n_stage][sw]
-  u64* s_base = s_stage + (size_t)g.n_stage * sw;                        // [2][run_slots][sw]
-  unsigned char* s_idx = (unsigned char*)(s_base + (size_t)2 * g.run_slots * sw);  // [2][64][sw]
-  WalkRow* s_rows = (WalkRow*)(s_idx + (size_t)2 * kWalkBlockRows * sw);  // [2][64]
-  int* s_hdr = (int*)(s_rows + 2 * kWalkBlockRows);                      // [2][4]: rows of the block
+  u64* s_stage = s_pm + (size_t)pl.n_big * sw * 65;                      // [n_stage + 1][sw]: row n_stage = all ones ("no staged plane row")
+  u64* s_base = s_stage + (size_t)(g.n_stage + 1) * sw;                  // [NB][run_slots][sw]
+  unsigned char* s_idx = (unsigned char*)(s_base + (size_t)NB * g.run_slots * sw);  // [NB][32][sw]
+  WalkRow* s_rows = (WalkRow*)(s_idx + (size_t)NB * kWalkBlockRows * sw);  // [NB][32]
+  int* s_ready = (int*)(s_rows + NB * kWalkBlockRows);                   // [NB] block number + 1 that sits in the buffer
+  int* s_used = s_ready + NB;                                            // [NB] store waves that have finished with the buffer, ever
   const bool all_fail = pin_enabled & 2;
   const bool pin_on = pin_enabled & 1;
   const int slice = blockIdx.x % g.n_slices, group = blockIdx.x / g.n_slices;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const int w_first = slice * sw;  // first row word of the slice
-  // ---- once per workgroup: the mask tables and the staged plane rows of the slice
+  // this lane's word pair (store waves, and the loaders' base words); pairs past the slice or the row hold zeros and store nothing
+  const int w_true = w_first + 2 * lane;
+  const bool in_row = 2 * lane < sw && w_true < row_stride;
+  const unsigned voff = in_row ? (unsigned)w_true * 8u : 0u;  // byte offset of the pair in a plane / bitmap row
+  u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};
+  if (all_fail) keep = u64x2{0, 0};
+  // the pod-independent row of the request family (row 0) is the cached request row of EVERY class: folded into `keep` once
+  if (pl.res) keep &= *(const u64x2*)((const char*)pl.res + voff);
+  // ---- once per workgroup: the mask tables and the staged plane rows of the slice, the buffer flags
   {
     const int cnt = max(min(sw, pl.n_words - w_first), 0) * 65;
     for (int b = 0; b < pl.n_big; ++b) {
       const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)w_first) * 65;
-      for (int i = threadIdx.x; i < sw * 65; i += kWalkThreads) s_pm[(size_t)b * sw * 65 + i] = i < cnt ? src[i] : 0ull;
+      for (int i = (int)threadIdx.x; i < sw * 65; i += kWalkThreads) s_pm[(size_t)b * sw * 65 + i] = i < cnt ? src[i] : 0ull;
     }
     for (int k = 0; k < g.n_stage; ++k) {
       const u64* src = pl.res + (size_t)g.stage_row[k] * pl.stride + w_first;
-      for (int i = threadIdx.x; i < sw; i += kWalkThreads) s_stage[(size_t)k * sw + i] = w_first + i < row_words ? src[i] : 0ull;
+      for (int i = (int)threadIdx.x; i < sw; i += kWalkThreads) s_stage[(size_t)k * sw + i] = w_first + i < row_words ? src[i] : 0ull;
     }
+    for (int i = (int)threadIdx.x; i < sw; i += kWalkThreads) s_stage[(size_t)g.n_stage * sw + i] = ~0ull;
+    if ((int)threadIdx.x < 2 * NB) s_ready[threadIdx.x] = 0;
   }
+  __syncthreads();
   const int c_begin = group * g.chunks_per_group, c_end = min(c_begin + g.chunks_per_group, n_chunks);
-  // this lane's word pair (store waves, and the loader's base words); pairs past the slice or the row hold zeros and store nothing
-  const int w_true = w_first + 2 * lane;
-  const bool in_row = 2 * lane < sw && w_true < row_stride;
-  const u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};
-  const unsigned voff = in_row ? (unsigned)w_true * 8u : 0u;  // byte offset of the pair in a plane / bitmap row
-  const bool loader = wave == kWalkStoreWaves;
-
-  // The loader fills buffer `buf` with the block that starts at chunk c0; returns nothing (the block's row count goes to s_hdr).
-  auto fill = [&](int buf, int c0) {
-    int n_rows = max(min(kWalkBlockRows, c_end - c0), 0);
-    int cls = 0, meta = 0, pin = -1, mem0 = -1, st = -1, sa = -1, ss = -1, p0 = -1, prow = -1, irow = 1 << kRowBigShift;
-    if (lane < n_rows) {
-      const int4* dp = (const int4*)(desc + c0 + lane);
-      const int4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
-      cls = d0.x, meta = d0.y, pin = d0.z, mem0 = d0.w;
-      st = d1.x, sa = d1.y, ss = d1.z, p0 = d1.w;
-      prow = (meta & kSlicePlane) ? d2.x : -1;
-      irow = d2.y;
-    }
-    const bool fast = (meta & (kSliceLive | kSliceGeneral)) == kSliceLive;
-    // runs: a fast row starts one when no fast row precedes it in the block or its cached rows differ from the previous fast row's
-    const u64 fast_m = __ballot(fast);
-    const u64 below = fast_m & ((1ull << lane) - 1ull);
-    const int prev = below ? 63 - __clzll((long long)below) : lane;
-    const bool change = fast && (below == 0 || __shfl(st, prev, kWave) != st || __shfl(sa, prev, kWave) != sa || __shfl(ss, prev, kWave) != ss ||
-                                 __shfl(p0, prev, kWave) != p0);
-    u64 change_m = __ballot(change);
-    int run = __popcll(change_m & ((2ull << lane) - 1ull)) - 1;  // (lane 63: 2 << 63 wraps to 0, - 1 = all ones)
-    if (__popcll(change_m) > g.run_slots) {
-      // out of base slots: the block ends in front of the row that would start run number run_slots
-      u64 m = change_m;
-      for (int k = 0; k < g.run_slots; ++k) m &= m - 1;
-      n_rows = __ffsll((long long)m) - 1;
-      change_m &= (1ull << n_rows) - 1ull;
-    }
-    const int n_runs = __popcll(change_m);
-    // row records
-    if (lane < n_rows) {
-      int stage = -1;
-      if (fast && prow >= 0)
-        for (int k = 0; k < g.n_stage; ++k)
-          if (g.stage_row[k] == prow) stage = k;
-      WalkRow r;
-      r.dest = mem0;
-      r.cls = cls;
-      r.slot = fast ? run : -1;
-      r.stage = stage;
-      r.prow = stage >= 0 ? -1 : prow;
-      r.pin = pin_on ? pin : -1;
-      r.big = (irow >> kRowBigShift) - 1;
-      r.pad = 0;
-      s_rows[buf * kWalkBlockRows + lane] = r;
-    }
-    // index bytes of the slice, lane = row: 16-byte pieces of the row's byte string (sw is a multiple of 16, so is idx_stride)
-    if (lane < n_rows && fast) {
-      const unsigned char* src = pl.res_idx + (size_t)(irow & ((1 << kRowBigShift) - 1)) * pl.idx_stride;
-      unsigned char* dst = s_idx + ((size_t)buf * kWalkBlockRows + lane) * sw;
-      for (int k = 0; k < sw; k += 16) {
-        uint4 v = {0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u};  // 64 = the empty entry of a mask table
-        if (w_first + k < pl.idx_stride) v = *(const uint4*)(src + w_first + k);
-        *(uint4*)(dst + k) = v;
-      }
-    }
-    // base words of every run, lane = word pair
-    for (int r = 0; r < n_runs; ++r) {
-      u64 m = change_m;
-      for (int k = 0; k < r; ++k) m &= m - 1;
-      const int lead = __ffsll((long long)m) - 1;
-      const int rst = __builtin_amdgcn_readlane(st, lead), rsa = __builtin_amdgcn_readlane(sa, lead), rss = __builtin_amdgcn_readlane(ss, lead),
-                rp0 = __builtin_amdgcn_readlane(p0, lead);
-      u64x2 b = keep;
-      if (all_fail) b = u64x2{0, 0};
-      if (pl.tol && rst >= 0) b &= *(const u64x2*)((const char*)(pl.tol + (size_t)rst * pl.stride) + voff);
-      if (pl.aff && rsa >= 0) b &= *(const u64x2*)((const char*)(pl.aff + (size_t)rsa * pl.stride) + voff);
-      if (pl.spread && rss >= 0) b &= *(const u64x2*)((const char*)(pl.spread + (size_t)rss * pl.stride) + voff);
-      if (pl.res && rp0 >= 0) b &= *(const u64x2*)((const char*)(pl.res + (size_t)rp0 * pl.stride) + voff);
-      if (2 * lane < sw) *(u64x2*)(s_base + ((size_t)buf * g.run_slots + r) * sw + 2 * lane) = b;
-    }
-    if (lane == 0) s_hdr[buf * 4] = n_rows;
+  const int n_blocks = (max(c_end - c_begin, 0) + kWalkBlockRows - 1) / kWalkBlockRows;
+  // the cached rows of a run, ANDed (lane = word pair); rows that are absent (family disabled, signature -1) count as all ones
+  auto run_base = [&](int rst, int rsa, int rss) {
+    u64x2 b = keep;
+    if (pl.tol && rst >= 0) b &= *(const u64x2*)((const char*)(pl.tol + (size_t)rst * pl.stride) + voff);
+    if (pl.aff && rsa >= 0) b &= *(const u64x2*)((const char*)(pl.aff + (size_t)rsa * pl.stride) + voff);
+    if (pl.spread && rss >= 0) b &= *(const u64x2*)((const char*)(pl.spread + (size_t)rss * pl.stride) + voff);
+    return b;
   };
 
-  if (loader) fill(0, c_begin);
-  __syncthreads();
-  int buf = 0, c0 = c_begin;
-  for (;;) {
-    const int n_rows = s_hdr[buf * 4];
-    if (n_rows == 0) break;  // (the same value for every thread: written before the barrier)
-    if (loader) {
-      fill(buf ^ 1, c0 + n_rows);
-    } else {
-      for (int i = wave; i < n_rows; i += kWalkStoreWaves) {
-        const WalkRow r = s_rows[buf * kWalkBlockRows + i];  // (every lane reads the same record: an LDS broadcast)
-        const int slot = __builtin_amdgcn_readfirstlane(r.slot);
-        if (slot < 0) continue;
-        const int dest = __builtin_amdgcn_readfirstlane(r.dest), cls = __builtin_amdgcn_readfirstlane(r.cls);
-        const int stage = __builtin_amdgcn_readfirstlane(r.stage), prow = __builtin_amdgcn_readfirstlane(r.prow);
-        const int pin = __builtin_amdgcn_readfirstlane(r.pin), big = __builtin_amdgcn_readfirstlane(r.big);
-        u64x2 x = {0, 0};
-        if (2 * lane < sw) {
-          const unsigned two = *(const unsigned short*)(s_idx + ((size_t)buf * kWalkBlockRows + i) * sw + 2 * lane);
-          const u64* tab = s_pm + ((size_t)big * sw + 2 * lane) * 65;
-          x = *(const u64x2*)(s_base + ((size_t)buf * g.run_slots + slot) * sw + 2 * lane);
-          x.x &= tab[two & 0xffu];
-          x.y &= tab[65 + (two >> 8)];
-          if (stage >= 0) x &= *(const u64x2*)(s_stage + (size_t)stage * sw + 2 * lane);
+  if (wave >= kWalkStoreWaves) {
+    // =========================================================== LOADER: every global load of the workgroup's steady state
+    constexpr int kHalfPieces = kSliceMaxWords / 16 / 2;  // 16-byte index pieces one lane takes: lanes 0-31 the first half of the row's
+    const int row_l = lane & (kWalkBlockRows - 1), half = lane / kWalkBlockRows;  // bytes, lanes 32-63 the second
+    // The descriptors of a loader's NEXT block are requested before it works on the current one: a block then costs one memory
+    // round trip on the loader's critical path (index bytes + base words, issued together), not three in a row.
+    int4 nd0 = {0, 0, -1, -1}, nd1 = {-1, -1, -1, -1}, nd2 = {-1, 1 << kRowBigShift, 0, 0};
+    auto request_desc = [&](int blk) {
+      const int c0 = c_begin + blk * kWalkBlockRows;
+      if (blk < n_blocks && row_l < min(kWalkBlockRows, c_end - c0)) {
+        const int4* dp = (const int4*)(desc + c0 + row_l);
+        nd0 = dp[0], nd1 = dp[1], nd2 = dp[2];
+      } else {
+        nd0 = int4{0, 0, -1, -1};  // (meta 0: not live)
+      }
+    };
+    request_desc(wave - kWalkStoreWaves);
+    for (int blk = wave - kWalkStoreWaves; blk < n_blocks; blk += kWalkLoaders) {
+      const int buf = blk % NB, c0 = c_begin + blk * kWalkBlockRows;
+      const int n_rows = min(kWalkBlockRows, c_end - c0);
+      const int cls = nd0.x, meta = nd0.y, pin = nd0.z, mem0 = nd0.w, st = nd1.x, sa = nd1.y, ss = nd1.z;
+      const int prow = (meta & kSlicePlane) ? nd2.x : -1, irow = nd2.y;
+      request_desc(blk + kWalkLoaders);
+      const bool fast = (meta & (kSliceLive | kSliceGeneral)) == kSliceLive;
+      // runs (lanes 0-31 decide): a fast row starts one when no fast row precedes it in the block or its cached rows differ from the
+      // previous fast row's
+      const u64 fast_m = __ballot(fast) & 0xffffffffull;
+      const u64 below = fast_m & ((1ull << row_l) - 1ull);
+      const int prev = below ? 63 - __clzll((long long)below) : row_l;
+      const bool change = fast && (below == 0 || __shfl(st, prev, kWave) != st || __shfl(sa, prev, kWave) != sa || __shfl(ss, prev, kWave) != ss);
+      const u64 change_m = __ballot(change) & 0xffffffffull;
+      const int run = (int)__popcll(change_m & ((2ull << row_l) - 1ull)) - 1;
+      const int n_runs = min((int)__popcll(change_m), g.run_slots);  // runs that get a base slot
+      // the buffer must be free: the store waves have finished with the block that used it last
+      const u64 tl0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      if (blk >= NB) {
+        const int want = kWalkStoreWaves * (blk / NB);
+        while (__hip_atomic_load(s_used + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
+      }
+      const u64 tl1 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+      t_spin += tl1 - tl0;
+      // index bytes of the slice: 16-byte pieces of the row's byte string (sw and idx_stride are multiples of 16).
+      // Issued first, consumed after the base words: one wait serves both.
+      uint4 ib[kHalfPieces];
+      const unsigned char* isrc = pl.res_idx + (size_t)(irow & ((1 << kRowBigShift) - 1)) * pl.idx_stride + w_first;
+#pragma unroll
+      for (int k = 0; k < kHalfPieces; ++k) {
+        const int off = (half * kHalfPieces + k) * 16;
+        ib[k] = uint4{0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u};  // 64 = the empty entry of a mask table
+        if (!(g.mode & 1) && fast && off < sw && w_first + off < pl.idx_stride) ib[k] = *(const uint4*)(isrc + off);
+      }
+      // base words of the runs, kWalkRunGroup at a time: all their loads go out before the first AND
+      for (int r0 = 0; r0 < n_runs; r0 += kWalkRunGroup) {
+        u64x2 b[kWalkRunGroup];
+#pragma unroll
+        for (int j = 0; j < kWalkRunGroup; ++j) {
+          b[j] = keep;
+          if (r0 + j < n_runs && !(g.mode & 2)) {
+            u64 m = change_m;
+            for (int k = 0; k < r0 + j; ++k) m &= m - 1;
+            const int lead = __ffsll((long long)m) - 1;
+            b[j] = run_base(__builtin_amdgcn_readlane(st, lead), __builtin_amdgcn_readlane(sa, lead), __builtin_amdgcn_readlane(ss, lead));
+          }
         }
-        if (prow >= 0) x &= *(const u64x2*)((const char*)(pl.res + (size_t)prow * pl.stride) + voff);  // (a plane row that is not staged)
-        if (pin >= 0) {
-          x.x &= (w_true == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
-          x.y &= (w_true + 1 == (pin >> 6)) ? (1ull << (pin & 63)) : 0ull;
+#pragma unroll
+        for (int j = 0; j < kWalkRunGroup; ++j)
+          if (r0 + j < n_runs && 2 * lane < sw) *(u64x2*)(s_base + ((size_t)buf * g.run_slots + r0 + j) * sw + 2 * lane) = b[j];
+      }
+      if (row_l < n_rows) {
+        if (fast) {
+          unsigned char* dst = s_idx + ((size_t)buf * kWalkBlockRows + row_l) * sw;
+#pragma unroll
+          for (int k = 0; k < kHalfPieces; ++k) {
+            const int off = (half * kHalfPieces + k) * 16;
+            if (off < sw) *(uint4*)(dst + off) = ib[k];
+          }
         }
-        if (!in_row) x = u64x2{0, 0};
-        const int pc = wave_sum_lane63(__popcll(x.x) + __popcll(x.y));
-        if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
-        if (in_row) *(u64x2*)((char*)(bitmap + (size_t)dest * row_stride) + voff) = x;
+        if (half == 0) {
+          int stage = -1;
+          if (fast && prow >= 0)
+            for (int k = 0; k < g.n_stage; ++k)
+              if (g.stage_row[k] == prow) stage = k;
+          WalkRow r;
+          r.dest = mem0;
+          r.cls = cls;
+          r.slot = !fast ? -1 : (run < g.run_slots ? run : -2);
+          r.chunk = c0 + row_l;
+          r.prow = stage >= 0 ? -1 : prow;
+          r.pin = pin_on ? pin : -1;
+          r.pm_off = max((irow >> kRowBigShift) - 1, 0) * sw * 65;
+          r.stage_off = (stage >= 0 ? stage : g.n_stage) * sw;
+          s_rows[buf * kWalkBlockRows + row_l] = r;
+        }
+      }
+      // publish: every LDS write of this wave is complete before the flag moves
+      if (lane == 0) __hip_atomic_store(s_ready + buf, blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (dbg) t_work += __builtin_amdgcn_s_memtime() - tl1;
+    }
+    if (dbg && lane == 0) {
+      atomicAdd(dbg + 0, t_spin);
+      atomicAdd(dbg + 1, t_work);
+    }
+    return;
+  }
+  // ============================================================= STORE waves: LDS in, 16-byte stores out
+  for (int blk = 0; blk < n_blocks; ++blk) {
+    const int buf = blk % NB, c0 = c_begin + blk * kWalkBlockRows;
+    const int n_rows = min(kWalkBlockRows, c_end - c0);
+    const u64 ts0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    while (__hip_atomic_load(s_ready + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != blk + 1) __builtin_amdgcn_s_sleep(1);
+    const u64 ts1 = dbg ? __builtin_amdgcn_s_memtime() : 0;
+    t_spin += ts1 - ts0;
+    if (!(g.mode & 8)) {
+      // kWalkRowsPerWave consecutive rows of the block per wave, stage by stage for ALL of them: a row is a chain of dependent LDS
+      // reads (record -> index bytes / base -> mask tables), ~1 300 cycles when walked alone (s_memtime, session 9); side by side
+      // the chains of the four rows overlap. The kernel is bound by INSTRUCTION ISSUE (SQ counters, session 10: 72 VALU + 48 SALU
+      // per (row, slice) pair in the first form), so the stages are lean and branch-free: record fields go to SGPRs, LDS offsets
+      // come ready-made from the loader, "no staged row" is an all-ones row, lanes past the slice are switched off as a whole, two
+      // rows share one DPP reduction (16-bit fields); the rare shapes (a run without a base slot, a plane row that is not staged, a
+      // pinned node) are patched afterwards under wave-uniform branches. (Letting the LOADER write the rows of slot-less runs
+      // instead was measured slower: 2.89 -> 3.19 ms, session 9.)
+      constexpr int K = kWalkRowsPerWave;
+      static_assert(K % 2 == 0, "rows are reduced in pairs");
+      const int rows0 = buf * kWalkBlockRows;
+      int slot[K], dest[K], cls[K], prow[K], pin[K], chunk[K], pm_off[K], stage_off[K];
+      bool live[K];
+      {
+        int4 ra[K], rb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {  // (every lane reads the same record: an LDS broadcast)
+          const int4* rp = (const int4*)(s_rows + rows0 + min(wave * K + k, n_rows - 1));
+          ra[k] = rp[0];
+          rb[k] = rp[1];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          dest[k] = __builtin_amdgcn_readfirstlane(ra[k].x);
+          cls[k] = __builtin_amdgcn_readfirstlane(ra[k].y);
+          slot[k] = __builtin_amdgcn_readfirstlane(ra[k].z);
+          chunk[k] = __builtin_amdgcn_readfirstlane(ra[k].w);
+          prow[k] = __builtin_amdgcn_readfirstlane(rb[k].x);
+          pin[k] = __builtin_amdgcn_readfirstlane(rb[k].y);
+          pm_off[k] = __builtin_amdgcn_readfirstlane(rb[k].z);
+          stage_off[k] = __builtin_amdgcn_readfirstlane(rb[k].w);
+          live[k] = wave * K + k < n_rows && slot[k] != -1;
+        }
+      }
+      u64x2 x[K];
+      int pcl[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        x[k] = u64x2{0, 0};
+        pcl[k] = 0;
+      }
+      if (2 * lane < sw) {  // (the lanes past the slice sit the stages out; their counts stay zero)
+        const int lp = 2 * lane;
+        unsigned two[K];
+        u64x2 p[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int i = min(wave * K + k, n_rows - 1);
+          two[k] = *(const unsigned short*)(s_idx + (rows0 + i) * sw + lp);
+          x[k] = *(const u64x2*)(s_base + (buf * g.run_slots + max(slot[k], 0)) * sw + lp);
+          p[k] = *(const u64x2*)(s_stage + stage_off[k] + lp);
+        }
+        u64x2 m[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const u64* tab = s_pm + pm_off[k] + lp * 65;
+          m[k] = u64x2{tab[two[k] & 0xffu], tab[65 + (two[k] >> 8)]};
+          if (g.mode & 32) m[k] = u64x2{two[k], two[k]};
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          m[k] &= p[k];
+          x[k] &= m[k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (live[k] && slot[k] == -2) {  // the block had more runs than base slots: this row fetches its cached rows itself (and the
+            const SliceDesc* d = desc + chunk[k];  // wave drains its store queue for it: one in-order vmcnt)
+            x[k] = run_base(d->st, d->sa, d->ss) & m[k];
+          }
+          if (live[k] && prow[k] >= 0) x[k] &= *(const u64x2*)((const char*)(pl.res + (size_t)prow[k] * pl.stride) + voff);  // (rare) a plane row that is not staged
+          if (pin[k] >= 0) {
+            x[k].x &= (w_true == (pin[k] >> 6)) ? (1ull << (pin[k] & 63)) : 0ull;
+            x[k].y &= (w_true + 1 == (pin[k] >> 6)) ? (1ull << (pin[k] & 63)) : 0ull;
+          }
+          pcl[k] = __popcll(x[k].x) + __popcll(x[k].y);
+        }
+      }
+      // feasible counts: a lane's count is <= 128 and a row's <= 8 192, so two rows ride in one 32-bit DPP reduction
+      int pc[K];
+#pragma unroll
+      for (int k = 0; k < K; k += 2) {
+        const int both = (g.mode & 64) ? pcl[k] : wave_sum_lane63(pcl[k] | (pcl[k + 1] << 16));
+        pc[k] = both & 0xffff;
+        pc[k + 1] = (int)((unsigned)both >> 16);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (!live[k]) continue;  // (wave-uniform)
+        if (lane == 63 && pc[k] && !(g.mode & 16)) atomicAdd(&class_count[cls[k]], pc[k]);
+        if (in_row && !(g.mode & 4)) *(u64x2*)((char*)(bitmap + (size_t)dest[k] * row_stride) + voff) = x[k];
       }
     }
-    __syncthreads();
-    c0 += n_rows;
-    buf ^= 1;
+    // Done with the buffer. RELAXED on purpose: a release here would drain the wave's GLOBAL stores (s_waitcnt vmcnt(0)) at every
+    // block boundary. What has to be ordered is only LDS against LDS, and a wave's LDS operations execute in order: the reads
+    // above are done when the add is.
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(s_used + buf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (dbg) t_work += __builtin_amdgcn_s_memtime() - ts1;
+  }
+  if (dbg && lane == 0) {
+    atomicAdd(dbg + 2, t_spin);
+    atomicAdd(dbg + 3, t_work);
   }
 }
 

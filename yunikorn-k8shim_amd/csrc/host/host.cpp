@@ -240,15 +240,7 @@ int recreate_engine(ykhost* h) {
   c.topology_keys = h->enc.KD;
   c.selector_classes = h->enc.KS;
   c.port_words = h->enc.KP;
-  // engine tunables for experiments: YKPRED_CHUNK_MEMBERS=1..64, YKPRED_CHUNK_UNSORTED=1
-  if (const char* v = getenv("YKPRED_CHUNK_MEMBERS")) c.reserved[0] = atoi(v);
-  if (const char* v = getenv("YKPRED_CHUNK_UNSORTED")) c.reserved[1] = atoi(v);
-  if (const char* v = getenv("YKPRED_COMBINE_LDS")) c.reserved[2] = atoi(v);
-  if (const char* v = getenv("YKPRED_GRAPH")) c.reserved[3] = atoi(v);
-  if (const char* v = getenv("YKPRED_WALK_ROWS")) c.reserved[4] = atoi(v);
-  if (const char* v = getenv("YKPRED_WAVE_COMBINE_BELOW")) c.reserved[5] = atoi(v);
-  if (const char* v = getenv("YKPRED_BAND_STEPS")) c.reserved[6] = atoi(v);      // band height of the zone-A layout (-1 = no band layout)
-  if (const char* v = getenv("YKPRED_COMBINE_BESIDE")) c.reserved[7] = atoi(v) ? 2 : 0;  // class-by-class writer beside the band writer
+  // (engine tunables for tests come from YKPRED_TUNE, read by ykpred_create itself)
   int r = ykpred_create(&c, &h->eng);
   if (r != YKPRED_OK) return fail(h, std::string("ykpred_create: ") + ykpred_last_error(nullptr), r);
   h->cfgR = c.num_resources;
@@ -274,12 +266,10 @@ int encode_tables(ykhost* h, EncodedTables* T) {
       h->spec_templates.push_back(t);
     }
   }
-  auto _t1 = std::chrono::steady_clock::now();
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
   h->unsupported_asks = 0;
   if (!h->enc.unsupported.empty())
     for (const Pod* p : h->pending) h->unsupported_asks += h->enc.unsupported.count(p->tpl) ? 1 : 0;
-  auto _t2 = std::chrono::steady_clock::now();
   const int R = h->enc.R, KT = h->enc.KT, W = h->enc.W, KD = h->enc.KD, KS = h->enc.KS, KP = h->enc.KP;
   const size_t N = h->nodes.size();
   T->ports.assign(N * KP + 1, 0);
@@ -310,8 +300,6 @@ int encode_tables(ykhost* h, EncodedTables* T) {
     for (int k = 0; k < KT; ++k) T->taints[(size_t)k * N + n] = t1[(size_t)k];
     for (int w = 0; w < W; ++w) T->labels[(size_t)w * N + n] = l1[(size_t)w];
   }
-  auto _t3 = std::chrono::steady_clock::now();
-  if (getenv("YKHOST_PROFILE")) fprintf(stderr, "encode: dict %.1f ms, nodes %.1f ms\n", std::chrono::duration<double, std::milli>(_t2 - _t1).count(), std::chrono::duration<double, std::milli>(_t3 - _t2).count());
   ykpred_nodes_t& nt = T->nt;
   nt = ykpred_nodes_t{};
   nt.count = (int32_t)N;
@@ -1190,8 +1178,7 @@ static int update_pod_value(ykhost* h, const mj::Value& v) {
 // template that was seen before costs no parse at all. Anything the scanner does not vouch for takes the full parser.
 static int update_pod_text(ykhost* h, js::Range doc) {
   js::PodScan sc;
-  static const bool no_memo = getenv("YKHOST_NO_TEMPLATE_MEMO") != nullptr;  // (measurements: the round-2 ingest path)
-  if (no_memo || !js::scan_pod(doc, &sc) || sc.needs_full_parse) {
+  if (!js::scan_pod(doc, &sc) || sc.needs_full_parse) {
     h->ingest_full++;
     mj::ValuePtr v = mj::parse(std::string(doc.b, doc.e));
     return update_pod_value(h, *v);

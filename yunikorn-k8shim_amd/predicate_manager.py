@@ -381,7 +381,7 @@ class GpuPredicateManager:
         return n.value
 
     def evaluate_into(self, bitmap=None, counts=None, decisions=None, keys=None, stream=None, allocate=True, profile=False,
-                      direct=False, variant=0, spread_count_only=False, spread_counts_ready=False):
+                      direct=False, spread_count_only=False, spread_counts_ready=False):
         """ykpred_eval with caller-owned DEVICE outputs (objects exposing data_ptr(), e.g. torch tensors) on the
         caller's HIP stream — how a multi-GPU driver keeps the results where its collectives can reach them."""
         self.sync()
@@ -389,7 +389,7 @@ class GpuPredicateManager:
         a.prefilter_plugins = self._masks[1] if allocate else self._masks[0]
         a.filter_plugins = self._masks[3] if allocate else self._masks[2]
         a.options = OUT_BITMAP | OUT_COUNTS | OUT_DECISIONS | (OUT_DECISION_KEYS if keys is not None else 0)
-        a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0) | ((variant & 3) << 16)
+        a.options |= (EVAL_PROFILE if profile else 0) | (EVAL_DIRECT if direct else 0)
         a.options |= (EVAL_SPREAD_COUNT_ONLY if spread_count_only else 0) | (EVAL_SPREAD_COUNTS_READY if spread_counts_ready else 0)
         a.bitmap = None if bitmap is None else bitmap.data_ptr()
         a.bitmap_rows = 0 if bitmap is None else int(bitmap.shape[0])  # a caller-owned bitmap states the rows it holds
