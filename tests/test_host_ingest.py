@@ -80,3 +80,55 @@ def test_real_world_shaped_documents_and_errors():
         assert rc == -2 and b"malformed" in m._L.ykhost_last_error(m._h)  # -1 - (one document applied)
     finally:
         m.close()
+
+
+def test_large_batch_takes_the_scanning_threads_and_equals_one_thread(cluster_docs, monkeypatch):
+    """A batch of a few hundred KB is cut into pieces scanned by several threads (YKHOST_INGEST_THREADS pins the count: the
+    build container reports more cores than it has); mirror, encoded tables and ingest counters equal the one-thread path's."""
+    docs, _ = cluster_docs
+    assert len(docs[1]) > 4 * 65536
+    results = []
+    for threads in ("1", "4"):
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
+        m = pkg.GpuPredicateManager(device=-1)
+        try:
+            assert [m.update_documents(k, docs[k]) for k in (0, 1, 2)] == [d.count(b"\n") for d in docs]
+            results.append((m.dump_snapshot(), m.encoded_tables(), m.ingest_stats()))
+        finally:
+            m.close()
+    assert results[0] == results[1]
+    # a pretty-printed batch (raw newlines inside documents) cannot be cut: it takes the one-thread path and still loads
+    monkeypatch.setenv("YKHOST_INGEST_THREADS", "4")
+    pretty = b"\n".join(json.dumps(json.loads(d), indent=1).encode() for d in docs[2].splitlines()[:600])
+    m = pkg.GpuPredicateManager(device=-1)
+    try:
+        m.update_documents(0, docs[0])
+        assert m.update_documents(2, pretty) == 600
+    finally:
+        m.close()
+
+
+def test_parallel_ingest_under_thread_sanitizer(cluster_docs, tmp_path):
+    """libykhost's sources + tests/c/ingest_tsan.c under -fsanitize=thread: the scanning threads of the batch forms and two
+    concurrent reader threads on the same handle produce no data-race report."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "yunikorn-k8shim_amd", "lib")
+    pkg.build_all()
+    docs, _ = cluster_docs
+    paths = []
+    for k, d in enumerate(docs):
+        paths.append(str(tmp_path / f"docs{k}.ndjson"))
+        with open(paths[-1], "wb") as f:
+            f.write(d)
+    exe = str(tmp_path / "ingest_tsan")
+    san = ["-fsanitize=thread", "-fno-omit-frame-pointer", "-g", "-O1"]
+    subprocess.check_call(["gcc", "-std=c11"] + san + ["-I" + os.path.join(root, "include"), "-c", os.path.join(root, "tests", "c", "ingest_tsan.c"),
+                           "-o", str(tmp_path / "ingest_tsan.o")])
+    subprocess.check_call(["g++", "-std=c++17"] + san + ["-I" + os.path.join(root, "include"), os.path.join(root, "yunikorn-k8shim_amd", "csrc", "host", "host.cpp"),
+                           str(tmp_path / "ingest_tsan.o"), "-o", exe, "-L" + lib, "-lykpred", "-lpthread", "-Wl,-rpath," + lib])
+    out = subprocess.run([exe] + paths, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, YKHOST_INGEST_THREADS="4", TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0"))
+    assert out.returncode == 0 and "ingest ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-4000:]

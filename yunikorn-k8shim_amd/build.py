@@ -17,7 +17,7 @@ LIB = os.path.join(PKG, "lib")
 ENGINE_SRC = os.path.join(PKG, "csrc", "engine", "engine.hip")
 ENGINE_DEPS = [ENGINE_SRC, os.path.join(PKG, "csrc", "engine", "kernels.hip.h"), os.path.join(ROOT, "include", "ykpred.h")]
 HOST_SRC = os.path.join(PKG, "csrc", "host", "host.cpp")
-HOST_DEPS = [HOST_SRC] + [os.path.join(PKG, "csrc", "host", f) for f in ("encoder.h", "objects.h", "minijson.h", "quantity.h")] + [
+HOST_DEPS = [HOST_SRC] + [os.path.join(PKG, "csrc", "host", f) for f in ("encoder.h", "objects.h", "minijson.h", "quantity.h", "jsonscan.h")] + [
     os.path.join(ROOT, "include", "ykhost.h"), os.path.join(ROOT, "include", "ykpred.h")]
 LIBYKPRED = os.path.join(LIB, "libykpred.so")
 LIBYKHOST = os.path.join(LIB, "libykhost.so")

@@ -292,9 +292,6 @@ struct ykpred_engine {
   int sig_wpl = 0;                  // sig_wpl: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // combine_slices: 0 = index-row populations take the wave-per-chunk writer instead of k_walk_rows
   int decide_groups_from = 16384;   // decide_groups_from: classes from which k_decide serves four classes per wave
-  int walk_mode = 0, walk_run_slots = 10, walk_buffers = 8, walk_debug = 0;
-  DevBuf d_walk_dbg;
-  int walk_chunks_per_group = 2048, walk_throttle = 0;  // (experiments of this round: walk_chunks, walk_throttle)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
@@ -1143,12 +1140,6 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
         e->band_steps = val > 0 ? std::min(256, std::max(4, (val + 3) / 4 * 4)) : 0;
       } else if (key == "chunk_members") e->chunk_members = std::min(std::max(val, 1), (int)ykk::kChunkMembers);
       else if (key == "wave_combine_below") e->wave_combine_below = std::max(val, 0);
-      else if (key == "walk_chunks") e->walk_chunks_per_group = std::max(val, 64);
-      else if (key == "walk_throttle") e->walk_throttle = val;
-      else if (key == "walk_mode") e->walk_mode = val;
-      else if (key == "walk_debug") e->walk_debug = val;
-      else if (key == "walk_run_slots") e->walk_run_slots = std::max(val, 2);
-      else if (key == "walk_buffers") e->walk_buffers = std::max(val, 2);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
         delete e;
@@ -1960,8 +1951,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       wg.slice_words = ((e->row_stride + wg.n_slices - 1) / wg.n_slices + 15) / 16 * 16;  // (row_stride is a multiple of 16)
       wg.n_stage = (int)e->h_stage_rows.size();
       for (int k = 0; k < wg.n_stage; ++k) wg.stage_row[k] = e->h_stage_rows[(size_t)k];
-      wg.run_slots = e->walk_run_slots;
-      wg.n_buffers = e->walk_buffers;
+      wg.run_slots = 10;
+      wg.n_buffers = 8;
       // shed what is optional until the workgroup's LDS fits the device: plane rows staged beyond 8, block buffers, base slots, staged rows
       auto fits = [&]() { return ykk::walk_lds_bytes(pc.n_big, wg) <= (size_t)e->max_lds_bytes; };
       while (!fits() && wg.n_stage > 8) wg.n_stage--;
@@ -1975,9 +1966,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (slices) {
       // chunk descriptors first, one thread per chunk (what a wave needs to know about a chunk, resolved once per pass)
       const size_t lds = ykk::walk_lds_bytes(pc.n_big, wg);
-      wg.chunks_per_group = e->walk_chunks_per_group;
-      wg.throttle = e->walk_throttle;
-      wg.mode = e->walk_mode;
+      wg.chunks_per_group = 2048;
       HIPCHK(e->d_slice_desc.ensure((size_t)std::max(e->NC, 1) * sizeof(ykk::SliceDesc)));
       HIPCHK(e->d_slice_general.ensure(sizeof(int)));
       HIPCHK(hipMemsetAsync(e->d_slice_general.p, 0, sizeof(int), sz));
@@ -1986,21 +1975,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       tm.end(sz, "k_slice_desc");
       tm.begin(sz);
       const dim3 sgrid((unsigned)(((e->NC + wg.chunks_per_group - 1) / wg.chunks_per_group) * wg.n_slices));
-      if (e->walk_debug && !e->d_walk_dbg.p) {
-        HIPCHK(e->d_walk_dbg.ensure(4 * sizeof(u64)));
-        HIPCHK(hipMemset(e->d_walk_dbg.p, 0, 4 * sizeof(u64)));
-      }
       if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ykk::k_walk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(ykk::k_walk_rows, sgrid, dim3(ykk::kWalkThreads), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words,
-                         e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, wg, e->walk_debug ? e->d_walk_dbg.as<u64>() : (u64*)nullptr);
+                         e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, wg);
       tm.end(sz, "k_walk_rows");
-      if (e->walk_debug) {
-        u64 h[4] = {0, 0, 0, 0};
-        (void)hipStreamSynchronize(sz);
-        (void)hipMemcpy(h, e->d_walk_dbg.p, sizeof h, hipMemcpyDeviceToHost);
-        fprintf(stderr, "k_walk_rows cycles (sum over waves): loaders spin %llu work %llu | store waves spin %llu work %llu | groups %u\n", h[0], h[1], h[2], h[3], sgrid.x);
-        (void)hipMemset(e->d_walk_dbg.p, 0, sizeof h);
-      }
       tm.begin(sz);
       // chunks the fast path does not cover (several member rows, pins to unknown nodes, other row shapes): wave per chunk
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,

@@ -1308,8 +1308,6 @@ struct WalkGeom {
   int run_slots;               // base slots per block: rows of further runs fetch their cached rows themselves
   int n_buffers;               // LDS block buffers: how far the loaders run ahead of the store waves (>= 2 x loaders wanted)
   int chunks_per_group;        // chunks one workgroup walks
-  int throttle;                // stores a store wave keeps in flight (0 = as many as the counter allows)
-  int mode;                    // EXPERIMENT (timing only, wrong bitmaps): 1 no index loads, 2 no base loads, 4 no stores, 8 store waves idle, 16 no atomics
   int n_stage;                 // staged plane rows ...
   int stage_row[kWalkMaxStage];  // ... their row ids in the request family
 };
@@ -1326,10 +1324,9 @@ __host__ __device__ inline size_t walk_lds_bytes(int n_big, const WalkGeom& g) {
 }
 __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words,
                                                             int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
-                                                            WalkGeom g, u64* __restrict__ dbg) {
+                                                            WalkGeom g) {
   typedef u64x2_t u64x2;
   extern __shared__ u64 walk_lds[];
-  u64 t_spin = 0, t_work = 0;  // (dbg: cycles this wave spent waiting for the other side / working)
   const int sw = g.slice_words, NB = g.n_buffers;
   u64* s_pm = walk_lds;                                                  // [n_big][sw][65]
   u64* s_stage = s_pm + (size_t)pl.n_big * sw * 65;                      // [n_stage + 1][sw]: row n_stage = all ones ("no staged plane row")
@@ -1411,13 +1408,10 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
       const int run = (int)__popcll(change_m & ((2ull << row_l) - 1ull)) - 1;
       const int n_runs = min((int)__popcll(change_m), g.run_slots);  // runs that get a base slot
       // the buffer must be free: the store waves have finished with the block that used it last
-      const u64 tl0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
       if (blk >= NB) {
         const int want = kWalkStoreWaves * (blk / NB);
         while (__hip_atomic_load(s_used + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
       }
-      const u64 tl1 = dbg ? __builtin_amdgcn_s_memtime() : 0;
-      t_spin += tl1 - tl0;
       // index bytes of the slice: 16-byte pieces of the row's byte string (sw and idx_stride are multiples of 16).
       // Issued first, consumed after the base words: one wait serves both.
       uint4 ib[kHalfPieces];
@@ -1426,7 +1420,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
       for (int k = 0; k < kHalfPieces; ++k) {
         const int off = (half * kHalfPieces + k) * 16;
         ib[k] = uint4{0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u};  // 64 = the empty entry of a mask table
-        if (!(g.mode & 1) && fast && off < sw && w_first + off < pl.idx_stride) ib[k] = *(const uint4*)(isrc + off);
+        if (fast && off < sw && w_first + off < pl.idx_stride) ib[k] = *(const uint4*)(isrc + off);
       }
       // base words of the runs, kWalkRunGroup at a time: all their loads go out before the first AND
       for (int r0 = 0; r0 < n_runs; r0 += kWalkRunGroup) {
@@ -1434,7 +1428,7 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
 #pragma unroll
         for (int j = 0; j < kWalkRunGroup; ++j) {
           b[j] = keep;
-          if (r0 + j < n_runs && !(g.mode & 2)) {
+          if (r0 + j < n_runs) {
             u64 m = change_m;
             for (int k = 0; k < r0 + j; ++k) m &= m - 1;
             const int lead = __ffsll((long long)m) - 1;
@@ -1473,11 +1467,6 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
       }
       // publish: every LDS write of this wave is complete before the flag moves
       if (lane == 0) __hip_atomic_store(s_ready + buf, blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (dbg) t_work += __builtin_amdgcn_s_memtime() - tl1;
-    }
-    if (dbg && lane == 0) {
-      atomicAdd(dbg + 0, t_spin);
-      atomicAdd(dbg + 1, t_work);
     }
     return;
   }
@@ -1485,11 +1474,8 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
   for (int blk = 0; blk < n_blocks; ++blk) {
     const int buf = blk % NB, c0 = c_begin + blk * kWalkBlockRows;
     const int n_rows = min(kWalkBlockRows, c_end - c0);
-    const u64 ts0 = dbg ? __builtin_amdgcn_s_memtime() : 0;
     while (__hip_atomic_load(s_ready + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != blk + 1) __builtin_amdgcn_s_sleep(1);
-    const u64 ts1 = dbg ? __builtin_amdgcn_s_memtime() : 0;
-    t_spin += ts1 - ts0;
-    if (!(g.mode & 8)) {
+    {
       // kWalkRowsPerWave consecutive rows of the block per wave, stage by stage for ALL of them: a row is a chain of dependent LDS
       // reads (record -> index bytes / base -> mask tables), ~1 300 cycles when walked alone (s_memtime, session 9); side by side
       // the chains of the four rows overlap. The kernel is bound by INSTRUCTION ISSUE (SQ counters, session 10: 72 VALU + 48 SALU
@@ -1547,7 +1533,6 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
         for (int k = 0; k < K; ++k) {
           const u64* tab = s_pm + pm_off[k] + lp * 65;
           m[k] = u64x2{tab[two[k] & 0xffu], tab[65 + (two[k] >> 8)]};
-          if (g.mode & 32) m[k] = u64x2{two[k], two[k]};
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -1572,15 +1557,15 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
       int pc[K];
 #pragma unroll
       for (int k = 0; k < K; k += 2) {
-        const int both = (g.mode & 64) ? pcl[k] : wave_sum_lane63(pcl[k] | (pcl[k + 1] << 16));
+        const int both = wave_sum_lane63(pcl[k] | (pcl[k + 1] << 16));
         pc[k] = both & 0xffff;
         pc[k + 1] = (int)((unsigned)both >> 16);
       }
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         if (!live[k]) continue;  // (wave-uniform)
-        if (lane == 63 && pc[k] && !(g.mode & 16)) atomicAdd(&class_count[cls[k]], pc[k]);
-        if (in_row && !(g.mode & 4)) *(u64x2*)((char*)(bitmap + (size_t)dest[k] * row_stride) + voff) = x[k];
+        if (lane == 63 && pc[k]) atomicAdd(&class_count[cls[k]], pc[k]);
+        if (in_row) *(u64x2*)((char*)(bitmap + (size_t)dest[k] * row_stride) + voff) = x[k];
       }
     }
     // Done with the buffer. RELAXED on purpose: a release here would drain the wave's GLOBAL stores (s_waitcnt vmcnt(0)) at every
@@ -1588,11 +1573,6 @@ __global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const Sli
     // above are done when the add is.
     asm volatile("" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(s_used + buf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (dbg) t_work += __builtin_amdgcn_s_memtime() - ts1;
-  }
-  if (dbg && lane == 0) {
-    atomicAdd(dbg + 2, t_spin);
-    atomicAdd(dbg + 3, t_work);
   }
 }
 

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -1230,9 +1231,181 @@ int32_t ykhost_update_pod(ykhost_t* h, const char* pod_json) {
 // comma-separated; a JSON array body works). What InitializeState (context.go:1411-1484) replays at start-up — every node,
 // every pod — crosses cgo once, takes the handle's lock once, and the pods share the template memo. → documents applied;
 // on a malformed or rejected document: -1 - (documents applied before it), reason in ykhost_last_error.
+// ---- the batch in parallel -------------------------------------------------------------------------------------------
+// What costs the time of a large batch is not the cache bookkeeping but reading the text: finding the documents, the five
+// fields and the template key of each, and parsing the templates nobody has seen yet (1.2-1.4 us per document on one thread:
+// 5.4 s for the 3.8 M documents of InitializeState at configs[2] size). That part has no shared state, so it runs on every
+// host core: the buffer is cut at newlines into one piece per thread, each thread scans its documents into finished Pod
+// objects (strings allocated there) and parses the templates the memo does not know into a list of its own. The cache
+// bookkeeping — SchedulerCache.UpdatePod is order-dependent: a later version of a pod replaces an earlier one — then runs on
+// the calling thread, document by document in the buffer's order, exactly as the one-thread form does.
+// The cut assumes what encoding/json.Marshal produces: no raw newline inside a document. A piece whose first or last
+// document does not parse (the cut fell inside a pretty-printed document) makes the whole batch take the one-thread path:
+// nothing has been applied at that point.
+namespace {
+// templates the memo does not know yet, shared by the scanning threads: the first thread that meets a key parses the
+// document, the others find the entry (a thread-local map in front keeps the shard locks off the common path)
+struct SharedTemplates {
+  static constexpr int kShards = 64;
+  struct Shard {
+    std::mutex mu;
+    std::unordered_map<std::string, int> index;
+    std::deque<PodTemplate> tpls;
+    std::deque<std::string> keys;
+  } shard[kShards];
+};
+struct ScannedPod {
+  Pod pod;                 // uid / name / node_name / terminating; tpl when the memo had it
+  std::string phase;
+  int tpl_shard = -1, tpl_index = -1;  // else: the shared new template ...
+  bool first = false;                  // ... and whether this document is the one it was parsed from
+  js::Range full{};        // else: the document takes the full parser (in the ordered pass)
+};
+struct ScannedPiece {
+  std::vector<ScannedPod> pods;
+  bool ok = true;
+  std::string error;
+};
+void scan_piece(const ykhost* h, SharedTemplates* shared, const char* b, const char* e, ScannedPiece* out) {
+  try {
+    std::unordered_map<std::string, std::pair<int, int>> local;
+    out->pods.reserve((size_t)(e - b) / 256);
+    long n = js::documents(b, e, [&](js::Range doc) {
+      if (memchr(doc.b, '\n', doc.size())) out->ok = false;  // (not the layout the cut relies on)
+      out->pods.emplace_back();
+      ScannedPod& sp = out->pods.back();
+      js::PodScan sc;
+      if (!js::scan_pod(doc, &sc) || sc.needs_full_parse) {
+        sp.full = doc;
+        return;
+      }
+      auto it = h->tpl_memo.find(sc.key);  // (read-only while the pieces are scanned)
+      if (it != h->tpl_memo.end()) {
+        sp.pod.tpl = it->second;
+      } else {
+        auto lt = local.find(sc.key);
+        if (lt == local.end()) {
+          SharedTemplates::Shard& sh = shared->shard[std::hash<std::string>{}(sc.key) % SharedTemplates::kShards];
+          int idx = -1;
+          {
+            std::lock_guard<std::mutex> lock(sh.mu);
+            auto st = sh.index.find(sc.key);
+            if (st != sh.index.end()) idx = st->second;
+          }
+          if (idx < 0) {
+            PodTemplate parsed = read_template(*mj::parse(std::string(doc.b, doc.e)));  // (outside the lock; a race parses twice, keeps one)
+            std::lock_guard<std::mutex> lock(sh.mu);
+            auto st = sh.index.find(sc.key);
+            if (st != sh.index.end()) {
+              idx = st->second;
+            } else {
+              idx = (int)sh.tpls.size();
+              sh.tpls.push_back(std::move(parsed));
+              sh.keys.push_back(sc.key);
+              sh.index.emplace(sc.key, idx);
+              sp.first = true;
+            }
+          }
+          lt = local.emplace(std::move(sc.key), std::make_pair((int)(&sh - shared->shard), idx)).first;
+        }
+        sp.tpl_shard = lt->second.first;
+        sp.tpl_index = lt->second.second;
+      }
+      sp.pod.uid = sc.uid.str();
+      sp.pod.name = sc.name.str();
+      sp.pod.terminating = sc.terminating;
+      sp.pod.node_name = sc.node_name.str();
+      sp.phase = sc.phase.str();
+    });
+    if (n < 0) out->ok = false;
+  } catch (const std::exception& ex) {
+    out->ok = false;
+    out->error = ex.what();
+  }
+}
+// → documents applied, -1 when the batch has to take the one-thread path (nothing applied), or the error code of a rejected
+// document (-1 - applied, like the one-thread form)
+long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallback) {
+  *fallback = true;
+  // YKHOST_INGEST_THREADS: a container with a CPU quota still reports every core of its host (hardware_concurrency), and
+  // scanning threads that share two real cores are slower than one; 1 = the one-thread path
+  static const int want = [] {
+    const char* v = getenv("YKHOST_INGEST_THREADS");
+    return v ? atoi(v) : 0;
+  }();
+  const unsigned hw = want > 0 ? (unsigned)want : std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  const int64_t min_piece = 1 << 16;
+  const int T = (int)std::min<int64_t>(hw, len / min_piece);
+  if (T < 2) return -1;
+  std::vector<const char*> cut((size_t)T + 1);
+  cut[0] = text;
+  cut[(size_t)T] = text + len;
+  for (int t = 1; t < T; ++t) {
+    const char* p = text + len * t / T;
+    p = (const char*)memchr(p, '\n', (size_t)(text + len - p));
+    cut[(size_t)t] = p ? p + 1 : text + len;
+  }
+  std::vector<ScannedPiece> pieces((size_t)T);
+  auto shared = std::make_unique<SharedTemplates>();
+  {
+    std::vector<std::thread> threads;
+    for (int t = 1; t < T; ++t) threads.emplace_back(scan_piece, h, shared.get(), cut[(size_t)t], cut[(size_t)t + 1], &pieces[(size_t)t]);
+    scan_piece(h, shared.get(), cut[0], cut[1], &pieces[0]);
+    for (auto& th : threads) th.join();
+  }
+  for (const ScannedPiece& pc : pieces)
+    if (!pc.ok) return -1;
+  *fallback = false;
+  // ---- the ordered pass: a new template is interned when the first pod that carries it is reached — the order the one-thread
+  // form interns them in — then the pod goes through the cache
+  std::vector<std::vector<const PodTemplate*>> interned(SharedTemplates::kShards);
+  for (int k = 0; k < SharedTemplates::kShards; ++k) interned[(size_t)k].assign(shared->shard[k].tpls.size(), nullptr);
+  long applied = 0;
+  ensure_uid_index(h);
+  try {
+    for (ScannedPiece& pc : pieces) {
+      for (ScannedPod& sp : pc.pods) {
+        if (sp.full.present()) {
+          h->ingest_full++;
+          mj::ValuePtr v = mj::parse(std::string(sp.full.b, sp.full.e));
+          update_pod_value(h, *v);
+        } else {
+          if (sp.tpl_shard >= 0) {
+            const PodTemplate*& slot = interned[(size_t)sp.tpl_shard][(size_t)sp.tpl_index];
+            if (!slot) {
+              SharedTemplates::Shard& sh = shared->shard[sp.tpl_shard];
+              slot = h->pool.intern(std::move(sh.tpls[(size_t)sp.tpl_index]));
+              if (h->tpl_memo.size() < 262144) h->tpl_memo.emplace(std::move(sh.keys[(size_t)sp.tpl_index]), slot);
+              h->ingest_full++;  // (one full parse per new template, as on one thread)
+            } else {
+              h->ingest_fast++;
+            }
+            sp.pod.tpl = slot;
+          } else {
+            h->ingest_fast++;
+          }
+          if (sp.pod.uid.empty()) sp.pod.uid = "anon-" + std::to_string(h->pod_store.size());
+          apply_pod(h, store_pod(h, std::move(sp.pod)), sp.phase);
+        }
+        ++applied;
+      }
+    }
+  } catch (const std::exception& ex) {
+    fail(h, std::string("document #") + std::to_string(applied) + ": " + ex.what());
+    return -1 - applied;
+  }
+  return applied;
+}
+}  // namespace
+
 int32_t ykhost_update_pods_batch(ykhost_t* h, const char* text, int64_t len) {
   YKHOST_LOCKED(h);
   if (!text || len < 0) return fail(h, "bad argument");
+  {
+    bool fallback = true;
+    const long n = update_pods_parallel(h, text, len, &fallback);
+    if (!fallback) return (int32_t)n;
+  }
   long applied = 0;
   try {
     long n = js::documents(text, text + len, [&](js::Range doc) {
