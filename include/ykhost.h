@@ -192,6 +192,12 @@ int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5);
 int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32_t apply, int32_t* out_nodes /* [n] */);
 int32_t ykhost_round_stats(ykhost_t* h, int64_t* out4);
 
+/* Engine calls that came back YKPRED_E_DEVICE / YKPRED_E_NOMEM so far (failed allocation, lost device). Each one marks the whole
+ * device state stale: the failing call returns its error (Predicates() < 0: the Go manager routes the ask to the CPU predicate
+ * manager — SURVEY.md §5, "must degrade, never fail scheduling"), the mirror stays intact, and the next ykhost_sync /
+ * ykhost_evaluate re-uploads every table and runs a full pass. */
+int64_t ykhost_device_errors(ykhost_t* h);
+
 /* victims: UIDs of pods assigned to the node (NULL / unknown UID = nil victim). Returns the index or -1. */
 int32_t ykhost_preemption_predicates(ykhost_t* h, int32_t pod, int32_t node, const char* const* victim_uids, int32_t num_victims,
                                      int32_t start_index);

@@ -415,6 +415,11 @@ int32_t ykpred_preemption_batch(ykpred_engine_t* e, int32_t num_queries, const i
  *                           ykpred_preemption reuse those cluster-wide histograms instead of rebuilding shard-local ones.
  * Not sharded: PreemptionPredicates (one node, sequential victim prefix) runs on the shard that owns the node. */
 #define YKPRED_COMM_ID_BYTES 128
+/* Which shared library provides the collectives (ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather /
+ * ncclAllReduce / ncclGetErrorString): by default librccl, loaded on the first ykpred_comm_* call. Effective only BEFORE that
+ * first call of the process. The tests point it at tests/c/rccl_stub.cpp — the same entry points over shared memory between
+ * processes that share one GPU, which RCCL itself refuses — so that the world > 1 branches run on a one-GPU box. */
+int32_t ykpred_comm_use_library(const char* path);
 int32_t ykpred_comm_unique_id(uint8_t* id /* [YKPRED_COMM_ID_BYTES] */);
 int32_t ykpred_comm_init(ykpred_engine_t* e, const uint8_t* id, int32_t rank, int32_t world, int32_t node_offset);
 int32_t ykpred_comm_destroy(ykpred_engine_t* e);

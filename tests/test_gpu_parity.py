@@ -1216,6 +1216,27 @@ def test_sharded_cluster_ranks(world, total_nodes):
     assert out.stdout.count("rows True counts True decisions True") == world, out.stdout[-1500:]
 
 
+@pytest.mark.parametrize("world,total_nodes", [(2, 200), (3, 1000), (2, 5000)])
+def test_sharded_cluster_ranks_through_the_c_abi_collectives(tmp_path, world, total_nodes):
+    """The SAME check with the exchanges going through the C ABI with world > 1 on this box's one GPU: ykpred_comm_init,
+    ykpred_gather_bitmap, ykpred_gather_bitmap_compressed (per-peer header exchange: the shards' class partitions differ),
+    ykpred_exchange_decisions and the in-place histogram all-reduces inside ykpred_eval — libykpred loads tests/c/rccl_stub.cpp
+    (the collectives' entry points over shared memory between the rank processes) instead of librccl, which refuses two ranks on
+    one device. What RCCL itself does over xGMI stays the driver's 8-GPU run; every line of libykpred's side of it runs here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-fPIC", "-shared", "-std=c++17", os.path.join(root, "tests", "c", "rccl_stub.cpp"), "-o", stub, "-lrt"])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + world * 7 + total_nodes % 89), os.path.join(root, "tests", "_shard_worker.py"),
+           str(total_nodes), "700"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SHARD_RCCL_STUB=stub))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    assert out.stdout.count("rccl-stub: rows True counts True decisions True") == world, out.stdout[-1500:]
+    assert out.stdout.count("class-compressed gather True") == world
+
+
 def test_rccl_communicator_single_rank():
     """The C-ABI communicator with world = 1 on this box's GPU: librccl is loaded on first use, the all-gather of a
     one-shard cluster is the bitmap itself, the decision exchange maps local to global node indices (node_offset)."""
@@ -1725,3 +1746,37 @@ def test_match_label_keys_and_all_namespace_selectors_against_the_oracle(pm, see
     dec = pm.read_decisions()
     for p in range(0, len(snap["pods"]), 3):
         assert o.decide(p, orc.RESERVE_PRE, orc.RESERVE_FILT) == (int(want[p].sum()), int(dec[p]))
+
+
+@pytest.mark.parametrize("fail_after", [1, 2, 5, 9, 14, 20, 27, 35, 44, 54, 65, 80, 100, 130])
+def test_device_failure_injection_degrades_and_recovers(monkeypatch, fail_after):
+    """"if the GPU engine errors it must degrade to the CPU path, never fail scheduling" (the reference's pattern for
+    fault injection is a mock function, pkg/client/apifactory_mock.go:137-165). YKPRED_TUNE fail_after=n makes the n-th checked
+    device call of a LIVE engine fail (allocation, copy, launch check — wherever n lands: uploads, class build, any stage of the
+    evaluation, the incremental patch). The failing entry point reports it, the host marks every device table stale, a callback
+    in that state errors (the Go manager counts it RoutedOnError and asks the CPU manager), and the next evaluation re-uploads
+    and is bit-exact again."""
+    monkeypatch.setenv("YKPRED_TUNE", f"fail_after={fail_after}")
+    snap = _gen.random_snapshot(7700 + fail_after, n_nodes=150, n_pods=60, scalars=True, spread=bool(fail_after % 2), interpod=bool(fail_after % 3 == 0))
+    m = pkg.GpuPredicateManager()
+    try:
+        failed = 0
+        steps = [lambda: m.load_snapshot(snap), lambda: m.evaluate(),
+                 lambda: (m.assume_pod(snap["pods"][0]["metadata"]["uid"], snap["nodes"][1]["metadata"]["name"]), m.evaluate_dirty(decisions=True)),
+                 lambda: m.evaluate()]
+        for step in steps:
+            try:
+                step()
+            except RuntimeError as e:
+                failed += 1
+                assert "hip" in str(e).lower() or "ykpred" in str(e).lower(), e
+        assert m.device_errors() == failed <= 1
+        # whatever failed: the mirror is intact, the next evaluation re-uploads what is stale and agrees with the oracle
+        m.evaluate()
+        lay = m.layout()
+        o = orc.Oracle(m.dump_snapshot())
+        want = o.eval_grid(threads=8)
+        idx = np.array([m.pod_index(p["metadata"]["uid"]) for p in json.loads(m.dump_snapshot())["pods"]])
+        assert np.array_equal(unpack(m.read_bitmap(), lay.num_nodes)[idx], want)
+    finally:
+        m.close()

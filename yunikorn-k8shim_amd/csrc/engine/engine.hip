@@ -288,6 +288,7 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
+  int fail_after = 0;               // fail_after: failure injection — the n-th checked device call fails (0 = off)
   // Test knobs (YKPRED_TUNE, see ykpred_create): they force paths the populations of the test suite would not choose themselves.
   int sig_wpl = 0;                  // sig_wpl: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // combine_slices: 0 = index-row populations take the wave-per-chunk writer instead of k_walk_rows
@@ -387,11 +388,24 @@ namespace {
 
 int fail(ykpred_engine* e, int code, const std::string& msg) {
   if (e) e->err = msg;
+  if (e && (code == YKPRED_E_DEVICE || code == YKPRED_E_NOMEM)) {
+    // a device call failed somewhere inside an entry point: whatever that call was building is unfinished. Nothing derived from
+    // it may be served — the caller re-uploads its tables (the host library does: host.cpp fail()) and evaluates again.
+    e->last_eval_valid = false;
+    e->rank_valid = false;
+    e->classes_dirty = true;
+    e->spread_dirty = true;
+    e->hist_epoch = 0;
+    e->ranked_nodes_epoch = 0;
+    e->tables_version++;
+  }
   return code;
 }
+// Failure injection (tests only, YKPRED_TUNE fail_after=n): the n-th checked device call of the engine fails WITHOUT being made.
+inline bool inject_failure(ykpred_engine* e) { return e && e->fail_after > 0 && --e->fail_after == 0; }
 #define HIPCHK(call)                                                                                        \
   do {                                                                                                      \
-    hipError_t _s = (call);                                                                                 \
+    hipError_t _s = inject_failure(e) ? hipErrorUnknown : (call);                                          \
     if (_s != hipSuccess)                                                                                   \
       return fail(e, _s == hipErrorOutOfMemory ? YKPRED_E_NOMEM : YKPRED_E_DEVICE,                          \
                   std::string(#call) + ": " + hipGetErrorString(_s));                                       \
@@ -970,13 +984,24 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string error;
 };
+std::string& rccl_library_override() {
+  static std::string path;  // ykpred_comm_use_library
+  return path;
+}
 Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    if (!rccl_library_override().empty()) {
+      r.lib = dlopen(rccl_library_override().c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (!r.lib) {
+        r.error = std::string("cannot load ") + rccl_library_override() + ": " + dlerror();
+        return;
+      }
+    }
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
       if (r.lib) break;
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     }
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       if (r.lib) break;
@@ -1140,6 +1165,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
         e->band_steps = val > 0 ? std::min(256, std::max(4, (val + 3) / 4 * 4)) : 0;
       } else if (key == "chunk_members") e->chunk_members = std::min(std::max(val, 1), (int)ykk::kChunkMembers);
       else if (key == "wave_combine_below") e->wave_combine_below = std::max(val, 0);
+      else if (key == "fail_after") e->fail_after = std::max(val, 0);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
         delete e;
@@ -2997,6 +3023,12 @@ int32_t ykpred_preemption(ykpred_engine_t* e, int32_t pod, int32_t node, int32_t
 // ---------------------------------------------------------------------------------------------------
 // multi-GPU exchanges over RCCL (see ykpred.h)
 // ---------------------------------------------------------------------------------------------------
+int32_t ykpred_comm_use_library(const char* path) {
+  if (!path) return YKPRED_E_INVALID;
+  rccl_library_override() = path;
+  return YKPRED_OK;
+}
+
 int32_t ykpred_comm_unique_id(uint8_t* id) {
   if (!id) return YKPRED_E_INVALID;
   Rccl* r = rccl();

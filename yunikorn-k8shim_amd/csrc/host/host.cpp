@@ -138,6 +138,7 @@ struct ykhost {
   int64_t last_encode_us = 0;
   int64_t unsupported_asks = 0;    // asks whose template the encoder marked unsupported at the last full encode
   int64_t routed_to_cpu = 0;
+  int64_t device_errors = 0;       // engine calls that came back YKPRED_E_DEVICE / YKPRED_E_NOMEM (each forces a full re-upload)
   int64_t rounds_on_device = 0, round_asks_on_device = 0, round_asks_one_by_one = 0, round_asks_routed = 0;
   int64_t dictionary_growths = 0;  // new asks whose selector requirements were added to the dictionaries in place
   // label key → value → nodes carrying it (built on the first dictionary growth, dropped whenever a node object changes): a
@@ -174,6 +175,18 @@ namespace {
 
 int fail(ykhost* h, const std::string& m, int code = -1) {
   h->err = m;
+  if (code == YKPRED_E_DEVICE || code == YKPRED_E_NOMEM) {
+    // The engine lost a device call (failed allocation, lost device): nothing on the device can be trusted to describe the
+    // mirror any more. The mirror itself is intact — it is the source of truth — so the next sync re-encodes and re-uploads
+    // everything and the next evaluation is a full pass; until then callbacks fail and the Go manager routes them to the CPU
+    // predicate manager (the engine must degrade, never fail scheduling).
+    h->dirty_all = true;
+    h->resident.valid = false;
+    h->answers.pod = -1;
+    h->last_eval_phase = -1;
+    h->decisions_stale = true;
+    h->device_errors++;
+  }
   return code;
 }
 void copy_out(const std::string& s, char* out, int64_t len) {
@@ -2162,6 +2175,11 @@ int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32
     assume(h->pending[(size_t)list[k]], dec);
   }
   return placed;
+}
+
+int64_t ykhost_device_errors(ykhost_t* h) {
+  YKHOST_LOCKED(h);
+  return h->device_errors;
 }
 
 int32_t ykhost_round_stats(ykhost_t* h, int64_t* out4) {

@@ -334,6 +334,10 @@ class GpuPredicateManager:
         self._check(self._L.ykhost_allocate_round(self._h, count, ptr, 1 if apply else 0, out.ctypes.data))
         return out[:count].copy()
 
+    def device_errors(self):
+        """Engine calls that failed on the device so far (each forces a full re-upload + full pass; see ykhost_device_errors)."""
+        return int(self._L.ykhost_device_errors(self._h))
+
     def round_stats(self):
         out = np.zeros(4, dtype=np.int64)
         self._L.ykhost_round_stats(self._h, out.ctypes.data)
