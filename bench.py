@@ -69,6 +69,7 @@ def parse_args():
     ap.add_argument("--variant-steps", type=int, default=5)
     ap.add_argument("--no-ingest", action="store_true", help="N=1: leave the JSON ingest leg out of `end_to_end`")
     ap.add_argument("--no-configs4", action="store_true", help="N=1: leave the configs[4] (100k x 5M, one GPU) leg out of `variants`")
+    ap.add_argument("--seed-offset", type=int, default=0, help="added to the workload seed (the configs[4] leg of the default run uses +2)")
     ap.add_argument("--no-verify", action="store_true", help="skip the checks that make every published number self-verifying (verify_leg)")
     return ap.parse_args()
 
@@ -210,16 +211,18 @@ BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_walk_rows"
 
 
 def measured_traffic(workload, pods, nodes):
-    """profiles/traffic_r03.json (scripts/pmc_passes.sh + summarize_pmc.py: separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes,
+    """profiles/traffic_r04.json (scripts/pmc_passes.sh + summarize_pmc.py: separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes,
     calibrated and corrected as MI355X_MICROARCH.md prescribes): HBM bytes per launch of every engine kernel for this population."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r03.json")) as f:
-            tj = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if tj.get("pods") != pods or tj.get("nodes") != nodes:
-        return None
-    return tj.get("workloads", {}).get(workload)
+    for name in ("traffic_r04.json", "traffic_r03.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tj = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = tj.get("workloads", {}).get(workload)
+        if w and (w.get("pods", tj.get("pods")), w.get("nodes", tj.get("nodes"))) == (pods, nodes):
+            return dict(w, source="profiles/" + name)
+    return None
 
 
 def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0):
@@ -490,7 +493,7 @@ def main():
     first, count = ranges[rank]
     pm = pkg.GpuPredicateManager(device=local_rank)
     t_gen = time.perf_counter()
-    kwok = dict(seed=SEED + 2, num_pods=a.pods, num_templates=a.templates, node_affinity=0 if a.no_affinity else 1,
+    kwok = dict(seed=SEED + 2 + a.seed_offset, num_pods=a.pods, num_templates=a.templates, node_affinity=0 if a.no_affinity else 1,
                 unique_requests=1 if a.unique_requests else 0, spread=1 if a.spread else 0, gang_size=gang)
     pm.generate_kwok(num_nodes=count, node_index_offset=first, total_nodes=total_nodes, **kwok)
     if world > 1:
@@ -703,7 +706,7 @@ def main():
             try:
                 variants["configs4_one_gpu"] = dict(
                     timed_leg(pkg, dev, stream, a, a.variant_steps, 1, 2, seed=SEED + 4, num_nodes=100_000, num_pods=5_000_000,
-                              num_templates=a.templates, node_affinity=1, spread=1),
+                              num_templates=a.templates, node_affinity=1, spread=1, _workload="configs4_one_gpu"),
                     workload="configs[4]: 100k nodes x 5M pods, full Filter set (NodeResourcesFit, TaintToleration, NodeAffinity, "
                              "PodTopologySpread DoNotSchedule on 10 % of the templates, ...) + bin-pack decisions, one GPU")
             except Exception as exc:  # noqa: BLE001

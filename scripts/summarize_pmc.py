@@ -16,7 +16,8 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_r03"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORKLOADS = ("default", "own_template_per_ask", "unique_request_vectors")
+WORKLOADS = ("default", "own_template_per_ask", "unique_request_vectors", "configs4_one_gpu")
+SIZES = {"configs4_one_gpu": (5_000_000, 100_000)}  # (pods, nodes); the others: 1 000 000 x 50 000
 TIMER_LABEL = {"k_combine_wave": "k_combine", "k_fix_rows": "k_expand_bands",
                "k_dim_sort": "k_dim_walk", "k_dim_prefix_max": "k_dim_walk", "k_rank_hist": "k_rank", "k_rank_scan": "k_rank",
                "k_rank_fill": "k_rank", "k_rank_final": "k_rank", "k_decide_groups": "k_decide"}
@@ -69,7 +70,8 @@ for wl in WORKLOADS:
         e["hbm_bytes"] = int(e["write_bytes"] + 2 * e["fetch_bytes_raw"])
         e["write_bytes"], e["fetch_bytes_raw"] = int(e["write_bytes"]), int(e["fetch_bytes_raw"])
         e.pop("_top", None)
-    traffic["workloads"][wl] = {"kernels_per_step": kernels, "step_hbm_bytes": int(sum(e["hbm_bytes"] for e in kernels.values()))}
+    pods, nodes = SIZES.get(wl, (1_000_000, 50_000))
+    traffic["workloads"][wl] = {"pods": pods, "nodes": nodes, "kernels_per_step": kernels, "step_hbm_bytes": int(sum(e["hbm_bytes"] for e in kernels.values()))}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", f"traffic_{rnd}.json"), "w"), indent=1)
 print(json.dumps({wl: {"step_hbm_bytes": t["step_hbm_bytes"], "top": sorted(((k, v["hbm_bytes"]) for k, v in t["kernels_per_step"].items()), key=lambda x: -x[1])[:4]}

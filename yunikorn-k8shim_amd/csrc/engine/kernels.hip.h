@@ -2340,6 +2340,7 @@ __global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable
   const bool name_on = a.filt & kPlugNodeName;
   const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
   int p_l = 0, spec_l = 0, pin_l = -1, cls_l = 0;
+  int last_spec = -1, last_win = -1;  // (per launch: the first ask of a launch takes the scans)
   for (int i = 0; i < a.n_asks; ++i) {
     if ((i & (kWave - 1)) == 0) {  // the headers of the next 64 asks, one load round
       const int j = i + lane;
@@ -2353,7 +2354,21 @@ __global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable
     const int spec = __builtin_amdgcn_readlane(spec_l, i & (kWave - 1)), cls = __builtin_amdgcn_readlane(cls_l, i & (kWave - 1));
     const int pin = name_on ? __builtin_amdgcn_readlane(pin_l, i & (kWave - 1)) : -1;
     int win = -1;
-    if (a.all_fail || pin == -2) {
+    bool again = false;
+    if (!a.all_fail && pin == -1 && spec == last_spec && last_win >= 0) {
+      // The same spec as the ask before, which went to node last_win: that node is AT LEAST as early in the bin-pack order now
+      // (an allocation only raises a node's utilisation, i.e. lowers its score; every other node stands where it stood), so it
+      // is this ask's node too as long as it still fits — one pair instead of the two scans. Bin-packing sends long runs of a
+      // Deployment's or task group's asks to one node: this is the common case.
+      NodeRegs nr;
+      load_node_live(t, last_win, &nr);
+      int code;
+      unsigned reason;
+      again = eval_pair(s, spec, -1, last_win, nr, a.pre, a.filt, &code, &reason);
+    }
+    if (again) {
+      win = last_win;
+    } else if (a.all_fail || pin == -2) {
       // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
     } else if (pin >= 0) {
       NodeRegs nr;
@@ -2428,6 +2443,8 @@ __global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable
       win = (an >= 0 && (bn < 0 || ak < bk || (ak == bk && at < bt))) ? an : bn;
     }
     if (lane == 0) a.out[a.first + i] = win;
+    last_spec = pin == -1 ? spec : -1;
+    last_win = win;
     if (win < 0) continue;  // (wave-uniform)
     // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod)
     i64 used[2] = {0, 0};
