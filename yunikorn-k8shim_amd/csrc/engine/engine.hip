@@ -248,7 +248,7 @@ struct ykpred_engine {
   int res_vectors = 0;                                    // distinct request vectors (class key component)
   std::vector<i64> h_dim_val;                             // [rows]
   std::vector<int32_t> h_dim_of;                          // [rows] dimension, -1 for row 0
-  std::vector<int32_t> h_stage_rows;                      // ballot rows (not index rows) of the family, at most ykk::kWalkMaxStage
+  std::vector<int32_t> h_stage_rows;                      // ballot rows (not index rows) of the family, at most ykk::kWalkMaxStage: k_walk_rows keeps them in LDS
   DevBuf d_dim_val, d_dim_order, d_dim_chunk_dim, d_dim_chunk_begin, d_dim_chunk_len, d_res_rows;
   int dim_chunks = 0;
   // dimensions with >= walk_rows distinct values are evaluated by the sorted walk (k_dim_sort / k_dim_walk)
@@ -256,7 +256,7 @@ struct ykpred_engine {
   int wave_combine_below = 16;  // tunable: cfg.reserved[5] — average members per chunk below which k_combine_wave is used
   int n_big = 0, walk_chunks = 0, index_rows = 0;
   int NCB = 0;                      // zone-B chunks (d_chunk_list_b)
-  DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r;
+  DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r, d_rbits_c;
   DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
   static constexpr bool decide_skip = true;  // k_decide starts a class's scan where its rows can first have a bit
   DevBuf d_chunk_list_b;    // [NCB] numbers of the zone-B chunks (ascending)
@@ -797,7 +797,8 @@ int ensure_planes(ykpred_engine* e, hipStream_t st) {
     f->base = rows;
     rows += std::max(f->D, 1);
   }
-  size_t need = (size_t)rows * (size_t)e->row_stride * sizeof(u64);
+  // (+ 64 words: k_walk_rows reads whole 64-word groups, the lanes past the end of the LAST row stay inside the buffer)
+  size_t need = ((size_t)rows * (size_t)e->row_stride + 64) * sizeof(u64);
   for (DevBuf* b : {&e->planes_canon, &e->planes_ranked}) {
     if (b->cap < need || e->plane_rows_alloc != rows) {
       e->tables_version++;
@@ -1062,7 +1063,7 @@ ykk::Planes ranked_planes_of(const ykpred_engine* e, unsigned pre, unsigned filt
   ykk::Planes pr{res_on ? ranked_of(e->fam_res) : nullptr, ranked_of(e->fam_tol), aff_on ? ranked_of(e->fam_aff) : nullptr,
                  spread_on ? ranked_of(e->fam_spread) : nullptr, e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(),
                  e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words, first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base,
-                 e->fam_spread.base, 0, nullptr, nullptr};
+                 e->fam_spread.base, 0, nullptr, nullptr, nullptr};
   pr.n_big = res_on ? e->n_big : 0;
   if (first_r && res_on && e->n_big > 0 && !fit_error) {
     pr.res_val = e->d_dim_val.as<i64>();
@@ -1213,7 +1214,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1567,7 +1568,6 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     }
     e->index_rows = 0;
     for (int32_t len : wlen) e->index_rows += len;
-    // the first ballot rows of the family (request values of the few-valued dimensions): k_walk_rows stages their slices in LDS
     e->h_stage_rows.clear();
     {
       std::vector<uint8_t> walked((size_t)R, 0);
@@ -1688,6 +1688,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     const size_t cells = (size_t)e->n_big * (size_t)std::max(e->row_words, 1);
     for (DevBuf* b : {&e->d_sfree_c, &e->d_sfree_r}) HIPCHK(b->ensure(cells * 64 * sizeof(i64)));
     for (DevBuf* b : {&e->d_pmask_c, &e->d_pmask_r}) HIPCHK(b->ensure(cells * 65 * sizeof(u64)));
+    HIPCHK(e->d_rbits_c.ensure(cells * ykk::kRankBits * sizeof(u64)));
     // (a forced row stride — unequal shards — may exceed the rounded row length: consumers address index bytes by row word)
     const int idx_stride_before = e->idx_stride;
     e->idx_stride = (std::max(e->row_words, e->row_stride) + 63) / 64 * 64;
@@ -1753,7 +1754,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
-                 nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
+                 nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
   // first non-zero word of every rank-ordered plane row (whole buffer: families at their base rows), reset per pass
   int* first_r = nullptr;
   if ((a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->decide_skip) {
@@ -1763,6 +1764,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (first_r && res_on && e->n_big > 0 && !fit_error) HIPCHK(e->d_pfx_r.ensure((size_t)e->n_big * (size_t)std::max(e->row_words, 1) * sizeof(i64)));
   ykk::Planes pr = ranked_planes_of(e, pre, filt, spread_on, first_r != nullptr);
   pc.n_big = pr.n_big;
+  pc.rbits = e->d_rbits_c.as<u64>();
   const int pin_on = ((filt & YKPRED_PLUGIN_NODE_NAME) ? 1 : 0) | (spread_err ? 2 : 0);
   hipStream_t sb = e->aux_stream;
 
@@ -1874,7 +1876,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       const bool ranked = perm != nullptr;
       ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
                       e->d_walk_len.as<int>(), (ranked ? e->d_sfree_r : e->d_sfree_c).as<i64>(), (ranked ? e->d_pmask_r : e->d_pmask_c).as<u64>(),
-                      e->n_big, e->walk_chunks, e->row_words};
+                      e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>()};
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
       hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords))), dim3(ykk::kBlock),
@@ -1887,6 +1889,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       // mask table is the empty mask (the tables are only written by k_dim_sort: clear them as well)
       (void)hipMemsetAsync((ranked_walk(perm) ? e->d_idx_r : e->d_idx_c).p, 64, (size_t)e->fam_res.D * (size_t)e->idx_stride, s);
       (void)hipMemsetAsync((ranked_walk(perm) ? e->d_pmask_r : e->d_pmask_c).p, 0, (size_t)e->n_big * (size_t)e->row_words * 65 * sizeof(u64), s);
+      if (!ranked_walk(perm)) (void)hipMemsetAsync(e->d_rbits_c.p, 0, (size_t)e->n_big * (size_t)e->row_words * ykk::kRankBits * sizeof(u64), s);
     }
   };
   if (res_on || spread_on) launch_ballot_planes(st, nullptr, "k_planes");
@@ -1968,42 +1971,65 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     }
     tm.begin(sz);
     const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
-    // Index rows to decode: k_walk_rows — a workgroup per slice (<= 128 words) of the row with the slice's mask tables, staged
-    // plane rows, index bytes and base words in LDS (loader / store waves). Only where the device grants that much LDS.
-    ykk::WalkGeom wg{};
-    bool slices = small_chunks && e->combine_slices != 0 && pc.n_big > 0;
+    // Index rows to decode: k_walk_rows — a wave writes whole rows, the rank planes of the walked dimensions (56 bytes per word) staged
+    // in LDS per workgroup; rows wider than kWalkMaxIt x 64 words go segment by segment (grid.y). Only where the device grants the LDS.
+    // Segments of whole 64-word groups: as few as possible with at most kWalkMaxIt groups (register budget: 4 waves per SIMD) and an
+    // LDS footprint that lets two workgroups share a CU; sizes differ by at most one — `walk_long` segments of walk_nit groups, then
+    // the rest with walk_nit - 1; the last one holds the tail.
+    int walk_nit = 0, walk_segs = 0, walk_long = 0;
+    ykk::WalkStage wstage{};
+    wstage.n = (int)e->h_stage_rows.size();
+    for (int k = 0; k < wstage.n; ++k) wstage.row[k] = e->h_stage_rows[(size_t)k];
+    bool slices = small_chunks && e->combine_slices != 0 && pc.n_big > 0 && pc.res != nullptr;
     if (slices) {
-      wg.n_slices = (e->row_stride + ykk::kSliceMaxWords - 1) / ykk::kSliceMaxWords;
-      wg.slice_words = ((e->row_stride + wg.n_slices - 1) / wg.n_slices + 15) / 16 * 16;  // (row_stride is a multiple of 16)
-      wg.n_stage = (int)e->h_stage_rows.size();
-      for (int k = 0; k < wg.n_stage; ++k) wg.stage_row[k] = e->h_stage_rows[(size_t)k];
-      wg.run_slots = 10;
-      wg.n_buffers = 8;
-      // shed what is optional until the workgroup's LDS fits the device: plane rows staged beyond 8, block buffers, base slots, staged rows
-      auto fits = [&]() { return ykk::walk_lds_bytes(pc.n_big, wg) <= (size_t)e->max_lds_bytes; };
-      while (!fits() && wg.n_stage > 8) wg.n_stage--;
-      while (!fits() && wg.n_buffers > 8) wg.n_buffers--;
-      while (!fits() && wg.run_slots > 4) wg.run_slots--;
-      while (!fits() && wg.n_buffers > 2) wg.n_buffers--;
-      while (!fits() && wg.n_stage > 0) wg.n_stage--;
-      while (!fits() && wg.run_slots > 2) wg.run_slots--;
-      slices = fits();
+      const int its = (e->row_stride + ykk::kWave - 1) / ykk::kWave;
+      const size_t lds_cap = std::min((size_t)e->max_lds_bytes, (size_t)80 * 1024);
+      walk_segs = (its + ykk::kWalkMaxIt - 1) / ykk::kWalkMaxIt;
+      walk_nit = (its + walk_segs - 1) / walk_segs;
+      while (walk_nit > 1 && ykk::walk_lds_bytes(pc.n_big, wstage.n, walk_nit) > lds_cap) {
+        ++walk_segs;
+        walk_nit = (its + walk_segs - 1) / walk_segs;
+      }
+      walk_long = walk_segs - (walk_nit * walk_segs - its);
+      slices = ykk::walk_lds_bytes(pc.n_big, wstage.n, walk_nit) <= (size_t)e->max_lds_bytes && its * ykk::kWave <= e->idx_stride;
     }
     if (slices) {
       // chunk descriptors first, one thread per chunk (what a wave needs to know about a chunk, resolved once per pass)
-      const size_t lds = ykk::walk_lds_bytes(pc.n_big, wg);
-      wg.chunks_per_group = 2048;
       HIPCHK(e->d_slice_desc.ensure((size_t)std::max(e->NC, 1) * sizeof(ykk::SliceDesc)));
       HIPCHK(e->d_slice_general.ensure(sizeof(int)));
       HIPCHK(hipMemsetAsync(e->d_slice_general.p, 0, sizeof(int), sz));
       hipLaunchKernelGGL(ykk::k_slice_desc, dim3((unsigned)((e->NC + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, sz, ct, pc, e->NC, class_dirty,
-                         pin_on, e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>());
+                         pin_on, e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>(), wstage);
       tm.end(sz, "k_slice_desc");
       tm.begin(sz);
-      const dim3 sgrid((unsigned)(((e->NC + wg.chunks_per_group - 1) / wg.chunks_per_group) * wg.n_slices));
-      if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)ykk::k_walk_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(ykk::k_walk_rows, sgrid, dim3(ykk::kWalkThreads), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap, e->row_words,
-                         e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, wg);
+      const int per_group = ykk::kRowsWaves * ykk::kWalkChunksPerWave;
+      const unsigned gx = (unsigned)((e->NC + per_group - 1) / per_group);
+      auto launch_walk = [&](auto kernel, int nit, int segs, int w_base) -> int {
+        const size_t lds = ykk::walk_lds_bytes(pc.n_big, wstage.n, nit);
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3(gx, (unsigned)segs), dim3(ykk::kRowsThreads), lds, sz, pc, e->d_slice_desc.as<ykk::SliceDesc>(), bitmap,
+                           e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, w_base, wstage);
+        return YKPRED_OK;
+      };
+      // (segs segments of nit groups from word w_base; the row's last segment is launched on its own with the tail predicate)
+      auto launch_segments = [&](int nit, int segs, int w_base, bool tail) -> int {
+        if (segs <= 0) return YKPRED_OK;
+        switch (nit * 2 + (tail ? 1 : 0)) {
+#define YK_WALK_CASE(N)                                                         \
+  case (N) * 2: return launch_walk(ykk::k_walk_rows<(N), false>, nit, segs, w_base); \
+  case (N) * 2 + 1: return launch_walk(ykk::k_walk_rows<(N), true>, nit, segs, w_base);
+          YK_WALK_CASE(1) YK_WALK_CASE(2) YK_WALK_CASE(3) YK_WALK_CASE(4) YK_WALK_CASE(5) YK_WALK_CASE(6) YK_WALK_CASE(7)
+#undef YK_WALK_CASE
+        }
+        return fail(e, YKPRED_E_INVALID, "k_walk_rows: no kernel for " + std::to_string(nit) + " word groups per lane");
+      };
+      {
+        const int n_short = walk_segs - walk_long, nit_last = n_short > 0 ? walk_nit - 1 : walk_nit;
+        const int long_plain = n_short > 0 ? walk_long : walk_long - 1, short_plain = n_short > 0 ? n_short - 1 : 0;
+        TRY(launch_segments(walk_nit, long_plain, 0, false));
+        TRY(launch_segments(walk_nit - 1, short_plain, walk_long * walk_nit * ykk::kWave, false));
+        TRY(launch_segments(nit_last, 1, (long_plain * walk_nit + short_plain * (walk_nit - 1)) * ykk::kWave, true));
+      }
       tm.end(sz, "k_walk_rows");
       tm.begin(sz);
       // chunks the fast path does not cover (several member rows, pins to unknown nodes, other row shapes): wave per chunk
@@ -3153,7 +3179,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
-  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
     hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),

@@ -294,6 +294,7 @@ __device__ __forceinline__ void plane_dim(const NodeTable& t, const int* __restr
 // — lanes are consecutive words, so a wave writes 512 contiguous bytes of a row. Cost: the plane bytes written once
 // (HBM-write bound) instead of rows × N compares (ALU bound).
 constexpr int kWalkRows = 512;  // rows per walk chunk (one binary search per thread and chunk)
+constexpr int kRankBits = 7;    // rank planes of a word: bit k of r' = valid ? position in the word's ascending free list + 1 : 0 (0..64)
 struct DimWalk {
   const i64* val;          // [rows]
   const int* order;        // [rows] row ids grouped by dimension; inside a walked dimension ascending by value
@@ -304,6 +305,7 @@ struct DimWalk {
   i64* sfree;              // [n_big][n_words][64]
   u64* pmask;              // [n_big][n_words][65]
   int n_big, n_chunks, n_words;
+  u64* rbits;              // [n_big][kRankBits][n_words] the same sets bit-sliced (k_walk_rows): pmask[j] = { node : r' > j }; null = not kept
 };
 // blockIdx.x: walked dimension, blockIdx.y: group of 4 words; wave = word, lane = node position
 __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __restrict__ perm, DimWalk a) {
@@ -328,6 +330,16 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
   }
   a.pmask[cell * 65 + lane] = keep;
   if (lane == 0) a.pmask[cell * 65 + 64] = 0;
+  if (a.rbits) {
+    const int r1 = valid ? rank + 1 : 0;
+    u64 plane = 0;
+#pragma unroll
+    for (int k = 0; k < kRankBits; ++k) {
+      const u64 b = __ballot((r1 >> k) & 1);
+      if (k == lane) plane = b;
+    }
+    if (lane < kRankBits) a.rbits[((size_t)blockIdx.x * kRankBits + lane) * a.n_words + word] = plane;
+  }
 }
 // blockIdx.x: walk chunk, blockIdx.y: block of 256 * kWalkWords words; thread = kWalkWords ADJACENT words.
 // The rows it produces are INDEX rows: one BYTE per 64-node word — the position `ptr` in the word's sorted free list — instead of
@@ -956,6 +968,7 @@ struct Planes {
   const i64* res_val;     // [rows] request value of a plane / index row of `res` (rank-ordered planes: with `pfx`, else null)
   const i64* pfx;         // [walked dimensions][n_words] rank order only: largest free value among the nodes of words 0..w
                           // (k_dim_prefix_max) — a row of value v has no bit before the first word with pfx >= v
+  const u64* rbits;       // [walked dimensions][kRankBits][n_words] the same tables bit-sliced (k_walk_rows); null: not kept (rank order)
 };
 constexpr int kMaxClassRows = 3 + 1 + kMaxR;
 constexpr int kMaxIdxRows = 2;     // sorted-walk dimensions (further many-valued dimensions stay on ballot planes)
@@ -1230,7 +1243,13 @@ typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
 struct SliceDesc {   // 48 bytes = three 16-byte loads
   int cls, meta, pin, mem0;   // meta: len | first << 8 | general path << 9 | per-chunk plane row << 10 | live << 15
   int st, sa, ss, p0;         // signature rows + the cached plane row (-1: none)
-  int prow, irow, begin, pad; // per-chunk plane row, index row (walked dimension << kRowBigShift | row), first member slot
+  int prow, irow, begin, slot; // per-chunk plane row, index row (walked dimension << kRowBigShift | row), first member slot, the plane
+                               // row's slot among the rows k_walk_rows stages in LDS (WalkStage::n: none — the all-ones row)
+};
+constexpr int kWalkMaxStage = 16;    // ballot rows of the request family k_walk_rows keeps in LDS
+struct WalkStage {
+  int n;
+  int row[kWalkMaxStage];  // their row ids in the request family
 };
 constexpr int kSliceFirst = 1 << 8, kSliceGeneral = 1 << 9, kSlicePlane = 1 << 10, kSliceLive = 1 << 15;
 __device__ __forceinline__ bool slice_desc_general(const SliceDesc* desc, int chunk) {
@@ -1238,7 +1257,7 @@ __device__ __forceinline__ bool slice_desc_general(const SliceDesc* desc, int ch
 }
 // n_general (zeroed by the caller): the number of live chunks left to k_combine_wave
 __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl, int n_chunks, const int* __restrict__ class_dirty, int pin_enabled,
-                                                       SliceDesc* __restrict__ out, int* __restrict__ n_general) {
+                                                       SliceDesc* __restrict__ out, int* __restrict__ n_general, WalkStage stage) {
   const int chunk = blockIdx.x * kBlock + threadIdx.x;
   if (chunk >= n_chunks) return;
   SliceDesc d{};
@@ -1268,311 +1287,205 @@ __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl,
           ++np;
         }
       }
-    // the general path: several member rows, the tail chunk of a longer class (it adds no count), a freed member slot, an
-    // unknown pinned node, or a shape the fast path has no code for — so the fast path needs no test for any of them
-    if (len != 1 || !(d.meta & kSliceFirst) || d.mem0 < 0 || d.pin == -2 || np > 2 || ni != 1) d.meta |= kSliceGeneral;
-    if (np >= 2) d.meta |= kSlicePlane;
+    // the general path: several member rows, the tail chunk of a longer class (it adds no count), a freed member slot, a
+    // pinned node (NodeName), a plane row that is not staged, or a shape the fast path has no code for — so the fast path needs no test for any of them
+    d.slot = stage.n;
+    if (np >= 2) {
+      d.meta |= kSlicePlane;
+      d.slot = -1;
+      for (int k = 0; k < stage.n; ++k)
+        if (stage.row[k] == d.prow) d.slot = k;
+    }
+    if (len != 1 || !(d.meta & kSliceFirst) || d.mem0 < 0 || d.pin != -1 || np > 2 || ni != 1 || d.slot < 0) d.meta |= kSliceGeneral;
     if (d.meta & kSliceGeneral) atomicAdd(n_general, 1);
   }
   out[chunk] = d;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_walk_rows: the zone-B writer of populations with INDEX rows (10^6 single-member classes), loader / store waves.
+// k_walk_rows: the zone-B writer of populations with INDEX rows (10^6 single-member classes). A wave writes whole row segments.
 //
-// Round 3's k_combine_slices had the right data flow — a workgroup owns ONE slice (<= 128 words) of the row for a long run of
-// chunks, the 65-entry mask tables of the slice sit in LDS, index bytes and plane words arrive as coalesced streams — and the
-// wrong execution shape: every wave loaded the index bytes of a batch of 6 rows, waited a full memory round trip, decoded,
-// stored; 76 % of its wave cycles were s_waitcnt at 4 waves per SIMD (SQ counters, profiles/r03_sessions7_20_*): 2.0 ms of the
-// 3.15 ms were there with stores, atomics and decode switched OFF. Instruction count was never the limit (27 k (row, slice)
-// pairs per CU x ~140 instructions = 0.4 ms of issue). So the structure of the band writer (k_expand_bands) is applied:
-//   * ONE LOADER wave per workgroup does every global load: per block of <= 64 consecutive chunks it fetches the descriptors
-//     (coalesced), the slice's index bytes of every row (lane = row: <= 8 x 16 bytes, written to LDS as the row's byte string),
-//     and — per RUN of rows with the same cached rows (toleration / affinity / spread signature, pod-independent request row) —
-//     the AND of those rows' slice words ("base", lane = word pair), all into the LDS buffer of the NEXT block;
-//   * the STORE waves never load from global memory: per row one LDS read of its two index bytes, two LDS reads of the mask
-//     tables, one of the run's base words, one of the row's staged request-value plane (the ballot rows of the request family
-//     are staged once per workgroup), AND, popcount, one 16-byte store. Their vmcnt only ever counts stores;
-//   * one s_barrier per block joins them.
-// Chunks without this fast path (several member rows, a pinned unknown node, two index rows, more than two plane rows) are
-// left to k_combine_wave through the descriptor filter, as before.
-constexpr int kWalkStoreWaves = 8;     // x kWalkRowsPerWave rows of a block each, all their LDS reads in flight together
-constexpr int kWalkLoaders = 6;      // loader waves: each fills whole blocks (block k belongs to loader k % kWalkLoaders)
-constexpr int kWalkThreads = (kWalkStoreWaves + kWalkLoaders) * kWave;
-constexpr int kWalkBlockRows = 32;   // rows (chunks) per block: lanes j and j + 32 of a loader = row j (each takes half of its index bytes)
-constexpr int kWalkRowsPerWave = kWalkBlockRows / kWalkStoreWaves;
-constexpr int kWalkMaxStage = 16;    // ballot rows of the request family staged in LDS
-constexpr int kWalkRunGroup = 8;     // runs whose base loads a loader keeps in flight together (3 planes x 16 bytes x 8 = 96 VGPRs)
-struct WalkGeom {
-  int n_slices, slice_words;   // slice_words: multiple of 16 (index bytes travel in 16-byte pieces), <= kSliceMaxWords
-  int run_slots;               // base slots per block: rows of further runs fetch their cached rows themselves
-  int n_buffers;               // LDS block buffers: how far the loaders run ahead of the store waves (>= 2 x loaders wanted)
-  int chunks_per_group;        // chunks one workgroup walks
-  int n_stage;                 // staged plane rows ...
-  int stage_row[kWalkMaxStage];  // ... their row ids in the request family
-};
-struct WalkRow {  // what a store wave needs to know about a row of the block (LDS, 32 bytes)
-  int dest, cls, slot, chunk;    // bitmap row; class; base slot of the row's run (-1: row not on the fast path, -2: run without a slot); chunk (slot == -2 re-reads its descriptor)
-  int prow, pin, pm_off, stage_off;  // per-row plane row when it is not staged (-1: none); pinned node (-1: none); u64 offsets of the walked
-                                     // dimension's mask table and of the staged plane row (the all-ones row when there is none) in LDS
-};
-// dynamic LDS: [pmask n_big x sw x 65 u64][stage (n_stage + 1) x sw u64, the last row all ones][base NB x run_slots x sw u64][idx NB x 32 x sw bytes][rows NB x 32 WalkRow][flags 2 x NB int]
-__host__ __device__ inline size_t walk_lds_bytes(int n_big, const WalkGeom& g) {
-  const size_t sw = (size_t)g.slice_words, nb = (size_t)g.n_buffers;
-  return (size_t)n_big * sw * 65 * 8 + (size_t)(g.n_stage + 1) * sw * 8 + nb * g.run_slots * sw * 8 + nb * kWalkBlockRows * sw +
-         nb * kWalkBlockRows * sizeof(WalkRow) + 2 * nb * sizeof(int) + 16;
+// History. Round 3's k_combine_slices and the first k_walk_rows of round 4 decoded an index byte with a lookup into the word's
+// 65-entry mask table (520 bytes per word): a row's tables (408 KB) do not fit the LDS, so a workgroup owned a SLICE of <= 128
+// words of the row — 7 (row, slice) pairs per row at 50 k nodes, ~134 instructions per pair, one workgroup per CU (157 KB of LDS),
+// 2.8–3.2 ms for 6.27 GB whatever was tuned (profiles/r03_sessions7_20_*, profiles/r04_walk_rows.txt: latency at 3.5 waves per SIMD).
+// The table is the wrong data structure for the LDS. mask(word, j) = { node : valid and rank(node) >= j } with rank = the node's
+// position in the word's ascending free list: a COMPARE of 64 small numbers with j. Bit-sliced — plane k of a word holds bit k of
+// r' = valid ? rank + 1 : 0 for its 64 nodes, mask = r' > j — the compare is a ripple of 7 majority steps on whole words
+// (gt = maj(gt, r_k, ~j_k): ONE v_bitop3_b32 per step and 32-bit half on gfx950), and the "table" is 56 bytes per word instead of
+// 520: a whole row of 50 k nodes is 44 KB. So:
+//   * a workgroup stages, for a segment of NIT x 64 words of the row, the rank planes of the walked dimensions ([dimension][7][words])
+//     and the ballot rows of the request family (the few-valued dimensions' planes, <= kWalkMaxStage rows + an all-ones row) —
+//     everything a row ANDs per word except its own index bytes; read with lane = word: conflict-free ds_read_b64;
+//   * a WAVE owns a run of consecutive chunks and writes each row's segment whole, lane = word, NIT words per lane in registers: the
+//     AND of the cached rows (toleration / affinity / spread / pod-independent request row) stays in registers while the signature
+//     does not change (zone-B chunks come in signature order); per row the only global loads are NIT index bytes per lane;
+//   * those are prefetched a group of 3–4 rows ahead (two register banks, the loop body unrolled twice): under the store stream
+//     of this kernel a load takes several microseconds, and with one row of look-ahead a wave did one row per round trip
+//     (second form: 2.99 ms). Loads are never predicated and never sit under a data-dependent branch: a conditional load into a
+//     register the compiler also writes costs an s_waitcnt vmcnt(0) in front of it (first form: 5.4 ms);
+//   * chunk descriptors (k_slice_desc) are wave-uniform scalar loads from the constant address space: they stay out of the
+//     in-order vmcnt.
+// Lanes past the row read inside the buffers (index rows are padded to 64 words with the empty position, the plane buffers carry
+// 64 words of slack) and their words are masked by `base`; an absent cached row (no toleration / affinity / spread signature) is
+// read as row 0 of the request family, which is part of every class anyway. Chunks without this fast path (several member rows,
+// a pinned node, two index rows, more than two plane rows, a plane row that is not staged) are left to k_combine_wave through the
+// descriptor filter, as before.
+constexpr int kRowsWaves = 8;
+constexpr int kRowsThreads = kRowsWaves * kWave;
+constexpr int kWalkMaxIt = 7;         // words per lane and segment (register budget): wider rows are written segment by segment (grid.y)
+constexpr int kWalkChunksPerWave = 64;
+// gfx950's three-operand bit operation (truth table in the immediate: a = 0xF0, b = 0xCC, c = 0xAA)
+__device__ __forceinline__ unsigned maj32(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+__device__ __forceinline__ unsigned and3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80); }
+__host__ __device__ inline size_t walk_lds_bytes(int n_big, int n_stage, int nit) {
+  return (size_t)(n_big * kRankBits + n_stage + 1) * (size_t)nit * kWave * sizeof(u64);
 }
-__global__ __launch_bounds__(kWalkThreads) void k_walk_rows(Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words,
-                                                            int row_stride, int pin_enabled, int* __restrict__ class_count, int n_chunks,
-                                                            WalkGeom g) {
-  typedef u64x2_t u64x2;
-  extern __shared__ u64 walk_lds[];
-  const int sw = g.slice_words, NB = g.n_buffers;
-  u64* s_pm = walk_lds;                                                  // [n_big][sw][65]
-  u64* s_stage = s_pm + (size_t)pl.n_big * sw * 65;                      // [n_stage + 1][sw]: row n_stage = all ones ("no staged plane row")
-  u64* s_base = s_stage + (size_t)(g.n_stage + 1) * sw;                  // [NB][run_slots][sw]
-  unsigned char* s_idx = (unsigned char*)(s_base + (size_t)NB * g.run_slots * sw);  // [NB][32][sw]
-  WalkRow* s_rows = (WalkRow*)(s_idx + (size_t)NB * kWalkBlockRows * sw);  // [NB][32]
-  int* s_ready = (int*)(s_rows + NB * kWalkBlockRows);                   // [NB] block number + 1 that sits in the buffer
-  int* s_used = s_ready + NB;                                            // [NB] store waves that have finished with the buffer, ever
+// NIT: words per lane (the segment is NIT x 64 words, every one of them inside the row rounded up to 64 words); TAIL: the segment
+// holds the row's last word group, whose lanes past row_stride must not store.
+template <int NIT, bool TAIL>
+__global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_walk_rows(
+    Planes pl, const SliceDesc* __restrict__ desc, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled,
+    int* __restrict__ class_count, int n_chunks, int w_base, WalkStage stage) {
+  extern __shared__ u64 walk_lds[];  // [n_big][kRankBits][SW] rank planes, then [stage.n + 1][SW] ballot rows (the last one all ones)
+  constexpr int SW = NIT * kWave;
   const bool all_fail = pin_enabled & 2;
-  const bool pin_on = pin_enabled & 1;
-  const int slice = blockIdx.x % g.n_slices, group = blockIdx.x / g.n_slices;
-  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-  const int w_first = slice * sw;  // first row word of the slice
-  // this lane's word pair (store waves, and the loaders' base words); pairs past the slice or the row hold zeros and store nothing
-  const int w_true = w_first + 2 * lane;
-  const bool in_row = 2 * lane < sw && w_true < row_stride;
-  const unsigned voff = in_row ? (unsigned)w_true * 8u : 0u;  // byte offset of the pair in a plane / bitmap row
-  u64x2 keep = {in_row && w_true < row_words ? ~0ull : 0ull, in_row && w_true + 1 < row_words ? ~0ull : 0ull};
-  if (all_fail) keep = u64x2{0, 0};
-  // the pod-independent row of the request family (row 0) is the cached request row of EVERY class: folded into `keep` once
-  if (pl.res) keep &= *(const u64x2*)((const char*)pl.res + voff);
-  // ---- once per workgroup: the mask tables and the staged plane rows of the slice, the buffer flags
-  {
-    const int cnt = max(min(sw, pl.n_words - w_first), 0) * 65;
-    for (int b = 0; b < pl.n_big; ++b) {
-      const u64* src = pl.pmask + ((size_t)b * pl.n_words + (size_t)w_first) * 65;
-      for (int i = (int)threadIdx.x; i < sw * 65; i += kWalkThreads) s_pm[(size_t)b * sw * 65 + i] = i < cnt ? src[i] : 0ull;
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+  const int w_first = w_base + blockIdx.y * SW;
+  u64* s_stage = walk_lds + (size_t)pl.n_big * kRankBits * SW;
+  for (int i = (int)threadIdx.x; i < pl.n_big * kRankBits * SW; i += kRowsThreads) {
+    const int plane = i / SW, w = w_first + i % SW;
+    walk_lds[i] = w < pl.n_words ? pl.rbits[(size_t)plane * pl.n_words + w] : 0ull;
+  }
+  for (int i = (int)threadIdx.x; i < (stage.n + 1) * SW; i += kRowsThreads) {
+    const int k = i / SW, w = w_first + i % SW;
+    u64 v = ~0ull;
+    if (k < stage.n) {
+      int row = stage.row[0];
+#pragma unroll
+      for (int q = 1; q < kWalkMaxStage; ++q) row = k == q ? stage.row[q] : row;
+      v = w < row_words ? pl.res[(size_t)row * pl.stride + w] : 0ull;
     }
-    for (int k = 0; k < g.n_stage; ++k) {
-      const u64* src = pl.res + (size_t)g.stage_row[k] * pl.stride + w_first;
-      for (int i = (int)threadIdx.x; i < sw; i += kWalkThreads) s_stage[(size_t)k * sw + i] = w_first + i < row_words ? src[i] : 0ull;
-    }
-    for (int i = (int)threadIdx.x; i < sw; i += kWalkThreads) s_stage[(size_t)g.n_stage * sw + i] = ~0ull;
-    if ((int)threadIdx.x < 2 * NB) s_ready[threadIdx.x] = 0;
+    s_stage[i] = v;
   }
   __syncthreads();
-  const int c_begin = group * g.chunks_per_group, c_end = min(c_begin + g.chunks_per_group, n_chunks);
-  const int n_blocks = (max(c_end - c_begin, 0) + kWalkBlockRows - 1) / kWalkBlockRows;
-  // the cached rows of a run, ANDed (lane = word pair); rows that are absent (family disabled, signature -1) count as all ones
-  auto run_base = [&](int rst, int rsa, int rss) {
-    u64x2 b = keep;
-    if (pl.tol && rst >= 0) b &= *(const u64x2*)((const char*)(pl.tol + (size_t)rst * pl.stride) + voff);
-    if (pl.aff && rsa >= 0) b &= *(const u64x2*)((const char*)(pl.aff + (size_t)rsa * pl.stride) + voff);
-    if (pl.spread && rss >= 0) b &= *(const u64x2*)((const char*)(pl.spread + (size_t)rss * pl.stride) + voff);
-    return b;
+  const bool tail_store = w_first + (NIT - 1) * kWave + lane < row_stride;  // (TAIL: this lane's last word lies inside the row)
+  const int c0 = ((int)blockIdx.x * kRowsWaves + wave) * kWalkChunksPerWave, c1 = min(c0 + kWalkChunksPerWave, n_chunks);
+  struct Row {
+    int cls, dest, st, sa, ss, slot, irow;
   };
-
-  if (wave >= kWalkStoreWaves) {
-    // =========================================================== LOADER: every global load of the workgroup's steady state
-    constexpr int kHalfPieces = kSliceMaxWords / 16 / 2;  // 16-byte index pieces one lane takes: lanes 0-31 the first half of the row's
-    const int row_l = lane & (kWalkBlockRows - 1), half = lane / kWalkBlockRows;  // bytes, lanes 32-63 the second
-    // The descriptors of a loader's NEXT block are requested before it works on the current one: a block then costs one memory
-    // round trip on the loader's critical path (index bytes + base words, issued together), not three in a row.
-    int4 nd0 = {0, 0, -1, -1}, nd1 = {-1, -1, -1, -1}, nd2 = {-1, 1 << kRowBigShift, 0, 0};
-    auto request_desc = [&](int blk) {
-      const int c0 = c_begin + blk * kWalkBlockRows;
-      if (blk < n_blocks && row_l < min(kWalkBlockRows, c_end - c0)) {
-        const int4* dp = (const int4*)(desc + c0 + row_l);
-        nd0 = dp[0], nd1 = dp[1], nd2 = dp[2];
+  // the next chunk of the wave's range that is on the fast path (wave-uniform: scalar loads); false: none left, r unchanged
+  int c = c0;
+  auto fetch = [&](Row& r) -> bool {
+    for (; c < c1; ++c) {
+      typedef const SliceDesc __attribute__((address_space(4))) ConstDesc;
+      const ConstDesc* d = (const ConstDesc*)(unsigned long long)(desc + c);
+      const int meta = d->meta;
+      if ((meta & (kSliceLive | kSliceGeneral)) != kSliceLive) continue;
+      r.cls = d->cls, r.dest = d->mem0;
+      r.st = d->st, r.sa = d->sa, r.ss = d->ss;
+      r.slot = d->slot;
+      r.irow = d->irow;
+      ++c;
+      return true;
+    }
+    return false;
+  };
+  auto issue = [&](const Row& r, unsigned (&idx)[NIT]) {
+    const unsigned char* isrc = pl.res_idx + (size_t)(r.irow & ((1 << kRowBigShift) - 1)) * pl.idx_stride + w_first + lane;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) idx[it] = isrc[it * kWave];
+  };
+  int cst = -2, csa = -2, css = -2;  // the signature rows folded into `base`
+  u64 base[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) base[it] = 0;
+  auto write_row = [&](const Row& r, const unsigned (&idx)[NIT]) {
+    if (r.st != cst || r.sa != csa || r.ss != css) {  // (wave-uniform; rare: chunks come in signature order)
+      cst = r.st, csa = r.sa, css = r.ss;
+      int rw = all_fail ? 0 : row_words;
+      asm volatile("" : "+s"(rw));  // (keeps the masks below out of the loop-invariant registers)
+      const u64* r0 = pl.res + w_first + lane;  // row 0 of the request family: the pod-independent part, in every class
+      const u64* rt = (pl.tol && cst >= 0) ? pl.tol + (size_t)cst * pl.stride + w_first + lane : r0;
+      const u64* ra_ = (pl.aff && csa >= 0) ? pl.aff + (size_t)csa * pl.stride + w_first + lane : r0;
+      const u64* rs = (pl.spread && css >= 0) ? pl.spread + (size_t)css * pl.stride + w_first + lane : r0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const u64 v = r0[it * kWave] & rt[it * kWave] & ra_[it * kWave] & rs[it * kWave];
+        base[it] = w_first + it * kWave + lane < rw ? v : 0ull;
+        if (it % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // (register budget: two words' loads in flight)
+      }
+    }
+    const u64* planes = walk_lds + (size_t)max((r.irow >> kRowBigShift) - 1, 0) * kRankBits * SW + lane;
+    const u64* srow = s_stage + r.slot * SW + lane;
+    u64* dst = bitmap + (size_t)r.dest * row_stride + w_first + lane;
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const unsigned nj = ~idx[it];
+      u64 rk[kRankBits];
+#pragma unroll
+      for (int k = 0; k < kRankBits; ++k) rk[k] = planes[k * SW + it * kWave];
+      const u64 pw = srow[it * kWave];
+      unsigned m = (unsigned)((int)(nj << 31) >> 31);
+      unsigned glo = (unsigned)rk[0] & m, ghi = (unsigned)(rk[0] >> 32) & m;
+#pragma unroll
+      for (int k = 1; k < kRankBits; ++k) {
+        m = (unsigned)((int)(nj << (31 - k)) >> 31);
+        glo = maj32(glo, (unsigned)rk[k], m);
+        ghi = maj32(ghi, (unsigned)(rk[k] >> 32), m);
+      }
+      const unsigned xlo = and3((unsigned)base[it], (unsigned)pw, glo), xhi = and3((unsigned)(base[it] >> 32), (unsigned)(pw >> 32), ghi);
+      cnt += __popc(xlo) + __popc(xhi);
+      const u64 x = (u64)xlo | ((u64)xhi << 32);
+      if (TAIL && it == NIT - 1) {
+        if (tail_store) dst[it * kWave] = x;
       } else {
-        nd0 = int4{0, 0, -1, -1};  // (meta 0: not live)
+        dst[it * kWave] = x;
       }
-    };
-    request_desc(wave - kWalkStoreWaves);
-    for (int blk = wave - kWalkStoreWaves; blk < n_blocks; blk += kWalkLoaders) {
-      const int buf = blk % NB, c0 = c_begin + blk * kWalkBlockRows;
-      const int n_rows = min(kWalkBlockRows, c_end - c0);
-      const int cls = nd0.x, meta = nd0.y, pin = nd0.z, mem0 = nd0.w, st = nd1.x, sa = nd1.y, ss = nd1.z;
-      const int prow = (meta & kSlicePlane) ? nd2.x : -1, irow = nd2.y;
-      request_desc(blk + kWalkLoaders);
-      const bool fast = (meta & (kSliceLive | kSliceGeneral)) == kSliceLive;
-      // runs (lanes 0-31 decide): a fast row starts one when no fast row precedes it in the block or its cached rows differ from the
-      // previous fast row's
-      const u64 fast_m = __ballot(fast) & 0xffffffffull;
-      const u64 below = fast_m & ((1ull << row_l) - 1ull);
-      const int prev = below ? 63 - __clzll((long long)below) : row_l;
-      const bool change = fast && (below == 0 || __shfl(st, prev, kWave) != st || __shfl(sa, prev, kWave) != sa || __shfl(ss, prev, kWave) != ss);
-      const u64 change_m = __ballot(change) & 0xffffffffull;
-      const int run = (int)__popcll(change_m & ((2ull << row_l) - 1ull)) - 1;
-      const int n_runs = min((int)__popcll(change_m), g.run_slots);  // runs that get a base slot
-      // the buffer must be free: the store waves have finished with the block that used it last
-      if (blk >= NB) {
-        const int want = kWalkStoreWaves * (blk / NB);
-        while (__hip_atomic_load(s_used + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
-      }
-      // index bytes of the slice: 16-byte pieces of the row's byte string (sw and idx_stride are multiples of 16).
-      // Issued first, consumed after the base words: one wait serves both.
-      uint4 ib[kHalfPieces];
-      const unsigned char* isrc = pl.res_idx + (size_t)(irow & ((1 << kRowBigShift) - 1)) * pl.idx_stride + w_first;
-#pragma unroll
-      for (int k = 0; k < kHalfPieces; ++k) {
-        const int off = (half * kHalfPieces + k) * 16;
-        ib[k] = uint4{0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u};  // 64 = the empty entry of a mask table
-        if (fast && off < sw && w_first + off < pl.idx_stride) ib[k] = *(const uint4*)(isrc + off);
-      }
-      // base words of the runs, kWalkRunGroup at a time: all their loads go out before the first AND
-      for (int r0 = 0; r0 < n_runs; r0 += kWalkRunGroup) {
-        u64x2 b[kWalkRunGroup];
-#pragma unroll
-        for (int j = 0; j < kWalkRunGroup; ++j) {
-          b[j] = keep;
-          if (r0 + j < n_runs) {
-            u64 m = change_m;
-            for (int k = 0; k < r0 + j; ++k) m &= m - 1;
-            const int lead = __ffsll((long long)m) - 1;
-            b[j] = run_base(__builtin_amdgcn_readlane(st, lead), __builtin_amdgcn_readlane(sa, lead), __builtin_amdgcn_readlane(ss, lead));
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kWalkRunGroup; ++j)
-          if (r0 + j < n_runs && 2 * lane < sw) *(u64x2*)(s_base + ((size_t)buf * g.run_slots + r0 + j) * sw + 2 * lane) = b[j];
-      }
-      if (row_l < n_rows) {
-        if (fast) {
-          unsigned char* dst = s_idx + ((size_t)buf * kWalkBlockRows + row_l) * sw;
-#pragma unroll
-          for (int k = 0; k < kHalfPieces; ++k) {
-            const int off = (half * kHalfPieces + k) * 16;
-            if (off < sw) *(uint4*)(dst + off) = ib[k];
-          }
-        }
-        if (half == 0) {
-          int stage = -1;
-          if (fast && prow >= 0)
-            for (int k = 0; k < g.n_stage; ++k)
-              if (g.stage_row[k] == prow) stage = k;
-          WalkRow r;
-          r.dest = mem0;
-          r.cls = cls;
-          r.slot = !fast ? -1 : (run < g.run_slots ? run : -2);
-          r.chunk = c0 + row_l;
-          r.prow = stage >= 0 ? -1 : prow;
-          r.pin = pin_on ? pin : -1;
-          r.pm_off = max((irow >> kRowBigShift) - 1, 0) * sw * 65;
-          r.stage_off = (stage >= 0 ? stage : g.n_stage) * sw;
-          s_rows[buf * kWalkBlockRows + row_l] = r;
-        }
-      }
-      // publish: every LDS write of this wave is complete before the flag moves
-      if (lane == 0) __hip_atomic_store(s_ready + buf, blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (it % 2 == 1) __builtin_amdgcn_sched_barrier(0);  // two words' LDS reads in flight, not all of them (register budget)
     }
-    return;
-  }
-  // ============================================================= STORE waves: LDS in, 16-byte stores out
-  for (int blk = 0; blk < n_blocks; ++blk) {
-    const int buf = blk % NB, c0 = c_begin + blk * kWalkBlockRows;
-    const int n_rows = min(kWalkBlockRows, c_end - c0);
-    while (__hip_atomic_load(s_ready + buf, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != blk + 1) __builtin_amdgcn_s_sleep(1);
-    {
-      // kWalkRowsPerWave consecutive rows of the block per wave, stage by stage for ALL of them: a row is a chain of dependent LDS
-      // reads (record -> index bytes / base -> mask tables), ~1 300 cycles when walked alone (s_memtime, session 9); side by side
-      // the chains of the four rows overlap. The kernel is bound by INSTRUCTION ISSUE (SQ counters, session 10: 72 VALU + 48 SALU
-      // per (row, slice) pair in the first form), so the stages are lean and branch-free: record fields go to SGPRs, LDS offsets
-      // come ready-made from the loader, "no staged row" is an all-ones row, lanes past the slice are switched off as a whole, two
-      // rows share one DPP reduction (16-bit fields); the rare shapes (a run without a base slot, a plane row that is not staged, a
-      // pinned node) are patched afterwards under wave-uniform branches. (Letting the LOADER write the rows of slot-less runs
-      // instead was measured slower: 2.89 -> 3.19 ms, session 9.)
-      constexpr int K = kWalkRowsPerWave;
-      static_assert(K % 2 == 0, "rows are reduced in pairs");
-      const int rows0 = buf * kWalkBlockRows;
-      int slot[K], dest[K], cls[K], prow[K], pin[K], chunk[K], pm_off[K], stage_off[K];
-      bool live[K];
-      {
-        int4 ra[K], rb[K];
+    const int pc = wave_sum_lane63(cnt);
+    if (lane == 63 && pc) atomicAdd(&class_count[r.cls], pc);
+  };
+  // Two register banks of D rows each, the loop body unrolled twice: the index bytes of the next group are issued, then the
+  // current group is written. The loads are unconditional — when the wave's range is exhausted a slot repeats the row before it
+  // (`live` off) — so the compiler's vmcnt bookkeeping never has to assume a path without them (a branch around them cost an
+  // s_waitcnt for the stores of the row before), and no register set travels around the loop through copies (a rotation of four
+  // single-row sets did: every copy of a value still in flight is a wait).
+  constexpr int D = NIT <= 5 ? 4 : 3;  // rows per bank (register budget: 2 x D x NIT index registers beside base, planes and temporaries)
+  Row ra[D], rb[D];
+  bool la[D], lb[D];
+  unsigned ia[D][NIT], ib[D][NIT];
+  auto fetch_group = [&](Row (&r)[D], bool (&l)[D], const Row& before) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {  // (every lane reads the same record: an LDS broadcast)
-          const int4* rp = (const int4*)(s_rows + rows0 + min(wave * K + k, n_rows - 1));
-          ra[k] = rp[0];
-          rb[k] = rp[1];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          dest[k] = __builtin_amdgcn_readfirstlane(ra[k].x);
-          cls[k] = __builtin_amdgcn_readfirstlane(ra[k].y);
-          slot[k] = __builtin_amdgcn_readfirstlane(ra[k].z);
-          chunk[k] = __builtin_amdgcn_readfirstlane(ra[k].w);
-          prow[k] = __builtin_amdgcn_readfirstlane(rb[k].x);
-          pin[k] = __builtin_amdgcn_readfirstlane(rb[k].y);
-          pm_off[k] = __builtin_amdgcn_readfirstlane(rb[k].z);
-          stage_off[k] = __builtin_amdgcn_readfirstlane(rb[k].w);
-          live[k] = wave * K + k < n_rows && slot[k] != -1;
-        }
-      }
-      u64x2 x[K];
-      int pcl[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        x[k] = u64x2{0, 0};
-        pcl[k] = 0;
-      }
-      if (2 * lane < sw) {  // (the lanes past the slice sit the stages out; their counts stay zero)
-        const int lp = 2 * lane;
-        unsigned two[K];
-        u64x2 p[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const int i = min(wave * K + k, n_rows - 1);
-          two[k] = *(const unsigned short*)(s_idx + (rows0 + i) * sw + lp);
-          x[k] = *(const u64x2*)(s_base + (buf * g.run_slots + max(slot[k], 0)) * sw + lp);
-          p[k] = *(const u64x2*)(s_stage + stage_off[k] + lp);
-        }
-        u64x2 m[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const u64* tab = s_pm + pm_off[k] + lp * 65;
-          m[k] = u64x2{tab[two[k] & 0xffu], tab[65 + (two[k] >> 8)]};
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          m[k] &= p[k];
-          x[k] &= m[k];
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          if (live[k] && slot[k] == -2) {  // the block had more runs than base slots: this row fetches its cached rows itself (and the
-            const SliceDesc* d = desc + chunk[k];  // wave drains its store queue for it: one in-order vmcnt)
-            x[k] = run_base(d->st, d->sa, d->ss) & m[k];
-          }
-          if (live[k] && prow[k] >= 0) x[k] &= *(const u64x2*)((const char*)(pl.res + (size_t)prow[k] * pl.stride) + voff);  // (rare) a plane row that is not staged
-          if (pin[k] >= 0) {
-            x[k].x &= (w_true == (pin[k] >> 6)) ? (1ull << (pin[k] & 63)) : 0ull;
-            x[k].y &= (w_true + 1 == (pin[k] >> 6)) ? (1ull << (pin[k] & 63)) : 0ull;
-          }
-          pcl[k] = __popcll(x[k].x) + __popcll(x[k].y);
-        }
-      }
-      // feasible counts: a lane's count is <= 128 and a row's <= 8 192, so two rows ride in one 32-bit DPP reduction
-      int pc[K];
-#pragma unroll
-      for (int k = 0; k < K; k += 2) {
-        const int both = wave_sum_lane63(pcl[k] | (pcl[k + 1] << 16));
-        pc[k] = both & 0xffff;
-        pc[k + 1] = (int)((unsigned)both >> 16);
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (!live[k]) continue;  // (wave-uniform)
-        if (lane == 63 && pc[k]) atomicAdd(&class_count[cls[k]], pc[k]);
-        if (in_row) *(u64x2*)((char*)(bitmap + (size_t)dest[k] * row_stride) + voff) = x[k];
-      }
+    for (int k = 0; k < D; ++k) {
+      r[k] = k ? r[k - 1] : before;
+      l[k] = fetch(r[k]);
     }
-    // Done with the buffer. RELAXED on purpose: a release here would drain the wave's GLOBAL stores (s_waitcnt vmcnt(0)) at every
-    // block boundary. What has to be ordered is only LDS against LDS, and a wave's LDS operations execute in order: the reads
-    // above are done when the add is.
-    asm volatile("" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(s_used + buf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto issue_group = [&](const Row (&r)[D], unsigned (&idx)[D][NIT]) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) issue(r[k], idx[k]);
+  };
+  auto write_group = [&](const Row (&r)[D], const bool (&l)[D], const unsigned (&idx)[D][NIT]) {
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      if (l[k]) write_row(r[k], idx[k]);
+  };
+  fetch_group(ra, la, Row{0, 0, -1, -1, -1, stage.n, 1 << kRowBigShift});
+  if (!la[0]) return;
+  issue_group(ra, ia);
+  for (;;) {
+    fetch_group(rb, lb, ra[D - 1]);
+    issue_group(rb, ib);
+    write_group(ra, la, ia);
+    if (!lb[0]) break;
+    fetch_group(ra, la, rb[D - 1]);
+    issue_group(ra, ia);
+    write_group(rb, lb, ib);
+    if (!la[0]) break;
   }
 }
 
