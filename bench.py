@@ -229,7 +229,8 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
     """The kernel with the largest average duration + the whole step, both against the HBM peak.
 
     `achieved` prices the kernel with ITS algorithmic bytes: the band writer is charged the bitmap rows it writes
-    (layout.band_rows), the class-by-class writer the rest of the step's bytes (its rows + every input read once); the plane
+    (layout.band_rows), the class-by-class writer the rest of the step's bytes (its rows + every input read once), k_walk_rows its
+    rows + the index rows; the plane
     kernels are charged the planes they write plus the node table they read; kernels without a byte model here (the decision pass reads class rows out of L2 and
     is bound by the ordered scan, not by HBM) report achieved / frac = null — `whole_step_frac` always stands."""
     if not kern:
@@ -245,6 +246,8 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
     band_bytes = (lay.band_rows * lay.row_words * 8) if lay is not None else 0
     if base == "k_expand_bands":
         own = band_bytes if lay is not None else algo_bytes
+    elif base == "k_walk_rows" and lay is not None:  # its bitmap rows + the index rows it decodes (one byte per word), nothing else
+        own = (lay.num_pods * lay.row_words * 8 - band_bytes) + lay.index_rows * lay.row_words
     elif base in BITMAP_WRITERS:
         own = max(algo_bytes - band_bytes, 0)
     elif lay is not None and base in ("k_sig_planes", "k_base_planes", "k_planes", "k_dim_walk"):
