@@ -292,8 +292,10 @@ def json_ingest_leg(pkg, dev, a, gang):
         n_docs = sum(out["documents"].values())
         out.update({"json_ingest_ms": round(t_ingest * 1e3, 1), "nodes_ms": round(t_nodes * 1e3, 1), "us_per_document": round(t_ingest / max(n_docs, 1) * 1e6, 2),
                     "encode_upload_ms": round((t_sync - t_ingest) * 1e3, 1), "first_evaluation_ms": round((t_all - t_sync) * 1e3, 1),
-                    "asks_mirrored": dst.num_pods, "templates": dst.stats()["templates"], "ingest": dst.ingest_stats(),
-                    "note": "one cgo-shaped crossing per object kind (ykhost_update_nodes_batch / ykhost_update_pods_batch), single host thread"})
+                    "asks_mirrored": dst.num_pods, "templates": dst.stats()["templates"], "ingest": dst.ingest_stats(), "ingest_timing": dst.ingest_timing(),
+                    "host_cores": len(os.sched_getaffinity(0)),
+                    "note": "one cgo-shaped crossing per object kind (ykhost_update_nodes_batch / ykhost_update_pods_batch); the pod batches are "
+                            "scanned on `ingest_timing.threads` threads (scan_ms), the cache pass runs on the caller's thread (apply_ms)"})
     finally:
         dst.close()
     return out

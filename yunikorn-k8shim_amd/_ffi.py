@@ -189,6 +189,7 @@ def load_ykhost():
     L.ykhost_dump_documents.restype = C.c_int64
     L.ykhost_dump_documents.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
     L.ykhost_ingest_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykhost_ingest_timing.argtypes = [C.c_void_p, C.c_void_p]
     L.ykhost_candidates.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     L.ykhost_resident_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.ykhost_allocate_round.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]

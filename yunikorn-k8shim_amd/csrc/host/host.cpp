@@ -81,6 +81,7 @@ struct ykhost {
   // differ in name and uid only, so all but the first skip the JSON tree, read_template and the canonical re-serialisation
   std::unordered_map<std::string, const PodTemplate*> tpl_memo;
   int64_t ingest_fast = 0, ingest_full = 0;  // pod documents that took the memo / the full parser
+  int64_t ingest_threads = 0, ingest_scan_us = 0, ingest_apply_us = 0, ingest_parallel_batches = 0;  // ykhost_ingest_timing
   std::deque<NodeInfo> node_store;
   std::vector<NodeInfo*> nodes;  // index = engine node index
   std::unordered_map<std::string, int> node_ix;
@@ -1358,6 +1359,7 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
     p = (const char*)memchr(p, '\n', (size_t)(text + len - p));
     cut[(size_t)t] = p ? p + 1 : text + len;
   }
+  const auto t_begin = std::chrono::steady_clock::now();
   std::vector<ScannedPiece> pieces((size_t)T);
   auto shared = std::make_unique<SharedTemplates>();
   {
@@ -1369,6 +1371,13 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
   for (const ScannedPiece& pc : pieces)
     if (!pc.ok) return -1;
   *fallback = false;
+  const auto t_scanned = std::chrono::steady_clock::now();
+  auto account = [&]() {
+    h->ingest_threads = T;
+    h->ingest_parallel_batches++;
+    h->ingest_scan_us += std::chrono::duration_cast<std::chrono::microseconds>(t_scanned - t_begin).count();
+    h->ingest_apply_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_scanned).count();
+  };
   // ---- the ordered pass: a new template is interned when the first pod that carries it is reached — the order the one-thread
   // form interns them in — then the pod goes through the cache
   std::vector<std::vector<const PodTemplate*>> interned(SharedTemplates::kShards);
@@ -1405,8 +1414,10 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
     }
   } catch (const std::exception& ex) {
     fail(h, std::string("document #") + std::to_string(applied) + ": " + ex.what());
+    account();
     return -1 - applied;
   }
+  account();
   return applied;
 }
 }  // namespace
@@ -1744,6 +1755,14 @@ int32_t ykhost_ingest_stats(ykhost_t* h, int64_t* out2) {
   YKHOST_LOCKED(h);
   out2[0] = h->ingest_fast;
   out2[1] = h->ingest_full;
+  return 0;
+}
+int32_t ykhost_ingest_timing(ykhost_t* h, int64_t* out4) {
+  YKHOST_LOCKED(h);
+  out4[0] = h->ingest_threads;
+  out4[1] = h->ingest_scan_us;
+  out4[2] = h->ingest_apply_us;
+  out4[3] = h->ingest_parallel_batches;
   return 0;
 }
 

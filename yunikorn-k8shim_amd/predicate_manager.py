@@ -207,6 +207,12 @@ class GpuPredicateManager:
         self._L.ykhost_ingest_stats(self._h, out.ctypes.data)
         return {"template_reused": int(out[0]), "full_parse": int(out[1])}
 
+    def ingest_timing(self):
+        """Pod batches: scanning threads of the last parallel batch, ms of the parallel scan / of the ordered cache pass (summed)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._L.ykhost_ingest_timing(self._h, out.ctypes.data)
+        return {"threads": int(out[0]), "scan_ms": round(float(out[1]) / 1e3, 1), "apply_ms": round(float(out[2]) / 1e3, 1), "parallel_batches": int(out[3])}
+
     def encoded_tables(self):
         """The structure-of-arrays tables the encoder produces (dict; masks as Python ints). Needs no device."""
         need = self._L.ykhost_encoded_tables_json(self._h, None, 0)
