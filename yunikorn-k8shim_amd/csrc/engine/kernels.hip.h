@@ -348,7 +348,8 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
 // decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word; k_combine_slices keeps the tables
 // of a row slice in LDS).
 // Four words per thread, one dword store per row: with a byte per thread the kernel sat on its 13 M byte-store instructions per
-// pass (64 bytes per wave store; SQ counters: 73 % of the wave cycles waiting, 0.55–0.9 ms for 0.78 GB).
+// pass (64 bytes per wave store; SQ counters: 73 % of the wave cycles waiting, 0.55–0.9 ms for 0.78 GB). EIGHT words per thread
+// (8-byte stores, half the threads) are slower: 0.35 -> 0.52 ms, the rank-ordered walk 0.45 -> 0.71 ms (round 4, session 21).
 constexpr int kWalkWords = 4;
 __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* __restrict__ out, int stride) {
   const int chunk = blockIdx.x;
