@@ -133,8 +133,9 @@ int64_t ykhost_dump_documents(ykhost_t* h, int32_t kind, char* out, int64_t len)
 int32_t ykhost_ingest_stats(ykhost_t* h, int64_t* out2);
 /* Where the time of the pod batches went (summed over the handle's life): out[0] = scanning threads of the last batch that was
  * cut into pieces, out[1] = microseconds of the parallel scan, out[2] = microseconds of the ordered cache pass on the calling
- * thread, out[3] = batches that took the parallel path. */
-int32_t ykhost_ingest_timing(ykhost_t* h, int64_t* out4);
+ * thread (or of the bulk pass), out[3] = batches that took the parallel path, out[4] = those of them whose cache pass was the
+ * bulk pass on every core (all pods new, everything to be re-encoded anyway — the start-up replay). */
+int32_t ykhost_ingest_timing(ykhost_t* h, int64_t* out5);
 /* on != 0: ykhost_dump_snapshot writes runs of on-node pods that share a pod template once, with "replicas": k (the loaders
  * expand them; their uids get a "#r" suffix) — what keeps the dump of a 50 000-node cluster small enough to hand to the
  * oracle for full-grid parity. */

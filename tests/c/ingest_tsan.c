@@ -75,7 +75,10 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 2; ++i) pthread_join(th[i], NULL);
   int64_t st[2] = {0, 0};
   ykhost_ingest_stats(H, st);
-  printf("ingest ok: %d asks, %lld memo hits, %lld parses, %ld reader calls\n", ykhost_num_pods(H), (long long)st[0], (long long)st[1], calls[0] + calls[1]);
+  int64_t tm[5] = {0, 0, 0, 0, 0};
+  ykhost_ingest_timing(H, tm);
+  printf("ingest ok: %d asks, %lld memo hits, %lld parses, %ld reader calls, bulk batches %lld\n", ykhost_num_pods(H), (long long)st[0], (long long)st[1],
+         calls[0] + calls[1], (long long)tm[4]);
   ykhost_destroy(H);
   return rc;
 }

@@ -108,6 +108,41 @@ def test_large_batch_takes_the_scanning_threads_and_equals_one_thread(cluster_do
         m.close()
 
 
+def _load(monkeypatch, threads, batches):
+    monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
+    m = pkg.GpuPredicateManager(device=-1)
+    try:
+        counts = [m.update_documents(k, d) for k, d in batches]
+        return counts, m.dump_snapshot(), m.encoded_tables(), m.ingest_stats(), m.ingest_timing()
+    finally:
+        m.close()
+
+
+def test_bulk_cache_pass_equals_the_ordered_pass(cluster_docs, monkeypatch):
+    """The start-up replay (every pod new, everything to be encoded anyway) takes the bulk cache pass — pod slots and ask rows by
+    piece, the uid index by shard, the nodes' pod lists by node group, each on its own thread; anything it does not cover falls
+    back to the ordered pass: a uid that occurs twice in the batch or is cached already, a terminated pod, a pod without a uid.
+    Mirror, encoded tables and ingest counters equal the one-thread path's in every case; orphans go through the bulk pass. (A batch
+    behind an ordered pass that recycled pod slots is ordered as well: the bulk pass does not reuse freed slots.)"""
+    docs, _ = cluster_docs
+    on_nodes, asks = docs[1].splitlines(), docs[2].splitlines()
+    assert len(docs[1]) > 4 * 65536
+    ghost = [json.dumps(dict(json.loads(d), spec=dict(json.loads(d)["spec"], nodeName="ghost-node"))).encode() for d in on_nodes[:40]]
+    done = [json.dumps(dict(json.loads(d), status={"phase": "Succeeded"})).encode() for d in on_nodes[40:44]]
+    cases = {
+        "plain": ([(0, docs[0]), (1, docs[1]), (2, docs[2])], 2),
+        "orphans": ([(0, docs[0]), (1, b"\n".join(ghost + on_nodes[40:])), (2, docs[2])], 2),
+        "uid twice in the batch": ([(0, docs[0]), (1, b"\n".join(on_nodes + on_nodes[:30])), (2, docs[2])], 0),
+        "uid cached already": ([(0, docs[0]), (1, docs[1]), (1, docs[1]), (2, docs[2])], 1),
+        "terminated pod": ([(0, docs[0]), (1, b"\n".join(on_nodes[:40] + done + on_nodes[44:])), (2, docs[2])], 1),
+    }
+    for name, (batches, want_bulk) in cases.items():
+        one = _load(monkeypatch, "1", batches)
+        four = _load(monkeypatch, "4", batches)
+        assert one[:4] == four[:4], name
+        assert four[4]["bulk_batches"] == want_bulk and one[4]["bulk_batches"] == 0, (name, four[4])
+
+
 def test_parallel_ingest_under_thread_sanitizer(cluster_docs, tmp_path):
     """libykhost's sources + tests/c/ingest_tsan.c under -fsanitize=thread: the scanning threads of the batch forms and two
     concurrent reader threads on the same handle produce no data-race report."""
@@ -130,5 +165,5 @@ def test_parallel_ingest_under_thread_sanitizer(cluster_docs, tmp_path):
                            str(tmp_path / "ingest_tsan.o"), "-o", exe, "-L" + lib, "-lykpred", "-lpthread", "-Wl,-rpath," + lib])
     out = subprocess.run([exe] + paths, capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, YKHOST_INGEST_THREADS="4", TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0"))
-    assert out.returncode == 0 and "ingest ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+    assert out.returncode == 0 and "ingest ok" in out.stdout and "bulk batches 2" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
     assert "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-4000:]

@@ -6,6 +6,7 @@
 // the human-readable status message AFTER the device has named the failing plugin.
 #include "../../../include/ykhost.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -66,6 +67,61 @@ struct EncodedTables {
   ykpred_spread_t no_spread{};
 };
 
+// podsMap of the SchedulerCache (scheduler_cache.go:57): uid -> the cached version of the pod. Sharded by a hash of the uid so
+// that a bulk load can fill the shards on different threads (update_pods_bulk); every other caller sees the subset of the
+// std::unordered_map interface it used before (find / end / operator[] / erase / iteration).
+struct UidIndex {
+  static constexpr int kShards = 64;
+  using Map = std::unordered_map<std::string, Pod*>;
+  Map shard[kShards];
+  static unsigned shard_of(const std::string& uid) { return (unsigned)((std::hash<std::string>{}(uid) * 0x9E3779B97F4A7C15ull) >> 58); }
+  struct iterator {
+    UidIndex* ix;
+    int s;
+    Map::iterator it;
+    Map::value_type& operator*() const { return *it; }
+    Map::value_type* operator->() const { return &*it; }
+    bool operator==(const iterator& o) const { return s == o.s && (s == kShards || it == o.it); }
+    bool operator!=(const iterator& o) const { return !(*this == o); }
+    void settle() {
+      while (s < kShards && it == ix->shard[s].end()) {
+        ++s;
+        if (s < kShards) it = ix->shard[s].begin();
+      }
+    }
+    iterator& operator++() {
+      ++it;
+      settle();
+      return *this;
+    }
+  };
+  iterator end() { return iterator{this, kShards, Map::iterator{}}; }
+  iterator begin() {
+    iterator i{this, 0, shard[0].begin()};
+    i.settle();
+    return i;
+  }
+  iterator find(const std::string& uid) {
+    const int s = (int)shard_of(uid);
+    auto it = shard[s].find(uid);
+    return it == shard[s].end() ? end() : iterator{this, s, it};
+  }
+  Pod*& operator[](const std::string& uid) { return shard[shard_of(uid)][uid]; }
+  void erase(iterator i) { shard[i.s].erase(i.it); }
+  size_t erase(const std::string& uid) { return shard[shard_of(uid)].erase(uid); }
+  void clear() {
+    for (Map& m : shard) m.clear();
+  }
+  void reserve(size_t n) {
+    for (Map& m : shard) m.reserve(n / kShards + n / (8 * kShards) + 16);
+  }
+  size_t size() const {
+    size_t n = 0;
+    for (const Map& m : shard) n += m.size();
+    return n;
+  }
+};
+
 struct ykhost {
   // Context.IsPodFitNode runs under read locks only (context.go:697,709), so several core goroutines may be inside
   // Predicates() at once while the mirror's answer cache and lazy sync mutate state: one lock around every entry point.
@@ -81,14 +137,15 @@ struct ykhost {
   // differ in name and uid only, so all but the first skip the JSON tree, read_template and the canonical re-serialisation
   std::unordered_map<std::string, const PodTemplate*> tpl_memo;
   int64_t ingest_fast = 0, ingest_full = 0;  // pod documents that took the memo / the full parser
-  int64_t ingest_threads = 0, ingest_scan_us = 0, ingest_apply_us = 0, ingest_parallel_batches = 0;  // ykhost_ingest_timing
+  int64_t ingest_threads = 0, ingest_scan_us = 0, ingest_apply_us = 0, ingest_parallel_batches = 0, ingest_bulk_batches = 0;  // ykhost_ingest_timing
   std::deque<NodeInfo> node_store;
   std::vector<NodeInfo*> nodes;  // index = engine node index
   std::unordered_map<std::string, int> node_ix;
   std::deque<Pod> pod_store;
+  std::deque<std::vector<Pod>> pod_blocks;  // pods of bulk loads (update_pods_bulk): one block per scanned piece, filled on its thread
   std::vector<Pod*> free_pods;  // slots of pod versions nothing refers to any more (reused by the next update)
   std::vector<Pod*> pending;  // index = engine pod index
-  std::unordered_map<std::string, Pod*> by_uid;
+  UidIndex by_uid;
   bool uid_index = true;  // false for generated clusters until first needed
 
   // ---- encoder state
@@ -155,6 +212,7 @@ struct ykhost {
     nodes.clear();
     node_ix.clear();
     pod_store.clear();
+    pod_blocks.clear();
     free_pods.clear();
     pending.clear();
     by_uid.clear();
@@ -200,9 +258,14 @@ void copy_out(const std::string& s, char* out, int64_t len) {
 void ensure_uid_index(ykhost* h) {
   if (h->uid_index) return;
   h->by_uid.clear();
-  h->by_uid.reserve(h->pod_store.size());
+  size_t n = h->pod_store.size();
+  for (auto& b : h->pod_blocks) n += b.size();
+  h->by_uid.reserve(n);
   for (Pod& p : h->pod_store)
     if (p.tpl) h->by_uid[p.uid] = &p;
+  for (auto& b : h->pod_blocks)
+    for (Pod& p : b)
+      if (p.tpl) h->by_uid[p.uid] = &p;
   h->uid_index = true;
 }
 
@@ -1279,6 +1342,9 @@ struct ScannedPiece {
   std::vector<ScannedPod> pods;
   bool ok = true;
   std::string error;
+  // what decides whether the batch can take the bulk pass (update_pods_bulk)
+  bool plain = true;                  // no document for the full parser, no terminated pod, no pod without a uid
+  std::vector<int32_t> shared_tpl;    // indices of the pods that carry a template from the shared (new) list
 };
 void scan_piece(const ykhost* h, SharedTemplates* shared, const char* b, const char* e, ScannedPiece* out) {
   try {
@@ -1308,6 +1374,7 @@ void scan_piece(const ykhost* h, SharedTemplates* shared, const char* b, const c
           }
           if (idx < 0) {
             PodTemplate parsed = read_template(*mj::parse(std::string(doc.b, doc.e)));  // (outside the lock; a race parses twice, keeps one)
+            TemplatePool::prepare(parsed);  // canonical key + request vector: the ordered part of interning is a map insert
             std::lock_guard<std::mutex> lock(sh.mu);
             auto st = sh.index.find(sc.key);
             if (st != sh.index.end()) {
@@ -1330,23 +1397,167 @@ void scan_piece(const ykhost* h, SharedTemplates* shared, const char* b, const c
       sp.pod.terminating = sc.terminating;
       sp.pod.node_name = sc.node_name.str();
       sp.phase = sc.phase.str();
+      if (sp.tpl_shard >= 0) out->shared_tpl.push_back((int32_t)out->pods.size() - 1);
+      if (sp.pod.uid.empty() || sp.phase == "Failed" || sp.phase == "Succeeded") out->plain = false;
     });
     if (n < 0) out->ok = false;
+    for (const ScannedPod& sp : out->pods)
+      if (sp.full.present()) out->plain = false;
   } catch (const std::exception& ex) {
     out->ok = false;
     out->error = ex.what();
   }
 }
+// The cache pass of a BULK load on every core. SchedulerCache.UpdatePod is order-dependent only per uid (a later version of a
+// pod replaces an earlier one) and per shared structure (a node's pod list, the ask table) — and at start-up, when
+// Context.InitializeState replays the informer caches (context.go:1411-1484), neither bites: every pod is new. So when
+//   * every table is going to be re-encoded anyway (dirty_all: no per-row / per-node patch bookkeeping to keep),
+//   * no document needs the full parser, no pod is terminated or anonymous, no freed slot waits for reuse,
+//   * and no uid of the batch is already cached or occurs twice in it (found out while the shards of the uid index are filled:
+//     a clash rolls the batch back and the ordered pass takes it),
+// the pass is split by what it writes: pod slots and ask rows by PIECE (document order = slot order = ask order), the uid
+// index by uid SHARD, the nodes' pod lists and Requested sums by NODE GROUP — each structure is written by exactly one thread,
+// in document order. The result is the ordered pass's, field by field (tests/test_host_ingest.py holds them equal; the same
+// pass runs under ThreadSanitizer). Measured at configs[2] size on a 16-core quota: the ordered pass 3.8 s for 3.76 M
+// documents (it was 93 % of the ingest), this one: DESIGN.md section 4.9.
+// -> false: nothing was applied, the caller runs the ordered pass.
+bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTemplates* shared, long* applied_out) {
+  const int T = (int)pieces.size();
+  if (!h->dirty_all || !h->free_pods.empty()) return false;
+  for (const ScannedPiece& pc : pieces)
+    if (!pc.plain) return false;
+  std::vector<size_t> offset((size_t)T + 1, 0);
+  for (int t = 0; t < T; ++t) offset[(size_t)t + 1] = offset[(size_t)t] + pieces[(size_t)t].pods.size();
+  const size_t M = offset[(size_t)T];
+  if (M == 0) return false;
+  ensure_uid_index(h);
+  std::vector<std::vector<Pod>> block((size_t)T);  // the pods' final storage, one block per piece (published at the end)
+  auto slot_of = [&](int t, int32_t local) { return &block[(size_t)t][(size_t)local]; };
+  const int G = std::max(1, std::min<int>(4 * T, (int)h->nodes.size()));  // node groups (contiguous index ranges)
+  const size_t N = h->nodes.size();
+  auto group_of = [&](int node) { return (int)((size_t)node * (size_t)G / std::max<size_t>(N, 1)); };
+  std::vector<std::vector<std::vector<int32_t>>> by_shard((size_t)T, std::vector<std::vector<int32_t>>(UidIndex::kShards));
+  std::vector<std::vector<std::vector<int32_t>>> by_group((size_t)T, std::vector<std::vector<int32_t>>((size_t)G));
+  std::vector<std::vector<int32_t>> node_of((size_t)T);
+  std::vector<size_t> asks_in((size_t)T, 0);
+  auto run = [&](int n, auto&& f) {  // f(0..n-1) on T threads (the caller is one of them)
+    std::atomic<int> next{0};
+    auto body = [&]() {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    };
+    std::vector<std::thread> threads;
+    for (int t = 1; t < std::min(T, n); ++t) threads.emplace_back(body);
+    body();
+    for (auto& th : threads) th.join();
+  };
+  // P1, by piece: where every pod goes (uid shard, node, node group), how many asks the piece holds
+  run(T, [&](int t) {
+    const std::vector<ScannedPod>& pods = pieces[(size_t)t].pods;
+    block[(size_t)t].resize(pods.size());
+    node_of[(size_t)t].resize(pods.size());
+    for (auto& v : by_shard[(size_t)t]) v.reserve(pods.size() / UidIndex::kShards + 8);
+    size_t asks = 0;
+    for (size_t i = 0; i < pods.size(); ++i) {
+      const ScannedPod& sp = pods[i];
+      by_shard[(size_t)t][UidIndex::shard_of(sp.pod.uid)].push_back((int32_t)i);
+      int node = -1;  // -1: no spec.nodeName, -2: names a node the cache does not hold (orphan)
+      if (!sp.pod.node_name.empty()) {
+        auto nt = h->node_ix.find(sp.pod.node_name);
+        node = nt == h->node_ix.end() ? -2 : nt->second;
+      }
+      node_of[(size_t)t][i] = node;
+      if (node >= 0) by_group[(size_t)t][(size_t)group_of(node)].push_back((int32_t)i);
+      if (node == -1 && sp.phase != "Running") ++asks;
+    }
+    asks_in[(size_t)t] = asks;
+  });
+  // P2, by uid shard: the index entries of the new slots; a uid that is already there ends the bulk pass
+  std::atomic<bool> clash{false};
+  run(UidIndex::kShards, [&](int s) {
+    UidIndex::Map& m = h->by_uid.shard[s];
+    size_t n = 0;
+    for (int t = 0; t < T; ++t) n += by_shard[(size_t)t][(size_t)s].size();
+    m.reserve(m.size() + n);
+    for (int t = 0; t < T; ++t)
+      for (int32_t i : by_shard[(size_t)t][(size_t)s])
+        if (!m.emplace(pieces[(size_t)t].pods[(size_t)i].pod.uid, slot_of(t, i)).second) clash.store(true, std::memory_order_relaxed);
+  });
+  if (clash.load()) {
+    run(UidIndex::kShards, [&](int s) {
+      UidIndex::Map& m = h->by_uid.shard[s];
+      for (int t = 0; t < T; ++t)
+        for (int32_t i : by_shard[(size_t)t][(size_t)s]) {
+          auto it = m.find(pieces[(size_t)t].pods[(size_t)i].pod.uid);
+          if (it != m.end() && it->second == slot_of(t, i)) m.erase(it);
+        }
+    });
+    return false;
+  }
+  // the new templates, interned in the order the ordered pass meets them
+  std::vector<std::vector<const PodTemplate*>> interned(SharedTemplates::kShards);
+  for (int k = 0; k < SharedTemplates::kShards; ++k) interned[(size_t)k].assign(shared->shard[k].tpls.size(), nullptr);
+  int64_t new_templates = 0;
+  for (int t = 0; t < T; ++t)
+    for (int32_t i : pieces[(size_t)t].shared_tpl) {
+      const ScannedPod& sp = pieces[(size_t)t].pods[(size_t)i];
+      const PodTemplate*& slot = interned[(size_t)sp.tpl_shard][(size_t)sp.tpl_index];
+      if (slot) continue;
+      SharedTemplates::Shard& sh = shared->shard[sp.tpl_shard];
+      slot = h->pool.intern_prepared(std::move(sh.tpls[(size_t)sp.tpl_index]));
+      if (h->tpl_memo.size() < 262144) h->tpl_memo.emplace(std::move(sh.keys[(size_t)sp.tpl_index]), slot);
+      ++new_templates;
+    }
+  h->ingest_full += new_templates;
+  h->ingest_fast += (int64_t)M - new_templates;
+  // P3, by piece: the pods move into their slots; asks take their rows (document order)
+  std::vector<size_t> ask_base((size_t)T + 1, h->pending.size());
+  for (int t = 0; t < T; ++t) ask_base[(size_t)t + 1] = ask_base[(size_t)t] + asks_in[(size_t)t];
+  h->pending.resize(ask_base[(size_t)T]);
+  std::atomic<bool> any_on_node{false};
+  run(T, [&](int t) {
+    std::vector<ScannedPod>& pods = pieces[(size_t)t].pods;
+    size_t row = ask_base[(size_t)t];
+    bool on_node = false;
+    for (size_t i = 0; i < pods.size(); ++i) {
+      ScannedPod& sp = pods[i];
+      Pod* p = slot_of(t, (int32_t)i);
+      if (sp.tpl_shard >= 0) sp.pod.tpl = interned[(size_t)sp.tpl_shard][(size_t)sp.tpl_index];
+      *p = std::move(sp.pod);
+      const int node = node_of[(size_t)t][i];
+      if (node >= 0) {
+        p->assigned_node = p->node_name;
+        on_node = true;
+      } else if (node == -2) {
+        p->orphan = true;
+      } else if (sp.phase != "Running") {
+        p->ask = true;
+        p->row = (int32_t)row;
+        h->pending[row++] = p;
+      }
+    }
+    if (on_node) any_on_node.store(true, std::memory_order_relaxed);
+    std::vector<ScannedPod>().swap(pods);  // (freed here, on the piece's thread)
+  });
+  // P4, by node group: pod lists and Requested sums
+  run(G, [&](int g) {
+    for (int t = 0; t < T; ++t)
+      for (int32_t i : by_group[(size_t)t][(size_t)g]) h->nodes[(size_t)node_of[(size_t)t][(size_t)i]]->add_pod(slot_of(t, i));
+  });
+  for (auto& b : block)
+    if (!b.empty()) h->pod_blocks.push_back(std::move(b));  // (a moved vector keeps its buffer: the slots stay where they are)
+  if (any_on_node.load()) h->resident.valid = false;  // (touch_node: node columns changed under a resident answer)
+  *applied_out = (long)M;
+  return true;
+}
+
 // → documents applied, -1 when the batch has to take the one-thread path (nothing applied), or the error code of a rejected
 // document (-1 - applied, like the one-thread form)
 long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallback) {
   *fallback = true;
   // YKHOST_INGEST_THREADS: a container with a CPU quota still reports every core of its host (hardware_concurrency), and
   // scanning threads that share two real cores are slower than one; 1 = the one-thread path
-  static const int want = [] {
-    const char* v = getenv("YKHOST_INGEST_THREADS");
-    return v ? atoi(v) : 0;
-  }();
+  const char* env = getenv("YKHOST_INGEST_THREADS");  // (read per batch: the tests switch it inside one process)
+  const int want = env ? atoi(env) : 0;
   const unsigned hw = want > 0 ? (unsigned)want : std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
   const int64_t min_piece = 1 << 16;
   const int T = (int)std::min<int64_t>(hw, len / min_piece);
@@ -1378,6 +1589,14 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
     h->ingest_scan_us += std::chrono::duration_cast<std::chrono::microseconds>(t_scanned - t_begin).count();
     h->ingest_apply_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_scanned).count();
   };
+  {
+    long bulk_applied = 0;
+    if (update_pods_bulk(h, pieces, shared.get(), &bulk_applied)) {
+      h->ingest_bulk_batches++;
+      account();
+      return bulk_applied;
+    }
+  }
   // ---- the ordered pass: a new template is interned when the first pod that carries it is reached — the order the one-thread
   // form interns them in — then the pod goes through the cache
   std::vector<std::vector<const PodTemplate*>> interned(SharedTemplates::kShards);
@@ -1396,7 +1615,7 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
             const PodTemplate*& slot = interned[(size_t)sp.tpl_shard][(size_t)sp.tpl_index];
             if (!slot) {
               SharedTemplates::Shard& sh = shared->shard[sp.tpl_shard];
-              slot = h->pool.intern(std::move(sh.tpls[(size_t)sp.tpl_index]));
+              slot = h->pool.intern_prepared(std::move(sh.tpls[(size_t)sp.tpl_index]));
               if (h->tpl_memo.size() < 262144) h->tpl_memo.emplace(std::move(sh.keys[(size_t)sp.tpl_index]), slot);
               h->ingest_full++;  // (one full parse per new template, as on one thread)
             } else {
@@ -1757,12 +1976,14 @@ int32_t ykhost_ingest_stats(ykhost_t* h, int64_t* out2) {
   out2[1] = h->ingest_full;
   return 0;
 }
-int32_t ykhost_ingest_timing(ykhost_t* h, int64_t* out4) {
+int32_t ykhost_ingest_timing(ykhost_t* h, int64_t* out5) {
+  int64_t* out4 = out5;
   YKHOST_LOCKED(h);
   out4[0] = h->ingest_threads;
   out4[1] = h->ingest_scan_us;
   out4[2] = h->ingest_apply_us;
   out4[3] = h->ingest_parallel_batches;
+  out4[4] = h->ingest_bulk_batches;
   return 0;
 }
 

@@ -579,14 +579,21 @@ inline void node_json(const NodeInfo& ni, std::string& o, bool compact = false) 
 // ---------------------------------------------------------------------------------------------------
 class TemplatePool {
  public:
-  const PodTemplate* intern(PodTemplate&& t) {
+  // the part of interning that touches no shared state (the scanning threads of a batch do it for the templates they parse)
+  static void prepare(PodTemplate& t) {
     std::string meta, spec;
     template_json(t, meta, spec);
-    std::string key = meta + "|" + spec;
-    auto it = by_key_.find(key);
-    if (it != by_key_.end()) return it->second.get();
-    t.canonical = key;
+    t.canonical = meta + "|" + spec;
     t.requests = compute_requests(t);
+  }
+  const PodTemplate* intern(PodTemplate&& t) {
+    prepare(t);
+    return intern_prepared(std::move(t));
+  }
+  const PodTemplate* intern_prepared(PodTemplate&& t) {
+    auto it = by_key_.find(t.canonical);
+    if (it != by_key_.end()) return it->second.get();
+    std::string key = t.canonical;
     auto up = std::make_unique<PodTemplate>(std::move(t));
     const PodTemplate* raw = up.get();
     by_key_.emplace(std::move(key), std::move(up));

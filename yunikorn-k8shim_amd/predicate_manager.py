@@ -209,9 +209,9 @@ class GpuPredicateManager:
 
     def ingest_timing(self):
         """Pod batches: scanning threads of the last parallel batch, ms of the parallel scan / of the ordered cache pass (summed)."""
-        out = np.zeros(4, dtype=np.int64)
+        out = np.zeros(5, dtype=np.int64)
         self._L.ykhost_ingest_timing(self._h, out.ctypes.data)
-        return {"threads": int(out[0]), "scan_ms": round(float(out[1]) / 1e3, 1), "apply_ms": round(float(out[2]) / 1e3, 1), "parallel_batches": int(out[3])}
+        return {"threads": int(out[0]), "scan_ms": round(float(out[1]) / 1e3, 1), "apply_ms": round(float(out[2]) / 1e3, 1), "parallel_batches": int(out[3]), "bulk_batches": int(out[4])}
 
     def encoded_tables(self):
         """The structure-of-arrays tables the encoder produces (dict; masks as Python ints). Needs no device."""
