@@ -108,6 +108,37 @@ def test_large_batch_takes_the_scanning_threads_and_equals_one_thread(cluster_do
         m.close()
 
 
+def test_node_batch_parses_on_every_core_and_stops_where_one_thread_would(cluster_docs, monkeypatch):
+    """ykhost_update_nodes_batch parses its documents on the scanning threads and applies them in order: the mirror equals the
+    one-thread form's, and a document that does not parse (or a malformed one) stops the batch at its position — the nodes in
+    front of it are in the cache, the ones behind it are not."""
+    docs, _ = cluster_docs
+    lines = docs[0].splitlines()
+    assert len(lines) >= 256
+    broken = b"\n".join(lines[:100] + [b'{"metadata": {"name": "half"'] + lines[100:])
+    wrong = b"\n".join(lines[:70] + [b'{"metadata": {"name": 7, "labels": "x"}, "status": {"allocatable": {"cpu": "lots"}}}'] + lines[70:])
+    seen = []
+    for threads in ("1", "4"):
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
+        m = pkg.GpuPredicateManager(device=-1)
+        try:
+            assert m.update_documents(0, docs[0]) == len(lines)
+            full = m.dump_snapshot()
+        finally:
+            m.close()
+        outcome = [full]
+        for text in (broken, wrong):
+            m = pkg.GpuPredicateManager(device=-1)
+            try:
+                rc = m._L.ykhost_update_nodes_batch(m._h, text, len(text))
+                outcome.append((rc, m._L.ykhost_last_error(m._h), m.num_nodes))
+            finally:
+                m.close()
+        seen.append(outcome)
+    assert seen[0] == seen[1]
+    assert seen[0][1][0] == -101 and seen[0][1][2] == 100
+
+
 def _load(monkeypatch, threads, batches):
     monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
     m = pkg.GpuPredicateManager(device=-1)
