@@ -282,10 +282,11 @@ def test_sig_planes_words_per_lane(monkeypatch, wpl, n_nodes):
 
 @pytest.mark.parametrize("walk_rows,n_nodes", [(1, 333), (3, 129), (1, 8300)])
 def test_slice_writer_equals_wave_writer_and_oracle(monkeypatch, walk_rows, n_nodes):
-    """The zone-B writer of populations with index rows (k_slice_desc + k_walk_rows: loader / store waves, the mask tables, index
-    bytes and base words of a row slice in LDS; everything else through the descriptor-filtered k_combine_wave) against the plain
-    wave-per-chunk writer (YKPRED_TUNE combine_slices=0) on the same snapshot: one / two walked dimensions, pinned pods, duplicated
-    pods (several member rows), rows narrower and wider than one 128-word slice — bitmap, counts, decisions, and the oracle."""
+    """The zone-B writer of populations with index rows (k_slice_desc + k_walk_rows: a wave writes whole row segments, index bytes
+    decoded through the rank planes, ballot rows staged in LDS; everything else through the descriptor-filtered k_combine_wave)
+    against the plain wave-per-chunk writer (YKPRED_TUNE combine_slices=0) on the same snapshot: one / two walked dimensions, pinned
+    pods, duplicated pods (several member rows), rows of one partial word group up to several segments — bitmap, counts, decisions,
+    and the oracle."""
     snap = _gen.random_snapshot(9900 + walk_rows, n_nodes=n_nodes, n_pods=150, scalars=True)
     got = {}
     for knob in ("0", "1"):

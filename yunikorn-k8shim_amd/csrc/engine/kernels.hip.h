@@ -345,8 +345,8 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
 // The rows it produces are INDEX rows: one BYTE per 64-node word — the position `ptr` in the word's sorted free list — instead of
 // the 8-byte plane word pmask[word][ptr] itself. A walked dimension has up to 10^6 rows; as u64 planes they are 6.5 GB written
 // here and read again by the combine / decide kernels (half of that population's traffic), as index rows 0.8 GB. Consumers
-// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word; k_combine_slices keeps the tables
-// of a row slice in LDS).
+// decode with one lookup into the 65-entry mask table of the word (Planes::pmask; class_word); k_walk_rows
+// decodes with the rank planes of k_dim_sort instead.
 // Four words per thread, one dword store per row: with a byte per thread the kernel sat on its 13 M byte-store instructions per
 // pass (64 bytes per wave store; SQ counters: 73 % of the wave cycles waiting, 0.55–0.9 ms for 0.78 GB). EIGHT words per thread
 // (8-byte stores, half the threads) are slower: 0.35 -> 0.52 ms, the rank-ordered walk 0.45 -> 0.71 ms (round 4, session 21).
@@ -965,7 +965,7 @@ struct Planes {
   int n_words;
   const int* first;       // rank-ordered planes: first non-zero word per plane row of the whole buffer (null: not kept) ...
   int base_res, base_tol, base_aff, base_spread;  // ... indexed by family base + signature
-  int n_big;              // walked dimensions with a mask table in `pmask` (k_combine_slices stages their slices in LDS)
+  int n_big;              // walked dimensions with a mask table in `pmask` and rank planes in `rbits`
   const i64* res_val;     // [rows] request value of a plane / index row of `res` (rank-ordered planes: with `pfx`, else null)
   const i64* pfx;         // [walked dimensions][n_words] rank order only: largest free value among the nodes of words 0..w
                           // (k_dim_prefix_max) — a row of value v has no bit before the first word with pfx >= v
@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
                                                          int pin_enabled, int* __restrict__ class_count, int n_chunks,
                                                          const int* __restrict__ class_dirty /* null = every class */,
                                                          const SliceDesc* __restrict__ only_general /* non-null: only the chunks whose
-                                                         descriptor says `general` (the rest belongs to k_combine_slices) */,
+                                                         descriptor says `general` (the rest belongs to k_walk_rows) */,
                                                          const int* __restrict__ n_general /* with only_general: their number */,
                                                          const int* __restrict__ chunk_list /* null: n_chunks = every chunk; else the
                                                          n_chunks chunks to run */) {
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
 }
 
 // Sum of an int over the 64 lanes of the wave, valid in LANE 63: the DPP row-shift / row-broadcast ladder (VALU only — six
-// ds_bpermute round trips per reduction were a visible part of k_combine_slices' per-chunk latency).
+// ds_bpermute round trips per reduction were a visible part of the slice writer's per-chunk latency in round 3).
 __device__ __forceinline__ int wave_sum_lane63(int v) {
   int t = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
   t += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);         // row_shr:2
@@ -1209,35 +1209,17 @@ __device__ __forceinline__ int wave_sum_lane63(int v) {
   t += __builtin_amdgcn_update_dpp(0, t, 0x143, 0xc, 0xf, true);         // row_bcast:31 into rows 2 and 3
   return t;
 }
-// Slice form of the class-by-class writer for populations with INDEX rows (every ask its own request value: 10^6 single-member
-// classes). Decoding an index byte through the word's 65-entry mask table is a gather with a 520-byte lane stride: in
-// k_combine_wave (lane = word) every lane of a wave load hits its own cache line, ≈ 100 KB of L2 → L1 line traffic per 6 KB row
-// written, and that — not HBM — sets the pace (4.5 ms alone, 6.8 ms beside the decision kernels for a 6.27 GB bitmap).
-// Here a workgroup owns ONE slice of `slice_words` (<= 128) words of the row for a long run of chunks:
-//   * the mask tables of the slice (520 bytes per word and walked dimension) sit in LDS — the decode is a ds_read_b64, and
-//     global memory only sees coalesced streams (index bytes, plane words, row pieces of <= 1 KiB: lane = a pair of words);
-//   * what a wave has to know about a chunk (class, member row, signature rows, request-value rows) is resolved once per pass
-//     by one thread per chunk (k_slice_desc) and read coalesced: lane j holds the descriptor of chunk c0 + j, broadcast with
-//     v_readlane — no chain of dependent scalar loads per chunk, no table walk repeated per slice;
-//   * zone-B chunks come in signature order (aff, tol, spread, request vector: build_classes), so the toleration / affinity /
-//     spread words and the pod-independent request row of a lane are kept in registers (w_base) and reloaded only when they
-//     change — their loads go out together with the batch's loads, one wait serves both;
-//   * single-row chunks of one such key are served in batches of kSliceBatch: every load, one wait, every mask, then the
-//     counts and the stores (slice_issue / slice_finish); every other chunk is left to k_combine_wave (descriptor filter).
-// History (profiles/r03_sessions7_20_small_class_paths.txt): one word per lane and every row pointer rebuilt per (chunk, slice)
-// 9.3 ms; two words per lane with cached signature words 4.6 ms; batches of 8 3.4 ms alone; chunk descriptors 3.4 ms; 28 % fewer
-// instructions 3.4 ms; no scratch + one wait per batch 3.15 ms. SQ counters: 76 % of the wave cycles in s_waitcnt at two 8-wave
-// workgroups per CU, no back-pressure anywhere in the memory path — the kernel is bound by latency at low occupancy.
-constexpr int kSliceWaves = 8;
-constexpr int kSliceBlock = kSliceWaves * kWave;
-constexpr int kSliceBatch = 6;      // chunks whose loads are in flight together (8 spill a lane offset to scratch: every reload is a vmcnt(0))
-constexpr int kSliceMaxWords = 128;
+// Populations with INDEX rows (every ask its own request value: 10^6 single-member classes). Decoding an index byte through the
+// word's 65-entry mask table is a gather with a 520-byte lane stride: in k_combine_wave (lane = word) every lane of a wave load
+// hits its own cache line, ≈ 100 KB of L2 → L1 line traffic per 6 KB row written, and that — not HBM — sets the pace (4.5 ms alone
+// for a 6.27 GB bitmap). Round 3 kept the tables of a <= 128-word slice of the row in LDS (k_combine_slices, 3.15 ms; its history
+// is in profiles/r03_sessions7_20_small_class_paths.txt); round 4 decodes with rank planes instead: k_walk_rows below.
 typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
 
-// Chunk descriptors of the slice writer: what a wave needs to know about a chunk, resolved ONCE per pass by one thread per chunk
-// (k_slice_desc) instead of once per (chunk, slice) by the writer — the walk chunk → class → signatures → request-value rows is
-// three levels of dependent, uncoalesced loads from tables that do not fit the L2; seven slices repeated it seven times and every
-// wave of the writer sat through it before its first store (27 M random 64-byte reads per pass: profiles/r03_session11_pmc.txt).
+// Chunk descriptors of k_walk_rows: what a wave needs to know about a chunk, resolved ONCE per pass by one thread per chunk
+// (k_slice_desc) instead of by the writer — the walk chunk → class → signatures → request-value rows is three levels of dependent,
+// uncoalesced loads from tables that do not fit the L2 (27 M random 64-byte reads per pass when the slice writer of round 3 did it
+// per (chunk, slice): profiles/r03_session11_pmc.txt); the writer reads them as wave-uniform scalar loads.
 // A class's rows on the fast path: toleration, affinity, spread and the FIRST request-value plane row (row 0 of the family, the
 // pod-independent part — the same row for every class) are "cached" rows, folded into the lane's base words while they do not
 // change from chunk to chunk; what remains per chunk is at most one more plane row and exactly one index row.
