@@ -1151,6 +1151,22 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
   }
 }
 // Many Node documents in one call (see ykhost_update_pods_batch). → documents applied, or -1 - (documents applied before the bad one).
+// Threads for the batch forms: YKHOST_INGEST_THREADS, else the cores this process may really use — a container with a CPU quota
+// (cgroup v2 cpu.max) still reports every core of its host through hardware_concurrency (the GPU boxes of this pool: 256 visible,
+// 16 granted), and 64 scanning threads on 16 cores only add context switches — at most 64.
+static unsigned ingest_threads() {
+  const char* env = getenv("YKHOST_INGEST_THREADS");  // (read per batch: the tests switch it inside one process)
+  const int want = env ? atoi(env) : 0;
+  if (want > 0) return (unsigned)want;
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0;
+    if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+      hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    fclose(f);
+  }
+  return std::min(hw, 64u);
+}
 int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len) {
   YKHOST_LOCKED(h);
   if (!text || len < 0) return fail(h, "bad argument");
@@ -1165,10 +1181,7 @@ int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len) {
     std::vector<std::string> errors(D);
     std::vector<char> bad(D, 0);
     {
-      const char* env = getenv("YKHOST_INGEST_THREADS");
-      const int want = env ? atoi(env) : 0;
-      const unsigned hw = want > 0 ? (unsigned)want : std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
-      const int T = (int)std::max<size_t>(1, std::min<size_t>(hw, D / 64));
+      const int T = (int)std::max<size_t>(1, std::min<size_t>(ingest_threads(), D / 64));
       std::atomic<size_t> next{0};
       auto body = [&]() {
         for (size_t i = next.fetch_add(64); i < D; i = next.fetch_add(64))
@@ -1592,9 +1605,7 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
   *fallback = true;
   // YKHOST_INGEST_THREADS: a container with a CPU quota still reports every core of its host (hardware_concurrency), and
   // scanning threads that share two real cores are slower than one; 1 = the one-thread path
-  const char* env = getenv("YKHOST_INGEST_THREADS");  // (read per batch: the tests switch it inside one process)
-  const int want = env ? atoi(env) : 0;
-  const unsigned hw = want > 0 ? (unsigned)want : std::min(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  const unsigned hw = ingest_threads();
   const int64_t min_piece = 1 << 16;
   const int T = (int)std::min<int64_t>(hw, len / min_piece);
   if (T < 2) return -1;
