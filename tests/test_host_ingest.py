@@ -38,6 +38,56 @@ def test_template_memo_path_equals_the_full_parser(cluster_docs):
         slow.close()
 
 
+def test_scanner_against_the_full_parser_on_reshaped_documents(cluster_docs, monkeypatch):
+    """The one-pass scanner (jsonscan.h: scan_pod) against the tree parser on documents encoding/json would not produce but the API
+    server may relay: members in another order (nodeName last, status first), whitespace between tokens, unknown members,
+    escaped characters inside ignored strings — the mirror must not depend on which path read a pod."""
+    import random
+    docs, _ = cluster_docs
+    rng = random.Random(7)
+
+    def reshape(line):
+        d = json.loads(line)
+        meta, spec, status = d["metadata"], d["spec"], d.get("status", {})
+        keys = list(spec)
+        rng.shuffle(keys)
+        if "nodeName" in spec and rng.random() < 0.5:
+            keys.remove("nodeName")
+            keys.append("nodeName")  # the last member: cut out without a trailing comma
+        spec = {k: spec[k] for k in keys}
+        if rng.random() < 0.3:
+            spec["schedulerName"] = 'yuni"korn {x} [y]'
+        meta = dict(reversed(list(meta.items())))
+        if rng.random() < 0.3:
+            meta["annotations"] = {"note": "brace } bracket ] quote \" backslash \\ done"}
+        top = [("status", status), ("kind", "Pod"), ("metadata", meta), ("spec", spec)]
+        rng.shuffle(top)
+        seps = rng.choice([(",", ":"), (", ", ": "), (" ,\t", " : ")])
+        return json.dumps(dict(top), separators=seps).encode()
+
+    shaped = [b"\n".join(reshape(l) for l in docs[k].splitlines()) for k in (1, 2)]
+    outcomes = []
+    for threads in ("1", "4"):
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
+        fast, slow = pkg.GpuPredicateManager(device=-1), pkg.GpuPredicateManager(device=-1)
+        try:
+            fast.update_documents(0, docs[0])
+            slow.update_documents(0, docs[0])
+            for k, text in zip((1, 2), shaped):
+                assert fast.update_documents(k, text) == text.count(b"\n") + 1
+                forced = b"\n".join(json.dumps(dict(json.loads(l), status=dict(json.loads(l).get("status", {}), resize="InProgress"))).encode()
+                                    for l in text.splitlines())
+                assert slow.update_documents(k, forced) == text.count(b"\n") + 1
+            assert slow.ingest_stats()["template_reused"] == 0 and fast.ingest_stats()["template_reused"] > 0
+            assert fast.dump_snapshot() == slow.dump_snapshot()
+            assert fast.encoded_tables() == slow.encoded_tables()
+            outcomes.append(fast.dump_snapshot())
+        finally:
+            fast.close()
+            slow.close()
+    assert outcomes[0] == outcomes[1]
+
+
 def test_batch_equals_one_call_per_object(cluster_docs):
     docs, n_asks = cluster_docs
     one, batch = pkg.GpuPredicateManager(device=-1), pkg.GpuPredicateManager(device=-1)
