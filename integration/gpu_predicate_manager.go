@@ -425,3 +425,59 @@ func (m *gpuPredicateManager) RoutingStats() (unsupported, refused, growths int6
 	C.ykhost_routing_stats(m.host, &out[0])
 	return int64(out[0]), int64(out[1]), int64(out[2])
 }
+
+// AllocateRound decides a scheduling round with conflict-resolved decisions: pods[i] is decided with pods[0..i-1] assumed on
+// their nodes — what the core's allocation loop obtains by calling Predicates() down the bin-pack order and AssumePod after every
+// allocation (scheduler_callback.go:49-98, context.go:828-885), in ONE device call where only node resources couple the asks
+// (ykhost_allocate_round; ask by ask on the host side where topology constraints or host ports do). nodes[i] is the node index in
+// the mirror's node order (NodeName resolves it), -1 when no node fits, -2 when the ask is routed to the CPU manager. apply = true
+// marks the chosen nodes' asks assumed in the mirror exactly as OnAssumePod would; with apply = false the core confirms through
+// OnAssumePod itself. Needs a current Refresh(allocate) with decisions.
+func (m *gpuPredicateManager) AllocateRound(pods []*v1.Pod, apply bool) ([]int32, error) {
+	if len(pods) == 0 {
+		return nil, nil
+	}
+	asks := make([]C.int32_t, len(pods))
+	for i, pod := range pods {
+		uid := C.CString(string(pod.UID))
+		asks[i] = C.ykhost_pod_index(m.host, uid)
+		C.free(unsafe.Pointer(uid))
+		if asks[i] < 0 {
+			return nil, fmt.Errorf("pod %s is not a pending ask of the mirror", pod.UID)
+		}
+	}
+	doApply := C.int32_t(0)
+	if apply {
+		doApply = 1
+	}
+	nodes := make([]C.int32_t, len(pods))
+	if rc := C.ykhost_allocate_round(m.host, C.int32_t(len(pods)), &asks[0], doApply, &nodes[0]); rc < 0 {
+		return nil, fmt.Errorf("ykhost_allocate_round: %s", C.GoString(C.ykhost_last_error(m.host)))
+	}
+	out := make([]int32, len(pods))
+	for i := range out {
+		out[i] = int32(nodes[i])
+	}
+	return out, nil
+}
+
+// RoundStats: rounds decided by one device call, asks decided in them, asks decided ask by ask, asks routed to the CPU manager.
+func (m *gpuPredicateManager) RoundStats() (deviceRounds, deviceAsks, oneByOne, routed int64) {
+	var out [4]C.int64_t
+	C.ykhost_round_stats(m.host, &out[0])
+	return int64(out[0]), int64(out[1]), int64(out[2]), int64(out[3])
+}
+
+// DeviceErrors: engine calls that failed (lost device, failed allocation) since the manager was created. Each one marked the
+// whole device state stale; the next Refresh re-uploads. A growing counter is what an operator alerts on.
+func (m *gpuPredicateManager) DeviceErrors() int64 {
+	return int64(C.ykhost_device_errors(m.host))
+}
+
+// IngestTiming: where the time of the pod batches went (ReplayState): scanning threads of the last batch, microseconds of the
+// parallel scan, microseconds of the cache pass, batches cut into pieces, batches whose cache pass was the bulk pass on every core.
+func (m *gpuPredicateManager) IngestTiming() (threads, scanMicros, cacheMicros, parallelBatches, bulkBatches int64) {
+	var out [5]C.int64_t
+	C.ykhost_ingest_timing(m.host, &out[0])
+	return int64(out[0]), int64(out[1]), int64(out[2]), int64(out[3]), int64(out[4])
+}
