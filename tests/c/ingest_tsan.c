@@ -74,6 +74,16 @@ int main(int argc, char** argv) {
   atomic_store(&stop_readers, 1);
   for (int i = 0; i < 2; ++i) pthread_join(th[i], NULL);
   int64_t st[2] = {0, 0};
+  {
+    /* a full encode of the ingested mirror (mirror-only handle: no device): its node loop runs on the scanning threads when the
+     * cluster has >= 4096 nodes */
+    char reason[256];
+    const int32_t sup = ykhost_ask_supported(H, 0, reason, sizeof reason);
+    if (sup < 0) {
+      fprintf(stderr, "encode: %s\n", ykhost_last_error(H));
+      return 1;
+    }
+  }
   ykhost_ingest_stats(H, st);
   int64_t tm[5] = {0, 0, 0, 0, 0};
   ykhost_ingest_timing(H, tm);

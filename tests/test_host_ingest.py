@@ -189,6 +189,22 @@ def test_node_batch_parses_on_every_core_and_stops_where_one_thread_would(cluste
     assert seen[0][1][0] == -101 and seen[0][1][2] == 100
 
 
+def test_full_encode_on_several_threads_equals_one_thread(monkeypatch):
+    """The node loop of a full encode runs on the host's cores when there are enough nodes and no selector classes (per-thread
+    label-tuple memo; YKHOST_INGEST_THREADS pins the count); the pass over every pod that looks for required anti-affinity terms
+    on running pods is skipped when no template of the pool carries one. The tables equal the one-thread encode's."""
+    tables = []
+    for threads in ("1", "5"):
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
+        m = pkg.GpuPredicateManager(device=-1)
+        try:
+            m.generate_kwok(seed=31, num_nodes=6000, num_pods=3000, num_templates=150, node_affinity=1, spread=0)
+            tables.append(m.encoded_tables())
+        finally:
+            m.close()
+    assert tables[0] == tables[1] and tables[0]["N"] == 6000 and tables[0]["KS"] == 0
+
+
 def _load(monkeypatch, threads, batches):
     monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
     m = pkg.GpuPredicateManager(device=-1)
@@ -225,14 +241,17 @@ def test_bulk_cache_pass_equals_the_ordered_pass(cluster_docs, monkeypatch):
 
 
 def test_parallel_ingest_under_thread_sanitizer(cluster_docs, tmp_path):
-    """libykhost's sources + tests/c/ingest_tsan.c under -fsanitize=thread: the scanning threads of the batch forms and two
-    concurrent reader threads on the same handle produce no data-race report."""
+    """libykhost's sources + tests/c/ingest_tsan.c under -fsanitize=thread: the scanning threads of the batch forms, the bulk cache
+    pass, the parallel node loop of a full encode and two concurrent reader threads on the same handle produce no data-race report."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "yunikorn-k8shim_amd", "lib")
     pkg.build_all()
-    docs, _ = cluster_docs
+    src = pkg.GpuPredicateManager(device=-1)  # (>= 4096 nodes: the encode at the end of the harness takes its parallel node loop)
+    src.generate_kwok(seed=6, num_nodes=4500, num_pods=3000, num_templates=100, node_affinity=1, spread=0)
+    docs = [src.dump_documents(k) for k in (0, 1, 2)]
+    src.close()
     paths = []
     for k, d in enumerate(docs):
         paths.append(str(tmp_path / f"docs{k}.ndjson"))

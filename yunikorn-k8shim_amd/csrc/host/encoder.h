@@ -236,7 +236,10 @@ class Encoder {
   static constexpr int kLimitR = 8, kLimitTaintBits = 256, kLimitRequirements = 2048, kLimitPorts = 256, kLimitTopoKeys = 8, kLimitClasses = 4096;
 
   // Builds every dictionary from the current objects. Returns false (error set) on unsupported input.
-  bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates) {
+  // may_have_existing_anti = false: the caller knows that NO pod template of the cluster carries a required anti-affinity term
+  // (the common case) — the pass over every pod on every node that collects such templates is skipped (2.76 M pointer chases,
+  // 45 of the 165 ms of a full encode at configs[2] size).
+  bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates, bool may_have_existing_anti = true) {
     error.clear();
     scalar_names.clear();
     taint_dict.clear();
@@ -261,7 +264,7 @@ class Encoder {
     port_ix_.clear();
     // InterPodAffinity: topology keys of the anti-affinity terms carried by pods that are already on nodes
     existing_anti_templates_.clear();
-    {
+    if (may_have_existing_anti) {
       std::set<const PodTemplate*> seen;
       for (const NodeInfo* ni : nodes)
         for (const Pod* p : ni->pods)
@@ -557,8 +560,12 @@ class Encoder {
   }
 
   // ---- node rows -----------------------------------------------------------------------------------
+  typedef std::unordered_map<std::string, std::vector<uint64_t>> LabelMemo;
+  // memo: the label-tuple cache to use — null = the encoder's own (single-threaded callers); the parallel node loop of a full
+  // encode hands every thread its own (the cache only saves work, the words are the same)
   void encode_node(const NodeInfo& ni, int64_t* alloc, int64_t* requested, int32_t* allowed, int32_t* count, uint32_t* flags,
-                   uint64_t* taints, uint64_t* labels) const {
+                   uint64_t* taints, uint64_t* labels, LabelMemo* memo_in = nullptr) const {
+    LabelMemo& label_memo = memo_in ? *memo_in : label_memo_;
     std::fill(alloc, alloc + R, 0);
     std::fill(requested, requested + R, 0);
     alloc[0] = ni.allocatable.milli_cpu;
@@ -598,12 +605,12 @@ class Encoder {
       }
       sig.push_back('\x1f');
     }
-    auto memo = label_memo_.find(sig);
-    if (memo == label_memo_.end()) {
+    auto memo = label_memo.find(sig);
+    if (memo == label_memo.end()) {
       std::vector<uint64_t> words((size_t)W, 0);
       for (int q : label_reqs_)
         if (req_dict[(size_t)q].eval(ni.node)) words[(size_t)q >> 6] |= 1ull << (q & 63);
-      memo = label_memo_.emplace(std::move(sig), std::move(words)).first;
+      memo = label_memo.emplace(std::move(sig), std::move(words)).first;
     }
     std::copy(memo->second.begin(), memo->second.end(), labels);
     if (ni.node.name.empty()) {  // matchFields are not consulted for a nameless node (DictReq::eval)
@@ -784,7 +791,7 @@ class Encoder {
   std::vector<int> label_reqs_, name_reqs_;  // dictionary indices: requirements on labels / on the node name
   std::vector<int> name_other_;              // name requirements that are not "name == x" (NotIn, other field keys)
   std::unordered_map<std::string, std::vector<int>> name_equals_;  // node name → requirements that hold exactly there
-  mutable std::unordered_map<std::string, std::vector<uint64_t>> label_memo_;  // label-value tuple → requirement words
+  mutable LabelMemo label_memo_;  // label-value tuple → requirement words
   std::vector<const PodTemplate*> existing_anti_templates_;  // distinct templates of on-node pods that carry anti-affinity terms
   std::vector<const PodAffinityTerm*> wild_anti_terms_;  // anti-affinity terms of on-node pods the engine cannot decide
   bool is_wild(const PodAffinityTerm* t) const { return std::find(wild_anti_terms_.begin(), wild_anti_terms_.end(), t) != wild_anti_terms_.end(); }

@@ -333,6 +333,22 @@ int recreate_engine(ykhost* h) {
 void refresh_spec_view(ykhost* h, EncodedTables* T);
 
 // Dictionaries + node rows + spec rows from the current objects (no device involved).
+// Threads for the batch forms and the node loop of a full encode: YKHOST_INGEST_THREADS, else the cores this process may really use — a container with a CPU quota
+// (cgroup v2 cpu.max) still reports every core of its host through hardware_concurrency (the GPU boxes of this pool: 256 visible,
+// 16 granted), and 64 scanning threads on 16 cores only add context switches — at most 64.
+unsigned host_threads() {
+  const char* env = getenv("YKHOST_INGEST_THREADS");  // (read per batch: the tests switch it inside one process)
+  const int want = env ? atoi(env) : 0;
+  if (want > 0) return (unsigned)want;
+  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0;
+    if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+      hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    fclose(f);
+  }
+  return std::min(hw, 64u);
+}
 int encode_tables(ykhost* h, EncodedTables* T) {
   // templates of pending asks, in first-use order → spec ids
   h->spec_templates.clear();
@@ -344,7 +360,9 @@ int encode_tables(ykhost* h, EncodedTables* T) {
       h->spec_templates.push_back(t);
     }
   }
-  if (!h->enc.build_dictionaries(h->nodes, h->spec_templates)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
+  bool any_anti = false;  // (templates are never dropped from the pool: conservative)
+  for (const PodTemplate* t : h->pool.all()) any_anti = any_anti || !t->pod_anti_affinity.empty();
+  if (!h->enc.build_dictionaries(h->nodes, h->spec_templates, any_anti)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
   h->unsupported_asks = 0;
   if (!h->enc.unsupported.empty())
     for (const Pod* p : h->pending) h->unsupported_asks += h->enc.unsupported.count(p->tpl) ? 1 : 0;
@@ -360,23 +378,38 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   T->flags.assign(N, 0);
   T->taints.assign(N * KT, 0);
   T->labels.assign(N * W, 0);
-  std::vector<uint64_t> p1(KP + 1), t1(KT), l1(W);
-  std::vector<int64_t> a1(R), r1(R);
-  std::vector<int32_t> d1(KD + 1), s1(KS + 1);
-  for (size_t n = 0; n < N; ++n) {
-    h->nodes[n]->index = (int32_t)n;
-    h->enc.encode_node(*h->nodes[n], a1.data(), r1.data(), &T->allowed[n], &T->count[n], &T->flags[n], t1.data(), l1.data());
-    h->enc.encode_node_spread(*h->nodes[n], d1.data(), s1.data());
-    for (int k = 0; k < KD; ++k) T->domain[(size_t)k * N + n] = d1[(size_t)k];
-    for (int k = 0; k < KS; ++k) T->selcount[(size_t)k * N + n] = s1[(size_t)k];
-    h->enc.encode_ports(h->nodes[n]->pods, p1.data());
-    for (int k = 0; k < KP; ++k) T->ports[(size_t)k * N + n] = p1[(size_t)k];
-    for (int r = 0; r < R; ++r) {
-      T->alloc[(size_t)r * N + n] = a1[(size_t)r];
-      T->req[(size_t)r * N + n] = r1[(size_t)r];
+  // One row per node. The rows are independent; what is shared is read-only after build_dictionaries except two caches: the
+  // label-tuple memo (every thread gets its own) and the selector-class memo of encode_node_spread (KS > 0: one thread).
+  auto encode_rows = [&](size_t n0, size_t n1, Encoder::LabelMemo* memo) {
+    std::vector<uint64_t> p1(KP + 1), t1(KT), l1(W);
+    std::vector<int64_t> a1(R), r1(R);
+    std::vector<int32_t> d1(KD + 1), s1(KS + 1);
+    for (size_t n = n0; n < n1; ++n) {
+      h->nodes[n]->index = (int32_t)n;
+      h->enc.encode_node(*h->nodes[n], a1.data(), r1.data(), &T->allowed[n], &T->count[n], &T->flags[n], t1.data(), l1.data(), memo);
+      h->enc.encode_node_spread(*h->nodes[n], d1.data(), s1.data());
+      for (int k = 0; k < KD; ++k) T->domain[(size_t)k * N + n] = d1[(size_t)k];
+      for (int k = 0; k < KS; ++k) T->selcount[(size_t)k * N + n] = s1[(size_t)k];
+      h->enc.encode_ports(h->nodes[n]->pods, p1.data());
+      for (int k = 0; k < KP; ++k) T->ports[(size_t)k * N + n] = p1[(size_t)k];
+      for (int r = 0; r < R; ++r) {
+        T->alloc[(size_t)r * N + n] = a1[(size_t)r];
+        T->req[(size_t)r * N + n] = r1[(size_t)r];
+      }
+      for (int k = 0; k < KT; ++k) T->taints[(size_t)k * N + n] = t1[(size_t)k];
+      for (int w = 0; w < W; ++w) T->labels[(size_t)w * N + n] = l1[(size_t)w];
     }
-    for (int k = 0; k < KT; ++k) T->taints[(size_t)k * N + n] = t1[(size_t)k];
-    for (int w = 0; w < W; ++w) T->labels[(size_t)w * N + n] = l1[(size_t)w];
+  };
+  const int threads = (KS == 0 && N >= 4096) ? (int)std::min<size_t>(host_threads(), N / 1024) : 1;
+  if (threads > 1) {
+    std::vector<std::thread> pool;
+    std::vector<Encoder::LabelMemo> memos((size_t)threads);
+    for (int t = 1; t < threads; ++t)
+      pool.emplace_back(encode_rows, N * (size_t)t / (size_t)threads, N * (size_t)(t + 1) / (size_t)threads, &memos[(size_t)t]);
+    encode_rows(0, N / (size_t)threads, &memos[0]);
+    for (auto& th : pool) th.join();
+  } else {
+    encode_rows(0, N, nullptr);
   }
   ykpred_nodes_t& nt = T->nt;
   nt = ykpred_nodes_t{};
@@ -1151,22 +1184,6 @@ int32_t ykhost_update_node(ykhost_t* h, const char* node_json) {
   }
 }
 // Many Node documents in one call (see ykhost_update_pods_batch). → documents applied, or -1 - (documents applied before the bad one).
-// Threads for the batch forms: YKHOST_INGEST_THREADS, else the cores this process may really use — a container with a CPU quota
-// (cgroup v2 cpu.max) still reports every core of its host through hardware_concurrency (the GPU boxes of this pool: 256 visible,
-// 16 granted), and 64 scanning threads on 16 cores only add context switches — at most 64.
-static unsigned ingest_threads() {
-  const char* env = getenv("YKHOST_INGEST_THREADS");  // (read per batch: the tests switch it inside one process)
-  const int want = env ? atoi(env) : 0;
-  if (want > 0) return (unsigned)want;
-  unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    long long quota = 0, period = 0;
-    if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
-      hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
-    fclose(f);
-  }
-  return std::min(hw, 64u);
-}
 int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len) {
   YKHOST_LOCKED(h);
   if (!text || len < 0) return fail(h, "bad argument");
@@ -1181,7 +1198,7 @@ int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len) {
     std::vector<std::string> errors(D);
     std::vector<char> bad(D, 0);
     {
-      const int T = (int)std::max<size_t>(1, std::min<size_t>(ingest_threads(), D / 64));
+      const int T = (int)std::max<size_t>(1, std::min<size_t>(host_threads(), D / 64));
       std::atomic<size_t> next{0};
       auto body = [&]() {
         for (size_t i = next.fetch_add(64); i < D; i = next.fetch_add(64))
@@ -1605,7 +1622,7 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
   *fallback = true;
   // YKHOST_INGEST_THREADS: a container with a CPU quota still reports every core of its host (hardware_concurrency), and
   // scanning threads that share two real cores are slower than one; 1 = the one-thread path
-  const unsigned hw = ingest_threads();
+  const unsigned hw = host_threads();
   const int64_t min_piece = 1 << 16;
   const int T = (int)std::min<int64_t>(hw, len / min_piece);
   if (T < 2) return -1;
