@@ -1497,8 +1497,9 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
   const size_t M = offset[(size_t)T];
   if (M == 0) return false;
   ensure_uid_index(h);
-  std::vector<std::vector<Pod>> block((size_t)T);  // the pods' final storage, one block per piece (published at the end)
-  auto slot_of = [&](int t, int32_t local) { return &block[(size_t)t][(size_t)local]; };
+  std::vector<std::vector<Pod>> block((size_t)T);  // the pods' final storage, one block per piece (published once no uid clashes)
+  std::vector<Pod*> slot_base((size_t)T, nullptr);
+  auto slot_of = [&](int t, int32_t local) { return slot_base[(size_t)t] + local; };
   const int G = std::max(1, std::min<int>(4 * T, (int)h->nodes.size()));  // node groups (contiguous index ranges)
   const size_t N = h->nodes.size();
   auto group_of = [&](int node) { return (int)((size_t)node * (size_t)G / std::max<size_t>(N, 1)); };
@@ -1506,20 +1507,32 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
   std::vector<std::vector<std::vector<int32_t>>> by_group((size_t)T, std::vector<std::vector<int32_t>>((size_t)G));
   std::vector<std::vector<int32_t>> node_of((size_t)T);
   std::vector<size_t> asks_in((size_t)T, 0);
-  auto run = [&](int n, auto&& f) {  // f(0..n-1) on T threads (the caller is one of them)
+  auto run = [&](int n, auto&& f) {  // f(0..n-1) on T threads (the caller is one of them); an exception of a worker is rethrown here
     std::atomic<int> next{0};
+    std::mutex err_mu;
+    std::string err;
+    bool failed = false;
     auto body = [&]() {
-      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+      try {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+      } catch (const std::exception& ex) {
+        std::lock_guard<std::mutex> lock(err_mu);
+        failed = true;
+        err = ex.what();
+        next.store(n);
+      }
     };
     std::vector<std::thread> threads;
     for (int t = 1; t < std::min(T, n); ++t) threads.emplace_back(body);
     body();
     for (auto& th : threads) th.join();
+    if (failed) throw std::runtime_error("bulk cache pass: " + err);
   };
   // P1, by piece: where every pod goes (uid shard, node, node group), how many asks the piece holds
   run(T, [&](int t) {
     const std::vector<ScannedPod>& pods = pieces[(size_t)t].pods;
     block[(size_t)t].resize(pods.size());
+    slot_base[(size_t)t] = block[(size_t)t].data();
     node_of[(size_t)t].resize(pods.size());
     for (auto& v : by_shard[(size_t)t]) v.reserve(pods.size() / UidIndex::kShards + 8);
     size_t asks = 0;
@@ -1559,6 +1572,8 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
     });
     return false;
   }
+  for (auto& b : block)
+    if (!b.empty()) h->pod_blocks.push_back(std::move(b));  // (a moved vector keeps its buffer: the slots stay where they are)
   // the new templates, interned in the order the ordered pass meets them
   std::vector<std::vector<const PodTemplate*>> interned(SharedTemplates::kShards);
   for (int k = 0; k < SharedTemplates::kShards; ++k) interned[(size_t)k].assign(shared->shard[k].tpls.size(), nullptr);
@@ -1609,8 +1624,6 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
     for (int t = 0; t < T; ++t)
       for (int32_t i : by_group[(size_t)t][(size_t)g]) h->nodes[(size_t)node_of[(size_t)t][(size_t)i]]->add_pod(slot_of(t, i));
   });
-  for (auto& b : block)
-    if (!b.empty()) h->pod_blocks.push_back(std::move(b));  // (a moved vector keeps its buffer: the slots stay where they are)
   if (any_on_node.load()) h->resident.valid = false;  // (touch_node: node columns changed under a resident answer)
   *applied_out = (long)M;
   return true;
@@ -1708,10 +1721,16 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
 int32_t ykhost_update_pods_batch(ykhost_t* h, const char* text, int64_t len) {
   YKHOST_LOCKED(h);
   if (!text || len < 0) return fail(h, "bad argument");
-  {
+  try {
     bool fallback = true;
     const long n = update_pods_parallel(h, text, len, &fallback);
     if (!fallback) return (int32_t)n;
+  } catch (const std::exception& e) {
+    // (out of memory in the middle of the bulk pass: the mirror may hold a part of the batch — everything is re-encoded anyway,
+    // and the caller is told)
+    h->dirty_all = true;
+    h->uid_index = false;
+    return fail(h, std::string("pod batch: ") + e.what());
   }
   long applied = 0;
   try {
