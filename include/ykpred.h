@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-/* 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row / ykpred_peek_outputs (the resident
+/* 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row (the resident
  *    answer served to single Predicates() callbacks), ykpred_eval_nodes is collective on a sharded engine with topology signatures
  * 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
  *    gather / exchange entry points (version 1 = the round-1 ABI: rows in ask order, no collectives) */

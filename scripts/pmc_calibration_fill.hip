@@ -1,5 +1,7 @@
-// fill_probe.hip — write-bandwidth probes on MI355X for the bitmap shape of configs[2] (1M rows x 6272 B).
-// Build+run on the GPU box: hipcc --offload-arch=gfx950 -O3 scripts/fill_probe.hip -o /tmp/fill_probe && /tmp/fill_probe
+// pmc_calibration_fill.hip — fills of KNOWN size in the bitmap shape of configs[2] (1M rows x 6272 B): scripts/pmc_passes.sh runs it under
+// `rocprofv3 --pmc WRITE_SIZE` / `FETCH_SIZE` to calibrate the counters (ratio 1.000 on the linear fill) before they price the engine's
+// kernels; it is also the write-ceiling probe of round 1 (linear fills and row-shaped writes at several launch shapes).
+// Build+run on the GPU box: hipcc --offload-arch=gfx950 -O3 scripts/pmc_calibration_fill.hip -o /tmp/fill_probe && /tmp/fill_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -8,7 +8,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p "$OUT"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-hipcc --offload-arch=gfx950 -O3 "$ROOT/scripts/fill_probe.hip" -o /tmp/fill_probe 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 "$ROOT/scripts/pmc_calibration_fill.hip" -o /tmp/fill_probe 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 COMMON="--steps 3 --warmup 1 --cpu-seconds 0 --profile-steps 0 --no-variants --no-ingest --no-verify"
 for C in WRITE_SIZE FETCH_SIZE; do

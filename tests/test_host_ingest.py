@@ -88,6 +88,42 @@ def test_scanner_against_the_full_parser_on_reshaped_documents(cluster_docs, mon
     assert outcomes[0] == outcomes[1]
 
 
+def test_documents_with_a_key_twice_read_like_the_tree_parser(cluster_docs):
+    """a `spec` (or `metadata` / `status`) key that occurs twice is legal JSON and means last-wins to the tree parser.
+    The one-pass scanner used to cut the nodeName member of the FIRST spec out of the text of the LAST one (a negative length:
+    the document was rejected and the batch stopped) and to merge the fields of two metadata objects; such documents now take
+    the full parser, and the mirror equals the one of the de-duplicated document."""
+    docs, _ = cluster_docs
+    lines = docs[1].splitlines()[:40]
+
+    def twice(line, key):
+        d = json.loads(line)
+        first = dict(d[key])
+        if key == "spec":
+            first["nodeName"] = "some-other-node"   # an EARLIER spec with a nodeName member ...
+            last = {k: v for k, v in d[key].items()}  # ... and the last one, the one that counts
+        else:
+            first = dict(first, name="shadowed-name", uid="shadowed-uid")
+            last = d[key]
+        body = json.dumps(d)
+        dup = json.dumps({key: first})[1:-1] + ", " + body[1:]
+        return ("{" + dup).encode()
+
+    for key in ("spec", "metadata"):
+        dup, plain = pkg.GpuPredicateManager(device=-1), pkg.GpuPredicateManager(device=-1)
+        try:
+            for m in (dup, plain):
+                m.update_documents(0, docs[0])
+            text = b"\n".join(twice(l, key) for l in lines)
+            assert json.loads(text.splitlines()[0]) == json.loads(lines[0])  # (python's reader is last-wins as well)
+            assert dup.update_documents(1, text) == len(lines), dup._L.ykhost_last_error(dup._h)
+            assert plain.update_documents(1, b"\n".join(lines)) == len(lines)
+            assert dup.dump_snapshot() == plain.dump_snapshot()
+        finally:
+            dup.close()
+            plain.close()
+
+
 def test_batch_equals_one_call_per_object(cluster_docs):
     docs, n_asks = cluster_docs
     one, batch = pkg.GpuPredicateManager(device=-1), pkg.GpuPredicateManager(device=-1)
@@ -238,6 +274,36 @@ def test_bulk_cache_pass_equals_the_ordered_pass(cluster_docs, monkeypatch):
         four = _load(monkeypatch, "4", batches)
         assert one[:4] == four[:4], name
         assert four[4]["bulk_batches"] == want_bulk and one[4]["bulk_batches"] == 0, (name, four[4])
+
+
+def test_threads_that_cannot_be_created_degrade_to_fewer_threads(cluster_docs, monkeypatch):
+    """ADVICE r4 (medium): std::thread's constructor throws EAGAIN under a pids / thread cgroup limit. Every per-batch spawn goes
+    through run_on_threads (host.cpp): the threads that did start — at worst the caller alone — take the items of the ones that
+    did not, nothing is left joinable, nothing terminates. YKHOST_TEST_THREAD_LIMIT=k makes creation fail after k workers: the
+    pod batches (scan + bulk cache pass), the node batch and the node loop of the full encode give the results of four real
+    threads with zero and with one worker."""
+    docs, _ = cluster_docs
+    batches = [(0, docs[0]), (1, docs[1]), (2, docs[2])]
+    want = _load(monkeypatch, "4", batches)
+    for limit in ("0", "1"):
+        monkeypatch.setenv("YKHOST_TEST_THREAD_LIMIT", limit)
+        got = _load(monkeypatch, "4", batches)
+        assert got[:4] == want[:4], limit
+        assert got[4]["bulk_batches"] == want[4]["bulk_batches"] == 2  # the bulk pass itself ran, on fewer threads
+    tables = []
+    for limit in (None, "0", "2"):
+        if limit is None:
+            monkeypatch.delenv("YKHOST_TEST_THREAD_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("YKHOST_TEST_THREAD_LIMIT", limit)
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", "5")
+        m = pkg.GpuPredicateManager(device=-1)
+        try:
+            m.generate_kwok(seed=31, num_nodes=6000, num_pods=3000, num_templates=150, node_affinity=1, spread=0)
+            tables.append(m.encoded_tables())
+        finally:
+            m.close()
+    assert tables[0] == tables[1] == tables[2]
 
 
 def test_parallel_ingest_under_thread_sanitizer(cluster_docs, tmp_path):

@@ -330,7 +330,7 @@ struct ykpred_engine {
   // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr;
-  // --- the resident answer served to single callbacks (ykpred_peek_row / ykpred_peek_outputs): a copy stream ordered after the
+  // --- the resident answer served to single callbacks (ykpred_peek_row): a copy stream ordered after the
   // last evaluation by an event, pinned staging memory
   hipStream_t peek_stream = nullptr;
   hipEvent_t ev_eval_done = nullptr;

@@ -11,12 +11,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <set>
+#include <sched.h>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -341,13 +344,75 @@ unsigned host_threads() {
   const int want = env ? atoi(env) : 0;
   if (want > 0) return (unsigned)want;
   unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+  // the CPUs this process may run on (cpuset cgroups, taskset): hardware_concurrency does not look at the affinity mask
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) {
+    const int n = CPU_COUNT(&set);
+    if (n > 0) hw = std::min<unsigned>(hw, (unsigned)n);
+  }
+  auto cap_by_quota = [&](long long quota, long long period) {
+    if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+  };
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
     long long quota = 0, period = 0;
-    if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
-      hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    if (fscanf(f, "%lld %lld", &quota, &period) == 2) cap_by_quota(quota, period);
     fclose(f);
+  } else {  // cgroup v1: cpu.cfs_quota_us (-1 = no quota) / cpu.cfs_period_us, under either mount name
+    for (const char* dir : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+      long long quota = 0, period = 0;
+      bool have = false;
+      if (FILE* q = fopen((std::string(dir) + "/cpu.cfs_quota_us").c_str(), "r")) {
+        have = fscanf(q, "%lld", &quota) == 1;
+        fclose(q);
+      }
+      if (!have) continue;
+      if (FILE* pf = fopen((std::string(dir) + "/cpu.cfs_period_us").c_str(), "r")) {
+        if (fscanf(pf, "%lld", &period) == 1) cap_by_quota(quota, period);
+        fclose(pf);
+      }
+      break;
+    }
   }
   return std::min(hw, 64u);
+}
+// f(i) for every i in [0, n), claimed one at a time by at most `threads` threads — the caller is one of them. The design rule of
+// this library is "degrade, never fail scheduling": a thread that cannot be created (std::system_error / EAGAIN under a pids or
+// thread cgroup limit) is simply not there and the threads that did start — at worst the caller alone — take its items; an
+// exception thrown by f on a worker is caught there, stops the hand-out, and is rethrown on the caller once every thread that
+// started has been joined (a joinable std::thread must never be destroyed: std::terminate would take the scheduler down).
+// YKHOST_TEST_THREAD_LIMIT=k (tests): thread creation "fails" after k workers.
+template <class F>
+void run_on_threads(int threads, int n, F&& f) {
+  if (n <= 0) return;
+  std::atomic<int> next{0};
+  std::mutex err_mu;
+  std::exception_ptr err;
+  auto body = [&]() {
+    try {
+      for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(err_mu);
+      if (!err) err = std::current_exception();
+      next.store(n);
+    }
+  };
+  const char* lim = getenv("YKHOST_TEST_THREAD_LIMIT");
+  const int limit = lim ? atoi(lim) : -1;
+  std::vector<std::thread> pool;
+  const int want = std::min(threads, n) - 1;
+  try {
+    pool.reserve((size_t)std::max(want, 0));
+    for (int t = 0; t < want; ++t) {
+      if (limit >= 0 && t >= limit) throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+      pool.emplace_back(body);
+    }
+  } catch (...) {
+    // no more threads: carry on with the ones that exist
+  }
+  body();
+  for (auto& th : pool) th.join();
+  if (err) std::rethrow_exception(err);
 }
 int encode_tables(ykhost* h, EncodedTables* T) {
   // templates of pending asks, in first-use order → spec ids
@@ -401,15 +466,25 @@ int encode_tables(ykhost* h, EncodedTables* T) {
     }
   };
   const int threads = (KS == 0 && N >= 4096) ? (int)std::min<size_t>(host_threads(), N / 1024) : 1;
+  bool rows_done = false;
   if (threads > 1) {
-    std::vector<std::thread> pool;
-    std::vector<Encoder::LabelMemo> memos((size_t)threads);
-    for (int t = 1; t < threads; ++t)
-      pool.emplace_back(encode_rows, N * (size_t)t / (size_t)threads, N * (size_t)(t + 1) / (size_t)threads, &memos[(size_t)t]);
-    encode_rows(0, N / (size_t)threads, &memos[0]);
-    for (auto& th : pool) th.join();
-  } else {
-    encode_rows(0, N, nullptr);
+    // (one node range and one label memo per item; an item runs on exactly one thread, whichever claims it)
+    try {
+      std::vector<Encoder::LabelMemo> memos((size_t)threads);
+      run_on_threads(threads, threads, [&](int t) {
+        encode_rows(N * (size_t)t / (size_t)threads, N * (size_t)(t + 1) / (size_t)threads, &memos[(size_t)t]);
+      });
+      rows_done = true;
+    } catch (const std::exception&) {
+      // a worker ran out of memory: the rows are independent and idempotent — once more on this thread alone
+    }
+  }
+  if (!rows_done) {
+    try {
+      encode_rows(0, N, nullptr);
+    } catch (const std::exception& ex) {
+      return fail(h, std::string("encoder: node rows: ") + ex.what(), YKPRED_E_NOMEM);
+    }
   }
   ykpred_nodes_t& nt = T->nt;
   nt = ykpred_nodes_t{};
@@ -1199,22 +1274,16 @@ int32_t ykhost_update_nodes_batch(ykhost_t* h, const char* text, int64_t len) {
     std::vector<char> bad(D, 0);
     {
       const int T = (int)std::max<size_t>(1, std::min<size_t>(host_threads(), D / 64));
-      std::atomic<size_t> next{0};
-      auto body = [&]() {
-        for (size_t i = next.fetch_add(64); i < D; i = next.fetch_add(64))
-          for (size_t j = i; j < std::min(D, i + 64); ++j) {
-            try {
-              parsed[j] = parse_node_text(docs[j]);
-            } catch (const std::exception& e) {
-              bad[j] = 1;
-              errors[j] = e.what();
-            }
+      run_on_threads(T, (int)((D + 63) / 64), [&](int blk) {
+        for (size_t j = (size_t)blk * 64; j < std::min(D, (size_t)blk * 64 + 64); ++j) {
+          try {
+            parsed[j] = parse_node_text(docs[j]);
+          } catch (const std::exception& e) {
+            bad[j] = 1;
+            errors[j] = e.what();
           }
-      };
-      std::vector<std::thread> threads;
-      for (int t = 1; t < T; ++t) threads.emplace_back(body);
-      body();
-      for (auto& th : threads) th.join();
+        }
+      });
     }
     for (size_t i = 0; i < D; ++i) {
       if (bad[i]) return fail(h, std::string("document #") + std::to_string(applied) + ": " + errors[i], (int)(-1 - applied));
@@ -1508,25 +1577,11 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
   std::vector<std::vector<int32_t>> node_of((size_t)T);
   std::vector<size_t> asks_in((size_t)T, 0);
   auto run = [&](int n, auto&& f) {  // f(0..n-1) on T threads (the caller is one of them); an exception of a worker is rethrown here
-    std::atomic<int> next{0};
-    std::mutex err_mu;
-    std::string err;
-    bool failed = false;
-    auto body = [&]() {
-      try {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
-      } catch (const std::exception& ex) {
-        std::lock_guard<std::mutex> lock(err_mu);
-        failed = true;
-        err = ex.what();
-        next.store(n);
-      }
-    };
-    std::vector<std::thread> threads;
-    for (int t = 1; t < std::min(T, n); ++t) threads.emplace_back(body);
-    body();
-    for (auto& th : threads) th.join();
-    if (failed) throw std::runtime_error("bulk cache pass: " + err);
+    try {
+      run_on_threads(T, n, f);
+    } catch (const std::exception& ex) {
+      throw std::runtime_error(std::string("bulk cache pass: ") + ex.what());
+    }
   };
   // P1, by piece: where every pod goes (uid shard, node, node group), how many asks the piece holds
   run(T, [&](int t) {
@@ -1591,10 +1646,34 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
   h->ingest_full += new_templates;
   h->ingest_fast += (int64_t)M - new_templates;
   // P3, by piece: the pods move into their slots; asks take their rows (document order)
-  std::vector<size_t> ask_base((size_t)T + 1, h->pending.size());
+  const size_t pending_before = h->pending.size();
+  std::vector<size_t> ask_base((size_t)T + 1, pending_before);
   for (int t = 0; t < T; ++t) ask_base[(size_t)t + 1] = ask_base[(size_t)t] + asks_in[(size_t)t];
-  h->pending.resize(ask_base[(size_t)T]);
   std::atomic<bool> any_on_node{false};
+  // From here on the mirror is being changed. If P3 / P4 run out of memory half-way, what they did is made consistent again
+  // before the exception leaves: the ask table keeps no empty row (the rows that were filled close up, in document
+  // order) and every pod that carries a node is on that node's list exactly once. The caller re-encodes everything anyway.
+  auto repair = [&]() {
+    size_t keep = pending_before;
+    for (size_t i = pending_before; i < h->pending.size(); ++i)
+      if (Pod* p = h->pending[i]) {
+        p->row = (int32_t)keep;
+        h->pending[keep++] = p;
+      }
+    h->pending.resize(keep);
+    for (int t = 0; t < T; ++t)
+      for (size_t i = 0; i < offset[(size_t)t + 1] - offset[(size_t)t]; ++i) {
+        const Pod* q = slot_of(t, (int32_t)i);  // (a slot P3 did not reach is an empty Pod: no node)
+        if (q->assigned_node.empty()) continue;
+        auto nt = h->node_ix.find(q->assigned_node);
+        if (nt == h->node_ix.end()) continue;
+        NodeInfo& ni = *h->nodes[(size_t)nt->second];
+        if (std::find(ni.pods.begin(), ni.pods.end(), q) == ni.pods.end()) ni.add_pod(q);
+      }
+    h->resident.valid = false;
+  };
+  try {
+  h->pending.resize(ask_base[(size_t)T]);
   run(T, [&](int t) {
     std::vector<ScannedPod>& pods = pieces[(size_t)t].pods;
     size_t row = ask_base[(size_t)t];
@@ -1624,6 +1703,10 @@ bool update_pods_bulk(ykhost* h, std::vector<ScannedPiece>& pieces, SharedTempla
     for (int t = 0; t < T; ++t)
       for (int32_t i : by_group[(size_t)t][(size_t)g]) h->nodes[(size_t)node_of[(size_t)t][(size_t)i]]->add_pod(slot_of(t, i));
   });
+  } catch (...) {
+    repair();
+    throw;
+  }
   if (any_on_node.load()) h->resident.valid = false;  // (touch_node: node columns changed under a resident answer)
   *applied_out = (long)M;
   return true;
@@ -1650,11 +1733,10 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<ScannedPiece> pieces((size_t)T);
   auto shared = std::make_unique<SharedTemplates>();
-  {
-    std::vector<std::thread> threads;
-    for (int t = 1; t < T; ++t) threads.emplace_back(scan_piece, h, shared.get(), cut[(size_t)t], cut[(size_t)t + 1], &pieces[(size_t)t]);
-    scan_piece(h, shared.get(), cut[0], cut[1], &pieces[0]);
-    for (auto& th : threads) th.join();
+  try {
+    run_on_threads(T, T, [&](int t) { scan_piece(h, shared.get(), cut[(size_t)t], cut[(size_t)t + 1], &pieces[(size_t)t]); });
+  } catch (const std::exception&) {
+    return -1;  // (a piece that threw — bad_alloc — has applied nothing: the one-thread path takes the batch)
   }
   for (const ScannedPiece& pc : pieces)
     if (!pc.ok) return -1;

@@ -198,10 +198,17 @@ inline bool scan_pod(Range doc, PodScan* out) {
     return true;
   };
   // value of a top-level member: an object of one of the three kinds is walked, anything else skipped
+  // A key that occurs twice is legal JSON with last-wins meaning in the tree parser; the one-pass form would merge the fields of
+  // two `metadata` objects and cut a `nodeName` member found in an EARLIER `spec` out of the LAST one: such a
+  // document goes to the full parser, and the nodeName state always belongs to the spec object being walked.
+  int seen[3] = {0, 0, 0};
   auto value = [&](const char* q, int kind) -> const char* {
+    if (kind < 3 && ++seen[kind] > 1) out->needs_full_parse = true;
     if (q < end && *q == '{') {
       if (kind == 0) return members_from(q, end, meta_f);
       if (kind == 1) {
+        node_member = Range{};
+        out->node_name = Range{};
         const char* e = members_from(q, end, spec_f);
         if (e) spec = Range{q, e};
         return e;
@@ -241,7 +248,7 @@ inline bool scan_pod(Range doc, PodScan* out) {
   if (labels.present()) out->key.append(labels.b, labels.size());
   out->key.push_back('\x1f');
   if (spec.present()) {
-    if (node_member.present()) {
+    if (node_member.present() && node_member.b >= spec.b && node_member.e <= spec.e) {
       out->key.append(spec.b, (size_t)(node_member.b - spec.b));
       out->key.append(node_member.e, (size_t)(spec.e - node_member.e));
     } else {

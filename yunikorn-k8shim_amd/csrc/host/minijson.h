@@ -36,8 +36,10 @@ struct Value {
   // nullptr when the key is absent (an explicit null yields a Value of Kind::Null).
   const Value* get(const std::string& key) const {
     if (kind != Kind::Object) return nullptr;
-    for (auto& kv : obj)
-      if (kv.first == key) return kv.second.get();
+    // (a key that occurs twice: the LAST occurrence counts, as in every mainstream reader; the one-pass scanner of jsonscan.h
+    // hands such documents to this parser)
+    for (auto it = obj.rbegin(); it != obj.rend(); ++it)
+      if (it->first == key) return it->second.get();
     return nullptr;
   }
   // Absent or null → nullptr.
