@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-/* 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row (the resident
+/* (additive since 3, no version bump: ykpred_set_spec_effects + ykpred_spec_effects_t — allocation rounds with topology constraints and
+ *    host ports on the device)
+ * 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row (the resident
  *    answer served to single Predicates() callbacks), ykpred_eval_nodes is collective on a sharded engine with topology signatures
  * 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
  *    gather / exchange entry points (version 1 = the round-1 ABI: rows in ask order, no collectives) */
@@ -328,10 +330,33 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
  * round runs on a scratch copy of the node columns; the caller applies the allocations the core accepts through the cache
  * hooks (ykhost_assume_pod → ykpred_update_node) as it does for any AssumePod.
  * Needs a current evaluation WITH decisions of the same plugin lists (YKPRED_E_STATE otherwise). YKPRED_E_UNSUPPORTED — decide ask by
- * ask instead — when something other than node resources couples the asks of the round: active PodTopologySpread /
- * InterPodAffinity signatures, an ask that requests a host port, or a node-sharded engine. */
+ * ask instead — on a node-sharded engine, and when something other than node resources couples the asks of the round (active
+ * PodTopologySpread / InterPodAffinity signatures, an ask that requests a host port) while the specs' effects
+ * (ykpred_set_spec_effects, below) are not uploaded for the current spec table. */
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t n_asks,
                               const int32_t* asks /* host, [n_asks] ask indices in decision order */, int32_t* out_nodes /* host, [n_asks] */);
+/* What NodeInfo.AddPod (behind SchedulerCache.AssumePod, /root/reference/pkg/cache/external/scheduler_cache.go:443-461) adds to a
+ * node BESIDES the pod's request vector and len(Pods) += 1, per pod spec — the part of the upstream NodeInfo the Filters of
+ * predicate_manager.go:339-352 read again for the NEXT ask: UsedPorts (NodePorts), and the pod itself in Pods / PodsWithAffinity /
+ * PodsWithRequiredAntiAffinity, which this ABI encodes as the per-node match counts selector_count[KS][N] (PodTopologySpread's
+ * countPodsMatchSelector, InterPodAffinity's topologyToMatchedTermCount). A pod's contribution to a count column is a function of
+ * (column, pod template) alone, so the host states it once per spec:
+ *   contrib_*      spec s adds contrib_count[k] to column contrib_class[k] of the node it lands on, k in [contrib_off[s], contrib_off[s+1])
+ *   occupied_ports [count][KP] bit k: once a pod of the spec is on a node, the node's port_bits gain bit k (HostPortInfo.CheckConflict of
+ *                  the pod's host ports against dictionary port k)
+ * With the effects of the CURRENT spec table uploaded (ykpred_set_specs drops them), ykpred_allocate_round keeps the topology
+ * histograms and the port words of its scratch state current ask by ask on the device, and active PodTopologySpread /
+ * InterPodAffinity signatures or host-port asks no longer make it return YKPRED_E_UNSUPPORTED. The shards' dictionaries must
+ * list the selector classes of every template that can be ASSUMED during a round, not only of the pods already on nodes (the
+ * host encoder does: encoder.h, existing_anti_templates_). */
+typedef struct ykpred_spec_effects {
+  int32_t count;                  /* == the uploaded spec table's count */
+  const int32_t* contrib_off;     /* [count+1]; NULL = no spec adds to any count column */
+  const int32_t* contrib_class;   /* [contrib_off[count]] column of selector_count, 0 <= class < KS */
+  const int32_t* contrib_count;   /* [contrib_off[count]] > 0 */
+  const uint64_t* occupied_ports; /* [count][KP]; NULL = no spec occupies a dictionary host port (or KP == 0) */
+} ykpred_spec_effects_t;
+int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t* fx /* NULL: drop the uploaded effects */);
 
 /* Debugging aid (no reference counterpart). With YKPRED_GUARD_PAGES=1 (2) in the environment every device block of the engine
  * ends (starts) on the last (first) byte of its mapping with an unmapped granule behind (in front of) it. The self-test proves the

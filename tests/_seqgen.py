@@ -16,7 +16,7 @@ def perf_shape(n_nodes, n_pods, apps=5):
     return {"nodes": nodes, "pods": pods}
 
 
-def competing(seed, n_nodes=40, n_pods=120, taints=True, selectors=True, pins=True, scalars=False, spread=False, ports=False):
+def competing(seed, n_nodes=40, n_pods=120, taints=True, selectors=True, pins=True, scalars=False, spread=False, ports=False, ipa=False):
     """Small nodes, asks from a handful of templates that mostly fit somewhere: resources and pod slots run out during the round."""
     rng = random.Random(seed)
     zones = ["a", "b", "c"]
@@ -48,6 +48,18 @@ def competing(seed, n_nodes=40, n_pods=120, taints=True, selectors=True, pins=Tr
                                                   "labelSelector": {"matchLabels": {"app": f"t{t}"}}}]
         if ports and rng.random() < 0.5:
             spec["containers"][0]["ports"] = [{"hostPort": rng.choice([80, 443, 8080]), "containerPort": 80}]
+        if ipa and rng.random() < 0.7:
+            # required inter-pod (anti)affinity between the asks themselves and towards the pods already running ("w" / "v"): an ask
+            # assumed earlier in the round is an EXISTING pod for every ask behind it, in both directions of the anti-affinity rule
+            who = lambda: rng.choice([f"t{t}", f"t{rng.randrange(0, t + 1)}", "w", "v"])
+            term = lambda: {"labelSelector": {"matchLabels": {"app": who()}}, "topologyKey": rng.choice(["kubernetes.io/hostname", "zone"])}
+            aff = {}
+            if rng.random() < 0.7:
+                aff["podAntiAffinity"] = {"requiredDuringSchedulingIgnoredDuringExecution": [term() for _ in range(rng.choice([1, 1, 2]))]}
+            if rng.random() < 0.4:
+                aff["podAffinity"] = {"requiredDuringSchedulingIgnoredDuringExecution": [term()]}
+            if aff:
+                spec["affinity"] = aff
         templates.append((f"t{t}", spec))
     pods = []
     for k in range(n_pods):

@@ -68,10 +68,62 @@ def test_allocation_round_in_a_given_order(pm, seed):
     round_against_oracle(pm, snap, asks=order)
 
 
-@pytest.mark.parametrize("seed,kind", [(0, "spread"), (1, "spread"), (2, "ports"), (3, "ports")])
-def test_allocation_round_goes_ask_by_ask_where_more_than_resources_couples_the_asks(pm, seed, kind):
-    snap = _seqgen.competing(200 + seed, n_nodes=20, n_pods=40, spread=kind == "spread", ports=kind == "ports")
+KINDS = {"spread": dict(spread=True), "ports": dict(ports=True), "ipa": dict(ipa=True), "all": dict(spread=True, ports=True, ipa=True)}
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("kind", sorted(KINDS))
+def test_allocation_round_on_the_device_with_topology_constraints_and_host_ports(pm, seed, kind):
+    """More than node resources couples the asks of these rounds: an assumed pod moves the PodTopologySpread / InterPodAffinity
+    match counts of its topology domains (for every later ask whose selector it matches, in both directions of an anti-affinity
+    rule) and occupies host ports on its node. The device round keeps that state live (ykpred_set_spec_effects) — every decision
+    equals the oracle's sequential loop, and nothing is decided ask by ask on the host."""
+    snap = _seqgen.competing(200 + 10 * seed + len(kind), n_nodes=24 + 3 * seed, n_pods=90, **KINDS[kind])
+    got = round_against_oracle(pm, snap, expect_device=True)
+    assert (got >= 0).sum() > 5
+
+
+@pytest.mark.parametrize("seed,kind", [(0, "spread"), (1, "ports"), (2, "all")])
+def test_allocation_round_goes_ask_by_ask_without_the_specs_effects(pm, seed, kind, monkeypatch):
+    """The path node-sharded engines (and hosts that do not upload the specs' effects) still take: AssumePod + column patch per
+    ask through the resident answer — same decisions. YKHOST_ROUND_ON_HOST withholds the effects."""
+    monkeypatch.setenv("YKHOST_ROUND_ON_HOST", "1")
+    snap = _seqgen.competing(200 + seed, n_nodes=20, n_pods=40, **KINDS[kind])
     round_against_oracle(pm, snap, expect_device=False)
+
+
+def test_allocation_round_many_spread_constraints_move_their_minimum_at_once(pm):
+    """Twenty templates spread over three zones by the SAME selector with twenty different maxSkew values: twenty constraints
+    count the same pods, so their minima rise in the same ask — more at once than the workgroup's shared list holds (kRoundDirty),
+    the rest are recomputed by their owner threads. Hostname-keyed anti-affinity on top (one domain per node)."""
+    nodes = [{"metadata": {"name": f"n{i:03d}", "labels": {"zone": "abc"[i % 3], "kubernetes.io/hostname": f"n{i:03d}"}}, "spec": {},
+              "status": {"allocatable": {"cpu": "8", "memory": "16Gi", "pods": "6"}}, "pods": []} for i in range(30)]
+    pods = []
+    for k in range(150):
+        t = k % 20
+        spec = {"containers": [{"name": "c", "resources": {"requests": {"cpu": "250m", "memory": "256Mi"}}}],
+                "topologySpreadConstraints": [{"maxSkew": 1 + t, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule",
+                                               "labelSelector": {"matchLabels": {"app": "shared"}}}]}
+        if t % 5 == 0:
+            spec["affinity"] = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+                {"labelSelector": {"matchLabels": {"tier": f"x{t}"}}, "topologyKey": "kubernetes.io/hostname"}]}}
+        pods.append({"metadata": {"name": f"ask-{k}", "uid": f"ask-{k}", "namespace": "default", "labels": {"app": "shared", "tier": f"x{t}"}}, "spec": spec})
+    got = round_against_oracle(pm, {"nodes": nodes, "pods": pods}, expect_device=True)
+    assert (got >= 0).sum() > 60
+
+
+def test_allocation_round_kwok_cluster_with_hard_spread_constraints(pm):
+    """The configs[4] ask mix at test size: KWOK-style nodes in 16 zones, 6 000 asks of 60 templates, a tenth of the templates with
+    a hard zone spread constraint — on the device, against the oracle's sequential loop."""
+    pm.generate_kwok(seed=0x59554E49 + 11, num_nodes=400, num_pods=6000, num_templates=60, node_affinity=1, spread=1)
+    before = pm.round_stats()
+    o = orc.Oracle(pm.dump_snapshot())
+    want = o.allocate_sequential()
+    got = pm.allocate_round()
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+    st = pm.round_stats()
+    assert st["rounds_on_device"] == before["rounds_on_device"] + 1 and st["asks_one_by_one"] == before["asks_one_by_one"]
+    assert (got >= 0).sum() > 1000 and pm.layout().num_classes > 60
 
 
 def test_allocation_round_kwok_cluster(pm):

@@ -294,3 +294,46 @@ def test_pending_pod_in_the_middle_of_a_resize(mirror):
     for p, pod in enumerate(snap["pods"]):
         got = [soa.eval_pair(t, p, n, orc.ALL, orc.ALL)[0] for n in range(3)]
         assert got == want[pod["metadata"]["name"]] == grid[p].tolist(), pod["metadata"]["name"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_spec_effects_are_what_an_assumed_pod_adds_to_its_node(mirror, seed):
+    """ykpred_spec_effects_t (what the device round adds to a node for an assumed ask, besides resources): for asks of every
+    template, AssumePod through the cache hook and re-encode — the node's selector_count column must have grown by exactly the
+    spec's contributions and its port_bits by the spec's occupied ports, no other node's moved, and the dictionaries (count
+    classes, topology keys, ports) are the same before and after: pending templates with required anti-affinity terms have
+    their symmetric count classes from the start, so a round never stops for a dictionary rebuild."""
+    import _seqgen
+    import random
+    snap = _seqgen.competing(400 + seed, n_nodes=12, n_pods=60, spread=True, ports=seed % 2 == 0, ipa=True, pins=False)
+    mirror.load_snapshot(snap)
+    t0 = mirror.encoded_tables()
+    assert t0["KS"] > 0
+    rng = random.Random(seed)
+    names = [n["metadata"]["name"] for n in snap["nodes"]]
+    seen_specs, moved = set(), 0
+    for p in range(t0["P"]):
+        spec = t0["pod_spec"][p]
+        if spec in seen_specs or t0["pod_spec"].index(spec) == p:
+            continue  # (not the first user of its template: the template keeps its place in first-use order once this ask is gone)
+        seen_specs.add(spec)
+        node = rng.randrange(len(names))
+        uid = snap["pods"][p]["metadata"]["uid"]
+        mirror.assume_pod(uid, names[node])
+        t1 = mirror.encoded_tables()
+        for k in ("KS", "KD", "KP", "N", "S", "domain_id"):
+            assert t1[k] == t0[k], k
+        N, KS, KP = t0["N"], t0["KS"], t0["KP"]
+        adds = {t0["effect_class"][k]: t0["effect_count"][k] for k in range(t0["effect_off"][spec], t0["effect_off"][spec + 1])}
+        for s_ in range(KS):
+            for n in range(N):
+                want = t0["selector_count"][s_ * N + n] + (adds.get(s_, 0) if n == node else 0)
+                assert t1["selector_count"][s_ * N + n] == want, (p, s_, n)
+        for k in range(KP):
+            for n in range(N):
+                want = t0["port_bits"][k * N + n] | (t0["occupied_ports"][spec * KP + k] if n == node else 0)
+                assert t1["port_bits"][k * N + n] == want, (p, k, n)
+        moved += bool(adds) or any(t0["occupied_ports"][spec * KP + k] for k in range(KP))
+        mirror.load_snapshot(snap)
+        assert mirror.encoded_tables() == t0
+    assert moved > 0

@@ -23,7 +23,8 @@ def one_at_a_time(snap):
     return np.array(out, dtype=np.int32), snap
 
 
-@pytest.mark.parametrize("seed,kw", [(0, {}), (1, {"scalars": True}), (2, {"spread": True}), (3, {"ports": True}), (4, {"spread": True, "ports": True})])
+@pytest.mark.parametrize("seed,kw", [(0, {}), (1, {"scalars": True}), (2, {"spread": True}), (3, {"ports": True}), (4, {"spread": True, "ports": True}),
+                                     (5, {"ipa": True}), (6, {"ipa": True}), (7, {"spread": True, "ports": True, "ipa": True})])
 def test_sequential_loop_equals_one_ask_at_a_time(seed, kw):
     snap = _seqgen.competing(seed, n_nodes=15, n_pods=40, **kw)
     o = orc.Oracle(snap)

@@ -101,6 +101,7 @@ def load_ykpred():
     L.ykpred_check_class_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ykpred_guard_selftest.argtypes = [C.c_void_p, C.c_int32]
     L.ykpred_allocate_round.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.ykpred_set_spec_effects.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_comm_use_library.argtypes = [C.c_char_p]
     L.ykpred_comm_unique_id.argtypes = [C.c_void_p]
     L.ykpred_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]

@@ -310,6 +310,10 @@ struct ykpred_engine {
   unsigned ranked_pre = 0, ranked_filt = 0;
   bool ranked_has_first = false;
   DevBuf d_round;           // scratch of ykpred_allocate_round
+  // what an assumed pod of a spec adds to its node besides resources (ykpred_set_spec_effects): valid for specs_version == fx_version
+  DevBuf d_fx_off, d_fx_cls, d_fx_cnt, d_fx_occ, d_sp_sig_of;
+  uint64_t fx_version = 0;
+  bool fx_contrib = false, fx_ports = false;  // some spec adds to a count column / occupies a dictionary host port
   DevBuf d_patches, d_rows, d_row_count, d_row_best;
   unsigned last_pre = 0, last_filt = 0;  // plugin lists of the last full evaluation (ykpred_eval_nodes must match them)
   bool last_eval_valid = false;
@@ -2526,6 +2530,43 @@ int32_t ykpred_eval_pods(ykpred_engine_t* e, const ykpred_eval_args_t* a, int32_
 }
 
 // Conflict-resolved decisions for a sequence of asks. See ykpred.h.
+int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t* fx) {
+  YK_SERIALISE(e);
+  if (!e) return fail(e, YKPRED_E_INVALID, "set_spec_effects: bad argument");
+  if (!fx) {  // drop them: rounds with topology constraints / host-port asks answer YKPRED_E_UNSUPPORTED again
+    e->fx_version = 0;
+    return YKPRED_OK;
+  }
+  if (!e->specs_set || fx->count != e->S) return fail(e, YKPRED_E_STATE, "set_spec_effects: the effects must describe the uploaded spec table (same count)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t st = e->own_stream;
+  const size_t S = (size_t)e->S;
+  e->fx_version = 0;
+  e->fx_contrib = false;
+  e->fx_ports = false;
+  if (fx->contrib_off) {
+    const int total = fx->contrib_off[S];
+    if (fx->contrib_off[0] != 0 || total < 0 || (total > 0 && (!fx->contrib_class || !fx->contrib_count)))
+      return fail(e, YKPRED_E_INVALID, "set_spec_effects: malformed contribution rows");
+    for (size_t i = 0; i < S; ++i)
+      if (fx->contrib_off[i + 1] < fx->contrib_off[i]) return fail(e, YKPRED_E_INVALID, "set_spec_effects: contrib_off must not decrease");
+    for (int k = 0; k < total; ++k)
+      if (fx->contrib_class[k] < 0 || fx->contrib_class[k] >= e->KS || fx->contrib_count[k] <= 0)
+        return fail(e, YKPRED_E_INVALID, "set_spec_effects: contribution outside the selector classes of the node table, or not positive");
+    TRY(upload(e, e->d_fx_off, fx->contrib_off, S + 1, st));
+    TRY(upload(e, e->d_fx_cls, fx->contrib_class, (size_t)std::max(total, 1), st));
+    TRY(upload(e, e->d_fx_cnt, fx->contrib_count, (size_t)std::max(total, 1), st));
+    e->fx_contrib = total > 0;
+  }
+  if (fx->occupied_ports && e->KP > 0) {
+    TRY(upload(e, e->d_fx_occ, fx->occupied_ports, S * (size_t)e->KP, st));
+    for (size_t i = 0; i < S * (size_t)e->KP && !e->fx_ports; ++i) e->fx_ports = fx->occupied_ports[i] != 0;
+  }
+  HIPCHK(hipStreamSynchronize(st));  // (the caller's arrays are not retained)
+  e->fx_version = e->specs_version;
+  return YKPRED_OK;
+}
+
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, int32_t n_asks, const int32_t* asks, int32_t* out_nodes) {
   YK_SERIALISE(e);
   Range roctx_range("ykpred:allocate_round");
@@ -2535,39 +2576,51 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     return fail(e, YKPRED_E_STATE, "allocate_round: no current evaluation WITH decisions of these plugin lists (run ykpred_eval with YKPRED_OUT_DECISIONS)");
   if (e->comm && e->comm_world > 1)
     return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: node-sharded engines decide ask by ask (the winner of every ask is a cross-shard exchange)");
-  if ((pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0)
-    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints are active (an assumed pod's labels move the histograms of later asks): decide ask by ask");
+  const bool fx_current = e->fx_version == e->specs_version;
+  const bool topo_on = (pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0;
+  if (topo_on && !fx_current)
+    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints are active (an assumed pod's labels move the histograms of later asks) and the "
+                                         "specs' effects are not uploaded (ykpred_set_spec_effects): decide ask by ask");
   const bool ports_on = (pre & filt & YKPRED_PLUGIN_NODE_PORTS) && e->KP > 0;
+  bool port_asks = false;  // some ask of the round requests a host port: the round keeps the nodes' port words live
   for (int i = 0; i < n_asks; ++i) {
     if (asks[i] < 0 || asks[i] >= e->P) return fail(e, YKPRED_E_INVALID, "allocate_round: ask index out of range");
     if ((size_t)asks[i] < e->h_row_stale.size() && e->h_row_stale[(size_t)asks[i]])
       return fail(e, YKPRED_E_STATE, "allocate_round: an ask of the round was patched and not re-evaluated yet");
-    if (ports_on) {
+    if (ports_on && !port_asks) {
       const size_t sp = (size_t)e->h_pod_spec[(size_t)asks[i]];
-      for (int k = 0; k < e->KP; ++k)
-        if (e->h_wanted[sp * (size_t)e->KP + (size_t)k])
-          return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: an ask of the round requests a host port (an assumed pod's ports change later answers): decide ask by ask");
+      for (int k = 0; k < e->KP; ++k) port_asks = port_asks || e->h_wanted[sp * (size_t)e->KP + (size_t)k] != 0;
     }
   }
+  if (port_asks && !fx_current)
+    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: an ask of the round requests a host port (an assumed pod's ports change later answers) and the specs' "
+                                         "effects are not uploaded (ykpred_set_spec_effects): decide ask by ask");
   if (n_asks == 0) return YKPRED_OK;
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   if (e->ev_eval_done) HIPCHK(hipStreamWaitEvent(st, e->ev_eval_done, 0));
+  if (topo_on) TRY(ensure_histograms(e, st));  // (current after the evaluation this round builds on; a no-op then)
+  const bool live_ports = port_asks || (ports_on && e->fx_ports && fx_current);
   const size_t N = (size_t)std::max(e->N, 1), R = (size_t)e->R, C = (size_t)std::max(e->C, 1), RW = (size_t)std::max(e->row_words, 1);
-  // scratch layout, 8-byte pieces first: Requested copy | moved keys | moved bits | pod counts | cursors | moved list | asks | out | n_moved
+  const size_t G = topo_on ? (size_t)std::max(e->spread_constraints, 1) : 0, cells = topo_on ? (size_t)std::max<int64_t>(e->spread_cells, 1) : 0;
+  // scratch layout, 8-byte pieces first: Requested copy | moved keys | moved bits | port words | pod counts | cursors | moved list | asks | out |
+  // n_moved | histogram copy | minimum copy | raw minima | domains at the minimum | present domains
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t at = off;
     off += (bytes + 7) / 8 * 8;
     return at;
   };
-  const size_t o_req = take(R * N * sizeof(i64)), o_key = take(N * sizeof(u64)), o_bits = take(RW * sizeof(u64)), o_cnt = take(N * sizeof(int)),
-               o_cur = take(C * sizeof(int)), o_list = take(N * sizeof(int)), o_asks = take((size_t)n_asks * sizeof(int)),
-               o_out = take((size_t)n_asks * sizeof(int)), o_nm = take(sizeof(int));
+  const size_t o_req = take(R * N * sizeof(i64)), o_key = take(N * sizeof(u64)), o_bits = take(RW * sizeof(u64)),
+               o_ports = take(live_ports ? (size_t)e->KP * N * sizeof(u64) : 0), o_cnt = take(N * sizeof(int)), o_cur = take(C * sizeof(int)),
+               o_list = take(N * sizeof(int)), o_asks = take((size_t)n_asks * sizeof(int)), o_out = take((size_t)n_asks * sizeof(int)),
+               o_nm = take(sizeof(int)), o_hist = take(cells * sizeof(int)), o_minv = take(G * sizeof(int)), o_mn = take(G * sizeof(int)),
+               o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int));
   HIPCHK(e->d_round.ensure(off));
   char* base = (char*)e->d_round.p;
   HIPCHK(hipMemcpyAsync(base + o_req, e->d_req.p, R * (size_t)e->N * sizeof(i64), hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(base + o_cnt, e->d_count.p, (size_t)e->N * sizeof(int), hipMemcpyDeviceToDevice, st));
+  if (live_ports) HIPCHK(hipMemcpyAsync(base + o_ports, e->d_ports.p, (size_t)e->KP * (size_t)e->N * sizeof(u64), hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemsetAsync(base + o_bits, 0, RW * sizeof(u64), st));
   HIPCHK(hipMemsetAsync(base + o_cur, 0xff, C * sizeof(int), st));
   HIPCHK(hipMemsetAsync(base + o_nm, 0, sizeof(int), st));
@@ -2575,6 +2628,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   ykk::NodeTable nt = node_table(e);
   nt.req = (const i64*)(base + o_req);
   nt.count = (const int*)(base + o_cnt);
+  if (live_ports) nt.ports = (const u64*)(base + o_ports);
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   const bool spread_err = ((filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) && !(pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) ||
@@ -2595,21 +2649,53 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   ra.all_fail = spread_err ? 1 : 0;
   ra.req = (i64*)(base + o_req);
   ra.count = (int*)(base + o_cnt);
+  ra.ports = live_ports ? (u64*)(base + o_ports) : nullptr;
   ra.moved_bits = (u64*)(base + o_bits);
   ra.cursor = (int*)(base + o_cur);
   ra.moved_list = (int*)(base + o_list);
   ra.moved_key = (u64*)(base + o_key);
   ra.n_moved = (int*)(base + o_nm);
   ra.out = (int*)(base + o_out);
+  if (fx_current) {
+    ra.fx.off = e->fx_contrib ? e->d_fx_off.as<int>() : nullptr;
+    ra.fx.cls = e->d_fx_cls.as<int>();
+    ra.fx.cnt = e->d_fx_cnt.as<int>();
+    ra.fx.occupied = (live_ports && e->fx_ports) ? e->d_fx_occ.as<u64>() : nullptr;
+  }
+  ykk::SpecTable stbl = spec_table(e);
+  if (topo_on) {
+    // the round's own copy of the PreFilter state of the topology plugins (the engine's stays what the evaluation left) + what keeps
+    // a spread constraint's minimum current; constraint → signature for the eligibility test of the node an ask lands on
+    HIPCHK(hipMemcpyAsync(base + o_hist, e->d_sp_cnt.p, (size_t)e->spread_cells * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(base + o_minv, e->d_sp_min.p, (size_t)e->spread_constraints * sizeof(int), hipMemcpyDeviceToDevice, st));
+    stbl.spread.cnt = (int*)(base + o_hist);
+    stbl.spread.minv = (int*)(base + o_minv);
+    std::vector<int32_t> sig_of;
+    for (size_t d = 0; d < e->spread_sig.size(); ++d) sig_of.insert(sig_of.end(), e->spread_sig[d].size(), (int32_t)d);
+    sig_of.resize(G, 0);
+    TRY(upload(e, e->d_sp_sig_of, sig_of.data(), sig_of.size(), st));
+    HIPCHK(hipStreamSynchronize(st));  // (sig_of is a local)
+    ra.topo_on = 1;
+    ra.G = e->spread_constraints;
+    ra.sig_aff = ykk::AffSigs{e->d_sig_aff_flags.as<unsigned>(), e->d_sig_aff_off.as<int>(), e->d_sig_aff_terms.as<u64>(), e->d_sig_pre_off.as<int>(),
+                              e->d_sig_pre_terms.as<u64>()};
+    ra.sig_tol = e->d_sig_tol.as<u64>();
+    ra.sig_of = e->d_sp_sig_of.as<int>();
+    ra.mn = (int*)(base + o_mn);
+    ra.at_min = (int*)(base + o_at);
+    ra.nd = (int*)(base + o_nd);
+    if (e->spread_constraints > 0)
+      hipLaunchKernelGGL(ykk::k_round_topo_init, dim3((unsigned)e->spread_constraints), dim3(ykk::kWave), 0, st, stbl.spread, e->spread_constraints,
+                         (int*)(base + o_mn), (int*)(base + o_at), (int*)(base + o_nd));
+  }
   const ykk::Planes pr = ranked_planes_of(e, pre, filt, false, e->ranked_has_first);
-  const ykk::SpecTable stbl = spec_table(e);
-  // one launch per 32 768 asks: the loop is a single wave, and a bounded launch keeps the queue responsive (the state of the
+  // one launch per 32 768 asks: the loop is a single workgroup, and a bounded launch keeps the queue responsive (the state of the
   // round — scratch tables, moved list — lives in memory between the launches)
   const int per_launch = 32768;
   for (int first = 0; first < n_asks; first += per_launch) {
     ra.first = first;
     ra.n_asks = std::min(per_launch, n_asks - first);
-    hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kWave), 0, st, nt, stbl, ct, pr, ra);
+    hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, nt, stbl, ct, pr, ra);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_nodes, base + o_out, (size_t)n_asks * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -75,6 +75,22 @@ struct NodeTable {
   const u64* ports;    // [KP][n] bit k: a pod on the node conflicts with dictionary host port k
 };
 
+// State that a running kernel changes and re-reads (ykpred_allocate_round: the scratch copies of Requested / pod counts / topology
+// histograms / host-port words): agent-scope atomics, i.e. loads that do not hit a stale L1 line.
+template <class T>
+__device__ __forceinline__ T ld_live(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_live(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LIVE, class T>
+__device__ __forceinline__ T ld_maybe_live(const T* p) {
+  if constexpr (LIVE) return ld_live(p);
+  else return *p;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // bin-pack score + rank
 // ---------------------------------------------------------------------------------------------------
@@ -760,43 +776,58 @@ struct SpreadSigs {
   int* minv;            // [G] global minimum after the minDomains rule                           (criticalPaths / minMatchNum)
 };
 
+// Is node n one of the nodes whose pods COUNT for the PodTopologySpread constraints of signature d? It must carry ALL topology
+// keys of the signature's spread constraints (nodeLabelsMatchSpreadConstraints) and pass the inclusion policies a constraint asks
+// for (matchNodeInclusionPolicies: nodeAffinityPolicy / nodeTaintsPolicy == Honor). Node properties only — pods do not move it.
+struct SpreadElig {
+  bool keys, aff_ok, tol_ok;
+};
+__device__ __forceinline__ SpreadElig spread_eligibility(const NodeTable& t, const SpreadSigs& sp, const AffSigs& aff, const u64* __restrict__ sig_tol,
+                                                         int d, int n) {
+  const int c0 = sp.c_off[d], c1 = sp.c_off[d + 1];
+  SpreadElig el{true, true, true};
+  bool need_aff = false, need_tol = false;
+  for (int g = c0; g < c1; ++g) {
+    if (sp.c[g].kind != kKindSpread) continue;
+    if (t.domain[(size_t)sp.c[g].kd * t.n + n] < 0) el.keys = false;  // nodeLabelsMatchSpreadConstraints
+    need_aff |= (sp.c[g].flags & kSpreadHonorAffinity) != 0;
+    need_tol |= (sp.c[g].flags & kSpreadHonorTaints) != 0;
+  }
+  if (el.keys && need_aff) {
+    u64 lb[kMaxW];
+#pragma unroll
+    for (int w = 0; w < kMaxW; ++w) lb[w] = w < t.W ? t.labels[(size_t)w * t.n + n] : 0;
+    const int a = sp.aff_sig[d];
+    el.aff_ok = dnf_match(aff.terms, aff.term_off[a], aff.term_off[a + 1], lb, t.W, t.labels + (size_t)kMaxW * t.n + n, (size_t)t.n);
+  }
+  if (el.keys && need_tol) {
+    const u64* tol = sig_tol + (size_t)sp.tol_sig[d] * t.KT;
+    for (int k = 0; k < t.KT; ++k) el.tol_ok = el.tol_ok && (t.taints[(size_t)k * t.n + n] & ~tol[k]) == 0;
+  }
+  return el;
+}
+// does a pod on node n (domain `dom` of the constraint's key, already known to be a valid id) count for constraint c?
+__device__ __forceinline__ bool spread_counts_here(const SpreadC& c, const SpreadElig& el) {
+  if (c.kind != kKindSpread) return true;  // InterPodAffinity: the node only needs the constraint's own key (topologyToMatchedTermCount.update)
+  if (!el.keys) return false;
+  if ((c.flags & kSpreadHonorAffinity) && !el.aff_ok) return false;  // matchNodeInclusionPolicies
+  if ((c.flags & kSpreadHonorTaints) && !el.tol_ok) return false;
+  return true;
+}
 // thread = node; blockIdx.x = signature, blockIdx.y = block of 256 nodes. Eligible nodes add their match counts to their
-// domain's cell. PodTopologySpread: the node must carry ALL topology keys of the signature's spread constraints and
-// pass the inclusion policies. InterPodAffinity: the node only needs the constraint's own key (topologyToMatchedTermCount.update).
+// domain's cell.
 __global__ __launch_bounds__(kBlock) void k_spread_count(NodeTable t, SpreadSigs sp, AffSigs aff, const u64* __restrict__ sig_tol) {
   const int n = blockIdx.y * kBlock + threadIdx.x;
   if (n >= t.n) return;
   const int d = blockIdx.x;
   const int c0 = sp.c_off[d], c1 = sp.c_off[d + 1];
-  bool spread_keys = true, need_aff = false, need_tol = false;
-  for (int g = c0; g < c1; ++g) {
-    if (sp.c[g].kind != kKindSpread) continue;
-    if (t.domain[(size_t)sp.c[g].kd * t.n + n] < 0) spread_keys = false;  // nodeLabelsMatchSpreadConstraints
-    need_aff |= (sp.c[g].flags & kSpreadHonorAffinity) != 0;
-    need_tol |= (sp.c[g].flags & kSpreadHonorTaints) != 0;
-  }
-  bool aff_ok = true, tol_ok = true;
-  if (spread_keys && need_aff) {
-    u64 lb[kMaxW];
-#pragma unroll
-    for (int w = 0; w < kMaxW; ++w) lb[w] = w < t.W ? t.labels[(size_t)w * t.n + n] : 0;
-    const int a = sp.aff_sig[d];
-    aff_ok = dnf_match(aff.terms, aff.term_off[a], aff.term_off[a + 1], lb, t.W, t.labels + (size_t)kMaxW * t.n + n, (size_t)t.n);
-  }
-  if (spread_keys && need_tol) {
-    const u64* tol = sig_tol + (size_t)sp.tol_sig[d] * t.KT;
-    for (int k = 0; k < t.KT; ++k) tol_ok = tol_ok && (t.taints[(size_t)k * t.n + n] & ~tol[k]) == 0;
-  }
+  const SpreadElig el = spread_eligibility(t, sp, aff, sig_tol, d, n);
   for (int g = c0; g < c1; ++g) {
     const SpreadC c = sp.c[g];
     const int dom = t.domain[(size_t)c.kd * t.n + n];
     if (dom < 0 || dom >= c.dom_size) continue;
-    if (c.kind == kKindSpread) {
-      if (!spread_keys) continue;
-      if ((c.flags & kSpreadHonorAffinity) && !aff_ok) continue;  // matchNodeInclusionPolicies
-      if ((c.flags & kSpreadHonorTaints) && !tol_ok) continue;
-      sp.present[c.cnt_off + dom] = 1;
-    }
+    if (!spread_counts_here(c, el)) continue;
+    if (c.kind == kKindSpread) sp.present[c.cnt_off + dom] = 1;
     const int v = c.ks >= 0 ? t.selcount[(size_t)c.ks * t.n + n] : 0;
     if (v) atomicAdd(&sp.cnt[c.cnt_off + dom], v);
   }
@@ -864,6 +895,8 @@ __global__ __launch_bounds__(kBlock) void k_mark_dirty_classes(int n_classes, co
 //     matches anywhere and the pod matches its own terms; an anti-affinity / existing-anti-affinity match in the node's
 //     domain fails.
 // Returns 0 = ok, 7 = PodTopologySpread failed, 8 = InterPodAffinity failed.
+// LIVE: the histograms are being changed by the running kernel (ykpred_allocate_round) — read them past the L1.
+template <bool LIVE = false>
 __device__ __forceinline__ int constraints_fail(const SpreadSigs& sp, int d, const int (&dom)[kMaxKD], bool spread_en, bool ipa_en,
                                                 unsigned* missing) {
   bool pods_exist = true, any_affinity = false, self_match = false;
@@ -875,7 +908,7 @@ __device__ __forceinline__ int constraints_fail(const SpreadSigs& sp, int d, con
 #pragma unroll
     for (int k = 0; k < kMaxKD; ++k)
       if (k == c.kd) dm = dom[k];
-    const i64 match = (dm >= 0 && dm < c.dom_size) ? sp.cnt[c.cnt_off + dm] : 0;
+    const i64 match = (dm >= 0 && dm < c.dom_size) ? ld_maybe_live<LIVE>(sp.cnt + c.cnt_off + dm) : 0;
     if (c.kind == kKindSpread) {
       if (!spread_en) continue;
       if (dm < 0) {
@@ -883,12 +916,12 @@ __device__ __forceinline__ int constraints_fail(const SpreadSigs& sp, int d, con
         return 7;
       }
       const i64 m = (dm < c.dom_size && sp.present[c.cnt_off + dm]) ? match : 0;
-      if (m + c.self_match - (i64)sp.minv[g] > (i64)c.max_skew) return 7;
+      if (m + c.self_match - (i64)ld_maybe_live<LIVE>(sp.minv + g) > (i64)c.max_skew) return 7;
     } else if (ipa_en && !ipa_fail) {
       if (c.kind == kKindPodAffinity) {
         any_affinity = true;
         self_match = c.self_match != 0;
-        aff_domains += sp.minv[g];
+        aff_domains += ld_maybe_live<LIVE>(sp.minv + g);
         if (dm < 0) ipa_fail = 8;  // all topology labels must exist on the node
         if (match <= 0) pods_exist = false;
       } else if (dm >= 0 && match > 0) {
@@ -1816,6 +1849,7 @@ __device__ __forceinline__ void load_node(const NodeTable& t, int n, NodeRegs* r
 
 // One Predicates() call: PreFilter pass, then the ordered Filter list with early exit
 // (predicate_manager.go:206-283). Returns fit; *code / *reason describe the first failure.
+template <bool LIVE = false>
 __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin, int node, const NodeRegs& nr, unsigned pre_mask,
                                           unsigned filt_mask, int* code, unsigned* reason) {
   unsigned f = s.flags[spec];
@@ -1909,7 +1943,7 @@ __device__ __forceinline__ bool eval_pair(const SpecTable& s, int spec, int pin,
     const bool spread_en = filt_mask & kPlugSpread, ipa_en = (filt_mask & kPlugInterPod) && (pre_mask & kPlugInterPod);
     if (d >= 0 && (spread_en || ipa_en)) {
       unsigned missing = 0;
-      int f = constraints_fail(s.spread, d, nr.dom, spread_en, ipa_en, &missing);
+      int f = constraints_fail<LIVE>(s.spread, d, nr.dom, spread_en, ipa_en, &missing);
       if (f == 7) {
         *code = 7;
         *reason = missing ? (1u << 3) : 0u;
@@ -2178,30 +2212,34 @@ __global__ __launch_bounds__(kWave) void k_preempt(NodeTable t, SpecTable s, int
 // round, in order: the first node of the bin-pack order — under the state the EARLIER asks of the round left behind — that
 // passes Predicates() (scheduler_callback.go:203-205 → context.go:696-716); then AssumePod (context.go:828-885 →
 // scheduler_cache.go:443-461 → NodeInfo.AddPod): the node's Requested grows by the ask's request vector, len(Pods) by one, its
-// bin-pack score moves, and the next ask sees that.
+// bin-pack score moves, its used host ports and the match counts of the topology plugins grow — and the next ask sees that.
 //
-// One wave runs the loop (the asks are a dependency chain); the work per ask stays small because a snapshot evaluation with
-// decisions is current when the round starts:
+// ONE WORKGROUP of kRoundWaves waves runs the loop (the asks are a dependency chain; the parallelism is inside an ask). The work
+// per ask stays small because a snapshot evaluation with decisions is current when the round starts:
 //   * UNMOVED nodes (no allocation in this round yet) keep their state and their relative order: the first feasible one of a
-//     class is the first set bit of (AND of the class's rank-ordered planes) & ~moved — one lane-parallel scan from a per-class
-//     cursor that only ever advances (bits only leave);
-//   * MOVED nodes (a short list: bin-packing piles the asks onto few nodes, and a node without a free pod slot leaves the
-//     list for good) are evaluated per pair from the LIVE tables (eval_pair: the routine of k_query / k_direct), lane = node,
-//     with their current score key;
+//     class is the first set bit of (AND of the class's rank-ordered planes) & ~moved — thread = 64-node word, the whole row of
+//     a 50 k-node cluster in two steps, from a per-class cursor that only ever advances (bits only leave);
+//   * MOVED nodes (bin-packing piles the asks onto few nodes, and a node without a free pod slot leaves the list for good) are
+//     evaluated per pair from the LIVE tables (eval_pair: the routine of k_query / k_direct), thread = node, with their current
+//     score key — kRoundThreads of them per step;
 //   * the winner is the smaller (score key, NodeID rank) of the two candidates — what a walk over the re-sorted node list
 //     would have found first.
-// Mutable state (Requested / pod counts of the scratch copy, moved bits, the list, cursors) is read and written with
-// agent-scope atomics and a fence per ask: lanes of the wave read what lane 0 wrote through L2, never a stale L1 line.
-// The caller guarantees: no topology signature is active and no ask of the round requests a host port — those couple asks
-// through more than the node's resources (pod labels, port sets) and take the host's ask-by-ask path instead.
-template <class T>
-__device__ __forceinline__ T ld_live(const T* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class T>
-__device__ __forceinline__ void st_live(T* p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// What an assumed pod changes BESIDES the node's resources (SpecEffects, uploaded by the host per spec): the host-port words of
+// the node (NodePorts) and the match counts behind PodTopologySpread / InterPodAffinity. The round keeps the PreFilter state of
+// the topology plugins LIVE: one histogram cell per assumed pod and matching constraint, the running minimum of a spread
+// constraint through a count of the domains that sit at the minimum (a full pass over the constraint's domains only when that
+// count reaches zero). A class with a topology signature cannot use its snapshot plane for those plugins — an assumed pod
+// moves the verdict of every node of its domain, and of every node when the minimum rises — so its unmoved candidates (AND of
+// the OTHER planes) are checked against the live histograms, a wave per 64-node word, lane = node.
+// Mutable state is read with agent-scope atomics (or after the per-ask fence) and written by one thread per item.
+constexpr int kRoundWaves = 8, kRoundThreads = kRoundWaves * kWave;
+constexpr int kRoundDirty = 16;  // spread constraints whose minimum has to be recomputed after one assume (more: the owner thread does it alone)
+struct SpecEffects {       // what NodeInfo.AddPod of a pod of spec s adds to its node besides the request vector (null: none uploaded)
+  const int* off;          // [S+1] rows of cls / cnt
+  const int* cls;          // selector class (column of selector_count)
+  const int* cnt;          // what one pod of the spec adds to that column
+  const u64* occupied;     // [S][KP] dictionary host ports a pod of the spec conflicts with once it is on a node
+};
 struct RoundArgs {
   int first, n_asks;        // this launch decides asks [first, first + n_asks) of the round
   const int* asks;          // [round] ask (pod) indices in decision order
@@ -2216,29 +2254,92 @@ struct RoundArgs {
   int row_words, all_fail;
   i64* req;                 // [R][N] scratch copy of Requested — grows with the round (t.req points here too)
   int* count;               // [N] scratch copy of len(Pods)
+  u64* ports;               // [KP][N] scratch copy of the host-port words (t.ports points here too); null: no ask of the round has host ports
   u64* moved_bits;          // [row_words], rank order
   int* cursor;              // [C] -1 = not started
   int* moved_list;          // [N]
   u64* moved_key;           // [N] current score key of a moved node
   int* n_moved;             // carried between the launches of one round
   int* out;                 // [round] node index, -1 = no node fits
+  // topology plugins (s.spread.cnt / .minv point at the round's scratch copies); topo_on = 0: no signature is active
+  int topo_on, G;           // G = constraints of all signatures
+  AffSigs sig_aff;          // eligibility tables of the signatures (nodeAffinityPolicy / nodeTaintsPolicy == Honor)
+  const u64* sig_tol;
+  const int* sig_of;        // [G] signature of constraint g
+  int* mn;                  // [G] spread: minimum over the present domains (before the minDomains rule)
+  int* at_min;              // [G] spread: present domains whose count equals mn
+  const int* nd;            // [G] spread: present domains
+  SpecEffects fx;
 };
-__device__ __forceinline__ void load_node_live(const NodeTable& t, int n, NodeRegs* r) {
+__device__ __forceinline__ void load_node_live(const NodeTable& t, const RoundArgs& a, int n, NodeRegs* r) {
   load_node(t, n, r);  // immutable columns (the stale-prone ones are overwritten below)
 #pragma unroll
   for (int i = 0; i < kMaxR; ++i)
     if (i < t.R) r->fr[i] = t.alloc[(size_t)i * t.n + n] - ld_live(t.req + (size_t)i * t.n + n);
   r->slots_ok = (i64)ld_live(t.count + n) + 1 <= (i64)t.allowed[n];
+  if (a.ports) {
+#pragma unroll
+    for (int i = 0; i < kMaxKP; ++i)
+      if (i < t.KP) r->pt[i] = ld_live(a.ports + (size_t)i * t.n + n);
+  }
 }
-__global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable s, ClassTable ct, Planes ranked, RoundArgs a) {
-  const int lane = threadIdx.x;
+// one wave per constraint: what the round needs to keep a spread constraint's minimum current (k_spread_min's numbers, unfolded)
+__global__ __launch_bounds__(kWave) void k_round_topo_init(SpreadSigs sp, int n_constraints, int* __restrict__ mn_out, int* __restrict__ at_min_out,
+                                                           int* __restrict__ nd_out) {
+  const int g = blockIdx.x;
+  if (g >= n_constraints) return;
+  const SpreadC c = sp.c[g];
+  int mn = 0x7fffffff, nd = 0;
+  for (int i = threadIdx.x; i < c.dom_size; i += kWave)
+    if (sp.present[c.cnt_off + i]) {
+      mn = min(mn, sp.cnt[c.cnt_off + i]);
+      ++nd;
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, __shfl_xor(mn, off, kWave));
+    nd += __shfl_xor(nd, off, kWave);
+  }
+  int at = 0;
+  for (int i = threadIdx.x; i < c.dom_size; i += kWave) at += (sp.present[c.cnt_off + i] && sp.cnt[c.cnt_off + i] == mn) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) at += __shfl_xor(at, off, kWave);
+  if (threadIdx.x == 0) {
+    mn_out[g] = mn;
+    at_min_out[g] = at;
+    nd_out[g] = nd;
+  }
+}
+__global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, SpecTable s, ClassTable ct, Planes ranked, RoundArgs a) {
+  __shared__ int sh_aw[kRoundWaves], sh_cw[kRoundWaves], sh_bt[kRoundWaves], sh_bn[kRoundWaves];
+  __shared__ u64 sh_ax[kRoundWaves], sh_bk[kRoundWaves];
+  // (flags of one ask; two sets, used alternately: thread 0 re-arms the set of ask i + 1 while ask i runs — nobody touches it then)
+  __shared__ int sh_stop_[2], sh_at_[2], sh_ndirty_[2], sh_dirty[kRoundDirty];
+  __shared__ int sh_rmn[kRoundWaves], sh_rat[kRoundWaves];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   int n_moved = ld_live(a.n_moved);
   const bool name_on = a.filt & kPlugNodeName;
   const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
+  const bool spread_en = a.filt & kPlugSpread, ipa_en = (a.filt & kPlugInterPod) && (a.pre & kPlugInterPod);
+  const SpreadSigs& sp = s.spread;
   int p_l = 0, spec_l = 0, pin_l = -1, cls_l = 0;
   int last_spec = -1, last_win = -1;  // (per launch: the first ask of a launch takes the scans)
+  if (tid == 0) {
+    sh_stop_[0] = 0x7fffffff;
+    sh_ndirty_[0] = 0;
+    sh_at_[0] = -1;
+  }
+  __syncthreads();
   for (int i = 0; i < a.n_asks; ++i) {
-    if ((i & (kWave - 1)) == 0) {  // the headers of the next 64 asks, one load round
+    int& sh_stop = sh_stop_[i & 1];
+    int& sh_at = sh_at_[i & 1];
+    int& sh_ndirty = sh_ndirty_[i & 1];
+    if (tid == 0) {
+      sh_stop_[(i + 1) & 1] = 0x7fffffff;
+      sh_ndirty_[(i + 1) & 1] = 0;
+      sh_at_[(i + 1) & 1] = -1;
+    }
+    if ((i & (kWave - 1)) == 0) {  // the headers of the next 64 asks, one load round per wave
       const int j = i + lane;
       if (j < a.n_asks) {
         p_l = a.asks[a.first + j];
@@ -2249,18 +2350,20 @@ __global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable
     }
     const int spec = __builtin_amdgcn_readlane(spec_l, i & (kWave - 1)), cls = __builtin_amdgcn_readlane(cls_l, i & (kWave - 1));
     const int pin = name_on ? __builtin_amdgcn_readlane(pin_l, i & (kWave - 1)) : -1;
+    const int tsig = (a.topo_on && s.spread_sig) ? s.spread_sig[spec] : -1;  // the spec's topology signature: its verdicts move with every assume
     int win = -1;
     bool again = false;
-    if (!a.all_fail && pin == -1 && spec == last_spec && last_win >= 0) {
+    if (!a.all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
       // The same spec as the ask before, which went to node last_win: that node is AT LEAST as early in the bin-pack order now
       // (an allocation only raises a node's utilisation, i.e. lowers its score; every other node stands where it stood), so it
       // is this ask's node too as long as it still fits — one pair instead of the two scans. Bin-packing sends long runs of a
-      // Deployment's or task group's asks to one node: this is the common case.
+      // Deployment's or task group's asks to one node: this is the common case. (Not for a spec with a topology signature: the
+      // assume moved the verdicts of OTHER nodes — an earlier node may have become feasible.)
       NodeRegs nr;
-      load_node_live(t, last_win, &nr);
+      load_node_live(t, a, last_win, &nr);
       int code;
       unsigned reason;
-      again = eval_pair(s, spec, -1, last_win, nr, a.pre, a.filt, &code, &reason);
+      again = eval_pair<true>(s, spec, -1, last_win, nr, a.pre, a.filt, &code, &reason);
     }
     if (again) {
       win = last_win;
@@ -2268,54 +2371,75 @@ __global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable
       // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
     } else if (pin >= 0) {
       NodeRegs nr;
-      load_node_live(t, pin, &nr);
+      load_node_live(t, a, pin, &nr);
       int code;
       unsigned reason;
-      if (eval_pair(s, spec, pin, pin, nr, a.pre, a.filt, &code, &reason)) win = pin;
+      if (eval_pair<true>(s, spec, pin, pin, nr, a.pre, a.filt, &code, &reason)) win = pin;
     } else {
-      // ---- candidate A: the first unmoved feasible node in snapshot order
-      int an = -1, at = 0;
-      u64 ak = 0;
+      // ---- candidate A: the first unmoved feasible node in snapshot order. aw / ax: the first word of THIS wave with a feasible
+      // node and its bits; cw: the first word of this wave with a candidate of the snapshot planes (the class's cursor)
+      int aw = 0x7fffffff, cw = 0x7fffffff;
+      u64 ax = 0;
       {
-        const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
-        const ClassRows cr = class_rows(ranked, sr, st, sa, ss);
+        const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2];
+        const ClassRows cr = class_rows(ranked, sr, st, sa, -1);  // (ranked.spread is null: the topology family is checked live)
         int w0 = ld_live(a.cursor + cls);
         if (w0 < 0) w0 = cr.start;  // (kNoWord: some row of the class is empty)
-        int found_w = a.row_words;
-        for (int base = w0 < a.row_words ? (w0 & ~(kWave - 1)) : a.row_words; base < a.row_words; base += kWave) {
-          const int w = base + lane;
+        for (int base = w0 < a.row_words ? (w0 & ~(kWave - 1)) : a.row_words; base < a.row_words && aw == 0x7fffffff; base += kRoundThreads) {
+          const int w = base + tid;
           u64 x = 0;
-          if (w < a.row_words) {
+          if (w >= w0 && w < a.row_words) {
             x = ~ld_live(a.moved_bits + w);
             if (x) x &= class_word(cr, w);
           }
-          const u64 any = __ballot(x != 0);
-          if (any) {
-            const int fl = __ffsll((long long)any) - 1;
-            const u64 xw = __shfl(x, fl, kWave);
-            an = a.perm[(base + fl) * kWave + (__ffsll((long long)xw) - 1)];
-            found_w = base + fl;
-            break;
+          u64 todo = __ballot(x != 0);
+          if (!todo) continue;  // (wave-uniform)
+          const int wave_w = base + wave * kWave;
+          if (cw == 0x7fffffff) cw = wave_w + __ffsll((long long)todo) - 1;
+          if (tsig < 0) {
+            const int fl = __ffsll((long long)todo) - 1;
+            aw = wave_w + fl;
+            ax = __shfl(x, fl, kWave);
+          } else {
+            // the class's topology constraints against the live histograms, word after word, lane = node; a wave gives up once
+            // another one has found a node in an earlier word
+            while (todo) {
+              const int fl = __ffsll((long long)todo) - 1;
+              todo &= todo - 1;
+              const int ww = wave_w + fl;
+              if (__builtin_amdgcn_readfirstlane(*(volatile int*)&sh_stop) < ww) break;
+              const u64 xw = __shfl(x, fl, kWave);
+              bool ok = false;
+              if ((xw >> lane) & 1ull) {
+                const int n = a.perm[ww * kWave + lane];
+                int dom[kMaxKD];
+#pragma unroll
+                for (int k = 0; k < kMaxKD; ++k) dom[k] = k < t.KD ? t.domain[(size_t)k * t.n + n] : -1;
+                ok = constraints_fail<true>(sp, tsig, dom, spread_en, ipa_en, nullptr) == 0;
+              }
+              const u64 y = __ballot(ok);
+              if (y) {
+                aw = ww;
+                ax = y;
+                if (lane == 0) atomicMin(&sh_stop, ww);
+                break;
+              }
+            }
           }
-        }
-        if (lane == 0) st_live(a.cursor + cls, found_w);
-        if (an >= 0) {
-          ak = a.key0[an];
-          at = a.name_rank ? a.name_rank[an] : an;
         }
       }
       // ---- candidate B: the best moved node, per pair from the live tables
       u64 bk = ~0ull;
       int bt = 0x7fffffff, bn = -1;
-      for (int j0 = 0; j0 < n_moved; j0 += kWave) {
-        const int j = j0 + lane;
+      for (int j0 = 0; j0 < n_moved; j0 += kRoundThreads) {
+        const int j = j0 + tid;
         if (j < n_moved) {
           const int m = ld_live(a.moved_list + j);
           NodeRegs nr;
-          load_node_live(t, m, &nr);
+          load_node_live(t, a, m, &nr);
           int code;
           unsigned reason;
-          if (eval_pair(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) {
+          if (eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) {
             const u64 k = ld_live(a.moved_key + m);
             const int tie = a.name_rank ? a.name_rank[m] : m;
             if (k < bk || (k == bk && tie < bt)) {
@@ -2336,49 +2460,168 @@ __global__ __launch_bounds__(kWave) void k_allocate_round(NodeTable t, SpecTable
           bn = on;
         }
       }
+      // ---- the waves' candidates meet in LDS; every thread reduces them (the result is workgroup-uniform)
+      if (lane == 0) {
+        sh_aw[wave] = aw;
+        sh_ax[wave] = ax;
+        sh_cw[wave] = cw;
+        sh_bk[wave] = bk;
+        sh_bt[wave] = bt;
+        sh_bn[wave] = bn;
+      }
+      __syncthreads();
+      int gaw = 0x7fffffff, gcw = 0x7fffffff;
+      u64 gax = 0;
+      bk = ~0ull;
+      bt = 0x7fffffff;
+      bn = -1;
+#pragma unroll
+      for (int k = 0; k < kRoundWaves; ++k) {
+        if (sh_aw[k] < gaw) {
+          gaw = sh_aw[k];
+          gax = sh_ax[k];
+        }
+        gcw = min(gcw, sh_cw[k]);
+        const u64 ok = sh_bk[k];
+        const int ot = sh_bt[k], on = sh_bn[k];
+        if (on >= 0 && (bn < 0 || ok < bk || (ok == bk && ot < bt))) {
+          bk = ok;
+          bt = ot;
+          bn = on;
+        }
+      }
+      // (a wave that stopped early had nothing in front of the word another wave found: the minimum over the waves is exact)
+      if (tid == 0) st_live(a.cursor + cls, gcw < a.row_words ? gcw : a.row_words);
+      int an = -1, at = 0;
+      u64 ak = 0;
+      if (gaw < a.row_words) {
+        an = a.perm[gaw * kWave + (__ffsll((long long)gax) - 1)];
+        ak = a.key0[an];
+        at = a.name_rank ? a.name_rank[an] : an;
+      }
       win = (an >= 0 && (bn < 0 || ak < bk || (ak == bk && at < bt))) ? an : bn;
     }
-    if (lane == 0) a.out[a.first + i] = win;
+    if (tid == 0) a.out[a.first + i] = win;
     last_spec = pin == -1 ? spec : -1;
     last_win = win;
-    if (win < 0) continue;  // (wave-uniform)
-    // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod)
-    i64 used[2] = {0, 0};
-    for (int r = 0; r < t.R; ++r) {
-      const i64 v = ld_live(a.req + (size_t)r * t.n + win) + s.req[(size_t)spec * s.R + r];
-      if (r < 2) used[r] = v;
-      if (lane == 0) st_live(a.req + (size_t)r * t.n + win, v);
+    if (win >= 0) {  // (workgroup-uniform)
+      // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod)
+      const int cnt = ld_live(a.count + win) + 1;
+      const int rk = a.rank[win];
+      const bool was_moved = (ld_live(a.moved_bits + (rk >> 6)) >> (rk & 63)) & 1ull;
+      const bool dead = fit_on && (i64)cnt + 1 > (i64)t.allowed[win];  // no pod slot left: no ask of this phase fits it any more
+      if (was_moved && dead) {
+        // leaves the list (its slot is taken by the last entry): find it, every thread a share of the list
+        for (int j = tid; j < n_moved; j += kRoundThreads)
+          if (ld_live(a.moved_list + j) == win) sh_at = j;
+      }
+      if (tid == 0) {
+        i64 used[2] = {0, 0};
+        for (int r = 0; r < t.R; ++r) {
+          const i64 v = ld_live(a.req + (size_t)r * t.n + win) + s.req[(size_t)spec * s.R + r];
+          if (r < 2) used[r] = v;
+          st_live(a.req + (size_t)r * t.n + win, v);
+        }
+        st_live(a.count + win, cnt);
+        const i64 total[2] = {t.alloc[win], t.alloc[(size_t)t.n + win]};
+        st_live(a.moved_key + win, sortable_key(node_score_of(total, used)));
+        if (!was_moved) {
+          atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
+          if (!dead) st_live(a.moved_list + n_moved, win);
+        }
+      }
+      // host ports the pod occupies from now on (NodeInfo.UsedPorts)
+      if (a.ports && a.fx.occupied && tid < t.KP) {
+        const u64 occ = a.fx.occupied[(size_t)spec * t.KP + tid];
+        if (occ) atomicOr(a.ports + (size_t)tid * t.n + win, occ);
+      }
+      // match counts of the topology plugins: thread = constraint (of any signature) whose selector class the pod adds to
+      if (a.topo_on && a.fx.off) {
+        const int f0 = a.fx.off[spec], f1 = a.fx.off[spec + 1];
+        if (f1 > f0) {
+          for (int g = tid; g < a.G; g += kRoundThreads) {
+            const SpreadC c = sp.c[g];
+            int v = 0;
+            for (int k = f0; k < f1; ++k)
+              if (a.fx.cls[k] == c.ks) v = a.fx.cnt[k];
+            if (v == 0) continue;
+            const int dom = t.domain[(size_t)c.kd * t.n + win];
+            if (dom < 0 || dom >= c.dom_size) continue;
+            if (c.kind == kKindSpread && !spread_counts_here(c, spread_eligibility(t, sp, a.sig_aff, a.sig_tol, a.sig_of[g], win))) continue;
+            const int old = atomicAdd(sp.cnt + c.cnt_off + dom, v);
+            if (c.kind == kKindSpread) {
+              // (an eligible node carries the domain: it is a present one. Its count leaves the minimum; the minimum itself moves
+              // only when no present domain is left there)
+              if (old == ld_live(a.mn + g)) {
+                const int left = ld_live(a.at_min + g) - 1;
+                st_live(a.at_min + g, left);
+                if (left == 0) {
+                  const int slot = atomicAdd(&sh_ndirty, 1);
+                  if (slot < kRoundDirty) {
+                    sh_dirty[slot] = g;
+                  } else {  // (more than a handful at once: this thread recomputes its constraint alone)
+                    int mn = 0x7fffffff, at = 0;
+                    for (int q = 0; q < c.dom_size; ++q)
+                      if (sp.present[c.cnt_off + q]) mn = min(mn, ld_live(sp.cnt + c.cnt_off + q));
+                    for (int q = 0; q < c.dom_size; ++q) at += (sp.present[c.cnt_off + q] && ld_live(sp.cnt + c.cnt_off + q) == mn) ? 1 : 0;
+                    st_live(a.mn + g, mn);
+                    st_live(a.at_min + g, at);
+                    st_live(sp.minv + g, a.nd[g] < c.min_domains ? 0 : mn);
+                  }
+                }
+              }
+            } else if (old <= 0 && old + v > 0) {
+              st_live(sp.minv + g, ld_live(sp.minv + g) + 1);  // InterPodAffinity: domains with a match (k_spread_min's `tot`)
+            }
+          }
+        }
+      }
+      __threadfence();
+      __syncthreads();
+      if (!was_moved) {
+        if (!dead) ++n_moved;
+      } else if (dead) {
+        const int at_l = sh_at;
+        if (at_l >= 0) {
+          if (tid == 0) st_live(a.moved_list + at_l, ld_live(a.moved_list + n_moved - 1));
+          --n_moved;
+        }
+      }
+      // spread constraints whose last domain left the minimum: the new minimum, the whole workgroup over the constraint's domains
+      const int ndirty = min(sh_ndirty, kRoundDirty);
+      for (int q = 0; q < ndirty; ++q) {
+        const int g = sh_dirty[q];
+        const SpreadC c = sp.c[g];
+        int mn = 0x7fffffff;
+        for (int d = tid; d < c.dom_size; d += kRoundThreads)
+          if (sp.present[c.cnt_off + d]) mn = min(mn, ld_live(sp.cnt + c.cnt_off + d));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, kWave));
+        if (lane == 0) sh_rmn[wave] = mn;
+        __syncthreads();
+        mn = sh_rmn[0];
+#pragma unroll
+        for (int k = 1; k < kRoundWaves; ++k) mn = min(mn, sh_rmn[k]);
+        int at = 0;
+        for (int d = tid; d < c.dom_size; d += kRoundThreads) at += (sp.present[c.cnt_off + d] && ld_live(sp.cnt + c.cnt_off + d) == mn) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) at += __shfl_xor(at, off, kWave);
+        if (lane == 0) sh_rat[wave] = at;
+        __syncthreads();
+        if (tid == 0) {
+          at = 0;
+          for (int k = 0; k < kRoundWaves; ++k) at += sh_rat[k];
+          st_live(a.mn + g, mn);
+          st_live(a.at_min + g, at);
+          st_live(sp.minv + g, a.nd[g] < c.min_domains ? 0 : mn);
+        }
+      }
+      if (ndirty) __threadfence();
     }
-    const int cnt = ld_live(a.count + win) + 1;
-    if (lane == 0) st_live(a.count + win, cnt);
-    const i64 total[2] = {t.alloc[win], t.alloc[(size_t)t.n + win]};
-    if (lane == 0) st_live(a.moved_key + win, sortable_key(node_score_of(total, used)));
-    const int rk = a.rank[win];
-    const bool was_moved = (ld_live(a.moved_bits + (rk >> 6)) >> (rk & 63)) & 1ull;
-    const bool dead = fit_on && (i64)cnt + 1 > (i64)t.allowed[win];  // no pod slot left: no ask of this phase fits it any more
-    if (!was_moved) {
-      if (lane == 0) atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
-      if (!dead) {
-        if (lane == 0) st_live(a.moved_list + n_moved, win);
-        ++n_moved;
-      }
-    } else if (dead) {
-      // leaves the list: its slot is taken by the last entry
-      int at_l = -1;
-      for (int j0 = 0; j0 < n_moved && at_l < 0; j0 += kWave) {
-        const int j = j0 + lane;
-        const u64 hit = __ballot(j < n_moved && ld_live(a.moved_list + j) == win);
-        if (hit) at_l = j0 + __ffsll((long long)hit) - 1;
-      }
-      if (at_l >= 0) {
-        const int last = ld_live(a.moved_list + n_moved - 1);
-        if (lane == 0) st_live(a.moved_list + at_l, last);
-        --n_moved;
-      }
-    }
-    __threadfence();
+    // (the exchange slots are rewritten by the next ask only after this barrier; every wave has read them by now)
+    __syncthreads();
   }
-  if (lane == 0) st_live(a.n_moved, n_moved);
+  if (tid == 0) st_live(a.n_moved, n_moved);
 }
 
 // order-independent checksum of the bitmap: Σ mix64(word ⊕ position-salt) over the meaningful words

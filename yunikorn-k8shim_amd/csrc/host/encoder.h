@@ -262,31 +262,40 @@ class Encoder {
     sel_memo_.clear();
     port_dict.clear();
     port_ix_.clear();
-    // InterPodAffinity: topology keys of the anti-affinity terms carried by pods that are already on nodes
+    // InterPodAffinity: topology keys of the anti-affinity terms carried by pods that are already on nodes — and by the pending
+    // asks themselves: an allocation round ASSUMES asks one after the other (context.go:828-885), and an assumed pod is an
+    // existing pod for every ask behind it (satisfyExistingPodsAntiAffinity). Their count classes exist from the start (all
+    // zero until somebody is assumed), so a round never has to stop for a dictionary rebuild and the device can run it.
     existing_anti_templates_.clear();
     if (may_have_existing_anti) {
       std::set<const PodTemplate*> seen;
-      for (const NodeInfo* ni : nodes)
-        for (const Pod* p : ni->pods)
-          if (!p->tpl->pod_anti_affinity.empty() && seen.insert(p->tpl).second) {
-            // An anti-affinity term of a pod that already runs constrains the asks its selector matches. A term the mirror
-            // cannot decide (non-empty namespaceSelector: needs Namespace labels; a selector that does not parse) costs
-            // exactly THOSE asks their place on the engine — whoever it cannot match (labels) is unaffected whatever the
-            // namespaces turn out to be. Topology keys beyond the engine's 8 are handled the same way.
-            bool any_evaluable = false;
-            for (auto& term : p->tpl->pod_anti_affinity) {
-              bool invalid = false;
-              selector_matches(term.selector, p->tpl->labels, &invalid);
-              const bool new_key = !topo_ix_.count(term.topology_key);
-              if (invalid || term.namespace_selector_unsupported || (new_key && (int)topo_keys.size() >= kLimitTopoKeys)) {
-                wild_anti_terms_.push_back(&term);
-                continue;
-              }
-              topo_key(term.topology_key);
-              any_evaluable = true;
-            }
-            if (any_evaluable) existing_anti_templates_.push_back(p->tpl);
+      auto consider = [&](const PodTemplate* tpl) {
+        if (tpl->pod_anti_affinity.empty() || !seen.insert(tpl).second) return;
+        // An anti-affinity term of a pod that already runs constrains the asks its selector matches. A term the mirror
+        // cannot decide (non-empty namespaceSelector: needs Namespace labels; a selector that does not parse) costs
+        // exactly THOSE asks their place on the engine — whoever it cannot match (labels) is unaffected whatever the
+        // namespaces turn out to be. Topology keys beyond the engine's 8 are handled the same way.
+        bool any_evaluable = false;
+        for (auto& term : tpl->pod_anti_affinity) {
+          bool invalid = false;
+          selector_matches(term.selector, tpl->labels, &invalid);
+          const bool new_key = !topo_ix_.count(term.topology_key);
+          if (invalid || term.namespace_selector_unsupported || (new_key && (int)topo_keys.size() >= kLimitTopoKeys)) {
+            wild_anti_terms_.push_back(&term);
+            continue;
           }
+          topo_key(term.topology_key);
+          any_evaluable = true;
+        }
+        if (any_evaluable) existing_anti_templates_.push_back(tpl);
+      };
+      // (pending templates first: an ask that is assumed during a round moves its template from "pending" to "on a node", and
+      // the numbering of topology keys and count classes must not depend on which of the two lists met it first. A pending
+      // template the engine cannot evaluate is never assumed by a device round: it stays out)
+      for (const PodTemplate* t : templates)
+        if (!t->pod_anti_affinity.empty() && template_error(*t).empty()) consider(t);
+      for (const NodeInfo* ni : nodes)
+        for (const Pod* p : ni->pods) consider(p->tpl);
     }
     // Node-driven entries. Nothing here can cost the cluster its engine: taints are unbounded (their BITS are assigned below,
     // once the asks' toleration lists are known), and a scalar resource only becomes a dimension when an ask requests it —
@@ -448,6 +457,8 @@ class Encoder {
   // the caller then rebuilds the dictionaries.
   bool encode_spec_if_covered(const PodTemplate& t, EncodedSpec* spec, std::vector<uint64_t>* wanted) const {
     if (!template_error(t).empty() || unsupported.count(&t)) return false;
+    // (a template with required anti-affinity terms is a future EXISTING pod: the asks it matches need its count classes)
+    if (!node_pod_known(t)) return false;
     missing_ = false;
     try {
       *spec = encode_spec(t);
@@ -471,6 +482,61 @@ class Encoder {
     wanted->assign((size_t)std::max(KP, 1), 0);
     encode_wanted_ports(t, wanted->data());
     return !missing_;
+  }
+
+  // What NodeInfo.AddPod of a pod of each template adds to its node besides resources (ykpred_spec_effects_t): its contribution
+  // to every count class — class_contribution, the function encode_node_spread sums over the pods of a node — and the dictionary
+  // host ports it occupies (encode_ports of the pod alone). A class is only tried against the templates that can match it: most
+  // classes are a matchLabels selector, so they hang under one of their (key, value) pairs and a template looks under its own
+  // labels (plus the few classes without such a pair, and — for templates with required anti-affinity — the symmetric classes).
+  void spec_effects(const std::vector<PodTemplate*>& templates, std::vector<int32_t>* off, std::vector<int32_t>* cls, std::vector<int32_t>* cnt,
+                    std::vector<uint64_t>* occupied) const {
+    std::unordered_map<std::string, std::vector<int>> by_pair;
+    std::vector<int> general, symmetric;
+    for (int c = 0; c < KS; ++c) {
+      const SelectorClass& sc = sel_classes[(size_t)c];
+      if (sc.kind == SelectorClass::kExistingAnti) {
+        symmetric.push_back(c);
+        continue;
+      }
+      const LabelSelector* sel = sc.kind == SelectorClass::kSpread ? &sc.selector : (sc.terms.empty() ? nullptr : &sc.terms[0].selector);
+      if (sel && sel->present && !sel->match_labels.empty()) {
+        auto& kv = *sel->match_labels.begin();
+        by_pair[kv.first + '\x1f' + kv.second].push_back(c);
+      } else {
+        general.push_back(c);
+      }
+    }
+    off->assign(1, 0);
+    cls->clear();
+    cnt->clear();
+    occupied->assign(templates.size() * (size_t)std::max(KP, 1), 0);
+    std::vector<int> cand;
+    for (size_t i = 0; i < templates.size(); ++i) {
+      const PodTemplate& t = *templates[i];
+      if (KS > 0) {
+        cand = general;
+        for (auto& kv : t.labels) {
+          auto it = by_pair.find(kv.first + '\x1f' + kv.second);
+          if (it != by_pair.end()) cand.insert(cand.end(), it->second.begin(), it->second.end());
+        }
+        if (!t.pod_anti_affinity.empty()) cand.insert(cand.end(), symmetric.begin(), symmetric.end());
+        std::sort(cand.begin(), cand.end());
+        for (int c : cand) {
+          const int v = class_contribution(sel_classes[(size_t)c], t);
+          if (v > 0) {
+            cls->push_back(c);
+            cnt->push_back(v);
+          }
+        }
+      }
+      off->push_back((int32_t)cls->size());
+      if (KP > 0) {
+        Pod probe;
+        probe.tpl = &t;
+        encode_ports({&probe}, occupied->data() + i * (size_t)KP);
+      }
+    }
   }
 
   // NodePorts: bit k = some pod in `pods` uses a host port that conflicts with dictionary port k

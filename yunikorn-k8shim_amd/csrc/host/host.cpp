@@ -163,6 +163,8 @@ struct ykhost {
   uint64_t placeholder_serial = 0;    // nonce source of generated placeholder names
   std::shared_ptr<EncodedTables> tables;  // what the last full encode uploaded; spec rows are appended for new templates
   bool specs_dirty = false;               // spec rows were appended since the last ykpred_set_specs
+  bool fx_uploaded = false;               // ykpred_set_spec_effects describes the spec table the engine holds (allocation rounds)
+  int64_t fx_uploads = 0;
   // answers of one ask against every node (ykpred_query_pod), so that the core's per-node Predicates() callbacks of a
   // scheduling attempt are served from host memory; dropped whenever any table changes
   struct AskAnswers {
@@ -311,6 +313,7 @@ int recreate_engine(ykhost* h) {
                    "(ykhost_comm_init is collective and cannot be repeated silently)", YKPRED_E_STATE);
   if (h->eng) ykpred_destroy(h->eng);
   h->eng = nullptr;
+  h->fx_uploaded = false;
   if (h->device < 0) return fail(h, "mirror-only handle (device < 0): no device engine, nothing can be evaluated", YKPRED_E_STATE);
   ykpred_config_t c{};
   c.abi_version = YKPRED_ABI_VERSION;
@@ -660,6 +663,7 @@ int full_sync(ykhost* h) {
   if (rc) return fail(h, std::string("ykpred_set_row_capacity: ") + ykpred_last_error(h->eng), rc);
   rc = ykpred_set_nodes(h->eng, &T.nt);
   if (rc) return fail(h, std::string("ykpred_set_nodes: ") + ykpred_last_error(h->eng), rc);
+  h->fx_uploaded = false;
   rc = ykpred_set_specs(h->eng, &T.sp);
   if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
   h->dirty_all = false;
@@ -772,6 +776,7 @@ int sync(ykhost* h) {
     h->dirty_nodes.clear();
   }
   if (h->specs_dirty && !h->dirty_all) {
+    h->fx_uploaded = false;
     int rc = ykpred_set_specs(h->eng, &h->tables->sp);
     if (rc) return fail(h, std::string("ykpred_set_specs: ") + ykpred_last_error(h->eng), rc);
     h->specs_dirty = false;
@@ -2210,6 +2215,15 @@ int64_t ykhost_encoded_tables_json(ykhost_t* h, char* out, int64_t len) {
   for (size_t p = 0; p < P; ++p) encode_row(h, h->pending[p], &spec[p], &pin[p]);
   ints("pod_spec", spec.data(), P);
   ints("pod_node_name", pin.data(), P);
+  {  // what an assumed pod of each spec adds to its node besides resources (ykpred_spec_effects_t)
+    std::vector<int32_t> fx_off, fx_cls, fx_cnt;
+    std::vector<uint64_t> occupied;
+    h->enc.spec_effects(h->spec_templates, &fx_off, &fx_cls, &fx_cnt, &occupied);
+    ints("effect_off", fx_off.data(), fx_off.size());
+    ints("effect_class", fx_cls.data(), fx_cls.size());
+    ints("effect_count", fx_cnt.data(), fx_cnt.size());
+    masks("occupied_ports", occupied.data(), S * KP);
+  }
   o += "\"spread_constraints\":" + std::to_string(T.spread.size()) + "}";
   if (out && len > 0) copy_out(o, out, len);
   return (int64_t)o.size() + 1;
@@ -2501,6 +2515,30 @@ int32_t ykhost_candidates(ykhost_t* h, int32_t pod, int32_t allocate, int32_t k,
   return found;
 }
 
+// What AssumePod of an ask adds to its node besides its resources — the selector-class counts behind PodTopologySpread /
+// InterPodAffinity and the host ports it occupies — per spec, so that the device round can keep that state current ask by ask
+// (ykpred_set_spec_effects). Only a round needs it: built and uploaded on the first round after the spec table moved.
+static int upload_spec_effects(ykhost* h) {
+  if (h->fx_uploaded) return 0;
+  if (h->enc.KS == 0 && h->enc.KP == 0) return 0;  // nothing but resources couples the asks
+  std::vector<int32_t> off, cls, cnt;
+  std::vector<uint64_t> occupied;
+  h->enc.spec_effects(h->spec_templates, &off, &cls, &cnt, &occupied);
+  cls.push_back(0);  // (never empty: the C side takes data() of them)
+  cnt.push_back(0);
+  ykpred_spec_effects_t fx{};
+  fx.count = (int32_t)h->spec_templates.size();
+  fx.contrib_off = off.data();
+  fx.contrib_class = cls.data();
+  fx.contrib_count = cnt.data();
+  fx.occupied_ports = h->enc.KP > 0 ? occupied.data() : nullptr;
+  const int rc = ykpred_set_spec_effects(h->eng, &fx);
+  if (rc) return fail(h, std::string("ykpred_set_spec_effects: ") + ykpred_last_error(h->eng), rc);
+  h->fx_uploaded = true;
+  h->fx_uploads++;
+  return 0;
+}
+
 // One scheduling round with conflict-resolved decisions. See ykhost.h.
 int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32_t apply, int32_t* out_nodes) {
   YKHOST_LOCKED(h);
@@ -2538,12 +2576,28 @@ int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32
   int placed = 0;
   if (list.empty()) return 0;
   std::vector<int32_t> got(list.size(), -1);
+  // YKHOST_ROUND_ON_HOST=1 (tests): the specs' effects are withheld, so that a round with topology constraints or host ports takes
+  // the ask-by-ask path below — the path node-sharded engines still take
+  const char* on_host_env = getenv("YKHOST_ROUND_ON_HOST");  // (read per round: the tests switch it inside one process)
+  const bool round_on_host = on_host_env && atoi(on_host_env) != 0;
+  if (round_on_host) {
+    ykpred_set_spec_effects(h->eng, nullptr);
+    h->fx_uploaded = false;
+  }
+  if (!round_on_host) {
+    rc = upload_spec_effects(h);
+    if (rc) return rc;
+  }
   rc = ykpred_allocate_round(h->eng, h->alloc_pre, h->alloc_filt, (int32_t)list.size(), list.data(), got.data());
   if (rc == YKPRED_E_STATE) {
     // the patched evaluation is current but its rank-ordered planes are not (e.g. a template was appended since the last
     // decision pass): one full pass, then the round
     rc = ykhost_evaluate(h, 1, want);
     if (rc) return rc;
+    if (!round_on_host) {
+      rc = upload_spec_effects(h);
+      if (rc) return rc;
+    }
     rc = ykpred_allocate_round(h->eng, h->alloc_pre, h->alloc_filt, (int32_t)list.size(), list.data(), got.data());
   }
   if (rc == YKPRED_OK) {

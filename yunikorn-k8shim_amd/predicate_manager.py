@@ -220,7 +220,7 @@ class GpuPredicateManager:
         buf = C.create_string_buffer(need)
         self._check(self._L.ykhost_encoded_tables_json(self._h, buf, need))
         t = json.loads(buf.value.decode())
-        for k in ("taint_bits", "label_bits", "port_bits", "tolerated", "aff_terms", "pre_terms", "wanted_ports"):
+        for k in ("taint_bits", "label_bits", "port_bits", "tolerated", "aff_terms", "pre_terms", "wanted_ports", "occupied_ports"):
             t[k] = [int(x, 16) for x in t[k]]
         return t
 
