@@ -305,7 +305,28 @@ class Encoder {
         if (t.effect == "NoSchedule" || t.effect == "NoExecute") taint(t);
     // ask-driven entries, template by template: a template whose entries would not fit is rolled back and marked
     // unsupported on its own — the asks before and after it keep their place in the dictionaries
-    for (const PodTemplate* t : templates) {
+    // Templates of one dictionary SHAPE (PodTemplate::shape_id: everything but labels and request values) register the same
+    // entries and are refused for the same reasons — one of them is visited, the others inherit its verdict. Only while no
+    // anti-affinity term of an on-node or pending pod exists: those are matched against every ask's LABELS.
+    const bool by_shape = existing_anti_templates_.empty() && wild_anti_terms_.empty();
+    std::vector<const PodTemplate*> shape_rep;
+    std::vector<PodTemplate*> visited;  // the templates that went through the loop body, in order (assign_taint_bits reads their toleration lists)
+    if (by_shape) {
+      int32_t max_shape = -1;
+      for (const PodTemplate* t : templates) max_shape = std::max(max_shape, t->shape_id);
+      shape_rep.assign((size_t)(max_shape + 1), nullptr);
+    }
+    for (PodTemplate* t : templates) {
+      if (by_shape && t->shape_id >= 0) {
+        const PodTemplate*& rep = shape_rep[(size_t)t->shape_id];
+        if (rep) {
+          auto un = unsupported.find(rep);
+          if (un != unsupported.end()) unsupported[t] = un->second;
+          continue;
+        }
+        rep = t;
+      }
+      visited.push_back(t);
       {
         std::string why = template_error(*t);
         if (!why.empty()) {
@@ -347,7 +368,7 @@ class Encoder {
         unsupported[t] = std::string("the ask needs more ") + over + " than the dictionaries can still take";
       }
     }
-    assign_taint_bits(templates);
+    assign_taint_bits(visited, templates);
     KD = (int)topo_keys.size();
     KS = (int)sel_classes.size();
     KP = ((int)port_dict.size() + 63) / 64;
@@ -870,7 +891,8 @@ class Encoder {
   // bit. Keyed tolerations are matched through an index by taint key, so the cost is (#lists x their tolerations + #taints),
   // not #lists x #taints; a toleration without a key (operator Exists) covers every taint of its effect and never tells two
   // taints of one effect apart — the effect is part of the group key instead.
-  void assign_taint_bits(const std::vector<PodTemplate*>& templates) {
+  // lists_of: the templates whose toleration lists are read (one per dictionary shape suffices); templates: all of them
+  void assign_taint_bits(const std::vector<PodTemplate*>& lists_of, const std::vector<PodTemplate*>& templates) {
     const size_t T = taint_dict.size();
     taint_bit.assign(T, 0);
     taint_members.clear();
@@ -881,7 +903,7 @@ class Encoder {
     std::unordered_map<std::string, int32_t> list_ids;
     std::vector<const PodTemplate*> list_owner;
     std::vector<std::vector<int32_t>> tolerated_by(T);  // [taint] → ids of the lists that tolerate it through a keyed toleration
-    for (const PodTemplate* t : templates) {
+    for (const PodTemplate* t : lists_of) {
       if (unsupported.count(t) || t->tolerations.empty()) continue;
       std::string k;
       for (auto& tol : t->tolerations) k += tol.key + '\x1f' + tol.op + '\x1f' + tol.value + '\x1f' + tol.effect + '\x1e';

@@ -418,6 +418,8 @@ void run_on_threads(int threads, int n, F&& f) {
   if (err) std::rethrow_exception(err);
 }
 int encode_tables(ykhost* h, EncodedTables* T) {
+  auto tp0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (getenv("YKHOST_TRACE_ENCODE")) { auto n = std::chrono::steady_clock::now(); fprintf(stderr, "encode %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - tp0).count()); tp0 = n; } };
   // templates of pending asks, in first-use order → spec ids
   h->spec_templates.clear();
   for (PodTemplate* t : h->pool.all()) t->spec_id = -1;
@@ -430,7 +432,9 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   }
   bool any_anti = false;  // (templates are never dropped from the pool: conservative)
   for (const PodTemplate* t : h->pool.all()) any_anti = any_anti || !t->pod_anti_affinity.empty();
+  lap("spec ids");
   if (!h->enc.build_dictionaries(h->nodes, h->spec_templates, any_anti)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
+  lap("dictionaries");
   h->unsupported_asks = 0;
   if (!h->enc.unsupported.empty())
     for (const Pod* p : h->pending) h->unsupported_asks += h->enc.unsupported.count(p->tpl) ? 1 : 0;
@@ -489,6 +493,7 @@ int encode_tables(ykhost* h, EncodedTables* T) {
       return fail(h, std::string("encoder: node rows: ") + ex.what(), YKPRED_E_NOMEM);
     }
   }
+  lap("node rows");
   ykpred_nodes_t& nt = T->nt;
   nt = ykpred_nodes_t{};
   nt.count = (int32_t)N;
@@ -514,6 +519,7 @@ int encode_tables(ykhost* h, EncodedTables* T) {
     nt.name_rank = T->name_rank.data();
   }
 
+  lap("name ranks");
   const size_t S = h->spec_templates.size();
   T->sreq.assign(S * R, 0);
   T->stol.assign(S * KT, 0);
@@ -525,19 +531,64 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   T->pre_off.assign(1, 0);
   T->spread_off.assign(1, 0);
   T->spread.clear();
-  for (size_t s = 0; s < S; ++s) {
-    EncodedSpec es = h->enc.encode_spec(*h->spec_templates[s]);
-    T->spread.insert(T->spread.end(), es.spread.begin(), es.spread.end());
-    T->spread_off.push_back((int32_t)T->spread.size());
-    std::copy(es.req.begin(), es.req.end(), T->sreq.begin() + (long)(s * R));
-    std::copy(es.tol.begin(), es.tol.end(), T->stol.begin() + (long)(s * KT));
-    T->sflags[s] = es.flags;
-    h->enc.encode_wanted_ports(*h->spec_templates[s], T->wanted.data() + s * KP);
-    for (auto& t : es.terms) T->aff_terms.insert(T->aff_terms.end(), t.begin(), t.end());
-    for (auto& t : es.pre_terms) T->pre_terms.insert(T->pre_terms.end(), t.begin(), t.end());
-    T->aff_off.push_back((int32_t)(T->aff_terms.size() / (size_t)W));
-    T->pre_off.push_back((int32_t)(T->pre_terms.size() / (size_t)W));
+  // One row per spec. encode_spec only READS the dictionaries, so the rows are encoded on the host's cores, a block of specs at a
+  // time: the fixed-width columns are written in place, the variable-length ones (Filter / PreFilter DNF terms, topology
+  // constraints) into the block's own vectors, which are then appended in block order — the tables are the one-thread encode's.
+  struct SpecBlock {
+    std::vector<ykpred_spread_t> spread;
+    std::vector<uint64_t> aff, pre;
+    std::vector<int32_t> n_spread, n_aff, n_pre;  // per spec of the block
+  };
+  const size_t kSpecBlock = 2048;
+  const size_t n_blocks = (S + kSpecBlock - 1) / kSpecBlock;
+  std::vector<SpecBlock> blocks(n_blocks);
+  auto encode_block = [&](int b) {
+    SpecBlock& blk = blocks[(size_t)b];
+    const size_t s0 = (size_t)b * kSpecBlock, s1 = std::min(S, s0 + kSpecBlock);
+    for (size_t s = s0; s < s1; ++s) {
+      EncodedSpec es = h->enc.encode_spec(*h->spec_templates[s]);
+      blk.spread.insert(blk.spread.end(), es.spread.begin(), es.spread.end());
+      blk.n_spread.push_back((int32_t)es.spread.size());
+      std::copy(es.req.begin(), es.req.end(), T->sreq.begin() + (long)(s * R));
+      std::copy(es.tol.begin(), es.tol.end(), T->stol.begin() + (long)(s * KT));
+      T->sflags[s] = es.flags;
+      h->enc.encode_wanted_ports(*h->spec_templates[s], T->wanted.data() + s * KP);
+      for (auto& t : es.terms) blk.aff.insert(blk.aff.end(), t.begin(), t.end());
+      for (auto& t : es.pre_terms) blk.pre.insert(blk.pre.end(), t.begin(), t.end());
+      blk.n_aff.push_back((int32_t)es.terms.size());
+      blk.n_pre.push_back((int32_t)es.pre_terms.size());
+    }
+  };
+  {
+    const int spec_threads = S >= 4 * kSpecBlock ? (int)std::min<size_t>(host_threads(), n_blocks) : 1;
+    bool done = false;
+    if (spec_threads > 1) {
+      try {
+        run_on_threads(spec_threads, (int)n_blocks, encode_block);
+        done = true;
+        lap("spec rows (blocks)");
+      } catch (const std::exception&) {
+        for (SpecBlock& blk : blocks) blk = SpecBlock{};  // (a worker ran out of memory: once more, on this thread alone)
+      }
+    }
+    try {
+      if (!done)
+        for (size_t b = 0; b < n_blocks; ++b) encode_block((int)b);
+      for (const SpecBlock& blk : blocks) {
+        T->spread.insert(T->spread.end(), blk.spread.begin(), blk.spread.end());
+        T->aff_terms.insert(T->aff_terms.end(), blk.aff.begin(), blk.aff.end());
+        T->pre_terms.insert(T->pre_terms.end(), blk.pre.begin(), blk.pre.end());
+        for (size_t i = 0; i < blk.n_spread.size(); ++i) {
+          T->spread_off.push_back(T->spread_off.back() + blk.n_spread[i]);
+          T->aff_off.push_back(T->aff_off.back() + blk.n_aff[i]);
+          T->pre_off.push_back(T->pre_off.back() + blk.n_pre[i]);
+        }
+      }
+    } catch (const std::exception& ex) {
+      return fail(h, std::string("encoder: spec rows: ") + ex.what(), YKPRED_E_NOMEM);
+    }
   }
+  lap("spec rows");
   refresh_spec_view(h, T);
   return 0;
 }

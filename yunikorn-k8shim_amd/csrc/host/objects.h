@@ -96,6 +96,13 @@ struct PodTemplate {
   std::vector<std::string> volume_kinds;
   int32_t resource_claims = 0;
   std::string canonical;      // interning key (canonical JSON of the fields above)
+  // What the encoder's DICTIONARIES can learn from this template: everything except its labels and the VALUES of its requests —
+  // namespace, host ports, the names of the scalar resources it requests, and the spec behind the containers (selectors, affinity,
+  // tolerations, spread constraints, volumes ...). Two templates of one shape register the same entries and are refused for the
+  // same reasons, so a full encode visits one of them (10^6 asks that differ only in their cpu request are a few 10^4 shapes).
+  // The pool numbers the shapes; the text is dropped after interning.
+  std::string dict_shape;
+  int32_t shape_id = -1;
   // derived once at interning time
   ResMap requests;            // upstream PodRequests (resource.go:56-109 minus the "pods" entry)
   int32_t spec_id = -1;       // engine spec index (assigned by the encoder)
@@ -370,7 +377,7 @@ inline void js_containers(std::string& o, const std::vector<Container>& cs) {
 }
 
 // "metadata" (namespace + labels only) and "spec" members of a pod, without identity and nodeName.
-inline void template_json(const PodTemplate& t, std::string& meta, std::string& spec) {
+inline void template_json(const PodTemplate& t, std::string& meta, std::string& spec, size_t* rest_at = nullptr) {
   meta.clear();
   spec.clear();
   meta += "\"namespace\":";
@@ -383,6 +390,7 @@ inline void template_json(const PodTemplate& t, std::string& meta, std::string& 
     spec += ",\"initContainers\":";
     js_containers(spec, t.init_containers);
   }
+  if (rest_at) *rest_at = spec.size();  // (everything behind the containers: selectors, affinity, tolerations, constraints, volumes ...)
   if (t.has_node_selector) {
     spec += ",\"nodeSelector\":";
     js_map(spec, t.node_selector);
@@ -582,9 +590,30 @@ class TemplatePool {
   // the part of interning that touches no shared state (the scanning threads of a batch do it for the templates they parse)
   static void prepare(PodTemplate& t) {
     std::string meta, spec;
-    template_json(t, meta, spec);
+    size_t rest_at = 0;
+    template_json(t, meta, spec, &rest_at);
     t.canonical = meta + "|" + spec;
     t.requests = compute_requests(t);
+    std::string& sh = t.dict_shape;
+    sh.clear();
+    sh += t.ns;
+    sh.push_back('\x1f');
+    for (const HostPort& hp : template_host_ports(t)) {
+      sh += hp.protocol;
+      sh.push_back(',');
+      sh += hp.ip;
+      sh.push_back(',');
+      sh += std::to_string(hp.port);
+      sh.push_back(';');
+    }
+    sh.push_back('\x1f');
+    for (auto& kv : t.requests)
+      if (kv.second > 0 && is_scalar_resource_name(kv.first)) {
+        sh += kv.first;
+        sh.push_back(';');
+      }
+    sh.push_back('\x1f');
+    sh.append(spec, rest_at, std::string::npos);
   }
   const PodTemplate* intern(PodTemplate&& t) {
     prepare(t);
@@ -594,6 +623,8 @@ class TemplatePool {
     auto it = by_key_.find(t.canonical);
     if (it != by_key_.end()) return it->second.get();
     std::string key = t.canonical;
+    t.shape_id = shapes_.emplace(std::move(t.dict_shape), (int32_t)shapes_.size()).first->second;
+    t.dict_shape = std::string();
     auto up = std::make_unique<PodTemplate>(std::move(t));
     const PodTemplate* raw = up.get();
     by_key_.emplace(std::move(key), std::move(up));
@@ -601,14 +632,17 @@ class TemplatePool {
     return raw;
   }
   const std::vector<PodTemplate*>& all() const { return order_; }
+  size_t num_shapes() const { return shapes_.size(); }
   void clear() {
     by_key_.clear();
     order_.clear();
+    shapes_.clear();
   }
 
  private:
   std::unordered_map<std::string, std::unique_ptr<PodTemplate>> by_key_;
   std::vector<PodTemplate*> order_;
+  std::unordered_map<std::string, int32_t> shapes_;  // dictionary shape → id (PodTemplate::shape_id)
 };
 
 // KEP-1287 in-place resize (resource.go:110-142, computeContainerResource / isResizeInfeasible): a container that has a
