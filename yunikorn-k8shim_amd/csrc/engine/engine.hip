@@ -297,6 +297,8 @@ struct ykpred_engine {
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
   DevBuf d_band_tab, d_class_rows_a, d_class_list_a, d_class_slot_a, d_fix_row, d_fix_slot, d_chunk_zone;
+  DevBuf d_class_list_b;            // the zone-B classes (k_class_rows counts them too when there are few: ykpred_eval)
+  int n_classes_b = 0;
   std::vector<int32_t> h_ch_zone;
   std::vector<uint8_t> h_row_stale;  // bitmap row rewritten by ykpred_update_pods and not re-evaluated yet: it must not serve
                                      // as the representative row of its class (k_column_class reads that row)
@@ -333,7 +335,7 @@ struct ykpred_engine {
 
   // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr, ev_counts = nullptr;
   // --- the resident answer served to single callbacks (ykpred_peek_row): a copy stream ordered after the
   // last evaluation by an event, pinned staging memory
   hipStream_t peek_stream = nullptr;
@@ -716,6 +718,8 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     });
     for (int32_t c : order_b)
       for (int i = class_off[(size_t)c]; i < class_off[(size_t)c + 1]; ++i) e->h_pod_row[(size_t)members[(size_t)i]] = next_row++;
+    e->n_classes_b = (int)order_b.size();
+    TRY(upload(e, e->d_class_list_b, order_b.data(), order_b.size(), st));
   }
   e->rows_total = next_row;
   e->rows_a = rows_a;
@@ -1196,6 +1200,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   (void)hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_planes, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&e->ev_counts, hipEventDisableTiming);
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   e->ev_ready = true;
   *out = e;
@@ -1224,13 +1229,16 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
                     &e->d_members, &e->d_patches, &e->d_rows, &e->d_row_count, &e->d_row_best, &e->d_class_count, &e->d_class_best, &e->d_bitmap, &e->d_counts, &e->d_decisions, &e->d_keys, &e->d_scratch,
                     &e->d_member_key, &e->d_name_rank, &e->d_member_tie, &e->d_class_rows_all, &e->d_gathered_classes, &e->d_class_rows_slot,
-                    &e->d_class_sig_ident, &e->d_expand_count, &e->d_layout_hash, &e->d_gathered_pod_class, &e->d_row_pod})
+                    &e->d_class_sig_ident, &e->d_expand_count, &e->d_layout_hash, &e->d_gathered_pod_class, &e->d_row_pod,
+                    &e->d_round, &e->d_fx_off, &e->d_fx_cls, &e->d_fx_cnt, &e->d_fx_occ, &e->d_sp_sig_of, &e->d_class_list_b, &e->d_gathered, &e->d_gathered_map,
+                    &e->d_xkey, &e->d_xcand})
     b->release();
   if (e->ev_ready)
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
+  if (e->ev_counts) (void)hipEventDestroy(e->ev_counts);
   if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
   if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
   if (e->peek_stream) (void)hipStreamDestroy(e->peek_stream);
@@ -1807,12 +1815,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     bp.stride = e->row_stride;
     return bp;
   };
-  auto launch_dictionary_planes = [&](hipStream_t s, const int* perm, bool ranked, const char* base_name, const char* sig_name) {
+  auto launch_dictionary_planes = [&](hipStream_t s, const int* perm, bool ranked, const char* base_name, const char* sig_name, bool base_done = false) {
     ykk::BasePlanes bp = base_of(ranked ? e->base_ranked : e->base_canon);
-    tm.begin(s);
-    hipLaunchKernelGGL(ykk::k_base_planes, dim3((unsigned)(e->W + e->KT + e->KP + 1), wgroups), dim3(ykk::kBlock), 0, s, nt, perm, bp,
-                       e->row_words);
-    tm.end(s, base_name);
+    if (!base_done) {
+      tm.begin(s);
+      hipLaunchKernelGGL(ykk::k_base_planes, dim3((unsigned)(e->W + e->KT + e->KP + 1), wgroups), dim3(ykk::kBlock), 0, s, nt, perm, bp,
+                         e->row_words);
+      tm.end(s, base_name);
+    }
     ykk::SigPlaneArgs sa{};
     sa.base = bp;
     sa.tol = o_tol;
@@ -1854,7 +1864,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
   // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
   auto ranked_walk = [](const int* perm) { return perm != nullptr; };
-  auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name) {
+  auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name, bool with_base = false) {
     ykk::PlaneArgs pa{};
     pa.perm = perm;
     pa.res = o_res;
@@ -1873,7 +1883,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     pa.ipa_en = ipa_en ? 1 : 0;
     unsigned xchunks = std::max((unsigned)pa.dims.n_chunks, sig_chunks(pa.spread.D));
     tm.begin(s);
-    hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, s, nt, pa);
+    if (with_base) {
+      // the bit-sliced dictionaries of the same node order ride in the same launch (k_node_planes: one boundary instead of two)
+      xchunks = std::max(xchunks, (unsigned)(e->W + e->KT + e->KP + 1));
+      hipLaunchKernelGGL(ykk::k_node_planes, dim3(std::max(xchunks, 1u), wgroups, 3u), dim3(ykk::kBlock), 0, s, nt, pa,
+                         base_of(perm ? e->base_ranked : e->base_canon));
+    } else {
+      hipLaunchKernelGGL(ykk::k_planes, dim3(std::max(xchunks, 1u), wgroups, spread_on ? 2u : 1u), dim3(ykk::kBlock), 0, s, nt, pa);
+    }
     tm.end(s, name);
     if (res_on && e->n_big > 0 && !fit_error) {
       // many-valued dimensions: sort every word's free values once, then one thread per word walks the sorted rows
@@ -1896,8 +1913,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       if (!ranked_walk(perm)) (void)hipMemsetAsync(e->d_rbits_c.p, 0, (size_t)e->n_big * (size_t)e->row_words * ykk::kRankBits * sizeof(u64), s);
     }
   };
-  if (res_on || spread_on) launch_ballot_planes(st, nullptr, "k_planes");
-  launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes");
+  const bool fused_planes = res_on || spread_on;
+  if (fused_planes) launch_ballot_planes(st, nullptr, "k_planes+k_base_planes", true);
+  launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes", fused_planes);
   // ---- stream B, part 3 (after the canonical ballot planes): their rank-ordered copies by bit permutation, then the
   // first feasible node of every class. Overlaps the start of k_combine.
   if (want_dec) {
@@ -1925,7 +1943,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>(), e->C <= 4096 ? 1 : 0);
     }
     tm.end(sb, "k_decide");
-    HIPCHK(hipEventRecord(e->ev_join, sb));
   }
   // ---- stream A: combine → bitmap (skipped by ykpred_eval_nodes' decision refresh: bitmap and class counts were
   // patched incrementally)
@@ -1939,7 +1956,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                        e->d_class_sig.as<int>(), e->d_sig_changed.as<int>(), e->d_class_dirty.as<int>(), e->d_class_count.as<int>());
     class_dirty = e->d_class_dirty.as<int>();
   }
-  if (!skip_combine && !dirty_only) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
+  // Threads per chunk of the class-by-class writer decide its form; with a SMALL zone B (the band layout took nearly every class)
+  // k_class_rows counts the zone-B classes as well: every class count is known before a bitmap row is written, so the per-ask
+  // scatter runs on the decision stream beside the band writer instead of behind it, and the writers add nothing to the counts.
+  const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
+  const bool counts_early = !skip_combine && !dirty_only && e->n_classes_a > 0 && e->patch_chunks == 0 && !small_chunks && e->n_classes_b <= 16384;
+  bool scattered = false;
+  if (!skip_combine && !dirty_only && !counts_early) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   if (!skip_combine) {
     // threads per group of k_combine: the smallest whole number of waves (64/128/256) whose single pass covers a row
     int tpg = ykk::kBlock;
@@ -1958,23 +1981,34 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (!dirty_only && e->n_classes_a > 0) {
       // zone A: class rows → table (and the classes' feasible counts), then the fill-pattern expansion over the band layout
       tm.begin(st);
-      hipLaunchKernelGGL(ykk::k_class_rows, dim3((unsigned)((e->n_classes_a + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
+      const int n_counted_b = counts_early ? e->n_classes_b : 0;
+      hipLaunchKernelGGL(ykk::k_class_rows, dim3((unsigned)((e->n_classes_a + n_counted_b + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, st,
                          ct, pc, e->d_class_list_a.as<int>(), e->n_classes_a, e->row_words, e->row_stride, pin_on, e->d_class_rows_a.as<u64>(),
-                         e->d_class_count.as<int>(), (const int*)nullptr);
+                         e->d_class_count.as<int>(), (const int*)nullptr, e->d_class_list_b.as<int>(), n_counted_b);
       tm.end(st, "k_class_rows");
+      if (counts_early && want_dec) {
+        // counts (this stream) and decisions (decision stream) are both final: per-ask outputs now, beside the band writer
+        HIPCHK(hipEventRecord(e->ev_counts, st));
+        HIPCHK(hipStreamWaitEvent(sb, e->ev_counts, 0));
+        tm.begin(sb);
+        hipLaunchKernelGGL(ykk::k_scatter, dim3((unsigned)((P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, sb, P,
+                           e->d_pod_class.as<int>(), e->d_class_count.as<int>(), e->d_class_best.as<int>(), e->d_key.as<u64>(),
+                           want_cnt ? (int*)e->last_counts : nullptr, (int*)e->last_decisions, want_keys ? (i64*)e->last_keys : nullptr);
+        tm.end(sb, "k_scatter");
+        scattered = true;
+      }
       const size_t lds_bytes = (size_t)2 * ykk::kBandClasses * (size_t)e->row_stride * sizeof(u64);
       if (lds_bytes > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void*)ykk::k_expand_bands, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
       tm.begin(st);
       hipLaunchKernelGGL(ykk::k_expand_bands, dim3((unsigned)ykk::kBandGroups), dim3(ykk::kBandBlock), lds_bytes, st, bitmap,
                          e->d_class_rows_a.as<u64>(), e->d_band_tab.as<ykk::BandEntry>(), e->n_bands, e->row_stride);
-      if (e->n_fix_rows > 0)
+      if (e->n_fix_rows > 0 && !counts_early)
         hipLaunchKernelGGL(ykk::k_fix_rows, dim3((unsigned)e->n_fix_rows), dim3(ykk::kBlock), 0, st, bitmap, e->d_class_rows_a.as<u64>(),
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
       tm.end(st, "k_expand_bands");
     }
     tm.begin(sz);
-    const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
     // Index rows to decode: k_walk_rows — a wave writes whole rows, the rank planes of the walked dimensions (56 bytes per word) staged
     // in LDS per workgroup; rows wider than kWalkMaxIt x 64 words go segment by segment (grid.y). Only where the device grants the LDS.
     // Segments of whole 64-word groups: as few as possible with at most kWalkMaxIt groups (register budget: 4 waves per SIMD) and an
@@ -2040,6 +2074,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       hipLaunchKernelGGL(ykk::k_combine_wave, dim3((unsigned)((e->NC + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sz, ct,
                          pc, bitmap, e->row_words, e->row_stride, pin_on, e->d_class_count.as<int>(), e->NC, class_dirty,
                          e->d_slice_desc.as<ykk::SliceDesc>(), e->d_slice_general.as<int>(), (const int*)nullptr);
+    } else if (counts_early) {
+      // one launch behind the band writer: the zone-B chunks (their counts are known: none added here) and, in further workgroups,
+      // the straddling rows of the band layout (k_fix_rows' work)
+      const ykk::FixRows fix{e->d_class_rows_a.as<u64>(), e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows};
+      const int blocks = n_run + e->n_fix_rows;
+      if (blocks > 0)
+        hipLaunchKernelGGL(ykk::k_combine, dim3((unsigned)blocks, grid.y), dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, sz, ct, pc, bitmap, e->row_words,
+                           e->row_stride, pin_on, (int*)nullptr, tpg, class_dirty, chunk_list, fix, n_run);
     } else if (n_run == 0) {
       // (no chunk outside the band layout: nothing to launch)
     } else if (small_chunks) {
@@ -2050,12 +2092,15 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     } else {
       // dynamic LDS is requested only to cap the blocks resident per CU (see combine_lds_bytes)
       hipLaunchKernelGGL(ykk::k_combine, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, sz, ct, pc, bitmap, e->row_words, e->row_stride,
-                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty, chunk_list);
+                         pin_on, e->d_class_count.as<int>(), tpg, class_dirty, chunk_list, ykk::FixRows{nullptr, nullptr, nullptr, 0}, n_run);
     }
     tm.end(sz, dirty_only ? "k_combine(dirty classes)" : "k_combine");
   }
-  if (want_dec) HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
-  if (want_dec || want_cnt) {
+  if (want_dec) {
+    HIPCHK(hipEventRecord(e->ev_join, sb));
+    HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
+  }
+  if ((want_dec || want_cnt) && !scattered) {
     tm.begin(st);
     hipLaunchKernelGGL(ykk::k_scatter, dim3((unsigned)((P + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, P,
                        e->d_pod_class.as<int>(), e->d_class_count.as<int>(), e->d_class_best.as<int>(), e->d_key.as<u64>(),
@@ -3290,7 +3335,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
     const int seg = tpg * ykk::kCombineUnroll * 2;
     dim3 grid((unsigned)e->NC, (unsigned)((e->row_stride + seg - 1) / seg));
     hipLaunchKernelGGL(ykk::k_combine, grid, dim3(ykk::kBlock), (size_t)e->combine_lds_bytes, st, ct, pl, out, e->row_stride, e->row_stride, 0,
-                       e->d_expand_count.as<int>(), tpg, (const int*)nullptr, (const int*)nullptr);
+                       e->d_expand_count.as<int>(), tpg, (const int*)nullptr, (const int*)nullptr, ykk::FixRows{nullptr, nullptr, nullptr, 0}, e->NC);
   }
   HIPCHK(hipGetLastError());
   return YKPRED_OK;

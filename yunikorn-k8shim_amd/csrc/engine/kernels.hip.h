@@ -484,7 +484,7 @@ struct BasePlanes {
   int stride;
 };
 // blockIdx.x: dictionary word (0..W-1 labels, then KT taint words, then KP port words, last = flags); blockIdx.y: group of 4 node words.
-__global__ __launch_bounds__(kBlock) void k_base_planes(NodeTable t, const int* __restrict__ perm, BasePlanes o, int n_words) {
+__device__ __forceinline__ void plane_base(const NodeTable& t, const int* __restrict__ perm, const BasePlanes& o, int n_words) {
   int word;
   const int n = plane_node(t.n, perm, &word);
   if (word >= n_words) return;
@@ -513,6 +513,10 @@ __global__ __launch_bounds__(kBlock) void k_base_planes(NodeTable t, const int* 
       o.exists[word] = ex;
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_base_planes(NodeTable t, const int* __restrict__ perm, BasePlanes o, int n_words) {
+  if ((int)blockIdx.x < t.W + t.KT + t.KP + 1) plane_base(t, perm, o, n_words);
 }
 
 struct SigPlaneArgs {
@@ -969,6 +973,18 @@ __global__ __launch_bounds__(kBlock) void k_planes(NodeTable t, PlaneArgs a) {
     if ((int)blockIdx.x * sigs_per_block(a.spread.D) < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words, a.spread_en != 0, a.ipa_en != 0);
   }
 }
+// The three node-reading plane kernels of one node order in ONE launch (they are independent of each other and each is a few
+// microseconds of latency: launched one after the other they are three boundaries on the step's critical path). blockIdx.z:
+// 0 = request-value planes, 1 = topology planes, 2 = bit-sliced dictionaries (k_base_planes).
+__global__ __launch_bounds__(kBlock) void k_node_planes(NodeTable t, PlaneArgs a, BasePlanes base) {
+  if (blockIdx.z == 0) {
+    if ((int)blockIdx.x < a.dims.n_chunks) plane_dim(t, a.perm, a.dims, a.res, a.fit_error, a.n_words);
+  } else if (blockIdx.z == 1) {
+    if ((int)blockIdx.x * sigs_per_block(a.spread.D) < a.spread.D) plane_spread(t, a.perm, a.spreads, a.spread, a.n_words, a.spread_en != 0, a.ipa_en != 0);
+  } else {
+    if ((int)blockIdx.x < t.W + t.KT + t.KP + 1) plane_base(t, a.perm, base, a.n_words);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // combine: class row = AND of its planes; stream it into every member pod's bitmap row
@@ -1090,6 +1106,20 @@ __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
   return v;
 }
 
+// The rows of the band layout that straddle a window boundary are rewritten whole from their class's row (see k_expand_bands).
+struct FixRows {
+  const u64* class_rows;  // zone-A class-row table
+  const int* rows;        // [n] physical bitmap rows
+  const int* slots;       // [n] their class's slot in the table
+  int n;
+};
+__device__ __forceinline__ void fix_row(const FixRows& f, int i, u64* __restrict__ out, int row_stride) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  if (i >= f.n) return;
+  const u64* src = f.class_rows + (size_t)f.slots[i] * row_stride;
+  u64* dst = out + (size_t)f.rows[i] * row_stride;
+  for (int w = threadIdx.x * 2; w < row_stride; w += 2 * kBlock) *(u64x2*)(dst + w) = *(const u64x2*)(src + w);
+}
 // grid.x = chunks, grid.y = row super-segments of tpg*kCombineUnroll*WPL words. The block is split into kBlock/tpg
 // thread groups (tpg = threads per group: 64, 128 or 256, a whole number of waves) that write DIFFERENT member rows
 // concurrently: wide rows (≥ 512 words, e.g. 50 k nodes) use one group of 256 threads, narrow rows of a node shard
@@ -1101,9 +1131,16 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
                                                     int pin_enabled, int* __restrict__ class_count, int tpg,
                                                     const int* __restrict__ class_dirty /* null = every class */,
                                                     const int* __restrict__ chunk_list /* null: grid.x = every chunk; else the chunks
-                                                    to run (the full pass lists the zone-B chunks: no workgroup for the others) */) {
+                                                    to run (the full pass lists the zone-B chunks: no workgroup for the others) */,
+                                                    FixRows fix /* workgroups n_run .. n_run + fix.n - 1 rewrite the band layout's
+                                                    straddling rows (k_fix_rows' work in this launch); fix.n = 0: none */,
+                                                    int n_run) {
   // pin_enabled bit 0: NodeName filter on; bit 1: a Filter has no PreFilter state ⇒ every pair fails
   constexpr int WPL = 2;  // adjacent words per thread: one wave store writes 64 x 16 contiguous bytes
+  if ((int)blockIdx.x >= n_run) {
+    if (blockIdx.y == 0) fix_row(fix, (int)blockIdx.x - n_run, bitmap, row_stride);
+    return;
+  }
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int chunk = chunk_list ? chunk_list[blockIdx.x] : (int)blockIdx.x;
@@ -1141,7 +1178,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
     // feasible-node count of the class: wave reduce, one atomic per wave (thread group 0 holds the whole segment)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
-    if (lane == 0 && pc) atomicAdd(&class_count[cls], pc);
+    if (lane == 0 && pc && class_count) atomicAdd(&class_count[cls], pc);  // (null: k_class_rows counted this class already)
   }
   // member rows: lane i of every wave holds the bitmap row of member i (one coalesced 256 B load), broadcast by v_readlane
   int mine = lane < len ? ct.members[begin + lane] : 0;
@@ -1533,15 +1570,19 @@ struct BandEntry {  // what one workgroup needs during one band
 };
 
 // one wave per zone-A class: class row = AND of its planes (+ NodeName pin), written to the class-row table
+// (class_list_b / n_b: further classes whose feasible COUNT is wanted here and whose row is not — the zone-B classes of a pass
+// whose zone B is small: every class count is then known before a single bitmap row is written, see ykpred_eval)
 __global__ __launch_bounds__(kBlock) void k_class_rows(ClassTable ct, Planes pl, const int* __restrict__ class_list, int n_list, int row_words,
                                                        int row_stride, int pin_enabled, u64* __restrict__ row_table,
-                                                       int* __restrict__ class_count, const int* __restrict__ class_dirty) {
+                                                       int* __restrict__ class_count, const int* __restrict__ class_dirty,
+                                                       const int* __restrict__ class_list_b, int n_b) {
   typedef u64 u64x2 __attribute__((ext_vector_type(2)));
   const bool all_fail = pin_enabled & 2;
   pin_enabled &= 1;
   const int k = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  if (k >= n_list) return;
-  const int cls = class_list[k];
+  if (k >= n_list + n_b) return;
+  const bool store = k < n_list;
+  const int cls = store ? class_list[k] : class_list_b[k - n_list];
   if (class_dirty && !class_dirty[cls]) return;
   const int lane = threadIdx.x % kWave;
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
@@ -1567,7 +1608,7 @@ __global__ __launch_bounds__(kBlock) void k_class_rows(ClassTable ct, Planes pl,
       }
     }
     pc += __popcll(x.x) + __popcll(x.y);
-    *(u64x2*)(dst + w) = x;
+    if (store) *(u64x2*)(dst + w) = x;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off, kWave);
