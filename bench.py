@@ -305,30 +305,37 @@ def json_ingest_leg(pkg, dev, a, gang):
     return out
 
 
-def device_round(pm, n_asks, check_prefix):
-    """One conflict-resolved round of the first n_asks asks of a loaded manager (apply = False: the tables stay as they are), the
-    first `check_prefix` decisions against the oracle's sequential loop on one host core."""
+def device_rounds(pm, sizes, check_prefix):
+    """Conflict-resolved rounds of the first n asks of a loaded manager for every n in `sizes` (apply = False: the tables stay as they
+    are, so every round starts from the same state and the rounds are prefixes of one another), the first `check_prefix` decisions
+    of each against ONE run of the oracle's sequential loop on one host core (its PreFilter-once form: the per-candidate form needs
+    seconds per ask once topology constraints are on)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as orc
     pm.evaluate(decisions=True)
     pm.synchronize()
-    asks = np.arange(min(n_asks, pm.num_pods), dtype=np.int32)
-    before = pm.round_stats()
-    pm.allocate_round(asks=asks[:64], apply=False)  # (first call: scratch allocation, the specs' effects)
+    k = min(check_prefix, pm.num_pods)
+    o = orc.Oracle(pm.dump_snapshot(pods=np.arange(k, dtype=np.int32), compact=True))
     t0 = time.perf_counter()
-    got = pm.allocate_round(asks=asks, apply=False)
-    t_round = time.perf_counter() - t0
-    after = pm.round_stats()
-    k = min(check_prefix, len(asks))
-    o = orc.Oracle(pm.dump_snapshot(pods=asks[:k], compact=True))
-    t0 = time.perf_counter()
-    want = o.allocate_sequential()
+    want = o.allocate_sequential(prefilter_once=True)
     t_cpu = time.perf_counter() - t0
-    return {"nodes": pm.num_nodes, "asks": int(len(asks)), "allocated": int((got >= 0).sum()), "distinct_nodes": int(len(np.unique(got[got >= 0]))),
-            "allocations_per_sec": len(asks) / t_round, "round_ms": round(t_round * 1e3, 2), "us_per_ask": round(t_round / len(asks) * 1e6, 2),
-            "on_device": bool(after["rounds_on_device"] == before["rounds_on_device"] + 2),
-            "asks_one_by_one": int(after["asks_one_by_one"] - before["asks_one_by_one"]),
-            "cpu_sequential_per_sec": k / t_cpu, "cpu_cores": 1, "checked_decisions": int(k), "verified": bool(np.array_equal(got[:k], want))}
+    out = []
+    for n_asks in sizes:
+        asks = np.arange(min(n_asks, pm.num_pods), dtype=np.int32)
+        before = pm.round_stats()
+        pm.allocate_round(asks=asks[:64], apply=False)  # (first call: scratch allocation, the specs' effects)
+        t0 = time.perf_counter()
+        got = pm.allocate_round(asks=asks, apply=False)
+        t_round = time.perf_counter() - t0
+        after = pm.round_stats()
+        kk = min(k, len(asks))
+        out.append({"nodes": pm.num_nodes, "asks": int(len(asks)), "allocated": int((got >= 0).sum()),
+                    "distinct_nodes": int(len(np.unique(got[got >= 0]))),
+                    "allocations_per_sec": len(asks) / t_round, "round_ms": round(t_round * 1e3, 2), "us_per_ask": round(t_round / len(asks) * 1e6, 2),
+                    "on_device": bool(after["rounds_on_device"] == before["rounds_on_device"] + 2),
+                    "asks_one_by_one": int(after["asks_one_by_one"] - before["asks_one_by_one"]),
+                    "cpu_sequential_per_sec": k / t_cpu, "cpu_cores": 1, "checked_decisions": int(kk), "verified": bool(np.array_equal(got[:kk], want[:kk]))})
+    return out
 
 
 def allocation_round_leg(pkg, dev, big_pm=None, big_asks=2000):
@@ -371,11 +378,10 @@ def allocation_round_leg(pkg, dev, big_pm=None, big_asks=2000):
     finally:
         pm.close()
     if big_pm is not None:
-        out["main_workload_round"] = device_round(big_pm, big_asks, big_asks)
-        # the round that moves thousands of nodes: 20 000 asks of the same workload; the sequential oracle
-        # needs minutes for that many at 50 000 nodes, so it checks the first `big_asks` decisions — a prefix of a sequential
-        # round depends on nothing behind it
-        out["main_workload_round_20k"] = device_round(big_pm, 20_000, big_asks)
+        # a round of the first `big_asks` asks of the main workload, and the round that moves thousands of nodes:
+        # 20 000 asks of the same workload. The sequential oracle needs minutes for that many at 50 000 nodes, so it checks the first
+        # `big_asks` decisions of both — a prefix of a sequential round depends on nothing behind it
+        out["main_workload_round"], out["main_workload_round_20k"] = device_rounds(big_pm, [big_asks, 20_000], big_asks)
     out["definition"] = ("decisions/sec, conflict-resolved: ask i is decided with asks 0..i-1 of the round assumed on their nodes — identical to the "
                          "oracle run sequentially; `decisions_per_sec` of the line is the SNAPSHOT form (every ask against one state)")
     return out
@@ -457,7 +463,7 @@ def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
             # a conflict-resolved round of this workload's first asks (configs[4]: hard spread constraints on a tenth of the
             # templates — the histograms move with every assumed pod, on the device)
             try:
-                out["allocation_round"] = device_round(pm, round_asks, 600)
+                out["allocation_round"] = device_rounds(pm, [round_asks], 300)[0]
             except Exception as exc:  # noqa: BLE001
                 out["allocation_round"] = {"error": str(exc)}
     finally:
@@ -789,6 +795,15 @@ def main():
         }
         if gather:
             out["bitmap_allgather"] = gather
+            # the same step for consumers that need decisions + feasible counts only (the core's allocation loop): nothing but 16 bytes
+            # per ask crosses the links (ykpred_exchange_decisions) — the configuration that can scale with the shard evaluation;
+            # `python bench.py --gpus N --no-gather` times it as the line's own step
+            out["decisions_only"] = {"ms_per_step": gather["step_without_gather_ms"], "evals_per_sec": gather["evals_per_sec_without_gather"],
+                                     "decisions_per_sec": float(P) / (gather["step_without_gather_ms"] * 1e-3), "link_bytes_per_ask": 16,
+                                     "note": "measured outside the timed region of this line (same engine, same outputs, gather switched off)"}
+        elif world > 1:
+            out["decisions_only"] = {"ms_per_step": ms_per_step, "evals_per_sec": evals / elapsed, "decisions_per_sec": float(P) * a.steps / elapsed,
+                                     "link_bytes_per_ask": 16, "note": "this line: the bitmap gather is not in the step"}
         if variants is not None:
             out["variants"] = variants
         if end_to_end is not None:

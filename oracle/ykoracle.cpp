@@ -1450,7 +1450,8 @@ int orc_decide_once(void* h, int pod, unsigned pre_mask, unsigned filt_mask, int
 //     → NodeInfo.AddPod (:363): the node's Requested, pod list (labels for the topology plugins), used host ports grow.
 // out[i] = node index or -1 (no node fits: the ask stays pending, nothing is assumed). The snapshot is MUTATED.
 // The node order is kept in an ordered set keyed by (score, name) and only the allocated node is re-keyed — what the core's
-// sorted node collection does; `early_exit` = 0 evaluates every node instead (the naive argmin form; same answers).
+// sorted node collection does; `early_exit` = 0 evaluates every node instead (the naive argmin form; same answers), 2 = early
+// exit with the ask's PreFilter pass run once instead of once per candidate (same answers; what large clusters can afford).
 int orc_allocate_sequential(void* h, const int* pods, int np, unsigned pre_mask, unsigned filt_mask, int* out, int early_exit) {
   Snapshot* s = static_cast<Snapshot*>(h);
   struct Key {
@@ -1474,7 +1475,18 @@ int orc_allocate_sequential(void* h, const int* pods, int np, unsigned pre_mask,
     const size_t pi = static_cast<size_t>(pods ? pods[i] : i);
     orc::Pod* p = const_cast<orc::Pod*>(s->pending[pi]);
     int best = -1;
-    if (early_exit) {
+    if (early_exit == 2) {
+      // the PreFilter pass of the ask ONCE, its outcome replayed for every candidate node (orc_eval_rows' form, held equal to the
+      // per-pair form by tests/test_oracle_golden.py and tests/test_oracle_sequential.py): nothing changes between the candidates
+      // of one ask, and the per-pair form costs a walk over every pod of the cluster per CANDIDATE once an ask carries a topology
+      // constraint — minutes per ask at 10^5 nodes
+      const orc::PreFilterReplay replay = orc::prefilter_once(*s, *p, pre_mask);
+      for (const Key& k : order)
+        if (orc::pod_fits_node_replayed(replay, *p, s->nodes[k.idx], filt_mask).fit) {
+          best = static_cast<int>(k.idx);
+          break;
+        }
+    } else if (early_exit) {
       for (const Key& k : order)
         if (orc::pod_fits_node(*s, *p, s->nodes[k.idx], pre_mask, filt_mask).fit) {
           best = static_cast<int>(k.idx);

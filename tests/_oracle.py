@@ -152,12 +152,15 @@ class Oracle:
         return c.value, b.value
 
 
-    def allocate_sequential(self, pods=None, pre_mask=ALL, filt_mask=ALL, early_exit=True):
+    def allocate_sequential(self, pods=None, pre_mask=ALL, filt_mask=ALL, early_exit=True, prefilter_once=False):
         """The loop yunikorn-core drives: decide pods[i] on the current state (first fit in bin-pack order), AssumePod it, go on.
-        → node index per ask (-1: none fits). MUTATES the loaded snapshot (the assumed asks now sit on their nodes)."""
+        → node index per ask (-1: none fits). MUTATES the loaded snapshot (the assumed asks now sit on their nodes).
+        prefilter_once: the ask's PreFilter pass once instead of once per candidate node (same answers — held equal by
+        tests/test_oracle_sequential.py; the only form large clusters with topology constraints can afford)."""
         pods = np.arange(self.num_pods, dtype=np.int32) if pods is None else np.ascontiguousarray(pods, dtype=np.int32)
         out = np.full(len(pods), -1, dtype=np.int32)
-        lib().orc_allocate_sequential(self._h, pods.ctypes.data, len(pods), pre_mask, filt_mask, out.ctypes.data, 1 if early_exit else 0)
+        mode = 2 if (prefilter_once and early_exit) else (1 if early_exit else 0)
+        lib().orc_allocate_sequential(self._h, pods.ctypes.data, len(pods), pre_mask, filt_mask, out.ctypes.data, mode)
         return out
 
 

@@ -33,6 +33,7 @@ def test_sequential_loop_equals_one_ask_at_a_time(seed, kw):
     assert np.array_equal(got, want)
     assert (got >= 0).sum() >= 5
     assert np.array_equal(orc.Oracle(snap).allocate_sequential(early_exit=False), want)  # the argmin form: same answers
+    assert np.array_equal(orc.Oracle(snap).allocate_sequential(prefilter_once=True), want)  # PreFilter once per ask: same answers
     o2 = orc.Oracle(final)
     for n in range(o.num_nodes):
         assert o.node_info(n) == o2.node_info(n)

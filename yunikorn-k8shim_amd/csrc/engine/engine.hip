@@ -263,7 +263,8 @@ struct ykpred_engine {
   DevBuf d_slice_general;   // one int: chunks of the pass that k_walk_rows leaves to k_combine_wave
   DevBuf d_slice_desc;      // [NC] chunk descriptors of k_walk_rows (k_slice_desc, refilled per pass)
   DevBuf d_pfx_r;           // [n_big][row_words] running maximum of the free values along the bin-pack order (k_dim_prefix_max)
-  DevBuf d_idx_c, d_idx_r;  // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical / rank order
+  DevBuf d_idx_c;           // index rows of the walked dimensions: [fam_res.D][idx_stride] bytes, canonical order
+  DevBuf d_win_r;           // rank order: the 64-byte WINDOW of every index row (k_dim_walk_window): [fam_res.D][64]
   int idx_stride = 0;
   DevBuf d_sig_tol, d_sig_tolflags, d_sig_ports, d_swanted;                    // [Dtol][KT], [Dtol], [Dtol][KP]; [S][KP]
   DevBuf d_sig_aff_flags, d_sig_aff_off, d_sig_aff_terms, d_sig_pre_off, d_sig_pre_terms;
@@ -1069,13 +1070,16 @@ ykk::Planes ranked_planes_of(const ykpred_engine* e, unsigned pre, unsigned filt
   auto ranked_of = [&](const Family& f) { return e->planes_ranked.as<u64>() + (size_t)f.base * e->row_stride; };
   int* first_r = with_first ? e->d_first_r.as<int>() : nullptr;
   ykk::Planes pr{res_on ? ranked_of(e->fam_res) : nullptr, ranked_of(e->fam_tol), aff_on ? ranked_of(e->fam_aff) : nullptr,
-                 spread_on ? ranked_of(e->fam_spread) : nullptr, e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_r.as<unsigned char>(),
+                 spread_on ? ranked_of(e->fam_spread) : nullptr, e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, nullptr,
                  e->idx_stride, e->d_pmask_r.as<u64>(), e->row_words, first_r, e->fam_res.base, e->fam_tol.base, e->fam_aff.base,
-                 e->fam_spread.base, 0, nullptr, nullptr, nullptr};
+                 e->fam_spread.base, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   pr.n_big = res_on ? e->n_big : 0;
-  if (first_r && res_on && e->n_big > 0 && !fit_error) {
+  if (res_on && e->n_big > 0) {
+    // index rows in rank order: a 64-byte window per row + the words' sorted free lists for everything outside it
+    pr.res_win = e->d_win_r.as<unsigned char>();
+    pr.sfree = e->d_sfree_r.as<i64>();
     pr.res_val = e->d_dim_val.as<i64>();
-    pr.pfx = e->d_pfx_r.as<i64>();
+    if (!fit_error) pr.pfx = e->d_pfx_r.as<i64>();  // (Filter without PreFilter state: every mask table is empty, no window is consulted)
   }
   return pr;
 }
@@ -1223,7 +1227,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_idx_c, &e->d_idx_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1704,11 +1708,18 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     // (a forced row stride — unequal shards — may exceed the rounded row length: consumers address index bytes by row word)
     const int idx_stride_before = e->idx_stride;
     e->idx_stride = (std::max(e->row_words, e->row_stride) + 63) / 64 * 64;
-    for (DevBuf* b : {&e->d_idx_c, &e->d_idx_r}) {
+    for (DevBuf* b : {&e->d_idx_c}) {
       const size_t need = (size_t)e->fam_res.D * (size_t)e->idx_stride;
       if (b->cap < need || !b->p || idx_stride_before != e->idx_stride) {
         HIPCHK(b->ensure(need));
         HIPCHK(hipMemsetAsync(b->p, 64, need, st));  // bytes past the row decode to entry 64 of a mask table: no node
+      }
+    }
+    {  // (window bytes nobody wrote are never read: a word is looked up in a window only where the walk stored it)
+      const size_t need = (size_t)e->fam_res.D * 64;
+      if (e->d_win_r.cap < need || !e->d_win_r.p) {
+        HIPCHK(e->d_win_r.ensure(need));
+        HIPCHK(hipMemsetAsync(e->d_win_r.p, 64, need, st));
       }
     }
   }
@@ -1766,14 +1777,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
-                 nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+                 nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   // first non-zero word of every rank-ordered plane row (whole buffer: families at their base rows), reset per pass
   int* first_r = nullptr;
   if ((a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->decide_skip) {
     HIPCHK(e->d_first_r.ensure((size_t)std::max(e->plane_rows_alloc, 1) * sizeof(int)));
     first_r = e->d_first_r.as<int>();
   }
-  if (first_r && res_on && e->n_big > 0 && !fit_error) HIPCHK(e->d_pfx_r.ensure((size_t)e->n_big * (size_t)std::max(e->row_words, 1) * sizeof(i64)));
+  if (want_dec && res_on && e->n_big > 0 && !fit_error) HIPCHK(e->d_pfx_r.ensure((size_t)e->n_big * (size_t)std::max(e->row_words, 1) * sizeof(i64)));
   ykk::Planes pr = ranked_planes_of(e, pre, filt, spread_on, first_r != nullptr);
   pc.n_big = pr.n_big;
   pc.rbits = e->d_rbits_c.as<u64>();
@@ -1900,15 +1911,20 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                       e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>()};
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
-      hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords))), dim3(ykk::kBlock),
-                         0, s, dw, (ranked ? e->d_idx_r : e->d_idx_c).as<unsigned char>(), e->idx_stride);
-      if (ranked && pr.pfx)  // running maximum of the free values along the bin-pack order: where a value's row can start (k_decide)
+      const dim3 walk_grid((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords)));
+      if (!ranked) {
+        hipLaunchKernelGGL(ykk::k_dim_walk, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_idx_c.as<unsigned char>(), e->idx_stride);
+      } else {
+        // running maximum of the free values along the bin-pack order: where a value's row can start (k_decide) — and the window
+        // of the row that is worth writing in rank order (k_dim_walk_window)
         hipLaunchKernelGGL(ykk::k_dim_prefix_max, dim3((unsigned)e->n_big), dim3(ykk::kPfxBlock), 0, s, dw, e->d_pfx_r.as<i64>());
+        hipLaunchKernelGGL(ykk::k_dim_walk_window, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+      }
       tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
     } else if (res_on && e->n_big > 0) {
       // Filter without PreFilter state: the walked rows fit nowhere like every other row of the family — position 64 of every
       // mask table is the empty mask (the tables are only written by k_dim_sort: clear them as well)
-      (void)hipMemsetAsync((ranked_walk(perm) ? e->d_idx_r : e->d_idx_c).p, 64, (size_t)e->fam_res.D * (size_t)e->idx_stride, s);
+      if (!ranked_walk(perm)) (void)hipMemsetAsync(e->d_idx_c.p, 64, (size_t)e->fam_res.D * (size_t)e->idx_stride, s);
       (void)hipMemsetAsync((ranked_walk(perm) ? e->d_pmask_r : e->d_pmask_c).p, 0, (size_t)e->n_big * (size_t)e->row_words * 65 * sizeof(u64), s);
       if (!ranked_walk(perm)) (void)hipMemsetAsync(e->d_rbits_c.p, 0, (size_t)e->n_big * (size_t)e->row_words * ykk::kRankBits * sizeof(u64), s);
     }
@@ -3310,7 +3326,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
-  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr};
+  ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));
     hipLaunchKernelGGL(ykk::k_pick_class_rows, dim3((unsigned)e->n_classes_a), dim3(ykk::kBlock), 0, st, class_rows, e->d_class_list_a.as<int>(),

@@ -440,6 +440,73 @@ __global__ __launch_bounds__(kPfxBlock) void k_dim_prefix_max(DimWalk a, i64* __
   }
 }
 
+// Rank order: the WINDOW of every index row instead of the row (Planes::res_win). The decision scan of a class begins at the
+// first word its rows can have a bit in — for an index row of value v the first word whose running maximum of the free values
+// reaches v (pfx) — and finds its node within a few words, so of the 784 bytes of a rank-ordered row it read a dozen; the rows
+// were written whole only for that (0.45 ms and 0.8 GB per pass at 10^6 rows). A thread owns four adjacent words as in
+// k_dim_walk and stores a row's dword only when its word group lies in the row's window [start & ~3, +64): start <= w0 + 3 and
+// start >= w0 - 60, i.e. pfx[w0 - 61] < v <= pfx[w0 + 3] — a contiguous run of the ascending values of a chunk, and no run at
+// all for most (chunk, thread) pairs: a twelfth of the walk's work.
+__global__ __launch_bounds__(kBlock) void k_dim_walk_window(DimWalk a, const i64* __restrict__ pfx, unsigned char* __restrict__ win) {
+  const int chunk = blockIdx.x;
+  const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
+  const int lane = threadIdx.x % kWave;
+  const int w0 = (blockIdx.y * kBlock + threadIdx.x) * kWalkWords;
+  if (w0 - lane * kWalkWords >= a.n_words) return;  // whole wave beyond the row
+  const bool live = w0 < a.n_words;
+  const i64 kMax = 0x7fffffffffffffffll, kMin = (i64)0x8000000000000000ull;
+  const i64* px = pfx + (size_t)big * a.n_words;
+  const i64 hi = live ? px[min(w0 + 3, a.n_words - 1)] : kMin;  // v <= hi: the row can have a bit at or before this word group
+  const i64 lo = (live && w0 >= 61) ? px[w0 - 61] : kMin;         // v > lo:  ... and not before word w0 - 60
+  const i64 v_first = a.val[a.order[begin]], v_last = a.val[a.order[begin + len - 1]];
+  const bool mine = live && hi > lo && v_last > lo && v_first <= hi;
+  if (__ballot(mine) == 0) return;  // (wave-uniform: the value exchanges below need every lane)
+  const i64* sf[kWalkWords];
+  int ptr[kWalkWords];
+  i64 next[kWalkWords];
+#pragma unroll
+  for (int j = 0; j < kWalkWords; ++j) {
+    const int w = min(w0 + j, a.n_words - 1);
+    sf[j] = a.sfree + ((size_t)big * a.n_words + w) * 64;
+    ptr[j] = 0;
+    next[j] = mine ? sf[j][0] : kMax;
+  }
+  bool started = false;
+  for (int i0 = 0; i0 < len; i0 += kWave) {
+    const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
+    const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
+    const int m = min(kWave, len - i0);
+    for (int i = 0; i < m; ++i) {
+      const i64 v = readlane_i64(my_val, i);
+      const int row = __builtin_amdgcn_readlane(my_row, i);
+      if (!(mine && v > lo && v <= hi)) continue;
+      if (!started) {  // the first row of this thread's run: one binary search per word, then the walk only advances
+        started = true;
+#pragma unroll
+        for (int j = 0; j < kWalkWords; ++j) {
+          int l = 0, h = 64;
+          while (l < h) {
+            const int mid = (l + h) >> 1;
+            if (sf[j][mid] < v) l = mid + 1; else h = mid;
+          }
+          ptr[j] = l;
+          next[j] = l < 64 ? sf[j][l] : kMax;
+        }
+      }
+      unsigned packed = 0;
+#pragma unroll
+      for (int j = 0; j < kWalkWords; ++j) {
+        while (next[j] < v) {
+          ++ptr[j];
+          next[j] = ptr[j] < 64 ? sf[j][ptr[j]] : kMax;
+        }
+        packed |= (unsigned)ptr[j] << (8 * j);
+      }
+      *(unsigned*)(win + (size_t)row * 64 + (w0 & 63)) = packed;
+    }
+  }
+}
+
 // NodeAffinity PreFilter + Filter (A.5). Signature = (flags, Filter DNF, PreFilter node-name DNF).
 struct AffSigs {
   const unsigned* flags;  // [D]
@@ -1019,6 +1086,11 @@ struct Planes {
   const i64* pfx;         // [walked dimensions][n_words] rank order only: largest free value among the nodes of words 0..w
                           // (k_dim_prefix_max) — a row of value v has no bit before the first word with pfx >= v
   const u64* rbits;       // [walked dimensions][kRankBits][n_words] the same tables bit-sliced (k_walk_rows); null: not kept (rank order)
+  // Rank order keeps only a WINDOW of every index row (res_idx is null then): the 64 bytes of the words [start & ~3, +64), start =
+  // the first word the row can have a bit in (pfx) — the decision scan begins there and rarely gets further; byte of word w at
+  // res_win[row * 64 + (w & 63)]. A word outside the window is decoded from the word's sorted free list instead (sfree).
+  const unsigned char* res_win;  // [rows][64]
+  const i64* sfree;              // [walked dimensions][n_words][64] ascending free values of every word (k_dim_sort)
 };
 constexpr int kMaxClassRows = 3 + 1 + kMaxR;
 constexpr int kMaxIdxRows = 2;     // sorted-walk dimensions (further many-valued dimensions stay on ballot planes)
@@ -1031,6 +1103,11 @@ struct ClassRows {
   int n;
   const unsigned char* irow[kMaxIdxRows];  // index rows (sorted-walk dimensions) ...
   const u64* ipm[kMaxIdxRows];             // ... and the mask table of their dimension
+  // windowed index rows (rank order): irow = the row's 64-byte window; the value, the window's first word group (words / 4) and the
+  // sorted free lists of the dimension for the words outside it. isf == null: irow is a whole row.
+  const i64* isf[kMaxIdxRows];
+  i64 ival[kMaxIdxRows];
+  int ig4[kMaxIdxRows];
   int ni;
   int start;                               // no row of the class has a bit before this word (kNoWord: some row is empty)
 };
@@ -1045,6 +1122,9 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
   for (int i = 0; i < kMaxIdxRows; ++i) {
     cr.irow[i] = nullptr;
     cr.ipm[i] = nullptr;
+    cr.isf[i] = nullptr;
+    cr.ival[i] = 0;
+    cr.ig4[i] = 0x3fffffff;
   }
   auto add = [&](const u64* p, int global_row) {
 #pragma unroll
@@ -1063,14 +1143,8 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
       if (r < 0) continue;
       const int big = r >> kRowBigShift, rid = r & ((1 << kRowBigShift) - 1);
       if (big) {
-#pragma unroll
-        for (int i = 0; i < kMaxIdxRows; ++i)
-          if (i == cr.ni) {
-            cr.irow[i] = pl.res_idx + (size_t)rid * pl.idx_stride;
-            cr.ipm[i] = pl.pmask + (size_t)(big - 1) * pl.n_words * 65;
-          }
-        ++cr.ni;
-        if (pl.first && pl.pfx) {
+        int first_word = -1;  // the first word the row can have a bit in (-1: not known)
+        if (pl.pfx) {
           // index rows keep no first-word table (10^6 rows); the walked dimension is monotone instead: nodes with free >= v
           // first appear in the first word whose running maximum reaches v — one binary search in an L1-resident array
           const i64 v = pl.res_val[rid];
@@ -1080,8 +1154,23 @@ __device__ __forceinline__ ClassRows class_rows(const Planes& pl, int sr, int st
             const int mid = (lo + hi) >> 1;
             if (px[mid] < v) lo = mid + 1; else hi = mid;
           }
-          cr.start = max(cr.start, lo < pl.n_words ? lo : kNoWord);
+          first_word = lo < pl.n_words ? lo : kNoWord;
+          if (pl.first) cr.start = max(cr.start, first_word);
         }
+#pragma unroll
+        for (int i = 0; i < kMaxIdxRows; ++i)
+          if (i == cr.ni) {
+            cr.ipm[i] = pl.pmask + (size_t)(big - 1) * pl.n_words * 65;
+            if (pl.res_win) {
+              cr.irow[i] = pl.res_win + (size_t)rid * 64;
+              cr.isf[i] = pl.sfree + (size_t)(big - 1) * pl.n_words * 64;
+              cr.ival[i] = pl.res_val[rid];
+              cr.ig4[i] = (first_word >= 0 && first_word != kNoWord) ? (first_word >> 2) : 0x3fffffff;  // (no window: every word from the lists)
+            } else {
+              cr.irow[i] = pl.res_idx + (size_t)rid * pl.idx_stride;
+            }
+          }
+        ++cr.ni;
       } else {
         add(pl.res + (size_t)rid * pl.stride, pl.base_res + rid);
       }
@@ -1094,7 +1183,24 @@ __device__ __forceinline__ u64 class_idx_word(const ClassRows& cr, int w) {
   u64 v = ~0ull;
 #pragma unroll
   for (int i = 0; i < kMaxIdxRows; ++i)
-    if (i < cr.ni) v &= cr.ipm[i][(size_t)w * 65 + min((int)cr.irow[i][w], 64)];  // (a byte is 0..64; the clamp keeps a stray one inside the table)
+    if (i < cr.ni) {
+      int pos;
+      if (!cr.isf[i]) {
+        pos = cr.irow[i][w];
+      } else if ((unsigned)((w >> 2) - cr.ig4[i]) < 16u) {
+        pos = cr.irow[i][w & 63];  // inside the row's window
+      } else {
+        // outside it: the number of the word's free values below the row's value (what k_dim_walk would have stored)
+        const i64* sf = cr.isf[i] + (size_t)w * 64;
+        int lo = 0, hi = 64;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (sf[mid] < cr.ival[i]) lo = mid + 1; else hi = mid;
+        }
+        pos = lo;
+      }
+      v &= cr.ipm[i][(size_t)w * 65 + min(pos, 64)];  // (a byte is 0..64; the clamp keeps a stray one inside the table)
+    }
   return v;
 }
 __device__ __forceinline__ u64 class_word(const ClassRows& cr, int w) {
