@@ -126,6 +126,18 @@ def test_allocation_round_kwok_cluster_with_hard_spread_constraints(pm):
     assert (got >= 0).sum() > 1000 and pm.layout().num_classes > 60
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_allocation_round_runs_of_one_template(pm, seed):
+    """Asks arrive template by template (a Deployment's replicas, a task group's members): a run of one spec lands on one node while
+    it fits, and the device decides such a run in one step — as many asks as the node's free resources and pod slots hold, at most
+    up to the next multiple of 64 of the round. Small nodes (3 to 8 pod slots, a few cores) end the runs early and in the middle
+    of the 64-ask windows; pins, host ports and topology constraints inside the stream break them."""
+    snap = _seqgen.competing(500 + seed, n_nodes=30, n_pods=400, ports=seed == 2, spread=seed == 3)
+    snap["pods"].sort(key=lambda p: (p["metadata"]["labels"]["app"], p["metadata"]["name"]))
+    got = round_against_oracle(pm, snap, expect_device=True)
+    assert (got >= 0).sum() > 40
+
+
 def test_allocation_round_kwok_cluster(pm):
     """KWOK-style nodes (random utilisation, 110 slots, taints, selectors) and 4 000 asks of 40 templates: long runs of asks pile
     onto the same node until its slots or resources run out."""

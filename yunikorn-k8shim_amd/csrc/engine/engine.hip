@@ -2664,17 +2664,26 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   const bool live_ports = port_asks || (ports_on && e->fx_ports && fx_current);
   const size_t N = (size_t)std::max(e->N, 1), R = (size_t)e->R, C = (size_t)std::max(e->C, 1), RW = (size_t)std::max(e->row_words, 1);
   const size_t G = topo_on ? (size_t)std::max(e->spread_constraints, 1) : 0, cells = topo_on ? (size_t)std::max<int64_t>(e->spread_cells, 1) : 0;
-  // scratch layout, 8-byte pieces first: Requested copy | moved keys | moved bits | port words | pod counts | cursors | moved list | asks | out |
-  // n_moved | histogram copy | minimum copy | raw minima | domains at the minimum | present domains
+  // scratch layout (8-byte aligned pieces): the node-indexed copies of what a round changes (Requested, pod counts, port words), the
+  // round's bookkeeping (moved bits in rank order, class cursors, node -> slot), the slot columns of the moved nodes, the bitsets
+  // over slots (dead nodes; per class: slots it failed on), asks / decisions, and the live PreFilter state of the topology plugins
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t at = off;
     off += (bytes + 7) / 8 * 8;
     return at;
   };
-  const size_t o_req = take(R * N * sizeof(i64)), o_key = take(N * sizeof(u64)), o_bits = take(RW * sizeof(u64)),
+  const size_t cap = N, cap64 = (N + 63) / 64, Wc = (size_t)std::min(e->W, ykk::kMaxW), KP1 = (size_t)std::max(e->KP, 1), KD1 = (size_t)std::max(e->KD, 1);
+  // the "failed before" bits of every class: kept while they fit in a quarter of a GB (2 061 classes x 50 000 nodes: 13 MB; a
+  // population with 10^6 classes does without them and evaluates every live slot)
+  const bool keep_failed = C * cap64 * sizeof(u64) <= ((size_t)256 << 20);
+  const size_t o_req = take(R * N * sizeof(i64)), o_bits = take(RW * sizeof(u64)),
                o_ports = take(live_ports ? (size_t)e->KP * N * sizeof(u64) : 0), o_cnt = take(N * sizeof(int)), o_cur = take(C * sizeof(int)),
-               o_list = take(N * sizeof(int)), o_asks = take((size_t)n_asks * sizeof(int)), o_out = take((size_t)n_asks * sizeof(int)),
+               o_slot = take(N * sizeof(int)), o_mnode = take(cap * sizeof(int)), o_mtie = take(cap * sizeof(int)), o_mkey = take(cap * sizeof(u64)),
+               o_mfree = take(R * cap * sizeof(i64)), o_mroom = take(cap * sizeof(int)), o_mports = take(KP1 * cap * sizeof(u64)),
+               o_mtaint = take((size_t)e->KT * cap * sizeof(u64)), o_mlabel = take(Wc * cap * sizeof(u64)), o_mdom = take(KD1 * cap * sizeof(int)),
+               o_mflags = take(cap * sizeof(unsigned)), o_dead = take(cap64 * sizeof(u64)), o_failed = take(keep_failed ? C * cap64 * sizeof(u64) : 0),
+               o_asks = take((size_t)n_asks * sizeof(int)), o_out = take((size_t)n_asks * sizeof(int)),
                o_nm = take(sizeof(int)), o_hist = take(cells * sizeof(int)), o_minv = take(G * sizeof(int)), o_mn = take(G * sizeof(int)),
                o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int));
   HIPCHK(e->d_round.ensure(off));
@@ -2684,6 +2693,9 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   if (live_ports) HIPCHK(hipMemcpyAsync(base + o_ports, e->d_ports.p, (size_t)e->KP * (size_t)e->N * sizeof(u64), hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemsetAsync(base + o_bits, 0, RW * sizeof(u64), st));
   HIPCHK(hipMemsetAsync(base + o_cur, 0xff, C * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(base + o_slot, 0xff, N * sizeof(int), st));
+  HIPCHK(hipMemsetAsync(base + o_dead, 0, cap64 * sizeof(u64), st));
+  if (keep_failed) HIPCHK(hipMemsetAsync(base + o_failed, 0, C * cap64 * sizeof(u64), st));
   HIPCHK(hipMemsetAsync(base + o_nm, 0, sizeof(int), st));
   HIPCHK(hipMemcpyAsync(base + o_asks, asks, (size_t)n_asks * sizeof(int), hipMemcpyHostToDevice, st));
   ykk::NodeTable nt = node_table(e);
@@ -2713,9 +2725,22 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   ra.ports = live_ports ? (u64*)(base + o_ports) : nullptr;
   ra.moved_bits = (u64*)(base + o_bits);
   ra.cursor = (int*)(base + o_cur);
-  ra.moved_list = (int*)(base + o_list);
-  ra.moved_key = (u64*)(base + o_key);
   ra.n_moved = (int*)(base + o_nm);
+  ra.cap = (int)cap;
+  ra.cap64 = (int)cap64;
+  ra.slot_of = (int*)(base + o_slot);
+  ra.m_node = (int*)(base + o_mnode);
+  ra.m_tie = (int*)(base + o_mtie);
+  ra.m_key = (u64*)(base + o_mkey);
+  ra.m_free = (i64*)(base + o_mfree);
+  ra.m_room = (int*)(base + o_mroom);
+  ra.m_ports = (u64*)(base + o_mports);
+  ra.m_taint = (u64*)(base + o_mtaint);
+  ra.m_label = (u64*)(base + o_mlabel);
+  ra.m_dom = (int*)(base + o_mdom);
+  ra.m_flags = (unsigned*)(base + o_mflags);
+  ra.dead = (u64*)(base + o_dead);
+  ra.failed = keep_failed ? (u64*)(base + o_failed) : nullptr;
   ra.out = (int*)(base + o_out);
   if (fx_current) {
     ra.fx.off = e->fx_contrib ? e->d_fx_off.as<int>() : nullptr;

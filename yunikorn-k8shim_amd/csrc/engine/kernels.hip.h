@@ -2404,10 +2404,26 @@ struct RoundArgs {
   u64* ports;               // [KP][N] scratch copy of the host-port words (t.ports points here too); null: no ask of the round has host ports
   u64* moved_bits;          // [row_words], rank order
   int* cursor;              // [C] -1 = not started
-  int* moved_list;          // [N]
-  u64* moved_key;           // [N] current score key of a moved node
-  int* n_moved;             // carried between the launches of one round
+  int* n_moved;             // slots in use, carried between the launches of one round
   int* out;                 // [round] node index, -1 = no node fits
+  // MOVED nodes live in SLOTS (the order in which they first received a pod of this round; a slot is never reused): their columns
+  // side by side, so that the per-ask scan over them is coalesced loads by slot instead of twenty gathers by node index
+  int cap, cap64;           // slots (= N), 64-bit words of a bitset over them
+  int* slot_of;             // [N] node -> slot, -1 = unmoved
+  int* m_node;              // [cap] slot -> node
+  int* m_tie;               // [cap] NodeID rank (tie-break)
+  u64* m_key;               // [cap] current score key                          (live)
+  i64* m_free;              // [R][cap] Allocatable - Requested                   (live)
+  int* m_room;              // [cap] AllowedPodNumber - len(Pods)                 (live)
+  u64* m_ports;             // [KP][cap] host-port words                          (live when a.ports)
+  u64* m_taint;             // [KT][cap]
+  u64* m_label;             // [min(W, kMaxW)][cap]
+  int* m_dom;               // [KD][cap]
+  unsigned* m_flags;        // [cap] node flags
+  u64* dead;                // [cap64] no pod slot left: out of every later ask's reach
+  u64* failed;              // [C][cap64] bit = the class did not fit the slot's node when it last looked. Without a topology signature a
+                            // verdict only ever turns from fit to fail during a round (Requested, pod counts and port sets only grow; taints,
+                            // labels and names do not move), so a set bit is final. null: too many classes to keep the bits
   // topology plugins (s.spread.cnt / .minv point at the round's scratch copies); topo_on = 0: no signature is active
   int topo_on, G;           // G = constraints of all signatures
   AffSigs sig_aff;          // eligibility tables of the signatures (nodeAffinityPolicy / nodeTaintsPolicy == Honor)
@@ -2429,6 +2445,24 @@ __device__ __forceinline__ void load_node_live(const NodeTable& t, const RoundAr
     for (int i = 0; i < kMaxKP; ++i)
       if (i < t.KP) r->pt[i] = ld_live(a.ports + (size_t)i * t.n + n);
   }
+}
+// the same registers from the slot columns of a moved node
+__device__ __forceinline__ void load_slot_live(const NodeTable& t, const RoundArgs& a, int slot, NodeRegs* r) {
+  const size_t c = (size_t)a.cap;
+#pragma unroll
+  for (int i = 0; i < kMaxR; ++i) r->fr[i] = i < t.R ? ld_live(a.m_free + (size_t)i * c + slot) : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxKT; ++i) r->tn[i] = i < t.KT ? a.m_taint[(size_t)i * c + slot] : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxW; ++i) r->lb[i] = i < t.W ? a.m_label[(size_t)i * c + slot] : 0;
+  r->lb_more = t.W > kMaxW ? t.labels + (size_t)kMaxW * t.n + a.m_node[slot] : nullptr;
+  r->lb_stride = (size_t)t.n;
+#pragma unroll
+  for (int i = 0; i < kMaxKP; ++i) r->pt[i] = i < t.KP ? ld_live(a.m_ports + (size_t)i * c + slot) : 0;
+#pragma unroll
+  for (int i = 0; i < kMaxKD; ++i) r->dom[i] = i < t.KD ? a.m_dom[(size_t)i * c + slot] : -1;
+  r->slots_ok = ld_live(a.m_room + slot) >= 1;
+  r->unsched = a.m_flags[slot] & kNodeUnschedulable;
 }
 // one wave per constraint: what the round needs to keep a spread constraint's minimum current (k_spread_min's numbers, unfolded)
 __global__ __launch_bounds__(kWave) void k_round_topo_init(SpreadSigs sp, int n_constraints, int* __restrict__ mn_out, int* __restrict__ at_min_out,
@@ -2461,7 +2495,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
   __shared__ int sh_aw[kRoundWaves], sh_cw[kRoundWaves], sh_bt[kRoundWaves], sh_bn[kRoundWaves];
   __shared__ u64 sh_ax[kRoundWaves], sh_bk[kRoundWaves];
   // (flags of one ask; two sets, used alternately: thread 0 re-arms the set of ask i + 1 while ask i runs — nobody touches it then)
-  __shared__ int sh_stop_[2], sh_at_[2], sh_ndirty_[2], sh_dirty[kRoundDirty];
+  __shared__ int sh_stop_[2], sh_ndirty_[2], sh_dirty[kRoundDirty];
   __shared__ int sh_rmn[kRoundWaves], sh_rat[kRoundWaves];
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   int n_moved = ld_live(a.n_moved);
@@ -2469,35 +2503,39 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
   const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
   const bool spread_en = a.filt & kPlugSpread, ipa_en = (a.filt & kPlugInterPod) && (a.pre & kPlugInterPod);
   const SpreadSigs& sp = s.spread;
+  const size_t cap = (size_t)a.cap;
   int p_l = 0, spec_l = 0, pin_l = -1, cls_l = 0;
   int last_spec = -1, last_win = -1;  // (per launch: the first ask of a launch takes the scans)
   if (tid == 0) {
     sh_stop_[0] = 0x7fffffff;
     sh_ndirty_[0] = 0;
-    sh_at_[0] = -1;
   }
   __syncthreads();
-  for (int i = 0; i < a.n_asks; ++i) {
+  int step = 0;  // (asks decided by an iteration: runs of one spec that land on one node are decided together)
+  for (int i = 0; i < a.n_asks; i += step) {
     int& sh_stop = sh_stop_[i & 1];
-    int& sh_at = sh_at_[i & 1];
     int& sh_ndirty = sh_ndirty_[i & 1];
-    if (tid == 0) {
-      sh_stop_[(i + 1) & 1] = 0x7fffffff;
-      sh_ndirty_[(i + 1) & 1] = 0;
-      sh_at_[(i + 1) & 1] = -1;
-    }
+    step = 1;
     if ((i & (kWave - 1)) == 0) {  // the headers of the next 64 asks, one load round per wave
       const int j = i + lane;
       if (j < a.n_asks) {
         p_l = a.asks[a.first + j];
         spec_l = a.pod_spec[p_l];
-        pin_l = a.pod_pin[p_l];
+        pin_l = name_on ? a.pod_pin[p_l] : -1;
         cls_l = a.pod_class[p_l];
+      } else {
+        spec_l = -1;
       }
     }
-    const int spec = __builtin_amdgcn_readlane(spec_l, i & (kWave - 1)), cls = __builtin_amdgcn_readlane(cls_l, i & (kWave - 1));
-    const int pin = name_on ? __builtin_amdgcn_readlane(pin_l, i & (kWave - 1)) : -1;
+    const int hl = i & (kWave - 1);
+    const int spec = __builtin_amdgcn_readlane(spec_l, hl), cls = __builtin_amdgcn_readlane(cls_l, hl);
+    const int pin = __builtin_amdgcn_readlane(pin_l, hl);
     const int tsig = (a.topo_on && s.spread_sig) ? s.spread_sig[spec] : -1;  // the spec's topology signature: its verdicts move with every assume
+    // (the flag set of the NEXT ask, whichever it will be: an iteration advances by `step`, and both parities may follow)
+    if (tid == 0) {
+      sh_stop_[(i + 1) & 1] = 0x7fffffff;
+      sh_ndirty_[(i + 1) & 1] = 0;
+    }
     int win = -1;
     bool again = false;
     if (!a.all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
@@ -2575,26 +2613,41 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
           }
         }
       }
-      // ---- candidate B: the best moved node, per pair from the live tables
+      // ---- candidate B: the best moved node, per pair from the live slot columns. A wave's 64 slots are one word of the bitsets:
+      // slots of dead nodes and — for a class without topology signature — slots the class failed on before are skipped without
+      // a load; what it fails on now is remembered.
       u64 bk = ~0ull;
       int bt = 0x7fffffff, bn = -1;
+      u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
       for (int j0 = 0; j0 < n_moved; j0 += kRoundThreads) {
-        const int j = j0 + tid;
-        if (j < n_moved) {
-          const int m = ld_live(a.moved_list + j);
+        const int wi = (j0 >> 6) + wave;
+        const int slot = j0 + tid;
+        if (wi * kWave >= n_moved) continue;  // (wave-uniform)
+        u64 fbits = fw ? ld_live(fw + wi) : 0ull;
+        const u64 skip = fbits | ld_live(a.dead + wi);
+        const bool act = slot < n_moved && !((skip >> lane) & 1ull);
+        if (__ballot(act) == 0) continue;
+        bool fit = false;
+        if (act) {
           NodeRegs nr;
-          load_node_live(t, a, m, &nr);
+          load_slot_live(t, a, slot, &nr);
           int code;
           unsigned reason;
-          if (eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) {
-            const u64 k = ld_live(a.moved_key + m);
-            const int tie = a.name_rank ? a.name_rank[m] : m;
+          const int m = a.m_node[slot];
+          fit = eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason);
+          if (fit) {
+            const u64 k = ld_live(a.m_key + slot);
+            const int tie = a.m_tie[slot];
             if (k < bk || (k == bk && tie < bt)) {
               bk = k;
               bt = tie;
               bn = m;
             }
           }
+        }
+        if (fw) {
+          const u64 nf = __ballot(act && !fit);
+          if (nf && lane == 0) st_live(fw + wi, fbits | nf);  // (this wave is the only writer of the word during this ask)
         }
       }
 #pragma unroll
@@ -2648,92 +2701,119 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       }
       win = (an >= 0 && (bn < 0 || ak < bk || (ak == bk && at < bt))) ? an : bn;
     }
-    if (tid == 0) a.out[a.first + i] = win;
     last_spec = pin == -1 ? spec : -1;
     last_win = win;
     if (win >= 0) {  // (workgroup-uniform)
-      // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod)
-      const int cnt = ld_live(a.count + win) + 1;
+      // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod).
+      // A RUN of asks with this spec lands on this node as long as it fits (the argument of the `again` path), and for a spec whose
+      // pods couple through nothing but resources "fits k more times" is arithmetic: k = what the free resources and pod slots
+      // hold. The run is decided here in one step (the asks of a Deployment or task group: 110 per node in the reference's perf
+      // shape) — the headers in this wave's registers bound it to the asks up to the next multiple of 64.
+      int k_run = 1;
+      const i64* rq = s.req + (size_t)spec * s.R;
+      const bool occupies = a.fx.occupied && a.ports;  // (a pod that occupies host ports conflicts with its own twin: no run)
+      bool any_occ = false;
+      if (occupies)
+        for (int k = 0; k < t.KP; ++k) any_occ = any_occ || a.fx.occupied[(size_t)spec * t.KP + k] != 0;
+      const bool contributes = a.topo_on && a.fx.off && a.fx.off[spec + 1] > a.fx.off[spec];
+      if (pin == -1 && tsig < 0 && !any_occ && !contributes && fit_on) {
+        // asks hl+1 .. of the header window with the same spec and no pin, consecutively
+        const u64 same = __ballot(spec_l == spec && pin_l == -1);
+        const u64 behind = hl < 63 ? (~same) >> (hl + 1) : ~0ull;  // first 0 of `same` behind lane hl ends the run
+        const int run = behind ? (int)(__ffsll((long long)behind) - 1) : (63 - hl);
+        i64 fits = (i64)t.allowed[win] - (i64)ld_live(a.count + win);  // pod slots left (>= 1: the ask fits)
+        for (int r = 0; r < t.R; ++r)
+          if (rq[r] > 0) fits = min(fits, (t.alloc[(size_t)r * t.n + win] - ld_live(a.req + (size_t)r * t.n + win)) / rq[r]);
+        k_run = (int)max((i64)1, min(fits, (i64)(1 + min(run, 63 - hl))));
+        k_run = min(k_run, a.n_asks - i);
+      }
+      step = k_run;
+      if (tid < k_run) a.out[a.first + i + tid] = win;
+      const int cnt = ld_live(a.count + win) + k_run;
       const int rk = a.rank[win];
       const bool was_moved = (ld_live(a.moved_bits + (rk >> 6)) >> (rk & 63)) & 1ull;
       const bool dead = fit_on && (i64)cnt + 1 > (i64)t.allowed[win];  // no pod slot left: no ask of this phase fits it any more
-      if (was_moved && dead) {
-        // leaves the list (its slot is taken by the last entry): find it, every thread a share of the list
-        for (int j = tid; j < n_moved; j += kRoundThreads)
-          if (ld_live(a.moved_list + j) == win) sh_at = j;
-      }
+      const int slot = was_moved ? ld_live(a.slot_of + win) : n_moved;
       if (tid == 0) {
         i64 used[2] = {0, 0};
         for (int r = 0; r < t.R; ++r) {
-          const i64 v = ld_live(a.req + (size_t)r * t.n + win) + s.req[(size_t)spec * s.R + r];
+          const i64 v = ld_live(a.req + (size_t)r * t.n + win) + rq[r] * (i64)k_run;
           if (r < 2) used[r] = v;
           st_live(a.req + (size_t)r * t.n + win, v);
+          st_live(a.m_free + (size_t)r * cap + slot, t.alloc[(size_t)r * t.n + win] - v);
         }
         st_live(a.count + win, cnt);
+        st_live(a.m_room + slot, t.allowed[win] - cnt);
         const i64 total[2] = {t.alloc[win], t.alloc[(size_t)t.n + win]};
-        st_live(a.moved_key + win, sortable_key(node_score_of(total, used)));
+        st_live(a.m_key + slot, sortable_key(node_score_of(total, used)));
         if (!was_moved) {
           atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
-          if (!dead) st_live(a.moved_list + n_moved, win);
+          st_live(a.slot_of + win, slot);
+          a.m_node[slot] = win;
+          a.m_tie[slot] = a.name_rank ? a.name_rank[win] : win;
+          a.m_flags[slot] = t.flags[win];
         }
+        if (dead) atomicOr(a.dead + (slot >> 6), 1ull << (slot & 63));
       }
       // host ports the pod occupies from now on (NodeInfo.UsedPorts)
-      if (a.ports && a.fx.occupied && tid < t.KP) {
-        const u64 occ = a.fx.occupied[(size_t)spec * t.KP + tid];
-        if (occ) atomicOr(a.ports + (size_t)tid * t.n + win, occ);
+      if (a.ports && tid < t.KP) {
+        const u64 occ = a.fx.occupied ? a.fx.occupied[(size_t)spec * t.KP + tid] : 0ull;
+        const u64 now = (occ ? atomicOr(a.ports + (size_t)tid * t.n + win, occ) : ld_live(a.ports + (size_t)tid * t.n + win)) | occ;
+        if (occ || !was_moved) st_live(a.m_ports + (size_t)tid * cap + slot, now);
+      } else if (!a.ports && !was_moved && tid < t.KP) {
+        a.m_ports[(size_t)tid * cap + slot] = t.ports[(size_t)tid * t.n + win];
+      }
+      // the static columns of a node that has just moved: one thread per column
+      if (!was_moved) {
+        const int c0 = 8;  // (threads 0..7 are busy above)
+        const int Wc = min(t.W, kMaxW);
+        const int col = tid - c0;
+        if (col >= 0 && col < t.KT) a.m_taint[(size_t)col * cap + slot] = t.taints[(size_t)col * t.n + win];
+        else if (col >= t.KT && col < t.KT + Wc) a.m_label[(size_t)(col - t.KT) * cap + slot] = t.labels[(size_t)(col - t.KT) * t.n + win];
+        else if (col >= t.KT + Wc && col < t.KT + Wc + t.KD) a.m_dom[(size_t)(col - t.KT - Wc) * cap + slot] = t.domain[(size_t)(col - t.KT - Wc) * t.n + win];
       }
       // match counts of the topology plugins: thread = constraint (of any signature) whose selector class the pod adds to
-      if (a.topo_on && a.fx.off) {
+      if (contributes) {
         const int f0 = a.fx.off[spec], f1 = a.fx.off[spec + 1];
-        if (f1 > f0) {
-          for (int g = tid; g < a.G; g += kRoundThreads) {
-            const SpreadC c = sp.c[g];
-            int v = 0;
-            for (int k = f0; k < f1; ++k)
-              if (a.fx.cls[k] == c.ks) v = a.fx.cnt[k];
-            if (v == 0) continue;
-            const int dom = t.domain[(size_t)c.kd * t.n + win];
-            if (dom < 0 || dom >= c.dom_size) continue;
-            if (c.kind == kKindSpread && !spread_counts_here(c, spread_eligibility(t, sp, a.sig_aff, a.sig_tol, a.sig_of[g], win))) continue;
-            const int old = atomicAdd(sp.cnt + c.cnt_off + dom, v);
-            if (c.kind == kKindSpread) {
-              // (an eligible node carries the domain: it is a present one. Its count leaves the minimum; the minimum itself moves
-              // only when no present domain is left there)
-              if (old == ld_live(a.mn + g)) {
-                const int left = ld_live(a.at_min + g) - 1;
-                st_live(a.at_min + g, left);
-                if (left == 0) {
-                  const int slot = atomicAdd(&sh_ndirty, 1);
-                  if (slot < kRoundDirty) {
-                    sh_dirty[slot] = g;
-                  } else {  // (more than a handful at once: this thread recomputes its constraint alone)
-                    int mn = 0x7fffffff, at = 0;
-                    for (int q = 0; q < c.dom_size; ++q)
-                      if (sp.present[c.cnt_off + q]) mn = min(mn, ld_live(sp.cnt + c.cnt_off + q));
-                    for (int q = 0; q < c.dom_size; ++q) at += (sp.present[c.cnt_off + q] && ld_live(sp.cnt + c.cnt_off + q) == mn) ? 1 : 0;
-                    st_live(a.mn + g, mn);
-                    st_live(a.at_min + g, at);
-                    st_live(sp.minv + g, a.nd[g] < c.min_domains ? 0 : mn);
-                  }
+        for (int g = tid; g < a.G; g += kRoundThreads) {
+          const SpreadC c = sp.c[g];
+          int v = 0;
+          for (int k = f0; k < f1; ++k)
+            if (a.fx.cls[k] == c.ks) v = a.fx.cnt[k];
+          if (v == 0) continue;
+          const int dom = t.domain[(size_t)c.kd * t.n + win];
+          if (dom < 0 || dom >= c.dom_size) continue;
+          if (c.kind == kKindSpread && !spread_counts_here(c, spread_eligibility(t, sp, a.sig_aff, a.sig_tol, a.sig_of[g], win))) continue;
+          const int old = atomicAdd(sp.cnt + c.cnt_off + dom, v);
+          if (c.kind == kKindSpread) {
+            // (an eligible node carries the domain: it is a present one. Its count leaves the minimum; the minimum itself moves
+            // only when no present domain is left there)
+            if (old == ld_live(a.mn + g)) {
+              const int left = ld_live(a.at_min + g) - 1;
+              st_live(a.at_min + g, left);
+              if (left == 0) {
+                const int dslot = atomicAdd(&sh_ndirty, 1);
+                if (dslot < kRoundDirty) {
+                  sh_dirty[dslot] = g;
+                } else {  // (more than a handful at once: this thread recomputes its constraint alone)
+                  int mn = 0x7fffffff, at = 0;
+                  for (int q = 0; q < c.dom_size; ++q)
+                    if (sp.present[c.cnt_off + q]) mn = min(mn, ld_live(sp.cnt + c.cnt_off + q));
+                  for (int q = 0; q < c.dom_size; ++q) at += (sp.present[c.cnt_off + q] && ld_live(sp.cnt + c.cnt_off + q) == mn) ? 1 : 0;
+                  st_live(a.mn + g, mn);
+                  st_live(a.at_min + g, at);
+                  st_live(sp.minv + g, a.nd[g] < c.min_domains ? 0 : mn);
                 }
               }
-            } else if (old <= 0 && old + v > 0) {
-              st_live(sp.minv + g, ld_live(sp.minv + g) + 1);  // InterPodAffinity: domains with a match (k_spread_min's `tot`)
             }
+          } else if (old <= 0 && old + v > 0) {
+            st_live(sp.minv + g, ld_live(sp.minv + g) + 1);  // InterPodAffinity: domains with a match (k_spread_min's `tot`)
           }
         }
       }
       __threadfence();
       __syncthreads();
-      if (!was_moved) {
-        if (!dead) ++n_moved;
-      } else if (dead) {
-        const int at_l = sh_at;
-        if (at_l >= 0) {
-          if (tid == 0) st_live(a.moved_list + at_l, ld_live(a.moved_list + n_moved - 1));
-          --n_moved;
-        }
-      }
+      if (!was_moved) ++n_moved;
       // spread constraints whose last domain left the minimum: the new minimum, the whole workgroup over the constraint's domains
       const int ndirty = min(sh_ndirty, kRoundDirty);
       for (int q = 0; q < ndirty; ++q) {
@@ -2764,6 +2844,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
         }
       }
       if (ndirty) __threadfence();
+    } else if (tid == 0) {
+      a.out[a.first + i] = -1;
     }
     // (the exchange slots are rewritten by the next ask only after this barrier; every wave has read them by now)
     __syncthreads();
