@@ -294,6 +294,7 @@ struct ykpred_engine {
   int sig_wpl = 0;                  // sig_wpl: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
   int combine_slices = 1;           // combine_slices: 0 = index-row populations take the wave-per-chunk writer instead of k_walk_rows
   int decide_groups_from = 16384;   // decide_groups_from: classes from which k_decide serves four classes per wave
+  int early_counts = 1;             // early_counts: 0 = class counts by the writers and the per-ask scatter behind them (the round-4 order)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
@@ -1173,6 +1174,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "combine_slices") e->combine_slices = val;
       else if (key == "decide_groups_from") e->decide_groups_from = val;
       else if (key == "graph") e->graph_disabled = val != 1;
+      else if (key == "early_counts") e->early_counts = val;
       else if (key == "band_steps") {
         e->bands_enabled = val >= 0;
         e->band_steps = val > 0 ? std::min(256, std::max(4, (val + 3) / 4 * 4)) : 0;
@@ -1976,7 +1978,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   // k_class_rows counts the zone-B classes as well: every class count is known before a bitmap row is written, so the per-ask
   // scatter runs on the decision stream beside the band writer instead of behind it, and the writers add nothing to the counts.
   const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
-  const bool counts_early = !skip_combine && !dirty_only && e->n_classes_a > 0 && e->patch_chunks == 0 && !small_chunks && e->n_classes_b <= 16384;
+  const bool counts_early = e->early_counts != 0 && !skip_combine && !dirty_only && e->n_classes_a > 0 && e->patch_chunks == 0 && !small_chunks && e->n_classes_b <= 16384;
   bool scattered = false;
   if (!skip_combine && !dirty_only && !counts_early) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
   if (!skip_combine) {

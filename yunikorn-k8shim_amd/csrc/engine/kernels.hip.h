@@ -367,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
 // pass (64 bytes per wave store; SQ counters: 73 % of the wave cycles waiting, 0.55–0.9 ms for 0.78 GB). EIGHT words per thread
 // (8-byte stores, half the threads) are slower: 0.35 -> 0.52 ms, the rank-ordered walk 0.45 -> 0.71 ms (round 4, session 21).
 constexpr int kWalkWords = 4;
+constexpr int kWalkBatch = 32;  // rows whose positions are staged in LDS before they are stored (32 KB per workgroup)
 __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* __restrict__ out, int stride) {
   const int chunk = blockIdx.x;
   const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
@@ -391,23 +392,35 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk(DimWalk a, unsigned char* _
     ptr[j] = lo;
     next[j] = lo < 64 ? sf[j][lo] : kMax;
   }
+  // Rows go in batches of kWalkBatch: the positions of a batch are computed into LDS first (a column per thread: no barrier), then stored
+  // back to back. A store inside the walking loop puts a wait for ALL outstanding memory operations in front of the next
+  // position load (gfx9 counts loads and stores in one in-order vmcnt, and across a loop back-edge the compiler waits for zero) —
+  // a store round trip per row, 73 % of the kernel's wave cycles in round 3's counters.
+  __shared__ unsigned stage[kWalkBatch * kBlock];
   for (int i0 = 0; i0 < len; i0 += kWave) {
     const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
     const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
     const int m = min(kWave, len - i0);
-    for (int i = 0; i < m; ++i) {
-      const i64 v = readlane_i64(my_val, i);
-      const int row = __builtin_amdgcn_readlane(my_row, i);
-      unsigned packed = 0;
+    for (int h = 0; h < m; h += kWalkBatch) {
+      const int he = min(h + kWalkBatch, m);
+      for (int i = h; i < he; ++i) {
+        const i64 v = readlane_i64(my_val, i);
+        unsigned packed = 0;
 #pragma unroll
-      for (int j = 0; j < kWalkWords; ++j) {
-        while (next[j] < v) {
-          ++ptr[j];
-          next[j] = ptr[j] < 64 ? sf[j][ptr[j]] : kMax;
+        for (int j = 0; j < kWalkWords; ++j) {
+          while (next[j] < v) {
+            ++ptr[j];
+            next[j] = ptr[j] < 64 ? sf[j][ptr[j]] : kMax;
+          }
+          packed |= (unsigned)ptr[j] << (8 * j);
         }
-        packed |= (unsigned)ptr[j] << (8 * j);
+        stage[(i - h) * kBlock + threadIdx.x] = packed;
       }
-      if (live) *(unsigned*)(out + (size_t)row * stride + w0) = packed;
+      if (live)
+        for (int i = h; i < he; ++i) {
+          const int row = __builtin_amdgcn_readlane(my_row, i);
+          *(unsigned*)(out + (size_t)row * stride + w0) = stage[(i - h) * kBlock + threadIdx.x];
+        }
     }
   }
 }
@@ -472,38 +485,53 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk_window(DimWalk a, const i64
     next[j] = mine ? sf[j][0] : kMax;
   }
   bool started = false;
+  // (positions of a batch of 64 rows into LDS, then the stores back to back — see k_dim_walk; 0xffffffff = the row's window does not
+  // hold this thread's words)
+  __shared__ unsigned stage[kWalkBatch * kBlock];
   for (int i0 = 0; i0 < len; i0 += kWave) {
     const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
     const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
     const int m = min(kWave, len - i0);
-    for (int i = 0; i < m; ++i) {
+   for (int h = 0; h < m; h += kWalkBatch) {
+    const int he = min(h + kWalkBatch, m);
+    // (a batch whose values all lie outside this wave's windows is skipped whole)
+    const i64 b_first = readlane_i64(my_val, h), b_last = readlane_i64(my_val, he - 1);
+    if (__ballot(mine && b_last > lo && b_first <= hi) == 0) continue;
+    for (int i = h; i < he; ++i) {
       const i64 v = readlane_i64(my_val, i);
-      const int row = __builtin_amdgcn_readlane(my_row, i);
-      if (!(mine && v > lo && v <= hi)) continue;
-      if (!started) {  // the first row of this thread's run: one binary search per word, then the walk only advances
-        started = true;
+      unsigned packed = 0xffffffffu;
+      if (mine && v > lo && v <= hi) {
+        if (!started) {  // the first row of this thread's run: one binary search per word, then the walk only advances
+          started = true;
+#pragma unroll
+          for (int j = 0; j < kWalkWords; ++j) {
+            int l = 0, h = 64;
+            while (l < h) {
+              const int mid = (l + h) >> 1;
+              if (sf[j][mid] < v) l = mid + 1; else h = mid;
+            }
+            ptr[j] = l;
+            next[j] = l < 64 ? sf[j][l] : kMax;
+          }
+        }
+        packed = 0;
 #pragma unroll
         for (int j = 0; j < kWalkWords; ++j) {
-          int l = 0, h = 64;
-          while (l < h) {
-            const int mid = (l + h) >> 1;
-            if (sf[j][mid] < v) l = mid + 1; else h = mid;
+          while (next[j] < v) {
+            ++ptr[j];
+            next[j] = ptr[j] < 64 ? sf[j][ptr[j]] : kMax;
           }
-          ptr[j] = l;
-          next[j] = l < 64 ? sf[j][l] : kMax;
+          packed |= (unsigned)ptr[j] << (8 * j);
         }
       }
-      unsigned packed = 0;
-#pragma unroll
-      for (int j = 0; j < kWalkWords; ++j) {
-        while (next[j] < v) {
-          ++ptr[j];
-          next[j] = ptr[j] < 64 ? sf[j][ptr[j]] : kMax;
-        }
-        packed |= (unsigned)ptr[j] << (8 * j);
-      }
-      *(unsigned*)(win + (size_t)row * 64 + (w0 & 63)) = packed;
+      stage[(i - h) * kBlock + threadIdx.x] = packed;
     }
+    for (int i = h; i < he; ++i) {
+      const int row = __builtin_amdgcn_readlane(my_row, i);
+      const unsigned packed = stage[(i - h) * kBlock + threadIdx.x];
+      if (packed != 0xffffffffu) *(unsigned*)(win + (size_t)row * 64 + (w0 & 63)) = packed;
+    }
+   }
   }
 }
 
@@ -2619,12 +2647,20 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       u64 bk = ~0ull;
       int bt = 0x7fffffff, bn = -1;
       u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
+      u64 fb_l = 0, dead_l = ~0ull;  // lane k: this wave's bitset words of step (j0 / kRoundThreads) % 64 == k, one load round for 64 steps
       for (int j0 = 0; j0 < n_moved; j0 += kRoundThreads) {
+        const int st_k = (j0 / kRoundThreads) & (kWave - 1);
+        if (st_k == 0) {
+          const int wl = ((j0 + lane * kRoundThreads) >> 6) + wave;
+          const bool in = wl * kWave < n_moved;
+          fb_l = (in && fw) ? ld_live(fw + wl) : 0ull;
+          dead_l = in ? ld_live(a.dead + wl) : ~0ull;
+        }
         const int wi = (j0 >> 6) + wave;
         const int slot = j0 + tid;
         if (wi * kWave >= n_moved) continue;  // (wave-uniform)
-        u64 fbits = fw ? ld_live(fw + wi) : 0ull;
-        const u64 skip = fbits | ld_live(a.dead + wi);
+        const u64 fbits = __shfl(fb_l, st_k, kWave);
+        const u64 skip = fbits | __shfl(dead_l, st_k, kWave);
         const bool act = slot < n_moved && !((skip >> lane) & 1ull);
         if (__ballot(act) == 0) continue;
         bool fit = false;
