@@ -289,6 +289,7 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
+  int round_prof = 0;               // round_prof: 1 = k_allocate_round counts thread 0's ticks per phase, printed on stderr
   int fail_after = 0;               // fail_after: failure injection — the n-th checked device call fails (0 = off)
   // Test knobs (YKPRED_TUNE, see ykpred_create): they force paths the populations of the test suite would not choose themselves.
   int sig_wpl = 0;                  // sig_wpl: row words per lane of k_sig_planes (1, 2, 4); 0 = from the row width
@@ -1181,6 +1182,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       } else if (key == "chunk_members") e->chunk_members = std::min(std::max(val, 1), (int)ykk::kChunkMembers);
       else if (key == "wave_combine_below") e->wave_combine_below = std::max(val, 0);
       else if (key == "fail_after") e->fail_after = std::max(val, 0);
+      else if (key == "round_prof") e->round_prof = val;
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
         delete e;
@@ -2687,7 +2689,8 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                o_mflags = take(cap * sizeof(unsigned)), o_dead = take(cap64 * sizeof(u64)), o_failed = take(keep_failed ? C * cap64 * sizeof(u64) : 0),
                o_asks = take((size_t)n_asks * sizeof(int)), o_out = take((size_t)n_asks * sizeof(int)),
                o_nm = take(sizeof(int)), o_hist = take(cells * sizeof(int)), o_minv = take(G * sizeof(int)), o_mn = take(G * sizeof(int)),
-               o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int));
+               o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int)), o_prof = take(16 * sizeof(i64)),
+               o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int));
   HIPCHK(e->d_round.ensure(off));
   char* base = (char*)e->d_round.p;
   HIPCHK(hipMemcpyAsync(base + o_req, e->d_req.p, R * (size_t)e->N * sizeof(i64), hipMemcpyDeviceToDevice, st));
@@ -2699,6 +2702,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   HIPCHK(hipMemsetAsync(base + o_dead, 0, cap64 * sizeof(u64), st));
   if (keep_failed) HIPCHK(hipMemsetAsync(base + o_failed, 0, C * cap64 * sizeof(u64), st));
   HIPCHK(hipMemsetAsync(base + o_nm, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(base + o_prof, 0, 16 * sizeof(i64), st));
   HIPCHK(hipMemcpyAsync(base + o_asks, asks, (size_t)n_asks * sizeof(int), hipMemcpyHostToDevice, st));
   ykk::NodeTable nt = node_table(e);
   nt.req = (const i64*)(base + o_req);
@@ -2718,6 +2722,11 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   ra.rank = e->d_rank.as<int>();
   ra.key0 = e->d_key.as<u64>();
   ra.name_rank = e->has_name_rank ? e->d_name_rank.as<int>() : nullptr;
+  ra.rkey = (const u64*)(base + o_rkey);
+  ra.rtie = (const int*)(base + o_rtie);
+  if (e->N > 0)
+    hipLaunchKernelGGL(ykk::k_round_ranked_keys, dim3((unsigned)((e->N + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, e->N, ra.perm, ra.key0,
+                       ra.name_rank, (u64*)(base + o_rkey), (int*)(base + o_rtie));
   ra.pre = pre;
   ra.filt = filt;
   ra.row_words = e->row_words;
@@ -2744,6 +2753,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   ra.dead = (u64*)(base + o_dead);
   ra.failed = keep_failed ? (u64*)(base + o_failed) : nullptr;
   ra.out = (int*)(base + o_out);
+  ra.prof = e->round_prof ? (i64*)(base + o_prof) : nullptr;
   if (fx_current) {
     ra.fx.off = e->fx_contrib ? e->d_fx_off.as<int>() : nullptr;
     ra.fx.cls = e->d_fx_cls.as<int>();
@@ -2788,6 +2798,13 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_nodes, base + o_out, (size_t)n_asks * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (e->round_prof) {
+    i64 pr_[16];
+    HIPCHK(hipMemcpy(pr_, base + o_prof, sizeof(pr_), hipMemcpyDeviceToHost));
+    fprintf(stderr, "round_prof asks=%d iters=%lld again=%lld B_active_iters=%lld | us: header %.0f again %.0f pin %.0f A %.0f B %.0f exchange %.0f assume %.0f tail %.0f\n",
+            n_asks, (long long)pr_[8], (long long)pr_[9], (long long)pr_[10], pr_[0] / 100.0, pr_[1] / 100.0, pr_[2] / 100.0, pr_[3] / 100.0, pr_[4] / 100.0,
+            pr_[5] / 100.0, pr_[6] / 100.0, pr_[7] / 100.0);
+  }
   return YKPRED_OK;
 }
 

@@ -2424,6 +2424,8 @@ struct RoundArgs {
   const int* perm;          // bin-pack order of the snapshot ...
   const int* rank;
   const u64* key0;          // ... and its score keys
+  const u64* rkey;          // [N] key0 in bin-pack order (rkey[pos] = key0[perm[pos]]) and the NodeID ranks beside it: what candidate A
+  const int* rtie;          //     needs of its node, addressed by the POSITION the scan found (k_round_ranked_keys, once per round)
   const int* name_rank;     // NodeID order (null: node index)
   unsigned pre, filt;
   int row_words, all_fail;
@@ -2461,7 +2463,14 @@ struct RoundArgs {
   int* at_min;              // [G] spread: present domains whose count equals mn
   const int* nd;            // [G] spread: present domains
   SpecEffects fx;
+  i64* prof;                // YKPRED_TUNE round_prof=1: thread 0's 100 MHz ticks per phase of the loop (null: off)
 };
+#define YK_RP(k)                                  \
+  if (a.prof && tid == 0) {                       \
+    const i64 now_ = (i64)wall_clock64();         \
+    a.prof[k] += now_ - rp_prev;                  \
+    rp_prev = now_;                               \
+  }
 __device__ __forceinline__ void load_node_live(const NodeTable& t, const RoundArgs& a, int n, NodeRegs* r) {
   load_node(t, n, r);  // immutable columns (the stale-prone ones are overwritten below)
 #pragma unroll
@@ -2475,7 +2484,7 @@ __device__ __forceinline__ void load_node_live(const NodeTable& t, const RoundAr
   }
 }
 // the same registers from the slot columns of a moved node
-__device__ __forceinline__ void load_slot_live(const NodeTable& t, const RoundArgs& a, int slot, NodeRegs* r) {
+__device__ __forceinline__ void load_slot_live(const NodeTable& t, const RoundArgs& a, int slot, bool with_domains, NodeRegs* r) {
   const size_t c = (size_t)a.cap;
 #pragma unroll
   for (int i = 0; i < kMaxR; ++i) r->fr[i] = i < t.R ? ld_live(a.m_free + (size_t)i * c + slot) : 0;
@@ -2488,9 +2497,79 @@ __device__ __forceinline__ void load_slot_live(const NodeTable& t, const RoundAr
 #pragma unroll
   for (int i = 0; i < kMaxKP; ++i) r->pt[i] = i < t.KP ? ld_live(a.m_ports + (size_t)i * c + slot) : 0;
 #pragma unroll
-  for (int i = 0; i < kMaxKD; ++i) r->dom[i] = i < t.KD ? a.m_dom[(size_t)i * c + slot] : -1;
+  for (int i = 0; i < kMaxKD; ++i) r->dom[i] = (with_domains && i < t.KD) ? a.m_dom[(size_t)i * c + slot] : -1;
   r->slots_ok = ld_live(a.m_room + slot) >= 1;
   r->unsched = a.m_flags[slot] & kNodeUnschedulable;
+}
+// What the Filter list reads of a SPEC, loaded once per ask: the scan over the moved nodes evaluates one spec against many
+// slots, and eval_pair's loads sit behind its early exits — a chain of dependent round trips per pair.
+struct SpecRegs {
+  unsigned f;
+  u64 tol[kMaxKT];
+  i64 req[kMaxR];
+  u64 want[kMaxKP];
+  int pre_b, pre_e, term_b, term_e;
+};
+__device__ __forceinline__ void load_spec_regs(const SpecTable& s, int spec, SpecRegs* q) {
+  q->f = s.flags[spec];
+#pragma unroll
+  for (int k = 0; k < kMaxKT; ++k) q->tol[k] = k < s.KT ? s.tol[(size_t)spec * s.KT + k] : ~0ull;
+#pragma unroll
+  for (int k = 0; k < kMaxR; ++k) q->req[k] = k < s.R ? s.req[(size_t)spec * s.R + k] : 0;
+#pragma unroll
+  for (int k = 0; k < kMaxKP; ++k) q->want[k] = k < s.KP ? s.wanted_ports[(size_t)spec * s.KP + k] : 0ull;
+  q->pre_b = s.aff.pre_off[spec];
+  q->pre_e = s.aff.pre_off[spec + 1];
+  q->term_b = s.aff.term_off[spec];
+  q->term_e = s.aff.term_off[spec + 1];
+}
+// eval_pair's VERDICT (fit or not; no failing plugin) for an ask without pin whose spec has no topology signature, from the
+// registers above and without early exits: the same conditions in the same plugin order (predicate_manager.go:221-283).
+__device__ __forceinline__ bool spec_fits_node(const SpecTable& s, const SpecRegs& q, const NodeRegs& nr, unsigned pre_mask, unsigned filt_mask) {
+  const unsigned f = q.f;
+  bool ok = !(f & kSpecUnsupported);
+  if ((pre_mask & kPlugAffinity) && !(f & kSpecAffSkip)) {
+    if (f & kSpecPreReject) ok = false;
+    else if (f & kSpecPreNames) ok = dnf_match(s.aff.pre_terms, q.pre_b, q.pre_e, nr.lb, s.W, nr.lb_more, nr.lb_stride) && ok;
+  }
+  if ((filt_mask & kPlugUnsched) && nr.unsched && !(f & kSpecToleratesUnsched)) ok = false;
+  if (filt_mask & kPlugTaint) {
+#pragma unroll
+    for (int k = 0; k < kMaxKT; ++k)
+      if (k < s.KT) ok = ok && (nr.tn[k] & ~q.tol[k]) == 0;
+  }
+  if (filt_mask & kPlugAffinity) {
+    const bool skip = (pre_mask & kPlugAffinity) && (f & kSpecAffSkip);
+    if (!skip) ok = dnf_match(s.aff.terms, q.term_b, q.term_e, nr.lb, s.W, nr.lb_more, nr.lb_stride) && ok;
+  }
+  if (filt_mask & kPlugPorts) {
+    bool any = false, conflict = false;
+#pragma unroll
+    for (int k = 0; k < kMaxKP; ++k)
+      if (k < s.KP) {
+        any = any || q.want[k] != 0;
+        conflict = conflict || (nr.pt[k] & q.want[k]) != 0;
+      }
+    if (!(pre_mask & kPlugPorts) || (any && conflict)) ok = false;
+  }
+  if (filt_mask & kPlugFit) {
+    if (!(pre_mask & kPlugFit) || !nr.slots_ok) ok = false;
+#pragma unroll
+    for (int r = 0; r < kMaxR; ++r)
+      if (r < s.R && q.req[r] > 0 && q.req[r] > nr.fr[r]) ok = false;
+  }
+  if ((filt_mask & kPlugSpread) && !(pre_mask & kPlugSpread)) ok = false;
+  if ((filt_mask & kPlugInterPod) && !(pre_mask & kPlugInterPod)) ok = false;
+  return ok;
+}
+// score keys and NodeID ranks in bin-pack order (see RoundArgs::rkey)
+__global__ __launch_bounds__(kBlock) void k_round_ranked_keys(int n_nodes, const int* __restrict__ perm, const u64* __restrict__ key0,
+                                                              const int* __restrict__ name_rank, u64* __restrict__ rkey, int* __restrict__ rtie) {
+  const int pos = blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n_nodes) return;
+  const int n = perm[pos];
+  rkey[pos] = key0[n];
+  rtie[pos] = name_rank ? name_rank[n] : n;
 }
 // one wave per constraint: what the round needs to keep a spread constraint's minimum current (k_spread_min's numbers, unfolded)
 __global__ __launch_bounds__(kWave) void k_round_topo_init(SpreadSigs sp, int n_constraints, int* __restrict__ mn_out, int* __restrict__ at_min_out,
@@ -2520,8 +2599,9 @@ __global__ __launch_bounds__(kWave) void k_round_topo_init(SpreadSigs sp, int n_
   }
 }
 __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, SpecTable s, ClassTable ct, Planes ranked, RoundArgs a) {
-  __shared__ int sh_aw[kRoundWaves], sh_cw[kRoundWaves], sh_bt[kRoundWaves], sh_bn[kRoundWaves];
-  __shared__ u64 sh_ax[kRoundWaves], sh_bk[kRoundWaves];
+  __shared__ int sh_aw[kRoundWaves], sh_cw[kRoundWaves], sh_bt[kRoundWaves], sh_bn[kRoundWaves], sh_an[kRoundWaves], sh_at[kRoundWaves];
+  __shared__ u64 sh_ak[kRoundWaves], sh_bk[kRoundWaves];
+  __shared__ int sh_step, sh_was_moved;  // what wave 0's assume decided: asks of the run, the node had a slot already
   // (flags of one ask; two sets, used alternately: thread 0 re-arms the set of ask i + 1 while ask i runs — nobody touches it then)
   __shared__ int sh_stop_[2], sh_ndirty_[2], sh_dirty[kRoundDirty];
   __shared__ int sh_rmn[kRoundWaves], sh_rat[kRoundWaves];
@@ -2540,7 +2620,9 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
   }
   __syncthreads();
   int step = 0;  // (asks decided by an iteration: runs of one spec that land on one node are decided together)
+  i64 rp_prev = a.prof ? (i64)wall_clock64() : 0;
   for (int i = 0; i < a.n_asks; i += step) {
+    if (a.prof && tid == 0) a.prof[8] += 1;
     int& sh_stop = sh_stop_[i & 1];
     int& sh_ndirty = sh_ndirty_[i & 1];
     step = 1;
@@ -2566,6 +2648,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
     }
     int win = -1;
     bool again = false;
+    YK_RP(0)
     if (!a.all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
       // The same spec as the ask before, which went to node last_win: that node is AT LEAST as early in the bin-pack order now
       // (an allocation only raises a node's utilisation, i.e. lowers its score; every other node stands where it stood), so it
@@ -2578,8 +2661,10 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       unsigned reason;
       again = eval_pair<true>(s, spec, -1, last_win, nr, a.pre, a.filt, &code, &reason);
     }
+    YK_RP(1)
     if (again) {
       win = last_win;
+      if (a.prof && tid == 0) a.prof[9] += 1;
     } else if (a.all_fail || pin == -2) {
       // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
     } else if (pin >= 0) {
@@ -2588,11 +2673,23 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       int code;
       unsigned reason;
       if (eval_pair<true>(s, spec, pin, pin, nr, a.pre, a.filt, &code, &reason)) win = pin;
+      YK_RP(2)
     } else {
       // ---- candidate A: the first unmoved feasible node in snapshot order. aw / ax: the first word of THIS wave with a feasible
       // node and its bits; cw: the first word of this wave with a candidate of the snapshot planes (the class's cursor)
       int aw = 0x7fffffff, cw = 0x7fffffff;
       u64 ax = 0;
+      // (requested before the scan, used behind it: the spec's registers and the bitset words of the first 64 steps of candidate B)
+      SpecRegs q;
+      if (tsig < 0) load_spec_regs(s, spec, &q);
+      u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
+      u64 fb_l = 0, dead_l = ~0ull;  // lane k: this wave's bitset words of step (j0 / kRoundThreads) % 64 == k, one load round for 64 steps
+      {
+        const int wl = lane * kRoundWaves + wave;
+        const bool in = wl * kWave < n_moved;
+        fb_l = (in && fw) ? ld_live(fw + wl) : 0ull;
+        dead_l = in ? ld_live(a.dead + wl) : ~0ull;
+      }
       {
         const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2];
         const ClassRows cr = class_rows(ranked, sr, st, sa, -1);  // (ranked.spread is null: the topology family is checked live)
@@ -2641,16 +2738,24 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
           }
         }
       }
+      // the node behind the found position, its key and NodeID rank: in flight while this wave scans the moved nodes
+      int an_w = -1, at_w = 0;
+      u64 ak_w = 0;
+      if (aw != 0x7fffffff) {
+        const int pos = aw * kWave + (__ffsll((long long)ax) - 1);
+        an_w = a.perm[pos];
+        ak_w = a.rkey[pos];
+        at_w = a.rtie[pos];
+      }
+      YK_RP(3)
       // ---- candidate B: the best moved node, per pair from the live slot columns. A wave's 64 slots are one word of the bitsets:
       // slots of dead nodes and — for a class without topology signature — slots the class failed on before are skipped without
       // a load; what it fails on now is remembered.
       u64 bk = ~0ull;
       int bt = 0x7fffffff, bn = -1;
-      u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
-      u64 fb_l = 0, dead_l = ~0ull;  // lane k: this wave's bitset words of step (j0 / kRoundThreads) % 64 == k, one load round for 64 steps
       for (int j0 = 0; j0 < n_moved; j0 += kRoundThreads) {
         const int st_k = (j0 / kRoundThreads) & (kWave - 1);
-        if (st_k == 0) {
+        if (st_k == 0 && j0 > 0) {
           const int wl = ((j0 + lane * kRoundThreads) >> 6) + wave;
           const bool in = wl * kWave < n_moved;
           fb_l = (in && fw) ? ld_live(fw + wl) : 0ull;
@@ -2663,17 +2768,22 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
         const u64 skip = fbits | __shfl(dead_l, st_k, kWave);
         const bool act = slot < n_moved && !((skip >> lane) & 1ull);
         if (__ballot(act) == 0) continue;
+        if (a.prof && tid == 0) a.prof[10] += 1;
         bool fit = false;
         if (act) {
           NodeRegs nr;
-          load_slot_live(t, a, slot, &nr);
-          int code;
-          unsigned reason;
+          load_slot_live(t, a, slot, tsig >= 0, &nr);
           const int m = a.m_node[slot];
-          fit = eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason);
+          const u64 k = ld_live(a.m_key + slot);  // (with the columns, not behind the verdict: one round trip per step)
+          const int tie = a.m_tie[slot];
+          if (tsig < 0) {
+            fit = spec_fits_node(s, q, nr, a.pre, a.filt);
+          } else {
+            int code;
+            unsigned reason;
+            fit = eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason);
+          }
           if (fit) {
-            const u64 k = ld_live(a.m_key + slot);
-            const int tie = a.m_tie[slot];
             if (k < bk || (k == bk && tie < bt)) {
               bk = k;
               bt = tie;
@@ -2696,10 +2806,13 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
           bn = on;
         }
       }
+      YK_RP(4)
       // ---- the waves' candidates meet in LDS; every thread reduces them (the result is workgroup-uniform)
       if (lane == 0) {
         sh_aw[wave] = aw;
-        sh_ax[wave] = ax;
+        sh_an[wave] = an_w;
+        sh_ak[wave] = ak_w;
+        sh_at[wave] = at_w;
         sh_cw[wave] = cw;
         sh_bk[wave] = bk;
         sh_bt[wave] = bt;
@@ -2707,7 +2820,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       }
       __syncthreads();
       int gaw = 0x7fffffff, gcw = 0x7fffffff;
-      u64 gax = 0;
+      int an = -1, at = 0;
+      u64 ak = 0;
       bk = ~0ull;
       bt = 0x7fffffff;
       bn = -1;
@@ -2715,7 +2829,9 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       for (int k = 0; k < kRoundWaves; ++k) {
         if (sh_aw[k] < gaw) {
           gaw = sh_aw[k];
-          gax = sh_ax[k];
+          an = sh_an[k];
+          ak = sh_ak[k];
+          at = sh_at[k];
         }
         gcw = min(gcw, sh_cw[k]);
         const u64 ok = sh_bk[k];
@@ -2728,14 +2844,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       }
       // (a wave that stopped early had nothing in front of the word another wave found: the minimum over the waves is exact)
       if (tid == 0) st_live(a.cursor + cls, gcw < a.row_words ? gcw : a.row_words);
-      int an = -1, at = 0;
-      u64 ak = 0;
-      if (gaw < a.row_words) {
-        an = a.perm[gaw * kWave + (__ffsll((long long)gax) - 1)];
-        ak = a.key0[an];
-        at = a.name_rank ? a.name_rank[an] : an;
-      }
       win = (an >= 0 && (bn < 0 || ak < bk || (ak == bk && at < bt))) ? an : bn;
+      YK_RP(5)
     }
     last_spec = pin == -1 ? spec : -1;
     last_win = win;
@@ -2745,68 +2855,83 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       // pods couple through nothing but resources "fits k more times" is arithmetic: k = what the free resources and pod slots
       // hold. The run is decided here in one step (the asks of a Deployment or task group: 110 per node in the reference's perf
       // shape) — the headers in this wave's registers bound it to the asks up to the next multiple of 64.
-      int k_run = 1;
-      const i64* rq = s.req + (size_t)spec * s.R;
-      const bool occupies = a.fx.occupied && a.ports;  // (a pod that occupies host ports conflicts with its own twin: no run)
-      bool any_occ = false;
-      if (occupies)
-        for (int k = 0; k < t.KP; ++k) any_occ = any_occ || a.fx.occupied[(size_t)spec * t.KP + k] != 0;
+      // The assume is WAVE 0's: everything it reads of the node, the spec and the round's bookkeeping is requested in ONE load round
+      // (lane r = resource r; lanes 8.. = the static columns a node brings along when it takes a slot), then stored; the other
+      // waves go on to the topology counts and meet it at the barrier.
       const bool contributes = a.topo_on && a.fx.off && a.fx.off[spec + 1] > a.fx.off[spec];
-      if (pin == -1 && tsig < 0 && !any_occ && !contributes && fit_on) {
-        // asks hl+1 .. of the header window with the same spec and no pin, consecutively
-        const u64 same = __ballot(spec_l == spec && pin_l == -1);
-        const u64 behind = hl < 63 ? (~same) >> (hl + 1) : ~0ull;  // first 0 of `same` behind lane hl ends the run
-        const int run = behind ? (int)(__ffsll((long long)behind) - 1) : (63 - hl);
-        i64 fits = (i64)t.allowed[win] - (i64)ld_live(a.count + win);  // pod slots left (>= 1: the ask fits)
-        for (int r = 0; r < t.R; ++r)
-          if (rq[r] > 0) fits = min(fits, (t.alloc[(size_t)r * t.n + win] - ld_live(a.req + (size_t)r * t.n + win)) / rq[r]);
-        k_run = (int)max((i64)1, min(fits, (i64)(1 + min(run, 63 - hl))));
-        k_run = min(k_run, a.n_asks - i);
-      }
-      step = k_run;
-      if (tid < k_run) a.out[a.first + i + tid] = win;
-      const int cnt = ld_live(a.count + win) + k_run;
-      const int rk = a.rank[win];
-      const bool was_moved = (ld_live(a.moved_bits + (rk >> 6)) >> (rk & 63)) & 1ull;
-      const bool dead = fit_on && (i64)cnt + 1 > (i64)t.allowed[win];  // no pod slot left: no ask of this phase fits it any more
-      const int slot = was_moved ? ld_live(a.slot_of + win) : n_moved;
-      if (tid == 0) {
-        i64 used[2] = {0, 0};
-        for (int r = 0; r < t.R; ++r) {
-          const i64 v = ld_live(a.req + (size_t)r * t.n + win) + rq[r] * (i64)k_run;
-          if (r < 2) used[r] = v;
-          st_live(a.req + (size_t)r * t.n + win, v);
-          st_live(a.m_free + (size_t)r * cap + slot, t.alloc[(size_t)r * t.n + win] - v);
+      if (wave == 0) {
+        const bool lr = lane < t.R, lp = lane < t.KP;
+        const i64 rq_l = lr ? s.req[(size_t)spec * s.R + lane] : 0;
+        const i64 al_l = lr ? t.alloc[(size_t)lane * t.n + win] : 0;
+        const i64 old_l = lr ? ld_live(a.req + (size_t)lane * t.n + win) : 0;
+        const int cnt0 = ld_live(a.count + win), allowed = t.allowed[win];
+        const int slot_prev = ld_live(a.slot_of + win);
+        const int rk = a.rank[win], tie_w = a.name_rank ? a.name_rank[win] : win;
+        const unsigned flags_w = t.flags[win];
+        const u64 occ_l = (lp && a.ports && a.fx.occupied) ? a.fx.occupied[(size_t)spec * t.KP + lane] : 0ull;
+        const u64 port_l = lp ? (a.ports ? ld_live(a.ports + (size_t)lane * t.n + win) : t.ports[(size_t)lane * t.n + win]) : 0ull;
+        const int c0 = 8, Wc = min(t.W, kMaxW), col = lane - c0;  // (lanes 0..7 hold the resources)
+        u64 stat_l = 0;
+        int dom_l = -1;
+        if (col >= 0 && col < t.KT) stat_l = t.taints[(size_t)col * t.n + win];
+        else if (col >= t.KT && col < t.KT + Wc) stat_l = t.labels[(size_t)(col - t.KT) * t.n + win];
+        else if (col >= t.KT + Wc && col < t.KT + Wc + t.KD) dom_l = t.domain[(size_t)(col - t.KT - Wc) * t.n + win];
+        const bool was_moved = slot_prev >= 0;
+        const int slot = was_moved ? slot_prev : n_moved;
+        // A RUN of asks with this spec lands on this node as long as it fits (the argument of the `again` path), and for a spec whose
+        // pods couple through nothing but resources "fits k more times" is arithmetic: k = what the free resources and pod slots
+        // hold. The run is decided here in one step (the asks of a Deployment or task group: 110 per node in the reference's perf
+        // shape) — the headers in this wave's registers bound it to the asks up to the next multiple of 64.
+        int k_run = 1;
+        const bool any_occ = __ballot(occ_l != 0) != 0;  // (a pod that occupies host ports conflicts with its own twin: no run)
+        if (pin == -1 && tsig < 0 && !any_occ && !contributes && fit_on) {
+          // asks hl+1 .. of the header window with the same spec and no pin, consecutively
+          const u64 same = __ballot(spec_l == spec && pin_l == -1);
+          const u64 behind = hl < 63 ? (~same) >> (hl + 1) : ~0ull;  // first 0 of `same` behind lane hl ends the run
+          const int run = behind ? (int)(__ffsll((long long)behind) - 1) : (63 - hl);
+          i64 fits_l = (lr && rq_l > 0) ? (al_l - old_l) / rq_l : 0x7fffffffffffffffll;
+#pragma unroll
+          for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
+          const i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));  // pod slots left (>= 1: the ask fits)
+          k_run = (int)max((i64)1, min(fits, (i64)(1 + min(run, 63 - hl))));
+          k_run = min(k_run, a.n_asks - i);
         }
-        st_live(a.count + win, cnt);
-        st_live(a.m_room + slot, t.allowed[win] - cnt);
-        const i64 total[2] = {t.alloc[win], t.alloc[(size_t)t.n + win]};
-        st_live(a.m_key + slot, sortable_key(node_score_of(total, used)));
+        if (lane < k_run) a.out[a.first + i + lane] = win;
+        const int cnt = cnt0 + k_run;
+        const bool dead = fit_on && (i64)cnt + 1 > (i64)allowed;  // no pod slot left: no ask of this phase fits it any more
+        const i64 v_l = old_l + rq_l * (i64)k_run;
+        if (lr) {
+          st_live(a.req + (size_t)lane * t.n + win, v_l);
+          st_live(a.m_free + (size_t)lane * cap + slot, al_l - v_l);
+        }
+        const i64 used[2] = {(i64)__shfl((long long)v_l, 0, kWave), (i64)__shfl((long long)v_l, 1, kWave)};
+        const i64 total[2] = {(i64)__shfl((long long)al_l, 0, kWave), (i64)__shfl((long long)al_l, 1, kWave)};
+        if (lane == 0) {
+          st_live(a.count + win, cnt);
+          st_live(a.m_room + slot, allowed - cnt);
+          st_live(a.m_key + slot, sortable_key(node_score_of(total, used)));
+          if (!was_moved) {
+            atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
+            st_live(a.slot_of + win, slot);
+            a.m_node[slot] = win;
+            a.m_tie[slot] = tie_w;
+            a.m_flags[slot] = flags_w;
+          }
+          if (dead) atomicOr(a.dead + (slot >> 6), 1ull << (slot & 63));
+          sh_step = k_run;
+          sh_was_moved = was_moved ? 1 : 0;
+        }
+        // host ports the pod occupies from now on (NodeInfo.UsedPorts)
+        if (lp) {
+          if (a.ports && occ_l) atomicOr(a.ports + (size_t)lane * t.n + win, occ_l);
+          if (occ_l || !was_moved) st_live(a.m_ports + (size_t)lane * cap + slot, port_l | occ_l);
+        }
+        // the static columns of a node that has just taken a slot: one lane per column
         if (!was_moved) {
-          atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
-          st_live(a.slot_of + win, slot);
-          a.m_node[slot] = win;
-          a.m_tie[slot] = a.name_rank ? a.name_rank[win] : win;
-          a.m_flags[slot] = t.flags[win];
+          if (col >= 0 && col < t.KT) a.m_taint[(size_t)col * cap + slot] = stat_l;
+          else if (col >= t.KT && col < t.KT + Wc) a.m_label[(size_t)(col - t.KT) * cap + slot] = stat_l;
+          else if (col >= t.KT + Wc && col < t.KT + Wc + t.KD) a.m_dom[(size_t)(col - t.KT - Wc) * cap + slot] = dom_l;
         }
-        if (dead) atomicOr(a.dead + (slot >> 6), 1ull << (slot & 63));
-      }
-      // host ports the pod occupies from now on (NodeInfo.UsedPorts)
-      if (a.ports && tid < t.KP) {
-        const u64 occ = a.fx.occupied ? a.fx.occupied[(size_t)spec * t.KP + tid] : 0ull;
-        const u64 now = (occ ? atomicOr(a.ports + (size_t)tid * t.n + win, occ) : ld_live(a.ports + (size_t)tid * t.n + win)) | occ;
-        if (occ || !was_moved) st_live(a.m_ports + (size_t)tid * cap + slot, now);
-      } else if (!a.ports && !was_moved && tid < t.KP) {
-        a.m_ports[(size_t)tid * cap + slot] = t.ports[(size_t)tid * t.n + win];
-      }
-      // the static columns of a node that has just moved: one thread per column
-      if (!was_moved) {
-        const int c0 = 8;  // (threads 0..7 are busy above)
-        const int Wc = min(t.W, kMaxW);
-        const int col = tid - c0;
-        if (col >= 0 && col < t.KT) a.m_taint[(size_t)col * cap + slot] = t.taints[(size_t)col * t.n + win];
-        else if (col >= t.KT && col < t.KT + Wc) a.m_label[(size_t)(col - t.KT) * cap + slot] = t.labels[(size_t)(col - t.KT) * t.n + win];
-        else if (col >= t.KT + Wc && col < t.KT + Wc + t.KD) a.m_dom[(size_t)(col - t.KT - Wc) * cap + slot] = t.domain[(size_t)(col - t.KT - Wc) * t.n + win];
       }
       // match counts of the topology plugins: thread = constraint (of any signature) whose selector class the pod adds to
       if (contributes) {
@@ -2849,7 +2974,9 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       }
       __threadfence();
       __syncthreads();
-      if (!was_moved) ++n_moved;
+      YK_RP(6)
+      step = sh_step;
+      if (!sh_was_moved) ++n_moved;
       // spread constraints whose last domain left the minimum: the new minimum, the whole workgroup over the constraint's domains
       const int ndirty = min(sh_ndirty, kRoundDirty);
       for (int q = 0; q < ndirty; ++q) {
@@ -2885,6 +3012,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
     }
     // (the exchange slots are rewritten by the next ask only after this barrier; every wave has read them by now)
     __syncthreads();
+    YK_RP(7)
   }
   if (tid == 0) st_live(a.n_moved, n_moved);
 }
