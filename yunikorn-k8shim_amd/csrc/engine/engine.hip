@@ -2685,12 +2685,12 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                o_ports = take(live_ports ? (size_t)e->KP * N * sizeof(u64) : 0), o_cnt = take(N * sizeof(int)), o_cur = take(C * sizeof(int)),
                o_slot = take(N * sizeof(int)), o_mnode = take(cap * sizeof(int)), o_mtie = take(cap * sizeof(int)), o_mkey = take(cap * sizeof(u64)),
                o_mfree = take(R * cap * sizeof(i64)), o_mroom = take(cap * sizeof(int)), o_mports = take(KP1 * cap * sizeof(u64)),
-               o_mtaint = take((size_t)e->KT * cap * sizeof(u64)), o_mlabel = take(Wc * cap * sizeof(u64)), o_mdom = take(KD1 * cap * sizeof(int)),
+               o_mtaint = take((size_t)std::max(e->KT, 1) * cap * sizeof(u64)), o_mlabel = take(std::max<size_t>(Wc, 1) * cap * sizeof(u64)), o_mdom = take(KD1 * cap * sizeof(int)),
                o_mflags = take(cap * sizeof(unsigned)), o_dead = take(cap64 * sizeof(u64)), o_failed = take(keep_failed ? C * cap64 * sizeof(u64) : 0),
                o_asks = take((size_t)n_asks * sizeof(int)), o_out = take((size_t)n_asks * sizeof(int)),
                o_nm = take(sizeof(int)), o_hist = take(cells * sizeof(int)), o_minv = take(G * sizeof(int)), o_mn = take(G * sizeof(int)),
                o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int)), o_prof = take(16 * sizeof(i64)),
-               o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int));
+               o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int)), o_cdesc = take(C * ykk::kDescWords * sizeof(u64));
   HIPCHK(e->d_round.ensure(off));
   char* base = (char*)e->d_round.p;
   HIPCHK(hipMemcpyAsync(base + o_req, e->d_req.p, R * (size_t)e->N * sizeof(i64), hipMemcpyDeviceToDevice, st));
@@ -2787,13 +2787,18 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                          (int*)(base + o_mn), (int*)(base + o_at), (int*)(base + o_nd));
   }
   const ykk::Planes pr = ranked_planes_of(e, pre, filt, false, e->ranked_has_first);
+  // the plane rows of every class, resolved once (the loop reads a class's descriptor in one load round instead of walking the tables)
+  ra.cdesc = (const u64*)(base + o_cdesc);
+  if (e->C > 0)
+    hipLaunchKernelGGL(ykk::k_round_class_desc, dim3((unsigned)((e->C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, ct, pr, e->C,
+                       (u64*)(base + o_cdesc));
   // one launch per 32 768 asks: the loop is a single workgroup, and a bounded launch keeps the queue responsive (the state of the
   // round — scratch tables, moved list — lives in memory between the launches)
   const int per_launch = 32768;
   for (int first = 0; first < n_asks; first += per_launch) {
     ra.first = first;
     ra.n_asks = std::min(per_launch, n_asks - first);
-    hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, nt, stbl, ct, pr, ra);
+    hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_nodes, base + o_out, (size_t)n_asks * sizeof(int), hipMemcpyDeviceToHost, st));

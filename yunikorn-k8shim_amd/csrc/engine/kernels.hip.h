@@ -2426,6 +2426,7 @@ struct RoundArgs {
   const u64* key0;          // ... and its score keys
   const u64* rkey;          // [N] key0 in bin-pack order (rkey[pos] = key0[perm[pos]]) and the NodeID ranks beside it: what candidate A
   const int* rtie;          //     needs of its node, addressed by the POSITION the scan found (k_round_ranked_keys, once per round)
+  const u64* cdesc;         // [C][kDescWords] the rank-ordered plane rows of every class, resolved once per round (k_round_class_desc)
   const int* name_rank;     // NodeID order (null: node index)
   unsigned pre, filt;
   int row_words, all_fail;
@@ -2465,12 +2466,21 @@ struct RoundArgs {
   SpecEffects fx;
   i64* prof;                // YKPRED_TUNE round_prof=1: thread 0's 100 MHz ticks per phase of the loop (null: off)
 };
+// Per-phase ticks of the loop (thread 0, 100 MHz): compiled in with -DYK_ROUND_PROF only (build.py: YK_ROUND_PROF=1) — the kernel
+// has no scalar register to spare for a pointer it does not use.
+#ifdef YK_ROUND_PROF
 #define YK_RP(k)                                  \
   if (a.prof && tid == 0) {                       \
     const i64 now_ = (i64)wall_clock64();         \
     a.prof[k] += now_ - rp_prev;                  \
     rp_prev = now_;                               \
   }
+#define YK_RP_COUNT(k) \
+  if (a.prof && tid == 0) a.prof[k] += 1;
+#else
+#define YK_RP(k)
+#define YK_RP_COUNT(k)
+#endif
 __device__ __forceinline__ void load_node_live(const NodeTable& t, const RoundArgs& a, int n, NodeRegs* r) {
   load_node(t, n, r);  // immutable columns (the stale-prone ones are overwritten below)
 #pragma unroll
@@ -2501,23 +2511,100 @@ __device__ __forceinline__ void load_slot_live(const NodeTable& t, const RoundAr
   r->slots_ok = ld_live(a.m_room + slot) >= 1;
   r->unsched = a.m_flags[slot] & kNodeUnschedulable;
 }
+// The FLAT form of the scan over the moved nodes — tables of the usual width (kFlat* below), spec without topology signature:
+// the same registers WITHOUT a branch between the loads. A column past the table's width re-reads the last real column and is
+// masked afterwards, so that every load of a slot sits in one basic block — one round trip per step of the scan instead of one
+// per column group (the compiler waits at every branch that guards a load). Wider tables take load_slot_live + eval_pair.
+constexpr int kFlatR = 4, kFlatKT = 1, kFlatW = 4, kFlatKP = 1;
+struct SlotFlat {
+  i64 fr[kFlatR];
+  u64 tn[kFlatKT], lb[kFlatW], pt[kFlatKP];
+  bool slots_ok, unsched;
+};
+__device__ __forceinline__ void load_slot_flat(const NodeTable& t, const RoundArgs& a, int slot, SlotFlat* r, int* m, u64* key, int* tie) {
+  const size_t c = (size_t)a.cap;
+  const int R1 = t.R - 1, KT1 = max(t.KT, 1) - 1, W1 = max(t.W, 1) - 1, KP1 = max(t.KP, 1) - 1;
+  i64 fr[kFlatR];
+  u64 tn[kFlatKT], lb[kFlatW], pt[kFlatKP];
+#pragma unroll
+  for (int i = 0; i < kFlatR; ++i) fr[i] = ld_live(a.m_free + (size_t)min(i, R1) * c + slot);
+#pragma unroll
+  for (int i = 0; i < kFlatKT; ++i) tn[i] = a.m_taint[(size_t)min(i, KT1) * c + slot];
+#pragma unroll
+  for (int i = 0; i < kFlatW; ++i) lb[i] = a.m_label[(size_t)min(i, W1) * c + slot];
+#pragma unroll
+  for (int i = 0; i < kFlatKP; ++i) pt[i] = ld_live(a.m_ports + (size_t)min(i, KP1) * c + slot);
+  const int room = ld_live(a.m_room + slot);
+  const unsigned fl = a.m_flags[slot];
+  *m = a.m_node[slot];
+  *key = ld_live(a.m_key + slot);
+  *tie = a.m_tie[slot];
+#pragma unroll
+  for (int i = 0; i < kFlatR; ++i) r->fr[i] = i < t.R ? fr[i] : 0;
+#pragma unroll
+  for (int i = 0; i < kFlatKT; ++i) r->tn[i] = i < t.KT ? tn[i] : 0;
+#pragma unroll
+  for (int i = 0; i < kFlatW; ++i) r->lb[i] = i < t.W ? lb[i] : 0;
+#pragma unroll
+  for (int i = 0; i < kFlatKP; ++i) r->pt[i] = i < t.KP ? pt[i] : 0;
+  r->slots_ok = room >= 1;
+  r->unsched = fl & kNodeUnschedulable;
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int l) {
+  return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+// dnf_match over terms held in LANE registers: lane j of `tv` = word j of the spec's term rows (term t, word w at lane t * W + w;
+// nt * W <= 64, W <= kFlatW). No memory behind the slot loads: the mask words come out of the register file.
+__device__ __forceinline__ bool dnf_match_lanes(u64 tv, int nt, const u64 (&lb)[kFlatW], int W) {
+  bool any = false;
+  for (int tt = 0; tt < nt; ++tt) {
+    bool all = true;
+#pragma unroll
+    for (int w = 0; w < kFlatW; ++w)
+      if (w < W) {
+        const u64 mw = readlane64(tv, tt * W + w);
+        all = all && (lb[w] & mw) == mw;
+      }
+    any = any || all;
+  }
+  return any;
+}
+// The plane rows of a class as the round's scan reads them: kDescRows row pointers (the last real one repeated — an AND with a
+// duplicate changes nothing, and the loads need no branch), then [kDescRows] = rows | first word << 32. rows = 0xffffffff: the class
+// has index rows or more plane rows than fit — it takes class_rows() per ask.
+constexpr int kDescRows = 8, kDescWords = kDescRows + 2;
+__global__ __launch_bounds__(kBlock) void k_round_class_desc(ClassTable ct, Planes ranked, int n_classes, u64* __restrict__ desc) {
+  const int cls = blockIdx.x * kBlock + threadIdx.x;
+  if (cls >= n_classes) return;
+  const ClassRows cr = class_rows(ranked, ct.sig[cls * 4 + 0], ct.sig[cls * 4 + 1], ct.sig[cls * 4 + 2], -1);
+  u64* d = desc + (size_t)cls * kDescWords;
+  const bool slow = cr.ni > 0 || cr.n > kDescRows;
+  const u64* last = nullptr;
+#pragma unroll
+  for (int i = 0; i < kMaxClassRows; ++i)
+    if (i < cr.n) last = cr.row[i];
+#pragma unroll
+  for (int i = 0; i < kDescRows; ++i) d[i] = (u64)(i < cr.n ? cr.row[i] : last);
+  d[kDescRows] = (u64)(slow ? 0xffffffffu : (unsigned)cr.n) | ((u64)(unsigned)cr.start << 32);
+  d[kDescRows + 1] = 0;
+}
 // What the Filter list reads of a SPEC, loaded once per ask: the scan over the moved nodes evaluates one spec against many
 // slots, and eval_pair's loads sit behind its early exits — a chain of dependent round trips per pair.
 struct SpecRegs {
   unsigned f;
-  u64 tol[kMaxKT];
-  i64 req[kMaxR];
-  u64 want[kMaxKP];
+  u64 tol[kFlatKT];
+  i64 req[kFlatR];
+  u64 want[kFlatKP];
   int pre_b, pre_e, term_b, term_e;
 };
 __device__ __forceinline__ void load_spec_regs(const SpecTable& s, int spec, SpecRegs* q) {
   q->f = s.flags[spec];
 #pragma unroll
-  for (int k = 0; k < kMaxKT; ++k) q->tol[k] = k < s.KT ? s.tol[(size_t)spec * s.KT + k] : ~0ull;
+  for (int k = 0; k < kFlatKT; ++k) q->tol[k] = k < s.KT ? s.tol[(size_t)spec * s.KT + k] : ~0ull;
 #pragma unroll
-  for (int k = 0; k < kMaxR; ++k) q->req[k] = k < s.R ? s.req[(size_t)spec * s.R + k] : 0;
+  for (int k = 0; k < kFlatR; ++k) q->req[k] = k < s.R ? s.req[(size_t)spec * s.R + k] : 0;
 #pragma unroll
-  for (int k = 0; k < kMaxKP; ++k) q->want[k] = k < s.KP ? s.wanted_ports[(size_t)spec * s.KP + k] : 0ull;
+  for (int k = 0; k < kFlatKP; ++k) q->want[k] = k < s.KP ? s.wanted_ports[(size_t)spec * s.KP + k] : 0ull;
   q->pre_b = s.aff.pre_off[spec];
   q->pre_e = s.aff.pre_off[spec + 1];
   q->term_b = s.aff.term_off[spec];
@@ -2525,38 +2612,37 @@ __device__ __forceinline__ void load_spec_regs(const SpecTable& s, int spec, Spe
 }
 // eval_pair's VERDICT (fit or not; no failing plugin) for an ask without pin whose spec has no topology signature, from the
 // registers above and without early exits: the same conditions in the same plugin order (predicate_manager.go:221-283).
-__device__ __forceinline__ bool spec_fits_node(const SpecTable& s, const SpecRegs& q, const NodeRegs& nr, unsigned pre_mask, unsigned filt_mask) {
+// tv / pv: the spec's Filter terms / PreFilter names in lane registers, see dnf_match_lanes.
+__device__ __forceinline__ bool spec_fits_node(const SpecTable& s, const SpecRegs& q, const SlotFlat& nr, unsigned pre_mask, unsigned filt_mask, u64 tv, u64 pv) {
   const unsigned f = q.f;
   bool ok = !(f & kSpecUnsupported);
   if ((pre_mask & kPlugAffinity) && !(f & kSpecAffSkip)) {
     if (f & kSpecPreReject) ok = false;
-    else if (f & kSpecPreNames) ok = dnf_match(s.aff.pre_terms, q.pre_b, q.pre_e, nr.lb, s.W, nr.lb_more, nr.lb_stride) && ok;
+    else if (f & kSpecPreNames) ok = dnf_match_lanes(pv, q.pre_e - q.pre_b, nr.lb, s.W) && ok;
   }
   if ((filt_mask & kPlugUnsched) && nr.unsched && !(f & kSpecToleratesUnsched)) ok = false;
   if (filt_mask & kPlugTaint) {
 #pragma unroll
-    for (int k = 0; k < kMaxKT; ++k)
-      if (k < s.KT) ok = ok && (nr.tn[k] & ~q.tol[k]) == 0;
+    for (int k = 0; k < kFlatKT; ++k) ok = ok && (nr.tn[k] & ~q.tol[k]) == 0;
   }
   if (filt_mask & kPlugAffinity) {
     const bool skip = (pre_mask & kPlugAffinity) && (f & kSpecAffSkip);
-    if (!skip) ok = dnf_match(s.aff.terms, q.term_b, q.term_e, nr.lb, s.W, nr.lb_more, nr.lb_stride) && ok;
+    if (!skip) ok = dnf_match_lanes(tv, q.term_e - q.term_b, nr.lb, s.W) && ok;
   }
   if (filt_mask & kPlugPorts) {
     bool any = false, conflict = false;
 #pragma unroll
-    for (int k = 0; k < kMaxKP; ++k)
-      if (k < s.KP) {
-        any = any || q.want[k] != 0;
-        conflict = conflict || (nr.pt[k] & q.want[k]) != 0;
-      }
+    for (int k = 0; k < kFlatKP; ++k) {
+      any = any || q.want[k] != 0;
+      conflict = conflict || (nr.pt[k] & q.want[k]) != 0;
+    }
     if (!(pre_mask & kPlugPorts) || (any && conflict)) ok = false;
   }
   if (filt_mask & kPlugFit) {
     if (!(pre_mask & kPlugFit) || !nr.slots_ok) ok = false;
 #pragma unroll
-    for (int r = 0; r < kMaxR; ++r)
-      if (r < s.R && q.req[r] > 0 && q.req[r] > nr.fr[r]) ok = false;
+    for (int r = 0; r < kFlatR; ++r)
+      if (q.req[r] > 0 && q.req[r] > nr.fr[r]) ok = false;
   }
   if ((filt_mask & kPlugSpread) && !(pre_mask & kPlugSpread)) ok = false;
   if ((filt_mask & kPlugInterPod) && !(pre_mask & kPlugInterPod)) ok = false;
@@ -2598,7 +2684,28 @@ __global__ __launch_bounds__(kWave) void k_round_topo_init(SpreadSigs sp, int n_
     nd_out[g] = nd;
   }
 }
-__global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, SpecTable s, ClassTable ct, Planes ranked, RoundArgs a) {
+// The kernel's tables are a hundred pointers. Taken as ordinary arguments they are all loaded at entry and stay live through the
+// loop: twice the scalar register file, spilled to vector lanes and those to scratch — every reload a full wait in the middle of a
+// load round. So the loop reads them where it uses them, from the kernel-argument segment itself (scalar loads, constant cache),
+// through a pointer the compiler has to take as new at the head of every phase (YK_CTX_FRESH): nothing is carried across phases.
+struct RoundCtx {
+  NodeTable nodes;
+  SpecTable specs;
+  ClassTable classes;
+  Planes planes;
+  RoundArgs args;
+};
+static_assert(sizeof(RoundCtx) <= 3584, "the round's tables travel in the kernel-argument segment");
+typedef const RoundCtx __attribute__((address_space(4))) * RoundCtxPtr;
+#define YK_CTX_FRESH() asm volatile("" : "+s"(cx))
+#define t (*(const NodeTable*)&cx->nodes)
+#define s (*(const SpecTable*)&cx->specs)
+#define ct (*(const ClassTable*)&cx->classes)
+#define ranked (*(const Planes*)&cx->planes)
+#define a (*(const RoundArgs*)&cx->args)
+#define sp (*(const SpreadSigs*)&cx->specs.spread)
+__global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_value) {
+  RoundCtxPtr cx = (RoundCtxPtr)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ int sh_aw[kRoundWaves], sh_cw[kRoundWaves], sh_bt[kRoundWaves], sh_bn[kRoundWaves], sh_an[kRoundWaves], sh_at[kRoundWaves];
   __shared__ u64 sh_ak[kRoundWaves], sh_bk[kRoundWaves];
   __shared__ int sh_step, sh_was_moved;  // what wave 0's assume decided: asks of the run, the node had a slot already
@@ -2610,7 +2717,6 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
   const bool name_on = a.filt & kPlugNodeName;
   const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
   const bool spread_en = a.filt & kPlugSpread, ipa_en = (a.filt & kPlugInterPod) && (a.pre & kPlugInterPod);
-  const SpreadSigs& sp = s.spread;
   const size_t cap = (size_t)a.cap;
   int p_l = 0, spec_l = 0, pin_l = -1, cls_l = 0;
   int last_spec = -1, last_win = -1;  // (per launch: the first ask of a launch takes the scans)
@@ -2620,9 +2726,12 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
   }
   __syncthreads();
   int step = 0;  // (asks decided by an iteration: runs of one spec that land on one node are decided together)
+#ifdef YK_ROUND_PROF
   i64 rp_prev = a.prof ? (i64)wall_clock64() : 0;
+#endif
   for (int i = 0; i < a.n_asks; i += step) {
-    if (a.prof && tid == 0) a.prof[8] += 1;
+    YK_CTX_FRESH();
+    YK_RP_COUNT(8)
     int& sh_stop = sh_stop_[i & 1];
     int& sh_ndirty = sh_ndirty_[i & 1];
     step = 1;
@@ -2664,7 +2773,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
     YK_RP(1)
     if (again) {
       win = last_win;
-      if (a.prof && tid == 0) a.prof[9] += 1;
+      YK_RP_COUNT(9)
     } else if (a.all_fail || pin == -2) {
       // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
     } else if (pin >= 0) {
@@ -2675,13 +2784,32 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       if (eval_pair<true>(s, spec, pin, pin, nr, a.pre, a.filt, &code, &reason)) win = pin;
       YK_RP(2)
     } else {
+      YK_CTX_FRESH();
       // ---- candidate A: the first unmoved feasible node in snapshot order. aw / ax: the first word of THIS wave with a feasible
       // node and its bits; cw: the first word of this wave with a candidate of the snapshot planes (the class's cursor)
       int aw = 0x7fffffff, cw = 0x7fffffff;
       u64 ax = 0;
       // (requested before the scan, used behind it: the spec's registers and the bitset words of the first 64 steps of candidate B)
       SpecRegs q;
-      if (tsig < 0) load_spec_regs(s, spec, &q);
+      u64 tv_l = 0, pv_l = 0;
+      bool flat = tsig < 0 && t.R <= kFlatR && t.KT <= kFlatKT && t.W <= kFlatW && t.KP <= kFlatKP;  // (the tables are of the usual width)
+      // (the class's descriptor: every lane reads the same words — they stay in vector registers, the scalar file is full of table pointers)
+      const u64* dsc = a.cdesc + (size_t)cls * kDescWords;
+      typedef const u64 __attribute__((address_space(1))) * GlobalRow;  // (a pointer that comes out of memory: said to be global, else the loads are flat)
+      GlobalRow dr[kDescRows];
+#pragma unroll
+      for (int k = 0; k < kDescRows; ++k) dr[k] = (GlobalRow)dsc[k];
+      const u64 meta = dsc[kDescRows];
+      int w0 = ld_live(a.cursor + cls);
+      if (flat) {
+        load_spec_regs(s, spec, &q);
+        const int nt = (q.term_e - q.term_b) * s.W, np = (q.pre_e - q.pre_b) * s.W;
+        flat = nt <= kWave && np <= kWave;  // (the spec's term rows fit the lanes of a wave)
+        if (flat) {  // (a lane past the spec's words re-reads its last one — never consulted)
+          tv_l = nt > 0 ? s.aff.terms[(size_t)q.term_b * s.W + min(lane, nt - 1)] : 0ull;
+          pv_l = np > 0 ? s.aff.pre_terms[(size_t)q.pre_b * s.W + min(lane, np - 1)] : 0ull;
+        }
+      }
       u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
       u64 fb_l = 0, dead_l = ~0ull;  // lane k: this wave's bitset words of step (j0 / kRoundThreads) % 64 == k, one load round for 64 steps
       {
@@ -2691,16 +2819,27 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
         dead_l = in ? ld_live(a.dead + wl) : ~0ull;
       }
       {
-        const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2];
-        const ClassRows cr = class_rows(ranked, sr, st, sa, -1);  // (ranked.spread is null: the topology family is checked live)
-        int w0 = ld_live(a.cursor + cls);
+        // (ranked.spread is null: the topology family is checked live)
+        const int dn = (int)(unsigned)meta;  // plane rows of the class (-1: resolved here, per ask)
+        ClassRows cr;
+        cr.n = 0;
+        cr.ni = 0;
+        cr.start = (int)(meta >> 32);
+        if (dn < 0) cr = class_rows(ranked, ct.sig[cls * 4 + 0], ct.sig[cls * 4 + 1], ct.sig[cls * 4 + 2], -1);
         if (w0 < 0) w0 = cr.start;  // (kNoWord: some row of the class is empty)
         for (int base = w0 < a.row_words ? (w0 & ~(kWave - 1)) : a.row_words; base < a.row_words && aw == 0x7fffffff; base += kRoundThreads) {
           const int w = base + tid;
           u64 x = 0;
           if (w >= w0 && w < a.row_words) {
-            x = ~ld_live(a.moved_bits + w);
-            if (x) x &= class_word(cr, w);
+            const u64 mv = ld_live(a.moved_bits + w);
+            u64 v = ~0ull;
+            if (dn > 0) {  // (one load round: the moved bits and every row of the class)
+#pragma unroll
+              for (int k = 0; k < kDescRows; ++k) v &= dr[k][w];
+            } else if (dn < 0) {
+              v = class_word(cr, w);
+            }
+            x = ~mv & v;
           }
           u64 todo = __ballot(x != 0);
           if (!todo) continue;  // (wave-uniform)
@@ -2748,6 +2887,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
         at_w = a.rtie[pos];
       }
       YK_RP(3)
+      YK_CTX_FRESH();
       // ---- candidate B: the best moved node, per pair from the live slot columns. A wave's 64 slots are one word of the bitsets:
       // slots of dead nodes and — for a class without topology signature — slots the class failed on before are skipped without
       // a load; what it fails on now is remembered.
@@ -2768,17 +2908,21 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
         const u64 skip = fbits | __shfl(dead_l, st_k, kWave);
         const bool act = slot < n_moved && !((skip >> lane) & 1ull);
         if (__ballot(act) == 0) continue;
-        if (a.prof && tid == 0) a.prof[10] += 1;
+        YK_RP_COUNT(10)
         bool fit = false;
         if (act) {
-          NodeRegs nr;
-          load_slot_live(t, a, slot, tsig >= 0, &nr);
-          const int m = a.m_node[slot];
-          const u64 k = ld_live(a.m_key + slot);  // (with the columns, not behind the verdict: one round trip per step)
-          const int tie = a.m_tie[slot];
-          if (tsig < 0) {
-            fit = spec_fits_node(s, q, nr, a.pre, a.filt);
+          int m, tie;
+          u64 k;  // (the key with the columns, not behind the verdict: one round trip per step)
+          if (flat) {
+            SlotFlat nr;
+            load_slot_flat(t, a, slot, &nr, &m, &k, &tie);
+            fit = spec_fits_node(s, q, nr, a.pre, a.filt, tv_l, pv_l);
           } else {
+            NodeRegs nr;
+            load_slot_live(t, a, slot, tsig >= 0, &nr);
+            m = a.m_node[slot];
+            k = ld_live(a.m_key + slot);
+            tie = a.m_tie[slot];
             int code;
             unsigned reason;
             fit = eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason);
@@ -2807,6 +2951,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
         }
       }
       YK_RP(4)
+      YK_CTX_FRESH();
       // ---- the waves' candidates meet in LDS; every thread reduces them (the result is workgroup-uniform)
       if (lane == 0) {
         sh_aw[wave] = aw;
@@ -2849,6 +2994,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
     }
     last_spec = pin == -1 ? spec : -1;
     last_win = win;
+    YK_CTX_FRESH();
     if (win >= 0) {  // (workgroup-uniform)
       // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod).
       // A RUN of asks with this spec lands on this node as long as it fits (the argument of the `again` path), and for a spec whose
@@ -2861,9 +3007,9 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
       const bool contributes = a.topo_on && a.fx.off && a.fx.off[spec + 1] > a.fx.off[spec];
       if (wave == 0) {
         const bool lr = lane < t.R, lp = lane < t.KP;
-        const i64 rq_l = lr ? s.req[(size_t)spec * s.R + lane] : 0;
-        const i64 al_l = lr ? t.alloc[(size_t)lane * t.n + win] : 0;
-        const i64 old_l = lr ? ld_live(a.req + (size_t)lane * t.n + win) : 0;
+        const int rl = min(lane, t.R - 1);  // (lanes past the resources re-read the last one: no branch around the loads)
+        const i64 rq_raw = s.req[(size_t)spec * s.R + rl], al_raw = t.alloc[(size_t)rl * t.n + win], old_raw = ld_live(a.req + (size_t)rl * t.n + win);
+        const i64 rq_l = lr ? rq_raw : 0, al_l = lr ? al_raw : 0, old_l = lr ? old_raw : 0;
         const int cnt0 = ld_live(a.count + win), allowed = t.allowed[win];
         const int slot_prev = ld_live(a.slot_of + win);
         const int rk = a.rank[win], tie_w = a.name_rank ? a.name_rank[win] : win;
@@ -3016,6 +3162,13 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(NodeTable t, S
   }
   if (tid == 0) st_live(a.n_moved, n_moved);
 }
+#undef t
+#undef s
+#undef ct
+#undef ranked
+#undef a
+#undef sp
+#undef YK_CTX_FRESH
 
 // order-independent checksum of the bitmap: Σ mix64(word ⊕ position-salt) over the meaningful words
 __device__ __forceinline__ u64 mix64(u64 z) {
