@@ -76,15 +76,18 @@ struct NodeTable {
 };
 
 // State that a running kernel changes and re-reads (ykpred_allocate_round: the scratch copies of Requested / pod counts / topology
-// histograms / host-port words): agent-scope atomics, i.e. loads that do not hit a stale L1 line.
+// histograms / host-port words). The round is ONE workgroup, so WORKGROUP scope is all the coherence it needs: its waves share
+// the compute unit's L1, which sees the unit's own stores — plain loads and stores, ordered by the loop's barriers. (Agent scope
+// was what the loop cost most: on this part every such load bypasses the L2 of its XCD and every release fence writes it back.)
 template <class T>
 __device__ __forceinline__ T ld_live(const T* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 template <class T>
 __device__ __forceinline__ void st_live(T* p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void or_live(u64* p, u64 v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 template <bool LIVE, class T>
 __device__ __forceinline__ T ld_maybe_live(const T* p) {
   if constexpr (LIVE) return ld_live(p);
@@ -2553,6 +2556,19 @@ __device__ __forceinline__ void load_slot_flat(const NodeTable& t, const RoundAr
 __device__ __forceinline__ u64 readlane64(u64 v, int l) {
   return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, l);
 }
+// Minimum of an unsigned over the 64 lanes of the wave, in every lane: the DPP row-shift / row-broadcast ladder of wave_sum_to_lane63
+// with min for + (lanes without a source keep the identity), then one readlane — VALU only, no trip through the LDS crossbar.
+__device__ __forceinline__ unsigned wave_umin(unsigned v) {
+  const int id = -1;  // 0xffffffff
+  unsigned m = min(v, (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  m = min(m, (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xf, 0xf, false));           // row_shr:2
+  m = min(m, (unsigned)__builtin_amdgcn_update_dpp(id, (int)v, 0x113, 0xf, 0xf, false));           // row_shr:3
+  m = min(m, (unsigned)__builtin_amdgcn_update_dpp(id, (int)m, 0x114, 0xf, 0xe, false));           // row_shr:4, lanes 4..15 of every row
+  m = min(m, (unsigned)__builtin_amdgcn_update_dpp(id, (int)m, 0x118, 0xf, 0xc, false));           // row_shr:8, lanes 8..15: lane 15 holds the row's
+  m = min(m, (unsigned)__builtin_amdgcn_update_dpp(id, (int)m, 0x142, 0xa, 0xf, false));           // row_bcast:15 into rows 1 and 3
+  m = min(m, (unsigned)__builtin_amdgcn_update_dpp(id, (int)m, 0x143, 0xc, 0xf, false));           // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane((int)m, 63);
+}
 // dnf_match over terms held in LANE registers: lane j of `tv` = word j of the spec's term rows (term t, word w at lane t * W + w;
 // nt * W <= 64, W <= kFlatW). No memory behind the slot loads: the mask words come out of the register file.
 __device__ __forceinline__ bool dnf_match_lanes(u64 tv, int nt, const u64 (&lb)[kFlatW], int W) {
@@ -2613,12 +2629,12 @@ __device__ __forceinline__ void load_spec_regs(const SpecTable& s, int spec, Spe
 // eval_pair's VERDICT (fit or not; no failing plugin) for an ask without pin whose spec has no topology signature, from the
 // registers above and without early exits: the same conditions in the same plugin order (predicate_manager.go:221-283).
 // tv / pv: the spec's Filter terms / PreFilter names in lane registers, see dnf_match_lanes.
-__device__ __forceinline__ bool spec_fits_node(const SpecTable& s, const SpecRegs& q, const SlotFlat& nr, unsigned pre_mask, unsigned filt_mask, u64 tv, u64 pv) {
+__device__ __forceinline__ bool spec_fits_node(int W, const SpecRegs& q, const SlotFlat& nr, unsigned pre_mask, unsigned filt_mask, u64 tv, u64 pv) {
   const unsigned f = q.f;
   bool ok = !(f & kSpecUnsupported);
   if ((pre_mask & kPlugAffinity) && !(f & kSpecAffSkip)) {
     if (f & kSpecPreReject) ok = false;
-    else if (f & kSpecPreNames) ok = dnf_match_lanes(pv, q.pre_e - q.pre_b, nr.lb, s.W) && ok;
+    else if (f & kSpecPreNames) ok = dnf_match_lanes(pv, q.pre_e - q.pre_b, nr.lb, W) && ok;
   }
   if ((filt_mask & kPlugUnsched) && nr.unsched && !(f & kSpecToleratesUnsched)) ok = false;
   if (filt_mask & kPlugTaint) {
@@ -2627,7 +2643,7 @@ __device__ __forceinline__ bool spec_fits_node(const SpecTable& s, const SpecReg
   }
   if (filt_mask & kPlugAffinity) {
     const bool skip = (pre_mask & kPlugAffinity) && (f & kSpecAffSkip);
-    if (!skip) ok = dnf_match_lanes(tv, q.term_e - q.term_b, nr.lb, s.W) && ok;
+    if (!skip) ok = dnf_match_lanes(tv, q.term_e - q.term_b, nr.lb, W) && ok;
   }
   if (filt_mask & kPlugPorts) {
     bool any = false, conflict = false;
@@ -2728,6 +2744,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
   int step = 0;  // (asks decided by an iteration: runs of one spec that land on one node are decided together)
 #ifdef YK_ROUND_PROF
   i64 rp_prev = a.prof ? (i64)wall_clock64() : 0;
+  const i64 rp_c0 = (i64)clock64(), rp_w0 = (i64)wall_clock64();
 #endif
   for (int i = 0; i < a.n_asks; i += step) {
     YK_CTX_FRESH();
@@ -2827,11 +2844,13 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
         cr.start = (int)(meta >> 32);
         if (dn < 0) cr = class_rows(ranked, ct.sig[cls * 4 + 0], ct.sig[cls * 4 + 1], ct.sig[cls * 4 + 2], -1);
         if (w0 < 0) w0 = cr.start;  // (kNoWord: some row of the class is empty)
-        for (int base = w0 < a.row_words ? (w0 & ~(kWave - 1)) : a.row_words; base < a.row_words && aw == 0x7fffffff; base += kRoundThreads) {
+        const int row_words = a.row_words;
+        const u64* const moved_bits = a.moved_bits;
+        for (int base = w0 < row_words ? (w0 & ~(kWave - 1)) : row_words; base < row_words && aw == 0x7fffffff; base += kRoundThreads) {
           const int w = base + tid;
           u64 x = 0;
-          if (w >= w0 && w < a.row_words) {
-            const u64 mv = ld_live(a.moved_bits + w);
+          if (w >= w0 && w < row_words) {
+            const u64 mv = ld_live(moved_bits + w);
             u64 v = ~0ull;
             if (dn > 0) {  // (one load round: the moved bits and every row of the class)
 #pragma unroll
@@ -2848,7 +2867,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           if (tsig < 0) {
             const int fl = __ffsll((long long)todo) - 1;
             aw = wave_w + fl;
-            ax = __shfl(x, fl, kWave);
+            ax = readlane64(x, fl);
           } else {
             // the class's topology constraints against the live histograms, word after word, lane = node; a wave gives up once
             // another one has found a node in an earlier word
@@ -2857,7 +2876,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
               todo &= todo - 1;
               const int ww = wave_w + fl;
               if (__builtin_amdgcn_readfirstlane(*(volatile int*)&sh_stop) < ww) break;
-              const u64 xw = __shfl(x, fl, kWave);
+              const u64 xw = readlane64(x, fl);
               bool ok = false;
               if ((xw >> lane) & 1ull) {
                 const int n = a.perm[ww * kWave + lane];
@@ -2893,61 +2912,92 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
       // a load; what it fails on now is remembered.
       u64 bk = ~0ull;
       int bt = 0x7fffffff, bn = -1;
-      for (int j0 = 0; j0 < n_moved; j0 += kRoundThreads) {
-        const int st_k = (j0 / kRoundThreads) & (kWave - 1);
-        if (st_k == 0 && j0 > 0) {
-          const int wl = ((j0 + lane * kRoundThreads) >> 6) + wave;
-          const bool in = wl * kWave < n_moved;
-          fb_l = (in && fw) ? ld_live(fw + wl) : 0ull;
-          dead_l = in ? ld_live(a.dead + wl) : ~0ull;
-        }
-        const int wi = (j0 >> 6) + wave;
-        const int slot = j0 + tid;
-        if (wi * kWave >= n_moved) continue;  // (wave-uniform)
-        const u64 fbits = __shfl(fb_l, st_k, kWave);
-        const u64 skip = fbits | __shfl(dead_l, st_k, kWave);
-        const bool act = slot < n_moved && !((skip >> lane) & 1ull);
-        if (__ballot(act) == 0) continue;
-        YK_RP_COUNT(10)
-        bool fit = false;
-        if (act) {
-          int m, tie;
-          u64 k;  // (the key with the columns, not behind the verdict: one round trip per step)
-          if (flat) {
-            SlotFlat nr;
-            load_slot_flat(t, a, slot, &nr, &m, &k, &tie);
-            fit = spec_fits_node(s, q, nr, a.pre, a.filt, tv_l, pv_l);
-          } else {
-            NodeRegs nr;
-            load_slot_live(t, a, slot, tsig >= 0, &nr);
-            m = a.m_node[slot];
-            k = ld_live(a.m_key + slot);
-            tie = a.m_tie[slot];
-            int code;
-            unsigned reason;
-            fit = eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason);
-          }
-          if (fit) {
-            if (k < bk || (k == bk && tie < bt)) {
-              bk = k;
-              bt = tie;
-              bn = m;
-            }
-          }
-        }
-        if (fw) {
-          const u64 nf = __ballot(act && !fit);
-          if (nf && lane == 0) st_live(fw + wi, fbits | nf);  // (this wave is the only writer of the word during this ask)
-        }
+      // One step of the scan: 512 slots, a wave per bitset word. EVAL(slot) sets fit / m / k / tie of an active lane.
+#define YK_SCAN_MOVED(DEAD, EVAL)                                                                              \
+      for (int j0 = 0; j0 < n_moved; j0 += kRoundThreads) {                                                        \
+        const int st_k = (j0 / kRoundThreads) & (kWave - 1);                                                       \
+        if (st_k == 0 && j0 > 0) {                                                                                 \
+          const int wl = ((j0 + lane * kRoundThreads) >> 6) + wave;                                                \
+          const bool in = wl * kWave < n_moved;                                                                    \
+          fb_l = (in && fw) ? ld_live(fw + wl) : 0ull;                                                             \
+          dead_l = in ? ld_live((DEAD) + wl) : ~0ull;                                                              \
+        }                                                                                                          \
+        const int wi = (j0 >> 6) + wave;                                                                           \
+        const int slot = j0 + tid;                                                                                 \
+        if (wi * kWave >= n_moved) continue; /* (wave-uniform) */                                                  \
+        const u64 fbits = readlane64(fb_l, st_k);                                                                  \
+        const u64 skip = fbits | readlane64(dead_l, st_k);                                                         \
+        const bool act = slot < n_moved && !((skip >> lane) & 1ull);                                               \
+        if (__ballot(act) == 0) continue;                                                                          \
+        \
+        bool fit = false;                                                                                          \
+        if (act) {                                                                                                 \
+          int m, tie;                                                                                              \
+          u64 k; /* (the key with the columns, not behind the verdict: one round trip per step) */                 \
+          EVAL                                                                                                     \
+          if (fit && (k < bk || (k == bk && tie < bt))) {                                                          \
+            bk = k;                                                                                                \
+            bt = tie;                                                                                              \
+            bn = m;                                                                                                \
+          }                                                                                                        \
+        }                                                                                                          \
+        if (fw) {                                                                                                  \
+          const u64 nf = __ballot(act && !fit);                                                                    \
+          if (nf && lane == 0) st_live(fw + wi, fbits | nf); /* (this wave is the only writer of the word during this ask) */ \
+        }                                                                                                          \
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const u64 ok = __shfl_xor(bk, off, kWave);
-        const int ot = __shfl_xor(bt, off, kWave), on = __shfl_xor(bn, off, kWave);
-        if (on >= 0 && (bn < 0 || ok < bk || (ok == bk && ot < bt))) {
-          bk = ok;
-          bt = ot;
-          bn = on;
+      if (flat) {
+        // (what the scan reads of the tables, fetched here in one batch of scalar loads — inside the loop every pointer would be its
+        // own trip to the constant cache in front of the load it addresses)
+        RoundArgs ab;
+        ab.cap = a.cap;
+        ab.m_free = a.m_free;
+        ab.m_taint = a.m_taint;
+        ab.m_label = a.m_label;
+        ab.m_ports = a.m_ports;
+        ab.m_room = a.m_room;
+        ab.m_flags = a.m_flags;
+        ab.m_node = a.m_node;
+        ab.m_key = a.m_key;
+        ab.m_tie = a.m_tie;
+        NodeTable tb;
+        tb.R = t.R;
+        tb.KT = t.KT;
+        tb.W = t.W;
+        tb.KP = t.KP;
+        const u64* const dead_p = a.dead;
+        const unsigned pre_m = a.pre, filt_m = a.filt;
+        YK_SCAN_MOVED(dead_p, {
+          SlotFlat nr;
+          load_slot_flat(tb, ab, slot, &nr, &m, &k, &tie);
+          fit = spec_fits_node(tb.W, q, nr, pre_m, filt_m, tv_l, pv_l);
+        })
+      } else {
+        YK_SCAN_MOVED(a.dead, {
+          NodeRegs nr;
+          load_slot_live(t, a, slot, tsig >= 0, &nr);
+          m = a.m_node[slot];
+          k = ld_live(a.m_key + slot);
+          tie = a.m_tie[slot];
+          int code;
+          unsigned reason;
+          fit = eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason);
+        })
+      }
+#undef YK_SCAN_MOVED
+      {  // the wave's best: the lexicographic minimum of (key, NodeID rank) over the lanes that hold a candidate
+        bool cand = bn >= 0;
+        if (__ballot(cand)) {
+          const unsigned hi = wave_umin(cand ? (unsigned)(bk >> 32) : 0xffffffffu);
+          cand = cand && (unsigned)(bk >> 32) == hi;
+          const unsigned lo = wave_umin(cand ? (unsigned)bk : 0xffffffffu);
+          cand = cand && (unsigned)bk == lo;
+          const unsigned ti = wave_umin(cand ? (unsigned)bt : 0xffffffffu);
+          cand = cand && (unsigned)bt == ti;
+          const int src = __ffsll((long long)__ballot(cand)) - 1;
+          bk = ((u64)hi << 32) | lo;
+          bt = (int)ti;
+          bn = __builtin_amdgcn_readlane(bn, src);
         }
       }
       YK_RP(4)
@@ -3035,12 +3085,14 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           const u64 same = __ballot(spec_l == spec && pin_l == -1);
           const u64 behind = hl < 63 ? (~same) >> (hl + 1) : ~0ull;  // first 0 of `same` behind lane hl ends the run
           const int run = behind ? (int)(__ffsll((long long)behind) - 1) : (63 - hl);
-          i64 fits_l = (lr && rq_l > 0) ? (al_l - old_l) / rq_l : 0x7fffffffffffffffll;
+          if (run > 0) {  // (the next ask is another spec: nothing to divide)
+            i64 fits_l = (lr && rq_l > 0) ? (al_l - old_l) / rq_l : 0x7fffffffffffffffll;
 #pragma unroll
-          for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
-          const i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));  // pod slots left (>= 1: the ask fits)
-          k_run = (int)max((i64)1, min(fits, (i64)(1 + min(run, 63 - hl))));
-          k_run = min(k_run, a.n_asks - i);
+            for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
+            const i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));  // pod slots left (>= 1: the ask fits)
+            k_run = (int)max((i64)1, min(fits, (i64)(1 + min(run, 63 - hl))));
+            k_run = min(k_run, a.n_asks - i);
+          }
         }
         if (lane < k_run) a.out[a.first + i + lane] = win;
         const int cnt = cnt0 + k_run;
@@ -3057,19 +3109,19 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           st_live(a.m_room + slot, allowed - cnt);
           st_live(a.m_key + slot, sortable_key(node_score_of(total, used)));
           if (!was_moved) {
-            atomicOr(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
+            or_live(a.moved_bits + (rk >> 6), 1ull << (rk & 63));
             st_live(a.slot_of + win, slot);
             a.m_node[slot] = win;
             a.m_tie[slot] = tie_w;
             a.m_flags[slot] = flags_w;
           }
-          if (dead) atomicOr(a.dead + (slot >> 6), 1ull << (slot & 63));
+          if (dead) or_live(a.dead + (slot >> 6), 1ull << (slot & 63));
           sh_step = k_run;
           sh_was_moved = was_moved ? 1 : 0;
         }
         // host ports the pod occupies from now on (NodeInfo.UsedPorts)
         if (lp) {
-          if (a.ports && occ_l) atomicOr(a.ports + (size_t)lane * t.n + win, occ_l);
+          if (a.ports && occ_l) or_live(a.ports + (size_t)lane * t.n + win, occ_l);
           if (occ_l || !was_moved) st_live(a.m_ports + (size_t)lane * cap + slot, port_l | occ_l);
         }
         // the static columns of a node that has just taken a slot: one lane per column
@@ -3091,7 +3143,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           const int dom = t.domain[(size_t)c.kd * t.n + win];
           if (dom < 0 || dom >= c.dom_size) continue;
           if (c.kind == kKindSpread && !spread_counts_here(c, spread_eligibility(t, sp, a.sig_aff, a.sig_tol, a.sig_of[g], win))) continue;
-          const int old = atomicAdd(sp.cnt + c.cnt_off + dom, v);
+          const int old = __hip_atomic_fetch_add(sp.cnt + c.cnt_off + dom, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (c.kind == kKindSpread) {
             // (an eligible node carries the domain: it is a present one. Its count leaves the minimum; the minimum itself moves
             // only when no present domain is left there)
@@ -3118,7 +3170,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           }
         }
       }
-      __threadfence();
+      __threadfence_block();
       __syncthreads();
       YK_RP(6)
       step = sh_step;
@@ -3152,7 +3204,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           st_live(sp.minv + g, a.nd[g] < c.min_domains ? 0 : mn);
         }
       }
-      if (ndirty) __threadfence();
+      if (ndirty) __threadfence_block();
     } else if (tid == 0) {
       a.out[a.first + i] = -1;
     }
@@ -3161,6 +3213,12 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     YK_RP(7)
   }
   if (tid == 0) st_live(a.n_moved, n_moved);
+#ifdef YK_ROUND_PROF
+  if (a.prof && tid == 0) {  // shader clock against the 100 MHz counter
+    a.prof[12] += (i64)clock64() - rp_c0;
+    a.prof[13] += (i64)wall_clock64() - rp_w0;
+  }
+#endif
 }
 #undef t
 #undef s
