@@ -241,6 +241,43 @@ def test_full_encode_on_several_threads_equals_one_thread(monkeypatch):
     assert tables[0] == tables[1] and tables[0]["N"] == 6000 and tables[0]["KS"] == 0
 
 
+@pytest.mark.parametrize("interpod", [False, True], ids=["shapes-stand-for-templates", "anti-affinity-visits-every-template"])
+def test_full_encode_of_many_asks_on_several_threads_equals_one_thread(monkeypatch, interpod):
+    """With >= 65 536 pending asks the full encode numbers the specs, finds the first template of every dictionary shape, prepares what
+    those templates ask of the dictionaries, encodes the spec rows and places the variable-length columns on the host's cores; the
+    ordered dictionary loop only consumes what was prepared. The asks here carry every dictionary kind the encoder knows (selector
+    requirements and metadata.name fields, toleration lists, host ports, scalar resources, hard spread constraints, and — second
+    case — pod (anti)affinity terms, which make the loop visit every template instead of one per shape). Tables, spec numbering and
+    the routed asks equal the one-thread encode's, and so do they when thread creation fails half-way."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _gen
+    snap = _gen.random_snapshot(77, 200, 66_000, scalars=True, spread=True, interpod=False)
+    if interpod:  # (a few dozen templates with pod (anti)affinity terms: every one of them is matched against every ask's labels)
+        extra = _gen.random_snapshot(78, 200, 48, scalars=True, spread=True, interpod=True)["pods"]
+        for i, pod in enumerate(extra):
+            pod["metadata"] = dict(pod["metadata"], name=f"ipa-{i}", uid=f"ipa-{i}")
+        snap["pods"] = snap["pods"][:33_000] + extra + snap["pods"][33_000:]
+    snap = json.dumps(snap)
+    tables = []
+    for threads, limit in (("1", None), ("6", None), ("6", "2")):
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
+        if limit is None:
+            monkeypatch.delenv("YKHOST_TEST_THREAD_LIMIT", raising=False)
+        else:
+            monkeypatch.setenv("YKHOST_TEST_THREAD_LIMIT", limit)
+        m = pkg.GpuPredicateManager(device=-1)
+        try:
+            m.load_snapshot(snap)
+            assert m.num_pods >= 65_536
+            tables.append((m.encoded_tables(), m.routing_stats()))
+        finally:
+            m.close()
+    one = tables[0][0]
+    assert len(one["spec_flags"]) > 8192 and one["KP"] > 0 and one["KD"] > 0 and one["R"] > 3 and one["W"] > 0
+    assert tables[1] == tables[0] and tables[2] == tables[0]
+
+
 def _load(monkeypatch, threads, batches):
     monkeypatch.setenv("YKHOST_INGEST_THREADS", threads)
     m = pkg.GpuPredicateManager(device=-1)
@@ -308,14 +345,16 @@ def test_threads_that_cannot_be_created_degrade_to_fewer_threads(cluster_docs, m
 
 def test_parallel_ingest_under_thread_sanitizer(cluster_docs, tmp_path):
     """libykhost's sources + tests/c/ingest_tsan.c under -fsanitize=thread: the scanning threads of the batch forms, the bulk cache
-    pass, the parallel node loop of a full encode and two concurrent reader threads on the same handle produce no data-race report."""
+    pass, the full encode at the end (spec numbering, shape representatives, prepared dictionary items, node rows, spec rows and their
+    placement — every one on the host's cores: >= 65 536 asks of their own templates) and two concurrent reader threads on the same
+    handle produce no data-race report."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "yunikorn-k8shim_amd", "lib")
     pkg.build_all()
-    src = pkg.GpuPredicateManager(device=-1)  # (>= 4096 nodes: the encode at the end of the harness takes its parallel node loop)
-    src.generate_kwok(seed=6, num_nodes=4500, num_pods=3000, num_templates=100, node_affinity=1, spread=0)
+    src = pkg.GpuPredicateManager(device=-1)  # (>= 4096 nodes, >= 65 536 asks: the encode at the end of the harness takes its parallel loops)
+    src.generate_kwok(seed=6, num_nodes=4500, num_pods=66_000, num_templates=0, node_affinity=1, spread=0)
     docs = [src.dump_documents(k) for k in (0, 1, 2)]
     src.close()
     paths = []

@@ -19,6 +19,9 @@
 //  — never silently passed, and every other ask keeps evaluating on the device.
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <functional>
 #include <limits>
 #include <set>
 #include <stdexcept>
@@ -239,7 +242,32 @@ class Encoder {
   // may_have_existing_anti = false: the caller knows that NO pod template of the cluster carries a required anti-affinity term
   // (the common case) — the pass over every pod on every node that collects such templates is skipped (2.76 M pointer chases,
   // 45 of the 165 ms of a full encode at configs[2] size).
-  bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates, bool may_have_existing_anti = true) {
+  // What a template asks of the dictionaries that depends on nothing but the template (its refusal, if any; the host ports it
+  // requests; its selector requirements with their dictionary keys): prepared on the caller's threads (parallel_for) for the shape
+  // representatives, consumed by the ordered loop — which then does hash lookups only.
+  struct ReqItem {
+    DictReq::Kind kind;
+    std::string key, op;
+    std::vector<std::string> values;
+    std::string rk;
+  };
+  struct Prepared {
+    std::string error;
+    std::vector<HostPort> ports;
+    std::vector<ReqItem> reqs;
+    std::string tol_key;  // the toleration list's identity (assign_taint_bits)
+  };
+  static std::string toleration_list_key(const PodTemplate& t) {
+    std::string k;
+    for (auto& tol : t.tolerations) k += tol.key + '\x1f' + tol.op + '\x1f' + tol.value + '\x1f' + tol.effect + '\x1e';
+    return k;
+  }
+  using ParallelFor = std::function<void(int, const std::function<void(int)>&)>;
+  bool trace = false;
+  // shape_reps (optional): the indices into `templates` of the first template of every dictionary shape, ascending — the caller
+  // found them on its threads; without it the loop below finds them itself, one template after the other.
+  bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates, bool may_have_existing_anti = true,
+                          const std::vector<int32_t>* shape_reps = nullptr, const ParallelFor* parallel_for = nullptr) {
     error.clear();
     scalar_names.clear();
     taint_dict.clear();
@@ -300,9 +328,17 @@ class Encoder {
     // Node-driven entries. Nothing here can cost the cluster its engine: taints are unbounded (their BITS are assigned below,
     // once the asks' toleration lists are known), and a scalar resource only becomes a dimension when an ask requests it —
     // NodeResourcesFit never looks at a resource the pod does not ask for, however many device plugins the nodes advertise.
+    auto tq0 = std::chrono::steady_clock::now();
+    auto qlap = [&](const char* w) {  // (trace: the phases of the build on stderr — the host sets it from YKHOST_TRACE_ENCODE)
+      if (!trace) return;
+      auto n = std::chrono::steady_clock::now();
+      fprintf(stderr, "  dict %s %.1f ms\n", w, std::chrono::duration<double, std::milli>(n - tq0).count());
+      tq0 = n;
+    };
     for (const NodeInfo* ni : nodes)
       for (auto& t : ni->node.taints)
         if (t.effect == "NoSchedule" || t.effect == "NoExecute") taint(t);
+    qlap("node taints");
     // ask-driven entries, template by template: a template whose entries would not fit is rolled back and marked
     // unsupported on its own — the asks before and after it keep their place in the dictionaries
     // Templates of one dictionary SHAPE (PodTemplate::shape_id: everything but labels and request values) register the same
@@ -311,27 +347,33 @@ class Encoder {
     const bool by_shape = existing_anti_templates_.empty() && wild_anti_terms_.empty();
     std::vector<const PodTemplate*> shape_rep;
     std::vector<PodTemplate*> visited;  // the templates that went through the loop body, in order (assign_taint_bits reads their toleration lists)
-    if (by_shape) {
+    const bool listed = by_shape && shape_reps != nullptr;
+    if (by_shape && !listed) {
       int32_t max_shape = -1;
       for (const PodTemplate* t : templates) max_shape = std::max(max_shape, t->shape_id);
       shape_rep.assign((size_t)(max_shape + 1), nullptr);
     }
-    for (PodTemplate* t : templates) {
-      if (by_shape && t->shape_id >= 0) {
-        const PodTemplate*& rep = shape_rep[(size_t)t->shape_id];
-        if (rep) {
-          auto un = unsupported.find(rep);
-          if (un != unsupported.end()) unsupported[t] = un->second;
-          continue;
-        }
-        rep = t;
-      }
+    std::vector<Prepared> prepared;
+    if (listed && parallel_for && shape_reps->size() >= 4096) {
+      // (by_shape: no anti-affinity term of an on-node pod is in play — template_error reads nothing this loop changes)
+      prepared.resize(shape_reps->size());
+      (*parallel_for)((int)shape_reps->size(), [&](int i) {
+        const PodTemplate& t = *templates[(size_t)(*shape_reps)[(size_t)i]];
+        Prepared& p = prepared[(size_t)i];
+        p.error = template_error(t);
+        p.tol_key = toleration_list_key(t);
+        if (!p.error.empty()) return;
+        p.ports = template_host_ports(t);
+        p.reqs = requirement_items(t);
+      });
+    }
+    auto visit = [&](PodTemplate* t, Prepared* pre) {
       visited.push_back(t);
       {
-        std::string why = template_error(*t);
+        std::string why = pre ? pre->error : template_error(*t);
         if (!why.empty()) {
           unsupported[t] = why;
-          continue;
+          return;
         }
       }
       const Mark mark = mark_now();
@@ -346,7 +388,7 @@ class Encoder {
           if (!is_wild(&term) && pod_term_matches(term, et->ns, t->ns, t->labels))
             count_class("E|" + t->ns + '\x1f' + labels_key(t->labels) + '\x1f' + term.topology_key,
                         SelectorClass{SelectorClass::kExistingAnti, t->ns, {}, {}, t->labels, term.topology_key});
-      for (const HostPort& hp : template_host_ports(*t))
+      for (const HostPort& hp : pre ? pre->ports : template_host_ports(*t))
         if (port_ix_.emplace(port_key(hp), (int)port_dict.size()).second) port_dict.push_back(hp);
       for (auto& c : t->spread) {
         if (c.when_unsatisfiable != "DoNotSchedule") continue;  // ScheduleAnyway constraints only score
@@ -356,7 +398,11 @@ class Encoder {
       }
       for (auto& kv : t->requests)
         if (kv.second > 0 && is_scalar_resource_name(kv.first)) scalar(kv.first);  // a dimension exists because an ask requests it
-      collect_requirements(*t);
+      if (pre) {
+        for (ReqItem& it : pre->reqs) add_req_item(std::move(it));
+      } else {
+        collect_requirements(*t);
+      }
       const char* over = nullptr;
       if (3 + (int)scalar_names.size() > kLimitR) over = "scalar resource names (engine limit: 5 besides cpu, memory, ephemeral-storage)";
       else if ((int)req_dict.size() > kLimitRequirements) over = "distinct node-selector requirements (engine limit: 2048)";
@@ -367,8 +413,40 @@ class Encoder {
         rollback(mark);
         unsupported[t] = std::string("the ask needs more ") + over + " than the dictionaries can still take";
       }
+    };
+    if (listed) {
+      for (size_t i = 0; i < shape_reps->size(); ++i) visit(templates[(size_t)(*shape_reps)[i]], prepared.empty() ? nullptr : &prepared[i]);
+      if (!unsupported.empty()) {  // the other templates of a refused shape inherit the verdict
+        std::unordered_map<int32_t, const std::string*> refused;
+        for (const PodTemplate* t : visited) {
+          auto un = unsupported.find(t);
+          if (un != unsupported.end()) refused.emplace(t->shape_id, &un->second);
+        }
+        std::vector<std::pair<const PodTemplate*, const std::string*>> heirs;
+        for (const PodTemplate* t : templates) {
+          auto r = refused.find(t->shape_id);
+          if (r != refused.end() && !unsupported.count(t)) heirs.emplace_back(t, r->second);
+        }
+        for (auto& hr : heirs) unsupported.emplace(hr.first, *hr.second);  // (references into an unordered_map outlive its rehashes)
+      }
+    } else {
+      for (PodTemplate* t : templates) {
+        if (by_shape && t->shape_id >= 0) {
+          const PodTemplate*& rep = shape_rep[(size_t)t->shape_id];
+          if (rep) {
+            auto un = unsupported.find(rep);
+            if (un != unsupported.end()) unsupported[t] = un->second;
+            continue;
+          }
+          rep = t;
+        }
+        visit(t, nullptr);
+      }
     }
-    assign_taint_bits(visited, templates);
+    qlap("templates");
+    if (trace) fprintf(stderr, "  dict visited %zu of %zu templates, by_shape %d\n", visited.size(), templates.size(), (int)by_shape);
+    assign_taint_bits(visited, templates, prepared.empty() ? nullptr : &prepared);
+    qlap("taint bits");
     KD = (int)topo_keys.size();
     KS = (int)sel_classes.size();
     KP = ((int)port_dict.size() + 63) / 64;
@@ -387,7 +465,9 @@ class Encoder {
     // at least 32 spare requirement bits: an ask that arrives later with a selector nobody used before gets its bit(s)
     // without re-encoding the cluster (extend_requirements)
     W = std::min(kLimitRequirements / 64, std::max(1, ((int)req_dict.size() + 32 + 63) / 64));
+    qlap("domains");
     rebuild_requirement_index();
+    qlap("requirement index");
     return true;
   }
 
@@ -892,7 +972,8 @@ class Encoder {
   // not #lists x #taints; a toleration without a key (operator Exists) covers every taint of its effect and never tells two
   // taints of one effect apart — the effect is part of the group key instead.
   // lists_of: the templates whose toleration lists are read (one per dictionary shape suffices); templates: all of them
-  void assign_taint_bits(const std::vector<PodTemplate*>& lists_of, const std::vector<PodTemplate*>& templates) {
+  // prepared (optional): lists_of[i]'s toleration-list key sits in (*prepared)[i].tol_key
+  void assign_taint_bits(const std::vector<PodTemplate*>& lists_of, const std::vector<PodTemplate*>& templates, std::vector<Prepared>* prepared = nullptr) {
     const size_t T = taint_dict.size();
     taint_bit.assign(T, 0);
     taint_members.clear();
@@ -903,10 +984,10 @@ class Encoder {
     std::unordered_map<std::string, int32_t> list_ids;
     std::vector<const PodTemplate*> list_owner;
     std::vector<std::vector<int32_t>> tolerated_by(T);  // [taint] → ids of the lists that tolerate it through a keyed toleration
-    for (const PodTemplate* t : lists_of) {
-      if (unsupported.count(t) || t->tolerations.empty()) continue;
-      std::string k;
-      for (auto& tol : t->tolerations) k += tol.key + '\x1f' + tol.op + '\x1f' + tol.value + '\x1f' + tol.effect + '\x1e';
+    for (size_t li = 0; li < lists_of.size(); ++li) {
+      const PodTemplate* t = lists_of[li];
+      if (t->tolerations.empty() || (!unsupported.empty() && unsupported.count(t))) continue;
+      std::string k = prepared ? std::move((*prepared)[li].tol_key) : toleration_list_key(*t);
       auto ins = list_ids.emplace(std::move(k), (int32_t)list_ids.size());
       if (!ins.second) continue;
       list_owner.push_back(t);
@@ -1045,6 +1126,10 @@ class Encoder {
   }
   static std::string taint_key(const Taint& t) { return t.key + '\x1f' + t.value + '\x1f' + t.effect; }
   void taint(const Taint& t) {
+    // (a cluster's nodes carry the same handful of taints: while the dictionary is that small, compare before building a key)
+    if (taint_dict.size() <= 16)
+      for (const Taint& d : taint_dict)
+        if (d.key == t.key && d.value == t.value && d.effect == t.effect) return;
     if (taint_ix_.emplace(taint_key(t), (int)taint_dict.size()).second) taint_dict.push_back(t);
   }
   static std::vector<std::string> canonical_values(const Requirement& r) {
@@ -1061,15 +1146,17 @@ class Encoder {
     return s;
   }
   void add_req(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) {
-    std::string rk = req_key(k, key, op, values);
-    if (req_ix_.count(rk)) return;
-    req_keys_.push_back(rk);
-    req_ix_.emplace(std::move(rk), (int)req_dict.size());
+    add_req_item(ReqItem{k, key, op, values, req_key(k, key, op, values)});
+  }
+  void add_req_item(ReqItem&& it) {
+    if (req_ix_.count(it.rk)) return;
+    req_keys_.push_back(it.rk);
+    req_ix_.emplace(std::move(it.rk), (int)req_dict.size());
     DictReq d;
-    d.kind = k;
-    d.req.key = key;
-    d.req.op = op;
-    d.req.values = values;
+    d.kind = it.kind;
+    d.req.key = std::move(it.key);
+    d.req.op = std::move(it.op);
+    d.req.values = std::move(it.values);
     req_dict.push_back(std::move(d));
   }
   int find_req(DictReq::Kind k, const std::string& key, const std::string& op, const std::vector<std::string>& values) const {
@@ -1080,18 +1167,28 @@ class Encoder {
   static void set_bit(std::vector<uint64_t>& m, int q) {
     if (q >= 0 && (size_t)(q >> 6) < m.size()) m[(size_t)(q >> 6)] |= 1ull << (q & 63);
   }
-  void collect_requirements(const PodTemplate& t) {
-    for (auto& kv : t.node_selector) add_req(DictReq::kEquals, kv.first, "", {kv.second});
-    if (!t.has_required) return;
+  // the selector requirements of a template in the order collect_requirements registers them (a pure function of the template)
+  static std::vector<ReqItem> requirement_items(const PodTemplate& t) {
+    std::vector<ReqItem> out;
+    auto item = [&](DictReq::Kind k, const std::string& key, const std::string& op, std::vector<std::string> values) {
+      std::string rk = req_key(k, key, op, values);
+      out.push_back(ReqItem{k, key, op, std::move(values), std::move(rk)});
+    };
+    for (auto& kv : t.node_selector) item(DictReq::kEquals, kv.first, "", {kv.second});
+    if (!t.has_required) return out;
     for (auto& term : t.terms) {
       for (auto& e : term.exprs)
-        if (valid_label_requirement(e)) add_req(DictReq::kLabel, e.key, e.op, canonical_values(e));
+        if (valid_label_requirement(e)) item(DictReq::kLabel, e.key, e.op, canonical_values(e));
       for (auto& f : term.fields) {
-        if ((f.op == "In" || f.op == "NotIn") && f.values.size() == 1) add_req(DictReq::kField, f.key, f.op, f.values);
+        if ((f.op == "In" || f.op == "NotIn") && f.values.size() == 1) item(DictReq::kField, f.key, f.op, f.values);
         if (f.key == "metadata.name" && f.op == "In")
-          for (auto& v : f.values) add_req(DictReq::kNameIn, "", "", {v});
+          for (auto& v : f.values) item(DictReq::kNameIn, "", "", {v});
       }
     }
+    return out;
+  }
+  void collect_requirements(const PodTemplate& t) {
+    for (ReqItem& it : requirement_items(t)) add_req_item(std::move(it));
   }
 };
 

@@ -419,21 +419,114 @@ void run_on_threads(int threads, int n, F&& f) {
 }
 int encode_tables(ykhost* h, EncodedTables* T) {
   auto tp0 = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) { if (getenv("YKHOST_TRACE_ENCODE")) { auto n = std::chrono::steady_clock::now(); fprintf(stderr, "encode %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - tp0).count()); tp0 = n; } };
-  // templates of pending asks, in first-use order → spec ids
+  const bool trace = getenv("YKHOST_TRACE_ENCODE") != nullptr;
+  h->enc.trace = trace;
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "encode %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - tp0).count());
+    tp0 = n;
+  };
+  // templates of pending asks, in first-use order → spec ids. With many asks the three passes (reset, first use, numbering) are
+  // walks over a million scattered objects: they run on the host's cores — a template's id is the number of templates whose first
+  // row lies in front of its own, which every range of rows can count for itself.
   h->spec_templates.clear();
-  for (PodTemplate* t : h->pool.all()) t->spec_id = -1;
-  for (Pod* p : h->pending) {
-    PodTemplate* t = const_cast<PodTemplate*>(p->tpl);
-    if (t->spec_id < 0) {
-      t->spec_id = (int32_t)h->spec_templates.size();
-      h->spec_templates.push_back(t);
+  const std::vector<PodTemplate*>& all_templates = h->pool.all();
+  const size_t n_pending = h->pending.size();
+  const int id_threads = n_pending >= 65536 ? (int)std::min<size_t>(host_threads(), 32) : 1;
+  auto atomic_min = [](int32_t* at, int32_t v) {
+    int32_t cur = __atomic_load_n(at, __ATOMIC_RELAXED);
+    while (v < cur && !__atomic_compare_exchange_n(at, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+    }
+  };
+  bool ids_done = false;
+  if (id_threads > 1) {
+    try {
+      const size_t A = all_templates.size(), K = (size_t)id_threads;
+      std::vector<size_t> firsts(K + 1, 0);
+      run_on_threads(id_threads, id_threads, [&](int k) {
+        for (size_t i = A * (size_t)k / K; i < A * (size_t)(k + 1) / K; ++i) {
+          all_templates[i]->spec_id = -1;
+          all_templates[i]->first_row = 0x7fffffff;
+        }
+      });
+      run_on_threads(id_threads, id_threads, [&](int k) {
+        for (size_t r = n_pending * (size_t)k / K; r < n_pending * (size_t)(k + 1) / K; ++r)
+          atomic_min(&const_cast<PodTemplate*>(h->pending[r]->tpl)->first_row, (int32_t)r);
+      });
+      run_on_threads(id_threads, id_threads, [&](int k) {
+        size_t n = 0;
+        for (size_t r = n_pending * (size_t)k / K; r < n_pending * (size_t)(k + 1) / K; ++r) n += h->pending[r]->tpl->first_row == (int32_t)r ? 1 : 0;
+        firsts[(size_t)k + 1] = n;
+      });
+      for (size_t k = 0; k < K; ++k) firsts[k + 1] += firsts[k];
+      h->spec_templates.assign(firsts[K], nullptr);
+      run_on_threads(id_threads, id_threads, [&](int k) {
+        size_t id = firsts[(size_t)k];
+        for (size_t r = n_pending * (size_t)k / K; r < n_pending * (size_t)(k + 1) / K; ++r) {
+          PodTemplate* t = const_cast<PodTemplate*>(h->pending[r]->tpl);
+          if (t->first_row != (int32_t)r) continue;
+          t->spec_id = (int32_t)id;
+          h->spec_templates[id++] = t;
+        }
+      });
+      ids_done = true;
+    } catch (const std::exception&) {
+      h->spec_templates.clear();  // (no memory for the counters: the one-thread walk below)
     }
   }
-  bool any_anti = false;  // (templates are never dropped from the pool: conservative)
-  for (const PodTemplate* t : h->pool.all()) any_anti = any_anti || !t->pod_anti_affinity.empty();
+  if (!ids_done) {
+    for (PodTemplate* t : all_templates) t->spec_id = -1;
+    for (Pod* p : h->pending) {
+      PodTemplate* t = const_cast<PodTemplate*>(p->tpl);
+      if (t->spec_id < 0) {
+        t->spec_id = (int32_t)h->spec_templates.size();
+        h->spec_templates.push_back(t);
+      }
+    }
+  }
+  const bool any_anti = h->pool.any_anti_affinity();
+  // the first template of every dictionary shape, in spec order: what build_dictionaries visits when shapes may stand for their
+  // templates (it decides; see there). Found by the same kind of walk; a template without a shape id turns the shortcut off.
+  std::vector<int32_t> shape_reps;
+  bool have_reps = false;
+  if (ids_done && h->pool.num_shapes() > 0) {
+    try {
+      const size_t S0 = h->spec_templates.size(), K = (size_t)id_threads;
+      std::vector<int32_t> shape_first(h->pool.num_shapes(), 0x7fffffff);
+      std::atomic<bool> unshaped{false};
+      run_on_threads(id_threads, id_threads, [&](int k) {
+        for (size_t s = S0 * (size_t)k / K; s < S0 * (size_t)(k + 1) / K; ++s) {
+          const int32_t sh = h->spec_templates[s]->shape_id;
+          if (sh < 0 || (size_t)sh >= shape_first.size()) unshaped.store(true);
+          else atomic_min(&shape_first[(size_t)sh], (int32_t)s);
+        }
+      });
+      if (!unshaped.load()) {
+        for (int32_t s : shape_first)
+          if (s != 0x7fffffff) shape_reps.push_back(s);
+        std::sort(shape_reps.begin(), shape_reps.end());
+        have_reps = true;
+      }
+    } catch (const std::exception&) {
+      have_reps = false;
+    }
+  }
   lap("spec ids");
-  if (!h->enc.build_dictionaries(h->nodes, h->spec_templates, any_anti)) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
+  const Encoder::ParallelFor on_cores = [&](int n, const std::function<void(int)>& f) {
+    // (blocks of 256 items: a work item per template would be an atomic per microsecond of work)
+    const int kBlock = 256, blocks = (n + kBlock - 1) / kBlock;
+    run_on_threads(id_threads, blocks, [&](int b) {
+      for (int i = b * kBlock; i < std::min(n, (b + 1) * kBlock); ++i) f(i);
+    });
+  };
+  bool dict_ok = false;
+  try {
+    dict_ok = h->enc.build_dictionaries(h->nodes, h->spec_templates, any_anti, have_reps ? &shape_reps : nullptr, id_threads > 1 ? &on_cores : nullptr);
+  } catch (const std::exception& ex) {
+    return fail(h, std::string("encoder: dictionaries: ") + ex.what(), YKPRED_E_NOMEM);
+  }
+  if (!dict_ok) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
   lap("dictionaries");
   h->unsupported_asks = 0;
   if (!h->enc.unsupported.empty())
@@ -574,16 +667,59 @@ int encode_tables(ykhost* h, EncodedTables* T) {
     try {
       if (!done)
         for (size_t b = 0; b < n_blocks; ++b) encode_block((int)b);
-      for (const SpecBlock& blk : blocks) {
-        T->spread.insert(T->spread.end(), blk.spread.begin(), blk.spread.end());
-        T->aff_terms.insert(T->aff_terms.end(), blk.aff.begin(), blk.aff.end());
-        T->pre_terms.insert(T->pre_terms.end(), blk.pre.begin(), blk.pre.end());
+      // The blocks' variable-length columns go into the tables at offsets known from the blocks' sizes: the tables are sized once and
+      // every block copies its own piece (and writes the offset rows of its specs) — on the host's cores again.
+      std::vector<size_t> at_spread(n_blocks + 1, 0), at_aff(n_blocks + 1, 0), at_pre(n_blocks + 1, 0);
+      std::vector<int32_t> n0_spread(n_blocks + 1, 0), n0_aff(n_blocks + 1, 0), n0_pre(n_blocks + 1, 0);  // rows in front of the block
+      for (size_t b = 0; b < n_blocks; ++b) {
+        const SpecBlock& blk = blocks[b];
+        at_spread[b + 1] = at_spread[b] + blk.spread.size();
+        at_aff[b + 1] = at_aff[b] + blk.aff.size();
+        at_pre[b + 1] = at_pre[b] + blk.pre.size();
+        int32_t ns = 0, na = 0, np = 0;
         for (size_t i = 0; i < blk.n_spread.size(); ++i) {
-          T->spread_off.push_back(T->spread_off.back() + blk.n_spread[i]);
-          T->aff_off.push_back(T->aff_off.back() + blk.n_aff[i]);
-          T->pre_off.push_back(T->pre_off.back() + blk.n_pre[i]);
+          ns += blk.n_spread[i];
+          na += blk.n_aff[i];
+          np += blk.n_pre[i];
+        }
+        n0_spread[b + 1] = n0_spread[b] + ns;
+        n0_aff[b + 1] = n0_aff[b] + na;
+        n0_pre[b + 1] = n0_pre[b] + np;
+      }
+      T->spread.resize(at_spread[n_blocks]);
+      T->aff_terms.resize(at_aff[n_blocks]);
+      T->pre_terms.resize(at_pre[n_blocks]);
+      T->spread_off.assign(S + 1, 0);
+      T->aff_off.assign(S + 1, 0);
+      T->pre_off.assign(S + 1, 0);
+      auto place_block = [&](int bi) {
+        const size_t b = (size_t)bi;
+        const SpecBlock& blk = blocks[b];
+        std::copy(blk.spread.begin(), blk.spread.end(), T->spread.begin() + (long)at_spread[b]);
+        std::copy(blk.aff.begin(), blk.aff.end(), T->aff_terms.begin() + (long)at_aff[b]);
+        std::copy(blk.pre.begin(), blk.pre.end(), T->pre_terms.begin() + (long)at_pre[b]);
+        int32_t os = n0_spread[b], oa = n0_aff[b], op = n0_pre[b];
+        const size_t s0 = b * kSpecBlock;
+        for (size_t i = 0; i < blk.n_spread.size(); ++i) {
+          os += blk.n_spread[i];
+          oa += blk.n_aff[i];
+          op += blk.n_pre[i];
+          T->spread_off[s0 + i + 1] = os;
+          T->aff_off[s0 + i + 1] = oa;
+          T->pre_off[s0 + i + 1] = op;
+        }
+      };
+      bool placed = false;
+      if (spec_threads > 1) {
+        try {
+          run_on_threads(spec_threads, (int)n_blocks, place_block);
+          placed = true;
+        } catch (const std::exception&) {
+          // (no thread to be had: the pieces are independent and idempotent — once more on this thread alone)
         }
       }
+      if (!placed)
+        for (size_t b = 0; b < n_blocks; ++b) place_block((int)b);
     } catch (const std::exception& ex) {
       return fail(h, std::string("encoder: spec rows: ") + ex.what(), YKPRED_E_NOMEM);
     }

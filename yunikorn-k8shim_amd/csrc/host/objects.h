@@ -106,6 +106,7 @@ struct PodTemplate {
   // derived once at interning time
   ResMap requests;            // upstream PodRequests (resource.go:56-109 minus the "pods" entry)
   int32_t spec_id = -1;       // engine spec index (assigned by the encoder)
+  int32_t first_row = 0;      // scratch of a full encode: the first pending row that uses the template (spec ids follow first use)
 };
 
 struct Pod {
@@ -629,19 +630,23 @@ class TemplatePool {
     const PodTemplate* raw = up.get();
     by_key_.emplace(std::move(key), std::move(up));
     order_.push_back(const_cast<PodTemplate*>(raw));
+    if (!raw->pod_anti_affinity.empty()) ++with_anti_;
     return raw;
   }
   const std::vector<PodTemplate*>& all() const { return order_; }
+  bool any_anti_affinity() const { return with_anti_ > 0; }  // (templates are never dropped from the pool: conservative)
   size_t num_shapes() const { return shapes_.size(); }
   void clear() {
     by_key_.clear();
     order_.clear();
     shapes_.clear();
+    with_anti_ = 0;
   }
 
  private:
   std::unordered_map<std::string, std::unique_ptr<PodTemplate>> by_key_;
   std::vector<PodTemplate*> order_;
+  size_t with_anti_ = 0;  // templates with required pod anti-affinity terms
   std::unordered_map<std::string, int32_t> shapes_;  // dictionary shape → id (PodTemplate::shape_id)
 };
 
