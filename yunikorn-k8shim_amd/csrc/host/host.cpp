@@ -58,12 +58,39 @@ struct Rng {  // splitmix64
 using namespace ykh;
 
 // The encoded (structure-of-arrays) form of the mirror: exactly what crosses the C ABI in ykpred_set_nodes / set_specs.
+// A vector whose resize() leaves new elements uninitialised: the per-spec columns of a full encode are sized once and then written
+// whole by the threads that encode the rows — the first touch of a fresh page (the kernel's zero fill, a fault each) happens on
+// those threads instead of one after the other on the caller's.
+template <class T>
+struct NoInitAlloc {
+  using value_type = T;
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return std::allocator<T>().allocate(n); }
+  void deallocate(T* p, size_t n) { std::allocator<T>().deallocate(p, n); }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <class U>
+  bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+template <class T>
+using RawVec = std::vector<T, NoInitAlloc<T>>;
 struct EncodedTables {
-  std::vector<uint64_t> ports, taints, labels, stol, aff_terms, pre_terms, wanted;
-  std::vector<int64_t> alloc, req, sreq;
-  std::vector<int32_t> allowed, count, domain, selcount, dsizes, aff_off, pre_off, spread_off, name_rank;
-  std::vector<uint32_t> flags, sflags;
-  std::vector<ykpred_spread_t> spread;
+  std::vector<uint64_t> ports, taints, labels, wanted;
+  RawVec<uint64_t> stol, aff_terms, pre_terms;
+  std::vector<int64_t> alloc, req;
+  RawVec<int64_t> sreq;
+  std::vector<int32_t> allowed, count, domain, selcount, dsizes, name_rank;
+  RawVec<int32_t> aff_off, pre_off, spread_off;
+  std::vector<uint32_t> flags;
+  RawVec<uint32_t> sflags;
+  RawVec<ykpred_spread_t> spread;
   ykpred_nodes_t nt{};
   ykpred_specs_t sp{};
   uint64_t dummy = 0;
@@ -614,10 +641,10 @@ int encode_tables(ykhost* h, EncodedTables* T) {
 
   lap("name ranks");
   const size_t S = h->spec_templates.size();
-  T->sreq.assign(S * R, 0);
-  T->stol.assign(S * KT, 0);
+  T->sreq.resize(S * R);  // (left uninitialised: every row is written whole by the block that encodes it)
+  T->stol.resize(S * KT);
   T->wanted.assign(S * KP + 1, 0);
-  T->sflags.assign(S, 0);
+  T->sflags.resize(S);
   T->aff_terms.clear();
   T->pre_terms.clear();
   T->aff_off.assign(1, 0);
@@ -638,6 +665,10 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   auto encode_block = [&](int b) {
     SpecBlock& blk = blocks[(size_t)b];
     const size_t s0 = (size_t)b * kSpecBlock, s1 = std::min(S, s0 + kSpecBlock);
+    blk.n_spread.reserve(s1 - s0);
+    blk.n_aff.reserve(s1 - s0);
+    blk.n_pre.reserve(s1 - s0);
+    blk.aff.reserve((s1 - s0) * (size_t)W * 2);  // (two Filter terms per spec is the usual size: fewer regrowths of the block's column)
     for (size_t s = s0; s < s1; ++s) {
       EncodedSpec es = h->enc.encode_spec(*h->spec_templates[s]);
       blk.spread.insert(blk.spread.end(), es.spread.begin(), es.spread.end());
@@ -689,9 +720,10 @@ int encode_tables(ykhost* h, EncodedTables* T) {
       T->spread.resize(at_spread[n_blocks]);
       T->aff_terms.resize(at_aff[n_blocks]);
       T->pre_terms.resize(at_pre[n_blocks]);
-      T->spread_off.assign(S + 1, 0);
-      T->aff_off.assign(S + 1, 0);
-      T->pre_off.assign(S + 1, 0);
+      T->spread_off.resize(S + 1);
+      T->aff_off.resize(S + 1);
+      T->pre_off.resize(S + 1);
+      T->spread_off[0] = T->aff_off[0] = T->pre_off[0] = 0;
       auto place_block = [&](int bi) {
         const size_t b = (size_t)bi;
         const SpecBlock& blk = blocks[b];
