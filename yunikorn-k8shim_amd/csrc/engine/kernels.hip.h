@@ -2359,11 +2359,17 @@ __device__ __forceinline__ int preempt_one(const NodeTable& t, const SpecTable& 
   const i64 allowed = t.allowed[node];
   for (int i = 0; i < n_victims; ++i) {
     if (vpresent[i]) {  // removePodFromNodeNoFail (:181-192)
-      for (int r = 0; r < s.R && r < kMaxR; ++r) nr.fr[r] += vreq[(size_t)i * s.R + r];
+      // (compile-time indices: a register array indexed by a loop counter the compiler cannot unroll lives in scratch)
+#pragma unroll
+      for (int r = 0; r < kMaxR; ++r)
+        if (r < s.R) nr.fr[r] += vreq[(size_t)i * s.R + r];
       pods_on_node -= 1;
     }
-    if (ports_after)
-      for (int k = 0; k < t.KP && k < kMaxKP; ++k) nr.pt[k] = ports_after[(size_t)i * t.KP + k];
+    if (ports_after) {
+#pragma unroll
+      for (int k = 0; k < kMaxKP; ++k)
+        if (k < t.KP) nr.pt[k] = ports_after[(size_t)i * t.KP + k];
+    }
     if (i < start) continue;  // :161-163
     nr.slots_ok = pods_on_node + 1 <= allowed;
     // PreFilter outcomes were accepted above; eval_pair re-checks them (idempotent) and runs the filters (:168)
