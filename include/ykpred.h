@@ -330,9 +330,14 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
  * round runs on a scratch copy of the node columns; the caller applies the allocations the core accepts through the cache
  * hooks (ykhost_assume_pod → ykpred_update_node) as it does for any AssumePod.
  * Needs a current evaluation WITH decisions of the same plugin lists (YKPRED_E_STATE otherwise). YKPRED_E_UNSUPPORTED — decide ask by
- * ask instead — on a node-sharded engine, and when something other than node resources couples the asks of the round (active
- * PodTopologySpread / InterPodAffinity signatures, an ask that requests a host port) while the specs' effects
- * (ykpred_set_spec_effects, below) are not uploaded for the current spec table. */
+ * ask instead — when something other than node resources couples the asks of the round (active PodTopologySpread /
+ * InterPodAffinity signatures, an ask that requests a host port) while the specs' effects (ykpred_set_spec_effects, below) are not
+ * uploaded for the current spec table, and for active topology signatures on a node-sharded engine.
+ * NODE-SHARDED engines (communicator attached, world > 1): the call is COLLECTIVE — every rank passes the same asks in the same
+ * order — and out_nodes holds GLOBAL node indices (the winner's shard offset + its index there), identical on every rank. The
+ * round runs in batches: every shard proposes its best node per ask of a batch, one all-gather of 56 bytes per ask and rank, every
+ * rank accepts the same conflict-free prefix, the owners assume (engine.hip has the rule and its proof sketch). Equal keys
+ * across shards are ordered by global node index, as in ykpred_exchange_decisions. */
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t n_asks,
                               const int32_t* asks /* host, [n_asks] ask indices in decision order */, int32_t* out_nodes /* host, [n_asks] */);
 /* What NodeInfo.AddPod (behind SchedulerCache.AssumePod, /root/reference/pkg/cache/external/scheduler_cache.go:443-461) adds to a
@@ -448,6 +453,8 @@ int32_t ykpred_comm_use_library(const char* path);
 int32_t ykpred_comm_unique_id(uint8_t* id /* [YKPRED_COMM_ID_BYTES] */);
 int32_t ykpred_comm_init(ykpred_engine_t* e, const uint8_t* id, int32_t rank, int32_t world, int32_t node_offset);
 int32_t ykpred_comm_destroy(ykpred_engine_t* e);
+/* the attached communicator's geometry (rank 0, world 1, node_offset 0 without one); any of the pointers may be NULL */
+int32_t ykpred_comm_info(const ykpred_engine_t* e, int32_t* rank, int32_t* world, int32_t* node_offset);
 /* Rows of the NEXT ykpred_set_nodes get this stride (64-bit words, multiple of 16, >= the shard's own need); 0 = automatic.
  * Shards of unequal size agree on the stride of the largest one so that the gathered layout is regular. */
 int32_t ykpred_set_row_stride(ykpred_engine_t* e, int32_t words);

@@ -5,6 +5,8 @@
 #   1. tests/_shard_worker.py: every rank compares EVERY gathered row (plain and class-compressed gather), every exchanged feasible
 #      count and every exchanged decision with one engine that holds the whole cluster (hard spread constraints: the histograms
 #      are summed across shards); a rank that finds a difference exits 3 and the curve is not printed for that world size;
+#   1b. tests/_shard_round_worker.py: two allocation rounds decided by the ranks together (proposals per batch, one all-gather each)
+#      against the oracle's sequential loop over the whole cluster;
 #   2. bench.py --gpus W (BASELINE configs[3]: 50 000 nodes sharded W-way x 1M gang-placeholder asks, gathered bitmap in the step) and
 #      bench.py --gpus W --no-gather (decisions + counts only: 16 bytes per ask over the links) — each verifies its own shard slabs.
 # Output: one JSON line per (world, mode) under $OUT (default gpurun_out/scale), and the curve on stdout. Needs >= 2 GPUs.
@@ -31,6 +33,13 @@ for W in 2 4 8; do
     echo "   FAILED — see $OUT/check_w$W.log"; tail -8 "$OUT/check_w$W.log"; RC=1; continue
   fi
   grep "^rank" "$OUT/check_w$W.log"
+  echo "== world $W: allocation rounds on the sharded cluster against the oracle's sequential loop (12 800 nodes x 6 000 asks)"
+  if ! timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$W" --master-addr 127.0.0.1 --master-port "$((PORT + 20))" \
+        tests/_shard_round_worker.py 12800 6000 200 > "$OUT/rounds_w$W.log" 2>&1; then
+    echo "   FAILED — see $OUT/rounds_w$W.log"; tail -8 "$OUT/rounds_w$W.log"; RC=1
+  else
+    grep "^rank" "$OUT/rounds_w$W.log"
+  fi
   timeout 900 python bench.py --gpus "$W" --cpu-seconds 0 > "$OUT/n${W}_gathered.json" 2> "$OUT/n${W}_gathered.err" || { echo "   gathered bench failed"; RC=1; }
   timeout 900 python bench.py --gpus "$W" --no-gather --cpu-seconds 0 > "$OUT/n${W}_decisions_only.json" 2> "$OUT/n${W}_decisions_only.err" || { echo "   decisions-only bench failed"; RC=1; }
 done

@@ -106,6 +106,7 @@ def load_ykpred():
     L.ykpred_comm_unique_id.argtypes = [C.c_void_p]
     L.ykpred_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     L.ykpred_comm_destroy.argtypes = [C.c_void_p]
+    L.ykpred_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ykpred_set_row_stride.argtypes = [C.c_void_p, C.c_int32]
     L.ykpred_set_row_capacity.argtypes = [C.c_void_p, C.c_int32]
     L.ykpred_gather_bitmap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -366,6 +366,7 @@ struct ykpred_engine {
   // --- multi-GPU (node-axis shards): RCCL communicator, this shard's place in the cluster, exchange scratch
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1, node_offset = 0;
+  int64_t round_exchanges = 0;      // proposal exchanges of sharded allocation rounds so far
   int forced_stride = 0;  // ykpred_set_row_stride
   DevBuf d_gathered, d_gathered_map, d_xkey, d_xcand;
   bool last_has_keys = false;
@@ -2632,6 +2633,27 @@ int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t*
   return YKPRED_OK;
 }
 
+// Host forms of k_score's arithmetic (the same operation order; the file is compiled with -ffp-contract=off for host and device):
+// what a node's key becomes after k more pods of a spec, computed by every rank of a sharded round from the exchanged columns.
+static double host_node_score(const i64 (&total)[2], const i64 (&used)[2]) {
+  double sum = 0.0, wsum = 0.0;
+  for (int r = 0; r < 2; ++r) {
+    if (total[r] <= 0) continue;
+    const double avail = (double)(total[r] - used[r]);
+    const double share = 1.0 - avail / (double)total[r];
+    sum = sum + share;
+    wsum = wsum + 1.0;
+  }
+  if (wsum == 0.0) return 1.0;
+  return 1.0 - sum / wsum;
+}
+static u64 host_sortable_key(double v) {
+  u64 b;
+  memcpy(&b, &v, sizeof b);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+constexpr size_t kShardBatchMax = 512;  // asks proposed per exchange of a sharded round (the batch adapts below this)
+
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, int32_t n_asks, const int32_t* asks, int32_t* out_nodes) {
   YK_SERIALISE(e);
   Range roctx_range("ykpred:allocate_round");
@@ -2639,10 +2661,11 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   if (e->classes_dirty || !e->last_eval_valid || !e->rank_valid || e->bitmap_epoch != e->nodes_epoch || pre != e->last_pre || filt != e->last_filt ||
       e->ranked_pre != pre || e->ranked_filt != filt || e->ranked_nodes_epoch != e->nodes_epoch || e->ranked_specs_version != e->specs_version)
     return fail(e, YKPRED_E_STATE, "allocate_round: no current evaluation WITH decisions of these plugin lists (run ykpred_eval with YKPRED_OUT_DECISIONS)");
-  if (e->comm && e->comm_world > 1)
-    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: node-sharded engines decide ask by ask (the winner of every ask is a cross-shard exchange)");
+  const bool sharded = e->comm && e->comm_world > 1;
   const bool fx_current = e->fx_version == e->specs_version;
   const bool topo_on = (pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0;
+  if (sharded && topo_on)
+    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints on a node-sharded engine (an assumed pod moves histograms on every shard): decide ask by ask");
   if (topo_on && !fx_current)
     return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints are active (an assumed pod's labels move the histograms of later asks) and the "
                                          "specs' effects are not uploaded (ykpred_set_spec_effects): decide ask by ask");
@@ -2690,7 +2713,10 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                o_asks = take((size_t)n_asks * sizeof(int)), o_out = take((size_t)n_asks * sizeof(int)),
                o_nm = take(sizeof(int)), o_hist = take(cells * sizeof(int)), o_minv = take(G * sizeof(int)), o_mn = take(G * sizeof(int)),
                o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int)), o_prof = take(16 * sizeof(i64)),
-               o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int)), o_cdesc = take(C * ykk::kDescWords * sizeof(u64));
+               o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int)), o_cdesc = take(C * ykk::kDescWords * sizeof(u64)),
+               o_prop = take(sharded ? (size_t)n_asks * sizeof(ykk::RoundProposal) : 0),
+               o_allprop = take(sharded ? (size_t)e->comm_world * kShardBatchMax * sizeof(ykk::RoundProposal) : 0),
+               o_forced = take(sharded ? (size_t)n_asks * sizeof(int) : 0);
   HIPCHK(e->d_round.ensure(off));
   char* base = (char*)e->d_round.p;
   HIPCHK(hipMemcpyAsync(base + o_req, e->d_req.p, R * (size_t)e->N * sizeof(i64), hipMemcpyDeviceToDevice, st));
@@ -2754,6 +2780,8 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   ra.failed = keep_failed ? (u64*)(base + o_failed) : nullptr;
   ra.out = (int*)(base + o_out);
   ra.prof = e->round_prof ? (i64*)(base + o_prof) : nullptr;
+  ra.mode = ykk::kRoundDecide;
+  ra.node_offset = e->node_offset;
   if (fx_current) {
     ra.fx.off = e->fx_contrib ? e->d_fx_off.as<int>() : nullptr;
     ra.fx.cls = e->d_fx_cls.as<int>();
@@ -2792,6 +2820,111 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   if (e->C > 0)
     hipLaunchKernelGGL(ykk::k_round_class_desc, dim3((unsigned)((e->C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, ct, pr, e->C,
                        (u64*)(base + o_cdesc));
+  if (sharded) {
+    // ---- A round on a node-sharded engine, in batches. Every rank holds the whole ask table and its own node shard. Per batch:
+    //   1. every shard PROPOSES its best node for each ask of the batch against the state the accepted asks left (k_allocate_round in
+    //      propose mode: both candidates, no assume) — 48 bytes per ask: key, node, how many pods of the spec the node still holds,
+    //      and the four numbers its key is made of;
+    //   2. one all-gather of the proposals; the global candidate of an ask is the smallest (key, global node index) — the order
+    //      ykpred_exchange_decisions uses;
+    //   3. every rank accepts the same PREFIX of the batch, ask after ask, while no accepted ask can have changed the answer of the
+    //      next one. Without topology constraints a verdict only ever turns from fit to fail as a node fills, and an assume moves only
+    //      its own node, towards the front. So an accepted node u can change ask j's answer w only if u == w (the state of j's own
+    //      node moved), or u stood BEHIND w and now stands in front of it (it may fit j and would come first). A node that stood in
+    //      front of w did not fit j and never will; every other node is where it was. The first ask that fails the test ends the
+    //      prefix and is proposed again in the next batch — the first ask of a batch always passes, so a batch always makes progress.
+    //      A run of asks with one spec lands on one node as long as it fits (k_allocate_round's run argument): `fits` of them are
+    //      accepted at once, the node's key afterwards is arithmetic on the exchanged columns;
+    //   4. the owners of the accepted nodes assume them (assume mode), everybody moves on behind the prefix.
+    // The decisions equal the sequential loop's wherever NodeID order and node index order agree (zero-padded names: the tie-break
+    // between equal keys across shards is the global node index, as in ykpred_exchange_decisions).
+    Rccl* r = rccl();
+    const int W = e->comm_world;
+    ykk::RoundProposal* d_prop = (ykk::RoundProposal*)(base + o_prop);
+    ykk::RoundProposal* d_all = (ykk::RoundProposal*)(base + o_allprop);
+    int* d_forced = (int*)(base + o_forced);
+    std::vector<ykk::RoundProposal> all((size_t)W * kShardBatchMax);
+    std::vector<int32_t> forced;
+    struct Accepted {
+      int64_t gnode;
+      u64 key0, key1;  // the node's key when it was proposed / after the accepted pods
+    };
+    std::vector<Accepted> acc;
+    const int R = e->R;
+    int pos = 0, batch = 16;
+    int64_t exchanges = 0;
+    while (pos < n_asks) {
+      const int b = std::min(batch, n_asks - pos);
+      ra.mode = ykk::kRoundPropose;
+      ra.first = pos;
+      ra.n_asks = b;
+      ra.prop = d_prop;
+      hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
+      HIPCHK(hipGetLastError());
+      NCCLCHK(r->AllGather(d_prop + pos, d_all, (size_t)b * sizeof(ykk::RoundProposal), ncclInt8, e->comm, st));
+      HIPCHK(hipMemcpyAsync(all.data(), d_all, (size_t)W * (size_t)b * sizeof(ykk::RoundProposal), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      ++exchanges;
+      acc.clear();
+      forced.assign((size_t)b, -1);
+      int m = 0;
+      while (m < b) {
+        // the global candidate of ask pos + m
+        int best_rank = -1;
+        for (int g = 0; g < W; ++g) {
+          const ykk::RoundProposal& p = all[(size_t)g * (size_t)b + (size_t)m];
+          if (p.node < 0) continue;
+          if (best_rank < 0) { best_rank = g; continue; }
+          const ykk::RoundProposal& q = all[(size_t)best_rank * (size_t)b + (size_t)m];
+          if (p.key < q.key || (p.key == q.key && p.gnode < q.gnode)) best_rank = g;
+        }
+        if (best_rank < 0) {  // no node of any shard fits, and none will: verdicts only turn to fail
+          out_nodes[pos + m] = -1;
+          ++m;
+          continue;
+        }
+        const ykk::RoundProposal w = all[(size_t)best_rank * (size_t)b + (size_t)m];
+        const int64_t gnode = w.gnode;
+        bool conflict = false;
+        for (const Accepted& a2 : acc) {
+          const bool behind_before = a2.key0 > w.key || (a2.key0 == w.key && a2.gnode > gnode);
+          const bool in_front_now = a2.key1 < w.key || (a2.key1 == w.key && a2.gnode < gnode);
+          if (a2.gnode == gnode || (behind_before && in_front_now)) {
+            conflict = true;
+            break;
+          }
+        }
+        if (conflict) break;
+        // a run of asks with this spec and no pin lands on this node while it fits
+        const int ask0 = asks[pos + m];
+        const int spec = e->h_pod_spec[(size_t)ask0];
+        int k = 1;
+        if (e->h_pod_pin[(size_t)ask0] == YKPRED_NO_NODE_NAME)
+          while (k < w.fits && m + k < b && e->h_pod_spec[(size_t)asks[pos + m + k]] == spec && e->h_pod_pin[(size_t)asks[pos + m + k]] == YKPRED_NO_NODE_NAME) ++k;
+        const i64 total[2] = {w.alloc[0], w.alloc[1]};
+        const i64 used[2] = {w.req[0] + e->h_req[(size_t)spec * (size_t)R + 0] * k, w.req[1] + e->h_req[(size_t)spec * (size_t)R + 1] * k};
+        acc.push_back(Accepted{gnode, w.key, host_sortable_key(host_node_score(total, used))});
+        for (int q = 0; q < k; ++q) {
+          out_nodes[pos + m + q] = (int32_t)gnode;
+          if (best_rank == e->comm_rank) forced[(size_t)(m + q)] = w.node;
+        }
+        m += k;
+      }
+      // the owners assume what was accepted (the asks behind the prefix are proposed again)
+      HIPCHK(hipMemcpyAsync(d_forced + pos, forced.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, st));
+      ra.mode = ykk::kRoundAssume;
+      ra.first = pos;
+      ra.n_asks = m;
+      ra.forced = d_forced;
+      hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(st));  // (`forced` is reused by the next batch)
+      pos += m;
+      batch = (int)std::min<size_t>(kShardBatchMax, (size_t)std::max(8, 2 * m + 8));
+    }
+    e->round_exchanges += exchanges;
+    return YKPRED_OK;
+  }
   // one launch per 32 768 asks: the loop is a single workgroup, and a bounded launch keeps the queue responsive (the state of the
   // round — scratch tables, moved list — lives in memory between the launches)
   const int per_launch = 32768;
@@ -3284,6 +3417,14 @@ int32_t ykpred_comm_init(ykpred_engine_t* e, const uint8_t* id, int32_t rank, in
   e->comm_world = world;
   e->node_offset = node_offset;
   e->hist_epoch = 0;  // shard-local histograms are not the cluster's
+  return YKPRED_OK;
+}
+
+int32_t ykpred_comm_info(const ykpred_engine_t* e, int32_t* rank, int32_t* world, int32_t* node_offset) {
+  if (!e) return YKPRED_E_INVALID;
+  if (rank) *rank = e->comm ? e->comm_rank : 0;
+  if (world) *world = e->comm ? e->comm_world : 1;
+  if (node_offset) *node_offset = e->comm ? e->node_offset : 0;
   return YKPRED_OK;
 }
 

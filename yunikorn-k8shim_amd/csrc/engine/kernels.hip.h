@@ -2424,6 +2424,14 @@ struct SpecEffects {       // what NodeInfo.AddPod of a pod of spec s adds to it
   const int* cnt;          // what one pod of the spec adds to that column
   const u64* occupied;     // [S][KP] dictionary host ports a pod of the spec conflicts with once it is on a node
 };
+constexpr int kRoundDecide = 0, kRoundPropose = 1, kRoundAssume = 2;
+struct RoundProposal {      // a shard's best node for an ask, and what the other ranks need to order it and to re-key it after assumes
+  u64 key;                  // score key of the node as it stands (smaller = earlier)
+  int node;                 // node index in this shard, -1 = no node of the shard fits
+  int fits;                 // how many pods of the ask's spec the node still holds when they couple through resources only, else 1
+  i64 alloc[2], req[2];     // cpu / memory Allocatable and Requested: the key after k more pods of a spec is arithmetic on these
+  int gnode, pad;           // node index in the whole cluster (the shard's node offset + node): the tie-break between equal keys
+};
 struct RoundArgs {
   int first, n_asks;        // this launch decides asks [first, first + n_asks) of the round
   const int* asks;          // [round] ask (pod) indices in decision order
@@ -2473,6 +2481,14 @@ struct RoundArgs {
   int* at_min;              // [G] spread: present domains whose count equals mn
   const int* nd;            // [G] spread: present domains
   SpecEffects fx;
+  // Node-sharded engines decide a round in BATCHES (engine.hip, allocate_round_sharded): every shard PROPOSES its best node for the
+  // asks of a batch against the state the accepted asks left (mode 1: the loop below without the assume), the proposals are
+  // all-gathered, every rank accepts the same conflict-free prefix, and the owners of the winners assume them (mode 2: the loop's
+  // assume for given nodes, no scans).
+  int mode;                 // kRoundDecide (0), kRoundPropose, kRoundAssume
+  int node_offset;          // index of this shard's first node in the whole cluster
+  const int* forced;        // kRoundAssume: [round] the node (of this shard) an ask goes to, -1 = none of this shard's
+  RoundProposal* prop;      // kRoundPropose: [round]
   i64* prof;                // YKPRED_TUNE round_prof=1: thread 0's 100 MHz ticks per phase of the loop (null: off)
 };
 // Per-phase ticks of the loop (thread 0, 100 MHz): compiled in with -DYK_ROUND_PROF only (build.py: YK_ROUND_PROF=1) — the kernel
@@ -2781,7 +2797,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     int win = -1;
     bool again = false;
     YK_RP(0)
-    if (!a.all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
+    const int mode = a.mode;
+    if (mode == kRoundDecide && !a.all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
       // The same spec as the ask before, which went to node last_win: that node is AT LEAST as early in the bin-pack order now
       // (an allocation only raises a node's utilisation, i.e. lowers its score; every other node stands where it stood), so it
       // is this ask's node too as long as it still fits — one pair instead of the two scans. Bin-packing sends long runs of a
@@ -2797,6 +2814,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     if (again) {
       win = last_win;
       YK_RP_COUNT(9)
+    } else if (mode == kRoundAssume) {
+      win = a.forced[a.first + i];  // (decided by the exchange: the scans are somebody else's)
     } else if (a.all_fail || pin == -2) {
       // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
     } else if (pin >= 0) {
@@ -3051,7 +3070,41 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     last_spec = pin == -1 ? spec : -1;
     last_win = win;
     YK_CTX_FRESH();
-    if (win >= 0) {  // (workgroup-uniform)
+    if (mode == kRoundPropose) {
+      // ---- the shard's proposal for this ask; nothing is assumed. Wave 0, one load round (lane r = resource r).
+      if (wave == 0) {
+        const bool lr = lane < t.R;
+        const int rl = min(lane, t.R - 1), wn = max(win, 0);
+        const i64 rq_raw = s.req[(size_t)spec * s.R + rl], al_raw = t.alloc[(size_t)rl * t.n + wn], old_raw = ld_live(a.req + (size_t)rl * t.n + wn);
+        const int cnt0 = ld_live(a.count + wn), allowed = t.allowed[wn];
+        const u64 occ_l = (lane < t.KP && a.ports && a.fx.occupied) ? a.fx.occupied[(size_t)spec * t.KP + lane] : 0ull;
+        const bool contributes = a.topo_on && a.fx.off && a.fx.off[spec + 1] > a.fx.off[spec];
+        const i64 rq_l = lr ? rq_raw : 0, al_l = lr ? al_raw : 0, old_l = lr ? old_raw : 0;
+        const bool any_occ = __ballot(occ_l != 0) != 0;
+        i64 fits_l = (lr && rq_l > 0) ? (al_l - old_l) / rq_l : 0x7fffffffffffffffll;
+#pragma unroll
+        for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
+        i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));
+        if (pin != -1 || tsig >= 0 || any_occ || contributes || !fit_on) fits = 1;
+        const i64 used[2] = {(i64)__shfl((long long)old_l, 0, kWave), (i64)__shfl((long long)old_l, 1, kWave)};
+        const i64 total[2] = {(i64)__shfl((long long)al_l, 0, kWave), (i64)__shfl((long long)al_l, 1, kWave)};
+        if (lane == 0) {
+          RoundProposal pr;
+          pr.key = win >= 0 ? sortable_key(node_score_of(total, used)) : ~0ull;
+          pr.node = win;
+          pr.fits = win >= 0 ? (int)max((i64)1, min(fits, (i64)0x7fffffff)) : 0;
+          pr.alloc[0] = total[0];
+          pr.alloc[1] = total[1];
+          pr.req[0] = used[0];
+          pr.req[1] = used[1];
+          pr.gnode = win >= 0 ? a.node_offset + win : -1;
+          pr.pad = 0;
+          a.prop[a.first + i] = pr;
+        }
+      }
+      last_spec = -1;
+      last_win = -1;
+    } else if (win >= 0) {  // (workgroup-uniform)
       // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod).
       // A RUN of asks with this spec lands on this node as long as it fits (the argument of the `again` path), and for a spec whose
       // pods couple through nothing but resources "fits k more times" is arithmetic: k = what the free resources and pod slots
@@ -3086,7 +3139,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
         // shape) — the headers in this wave's registers bound it to the asks up to the next multiple of 64.
         int k_run = 1;
         const bool any_occ = __ballot(occ_l != 0) != 0;  // (a pod that occupies host ports conflicts with its own twin: no run)
-        if (pin == -1 && tsig < 0 && !any_occ && !contributes && fit_on) {
+        if (mode == kRoundDecide && pin == -1 && tsig < 0 && !any_occ && !contributes && fit_on) {
           // asks hl+1 .. of the header window with the same spec and no pin, consecutively
           const u64 same = __ballot(spec_l == spec && pin_l == -1);
           const u64 behind = hl < 63 ? (~same) >> (hl + 1) : ~0ull;  // first 0 of `same` behind lane hl ends the run

@@ -1048,7 +1048,10 @@ bool cache_update_pod(ykhost* h, Pod* old, Pod* p, bool running, bool terminated
     if (!prev.empty() && p->node_name.empty()) p->node_name = prev;  // "new pod wasn't assigned to a node, so use existing assignment"
     p->assumed = was_assumed;
   }
-  if (running || terminated) p->assumed = false;  // "pod has now been bound" (:344-347)
+  if (running || terminated) {  // "pod has now been bound" (:344-347)
+    p->assumed = false;
+    p->remote_node = -1;
+  }
   bool result = true;
   p->orphan = false;
   if (!p->node_name.empty() && !terminated) {
@@ -2244,6 +2247,7 @@ int32_t ykhost_forget_pod(ykhost_t* h, const char* uid) {
   cache_update_pod(h, p, p, false, false);
   if (p->assumed && p->ask) mark_row(h, p->row);  // the row now follows the cached pod: pinned to its node
   p->assumed = false;
+  p->remote_node = -1;
   return 1;
 }
 
@@ -2767,6 +2771,12 @@ int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32
   int rc = ykhost_evaluate_dirty(h, 1, want, nullptr);
   if (rc) return rc;
   const int P = (int)h->pending.size();
+  // A node-sharded engine (a communicator with world > 1 is attached to it): the round is COLLECTIVE — every rank calls with the same
+  // asks — and node indices in and out of it are indices in the WHOLE cluster (this shard's first node = shard_offset). An ask that
+  // went to another shard's node is assumed here as well (it is nobody's pending ask any more), without touching a node of this mirror.
+  int32_t shard_world = 1, shard_offset = 0;
+  ykpred_comm_info(h->eng, nullptr, &shard_world, &shard_offset);
+  const bool sharded = shard_world > 1;
   std::vector<int32_t> list, slot;  // asks of the round that the engine evaluates, and their position in `asks`
   list.reserve((size_t)n);
   slot.reserve((size_t)n);
@@ -2780,7 +2790,7 @@ int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32
       h->round_asks_routed++;
     } else if (p->assumed) {  // allocated by an earlier round and not bound yet: it keeps its node
       auto nt = h->node_ix.find(p->node_name);
-      out_nodes[i] = nt == h->node_ix.end() ? -1 : nt->second;
+      out_nodes[i] = p->remote_node >= 0 ? p->remote_node : nt == h->node_ix.end() ? -1 : nt->second + shard_offset;
     } else {
       list.push_back(row);
       slot.push_back(i);
@@ -2827,7 +2837,15 @@ int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32
       out_nodes[(size_t)slot[k]] = got[k];
       if (got[k] < 0) continue;
       ++placed;
-      if (apply) assume(h->pending[(size_t)list[k]], got[k]);
+      if (!apply) continue;
+      Pod* p = h->pending[(size_t)list[k]];
+      const int local = got[k] - shard_offset;  // (the engine of a sharded cluster answers in cluster-wide indices)
+      if (!sharded || (local >= 0 && local < (int)h->nodes.size())) {
+        assume(p, sharded ? local : got[k]);
+      } else {
+        p->assumed = true;
+        p->remote_node = got[k];
+      }
     }
     return placed;
   }

@@ -120,6 +120,7 @@ struct Pod {
   bool orphan = false;        // orphanedPods has uid: spec.nodeName names a node that is not in the cache
   bool ask = false;           // holds a row of the ask table (bitmap row); rows stay put across AssumePod / ForgetPod
   int32_t row = -1;           // that row
+  int32_t remote_node = -1;   // assumed by a round of a node-sharded cluster on ANOTHER shard's node: its index in the whole cluster
   const PodTemplate* tpl = nullptr;
 };
 
