@@ -2923,6 +2923,9 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       batch = (int)std::min<size_t>(kShardBatchMax, (size_t)std::max(8, 2 * m + 8));
     }
     e->round_exchanges += exchanges;
+    if (e->round_prof)
+      fprintf(stderr, "round_prof sharded round: %d asks in %lld batches (%.1f accepted per exchange)\n", n_asks, (long long)exchanges,
+              exchanges ? (double)n_asks / (double)exchanges : 0.0);
     return YKPRED_OK;
   }
   // one launch per 32 768 asks: the loop is a single workgroup, and a bounded launch keeps the queue responsive (the state of the
