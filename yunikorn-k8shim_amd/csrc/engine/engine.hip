@@ -1458,11 +1458,20 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   std::vector<uint32_t> sig_tolflags, sig_aff_flags;
   std::vector<int32_t> sig_aff_off{0}, sig_pre_off{0};
   const uint32_t aff_flag_mask = YKPRED_SPEC_AFFINITY_SKIP | YKPRED_SPEC_PREFILTER_REJECT | YKPRED_SPEC_PREFILTER_NAMES;
+  // (10^6 specs: the key strings are three buffers reused by every spec — a hit costs no allocation —, and the tables are sized for the
+  // population where every spec is its own request vector, so they do not rehash on the way there)
+  m_res.reserve((size_t)S);
+  if (S >= 65536)
+    for (auto& m : m_dim) m.reserve((size_t)S);
+  m_tol.reserve(4096);
+  m_aff.reserve(4096);
+  res_rows.reserve((size_t)std::min(S, 1 << 16) * (size_t)(R + 1));
+  std::string k, kt, ka;
   for (int i = 0; i < S; ++i) {
-    std::string k((const char*)(s->requests + (size_t)i * R), (size_t)R * sizeof(i64));
+    k.assign((const char*)(s->requests + (size_t)i * R), (size_t)R * sizeof(i64));
     auto it = m_res.find(k);
     if (it == m_res.end()) {
-      it = m_res.emplace(std::move(k), (int32_t)m_res.size()).first;
+      it = m_res.emplace(k, (int32_t)m_res.size()).first;
       res_rows.push_back(0);  // the pod-independent row
       for (int r = 0; r < R; ++r) {
         const i64 q = s->requests[(size_t)i * R + r];
@@ -1482,12 +1491,12 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     e->spec_sig_res[(size_t)i] = it->second;
 
     uint32_t tf = s->flags[i] & (YKPRED_SPEC_TOLERATES_UNSCHEDULABLE | YKPRED_SPEC_UNSUPPORTED);
-    std::string kt((const char*)(s->tolerated + (size_t)i * KT), (size_t)KT * sizeof(u64));
+    kt.assign((const char*)(s->tolerated + (size_t)i * KT), (size_t)KT * sizeof(u64));
     kt.append((const char*)&tf, sizeof(tf));
     if (KP > 0) kt.append((const char*)(s->wanted_ports + (size_t)i * KP), (size_t)KP * sizeof(u64));  // NodePorts rides in this family
     auto jt = m_tol.find(kt);
     if (jt == m_tol.end()) {
-      jt = m_tol.emplace(std::move(kt), (int32_t)m_tol.size()).first;
+      jt = m_tol.emplace(kt, (int32_t)m_tol.size()).first;
       sig_tol.insert(sig_tol.end(), s->tolerated + (size_t)i * KT, s->tolerated + (size_t)(i + 1) * KT);
       sig_tolflags.push_back(tf);
       if (KP > 0) sig_ports.insert(sig_ports.end(), s->wanted_ports + (size_t)i * KP, s->wanted_ports + (size_t)(i + 1) * KP);
@@ -1497,14 +1506,14 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     uint32_t af = s->flags[i] & aff_flag_mask;
     int t0 = s->aff_term_off[i], t1 = s->aff_term_off[i + 1], p0 = s->pre_term_off[i], p1 = s->pre_term_off[i + 1];
     if (t1 < t0 || p1 < p0) return fail(e, YKPRED_E_INVALID, "set_specs: offsets not monotone");
-    std::string ka((const char*)&af, sizeof(af));
+    ka.assign((const char*)&af, sizeof(af));
     int32_t nt = t1 - t0;
     ka.append((const char*)&nt, sizeof(nt));
     if (nt) ka.append((const char*)(s->aff_terms + (size_t)t0 * W), (size_t)nt * W * sizeof(u64));
     if (p1 > p0) ka.append((const char*)(s->pre_terms + (size_t)p0 * W), (size_t)(p1 - p0) * W * sizeof(u64));
     auto kt2 = m_aff.find(ka);
     if (kt2 == m_aff.end()) {
-      kt2 = m_aff.emplace(std::move(ka), (int32_t)m_aff.size()).first;
+      kt2 = m_aff.emplace(ka, (int32_t)m_aff.size()).first;
       sig_aff_flags.push_back(af);
       if (nt) sig_aff_terms.insert(sig_aff_terms.end(), s->aff_terms + (size_t)t0 * W, s->aff_terms + (size_t)t1 * W);
       if (p1 > p0) sig_pre_terms.insert(sig_pre_terms.end(), s->pre_terms + (size_t)p0 * W, s->pre_terms + (size_t)p1 * W);
