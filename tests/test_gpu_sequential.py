@@ -183,7 +183,7 @@ def test_round_without_apply_leaves_the_cluster_alone(pm):
 
 
 @pytest.mark.parametrize("world,total_nodes,n_pods,n_templates", [(2, 200, 600, 40), (3, 330, 900, 6), (2, 130, 500, 1)],
-                         ids=["two-shards", "three-shards-long-runs", "one-template"])
+                         ids=["two-shards", "three-shards-long-runs", "one-template-and-a-two-node-shard"])
 def test_allocation_rounds_on_a_node_sharded_cluster(tmp_path, world, total_nodes, n_pods, n_templates):
     """Rounds on node-sharded engines (world 2 and 3 on this box's one GPU, the collectives through tests/c/rccl_stub.cpp): every shard
     proposes its best node for a batch of asks, the proposals are all-gathered, every rank accepts the same conflict-free prefix —

@@ -3072,9 +3072,17 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     YK_CTX_FRESH();
     if (mode == kRoundPropose) {
       // ---- the shard's proposal for this ask; nothing is assumed. Wave 0, one load round (lane r = resource r).
-      if (wave == 0) {
+      if (wave == 0 && win < 0) {  // (no node of the shard fits — or the shard has no node at all)
+        if (lane == 0) {
+          RoundProposal pr{};
+          pr.key = ~0ull;
+          pr.node = -1;
+          pr.gnode = -1;
+          a.prop[a.first + i] = pr;
+        }
+      } else if (wave == 0) {
         const bool lr = lane < t.R;
-        const int rl = min(lane, t.R - 1), wn = max(win, 0);
+        const int rl = min(lane, t.R - 1), wn = win;
         const i64 rq_raw = s.req[(size_t)spec * s.R + rl], al_raw = t.alloc[(size_t)rl * t.n + wn], old_raw = ld_live(a.req + (size_t)rl * t.n + wn);
         const int cnt0 = ld_live(a.count + wn), allowed = t.allowed[wn];
         const u64 occ_l = (lane < t.KP && a.ports && a.fx.occupied) ? a.fx.occupied[(size_t)spec * t.KP + lane] : 0ull;
