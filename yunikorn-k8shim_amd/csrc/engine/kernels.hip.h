@@ -2756,6 +2756,10 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
   const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
   const bool spread_en = a.filt & kPlugSpread, ipa_en = (a.filt & kPlugInterPod) && (a.pre & kPlugInterPod);
   const size_t cap = (size_t)a.cap;
+  // (what every ask reads of the launch: once, into registers — behind the per-phase refresh each would be a trip to the constant cache)
+  const int n_asks = a.n_asks, first_ask = a.first, launch_mode = a.mode;
+  const bool all_fail = a.all_fail != 0;
+  const int* const spread_sig = a.topo_on ? s.spread_sig : nullptr;
   int p_l = 0, spec_l = 0, pin_l = -1, cls_l = 0;
   int last_spec = -1, last_win = -1;  // (per launch: the first ask of a launch takes the scans)
   if (tid == 0) {
@@ -2768,7 +2772,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
   i64 rp_prev = a.prof ? (i64)wall_clock64() : 0;
   const i64 rp_c0 = (i64)clock64(), rp_w0 = (i64)wall_clock64();
 #endif
-  for (int i = 0; i < a.n_asks; i += step) {
+  for (int i = 0; i < n_asks; i += step) {
     YK_CTX_FRESH();
     YK_RP_COUNT(8)
     int& sh_stop = sh_stop_[i & 1];
@@ -2776,8 +2780,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     step = 1;
     if ((i & (kWave - 1)) == 0) {  // the headers of the next 64 asks, one load round per wave
       const int j = i + lane;
-      if (j < a.n_asks) {
-        p_l = a.asks[a.first + j];
+      if (j < n_asks) {
+        p_l = a.asks[first_ask + j];
         spec_l = a.pod_spec[p_l];
         pin_l = name_on ? a.pod_pin[p_l] : -1;
         cls_l = a.pod_class[p_l];
@@ -2788,7 +2792,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     const int hl = i & (kWave - 1);
     const int spec = __builtin_amdgcn_readlane(spec_l, hl), cls = __builtin_amdgcn_readlane(cls_l, hl);
     const int pin = __builtin_amdgcn_readlane(pin_l, hl);
-    const int tsig = (a.topo_on && s.spread_sig) ? s.spread_sig[spec] : -1;  // the spec's topology signature: its verdicts move with every assume
+    const int tsig = spread_sig ? spread_sig[spec] : -1;  // the spec's topology signature: its verdicts move with every assume
     // (the flag set of the NEXT ask, whichever it will be: an iteration advances by `step`, and both parities may follow)
     if (tid == 0) {
       sh_stop_[(i + 1) & 1] = 0x7fffffff;
@@ -2797,8 +2801,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     int win = -1;
     bool again = false;
     YK_RP(0)
-    const int mode = a.mode;
-    if (mode == kRoundDecide && !a.all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
+    const int mode = launch_mode;
+    if (mode == kRoundDecide && !all_fail && pin == -1 && spec == last_spec && last_win >= 0 && tsig < 0) {
       // The same spec as the ask before, which went to node last_win: that node is AT LEAST as early in the bin-pack order now
       // (an allocation only raises a node's utilisation, i.e. lowers its score; every other node stands where it stood), so it
       // is this ask's node too as long as it still fits — one pair instead of the two scans. Bin-packing sends long runs of a
@@ -2815,8 +2819,8 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
       win = last_win;
       YK_RP_COUNT(9)
     } else if (mode == kRoundAssume) {
-      win = a.forced[a.first + i];  // (decided by the exchange: the scans are somebody else's)
-    } else if (a.all_fail || pin == -2) {
+      win = a.forced[first_ask + i];  // (decided by the exchange: the scans are somebody else's)
+    } else if (all_fail || pin == -2) {
       // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
     } else if (pin >= 0) {
       NodeRegs nr;
@@ -3078,7 +3082,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           pr.key = ~0ull;
           pr.node = -1;
           pr.gnode = -1;
-          a.prop[a.first + i] = pr;
+          a.prop[first_ask + i] = pr;
         }
       } else if (wave == 0) {
         const bool lr = lane < t.R;
@@ -3107,7 +3111,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           pr.req[1] = used[1];
           pr.gnode = win >= 0 ? a.node_offset + win : -1;
           pr.pad = 0;
-          a.prop[a.first + i] = pr;
+          a.prop[first_ask + i] = pr;
         }
       }
       last_spec = -1;
@@ -3158,10 +3162,10 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
             for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
             const i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));  // pod slots left (>= 1: the ask fits)
             k_run = (int)max((i64)1, min(fits, (i64)(1 + min(run, 63 - hl))));
-            k_run = min(k_run, a.n_asks - i);
+            k_run = min(k_run, n_asks - i);
           }
         }
-        if (lane < k_run) a.out[a.first + i + lane] = win;
+        if (lane < k_run) a.out[first_ask + i + lane] = win;
         const int cnt = cnt0 + k_run;
         const bool dead = fit_on && (i64)cnt + 1 > (i64)allowed;  // no pod slot left: no ask of this phase fits it any more
         const i64 v_l = old_l + rq_l * (i64)k_run;
@@ -3273,7 +3277,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
       }
       if (ndirty) __threadfence_block();
     } else if (tid == 0) {
-      a.out[a.first + i] = -1;
+      a.out[first_ask + i] = -1;
     }
     // (the exchange slots are rewritten by the next ask only after this barrier; every wave has read them by now)
     __syncthreads();
