@@ -428,9 +428,11 @@ func (m *gpuPredicateManager) RoutingStats() (unsupported, refused, growths int6
 
 // AllocateRound decides a scheduling round with conflict-resolved decisions: pods[i] is decided with pods[0..i-1] assumed on
 // their nodes — what the core's allocation loop obtains by calling Predicates() down the bin-pack order and AssumePod after every
-// allocation (scheduler_callback.go:49-98, context.go:828-885), in ONE device call where only node resources couple the asks
-// (ykhost_allocate_round; ask by ask on the host side where topology constraints or host ports do). nodes[i] is the node index in
-// the mirror's node order (NodeName resolves it), -1 when no node fits, -2 when the ask is routed to the CPU manager. apply = true
+// allocation (scheduler_callback.go:49-98, context.go:828-885), in ONE device call: node resources, pod slots, host ports and
+// the PreFilter state of PodTopologySpread / InterPodAffinity are kept live on the device while the round runs
+// (ykhost_allocate_round). nodes[i] is the node index in the mirror's node order (NodeName resolves it), -1 when no node fits, -2
+// when the ask is routed to the CPU manager. On a node-sharded cluster the call is collective (every rank's manager calls it with
+// the same pods) and nodes[i] is the index in the whole cluster: shard offset + local index (ykpred_comm_info). apply = true
 // marks the chosen nodes' asks assumed in the mirror exactly as OnAssumePod would; with apply = false the core confirms through
 // OnAssumePod itself. Needs a current Refresh(allocate) with decisions.
 func (m *gpuPredicateManager) AllocateRound(pods []*v1.Pod, apply bool) ([]int32, error) {

@@ -137,3 +137,53 @@ def test_gather_bitmap_reference_world2(tmp_path):
     rows = got["rows"].numpy().view(np.uint64)
     bits = np.unpackbits(rows.view(np.uint8), axis=1, bitorder="little")[:, :200]
     assert np.array_equal(bits.astype(bool), got["full"].numpy())
+
+
+def round_model(seed, n_total, n_asks, n_classes):
+    rng = np.random.default_rng(seed)
+    alloc = rng.choice([16, 32, 64], n_total).astype(np.int64) * 1000
+    used = (alloc * rng.integers(0, 950, n_total) // 1000).astype(np.int64)
+    static_ok = rng.random((n_classes, n_total)) < 0.6
+    cls = np.repeat(rng.integers(0, n_classes, n_asks // 3 + 1), 3)[:n_asks]  # runs of three asks of one class ...
+    req_of = rng.choice([100, 250, 500, 1000, 4000], n_classes).astype(np.int64)
+    req = req_of[cls]
+    req[::11] += 50  # ... broken up by asks with a request of their own
+    return alloc, used, static_ok, cls, req
+
+
+def round_sequential(alloc, used, static_ok, cls, req):
+    used = used.copy()
+    out = np.full(len(req), -1, dtype=np.int64)
+    for j in range(len(req)):
+        ok = static_ok[cls[j]] & (alloc - used >= req[j])
+        if ok.any():
+            cand = np.flatnonzero(ok)
+            n = cand[np.lexsort((cand, sharding.round_key(alloc, used)[cand]))[0]]
+            out[j] = n
+            used[n] += req[j]
+    return out
+
+
+def round_worker(rank, world, port, seed, n_total, n_asks, n_classes, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    alloc, used, static_ok, cls, req = round_model(seed, n_total, n_asks, n_classes)
+    first, count = sharding.shard_ranges(n_total, world)[rank]
+    got = sharding.ref_allocate_round_sharded(req, cls, static_ok[:, first:first + count], alloc[first:first + count],
+                                              used[first:first + count].copy(), first, dist)
+    torch.save(torch.from_numpy(got), f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allocation_round_in_batches_world2(tmp_path):
+    """The batch protocol of rounds on node-sharded engines (proposals, one all-gather, the conflict-free prefix, runs, owners assume)
+    on a one-resource model, world 2 over gloo: every rank ends with the decisions of the sequential loop over all nodes."""
+    for seed, n_total, n_asks, n_classes in ((3, 200, 400, 12), (4, 130, 300, 2)):
+        out = str(tmp_path / f"round{seed}")
+        mp.spawn(round_worker, args=(2, 29541 + seed, seed, n_total, n_asks, n_classes, out), nprocs=2, join=True)
+        alloc, used, static_ok, cls, req = round_model(seed, n_total, n_asks, n_classes)
+        want = round_sequential(alloc, used, static_ok, cls, req)
+        assert (want >= 0).sum() > n_asks // 2
+        for rank in range(2):
+            assert np.array_equal(torch.load(f"{out}.{rank}").numpy(), want), (seed, rank)

@@ -103,3 +103,59 @@ def gathered_row(gathered, row_maps, pod, ranges):
     slab is in the RECEIVING engine's row order, i.e. its pm.row_map() for every g. `ranges` = shard_ranges(...)."""
     parts = [gathered[g, int(row_maps[g][pod]), : -(-count // 64)] for g, (_, count) in enumerate(ranges) if count > 0]
     return torch.cat(parts)
+
+
+# ---- allocation rounds on a node-sharded cluster: the batch protocol of ykpred_allocate_round in reference form -----------------
+def round_key(alloc, used):
+    """Order key of a node in a bin-pack round of the reference model below: fuller nodes first (smaller key)."""
+    return 1.0 - np.asarray(used, dtype=np.float64) / np.asarray(alloc, dtype=np.float64)
+
+
+def ref_allocate_round_sharded(req, cls, static_ok, alloc, used, node_offset, dist, batch=16, batch_max=512):
+    """The protocol engine.hip runs for a round on node-sharded engines, on a model small enough to state in a few lines: node n
+    of this shard has capacity alloc[n] of one resource, used[n] of it taken (MUTATED here: the owner assumes), ask j requests
+    req[j] and is of class cls[j]; static_ok[c][n] says whether class c may run on node n at all. An ask fits a node iff the class
+    may and the request still fits; nodes are tried fullest first, ties by cluster-wide index. Per batch: every shard PROPOSES its
+    best node per ask against the state the accepted asks left, one all-gather, every rank accepts the same conflict-free PREFIX —
+    an accepted node u can change a later ask's answer w only if u == w, or u stood behind w and now stands in front of it —, a
+    run of asks with one (class, request) lands on one node while it fits, the owners assume. → cluster-wide node per ask, -1 = none;
+    identical on every rank and equal to deciding the asks one after the other over all nodes (tests/test_sharding_gloo.py)."""
+    world = dist.get_world_size()
+    n_asks, out, pos = len(req), np.full(len(req), -1, dtype=np.int64), 0
+    while pos < n_asks:
+        b = min(batch, n_asks - pos)
+        prop = np.zeros((b, 5), dtype=np.float64)  # key, cluster-wide node (-1: none), fits, alloc, used
+        key = round_key(alloc, used)
+        for j in range(b):
+            ok = static_ok[cls[pos + j]] & (alloc - used >= req[pos + j])
+            if not ok.any():
+                prop[j] = (np.inf, -1, 0, 0, 0)
+                continue
+            cand = np.flatnonzero(ok)
+            n = cand[np.lexsort((cand, key[cand]))[0]]
+            prop[j] = (key[n], node_offset + n, (alloc[n] - used[n]) // req[pos + j] if req[pos + j] > 0 else 1 << 30, alloc[n], used[n])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, prop)
+        accepted, m = [], 0  # accepted: (cluster-wide node, key when proposed, key after the accepted asks)
+        while m < b:
+            best = min(((g[m][0], g[m][1], r) for r, g in enumerate(gathered) if g[m][1] >= 0), default=None)
+            if best is None:
+                m += 1
+                continue
+            w_key, w_node, owner = best
+            conflict = any(u == w_node or ((k0, u) > (w_key, w_node) and (k1, u) < (w_key, w_node)) for u, k0, k1 in accepted)
+            if conflict:
+                break
+            fits, a_n, u_n = gathered[owner][m][2:5]
+            k = 1
+            while k < fits and m + k < b and cls[pos + m + k] == cls[pos + m] and req[pos + m + k] == req[pos + m]:
+                k += 1
+            accepted.append((w_node, w_key, float(round_key(a_n, u_n + k * req[pos + m]))))
+            out[pos + m:pos + m + k] = int(w_node)
+            local = int(w_node) - node_offset
+            if 0 <= local < len(alloc):
+                used[local] += k * req[pos + m]
+            m += k
+        pos += m
+        batch = min(batch_max, max(8, 2 * m + 8))
+    return out
