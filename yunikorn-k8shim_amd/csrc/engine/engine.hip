@@ -1449,8 +1449,46 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   e->spec_sig_res.assign((size_t)S, 0);
   e->spec_sig_tol.assign((size_t)S, 0);
   e->spec_sig_aff.assign((size_t)S, 0);
-  std::unordered_map<std::string, int32_t> m_res, m_tol, m_aff;
-  std::vector<std::unordered_map<i64, int32_t>> m_dim((size_t)R);  // per dimension: request value → plane row
+  std::unordered_map<std::string, int32_t> m_tol, m_aff;
+  // Request vectors → signature and request value → plane row (per dimension) are looked up once per spec and dimension, and the
+  // adversarial population has 10^6 distinct ones: open-addressing tables of int32 (no node per entry, no key copy — a slot names
+  // the first spec that carried the vector, resp. the row whose value it is), sized once for the worst case.
+  auto mix64 = [](u64 z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  };
+  size_t tab_cap = 64;
+  while (tab_cap < (size_t)S * 2 + 2) tab_cap <<= 1;
+  std::vector<int32_t> res_tab(tab_cap, -1);           // slot → signature id
+  std::vector<int32_t> res_first;                      // signature id → first spec with that request vector
+  std::vector<std::vector<int32_t>> dim_tab((size_t)R);  // per dimension, grown on demand: slot → plane row (its value: h_dim_val)
+  std::vector<size_t> dim_used((size_t)R, 0);
+  auto dim_row = [&](int r, i64 q) -> int32_t {  // the plane row of value q in dimension r (a new one when nobody had it)
+    std::vector<int32_t>& tab = dim_tab[(size_t)r];
+    if (tab.empty()) tab.assign(1024, -1);
+    if ((dim_used[(size_t)r] + 1) * 2 > tab.size()) {  // keep the table at most half full
+      std::vector<int32_t> bigger(tab.size() * 4, -1);
+      for (int32_t row : tab)
+        if (row >= 0) {
+          size_t at = (size_t)mix64((u64)e->h_dim_val[(size_t)row]) & (bigger.size() - 1);
+          while (bigger[at] >= 0) at = (at + 1) & (bigger.size() - 1);
+          bigger[at] = row;
+        }
+      tab.swap(bigger);
+    }
+    size_t at = (size_t)mix64((u64)q) & (tab.size() - 1);
+    while (tab[at] >= 0) {
+      if (e->h_dim_val[(size_t)tab[at]] == q) return tab[at];
+      at = (at + 1) & (tab.size() - 1);
+    }
+    const int32_t row = (int32_t)e->h_dim_val.size();
+    tab[at] = row;
+    dim_used[(size_t)r]++;
+    e->h_dim_val.push_back(q);
+    e->h_dim_of.push_back(r);
+    return row;
+  };
   std::vector<int32_t> res_rows;                                   // [vectors][1 + R]
   e->h_dim_val.assign(1, 0);
   e->h_dim_of.assign(1, -1);
@@ -1460,35 +1498,34 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   const uint32_t aff_flag_mask = YKPRED_SPEC_AFFINITY_SKIP | YKPRED_SPEC_PREFILTER_REJECT | YKPRED_SPEC_PREFILTER_NAMES;
   // (10^6 specs: the key strings are three buffers reused by every spec — a hit costs no allocation —, and the tables are sized for the
   // population where every spec is its own request vector, so they do not rehash on the way there)
-  m_res.reserve((size_t)S);
-  if (S >= 65536)
-    for (auto& m : m_dim) m.reserve((size_t)S);
   m_tol.reserve(4096);
   m_aff.reserve(4096);
   res_rows.reserve((size_t)std::min(S, 1 << 16) * (size_t)(R + 1));
-  std::string k, kt, ka;
+  std::string kt, ka;
   for (int i = 0; i < S; ++i) {
-    k.assign((const char*)(s->requests + (size_t)i * R), (size_t)R * sizeof(i64));
-    auto it = m_res.find(k);
-    if (it == m_res.end()) {
-      it = m_res.emplace(k, (int32_t)m_res.size()).first;
+    const int64_t* rq = s->requests + (size_t)i * R;
+    u64 hv = 0x9e3779b97f4a7c15ull;
+    for (int r = 0; r < R; ++r) hv = mix64(hv ^ (u64)rq[r]);
+    size_t at = (size_t)hv & (tab_cap - 1);
+    int32_t sig = -1;
+    while (res_tab[at] >= 0) {
+      if (memcmp(s->requests + (size_t)res_first[(size_t)res_tab[at]] * R, rq, (size_t)R * sizeof(i64)) == 0) {
+        sig = res_tab[at];
+        break;
+      }
+      at = (at + 1) & (tab_cap - 1);
+    }
+    if (sig < 0) {
+      sig = (int32_t)res_first.size();
+      res_tab[at] = sig;
+      res_first.push_back(i);
       res_rows.push_back(0);  // the pod-independent row
       for (int r = 0; r < R; ++r) {
-        const i64 q = s->requests[(size_t)i * R + r];
-        int32_t row = -1;
-        if (q > 0) {  // "req_r > 0 ∧ req_r > free_r" fails: a non-positive request never does
-          auto dv = m_dim[(size_t)r].find(q);
-          if (dv == m_dim[(size_t)r].end()) {
-            dv = m_dim[(size_t)r].emplace(q, (int32_t)e->h_dim_val.size()).first;
-            e->h_dim_val.push_back(q);
-            e->h_dim_of.push_back(r);
-          }
-          row = dv->second;
-        }
-        res_rows.push_back(row);
+        const i64 q = (i64)rq[r];
+        res_rows.push_back(q > 0 ? dim_row(r, q) : -1);  // "req_r > 0 ∧ req_r > free_r" fails: a non-positive request never does
       }
     }
-    e->spec_sig_res[(size_t)i] = it->second;
+    e->spec_sig_res[(size_t)i] = sig;
 
     uint32_t tf = s->flags[i] & (YKPRED_SPEC_TOLERATES_UNSCHEDULABLE | YKPRED_SPEC_UNSUPPORTED);
     kt.assign((const char*)(s->tolerated + (size_t)i * KT), (size_t)KT * sizeof(u64));
@@ -1556,7 +1593,7 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
   if (!spread_unchanged) e->spread_dirty = true;
   if (!spread_unchanged) e->nodes_epoch++;  // the histograms of the last pass do not describe the new signatures
   TRY(upload(e, e->d_spec_spread, e->spec_sig_spread.data(), e->spec_sig_spread.size(), st));
-  e->res_vectors = (int)m_res.size();
+  e->res_vectors = (int)res_first.size();
   e->fam_res.D = (int)e->h_dim_val.size();
   e->fam_tol.D = (int)m_tol.size();
   e->fam_aff.D = (int)m_aff.size();
