@@ -1034,7 +1034,7 @@ void touch_node_for(ykhost* h, int n, const Pod* p) {
 void detach_from_node(ykhost* h, Pod* p) {
   if (p->assigned_node.empty()) return;
   auto nt = h->node_ix.find(p->assigned_node);
-  if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid)) touch_node(h, nt->second);
+  if (nt != h->node_ix.end() && h->nodes[(size_t)nt->second]->remove_pod(p->uid, p)) touch_node(h, nt->second);
   p->assigned_node.clear();
 }
 // cache.updatePod for the new version `p` of the cached pod `old` (null: not cached; == p: re-evaluate in place).
