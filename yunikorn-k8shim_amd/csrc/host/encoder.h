@@ -256,6 +256,8 @@ class Encoder {
     std::vector<HostPort> ports;
     std::vector<ReqItem> reqs;
     std::string tol_key;  // the toleration list's identity (assign_taint_bits)
+    std::vector<std::string> scalars;  // names of the scalar resources the template requests (dimensions exist because an ask requests them)
+    bool plain = false;   // no pod (anti)affinity term, no spread constraint: the ordered loop has nothing to read in the template itself
   };
   static std::string toleration_list_key(const PodTemplate& t) {
     std::string k;
@@ -365,6 +367,9 @@ class Encoder {
         if (!p.error.empty()) return;
         p.ports = template_host_ports(t);
         p.reqs = requirement_items(t);
+        for (auto& kv : t.requests)
+          if (kv.second > 0 && is_scalar_resource_name(kv.first)) p.scalars.push_back(kv.first);
+        p.plain = t.pod_affinity.empty() && t.pod_anti_affinity.empty() && t.spread.empty();
       });
     }
     auto visit = [&](PodTemplate* t, Prepared* pre) {
@@ -377,6 +382,22 @@ class Encoder {
         }
       }
       const Mark mark = mark_now();
+      if (pre && pre->plain) {
+        // (everything the template asks of the dictionaries was prepared: the loop reads one contiguous record, not the template)
+        for (const HostPort& hp : pre->ports)
+          if (port_ix_.emplace(port_key(hp), (int)port_dict.size()).second) port_dict.push_back(hp);
+        for (const std::string& name : pre->scalars) scalar(name);
+        for (ReqItem& it : pre->reqs) add_req_item(std::move(it));
+        const char* full = nullptr;
+        if (3 + (int)scalar_names.size() > kLimitR) full = "scalar resource names (engine limit: 5 besides cpu, memory, ephemeral-storage)";
+        else if ((int)req_dict.size() > kLimitRequirements) full = "distinct node-selector requirements (engine limit: 2048)";
+        else if ((int)port_dict.size() > kLimitPorts) full = "distinct requested host ports (engine limit: 256)";
+        if (full) {
+          rollback(mark);
+          unsupported[t] = std::string("the ask needs more ") + full + " than the dictionaries can still take";
+        }
+        return;
+      }
       for (auto* terms : {&t->pod_affinity, &t->pod_anti_affinity})
         for (auto& term : *terms) topo_key(term.topology_key);
       if (!t->pod_affinity.empty())
