@@ -2988,9 +2988,10 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   if (e->round_prof) {
     i64 pr_[16];
     HIPCHK(hipMemcpy(pr_, base + o_prof, sizeof(pr_), hipMemcpyDeviceToHost));
-    fprintf(stderr, "round_prof asks=%d iters=%lld again=%lld B_active_iters=%lld | us: header %.0f again %.0f pin %.0f A %.0f B %.0f exchange %.0f assume %.0f tail %.0f\n",
-            n_asks, (long long)pr_[8], (long long)pr_[9], (long long)pr_[10], pr_[0] / 100.0, pr_[1] / 100.0, pr_[2] / 100.0, pr_[3] / 100.0, pr_[4] / 100.0,
-            pr_[5] / 100.0, pr_[6] / 100.0, pr_[7] / 100.0);
+    if (pr_[8] > 0)  // (the ticks exist in a -DYK_ROUND_PROF build of the engine only)
+      fprintf(stderr, "round_prof asks=%d iters=%lld again=%lld | us: header %.0f again %.0f pin %.0f A %.0f B %.0f exchange %.0f assume %.0f tail %.0f\n",
+              n_asks, (long long)pr_[8], (long long)pr_[9], pr_[0] / 100.0, pr_[1] / 100.0, pr_[2] / 100.0, pr_[3] / 100.0, pr_[4] / 100.0,
+              pr_[5] / 100.0, pr_[6] / 100.0, pr_[7] / 100.0);
     if (pr_[13] > 0) fprintf(stderr, "round_prof shader clock %.0f MHz\n", 100.0 * (double)pr_[12] / (double)pr_[13]);
   }
   return YKPRED_OK;
