@@ -300,9 +300,26 @@ def json_ingest_leg(pkg, dev, a, gang):
                     "host_cores": len(os.sched_getaffinity(0)),
                     "note": "one cgo-shaped crossing per object kind (ykhost_update_nodes_batch / ykhost_update_pods_batch); the pod batches are "
                             "scanned on `ingest_timing.threads` threads (scan_ms), the cache pass runs on the caller's thread (apply_ms)"})
+        try:
+            out["steady_state_burst"] = steady_state_burst(dst, docs[1])
+        except Exception as exc:  # noqa: BLE001 — a side leg never takes the line down
+            out["steady_state_burst"] = {"error": str(exc)}
     finally:
         dst.close()
     return out
+
+
+def steady_state_burst(dst, pod_docs):
+    """Informer traffic on the LOADED, encoded mirror (context.go:184-193,320-352): every 10th pod document of the cluster again in one
+    batch — an informer resync, every uid cached. The scanning threads resolve the uids, the ordered cache pass applies the batch."""
+    lines = pod_docs.split(b"\n")
+    burst = b"\n".join(lines[:-1][::10]) + b"\n"
+    del lines
+    t0 = time.perf_counter()
+    n = dst.update_documents(1, burst)
+    dt = time.perf_counter() - t0
+    return {"documents": int(n), "ms": round(dt * 1e3, 1), "us_per_document": round(dt / max(n, 1) * 1e6, 2),
+            "note": "every 10th pod document again on the loaded mirror (resync: uids cached, per-node / per-row bookkeeping live)"}
 
 
 def device_rounds(pm, sizes, check_prefix):

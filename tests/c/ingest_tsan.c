@@ -84,6 +84,18 @@ int main(int argc, char** argv) {
       return 1;
     }
   }
+  {
+    /* informer resync on the loaded mirror: the same pod documents again — every uid is cached, so the scanning threads look the
+     * uids up in the uid index (read-only, several threads) and the ordered pass applies the batch on their hints */
+    long len = 0;
+    char* text = slurp(argv[2], &len);
+    const int32_t n = (text && len >= 0) ? ykhost_update_pods_batch(H, text, len) : -1;
+    if (n < 0) {
+      fprintf(stderr, "resync batch: %s\n", ykhost_last_error(H));
+      rc = 1;
+    }
+    free(text);
+  }
   ykhost_ingest_stats(H, st);
   int64_t tm[5] = {0, 0, 0, 0, 0};
   ykhost_ingest_timing(H, tm);

@@ -313,6 +313,55 @@ def test_bulk_cache_pass_equals_the_ordered_pass(cluster_docs, monkeypatch):
         assert four[4]["bulk_batches"] == want_bulk and one[4]["bulk_batches"] == 0, (name, four[4])
 
 
+def test_steady_state_bursts_equal_the_one_thread_pass_and_the_single_hooks(cluster_docs, monkeypatch):
+    """Informer traffic WHILE scheduling (context.go:184-193,320-352), as batches on a mirror that is loaded and encoded: the scanning
+    threads look every uid up in the (current) uid index and hand the ordered cache pass the version they found; the pass trusts that
+    hint only while it still is a live pod of that uid. The burst mixes what can go wrong with it: unchanged pods (resync), asks that
+    were bound meanwhile, ONE uid five times in a row moving from node to node (the third version is stored in the slot the first one
+    vacated — the hint then points at the pod being applied), a pod that terminates and comes back under its uid, pods nobody has
+    seen. Mirror, encoded tables and counters equal the one-thread batch and one hook call per document."""
+    docs, _ = cluster_docs
+    nodes = [json.loads(d)["metadata"]["name"] for d in docs[0].splitlines()]
+    on_nodes, asks = docs[1].splitlines(), docs[2].splitlines()
+
+    def on(doc, node, phase=None, uid=None):
+        d = json.loads(doc)
+        d["spec"] = dict(d["spec"], nodeName=node)
+        if phase:
+            d["status"] = dict(d.get("status") or {}, phase=phase)
+        if uid:
+            d["metadata"] = dict(d["metadata"], uid=uid, name=uid)
+        return json.dumps(d).encode()
+
+    wanderer = [on(on_nodes[7], nodes[k % len(nodes)]) for k in (3, 9, 4, 9, 1)]
+    back = [on(on_nodes[11], nodes[2], phase="Succeeded"), on(on_nodes[11], nodes[5])]
+    fresh = [on(asks[k], "", uid=f"fresh-{k}") for k in range(0, 60, 3)]
+    bound = [on(a, nodes[(3 * i) % len(nodes)], phase="Running" if i % 2 else None) for i, a in enumerate(asks[100:1300:4])]
+    burst = on_nodes[0:4000:5] + bound[:150] + wanderer[:2] + fresh[:10] + wanderer[2:] + back + bound[150:] + fresh[10:] + on_nodes[1:4000:7]
+    text = b"\n".join(burst) + b"\n"
+    assert len(text) > 2 * 65536  # (enough for two scanning threads)
+    outcomes = []
+    for mode in ("1", "4", "hooks"):
+        monkeypatch.setenv("YKHOST_INGEST_THREADS", "4" if mode == "4" else "1")
+        m = pkg.GpuPredicateManager(device=-1)
+        try:
+            for k in (0, 1, 2):
+                m.update_documents(k, docs[k])
+            m.encoded_tables()  # (a full encode: from here on the mirror keeps its per-row / per-node bookkeeping)
+            before = m.ingest_timing()["parallel_batches"]
+            if mode == "hooks":
+                for doc in burst:
+                    m.update_pod(json.loads(doc))
+            else:
+                assert m.update_documents(1, text) == len(burst)
+                assert (m.ingest_timing()["parallel_batches"] - before) == (1 if mode == "4" else 0)
+            outcomes.append((m.dump_snapshot(), m.encoded_tables(), m.num_pods))
+        finally:
+            m.close()
+    assert outcomes[0] == outcomes[1], "four scanning threads vs one"
+    assert outcomes[0] == outcomes[2], "the batch vs one hook call per document"
+
+
 def test_threads_that_cannot_be_created_degrade_to_fewer_threads(cluster_docs, monkeypatch):
     """ADVICE r4 (medium): std::thread's constructor throws EAGAIN under a pids / thread cgroup limit. Every per-batch spawn goes
     through run_on_threads (host.cpp): the threads that did start — at worst the caller alone — take the items of the ones that

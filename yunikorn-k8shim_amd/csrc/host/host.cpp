@@ -136,6 +136,11 @@ struct UidIndex {
     auto it = shard[s].find(uid);
     return it == shard[s].end() ? end() : iterator{this, s, it};
   }
+  Pod* lookup(const std::string& uid) const {  // (read-only: safe from several threads while nobody writes the index)
+    const Map& m = shard[shard_of(uid)];
+    auto it = m.find(uid);
+    return it == m.end() ? nullptr : it->second;
+  }
   Pod*& operator[](const std::string& uid) { return shard[shard_of(uid)][uid]; }
   void erase(iterator i) { shard[i.s].erase(i.it); }
   size_t erase(const std::string& uid) { return shard[shard_of(uid)].erase(uid); }
@@ -1605,7 +1610,7 @@ int32_t ykhost_remove_node(ykhost_t* h, const char* name) {
 // Ask table: an unassigned, not yet running pod is a pending ask and holds a row; a pod that arrives with a
 // spec.nodeName of its own was bound by the cluster and holds none. A pod that already holds a row keeps it (in place)
 // while it is neither running nor terminated, so that rows stay stable while binds are in flight.
-static int apply_pod(ykhost* h, Pod* p, const std::string& phase);
+static int apply_pod(ykhost* h, Pod* p, const std::string& phase, Pod* hint = nullptr);
 static int update_pod_value(ykhost* h, const mj::Value& v) {
   ensure_uid_index(h);
   size_t anon = h->pod_store.size();
@@ -1644,14 +1649,32 @@ static int update_pod_text(ykhost* h, js::Range doc) {
   p.tpl = tpl;
   return apply_pod(h, store_pod(h, std::move(p)), sc.phase.str());
 }
-static int apply_pod(ykhost* h, Pod* p, const std::string& phase) {
+// hint: what the uid index held for this uid when the batch was scanned (null: nothing, or not looked up). The batch may have moved on
+// since — an earlier document of the same uid replaced or removed that version, and its slot may have been handed to another pod,
+// even to `p` itself — so the hint counts only if it still IS a live pod with this uid other than p: pod slots are recycled empty
+// (no template), and the cache never holds two live versions of one uid besides the one being applied. Anything else looks the uid up.
+static int apply_pod(ykhost* h, Pod* p, const std::string& phase, Pod* hint) {
   const bool running = phase == "Running";                           // utils.IsPodRunning (utils.go:89-91)
   const bool terminated = phase == "Failed" || phase == "Succeeded";  // utils.IsPodTerminated (:93-95)
-  auto it = h->by_uid.find(p->uid);
-  Pod* old = it == h->by_uid.end() ? nullptr : it->second;
+  Pod* old;
+  if (hint && hint != p && hint->tpl && hint->uid == p->uid) {
+    old = hint;
+  } else {
+    auto it = h->by_uid.find(p->uid);
+    old = it == h->by_uid.end() ? nullptr : it->second;
+  }
   const bool bound_by_cluster = !p->node_name.empty();
-  const bool ok = cache_update_pod(h, old, p, running, terminated);
   const bool wants_row = !terminated && !running && (old && old->ask ? true : !bound_by_cluster);
+  // A version that changes nothing the cache mirrors — an informer resync re-delivers every pod as it is — leaves the cache as it
+  // is: the reference's updatePod would take the pod off its node and put it back (scheduler_cache.go:321-360), with the same
+  // sums, the same maps and nothing for a predicate to see; here it would also mark the node and the ask row for re-evaluation.
+  if (old && old != p && !terminated && old->tpl == p->tpl && old->node_name == p->node_name && old->name == p->name &&
+      old->terminating == p->terminating && !old->assumed && !old->orphan && old->ask == wants_row &&
+      (old->node_name.empty() || old->assigned_node == old->node_name)) {
+    recycle_pod(h, p);
+    return 1;
+  }
+  const bool ok = cache_update_pod(h, old, p, running, terminated);
   set_ask_row(h, old, wants_row ? p : nullptr);
   if (old && old != p) recycle_pod(h, old);  // replaced by the new version everywhere
   if (terminated) recycle_pod(h, p);          // dropped from every map (scheduler_cache.go:377-383)
@@ -1699,6 +1722,8 @@ struct ScannedPod {
   int tpl_shard = -1, tpl_index = -1;  // else: the shared new template ...
   bool first = false;                  // ... and whether this document is the one it was parsed from
   js::Range full{};        // else: the document takes the full parser (in the ordered pass)
+  Pod* cached = nullptr;   // the version of this uid the cache held when the batch was SCANNED (uid index current then): a hint for the
+                           // ordered pass, which checks it before it trusts it (apply_pod) — the lookup is the pass's longest step
 };
 struct ScannedPiece {
   std::vector<ScannedPod> pods;
@@ -1759,6 +1784,7 @@ void scan_piece(const ykhost* h, SharedTemplates* shared, const char* b, const c
       sp.pod.terminating = sc.terminating;
       sp.pod.node_name = sc.node_name.str();
       sp.phase = sc.phase.str();
+      if (h->uid_index && !sp.pod.uid.empty()) sp.cached = h->by_uid.lookup(sp.pod.uid);
       if (sp.tpl_shard >= 0) out->shared_tpl.push_back((int32_t)out->pods.size() - 1);
       if (sp.pod.uid.empty() || sp.phase == "Failed" || sp.phase == "Succeeded") out->plain = false;
     });
@@ -1957,6 +1983,7 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
     p = (const char*)memchr(p, '\n', (size_t)(text + len - p));
     cut[(size_t)t] = p ? p + 1 : text + len;
   }
+  if (!h->dirty_all) ensure_uid_index(h);  // (steady state: the scanning threads look the uids up; a start-up replay fills the index in its bulk pass)
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<ScannedPiece> pieces((size_t)T);
   auto shared = std::make_unique<SharedTemplates>();
@@ -2012,7 +2039,7 @@ long update_pods_parallel(ykhost* h, const char* text, int64_t len, bool* fallba
             h->ingest_fast++;
           }
           if (sp.pod.uid.empty()) sp.pod.uid = "anon-" + std::to_string(h->pod_store.size());
-          apply_pod(h, store_pod(h, std::move(sp.pod)), sp.phase);
+          apply_pod(h, store_pod(h, std::move(sp.pod)), sp.phase, sp.cached);
         }
         ++applied;
       }
