@@ -555,8 +555,13 @@ int encode_tables(ykhost* h, EncodedTables* T) {
   bool dict_ok = false;
   try {
     dict_ok = h->enc.build_dictionaries(h->nodes, h->spec_templates, any_anti, have_reps ? &shape_reps : nullptr, id_threads > 1 ? &on_cores : nullptr);
-  } catch (const std::exception& ex) {
-    return fail(h, std::string("encoder: dictionaries: ") + ex.what(), YKPRED_E_NOMEM);
+  } catch (const std::exception&) {
+    // (a worker of the preparation ran out of memory: the build starts from cleared dictionaries — once more, everything on this thread)
+    try {
+      dict_ok = h->enc.build_dictionaries(h->nodes, h->spec_templates, any_anti, have_reps ? &shape_reps : nullptr, nullptr);
+    } catch (const std::exception& ex) {
+      return fail(h, std::string("encoder: dictionaries: ") + ex.what(), YKPRED_E_NOMEM);
+    }
   }
   if (!dict_ok) return fail(h, "encoder: " + h->enc.error, YKPRED_E_UNSUPPORTED);
   lap("dictionaries");
