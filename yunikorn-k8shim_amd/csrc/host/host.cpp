@@ -1076,7 +1076,7 @@ bool cache_update_pod(ykhost* h, Pod* old, Pod* p, bool running, bool terminated
     }
   }
   if (!terminated) {
-    h->by_uid[p->uid] = p;
+    if (old != p) h->by_uid[p->uid] = p;  // (re-evaluated in place — AssumePod, ForgetPod, an adopted orphan: the index holds this very pod)
   } else {
     p->assumed = p->orphan = false;
     h->by_uid.erase(p->uid);
