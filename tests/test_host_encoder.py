@@ -261,6 +261,22 @@ def test_match_label_keys_are_folded_into_the_selector(mirror):
     assert dumped["matchLabelKeys"] == ["pod-template-hash", "absent-key"] and dumped["labelSelector"]["matchExpressions"] == []
 
 
+def test_match_label_keys_two_hashes_of_one_rollout_are_two_count_classes(mirror):
+    """two templates of one Deployment rollout differ only in pod-template-hash; matchLabelKeys folds the
+    hash into the selector that names the spread count class, so they are two dictionary SHAPES — the second template used to
+    inherit the first one's entries, miss its class and fail the whole encode with "out of memory"."""
+    nodes = [_node(f"n{i}", labels={"zone": f"z{i % 2}"}) for i in range(4)]
+    tsc = [{"maxSkew": 1, "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule",
+            "labelSelector": {"matchLabels": {"app": "web"}}, "matchLabelKeys": ["pod-template-hash"]}]
+    asks = [_ask("old", labels={"app": "web", "pod-template-hash": "abc"}, topologySpreadConstraints=tsc),
+            _ask("new", labels={"app": "web", "pod-template-hash": "def"}, topologySpreadConstraints=tsc),
+            _ask("new2", labels={"app": "web", "pod-template-hash": "def", "extra": "x"}, topologySpreadConstraints=tsc)]
+    mirror.load_snapshot({"nodes": nodes, "pods": asks})
+    t = mirror.encoded_tables()
+    assert t["S"] == 3 and t["KS"] == 2 and t["spread_constraints"] == 3
+    assert [mirror.ask_supported(i) for i in range(3)] == [(True, "")] * 3
+
+
 def _resize_snapshot():
     """Three nodes with 1, 2 and 4 free cpus; pending pods in the middle of an in-place resize (KEP-1287): the request the Filter
     sees is yunikorn's GetPodResource (`pkg/common/resource.go:56-142`), for the ask size AND for NodeResourcesFit (DESIGN.md §2,

@@ -266,6 +266,7 @@ class Encoder {
   }
   using ParallelFor = std::function<void(int, const std::function<void(int)>&)>;
   bool trace = false;
+  bool use_shapes = true;  // (encode_tables clears it for one rebuild when a shape turned out not to stand for its templates)
   // shape_reps (optional): the indices into `templates` of the first template of every dictionary shape, ascending — the caller
   // found them on its threads; without it the loop below finds them itself, one template after the other.
   bool build_dictionaries(const std::vector<NodeInfo*>& nodes, const std::vector<PodTemplate*>& templates, bool may_have_existing_anti = true,
@@ -346,7 +347,7 @@ class Encoder {
     // Templates of one dictionary SHAPE (PodTemplate::shape_id: everything but labels and request values) register the same
     // entries and are refused for the same reasons — one of them is visited, the others inherit its verdict. Only while no
     // anti-affinity term of an on-node or pending pod exists: those are matched against every ask's LABELS.
-    const bool by_shape = existing_anti_templates_.empty() && wild_anti_terms_.empty();
+    const bool by_shape = use_shapes && existing_anti_templates_.empty() && wild_anti_terms_.empty();
     std::vector<const PodTemplate*> shape_rep;
     std::vector<PodTemplate*> visited;  // the templates that went through the loop body, in order (assign_taint_bits reads their toleration lists)
     const bool listed = by_shape && shape_reps != nullptr;

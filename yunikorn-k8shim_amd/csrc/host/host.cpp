@@ -762,6 +762,17 @@ int encode_tables(ykhost* h, EncodedTables* T) {
       }
       if (!placed)
         for (size_t b = 0; b < n_blocks; ++b) place_block((int)b);
+    } catch (const std::out_of_range& ex) {
+      // Not a memory problem: a template asked the dictionaries for an entry they do not hold — its shape's representative did not
+      // register what it needs. The dictionaries are rebuilt once with every template visited; if that does not help either the
+      // encoder is wrong about this cluster and says so (the caller keeps the CPU manager), it never reports "out of memory".
+      if (h->enc.use_shapes) {
+        h->enc.use_shapes = false;
+        const int rc = encode_tables(h, T);
+        h->enc.use_shapes = true;
+        return rc;
+      }
+      return fail(h, std::string("encoder: spec rows: a template needs a dictionary entry that was not registered (") + ex.what() + ")", YKPRED_E_UNSUPPORTED);
     } catch (const std::exception& ex) {
       return fail(h, std::string("encoder: spec rows: ") + ex.what(), YKPRED_E_NOMEM);
     }
@@ -1057,6 +1068,9 @@ bool cache_update_pod(ykhost* h, Pod* old, Pod* p, bool running, bool terminated
     old->orphan = false;
     if (!prev.empty() && p->node_name.empty()) p->node_name = prev;  // "new pod wasn't assigned to a node, so use existing assignment"
     p->assumed = was_assumed;
+    // (an ask assumed on another shard's node carries that node across its versions, like `assumed` itself: an informer update in
+    // front of the bind must not turn "allocated over there" into "no node fits")
+    if (old != p) p->remote_node = was_assumed ? old->remote_node : -1;
   }
   if (running || terminated) {  // "pod has now been bound" (:344-347)
     p->assumed = false;

@@ -626,6 +626,20 @@ class TemplatePool {
       }
     sh.push_back('\x1f');
     sh.append(spec, rest_at, std::string::npos);
+    // matchLabelKeys fold the POD'S label values into the selector that names the spread count class (read_template): two
+    // templates of one Deployment that differ in pod-template-hash register different classes — the values belong to the shape
+    for (const SpreadConstraint& c : t.spread) {
+      if (c.match_label_keys.empty() || !c.selector.present) continue;
+      sh.push_back('\x1f');
+      for (const std::string& key : c.match_label_keys) {
+        auto lv = t.labels.find(key);
+        if (lv == t.labels.end()) continue;
+        sh += key;
+        sh.push_back('=');
+        sh += lv->second;
+        sh.push_back('\x1e');
+      }
+    }
   }
   const PodTemplate* intern(PodTemplate&& t) {
     prepare(t);
