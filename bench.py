@@ -395,10 +395,12 @@ def allocation_round_leg(pkg, dev, big_pm=None, big_asks=2000):
     finally:
         pm.close()
     if big_pm is not None:
-        # a round of the first `big_asks` asks of the main workload, and the round that moves thousands of nodes:
-        # 20 000 asks of the same workload. The sequential oracle needs minutes for that many at 50 000 nodes, so it checks the first
-        # `big_asks` decisions of both — a prefix of a sequential round depends on nothing behind it
-        out["main_workload_round"], out["main_workload_round_20k"] = device_rounds(big_pm, [big_asks, 20_000], big_asks)
+        # a round of the first `big_asks` asks of the main workload, and the round that moves thousands of nodes: 20 000 asks of the
+        # same workload. EVERY decision of both is checked (the moved-slot scan over thousands of slots lies behind
+        # any short prefix): one run of the sequential oracle over all 20 000 asks, ≈ 40 s on one host core.
+        # BENCH_ROUND_CHECK=<n> bounds the checked prefix (a prefix of a sequential round depends on nothing behind it).
+        out["main_workload_round"], out["main_workload_round_20k"] = device_rounds(
+            big_pm, [big_asks, 20_000], int(os.environ.get("BENCH_ROUND_CHECK", "20000")))
     out["definition"] = ("decisions/sec, conflict-resolved: ask i is decided with asks 0..i-1 of the round assumed on their nodes — identical to the "
                          "oracle run sequentially; `decisions_per_sec` of the line is the SNAPSHOT form (every ask against one state)")
     return out
@@ -480,7 +482,8 @@ def timed_leg(pkg, dev, stream, a, steps, warmup, profile_steps, **kwok):
             # a conflict-resolved round of this workload's first asks (configs[4]: hard spread constraints on a tenth of the
             # templates — the histograms move with every assumed pod, on the device)
             try:
-                out["allocation_round"] = device_rounds(pm, [round_asks], 300)[0]
+                # (the oracle's PreFilter-once loop decides ≈ 30 asks/s at 100 000 nodes with spread constraints: 2 000 checked decisions)
+                out["allocation_round"] = device_rounds(pm, [round_asks], int(os.environ.get("BENCH_ROUND_CHECK_TOPOLOGY", "2000")))[0]
             except Exception as exc:  # noqa: BLE001
                 out["allocation_round"] = {"error": str(exc)}
     finally:

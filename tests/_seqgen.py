@@ -69,3 +69,43 @@ def competing(seed, n_nodes=40, n_pods=120, taints=True, selectors=True, pins=Tr
             spec["nodeName"] = rng.choice(nodes)["metadata"]["name"] if rng.random() < 0.8 else "no-such-node"
         pods.append({"metadata": {"name": f"ask-{k}", "uid": f"ask-{k}", "namespace": "default", "labels": {"app": name}}, "spec": spec})
     return {"nodes": nodes, "pods": pods}
+
+
+def small_slots(seed, n_nodes=3000, n_pods=12000, n_templates=24, spread=False, ports=False):
+    """Thousands of MOVED nodes in one round: nodes with 3 to 6 pod slots and a few cores, asks of a couple of dozen templates in
+    random order — a node takes a handful of asks and is full, so a 12 000-ask round moves well over 2 000 nodes and the scan over
+    the moved-node slots (512 slots per step in k_allocate_round) runs over many steps. `spread`: a third of the templates carry a
+    hard zone constraint on their own label; `ports`: a few templates want a host port (one such pod per node)."""
+    rng = random.Random(seed)
+    zones = [f"z{i}" for i in range(8)]
+    nodes = []
+    for i in range(n_nodes):
+        alloc = {"cpu": rng.choice(["2", "3", "4", "6"]), "memory": rng.choice(["4Gi", "6Gi", "8Gi"]), "pods": rng.choice(["3", "4", "5", "6"])}
+        node = {"metadata": {"name": f"s{rng.randrange(10**7):07d}-{i}", "labels": {"zone": rng.choice(zones), "kubernetes.io/hostname": f"h{i}",
+                                                                                     "pool": rng.choice(["a", "b", "c"])}},
+                "spec": {"taints": [], "unschedulable": rng.random() < 0.01}, "status": {"allocatable": alloc}, "pods": []}
+        if rng.random() < 0.15:
+            node["spec"]["taints"].append({"key": "dedicated", "value": rng.choice(["x", "y"]), "effect": "NoSchedule"})
+        if rng.random() < 0.3:
+            node["pods"].append({"metadata": {"name": f"r{i}", "uid": f"r{i}", "namespace": "default", "labels": {"app": rng.choice(["w", "v"])}},
+                                 "spec": {"containers": [{"name": "c", "resources": {"requests": {"cpu": rng.choice(["100m", "500m", "1"]), "memory": rng.choice(["256Mi", "1Gi"])}}}]}})
+        nodes.append(node)
+    templates = []
+    for t in range(n_templates):
+        req = {"cpu": rng.choice(["100m", "250m", "500m", "750m", "1"]), "memory": rng.choice(["128Mi", "512Mi", "1Gi", "1536Mi"])}
+        spec = {"containers": [{"name": "c", "resources": {"requests": req}}]}
+        if rng.random() < 0.4:
+            spec["tolerations"] = [{"key": "dedicated", "operator": "Equal", "value": rng.choice(["x", "y"]), "effect": "NoSchedule"}]
+        if rng.random() < 0.3:
+            spec["nodeSelector"] = {"pool": rng.choice(["a", "b", "c"])}
+        if spread and t % 3 == 0:
+            spec["topologySpreadConstraints"] = [{"maxSkew": rng.choice([1, 2, 5]), "topologyKey": "zone", "whenUnsatisfiable": "DoNotSchedule",
+                                                  "labelSelector": {"matchLabels": {"app": f"t{t}"}}}]
+        if ports and t % 6 == 1:
+            spec["containers"][0]["ports"] = [{"hostPort": rng.choice([80, 443, 8080]), "containerPort": 80}]
+        templates.append((f"t{t}", spec))
+    pods = []
+    for k in range(n_pods):
+        name, spec = rng.choice(templates)
+        pods.append({"metadata": {"name": f"ask-{k}", "uid": f"ask-{k}", "namespace": "default", "labels": {"app": name}}, "spec": dict(spec)})
+    return {"nodes": nodes, "pods": pods}

@@ -570,6 +570,72 @@ def taint_cases():
     ]]
 
 
+E2E_BINPACK = "test/e2e/bin_packing/bin_packing_test.go"
+
+
+def binpacking_cases():
+    """The reference's ONE behavioural pin of the bin-pack decision order (Verify_BinPacking_Node_Order_Memory,
+    test/e2e/bin_packing/bin_packing_test.go:52-189, queue config `nodesortpolicy: binpacking`, bin_packing_suite_test.go:66-89):
+      1. the worker nodes are sorted by increasing AVAILABLE memory: [nodeA, nodeB, ...]                              (:58-71)
+      2. a padding pod of 20 % of nodeA's available memory (cpu 0m) is placed on nodeA through nodeSelector
+         kubernetes.io/hostname=nodeA, labels node=nodeA; one of 10 % of nodeB's on nodeB                              (:77-110)
+      3. job A: 3 pods without requests and without constraints — ALL land on nodeA (least available memory first)    (:127-139,169-188)
+      4. job B: 3 pods with required pod anti-affinity to {node In [nodeA]} on kubernetes.io/hostname — ALL on nodeB  (:142-188)
+    The e2e reads the numbers off a live kind cluster; a fixture has to choose them. Chosen here: identical allocatable on every
+    worker (kind workers share the host), one system pod per node with equal cpu (kindnet's 100m / 50Mi) and a resident pod whose
+    memory makes the available-memory order strict and different from the NodeID order. The asks are listed in the order the e2e
+    submits them (it waits for each stage to run before the next: sequential assume) — one conflict-resolved round of 8 asks.
+    `expect` = spec.nodeName the e2e asserts, for the padding pods by construction of their nodeSelector."""
+    GI = 1 << 30
+    MI = 1 << 20
+    cases = []
+    for workers, resident_gi, names in [
+        (2, [3, 1], ["kind-worker", "kind-worker2"]),
+        (3, [1, 3, 2], ["kind-worker", "kind-worker2", "kind-worker3"]),            # memory order != NodeID order
+        (5, [2, 0, 4, 1, 3], ["kind-worker", "kind-worker2", "kind-worker3", "kind-worker4", "kind-worker5"]),
+    ]:
+        alloc_mem = 32 * GI
+        nodes, avail = [], {}
+        for name, gi in zip(names, resident_gi):
+            system = [pod({"nodeName": name, "containers": [{"name": "kindnet-cni", "resources": {"requests": {"cpu": "100m", "memory": "50Mi"}}}]},
+                          name=f"kindnet-{name}", uid=f"kindnet-{name}", namespace="kube-system", labels={"app": "kindnet"}),
+                      pod({"nodeName": name, "containers": [{"name": "kube-proxy"}]},
+                          name=f"kube-proxy-{name}", uid=f"kube-proxy-{name}", namespace="kube-system", labels={"k8s-app": "kube-proxy"})]
+            if gi:
+                system.append(pod({"nodeName": name, "containers": [{"name": "resident", "resources": {"requests": {"memory": f"{gi}Gi"}}}]},
+                                  name=f"resident-{name}", uid=f"resident-{name}", namespace="default", labels={"app": "resident"}))
+            nodes.append(node(name, labels={"kubernetes.io/hostname": name, "kubernetes.io/os": "linux"},
+                              alloc={"cpu": "8", "memory": str(alloc_mem), "pods": "110"}, pods=system))
+            avail[name] = alloc_mem - 50 * MI - gi * GI
+        by_avail = sorted(names, key=lambda n: avail[n])                      # :60-66 (strict by construction)
+        node_a, node_b = by_avail[0], by_avail[1]
+        asks, expect = [], []
+        for name, pct in ((node_a, 0.2), (node_b, 0.1)):                      # :77-110
+            padding = int(float(avail[name]) * pct)                           # int64(float64(nodeAvailMem.Value()) * padPct[i])
+            asks.append(pod({"nodeSelector": {"kubernetes.io/hostname": name},
+                             "containers": [{"name": "sleepcontainer", "resources": {"requests": {"cpu": "0m", "memory": str(padding)}}}]},
+                            name=f"{name}-padding", uid=f"{name}-padding", namespace="ns-binpack",
+                            labels={"node": name, "app": "app-padding", "applicationId": f"appid-{name}-padding"}))
+            expect.append(name)
+            avail[name] -= padding
+        after = sorted(names, key=lambda n: avail[n])                         # :113-124: the order the assertions use
+        assert after[:2] == [node_a, node_b]
+        for i in range(3):                                                    # job A :127-139
+            asks.append(pod({"containers": [{"name": "sleepcontainer"}]}, name=f"joba-{i}", uid=f"joba-{i}", namespace="ns-binpack",
+                            labels={"app": "sleep-joba", "applicationId": "appid-joba", "job-name": "joba"}))
+            expect.append(after[0])
+        anti = {"podAntiAffinity": {"requiredDuringSchedulingIgnoredDuringExecution": [
+            {"labelSelector": {"matchExpressions": [{"key": "node", "operator": "In", "values": [after[0]]}]}, "topologyKey": "kubernetes.io/hostname"}]}}
+        for i in range(3):                                                    # job B :142-167
+            asks.append(pod({"containers": [{"name": "sleepcontainer"}], "affinity": anti}, name=f"jobb-{i}", uid=f"jobb-{i}", namespace="ns-binpack",
+                            labels={"app": "sleep-jobb", "applicationId": "appid-jobb", "job-name": "jobb"}))
+            expect.append(after[1])
+        cases.append({"test": "Verify_BinPacking_Node_Order_Memory", "name": f"{workers} workers", "source": f"{E2E_BINPACK}:52-189",
+                      "nodes": nodes, "pods": asks, "expect": expect,
+                      "sorted_by_available_memory_after_padding": after})
+    return cases
+
+
 def main():
     with open(os.path.join(HERE, "taint_cases.json"), "w") as f:
         json.dump(taint_cases(), f, indent=1)
@@ -577,6 +643,8 @@ def main():
         json.dump(predicate_cases(), f, indent=1)
     with open(os.path.join(HERE, "preemption_cases.json"), "w") as f:
         json.dump(preemption_cases(), f, indent=1)
+    with open(os.path.join(HERE, "binpacking_cases.json"), "w") as f:
+        json.dump(binpacking_cases(), f, indent=1)
     req = request_cases()
     with open(os.path.join(HERE, "request_cases.json"), "w") as f:
         json.dump(req, f, indent=1)

@@ -1171,6 +1171,22 @@ def test_full_grid_oracle_parity(pm, n_nodes, n_pods, affinity, gang, spread):
     assert np.array_equal(dec, want_dec[pod_class]), f"{int((dec != want_dec[pod_class]).sum())} of {n_pods} decisions differ from the oracle"
     print(f"full grid {n_pods} x {n_nodes}: {len(rep)} classes x {n_nodes} nodes = {want.size} oracle calls in {t_oracle:.1f} s, "
           f"{int((want_dec >= 0).sum())} classes with a feasible node")
+    if n_pods > 1_000_000 or gang:
+        return
+    # ---- the RESERVATION phase at the same size (predicate_manager.go:321-368: no NodeResourcesFit, NodeUnschedulable first): the
+    # same proof — one representative per class x all nodes on the oracle under the reservation lists, every member row equal to its
+    # class's row — and the counts (this phase was only ever checked on clusters of a few hundred nodes)
+    pm.evaluate(allocate=False)
+    pod_class, rep = pm.pod_classes()
+    assert pm.check_class_rows() == 0
+    o.close()
+    o = orc.Oracle(pm.dump_snapshot(pods=rep, compact=True))
+    want = o.eval_grid(pre_mask=orc.RESERVE_PRE, filt_mask=orc.RESERVE_FILT, threads=os.cpu_count() or 8, prefilter_once=bool(spread))
+    got = unpack(pm.read_rows(rep), n_nodes)
+    assert np.array_equal(got, want), f"reservation phase: {int((got != want).sum())} of {want.size} representative pairs differ from the oracle"
+    assert np.array_equal(pm.read_counts(), want.sum(axis=1)[pod_class])
+    assert want.sum() > 0
+    o.close()
 
 
 @pytest.mark.parametrize("weak", [False, True])

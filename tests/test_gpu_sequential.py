@@ -153,6 +153,49 @@ def test_allocation_round_kwok_cluster(pm):
         assert o.node_info(n) == o2.node_info(n), n
 
 
+@pytest.mark.parametrize("kind", ["resources", "spread", "ports", "spread+ports"])
+def test_allocation_round_moves_thousands_of_nodes(pm, kind):
+    """the part of k_allocate_round that makes long rounds hard — candidate B over THOUSANDS of
+    moved-node slots, 512 slots per step — checked on every decision: 3 000 nodes with 3 to 6 pod slots x 12 000 asks of 24
+    templates in random order, ≈ 2 900 nodes receive a pod (six 512-slot steps), with and without hard spread constraints and
+    host ports. Every decision equals the oracle's sequential loop, on the device, and so does the state the round leaves."""
+    snap = _seqgen.small_slots(7, spread="spread" in kind, ports="ports" in kind)
+    pm.load_snapshot(snap)
+    before = pm.round_stats()
+    o = orc.Oracle(pm.dump_snapshot())
+    want = o.allocate_sequential(prefilter_once=True)
+    got = pm.allocate_round()
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"{len(bad)} decisions differ, first at position {bad[0]}: gpu={got[bad[0]]} oracle={want[bad[0]]}"
+    st = pm.round_stats()
+    assert st["rounds_on_device"] == before["rounds_on_device"] + 1 and st["asks_one_by_one"] == before["asks_one_by_one"]
+    assert len(np.unique(got[got >= 0])) > 2000 and (got >= 0).sum() > 10000
+    pm.evaluate(allocate=True)
+    o2 = orc.Oracle(pm.dump_snapshot())
+    for n in range(o.num_nodes):
+        assert o.node_info(n) == o2.node_info(n), n
+
+
+def _binpacking_cases():
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "binpacking_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _binpacking_cases(), ids=lambda c: c["name"])
+def test_binpacking_e2e_node_order_on_the_device(pm, case):
+    """Verify_BinPacking_Node_Order_Memory (test/e2e/bin_packing/bin_packing_test.go:52-189) through ykhost_allocate_round: the
+    padding pods go where their nodeSelector sends them, job A (no requests) piles onto the node with the least available memory,
+    job B (hostname anti-affinity to the padding pod assumed EARLIER IN THE SAME ROUND) onto the second — on the device."""
+    pm.load_snapshot({"nodes": case["nodes"], "pods": case["pods"]})
+    before = pm.round_stats()
+    names = [n["metadata"]["name"] for n in case["nodes"]]
+    got = pm.allocate_round()
+    assert [names[i] if i >= 0 else None for i in got] == case["expect"], case["source"]
+    st = pm.round_stats()
+    assert st["rounds_on_device"] == before["rounds_on_device"] + 1 and st["asks_one_by_one"] == before["asks_one_by_one"]
+
+
 def test_allocation_round_reference_perf_shape(pm):
     """scheduler_perf_test.go's shape at a tenth of its size (the full 5 000 x 50 000 is bench.py's `allocation_round` leg): the
     asks fill node after node in NodeID order, 110 pods each."""

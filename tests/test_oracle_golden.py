@@ -226,3 +226,22 @@ def test_prefilter_once_form_equals_the_per_pair_form(seed, allocate):
         a, pa = o.eval_grid(pre_mask=pre2, filt_mask=filt2, threads=4, want_plugin=True)
         b, pb = o.eval_grid(pre_mask=pre2, filt_mask=filt2, threads=4, want_plugin=True, prefilter_once=True)
         assert (a == b).all() and (pa == pb).all()
+
+
+@pytest.mark.parametrize("case", load("binpacking_cases.json"), ids=lambda c: c["name"])
+def test_binpacking_node_order(case):
+    """The reference's one behavioural pin of the DECISION ORDER (test/e2e/bin_packing/bin_packing_test.go:52-189, policy
+    `binpacking`): padding pods stabilise the order, job A's three request-less pods all land on the node with the least
+    available memory, job B's three pods — anti-affinity to that node's padding pod on kubernetes.io/hostname — all on the second.
+    The oracle's sequential loop (orc_allocate_sequential: ascending bin-pack score, ties by NodeID, first fit, AssumePod) must
+    place the eight asks exactly there — and must NOT under the reverse ("fair") order, so the pin really holds the direction."""
+    import numpy as np
+    o = orc.Oracle({"nodes": case["nodes"], "pods": case["pods"]})
+    scores = o.binpack_scores()
+    names = [n["metadata"]["name"] for n in case["nodes"]]
+    got = o.allocate_sequential()
+    assert [names[i] if i >= 0 else None for i in got] == case["expect"], case["source"]
+    # the direction: the node the e2e calls nodeA is the one with the LOWEST score before any ask, and a most-available-first
+    # walk would have put job A somewhere else
+    assert names[int(np.argmin(scores))] == case["expect"][0]
+    assert names[int(np.argmax(scores))] != case["expect"][2]
