@@ -38,13 +38,13 @@
 extern "C" {
 #endif
 
-/* (additive since 3, no version bump: ykpred_set_spec_effects + ykpred_spec_effects_t — allocation rounds with topology constraints and
- *    host ports on the device)
+/* 4: ykpred_set_spec_effects + ykpred_spec_effects_t, ykpred_comm_info (round 5 added them without a bump: a host built against the
+ *    header could not tell an older library apart), ykpred_layout_t.sweep_rows / index_rows_walked
  * 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row (the resident
  *    answer served to single Predicates() callbacks), ykpred_eval_nodes is collective on a sharded engine with topology signatures
  * 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
  *    gather / exchange entry points (version 1 = the round-1 ABI: rows in ask order, no collectives) */
-#define YKPRED_ABI_VERSION 3
+#define YKPRED_ABI_VERSION 4
 
 /* status codes */
 #define YKPRED_OK 0
@@ -241,6 +241,9 @@ typedef struct ykpred_layout {
   int32_t index_rows;   /* of plane_rows: request-value rows of many-valued resource dimensions, kept as INDEX rows (one byte per
                            64-node word instead of an 8-byte plane word) */
   int32_t band_steps;   /* band height (windows) the current row layout was built with */
+  int32_t sweep_rows;   /* rows of zone B laid out as RUNS of one signature in ascending order of a many-valued request dimension:
+                           a full pass writes them with k_sweep_rows (a row = its predecessor minus the nodes the larger value loses) */
+  int32_t index_rows_walked; /* of index_rows: the ones a full pass still materialises (k_dim_walk) — the sweep runs read none */
 } ykpred_layout_t;
 
 #define YKPRED_MAX_TIMED_KERNELS 24

@@ -30,7 +30,7 @@ def test_libraries_build_and_export_every_declared_symbol():
     for fn in hnames:
         assert hasattr(host, fn), f"libykhost.so does not export {fn}"
     pred.ykpred_abi_version.restype = ctypes.c_int32
-    assert pred.ykpred_abi_version() == 3
+    assert pred.ykpred_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -328,6 +328,91 @@ def test_unique_request_vectors_midsize(pm):
         assert o.decide(p) == (int(want[p].sum()), int(dec[p]))
 
 
+@pytest.mark.parametrize("n_nodes,n_pods,min_run", [(1500, 5000, 2), (1500, 5000, 16), (4100, 6000, 4), (8300, 4000, 2), (29000, 3000, 3)],
+                         ids=["one-group", "one-group-default-runs", "two-groups-tail", "three-groups", "two-segments"])
+def test_sweep_writer_equals_chunk_writers_and_oracle(monkeypatch, n_nodes, n_pods, min_run):
+    """k_sweep_rows (round 6): zone-B classes of one signature in ascending order of their walked request value are written as a RUN —
+    a lane keeps its word of the row in registers and only clears the nodes the next value loses (cursor lists of k_dim_sort in
+    LDS), no index row is decoded or even written for them. Against the chunk writers (YKPRED_TUNE sweep_min_run=0: k_walk_rows +
+    k_combine_wave, every index row walked) on the same cluster — bitmap, counts, decisions, both phases — and against the oracle:
+    rows of one partial word group up to two LDS segments, short runs forced in (min_run 2), the default threshold."""
+    got = {}
+    for knob in (0, min_run):
+        monkeypatch.setenv("YKPRED_TUNE", f"sweep_min_run={knob}")
+        m = pkg.GpuPredicateManager()
+        try:
+            m.generate_kwok(seed=4711 + n_nodes, num_nodes=n_nodes, num_pods=n_pods, num_templates=0, node_affinity=1, unique_requests=1)
+            m.evaluate()
+            lay = m.layout()
+            assert lay.index_rows >= n_pods - 10
+            if knob:
+                assert lay.sweep_rows > n_pods // 3 and lay.index_rows_walked < lay.index_rows, (lay.sweep_rows, lay.index_rows_walked)
+            else:
+                assert lay.sweep_rows == 0 and lay.index_rows_walked == lay.index_rows
+            assert m.check_class_rows() == 0
+            got[knob] = [unpack(m.read_bitmap(), n_nodes), m.read_counts(), m.read_decisions()]
+            m.evaluate(allocate=False)  # the reservation phase has no request rows: the chunk writers take every class
+            got[knob] += [unpack(m.read_bitmap(), n_nodes), m.read_counts()]
+            m.evaluate()                # ... and the sweep is back for the next allocation pass
+            assert np.array_equal(unpack(m.read_bitmap(), n_nodes), got[knob][0]) and np.array_equal(m.read_counts(), got[knob][1])
+            if knob:
+                o = orc.Oracle(m.dump_snapshot(compact=True))
+                sample = np.arange(n_pods) if n_nodes <= 1500 else np.random.default_rng(5).choice(n_pods, size=64, replace=False).astype(np.int32)
+                want = o.eval_grid(pods=sample, threads=os.cpu_count() or 8)
+                assert np.array_equal(got[knob][0][sample], want)
+                assert np.array_equal(got[knob][1][sample], want.sum(axis=1))
+                for k, p in enumerate(sample[:12]):
+                    assert o.decide(int(p)) == (int(want[k].sum()), int(got[knob][2][p]))
+        finally:
+            m.close()
+    for a, b in zip(got[0], got[min_run]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_sweep_writer_random_clusters_two_walked_dimensions(monkeypatch, seed):
+    """Random edge-case clusters with every request dimension walked (walk_rows=1) and runs from two rows on: two walked dimensions
+    in one request vector (no run: the chunk writers), pinned and duplicated pods, scalar resources, over-committed nodes, zero
+    requests — the whole grid, counts, failing plugins and decisions against the oracle."""
+    monkeypatch.setenv("YKPRED_TUNE", "walk_rows=1,sweep_min_run=2")
+    snap = _gen.random_snapshot(9950 + seed, n_nodes=[64, 130, 333, 700][seed], n_pods=260, scalars=True)
+    m = pkg.GpuPredicateManager()
+    try:
+        m.load_snapshot(snap)
+        check_against_oracle(m, snap, True)
+        check_against_oracle(m, snap, False)
+    finally:
+        m.close()
+
+
+def test_sweep_runs_survive_row_patches(monkeypatch):
+    """An ask of a sweep run that leaves (ykpred_update_pods) invalidates the run's row list: the passes after it fall back to the
+    chunk writers (which know every chunk) until the next class build; new asks, dirty-column patches and a full re-evaluation
+    in between — always the oracle's grid."""
+    monkeypatch.setenv("YKPRED_TUNE", "sweep_min_run=2")
+    m = pkg.GpuPredicateManager()
+    try:
+        m.generate_kwok(seed=99, num_nodes=700, num_pods=1500, num_templates=0, node_affinity=1, unique_requests=1)
+        m.evaluate()
+        assert m.layout().sweep_rows > 500
+        snap = json.loads(m.dump_snapshot())
+        uids = [p["metadata"]["uid"] for p in snap["pods"]]
+        for uid in uids[10:400:13]:
+            m.remove_pod(uid)
+        m.evaluate_dirty()
+        o = orc.Oracle(m.dump_snapshot())
+        assert m.layout().sweep_rows == 0  # (the row lists are stale: no sweep until the classes are built again)
+        assert np.array_equal(unpack(m.read_bitmap(), 700), o.eval_grid(threads=8))
+        m.evaluate()
+        lay = m.layout()
+        o = orc.Oracle(m.dump_snapshot())
+        want = o.eval_grid(threads=8)
+        assert lay.num_pods == o.num_pods and np.array_equal(unpack(m.read_bitmap(), 700), want)
+        assert np.array_equal(m.read_counts(), want.sum(axis=1))
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("plugins", [["NodeResourcesFit"], ["TaintToleration", "NodeUnschedulable"], ["NodeAffinity"], ["NodeName"], []])
 def test_random_clusters_plugin_subsets(plugins):
     snap = _gen.random_snapshot(77, n_nodes=130, n_pods=80)

@@ -42,7 +42,8 @@ class YkpredLayout(C.Structure):
                 ("bitmap_bytes", C.c_uint64), ("bitmap", C.c_void_p), ("counts", C.c_void_p), ("decisions", C.c_void_p),
                 ("decision_keys", C.c_void_p), ("spread_counts", C.c_void_p), ("spread_present", C.c_void_p),
                 ("spread_cells", C.c_int64), ("num_rows", C.c_int32), ("band_rows", C.c_int32), ("row_of_pod", C.c_void_p),
-                ("index_rows", C.c_int32), ("band_steps", C.c_int32)]
+                ("index_rows", C.c_int32), ("band_steps", C.c_int32),
+                ("sweep_rows", C.c_int32), ("index_rows_walked", C.c_int32)]
 
 
 MAX_TIMED = 24

@@ -61,7 +61,8 @@ def _stale(target, deps):
 def build_engine(force=False, verbose=False):
     with _build_lock():
         if force or _stale(LIBYKPRED, ENGINE_DEPS):
-            _compile([HIPCC] + HIPFLAGS + [ENGINE_SRC, "-o", LIBYKPRED], LIBYKPRED, verbose)
+            # (YKPRED_EXTRA_HIPFLAGS: compile-time knobs of kernel experiments, e.g. -DYK_SWEEP_BATCH=4 — scripts/r06_*.sh)
+            _compile([HIPCC] + HIPFLAGS + os.environ.get("YKPRED_EXTRA_HIPFLAGS", "").split() + [ENGINE_SRC, "-o", LIBYKPRED], LIBYKPRED, verbose)
     return LIBYKPRED
 
 

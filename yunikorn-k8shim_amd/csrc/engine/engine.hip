@@ -257,6 +257,25 @@ struct ykpred_engine {
   int n_big = 0, walk_chunks = 0, index_rows = 0;
   int NCB = 0;                      // zone-B chunks (d_chunk_list_b)
   DevBuf d_big_dim, d_walk_big, d_walk_begin, d_walk_len, d_sfree_c, d_pmask_c, d_sfree_r, d_pmask_r, d_rbits_c;
+  // Sweep runs (k_sweep_rows): zone-B classes of one (toleration, affinity, spread, staged plane row) signature in ascending order of
+  // their walked value. set_specs keeps what build_classes needs to find them: the request-vector table, every value row's position
+  // in its dimension's sorted order, the sorted values themselves (device: k_dim_sort turns free values into positions).
+  std::vector<int32_t> h_res_rows;   // [vectors][1 + R] as uploaded (index rows tagged with their walked dimension)
+  std::vector<int32_t> h_row_pos;    // [rows] position in the walked dimension's ascending value order, -1: not a walked row
+  std::vector<int32_t> h_row_big;    // [rows] its walked dimension (index into big_dim), -1
+  std::vector<int32_t> h_sorted_off; // [n_big + 1]
+  DevBuf d_sorted, d_sorted_off, d_ent_c;  // sorted values; cursor lists [n_big][65][row_words] (k_dim_sort, canonical order)
+  int sweep_min_run = 1;             // tunable (YKPRED_TUNE sweep_min_run): runs shorter than this stay with k_walk_rows; 0 = no sweep
+  int sweep_groups = 0;              // tunable (sweep_groups): persistent workgroups per segment; 0 = one per compute unit
+  bool sweep_ready = false;          // the current class build has sweep rows and nothing has touched their classes since
+  std::vector<int32_t> h_class_sweep;  // [C] 1 = the class is a row of a sweep run
+  int sweep_rows[ykk::kMaxIdxRows] = {0, 0}, sweep_row_off[ykk::kMaxIdxRows + 1] = {0, 0, 0}, sweep_runs = 0;  // per walked dimension
+  int index_rows_needed = 0;         // index rows some class OUTSIDE the sweep runs reads (the full pass walks only those)
+  DevBuf d_sweep_rows, d_sweep_runs; // SweepRow {class, bitmap row, position, run}; SweepRun
+  DevBuf d_chunk_list_b0;            // [NCB0] the zone-B chunks outside the sweep runs (a pass with the sweep runs the chunk writers over these)
+  int NCB0 = 0;
+  DevBuf d_walk2_order, d_walk2_big, d_walk2_begin, d_walk2_len;  // walk chunks over the needed index rows only
+  int walk2_chunks = -1;             // -1: no reduced walk (every index row is walked)
   DevBuf d_first_r;         // rank-ordered planes: first non-zero word per plane row (k_decide's starting point)
   static constexpr bool decide_skip = true;  // k_decide starts a class's scan where its rows can first have a bit
   DevBuf d_chunk_list_b;    // [NCB] numbers of the zone-B chunks (ascending)
@@ -297,6 +316,7 @@ struct ykpred_engine {
   int decide_groups_from = 16384;   // decide_groups_from: classes from which k_decide serves four classes per wave
   int early_counts = 1;             // early_counts: 0 = class counts by the writers and the per-ask scatter behind them (the round-4 order)
   int max_lds_bytes = 64 * 1024;   // opt-in dynamic LDS limit of the device (hipDeviceAttributeMaxSharedMemoryPerBlock)
+  int num_cus = 256;               // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int n_bands = 0, n_band_steps = 0, n_classes_a = 0, n_fix_rows = 0;
   std::vector<int32_t> h_class_slot_a;  // [C] index into the class-row table, -1 = zone B class
   DevBuf d_band_tab, d_class_rows_a, d_class_list_a, d_class_slot_a, d_fix_row, d_fix_slot, d_chunk_zone;
@@ -707,23 +727,162 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   // zone B: the remaining classes, class by class after zone A — in the order of their SIGNATURES (node-affinity signature
   // first: the family with the most planes), so that the chunk kernel's neighbouring workgroups AND the same plane rows at the
   // same time and find them in L2 instead of fetching 6 KB rows from the far cache or HBM once per class
+  // SWEEP RUNS (k_sweep_rows). A single-member, unpinned zone-B class whose request vector is the pod-independent row, at most one
+  // staged ballot row and exactly ONE index row differs from the classes of the same (affinity, toleration, spread, ballot row)
+  // only in the VALUE of its walked dimension. Inside such a group the classes are laid out in ascending order of that value:
+  // a run. Runs of at least sweep_min_run rows are written by k_sweep_rows, which keeps a row's words in registers and only
+  // clears the bits of the nodes the next value loses; everything else stays with the class-by-class writers.
   int next_row = rows_a;
+  e->h_class_sweep.assign((size_t)C, 0);
+  e->sweep_ready = false;
+  e->sweep_runs = 0;
+  e->walk2_chunks = -1;
+  e->index_rows_needed = e->index_rows;
+  for (int b = 0; b < ykk::kMaxIdxRows; ++b) e->sweep_rows[b] = 0;
   {
     std::vector<int32_t> order_b;
     for (int c = 0; c < C; ++c)
       if (e->h_class_slot_a[(size_t)c] < 0) order_b.push_back(c);
     auto key = [&](int32_t c, int f) { return class_sig[(size_t)c * 4 + (size_t)f]; };
+    const int R1 = 1 + e->R, big_mask = (1 << ykk::kRowBigShift) - 1;
+    bool sweep_possible = e->sweep_min_run > 0 && e->n_big > 0 && !e->h_res_rows.empty() && (int)e->h_sorted_off.size() == e->n_big + 1;
+    for (int b = 0; sweep_possible && b < e->n_big; ++b)
+      sweep_possible = e->h_sorted_off[(size_t)b + 1] - e->h_sorted_off[(size_t)b] < (1 << 26);  // (a position and a node share 32 bits)
+    // candidate classes: the walked dimension, the second ballot row, the position of the value (slot < 0: not a candidate)
+    std::vector<int32_t> cand_big, cand_slot, cand_pos;
+    if (sweep_possible) {
+      cand_big.assign((size_t)C, -1);
+      cand_slot.assign((size_t)C, -1);
+      cand_pos.assign((size_t)C, -1);
+      for (int32_t c : order_b) {
+        const int sr = key(c, 0);
+        if (class_size[(size_t)c] != 1 || class_pin[(size_t)c] != -1 || sr < 0 || (size_t)(sr + 1) * (size_t)R1 > e->h_res_rows.size()) continue;
+        const int32_t* rr = e->h_res_rows.data() + (size_t)sr * (size_t)R1;
+        int np = 0, ni = 0, prow = -1, irow = -1;
+        for (int k = 0; k < R1; ++k) {
+          const int r = rr[k];
+          if (r < 0) continue;
+          if (r >> ykk::kRowBigShift) {
+            if (ni == 0) irow = r;
+            ++ni;
+          } else {
+            if (np == 1) prow = r;
+            ++np;
+          }
+        }
+        if (ni != 1 || np < 1 || np > 2) continue;
+        const int slot = np == 2 ? prow : 0;  // the second ballot row of the request family (0: none — row 0 is in every class)
+        const int pos = e->h_row_pos[(size_t)(irow & big_mask)];
+        if (pos < 0) continue;
+        cand_big[(size_t)c] = (irow >> ykk::kRowBigShift) - 1;
+        cand_slot[(size_t)c] = slot;
+        cand_pos[(size_t)c] = pos;
+      }
+    }
+    auto is_cand = [&](int32_t c) { return sweep_possible && cand_slot[(size_t)c] >= 0; };
     std::sort(order_b.begin(), order_b.end(), [&](int32_t x, int32_t y) {
       if (key(x, 2) != key(y, 2)) return key(x, 2) < key(y, 2);  // aff
       if (key(x, 1) != key(y, 1)) return key(x, 1) < key(y, 1);  // tol
       if (key(x, 3) != key(y, 3)) return key(x, 3) < key(y, 3);  // spread
+      const bool cx = is_cand(x), cy = is_cand(y);
+      if (cx != cy) return cy;                                     // the others first, by request vector as before
+      if (cx) {
+        if (cand_big[(size_t)x] != cand_big[(size_t)y]) return cand_big[(size_t)x] < cand_big[(size_t)y];
+        if (cand_slot[(size_t)x] != cand_slot[(size_t)y]) return cand_slot[(size_t)x] < cand_slot[(size_t)y];
+        if (cand_pos[(size_t)x] != cand_pos[(size_t)y]) return cand_pos[(size_t)x] < cand_pos[(size_t)y];
+        return x < y;
+      }
       if (key(x, 0) != key(y, 0)) return key(x, 0) < key(y, 0);  // request vector
       return x < y;
     });
-    for (int32_t c : order_b)
+    std::vector<int32_t> first_row_of((size_t)C, -1);
+    for (int32_t c : order_b) {
+      first_row_of[(size_t)c] = next_row;
       for (int i = class_off[(size_t)c]; i < class_off[(size_t)c + 1]; ++i) e->h_pod_row[(size_t)members[(size_t)i]] = next_row++;
+    }
     e->n_classes_b = (int)order_b.size();
     TRY(upload(e, e->d_class_list_b, order_b.data(), order_b.size(), st));
+    if (sweep_possible) {
+      std::vector<int32_t> rows_of[ykk::kMaxIdxRows];  // flattened int4 {class, bitmap row, position, run}
+      std::vector<ykk::SweepRun> runs;
+      for (size_t i = 0; i < order_b.size();) {
+        const int32_t c = order_b[i];
+        if (!is_cand(c)) {
+          ++i;
+          continue;
+        }
+        size_t j = i + 1;
+        while (j < order_b.size() && is_cand(order_b[j]) && key(order_b[j], 2) == key(c, 2) && key(order_b[j], 1) == key(c, 1) &&
+               key(order_b[j], 3) == key(c, 3) && cand_big[(size_t)order_b[j]] == cand_big[(size_t)c] &&
+               cand_slot[(size_t)order_b[j]] == cand_slot[(size_t)c])
+          ++j;
+        if ((int)(j - i) >= e->sweep_min_run) {
+          const int big = cand_big[(size_t)c];
+          ykk::SweepRun run{};
+          run.st = key(c, 1), run.sa = key(c, 2), run.ss = key(c, 3), run.prow = cand_slot[(size_t)c];
+          const int32_t id = (int32_t)runs.size();
+          runs.push_back(run);
+          for (size_t k = i; k < j; ++k) {
+            const int32_t m = order_b[k];
+            e->h_class_sweep[(size_t)m] = 1;
+            rows_of[big].insert(rows_of[big].end(), {m, first_row_of[(size_t)m], cand_pos[(size_t)m], id});
+          }
+        }
+        i = j;
+      }
+      e->sweep_runs = (int)runs.size();
+      std::vector<int32_t> all_rows;
+      e->sweep_row_off[0] = 0;
+      for (int b = 0; b < ykk::kMaxIdxRows; ++b) {
+        e->sweep_rows[b] = (int)(rows_of[b].size() / 4);
+        all_rows.insert(all_rows.end(), rows_of[b].begin(), rows_of[b].end());
+        e->sweep_row_off[b + 1] = e->sweep_row_off[b] + e->sweep_rows[b];
+      }
+      if (!runs.empty()) {
+        TRY(upload(e, e->d_sweep_rows, all_rows.data(), all_rows.size(), st));
+        TRY(upload(e, e->d_sweep_runs, runs.data(), runs.size(), st));
+        e->sweep_ready = true;
+        // The index rows somebody OUTSIDE the runs still reads (zone-A classes, short runs, shapes without a fast path): the full
+        // pass walks only those (k_dim_walk over the reduced chunk lists below); a dirty-class pass walks them all.
+        const int n_rows = (int)e->h_row_pos.size();
+        std::vector<uint8_t> needed((size_t)n_rows, 0);
+        for (int c = 0; c < C; ++c) {
+          const int sr = key(c, 0);
+          if (e->h_class_sweep[(size_t)c] || sr < 0 || (size_t)(sr + 1) * (size_t)R1 > e->h_res_rows.size()) continue;
+          for (int k = 0; k < R1; ++k) {
+            const int r = e->h_res_rows[(size_t)sr * (size_t)R1 + (size_t)k];
+            if (r > 0 && (r >> ykk::kRowBigShift)) needed[(size_t)(r & big_mask)] = 1;
+          }
+        }
+        // in ascending value order per walked dimension: bucket by position
+        std::vector<int32_t> order2, wbig2, wbegin2, wlen2;
+        for (int b = 0; b < e->n_big; ++b) {
+          const int cnt = e->h_sorted_off[(size_t)b + 1] - e->h_sorted_off[(size_t)b];
+          std::vector<int32_t> at_pos((size_t)cnt, -1);
+          for (int r = 0; r < n_rows; ++r)
+            if (needed[(size_t)r] && e->h_row_pos[(size_t)r] >= 0 && e->h_row_big[(size_t)r] == b) at_pos[(size_t)e->h_row_pos[(size_t)r]] = r;
+          const int begin = (int)order2.size();
+          for (int32_t r : at_pos)
+            if (r >= 0) order2.push_back(r);
+          // (few rows: short chunks — a chunk is one thread's sequential walk, and a handful of 512-row chunks is a handful of
+          // workgroups walking for a quarter of a millisecond)
+          const int left = (int)order2.size() - begin;
+          const int clen = std::min(ykk::kWalkRows, std::max(16, left / 1024));
+          for (int q = begin; q < (int)order2.size(); q += clen) {
+            wbig2.push_back(b);
+            wbegin2.push_back(q);
+            wlen2.push_back(std::min(clen, (int)order2.size() - q));
+          }
+        }
+        e->index_rows_needed = (int)order2.size();
+        e->walk2_chunks = (int)wbig2.size();
+        order2.push_back(0);
+        TRY(upload(e, e->d_walk2_order, order2.data(), order2.size(), st));
+        TRY(upload(e, e->d_walk2_big, wbig2.data(), wbig2.size(), st));
+        TRY(upload(e, e->d_walk2_begin, wbegin2.data(), wbegin2.size(), st));
+        TRY(upload(e, e->d_walk2_len, wlen2.data(), wlen2.size(), st));
+      }
+    }
   }
   e->rows_total = next_row;
   e->rows_a = rows_a;
@@ -758,13 +917,20 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     ch_begin.push_back(k.begin);
     ch_len.push_back(k.len);
     ch_first.push_back(k.first);
-    e->h_ch_zone.push_back(e->h_class_slot_a[(size_t)k.cls] >= 0 ? 1 : 0);
+    e->h_ch_zone.push_back(e->h_class_slot_a[(size_t)k.cls] >= 0 ? 1 : (e->h_class_sweep[(size_t)k.cls] ? 2 : 0));
   }
   // the zone-B chunks by number: the full pass launches the class-by-class writer over this list only
   std::vector<int32_t> chunk_list_b;
   for (size_t k = 0; k < e->h_ch_zone.size(); ++k)
-    if (!e->h_ch_zone[k]) chunk_list_b.push_back((int32_t)k);
+    if (e->h_ch_zone[k] != 1) chunk_list_b.push_back((int32_t)k);  // (the chunks of sweep runs too: a pass without the sweep writes them here)
   e->NCB = (int)chunk_list_b.size();
+  {
+    std::vector<int32_t> chunk_list_b0;
+    for (size_t k = 0; k < e->h_ch_zone.size(); ++k)
+      if (e->h_ch_zone[k] == 0) chunk_list_b0.push_back((int32_t)k);
+    e->NCB0 = (int)chunk_list_b0.size();
+    TRY(upload(e, e->d_chunk_list_b0, chunk_list_b0.data(), chunk_list_b0.size(), st));
+  }
   e->h_class_first.assign((size_t)C, -1);
   for (int c = 0; c < C; ++c) e->h_class_first[(size_t)c] = members[(size_t)class_off[(size_t)c]];
   std::vector<int32_t> member_rows((size_t)P);
@@ -1156,6 +1322,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   {
     int lds = 0;  // what a workgroup may ask for with hipFuncAttributeMaxDynamicSharedMemorySize (64 KiB on gfx90a / gfx942, 160 KiB on gfx950)
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && lds > 0) e->max_lds_bytes = lds;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) e->num_cus = cus;
   }
   // YKPRED_TUNE="key=value,key=value": the ONE environment hook for engine tunables — what the tests use to force a path (index rows
   // on tiny clusters, a k_sig_planes width, the sub-wave decision kernel ...). Unknown keys are an error, not ignored.
@@ -1184,6 +1352,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "wave_combine_below") e->wave_combine_below = std::max(val, 0);
       else if (key == "fail_after") e->fail_after = std::max(val, 0);
       else if (key == "round_prof") e->round_prof = val;
+      else if (key == "sweep_min_run") e->sweep_min_run = std::max(val, 0);
+      else if (key == "sweep_groups") e->sweep_groups = std::max(val, 0);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
         delete e;
@@ -1232,7 +1402,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -1635,6 +1805,27 @@ int32_t ykpred_set_specs(ykpred_engine_t* e, const ykpred_specs_t* s) {
     }
     e->index_rows = 0;
     for (int32_t len : wlen) e->index_rows += len;
+    // what the sweep runs are built from (build_classes) and what k_dim_sort needs to turn a free value into a position
+    e->h_res_rows = res_rows;
+    e->h_row_pos.assign((size_t)rows, -1);
+    e->h_row_big.assign((size_t)rows, -1);
+    e->sweep_ready = false;  // (positions move with every new value: the runs are rebuilt with the classes)
+    e->h_sorted_off.assign(1, 0);
+    {
+      std::vector<i64> sorted;
+      for (size_t b = 0; b < big_dim.size(); ++b) {
+        const int g = big_dim[b] + 1, b0 = start[(size_t)g], b1 = start[(size_t)g + 1];
+        for (int i = b0; i < b1; ++i) {
+          e->h_row_pos[(size_t)order[(size_t)i]] = i - b0;
+          e->h_row_big[(size_t)order[(size_t)i]] = (int32_t)b;
+          sorted.push_back(e->h_dim_val[(size_t)order[(size_t)i]]);
+        }
+        e->h_sorted_off.push_back((int32_t)sorted.size());
+      }
+      sorted.push_back(0);  // (never empty)
+      TRY(upload(e, e->d_sorted, sorted.data(), sorted.size(), st));
+      TRY(upload(e, e->d_sorted_off, e->h_sorted_off.data(), e->h_sorted_off.size(), st));
+    }
     e->h_stage_rows.clear();
     {
       std::vector<uint8_t> walked((size_t)R, 0);
@@ -1756,6 +1947,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     for (DevBuf* b : {&e->d_sfree_c, &e->d_sfree_r}) HIPCHK(b->ensure(cells * 64 * sizeof(i64)));
     for (DevBuf* b : {&e->d_pmask_c, &e->d_pmask_r}) HIPCHK(b->ensure(cells * 65 * sizeof(u64)));
     HIPCHK(e->d_rbits_c.ensure(cells * ykk::kRankBits * sizeof(u64)));
+    HIPCHK(e->d_ent_c.ensure(cells * 65 * sizeof(unsigned)));
     // (a forced row stride — unequal shards — may exceed the rounded row length: consumers address index bytes by row word)
     const int idx_stride_before = e->idx_stride;
     e->idx_stride = (std::max(e->row_words, e->row_stride) + 63) / 64 * 64;
@@ -1824,8 +2016,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   ykk::PlaneOut o_tol{canon_of(e->fam_tol), ranked_of(e->fam_tol), e->row_stride, e->fam_tol.D, nullptr};
   ykk::PlaneOut o_aff{canon_of(e->fam_aff), ranked_of(e->fam_aff), e->row_stride, e->fam_aff.D, nullptr};
   ykk::PlaneOut o_spread{canon_of(e->fam_spread), ranked_of(e->fam_spread), e->row_stride, e->fam_spread.D, nullptr};
+  // k_sweep_rows takes the sweep runs of a FULL pass with NodeResourcesFit evaluated (the reservation phase has no request rows: every
+  // class of a signature shares one row and the chunk writers do it); a dirty-class pass, a pass without PreFilter state for the
+  // Filter, a class build whose runs were touched since — all fall back to the chunk writers, which know every chunk.
+  const bool use_sweep = e->sweep_ready && e->sweep_runs > 0 && res_on && !fit_error && e->n_big > 0 &&
+                         !(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES));
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), use_sweep ? 1 : 0};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
                  nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1959,11 +2156,26 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       const bool ranked = perm != nullptr;
       ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
                       e->d_walk_len.as<int>(), (ranked ? e->d_sfree_r : e->d_sfree_c).as<i64>(), (ranked ? e->d_pmask_r : e->d_pmask_c).as<u64>(),
-                      e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>()};
+                      e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>(),
+                      (!ranked && use_sweep) ? e->d_ent_c.as<unsigned>() : nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>()};
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
-      const dim3 walk_grid((unsigned)e->walk_chunks, (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords)));
-      if (!ranked) {
+      tm.end(s, ranked ? "k_dim_sort(ranked)" : "k_dim_sort");
+      tm.begin(s);
+      const unsigned walk_gy = (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords));
+      const dim3 walk_grid((unsigned)e->walk_chunks, walk_gy);
+      if (!ranked && use_sweep && e->walk2_chunks >= 0) {
+        // the sweep runs read no index row: only the rows somebody else decodes are walked (build_classes)
+        if (e->walk2_chunks > 0) {
+          ykk::DimWalk dw2 = dw;
+          dw2.order = e->d_walk2_order.as<int>();
+          dw2.chunk_big = e->d_walk2_big.as<int>();
+          dw2.chunk_begin = e->d_walk2_begin.as<int>();
+          dw2.chunk_len = e->d_walk2_len.as<int>();
+          dw2.n_chunks = e->walk2_chunks;
+          hipLaunchKernelGGL(ykk::k_dim_walk, dim3((unsigned)e->walk2_chunks, walk_gy), dim3(ykk::kBlock), 0, s, dw2, e->d_idx_c.as<unsigned char>(), e->idx_stride);
+        }
+      } else if (!ranked) {
         hipLaunchKernelGGL(ykk::k_dim_walk, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_idx_c.as<unsigned char>(), e->idx_stride);
       } else {
         // running maximum of the free values along the bin-pack order: where a value's row can start (k_decide) — and the window
@@ -2038,8 +2250,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     // the full pass runs the class-by-class writer over the zone-B chunks only (the dirty-class pass over every chunk)
     // (chunks appended by ykpred_update_pods since the class build are not in the list: then every chunk runs, as the dirty pass does)
     const bool listed = !dirty_only && e->patch_chunks == 0;
-    const int* chunk_list = listed ? e->d_chunk_list_b.as<int>() : nullptr;
-    const int n_run = listed ? e->NCB : e->NC;
+    const int* chunk_list = listed ? (use_sweep ? e->d_chunk_list_b0 : e->d_chunk_list_b).as<int>() : nullptr;
+    const int n_run = listed ? (use_sweep ? e->NCB0 : e->NCB) : e->NC;
     dim3 grid((unsigned)std::max(n_run, 1), (unsigned)((e->row_stride + seg - 1) / seg));
     // Both writers run on the launch stream, the band writer first. (Measured in round 3, profiles/r03_writer_knobs.txt: the
     // class-by-class writer BESIDE the band writer on a third stream upsets the one-workgroup-per-CU placement the band writer
@@ -2075,6 +2287,44 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
       tm.end(st, "k_expand_bands");
     }
+    if (use_sweep) {
+      // the sweep runs: one launch per walked dimension, the row's segments in grid.y (whole 64-word groups, at most kWalkMaxIt per
+      // lane, what the LDS holds — 65 list dwords per word), one persistent workgroup per compute unit and segment claiming batches of rows
+      const int its = (e->row_stride + ykk::kWave - 1) / ykk::kWave;
+      int segs = (its + ykk::kWalkMaxIt - 1) / ykk::kWalkMaxIt, nit = (its + segs - 1) / segs;
+      while (nit > 1 && ykk::sweep_lds_bytes(nit) > (size_t)e->max_lds_bytes) {
+        ++segs;
+        nit = (its + segs - 1) / segs;
+      }
+      const int n_long = segs - (nit * segs - its);
+      tm.begin(sz);
+      for (int b = 0; b < e->n_big; ++b) {
+        const int n_rows = e->sweep_rows[b];
+        if (n_rows == 0) continue;
+        const int batches = (n_rows + ykk::kSweepBatch - 1) / ykk::kSweepBatch;
+        const int groups = std::max(1, std::min(e->sweep_groups > 0 ? e->sweep_groups : e->num_cus, (batches + ykk::kSweepWaves - 1) / ykk::kSweepWaves));
+        auto launch_sweep = [&](auto kernel) -> int {
+          const size_t lds = ykk::sweep_lds_bytes(nit);
+          if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(kernel, dim3((unsigned)groups, (unsigned)segs), dim3(ykk::kSweepThreads), lds, sz, pc,
+                             e->d_ent_c.as<unsigned>() + (size_t)b * 65 * (size_t)e->row_words, e->d_pmask_c.as<u64>() + (size_t)b * (size_t)e->row_words * 65,
+                             e->d_sweep_rows.as<ykk::SweepRow>() + e->sweep_row_off[b], e->d_sweep_runs.as<ykk::SweepRun>(), n_rows,
+                             bitmap, e->row_words, e->row_stride, pin_on,
+                             e->d_class_count.as<int>(), n_long);
+          return YKPRED_OK;
+        };
+        switch (nit) {
+          case 1: TRY(launch_sweep(ykk::k_sweep_rows<1>)); break;
+          case 2: TRY(launch_sweep(ykk::k_sweep_rows<2>)); break;
+          case 3: TRY(launch_sweep(ykk::k_sweep_rows<3>)); break;
+          case 4: TRY(launch_sweep(ykk::k_sweep_rows<4>)); break;
+          case 5: TRY(launch_sweep(ykk::k_sweep_rows<5>)); break;
+          case 6: TRY(launch_sweep(ykk::k_sweep_rows<6>)); break;
+          default: TRY(launch_sweep(ykk::k_sweep_rows<7>)); break;
+        }
+      }
+      tm.end(sz, "k_sweep_rows");
+    }
     tm.begin(sz);
     // Index rows to decode: k_walk_rows — a wave writes whole rows, the rank planes of the walked dimensions (56 bytes per word) staged
     // in LDS per workgroup; rows wider than kWalkMaxIt x 64 words go segment by segment (grid.y). Only where the device grants the LDS.
@@ -2085,7 +2335,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     ykk::WalkStage wstage{};
     wstage.n = (int)e->h_stage_rows.size();
     for (int k = 0; k < wstage.n; ++k) wstage.row[k] = e->h_stage_rows[(size_t)k];
-    bool slices = small_chunks && e->combine_slices != 0 && pc.n_big > 0 && pc.res != nullptr;
+    // (with every run swept — sweep_min_run 1 — no chunk is left that k_walk_rows has a fast path for: what remains goes through the
+    // listed chunk writers below, without the descriptor pass over all chunks)
+    bool slices = small_chunks && e->combine_slices != 0 && pc.n_big > 0 && pc.res != nullptr && !(use_sweep && e->sweep_min_run <= 1 && listed);
     if (slices) {
       const int its = (e->row_stride + ykk::kWave - 1) / ykk::kWave;
       const size_t lds_cap = std::min((size_t)e->max_lds_bytes, (size_t)80 * 1024);
@@ -2426,6 +2678,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     const int c = e->h_pod_class[(size_t)p], slot = e->h_pod_slot[(size_t)p];
     e->h_members[(size_t)slot] = -1;
     put(T_MEMBERS, slot, -1);
+    if ((size_t)c < e->h_class_sweep.size() && e->h_class_sweep[(size_t)c]) e->sweep_ready = false;  // (its row list names a row that is gone: the chunk writers take the runs until the next class build)
     e->h_class_live[(size_t)c]--;
     if (e->h_class_first[(size_t)c] == p) {
       e->h_class_first[(size_t)c] = -1;
@@ -2781,7 +3034,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   nt.count = (const int*)(base + o_cnt);
   if (live_ports) nt.ports = (const u64*)(base + o_ports);
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), 0};
   const bool spread_err = ((filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) && !(pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) ||
                           ((filt & YKPRED_PLUGIN_INTER_POD_AFFINITY) && !(pre & YKPRED_PLUGIN_INTER_POD_AFFINITY)) ||
                           ((filt & YKPRED_PLUGIN_NODE_PORTS) && !(pre & YKPRED_PLUGIN_NODE_PORTS));
@@ -3021,6 +3274,8 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->row_of_pod = e->d_pod_row.p;
   o->index_rows = e->index_rows;
   o->band_steps = e->band_steps_now;
+  o->sweep_rows = e->sweep_ready ? e->sweep_row_off[ykk::kMaxIdxRows] : 0;
+  o->index_rows_walked = (e->sweep_ready && e->walk2_chunks >= 0) ? e->index_rows_needed : e->index_rows;
   o->bitmap_bytes = (uint64_t)std::max(o->num_rows, 1) * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
   o->counts = e->last_counts ? e->last_counts : e->d_counts.p;
@@ -3566,7 +3821,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   }
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>()};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), 0};
   ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));

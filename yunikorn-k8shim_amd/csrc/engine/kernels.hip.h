@@ -325,6 +325,11 @@ struct DimWalk {
   u64* pmask;              // [n_big][n_words][65]
   int n_big, n_chunks, n_words;
   u64* rbits;              // [n_big][kRankBits][n_words] the same sets bit-sliced (k_walk_rows): pmask[j] = { node : r' > j }; null = not kept
+  // cursor lists of k_sweep_rows (null = not kept): ent[(big * 65 + j) * n_words + word] = (g << 6) | node position, for the j-th
+  // smallest free value f of the word, g = how many of the dimension's sorted request values are <= f; row 64 = 0xffffffff
+  unsigned* ent;
+  const i64* sorted;       // the walked dimensions' request values, ascending, dimension after dimension
+  const int* sorted_off;   // [n_big + 1] into `sorted`
 };
 // blockIdx.x: walked dimension, blockIdx.y: group of 4 words; wave = word, lane = node position
 __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __restrict__ perm, DimWalk a) {
@@ -358,6 +363,17 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
       if (k == lane) plane = b;
     }
     if (lane < kRankBits) a.rbits[((size_t)blockIdx.x * kRankBits + lane) * a.n_words + word] = plane;
+  }
+  if (a.ent) {
+    const i64* sv = a.sorted + a.sorted_off[blockIdx.x];
+    int lo = 0, hi = a.sorted_off[blockIdx.x + 1] - a.sorted_off[blockIdx.x];  // upper bound: values [0, lo) are <= fr
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (sv[mid] <= fr) lo = mid + 1; else hi = mid;
+    }
+    unsigned* col = a.ent + (size_t)blockIdx.x * 65 * a.n_words + word;
+    col[(size_t)rank * a.n_words] = ((unsigned)lo << 6) | (unsigned)lane;
+    if (lane == 0) col[(size_t)64 * a.n_words] = 0xffffffffu;
   }
 }
 // blockIdx.x: walk chunk, blockIdx.y: block of 256 * kWalkWords words; thread = kWalkWords ADJACENT words.
@@ -1095,8 +1111,15 @@ struct ClassTable {
   const int* chunk_len;    // [NC] 1..kChunkMembers
   const int* chunk_first;  // [NC] 1 = first chunk of its class (owns the popcount)
   const int* members;      // chunk row lists: PHYSICAL bitmap rows (ykpred_layout_t.row_of_pod), -1 = unused entry
-  const int* chunk_zone;   // [NC] 1 = the chunk's class lives in zone A (the full pass writes it with k_expand_bands)
+  const int* chunk_zone;   // [NC] 1 = the chunk's class lives in zone A (the full pass writes it with k_expand_bands); 2 = zone B,
+                           // a class of a sweep run: written by k_sweep_rows in the full passes that run it (sweep_on), else like zone B
+  int sweep_on;
 };
+// full pass: is the chunk left to another writer (the band writer, k_sweep_rows)?
+__device__ __forceinline__ bool chunk_elsewhere(const ClassTable& ct, int chunk) {
+  const int z = ct.chunk_zone[chunk];
+  return z == 1 || (z == 2 && ct.sweep_on);
+}
 struct Planes {
   const u64* res;         // value planes of NodeResourcesFit (row 0 = pod-independent part); null = family disabled
   const u64* tol;
@@ -1282,7 +1305,7 @@ __global__ __launch_bounds__(kBlock) void k_combine(ClassTable ct, Planes pl, u6
   pin_enabled &= 1;
   const int chunk = chunk_list ? chunk_list[blockIdx.x] : (int)blockIdx.x;
   const int cls = ct.chunk_class[chunk];
-  if (class_dirty ? !class_dirty[cls] : ct.chunk_zone[chunk] != 0) return;  // full pass: zone B only; incremental pass: the dirty classes
+  if (class_dirty ? !class_dirty[cls] : chunk_elsewhere(ct, chunk)) return;  // full pass: zone B only; incremental pass: the dirty classes
   const int begin = ct.chunk_begin[chunk];
   const int len = ct.chunk_len[chunk];
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
@@ -1357,7 +1380,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) 
   if (only_general && (*n_general == 0 || !slice_desc_general(only_general, chunk))) return;
   const int lane = threadIdx.x % kWave;
   const int cls = ct.chunk_class[chunk];
-  if (class_dirty ? !class_dirty[cls] : ct.chunk_zone[chunk] != 0) return;
+  if (class_dirty ? !class_dirty[cls] : chunk_elsewhere(ct, chunk)) return;
   const int begin = ct.chunk_begin[chunk], len = ct.chunk_len[chunk];
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const int pin = pin_enabled ? ct.pin[cls] : -1;
@@ -1454,7 +1477,7 @@ __global__ __launch_bounds__(kBlock) void k_slice_desc(ClassTable ct, Planes pl,
   d.st = d.sa = d.ss = d.p0 = d.pin = d.mem0 = -1;
   d.irow = 1 << kRowBigShift;
   d.cls = ct.chunk_class[chunk];
-  const bool act = class_dirty ? class_dirty[d.cls] != 0 : ct.chunk_zone[chunk] == 0;
+  const bool act = class_dirty ? class_dirty[d.cls] != 0 : !chunk_elsewhere(ct, chunk);
   if (act) {
     const int len = ct.chunk_len[chunk];
     d.meta = kSliceLive | len | (ct.chunk_first[chunk] ? kSliceFirst : 0);
@@ -1676,6 +1699,208 @@ __global__ __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(4)
     issue_group(ra, ia);
     write_group(rb, lb, ib);
     if (!la[0]) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_sweep_rows: the zone-B writer of RUNS of index-row classes (round 6). What a row is: predicate_manager.go:260-283 for one
+// ask against every node — here for asks that differ from their neighbours ONLY in the value of one walked dimension.
+//
+// k_walk_rows decodes every (row, word) from scratch: 8 LDS reads and 16 bit operations per 8 bytes written, although two rows of
+// one signature differ only in a threshold. Here the zone-B classes of one (toleration, affinity, spread, staged plane row) are laid
+// out in ascending order of their walked value (build_classes; row_of_pod is a free permutation) — a RUN — and a lane (= word)
+// keeps the word's current mask in registers: going from value v to the next larger one only CLEARS the bits of the nodes whose
+// free value lies in [v, v'), found with a cursor into the word's ascending free list. Nothing is decoded per row, no index row
+// is read (k_dim_walk need not write it), and the kernel is what it should be: a store stream with an occasional LDS lookup.
+//   * k_dim_sort leaves, per (walked dimension, word), the list in the form the cursor wants: entry j = (g << 6) | node with
+//     g = the number of the dimension's sorted request values that are <= the j-th smallest free value of the word. A row at
+//     position `vi` of the sorted values fails node j  <=>  value > free  <=>  vi >= g  <=>  entry <= (vi << 6 | 63): one unsigned
+//     compare per word and row; entry 64 is a sentinel (0xffffffff) that no row reaches.
+//   * a workgroup stages the lists of its segment of NIT x 64 words ([65][SW] dwords, position-major: lanes are consecutive words,
+//     so every cursor read is conflict-free whatever the positions) and the staged ballot rows of the request family;
+//   * a wave owns a contiguous range of the sweep rows. At the start of a run (or of its range) a lane finds its position by
+//     binary search in LDS and takes mask = (AND of the run's plane rows) & pmask[word][position] from the mask table of k_dim_sort;
+//     from then on: compare, (rarely) advance the cursor and clear a bit, store. The feasible count of a row changes only when a
+//     bit was cleared in this segment; the popcount reduction runs only then.
+//   * row descriptors {class, bitmap row, position, run} are wave-uniform scalar loads (constant address space): the vector memory
+//     counter holds nothing but stores in the steady state, and nothing ever waits for them.
+struct SweepRow {   // 16 bytes
+  int cls, dest, vi, run;   // class (its feasible count), bitmap row, position of the value in the dimension's sorted order, run
+};
+struct SweepRun {   // 16 bytes: one scalar load
+  int st, sa, ss, prow;   // signature rows (-1: none) and the second ballot row of the request family (0: none — row 0 is in every class)
+};
+constexpr int kSweepWaves = 8;    // one workgroup per compute unit (the lists of a segment fill the LDS): two waves per SIMD, 256 VGPRs each
+constexpr int kSweepThreads = kSweepWaves * kWave;
+constexpr int kSweepBatch = 16;   // consecutive rows a wave takes at a time, round robin over all waves of the segment
+constexpr int kSweepMaxSegs = 16;
+__host__ __device__ inline size_t sweep_lds_bytes(int nit) {
+  return (size_t)65 * nit * kWave * sizeof(unsigned) + (size_t)kSweepWaves * kSweepBatch * 16;
+}
+// One launch per walked dimension: grid.x persistent workgroups (one per compute unit: the lists of a segment fill the LDS), grid.y =
+// the row's segments — `n_long` segments of NIT word groups, then segments of NIT - 1, the last one holding the row's tail.
+template <int NIT>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
+    Planes pl, const unsigned* __restrict__ ent /* [65][n_words] of this walked dimension */, const u64* __restrict__ pmask /* [n_words][65] */,
+    const SweepRow* __restrict__ rows, const SweepRun* __restrict__ runs, int n_rows, u64* __restrict__ bitmap,
+    int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_long) {
+  extern __shared__ u64 sweep_lds[];  // [65][SW] cursor lists, then [waves][kSweepBatch] row descriptors
+  constexpr int SW = NIT * kWave;
+  const bool all_fail = pin_enabled & 2;
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+  const int seg = (int)blockIdx.y;
+  const int nit = seg < n_long ? NIT : NIT - 1;  // word groups of this segment (wave-uniform)
+  const int w_first = (seg < n_long ? seg * NIT : n_long * NIT + (seg - n_long) * (NIT - 1)) * kWave;
+  const bool last_seg = seg == (int)gridDim.y - 1;
+  unsigned* s_ent = (unsigned*)sweep_lds;
+  int4* s_desc = (int4*)(s_ent + 65 * SW) + wave * kSweepBatch;
+  for (int i = (int)threadIdx.x; i < 65 * SW; i += kSweepThreads) {
+    const int j = i / SW, w = w_first + i % SW;
+    s_ent[i] = (j < 64 && i % SW < nit * kWave && w < pl.n_words) ? ent[(size_t)j * pl.n_words + w] : 0xffffffffu;
+  }
+  __syncthreads();
+  typedef const SweepRun __attribute__((address_space(4))) ConstRun;
+  // Row descriptors reach the loop through LDS, a batch at a time (lane i fetches row rb + i; the wave then reads a row's 16 bytes with
+  // a uniform address, one row ahead), the next batch's load issued a batch ahead. The vector memory counter of the steady state holds
+  // nothing but stores: gfx9 counts loads and stores in ONE in-order counter, so a wait for any load is a wait for the stores in
+  // front of it — a descriptor that arrived by a load per row put such a wait in front of every row (first forms: 2.8 TB/s).
+  // Batches go round robin over all waves of the segment: every wave meets the same mix of long runs (a compare and seven stores
+  // per row) and short ones (a run start: a binary search in LDS, one round of global loads — and the wait for them, which drains
+  // the wave's stores); a contiguous split left most of the chip waiting for the workgroups that drew the asks with a selector of
+  // their own. (Claiming batches from a counter costs a returning atomic per batch — whose wait is a drain as well: 3.2 TB/s on
+  // the long runs against 4.8.) profiles/r06_rowstore_probe.txt: the store pattern itself reaches 5.4-5.6 TB/s however the rows are
+  // dealt.
+  const int4* vrow = (const int4*)rows;
+  int next_batch = ((int)blockIdx.x * kSweepWaves + wave) * kSweepBatch;
+  const int batch_step = (int)gridDim.x * kSweepWaves * kSweepBatch;
+  auto claim = [&]() { const int v = next_batch; next_batch += batch_step; return v; };
+  auto fetch = [&](int rb) { return vrow[min(rb + min(lane, kSweepBatch - 1), n_rows - 1)]; };
+  int rb = claim();
+  if (rb >= n_rows) return;
+  int4 d_nx = fetch(rb);
+  if (lane < kSweepBatch) s_desc[lane] = d_nx;
+  int rb_nx = claim();
+  d_nx = fetch(rb_nx);
+  int r = rb, r1 = min(rb + kSweepBatch, n_rows);
+  int4 dd = s_desc[0];
+  u64 mask[NIT];
+  unsigned cur[NIT];   // the list entry under the cursor
+  int at[NIT];         // its dword index in s_ent
+  const int rw = all_fail ? 0 : row_words;
+  for (;;) {
+    // ---- a run begins — or this wave's first row of one: positions by binary search, masks from the planes and the mask table.
+    // (The rows a wave takes ascend: inside a run its cursors only ever move forward, whatever the other waves took in between.)
+    const int run = __builtin_amdgcn_readfirstlane(dd.w);
+    int pc;
+    {
+      const unsigned T = ((unsigned)__builtin_amdgcn_readfirstlane(dd.z) << 6) | 63u;
+      const ConstRun* cr = (const ConstRun*)(unsigned long long)(runs + run);
+      const int st = cr->st, sa = cr->sa, ss = cr->ss, prow = cr->prow;
+      const u64* p0 = pl.res + w_first + lane;  // row 0 of the request family: the pod-independent part, in every class
+      const u64* pp = pl.res + (size_t)prow * pl.stride + w_first + lane;
+      const u64* pt = (pl.tol && st >= 0) ? pl.tol + (size_t)st * pl.stride + w_first + lane : p0;
+      const u64* pa = (pl.aff && sa >= 0) ? pl.aff + (size_t)sa * pl.stride + w_first + lane : p0;
+      const u64* ps = (pl.spread && ss >= 0) ? pl.spread + (size_t)ss * pl.stride + w_first + lane : p0;
+      // the positions first (LDS only), then every global load of the run start in one round: the mask-table entries depend on the
+      // positions, and a wait for a load is a wait for every store this wave has in flight — one such wait per run start, not two
+      int lo[NIT], hi[NIT];  // the first entry the row does not reach: entries [0, lo) are <= T; the NIT searches step together
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) lo[it] = 0, hi[it] = 64;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        unsigned e[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) e[it] = s_ent[((lo[it] + hi[it]) >> 1) * SW + it * kWave + lane];  // (lo == hi == 64 reads the sentinel)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int mid = (lo[it] + hi[it]) >> 1;
+          const bool below = e[it] <= T;
+          lo[it] = below ? mid + 1 : lo[it];
+          hi[it] = below ? hi[it] : mid;
+        }
+      }
+      u64 pm[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int wl = it * kWave + lane;
+        at[it] = lo[it] * SW + wl;
+        cur[it] = s_ent[at[it]];
+        pm[it] = pmask[(size_t)min(w_first + wl, pl.n_words - 1) * 65 + lo[it]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) pm[it] &= p0[it * kWave] & pp[it * kWave];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) pm[it] &= pt[it * kWave] & pa[it * kWave] & ps[it * kWave];
+      int cnt = 0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        mask[it] = (w_first + it * kWave + lane < rw && it < nit) ? pm[it] : 0ull;
+        cnt += __popcll(mask[it]);
+      }
+      pc = __builtin_amdgcn_readlane(wave_sum_lane63(cnt), 63);
+    }
+    // ---- the rows of the run that are this wave's
+    for (;;) {
+      const int cls = __builtin_amdgcn_readfirstlane(dd.x), dest = __builtin_amdgcn_readfirstlane(dd.y);
+      const unsigned T = ((unsigned)__builtin_amdgcn_readfirstlane(dd.z) << 6) | 63u;
+      // Some word of the segment loses nodes between the previous value and this one: all cursors step together — the NIT list
+      // reads of a step are in flight at once — and a cursor that has nothing to clear re-reads its entry (no branch per word: the
+      // loop carries the state in place).
+      bool stepped = false;
+      for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) any |= cur[it] <= T;
+        if (!__builtin_amdgcn_ballot_w64(any)) break;
+        stepped = true;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const bool go = cur[it] <= T;
+          const u64 bit = 1ull << (cur[it] & 63u);
+          mask[it] &= go ? ~bit : ~0ull;
+          at[it] += go ? SW : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) cur[it] = s_ent[at[it]];
+      }
+      if (stepped) {
+        int cnt = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) cnt += __popcll(mask[it]);
+        pc = __builtin_amdgcn_readlane(wave_sum_lane63(cnt), 63);
+      }
+      // the next row's descriptor: in flight while this row is stored (behind the cursor check: the loop above waits for every LDS
+      // read that is outstanding when it is entered); a batch that is used up is replaced by the one fetched a batch ago
+      ++r;
+      bool more = true;
+      if (r == r1) {
+        if (rb_nx >= n_rows) {
+          more = false;
+        } else {
+          rb = rb_nx;
+          if (lane < kSweepBatch) s_desc[lane] = d_nx;
+          rb_nx = claim();
+          d_nx = fetch(rb_nx);
+          r = rb;
+          r1 = min(rb + kSweepBatch, n_rows);
+        }
+      }
+      if (more) dd = s_desc[r - rb];
+      u64* dst = bitmap + (size_t)dest * row_stride + w_first + lane;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (it < NIT - 2) {
+          dst[it * kWave] = mask[it];
+        } else if (it < nit) {  // (wave-uniform: the segment's last one or two word groups)
+          if (!last_seg || it < nit - 1 || w_first + it * kWave + lane < row_stride) dst[it * kWave] = mask[it];
+        }
+      }
+      if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+      if (!more) return;
+      if (__builtin_amdgcn_readfirstlane(dd.w) != run) break;
+    }
   }
 }
 
