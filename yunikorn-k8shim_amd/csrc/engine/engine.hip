@@ -271,7 +271,8 @@ struct ykpred_engine {
   std::vector<int32_t> h_class_sweep;  // [C] 1 = the class is a row of a sweep run
   int sweep_rows[ykk::kMaxIdxRows] = {0, 0}, sweep_row_off[ykk::kMaxIdxRows + 1] = {0, 0, 0}, sweep_runs = 0;  // per walked dimension
   int index_rows_needed = 0;         // index rows some class OUTSIDE the sweep runs reads (the full pass walks only those)
-  DevBuf d_sweep_rows, d_sweep_runs; // SweepRow {class, bitmap row, position, run}; SweepRun
+  DevBuf d_sweep_rows, d_sweep_runs, d_sweep_units; // SweepRow {class, bitmap row, position, run}; SweepRun; unit bounds [units + 1] per walked dimension
+  int sweep_units[ykk::kMaxIdxRows] = {0, 0}, sweep_unit_off[ykk::kMaxIdxRows + 1] = {0, 0, 0};
   DevBuf d_chunk_list_b0;            // [NCB0] the zone-B chunks outside the sweep runs (a pass with the sweep runs the chunk writers over these)
   int NCB0 = 0;
   DevBuf d_walk2_order, d_walk2_big, d_walk2_begin, d_walk2_len;  // walk chunks over the needed index rows only
@@ -831,13 +832,31 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
         i = j;
       }
       e->sweep_runs = (int)runs.size();
-      std::vector<int32_t> all_rows;
+      std::vector<int32_t> all_rows, all_units;
       e->sweep_row_off[0] = 0;
+      e->sweep_unit_off[0] = 0;
       for (int b = 0; b < ykk::kMaxIdxRows; ++b) {
-        e->sweep_rows[b] = (int)(rows_of[b].size() / 4);
+        const int n = (int)(rows_of[b].size() / 4);
+        e->sweep_rows[b] = n;
         all_rows.insert(all_rows.end(), rows_of[b].begin(), rows_of[b].end());
-        e->sweep_row_off[b + 1] = e->sweep_row_off[b] + e->sweep_rows[b];
+        e->sweep_row_off[b + 1] = e->sweep_row_off[b] + n;
+        // units of equal estimated cost (a row = 1, a run start = kSweepRunCost): eight per wave of a full launch, none empty
+        const int want = std::max(1, std::min(n / 4, e->num_cus * ykk::kSweepWaves * 8));
+        long total = 0;
+        for (int i = 0; i < n; ++i) total += 1 + ((i == 0 || rows_of[b][(size_t)i * 4 + 3] != rows_of[b][(size_t)(i - 1) * 4 + 3]) ? ykk::kSweepRunCost : 0);
+        const size_t first = all_units.size();
+        long acc = 0;
+        for (int i = 0; i < n; ++i) {
+          const long unit = (long)(all_units.size() - first);
+          if (unit < want && acc * want >= unit * total) all_units.push_back(i);  // (unit k begins at the first row whose prefix cost reaches k / want)
+          acc += 1 + ((i == 0 || rows_of[b][(size_t)i * 4 + 3] != rows_of[b][(size_t)(i - 1) * 4 + 3]) ? ykk::kSweepRunCost : 0);
+        }
+        e->sweep_units[b] = (int)(all_units.size() - first);
+        all_units.push_back(n);
+        e->sweep_unit_off[b + 1] = (int)all_units.size();
       }
+      all_units.push_back(0);
+      TRY(upload(e, e->d_sweep_units, all_units.data(), all_units.size(), st));
       if (!runs.empty()) {
         TRY(upload(e, e->d_sweep_rows, all_rows.data(), all_rows.size(), st));
         TRY(upload(e, e->d_sweep_runs, runs.data(), runs.size(), st));
@@ -1402,7 +1421,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -2301,15 +2320,15 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       for (int b = 0; b < e->n_big; ++b) {
         const int n_rows = e->sweep_rows[b];
         if (n_rows == 0) continue;
-        const int batches = (n_rows + ykk::kSweepBatch - 1) / ykk::kSweepBatch;
-        const int groups = std::max(1, std::min(e->sweep_groups > 0 ? e->sweep_groups : e->num_cus, (batches + ykk::kSweepWaves - 1) / ykk::kSweepWaves));
+        const int n_units = e->sweep_units[b];
+        const int groups = std::max(1, std::min(e->sweep_groups > 0 ? e->sweep_groups : e->num_cus, (n_units + ykk::kSweepWaves - 1) / ykk::kSweepWaves));
         auto launch_sweep = [&](auto kernel) -> int {
           const size_t lds = ykk::sweep_lds_bytes(nit);
           if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hipLaunchKernelGGL(kernel, dim3((unsigned)groups, (unsigned)segs), dim3(ykk::kSweepThreads), lds, sz, pc,
-                             e->d_ent_c.as<unsigned>() + (size_t)b * 65 * (size_t)e->row_words, e->d_pmask_c.as<u64>() + (size_t)b * (size_t)e->row_words * 65,
+                             e->d_ent_c.as<unsigned>() + (size_t)b * 65 * (size_t)e->row_words, e->d_rbits_c.as<u64>() + (size_t)b * ykk::kRankBits * (size_t)e->row_words,
                              e->d_sweep_rows.as<ykk::SweepRow>() + e->sweep_row_off[b], e->d_sweep_runs.as<ykk::SweepRun>(), n_rows,
-                             bitmap, e->row_words, e->row_stride, pin_on,
+                             e->d_sweep_units.as<int>() + e->sweep_unit_off[b], n_units, bitmap, e->row_words, e->row_stride, pin_on,
                              e->d_class_count.as<int>(), n_long);
           return YKPRED_OK;
         };

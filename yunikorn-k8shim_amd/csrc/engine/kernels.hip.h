@@ -1732,19 +1732,21 @@ struct SweepRun {   // 16 bytes: one scalar load
 };
 constexpr int kSweepWaves = 8;    // one workgroup per compute unit (the lists of a segment fill the LDS): two waves per SIMD, 256 VGPRs each
 constexpr int kSweepThreads = kSweepWaves * kWave;
-constexpr int kSweepBatch = 16;   // consecutive rows a wave takes at a time, round robin over all waves of the segment
+constexpr int kSweepBatch = 16;   // row descriptors a wave keeps in LDS at a time
+constexpr int kSweepRunCost = 4;  // what a run start costs a wave, in rows of a long run (a drain + a load round trip against 3.5 KB of stores)
 constexpr int kSweepMaxSegs = 16;
 __host__ __device__ inline size_t sweep_lds_bytes(int nit) {
-  return (size_t)65 * nit * kWave * sizeof(unsigned) + (size_t)kSweepWaves * kSweepBatch * 16;
+  return (size_t)65 * nit * kWave * sizeof(unsigned) + (size_t)kRankBits * nit * kWave * sizeof(u64) + (size_t)kSweepWaves * kSweepBatch * 16;
 }
 // One launch per walked dimension: grid.x persistent workgroups (one per compute unit: the lists of a segment fill the LDS), grid.y =
 // the row's segments — `n_long` segments of NIT word groups, then segments of NIT - 1, the last one holding the row's tail.
 template <int NIT>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
-    Planes pl, const unsigned* __restrict__ ent /* [65][n_words] of this walked dimension */, const u64* __restrict__ pmask /* [n_words][65] */,
-    const SweepRow* __restrict__ rows, const SweepRun* __restrict__ runs, int n_rows, u64* __restrict__ bitmap,
+    Planes pl, const unsigned* __restrict__ ent /* [65][n_words] of this walked dimension */, const u64* __restrict__ rbits /* [kRankBits][n_words] */,
+    const SweepRow* __restrict__ rows, const SweepRun* __restrict__ runs, int n_rows, const int* __restrict__ units /* [n_units + 1] */,
+    int n_units, u64* __restrict__ bitmap,
     int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_long) {
-  extern __shared__ u64 sweep_lds[];  // [65][SW] cursor lists, then [waves][kSweepBatch] row descriptors
+  extern __shared__ u64 sweep_lds[];  // [65][SW] cursor lists, [kRankBits][SW] rank planes, [waves][kSweepBatch] row descriptors
   constexpr int SW = NIT * kWave;
   const bool all_fail = pin_enabled & 2;
   const int lane = threadIdx.x % kWave;
@@ -1754,10 +1756,18 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
   const int w_first = (seg < n_long ? seg * NIT : n_long * NIT + (seg - n_long) * (NIT - 1)) * kWave;
   const bool last_seg = seg == (int)gridDim.y - 1;
   unsigned* s_ent = (unsigned*)sweep_lds;
-  int4* s_desc = (int4*)(s_ent + 65 * SW) + wave * kSweepBatch;
+  u64* s_rk = (u64*)(s_ent + 65 * SW);
+  int4* s_desc = (int4*)(s_rk + kRankBits * SW) + wave * kSweepBatch;
   for (int i = (int)threadIdx.x; i < 65 * SW; i += kSweepThreads) {
     const int j = i / SW, w = w_first + i % SW;
     s_ent[i] = (j < 64 && i % SW < nit * kWave && w < pl.n_words) ? ent[(size_t)j * pl.n_words + w] : 0xffffffffu;
+  }
+  // the rank planes of the segment (k_dim_sort: bit k of r' = valid ? position in the word's ascending free list + 1 : 0): the word of
+  // a row that starts at position j is { node : r' > j } — seven majority steps on LDS words. (The 65-entry mask table gives the
+  // same word with one load — a gather with a 520-byte lane stride: 448 cache lines per run start, which is what a run start cost.)
+  for (int i = (int)threadIdx.x; i < kRankBits * SW; i += kSweepThreads) {
+    const int k = i / SW, w = w_first + i % SW;
+    s_rk[i] = w < pl.n_words ? rbits[(size_t)k * pl.n_words + w] : 0ull;
   }
   __syncthreads();
   typedef const SweepRun __attribute__((address_space(4))) ConstRun;
@@ -1765,81 +1775,145 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
   // a uniform address, one row ahead), the next batch's load issued a batch ahead. The vector memory counter of the steady state holds
   // nothing but stores: gfx9 counts loads and stores in ONE in-order counter, so a wait for any load is a wait for the stores in
   // front of it — a descriptor that arrived by a load per row put such a wait in front of every row (first forms: 2.8 TB/s).
-  // Batches go round robin over all waves of the segment: every wave meets the same mix of long runs (a compare and seven stores
-  // per row) and short ones (a run start: a binary search in LDS, one round of global loads — and the wait for them, which drains
-  // the wave's stores); a contiguous split left most of the chip waiting for the workgroups that drew the asks with a selector of
-  // their own. (Claiming batches from a counter costs a returning atomic per batch — whose wait is a drain as well: 3.2 TB/s on
-  // the long runs against 4.8.) profiles/r06_rowstore_probe.txt: the store pattern itself reaches 5.4-5.6 TB/s however the rows are
-  // dealt.
+  // The rows are dealt in UNITS of equal estimated cost (build_classes: a row = one, a run start = kSweepRunCost rows — a binary
+  // search in LDS, one round of global loads and the wait for them, which drains the wave's stores), round robin over all waves of the
+  // segment. Inside a unit a wave walks consecutive rows: a run is started once per unit, not once per batch, and every wave gets
+  // the same share of the short runs (the asks with a selector of their own, at the end of the list). What did not work: a contiguous
+  // split by row count (most of the chip waiting for the workgroups that drew the short runs), batches of rows round robin (a run
+  // start per batch in every run below 32 k rows), batches claimed from a counter (a returning atomic per batch, whose wait is a drain
+  // as well: 3.2 TB/s on the long runs against 4.8). profiles/r06_rowstore_probe.txt: the store pattern itself reaches 5.4-5.6 TB/s
+  // however the rows are dealt.
   const int4* vrow = (const int4*)rows;
-  int next_batch = ((int)blockIdx.x * kSweepWaves + wave) * kSweepBatch;
-  const int batch_step = (int)gridDim.x * kSweepWaves * kSweepBatch;
-  auto claim = [&]() { const int v = next_batch; next_batch += batch_step; return v; };
+  typedef const int __attribute__((address_space(4))) ConstInt;
+  const ConstInt* ub = (const ConstInt*)(unsigned long long)units;
+  const int unit_step = (int)gridDim.x * kSweepWaves;
+  int u = (int)blockIdx.x * kSweepWaves + wave;
+  if (u >= n_units) return;
   auto fetch = [&](int rb) { return vrow[min(rb + min(lane, kSweepBatch - 1), n_rows - 1)]; };
-  int rb = claim();
-  if (rb >= n_rows) return;
+  int rb = ub[u], unit_end = ub[u + 1];
   int4 d_nx = fetch(rb);
   if (lane < kSweepBatch) s_desc[lane] = d_nx;
-  int rb_nx = claim();
-  d_nx = fetch(rb_nx);
-  int r = rb, r1 = min(rb + kSweepBatch, n_rows);
+  int r = rb, r1 = min(rb + kSweepBatch, unit_end);
+  d_nx = fetch(r1);
   int4 dd = s_desc[0];
   u64 mask[NIT];
   unsigned cur[NIT];   // the list entry under the cursor
   int at[NIT];         // its dword index in s_ent
   const int rw = all_fail ? 0 : row_words;
+  // row 0 of the request family — the pod-independent part, in every class — stays in registers, with the words past the row (and
+  // past this segment's word groups) cleared: every row is ANDed with it
+  u64 row0[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const u64 v = pl.res[w_first + it * kWave + lane];
+    row0[it] = (w_first + it * kWave + lane < rw && it < nit) ? v : 0ull;
+  }
+  // the first list entry a row of threshold T does not reach, per word group: entries [0, lo) are <= T. The NIT searches step together.
+  auto positions = [&](unsigned T, int (&lo)[NIT]) {
+    int hi[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) lo[it] = 0, hi[it] = 64;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      unsigned e[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) e[it] = s_ent[((lo[it] + hi[it]) >> 1) * SW + it * kWave + lane];  // (lo == hi == 64 reads the sentinel)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int mid = (lo[it] + hi[it]) >> 1;
+        const bool below = e[it] <= T;
+        lo[it] = below ? mid + 1 : lo[it];
+        hi[it] = below ? hi[it] : mid;
+      }
+    }
+  };
+  // the words of a run's row at the positions `lo`: the AND of its plane rows and { node : rank >= position } — every global load
+  // of a run start in one round (a wait for a load is a wait for every store this wave has in flight: one such wait per run start)
+  auto run_words = [&](int run, const int (&lo)[NIT], u64 (&pm)[NIT]) {
+    const ConstRun* cr = (const ConstRun*)(unsigned long long)(runs + run);
+    const int st = cr->st, sa = cr->sa, ss = cr->ss, prow = cr->prow;
+    const u64* p0 = pl.res + w_first + lane;  // (an absent signature row reads row 0 again)
+    const u64* pp = pl.res + (size_t)prow * pl.stride + w_first + lane;
+    const u64* pt = (pl.tol && st >= 0) ? pl.tol + (size_t)st * pl.stride + w_first + lane : p0;
+    const u64* pa = (pl.aff && sa >= 0) ? pl.aff + (size_t)sa * pl.stride + w_first + lane : p0;
+    const u64* ps = (pl.spread && ss >= 0) ? pl.spread + (size_t)ss * pl.stride + w_first + lane : p0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const unsigned nj = ~(unsigned)lo[it];
+      u64 rk[kRankBits];
+#pragma unroll
+      for (int k = 0; k < kRankBits; ++k) rk[k] = s_rk[k * SW + it * kWave + lane];
+      unsigned m = (unsigned)((int)(nj << 31) >> 31);
+      unsigned glo = (unsigned)rk[0] & m, ghi = (unsigned)(rk[0] >> 32) & m;
+#pragma unroll
+      for (int k = 1; k < kRankBits; ++k) {
+        m = (unsigned)((int)(nj << (31 - k)) >> 31);
+        glo = maj32(glo, (unsigned)rk[k], m);
+        ghi = maj32(ghi, (unsigned)(rk[k] >> 32), m);
+      }
+      pm[it] = (u64)glo | ((u64)ghi << 32);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) pm[it] &= row0[it] & pp[it * kWave];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) pm[it] &= pt[it * kWave] & pa[it * kWave] & ps[it * kWave];
+  };
+  auto popcount = [&](const u64 (&m)[NIT]) {
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) cnt += __popcll(m[it]);
+    return __builtin_amdgcn_readlane(wave_sum_lane63(cnt), 63);
+  };
+  auto emit = [&](int cls, int dest, const u64 (&m)[NIT], int pc) {
+    u64* dst = bitmap + (size_t)dest * row_stride + w_first + lane;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it < NIT - 2) {
+        dst[it * kWave] = m[it];
+      } else if (it < nit) {  // (wave-uniform: the segment's last one or two word groups)
+        if (!last_seg || it < nit - 1 || w_first + it * kWave + lane < row_stride) dst[it * kWave] = m[it];
+      }
+    }
+    if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+  };
   for (;;) {
+    // ---- SINGLE rows (the asks with a selector of their own: a run of one row each, tens of thousands of them in a row). A run
+    // start is a round of global loads and the wait for it; two of them that follow one another are started TOGETHER — one wait, as
+    // many loads in flight as the counter holds — and need no cursor: nothing follows them in their runs. Row i of the batch is
+    // single when row i + 1 (in the batch) belongs to another run.
+    {
+      const int i0 = r - rb, nb = r1 - rb;
+      const int my_run = s_desc[min(lane, kSweepBatch - 1)].w, nx_run = s_desc[min(lane + 1, kSweepBatch - 1)].w;
+      const u64 single = __builtin_amdgcn_ballot_w64(lane >= i0 && lane + 1 < nb && my_run != nx_run);
+      if (((single >> i0) & 3) == 3) {
+        const int4 da = dd, db = s_desc[i0 + 1];
+        int lo_a[NIT], lo_b[NIT];
+        u64 wa[NIT], wb[NIT];
+        positions(((unsigned)__builtin_amdgcn_readfirstlane(da.z) << 6) | 63u, lo_a);
+        positions(((unsigned)__builtin_amdgcn_readfirstlane(db.z) << 6) | 63u, lo_b);
+        run_words(__builtin_amdgcn_readfirstlane(da.w), lo_a, wa);
+        run_words(__builtin_amdgcn_readfirstlane(db.w), lo_b, wb);
+        emit(__builtin_amdgcn_readfirstlane(da.x), __builtin_amdgcn_readfirstlane(da.y), wa, popcount(wa));
+        emit(__builtin_amdgcn_readfirstlane(db.x), __builtin_amdgcn_readfirstlane(db.y), wb, popcount(wb));
+        r += 2;  // (r < r1: the second of them has its successor in the batch)
+        dd = s_desc[r - rb];
+        continue;
+      }
+    }
     // ---- a run begins — or this wave's first row of one: positions by binary search, masks from the planes and the mask table.
-    // (The rows a wave takes ascend: inside a run its cursors only ever move forward, whatever the other waves took in between.)
+    // (The rows a wave takes ascend: inside a run its cursors only ever move forward.)
     const int run = __builtin_amdgcn_readfirstlane(dd.w);
     int pc;
     {
-      const unsigned T = ((unsigned)__builtin_amdgcn_readfirstlane(dd.z) << 6) | 63u;
-      const ConstRun* cr = (const ConstRun*)(unsigned long long)(runs + run);
-      const int st = cr->st, sa = cr->sa, ss = cr->ss, prow = cr->prow;
-      const u64* p0 = pl.res + w_first + lane;  // row 0 of the request family: the pod-independent part, in every class
-      const u64* pp = pl.res + (size_t)prow * pl.stride + w_first + lane;
-      const u64* pt = (pl.tol && st >= 0) ? pl.tol + (size_t)st * pl.stride + w_first + lane : p0;
-      const u64* pa = (pl.aff && sa >= 0) ? pl.aff + (size_t)sa * pl.stride + w_first + lane : p0;
-      const u64* ps = (pl.spread && ss >= 0) ? pl.spread + (size_t)ss * pl.stride + w_first + lane : p0;
-      // the positions first (LDS only), then every global load of the run start in one round: the mask-table entries depend on the
-      // positions, and a wait for a load is a wait for every store this wave has in flight — one such wait per run start, not two
-      int lo[NIT], hi[NIT];  // the first entry the row does not reach: entries [0, lo) are <= T; the NIT searches step together
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) lo[it] = 0, hi[it] = 64;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        unsigned e[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) e[it] = s_ent[((lo[it] + hi[it]) >> 1) * SW + it * kWave + lane];  // (lo == hi == 64 reads the sentinel)
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const int mid = (lo[it] + hi[it]) >> 1;
-          const bool below = e[it] <= T;
-          lo[it] = below ? mid + 1 : lo[it];
-          hi[it] = below ? hi[it] : mid;
-        }
-      }
-      u64 pm[NIT];
+      int lo[NIT];
+      positions(((unsigned)__builtin_amdgcn_readfirstlane(dd.z) << 6) | 63u, lo);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int wl = it * kWave + lane;
-        at[it] = lo[it] * SW + wl;
+        at[it] = lo[it] * SW + it * kWave + lane;
         cur[it] = s_ent[at[it]];
-        pm[it] = pmask[(size_t)min(w_first + wl, pl.n_words - 1) * 65 + lo[it]];
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) pm[it] &= p0[it * kWave] & pp[it * kWave];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) pm[it] &= pt[it * kWave] & pa[it * kWave] & ps[it * kWave];
-      int cnt = 0;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        mask[it] = (w_first + it * kWave + lane < rw && it < nit) ? pm[it] : 0ull;
-        cnt += __popcll(mask[it]);
-      }
-      pc = __builtin_amdgcn_readlane(wave_sum_lane63(cnt), 63);
+      run_words(run, lo, mask);
+      pc = popcount(mask);
     }
     // ---- the rows of the run that are this wave's
     for (;;) {
@@ -1865,39 +1939,33 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
 #pragma unroll
         for (int it = 0; it < NIT; ++it) cur[it] = s_ent[at[it]];
       }
-      if (stepped) {
-        int cnt = 0;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) cnt += __popcll(mask[it]);
-        pc = __builtin_amdgcn_readlane(wave_sum_lane63(cnt), 63);
-      }
+      if (stepped) pc = popcount(mask);
       // the next row's descriptor: in flight while this row is stored (behind the cursor check: the loop above waits for every LDS
       // read that is outstanding when it is entered); a batch that is used up is replaced by the one fetched a batch ago
       ++r;
       bool more = true;
       if (r == r1) {
-        if (rb_nx >= n_rows) {
-          more = false;
-        } else {
-          rb = rb_nx;
+        if (r < unit_end) {  // the unit's next batch: its descriptors were fetched a batch ago
+          rb = r;
           if (lane < kSweepBatch) s_desc[lane] = d_nx;
-          rb_nx = claim();
-          d_nx = fetch(rb_nx);
-          r = rb;
-          r1 = min(rb + kSweepBatch, n_rows);
+          r1 = min(rb + kSweepBatch, unit_end);
+          d_nx = fetch(r1);
+        } else {
+          u += unit_step;
+          if (u >= n_units) {
+            more = false;
+          } else {  // the wave's next unit (a handful per wave: this fetch is waited for at once)
+            rb = ub[u], unit_end = ub[u + 1];
+            d_nx = fetch(rb);
+            if (lane < kSweepBatch) s_desc[lane] = d_nx;
+            r = rb;
+            r1 = min(rb + kSweepBatch, unit_end);
+            d_nx = fetch(r1);
+          }
         }
       }
       if (more) dd = s_desc[r - rb];
-      u64* dst = bitmap + (size_t)dest * row_stride + w_first + lane;
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        if (it < NIT - 2) {
-          dst[it * kWave] = mask[it];
-        } else if (it < nit) {  // (wave-uniform: the segment's last one or two word groups)
-          if (!last_seg || it < nit - 1 || w_first + it * kWave + lane < row_stride) dst[it * kWave] = mask[it];
-        }
-      }
-      if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+      emit(cls, dest, mask, pc);
       if (!more) return;
       if (__builtin_amdgcn_readfirstlane(dd.w) != run) break;
     }
