@@ -184,12 +184,17 @@ def node_row_bytes(pm):
 
 
 def algorithmic_bytes(pm, lay):
-    """ALGORITHMIC bytes of one pass over the local table: the bitmap written once, the node table, the
-    per-ask ids, the class table and the signature planes read once."""
+    """ALGORITHMIC bytes of one pass over the local table, SURVEY.md §8(d) to the letter:
+    bytes(P, N) = P·N/8 (bitmap written once) + N·B_node (node SoA read once) + P·B_pod (pod table read once) + 4·P feasible counts
+    + 8·P decisions, B_node = 8·R + 4 + 4 + 8·k + 8·w + 4·K, B_pod = 8·R + 8·k + 4 + T·8·w with the config's own R, k (taint words),
+    w (label words), K (topology keys) and T = 4 selector terms per ask (the survey's figure for configs[2]). The implementation's
+    own intermediates — signature planes, index rows, class tables — are NOT algorithmic bytes (round 5 added
+    `plane_bytes` here and overstated the fraction of the small-class populations by 4 points)."""
     st = pm.stats()
-    b_node = 8 * 2 * st["R"] + 4 + 4 + 4 + 8 * st["KT"] + 8 * st["W"]
-    return (lay.num_pods * lay.row_words * 8 + lay.num_nodes * b_node + lay.num_pods * (4 + 4 + 4) + lay.num_classes * 4 * 4 +
-            plane_bytes(lay))
+    R, KT, W = st["R"], st["KT"], st["W"]
+    b_node = 8 * R + 4 + 4 + 8 * KT + 8 * W + 4 * st.get("KD", 0)
+    b_pod = 8 * R + 8 * KT + 4 + 4 * 8 * W
+    return lay.num_pods * lay.row_words * 8 + lay.num_nodes * b_node + lay.num_pods * b_pod + 12 * lay.num_pods
 
 
 def plane_bytes(lay):
@@ -207,13 +212,13 @@ def profile_kernels(pm, run_step, n):
     return {k: float(np.mean(v)) for k, v in kern.items()}
 
 
-BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_walk_rows", "k_direct")
+BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_walk_rows", "k_sweep_rows", "k_direct")
 
 
 def measured_traffic(workload, pods, nodes):
     """profiles/traffic_r04.json (scripts/pmc_passes.sh + summarize_pmc.py: separate rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes,
     calibrated and corrected as MI355X_MICROARCH.md prescribes): HBM bytes per launch of every engine kernel for this population."""
-    for name in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json"):
+    for name in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tj = json.load(f)
@@ -237,7 +242,16 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
         return None
     dom = max(kern, key=kern.get)
     base = dom.split("(")[0]
-    step_traffic = traffic_source = None
+    step_traffic = traffic_source = int_ops = None
+    if isinstance(traffic, dict) and lay is not None:
+        # "report int-ops/eval to expose ALU-boundness" — wave-level VALU instructions (SQ_INSTS_VALU, its own rocprofv3
+        # --pmc pass) x 64 lanes / the evaluations of a step, for the dominant kernel and for the whole step
+        kv = traffic.get("kernels_per_step", {}).get(base, {}).get("valu_insts")
+        sv = traffic.get("step_valu_insts")
+        pairs = float(lay.num_pods) * lay.num_nodes
+        if kv is not None or sv is not None:
+            int_ops = {"kernel": None if kv is None else round(kv * 64 / pairs, 4), "step": None if sv is None else round(sv * 64 / pairs, 4),
+                       "unit": "VALU lane-operations per (pod, node) evaluation", "source": traffic.get("source")}
     if isinstance(traffic, dict):  # measured_traffic(): pick the dominant kernel's bytes per launch, keep the step's total
         # (the PMC passes are separate rocprofv3 runs — scripts/pmc_passes.sh; this line replays the committed summary for the same
         # workload and sizes, it does not count bytes itself)
@@ -249,8 +263,10 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
     band_bytes = (lay.band_rows * lay.row_words * 8) if lay is not None else 0
     if base == "k_expand_bands":
         own = band_bytes if lay is not None else algo_bytes
+    elif base == "k_sweep_rows" and lay is not None:  # the rows it writes — it reads no index row and a plane row per run start
+        own = lay.sweep_rows * lay.row_words * 8
     elif base == "k_walk_rows" and lay is not None:  # its bitmap rows + the index rows it decodes (one byte per word), nothing else
-        own = (lay.num_pods * lay.row_words * 8 - band_bytes) + lay.index_rows * lay.row_words
+        own = (lay.num_pods - lay.sweep_rows) * lay.row_words * 8 - band_bytes + lay.index_rows_walked * lay.row_words
     elif base in BITMAP_WRITERS:
         own = max(algo_bytes - band_bytes, 0)
     elif lay is not None and base in ("k_sig_planes", "k_base_planes", "k_planes", "k_dim_walk"):
@@ -260,7 +276,10 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
             "frac": round(achieved / HBM_PEAK_GBS, 4) if own else None, "traffic": traffic, "avg_launch_ms": round(kern[dom], 4),
             "traffic_source": traffic_source,
             "algorithmic_bytes": int(own) if own else None, "step_algorithmic_bytes": int(algo_bytes), "step_traffic": step_traffic,
-            "whole_step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            "whole_step_frac": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            # (the same number under the name VERDICT r5 asked for: `step_algorithmic_bytes` IS the §8(d) formula since round 6)
+            "whole_step_frac_8d": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "int_ops_per_eval": int_ops}
 
 
 def json_ingest_leg(pkg, dev, a, gang):
@@ -571,13 +590,28 @@ def main():
         else:
             try:
                 shard.attach_communicator(pm, dist, rank, world, first)
-            except Exception as exc:  # noqa: BLE001 - a scaling run must not die on the communicator; the line says what ran
+            except Exception as exc:  # noqa: BLE001 - reported below; whether the run goes on is the caller's choice
                 collectives = f"torch.distributed fallback (ykpred_comm_init failed: {exc})"
         flags_all = [None] * world
         dist.all_gather_object(flags_all, collectives)
         if any(f != "c-abi rccl" for f in flags_all) and collectives == "c-abi rccl":
             pm.comm_destroy()  # all ranks must take the same path
             collectives = "torch.distributed fallback (another rank could not create the communicator)"
+        wanted_abi = backend == "nccl" and os.environ.get("BENCH_COLLECTIVES") != "torch"
+        if wanted_abi and collectives != "c-abi rccl" and os.environ.get("BENCH_ALLOW_FALLBACK") != "1":
+            # a scaling line produced over torch.distributed is not a measurement of the C-ABI path. The run
+            # stops here with a non-zero exit and a line that says so (value null); BENCH_ALLOW_FALLBACK=1 runs the labelled fallback.
+            if rank == 0:
+                print(json.dumps({"metric": baseline_metric(), "value": None, "unit": "evals/s", "n_gpus": world, "steps": a.steps,
+                                  "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+                                  "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                                  "config": {"workload": "not run", "collectives": collectives},
+                                  "error": "the C-ABI communicator (ykpred_comm_init over librccl) could not be created on every rank; "
+                                           "set BENCH_ALLOW_FALLBACK=1 to time the torch.distributed reference exchanges instead",
+                                  "per_rank": flags_all}))
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(4)
     use_abi = collectives == "c-abi rccl"
     do_gather = strong and not a.no_gather
 
@@ -713,6 +747,11 @@ def main():
                       "per_peer_link_GBps": round(nbytes / (g_ms * 1e-3) / 1e9, 1), "layout": "[G][rows][row_stride] u64 (shard-major)",
                       "note": "device time of the last all-gather (max over ranks); every GPU receives one shard bitmap from each of its "
                               "world-1 peers, per_peer_link = one shard / that time" + ("; " + gather_note[0] if gather_note else "")}
+        # every rank holds the same gathered bitmap: a wrapping 64-bit sum of its words, compared across the ranks (outside the timed region)
+        checksums = [None] * world
+        dist.all_gather_object(checksums, int(gathered.view(-1).sum().item()))
+        gather["gathered_checksum"] = checksums[0]
+        gather["ranks_hold_the_same_gathered_bitmap"] = bool(len(set(checksums)) == 1)
         gather["step_without_gather_ms"] = round(no_gather_ms, 4)
         gather["evals_per_sec_without_gather"] = float(P) * total_nodes / (no_gather_ms * 1e-3)
 
@@ -743,6 +782,15 @@ def main():
         except Exception as exc:  # noqa: BLE001
             rounds = {"error": str(exc)}
     stats = pm.stats()
+    comm_report = None
+    if world > 1:
+        # what every rank's engine says about its communicator (ykpred_comm_info): rank, world and first node of the shard — the
+        # first multi-GPU run shows at a glance that N communicators of world N exist and that the shards tile the cluster
+        mine = dict(zip(("rank", "world", "node_offset"), pm.comm_info())) if use_abi else {"rank": rank, "world": world, "node_offset": first, "c_abi": False}
+        mine["nodes"] = N
+        reports = [None] * world
+        dist.all_gather_object(reports, mine)
+        comm_report = reports
     if use_abi:
         pm.comm_destroy()
     pm.close()
@@ -813,6 +861,8 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "host_setup_s": round(t_gen, 2), "encode_ms": round(stats["encode_us"] / 1e3, 1),
         }
+        if comm_report is not None:
+            out["communicators"] = comm_report
         if gather:
             out["bitmap_allgather"] = gather
             # the same step for consumers that need decisions + feasible counts only (the core's allocation loop): nothing but 16 bytes

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKLOADS = ("default", "own_template_per_ask", "unique_request_vectors", "configs4_one_gpu")
 SIZES = {"configs4_one_gpu": (5_000_000, 100_000)}  # (pods, nodes); the others: 1 000 000 x 50 000
 TIMER_LABEL = {"k_combine_wave": "k_combine", "k_fix_rows": "k_expand_bands",
-               "k_dim_sort": "k_dim_walk", "k_dim_prefix_max": "k_dim_walk", "k_rank_hist": "k_rank", "k_rank_scan": "k_rank",
+               "k_dim_prefix_max": "k_dim_walk", "k_dim_walk_window": "k_dim_walk", "k_rank_hist": "k_rank", "k_rank_scan": "k_rank",
                "k_rank_fill": "k_rank", "k_rank_final": "k_rank", "k_decide_groups": "k_decide"}
 
 
@@ -66,12 +66,29 @@ for wl in WORKLOADS:
         if mine_w + 2 * mine_f >= e["_top"]:
             e["_top"] = mine_w + 2 * mine_f
             e["launches_per_step"] = w[k]["launches"] / steps
+    # wave-level VALU instructions per step (its own --pmc SQ_INSTS_VALU pass, when scripts/r06_final.sh ran it): the int-ops/eval of
+    # SURVEY §8(d) = valu_insts x 64 lanes / (pods x nodes)
+    v = per_kernel(wl, "SQ_INSTS_VALU")
+    step_valu = None
+    if v:
+        step_valu = 0.0
+        for k in v:
+            if "ykk::" not in k:
+                continue
+            short = TIMER_LABEL.get(k.split("::")[-1].split("<")[0], k.split("::")[-1].split("<")[0])
+            mine = v[k]["avg_KiB"] * v[k]["launches"] / 4.0  # (per_kernel's field name says KiB; for this counter it is a plain count)
+            step_valu += mine
+            if short in kernels:
+                kernels[short]["valu_insts"] = kernels[short].get("valu_insts", 0.0) + mine
     for e in kernels.values():
         e["hbm_bytes"] = int(e["write_bytes"] + 2 * e["fetch_bytes_raw"])
         e["write_bytes"], e["fetch_bytes_raw"] = int(e["write_bytes"]), int(e["fetch_bytes_raw"])
         e.pop("_top", None)
     pods, nodes = SIZES.get(wl, (1_000_000, 50_000))
     traffic["workloads"][wl] = {"pods": pods, "nodes": nodes, "kernels_per_step": kernels, "step_hbm_bytes": int(sum(e["hbm_bytes"] for e in kernels.values()))}
+    if step_valu is not None:
+        traffic["workloads"][wl]["step_valu_insts"] = step_valu
+        traffic["workloads"][wl]["int_ops_per_eval"] = step_valu * 64 / (float(pods) * nodes)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(ROOT, "profiles", f"traffic_{rnd}.json"), "w"), indent=1)
 print(json.dumps({wl: {"step_hbm_bytes": t["step_hbm_bytes"], "top": sorted(((k, v["hbm_bytes"]) for k, v in t["kernels_per_step"].items()), key=lambda x: -x[1])[:4]}

@@ -438,6 +438,12 @@ class GpuPredicateManager:
     def comm_destroy(self):
         self._check(self._L.ykhost_comm_destroy(self._h))
 
+    def comm_info(self):
+        """(rank, world, node_offset) of the communicator attached to the engine — (0, 1, 0) without one (ykpred_comm_info)."""
+        r, w, o = C.c_int32(0), C.c_int32(1), C.c_int32(0)
+        self._pcheck(self._P.ykpred_comm_info(self.engine, C.byref(r), C.byref(w), C.byref(o)))
+        return int(r.value), int(w.value), int(o.value)
+
     def gather_bitmap(self, gathered=None, stream=None, compressed=False):
         """All-gather of the shard bitmaps of the last evaluation into [world][rows][row_stride] (device; engine-owned when
         `gathered` is None), on `stream`. compressed=True: the shards exchange their CLASS rows and every GPU expands the
