@@ -188,12 +188,19 @@ int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5);
  * decides an ask, AsyncRMCallback.UpdateAllocation → Context.AssumePod runs, scheduler_callback.go:49-98 / context.go:828-885,
  * and the next Predicates() call sees the node's new Requested / pod list). out_nodes[i] = node index, -1 = no node fits,
  * -2 = the ask is routed to the CPU manager (not evaluated by the engine) and takes no part in the round.
- * Where only node resources couple the asks, the whole round is ONE device call (ykpred_allocate_round); with active
- * topology constraints or host ports the host decides ask by ask (decision → AssumePod → column patch → next decision).
- * apply != 0: every ask that got a node is assumed in the mirror exactly as ykhost_assume_pod would (the ask-by-ask path
- * needs that to see its own allocations and refuses apply == 0 with YKHOST_E_UNSUPPORTED). → number of asks that got a node,
- * or a negative error. ykhost_round_stats: out[0] rounds decided by one device call, [1] asks decided in them, [2] asks decided
- * ask by ask, [3] asks routed. */
+ * The whole round is ONE device call (ykpred_allocate_round): node resources, pod slots, host ports and the match counts behind
+ * PodTopologySpread / InterPodAffinity are kept live on the device (the host uploads what a pod of every spec adds to its node:
+ * ykpred_set_spec_effects). Only when those effects are withheld (YKHOST_ROUND_ON_HOST=1, tests) does the host decide ask by ask
+ * (decision → AssumePod → column patch → next decision) — that path needs apply != 0 to see its own allocations and refuses
+ * apply == 0 with YKHOST_E_UNSUPPORTED.
+ * NODE-SHARDED cluster (a communicator with world > 1 is attached to the engine): the call is COLLECTIVE — every rank calls with the
+ * same asks in the same order — and node indices in out_nodes are indices in the WHOLE cluster (this shard's node 0 = its
+ * node_offset), identical on every rank; an ask that went to another shard's node is assumed here as well (it leaves the pending
+ * asks) without touching a node of this mirror. A sharded round the engine's collective form does not cover (topology constraints:
+ * an assumed pod moves histograms on every shard) returns YKHOST_E_UNSUPPORTED — it is never decided shard by shard.
+ * apply != 0: every ask that got a node is assumed in the mirror exactly as ykhost_assume_pod would. → number of asks that got a
+ * node, or a negative error. ykhost_round_stats: out[0] rounds decided by one device call, [1] asks decided in them, [2] asks
+ * decided ask by ask, [3] asks routed. */
 int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32_t apply, int32_t* out_nodes /* [n] */);
 int32_t ykhost_round_stats(ykhost_t* h, int64_t* out4);
 

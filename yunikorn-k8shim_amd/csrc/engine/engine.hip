@@ -271,6 +271,7 @@ struct ykpred_engine {
   std::vector<int32_t> h_class_sweep;  // [C] 1 = the class is a row of a sweep run
   int sweep_rows[ykk::kMaxIdxRows] = {0, 0}, sweep_row_off[ykk::kMaxIdxRows + 1] = {0, 0, 0}, sweep_runs = 0;  // per walked dimension
   int index_rows_needed = 0;         // index rows some class OUTSIDE the sweep runs reads (the full pass walks only those)
+  DevBuf d_agree;  // sharded rounds: what the ranks agree on before the first batch
   DevBuf d_sweep_rows, d_sweep_runs, d_sweep_units; // SweepRow {class, bitmap row, position, run}; SweepRun; unit bounds [units + 1] per walked dimension
   int sweep_units[ykk::kMaxIdxRows] = {0, 0}, sweep_unit_off[ykk::kMaxIdxRows + 1] = {0, 0, 0};
   DevBuf d_chunk_list_b0;            // [NCB0] the zone-B chunks outside the sweep runs (a pass with the sweep runs the chunk writers over these)
@@ -1421,7 +1422,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -2976,10 +2977,42 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   YK_SERIALISE(e);
   Range roctx_range("ykpred:allocate_round");
   if (!e || n_asks < 0 || (n_asks > 0 && (!asks || !out_nodes))) return fail(e, YKPRED_E_INVALID, "allocate_round: bad argument");
-  if (e->classes_dirty || !e->last_eval_valid || !e->rank_valid || e->bitmap_epoch != e->nodes_epoch || pre != e->last_pre || filt != e->last_filt ||
-      e->ranked_pre != pre || e->ranked_filt != filt || e->ranked_nodes_epoch != e->nodes_epoch || e->ranked_specs_version != e->specs_version)
-    return fail(e, YKPRED_E_STATE, "allocate_round: no current evaluation WITH decisions of these plugin lists (run ykpred_eval with YKPRED_OUT_DECISIONS)");
   const bool sharded = e->comm && e->comm_world > 1;
+  const bool stale = e->classes_dirty || !e->last_eval_valid || !e->rank_valid || e->bitmap_epoch != e->nodes_epoch || pre != e->last_pre || filt != e->last_filt ||
+                     e->ranked_pre != pre || e->ranked_filt != filt || e->ranked_nodes_epoch != e->nodes_epoch || e->ranked_specs_version != e->specs_version;
+  if (sharded) {
+    // The sharded round is collective: a rank that left through a rank-local exit (no current evaluation, a patched ask, a list that
+    // differs from the other ranks' — per-shard dictionaries can route different asks away) would leave the others blocked in the
+    // first all-gather. So the ranks AGREE first — status, ask count, a hash of the list — and all of them return the same error.
+    struct Agree {
+      int32_t rc, n;
+      u64 hash;
+    };
+    Agree mine{stale ? YKPRED_E_STATE : YKPRED_OK, n_asks, 0x9e3779b97f4a7c15ull};
+    for (int i = 0; i < n_asks; ++i) {
+      mine.hash = (mine.hash ^ (u64)(uint32_t)asks[i]) * 0x100000001b3ull;
+      if (asks[i] < 0 || asks[i] >= e->P) mine.rc = YKPRED_E_INVALID;
+      else if ((size_t)asks[i] < e->h_row_stale.size() && e->h_row_stale[(size_t)asks[i]]) mine.rc = YKPRED_E_STATE;
+    }
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int W = e->comm_world;
+    HIPCHK(e->d_agree.ensure((size_t)(W + 1) * sizeof(Agree)));
+    Agree* d = e->d_agree.as<Agree>();
+    HIPCHK(hipMemcpyAsync(d + W, &mine, sizeof(Agree), hipMemcpyHostToDevice, e->own_stream));
+    NCCLCHK(rccl()->AllGather(d + W, d, sizeof(Agree), ncclInt8, e->comm, e->own_stream));
+    std::vector<Agree> all((size_t)W);
+    HIPCHK(hipMemcpyAsync(all.data(), d, (size_t)W * sizeof(Agree), hipMemcpyDeviceToHost, e->own_stream));
+    HIPCHK(hipStreamSynchronize(e->own_stream));
+    for (int g = 0; g < W; ++g) {
+      if (all[(size_t)g].rc != YKPRED_OK)
+        return fail(e, all[(size_t)g].rc, "allocate_round (sharded): rank " + std::to_string(g) + " cannot run the round (no current evaluation with decisions, "
+                                          "an ask patched and not re-evaluated, or an ask index out of range): no rank runs it");
+      if (all[(size_t)g].n != mine.n || all[(size_t)g].hash != mine.hash)
+        return fail(e, YKPRED_E_INVALID, "allocate_round (sharded): rank " + std::to_string(g) + " was handed a different ask list: every rank passes the same asks in the same order");
+    }
+  }
+  if (stale)
+    return fail(e, YKPRED_E_STATE, "allocate_round: no current evaluation WITH decisions of these plugin lists (run ykpred_eval with YKPRED_OUT_DECISIONS)");
   const bool fx_current = e->fx_version == e->specs_version;
   const bool topo_on = (pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0;
   if (sharded && topo_on)

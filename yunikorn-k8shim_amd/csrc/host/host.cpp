@@ -2896,7 +2896,13 @@ int32_t ykhost_allocate_round(ykhost_t* h, int32_t n, const int32_t* asks, int32
     return placed;
   }
   if (rc != YKPRED_E_UNSUPPORTED) return fail(h, std::string("ykpred_allocate_round: ") + ykpred_last_error(h->eng), rc);
-  // ---- ask by ask: something other than node resources couples the asks (topology histograms, host ports, shards)
+  // A node-sharded cluster never decides ask by ask here: the path below takes this shard's own answer and assumes on this shard's
+  // node — every rank would place the ask on a different node, in shard-local indices. What the engine's collective round does not
+  // cover is refused as such; the caller keeps the per-pair Predicates() path of the CPU manager for these asks.
+  if (sharded)
+    return fail(h, std::string("a round on a node-sharded cluster that the engine's collective round does not cover (") + ykpred_last_error(h->eng) +
+                       "): not decided shard by shard", YKHOST_E_UNSUPPORTED);
+  // ---- ask by ask: something other than node resources couples the asks (topology histograms, host ports) and the specs' effects are withheld
   if (!apply) return fail(h, std::string("this round is decided ask by ask and has to assume as it goes (apply = 1): ") + ykpred_last_error(h->eng), YKHOST_E_UNSUPPORTED);
   ensure_uid_index(h);
   ykpred_layout_t lay{};
