@@ -212,7 +212,7 @@ def profile_kernels(pm, run_step, n):
     return {k: float(np.mean(v)) for k, v in kern.items()}
 
 
-BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_walk_rows", "k_sweep_rows", "k_direct")
+BITMAP_WRITERS = ("k_expand_bands", "k_combine", "k_combine_wave", "k_walk_rows", "k_sweep_rows", "k_class_runs", "k_direct")
 
 
 def measured_traffic(workload, pods, nodes):
@@ -263,6 +263,8 @@ def roofline_of(kern, algo_bytes, ms_per_step, traffic=None, lay=None, b_node=0)
     band_bytes = (lay.band_rows * lay.row_words * 8) if lay is not None else 0
     if base == "k_expand_bands":
         own = band_bytes if lay is not None else algo_bytes
+    elif base == "k_class_runs" and lay is not None:  # the rows it writes (a run's plane rows are read once per run, from L2)
+        own = lay.run_rows * lay.row_words * 8
     elif base == "k_sweep_rows" and lay is not None:  # the rows it writes — it reads no index row and a plane row per run start
         own = lay.sweep_rows * lay.row_words * 8
     elif base == "k_walk_rows" and lay is not None:  # its bitmap rows + the index rows it decodes (one byte per word), nothing else

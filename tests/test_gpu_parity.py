@@ -369,6 +369,41 @@ def test_sweep_writer_equals_chunk_writers_and_oracle(monkeypatch, n_nodes, n_po
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("n_nodes,n_pods", [(1500, 6000), (8300, 5000), (29000, 3000)], ids=["one-group", "three-groups", "two-segments"])
+def test_class_runs_writer_equals_chunk_writers_and_oracle(monkeypatch, n_nodes, n_pods):
+    """k_class_runs (round 6): the zone-B classes of one (toleration, affinity, spread) signature are written as a RUN — the AND of
+    the signature's rows once per run, a class = that & the request-value rows staged in LDS, stored to its member rows. Against
+    the chunk writers (YKPRED_TUNE class_runs=0) on the own-template population (every ask its own template: thousands of small
+    classes, one to a few rows each) — bitmap, counts, decisions, both phases — and against the oracle."""
+    got = {}
+    for knob in (0, 1):
+        monkeypatch.setenv("YKPRED_TUNE", f"class_runs={knob},class_runs_min_rows={1 if n_nodes == 8300 else 8}")
+        m = pkg.GpuPredicateManager()
+        try:
+            m.generate_kwok(seed=815 + n_nodes, num_nodes=n_nodes, num_pods=n_pods, num_templates=0, node_affinity=1)
+            m.evaluate()
+            lay = m.layout()
+            assert (lay.run_rows > n_pods // 4) if knob else (lay.run_rows == 0), lay.run_rows
+            assert m.check_class_rows() == 0
+            got[knob] = [unpack(m.read_bitmap(), n_nodes), m.read_counts(), m.read_decisions()]
+            m.evaluate(allocate=False)
+            got[knob] += [unpack(m.read_bitmap(), n_nodes), m.read_counts()]
+            m.evaluate()
+            assert np.array_equal(unpack(m.read_bitmap(), n_nodes), got[knob][0]) and np.array_equal(m.read_counts(), got[knob][1])
+            if knob:
+                o = orc.Oracle(m.dump_snapshot(compact=True))
+                sample = np.arange(n_pods) if n_nodes <= 1500 else np.random.default_rng(5).choice(n_pods, size=64, replace=False).astype(np.int32)
+                want = o.eval_grid(pods=sample, threads=os.cpu_count() or 8)
+                assert np.array_equal(got[knob][0][sample], want)
+                assert np.array_equal(got[knob][1][sample], want.sum(axis=1))
+                for k, p in enumerate(sample[:12]):
+                    assert o.decide(int(p)) == (int(want[k].sum()), int(got[knob][2][p]))
+        finally:
+            m.close()
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_sweep_writer_random_clusters_two_walked_dimensions(monkeypatch, seed):
     """Random edge-case clusters with every request dimension walked (walk_rows=1) and runs from two rows on: two walked dimensions

@@ -272,6 +272,11 @@ struct ykpred_engine {
   int sweep_rows[ykk::kMaxIdxRows] = {0, 0}, sweep_row_off[ykk::kMaxIdxRows + 1] = {0, 0, 0}, sweep_runs = 0;  // per walked dimension
   int index_rows_needed = 0;         // index rows some class OUTSIDE the sweep runs reads (the full pass walks only those)
   DevBuf d_agree;  // sharded rounds: what the ranks agree on before the first batch
+  // class runs (k_class_runs): zone-B classes WITHOUT an index row whose request-value rows are all staged, run by run
+  int class_runs = 1;                // tunable (YKPRED_TUNE class_runs): 0 = those classes stay with the chunk writers
+  int class_runs_min_rows = 16;      // tunable (class_runs_min_rows): rows of a signature from which its classes are written as a run
+  int run_classes = 0, run_units = 0, run_rows = 0;
+  DevBuf d_run_classes, d_run_units; // RunClass; unit bounds [run_units + 1]
   DevBuf d_sweep_rows, d_sweep_runs, d_sweep_units; // SweepRow {class, bitmap row, position, run}; SweepRun; unit bounds [units + 1] per walked dimension
   int sweep_units[ykk::kMaxIdxRows] = {0, 0}, sweep_unit_off[ykk::kMaxIdxRows + 1] = {0, 0, 0};
   DevBuf d_chunk_list_b0;            // [NCB0] the zone-B chunks outside the sweep runs (a pass with the sweep runs the chunk writers over these)
@@ -782,13 +787,42 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       }
     }
     auto is_cand = [&](int32_t c) { return sweep_possible && cand_slot[(size_t)c] >= 0; };
+    // BALLOT-ROW classes for k_class_runs: unpinned, no index row, at most four request-value rows, every one of them staged in LDS
+    // by the writers (h_stage_rows); run_slots = their slots, a byte each (n_stage: none — the all-ones row)
+    std::vector<int32_t> run_slots;
+    const bool runs_possible = e->class_runs != 0 && !e->h_res_rows.empty() && e->h_stage_rows.size() < 255;
+    if (runs_possible) {
+      run_slots.assign((size_t)C, -1);
+      const int n_stage = (int)e->h_stage_rows.size();
+      for (int32_t c : order_b) {
+        const int sr = key(c, 0);
+        if (class_pin[(size_t)c] != -1 || sr < 0 || (size_t)(sr + 1) * (size_t)R1 > e->h_res_rows.size()) continue;
+        const int32_t* rr = e->h_res_rows.data() + (size_t)sr * (size_t)R1;
+        int n = 0, packed = 0;
+        bool ok = true;
+        for (int k = 0; k < R1 && ok; ++k) {
+          const int r = rr[k];
+          if (r <= 0) continue;  // unused slot, or row 0 (part of every run's base)
+          if (r >> ykk::kRowBigShift) ok = false;
+          int slot = -1;
+          for (int q = 0; q < n_stage && ok; ++q)
+            if (e->h_stage_rows[(size_t)q] == r) slot = q;
+          if (slot < 0 || n >= 4) ok = false;
+          else packed |= slot << (8 * n++);
+        }
+        if (!ok) continue;
+        for (; n < 4; ++n) packed |= n_stage << (8 * n);
+        run_slots[(size_t)c] = packed;
+      }
+    }
+    auto kind_of = [&](int32_t c) { return is_cand(c) ? 2 : (runs_possible && run_slots[(size_t)c] >= 0 ? 1 : 0); };
     std::sort(order_b.begin(), order_b.end(), [&](int32_t x, int32_t y) {
       if (key(x, 2) != key(y, 2)) return key(x, 2) < key(y, 2);  // aff
       if (key(x, 1) != key(y, 1)) return key(x, 1) < key(y, 1);  // tol
       if (key(x, 3) != key(y, 3)) return key(x, 3) < key(y, 3);  // spread
-      const bool cx = is_cand(x), cy = is_cand(y);
-      if (cx != cy) return cy;                                     // the others first, by request vector as before
-      if (cx) {
+      const int kx = kind_of(x), ky = kind_of(y);
+      if (kx != ky) return kx < ky;                                // the others first, then the ballot-row classes, by request vector as before
+      if (kx == 2) {
         if (cand_big[(size_t)x] != cand_big[(size_t)y]) return cand_big[(size_t)x] < cand_big[(size_t)y];
         if (cand_slot[(size_t)x] != cand_slot[(size_t)y]) return cand_slot[(size_t)x] < cand_slot[(size_t)y];
         if (cand_pos[(size_t)x] != cand_pos[(size_t)y]) return cand_pos[(size_t)x] < cand_pos[(size_t)y];
@@ -804,9 +838,65 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     }
     e->n_classes_b = (int)order_b.size();
     TRY(upload(e, e->d_class_list_b, order_b.data(), order_b.size(), st));
+    std::vector<ykk::SweepRun> runs;  // of both kinds
+    e->run_classes = e->run_units = e->run_rows = 0;
+    if (runs_possible) {
+      std::vector<ykk::RunClass> rcs;
+      std::vector<int32_t> starts;  // 1 = the class starts a run
+      // A run is worth its start — a round of global loads and the wait for it, on a kernel with two workgroups per CU — from
+      // class_runs_min_rows rows on; the signatures with a handful of rows stay with k_combine_wave, whose many waves hide exactly
+      // that latency (measured on the own-template population, 410 k zone-B rows: every run through k_class_runs 0.89 ms, none 0.77 ms, the runs of 16 rows
+      // and more 0.42 ms = 5.0 TB/s for their 333 k rows + 0.34 ms of k_combine_wave for the 77 k single-row classes).
+      for (size_t i = 0; i < order_b.size();) {
+        const int32_t c = order_b[i];
+        if (kind_of(c) != 1) {
+          ++i;
+          continue;
+        }
+        size_t j = i;
+        long rows_in_run = 0;
+        while (j < order_b.size() && kind_of(order_b[j]) == 1 && key(order_b[j], 2) == key(c, 2) && key(order_b[j], 1) == key(c, 1) &&
+               key(order_b[j], 3) == key(c, 3)) {
+          rows_in_run += class_size[(size_t)order_b[j]];
+          ++j;
+        }
+        if (rows_in_run >= e->class_runs_min_rows) {
+          ykk::SweepRun run{};
+          run.st = key(c, 1), run.sa = key(c, 2), run.ss = key(c, 3), run.prow = 0;
+          runs.push_back(run);
+          for (size_t k = i; k < j; ++k) {
+            const int32_t m = order_b[k];
+            ykk::RunClass rc{};
+            rc.cls = m, rc.dest0 = first_row_of[(size_t)m], rc.len = class_size[(size_t)m], rc.slots = run_slots[(size_t)m], rc.run = (int32_t)runs.size() - 1;
+            rcs.push_back(rc);
+            starts.push_back(k == i ? 1 : 0);
+            e->h_class_sweep[(size_t)m] = 1;
+          }
+        }
+        i = j;
+      }
+      if (!rcs.empty()) {
+        const int n = (int)rcs.size();
+        auto cost = [&](int i) { return (long)rcs[(size_t)i].len + ykk::kRunsClassCost + (starts[(size_t)i] ? ykk::kSweepRunCost : 0); };
+        long total = 0;
+        for (int i = 0; i < n; ++i) total += cost(i);
+        const int want = std::max(1, std::min(n / 2, 2 * e->num_cus * ykk::kRunsWaves * 8));
+        std::vector<int32_t> units;
+        long acc = 0;
+        for (int i = 0; i < n; ++i) {
+          if ((long)units.size() < want && acc * want >= (long)units.size() * total) units.push_back(i);
+          acc += cost(i);
+        }
+        e->run_units = (int)units.size();
+        units.push_back(n);
+        e->run_classes = n;
+        for (const ykk::RunClass& rc : rcs) e->run_rows += rc.len;
+        TRY(upload(e, e->d_run_classes, rcs.data(), rcs.size(), st));
+        TRY(upload(e, e->d_run_units, units.data(), units.size(), st));
+      }
+    }
     if (sweep_possible) {
       std::vector<int32_t> rows_of[ykk::kMaxIdxRows];  // flattened int4 {class, bitmap row, position, run}
-      std::vector<ykk::SweepRun> runs;
       for (size_t i = 0; i < order_b.size();) {
         const int32_t c = order_b[i];
         if (!is_cand(c)) {
@@ -858,10 +948,9 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       }
       all_units.push_back(0);
       TRY(upload(e, e->d_sweep_units, all_units.data(), all_units.size(), st));
-      if (!runs.empty()) {
+      if (e->sweep_row_off[ykk::kMaxIdxRows] > 0) {
+        all_rows.push_back(0);
         TRY(upload(e, e->d_sweep_rows, all_rows.data(), all_rows.size(), st));
-        TRY(upload(e, e->d_sweep_runs, runs.data(), runs.size(), st));
-        e->sweep_ready = true;
         // The index rows somebody OUTSIDE the runs still reads (zone-A classes, short runs, shapes without a fast path): the full
         // pass walks only those (k_dim_walk over the reduced chunk lists below); a dirty-class pass walks them all.
         const int n_rows = (int)e->h_row_pos.size();
@@ -902,6 +991,12 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
         TRY(upload(e, e->d_walk2_begin, wbegin2.data(), wbegin2.size(), st));
         TRY(upload(e, e->d_walk2_len, wlen2.data(), wlen2.size(), st));
       }
+    }
+    if (getenv("YKPRED_TRACE_RUNS")) fprintf(stderr, "runs: %zu runs, %d run classes (%d rows, %d units), %d sweep rows\n", runs.size(), e->run_classes, e->run_rows, e->run_units, e->sweep_row_off[ykk::kMaxIdxRows]);
+    if (!runs.empty()) {
+      TRY(upload(e, e->d_sweep_runs, runs.data(), runs.size(), st));
+      e->sweep_runs = (int)runs.size();
+      e->sweep_ready = true;
     }
   }
   e->rows_total = next_row;
@@ -1374,6 +1469,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "round_prof") e->round_prof = val;
       else if (key == "sweep_min_run") e->sweep_min_run = std::max(val, 0);
       else if (key == "sweep_groups") e->sweep_groups = std::max(val, 0);
+      else if (key == "class_runs") e->class_runs = val;
+      else if (key == "class_runs_min_rows") e->class_runs_min_rows = std::max(val, 1);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
         delete e;
@@ -1422,7 +1519,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_run_classes, &e->d_run_units, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -2039,8 +2136,13 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   // k_sweep_rows takes the sweep runs of a FULL pass with NodeResourcesFit evaluated (the reservation phase has no request rows: every
   // class of a signature shares one row and the chunk writers do it); a dirty-class pass, a pass without PreFilter state for the
   // Filter, a class build whose runs were touched since — all fall back to the chunk writers, which know every chunk.
-  const bool use_sweep = e->sweep_ready && e->sweep_runs > 0 && res_on && !fit_error && e->n_big > 0 &&
-                         !(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES));
+  // (Not where the class counts are known before a row is written — counts_early below, a small zone B: those writers add nothing to
+  // the counts and the run kernels would count a class twice.)
+  const bool full_pass = !(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES));
+  const bool counts_early_here = e->early_counts != 0 && full_pass && e->n_classes_a > 0 && e->patch_chunks == 0 &&
+                                 !((long)e->NC * e->wave_combine_below > (long)P) && e->n_classes_b <= 16384;
+  const bool use_sweep = e->sweep_ready && e->sweep_runs > 0 && res_on && !fit_error && full_pass && !counts_early_here;
+  const bool sweep_rows_on = use_sweep && e->n_big > 0 && e->sweep_row_off[ykk::kMaxIdxRows] > 0;  // k_sweep_rows has rows (k_class_runs: run_classes)
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), use_sweep ? 1 : 0};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
@@ -2177,7 +2279,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
                       e->d_walk_len.as<int>(), (ranked ? e->d_sfree_r : e->d_sfree_c).as<i64>(), (ranked ? e->d_pmask_r : e->d_pmask_c).as<u64>(),
                       e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>(),
-                      (!ranked && use_sweep) ? e->d_ent_c.as<unsigned>() : nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>()};
+                      (!ranked && sweep_rows_on) ? e->d_ent_c.as<unsigned>() : nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>()};
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
       tm.end(s, ranked ? "k_dim_sort(ranked)" : "k_dim_sort");
@@ -2307,7 +2409,41 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                            e->d_fix_row.as<int>(), e->d_fix_slot.as<int>(), e->n_fix_rows, e->row_stride);
       tm.end(st, "k_expand_bands");
     }
-    if (use_sweep) {
+    if (use_sweep && e->run_classes > 0) {
+      // the runs of ballot-row classes (k_class_runs): the staged request-value rows in LDS, one persistent workgroup (or two) per CU
+      ykk::WalkStage rstage{};
+      rstage.n = (int)e->h_stage_rows.size();
+      for (int k = 0; k < rstage.n; ++k) rstage.row[k] = e->h_stage_rows[(size_t)k];
+      const int its = (e->row_stride + ykk::kWave - 1) / ykk::kWave;
+      int segs = (its + ykk::kWalkMaxIt - 1) / ykk::kWalkMaxIt, nit = (its + segs - 1) / segs;
+      while (nit > 1 && ykk::runs_lds_bytes(rstage.n, nit) > (size_t)e->max_lds_bytes) {
+        ++segs;
+        nit = (its + segs - 1) / segs;
+      }
+      const int n_long = segs - (nit * segs - its);
+      const size_t lds = ykk::runs_lds_bytes(rstage.n, nit);
+      const int per_cu = lds * 2 <= (size_t)e->max_lds_bytes ? 2 : 1;
+      const int groups = std::max(1, std::min(per_cu * e->num_cus, (e->run_units + ykk::kRunsWaves - 1) / ykk::kRunsWaves));
+      tm.begin(sz);
+      auto launch_runs = [&](auto kernel) -> int {
+        if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)groups, (unsigned)segs), dim3(ykk::kRunsThreads), lds, sz, pc, e->d_run_classes.as<ykk::RunClass>(),
+                           e->d_sweep_runs.as<ykk::SweepRun>(), e->run_classes, e->d_run_units.as<int>(), e->run_units, bitmap, e->row_words,
+                           e->row_stride, pin_on, e->d_class_count.as<int>(), n_long, rstage);
+        return YKPRED_OK;
+      };
+      switch (nit) {
+        case 1: TRY(launch_runs(ykk::k_class_runs<1>)); break;
+        case 2: TRY(launch_runs(ykk::k_class_runs<2>)); break;
+        case 3: TRY(launch_runs(ykk::k_class_runs<3>)); break;
+        case 4: TRY(launch_runs(ykk::k_class_runs<4>)); break;
+        case 5: TRY(launch_runs(ykk::k_class_runs<5>)); break;
+        case 6: TRY(launch_runs(ykk::k_class_runs<6>)); break;
+        default: TRY(launch_runs(ykk::k_class_runs<7>)); break;
+      }
+      tm.end(sz, "k_class_runs");
+    }
+    if (sweep_rows_on) {
       // the sweep runs: one launch per walked dimension, the row's segments in grid.y (whole 64-word groups, at most kWalkMaxIt per
       // lane, what the LDS holds — 65 list dwords per word), one persistent workgroup per compute unit and segment claiming batches of rows
       const int its = (e->row_stride + ykk::kWave - 1) / ykk::kWave;
@@ -3328,6 +3464,7 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->band_steps = e->band_steps_now;
   o->sweep_rows = e->sweep_ready ? e->sweep_row_off[ykk::kMaxIdxRows] : 0;
   o->index_rows_walked = (e->sweep_ready && e->walk2_chunks >= 0) ? e->index_rows_needed : e->index_rows;
+  o->run_rows = e->sweep_ready ? e->run_rows : 0;
   o->bitmap_bytes = (uint64_t)std::max(o->num_rows, 1) * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
   o->counts = e->last_counts ? e->last_counts : e->d_counts.p;

@@ -1973,6 +1973,145 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_class_runs: the zone-B writer of RUNS of ballot-row classes (round 6) — k_sweep_rows' sibling for classes without an index row.
+// The zone-B classes of one (toleration, affinity, spread) signature lie side by side (build_classes); they differ in nothing but
+// their request-value rows, and those are few (a palette of cpu and memory values): the ballot rows of the request family are staged
+// in LDS once per workgroup (WalkStage: at most kWalkMaxStage rows + an all-ones row), the AND of the signature's rows and row 0 is
+// fetched once per RUN and stays in registers, and a class is `base & staged rows` — no global load — stored to its member rows
+// (consecutive bitmap rows). k_combine_wave resolves every class on its own: three levels of dependent table loads, then four
+// plane rows per class from L2, a wait in front of every kilobyte it stores.
+struct RunClass {   // 32 bytes
+  int cls, dest0, len, slots;   // class, its first bitmap row, member rows, four staged-row slots (a byte each; WalkStage::n: none)
+  int run, pad0, pad1, pad2;
+};
+constexpr int kRunsWaves = 8;
+constexpr int kRunsThreads = kRunsWaves * kWave;
+constexpr int kRunsBatch = 16;    // class descriptors a wave keeps in LDS at a time
+constexpr int kRunsClassCost = 1; // what a class costs beside its rows, in rows (unit balance)
+__host__ __device__ inline size_t runs_lds_bytes(int n_stage, int nit) {
+  return (size_t)(n_stage + 1) * nit * kWave * sizeof(u64) + (size_t)kRunsWaves * kRunsBatch * 32;
+}
+template <int NIT>
+__global__ __launch_bounds__(kRunsThreads) void k_class_runs(
+    Planes pl, const RunClass* __restrict__ classes, const SweepRun* __restrict__ runs, int n_classes, const int* __restrict__ units /* [n_units + 1] */,
+    int n_units, u64* __restrict__ bitmap, int row_words, int row_stride, int pin_enabled, int* __restrict__ class_count, int n_long, WalkStage stage) {
+  extern __shared__ u64 runs_lds[];  // [stage.n + 1][SW] ballot rows of the request family (the last one all ones), [waves][kRunsBatch] descriptors
+  constexpr int SW = NIT * kWave;
+  const bool all_fail = pin_enabled & 2;
+  const int lane = threadIdx.x % kWave;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x / kWave);
+  const int seg = (int)blockIdx.y;
+  const int nit = seg < n_long ? NIT : NIT - 1;
+  const int w_first = (seg < n_long ? seg * NIT : n_long * NIT + (seg - n_long) * (NIT - 1)) * kWave;
+  const bool last_seg = seg == (int)gridDim.y - 1;
+  u64* s_stage = runs_lds;
+  int4* s_desc = (int4*)(s_stage + (size_t)(stage.n + 1) * SW) + wave * kRunsBatch * 2;
+  for (int i = (int)threadIdx.x; i < (stage.n + 1) * SW; i += kRunsThreads) {
+    const int k = i / SW, w = w_first + i % SW;
+    u64 v = ~0ull;
+    if (k < stage.n) {
+      int row = stage.row[0];
+#pragma unroll
+      for (int q = 1; q < kWalkMaxStage; ++q) row = k == q ? stage.row[q] : row;
+      v = w < row_words ? pl.res[(size_t)row * pl.stride + w] : 0ull;
+    }
+    s_stage[i] = v;
+  }
+  __syncthreads();
+  typedef const SweepRun __attribute__((address_space(4))) ConstRun;
+  typedef const int __attribute__((address_space(4))) ConstInt;
+  const ConstInt* ub = (const ConstInt*)(unsigned long long)units;
+  const int4* vcls = (const int4*)classes;  // two int4 per class
+  const int unit_step = (int)gridDim.x * kRunsWaves;
+  int u = (int)blockIdx.x * kRunsWaves + wave;
+  if (u >= n_units) return;
+  // (descriptors reach the loop through LDS, a batch at a time, the next batch's load issued a batch ahead — see k_sweep_rows)
+  auto fetch = [&](int cb) { return vcls[2 * (size_t)min(cb + (min(lane, 2 * kRunsBatch - 1) >> 1), n_classes - 1) + (lane & 1)]; };
+  int cb = ub[u], unit_end = ub[u + 1];
+  int4 d_nx = fetch(cb);
+  if (lane < 2 * kRunsBatch) s_desc[lane] = d_nx;
+  int c = cb, c1 = min(cb + kRunsBatch, unit_end);
+  d_nx = fetch(c1);
+  const int rw = all_fail ? 0 : row_words;
+  int4 da = s_desc[0], db = s_desc[1];
+  for (;;) {
+    // ---- a run begins: the AND of row 0 and the signature's rows, once
+    const int run = __builtin_amdgcn_readfirstlane(db.x);
+    u64 base[NIT];
+    {
+      const ConstRun* cr = (const ConstRun*)(unsigned long long)(runs + run);
+      const int st = cr->st, sa = cr->sa, ss = cr->ss;
+      const u64* p0 = pl.res + w_first + lane;
+      const u64* pt = (pl.tol && st >= 0) ? pl.tol + (size_t)st * pl.stride + w_first + lane : p0;
+      const u64* pa = (pl.aff && sa >= 0) ? pl.aff + (size_t)sa * pl.stride + w_first + lane : p0;
+      const u64* ps = (pl.spread && ss >= 0) ? pl.spread + (size_t)ss * pl.stride + w_first + lane : p0;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const u64 v = p0[it * kWave] & pt[it * kWave] & pa[it * kWave] & ps[it * kWave];
+        base[it] = (w_first + it * kWave + lane < rw && it < nit) ? v : 0ull;
+      }
+    }
+    // ---- the classes of the run that are this wave's
+    for (;;) {
+      const int cls = __builtin_amdgcn_readfirstlane(da.x), dest0 = __builtin_amdgcn_readfirstlane(da.y);
+      const int len = __builtin_amdgcn_readfirstlane(da.z), slots = __builtin_amdgcn_readfirstlane(da.w);
+      u64 m[NIT];
+      int cnt = 0;
+      {
+        const u64* r0 = s_stage + (slots & 255) * SW + lane;
+        const u64* r1 = s_stage + ((slots >> 8) & 255) * SW + lane;
+        const u64* r2 = s_stage + ((slots >> 16) & 255) * SW + lane;
+        const u64* r3 = s_stage + ((slots >> 24) & 255) * SW + lane;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          m[it] = base[it] & r0[it * kWave] & r1[it * kWave] & r2[it * kWave] & r3[it * kWave];
+          cnt += __popcll(m[it]);
+        }
+      }
+      const int pc = __builtin_amdgcn_readlane(wave_sum_lane63(cnt), 63);
+      // the next class's descriptor: in flight while this class is stored
+      ++c;
+      bool more = true;
+      if (c == c1) {
+        if (c < unit_end) {
+          cb = c;
+          if (lane < 2 * kRunsBatch) s_desc[lane] = d_nx;
+          c1 = min(cb + kRunsBatch, unit_end);
+          d_nx = fetch(c1);
+        } else {
+          u += unit_step;
+          if (u >= n_units) {
+            more = false;
+          } else {
+            cb = ub[u], unit_end = ub[u + 1];
+            d_nx = fetch(cb);
+            if (lane < 2 * kRunsBatch) s_desc[lane] = d_nx;
+            c = cb;
+            c1 = min(cb + kRunsBatch, unit_end);
+            d_nx = fetch(c1);
+          }
+        }
+      }
+      if (more) da = s_desc[2 * (c - cb)], db = s_desc[2 * (c - cb) + 1];
+      u64* dst = bitmap + (size_t)dest0 * row_stride + w_first + lane;
+      for (int i = 0; i < len; ++i, dst += row_stride) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          if (it < NIT - 2) {
+            dst[it * kWave] = m[it];
+          } else if (it < nit) {
+            if (!last_seg || it < nit - 1 || w_first + it * kWave + lane < row_stride) dst[it * kWave] = m[it];
+          }
+        }
+      }
+      if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
+      if (!more) return;
+      if (__builtin_amdgcn_readfirstlane(db.x) != run) break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // zone A of the bitmap: written with the store pattern of a linear fill (scripts/fill_probe*.hip)
 // ---------------------------------------------------------------------------------------------------
 // Measured on MI355X: of all ways to write the 6.27 GB bitmap only ONE reaches the hipMemset rate (6.4 TB/s against 5.4 for
