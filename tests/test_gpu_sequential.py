@@ -196,6 +196,30 @@ def test_binpacking_e2e_node_order_on_the_device(pm, case):
     assert st["rounds_on_device"] == before["rounds_on_device"] + 1 and st["asks_one_by_one"] == before["asks_one_by_one"]
 
 
+@pytest.mark.parametrize("run_decide", [1, 0])
+def test_allocation_round_on_a_population_of_sweep_runs(monkeypatch, run_decide):
+    """Every ask its own cpu request (index rows, sweep runs): the snapshot decisions of these classes come from k_run_decide, which
+    leaves the rank-ordered WINDOWS of their index rows unwritten — the round's class descriptors read every window, so the round
+    completes them first (complete_windows). Every decision of the round against the oracle's sequential loop, with the run-level
+    decisions on and off."""
+    monkeypatch.setenv("YKPRED_TUNE", f"run_decide={run_decide}")
+    m = pkg.GpuPredicateManager()
+    try:
+        m.generate_kwok(seed=0x59554E49 + 31, num_nodes=700, num_pods=4000, num_templates=0, node_affinity=1, unique_requests=1)
+        m.evaluate(decisions=True)
+        assert m.layout().sweep_rows > 3000
+        o = orc.Oracle(m.dump_snapshot())
+        dec = m.read_decisions()
+        for p in range(0, 4000, 97):  # the snapshot decisions themselves
+            assert o.decide(p)[1] == int(dec[p]), p
+        want = o.allocate_sequential()
+        got = m.allocate_round()
+        assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+        assert (got >= 0).sum() > 500
+    finally:
+        m.close()
+
+
 def test_allocation_round_reference_perf_shape(pm):
     """scheduler_perf_test.go's shape at a tenth of its size (the full 5 000 x 50 000 is bench.py's `allocation_round` leg): the
     asks fill node after node in NodeID order, 110 pods each."""

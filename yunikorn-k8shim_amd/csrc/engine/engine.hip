@@ -272,6 +272,11 @@ struct ykpred_engine {
   int sweep_rows[ykk::kMaxIdxRows] = {0, 0}, sweep_row_off[ykk::kMaxIdxRows + 1] = {0, 0, 0}, sweep_runs = 0;  // per walked dimension
   int index_rows_needed = 0;         // index rows some class OUTSIDE the sweep runs reads (the full pass walks only those)
   DevBuf d_agree;  // sharded rounds: what the ranks agree on before the first batch
+  // decisions of the sweep runs (k_run_decide): one range per run of the sweep row list, the classes k_decide leaves to it
+  int run_decide = 1;                // tunable (YKPRED_TUNE run_decide): 0 = k_decide scans every class
+  int run_ranges = 0, n_decide_list = 0;
+  bool win_partial = false;          // the rank-ordered windows of the last decision pass cover only the rows k_decide read (a round walks them all first)
+  DevBuf d_run_ranges, d_no_decide, d_glin_r;  // RunRange; the classes k_decide still scans (int list); g of every node's free value in rank order [n_big][row_words * 64]
   // class runs (k_class_runs): zone-B classes WITHOUT an index row whose request-value rows are all staged, run by run
   int class_runs = 1;                // tunable (YKPRED_TUNE class_runs): 0 = those classes stay with the chunk writers
   int class_runs_min_rows = 16;      // tunable (class_runs_min_rows): rows of a signature from which its classes are written as a run
@@ -743,6 +748,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
   e->h_class_sweep.assign((size_t)C, 0);
   e->sweep_ready = false;
   e->sweep_runs = 0;
+  e->run_ranges = 0;
   e->walk2_chunks = -1;
   e->index_rows_needed = e->index_rows;
   for (int b = 0; b < ykk::kMaxIdxRows; ++b) e->sweep_rows[b] = 0;
@@ -924,11 +930,21 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       }
       e->sweep_runs = (int)runs.size();
       std::vector<int32_t> all_rows, all_units;
+      std::vector<ykk::RunRange> ranges;
+      std::vector<uint8_t> no_decide((size_t)C, 0);
       e->sweep_row_off[0] = 0;
       e->sweep_unit_off[0] = 0;
       for (int b = 0; b < ykk::kMaxIdxRows; ++b) {
         const int n = (int)(rows_of[b].size() / 4);
         e->sweep_rows[b] = n;
+        for (int i = 0; i < n;) {  // one range per run of this dimension's list
+          int j = i + 1;
+          while (j < n && rows_of[b][(size_t)j * 4 + 3] == rows_of[b][(size_t)i * 4 + 3]) ++j;
+          for (int q = i; q < j; q += ykk::kRunDecideRows)
+            ranges.push_back(ykk::RunRange{rows_of[b][(size_t)i * 4 + 3], b, (int32_t)(all_rows.size() / 4) + q, std::min(ykk::kRunDecideRows, j - q)});
+          i = j;
+        }
+        for (int i = 0; i < n; ++i) no_decide[(size_t)rows_of[b][(size_t)i * 4]] = 1;
         all_rows.insert(all_rows.end(), rows_of[b].begin(), rows_of[b].end());
         e->sweep_row_off[b + 1] = e->sweep_row_off[b] + n;
         // units of equal estimated cost (a row = 1, a run start = kSweepRunCost): eight per wave of a full launch, none empty
@@ -948,9 +964,18 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       }
       all_units.push_back(0);
       TRY(upload(e, e->d_sweep_units, all_units.data(), all_units.size(), st));
+      e->run_ranges = 0;
       if (e->sweep_row_off[ykk::kMaxIdxRows] > 0) {
         all_rows.push_back(0);
         TRY(upload(e, e->d_sweep_rows, all_rows.data(), all_rows.size(), st));
+        e->run_ranges = (int)ranges.size();
+        TRY(upload(e, e->d_run_ranges, ranges.data(), ranges.size(), st));
+        std::vector<int32_t> decide_list;
+        for (int c = 0; c < C; ++c)
+          if (!no_decide[(size_t)c]) decide_list.push_back(c);
+        e->n_decide_list = (int)decide_list.size();
+        decide_list.push_back(0);
+        TRY(upload(e, e->d_no_decide, decide_list.data(), decide_list.size(), st));
         // The index rows somebody OUTSIDE the runs still reads (zone-A classes, short runs, shapes without a fast path): the full
         // pass walks only those (k_dim_walk over the reduced chunk lists below); a dirty-class pass walks them all.
         const int n_rows = (int)e->h_row_pos.size();
@@ -1348,6 +1373,21 @@ int ensure_histograms(ykpred_engine* e, hipStream_t st) {
 
 // The rank-ordered planes as the decision kernels address them (ykpred_eval's decision branch; ykpred_allocate_round re-reads
 // what that branch left in the buffers).
+// The rank-ordered windows of EVERY index row (k_dim_walk_window) from the sorted lists and the running maxima the last decision pass
+// left: a pass whose sweep classes got their decisions from k_run_decide wrote only the windows k_decide read; a round's class
+// descriptors read them all.
+int complete_windows(ykpred_engine* e, hipStream_t st) {
+  if (!e->win_partial || e->n_big == 0 || e->walk_chunks == 0) return YKPRED_OK;
+  ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
+                  e->d_walk_len.as<int>(), e->d_sfree_r.as<i64>(), e->d_pmask_r.as<u64>(), e->n_big, e->walk_chunks, e->row_words, nullptr,
+                  nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>(), nullptr};
+  const unsigned gy = (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords));
+  hipLaunchKernelGGL(ykk::k_dim_walk_window, dim3((unsigned)e->walk_chunks, gy), dim3(ykk::kBlock), 0, st, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+  HIPCHK(hipGetLastError());
+  e->win_partial = false;
+  return YKPRED_OK;
+}
+
 ykk::Planes ranked_planes_of(const ykpred_engine* e, unsigned pre, unsigned filt, bool spread_on, bool with_first) {
   const bool res_on = filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT, aff_on = (filt | pre) & YKPRED_PLUGIN_NODE_AFFINITY;
   const int fit_error = (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT) ? 0 : 1;
@@ -1470,6 +1510,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "sweep_min_run") e->sweep_min_run = std::max(val, 0);
       else if (key == "sweep_groups") e->sweep_groups = std::max(val, 0);
       else if (key == "class_runs") e->class_runs = val;
+      else if (key == "run_decide") e->run_decide = val;
       else if (key == "class_runs_min_rows") e->class_runs_min_rows = std::max(val, 1);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
@@ -1519,7 +1560,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_run_classes, &e->d_run_units, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_run_ranges, &e->d_no_decide, &e->d_glin_r, &e->d_run_classes, &e->d_run_units, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -2065,6 +2106,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     for (DevBuf* b : {&e->d_pmask_c, &e->d_pmask_r}) HIPCHK(b->ensure(cells * 65 * sizeof(u64)));
     HIPCHK(e->d_rbits_c.ensure(cells * ykk::kRankBits * sizeof(u64)));
     HIPCHK(e->d_ent_c.ensure(cells * 65 * sizeof(unsigned)));
+    HIPCHK(e->d_glin_r.ensure(cells * 65 * sizeof(unsigned)));  // (g per node + the largest g per word)
     // (a forced row stride — unequal shards — may exceed the rounded row length: consumers address index bytes by row word)
     const int idx_stride_before = e->idx_stride;
     e->idx_stride = (std::max(e->row_words, e->row_stride) + 63) / 64 * 64;
@@ -2097,6 +2139,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
 
   // Everything below only ENQUEUES work (kernels, memsets, cross-stream events) on `st` / the decision stream, so one pass
   // can be captured into a hipGraph. Returns 1 when the pass ends early (histograms only, per-pair kernel).
+  bool use_run_decide_pass = false;  // (set by enqueue: the pass left windows only for the rows k_decide read)
   auto enqueue = [&]() -> int {
   if (spread_on || (a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY)) {
     const bool ready = a->options & YKPRED_EVAL_SPREAD_COUNTS_READY, only = a->options & YKPRED_EVAL_SPREAD_COUNT_ONLY;
@@ -2143,8 +2186,14 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                                  !((long)e->NC * e->wave_combine_below > (long)P) && e->n_classes_b <= 16384;
   const bool use_sweep = e->sweep_ready && e->sweep_runs > 0 && res_on && !fit_error && full_pass && !counts_early_here;
   const bool sweep_rows_on = use_sweep && e->n_big > 0 && e->sweep_row_off[ykk::kMaxIdxRows] > 0;  // k_sweep_rows has rows (k_class_runs: run_classes)
+  // the decisions of the sweep runs come from k_run_decide wherever decisions are produced from walked request rows (any pass, also a
+  // decision refresh without the bitmap): k_decide skips those classes and no window of their index rows is written
+  const bool use_run_decide = e->run_decide != 0 && e->sweep_ready && e->run_ranges > 0 && res_on && !fit_error && e->n_big > 0 &&
+                              (a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->walk2_chunks >= 0;
+  use_run_decide_pass = use_run_decide;
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), use_sweep ? 1 : 0};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), use_sweep ? 1 : 0,
+                     use_run_decide ? e->d_no_decide.as<int>() : nullptr};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
                  nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -2279,7 +2328,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
                       e->d_walk_len.as<int>(), (ranked ? e->d_sfree_r : e->d_sfree_c).as<i64>(), (ranked ? e->d_pmask_r : e->d_pmask_c).as<u64>(),
                       e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>(),
-                      (!ranked && sweep_rows_on) ? e->d_ent_c.as<unsigned>() : nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>()};
+                      (!ranked && sweep_rows_on) ? e->d_ent_c.as<unsigned>() : nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>(),
+                      (ranked && use_run_decide) ? e->d_glin_r.as<unsigned>() : nullptr};
       tm.begin(s);
       hipLaunchKernelGGL(ykk::k_dim_sort, dim3((unsigned)e->n_big, wgroups), dim3(ykk::kBlock), 0, s, nt, perm, dw);
       tm.end(s, ranked ? "k_dim_sort(ranked)" : "k_dim_sort");
@@ -2303,7 +2353,20 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         // running maximum of the free values along the bin-pack order: where a value's row can start (k_decide) — and the window
         // of the row that is worth writing in rank order (k_dim_walk_window)
         hipLaunchKernelGGL(ykk::k_dim_prefix_max, dim3((unsigned)e->n_big), dim3(ykk::kPfxBlock), 0, s, dw, e->d_pfx_r.as<i64>());
-        hipLaunchKernelGGL(ykk::k_dim_walk_window, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+        if (use_run_decide) {
+          // only the windows k_decide reads (the classes outside the sweep runs); a round completes them first (complete_windows)
+          if (e->walk2_chunks > 0) {
+            ykk::DimWalk dw2 = dw;
+            dw2.order = e->d_walk2_order.as<int>();
+            dw2.chunk_big = e->d_walk2_big.as<int>();
+            dw2.chunk_begin = e->d_walk2_begin.as<int>();
+            dw2.chunk_len = e->d_walk2_len.as<int>();
+            dw2.n_chunks = e->walk2_chunks;
+            hipLaunchKernelGGL(ykk::k_dim_walk_window, dim3((unsigned)e->walk2_chunks, walk_gy), dim3(ykk::kBlock), 0, s, dw2, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+          }
+        } else {
+          hipLaunchKernelGGL(ykk::k_dim_walk_window, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+        }
       }
       tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
     } else if (res_on && e->n_big > 0) {
@@ -2333,15 +2396,26 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       // the signatures again in permuted node order is cheaper
       launch_ballot_planes(sb, e->d_perm.as<int>(), "k_planes(ranked)");
     }
+    if (use_run_decide) {
+      tm.begin(sb);
+      hipLaunchKernelGGL(ykk::k_run_decide, dim3((unsigned)((e->run_ranges + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, pr,
+                         e->d_sweep_runs.as<ykk::SweepRun>(), e->d_run_ranges.as<ykk::RunRange>(), e->run_ranges, e->d_sweep_rows.as<ykk::SweepRow>(),
+                         e->d_glin_r.as<unsigned>(), e->d_sorted.as<i64>(), e->d_sorted_off.as<int>(), e->d_perm.as<int>(), e->row_words, N, pin_on,
+                         e->d_class_best.as<int>());
+      tm.end(sb, "k_run_decide");
+    }
     tm.begin(sb);
-    if (e->C >= e->decide_groups_from) {
+    const int n_decide = use_run_decide ? e->n_decide_list : e->C;
+    if (n_decide == 0) {
+      // (every class is a row of a sweep run)
+    } else if (n_decide >= e->decide_groups_from) {
       // many classes: four per wave (k_decide_groups)
       const int per_block = ykk::kWavesPerBlock * ykk::kDecideGroups;
-      hipLaunchKernelGGL(ykk::k_decide_groups, dim3((unsigned)((e->C + per_block - 1) / per_block)), dim3(ykk::kBlock), 0, sb, ct, pr, e->C,
+      hipLaunchKernelGGL(ykk::k_decide_groups, dim3((unsigned)((n_decide + per_block - 1) / per_block)), dim3(ykk::kBlock), 0, sb, ct, pr, n_decide,
                          e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>());
     } else {
-      hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((e->C + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
-                         pr, e->C, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>(), e->C <= 4096 ? 1 : 0);
+      hipLaunchKernelGGL(ykk::k_decide, dim3((unsigned)((n_decide + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock)), dim3(ykk::kBlock), 0, sb, ct,
+                         pr, n_decide, e->row_words, e->d_perm.as<int>(), e->d_rank.as<int>(), pin_on, e->d_class_best.as<int>(), n_decide <= 4096 ? 1 : 0);
     }
     tm.end(sb, "k_decide");
   }
@@ -2649,6 +2723,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) e->n_full_evals++;
   if (!(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES))) std::fill(e->h_row_stale.begin(), e->h_row_stale.end(), 0);
   if (want_dec) {
+    e->win_partial = use_run_decide_pass;
     e->rank_valid = true;
     e->ranked_specs_version = e->specs_version;
     e->ranked_nodes_epoch = e->nodes_epoch;
@@ -3222,7 +3297,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   nt.count = (const int*)(base + o_cnt);
   if (live_ports) nt.ports = (const u64*)(base + o_ports);
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), 0};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), 0, nullptr};
   const bool spread_err = ((filt & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD) && !(pre & YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD)) ||
                           ((filt & YKPRED_PLUGIN_INTER_POD_AFFINITY) && !(pre & YKPRED_PLUGIN_INTER_POD_AFFINITY)) ||
                           ((filt & YKPRED_PLUGIN_NODE_PORTS) && !(pre & YKPRED_PLUGIN_NODE_PORTS));
@@ -3301,6 +3376,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       hipLaunchKernelGGL(ykk::k_round_topo_init, dim3((unsigned)e->spread_constraints), dim3(ykk::kWave), 0, st, stbl.spread, e->spread_constraints,
                          (int*)(base + o_mn), (int*)(base + o_at), (int*)(base + o_nd));
   }
+  TRY(complete_windows(e, st));  // (the class descriptors read the window of every index row)
   const ykk::Planes pr = ranked_planes_of(e, pre, filt, false, e->ranked_has_first);
   // the plane rows of every class, resolved once (the loop reads a class's descriptor in one load round instead of walking the tables)
   ra.cdesc = (const u64*)(base + o_cdesc);
@@ -4010,7 +4086,7 @@ int expand_class_rows_into(ykpred_engine_t* e, const u64* class_rows, u64* out, 
   }
   HIPCHK(e->d_expand_count.ensure((size_t)C * sizeof(int)));
   ykk::ClassTable ct{e->d_class_sig_ident.as<int>(), e->d_class_pin.as<int>(), e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), 0};
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), 0, nullptr};
   ykk::Planes pl{nullptr, class_rows, nullptr, nullptr, e->row_stride, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (e->n_classes_a > 0) {
     HIPCHK(e->d_class_rows_slot.ensure((size_t)e->n_classes_a * (size_t)e->row_stride * sizeof(u64)));

@@ -330,6 +330,8 @@ struct DimWalk {
   unsigned* ent;
   const i64* sorted;       // the walked dimensions' request values, ascending, dimension after dimension
   const int* sorted_off;   // [n_big + 1] into `sorted`
+  unsigned* glin;          // rank order, k_run_decide (null = not kept): glin[(big * n_words + word) * 64 + lane] = g of that node's free value;
+                           // behind them [n_big][n_words]: the largest g of every word
 };
 // blockIdx.x: walked dimension, blockIdx.y: group of 4 words; wave = word, lane = node position
 __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __restrict__ perm, DimWalk a) {
@@ -364,16 +366,26 @@ __global__ __launch_bounds__(kBlock) void k_dim_sort(NodeTable t, const int* __r
     }
     if (lane < kRankBits) a.rbits[((size_t)blockIdx.x * kRankBits + lane) * a.n_words + word] = plane;
   }
-  if (a.ent) {
+  if (a.ent || a.glin) {
     const i64* sv = a.sorted + a.sorted_off[blockIdx.x];
     int lo = 0, hi = a.sorted_off[blockIdx.x + 1] - a.sorted_off[blockIdx.x];  // upper bound: values [0, lo) are <= fr
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (sv[mid] <= fr) lo = mid + 1; else hi = mid;
     }
-    unsigned* col = a.ent + (size_t)blockIdx.x * 65 * a.n_words + word;
-    col[(size_t)rank * a.n_words] = ((unsigned)lo << 6) | (unsigned)lane;
-    if (lane == 0) col[(size_t)64 * a.n_words] = 0xffffffffu;
+    if (a.ent) {
+      unsigned* col = a.ent + (size_t)blockIdx.x * 65 * a.n_words + word;
+      col[(size_t)rank * a.n_words] = ((unsigned)lo << 6) | (unsigned)lane;
+      if (lane == 0) col[(size_t)64 * a.n_words] = 0xffffffffu;
+    }
+    if (a.glin) {
+      const unsigned g = valid ? (unsigned)lo : 0u;
+      a.glin[((size_t)blockIdx.x * a.n_words + word) * 64 + lane] = g;
+      unsigned mx = g;  // the word's largest g, behind the per-node values: k_run_decide looks at a word's nodes only where that can matter
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, kWave));
+      if (lane == 0) a.glin[(size_t)a.n_big * a.n_words * 64 + (size_t)blockIdx.x * a.n_words + word] = mx;
+    }
   }
 }
 // blockIdx.x: walk chunk, blockIdx.y: block of 256 * kWalkWords words; thread = kWalkWords ADJACENT words.
@@ -1114,6 +1126,7 @@ struct ClassTable {
   const int* chunk_zone;   // [NC] 1 = the chunk's class lives in zone A (the full pass writes it with k_expand_bands); 2 = zone B,
                            // a class of a sweep run: written by k_sweep_rows in the full passes that run it (sweep_on), else like zone B
   int sweep_on;
+  const int* decide_list;  // or null: the classes k_decide scans (those whose decision does not come from k_run_decide), n_classes = their number
 };
 // full pass: is the chunk left to another writer (the band writer, k_sweep_rows)?
 __device__ __forceinline__ bool chunk_elsewhere(const ClassTable& ct, int chunk) {
@@ -2299,6 +2312,7 @@ __global__ __launch_bounds__(kBlock) void k_decide(ClassTable ct, Planes ranked,
                                                    const int* __restrict__ rank, int pin_enabled, int* __restrict__ class_best, int eager) {
   int cls = blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   if (cls >= n_classes) return;
+  if (ct.decide_list) cls = ct.decide_list[cls];
   const int lane = threadIdx.x % kWave;
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
   const bool all_fail = pin_enabled & 2;
@@ -2361,7 +2375,7 @@ __global__ __launch_bounds__(kBlock) void k_decide_groups(ClassTable ct, Planes 
   const int lane = threadIdx.x % kWave, g = lane / kDecideLanes, l = lane % kDecideLanes;
   const int cls_raw = wave * kDecideGroups + g;
   const bool live = cls_raw < n_classes;
-  const int cls = live ? cls_raw : n_classes - 1;
+  const int cls = ct.decide_list ? ct.decide_list[live ? cls_raw : n_classes - 1] : (live ? cls_raw : n_classes - 1);
   const bool all_fail = pin_enabled & 2;
   // every lane of the group reads the same table entries (one broadcast load each): no cross-lane traffic needed afterwards
   const int sr = ct.sig[cls * 4 + 0], st = ct.sig[cls * 4 + 1], sa = ct.sig[cls * 4 + 2], ss = ct.sig[cls * 4 + 3];
@@ -2403,6 +2417,97 @@ __global__ __launch_bounds__(kBlock) void k_decide_groups(ClassTable ct, Planes 
 }
 
 // decision key = order-preserving signed image of the node's sortable score key (smaller = earlier in bin-pack order)
+// The decisions of the SWEEP RUNS (round 6). A run's rows share every plane row and ascend in the value of one walked dimension, so
+// their first feasible nodes in bin-pack order are one monotone staircase: walking the rank order once, a node enters the answer only
+// where it holds MORE of the dimension than every feasible node before it (a record of g = its free value's position among the sorted
+// request values, k_dim_sort), and it is the decision of every row of the run whose position lies below that record and above the
+// record before. One wave per run: the AND of the run's rank-ordered plane rows, 64 words at a time, the records found lane by lane,
+// the rows handed their node in order — no window of an index row is written or read for them (k_dim_walk_window), no scan per class
+// (k_decide). The scan starts where the smallest value of the run can first have a node (pfx: running maximum of the free values
+// along the order) and ends with the run's last row.
+constexpr int kRunDecideRows = 512;  // rows of a run one wave decides (a longer run is cut: every piece scans from where ITS smallest value can
+                                     // first have a node to its own last row — the scan is cheap, a wave walking 65 000 rows is not)
+struct RunRange {
+  int run, big, begin, count;  // run (SweepRun), walked dimension, first row in the sweep row list, rows
+};
+__global__ __launch_bounds__(kBlock) void k_run_decide(Planes ranked, const SweepRun* __restrict__ runs, const RunRange* __restrict__ ranges, int n_ranges,
+                                                       const SweepRow* __restrict__ rows, const unsigned* __restrict__ glin, const i64* __restrict__ sorted,
+                                                       const int* __restrict__ sorted_off, const int* __restrict__ perm, int n_words, int n_nodes,
+                                                       int pin_enabled, int* __restrict__ class_best) {
+  const int k = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWavesPerBlock + threadIdx.x / kWave));
+  if (k >= n_ranges) return;
+  const int lane = threadIdx.x % kWave;
+  const RunRange rr = ranges[k];
+  const SweepRun run = runs[rr.run];
+  const int4* vrow = (const int4*)(rows + rr.begin);
+  const bool all_fail = pin_enabled & 2;
+  const u64* p0 = ranked.res;
+  const u64* pp = ranked.res ? ranked.res + (size_t)run.prow * ranked.stride : nullptr;
+  const u64* pt = (ranked.tol && run.st >= 0) ? ranked.tol + (size_t)run.st * ranked.stride : p0;
+  const u64* pa = (ranked.aff && run.sa >= 0) ? ranked.aff + (size_t)run.sa * ranked.stride : p0;
+  const u64* ps = (ranked.spread && run.ss >= 0) ? ranked.spread + (size_t)run.ss * ranked.stride : p0;
+  const unsigned* gl = glin + (size_t)rr.big * n_words * 64;
+  const unsigned* gmax = glin + (size_t)ranked.n_big * n_words * 64 + (size_t)rr.big * n_words;
+  int i = 0, ib = 0;  // the next row without a node; the batch of 64 rows the lanes hold
+  int4 d = vrow[min(lane, rr.count - 1)];
+  int start = 0;
+  if (ranked.pfx) {  // the first word the run's smallest value can have a node in
+    const i64 v = sorted[sorted_off[rr.big] + __builtin_amdgcn_readfirstlane(d.z)];
+    const i64* px = ranked.pfx + (size_t)rr.big * n_words;
+    int lo = 0, hi = n_words;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (px[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    start = lo;
+  }
+  // the largest g among the feasible nodes so far — from the range's first position on: a node below it decides no row of the range
+  unsigned cur = (unsigned)__builtin_amdgcn_readfirstlane(d.z);
+  if (!all_fail && p0)
+    for (int wb = start & ~(kWave - 1); wb < n_words && i < rr.count; wb += kWave) {
+      const int w = wb + lane;
+      const u64 S = w < n_words ? (p0[w] & pp[w] & pt[w] & pa[w] & ps[w]) : 0ull;
+      const unsigned wmx = w < n_words ? gmax[w] : 0u;
+      u64 done_mask = 0;  // the words of the block looked at so far (in ascending order: a word passed over stays passed over — cur only grows)
+      for (;;) {
+        // the words of the block that have a feasible node AND a node that can set a record (their nodes are looked at one word at
+        // a time: a load per word, in order — so as few words as possible)
+        const u64 todo = __ballot(S != 0 && wmx > cur) & ~done_mask;
+        if (!todo || i >= rr.count) break;
+        const int wk = __ffsll((long long)todo) - 1;
+        done_mask |= (2ull << wk) - 1;
+        const u64 Sk = (u64)readlane_i64((i64)S, wk);
+        const unsigned g = gl[(size_t)(wb + wk) * 64 + lane];
+        u64 m = __ballot(((Sk >> lane) & 1ull) && g > cur);
+        while (m && i < rr.count) {
+          const int f = __ffsll((long long)m) - 1;
+          cur = (unsigned)__builtin_amdgcn_readlane((int)g, f);
+          const int pos = (wb + wk) * kWave + f;
+          const int node = pos < n_nodes ? perm[pos] : -1;
+          for (;;) {  // the rows below this record, in order (the lanes hold a batch of them)
+            const int idx = ib + lane;
+            const bool take = idx >= i && idx < rr.count && (unsigned)d.z < cur;
+            if (take) class_best[d.x] = node;
+            i += __popcll(__ballot(take));
+            if (i < ib + kWave || i >= rr.count) break;
+            ib += kWave;
+            d = vrow[min(ib + lane, rr.count - 1)];
+          }
+          m = __ballot(((Sk >> lane) & 1ull) && g > cur);
+        }
+      }
+    }
+  // rows no node of the run's planes holds enough for
+  while (i < rr.count) {
+    const int idx = ib + lane;
+    if (idx >= i && idx < rr.count) class_best[d.x] = -1;
+    i = min(ib + kWave, rr.count);
+    if (i < rr.count) {
+      ib += kWave;
+      d = vrow[min(ib + lane, rr.count - 1)];
+    }
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_scatter(int n_pods, const int* __restrict__ pod_class, const int* __restrict__ class_count,
                                                     const int* __restrict__ class_best, const u64* __restrict__ node_key,
                                                     int* __restrict__ counts, int* __restrict__ decisions, i64* __restrict__ keys) {
