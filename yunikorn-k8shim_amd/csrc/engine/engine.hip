@@ -370,7 +370,7 @@ struct ykpred_engine {
 
   // --- decision stream (score → rank → ranked planes → decide run beside the bitmap branch)
   hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr, ev_counts = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_planes = nullptr, ev_join = nullptr, ev_counts = nullptr, ev_zero = nullptr;
   // --- the resident answer served to single callbacks (ykpred_peek_row): a copy stream ordered after the
   // last evaluation by an event, pinned staging memory
   hipStream_t peek_stream = nullptr;
@@ -998,10 +998,11 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
           const int begin = (int)order2.size();
           for (int32_t r : at_pos)
             if (r >= 0) order2.push_back(r);
-          // (few rows: short chunks — a chunk is one thread's sequential walk, and a handful of 512-row chunks is a handful of
-          // workgroups walking for a quarter of a millisecond)
+          // (few rows: chunks of ONE row. A chunk is one thread's sequential walk down every word's sorted list — a chain of dependent
+          // loads that grows with the distance between the chunk's values, and the rows that are left are far apart: 16-row chunks of
+          // 1 112 rows made k_dim_walk_window the longest kernel of the decision stream, 1.1 ms beside the sweep)
           const int left = (int)order2.size() - begin;
-          const int clen = std::min(ykk::kWalkRows, std::max(16, left / 1024));
+          const int clen = std::min(ykk::kWalkRows, std::max(1, left / 2048));
           for (int q = begin; q < (int)order2.size(); q += clen) {
             wbig2.push_back(b);
             wbegin2.push_back(q);
@@ -1382,7 +1383,7 @@ int complete_windows(ykpred_engine* e, hipStream_t st) {
                   e->d_walk_len.as<int>(), e->d_sfree_r.as<i64>(), e->d_pmask_r.as<u64>(), e->n_big, e->walk_chunks, e->row_words, nullptr,
                   nullptr, e->d_sorted.as<i64>(), e->d_sorted_off.as<int>(), nullptr};
   const unsigned gy = (unsigned)((e->row_words + ykk::kBlock * ykk::kWalkWords - 1) / (ykk::kBlock * ykk::kWalkWords));
-  hipLaunchKernelGGL(ykk::k_dim_walk_window, dim3((unsigned)e->walk_chunks, gy), dim3(ykk::kBlock), 0, st, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+  hipLaunchKernelGGL(ykk::k_dim_walk_window<ykk::kWalkBatch>, dim3((unsigned)e->walk_chunks, gy), dim3(ykk::kBlock), 0, st, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
   HIPCHK(hipGetLastError());
   e->win_partial = false;
   return YKPRED_OK;
@@ -1538,6 +1539,7 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   (void)hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_planes, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_counts, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&e->ev_zero, hipEventDisableTiming);
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   e->ev_ready = true;
   *out = e;
@@ -1576,6 +1578,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
   if (e->ev_counts) (void)hipEventDestroy(e->ev_counts);
+  if (e->ev_zero) (void)hipEventDestroy(e->ev_zero);
   if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
   if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
   if (e->peek_stream) (void)hipStreamDestroy(e->peek_stream);
@@ -2184,6 +2187,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool full_pass = !(a->options & (YKPRED_EVAL_SKIP_BITMAP | YKPRED_EVAL_DIRTY_CLASSES));
   const bool counts_early_here = e->early_counts != 0 && full_pass && e->n_classes_a > 0 && e->patch_chunks == 0 &&
                                  !((long)e->NC * e->wave_combine_below > (long)P) && e->n_classes_b <= 16384;
+  const bool zero_counts_beside = full_pass && !counts_early_here && e->ev_zero != nullptr && e->C >= 65536 &&
+                                  (a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) != 0;
   const bool use_sweep = e->sweep_ready && e->sweep_runs > 0 && res_on && !fit_error && full_pass && !counts_early_here;
   const bool sweep_rows_on = use_sweep && e->n_big > 0 && e->sweep_row_off[ykk::kMaxIdxRows] > 0;  // k_sweep_rows has rows (k_class_runs: run_classes)
   // the decisions of the sweep runs come from k_run_decide wherever decisions are produced from walked request rows (any pass, also a
@@ -2214,6 +2219,12 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) {
     HIPCHK(hipEventRecord(e->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, e->ev_fork, 0));
+    if (zero_counts_beside) {
+      // the class counts of a pass whose writers add to them are zeroed here, beside the plane kernels (4 MB at 10^6 classes: a fill
+      // that took 60 us in front of the writers on the launch stream)
+      HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), sb));
+      HIPCHK(hipEventRecord(e->ev_zero, sb));
+    }
     if (first_r) HIPCHK(hipMemsetAsync(first_r, 0x7f, (size_t)std::max(e->plane_rows_alloc, 1) * sizeof(int), sb));  // = ykk::kNoWord
     tm.begin(sb);
     hipLaunchKernelGGL(ykk::k_score, dim3((unsigned)nblk_nodes), dim3(ykk::kBlock), 0, sb, nt, e->d_score.as<double>(), e->d_key.as<u64>());
@@ -2362,10 +2373,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
             dw2.chunk_begin = e->d_walk2_begin.as<int>();
             dw2.chunk_len = e->d_walk2_len.as<int>();
             dw2.n_chunks = e->walk2_chunks;
-            hipLaunchKernelGGL(ykk::k_dim_walk_window, dim3((unsigned)e->walk2_chunks, walk_gy), dim3(ykk::kBlock), 0, s, dw2, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+            hipLaunchKernelGGL(ykk::k_dim_walk_window<8>, dim3((unsigned)e->walk2_chunks, walk_gy), dim3(ykk::kBlock), 0, s, dw2, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
           }
         } else {
-          hipLaunchKernelGGL(ykk::k_dim_walk_window, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
+          hipLaunchKernelGGL(ykk::k_dim_walk_window<ykk::kWalkBatch>, walk_grid, dim3(ykk::kBlock), 0, s, dw, e->d_pfx_r.as<i64>(), e->d_win_r.as<unsigned char>());
         }
       }
       tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
@@ -2437,7 +2448,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   const bool small_chunks = (long)e->NC * e->wave_combine_below > (long)P;
   const bool counts_early = e->early_counts != 0 && !skip_combine && !dirty_only && e->n_classes_a > 0 && e->patch_chunks == 0 && !small_chunks && e->n_classes_b <= 16384;
   bool scattered = false;
-  if (!skip_combine && !dirty_only && !counts_early) HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
+  if (!skip_combine && !dirty_only && !counts_early) {
+    if (zero_counts_beside) HIPCHK(hipStreamWaitEvent(st, e->ev_zero, 0));
+    else HIPCHK(hipMemsetAsync(e->d_class_count.p, 0, (size_t)e->C * sizeof(int), st));
+  }
   if (!skip_combine) {
     // threads per group of k_combine: the smallest whole number of waves (64/128/256) whose single pass covers a row
     int tpg = ykk::kBlock;

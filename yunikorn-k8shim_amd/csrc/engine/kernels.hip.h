@@ -491,6 +491,9 @@ __global__ __launch_bounds__(kPfxBlock) void k_dim_prefix_max(DimWalk a, i64* __
 // k_dim_walk and stores a row's dword only when its word group lies in the row's window [start & ~3, +64): start <= w0 + 3 and
 // start >= w0 - 60, i.e. pfx[w0 - 61] < v <= pfx[w0 + 3] — a contiguous run of the ascending values of a chunk, and no run at
 // all for most (chunk, thread) pairs: a twelfth of the walk's work.
+// (BATCH = rows staged in LDS before they are stored: kWalkBatch for the walk over every row; 8 — 8 KB of LDS — for the short lists of
+// a pass whose sweep runs need no window: that launch runs BESIDE k_sweep_rows, whose workgroups leave 16 KB of every CU's LDS)
+template <int BATCH>
 __global__ __launch_bounds__(kBlock) void k_dim_walk_window(DimWalk a, const i64* __restrict__ pfx, unsigned char* __restrict__ win) {
   const int chunk = blockIdx.x;
   const int big = a.chunk_big[chunk], begin = a.chunk_begin[chunk], len = a.chunk_len[chunk];
@@ -518,13 +521,13 @@ __global__ __launch_bounds__(kBlock) void k_dim_walk_window(DimWalk a, const i64
   bool started = false;
   // (positions of a batch of 64 rows into LDS, then the stores back to back — see k_dim_walk; 0xffffffff = the row's window does not
   // hold this thread's words)
-  __shared__ unsigned stage[kWalkBatch * kBlock];
+  __shared__ unsigned stage[BATCH * kBlock];
   for (int i0 = 0; i0 < len; i0 += kWave) {
     const int my_row = i0 + lane < len ? a.order[begin + i0 + lane] : 0;
     const i64 my_val = i0 + lane < len ? a.val[my_row] : 0;
     const int m = min(kWave, len - i0);
-   for (int h = 0; h < m; h += kWalkBatch) {
-    const int he = min(h + kWalkBatch, m);
+   for (int h = 0; h < m; h += BATCH) {
+    const int he = min(h + BATCH, m);
     // (a batch whose values all lie outside this wave's windows is skipped whole)
     const i64 b_first = readlane_i64(my_val, h), b_last = readlane_i64(my_val, he - 1);
     if (__ballot(mine && b_last > lo && b_first <= hi) == 0) continue;
@@ -1890,29 +1893,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
     if (lane == 63 && pc) atomicAdd(&class_count[cls], pc);
   };
   for (;;) {
-    // ---- SINGLE rows (the asks with a selector of their own: a run of one row each, tens of thousands of them in a row). A run
-    // start is a round of global loads and the wait for it; two of them that follow one another are started TOGETHER — one wait, as
-    // many loads in flight as the counter holds — and need no cursor: nothing follows them in their runs. Row i of the batch is
-    // single when row i + 1 (in the batch) belongs to another run.
-    {
-      const int i0 = r - rb, nb = r1 - rb;
-      const int my_run = s_desc[min(lane, kSweepBatch - 1)].w, nx_run = s_desc[min(lane + 1, kSweepBatch - 1)].w;
-      const u64 single = __builtin_amdgcn_ballot_w64(lane >= i0 && lane + 1 < nb && my_run != nx_run);
-      if (((single >> i0) & 3) == 3) {
-        const int4 da = dd, db = s_desc[i0 + 1];
-        int lo_a[NIT], lo_b[NIT];
-        u64 wa[NIT], wb[NIT];
-        positions(((unsigned)__builtin_amdgcn_readfirstlane(da.z) << 6) | 63u, lo_a);
-        positions(((unsigned)__builtin_amdgcn_readfirstlane(db.z) << 6) | 63u, lo_b);
-        run_words(__builtin_amdgcn_readfirstlane(da.w), lo_a, wa);
-        run_words(__builtin_amdgcn_readfirstlane(db.w), lo_b, wb);
-        emit(__builtin_amdgcn_readfirstlane(da.x), __builtin_amdgcn_readfirstlane(da.y), wa, popcount(wa));
-        emit(__builtin_amdgcn_readfirstlane(db.x), __builtin_amdgcn_readfirstlane(db.y), wb, popcount(wb));
-        r += 2;  // (r < r1: the second of them has its successor in the batch)
-        dd = s_desc[r - rb];
-        continue;
-      }
-    }
     // ---- a run begins — or this wave's first row of one: positions by binary search, masks from the planes and the mask table.
     // (The rows a wave takes ascend: inside a run its cursors only ever move forward.)
     const int run = __builtin_amdgcn_readfirstlane(dd.w);
