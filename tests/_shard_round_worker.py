@@ -26,11 +26,12 @@ import _oracle as orc  # noqa: E402
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     total_nodes, n_pods, n_templates = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    spread = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 1: a tenth of the templates carry a hard zone-spread constraint (configs[4]'s mix)
     stub = os.environ.get("SHARD_RCCL_STUB")
     device = 0 if stub else rank
     torch.cuda.set_device(device)
     dist.init_process_group("gloo")
-    kw = dict(seed=0x59554E49 + 91, num_pods=n_pods, num_templates=n_templates, node_affinity=1, spread=0)
+    kw = dict(seed=0x59554E49 + 91, num_pods=n_pods, num_templates=n_templates, node_affinity=1, spread=spread)
     ranges = sharding.shard_ranges(total_nodes, world)
     first, count = ranges[rank]
     pm = pkg.GpuPredicateManager(device=device)
@@ -41,7 +42,7 @@ def main():
     # the whole cluster, CPU only: what the core's loop decides (first fit down the (score, NodeID) order, AssumePod, next ask)
     full = pkg.GpuPredicateManager(device=-1)
     full.generate_kwok(num_nodes=total_nodes, **kw)
-    want = orc.Oracle(full.dump_snapshot()).allocate_sequential()
+    want = orc.Oracle(full.dump_snapshot()).allocate_sequential(prefilter_once=bool(spread))
     full.close()
     half = n_pods // 2
     asks = np.arange(n_pods, dtype=np.int32)
@@ -54,7 +55,7 @@ def main():
     on_device = after["rounds_on_device"] == before["rounds_on_device"] + 2 and after["asks_one_by_one"] == before["asks_one_by_one"]
     bad = np.flatnonzero(got != want)
     detail = "" if ok else f" first difference at ask {bad[0]}: got {got[bad[0]]} want {want[bad[0]]} ({len(bad)} differ)"
-    print(f"rank {rank}/{world} {'rccl-stub' if stub else 'rccl'}: sharded rounds {ok} on_device {on_device} "
+    print(f"rank {rank}/{world} {'rccl-stub' if stub else 'rccl'}{' spread' if spread else ''}: sharded rounds {ok} on_device {on_device} "
           f"({n_pods} asks x {total_nodes} nodes, {int((want >= 0).sum())} allocated on {len(np.unique(want[want >= 0]))} nodes){detail}", flush=True)
     dist.barrier()
     pm.comm_destroy()

@@ -249,13 +249,18 @@ def test_round_without_apply_leaves_the_cluster_alone(pm):
     assert np.array_equal(a, b) and json.loads(pm.dump_snapshot()) == before
 
 
-@pytest.mark.parametrize("world,total_nodes,n_pods,n_templates", [(2, 200, 600, 40), (3, 330, 900, 6), (2, 130, 500, 1)],
-                         ids=["two-shards", "three-shards-long-runs", "one-template-and-a-two-node-shard"])
-def test_allocation_rounds_on_a_node_sharded_cluster(tmp_path, world, total_nodes, n_pods, n_templates):
+@pytest.mark.parametrize("world,total_nodes,n_pods,n_templates,spread", [(2, 200, 600, 40, 0), (3, 330, 900, 6, 0), (2, 130, 500, 1, 0),
+                                                                         (2, 256, 700, 40, 1), (3, 330, 600, 20, 1)],
+                         ids=["two-shards", "three-shards-long-runs", "one-template-and-a-two-node-shard", "two-shards-hard-spread",
+                              "three-shards-hard-spread"])
+def test_allocation_rounds_on_a_node_sharded_cluster(tmp_path, world, total_nodes, n_pods, n_templates, spread):
     """Rounds on node-sharded engines (world 2 and 3 on this box's one GPU, the collectives through tests/c/rccl_stub.cpp): every shard
     proposes its best node for a batch of asks, the proposals are all-gathered, every rank accepts the same conflict-free prefix —
     runs of one template land on one node while it fits — and the owners assume. Both rounds (apply = 1, then apply = 0 on top of it)
-    equal the oracle's sequential loop over the whole cluster on every rank, in cluster-wide node indices, and stay on the device."""
+    equal the oracle's sequential loop over the whole cluster on every rank, in cluster-wide node indices, and stay on the device.
+    hard-spread (round 6): a tenth of the templates carry a DoNotSchedule zone constraint — the histograms are cluster-wide state on
+    every shard: the owner of an accepted node records what its assume added (delta record), a second all-gather hands it to the
+    others (k_round_apply_deltas), and the prefix ends in front of the first ask with a topology signature behind a contribution."""
     import os
     import subprocess
     import sys
@@ -264,8 +269,8 @@ def test_allocation_rounds_on_a_node_sharded_cluster(tmp_path, world, total_node
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-fPIC", "-shared", "-std=c++17", os.path.join(root, "tests", "c", "rccl_stub.cpp"), "-o", stub, "-lrt"])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29800 + world * 11 + total_nodes % 83), os.path.join(root, "tests", "_shard_round_worker.py"),
-           str(total_nodes), str(n_pods), str(n_templates)]
+           str(total_nodes), str(n_pods), str(n_templates), str(spread)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, SHARD_RCCL_STUB=stub))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
-    assert out.stdout.count("sharded rounds True on_device True") == world, out.stdout[-1500:]
+    assert out.stdout.count("sharded rounds True on_device True") == world, (out.stdout[-1500:], out.stderr[-1500:])
 

@@ -351,6 +351,7 @@ struct ykpred_engine {
   DevBuf d_fx_off, d_fx_cls, d_fx_cnt, d_fx_occ, d_sp_sig_of;
   uint64_t fx_version = 0;
   bool fx_contrib = false, fx_ports = false;  // some spec adds to a count column / occupies a dictionary host port
+  std::vector<int32_t> h_fx_off;              // [S + 1] the contribution rows' offsets, host copy
   DevBuf d_patches, d_rows, d_row_count, d_row_best;
   unsigned last_pre = 0, last_filt = 0;  // plugin lists of the last full evaluation (ykpred_eval_nodes must match them)
   bool last_eval_valid = false;
@@ -3154,6 +3155,7 @@ int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t*
   e->fx_version = 0;
   e->fx_contrib = false;
   e->fx_ports = false;
+  e->h_fx_off.clear();
   if (fx->contrib_off) {
     const int total = fx->contrib_off[S];
     if (fx->contrib_off[0] != 0 || total < 0 || (total > 0 && (!fx->contrib_class || !fx->contrib_count)))
@@ -3164,6 +3166,7 @@ int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t*
       if (fx->contrib_class[k] < 0 || fx->contrib_class[k] >= e->KS || fx->contrib_count[k] <= 0)
         return fail(e, YKPRED_E_INVALID, "set_spec_effects: contribution outside the selector classes of the node table, or not positive");
     TRY(upload(e, e->d_fx_off, fx->contrib_off, S + 1, st));
+    e->h_fx_off.assign(fx->contrib_off, fx->contrib_off + S + 1);  // (a sharded round's prefix rule asks which specs move histograms)
     TRY(upload(e, e->d_fx_cls, fx->contrib_class, (size_t)std::max(total, 1), st));
     TRY(upload(e, e->d_fx_cnt, fx->contrib_count, (size_t)std::max(total, 1), st));
     e->fx_contrib = total > 0;
@@ -3240,8 +3243,6 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     return fail(e, YKPRED_E_STATE, "allocate_round: no current evaluation WITH decisions of these plugin lists (run ykpred_eval with YKPRED_OUT_DECISIONS)");
   const bool fx_current = e->fx_version == e->specs_version;
   const bool topo_on = (pre & filt & (YKPRED_PLUGIN_POD_TOPOLOGY_SPREAD | YKPRED_PLUGIN_INTER_POD_AFFINITY)) && e->fam_spread.D > 0;
-  if (sharded && topo_on)
-    return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints on a node-sharded engine (an assumed pod moves histograms on every shard): decide ask by ask");
   if (topo_on && !fx_current)
     return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: topology constraints are active (an assumed pod's labels move the histograms of later asks) and the "
                                          "specs' effects are not uploaded (ykpred_set_spec_effects): decide ask by ask");
@@ -3292,7 +3293,9 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int)), o_cdesc = take(C * ykk::kDescWords * sizeof(u64)),
                o_prop = take(sharded ? (size_t)n_asks * sizeof(ykk::RoundProposal) : 0),
                o_allprop = take(sharded ? (size_t)e->comm_world * kShardBatchMax * sizeof(ykk::RoundProposal) : 0),
-               o_forced = take(sharded ? (size_t)n_asks * sizeof(int) : 0);
+               o_forced = take(sharded ? (size_t)n_asks * sizeof(int) : 0),
+               o_delta = take((sharded && topo_on) ? (size_t)n_asks * ykk::kDeltaStride * sizeof(int) : 0),
+               o_alldelta = take((sharded && topo_on) ? (size_t)e->comm_world * kShardBatchMax * ykk::kDeltaStride * sizeof(int) : 0);
   HIPCHK(e->d_round.ensure(off));
   char* base = (char*)e->d_round.p;
   HIPCHK(hipMemcpyAsync(base + o_req, e->d_req.p, R * (size_t)e->N * sizeof(i64), hipMemcpyDeviceToDevice, st));
@@ -3304,6 +3307,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   HIPCHK(hipMemsetAsync(base + o_dead, 0, cap64 * sizeof(u64), st));
   if (keep_failed) HIPCHK(hipMemsetAsync(base + o_failed, 0, C * cap64 * sizeof(u64), st));
   HIPCHK(hipMemsetAsync(base + o_nm, 0, sizeof(int), st));
+  if (sharded && topo_on) HIPCHK(hipMemsetAsync(base + o_delta, 0, (size_t)n_asks * ykk::kDeltaStride * sizeof(int), st));
   HIPCHK(hipMemsetAsync(base + o_prof, 0, 16 * sizeof(i64), st));
   HIPCHK(hipMemcpyAsync(base + o_asks, asks, (size_t)n_asks * sizeof(int), hipMemcpyHostToDevice, st));
   ykk::NodeTable nt = node_table(e);
@@ -3422,6 +3426,17 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     int* d_forced = (int*)(base + o_forced);
     std::vector<ykk::RoundProposal> all((size_t)W * kShardBatchMax);
     std::vector<int32_t> forced;
+    // Topology signatures (round 6): the histograms are cluster-wide state every shard holds. An accepted ask whose pod adds to a
+    // selector class moves them — on its owner in the assume, on the others from the owner's delta record (second all-gather of
+    // the batch, k_round_apply_deltas) — and it can turn verdicts of asks WITH a topology signature from fail to fit anywhere:
+    // the conflict-free prefix therefore ends in front of the first such ask behind an accepted contribution.
+    int* d_delta = topo_on ? (int*)(base + o_delta) : nullptr;
+    int* d_alldelta = topo_on ? (int*)(base + o_alldelta) : nullptr;
+    std::vector<int32_t> h_alldelta;
+    auto spec_has_signature = [&](int spec) { return topo_on && e->spec_sig_spread[(size_t)spec] >= 0; };
+    auto spec_contributes = [&](int spec) {
+      return topo_on && e->fx_contrib && (size_t)spec + 1 < e->h_fx_off.size() && e->h_fx_off[(size_t)spec + 1] > e->h_fx_off[(size_t)spec];
+    };
     struct Accepted {
       int64_t gnode;
       u64 key0, key1;  // the node's key when it was proposed / after the accepted pods
@@ -3429,7 +3444,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     std::vector<Accepted> acc;
     const int R = e->R;
     int pos = 0, batch = 16;
-    int64_t exchanges = 0;
+    int64_t exchanges = 0, delta_exchanges = 0, delta_cells = 0;
     while (pos < n_asks) {
       const int b = std::min(batch, n_asks - pos);
       ra.mode = ykk::kRoundPropose;
@@ -3445,7 +3460,9 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       acc.clear();
       forced.assign((size_t)b, -1);
       int m = 0;
+      bool contributed = false;  // an ask accepted in this batch moved a histogram
       while (m < b) {
+        if (contributed && spec_has_signature(e->h_pod_spec[(size_t)asks[pos + m]])) break;  // (proposed again against the new histograms)
         // the global candidate of ask pos + m
         int best_rank = -1;
         for (int g = 0; g < W; ++g) {
@@ -3481,6 +3498,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
         const i64 total[2] = {w.alloc[0], w.alloc[1]};
         const i64 used[2] = {w.req[0] + e->h_req[(size_t)spec * (size_t)R + 0] * k, w.req[1] + e->h_req[(size_t)spec * (size_t)R + 1] * k};
         acc.push_back(Accepted{gnode, w.key, host_sortable_key(host_node_score(total, used))});
+        contributed = contributed || spec_contributes(spec);
         for (int q = 0; q < k; ++q) {
           out_nodes[pos + m + q] = (int32_t)gnode;
           if (best_rank == e->comm_rank) forced[(size_t)(m + q)] = w.node;
@@ -3493,16 +3511,37 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       ra.first = pos;
       ra.n_asks = m;
       ra.forced = d_forced;
+      ra.delta = d_delta;
       hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
       HIPCHK(hipGetLastError());
+      if (topo_on && contributed) {
+        // what the owners' assumes added to the histograms: every rank applies the others' records (its own are in its copy already)
+        const size_t rec_bytes = (size_t)m * ykk::kDeltaStride * sizeof(int);
+        NCCLCHK(r->AllGather(d_delta + (size_t)pos * ykk::kDeltaStride, d_alldelta, rec_bytes, ncclInt8, e->comm, st));
+        h_alldelta.resize((size_t)W * (size_t)m * ykk::kDeltaStride);
+        HIPCHK(hipMemcpyAsync(h_alldelta.data(), d_alldelta, (size_t)W * rec_bytes, hipMemcpyDeviceToHost, st));
+        for (int g = 0; g < W; ++g)
+          if (g != e->comm_rank)
+            hipLaunchKernelGGL(ykk::k_round_apply_deltas, dim3(1), dim3(ykk::kBlock), 0, st, stbl.spread, ra.mn, ra.at_min, ra.nd,
+                               d_alldelta + (size_t)g * (size_t)m * ykk::kDeltaStride, m);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        ++exchanges;
+        ++delta_exchanges;
+        for (size_t q = 0; q < (size_t)W * (size_t)m; ++q) delta_cells += h_alldelta[q * ykk::kDeltaStride];
+        for (size_t q = 0; q < (size_t)W * (size_t)m; ++q)  // (every rank reads the same records: the same verdict everywhere)
+          if (h_alldelta[q * ykk::kDeltaStride] > ykk::kDeltaMax)
+            return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round (sharded): an assumed pod moves more histogram cells than a delta record holds (" +
+                                                 std::to_string(ykk::kDeltaMax) + "): the round stops here on every rank");
+      }
       HIPCHK(hipStreamSynchronize(st));  // (`forced` is reused by the next batch)
       pos += m;
       batch = (int)std::min<size_t>(kShardBatchMax, (size_t)std::max(8, 2 * m + 8));
     }
     e->round_exchanges += exchanges;
     if (e->round_prof)
-      fprintf(stderr, "round_prof sharded round: %d asks in %lld batches (%.1f accepted per exchange)\n", n_asks, (long long)exchanges,
-              exchanges ? (double)n_asks / (double)exchanges : 0.0);
+      fprintf(stderr, "round_prof sharded round: %d asks in %lld exchanges (%.1f accepted per exchange), %lld of them histogram deltas (%lld cells)\n", n_asks,
+              (long long)exchanges, exchanges ? (double)n_asks / (double)exchanges : 0.0, (long long)delta_exchanges, (long long)delta_cells);
     return YKPRED_OK;
   }
   // one launch per 32 768 asks: the loop is a single workgroup, and a bounded launch keeps the queue responsive (the state of the

@@ -3007,7 +3007,13 @@ struct RoundArgs {
   const int* forced;        // kRoundAssume: [round] the node (of this shard) an ask goes to, -1 = none of this shard's
   RoundProposal* prop;      // kRoundPropose: [round]
   i64* prof;                // YKPRED_TUNE round_prof=1: thread 0's 100 MHz ticks per phase of the loop (null: off)
+  // kRoundAssume on a sharded engine with topology signatures: what the assume added to the histograms, for the OTHER shards (they
+  // hold the same cluster-wide histograms and cannot see this shard's node): [round][kDeltaStride] ints — word 0 = entries, then
+  // (constraint, domain, count) triples. null: not recorded.
+  int* delta;
 };
+constexpr int kDeltaMax = 10;                   // histogram cells one assumed pod can move (constraints whose selector class it adds to)
+constexpr int kDeltaStride = 2 + 3 * kDeltaMax; // ints per ask of the delta record (word 1: pad)
 // Per-phase ticks of the loop (thread 0, 100 MHz): compiled in with -DYK_ROUND_PROF only (build.py: YK_ROUND_PROF=1) — the kernel
 // has no scalar register to spare for a pointer it does not use.
 #ifdef YK_ROUND_PROF
@@ -3259,6 +3265,57 @@ typedef const RoundCtx __attribute__((address_space(4))) * RoundCtxPtr;
 #define ranked (*(const Planes*)&cx->planes)
 #define a (*(const RoundArgs*)&cx->args)
 #define sp (*(const SpreadSigs*)&cx->specs.spread)
+// A sharded round with topology signatures: the histogram steps of the asks OTHER shards assumed in this batch (their delta records,
+// all-gathered), applied to this shard's copy of the cluster-wide histograms. One workgroup, ask after ask, entry after entry: the
+// cell, then — for a spread constraint — its minimum over the present domains, how many domains sit there and the global minimum
+// after the minDomains rule, recomputed whole (the same numbers k_allocate_round's assume maintains incrementally; a step of an
+// InterPodAffinity term counts a domain that got its first match).
+__global__ __launch_bounds__(kBlock) void k_round_apply_deltas(SpreadSigs hist, int* __restrict__ mn_out, int* __restrict__ at_min_out,
+                                                               const int* __restrict__ nd, const int* __restrict__ recs, int n_asks) {
+  __shared__ int sh_mn[kWavesPerBlock], sh_at[kWavesPerBlock];
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  for (int i = 0; i < n_asks; ++i) {
+    const int* rec = recs + (size_t)i * kDeltaStride;
+    const int n = min(rec[0], kDeltaMax);
+    for (int k = 0; k < n; ++k) {
+      const int g = rec[2 + 3 * k], dom = rec[3 + 3 * k], v = rec[4 + 3 * k];
+      const SpreadC c = hist.c[g];
+      const int old = hist.cnt[c.cnt_off + dom];
+      __syncthreads();  // (everybody has read the old count)
+      if (tid == 0) hist.cnt[c.cnt_off + dom] = old + v;
+      __syncthreads();
+      if (c.kind == kKindSpread) {
+        int mn = 0x7fffffff;
+        for (int d = tid; d < c.dom_size; d += kBlock)
+          if (hist.present[c.cnt_off + d]) mn = min(mn, hist.cnt[c.cnt_off + d]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mn = min(mn, __shfl_xor(mn, off, kWave));
+        if (lane == 0) sh_mn[wave] = mn;
+        __syncthreads();
+        mn = sh_mn[0];
+#pragma unroll
+        for (int q = 1; q < kWavesPerBlock; ++q) mn = min(mn, sh_mn[q]);
+        int at = 0;
+        for (int d = tid; d < c.dom_size; d += kBlock) at += (hist.present[c.cnt_off + d] && hist.cnt[c.cnt_off + d] == mn) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) at += __shfl_xor(at, off, kWave);
+        if (lane == 0) sh_at[wave] = at;
+        __syncthreads();
+        if (tid == 0) {
+          at = 0;
+          for (int q = 0; q < kWavesPerBlock; ++q) at += sh_at[q];
+          mn_out[g] = mn;
+          at_min_out[g] = at;
+          hist.minv[g] = nd[g] < c.min_domains ? 0 : mn;
+        }
+        __syncthreads();
+      } else if (tid == 0 && old <= 0 && old + v > 0) {
+        hist.minv[g] = hist.minv[g] + 1;
+      }
+      __syncthreads();
+    }
+  }
+}
 __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_value) {
   RoundCtxPtr cx = (RoundCtxPtr)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ int sh_aw[kRoundWaves], sh_cw[kRoundWaves], sh_bt[kRoundWaves], sh_bn[kRoundWaves], sh_an[kRoundWaves], sh_at[kRoundWaves];
@@ -3732,6 +3789,15 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
           if (dom < 0 || dom >= c.dom_size) continue;
           if (c.kind == kKindSpread && !spread_counts_here(c, spread_eligibility(t, sp, a.sig_aff, a.sig_tol, a.sig_of[g], win))) continue;
           const int old = __hip_atomic_fetch_add(sp.cnt + c.cnt_off + dom, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (a.delta) {  // (sharded round: the other shards apply the same step to their copy — k_round_apply_deltas)
+            int* rec = a.delta + (size_t)(first_ask + i) * kDeltaStride;
+            const int k = atomicAdd(rec, 1);
+            if (k < kDeltaMax) {
+              rec[2 + 3 * k] = g;
+              rec[3 + 3 * k] = dom;
+              rec[4 + 3 * k] = v;
+            }
+          }
           if (c.kind == kKindSpread) {
             // (an eligible node carries the domain: it is a present one. Its count leaves the minimum; the minimum itself moves
             // only when no present domain is left there)
