@@ -196,8 +196,10 @@ int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5);
  * NODE-SHARDED cluster (a communicator with world > 1 is attached to the engine): the call is COLLECTIVE — every rank calls with the
  * same asks in the same order — and node indices in out_nodes are indices in the WHOLE cluster (this shard's node 0 = its
  * node_offset), identical on every rank; an ask that went to another shard's node is assumed here as well (it leaves the pending
- * asks) without touching a node of this mirror. A sharded round the engine's collective form does not cover (topology constraints:
- * an assumed pod moves histograms on every shard) returns YKHOST_E_UNSUPPORTED — it is never decided shard by shard.
+ * asks) without touching a node of this mirror. Topology constraints are part of the collective form (the owner of an accepted node
+ * hands what its assume added to the histograms to the other shards: ykpred.h). A sharded round the collective form does not cover
+ * (spec effects withheld; a pod that moves more histogram cells than a delta record holds) returns YKHOST_E_UNSUPPORTED — it is never
+ * decided shard by shard.
  * apply != 0: every ask that got a node is assumed in the mirror exactly as ykhost_assume_pod would. → number of asks that got a
  * node, or a negative error. ykhost_round_stats: out[0] rounds decided by one device call, [1] asks decided in them, [2] asks
  * decided ask by ask, [3] asks routed. */

@@ -336,12 +336,17 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
  * Needs a current evaluation WITH decisions of the same plugin lists (YKPRED_E_STATE otherwise). YKPRED_E_UNSUPPORTED — decide ask by
  * ask instead — when something other than node resources couples the asks of the round (active PodTopologySpread /
  * InterPodAffinity signatures, an ask that requests a host port) while the specs' effects (ykpred_set_spec_effects, below) are not
- * uploaded for the current spec table, and for active topology signatures on a node-sharded engine.
+ * uploaded for the current spec table.
  * NODE-SHARDED engines (communicator attached, world > 1): the call is COLLECTIVE — every rank passes the same asks in the same
  * order — and out_nodes holds GLOBAL node indices (the winner's shard offset + its index there), identical on every rank. The
  * round runs in batches: every shard proposes its best node per ask of a batch, one all-gather of 56 bytes per ask and rank, every
  * rank accepts the same conflict-free prefix, the owners assume (engine.hip has the rule and its proof sketch). Equal keys
- * across shards are ordered by global node index, as in ykpred_exchange_decisions. */
+ * across shards are ordered by global node index, as in ykpred_exchange_decisions. Before the first batch the ranks agree on status,
+ * ask count and a hash of the ask list (a rank that cannot run the round makes every rank return the same error). With active
+ * topology signatures the histograms are cluster-wide state on every shard: the owner of an accepted node records what its assume
+ * added (constraint, domain, count), a second all-gather of the batch hands the records to the other shards, and the prefix ends in
+ * front of the first ask WITH a topology signature behind an accepted contribution (its verdicts may have turned from fail to fit
+ * anywhere). YKPRED_E_UNSUPPORTED when one pod moves more than 10 histogram cells (every rank sees the same record and stops). */
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t n_asks,
                               const int32_t* asks /* host, [n_asks] ask indices in decision order */, int32_t* out_nodes /* host, [n_asks] */);
 /* What NodeInfo.AddPod (behind SchedulerCache.AssumePod, /root/reference/pkg/cache/external/scheduler_cache.go:443-461) adds to a
