@@ -823,7 +823,37 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       }
     }
     auto kind_of = [&](int32_t c) { return is_cand(c) ? 2 : (runs_possible && run_slots[(size_t)c] >= 0 ? 1 : 0); };
+    // The classes the run kernels will NOT take — shapes without a run form, signatures with too few rows — go to the END of zone B,
+    // side by side: the chunk writers then store consecutive rows (their chunks run in row order) instead of single rows scattered
+    // between the runs of 6 GB.
+    std::vector<uint8_t> tail((size_t)C, 0);
+    {
+      struct SigKey {
+        int32_t a, t, s, k, b, p;
+        bool operator==(const SigKey& o) const { return a == o.a && t == o.t && s == o.s && k == o.k && b == o.b && p == o.p; }
+      };
+      struct SigHash {
+        size_t operator()(const SigKey& q) const {
+          uint64_t h = 0x9e3779b97f4a7c15ull;
+          for (int32_t v : {q.a, q.t, q.s, q.k, q.b, q.p}) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001b3ull;
+          return (size_t)h;
+        }
+      };
+      std::unordered_map<SigKey, long, SigHash> rows_of_sig;
+      auto sig_key = [&](int32_t c, int kind) {
+        return SigKey{key(c, 2), key(c, 1), key(c, 3), kind, kind == 2 ? cand_big[(size_t)c] : 0, kind == 2 ? cand_slot[(size_t)c] : 0};
+      };
+      for (int32_t c : order_b) {
+        const int kind = kind_of(c);
+        if (kind) rows_of_sig[sig_key(c, kind)] += class_size[(size_t)c];
+      }
+      for (int32_t c : order_b) {
+        const int kind = kind_of(c);
+        tail[(size_t)c] = kind == 0 || rows_of_sig[sig_key(c, kind)] < (kind == 1 ? (long)e->class_runs_min_rows : (long)e->sweep_min_run);
+      }
+    }
     std::sort(order_b.begin(), order_b.end(), [&](int32_t x, int32_t y) {
+      if (tail[(size_t)x] != tail[(size_t)y]) return tail[(size_t)x] < tail[(size_t)y];
       if (key(x, 2) != key(y, 2)) return key(x, 2) < key(y, 2);  // aff
       if (key(x, 1) != key(y, 1)) return key(x, 1) < key(y, 1);  // tol
       if (key(x, 3) != key(y, 3)) return key(x, 3) < key(y, 3);  // spread
