@@ -274,7 +274,7 @@ struct ykpred_engine {
   DevBuf d_agree;  // sharded rounds: what the ranks agree on before the first batch
   // decisions of the sweep runs (k_run_decide): one range per run of the sweep row list, the classes k_decide leaves to it
   int run_decide = 1;                // tunable (YKPRED_TUNE run_decide): 0 = k_decide scans every class
-  int run_ranges = 0, n_decide_list = 0;
+  int run_ranges = 0, n_decide_list = 0, run_decide_classes = -1;  // (classes at the build the lists describe)
   bool win_partial = false;          // the rank-ordered windows of the last decision pass cover only the rows k_decide read (a round walks them all first)
   DevBuf d_run_ranges, d_no_decide, d_glin_r;  // RunRange; the classes k_decide still scans (int list); g of every node's free value in rank order [n_big][row_words * 64]
   // class runs (k_class_runs): zone-B classes WITHOUT an index row whose request-value rows are all staged, run by run
@@ -1005,6 +1005,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
         for (int c = 0; c < C; ++c)
           if (!no_decide[(size_t)c]) decide_list.push_back(c);
         e->n_decide_list = (int)decide_list.size();
+        e->run_decide_classes = C;
         decide_list.push_back(0);
         TRY(upload(e, e->d_no_decide, decide_list.data(), decide_list.size(), st));
         // The index rows somebody OUTSIDE the runs still reads (zone-A classes, short runs, shapes without a fast path): the full
@@ -2225,7 +2226,8 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   // the decisions of the sweep runs come from k_run_decide wherever decisions are produced from walked request rows (any pass, also a
   // decision refresh without the bitmap): k_decide skips those classes and no window of their index rows is written
   const bool use_run_decide = e->run_decide != 0 && e->sweep_ready && e->run_ranges > 0 && res_on && !fit_error && e->n_big > 0 &&
-                              (a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->walk2_chunks >= 0;
+                              (a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) && e->walk2_chunks >= 0 &&
+                              e->C == e->run_decide_classes;  // (a class that row patches added since the build is in neither list: k_decide takes them all then)
   use_run_decide_pass = use_run_decide;
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
                      e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), use_sweep ? 1 : 0,
