@@ -784,6 +784,11 @@ def main():
         except Exception as exc:  # noqa: BLE001
             rounds = {"error": str(exc)}
     stats = pm.stats()
+    try:
+        rt = pm.routing_stats()
+        routing = {"unsupported_asks": rt["unsupported_asks"], "fraction": rt["unsupported_asks"] / max(P, 1)}
+    except Exception:  # noqa: BLE001
+        routing = None
     comm_report = None
     if world > 1:
         # what every rank's engine says about its communicator (ykpred_comm_info): rank, world and first node of the shard — the
@@ -862,6 +867,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_ms": {k: round(v, 4) for k, v in kern.items()},
             "host_setup_s": round(t_gen, 2), "encode_ms": round(stats["encode_us"] / 1e3, 1),
+            # asks the engine does NOT evaluate (volumes, DRA claims, a pod-affinity namespaceSelector with requirements, dictionary
+            # overflow): routed to the CPU manager one by one — the fraction belongs beside every throughput figure (0 on the synthetic
+            # KWOK populations, which carry none of those)
+            "routed_asks": routing,
         }
         if comm_report is not None:
             out["communicators"] = comm_report

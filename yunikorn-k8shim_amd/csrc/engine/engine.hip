@@ -3472,6 +3472,26 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     struct Accepted {
       int64_t gnode;
       u64 key0, key1;  // the node's key when it was proposed / after the accepted pods
+      i64 alloc[ykk::kMaxR], used[ykk::kMaxR];  // its resource columns after the accepted pods
+      int room;        // pod slots left after them
+    };
+    const bool fit_on = (filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT) && (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT);
+    // Does a pod of `spec` still fit a node whose resource columns are (alloc, used) with `room` pod slots — NodeResourcesFit alone:
+    // what the other Filters said of the pair when it was proposed cannot have changed for a spec without a topology signature
+    // that wants no host port (taints, labels and names do not move during a round).
+    auto still_fits = [&](int spec, const Accepted& n) {
+      if (!fit_on) return true;
+      if (n.room < 1) return false;
+      for (int rr = 0; rr < e->R && rr < ykk::kMaxR; ++rr) {
+        const i64 q = e->h_req[(size_t)spec * (size_t)e->R + (size_t)rr];
+        if (q > 0 && q > n.alloc[rr] - n.used[rr]) return false;
+      }
+      return true;
+    };
+    auto spec_wants_ports = [&](int spec) {
+      for (int kp = 0; kp < e->KP; ++kp)
+        if (e->h_wanted[(size_t)spec * (size_t)e->KP + (size_t)kp] != 0) return true;
+      return false;
     };
     std::vector<Accepted> acc;
     const int R = e->R;
@@ -3511,25 +3531,57 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
         }
         const ykk::RoundProposal w = all[(size_t)best_rank * (size_t)b + (size_t)m];
         const int64_t gnode = w.gnode;
+        const int ask0 = asks[pos + m];
+        const int spec = e->h_pod_spec[(size_t)ask0];
+        // Round 6: the candidate may be a node that took pods EARLIER IN THIS BATCH — the common case under bin-packing, where ask
+        // after ask lands on the fullest node that fits until it is full. Its columns after those pods are arithmetic on what the
+        // proposals carry, and so is the question whether this ask still fits it: if it does, the node is this ask's answer too
+        // (it only moved towards the front); if not, the batch ends here and the ask is proposed again.
+        Accepted* same = nullptr;
+        for (Accepted& a2 : acc)
+          if (a2.gnode == gnode) same = &a2;
+        if (same && (spec_has_signature(spec) || spec_wants_ports(spec) || !still_fits(spec, *same))) break;
+        const u64 w_key_now = same ? same->key1 : w.key;
         bool conflict = false;
         for (const Accepted& a2 : acc) {
-          const bool behind_before = a2.key0 > w.key || (a2.key0 == w.key && a2.gnode > gnode);
-          const bool in_front_now = a2.key1 < w.key || (a2.key1 == w.key && a2.gnode < gnode);
-          if (a2.gnode == gnode || (behind_before && in_front_now)) {
+          if (a2.gnode == gnode) continue;
+          const bool behind_before = a2.key0 > w.key || (a2.key0 == w.key && a2.gnode > gnode);  // (against the keys the proposals were made with)
+          const bool in_front_now = a2.key1 < w_key_now || (a2.key1 == w_key_now && a2.gnode < gnode);
+          if (behind_before && in_front_now) {
             conflict = true;
             break;
           }
         }
         if (conflict) break;
+        Accepted node_now{};
+        if (same) {
+          node_now = *same;
+        } else {
+          node_now.gnode = gnode;
+          node_now.key0 = node_now.key1 = w.key;
+          for (int rr = 0; rr < ykk::kMaxR; ++rr) node_now.alloc[rr] = w.alloc[rr], node_now.used[rr] = w.req[rr];
+          node_now.room = w.room;
+        }
         // a run of asks with this spec and no pin lands on this node while it fits
-        const int ask0 = asks[pos + m];
-        const int spec = e->h_pod_spec[(size_t)ask0];
         int k = 1;
-        if (e->h_pod_pin[(size_t)ask0] == YKPRED_NO_NODE_NAME)
-          while (k < w.fits && m + k < b && e->h_pod_spec[(size_t)asks[pos + m + k]] == spec && e->h_pod_pin[(size_t)asks[pos + m + k]] == YKPRED_NO_NODE_NAME) ++k;
-        const i64 total[2] = {w.alloc[0], w.alloc[1]};
-        const i64 used[2] = {w.req[0] + e->h_req[(size_t)spec * (size_t)R + 0] * k, w.req[1] + e->h_req[(size_t)spec * (size_t)R + 1] * k};
-        acc.push_back(Accepted{gnode, w.key, host_sortable_key(host_node_score(total, used))});
+        const bool run_ok = e->h_pod_pin[(size_t)ask0] == YKPRED_NO_NODE_NAME && (same ? (fit_on && !spec_contributes(spec)) : true);
+        if (run_ok) {
+          // how many pods of the spec the node holds as it stands now (a node first met in this batch: the proposal's count)
+          i64 holds = same ? (i64)node_now.room : (i64)w.fits;
+          if (same)
+            for (int rr = 0; rr < R && rr < ykk::kMaxR; ++rr) {
+              const i64 q = e->h_req[(size_t)spec * (size_t)R + (size_t)rr];
+              if (q > 0) holds = std::min(holds, (node_now.alloc[rr] - node_now.used[rr]) / q);
+            }
+          while (k < holds && m + k < b && e->h_pod_spec[(size_t)asks[pos + m + k]] == spec && e->h_pod_pin[(size_t)asks[pos + m + k]] == YKPRED_NO_NODE_NAME) ++k;
+        }
+        for (int rr = 0; rr < R && rr < ykk::kMaxR; ++rr) node_now.used[rr] += e->h_req[(size_t)spec * (size_t)R + (size_t)rr] * k;
+        node_now.room -= k;
+        const i64 total[2] = {node_now.alloc[0], node_now.alloc[1]};
+        const i64 used[2] = {node_now.used[0], node_now.used[1]};
+        node_now.key1 = host_sortable_key(host_node_score(total, used));
+        if (same) *same = node_now;
+        else acc.push_back(node_now);
         contributed = contributed || spec_contributes(spec);
         for (int q = 0; q < k; ++q) {
           out_nodes[pos + m + q] = (int32_t)gnode;

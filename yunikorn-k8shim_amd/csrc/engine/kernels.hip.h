@@ -2946,8 +2946,10 @@ struct RoundProposal {      // a shard's best node for an ask, and what the othe
   u64 key;                  // score key of the node as it stands (smaller = earlier)
   int node;                 // node index in this shard, -1 = no node of the shard fits
   int fits;                 // how many pods of the ask's spec the node still holds when they couple through resources only, else 1
-  i64 alloc[2], req[2];     // cpu / memory Allocatable and Requested: the key after k more pods of a spec is arithmetic on these
-  int gnode, pad;           // node index in the whole cluster (the shard's node offset + node): the tie-break between equal keys
+  i64 alloc[kMaxR], req[kMaxR];  // Allocatable and Requested of every resource dimension ([0], [1] = cpu, memory: the key after k more pods
+                            // of a spec is arithmetic on these; all of them: whether a LATER ask of the batch still fits the node is too)
+  int gnode, room;          // node index in the whole cluster (the shard's node offset + node): the tie-break between equal keys;
+                            // pod slots left (AllowedPodNumber - len(Pods))
 };
 struct RoundArgs {
   int first, n_asks;        // this launch decides asks [first, first + n_asks) of the round
@@ -3674,18 +3676,17 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
         if (pin != -1 || tsig >= 0 || any_occ || contributes || !fit_on) fits = 1;
         const i64 used[2] = {(i64)__shfl((long long)old_l, 0, kWave), (i64)__shfl((long long)old_l, 1, kWave)};
         const i64 total[2] = {(i64)__shfl((long long)al_l, 0, kWave), (i64)__shfl((long long)al_l, 1, kWave)};
+        RoundProposal* out = a.prop + first_ask + i;
+        if (lane < kMaxR) {  // (lane r = resource r; lanes past the table's dimensions hold zeros)
+          out->alloc[lane] = al_l;
+          out->req[lane] = old_l;
+        }
         if (lane == 0) {
-          RoundProposal pr;
-          pr.key = win >= 0 ? sortable_key(node_score_of(total, used)) : ~0ull;
-          pr.node = win;
-          pr.fits = win >= 0 ? (int)max((i64)1, min(fits, (i64)0x7fffffff)) : 0;
-          pr.alloc[0] = total[0];
-          pr.alloc[1] = total[1];
-          pr.req[0] = used[0];
-          pr.req[1] = used[1];
-          pr.gnode = win >= 0 ? a.node_offset + win : -1;
-          pr.pad = 0;
-          a.prop[first_ask + i] = pr;
+          out->key = win >= 0 ? sortable_key(node_score_of(total, used)) : ~0ull;
+          out->node = win;
+          out->fits = win >= 0 ? (int)max((i64)1, min(fits, (i64)0x7fffffff)) : 0;
+          out->gnode = win >= 0 ? a.node_offset + win : -1;
+          out->room = allowed - cnt0;
         }
       }
       last_spec = -1;
