@@ -1246,6 +1246,34 @@ def test_full_size_configs(pm, n_nodes, n_pods, affinity):
     assert pm.checksum() == sum_plane
 
 
+@pytest.mark.parametrize("unique", [1, 0], ids=["a-request-of-its-own-per-ask", "a-template-of-its-own-per-ask"])
+def test_full_size_small_class_populations(pm, unique):
+    """The two small-class populations of bench.py at configs[2] size (50 000 nodes x 10^6 asks) — the run writers (k_sweep_rows /
+    k_class_runs), the run-level decisions and what is left to the chunk writers: every member row = its class's row
+    (k_check_class_rows), the whole bitmap's checksum = the independent per-pair kernel's (k_direct evaluates every one of the
+    5e10 pairs from the tables), 48 sampled classes x all nodes, their counts and their decisions against the oracle."""
+    pm.generate_kwok(seed=0x59554E49 + 40 + unique, num_nodes=50_000, num_pods=1_000_000, num_templates=0, node_affinity=1, unique_requests=unique)
+    pm.evaluate()
+    lay = pm.layout()
+    assert (lay.sweep_rows > 900_000) if unique else (lay.run_rows > 250_000), (lay.sweep_rows, lay.run_rows)
+    assert pm.check_class_rows() == 0
+    plane_sum = pm.checksum()
+    counts, dec = pm.read_counts(), pm.read_decisions()
+    pod_class, rep = pm.pod_classes()
+    sample = np.sort(np.random.default_rng(11).choice(len(rep), 48, replace=False))
+    reps = rep[sample].astype(np.int32)
+    o = orc.Oracle(pm.dump_snapshot(pods=reps, compact=True))
+    want = o.eval_grid(threads=os.cpu_count() or 8)
+    assert np.array_equal(unpack(pm.read_rows(reps), 50_000), want)
+    assert np.array_equal(counts[reps], want.sum(axis=1))
+    for k in range(len(reps)):
+        assert o.decide(k) == (int(want[k].sum()), int(dec[reps[k]])), k
+    assert np.array_equal(dec, dec[rep][pod_class]) and np.array_equal(counts, counts[rep][pod_class])
+    pm.evaluate(direct=True, counts=False, decisions=False)
+    assert pm.checksum() == plane_sum
+    o.close()
+
+
 @pytest.mark.parametrize("n_nodes,n_pods,affinity,gang,spread", [(10_000, 100_000, 0, 0, 0), (50_000, 1_000_000, 1, 0, 0), (50_000, 1_000_000, 1, 100, 0),
                                                                  (100_000, 1_000_000, 1, 0, 1), (100_000, 5_000_000, 1, 0, 1)],
                          ids=["configs1", "configs2", "configs3-gang", "configs4-shape", "configs4-size"])
