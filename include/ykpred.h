@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 /* 4: ykpred_set_spec_effects + ykpred_spec_effects_t, ykpred_comm_info (round 5 added them without a bump: a host built against the
- *    header could not tell an older library apart), ykpred_layout_t.sweep_rows / index_rows_walked / run_rows
+ *    header could not tell an older library apart), ykpred_layout_t.sweep_rows / index_rows_walked / run_rows / fused_rows
  * 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row (the resident
  *    answer served to single Predicates() callbacks), ykpred_eval_nodes is collective on a sharded engine with topology signatures
  * 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
@@ -245,6 +245,8 @@ typedef struct ykpred_layout {
                            a full pass writes them with k_sweep_rows (a row = its predecessor minus the nodes the larger value loses) */
   int32_t index_rows_walked; /* of index_rows: the ones a full pass still materialises (k_dim_walk) — the sweep runs read none */
   int32_t run_rows;     /* rows of zone B whose classes (no index row, staged request-value rows) are written run by run: k_class_runs */
+  int32_t fused_rows;   /* rows of zone B whose classes no run kernel takes and whose rows are plain plane rows: written from records resolved
+                           at class-build time (k_fused_rows) */
 } ykpred_layout_t;
 
 #define YKPRED_MAX_TIMED_KERNELS 24

@@ -404,6 +404,44 @@ def test_class_runs_writer_equals_chunk_writers_and_oracle(monkeypatch, n_nodes,
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("n_nodes,n_pods", [(1500, 6000), (8300, 5000), (29000, 3000), (50_000, 4000)],
+                         ids=["one-group", "three-groups", "two-segments", "configs2-width"])
+def test_fused_rows_equal_chunk_writers_and_oracle(monkeypatch, n_nodes, n_pods):
+    """k_fused_rows (round 6): the zone-B classes no run kernel takes — signatures with a handful of rows, asks with a selector of
+    their own — written from records resolved at class-build time (the plane rows to AND, the member rows to store; compute waves
+    that only load, a store wave that only stores). Against the chunk writers (YKPRED_TUNE fuse_rows=0) on the own-template
+    population — bitmap, counts, decisions, both phases, further allocation passes — and against the oracle."""
+    got = {}
+    for knob in (0, 1):
+        monkeypatch.setenv("YKPRED_TUNE", f"fuse_rows={knob},class_runs_min_rows=8")
+        m = pkg.GpuPredicateManager()
+        try:
+            m.generate_kwok(seed=2718 + n_nodes, num_nodes=n_nodes, num_pods=n_pods, num_templates=0, node_affinity=1)
+            m.evaluate()
+            lay = m.layout()
+            assert (lay.fused_rows > n_pods // 100) if knob else (lay.fused_rows == 0), lay.fused_rows
+            assert m.check_class_rows() == 0
+            got[knob] = [unpack(m.read_bitmap(), n_nodes), m.read_counts(), m.read_decisions()]
+            m.evaluate(allocate=False)  # the reservation phase: no request rows, no run kernels, no fused rows
+            got[knob] += [unpack(m.read_bitmap(), n_nodes), m.read_counts()]
+            m.evaluate()
+            assert np.array_equal(unpack(m.read_bitmap(), n_nodes), got[knob][0]) and np.array_equal(m.read_counts(), got[knob][1])
+            m.evaluate(decisions=False)
+            assert np.array_equal(unpack(m.read_bitmap(), n_nodes), got[knob][0]) and np.array_equal(m.read_counts(), got[knob][1])
+            if knob:
+                o = orc.Oracle(m.dump_snapshot(compact=True))
+                sample = np.arange(n_pods) if n_nodes <= 1500 else np.random.default_rng(5).choice(n_pods, size=64, replace=False).astype(np.int32)
+                want = o.eval_grid(pods=sample, threads=os.cpu_count() or 8)
+                assert np.array_equal(got[knob][0][sample], want)
+                assert np.array_equal(got[knob][1][sample], want.sum(axis=1))
+                for k, p in enumerate(sample[:12]):
+                    assert o.decide(int(p)) == (int(want[k].sum()), int(got[knob][2][p]))
+        finally:
+            m.close()
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_sweep_writer_random_clusters_two_walked_dimensions(monkeypatch, seed):
     """Random edge-case clusters with every request dimension walked (walk_rows=1) and runs from two rows on: two walked dimensions

@@ -43,7 +43,7 @@ class YkpredLayout(C.Structure):
                 ("decision_keys", C.c_void_p), ("spread_counts", C.c_void_p), ("spread_present", C.c_void_p),
                 ("spread_cells", C.c_int64), ("num_rows", C.c_int32), ("band_rows", C.c_int32), ("row_of_pod", C.c_void_p),
                 ("index_rows", C.c_int32), ("band_steps", C.c_int32),
-                ("sweep_rows", C.c_int32), ("index_rows_walked", C.c_int32), ("run_rows", C.c_int32)]
+                ("sweep_rows", C.c_int32), ("index_rows_walked", C.c_int32), ("run_rows", C.c_int32), ("fused_rows", C.c_int32)]
 
 
 MAX_TIMED = 24

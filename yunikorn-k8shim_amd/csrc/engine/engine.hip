@@ -272,6 +272,16 @@ struct ykpred_engine {
   int sweep_rows[ykk::kMaxIdxRows] = {0, 0}, sweep_row_off[ykk::kMaxIdxRows + 1] = {0, 0, 0}, sweep_runs = 0;  // per walked dimension
   int index_rows_needed = 0;         // index rows some class OUTSIDE the sweep runs reads (the full pass walks only those)
   DevBuf d_agree;  // sharded rounds: what the ranks agree on before the first batch
+  // fused rows (k_fused_rows): the zone-B classes no run kernel takes whose rows are plain plane rows, resolved to records at class-build time
+  int fuse_rows = 1;                 // tunable (YKPRED_TUNE fuse_rows): 0 = those classes stay with the chunk writers
+  int fuse_wpl = 0;                  // tunable (YKPRED_TUNE fuse_wpl): words per lane of k_fused_rows (1, 2, 5); 0 = from the row width
+  int fuse_count = 0, fuse_row_count = 0;  // classes / bitmap rows
+  bool fuse_ready = false;           // the current class build has fused classes and nothing has touched them since
+  DevBuf d_fuse_rec;                 // FuseRec[fuse_count]
+  int fuse_combos = 0;               // distinct (toleration, request vector) pairs among them: their ANDs are written first (0: records name their rows directly)
+  int fuse_combine = 1;              // tunable (YKPRED_TUNE fuse_combine): 0 = never
+  DevBuf d_fuse_combo_rec, d_fuse_combo;  // FuseRec[fuse_combos]; the combination table [fuse_combos][row_stride]
+  std::vector<uint8_t> h_class_fused;
   // decisions of the sweep runs (k_run_decide): one range per run of the sweep row list, the classes k_decide leaves to it
   int run_decide = 1;                // tunable (YKPRED_TUNE run_decide): 0 = k_decide scans every class
   int run_ranges = 0, n_decide_list = 0, run_decide_classes = -1;  // (classes at the build the lists describe)
@@ -1056,6 +1066,96 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
       e->sweep_runs = (int)runs.size();
       e->sweep_ready = true;
     }
+    // FUSED ROWS: what is left to the chunk writers — the signatures with a handful of rows, the asks with a selector of their own — is
+    // written by k_fused_rows from RECORDS resolved here (see FuseRec): unpinned classes without a topology signature whose rows are
+    // plain plane rows, in row order. They need a full pass with NodeResourcesFit and NodeAffinity evaluated and counts added by the
+    // writers (the run kernels' pass conditions).
+    e->fuse_count = e->fuse_row_count = 0;
+    e->fuse_ready = false;
+    e->h_class_fused.assign((size_t)C, 0);
+    if (e->fuse_rows != 0 && e->fam_aff.D > 0 && !e->h_res_rows.empty()) {
+      std::vector<int32_t> users((size_t)e->fam_aff.D, 0);
+      for (int c = 0; c < C; ++c)
+        if (key(c, 2) >= 0 && key(c, 2) < e->fam_aff.D) users[(size_t)key(c, 2)]++;
+      std::vector<ykk::FuseRec> recs;
+      for (int32_t c : order_b) {
+        const int sa = key(c, 2), sr = key(c, 0), stl = key(c, 1);
+        if (!tail[(size_t)c] || e->h_class_sweep[(size_t)c] || class_size[(size_t)c] < 1 || class_pin[(size_t)c] != -1 || key(c, 3) >= 0) continue;
+        if (sa < 0 || sa >= e->fam_aff.D || sr < 0 || (size_t)(sr + 1) * (size_t)R1 > e->h_res_rows.size()) continue;
+        ykk::FuseRec rec{};
+        rec.cls = c, rec.dest = first_row_of[(size_t)c], rec.len = class_size[(size_t)c];
+        rec.row[rec.n++] = (2 << ykk::kFuseFamShift) | sa;  // (family-relative: the families' first rows are known per pass, ensure_planes)
+        if (stl >= 0) rec.row[rec.n++] = (1 << ykk::kFuseFamShift) | stl;
+        bool ok = true;
+        for (int k = 0; k < R1 && ok; ++k) {
+          const int r = e->h_res_rows[(size_t)sr * (size_t)R1 + (size_t)k];
+          if (r < 0) continue;
+          if ((r >> ykk::kRowBigShift) || rec.n >= 8) ok = false;
+          else rec.row[rec.n++] = r;
+        }
+        if (!ok) continue;
+        recs.push_back(rec);
+        e->h_class_fused[(size_t)c] = 1;
+        e->fuse_count++;
+        e->fuse_row_count += rec.len;
+      }
+      e->fuse_combos = 0;
+      if (e->fuse_count > 0) {
+        // Classes that differ only in their node-affinity signature share the AND of their other rows: one COMBINATION per distinct
+        // (toleration, request vector) pair, written first by the same kernel; a class is then two rows. Worth it while a
+        // combination serves several classes (else the records keep naming their rows).
+        std::unordered_map<uint64_t, int32_t> combo_of;
+        std::vector<ykk::FuseRec> combo_recs;
+        std::vector<int32_t> combo_ix(recs.size(), -1);
+        for (size_t i = 0; i < recs.size(); ++i) {
+          const int32_t c = recs[i].cls;
+          const uint64_t k2 = ((uint64_t)(uint32_t)key(c, 1) << 32) | (uint32_t)key(c, 0);
+          auto it = combo_of.find(k2);
+          if (it == combo_of.end()) {
+            it = combo_of.emplace(k2, (int32_t)combo_recs.size()).first;
+            ykk::FuseRec cr{};
+            cr.cls = 0, cr.dest = it->second, cr.len = 1;
+            for (int k = 1; k < recs[i].n; ++k) cr.row[cr.n++] = recs[i].row[k];
+            combo_recs.push_back(cr);
+          }
+          combo_ix[i] = it->second;
+        }
+        bool combine = e->fuse_combine != 0 && combo_recs.size() * 4 <= recs.size() && combo_recs.size() <= 16384;
+        for (const ykk::FuseRec& cr : combo_recs) combine = combine && cr.n >= 1;  // (a class of the affinity row alone has nothing to combine)
+        if (combine) {
+          for (size_t i = 0; i < recs.size(); ++i) {
+            recs[i].n = 2;
+            recs[i].row[1] = (3 << ykk::kFuseFamShift) | combo_ix[i];
+          }
+          e->fuse_combos = (int)combo_recs.size();
+          TRY(upload(e, e->d_fuse_combo_rec, combo_recs.data(), combo_recs.size(), st));
+          HIPCHK(e->d_fuse_combo.ensure((size_t)e->fuse_combos * (size_t)e->row_stride * sizeof(u64)));
+        }
+        TRY(upload(e, e->d_fuse_rec, recs.data(), recs.size(), st));
+        e->fuse_ready = true;
+      }
+      if (getenv("YKPRED_TRACE_RUNS")) {
+        // what the chunk writers keep: tail classes by size and by the number of classes that share their affinity signature
+        long t_cls = 0, t_rows = 0, t_single = 0, t_single_shared = 0, t_single_big = 0, t_single_spread = 0, t_pinned = 0;
+        for (int32_t c : order_b) {
+          if (!tail[(size_t)c] || e->h_class_sweep[(size_t)c] || e->h_class_fused[(size_t)c]) continue;
+          ++t_cls, t_rows += class_size[(size_t)c];
+          if (class_size[(size_t)c] == 1) {
+            ++t_single;
+            const int sa = key(c, 2);
+            if (sa >= 0 && sa < e->fam_aff.D && users[(size_t)sa] != 1) ++t_single_shared;
+            if (key(c, 3) >= 0) ++t_single_spread;
+            if (class_pin[(size_t)c] != -1) ++t_pinned;
+            const int sr = key(c, 0);
+            if (sr >= 0)
+              for (int k = 0; k < R1; ++k)
+                if (e->h_res_rows[(size_t)sr * (size_t)R1 + (size_t)k] > 0 && (e->h_res_rows[(size_t)sr * (size_t)R1 + (size_t)k] >> ykk::kRowBigShift)) { ++t_single_big; break; }
+          }
+        }
+        fprintf(stderr, "fused: %d classes, %d rows, %d combinations; chunk writers keep %ld classes / %ld rows of zone B (%ld single-row: %ld share their affinity signature, %ld with an index row, %ld spread, %ld pinned)\n",
+                e->fuse_count, e->fuse_row_count, e->fuse_combos, t_cls, t_rows, t_single, t_single_shared, t_single_big, t_single_spread, t_pinned);
+      }
+    }
   }
   e->rows_total = next_row;
   e->rows_a = rows_a;
@@ -1090,7 +1190,7 @@ int build_classes(ykpred_engine* e, hipStream_t st) {
     ch_begin.push_back(k.begin);
     ch_len.push_back(k.len);
     ch_first.push_back(k.first);
-    e->h_ch_zone.push_back(e->h_class_slot_a[(size_t)k.cls] >= 0 ? 1 : (e->h_class_sweep[(size_t)k.cls] ? 2 : 0));
+    e->h_ch_zone.push_back(e->h_class_slot_a[(size_t)k.cls] >= 0 ? 1 : (e->h_class_sweep[(size_t)k.cls] ? 2 : (e->h_class_fused[(size_t)k.cls] ? 3 : 0)));
   }
   // the zone-B chunks by number: the full pass launches the class-by-class writer over this list only
   std::vector<int32_t> chunk_list_b;
@@ -1544,6 +1644,9 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "sweep_groups") e->sweep_groups = std::max(val, 0);
       else if (key == "class_runs") e->class_runs = val;
       else if (key == "run_decide") e->run_decide = val;
+      else if (key == "fuse_rows") e->fuse_rows = val;
+      else if (key == "fuse_wpl") e->fuse_wpl = val;
+      else if (key == "fuse_combine") e->fuse_combine = val;
       else if (key == "class_runs_min_rows") e->class_runs_min_rows = std::max(val, 1);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
@@ -1594,7 +1697,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
                     &e->d_rank, &e->d_perm, &e->d_sreq, &e->d_stol, &e->d_sflags, &e->d_aff_off, &e->d_aff_terms, &e->d_pre_off,
                     &e->d_pre_terms, &e->d_dim_val, &e->d_dim_order, &e->d_dim_chunk_dim, &e->d_dim_chunk_begin, &e->d_dim_chunk_len,
                     &e->d_res_rows, &e->d_big_dim, &e->d_walk_big, &e->d_walk_begin, &e->d_walk_len, &e->d_sfree_c, &e->d_pmask_c,
-                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_run_ranges, &e->d_no_decide, &e->d_glin_r, &e->d_run_classes, &e->d_run_units, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
+                    &e->d_sfree_r, &e->d_pmask_r, &e->d_rbits_c, &e->d_sorted, &e->d_sorted_off, &e->d_ent_c, &e->d_agree, &e->d_fuse_rec, &e->d_fuse_combo_rec, &e->d_fuse_combo, &e->d_run_ranges, &e->d_no_decide, &e->d_glin_r, &e->d_run_classes, &e->d_run_units, &e->d_sweep_rows, &e->d_sweep_runs, &e->d_sweep_units, &e->d_chunk_list_b0, &e->d_walk2_order, &e->d_walk2_big, &e->d_walk2_begin, &e->d_walk2_len, &e->d_idx_c, &e->d_win_r, &e->d_pfx_r, &e->d_slice_desc, &e->d_slice_general, &e->d_chunk_list_b, &e->d_first_r, &e->d_sig_tol, &e->d_sig_tolflags, &e->d_sig_aff_flags, &e->d_sig_aff_off,
                     &e->d_sig_aff_terms, &e->d_sig_pre_off, &e->d_sig_pre_terms, &e->d_pod_spec, &e->d_pod_pin, &e->d_pod_class,
                     &e->d_class_sig, &e->d_class_pin, &e->d_class_first, &e->d_class_word, &e->d_chunk_class, &e->d_chunk_begin, &e->d_chunk_len, &e->d_chunk_first,
                     &e->d_pod_row, &e->d_band_tab, &e->d_class_rows_a, &e->d_class_list_a, &e->d_class_slot_a, &e->d_fix_row, &e->d_fix_slot, &e->d_chunk_zone,
@@ -2223,6 +2326,9 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                                   (a->options & (YKPRED_OUT_DECISIONS | YKPRED_OUT_DECISION_KEYS)) != 0;
   const bool use_sweep = e->sweep_ready && e->sweep_runs > 0 && res_on && !fit_error && full_pass && !counts_early_here;
   const bool sweep_rows_on = use_sweep && e->n_big > 0 && e->sweep_row_off[ykk::kMaxIdxRows] > 0;  // k_sweep_rows has rows (k_class_runs: run_classes)
+  // k_fused_rows takes the fused classes of a full pass whose writers add the counts (NodeResourcesFit and node affinity evaluated,
+  // every Filter with its PreFilter state)
+  const bool fuse_on = e->fuse_ready && res_on && !fit_error && full_pass && !counts_early_here && aff_on && !spread_err;
   // the decisions of the sweep runs come from k_run_decide wherever decisions are produced from walked request rows (any pass, also a
   // decision refresh without the bitmap): k_decide skips those classes and no window of their index rows is written
   const bool use_run_decide = e->run_decide != 0 && e->sweep_ready && e->run_ranges > 0 && res_on && !fit_error && e->n_big > 0 &&
@@ -2230,7 +2336,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                               e->C == e->run_decide_classes;  // (a class that row patches added since the build is in neither list: k_decide takes them all then)
   use_run_decide_pass = use_run_decide;
   ykk::ClassTable ct{e->d_class_sig.as<int>(), e->d_class_pin.as<int>(),  e->d_chunk_class.as<int>(), e->d_chunk_begin.as<int>(),
-                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), use_sweep ? 1 : 0,
+                     e->d_chunk_len.as<int>(), e->d_chunk_first.as<int>(), e->d_members.as<int>(), e->d_chunk_zone.as<int>(), (use_sweep ? 1 : 0) | (fuse_on ? 2 : 0),
                      use_run_decide ? e->d_no_decide.as<int>() : nullptr};
   ykk::Planes pc{res_on ? o_res.canon : nullptr, o_tol.canon, aff_on ? o_aff.canon : nullptr, spread_on ? o_spread.canon : nullptr,
                  e->row_stride, e->d_res_rows.as<int>(), 1 + e->R, e->d_idx_c.as<unsigned char>(), e->idx_stride, e->d_pmask_c.as<u64>(), e->row_words,
@@ -2289,7 +2395,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     bp.stride = e->row_stride;
     return bp;
   };
-  auto launch_dictionary_planes = [&](hipStream_t s, const int* perm, bool ranked, const char* base_name, const char* sig_name, bool base_done = false) {
+  auto launch_dictionary_planes = [&](hipStream_t s, const int* perm, bool ranked, const char* base_name, const char* sig_name, bool base_done = false) -> int {
     ykk::BasePlanes bp = base_of(ranked ? e->base_ranked : e->base_canon);
     if (!base_done) {
       tm.begin(s);
@@ -2319,23 +2425,24 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     sa.pre_mask = pre;
     sa.filt_mask = filt;
     sa.n_words = e->row_words;
-    const unsigned chunks = (unsigned)((std::max(sa.tol.D, sa.aff.D) + ykk::kBitSigsPerBlock - 1) / ykk::kBitSigsPerBlock);
     tm.begin(s);
     // words per lane: wide rows give a lane 4 (or 2) words 64 apart — the per-signature latency chain moves more bytes
     const int wpl = e->sig_wpl > 0 ? e->sig_wpl : (e->row_words >= 4 * ykk::kWave ? 4 : (e->row_words >= 2 * ykk::kWave ? 2 : 1));
+    const unsigned chunks = std::max((unsigned)((std::max(sa.tol.D, sa.aff.D) + ykk::kBitSigsPerBlock - 1) / ykk::kBitSigsPerBlock), 1u);
     const unsigned ygroups = (unsigned)((e->row_words + ykk::kBlock * wpl - 1) / (ykk::kBlock * wpl));
     if (wpl >= 4)
-      hipLaunchKernelGGL(ykk::k_sig_planes<4>, dim3(std::max(chunks, 1u), ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
+      hipLaunchKernelGGL(ykk::k_sig_planes<4>, dim3(chunks, ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
     else if (wpl >= 2)
-      hipLaunchKernelGGL(ykk::k_sig_planes<2>, dim3(std::max(chunks, 1u), ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
+      hipLaunchKernelGGL(ykk::k_sig_planes<2>, dim3(chunks, ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
     else
-      hipLaunchKernelGGL(ykk::k_sig_planes<1>, dim3(std::max(chunks, 1u), ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
+      hipLaunchKernelGGL(ykk::k_sig_planes<1>, dim3(chunks, ygroups, 2u), dim3(ykk::kBlock), 0, s, sa);
     tm.end(s, sig_name);
+    return YKPRED_OK;
   };
   // ---- stream B, part 2: dictionary planes in rank order (needs only the bin-pack order). With few signature planes
   // altogether the rank-ordered copies of ALL of them come from one bit permutation of the canonical planes (part 3) — a
   // fraction of the work of evaluating the dictionary families a second time, and less traffic beside the band writer.
-  if (want_dec) launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)");
+  if (want_dec) TRY(launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)"));
   // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
   auto ranked_walk = [](const int* perm) { return perm != nullptr; };
   auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name, bool with_base = false) {
@@ -2423,7 +2530,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   };
   const bool fused_planes = res_on || spread_on;
   if (fused_planes) launch_ballot_planes(st, nullptr, "k_planes+k_base_planes", true);
-  launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes", fused_planes);
+  TRY(launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes", fused_planes));
   // ---- stream B, part 3 (after the canonical ballot planes): their rank-ordered copies by bit permutation, then the
   // first feasible node of every class. Overlaps the start of k_combine.
   if (want_dec) {
@@ -2493,8 +2600,11 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     // the full pass runs the class-by-class writer over the zone-B chunks only (the dirty-class pass over every chunk)
     // (chunks appended by ykpred_update_pods since the class build are not in the list: then every chunk runs, as the dirty pass does)
     const bool listed = !dirty_only && e->patch_chunks == 0;
-    const int* chunk_list = listed ? (use_sweep ? e->d_chunk_list_b0 : e->d_chunk_list_b).as<int>() : nullptr;
-    const int n_run = listed ? (use_sweep ? e->NCB0 : e->NCB) : e->NC;
+    // (the short list — zone 0 alone — when both the run kernels and the fused rows are on, or no class is fused; else every zone-B chunk
+    // goes through the writers' zone filter)
+    const bool short_list = use_sweep && (fuse_on || e->fuse_count == 0);
+    const int* chunk_list = listed ? (short_list ? e->d_chunk_list_b0 : e->d_chunk_list_b).as<int>() : nullptr;
+    const int n_run = listed ? (short_list ? e->NCB0 : e->NCB) : e->NC;
     dim3 grid((unsigned)std::max(n_run, 1), (unsigned)((e->row_stride + seg - 1) / seg));
     // Both writers run on the launch stream, the band writer first. (Measured in round 3, profiles/r03_writer_knobs.txt: the
     // class-by-class writer BESIDE the band writer on a third stream upsets the one-workgroup-per-CU placement the band writer
@@ -2601,6 +2711,33 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         }
       }
       tm.end(sz, "k_sweep_rows");
+    }
+    if (fuse_on) {
+      // the classes no run kernel takes, from their records: three compute waves of WPL words per lane cover a group of 192 * WPL
+      // words (50 k nodes = 782 words: one group at WPL 5; a 6 250-node shard = 98 words: WPL 1)
+      const int wpl = e->fuse_wpl >= 5 ? 5 : (e->fuse_wpl >= 2 ? 2 : (e->fuse_wpl == 1 ? 1 : (e->row_words > 384 ? 5 : (e->row_words > 192 ? 2 : 1))));
+      const int gw = ykk::kFuseComputeWaves * ykk::kWave * wpl;
+      const unsigned ygroups = (unsigned)((e->row_words + gw - 1) / gw);
+      ykk::FuseSrc fsrc{e->planes_canon.as<u64>(), e->fuse_combos > 0 ? e->d_fuse_combo.as<u64>() : nullptr, {e->fam_res.base, e->fam_tol.base, e->fam_aff.base}};
+      tm.begin(sz);
+      auto launch_fused = [&](auto kernel, const ykk::FuseRec* recs, int n, u64* out, int* counts) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((n + ykk::kFuseRecsPerBlock - 1) / ykk::kFuseRecsPerBlock), ygroups), dim3(ykk::kBlock), 0, sz, recs, n, fsrc,
+                           e->row_words, e->row_stride, out, counts);
+      };
+      auto launch_wide = [&](const ykk::FuseRec* recs, int n, u64* out, int* counts) {  // records that name up to eight rows
+        if (wpl == 5) launch_fused(ykk::k_fused_rows<5, 8>, recs, n, out, counts);
+        else if (wpl == 2) launch_fused(ykk::k_fused_rows<2, 8>, recs, n, out, counts);
+        else launch_fused(ykk::k_fused_rows<1, 8>, recs, n, out, counts);
+      };
+      if (e->fuse_combos > 0) {
+        launch_wide(e->d_fuse_combo_rec.as<ykk::FuseRec>(), e->fuse_combos, e->d_fuse_combo.as<u64>(), nullptr);
+        if (wpl == 5) launch_fused(ykk::k_fused_rows<5, 2>, e->d_fuse_rec.as<ykk::FuseRec>(), e->fuse_count, bitmap, e->d_class_count.as<int>());
+        else if (wpl == 2) launch_fused(ykk::k_fused_rows<2, 2>, e->d_fuse_rec.as<ykk::FuseRec>(), e->fuse_count, bitmap, e->d_class_count.as<int>());
+        else launch_fused(ykk::k_fused_rows<1, 2>, e->d_fuse_rec.as<ykk::FuseRec>(), e->fuse_count, bitmap, e->d_class_count.as<int>());
+      } else {
+        launch_wide(e->d_fuse_rec.as<ykk::FuseRec>(), e->fuse_count, bitmap, e->d_class_count.as<int>());
+      }
+      tm.end(sz, "k_fused_rows");
     }
     tm.begin(sz);
     // Index rows to decode: k_walk_rows — a wave writes whole rows, the rank planes of the walked dimensions (56 bytes per word) staged
@@ -2956,7 +3093,7 @@ int32_t ykpred_update_pods(ykpred_engine_t* e, int32_t num_pods_after, int32_t c
     const int c = e->h_pod_class[(size_t)p], slot = e->h_pod_slot[(size_t)p];
     e->h_members[(size_t)slot] = -1;
     put(T_MEMBERS, slot, -1);
-    if ((size_t)c < e->h_class_sweep.size() && e->h_class_sweep[(size_t)c]) e->sweep_ready = false;  // (its row list names a row that is gone: the chunk writers take the runs until the next class build)
+    if ((size_t)c < e->h_class_sweep.size() && (e->h_class_sweep[(size_t)c] || e->h_class_fused[(size_t)c])) e->sweep_ready = e->fuse_ready = false;  // (its row list names a row that is gone: the chunk writers take the runs until the next class build)
     e->h_class_live[(size_t)c]--;
     if (e->h_class_first[(size_t)c] == p) {
       e->h_class_first[(size_t)c] = -1;
@@ -3678,6 +3815,7 @@ int32_t ykpred_get_layout(const ykpred_engine_t* e, ykpred_layout_t* o) {
   o->sweep_rows = e->sweep_ready ? e->sweep_row_off[ykk::kMaxIdxRows] : 0;
   o->index_rows_walked = (e->sweep_ready && e->walk2_chunks >= 0) ? e->index_rows_needed : e->index_rows;
   o->run_rows = e->sweep_ready ? e->run_rows : 0;
+  o->fused_rows = e->fuse_ready ? e->fuse_row_count : 0;
   o->bitmap_bytes = (uint64_t)std::max(o->num_rows, 1) * (uint64_t)e->row_stride * sizeof(u64);
   o->bitmap = e->last_bitmap;
   o->counts = e->last_counts ? e->last_counts : e->d_counts.p;

@@ -1132,9 +1132,10 @@ struct ClassTable {
   const int* decide_list;  // or null: the classes k_decide scans (those whose decision does not come from k_run_decide), n_classes = their number
 };
 // full pass: is the chunk left to another writer (the band writer, k_sweep_rows)?
+// (zone 3: a class with a FuseRec — k_fused_rows writes its rows in the passes that run it: sweep_on bit 1)
 __device__ __forceinline__ bool chunk_elsewhere(const ClassTable& ct, int chunk) {
   const int z = ct.chunk_zone[chunk];
-  return z == 1 || (z == 2 && ct.sweep_on);
+  return z == 1 || (z == 2 && (ct.sweep_on & 1)) || (z == 3 && (ct.sweep_on & 2));
 }
 struct Planes {
   const u64* res;         // value planes of NodeResourcesFit (row 0 = pod-independent part); null = family disabled
@@ -1963,6 +1964,157 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_rows(
       if (__builtin_amdgcn_readfirstlane(dd.w) != run) break;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_fused_rows: the zone-B writer of the classes NO run kernel takes (round 6) — a signature with a handful of rows, an ask with a
+// node selector of its own: unpinned classes whose rows are plain plane rows (no index row, no topology signature). 77 k of them
+// took k_combine_wave 0.34 ms on the own-template population (1.4 TB/s): a wave there resolves its class through three levels of
+// dependent table loads and then alternates loads and stores, and gfx9 counts both in ONE in-order counter — every wait for a
+// plane word is a wait for the kilobyte stored before it. Here the class is a RECORD the host resolved at class-build time (the
+// plane rows to AND, the bitmap rows to write), and the roles are split the way the band writer splits them: waves 0..2 of a
+// workgroup COMPUTE (they only ever load: a record's rows, WPL words per lane), wave 3 STORES (it only ever reads LDS): a class's
+// words go through a double-buffered LDS row, one s_barrier per class with LDS-scope fences only — no vmcnt wait stands between a
+// load and an earlier store anywhere.
+//
+// What the first form of it showed (profiles/r06_fused_rows_experiments.txt): with five rows per record — affinity, toleration,
+// three request-value rows — the kernel was no faster than k_combine_wave, and its time was the SUM of three parts: 0.12 ms the
+// affinity row + the per-record step (LDS, barrier), 0.11 ms the four shared rows (L2 hits, but every word of them through the
+// compute unit's texture path: 31 KB per 6 KB written), 0.06 ms the stores; prefetching the affinity row further ahead changed
+// nothing. So the shared rows are COMBINED first: classes that differ only in their node-affinity signature share the AND of their
+// other rows (toleration & request values: as many combinations as there are distinct (toleration, request vector) pairs among
+// these classes), the same kernel writes those combination rows into a small table (MAXR 8, a launch of a few hundred records), and
+// a class is affinity row & combination row (MAXR 2): two loads per 6 KB written, half the registers, twice the workgroups per CU.
+struct FuseRec {
+  int cls, dest, len, n;  // class (count slot), its first output row, member rows (consecutive), plane rows to AND
+  int row[8];             // family << kFuseFamShift | row of the family: 0 = request values, 1 = toleration, 2 = node affinity (first),
+                          // 3 = the combination table
+};
+constexpr int kFuseFamShift = 28;
+constexpr int kFuseComputeWaves = 3;
+constexpr int kFuseRecInts = sizeof(FuseRec) / sizeof(int);
+constexpr int kFuseRecsPerBlock = 16;  // 192 ints: three registers of a wave hold the block's records
+__device__ __forceinline__ void wg_barrier_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// int j (wave-uniform) of the block's records, held by lanes of three registers
+__device__ __forceinline__ int fuse_rec_field(int l0, int l1, int l2, int j) {
+  const int v = j < kWave ? l0 : (j < 2 * kWave ? l1 : l2);
+  return __builtin_amdgcn_readlane(v, j & (kWave - 1));
+}
+struct FuseSrc {
+  const u64* planes;  // the canonical plane buffer
+  const u64* combos;  // the combination table (family 3), or null
+  int base[3];        // first rows of the request-value, toleration and node-affinity families in `planes`
+};
+__device__ __forceinline__ const u64* fuse_row(const FuseSrc& src, int enc, int stride) {
+  const int fam = enc >> kFuseFamShift, id = enc & ((1 << kFuseFamShift) - 1);
+  const int b0 = src.base[0], b1 = src.base[1], b2 = src.base[2];
+  const u64* p = fam == 3 ? src.combos : src.planes;
+  const int base = fam == 0 ? b0 : (fam == 1 ? b1 : (fam == 2 ? b2 : 0));
+  return p + (size_t)(id + base) * stride;
+}
+// grid.x = blocks of kFuseRecsPerBlock records, grid.y = groups of 3 * 64 * WPL row words; MAXR = most rows a record of the launch has
+template <int WPL, int MAXR>
+__global__ __launch_bounds__(kBlock) void k_fused_rows(const FuseRec* __restrict__ recs, int n_recs, FuseSrc src, int n_words, int stride,
+                                                       u64* __restrict__ out, int* __restrict__ class_count /* null: not counted */) {
+  typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+  constexpr int GW = kFuseComputeWaves * kWave * WPL;  // words of a group (a multiple of 16)
+  __shared__ __attribute__((aligned(16))) u64 buf[2][GW];
+  __shared__ __attribute__((aligned(16))) int hdr[2][4];
+  const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+  const int gbase = blockIdx.y * GW;
+  const int r0 = blockIdx.x * kFuseRecsPerBlock;
+  const int nr = min(kFuseRecsPerBlock, n_recs - r0);
+  if (nr <= 0 || gbase >= n_words) return;  // (workgroup-uniform)
+  if (wave == kFuseComputeWaves) {
+    // ---- the store wave: lane l owns the word pairs l, l + 64, .. of the group
+    constexpr int NP = (GW / 2 + kWave - 1) / kWave;
+    for (int q = 0; q < nr; ++q) {
+      wg_barrier_lds();
+      const int b = q & 1;
+      const int dest = hdr[b][0], len = hdr[b][1], cls = hdr[b][2];
+      u64x2 v[NP];
+      int pc = 0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const int p = k * kWave + lane;
+        v[k] = p < GW / 2 ? *(const u64x2*)&buf[b][2 * p] : u64x2{0, 0};
+        pc += __popcll(v[k].x) + __popcll(v[k].y);
+      }
+      u64* dst = out + (size_t)dest * stride + gbase;
+      for (int r = 0; r < len; ++r, dst += stride) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int p = k * kWave + lane;
+          if (p < GW / 2 && gbase + 2 * p < stride) *(u64x2*)(dst + 2 * p) = v[k];  // (stride is a multiple of 16: a pair never straddles the end)
+        }
+      }
+      if (class_count) {
+        pc = wave_sum_lane63(pc);
+        if (lane == kWave - 1 && pc) atomicAdd(&class_count[cls], pc);
+      }
+    }
+    return;
+  }
+  // ---- compute waves: lane j of rec_l[r] = int (r * 64 + j) of the block's records
+  int rec_l[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int j = r * kWave + lane;
+    rec_l[r] = j < nr * kFuseRecInts ? ((const int*)(recs + r0))[j] : 0;
+  }
+  const int rl0 = rec_l[0], rl1 = rec_l[1], rl2 = rec_l[2];
+#define YK_REC_FIELD(q, k) fuse_rec_field(rl0, rl1, rl2, (q) * kFuseRecInts + (k))
+#define YK_REC_ROW(q, k) fuse_row(src, YK_REC_FIELD(q, 4 + (k)), stride)
+  const int lbase = wave * (kWave * WPL);
+  int w[WPL];
+  u64 keep[WPL];  // all ones for the words of the row, 0 past its end
+#pragma unroll
+  for (int j = 0; j < WPL; ++j) {
+    const int w_raw = gbase + lbase + j * kWave + lane;
+    w[j] = min(w_raw, n_words - 1);
+    keep[j] = w_raw < n_words ? ~0ull : 0ull;
+  }
+  // A record's first row (the node-affinity plane: read once, from HBM) is fetched a record ahead; its other rows are all in flight at once.
+  u64 head[WPL];
+  {
+    const u64* row = YK_REC_ROW(0, 0);
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) head[j] = row[w[j]];
+  }
+  for (int q = 0; q < nr; ++q) {
+    const int n = YK_REC_FIELD(q, 3);
+    u64 x[WPL], r[MAXR - 1][WPL];
+#pragma unroll
+    for (int k = 1; k < MAXR; ++k)
+      if (k < n) {  // (wave-uniform)
+        const u64* row = YK_REC_ROW(q, k);
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) r[k - 1][j] = row[w[j]];
+      }
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) x[j] = keep[j] & head[j];
+    if (q + 1 < nr) {
+      const u64* row = YK_REC_ROW(q + 1, 0);
+#pragma unroll
+      for (int j = 0; j < WPL; ++j) head[j] = row[w[j]];
+    }
+#pragma unroll
+    for (int k = 1; k < MAXR; ++k)
+      if (k < n) {
+#pragma unroll
+        for (int j = 0; j < WPL; ++j) x[j] &= r[k - 1][j];
+      }
+#pragma unroll
+    for (int j = 0; j < WPL; ++j) buf[q & 1][lbase + j * kWave + lane] = x[j];
+    if (threadIdx.x == 0) *(int4*)hdr[q & 1] = int4{YK_REC_FIELD(q, 1), YK_REC_FIELD(q, 2), YK_REC_FIELD(q, 0), 0};
+    wg_barrier_lds();
+  }
+#undef YK_REC_ROW
+#undef YK_REC_FIELD
 }
 
 // ---------------------------------------------------------------------------------------------------
