@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>  // types only: the library is loaded on first use of a ykpred_comm_* entry point
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -330,6 +331,8 @@ struct ykpred_engine {
   bool bands_enabled = true;       // tunable: cfg.reserved[6] == -1 disables the band layout (every class in zone B)
   int band_steps = 0;              // tunable: cfg.reserved[6] > 0 (4..256); 0 = chosen per node table from the row length
   int band_steps_now = 128;        // the band height the current class build used
+  int round_batched = -1;           // round_batched: rounds on one GPU in batches (parallel proposals, the host replays the loop; sharded engines always): 1 = always, 0 = never, -1 = by the ask list's mean run length
+  int round_node_assume = 1;        // round_node_assume: 0 = batched rounds always assume ask after ask (k_allocate_round's assume mode)
   int round_prof = 0;               // round_prof: 1 = k_allocate_round counts thread 0's ticks per phase, printed on stderr
   int fail_after = 0;               // fail_after: failure injection — the n-th checked device call fails (0 = off)
   // Test knobs (YKPRED_TUNE, see ykpred_create): they force paths the populations of the test suite would not choose themselves.
@@ -362,6 +365,8 @@ struct ykpred_engine {
   uint64_t fx_version = 0;
   bool fx_contrib = false, fx_ports = false;  // some spec adds to a count column / occupies a dictionary host port
   std::vector<int32_t> h_fx_off;              // [S + 1] the contribution rows' offsets, host copy
+  std::vector<int32_t> h_fx_cls;              // the selector class of every contribution row, host copy
+  std::vector<uint8_t> h_fx_occupies;         // [S] the spec's pods occupy a host port once on a node
   DevBuf d_patches, d_rows, d_row_count, d_row_best;
   unsigned last_pre = 0, last_filt = 0;  // plugin lists of the last full evaluation (ykpred_eval_nodes must match them)
   bool last_eval_valid = false;
@@ -1640,6 +1645,8 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "wave_combine_below") e->wave_combine_below = std::max(val, 0);
       else if (key == "fail_after") e->fail_after = std::max(val, 0);
       else if (key == "round_prof") e->round_prof = val;
+      else if (key == "round_batched") e->round_batched = val;
+      else if (key == "round_node_assume") e->round_node_assume = val;
       else if (key == "sweep_min_run") e->sweep_min_run = std::max(val, 0);
       else if (key == "sweep_groups") e->sweep_groups = std::max(val, 0);
       else if (key == "class_runs") e->class_runs = val;
@@ -3325,6 +3332,7 @@ int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t*
   e->fx_contrib = false;
   e->fx_ports = false;
   e->h_fx_off.clear();
+  e->h_fx_cls.clear();
   if (fx->contrib_off) {
     const int total = fx->contrib_off[S];
     if (fx->contrib_off[0] != 0 || total < 0 || (total > 0 && (!fx->contrib_class || !fx->contrib_count)))
@@ -3335,14 +3343,20 @@ int32_t ykpred_set_spec_effects(ykpred_engine_t* e, const ykpred_spec_effects_t*
       if (fx->contrib_class[k] < 0 || fx->contrib_class[k] >= e->KS || fx->contrib_count[k] <= 0)
         return fail(e, YKPRED_E_INVALID, "set_spec_effects: contribution outside the selector classes of the node table, or not positive");
     TRY(upload(e, e->d_fx_off, fx->contrib_off, S + 1, st));
-    e->h_fx_off.assign(fx->contrib_off, fx->contrib_off + S + 1);  // (a sharded round's prefix rule asks which specs move histograms)
+    e->h_fx_off.assign(fx->contrib_off, fx->contrib_off + S + 1);  // (a batched round's prefix rule asks which specs move which histograms)
+    if (total > 0) e->h_fx_cls.assign(fx->contrib_class, fx->contrib_class + total);
     TRY(upload(e, e->d_fx_cls, fx->contrib_class, (size_t)std::max(total, 1), st));
     TRY(upload(e, e->d_fx_cnt, fx->contrib_count, (size_t)std::max(total, 1), st));
     e->fx_contrib = total > 0;
   }
+  e->h_fx_occupies.assign(S, 0);
   if (fx->occupied_ports && e->KP > 0) {
     TRY(upload(e, e->d_fx_occ, fx->occupied_ports, S * (size_t)e->KP, st));
-    for (size_t i = 0; i < S * (size_t)e->KP && !e->fx_ports; ++i) e->fx_ports = fx->occupied_ports[i] != 0;
+    for (size_t i = 0; i < S * (size_t)e->KP; ++i)
+      if (fx->occupied_ports[i] != 0) {
+        e->fx_ports = true;
+        e->h_fx_occupies[i / (size_t)e->KP] = 1;
+      }
   }
   HIPCHK(hipStreamSynchronize(st));  // (the caller's arrays are not retained)
   e->fx_version = e->specs_version;
@@ -3368,7 +3382,10 @@ static u64 host_sortable_key(double v) {
   memcpy(&b, &v, sizeof b);
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
-constexpr size_t kShardBatchMax = 512;  // asks proposed per exchange of a sharded round (the batch adapts below this)
+constexpr size_t kShardBatchMax = 256;  // asks proposed per batch of a batched round (the batch adapts below this)
+constexpr size_t kBatchBytesMax = kShardBatchMax * ykk::kPropK * sizeof(ykk::RoundProposal) +
+                                  kShardBatchMax * ((kShardBatchMax * ykk::kPropK + 63) / 64) * sizeof(u64);  // proposals + pair bits of one shard
+static_assert(kShardBatchMax * ykk::kPropK * 2 <= (size_t)ykk::kDistinctSlots, "k_round_distinct's table holds a batch's proposals");
 
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, int32_t n_asks, const int32_t* asks, int32_t* out_nodes) {
   YK_SERIALISE(e);
@@ -3430,6 +3447,16 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     return fail(e, YKPRED_E_UNSUPPORTED, "allocate_round: an ask of the round requests a host port (an assumed pod's ports change later answers) and the specs' "
                                          "effects are not uploaded (ykpred_set_spec_effects): decide ask by ask");
   if (n_asks == 0) return YKPRED_OK;
+  // One GPU: the sequential kernel decides runs of one spec by arithmetic (millions of asks per second) and pays ~10 us for every
+  // other ask; the batched form pays per batch and wins on a mix of specs (configs[2]: 100 k -> 250 k+ asks/s). With topology
+  // constraints live its batches end at every ask behind a contribution to a class it counts (configs[4]'s mix: 51 k against 59 k/s).
+  // round_batched < 0 (default): batched without topology constraints when the list's mean run is shorter than four asks.
+  bool batched = sharded || e->round_batched > 0;
+  if (!sharded && e->round_batched < 0 && !topo_on && n_asks >= 512) {
+    int changes = 1;
+    for (int i = 1; i < n_asks; ++i) changes += e->h_pod_spec[(size_t)asks[i]] != e->h_pod_spec[(size_t)asks[i - 1]] ? 1 : 0;
+    batched = (int64_t)changes * 4 >= (int64_t)n_asks;
+  }
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t st = e->own_stream;
   if (e->ev_eval_done) HIPCHK(hipStreamWaitEvent(st, e->ev_eval_done, 0));
@@ -3460,9 +3487,11 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                o_nm = take(sizeof(int)), o_hist = take(cells * sizeof(int)), o_minv = take(G * sizeof(int)), o_mn = take(G * sizeof(int)),
                o_at = take(G * sizeof(int)), o_nd = take(G * sizeof(int)), o_prof = take(16 * sizeof(i64)),
                o_rkey = take(N * sizeof(u64)), o_rtie = take(N * sizeof(int)), o_cdesc = take(C * ykk::kDescWords * sizeof(u64)),
-               o_prop = take(sharded ? (size_t)n_asks * sizeof(ykk::RoundProposal) : 0),
-               o_allprop = take(sharded ? (size_t)e->comm_world * kShardBatchMax * sizeof(ykk::RoundProposal) : 0),
-               o_forced = take(sharded ? (size_t)n_asks * sizeof(int) : 0),
+               o_prop = take(batched ? kBatchBytesMax : 0),
+               o_allprop = take(sharded ? (size_t)e->comm_world * kBatchBytesMax : 0),
+               o_list = take(batched ? (kShardBatchMax * ykk::kPropK + 2) * sizeof(int) : 0),
+               o_forced = take(batched ? (size_t)n_asks * sizeof(int) : 0), o_runlen = take(batched ? (size_t)n_asks * sizeof(int) : 0),
+               o_deltas = take(batched ? kShardBatchMax * sizeof(ykk::RoundNodeDelta) : 0),
                o_delta = take((sharded && topo_on) ? (size_t)n_asks * ykk::kDeltaStride * sizeof(int) : 0),
                o_alldelta = take((sharded && topo_on) ? (size_t)e->comm_world * kShardBatchMax * ykk::kDeltaStride * sizeof(int) : 0);
   HIPCHK(e->d_round.ensure(off));
@@ -3570,51 +3599,79 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   if (e->C > 0)
     hipLaunchKernelGGL(ykk::k_round_class_desc, dim3((unsigned)((e->C + ykk::kBlock - 1) / ykk::kBlock)), dim3(ykk::kBlock), 0, st, ct, pr, e->C,
                        (u64*)(base + o_cdesc));
-  if (sharded) {
-    // ---- A round on a node-sharded engine, in batches. Every rank holds the whole ask table and its own node shard. Per batch:
-    //   1. every shard PROPOSES its best node for each ask of the batch against the state the accepted asks left (k_allocate_round in
-    //      propose mode: both candidates, no assume) — 48 bytes per ask: key, node, how many pods of the spec the node still holds,
-    //      and the four numbers its key is made of;
-    //   2. one all-gather of the proposals; the global candidate of an ask is the smallest (key, global node index) — the order
-    //      ykpred_exchange_decisions uses;
-    //   3. every rank accepts the same PREFIX of the batch, ask after ask, while no accepted ask can have changed the answer of the
-    //      next one. Without topology constraints a verdict only ever turns from fit to fail as a node fills, and an assume moves only
-    //      its own node, towards the front. So an accepted node u can change ask j's answer w only if u == w (the state of j's own
-    //      node moved), or u stood BEHIND w and now stands in front of it (it may fit j and would come first). A node that stood in
-    //      front of w did not fit j and never will; every other node is where it was. The first ask that fails the test ends the
-    //      prefix and is proposed again in the next batch — the first ask of a batch always passes, so a batch always makes progress.
-    //      A run of asks with one spec lands on one node as long as it fits (k_allocate_round's run argument): `fits` of them are
-    //      accepted at once, the node's key afterwards is arithmetic on the exchanged columns;
-    //   4. the owners of the accepted nodes assume them (assume mode), everybody moves on behind the prefix.
-    // The decisions equal the sequential loop's wherever NodeID order and node index order agree (zero-padded names: the tie-break
-    // between equal keys across shards is the global node index, as in ykpred_exchange_decisions).
-    Rccl* r = rccl();
-    const int W = e->comm_world;
-    ykk::RoundProposal* d_prop = (ykk::RoundProposal*)(base + o_prop);
-    ykk::RoundProposal* d_all = (ykk::RoundProposal*)(base + o_allprop);
+  if (batched) {
+    // ---- A round in BATCHES: node-sharded engines (every rank holds the whole ask table and its own node shard), and one GPU
+    // under YKPRED_TUNE round_batched=1. Per batch:
+    //   1. PROPOSE, the asks of the batch in parallel against the state the accepted asks left (k_round_propose: a workgroup per
+    //      ask, its kPropK best feasible nodes in (key, NodeID) order with the columns the key is made of); the distinct nodes a
+    //      shard proposed are numbered (k_round_distinct) and EVERY ask of the batch is evaluated against every one of them
+    //      (k_round_cross: a bit per pair);
+    //   2. one all-gather of proposals + bits (world > 1), one copy to the host;
+    //   3. every rank replays the sequential loop over the batch, ask after ask, as far as it is exact. A verdict only ever turns from
+    //      fit to fail as a node fills (no topology signature) and an assume moves only its own node, towards the front. So the
+    //      answer of ask j under the state the accepted asks left is the smallest (key, NodeID) among
+    //        - the first entry of j's merged candidate list that is NOT an accepted node (unchanged since the proposal; the merged
+    //          list is exact up to the last entry of the first shard list that came back full), and
+    //        - the accepted nodes j passes: its bit (every Filter, at the state of the proposal) and NodeResourcesFit on the node's
+    //          columns after the accepted pods — arithmetic on what the proposals carry.
+    //      The prefix ends where that is not enough: every list entry is an accepted node that is full and the lists were cut
+    //      (kPropK), an accepted node in front whose verdict is not arithmetic (the ask wants host ports or has a topology
+    //      signature), an ask with a topology signature behind an accepted contribution to the histograms. Runs of one spec are
+    //      accepted at once (k_allocate_round's run argument);
+    //   4. the owners of the accepted nodes assume them (k_allocate_round, assume mode), everybody moves on behind the prefix.
+    // The decisions equal the sequential loop's; across shards the tie-break between equal keys is the cluster-wide node index (as in
+    // ykpred_exchange_decisions: NodeID order wherever names are zero-padded), on one GPU the NodeID rank itself.
+    Rccl* r = sharded ? rccl() : nullptr;
+    const int W = sharded ? e->comm_world : 1, me = sharded ? e->comm_rank : 0;
+    constexpr int K = ykk::kPropK;
+    auto cw_of = [](int b) { return (b * K + 63) / 64; };
+    auto bytes_of = [&](int b) { return (size_t)b * K * sizeof(ykk::RoundProposal) + (size_t)b * (size_t)cw_of(b) * sizeof(u64); };
+    char* d_send = base + o_prop;
+    char* d_all = base + o_allprop;
+    int* d_list = (int*)(base + o_list);
+    int* d_nlist = d_list + kShardBatchMax * K;
     int* d_forced = (int*)(base + o_forced);
-    std::vector<ykk::RoundProposal> all((size_t)W * kShardBatchMax);
+    int* d_runlen = (int*)(base + o_runlen);
+    ykk::RoundNodeDelta* d_deltas = (ykk::RoundNodeDelta*)(base + o_deltas);
+    std::vector<ykk::RoundNodeDelta> deltas;
+    std::vector<int32_t> run_len;
+    std::vector<char> all((size_t)W * bytes_of((int)kShardBatchMax));
     std::vector<int32_t> forced;
-    // Topology signatures (round 6): the histograms are cluster-wide state every shard holds. An accepted ask whose pod adds to a
-    // selector class moves them — on its owner in the assume, on the others from the owner's delta record (second all-gather of
-    // the batch, k_round_apply_deltas) — and it can turn verdicts of asks WITH a topology signature from fail to fit anywhere:
-    // the conflict-free prefix therefore ends in front of the first such ask behind an accepted contribution.
-    int* d_delta = topo_on ? (int*)(base + o_delta) : nullptr;
-    int* d_alldelta = topo_on ? (int*)(base + o_alldelta) : nullptr;
+    // Topology signatures: the histograms are cluster-wide state every shard holds. An accepted ask whose pod adds to a selector class
+    // moves them — on its owner in the assume, on the others from the owner's delta record (second all-gather of the batch,
+    // k_round_apply_deltas) — and it can turn verdicts of asks whose topology signature COUNTS THAT CLASS from fail to fit
+    // anywhere: the prefix ends in front of the first such ask behind an accepted contribution to one of its classes. An ask whose
+    // constraints count other classes saw the histograms it reads when the batch was proposed: its bits and lists stand.
+    int* d_delta = (sharded && topo_on) ? (int*)(base + o_delta) : nullptr;
+    int* d_alldelta = (sharded && topo_on) ? (int*)(base + o_alldelta) : nullptr;
     std::vector<int32_t> h_alldelta;
     auto spec_has_signature = [&](int spec) { return topo_on && e->spec_sig_spread[(size_t)spec] >= 0; };
     auto spec_contributes = [&](int spec) {
       return topo_on && e->fx_contrib && (size_t)spec + 1 < e->h_fx_off.size() && e->h_fx_off[(size_t)spec + 1] > e->h_fx_off[(size_t)spec];
     };
+    std::vector<uint8_t> touched((size_t)std::max(e->KS, 1), 0);  // selector classes an accepted ask of this batch added to
+    std::vector<int32_t> touched_list;
+    auto touches = [&](int spec) {  // ... and whether a constraint of the spec's signature counts one of them
+      if (touched_list.empty()) return false;
+      const int d = e->spec_sig_spread[(size_t)spec];
+      if (d < 0 || (size_t)d >= e->spread_sig.size()) return true;
+      for (const ykpred_spread_t& c : e->spread_sig[(size_t)d])
+        if (c.selector_class >= 0 && c.selector_class < e->KS && touched[(size_t)c.selector_class]) return true;
+      return false;
+    };
     struct Accepted {
-      int64_t gnode;
+      int64_t ord;     // the tie-break between equal keys: cluster-wide node index (world > 1) / NodeID rank (one GPU)
+      int64_t gnode;   // cluster-wide node index
       u64 key0, key1;  // the node's key when it was proposed / after the accepted pods
       i64 alloc[ykk::kMaxR], used[ykk::kMaxR];  // its resource columns after the accepted pods
       int room;        // pod slots left after them
+      int rank, node, didx;  // its shard, its index there, its number among the shard's distinct nodes of this batch
+      int pods;        // pods the batch put on it, and what they request together (k_round_assume_nodes)
+      i64 add[ykk::kMaxR];
     };
     const bool fit_on = (filt & YKPRED_PLUGIN_NODE_RESOURCES_FIT) && (pre & YKPRED_PLUGIN_NODE_RESOURCES_FIT);
     // Does a pod of `spec` still fit a node whose resource columns are (alloc, used) with `room` pod slots — NodeResourcesFit alone:
-    // what the other Filters said of the pair when it was proposed cannot have changed for a spec without a topology signature
+    // what the other Filters said of the pair when the batch was proposed cannot have changed for a spec without a topology signature
     // that wants no host port (taints, labels and names do not move during a round).
     auto still_fits = [&](int spec, const Accepted& n) {
       if (!fit_on) return true;
@@ -3630,81 +3687,150 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
         if (e->h_wanted[(size_t)spec * (size_t)e->KP + (size_t)kp] != 0) return true;
       return false;
     };
+    auto less2 = [](u64 ka, int64_t oa, u64 kb, int64_t ob) { return ka < kb || (ka == kb && oa < ob); };
+    struct Entry {
+      u64 key;
+      int64_t ord;
+      int g, q;
+    };
     std::vector<Accepted> acc;
+    std::vector<Entry> ents;
     const int R = e->R;
-    int pos = 0, batch = 16;
-    int64_t exchanges = 0, delta_exchanges = 0, delta_cells = 0;
+    int pos = 0, batch = 32;
+    int64_t exchanges = 0, delta_exchanges = 0, delta_cells = 0, batches = 0;
+    double t_prop = 0, t_host = 0, t_assume = 0;  // (round_prof: seconds in the proposal kernels + copy, the replay, the assume)
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    int64_t ends[4] = {0, 0, 0, 0};  // what ended the prefixes: the batch itself, a topology ask behind a contribution, candidate lists used up, an accepted node in front of an ask that wants host ports
     while (pos < n_asks) {
-      const int b = std::min(batch, n_asks - pos);
+      const int b = std::min(batch, n_asks - pos), cw = cw_of(b);
+      const size_t nbytes = bytes_of(b);
+      const double t0 = e->round_prof ? now_s() : 0.0;
+      ykk::RoundProposal* d_props = (ykk::RoundProposal*)d_send;
+      u64* d_cross = (u64*)(d_send + (size_t)b * K * sizeof(ykk::RoundProposal));
       ra.mode = ykk::kRoundPropose;
       ra.first = pos;
       ra.n_asks = b;
-      ra.prop = d_prop;
-      hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
+      {
+        const ykk::RoundCtx ctx{nt, stbl, ct, pr, ra};
+        hipLaunchKernelGGL(ykk::k_round_propose, dim3((unsigned)b), dim3(ykk::kProposeThreads), 0, st, ctx, d_props);
+        hipLaunchKernelGGL(ykk::k_round_distinct, dim3(1), dim3(ykk::kBlock), 0, st, d_props, b * K, d_list, d_nlist);
+        hipLaunchKernelGGL(ykk::k_round_cross, dim3((unsigned)b), dim3(ykk::kBlock), 0, st, ctx, (const int*)d_list, (const int*)d_nlist, d_cross, cw);
+      }
       HIPCHK(hipGetLastError());
-      NCCLCHK(r->AllGather(d_prop + pos, d_all, (size_t)b * sizeof(ykk::RoundProposal), ncclInt8, e->comm, st));
-      HIPCHK(hipMemcpyAsync(all.data(), d_all, (size_t)W * (size_t)b * sizeof(ykk::RoundProposal), hipMemcpyDeviceToHost, st));
+      if (W > 1) {
+        NCCLCHK(r->AllGather(d_send, d_all, nbytes, ncclInt8, e->comm, st));
+        HIPCHK(hipMemcpyAsync(all.data(), d_all, (size_t)W * nbytes, hipMemcpyDeviceToHost, st));
+        ++exchanges;
+      } else {
+        HIPCHK(hipMemcpyAsync(all.data(), d_send, nbytes, hipMemcpyDeviceToHost, st));
+      }
       HIPCHK(hipStreamSynchronize(st));
-      ++exchanges;
+      const double t1 = e->round_prof ? now_s() : 0.0;
+      ++batches;
+      auto prop_of = [&](int g, int m, int q) -> const ykk::RoundProposal& {
+        return ((const ykk::RoundProposal*)(all.data() + (size_t)g * nbytes))[(size_t)m * K + (size_t)q];
+      };
+      auto bit_of = [&](const Accepted& a2, int m) {
+        const u64* cross = (const u64*)(all.data() + (size_t)a2.rank * nbytes + (size_t)b * K * sizeof(ykk::RoundProposal));
+        return a2.didx >= 0 && ((cross[(size_t)m * (size_t)cw + (size_t)(a2.didx >> 6)] >> (a2.didx & 63)) & 1ull) != 0;
+      };
+      auto ord_of = [&](const ykk::RoundProposal& p) { return W > 1 ? (int64_t)p.gnode : (int64_t)p.pad; };
       acc.clear();
       forced.assign((size_t)b, -1);
+      run_len.assign((size_t)b, 1);
+      for (int32_t c2 : touched_list) touched[(size_t)c2] = 0;
+      touched_list.clear();
       int m = 0;
       bool contributed = false;  // an ask accepted in this batch moved a histogram
+      bool plain = true;         // ... and none moved anything but resources and pod counts
       while (m < b) {
-        if (contributed && spec_has_signature(e->h_pod_spec[(size_t)asks[pos + m]])) break;  // (proposed again against the new histograms)
-        // the global candidate of ask pos + m
-        int best_rank = -1;
-        for (int g = 0; g < W; ++g) {
-          const ykk::RoundProposal& p = all[(size_t)g * (size_t)b + (size_t)m];
-          if (p.node < 0) continue;
-          if (best_rank < 0) { best_rank = g; continue; }
-          const ykk::RoundProposal& q = all[(size_t)best_rank * (size_t)b + (size_t)m];
-          if (p.key < q.key || (p.key == q.key && p.gnode < q.gnode)) best_rank = g;
+        const int ask0 = asks[pos + m];
+        const int spec = e->h_pod_spec[(size_t)ask0];
+        const bool has_sig = spec_has_signature(spec), ports = spec_wants_ports(spec);
+        if (contributed && has_sig && touches(spec)) {  // (proposed again against the new histograms)
+          ++ends[1];
+          break;
         }
-        if (best_rank < 0) {  // no node of any shard fits, and none will: verdicts only turn to fail
+        // the ask's candidates of every shard, merged; exact up to the last entry of the first list that came back full
+        ents.clear();
+        bool cut = false;
+        u64 h_key = ~0ull;
+        int64_t h_ord = INT64_MAX;
+        for (int g = 0; g < W; ++g) {
+          int n = 0;
+          for (int q = 0; q < K; ++q) {
+            const ykk::RoundProposal& p = prop_of(g, m, q);
+            if (p.node < 0) break;
+            ents.push_back(Entry{p.key, ord_of(p), g, q});
+            ++n;
+          }
+          if (n == K) {
+            const Entry& last = ents.back();
+            if (!cut || less2(last.key, last.ord, h_key, h_ord)) h_key = last.key, h_ord = last.ord;
+            cut = true;
+          }
+        }
+        std::sort(ents.begin(), ents.end(), [&](const Entry& x, const Entry& y) { return less2(x.key, x.ord, y.key, y.ord); });
+        const Entry* fresh = nullptr;  // the first candidate no accepted ask has touched
+        for (const Entry& en : ents) {
+          if (cut && less2(h_key, h_ord, en.key, en.ord)) break;
+          const int64_t gn = prop_of(en.g, m, en.q).gnode;
+          bool taken = false;
+          for (const Accepted& a2 : acc) taken = taken || a2.gnode == gn;
+          if (!taken) {
+            fresh = &en;
+            break;
+          }
+        }
+        const bool beyond = !fresh && cut;  // (a node behind the lists' horizon may fit: only its shard knows)
+        Accepted* best = nullptr;           // the accepted node the ask passes that stands first
+        const Accepted* unknown = nullptr;  // ... and the first one whose verdict is not arithmetic
+        for (Accepted& a2 : acc) {
+          if (!bit_of(a2, m)) continue;  // (failed when the batch was proposed: a node only fills)
+          if (ports) {  // (the node's port words moved with the pods it took: not arithmetic here)
+            if (!unknown || less2(a2.key1, a2.ord, unknown->key1, unknown->ord)) unknown = &a2;
+          } else if (still_fits(spec, a2)) {
+            if (!best || less2(a2.key1, a2.ord, best->key1, best->ord)) best = &a2;
+          }
+        }
+        if (beyond && !(best && less2(best->key1, best->ord, h_key, h_ord))) {
+          ++ends[2];
+          break;
+        }
+        const bool take_fresh = fresh && (!best || less2(fresh->key, fresh->ord, best->key1, best->ord));
+        if (unknown && ((!fresh && !best) || (take_fresh ? less2(unknown->key1, unknown->ord, fresh->key, fresh->ord)
+                                                          : less2(unknown->key1, unknown->ord, best->key1, best->ord)))) {
+          ++ends[3];
+          break;
+        }
+        if (!fresh && !best) {  // no node of any shard fits, and none will: verdicts only turn to fail
           out_nodes[pos + m] = -1;
           ++m;
           continue;
         }
-        const ykk::RoundProposal w = all[(size_t)best_rank * (size_t)b + (size_t)m];
-        const int64_t gnode = w.gnode;
-        const int ask0 = asks[pos + m];
-        const int spec = e->h_pod_spec[(size_t)ask0];
-        // Round 6: the candidate may be a node that took pods EARLIER IN THIS BATCH — the common case under bin-packing, where ask
-        // after ask lands on the fullest node that fits until it is full. Its columns after those pods are arithmetic on what the
-        // proposals carry, and so is the question whether this ask still fits it: if it does, the node is this ask's answer too
-        // (it only moved towards the front); if not, the batch ends here and the ask is proposed again.
-        Accepted* same = nullptr;
-        for (Accepted& a2 : acc)
-          if (a2.gnode == gnode) same = &a2;
-        if (same && (spec_has_signature(spec) || spec_wants_ports(spec) || !still_fits(spec, *same))) break;
-        const u64 w_key_now = same ? same->key1 : w.key;
-        bool conflict = false;
-        for (const Accepted& a2 : acc) {
-          if (a2.gnode == gnode) continue;
-          const bool behind_before = a2.key0 > w.key || (a2.key0 == w.key && a2.gnode > gnode);  // (against the keys the proposals were made with)
-          const bool in_front_now = a2.key1 < w_key_now || (a2.key1 == w_key_now && a2.gnode < gnode);
-          if (behind_before && in_front_now) {
-            conflict = true;
-            break;
-          }
-        }
-        if (conflict) break;
+        Accepted* same = take_fresh ? nullptr : best;
         Accepted node_now{};
+        int w_fits = 1;
         if (same) {
           node_now = *same;
         } else {
-          node_now.gnode = gnode;
+          const ykk::RoundProposal& w = prop_of(fresh->g, m, fresh->q);
+          node_now.ord = fresh->ord;
+          node_now.gnode = w.gnode;
           node_now.key0 = node_now.key1 = w.key;
           for (int rr = 0; rr < ykk::kMaxR; ++rr) node_now.alloc[rr] = w.alloc[rr], node_now.used[rr] = w.req[rr];
           node_now.room = w.room;
+          node_now.rank = fresh->g;
+          node_now.node = w.node;
+          node_now.didx = w.didx;
+          w_fits = w.fits;
         }
         // a run of asks with this spec and no pin lands on this node while it fits
         int k = 1;
         const bool run_ok = e->h_pod_pin[(size_t)ask0] == YKPRED_NO_NODE_NAME && (same ? (fit_on && !spec_contributes(spec)) : true);
         if (run_ok) {
           // how many pods of the spec the node holds as it stands now (a node first met in this batch: the proposal's count)
-          i64 holds = same ? (i64)node_now.room : (i64)w.fits;
+          i64 holds = same ? (i64)node_now.room : (i64)w_fits;
           if (same)
             for (int rr = 0; rr < R && rr < ykk::kMaxR; ++rr) {
               const i64 q = e->h_req[(size_t)spec * (size_t)R + (size_t)rr];
@@ -3712,37 +3838,79 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
             }
           while (k < holds && m + k < b && e->h_pod_spec[(size_t)asks[pos + m + k]] == spec && e->h_pod_pin[(size_t)asks[pos + m + k]] == YKPRED_NO_NODE_NAME) ++k;
         }
-        for (int rr = 0; rr < R && rr < ykk::kMaxR; ++rr) node_now.used[rr] += e->h_req[(size_t)spec * (size_t)R + (size_t)rr] * k;
+        for (int rr = 0; rr < R && rr < ykk::kMaxR; ++rr) {
+          node_now.used[rr] += e->h_req[(size_t)spec * (size_t)R + (size_t)rr] * k;
+          node_now.add[rr] += e->h_req[(size_t)spec * (size_t)R + (size_t)rr] * k;
+        }
         node_now.room -= k;
+        node_now.pods += k;
+        plain = plain && !spec_contributes(spec) && !((size_t)spec < e->h_fx_occupies.size() && e->h_fx_occupies[(size_t)spec]) && !ports;
         const i64 total[2] = {node_now.alloc[0], node_now.alloc[1]};
         const i64 used[2] = {node_now.used[0], node_now.used[1]};
         node_now.key1 = host_sortable_key(host_node_score(total, used));
+        for (int q = 0; q < k; ++q) {
+          out_nodes[pos + m + q] = (int32_t)node_now.gnode;
+          if (node_now.rank == me) forced[(size_t)(m + q)] = node_now.node;
+        }
+        for (int q = 0; q < k;) {  // (the assume takes a run in pieces that stay inside one 64-ask window of its loop)
+          const int piece = std::min(k - q, 64 - ((m + q) & 63));
+          run_len[(size_t)(m + q)] = piece;
+          q += piece;
+        }
         if (same) *same = node_now;
         else acc.push_back(node_now);
-        contributed = contributed || spec_contributes(spec);
-        for (int q = 0; q < k; ++q) {
-          out_nodes[pos + m + q] = (int32_t)gnode;
-          if (best_rank == e->comm_rank) forced[(size_t)(m + q)] = w.node;
+        if (spec_contributes(spec)) {
+          contributed = true;
+          if (e->h_fx_cls.size() >= (size_t)e->h_fx_off[(size_t)spec + 1])
+            for (int q = e->h_fx_off[(size_t)spec]; q < e->h_fx_off[(size_t)spec + 1]; ++q) {
+              const int32_t c2 = e->h_fx_cls[(size_t)q];
+              if (c2 >= 0 && c2 < e->KS && !touched[(size_t)c2]) {
+                touched[(size_t)c2] = 1;
+                touched_list.push_back(c2);
+              }
+            }
         }
         m += k;
       }
+      if (m >= b) ++ends[0];
+      const double t2 = e->round_prof ? now_s() : 0.0;
       // the owners assume what was accepted (the asks behind the prefix are proposed again)
-      HIPCHK(hipMemcpyAsync(d_forced + pos, forced.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, st));
       ra.mode = ykk::kRoundAssume;
       ra.first = pos;
       ra.n_asks = m;
-      ra.forced = d_forced;
-      ra.delta = d_delta;
-      hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
+      if (plain && e->round_node_assume != 0) {
+        // nothing but resources and pod counts moved: node by node, a wave each, from the sums of the replay
+        deltas.clear();
+        for (const Accepted& a2 : acc)
+          if (a2.rank == me && a2.pods > 0) {
+            ykk::RoundNodeDelta nd{};
+            nd.node = a2.node;
+            nd.pods = a2.pods;
+            for (int rr = 0; rr < ykk::kMaxR; ++rr) nd.add[rr] = a2.add[rr];
+            deltas.push_back(nd);
+          }
+        if (!deltas.empty()) {
+          HIPCHK(hipMemcpyAsync(d_deltas, deltas.data(), deltas.size() * sizeof(ykk::RoundNodeDelta), hipMemcpyHostToDevice, st));
+          hipLaunchKernelGGL(ykk::k_round_assume_nodes, dim3((unsigned)deltas.size()), dim3(ykk::kWave), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra},
+                             (const ykk::RoundNodeDelta*)d_deltas, (int)deltas.size());
+        }
+      } else {
+        HIPCHK(hipMemcpyAsync(d_forced + pos, forced.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_runlen + pos, run_len.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, st));
+        ra.run_len = d_runlen;
+        ra.forced = d_forced;
+        ra.delta = d_delta;
+        hipLaunchKernelGGL(ykk::k_allocate_round, dim3(1), dim3(ykk::kRoundThreads), 0, st, ykk::RoundCtx{nt, stbl, ct, pr, ra});
+      }
       HIPCHK(hipGetLastError());
-      if (topo_on && contributed) {
+      if (W > 1 && topo_on && contributed) {
         // what the owners' assumes added to the histograms: every rank applies the others' records (its own are in its copy already)
         const size_t rec_bytes = (size_t)m * ykk::kDeltaStride * sizeof(int);
         NCCLCHK(r->AllGather(d_delta + (size_t)pos * ykk::kDeltaStride, d_alldelta, rec_bytes, ncclInt8, e->comm, st));
         h_alldelta.resize((size_t)W * (size_t)m * ykk::kDeltaStride);
         HIPCHK(hipMemcpyAsync(h_alldelta.data(), d_alldelta, (size_t)W * rec_bytes, hipMemcpyDeviceToHost, st));
         for (int g = 0; g < W; ++g)
-          if (g != e->comm_rank)
+          if (g != me)
             hipLaunchKernelGGL(ykk::k_round_apply_deltas, dim3(1), dim3(ykk::kBlock), 0, st, stbl.spread, ra.mn, ra.at_min, ra.nd,
                                d_alldelta + (size_t)g * (size_t)m * ykk::kDeltaStride, m);
         HIPCHK(hipGetLastError());
@@ -3756,13 +3924,15 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
                                                  std::to_string(ykk::kDeltaMax) + "): the round stops here on every rank");
       }
       HIPCHK(hipStreamSynchronize(st));  // (`forced` is reused by the next batch)
+      if (e->round_prof) t_prop += t1 - t0, t_host += t2 - t1, t_assume += now_s() - t2;
       pos += m;
-      batch = (int)std::min<size_t>(kShardBatchMax, (size_t)std::max(8, 2 * m + 8));
+      batch = (int)std::min<size_t>(kShardBatchMax, (size_t)std::max(32, 2 * m + 16));
     }
     e->round_exchanges += exchanges;
     if (e->round_prof)
-      fprintf(stderr, "round_prof sharded round: %d asks in %lld exchanges (%.1f accepted per exchange), %lld of them histogram deltas (%lld cells)\n", n_asks,
-              (long long)exchanges, exchanges ? (double)n_asks / (double)exchanges : 0.0, (long long)delta_exchanges, (long long)delta_cells);
+      fprintf(stderr, "round_prof batched round (world %d): %d asks in %lld batches (%.1f accepted per batch), %lld exchanges, %lld of them histogram deltas (%lld cells); prefixes ended by: the batch %lld, a topology ask behind a contribution %lld, candidate lists used up %lld, an accepted node in front of an ask with host ports %lld; ms: proposals %.1f, replay %.1f, assume %.1f\n",
+              W, n_asks, (long long)batches, batches ? (double)n_asks / (double)batches : 0.0, (long long)exchanges, (long long)delta_exchanges, (long long)delta_cells,
+              (long long)ends[0], (long long)ends[1], (long long)ends[2], (long long)ends[3], t_prop * 1e3, t_host * 1e3, t_assume * 1e3);
     return YKPRED_OK;
   }
   // one launch per 32 768 asks: the loop is a single workgroup, and a bounded launch keeps the queue responsive (the state of the

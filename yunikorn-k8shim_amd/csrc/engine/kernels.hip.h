@@ -3102,6 +3102,8 @@ struct RoundProposal {      // a shard's best node for an ask, and what the othe
                             // of a spec is arithmetic on these; all of them: whether a LATER ask of the batch still fits the node is too)
   int gnode, room;          // node index in the whole cluster (the shard's node offset + node): the tie-break between equal keys;
                             // pod slots left (AllowedPodNumber - len(Pods))
+  int didx, pad;            // batched rounds: the node's number among the distinct nodes its shard proposed in this batch (k_round_distinct);
+                            // pad = its NodeID rank inside the shard (the tie-break on one GPU)
 };
 struct RoundArgs {
   int first, n_asks;        // this launch decides asks [first, first + n_asks) of the round
@@ -3159,6 +3161,8 @@ struct RoundArgs {
   int mode;                 // kRoundDecide (0), kRoundPropose, kRoundAssume
   int node_offset;          // index of this shard's first node in the whole cluster
   const int* forced;        // kRoundAssume: [round] the node (of this shard) an ask goes to, -1 = none of this shard's
+  const int* run_len;       // kRoundAssume: [round] asks from this one on that go to the same node with the same spec (a run the host accepted
+                            // at once: assumed in one step; inside one 64-ask header window); null: 1
   RoundProposal* prop;      // kRoundPropose: [round]
   i64* prof;                // YKPRED_TUNE round_prof=1: thread 0's 100 MHz ticks per phase of the loop (null: off)
   // kRoundAssume on a sharded engine with topology signatures: what the assume added to the histograms, for the OTHER shards (they
@@ -3892,6 +3896,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
             k_run = min(k_run, n_asks - i);
           }
         }
+        if (mode == kRoundAssume && a.run_len) k_run = max(1, min(min(a.run_len[first_ask + i], kWave - hl), n_asks - i));
         if (lane < k_run) a.out[first_ask + i + lane] = win;
         const int cnt = cnt0 + k_run;
         const bool dead = fit_on && (i64)cnt + 1 > (i64)allowed;  // no pod slot left: no ask of this phase fits it any more
@@ -4012,8 +4017,9 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
         }
       }
       if (ndirty) __threadfence_block();
-    } else if (tid == 0) {
-      a.out[first_ask + i] = -1;
+    } else {
+      if (tid == 0) a.out[first_ask + i] = -1;
+      if (mode == kRoundAssume && a.run_len) step = max(1, min(min(a.run_len[first_ask + i], kWave - hl), n_asks - i));  // (another shard's run)
     }
     // (the exchange slots are rewritten by the next ask only after this barrier; every wave has read them by now)
     __syncthreads();
@@ -4034,6 +4040,424 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
 #undef a
 #undef sp
 #undef YK_CTX_FRESH
+
+// ---------------------------------------------------------------------------------------------------
+// BATCHED rounds (round 6): the asks of a batch proposed IN PARALLEL. k_allocate_round decides ask after ask in one workgroup — the
+// asks are a dependency chain. A batch of asks evaluated against ONE frozen state is not: k_round_propose gives every ask of the
+// batch its own workgroup (the whole device instead of one compute unit) and finds its kPropK best feasible nodes in
+// (score key, NodeID rank) order — unmoved nodes from the class's rank-ordered plane rows, moved nodes per pair from the live slot
+// columns, exactly the two candidate scans of k_allocate_round, continued past the first hit. k_round_distinct numbers the distinct
+// nodes the batch proposed; k_round_cross evaluates EVERY ask of the batch against every one of them (a bit per pair). With that the
+// host can replay the sequential loop over the batch exactly (engine.hip, allocate_round_batched): a node that took pods earlier in
+// the batch is one of the numbered nodes — whether a later ask passes its other Filters is its bit, whether it still fits is
+// arithmetic on the columns the proposals carry — and a candidate that is full is followed by the next entry of the ask's list.
+// Nothing here writes the round's state (cursors and failed bits are read, never advanced).
+// ---------------------------------------------------------------------------------------------------
+#ifndef YK_PROP_K
+#define YK_PROP_K 8
+#endif
+constexpr int kPropK = YK_PROP_K;            // candidates per ask (and shard)
+constexpr int kProposeWaves = 4, kProposeThreads = kProposeWaves * kWave;
+constexpr int kDistinctSlots = 4096;         // hash slots of k_round_distinct: at least twice the proposals of a batch
+struct PropCand {
+  u64 key;
+  int tie, node;
+};
+__device__ __forceinline__ bool cand_less(u64 ka, int ta, u64 kb, int tb) { return ka < kb || (ka == kb && ta < tb); }
+// one proposal entry: what the ranks need of node `win` to order it, to re-key it after assumes and to re-check NodeResourcesFit
+// (wave 0 of the workgroup; the block of k_allocate_round's propose mode)
+__device__ __forceinline__ void write_proposal(const NodeTable& t, const SpecTable& s, const RoundArgs& a, int spec, int pin, int tsig, bool fit_on,
+                                               int win, RoundProposal* out) {
+  const int lane = threadIdx.x % kWave;
+  if (win < 0) {
+    if (lane == 0) {
+      RoundProposal pr{};
+      pr.key = ~0ull;
+      pr.node = -1;
+      pr.gnode = -1;
+      pr.didx = -1;
+      *out = pr;
+    }
+    return;
+  }
+  const bool lr = lane < t.R;
+  const int rl = min(lane, t.R - 1);
+  const i64 rq_raw = s.req[(size_t)spec * s.R + rl], al_raw = t.alloc[(size_t)rl * t.n + win], old_raw = ld_live(a.req + (size_t)rl * t.n + win);
+  const int cnt0 = ld_live(a.count + win), allowed = t.allowed[win];
+  const u64 occ_l = (lane < t.KP && a.ports && a.fx.occupied) ? a.fx.occupied[(size_t)spec * t.KP + lane] : 0ull;
+  const bool contributes = a.topo_on && a.fx.off && a.fx.off[spec + 1] > a.fx.off[spec];
+  const i64 rq_l = lr ? rq_raw : 0, al_l = lr ? al_raw : 0, old_l = lr ? old_raw : 0;
+  const bool any_occ = __ballot(occ_l != 0) != 0;
+  i64 fits_l = (lr && rq_l > 0) ? (al_l - old_l) / rq_l : 0x7fffffffffffffffll;
+#pragma unroll
+  for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
+  i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));
+  if (pin != -1 || tsig >= 0 || any_occ || contributes || !fit_on) fits = 1;
+  const i64 used[2] = {(i64)__shfl((long long)old_l, 0, kWave), (i64)__shfl((long long)old_l, 1, kWave)};
+  const i64 total[2] = {(i64)__shfl((long long)al_l, 0, kWave), (i64)__shfl((long long)al_l, 1, kWave)};
+  if (lane < kMaxR) {  // (lane r = resource r; lanes past the table's dimensions hold zeros)
+    out->alloc[lane] = al_l;
+    out->req[lane] = old_l;
+  }
+  if (lane == 0) {
+    out->key = sortable_key(node_score_of(total, used));
+    out->node = win;
+    out->fits = (int)max((i64)1, min(fits, (i64)0x7fffffff));
+    out->gnode = a.node_offset + win;
+    out->room = allowed - cnt0;
+    out->didx = -1;
+    out->pad = a.name_rank ? a.name_rank[win] : win;
+  }
+}
+// grid.x = asks of the batch (a.first .. a.first + gridDim.x of the round's list); out: [asks][kPropK], best first, node -1 = no further node
+__global__ __launch_bounds__(kProposeThreads) void k_round_propose(RoundCtx c, RoundProposal* __restrict__ out) {
+  const NodeTable& t = c.nodes;
+  const SpecTable& s = c.specs;
+  const ClassTable& ct = c.classes;
+  const Planes& ranked = c.planes;
+  const RoundArgs& a = c.args;
+  const SpreadSigs& sp = s.spread;
+  __shared__ int sh_apos[kProposeWaves][kPropK], sh_an[kProposeWaves], sh_alist[kPropK];
+  __shared__ u64 sh_wk[kProposeWaves];
+  __shared__ int sh_wt[kProposeWaves], sh_wn[kProposeWaves];
+  __shared__ PropCand sh_b[kPropK];
+  __shared__ int sh_win[kPropK], sh_nwin;
+  const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+  const int j = blockIdx.x;
+  const bool name_on = a.filt & kPlugNodeName;
+  const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
+  const bool spread_en = a.filt & kPlugSpread, ipa_en = (a.filt & kPlugInterPod) && (a.pre & kPlugInterPod);
+  const int p = a.asks[a.first + j];
+  const int spec = a.pod_spec[p], cls = a.pod_class[p];
+  const int pin = name_on ? a.pod_pin[p] : -1;
+  const int tsig = (a.topo_on && s.spread_sig) ? s.spread_sig[spec] : -1;
+  RoundProposal* o = out + (size_t)j * kPropK;
+  if (tid == 0) sh_nwin = 0;
+  __syncthreads();
+  if (a.all_fail || pin == -2) {
+    // a Filter without its PreFilter state / spec.nodeName names no node of the table: nothing fits
+  } else if (pin >= 0) {
+    if (tid == 0) {
+      NodeRegs nr;
+      load_node_live(t, a, pin, &nr);
+      int code;
+      unsigned reason;
+      if (eval_pair<true>(s, spec, pin, pin, nr, a.pre, a.filt, &code, &reason)) {
+        sh_win[0] = pin;
+        sh_nwin = 1;
+      }
+    }
+  } else {
+    // ---- unmoved nodes, snapshot order: the first kPropK set bits of (AND of the class's rank-ordered rows) & ~moved — for a class with
+    // a topology signature checked against the live histograms, word after word, lane = node
+    int na = 0;
+    {
+      const u64* dsc = a.cdesc + (size_t)cls * kDescWords;
+      const u64* dr[kDescRows];
+#pragma unroll
+      for (int k = 0; k < kDescRows; ++k) dr[k] = (const u64*)dsc[k];
+      const u64 meta = dsc[kDescRows];
+      const int dn = (int)(unsigned)meta;
+      ClassRows cr;
+      cr.n = 0;
+      cr.ni = 0;
+      cr.start = (int)(meta >> 32);
+      if (dn < 0) cr = class_rows(ranked, ct.sig[cls * 4 + 0], ct.sig[cls * 4 + 1], ct.sig[cls * 4 + 2], -1);
+      int w0 = ld_live(a.cursor + cls);
+      if (w0 < 0) w0 = cr.start;  // (kNoWord: some row of the class is empty)
+      const int row_words = a.row_words;
+      for (int base = w0 < row_words ? (w0 & ~(kWave - 1)) : row_words; base < row_words && na < kPropK; base += kProposeThreads) {
+        const int w = base + tid;
+        u64 x = 0;
+        if (w >= w0 && w < row_words) {
+          const u64 mv = ld_live(a.moved_bits + w);
+          u64 v = ~0ull;
+          if (dn > 0) {
+#pragma unroll
+            for (int k = 0; k < kDescRows; ++k) v &= dr[k][w];
+          } else if (dn < 0) {
+            v = class_word(cr, w);
+          }
+          x = ~mv & v;
+        }
+        const int wave_w = base + wave * kWave;
+        if (tsig >= 0) {
+          u64 todo = __ballot(x != 0), kept = 0;
+          int found = 0;
+          while (todo && found < kPropK) {
+            const int fl = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int ww = wave_w + fl;
+            const u64 xw = readlane64(x, fl);
+            bool ok = false;
+            if ((xw >> lane) & 1ull) {
+              const int n = a.perm[ww * kWave + lane];
+              int dom[kMaxKD];
+#pragma unroll
+              for (int k = 0; k < kMaxKD; ++k) dom[k] = k < t.KD ? t.domain[(size_t)k * t.n + n] : -1;
+              ok = constraints_fail<true>(sp, tsig, dom, spread_en, ipa_en, nullptr) == 0;
+            }
+            const u64 y = __ballot(ok);
+            if (lane == fl) kept = y;
+            found += __popcll(y);
+          }
+          x = kept;  // (words behind the wave's kPropK-th node are not looked at: they cannot be among the first kPropK)
+        }
+        u64 todo = __ballot(x != 0);
+        int cnt = 0;
+        while (todo && cnt < kPropK) {
+          const int fl = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          u64 xw = readlane64(x, fl);
+          while (xw && cnt < kPropK) {
+            const int b = __ffsll((long long)xw) - 1;
+            xw &= xw - 1;
+            if (lane == 0) sh_apos[wave][cnt] = (wave_w + fl) * kWave + b;
+            ++cnt;
+          }
+        }
+        if (lane == 0) sh_an[wave] = cnt;
+        __syncthreads();
+        for (int wv = 0; wv < kProposeWaves; ++wv)  // (wave wv holds the words in front of wave wv + 1's)
+          for (int q = 0; q < sh_an[wv] && na < kPropK; ++q, ++na)
+            if (tid == 0) sh_alist[na] = sh_apos[wv][q];
+        __syncthreads();
+      }
+    }
+    // ---- moved nodes: every live slot per pair from the slot columns, the thread's kPropK best in registers (ascending)
+    u64 lk[kPropK];
+    int lt[kPropK], ln[kPropK];
+#pragma unroll
+    for (int q = 0; q < kPropK; ++q) {
+      lk[q] = ~0ull;
+      lt[q] = 0x7fffffff;
+      ln[q] = -1;
+    }
+    {
+      const int n_moved = ld_live(a.n_moved);
+      const u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
+      for (int slot = tid; slot < n_moved; slot += kProposeThreads) {
+        const u64 skip = ld_live(a.dead + (slot >> 6)) | (fw ? ld_live(fw + (slot >> 6)) : 0ull);
+        if ((skip >> (slot & 63)) & 1ull) continue;
+        NodeRegs nr;
+        load_slot_live(t, a, slot, tsig >= 0, &nr);
+        const int m = a.m_node[slot];
+        int code;
+        unsigned reason;
+        if (!eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) continue;
+        u64 k = ld_live(a.m_key + slot);
+        int tie = a.m_tie[slot], nn = m;
+#pragma unroll
+        for (int q = 0; q < kPropK; ++q)  // (insertion: the entry sinks to its place, the last one falls off)
+          if (cand_less(k, tie, lk[q], lt[q])) {
+            const u64 k2 = lk[q];
+            const int t2 = lt[q], n2 = ln[q];
+            lk[q] = k;
+            lt[q] = tie;
+            ln[q] = nn;
+            k = k2;
+            tie = t2;
+            nn = n2;
+          }
+      }
+    }
+    // the workgroup's kPropK best: kPropK rounds of "smallest head", the owner of the winner moves on to its next entry
+    int nb = 0;
+    for (int r = 0; r < kPropK; ++r) {
+      bool cand = ln[0] >= 0;
+      u64 wk = ~0ull;
+      int wt = 0x7fffffff, wn = -1;
+      if (__ballot(cand)) {
+        const unsigned hi = wave_umin(cand ? (unsigned)(lk[0] >> 32) : 0xffffffffu);
+        cand = cand && (unsigned)(lk[0] >> 32) == hi;
+        const unsigned lo = wave_umin(cand ? (unsigned)lk[0] : 0xffffffffu);
+        cand = cand && (unsigned)lk[0] == lo;
+        const unsigned ti = wave_umin(cand ? (unsigned)lt[0] : 0xffffffffu);
+        cand = cand && (unsigned)lt[0] == ti;
+        const int src = __ffsll((long long)__ballot(cand)) - 1;
+        wk = ((u64)hi << 32) | lo;
+        wt = (int)ti;
+        wn = __builtin_amdgcn_readlane(ln[0], src);
+      }
+      if (lane == 0) {
+        sh_wk[wave] = wk;
+        sh_wt[wave] = wt;
+        sh_wn[wave] = wn;
+      }
+      __syncthreads();
+      u64 gk = ~0ull;
+      int gt = 0x7fffffff, gn = -1;
+#pragma unroll
+      for (int wv = 0; wv < kProposeWaves; ++wv)
+        if (sh_wn[wv] >= 0 && (gn < 0 || cand_less(sh_wk[wv], sh_wt[wv], gk, gt))) {
+          gk = sh_wk[wv];
+          gt = sh_wt[wv];
+          gn = sh_wn[wv];
+        }
+      __syncthreads();
+      if (gn < 0) break;  // (workgroup-uniform)
+      if (tid == 0) sh_b[nb] = PropCand{gk, gt, gn};
+      ++nb;
+      if (ln[0] == gn) {  // (a node sits in one slot: one thread holds it)
+#pragma unroll
+        for (int q = 0; q + 1 < kPropK; ++q) {
+          lk[q] = lk[q + 1];
+          lt[q] = lt[q + 1];
+          ln[q] = ln[q + 1];
+        }
+        lk[kPropK - 1] = ~0ull;
+        lt[kPropK - 1] = 0x7fffffff;
+        ln[kPropK - 1] = -1;
+      }
+    }
+    __syncthreads();
+    // ---- the two ascending lists merged
+    if (tid == 0) {
+      int ia = 0, ib = 0, n = 0;
+      while (n < kPropK && (ia < na || ib < nb)) {
+        bool take_a = ib >= nb;
+        if (ia < na && ib < nb) {
+          const int pos = sh_alist[ia];
+          take_a = cand_less(a.rkey[pos], a.rtie[pos], sh_b[ib].key, sh_b[ib].tie);
+        }
+        sh_win[n++] = take_a ? a.perm[sh_alist[ia++]] : sh_b[ib++].node;
+      }
+      sh_nwin = n;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int nwin = sh_nwin;
+    for (int r = 0; r < kPropK; ++r) write_proposal(t, s, a, spec, pin, tsig, fit_on, r < nwin ? sh_win[r] : -1, o + r);
+  }
+}
+// The distinct nodes among a batch's n proposals (one workgroup): list[0 .. *n_out) and every proposal's index into it (didx).
+__global__ __launch_bounds__(kBlock) void k_round_distinct(RoundProposal* __restrict__ props, int n, int* __restrict__ list, int* __restrict__ n_out) {
+  __shared__ int keys[kDistinctSlots], idx[kDistinctSlots];
+  __shared__ int cnt;
+  const int tid = threadIdx.x;
+  for (int h = tid; h < kDistinctSlots; h += kBlock) keys[h] = -1;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += kBlock) {
+    const int node = props[i].node;
+    if (node < 0) continue;
+    unsigned h = ((unsigned)node * 2654435761u) & (kDistinctSlots - 1);
+    for (;;) {
+      const int old = atomicCAS(&keys[h], -1, node);
+      if (old == -1 || old == node) break;
+      h = (h + 1) & (kDistinctSlots - 1);
+    }
+  }
+  __syncthreads();
+  for (int h = tid; h < kDistinctSlots; h += kBlock)
+    if (keys[h] >= 0) {
+      const int my = atomicAdd(&cnt, 1);
+      idx[h] = my;
+      list[my] = keys[h];
+    }
+  __syncthreads();
+  for (int i = tid; i < n; i += kBlock) {
+    const int node = props[i].node;
+    if (node < 0) continue;
+    unsigned h = ((unsigned)node * 2654435761u) & (kDistinctSlots - 1);
+    while (keys[h] != node) h = (h + 1) & (kDistinctSlots - 1);
+    props[i].didx = idx[h];
+  }
+  if (tid == 0) *n_out = cnt;
+}
+// What a batch's accepted asks add to ONE node, summed by the host's replay: the assume of a batch whose pods move nothing but
+// resources and pod counts (no host port, no contribution to a topology histogram) is independent node by node — a wave per node
+// instead of k_allocate_round's ask-after-ask assume mode (2.9 us per ask: half the time of a batched round on one GPU).
+struct RoundNodeDelta {
+  int node, pods;
+  i64 add[kMaxR];
+};
+__global__ __launch_bounds__(kWave) void k_round_assume_nodes(RoundCtx c, const RoundNodeDelta* __restrict__ list, int n) {
+  const NodeTable& t = c.nodes;
+  const RoundArgs& a = c.args;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  if (g >= n) return;
+  const int win = list[g].node, k_run = list[g].pods;
+  const bool fit_on = (a.filt & kPlugFit) && (a.pre & kPlugFit);
+  const size_t cap = (size_t)a.cap;
+  const bool lr = lane < t.R, lp = lane < t.KP;
+  const int rl = min(lane, t.R - 1);
+  const i64 add_raw = list[g].add[min(rl, kMaxR - 1)], al_raw = t.alloc[(size_t)rl * t.n + win], old_raw = a.req[(size_t)rl * t.n + win];
+  const i64 add_l = lr ? add_raw : 0, al_l = lr ? al_raw : 0, old_l = lr ? old_raw : 0;
+  const int cnt0 = a.count[win], allowed = t.allowed[win];
+  const int slot_prev = a.slot_of[win];
+  const int rk = a.rank[win], tie_w = a.name_rank ? a.name_rank[win] : win;
+  const unsigned flags_w = t.flags[win];
+  const u64 port_l = lp ? (a.ports ? a.ports[(size_t)lane * t.n + win] : t.ports[(size_t)lane * t.n + win]) : 0ull;
+  const int c0 = 8, Wc = min(t.W, kMaxW), col = lane - c0;  // (lanes 0..7 hold the resources, the others a static column each)
+  u64 stat_l = 0;
+  int dom_l = -1;
+  if (col >= 0 && col < t.KT) stat_l = t.taints[(size_t)col * t.n + win];
+  else if (col >= t.KT && col < t.KT + Wc) stat_l = t.labels[(size_t)(col - t.KT) * t.n + win];
+  else if (col >= t.KT + Wc && col < t.KT + Wc + t.KD) dom_l = t.domain[(size_t)(col - t.KT - Wc) * t.n + win];
+  const bool was_moved = slot_prev >= 0;
+  int slot = slot_prev;
+  if (!was_moved) {  // (the order in which nodes take their slots is free: every scan over them takes a minimum)
+    if (lane == 0) slot = atomicAdd(a.n_moved, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+  }
+  const int cnt = cnt0 + k_run;
+  const bool dead = fit_on && (i64)cnt + 1 > (i64)allowed;
+  const i64 v_l = old_l + add_l;
+  if (lr) {
+    a.req[(size_t)lane * t.n + win] = v_l;
+    a.m_free[(size_t)lane * cap + slot] = al_l - v_l;
+  }
+  const i64 used[2] = {(i64)__shfl((long long)v_l, 0, kWave), (i64)__shfl((long long)v_l, 1, kWave)};
+  const i64 total[2] = {(i64)__shfl((long long)al_l, 0, kWave), (i64)__shfl((long long)al_l, 1, kWave)};
+  if (lane == 0) {
+    a.count[win] = cnt;
+    a.m_room[slot] = allowed - cnt;
+    a.m_key[slot] = sortable_key(node_score_of(total, used));
+    if (!was_moved) {
+      atomicOr((unsigned long long*)(a.moved_bits + (rk >> 6)), 1ull << (rk & 63));
+      a.slot_of[win] = slot;
+      a.m_node[slot] = win;
+      a.m_tie[slot] = tie_w;
+      a.m_flags[slot] = flags_w;
+    }
+    if (dead) atomicOr((unsigned long long*)(a.dead + (slot >> 6)), 1ull << (slot & 63));
+  }
+  if (!was_moved) {
+    if (lp) a.m_ports[(size_t)lane * cap + slot] = port_l;
+    if (col >= 0 && col < t.KT) a.m_taint[(size_t)col * cap + slot] = stat_l;
+    else if (col >= t.KT && col < t.KT + Wc) a.m_label[(size_t)(col - t.KT) * cap + slot] = stat_l;
+    else if (col >= t.KT + Wc && col < t.KT + Wc + t.KD) a.m_dom[(size_t)(col - t.KT - Wc) * cap + slot] = dom_l;
+  }
+}
+// grid.x = asks of the batch; cross[ask][cw] bit d = the ask passes Predicates() on node list[d] as the round's state stands
+__global__ __launch_bounds__(kBlock) void k_round_cross(RoundCtx c, const int* __restrict__ list, const int* __restrict__ n_list, u64* __restrict__ cross, int cw) {
+  const NodeTable& t = c.nodes;
+  const SpecTable& s = c.specs;
+  const RoundArgs& a = c.args;
+  const int tid = threadIdx.x, lane = tid % kWave;
+  const int j = blockIdx.x;
+  const int p = a.asks[a.first + j];
+  const int spec = a.pod_spec[p];
+  const int pin = (a.filt & kPlugNodeName) ? a.pod_pin[p] : -1;
+  const int nd = *n_list;
+  const bool never = a.all_fail || pin == -2;
+  for (int d0 = 0; d0 < cw * kWave; d0 += kBlock) {
+    const int d = d0 + tid;
+    bool fit = false;
+    if (d < nd && !never) {
+      const int node = list[d];
+      NodeRegs nr;
+      load_node_live(t, a, node, &nr);
+      int code;
+      unsigned reason;
+      fit = eval_pair<true>(s, spec, pin, node, nr, a.pre, a.filt, &code, &reason);
+    }
+    const u64 bits = __ballot(fit);
+    if (lane == 0 && (d >> 6) < cw) cross[(size_t)j * cw + (d >> 6)] = bits;
+  }
+}
 
 // order-independent checksum of the bitmap: Σ mix64(word ⊕ position-salt) over the meaningful words
 __device__ __forceinline__ u64 mix64(u64 z) {
