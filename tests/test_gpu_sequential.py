@@ -249,6 +249,84 @@ def test_round_without_apply_leaves_the_cluster_alone(pm):
     assert np.array_equal(a, b) and json.loads(pm.dump_snapshot()) == before
 
 
+@pytest.fixture(scope="module")
+def pm_batched():
+    """A manager whose rounds ALWAYS run in batches (YKPRED_TUNE round_batched=1, read when the engine is created): parallel
+    proposals, pair bits, the host's replay, node-by-node assume — the form node-sharded engines use, here on one GPU."""
+    import os
+    old = os.environ.get("YKPRED_TUNE")
+    os.environ["YKPRED_TUNE"] = "round_batched=1"
+    try:
+        m = pkg.GpuPredicateManager()
+    finally:
+        if old is None:
+            del os.environ["YKPRED_TUNE"]
+        else:
+            os.environ["YKPRED_TUNE"] = old
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("kind", ["plain"] + sorted(KINDS))
+def test_batched_rounds_equal_the_oracle(pm_batched, seed, kind):
+    """Batched rounds (round 6) against the oracle's sequential loop, every decision and the state left behind: competing asks of a
+    few templates on small nodes — candidates that fill up inside a batch (the next list entry takes over), accepted nodes that
+    overtake a later ask's candidate (pair bit + NodeResourcesFit on the exchanged columns), pins, and with `kind` host ports
+    (an accepted node in front of a port ask ends the batch), PodTopologySpread / InterPodAffinity (an ask behind a contribution to
+    a class it counts ends the batch; such batches are assumed ask after ask)."""
+    kw = {} if kind == "plain" else KINDS[kind]
+    snap = _seqgen.competing(900 + 10 * seed + len(kind), n_nodes=24 + 3 * seed, n_pods=120, scalars=bool(seed % 2), **kw)
+    got = round_against_oracle(pm_batched, snap, expect_device=True)
+    assert (got >= 0).sum() > 5
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_batched_rounds_in_a_given_order_and_in_runs(pm_batched, seed):
+    snap = _seqgen.competing(950 + seed, n_nodes=30, n_pods=400, ports=seed == 1, spread=seed == 2)
+    order = np.random.default_rng(seed).permutation(400)[:300].astype(np.int32)
+    round_against_oracle(pm_batched, snap, asks=order)
+    snap = _seqgen.competing(960 + seed, n_nodes=30, n_pods=400, ports=seed == 1, spread=seed == 2)
+    snap["pods"].sort(key=lambda p: (p["metadata"]["labels"]["app"], p["metadata"]["name"]))  # (runs of one template: accepted at once)
+    round_against_oracle(pm_batched, snap)
+
+
+@pytest.mark.parametrize("kind", ["resources", "spread", "ports", "spread+ports"])
+def test_batched_round_moves_thousands_of_nodes(pm_batched, kind):
+    """The 12 000-ask round that moves 2 900 nodes (test_allocation_round_moves_thousands_of_nodes), in batches: every decision."""
+    snap = _seqgen.small_slots(7, spread="spread" in kind, ports="ports" in kind)
+    pm_batched.load_snapshot(snap)
+    o = orc.Oracle(pm_batched.dump_snapshot())
+    want = o.allocate_sequential(prefilter_once=True)
+    got = pm_batched.allocate_round()
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, f"{len(bad)} decisions differ, first at position {bad[0]}: gpu={got[bad[0]]} oracle={want[bad[0]]}"
+    assert len(np.unique(got[got >= 0])) > 2000
+    pm_batched.evaluate(allocate=True)
+    o2 = orc.Oracle(pm_batched.dump_snapshot())
+    for n in range(o.num_nodes):
+        assert o.node_info(n) == o2.node_info(n), n
+
+
+def test_batched_round_kwok_cluster_and_binpacking_pin(pm_batched):
+    """KWOK-style nodes x 4 000 asks of 40 templates in batches, then the reference's bin_packing e2e (the decision-order pin)."""
+    pm_batched.generate_kwok(seed=0x59554E49 + 7, num_nodes=300, num_pods=4000, num_templates=40, node_affinity=1)
+    o = orc.Oracle(pm_batched.dump_snapshot())
+    want = o.allocate_sequential()
+    got = pm_batched.allocate_round()
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+    pm_batched.generate_kwok(seed=0x59554E49 + 8, num_nodes=2000, num_pods=6000, num_templates=700, node_affinity=1)
+    o = orc.Oracle(pm_batched.dump_snapshot())
+    want = o.allocate_sequential()
+    got = pm_batched.allocate_round()
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:5]
+    for case in _binpacking_cases():
+        pm_batched.load_snapshot({"nodes": case["nodes"], "pods": case["pods"]})
+        names = [n["metadata"]["name"] for n in case["nodes"]]
+        got = pm_batched.allocate_round()
+        assert [names[i] if i >= 0 else None for i in got] == case["expect"], case["source"]
+
+
 @pytest.mark.parametrize("world,total_nodes,n_pods,n_templates,spread", [(2, 200, 600, 40, 0), (3, 330, 900, 6, 0), (2, 130, 500, 1, 0),
                                                                          (2, 256, 700, 40, 1), (3, 330, 600, 20, 1)],
                          ids=["two-shards", "three-shards-long-runs", "one-template-and-a-two-node-shard", "two-shards-hard-spread",

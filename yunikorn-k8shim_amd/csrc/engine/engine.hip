@@ -3707,7 +3707,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       const double t0 = e->round_prof ? now_s() : 0.0;
       ykk::RoundProposal* d_props = (ykk::RoundProposal*)d_send;
       u64* d_cross = (u64*)(d_send + (size_t)b * K * sizeof(ykk::RoundProposal));
-      ra.mode = ykk::kRoundPropose;
+      ra.mode = ykk::kRoundDecide;  // (the proposal kernels read the state; nothing is assumed)
       ra.first = pos;
       ra.n_asks = b;
       {

@@ -3093,7 +3093,7 @@ struct SpecEffects {       // what NodeInfo.AddPod of a pod of spec s adds to it
   const int* cnt;          // what one pod of the spec adds to that column
   const u64* occupied;     // [S][KP] dictionary host ports a pod of the spec conflicts with once it is on a node
 };
-constexpr int kRoundDecide = 0, kRoundPropose = 1, kRoundAssume = 2;
+constexpr int kRoundDecide = 0, kRoundAssume = 2;
 struct RoundProposal {      // a shard's best node for an ask, and what the other ranks need to order it and to re-key it after assumes
   u64 key;                  // score key of the node as it stands (smaller = earlier)
   int node;                 // node index in this shard, -1 = no node of the shard fits
@@ -3158,12 +3158,11 @@ struct RoundArgs {
   // asks of a batch against the state the accepted asks left (mode 1: the loop below without the assume), the proposals are
   // all-gathered, every rank accepts the same conflict-free prefix, and the owners of the winners assume them (mode 2: the loop's
   // assume for given nodes, no scans).
-  int mode;                 // kRoundDecide (0), kRoundPropose, kRoundAssume
+  int mode;                 // kRoundDecide (0) or kRoundAssume (the proposals of a batched round are k_round_propose's)
   int node_offset;          // index of this shard's first node in the whole cluster
   const int* forced;        // kRoundAssume: [round] the node (of this shard) an ask goes to, -1 = none of this shard's
   const int* run_len;       // kRoundAssume: [round] asks from this one on that go to the same node with the same spec (a run the host accepted
                             // at once: assumed in one step; inside one 64-ask header window); null: 1
-  RoundProposal* prop;      // kRoundPropose: [round]
   i64* prof;                // YKPRED_TUNE round_prof=1: thread 0's 100 MHz ticks per phase of the loop (null: off)
   // kRoundAssume on a sharded engine with topology signatures: what the assume added to the histograms, for the OTHER shards (they
   // hold the same cluster-wide histograms and cannot see this shard's node): [round][kDeltaStride] ints — word 0 = entries, then
@@ -3806,48 +3805,7 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
     last_spec = pin == -1 ? spec : -1;
     last_win = win;
     YK_CTX_FRESH();
-    if (mode == kRoundPropose) {
-      // ---- the shard's proposal for this ask; nothing is assumed. Wave 0, one load round (lane r = resource r).
-      if (wave == 0 && win < 0) {  // (no node of the shard fits — or the shard has no node at all)
-        if (lane == 0) {
-          RoundProposal pr{};
-          pr.key = ~0ull;
-          pr.node = -1;
-          pr.gnode = -1;
-          a.prop[first_ask + i] = pr;
-        }
-      } else if (wave == 0) {
-        const bool lr = lane < t.R;
-        const int rl = min(lane, t.R - 1), wn = win;
-        const i64 rq_raw = s.req[(size_t)spec * s.R + rl], al_raw = t.alloc[(size_t)rl * t.n + wn], old_raw = ld_live(a.req + (size_t)rl * t.n + wn);
-        const int cnt0 = ld_live(a.count + wn), allowed = t.allowed[wn];
-        const u64 occ_l = (lane < t.KP && a.ports && a.fx.occupied) ? a.fx.occupied[(size_t)spec * t.KP + lane] : 0ull;
-        const bool contributes = a.topo_on && a.fx.off && a.fx.off[spec + 1] > a.fx.off[spec];
-        const i64 rq_l = lr ? rq_raw : 0, al_l = lr ? al_raw : 0, old_l = lr ? old_raw : 0;
-        const bool any_occ = __ballot(occ_l != 0) != 0;
-        i64 fits_l = (lr && rq_l > 0) ? (al_l - old_l) / rq_l : 0x7fffffffffffffffll;
-#pragma unroll
-        for (int off = kMaxR / 2; off > 0; off >>= 1) fits_l = min(fits_l, (i64)__shfl_xor((long long)fits_l, off, kWave));
-        i64 fits = min((i64)allowed - (i64)cnt0, (i64)__shfl((long long)fits_l, 0, kWave));
-        if (pin != -1 || tsig >= 0 || any_occ || contributes || !fit_on) fits = 1;
-        const i64 used[2] = {(i64)__shfl((long long)old_l, 0, kWave), (i64)__shfl((long long)old_l, 1, kWave)};
-        const i64 total[2] = {(i64)__shfl((long long)al_l, 0, kWave), (i64)__shfl((long long)al_l, 1, kWave)};
-        RoundProposal* out = a.prop + first_ask + i;
-        if (lane < kMaxR) {  // (lane r = resource r; lanes past the table's dimensions hold zeros)
-          out->alloc[lane] = al_l;
-          out->req[lane] = old_l;
-        }
-        if (lane == 0) {
-          out->key = win >= 0 ? sortable_key(node_score_of(total, used)) : ~0ull;
-          out->node = win;
-          out->fits = win >= 0 ? (int)max((i64)1, min(fits, (i64)0x7fffffff)) : 0;
-          out->gnode = win >= 0 ? a.node_offset + win : -1;
-          out->room = allowed - cnt0;
-        }
-      }
-      last_spec = -1;
-      last_win = -1;
-    } else if (win >= 0) {  // (workgroup-uniform)
+    if (win >= 0) {  // (workgroup-uniform)
       // ---- AssumePod on the scratch state: Requested += the ask's request vector, len(Pods) += 1 (NodeInfo.AddPod).
       // A RUN of asks with this spec lands on this node as long as it fits (the argument of the `again` path), and for a spec whose
       // pods couple through nothing but resources "fits k more times" is arithmetic: k = what the free resources and pod slots
