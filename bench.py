@@ -362,15 +362,20 @@ def device_rounds(pm, sizes, check_prefix):
         asks = np.arange(min(n_asks, pm.num_pods), dtype=np.int32)
         before = pm.round_stats()
         pm.allocate_round(asks=asks[:64], apply=False)  # (first call: scratch allocation, the specs' effects)
+        info0 = pm.round_info()
         t0 = time.perf_counter()
         got = pm.allocate_round(asks=asks, apply=False)
         t_round = time.perf_counter() - t0
         after = pm.round_stats()
+        info1 = pm.round_info()
+        in_batches = info1["rounds_batched"] > info0["rounds_batched"]
         kk = min(k, len(asks))
         out.append({"nodes": pm.num_nodes, "asks": int(len(asks)), "allocated": int((got >= 0).sum()),
                     "distinct_nodes": int(len(np.unique(got[got >= 0]))),
                     "allocations_per_sec": len(asks) / t_round, "round_ms": round(t_round * 1e3, 2), "us_per_ask": round(t_round / len(asks) * 1e6, 2),
                     "on_device": bool(after["rounds_on_device"] == before["rounds_on_device"] + 2),
+                    "form": "batched: parallel proposals, pair bits, host replay, node-by-node assume" if in_batches else "sequential kernel (one workgroup)",
+                    "batches": int(info1["batches"] - info0["batches"]),
                     "asks_one_by_one": int(after["asks_one_by_one"] - before["asks_one_by_one"]),
                     "cpu_sequential_per_sec": k / t_cpu, "cpu_cores": 1, "checked_decisions": int(kk), "verified": bool(np.array_equal(got[:kk], want[:kk]))})
     return out
@@ -423,7 +428,8 @@ def allocation_round_leg(pkg, dev, big_pm=None, big_asks=2000):
         out["main_workload_round"], out["main_workload_round_20k"] = device_rounds(
             big_pm, [big_asks, 20_000], int(os.environ.get("BENCH_ROUND_CHECK", "20000")))
     out["definition"] = ("decisions/sec, conflict-resolved: ask i is decided with asks 0..i-1 of the round assumed on their nodes — identical to the "
-                         "oracle run sequentially; `decisions_per_sec` of the line is the SNAPSHOT form (every ask against one state)")
+                         "oracle run sequentially; `decisions_per_sec` of the line is the SNAPSHOT form (every ask against one state). `form`: the engine picks per round "
+                         "between the sequential kernel and the batched form (ykpred.h, ykpred_allocate_round) — identical decisions")
     return out
 
 

@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 /* 4: ykpred_set_spec_effects + ykpred_spec_effects_t, ykpred_comm_info (round 5 added them without a bump: a host built against the
- *    header could not tell an older library apart), ykpred_layout_t.sweep_rows / index_rows_walked / run_rows / fused_rows
+ *    header could not tell an older library apart), ykpred_layout_t.sweep_rows / index_rows_walked / run_rows / fused_rows, ykpred_get_round_info
  * 3: ykpred_eval_args_t.bitmap_rows (a caller-owned bitmap states its size), ykpred_peek_row (the resident
  *    answer served to single Predicates() callbacks), ykpred_eval_nodes is collective on a sharded engine with topology signatures
  * 2: bitmap rows addressed through ykpred_layout_t.row_of_pod, ykpred_nodes_t.name_rank, per-ask unsupported flag, communicator /
@@ -339,18 +339,30 @@ int32_t ykpred_check_class_rows(ykpred_engine_t* e, uint64_t* bad_words);
  * ask instead — when something other than node resources couples the asks of the round (active PodTopologySpread /
  * InterPodAffinity signatures, an ask that requests a host port) while the specs' effects (ykpred_set_spec_effects, below) are not
  * uploaded for the current spec table.
+ * ONE GPU, two forms with identical decisions. SEQUENTIAL: one workgroup runs the loop (k_allocate_round; the asks are a dependency
+ * chain, the parallelism is inside an ask) — a run of asks of one spec that lands on one node is decided by arithmetic (millions of
+ * asks per second), every other ask costs ~10 us. BATCHED: the asks of a batch are proposed in parallel against one frozen state
+ * (k_round_propose: a workgroup per ask, its 8 best feasible nodes with the columns their keys are made of), every ask is evaluated
+ * against every node the batch proposed (k_round_cross: a bit per pair), the host replays the loop over the batch exactly — an
+ * accepted node by its bit + NodeResourcesFit on the exchanged columns, a candidate that is full by the next entry of the ask's
+ * list — and the accepted pods are assumed node by node: 100 k -> 570 k asks/s on a 20 000-ask round of configs[2]. Chosen per round
+ * (YKPRED_TUNE round_batched: -1 = by the list, the default; 0 / 1 = never / always): batched for rounds of 512 asks and more
+ * without live topology constraints whose mean run of one spec is shorter than four asks. ykpred_get_round_info counts both.
  * NODE-SHARDED engines (communicator attached, world > 1): the call is COLLECTIVE — every rank passes the same asks in the same
  * order — and out_nodes holds GLOBAL node indices (the winner's shard offset + its index there), identical on every rank. The
- * round runs in batches: every shard proposes its best node per ask of a batch, one all-gather of 56 bytes per ask and rank, every
- * rank accepts the same conflict-free prefix, the owners assume (engine.hip has the rule and its proof sketch). Equal keys
- * across shards are ordered by global node index, as in ykpred_exchange_decisions. Before the first batch the ranks agree on status,
- * ask count and a hash of the ask list (a rank that cannot run the round makes every rank return the same error). With active
- * topology signatures the histograms are cluster-wide state on every shard: the owner of an accepted node records what its assume
- * added (constraint, domain, count), a second all-gather of the batch hands the records to the other shards, and the prefix ends in
- * front of the first ask WITH a topology signature behind an accepted contribution (its verdicts may have turned from fail to fit
- * anywhere). YKPRED_E_UNSUPPORTED when one pod moves more than 10 histogram cells (every rank sees the same record and stops). */
+ * round always runs in batches: proposals and pair bits of a batch in ONE all-gather, the same replay on every rank, the owners
+ * assume (engine.hip has the rule and its proof sketch). Equal keys across shards are ordered by global node index, as in
+ * ykpred_exchange_decisions. Before the first batch the ranks agree on status, ask count and a hash of the ask list (a rank that
+ * cannot run the round makes every rank return the same error). With active topology signatures the histograms are cluster-wide
+ * state on every shard: the owner of an accepted node records what its assume added (constraint, domain, count), a second
+ * all-gather of the batch hands the records to the other shards, and a batch ends in front of the first ask whose topology signature
+ * counts a selector class an accepted pod of the batch added to (its verdicts may have turned from fail to fit anywhere).
+ * YKPRED_E_UNSUPPORTED when one pod moves more than 10 histogram cells (every rank sees the same record and stops). */
 int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t prefilter_plugins, uint32_t filter_plugins, int32_t n_asks,
                               const int32_t* asks /* host, [n_asks] ask indices in decision order */, int32_t* out_nodes /* host, [n_asks] */);
+/* How the rounds so far were decided: out[0] rounds run in batches, [1] their asks, [2] their batches, [3] collective exchanges of
+ * sharded rounds (proposals + histogram deltas), [4] rounds run by the sequential kernel, [5] their asks. */
+int32_t ykpred_get_round_info(const ykpred_engine_t* e, int64_t* out6);
 /* What NodeInfo.AddPod (behind SchedulerCache.AssumePod, /root/reference/pkg/cache/external/scheduler_cache.go:443-461) adds to a
  * node BESIDES the pod's request vector and len(Pods) += 1, per pod spec — the part of the upstream NodeInfo the Filters of
  * predicate_manager.go:339-352 read again for the NEXT ask: UsedPorts (NodePorts), and the pod itself in Pods / PodsWithAffinity /

@@ -91,6 +91,7 @@ def load_ykpred():
     L.ykpred_get_layout.argtypes = [C.c_void_p, C.POINTER(YkpredLayout)]
     L.ykpred_last_timing.argtypes = [C.c_void_p, C.POINTER(YkpredTiming)]
     L.ykpred_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+    L.ykpred_get_round_info.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_read_bitmap.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.ykpred_read_counts.argtypes = [C.c_void_p, C.c_void_p]
     L.ykpred_read_decisions.argtypes = [C.c_void_p, C.c_void_p]

@@ -415,6 +415,7 @@ struct ykpred_engine {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1, node_offset = 0;
   int64_t round_exchanges = 0;      // proposal exchanges of sharded allocation rounds so far
+  int64_t rounds_batched = 0, round_batched_asks = 0, round_batches = 0, rounds_sequential = 0, round_sequential_asks = 0;  // ykpred_get_round_info
   int forced_stride = 0;  // ykpred_set_row_stride
   DevBuf d_gathered, d_gathered_map, d_xkey, d_xcand;
   bool last_has_keys = false;
@@ -3929,6 +3930,9 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       batch = (int)std::min<size_t>(kShardBatchMax, (size_t)std::max(32, 2 * m + 16));
     }
     e->round_exchanges += exchanges;
+    e->rounds_batched++;
+    e->round_batched_asks += n_asks;
+    e->round_batches += batches;
     if (e->round_prof)
       fprintf(stderr, "round_prof batched round (world %d): %d asks in %lld batches (%.1f accepted per batch), %lld exchanges, %lld of them histogram deltas (%lld cells); prefixes ended by: the batch %lld, a topology ask behind a contribution %lld, candidate lists used up %lld, an accepted node in front of an ask with host ports %lld; ms: proposals %.1f, replay %.1f, assume %.1f\n",
               W, n_asks, (long long)batches, batches ? (double)n_asks / (double)batches : 0.0, (long long)exchanges, (long long)delta_exchanges, (long long)delta_cells,
@@ -3946,6 +3950,8 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out_nodes, base + o_out, (size_t)n_asks * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  e->rounds_sequential++;
+  e->round_sequential_asks += n_asks;
   if (e->round_prof) {
     i64 pr_[16];
     HIPCHK(hipMemcpy(pr_, base + o_prof, sizeof(pr_), hipMemcpyDeviceToHost));
@@ -4094,6 +4100,18 @@ int32_t ykpred_get_counters(const ykpred_engine_t* e, int64_t* out) {
   out[3] = e->n_queries;
   out[4] = e->n_gathers;
   out[5] = e->n_uploads;
+  return YKPRED_OK;
+}
+
+int32_t ykpred_get_round_info(const ykpred_engine_t* e, int64_t* out) {
+  YK_SERIALISE(e);
+  if (!e || !out) return YKPRED_E_INVALID;
+  out[0] = e->rounds_batched;
+  out[1] = e->round_batched_asks;
+  out[2] = e->round_batches;
+  out[3] = e->round_exchanges;
+  out[4] = e->rounds_sequential;
+  out[5] = e->round_sequential_asks;
   return YKPRED_OK;
 }
 

@@ -570,6 +570,12 @@ class GpuPredicateManager:
                                           code.ctypes.data, reason.ctypes.data))
         return fit, code, reason
 
+    def round_info(self):
+        """ykpred_get_round_info: how the allocation rounds so far were decided (in batches / by the sequential kernel)."""
+        out = np.zeros(6, dtype=np.int64)
+        self._pcheck(self._P.ykpred_get_round_info(self.engine, out.ctypes.data))
+        return dict(zip(("rounds_batched", "batched_asks", "batches", "exchanges", "rounds_sequential", "sequential_asks"), (int(v) for v in out)))
+
     def counters(self):
         out = np.zeros(6, dtype=np.int64)
         self._pcheck(self._P.ykpred_get_counters(self.engine, out.ctypes.data))
