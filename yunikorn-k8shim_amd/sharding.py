@@ -111,51 +111,66 @@ def round_key(alloc, used):
     return 1.0 - np.asarray(used, dtype=np.float64) / np.asarray(alloc, dtype=np.float64)
 
 
-def ref_allocate_round_sharded(req, cls, static_ok, alloc, used, node_offset, dist, batch=16, batch_max=512):
-    """The protocol engine.hip runs for a round on node-sharded engines, on a model small enough to state in a few lines: node n
-    of this shard has capacity alloc[n] of one resource, used[n] of it taken (MUTATED here: the owner assumes), ask j requests
-    req[j] and is of class cls[j]; static_ok[c][n] says whether class c may run on node n at all. An ask fits a node iff the class
-    may and the request still fits; nodes are tried fullest first, ties by cluster-wide index. Per batch: every shard PROPOSES its
-    best node per ask against the state the accepted asks left, one all-gather, every rank accepts the same conflict-free PREFIX —
-    an accepted node u can change a later ask's answer w only if u == w, or u stood behind w and now stands in front of it —, a
-    run of asks with one (class, request) lands on one node while it fits, the owners assume. → cluster-wide node per ask, -1 = none;
-    identical on every rank and equal to deciding the asks one after the other over all nodes (tests/test_sharding_gloo.py)."""
+def ref_allocate_round_sharded(req, cls, static_ok, alloc, used, node_offset, dist, batch=32, batch_max=256, topk=4):
+    """The protocol engine.hip runs for a round on node-sharded engines (allocate_round, batched form), on a model small enough to
+    state in a few lines: node n of this shard has capacity alloc[n] of one resource, used[n] of it taken (MUTATED here: the owner
+    assumes), ask j requests req[j] and is of class cls[j]; static_ok[c][n] says whether class c may run on node n at all. An ask
+    fits a node iff the class may and the request still fits; nodes are tried fullest first, ties by cluster-wide index. Per batch:
+    every shard PROPOSES its `topk` best nodes per ask against the state the accepted asks left (k_round_propose) and a bit for every
+    (ask of the batch, node the shard proposed in this batch) pair (k_round_cross); one all-gather; every rank REPLAYS the loop over
+    the batch: the answer of an ask is the better of the first entry of its merged list that no accepted ask touched (the merged
+    list is exact up to the last entry of the first shard list that came back full) and the accepted nodes it passes — its bit, then
+    the request against the node's columns after the accepted asks; the batch ends where every known entry is an accepted node that
+    is full and the lists were cut. A run of asks with one (class, request) lands on one node while it fits; the owners assume.
+    → cluster-wide node per ask, -1 = none; identical on every rank and equal to deciding the asks one after the other over all
+    nodes (tests/test_sharding_gloo.py)."""
     world = dist.get_world_size()
     n_asks, out, pos = len(req), np.full(len(req), -1, dtype=np.int64), 0
     while pos < n_asks:
         b = min(batch, n_asks - pos)
-        prop = np.zeros((b, 5), dtype=np.float64)  # key, cluster-wide node (-1: none), fits, alloc, used
         key = round_key(alloc, used)
+        lists, number = [], {}  # per ask: [(key, cluster-wide node, alloc, used)]; local node -> its number among the proposed ones
         for j in range(b):
             ok = static_ok[cls[pos + j]] & (alloc - used >= req[pos + j])
-            if not ok.any():
-                prop[j] = (np.inf, -1, 0, 0, 0)
-                continue
             cand = np.flatnonzero(ok)
-            n = cand[np.lexsort((cand, key[cand]))[0]]
-            prop[j] = (key[n], node_offset + n, (alloc[n] - used[n]) // req[pos + j] if req[pos + j] > 0 else 1 << 30, alloc[n], used[n])
+            cand = cand[np.lexsort((cand, key[cand]))[:topk]]
+            lists.append([(float(key[n]), int(node_offset + n), float(alloc[n]), float(used[n])) for n in cand])
+            for n in cand:
+                number.setdefault(int(n), len(number))
+        nodes = np.fromiter(number.keys(), dtype=np.int64, count=len(number))
+        bits = [static_ok[cls[pos + j]][nodes] & (alloc[nodes] - used[nodes] >= req[pos + j]) if len(nodes) else np.zeros(0, bool) for j in range(b)]
         gathered = [None] * world
-        dist.all_gather_object(gathered, prop)
-        accepted, m = [], 0  # accepted: (cluster-wide node, key when proposed, key after the accepted asks)
+        dist.all_gather_object(gathered, (lists, {int(node_offset + n): d for n, d in number.items()}, bits))
+        acc, m = {}, 0  # cluster-wide node -> [key after the accepted asks, alloc, used, owner]
         while m < b:
-            best = min(((g[m][0], g[m][1], r) for r, g in enumerate(gathered) if g[m][1] >= 0), default=None)
-            if best is None:
+            ents = sorted((e[0], e[1], r, q) for r, g in enumerate(gathered) for q, e in enumerate(g[0][m]))
+            full = [max((e[0], e[1]) for e in g[0][m]) for g in gathered if len(g[0][m]) == topk]
+            horizon = min(full) if full else None
+            fresh = next((e for e in ents if (horizon is None or (e[0], e[1]) <= horizon) and e[1] not in acc), None)
+            passes = [(v[0], u) for u, v in acc.items() if gathered[v[3]][2][m][gathered[v[3]][1][u]] and v[1] - v[2] >= req[pos + m]]
+            best = min(passes) if passes else None
+            if fresh is None and horizon is not None and not (best is not None and best < horizon):
+                break  # (a node behind the lists may fit: only its shard knows)
+            if fresh is None and best is None:
                 m += 1
                 continue
-            w_key, w_node, owner = best
-            conflict = any(u == w_node or ((k0, u) > (w_key, w_node) and (k1, u) < (w_key, w_node)) for u, k0, k1 in accepted)
-            if conflict:
-                break
-            fits, a_n, u_n = gathered[owner][m][2:5]
+            if fresh is not None and (best is None or (fresh[0], fresh[1]) < best):
+                node, owner = fresh[1], fresh[2]
+                a_n, u_n = gathered[owner][0][m][fresh[3]][2:4]
+            else:
+                node = best[1]
+                _, a_n, u_n, owner = acc[node]
+            holds = (a_n - u_n) // req[pos + m] if req[pos + m] > 0 else 1 << 30
             k = 1
-            while k < fits and m + k < b and cls[pos + m + k] == cls[pos + m] and req[pos + m + k] == req[pos + m]:
+            while k < holds and m + k < b and cls[pos + m + k] == cls[pos + m] and req[pos + m + k] == req[pos + m]:
                 k += 1
-            accepted.append((w_node, w_key, float(round_key(a_n, u_n + k * req[pos + m]))))
-            out[pos + m:pos + m + k] = int(w_node)
-            local = int(w_node) - node_offset
+            u_n = u_n + k * req[pos + m]
+            acc[node] = [float(round_key(a_n, u_n)), a_n, u_n, owner]
+            out[pos + m:pos + m + k] = int(node)
+            local = int(node) - node_offset
             if 0 <= local < len(alloc):
                 used[local] += k * req[pos + m]
             m += k
         pos += m
-        batch = min(batch_max, max(8, 2 * m + 8))
+        batch = min(batch_max, max(32, 2 * m + 16))
     return out
