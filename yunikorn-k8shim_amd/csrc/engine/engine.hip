@@ -415,6 +415,8 @@ struct ykpred_engine {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 1, node_offset = 0;
   int64_t round_exchanges = 0;      // proposal exchanges of sharded allocation rounds so far
+  void* h_round_pinned = nullptr;   // page-locked landing buffer of a batched round's proposals (world x one shard's bytes)
+  size_t h_round_pinned_bytes = 0;
   int64_t rounds_batched = 0, round_batched_asks = 0, round_batches = 0, rounds_sequential = 0, round_sequential_asks = 0;  // ykpred_get_round_info
   int forced_stride = 0;  // ykpred_set_row_stride
   DevBuf d_gathered, d_gathered_map, d_xkey, d_xcand;
@@ -1722,6 +1724,7 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
   if (e->ev_counts) (void)hipEventDestroy(e->ev_counts);
   if (e->ev_zero) (void)hipEventDestroy(e->ev_zero);
+  if (e->h_round_pinned) (void)hipHostFree(e->h_round_pinned);
   if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
   if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
   if (e->peek_stream) (void)hipStreamDestroy(e->peek_stream);
@@ -3636,7 +3639,16 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
     ykk::RoundNodeDelta* d_deltas = (ykk::RoundNodeDelta*)(base + o_deltas);
     std::vector<ykk::RoundNodeDelta> deltas;
     std::vector<int32_t> run_len;
-    std::vector<char> all((size_t)W * bytes_of((int)kShardBatchMax));
+    // (the proposals land in page-locked memory: a pageable copy of a few hundred KB per batch is staged and costs tens of microseconds)
+    if (e->h_round_pinned_bytes < (size_t)W * kBatchBytesMax) {
+      if (e->h_round_pinned) (void)hipHostFree(e->h_round_pinned);
+      e->h_round_pinned = nullptr;
+      e->h_round_pinned_bytes = 0;
+      if (hipHostMalloc(&e->h_round_pinned, (size_t)W * kBatchBytesMax, hipHostMallocDefault) == hipSuccess) e->h_round_pinned_bytes = (size_t)W * kBatchBytesMax;
+      else (void)hipGetLastError();
+    }
+    std::vector<char> all_pageable(e->h_round_pinned ? 0 : (size_t)W * kBatchBytesMax);
+    char* const all = e->h_round_pinned ? (char*)e->h_round_pinned : all_pageable.data();
     std::vector<int32_t> forced;
     // Topology signatures: the histograms are cluster-wide state every shard holds. An accepted ask whose pod adds to a selector class
     // moves them — on its owner in the assume, on the others from the owner's delta record (second all-gather of the batch,
@@ -3720,19 +3732,19 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       HIPCHK(hipGetLastError());
       if (W > 1) {
         NCCLCHK(r->AllGather(d_send, d_all, nbytes, ncclInt8, e->comm, st));
-        HIPCHK(hipMemcpyAsync(all.data(), d_all, (size_t)W * nbytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(all, d_all, (size_t)W * nbytes, hipMemcpyDeviceToHost, st));
         ++exchanges;
       } else {
-        HIPCHK(hipMemcpyAsync(all.data(), d_send, nbytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(all, d_send, nbytes, hipMemcpyDeviceToHost, st));
       }
       HIPCHK(hipStreamSynchronize(st));
       const double t1 = e->round_prof ? now_s() : 0.0;
       ++batches;
       auto prop_of = [&](int g, int m, int q) -> const ykk::RoundProposal& {
-        return ((const ykk::RoundProposal*)(all.data() + (size_t)g * nbytes))[(size_t)m * K + (size_t)q];
+        return ((const ykk::RoundProposal*)(all + (size_t)g * nbytes))[(size_t)m * K + (size_t)q];
       };
       auto bit_of = [&](const Accepted& a2, int m) {
-        const u64* cross = (const u64*)(all.data() + (size_t)a2.rank * nbytes + (size_t)b * K * sizeof(ykk::RoundProposal));
+        const u64* cross = (const u64*)(all + (size_t)a2.rank * nbytes + (size_t)b * K * sizeof(ykk::RoundProposal));
         return a2.didx >= 0 && ((cross[(size_t)m * (size_t)cw + (size_t)(a2.didx >> 6)] >> (a2.didx & 63)) & 1ull) != 0;
       };
       auto ord_of = [&](const ykk::RoundProposal& p) { return W > 1 ? (int64_t)p.gnode : (int64_t)p.pad; };
