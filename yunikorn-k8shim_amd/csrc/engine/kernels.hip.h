@@ -4009,13 +4009,16 @@ __global__ __launch_bounds__(kRoundThreads) void k_allocate_round(RoundCtx by_va
 // host can replay the sequential loop over the batch exactly (engine.hip, allocate_round_batched): a node that took pods earlier in
 // the batch is one of the numbered nodes — whether a later ask passes its other Filters is its bit, whether it still fits is
 // arithmetic on the columns the proposals carry — and a candidate that is full is followed by the next entry of the ask's list.
-// Nothing here writes the round's state (cursors and failed bits are read, never advanced).
+// Of the round's state only the classes' failed-before bits are written here (set, never cleared); cursors are read, not advanced.
 // ---------------------------------------------------------------------------------------------------
 #ifndef YK_PROP_K
 #define YK_PROP_K 8
 #endif
 constexpr int kPropK = YK_PROP_K;            // candidates per ask (and shard)
-constexpr int kProposeWaves = 4, kProposeThreads = kProposeWaves * kWave;
+#ifndef YK_PROPOSE_WAVES
+#define YK_PROPOSE_WAVES 8
+#endif
+constexpr int kProposeWaves = YK_PROPOSE_WAVES, kProposeThreads = kProposeWaves * kWave;
 constexpr int kDistinctSlots = 4096;         // hash slots of k_round_distinct: at least twice the proposals of a batch
 struct PropCand {
   u64 key;
@@ -4078,7 +4081,7 @@ __global__ __launch_bounds__(kProposeThreads) void k_round_propose(RoundCtx c, R
   __shared__ int sh_apos[kProposeWaves][kPropK], sh_an[kProposeWaves], sh_alist[kPropK];
   __shared__ u64 sh_wk[kProposeWaves];
   __shared__ int sh_wt[kProposeWaves], sh_wn[kProposeWaves];
-  __shared__ PropCand sh_b[kPropK];
+  __shared__ PropCand sh_a[kPropK], sh_b[kPropK];
   __shared__ int sh_win[kPropK], sh_nwin;
   const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
   const int j = blockIdx.x;
@@ -4193,7 +4196,9 @@ __global__ __launch_bounds__(kProposeThreads) void k_round_propose(RoundCtx c, R
     }
     {
       const int n_moved = ld_live(a.n_moved);
-      const u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
+      // (the class's "failed before" bits: a verdict without topology signature only ever turns from fit to fail, so a set bit is final —
+      // set here too, by whichever workgroup of the class meets the slot first; later batches skip it without a load)
+      u64* fw = (a.failed && tsig < 0) ? a.failed + (size_t)cls * a.cap64 : nullptr;
       for (int slot = tid; slot < n_moved; slot += kProposeThreads) {
         const u64 skip = ld_live(a.dead + (slot >> 6)) | (fw ? ld_live(fw + (slot >> 6)) : 0ull);
         if ((skip >> (slot & 63)) & 1ull) continue;
@@ -4202,7 +4207,10 @@ __global__ __launch_bounds__(kProposeThreads) void k_round_propose(RoundCtx c, R
         const int m = a.m_node[slot];
         int code;
         unsigned reason;
-        if (!eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) continue;
+        if (!eval_pair<true>(s, spec, -1, m, nr, a.pre, a.filt, &code, &reason)) {
+          if (fw) atomicOr((unsigned long long*)(fw + (slot >> 6)), 1ull << (slot & 63));
+          continue;
+        }
         u64 k = ld_live(a.m_key + slot);
         int tie = a.m_tie[slot], nn = m;
 #pragma unroll
@@ -4269,24 +4277,26 @@ __global__ __launch_bounds__(kProposeThreads) void k_round_propose(RoundCtx c, R
       }
     }
     __syncthreads();
-    // ---- the two ascending lists merged
+    // ---- the two ascending lists merged (the unmoved candidates' keys, NodeID ranks and nodes fetched side by side first)
+    if (tid < na) {
+      const int pos = sh_alist[tid];
+      sh_a[tid] = PropCand{a.rkey[pos], a.rtie[pos], a.perm[pos]};
+    }
+    __syncthreads();
     if (tid == 0) {
       int ia = 0, ib = 0, n = 0;
       while (n < kPropK && (ia < na || ib < nb)) {
         bool take_a = ib >= nb;
-        if (ia < na && ib < nb) {
-          const int pos = sh_alist[ia];
-          take_a = cand_less(a.rkey[pos], a.rtie[pos], sh_b[ib].key, sh_b[ib].tie);
-        }
-        sh_win[n++] = take_a ? a.perm[sh_alist[ia++]] : sh_b[ib++].node;
+        if (ia < na && ib < nb) take_a = cand_less(sh_a[ia].key, sh_a[ia].tie, sh_b[ib].key, sh_b[ib].tie);
+        sh_win[n++] = take_a ? sh_a[ia++].node : sh_b[ib++].node;
       }
       sh_nwin = n;
     }
   }
   __syncthreads();
-  if (wave == 0) {
+  {  // (a wave per entry)
     const int nwin = sh_nwin;
-    for (int r = 0; r < kPropK; ++r) write_proposal(t, s, a, spec, pin, tsig, fit_on, r < nwin ? sh_win[r] : -1, o + r);
+    for (int r = wave; r < kPropK; r += kProposeWaves) write_proposal(t, s, a, spec, pin, tsig, fit_on, r < nwin ? sh_win[r] : -1, o + r);
   }
 }
 // The distinct nodes among a batch's n proposals (one workgroup): list[0 .. *n_out) and every proposal's index into it (didx).
