@@ -190,7 +190,8 @@ int32_t ykhost_resident_stats(ykhost_t* h, int64_t* out5);
  * -2 = the ask is routed to the CPU manager (not evaluated by the engine) and takes no part in the round.
  * The whole round is ONE device call (ykpred_allocate_round): node resources, pod slots, host ports and the match counts behind
  * PodTopologySpread / InterPodAffinity are kept live on the device (the host uploads what a pod of every spec adds to its node:
- * ykpred_set_spec_effects). Only when those effects are withheld (YKHOST_ROUND_ON_HOST=1, tests) does the host decide ask by ask
+ * ykpred_set_spec_effects); the engine runs it with its sequential kernel or in batches — parallel proposals, the loop replayed on
+ * the host — whichever the ask list favours, with identical decisions (ykpred.h: ykpred_allocate_round, ykpred_get_round_info). Only when those effects are withheld (YKHOST_ROUND_ON_HOST=1, tests) does the host decide ask by ask
  * (decision → AssumePod → column patch → next decision) — that path needs apply != 0 to see its own allocations and refuses
  * apply == 0 with YKHOST_E_UNSUPPORTED.
  * NODE-SHARDED cluster (a communicator with world > 1 is attached to the engine): the call is COLLECTIVE — every rank calls with the
