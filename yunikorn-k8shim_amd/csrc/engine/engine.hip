@@ -287,7 +287,7 @@ struct ykpred_engine {
   // same node order, on its own stream (both only read the node tables; the writers need both)
   int walk_beside = 1;               // tunable (YKPRED_TUNE walk_beside): 0 = on the launch stream, in front of k_sig_planes
   hipStream_t walk_stream = nullptr;
-  hipEvent_t ev_base = nullptr, ev_walk = nullptr, ev_tail_fork = nullptr, ev_tail_done = nullptr;
+  hipEvent_t ev_base = nullptr, ev_walk = nullptr;
   // decisions of the sweep runs (k_run_decide): one range per run of the sweep row list, the classes k_decide leaves to it
   int run_decide = 1;                // tunable (YKPRED_TUNE run_decide): 0 = k_decide scans every class
   int run_ranges = 0, n_decide_list = 0, run_decide_classes = -1;  // (classes at the build the lists describe)
@@ -1694,8 +1694,6 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   if (hipStreamCreateWithFlags(&e->walk_stream, hipStreamNonBlocking) != hipSuccess) e->walk_stream = nullptr;
   (void)hipEventCreateWithFlags(&e->ev_base, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_walk, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&e->ev_tail_fork, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&e->ev_tail_done, hipEventDisableTiming);
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   e->ev_ready = true;
   *out = e;
@@ -1737,8 +1735,6 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (e->ev_zero) (void)hipEventDestroy(e->ev_zero);
   if (e->ev_base) (void)hipEventDestroy(e->ev_base);
   if (e->ev_walk) (void)hipEventDestroy(e->ev_walk);
-  if (e->ev_tail_fork) (void)hipEventDestroy(e->ev_tail_fork);
-  if (e->ev_tail_done) (void)hipEventDestroy(e->ev_tail_done);
   if (e->walk_stream) (void)hipStreamDestroy(e->walk_stream);
   if (e->h_round_pinned) (void)hipHostFree(e->h_round_pinned);
   if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
@@ -2648,21 +2644,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     // class-by-class writer BESIDE the band writer on a third stream upsets the one-workgroup-per-CU placement the band writer
     // lives on, 1.22 -> 1.45 ms, and even a 241-row zone B costs 0.25 ms through the fork / join; zone B first gains nothing.)
     hipStream_t sz = st;
-    // The chunk writer's share of a pass whose rows go to the run kernels is a few thousand rows (the classes no run kernel and no
-    // record takes): it runs BESIDE them on the walk stream instead of behind them (k_combine_wave: a wave per chunk, no LDS).
-    const bool slices_first = small_chunks && e->combine_slices != 0 && pc.n_big > 0 && pc.res != nullptr && !(use_sweep && e->sweep_min_run <= 1 && listed);
-    const bool tail_aside = e->walk_beside != 0 && e->walk_stream && e->ev_tail_fork && e->ev_tail_done && use_sweep && listed && small_chunks && !slices_first &&
-                            !counts_early && n_run > 0 && class_dirty == nullptr && e->n_classes_a == 0;  // (never beside the band writer: measured, +1 %)
-    if (tail_aside) {
-      HIPCHK(hipEventRecord(e->ev_tail_fork, st));  // (planes complete, class counts zeroed)
-      HIPCHK(hipStreamWaitEvent(e->walk_stream, e->ev_tail_fork, 0));
-      tm.begin(e->walk_stream);
-      const dim3 wgrid((unsigned)((n_run + ykk::kWavesPerBlock - 1) / ykk::kWavesPerBlock));
-      hipLaunchKernelGGL(ykk::k_combine_wave, wgrid, dim3(ykk::kBlock), 0, e->walk_stream, ct, pc, bitmap, e->row_words, e->row_stride, pin_on,
-                         e->d_class_count.as<int>(), n_run, class_dirty, (const ykk::SliceDesc*)nullptr, (const int*)nullptr, chunk_list);
-      tm.end(e->walk_stream, "k_combine");
-      HIPCHK(hipEventRecord(e->ev_tail_done, e->walk_stream));
-    }
     if (!dirty_only && e->n_classes_a > 0) {
       // zone A: class rows → table (and the classes' feasible counts), then the fill-pattern expansion over the band layout
       tm.begin(st);
@@ -2792,9 +2773,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       }
       tm.end(sz, "k_fused_rows");
     }
-    if (tail_aside) {
-      HIPCHK(hipStreamWaitEvent(st, e->ev_tail_done, 0));
-    } else {
     tm.begin(sz);
     // Index rows to decode: k_walk_rows — a wave writes whole rows, the rank planes of the walked dimensions (56 bytes per word) staged
     // in LDS per workgroup; rows wider than kWalkMaxIt x 64 words go segment by segment (grid.y). Only where the device grants the LDS.
@@ -2807,7 +2785,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     for (int k = 0; k < wstage.n; ++k) wstage.row[k] = e->h_stage_rows[(size_t)k];
     // (with every run swept — sweep_min_run 1 — no chunk is left that k_walk_rows has a fast path for: what remains goes through the
     // listed chunk writers below, without the descriptor pass over all chunks)
-    bool slices = slices_first;
+    bool slices = small_chunks && e->combine_slices != 0 && pc.n_big > 0 && pc.res != nullptr && !(use_sweep && e->sweep_min_run <= 1 && listed);
     if (slices) {
       const int its = (e->row_stride + ykk::kWave - 1) / ykk::kWave;
       const size_t lds_cap = std::min((size_t)e->max_lds_bytes, (size_t)80 * 1024);
@@ -2884,7 +2862,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
                          pin_on, e->d_class_count.as<int>(), tpg, class_dirty, chunk_list, ykk::FixRows{nullptr, nullptr, nullptr, 0}, n_run);
     }
     tm.end(sz, dirty_only ? "k_combine(dirty classes)" : "k_combine");
-    }
   }
   if (want_dec) {
     HIPCHK(hipEventRecord(e->ev_join, sb));
