@@ -283,11 +283,6 @@ struct ykpred_engine {
   int fuse_combine = 1;              // tunable (YKPRED_TUNE fuse_combine): 0 = never
   DevBuf d_fuse_combo_rec, d_fuse_combo;  // FuseRec[fuse_combos]; the combination table [fuse_combos][row_stride]
   std::vector<uint8_t> h_class_fused;
-  // the sorted walk of the many-valued request dimensions (k_dim_sort, k_dim_walk) runs beside the dictionary signature planes of the
-  // same node order, on its own stream (both only read the node tables; the writers need both)
-  int walk_beside = 1;               // tunable (YKPRED_TUNE walk_beside): 0 = on the launch stream, in front of k_sig_planes
-  hipStream_t walk_stream = nullptr;
-  hipEvent_t ev_base = nullptr, ev_walk = nullptr;
   // decisions of the sweep runs (k_run_decide): one range per run of the sweep row list, the classes k_decide leaves to it
   int run_decide = 1;                // tunable (YKPRED_TUNE run_decide): 0 = k_decide scans every class
   int run_ranges = 0, n_decide_list = 0, run_decide_classes = -1;  // (classes at the build the lists describe)
@@ -1662,7 +1657,6 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
       else if (key == "fuse_rows") e->fuse_rows = val;
       else if (key == "fuse_wpl") e->fuse_wpl = val;
       else if (key == "fuse_combine") e->fuse_combine = val;
-      else if (key == "walk_beside") e->walk_beside = val;
       else if (key == "class_runs_min_rows") e->class_runs_min_rows = std::max(val, 1);
       else {
         g_create_error = "YKPRED_TUNE: unknown key '" + key + "'";
@@ -1691,9 +1685,6 @@ int32_t ykpred_create(const ykpred_config_t* cfg, ykpred_engine_t** out) {
   (void)hipEventCreateWithFlags(&e->ev_planes, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_counts, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&e->ev_zero, hipEventDisableTiming);
-  if (hipStreamCreateWithFlags(&e->walk_stream, hipStreamNonBlocking) != hipSuccess) e->walk_stream = nullptr;
-  (void)hipEventCreateWithFlags(&e->ev_base, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&e->ev_walk, hipEventDisableTiming);
   for (auto& ev : e->ev) (void)hipEventCreate(&ev);
   e->ev_ready = true;
   *out = e;
@@ -1733,9 +1724,6 @@ void ykpred_destroy(ykpred_engine_t* e) {
   if (e->ev_planes) (void)hipEventDestroy(e->ev_planes);
   if (e->ev_counts) (void)hipEventDestroy(e->ev_counts);
   if (e->ev_zero) (void)hipEventDestroy(e->ev_zero);
-  if (e->ev_base) (void)hipEventDestroy(e->ev_base);
-  if (e->ev_walk) (void)hipEventDestroy(e->ev_walk);
-  if (e->walk_stream) (void)hipStreamDestroy(e->walk_stream);
   if (e->h_round_pinned) (void)hipHostFree(e->h_round_pinned);
   if (e->ev_eval_done) (void)hipEventDestroy(e->ev_eval_done);
   if (e->peek_pinned) (void)hipHostFree(e->peek_pinned);
@@ -2468,9 +2456,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
   if (want_dec) TRY(launch_dictionary_planes(sb, e->d_perm.as<int>(), true, "k_base_planes(ranked)", "k_sig_planes(ranked)"));
   // ---- stream A: canonical planes. Ballot families (request vectors, spread) in one launch, then the bit-sliced ones.
   auto ranked_walk = [](const int* perm) { return perm != nullptr; };
-  bool walk_forked = false;  // the canonical walk went to walk_stream: the launch stream joins it behind its signature planes
-  auto launch_ballot_planes = [&](hipStream_t s0, const int* perm, const char* name, bool with_base = false, bool walk_aside = false) -> int {
-    hipStream_t s = s0;
+  auto launch_ballot_planes = [&](hipStream_t s, const int* perm, const char* name, bool with_base = false) {
     ykk::PlaneArgs pa{};
     pa.perm = perm;
     pa.res = o_res;
@@ -2501,12 +2487,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     if (res_on && e->n_big > 0 && !fit_error) {
       // many-valued dimensions: sort every word's free values once, then one thread per word walks the sorted rows
       const bool ranked = perm != nullptr;
-      if (walk_aside && !ranked && e->walk_beside != 0 && e->walk_stream && e->ev_base && e->ev_walk) {
-        HIPCHK(hipEventRecord(e->ev_base, s0));
-        HIPCHK(hipStreamWaitEvent(e->walk_stream, e->ev_base, 0));
-        s = e->walk_stream;
-        walk_forked = true;
-      }
       ykk::DimWalk dw{e->d_dim_val.as<i64>(), e->d_dim_order.as<int>(), e->d_big_dim.as<int>(), e->d_walk_big.as<int>(), e->d_walk_begin.as<int>(),
                       e->d_walk_len.as<int>(), (ranked ? e->d_sfree_r : e->d_sfree_c).as<i64>(), (ranked ? e->d_pmask_r : e->d_pmask_c).as<u64>(),
                       e->n_big, e->walk_chunks, e->row_words, ranked ? nullptr : e->d_rbits_c.as<u64>(),
@@ -2551,7 +2531,6 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
         }
       }
       tm.end(s, ranked ? "k_dim_walk(ranked)" : "k_dim_walk");
-      if (s != s0) HIPCHK(hipEventRecord(e->ev_walk, s));
     } else if (res_on && e->n_big > 0) {
       // Filter without PreFilter state: the walked rows fit nowhere like every other row of the family — position 64 of every
       // mask table is the empty mask (the tables are only written by k_dim_sort: clear them as well)
@@ -2559,12 +2538,10 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
       (void)hipMemsetAsync((ranked_walk(perm) ? e->d_pmask_r : e->d_pmask_c).p, 0, (size_t)e->n_big * (size_t)e->row_words * 65 * sizeof(u64), s);
       if (!ranked_walk(perm)) (void)hipMemsetAsync(e->d_rbits_c.p, 0, (size_t)e->n_big * (size_t)e->row_words * ykk::kRankBits * sizeof(u64), s);
     }
-    return YKPRED_OK;
   };
   const bool fused_planes = res_on || spread_on;
-  if (fused_planes) TRY(launch_ballot_planes(st, nullptr, "k_planes+k_base_planes", true, true));
+  if (fused_planes) launch_ballot_planes(st, nullptr, "k_planes+k_base_planes", true);
   TRY(launch_dictionary_planes(st, nullptr, false, "k_base_planes", "k_sig_planes", fused_planes));
-  if (walk_forked) HIPCHK(hipStreamWaitEvent(st, e->ev_walk, 0));
   // ---- stream B, part 3 (after the canonical ballot planes): their rank-ordered copies by bit permutation, then the
   // first feasible node of every class. Overlaps the start of k_combine.
   if (want_dec) {
@@ -2579,7 +2556,7 @@ int32_t ykpred_eval(ykpred_engine_t* e, const ykpred_eval_args_t* a) {
     } else if (res_on || spread_on) {
       // very many request / spread signatures: the bit gather would touch one cache line per lane and row; evaluating
       // the signatures again in permuted node order is cheaper
-      TRY(launch_ballot_planes(sb, e->d_perm.as<int>(), "k_planes(ranked)"));
+      launch_ballot_planes(sb, e->d_perm.as<int>(), "k_planes(ranked)");
     }
     if (use_run_decide) {
       tm.begin(sb);
