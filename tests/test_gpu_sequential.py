@@ -327,6 +327,20 @@ def test_batched_round_kwok_cluster_and_binpacking_pin(pm_batched):
         assert [names[i] if i >= 0 else None for i in got] == case["expect"], case["source"]
 
 
+def test_round_fuzz_seeds():
+    """A short slice of scripts/fuzz_rounds.py (random clusters and ask streams, every feature switched on at random, two rounds per
+    cluster): the batched form, the sequential kernel and the oracle's loop agree on every decision. The long sweep
+    (profiles/r06_fuzz_rounds.log: 3 000 seeds) runs outside the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "YKPRED_TUNE"}
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_rounds.py"), "720000", "60"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "60 ok, 0 bad" in r.stdout
+
+
 @pytest.mark.parametrize("world,total_nodes,n_pods,n_templates,spread", [(2, 200, 600, 40, 0), (3, 330, 900, 6, 0), (2, 130, 500, 1, 0),
                                                                          (2, 256, 700, 40, 1), (3, 330, 600, 20, 1)],
                          ids=["two-shards", "three-shards-long-runs", "one-template-and-a-two-node-shard", "two-shards-hard-spread",
