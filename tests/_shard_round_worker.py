@@ -31,7 +31,8 @@ def main():
     device = 0 if stub else rank
     torch.cuda.set_device(device)
     dist.init_process_group("gloo")
-    kw = dict(seed=0x59554E49 + 91, num_pods=n_pods, num_templates=n_templates, node_affinity=1, spread=spread)
+    seed = int(sys.argv[5]) if len(sys.argv) > 5 else 91
+    kw = dict(seed=0x59554E49 + seed, num_pods=n_pods, num_templates=n_templates, node_affinity=1, spread=spread)
     ranges = sharding.shard_ranges(total_nodes, world)
     first, count = ranges[rank]
     pm = pkg.GpuPredicateManager(device=device)
