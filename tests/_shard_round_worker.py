@@ -1,5 +1,5 @@
 """Ranks of a node-sharded cluster deciding ALLOCATION ROUNDS together (ykhost_allocate_round on a sharded engine: proposals per batch,
-one all-gather, the same conflict-free prefix accepted on every rank, the owners assume) against the oracle's sequential loop over
+one all-gather, the same replay of the sequential loop on every rank, the owners assume) against the oracle's sequential loop over
 the WHOLE cluster. Launched by tests/test_gpu_sequential.py through torch.distributed.run.
 
   SHARD_RCCL_STUB=<tests/c/rccl_stub.cpp built as a shared library>: the ranks share cuda:0 and the engine loads the stub instead of

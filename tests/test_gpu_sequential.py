@@ -347,12 +347,12 @@ def test_round_fuzz_seeds():
                               "three-shards-hard-spread"])
 def test_allocation_rounds_on_a_node_sharded_cluster(tmp_path, world, total_nodes, n_pods, n_templates, spread):
     """Rounds on node-sharded engines (world 2 and 3 on this box's one GPU, the collectives through tests/c/rccl_stub.cpp): every shard
-    proposes its best node for a batch of asks, the proposals are all-gathered, every rank accepts the same conflict-free prefix —
+    proposes its 8 best nodes per ask of a batch (+ a bit per (ask, proposed node) pair), the proposals are all-gathered, every rank replays the loop —
     runs of one template land on one node while it fits — and the owners assume. Both rounds (apply = 1, then apply = 0 on top of it)
     equal the oracle's sequential loop over the whole cluster on every rank, in cluster-wide node indices, and stay on the device.
     hard-spread (round 6): a tenth of the templates carry a DoNotSchedule zone constraint — the histograms are cluster-wide state on
     every shard: the owner of an accepted node records what its assume added (delta record), a second all-gather hands it to the
-    others (k_round_apply_deltas), and the prefix ends in front of the first ask with a topology signature behind a contribution."""
+    others (k_round_apply_deltas), and a batch ends in front of the first ask whose signature counts a class an accepted pod added to."""
     import os
     import subprocess
     import sys

@@ -177,7 +177,7 @@ def round_worker(rank, world, port, seed, n_total, n_asks, n_classes, out):
 
 
 def test_allocation_round_in_batches_world2(tmp_path):
-    """The batch protocol of rounds on node-sharded engines (proposals, one all-gather, the conflict-free prefix, runs, owners assume)
+    """The batch protocol of rounds on node-sharded engines (top-k proposals + pair bits, one all-gather, the replay of the loop, runs, owners assume)
     on a one-resource model, world 2 over gloo: every rank ends with the decisions of the sequential loop over all nodes."""
     for seed, n_total, n_asks, n_classes in ((3, 200, 400, 12), (4, 130, 300, 2)):
         out = str(tmp_path / f"round{seed}")

@@ -3154,10 +3154,10 @@ struct RoundArgs {
   int* at_min;              // [G] spread: present domains whose count equals mn
   const int* nd;            // [G] spread: present domains
   SpecEffects fx;
-  // Node-sharded engines decide a round in BATCHES (engine.hip, allocate_round_sharded): every shard PROPOSES its best node for the
-  // asks of a batch against the state the accepted asks left (mode 1: the loop below without the assume), the proposals are
-  // all-gathered, every rank accepts the same conflict-free prefix, and the owners of the winners assume them (mode 2: the loop's
-  // assume for given nodes, no scans).
+  // Batched rounds (engine.hip, ykpred_allocate_round: sharded engines always, one GPU by the ask list): the proposals of a batch
+  // come from k_round_propose / k_round_cross, the host replays the loop, and the accepted pods are assumed node by node
+  // (k_round_assume_nodes) or — batches that move host ports or topology histograms — by this kernel in assume mode: the loop's assume
+  // for given nodes, no scans.
   int mode;                 // kRoundDecide (0) or kRoundAssume (the proposals of a batched round are k_round_propose's)
   int node_offset;          // index of this shard's first node in the whole cluster
   const int* forced;        // kRoundAssume: [round] the node (of this shard) an ask goes to, -1 = none of this shard's
@@ -4026,7 +4026,7 @@ struct PropCand {
 };
 __device__ __forceinline__ bool cand_less(u64 ka, int ta, u64 kb, int tb) { return ka < kb || (ka == kb && ta < tb); }
 // one proposal entry: what the ranks need of node `win` to order it, to re-key it after assumes and to re-check NodeResourcesFit
-// (wave 0 of the workgroup; the block of k_allocate_round's propose mode)
+// (one wave; every lane takes part)
 __device__ __forceinline__ void write_proposal(const NodeTable& t, const SpecTable& s, const RoundArgs& a, int spec, int pin, int tsig, bool fit_on,
                                                int win, RoundProposal* out) {
   const int lane = threadIdx.x % kWave;
