@@ -10,6 +10,7 @@ oracle's loop over all asks in that order, as GLOBAL node indices, on every rank
 import importlib
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -48,8 +49,13 @@ def main():
     half = n_pods // 2
     asks = np.arange(n_pods, dtype=np.int32)
     before = pm.round_stats()
+    info0 = pm.round_info()
+    t0 = time.perf_counter()
     got1 = pm.allocate_round(asks=asks[:half], apply=True)
+    t1 = time.perf_counter()
     got2 = pm.allocate_round(asks=asks[half:], apply=False)
+    t2 = time.perf_counter()
+    info1 = pm.round_info()
     after = pm.round_stats()
     got = np.concatenate([got1, got2])
     ok = np.array_equal(got, want)
@@ -57,7 +63,9 @@ def main():
     bad = np.flatnonzero(got != want)
     detail = "" if ok else f" first difference at ask {bad[0]}: got {got[bad[0]]} want {want[bad[0]]} ({len(bad)} differ)"
     print(f"rank {rank}/{world} {'rccl-stub' if stub else 'rccl'}{' spread' if spread else ''}: sharded rounds {ok} on_device {on_device} "
-          f"({n_pods} asks x {total_nodes} nodes, {int((want >= 0).sum())} allocated on {len(np.unique(want[want >= 0]))} nodes){detail}", flush=True)
+          f"({n_pods} asks x {total_nodes} nodes, {int((want >= 0).sum())} allocated on {len(np.unique(want[want >= 0]))} nodes){detail}"
+          f" | round 1 incl. the mirror's assumes {half / (t1 - t0):.0f} asks/s, round 2 {(n_pods - half) / (t2 - t1):.0f} asks/s, "
+          f"{info1['batches'] - info0['batches']} batches, {info1['exchanges'] - info0['exchanges']} exchanges", flush=True)
     dist.barrier()
     pm.comm_destroy()
     pm.close()
