@@ -3707,6 +3707,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       int g, q;
     };
     std::vector<Accepted> acc;
+    std::unordered_map<int64_t, int32_t> acc_of;  // cluster-wide node -> its entry of acc
     std::vector<Entry> ents;
     const int R = e->R;
     int pos = 0, batch = 32;
@@ -3749,6 +3750,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
       };
       auto ord_of = [&](const ykk::RoundProposal& p) { return W > 1 ? (int64_t)p.gnode : (int64_t)p.pad; };
       acc.clear();
+      acc_of.clear();
       forced.assign((size_t)b, -1);
       run_len.assign((size_t)b, 1);
       for (int32_t c2 : touched_list) touched[(size_t)c2] = 0;
@@ -3787,10 +3789,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
         const Entry* fresh = nullptr;  // the first candidate no accepted ask has touched
         for (const Entry& en : ents) {
           if (cut && less2(h_key, h_ord, en.key, en.ord)) break;
-          const int64_t gn = prop_of(en.g, m, en.q).gnode;
-          bool taken = false;
-          for (const Accepted& a2 : acc) taken = taken || a2.gnode == gn;
-          if (!taken) {
+          if (acc_of.find((int64_t)prop_of(en.g, m, en.q).gnode) == acc_of.end()) {
             fresh = &en;
             break;
           }
@@ -3799,6 +3798,7 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
         Accepted* best = nullptr;           // the accepted node the ask passes that stands first
         const Accepted* unknown = nullptr;  // ... and the first one whose verdict is not arithmetic
         for (Accepted& a2 : acc) {
+          if (fresh && !less2(a2.key1, a2.ord, fresh->key, fresh->ord)) continue;  // (behind the untouched candidate: cannot be the answer)
           if (!bit_of(a2, m)) continue;  // (failed when the batch was proposed: a node only fills)
           if (ports) {  // (the node's port words moved with the pods it took: not arithmetic here)
             if (!unknown || less2(a2.key1, a2.ord, unknown->key1, unknown->ord)) unknown = &a2;
@@ -3870,8 +3870,12 @@ int32_t ykpred_allocate_round(ykpred_engine_t* e, uint32_t pre, uint32_t filt, i
           run_len[(size_t)(m + q)] = piece;
           q += piece;
         }
-        if (same) *same = node_now;
-        else acc.push_back(node_now);
+        if (same) {
+          *same = node_now;
+        } else {
+          acc_of.emplace(node_now.gnode, (int32_t)acc.size());
+          acc.push_back(node_now);
+        }
         if (spec_contributes(spec)) {
           contributed = true;
           if (e->h_fx_cls.size() >= (size_t)e->h_fx_off[(size_t)spec + 1])
